@@ -1,0 +1,184 @@
+/*
+ * nimble_amd.h — C ABI of the MI355X-native batched differentiable timestep.
+ *
+ * This is the drop-in boundary for ONE hot path of nimblephysics: the call
+ *   nimble.timestep(world, state, action)                      python/nimblephysics/timestep.py:63-69
+ * which in the reference goes through pybind11 into
+ *   neural::forwardPass(world)                                  dart/neural/NeuralUtils.cpp:26-66
+ *     -> World::step(true)                                      dart/simulation/World.cpp:221-254
+ *   BackpropSnapshot::backpropState(world, grad)                dart/neural/BackpropSnapshot.cpp:382-420
+ *
+ * Everything here is plain C: pointers, sizes, ints.  No torch types.
+ * All batched arrays are DEVICE pointers to fp64 in structure-of-arrays layout
+ *   x[d * B + b]      d = DOF (or row) index, b = world index   ("[dof][B]")
+ * so that one wavefront (64 consecutive worlds) reads one coalesced 512-byte line
+ * per DOF.  The caller owns every buffer; the library owns only the model handle
+ * and a workspace sized at nbl_workspace_bytes().
+ *
+ * Threading: one handle may be used from one host thread / one stream at a time
+ * (the reference's World is not thread-safe either, World.cpp:114-172).
+ * Multi-GPU: one handle per device, the batch is sharded by the caller.
+ *
+ * Return value of every int function: 0 = ok, <0 = error (see NBL_E_*).  This
+ * replaces the reference's "print to std::cerr and ignore the call"
+ * (World.cpp:2027-2033, 2063-2070) with a status the caller must check.
+ */
+#ifndef NIMBLE_AMD_H
+#define NIMBLE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- joint types (dart/dynamics/{Revolute,Prismatic,Free,Weld}Joint.cpp) ---- */
+#define NBL_JOINT_REVOLUTE 0
+#define NBL_JOINT_PRISMATIC 1
+#define NBL_JOINT_FREE 2 /* DART_USE_IDENTITY_JACOBIAN build: S = Ad(T_cj), FreeJoint.cpp:1049-1056 */
+#define NBL_JOINT_WELD 3 /* 0 DOF. The GPU library requires welds to be merged into the parent
+                            (host model builder does this); the CPU oracle accepts them. */
+
+/* ---- error codes ---- */
+#define NBL_OK 0
+#define NBL_E_BADARG -1
+#define NBL_E_UNSUPPORTED -2 /* model feature outside the hot-path scope */
+#define NBL_E_HIP -3         /* a HIP runtime call failed (nbl_last_error() has text) */
+#define NBL_E_WORKSPACE -4   /* workspace too small for this B */
+#define NBL_E_NOGPU -5
+
+/* ---- per-lane status bits written to status[b] by nbl_step_forward ---- */
+#define NBL_ST_CONTACT 0x1u       /* >=1 contact constraint was active */
+#define NBL_ST_LCP_STAGE0 0x2u    /* warm-start / guess classification was a valid LCP solution (BoxedLcpConstraintSolver.cpp:434-457) */
+#define NBL_ST_LCP_PIVOT 0x4u     /* pivoting (Dantzig-equivalent) stage used */
+#define NBL_ST_LCP_PGS 0x8u       /* CFM + PGS fallback used */
+#define NBL_ST_LCP_NOFRIC 0x10u   /* friction dropped fallback used */
+#define NBL_ST_LCP_FAILED 0x20u   /* every stage failed: impulses zeroed (BoxedLcpConstraintSolver.cpp:679-687) */
+#define NBL_ST_NAN 0x40u          /* non-finite value seen */
+#define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts than max_contacts; extra ones dropped */
+#define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
+
+/*
+ * Model description.  One model is shared by all B worlds of a batch; worlds differ only in
+ * (q, v, tau) and the LCP warm start.  Bodies are listed parents-before-children.
+ * Every body has exactly one parent joint.  Transforms are 12 doubles: R row-major (9) then p (3).
+ */
+typedef struct nbl_model_desc {
+  int32_t n_bodies;
+  int32_t n_dofs;
+  const int32_t* parent;     /* [n_bodies] parent body index, -1 = world */
+  const int32_t* joint_type; /* [n_bodies] NBL_JOINT_* */
+  const int32_t* dof_offset; /* [n_bodies] first DOF of the parent joint */
+  const double* T_pj;        /* [n_bodies][12] parent body -> joint  (Joint::mT_ParentBodyToJoint) */
+  const double* T_cj;        /* [n_bodies][12] child body  -> joint  (Joint::mT_ChildBodyToJoint) */
+  const double* axis;        /* [n_bodies][3] unit axis for revolute/prismatic */
+  const double* mass;        /* [n_bodies] */
+  const double* com;         /* [n_bodies][3] local COM (Inertia::mCenterOfMass) */
+  const double* inertia;     /* [n_bodies][6] Ixx Iyy Izz Ixy Ixz Iyz about the COM (Inertia.cpp:1368-1383) */
+  const double* damping;     /* [n_dofs] GenericJoint mDampingCoefficients */
+  const double* spring;      /* [n_dofs] mSpringStiffnesses */
+  const double* rest;        /* [n_dofs] mRestPositions */
+  const double* pos_lo;      /* [n_dofs] limits, used only by clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479) */
+  const double* pos_hi;
+  const double* vel_lo;
+  const double* vel_hi;
+  const double* force_lo;
+  const double* force_hi;
+  double gravity[3]; /* World::mGravity, default (0,-9.81,0) in the configs */
+  double dt;         /* World::mTimeStep, default 1e-3 (World.cpp:76) */
+
+  /* action space: tau[action_map[i]] = action[i], unmapped tau = 0 (World.cpp:2061-2086) */
+  int32_t n_action;
+  const int32_t* action_map; /* [n_action] */
+
+  /* ---- contact: box colliders only (dBoxBox path, DARTCollide.cpp:764-1450) ---- */
+  int32_t n_boxes;
+  const int32_t* box_body;  /* [n_boxes] body index, -1 = fixed to the world (immobile skeleton) */
+  const double* box_T;      /* [n_boxes][12] shape transform in the body frame */
+  const double* box_size;   /* [n_boxes][3] full side lengths */
+  const double* box_mu;     /* [n_boxes] friction coefficient of the owning body (default 1, BodyNodeAspect.hpp:47) */
+  int32_t max_contacts;     /* per world; rows m = 3 * max_contacts */
+
+  /* ---- options mirrored from the reference defaults ---- */
+  double contact_clipping_depth; /* 0.03  World.cpp:86 */
+  double fallback_cfm;           /* 1e-4  World.cpp:85 */
+} nbl_model_desc;
+
+typedef struct nbl_model nbl_model; /* opaque */
+
+/* Human-readable text for the last error on this thread. */
+const char* nbl_last_error(void);
+
+/* Library/ABI version (major<<16 | minor). */
+int32_t nbl_version(void);
+
+/* Number of visible HIP devices (0 if none). */
+int32_t nbl_device_count(void);
+
+/*
+ * Create a model on `device`.  Copies everything out of desc.
+ * Replaces: constructing a nimble.simulation.World + skeletons (World.cpp:93-172).
+ */
+int32_t nbl_model_create(const nbl_model_desc* desc, int32_t device, nbl_model** out);
+void nbl_model_destroy(nbl_model* m);
+
+int32_t nbl_model_num_dofs(const nbl_model* m);
+int32_t nbl_model_num_action(const nbl_model* m);
+int32_t nbl_model_lcp_rows(const nbl_model* m); /* 3 * max_contacts */
+
+/* Bytes of scratch the library needs for a batch of B worlds (forward or backward). */
+size_t nbl_workspace_bytes(const nbl_model* m, int64_t B);
+
+/*
+ * Bytes of the per-step "saved for backward" record for B worlds: what the reference keeps in a
+ * BackpropSnapshot (dart/neural/BackpropSnapshot.cpp:33-118): q_t, v_t, tau_t, the pre-step LCP
+ * cache and the constraint-group results.  Caller-owned device memory.
+ */
+size_t nbl_saved_bytes(const nbl_model* m, int64_t B);
+
+/*
+ * One differentiable timestep for B worlds.
+ *   state   [2n][B]  = [q; v]                              World::setState   World.cpp:2024-2036
+ *   action  [k][B]                                          World::setAction  World.cpp:2061-2086
+ *   lcp_cache_in  [m][B] or NULL (cold: guessSolution)      BoxedLcpConstraintSolver.cpp:202-208
+ *   next_state [2n][B]                                      World::getState   World.cpp:2040-2047
+ *   lcp_cache_out [m][B] or NULL
+ *   saved      nbl_saved_bytes() bytes or NULL (no backward wanted)
+ *   status     [B] uint32 or NULL
+ * `stream` is a hipStream_t (void* so this header needs no HIP include); NULL = default stream.
+ * Replaces: neural::forwardPass (NeuralUtils.cpp:26-66).
+ */
+int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const double* action,
+                         const double* lcp_cache_in, double* next_state, double* lcp_cache_out,
+                         void* saved, uint32_t* status, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/*
+ * Vector-Jacobian product of the step.
+ *   grad_next_state [2n][B]  dL/d[q';v']
+ *   grad_state      [2n][B]  dL/d[q;v]        (lossWrtState)
+ *   grad_action     [k][B]   dL/daction       (lossWrtAction)
+ * Replaces: BackpropSnapshot::backpropState (BackpropSnapshot.cpp:382-420), including
+ * clipLossGradientsToBounds (:425-479).
+ */
+int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const double* grad_next_state,
+                          double* grad_state, double* grad_action, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/*
+ * Layout helpers: the Python surface takes world-major tensors [B][d] like a stack of the
+ * reference's 1-D state vectors; these transpose to/from the library's [d][B] layout on device.
+ */
+int32_t nbl_transpose_to_soa(const double* src_bd, double* dst_db, int64_t B, int32_t d, void* stream);
+int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, int32_t d, void* stream);
+
+/* Average duration (ms) of the last timed launches, measured with HIP events on the launch stream. */
+int32_t nbl_set_timing(nbl_model* m, int32_t enabled);
+int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, double* bwd_ms_sum,
+                       int64_t* bwd_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIMBLE_AMD_H */

@@ -1,0 +1,380 @@
+"""Model descriptions for the batched timestep.
+
+One *model* (tree topology, joint types/axes, fixed transforms, spatial inertias, box colliders,
+friction) is shared by all worlds of a batch.  This module is the host-side replacement for the
+small part of `nimble.simulation.World` / `dart::dynamics::Skeleton` construction that the hot path
+needs (reference: dart/simulation/World.cpp:93-172, dart/utils/urdf/DartLoader.cpp:388-560,
+dart/utils/SkelParser.cpp).  It carries no dynamics; it only produces the flat arrays of
+`struct nbl_model_desc` (include/nimble_amd.h).
+
+Weld joints are merged into their parents at build time (`merge_welds`): a welded body and its
+parent are one rigid body, so the merged model is mathematically identical to the reference's
+0-DOF WeldJoint treatment (dart/dynamics/WeldJoint.cpp, Skeleton.cpp:12588-12608) while the GPU
+kernels only ever see 1-DOF and free joints.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+
+_DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def rpy_to_matrix(rpy: Sequence[float]) -> np.ndarray:
+    """URDF fixed-axis roll/pitch/yaw -> rotation matrix (R = Rz(y) Ry(p) Rx(r))."""
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    return np.array(
+        [
+            [cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+            [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+            [-sp, cp * sr, cp * cr],
+        ],
+        dtype=np.float64,
+    )
+
+
+def make_transform(xyz=(0.0, 0.0, 0.0), rpy=(0.0, 0.0, 0.0), R: Optional[np.ndarray] = None) -> np.ndarray:
+    T = np.eye(4)
+    T[:3, :3] = rpy_to_matrix(rpy) if R is None else np.asarray(R, dtype=np.float64)
+    T[:3, 3] = np.asarray(xyz, dtype=np.float64)
+    return T
+
+
+def _inv(T: np.ndarray) -> np.ndarray:
+    Ti = np.eye(4)
+    Ti[:3, :3] = T[:3, :3].T
+    Ti[:3, 3] = -T[:3, :3].T @ T[:3, 3]
+    return Ti
+
+
+def _t12(T: np.ndarray) -> np.ndarray:
+    return np.concatenate([T[:3, :3].reshape(9), T[:3, 3]])
+
+
+@dataclass
+class BodySpec:
+    name: str
+    parent: int  # index into the body list, -1 = world
+    joint_type: str  # revolute | prismatic | free | weld
+    joint_name: str = ""
+    axis: Sequence[float] = (0.0, 0.0, 1.0)
+    T_pj: np.ndarray = field(default_factory=lambda: np.eye(4))
+    T_cj: np.ndarray = field(default_factory=lambda: np.eye(4))
+    mass: float = 1.0
+    com: Sequence[float] = (0.0, 0.0, 0.0)
+    inertia: Sequence[float] = (1.0, 1.0, 1.0, 0.0, 0.0, 0.0)  # ixx iyy izz ixy ixz iyz about COM
+    damping: Sequence[float] = ()
+    spring: Sequence[float] = ()
+    rest: Sequence[float] = ()
+    pos_lo: Sequence[float] = ()
+    pos_hi: Sequence[float] = ()
+    vel_lo: Sequence[float] = ()
+    vel_hi: Sequence[float] = ()
+    force_lo: Sequence[float] = ()
+    force_hi: Sequence[float] = ()
+    friction: float = 1.0  # BodyNodeAspect.hpp:47
+
+
+@dataclass
+class BoxSpec:
+    body: int  # -1 = fixed to the world
+    T: np.ndarray
+    size: Sequence[float]
+    mu: float = 1.0
+
+
+def _inertia_matrix(i6) -> np.ndarray:
+    ixx, iyy, izz, ixy, ixz, iyz = i6
+    return np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]], dtype=np.float64)
+
+
+def _inertia6(I: np.ndarray):
+    return (I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2])
+
+
+class ModelDescription:
+    """Flat, topologically sorted description of one articulated model + its colliders."""
+
+    def __init__(self, name: str, bodies: List[BodySpec], boxes: Optional[List[BoxSpec]] = None,
+                 gravity=(0.0, -9.81, 0.0), dt: float = 1e-3, action_map: Optional[Sequence[int]] = None,
+                 max_contacts: int = 0, contact_clipping_depth: float = 0.03, fallback_cfm: float = 1e-4):
+        self.name = name
+        self.bodies = list(bodies)
+        self.boxes = list(boxes or [])
+        self.gravity = tuple(float(g) for g in gravity)
+        self.dt = float(dt)
+        self._action_map = None if action_map is None else [int(a) for a in action_map]
+        self.max_contacts = int(max_contacts)
+        self.contact_clipping_depth = float(contact_clipping_depth)
+        self.fallback_cfm = float(fallback_cfm)
+        for i, b in enumerate(self.bodies):
+            if not (-1 <= b.parent < i):
+                raise ValueError(f"body {i} ({b.name}): parent {b.parent} must precede it")
+            if b.joint_type not in _abi.JOINT_NAMES:
+                raise ValueError(f"unsupported joint type {b.joint_type!r} (hot-path scope: revolute, prismatic, free, weld)")
+
+    # ---- sizes ------------------------------------------------------------------------------
+    def joint_ndof(self, i: int) -> int:
+        return _abi.JOINT_NDOF[_abi.JOINT_NAMES[self.bodies[i].joint_type]]
+
+    @property
+    def num_dofs(self) -> int:
+        return sum(self.joint_ndof(i) for i in range(len(self.bodies)))
+
+    @property
+    def action_map(self) -> List[int]:
+        # default action space = all DOFs (World.cpp:2053-2058)
+        return list(range(self.num_dofs)) if self._action_map is None else list(self._action_map)
+
+    def set_action_space(self, mapping: Sequence[int]):
+        n = self.num_dofs
+        mapping = [int(a) for a in mapping]
+        for a in mapping:
+            if a < 0 or a >= n:
+                raise ValueError(f"action mapping {a} out of bounds [0,{n})")  # World.cpp:2118-2135 prints+ignores
+        self._action_map = mapping
+
+    def dof_names(self) -> List[str]:
+        out = []
+        for b in self.bodies:
+            nd = _abi.JOINT_NDOF[_abi.JOINT_NAMES[b.joint_type]]
+            if nd == 1:
+                out.append(b.joint_name or b.name)
+            elif nd == 6:
+                out += [f"{b.joint_name or b.name}_{s}" for s in ("rot_x", "rot_y", "rot_z", "pos_x", "pos_y", "pos_z")]
+        return out
+
+    # ---- weld merging -----------------------------------------------------------------------
+    def merge_welds(self) -> "ModelDescription":
+        """Return an equivalent model without weld joints (see module docstring)."""
+        bodies = self.bodies
+        nb = len(bodies)
+        # T_fix[i]: frame of body i expressed in the frame of the body it is merged into
+        target = list(range(nb))
+        T_in_target = [np.eye(4) for _ in range(nb)]
+        acc = {}  # target index -> (mass, com, I_about_com)
+        keep = []
+        for i, b in enumerate(bodies):
+            if b.joint_type == "weld":
+                T = b.T_pj @ _inv(b.T_cj)  # child frame in parent frame (constant)
+                if b.parent < 0:
+                    target[i] = -1
+                    T_in_target[i] = T
+                else:
+                    target[i] = target[b.parent]
+                    T_in_target[i] = T_in_target[b.parent] @ T
+            else:
+                keep.append(i)
+            t = target[i]
+            if t >= 0:
+                Tt = T_in_target[i]
+                R, p = Tt[:3, :3], Tt[:3, 3]
+                m_i = float(b.mass)
+                c_i = R @ np.asarray(b.com, dtype=np.float64) + p
+                I_i = R @ _inertia_matrix(b.inertia) @ R.T
+                if t not in acc:
+                    acc[t] = []
+                acc[t].append((m_i, c_i, I_i))
+        new_index = {old: k for k, old in enumerate(keep)}
+        out = []
+        for old in keep:
+            b = bodies[old]
+            parts = acc[old]
+            M = sum(p[0] for p in parts)
+            if M > 0:
+                com = sum(p[0] * p[1] for p in parts) / M
+            else:
+                com = np.zeros(3)
+            I = np.zeros((3, 3))
+            for m_i, c_i, I_i in parts:
+                d = c_i - com
+                I += I_i + m_i * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+            if b.parent < 0:
+                parent_new, T_pj = -1, b.T_pj
+            else:
+                tp = target[b.parent]
+                if tp < 0:  # parent chain welded to the world
+                    parent_new, T_pj = -1, T_in_target[b.parent] @ b.T_pj
+                else:
+                    parent_new, T_pj = new_index[tp], T_in_target[b.parent] @ b.T_pj
+            nbdy = BodySpec(**{**b.__dict__})
+            nbdy.parent = parent_new
+            nbdy.T_pj = T_pj
+            nbdy.mass = M
+            nbdy.com = tuple(com)
+            nbdy.inertia = _inertia6(I)
+            out.append(nbdy)
+        boxes = []
+        for bx in self.boxes:
+            if bx.body < 0:
+                boxes.append(BoxSpec(-1, bx.T.copy(), tuple(bx.size), bx.mu))
+            else:
+                t = target[bx.body]
+                Tb = T_in_target[bx.body] @ bx.T
+                boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu))
+        m = ModelDescription(self.name, out, boxes, self.gravity, self.dt, self._action_map, self.max_contacts,
+                             self.contact_clipping_depth, self.fallback_cfm)
+        return m
+
+    def has_welds(self) -> bool:
+        return any(b.joint_type == "weld" for b in self.bodies)
+
+    # ---- flat arrays / C struct -------------------------------------------------------------
+    def flat(self) -> dict:
+        nb = len(self.bodies)
+        n = self.num_dofs
+        inf = float("inf")
+        a = {
+            "parent": np.zeros(nb, np.int32), "joint_type": np.zeros(nb, np.int32), "dof_offset": np.zeros(nb, np.int32),
+            "T_pj": np.zeros((nb, 12)), "T_cj": np.zeros((nb, 12)), "axis": np.zeros((nb, 3)), "mass": np.zeros(nb),
+            "com": np.zeros((nb, 3)), "inertia": np.zeros((nb, 6)),
+            "damping": np.zeros(n), "spring": np.zeros(n), "rest": np.zeros(n),
+            "pos_lo": np.full(n, -inf), "pos_hi": np.full(n, inf), "vel_lo": np.full(n, -inf), "vel_hi": np.full(n, inf),
+            "force_lo": np.full(n, -inf), "force_hi": np.full(n, inf),
+        }
+        off = 0
+        for i, b in enumerate(self.bodies):
+            jt = _abi.JOINT_NAMES[b.joint_type]
+            nd = _abi.JOINT_NDOF[jt]
+            a["parent"][i] = b.parent
+            a["joint_type"][i] = jt
+            a["dof_offset"][i] = off
+            a["T_pj"][i] = _t12(np.asarray(b.T_pj, dtype=np.float64))
+            a["T_cj"][i] = _t12(np.asarray(b.T_cj, dtype=np.float64))
+            ax = np.asarray(b.axis, dtype=np.float64)
+            nrm = np.linalg.norm(ax)
+            a["axis"][i] = ax / nrm if nrm > 0 else ax  # RevoluteJoint::setAxis normalizes
+            a["mass"][i] = b.mass
+            a["com"][i] = b.com
+            a["inertia"][i] = b.inertia
+            for key in ("damping", "spring", "rest", "pos_lo", "pos_hi", "vel_lo", "vel_hi", "force_lo", "force_hi"):
+                vals = getattr(b, key)
+                if len(vals):
+                    if len(vals) != nd:
+                        raise ValueError(f"body {b.name}: {key} has {len(vals)} entries, joint has {nd} dofs")
+                    a[key][off:off + nd] = vals
+            off += nd
+        nbx = len(self.boxes)
+        a["box_body"] = np.array([bx.body for bx in self.boxes], np.int32).reshape(nbx)
+        a["box_T"] = np.array([_t12(bx.T) for bx in self.boxes], np.float64).reshape(nbx, 12)
+        a["box_size"] = np.array([bx.size for bx in self.boxes], np.float64).reshape(nbx, 3)
+        a["box_mu"] = np.array([bx.mu for bx in self.boxes], np.float64).reshape(nbx)
+        a["action_map"] = np.array(self.action_map, np.int32)
+        return a
+
+    def to_desc(self):
+        """Returns (ModelDesc, keepalive). The keepalive must outlive any use of the struct."""
+        a = self.flat()
+        for k in a:
+            a[k] = np.ascontiguousarray(a[k])
+        d = _abi.ModelDesc()
+        d.n_bodies = len(self.bodies)
+        d.n_dofs = self.num_dofs
+
+        def pd(x):
+            return x.ctypes.data_as(C.POINTER(C.c_double))
+
+        def pi(x):
+            return x.ctypes.data_as(C.POINTER(C.c_int32))
+
+        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map"):
+            setattr(d, k, pi(a[k]))
+        for k in ("T_pj", "T_cj", "axis", "mass", "com", "inertia", "damping", "spring", "rest", "pos_lo", "pos_hi",
+                  "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu"):
+            setattr(d, k, pd(a[k]))
+        d.gravity = (C.c_double * 3)(*self.gravity)
+        d.dt = self.dt
+        d.n_action = len(a["action_map"])
+        d.n_boxes = len(self.boxes)
+        d.max_contacts = self.max_contacts
+        d.contact_clipping_depth = self.contact_clipping_depth
+        d.fallback_cfm = self.fallback_cfm
+        return d, a
+
+    # ---- (de)serialisation ------------------------------------------------------------------
+    def to_json(self) -> dict:
+        def body(b: BodySpec):
+            d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()}
+            return d
+        return {
+            "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,
+            "max_contacts": self.max_contacts, "contact_clipping_depth": self.contact_clipping_depth,
+            "fallback_cfm": self.fallback_cfm, "bodies": [body(b) for b in self.bodies],
+            "boxes": [{"body": bx.body, "T": np.asarray(bx.T).tolist(), "size": list(bx.size), "mu": bx.mu} for bx in self.boxes],
+        }
+
+    @staticmethod
+    def from_json(d: dict) -> "ModelDescription":
+        bodies = []
+        for b in d["bodies"]:
+            b = dict(b)
+            b["T_pj"] = np.array(b["T_pj"], dtype=np.float64)
+            b["T_cj"] = np.array(b["T_cj"], dtype=np.float64)
+            bodies.append(BodySpec(**b))
+        boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0)) for bx in d.get("boxes", [])]
+        return ModelDescription(d["name"], bodies, boxes, d.get("gravity", (0, -9.81, 0)), d.get("dt", 1e-3),
+                                d.get("action_map"), d.get("max_contacts", 0), d.get("contact_clipping_depth", 0.03),
+                                d.get("fallback_cfm", 1e-4))
+
+    @staticmethod
+    def load(name_or_path: str) -> "ModelDescription":
+        path = name_or_path if os.path.exists(name_or_path) else os.path.join(_DATA_DIR, name_or_path + ".json")
+        with open(path) as f:
+            return ModelDescription.from_json(json.load(f))
+
+
+# ---------------------------------------------------------------------------------------------
+# The BASELINE.json configs
+# ---------------------------------------------------------------------------------------------
+def single_pendulum() -> ModelDescription:
+    """cfg1: data/skel/test/single_pendulum.skel — revolute z, m=5, I=diag(1,2,3), damping 10.
+
+    Body world transform (0.1,0,0), joint frame (-0.1,0,0) in the child => T_pj = identity.
+    """
+    b = BodySpec("link 1", -1, "revolute", "joint 1", axis=(0, 0, 1), T_pj=np.eye(4), T_cj=make_transform((-0.1, 0, 0)),
+                 mass=5.0, com=(0, 0, 0), inertia=(1, 2, 3, 0, 0, 0), damping=(10.0,))
+    return ModelDescription("single_pendulum", [b], gravity=(0, -9.81, 0), dt=1e-3)
+
+
+def cartpole() -> ModelDescription:
+    """cfg2: unittests/comprehensive/test_Gradients.cpp:1260-1316 — prismatic x + revolute z,
+    pole joint offset (0,-0.5,0) from the child body, default unit mass / identity inertia."""
+    sled = BodySpec("sled", -1, "prismatic", "sled_joint", axis=(1, 0, 0))
+    arm = BodySpec("arm", 0, "revolute", "arm_joint", axis=(0, 0, 1), T_cj=make_transform((0, -0.5, 0)))
+    return ModelDescription("cartpole", [sled, arm], gravity=(0, -9.81, 0), dt=1e-3)
+
+
+def atlas(variant: str = "atlas33", ground: bool = False) -> ModelDescription:
+    """cfg3/cfg5/metric: Atlas transcribed from data/sdf/atlas/atlas_v3_box_colliders.urdf by
+    tools/urdf_to_model.py (parameters only; committed as nimblephysics_amd/data/*.json).
+
+    variant "atlas33": free root + 27 revolutes (n = 33); "atlas20": arms and back_bkz welded (n = 20).
+    ground=True adds data/sdf/atlas/ground.urdf's 25 x 0.05 x 25 box at y = -0.95 (top face y = -0.925).
+    """
+    m = ModelDescription.load(variant + ("_ground" if ground else ""))
+    return m
+
+
+def box_stack() -> ModelDescription:
+    """cfg4: welded ground box 2 x 0.01 x 2 + two FreeJoint cubes of side 0.2, mu = 1."""
+    cube_I = 1.0 * (0.2 ** 2 + 0.2 ** 2) / 12.0
+    bodies = [
+        BodySpec("ground", -1, "weld", "ground_joint", mass=1.0),
+        BodySpec("box1", -1, "free", "box1_joint", mass=1.0, inertia=(cube_I, cube_I, cube_I, 0, 0, 0)),
+        BodySpec("box2", -1, "free", "box2_joint", mass=1.0, inertia=(cube_I, cube_I, cube_I, 0, 0, 0)),
+    ]
+    boxes = [
+        BoxSpec(0, make_transform((0, -0.005, 0)), (2.0, 0.01, 2.0), 1.0),
+        BoxSpec(1, np.eye(4), (0.2, 0.2, 0.2), 1.0),
+        BoxSpec(2, np.eye(4), (0.2, 0.2, 0.2), 1.0),
+    ]
+    return ModelDescription("box_stack", bodies, boxes, max_contacts=8)

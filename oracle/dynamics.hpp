@@ -1,0 +1,528 @@
+// oracle/dynamics.hpp — TEST INFRASTRUCTURE ONLY.
+//
+// Scalar restatement of the reference's articulated-body dynamics for the joint
+// types on the hot path (Revolute, Prismatic, Free [identity-Jacobian build], Weld).
+// One world at a time, no batching, written to follow the reference's recursion
+// order so that each routine can be read next to the file:line it cites.
+#pragma once
+#include "../include/nimble_amd.h"
+#include "spatial.hpp"
+
+namespace nbo {
+
+struct Body {
+  int parent, jtype, dofOff, ndof;
+  Iso Tpj, Tcj, TcjInv;
+  Vec3 axis;
+  Mat6 G;     // spatial inertia, Inertia.cpp:1368-1383
+  Vec6 S[6];  // constant relative Jacobian columns in the child frame
+  std::vector<int> children;
+};
+
+struct BoxCollider {
+  int body;  // -1 = world-fixed
+  Iso T;     // in body frame
+  Vec3 size;
+  s_t mu;
+};
+
+struct Model {
+  int nb, n;
+  std::vector<Body> bodies;
+  VecX damping, spring, rest, posLo, posHi, velLo, velHi, forceLo, forceHi;
+  Vec3 gravity;
+  s_t dt;
+  std::vector<int> actionMap;
+  std::vector<BoxCollider> boxes;
+  int maxContacts;
+  s_t clippingDepth, fallbackCfm;
+};
+
+inline Iso loadIso(const double* t) {
+  Iso r;
+  for (int i = 0; i < 9; i++) r.R.m[i] = t[i];
+  for (int i = 0; i < 3; i++) r.p.v[i] = t[9 + i];
+  return r;
+}
+
+inline Model buildModel(const nbl_model_desc* d) {
+  Model m;
+  m.nb = d->n_bodies;
+  m.n = d->n_dofs;
+  m.bodies.resize(m.nb);
+  for (int i = 0; i < m.nb; i++) {
+    Body& b = m.bodies[i];
+    b.parent = d->parent[i];
+    b.jtype = d->joint_type[i];
+    b.dofOff = d->dof_offset[i];
+    b.ndof = (b.jtype == NBL_JOINT_FREE) ? 6 : (b.jtype == NBL_JOINT_WELD ? 0 : 1);
+    b.Tpj = loadIso(d->T_pj + 12 * i);
+    b.Tcj = loadIso(d->T_cj + 12 * i);
+    b.TcjInv = inverse(b.Tcj);
+    b.axis = mk3(d->axis[3 * i], d->axis[3 * i + 1], d->axis[3 * i + 2]);
+    // spatial tensor (Inertia.cpp:1368-1383)
+    Vec3 c = mk3(d->com[3 * i], d->com[3 * i + 1], d->com[3 * i + 2]);
+    s_t mass = d->mass[i];
+    const double* I = d->inertia + 6 * i;
+    Mat3 Ic;
+    Ic(0, 0) = I[0]; Ic(1, 1) = I[1]; Ic(2, 2) = I[2];
+    Ic(0, 1) = Ic(1, 0) = I[3]; Ic(0, 2) = Ic(2, 0) = I[4]; Ic(1, 2) = Ic(2, 1) = I[5];
+    Mat3 C = skew(c);
+    Mat3 TL = Ic + mass * (C * transpose(C));
+    b.G = zero66();
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) {
+        b.G(r, cc) = TL(r, cc);
+        b.G(r, 3 + cc) = mass * C(r, cc);
+        b.G(3 + r, cc) = mass * C(cc, r);
+      }
+    b.G(3, 3) = b.G(4, 4) = b.G(5, 5) = mass;
+    // relative Jacobian
+    for (int k = 0; k < 6; k++) b.S[k] = zero6();
+    if (b.jtype == NBL_JOINT_REVOLUTE) {
+      // AdTAngular(T_cj, axis)  RevoluteJoint.cpp:141-152
+      b.S[0] = AdT(b.Tcj, mk6(b.axis, mk3(0, 0, 0)));
+    } else if (b.jtype == NBL_JOINT_PRISMATIC) {
+      // AdTLinear(T_cj, axis)   PrismaticJoint.cpp
+      b.S[0] = AdT(b.Tcj, mk6(mk3(0, 0, 0), b.axis));
+    } else if (b.jtype == NBL_JOINT_FREE) {
+      // getAdTMatrix(T_cj)      FreeJoint.cpp:1049-1056 (DART_USE_IDENTITY_JACOBIAN)
+      Mat6 A = AdTMatrix(b.Tcj);
+      for (int k = 0; k < 6; k++)
+        for (int r = 0; r < 6; r++) b.S[k][r] = A(r, k);
+    }
+    if (b.parent >= 0) m.bodies[b.parent].children.push_back(i);
+  }
+  auto cp = [&](const double* p, VecX& v, double dflt) {
+    v.assign(m.n, dflt);
+    if (p) for (int i = 0; i < m.n; i++) v[i] = p[i];
+  };
+  const double inf = INFINITY;
+  cp(d->damping, m.damping, 0); cp(d->spring, m.spring, 0); cp(d->rest, m.rest, 0);
+  cp(d->pos_lo, m.posLo, -inf); cp(d->pos_hi, m.posHi, inf);
+  cp(d->vel_lo, m.velLo, -inf); cp(d->vel_hi, m.velHi, inf);
+  cp(d->force_lo, m.forceLo, -inf); cp(d->force_hi, m.forceHi, inf);
+  m.gravity = mk3(d->gravity[0], d->gravity[1], d->gravity[2]);
+  m.dt = d->dt;
+  m.actionMap.assign(d->action_map, d->action_map + d->n_action);
+  for (int i = 0; i < d->n_boxes; i++) {
+    BoxCollider bc;
+    bc.body = d->box_body[i];
+    bc.T = loadIso(d->box_T + 12 * i);
+    bc.size = mk3(d->box_size[3 * i], d->box_size[3 * i + 1], d->box_size[3 * i + 2]);
+    bc.mu = d->box_mu[i];
+    m.boxes.push_back(bc);
+  }
+  m.maxContacts = d->max_contacts;
+  m.clippingDepth = d->contact_clipping_depth;
+  m.fallbackCfm = d->fallback_cfm;
+  return m;
+}
+
+// Per-body kinematic cache (BodyNode::mWorldTransform, mVelocity, mPartialAcceleration)
+struct Kin {
+  Iso Trel, Tworld;
+  Vec6 V, eta;
+};
+
+// Joint transform Q(q): RevoluteJoint.cpp:203-211, PrismaticJoint.cpp, FreeJoint.cpp:74-81,1027-1044
+inline Iso jointQ(const Body& b, const s_t* q) {
+  Iso Q = isoIdentity();
+  if (b.jtype == NBL_JOINT_REVOLUTE) Q.R = expAngular(b.axis * q[b.dofOff]);
+  else if (b.jtype == NBL_JOINT_PRISMATIC) Q.p = b.axis * q[b.dofOff];
+  else if (b.jtype == NBL_JOINT_FREE) {
+    Q.R = expMapRot(mk3(q[b.dofOff], q[b.dofOff + 1], q[b.dofOff + 2]));
+    Q.p = mk3(q[b.dofOff + 3], q[b.dofOff + 4], q[b.dofOff + 5]);
+  }
+  return Q;
+}
+
+inline Vec6 jointTwist(const Body& b, const s_t* v) {  // S * dq
+  Vec6 s = zero6();
+  for (int k = 0; k < b.ndof; k++) s = s + b.S[k] * v[b.dofOff + k];
+  return s;
+}
+
+// Forward kinematics: T = T_pj Q T_cj^-1; V = AdInvT(T, V_parent) + S dq; eta = ad(V, S dq) + dS dq
+// (detail/GenericJoint.hpp:1803-1824; dS = 0 for every joint type on the path)
+inline void kinematics(const Model& m, const s_t* q, const s_t* v, std::vector<Kin>& kin) {
+  kin.resize(m.nb);
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    Kin& k = kin[i];
+    k.Trel = b.Tpj * jointQ(b, q) * b.TcjInv;
+    Vec6 Sdq = jointTwist(b, v);
+    if (b.parent >= 0) {
+      k.Tworld = kin[b.parent].Tworld * k.Trel;
+      k.V = AdInvT(k.Trel, kin[b.parent].V) + Sdq;
+    } else {
+      k.Tworld = k.Trel;
+      k.V = Sdq;
+    }
+    k.eta = ad(k.V, Sdq);
+  }
+}
+
+// Articulated-body pass cache
+struct Art {
+  Mat6 AI;       // BodyNode::mArtInertia
+  s_t psi[36];   // Joint::mInvProjArtInertia (ndof x ndof, row-major with stride ndof)
+  Vec6 AIS[6];   // AI * S columns
+};
+
+inline void invertSmall(const s_t* A, int k, s_t* out) {
+  // math::inverse<ConfigSpaceT>: closed form up to 4, LDLT otherwise (ConfigurationSpace.hpp:48-65)
+  if (k == 0) return;
+  if (k == 1) { out[0] = 1.0 / A[0]; return; }
+  MatX a(k, k), ai;
+  for (int i = 0; i < k * k; i++) a.d[i] = A[i];
+  spdInverse(a, ai);
+  for (int i = 0; i < k * k; i++) out[i] = ai.d[i];
+}
+
+// BodyNode::updateArtInertia leaf->root (BodyNode.cpp:2046-2073; GenericJoint.hpp:2168-2185, 2276-2301)
+inline void articulatedInertias(const Model& m, const std::vector<Kin>& kin, std::vector<Art>& art) {
+  art.resize(m.nb);
+  for (int i = m.nb - 1; i >= 0; i--) {
+    const Body& b = m.bodies[i];
+    Art& a = art[i];
+    a.AI = b.G;
+    for (int c : b.children) {
+      const Body& cb = m.bodies[c];
+      const Art& ca = art[c];
+      Mat6 PI = ca.AI;
+      // PI -= AIS * psi * AIS^T
+      for (int r = 0; r < 6; r++)
+        for (int cc = 0; cc < 6; cc++) {
+          s_t s = 0;
+          for (int k1 = 0; k1 < cb.ndof; k1++)
+            for (int k2 = 0; k2 < cb.ndof; k2++) s += ca.AIS[k1][r] * ca.psi[k1 * cb.ndof + k2] * ca.AIS[k2][cc];
+          PI(r, cc) -= s;
+        }
+      a.AI = a.AI + transformInertia(inverse(kin[c].Trel), PI);
+    }
+    s_t proj[36];
+    for (int k = 0; k < b.ndof; k++) a.AIS[k] = a.AI * b.S[k];
+    for (int k1 = 0; k1 < b.ndof; k1++)
+      for (int k2 = 0; k2 < b.ndof; k2++) proj[k1 * b.ndof + k2] = dot(b.S[k1], a.AIS[k2]);
+    invertSmall(proj, b.ndof, a.psi);
+  }
+}
+
+// Skeleton::computeForwardDynamics (Skeleton.cpp:13296-13314).
+// Returns joint accelerations; optionally the body accelerations and transmitted forces.
+inline void forwardDynamics(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art, const s_t* q,
+                            const s_t* v, const s_t* tau, s_t* qdd, std::vector<Vec6>* bodyAcc = nullptr) {
+  std::vector<Vec6> bias(m.nb), acc(m.nb);
+  std::vector<s_t> total(m.n > 0 ? m.n : 1);
+  // leaf -> root: BodyNode::updateBiasForce (BodyNode.cpp:2076-2114)
+  for (int i = m.nb - 1; i >= 0; i--) {
+    const Body& b = m.bodies[i];
+    Vec6 Fg = b.G * AdInvRLinear(kin[i].Tworld, m.gravity);
+    Vec6 B = -dad(kin[i].V, b.G * kin[i].V) - Fg;  // no external force on this path
+    for (int c : b.children) {
+      const Body& cb = m.bodies[c];
+      // GenericJoint::addChildBiasForceToDynamic (GenericJoint.hpp:2395-2421)
+      Vec6 Spsiu = zero6();
+      for (int k1 = 0; k1 < cb.ndof; k1++) {
+        s_t pu = 0;
+        for (int k2 = 0; k2 < cb.ndof; k2++) pu += art[c].psi[k1 * cb.ndof + k2] * total[cb.dofOff + k2];
+        Spsiu = Spsiu + cb.S[k1] * pu;
+      }
+      Vec6 beta = bias[c] + art[c].AI * (kin[c].eta + Spsiu);
+      B = B + dAdInvT(kin[c].Trel, beta);
+    }
+    bias[i] = B;
+    // GenericJoint::updateTotalForceDynamic (GenericJoint.hpp:2554-2571)
+    Vec6 bodyForce = art[i].AI * kin[i].eta + B;
+    for (int k = 0; k < b.ndof; k++) {
+      int d = b.dofOff + k;
+      s_t springForce = -m.spring[d] * (q[d] - m.rest[d] + v[d] * m.dt);
+      s_t dampingForce = -m.damping[d] * v[d];
+      total[d] = tau[d] + springForce + dampingForce - dot(b.S[k], bodyForce);
+    }
+  }
+  // root -> leaf: updateAccelerationFD (BodyNode.cpp:2159-2185; GenericJoint.hpp:2656-2676)
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    Vec6 parentAcc = (b.parent >= 0) ? acc[b.parent] : zero6();
+    Vec6 Xa = AdInvT(kin[i].Trel, parentAcc);
+    Vec6 AIXa = art[i].AI * Xa;
+    s_t rhs[6];
+    for (int k = 0; k < b.ndof; k++) rhs[k] = total[b.dofOff + k] - dot(b.S[k], AIXa);
+    Vec6 A = Xa + kin[i].eta;
+    for (int k1 = 0; k1 < b.ndof; k1++) {
+      s_t a = 0;
+      for (int k2 = 0; k2 < b.ndof; k2++) a += art[i].psi[k1 * b.ndof + k2] * rhs[k2];
+      qdd[b.dofOff + k1] = a;
+      A = A + b.S[k1] * a;
+    }
+    acc[i] = A;
+  }
+  if (bodyAcc) *bodyAcc = acc;
+}
+
+// Impulse-based forward dynamics with an arbitrary set of body impulses
+// (BodyNode::updateBiasImpulse BodyNode.cpp:2117-2138, updateVelocityChangeFD :2188-2215;
+//  GenericJoint.hpp:2482-2498, 2607-2613, 2713-2725).  impulses[i] is the constraint impulse on body i
+// expressed in its own frame (BodyNode::mConstraintImpulse).  Returns delta joint velocities.
+inline void impulseDynamics(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art,
+                            const std::vector<Vec6>& impulses, s_t* delV) {
+  std::vector<Vec6> bias(m.nb), dV(m.nb);
+  std::vector<s_t> total(m.n > 0 ? m.n : 1);
+  for (int i = m.nb - 1; i >= 0; i--) {
+    const Body& b = m.bodies[i];
+    Vec6 B = -impulses[i];
+    for (int c : b.children) {
+      const Body& cb = m.bodies[c];
+      // addChildBiasImpulseToDynamic: beta = childBias + AI * S * psi * totalImpulse
+      Vec6 Spsiu = zero6();
+      for (int k1 = 0; k1 < cb.ndof; k1++) {
+        s_t pu = 0;
+        for (int k2 = 0; k2 < cb.ndof; k2++) pu += art[c].psi[k1 * cb.ndof + k2] * total[cb.dofOff + k2];
+        Spsiu = Spsiu + cb.S[k1] * pu;
+      }
+      Vec6 beta = bias[c] + art[c].AI * Spsiu;
+      B = B + dAdInvT(kin[c].Trel, beta);
+    }
+    bias[i] = B;
+    for (int k = 0; k < b.ndof; k++) total[b.dofOff + k] = -dot(b.S[k], B);  // constraint impulses on joints are 0 here
+  }
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    Vec6 parentDV = (b.parent >= 0) ? dV[b.parent] : zero6();
+    Vec6 X = AdInvT(kin[i].Trel, parentDV);
+    Vec6 AIX = art[i].AI * X;
+    s_t rhs[6];
+    for (int k = 0; k < b.ndof; k++) rhs[k] = total[b.dofOff + k] - dot(b.S[k], AIX);
+    Vec6 D = X;
+    for (int k1 = 0; k1 < b.ndof; k1++) {
+      s_t a = 0;
+      for (int k2 = 0; k2 < b.ndof; k2++) a += art[i].psi[k1 * b.ndof + k2] * rhs[k2];
+      delV[b.dofOff + k1] = a;
+      D = D + b.S[k1] * a;
+    }
+    dV[i] = D;
+  }
+}
+
+// Recursive Newton-Euler inverse dynamics  tau = M(q) a + C(q, v)  (gravity optional).
+// Used for: C+g  (Skeleton::updateCoriolisAndGravityForces Skeleton.cpp:12914-12943 with
+// BodyNode::updateCombinedVector/aggregateCombinedVector BodyNode.cpp:2455-2506; a = 0),
+// and M columns (Skeleton::updateMassMatrix Skeleton.cpp:12372-12434; v = 0, no gravity, a = e_j).
+// Gravity enters as a body force exactly as in the reference (mFgravity).
+inline void inverseDynamics(const Model& m, const std::vector<Kin>& kinQ /* Trel/Tworld only */, const s_t* v,
+                            const s_t* a, bool withVelocity, bool withGravity, s_t* tauOut,
+                            std::vector<Vec6>* Vout = nullptr, std::vector<Vec6>* Aout = nullptr,
+                            std::vector<Vec6>* Fout = nullptr) {
+  std::vector<Vec6> V(m.nb), A(m.nb), F(m.nb);
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    Vec6 Sdq = withVelocity ? jointTwist(b, v) : zero6();
+    Vec6 Sddq = jointTwist(b, a);
+    Vec6 Vp = (b.parent >= 0) ? AdInvT(kinQ[i].Trel, V[b.parent]) : zero6();
+    Vec6 Ap = (b.parent >= 0) ? AdInvT(kinQ[i].Trel, A[b.parent]) : zero6();
+    V[i] = Vp + Sdq;
+    A[i] = Ap + ad(V[i], Sdq) + Sddq;
+  }
+  for (int i = m.nb - 1; i >= 0; i--) {
+    const Body& b = m.bodies[i];
+    Vec6 f = b.G * A[i] - dad(V[i], b.G * V[i]);
+    if (withGravity) f = f - b.G * AdInvRLinear(kinQ[i].Tworld, m.gravity);
+    for (int c : b.children) f = f + dAdInvT(kinQ[c].Trel, F[c]);
+    F[i] = f;
+    for (int k = 0; k < b.ndof; k++) tauOut[b.dofOff + k] = dot(b.S[k], f);
+  }
+  if (Vout) *Vout = V;
+  if (Aout) *Aout = A;
+  if (Fout) *Fout = F;
+}
+
+inline MatX massMatrix(const Model& m, const std::vector<Kin>& kin) {
+  MatX M(m.n, m.n);
+  VecX a(m.n, 0.0), col(m.n, 0.0), zero(m.n, 0.0);
+  for (int j = 0; j < m.n; j++) {
+    a.assign(m.n, 0.0);
+    a[j] = 1.0;
+    inverseDynamics(m, kin, zero.data(), a.data(), false, false, col.data());
+    for (int i = 0; i < m.n; i++) M(i, j) = col[i];
+  }
+  return M;
+}
+
+// Skeleton::getInvMassMatrix.  The reference builds it column by column with unit-force ABA sweeps
+// (Skeleton.cpp:12621-12654) or, when weld joints are present, as M.llt().solve(I) (:12588-12608).
+// Here: unit-impulse ABA sweeps on joint space, i.e. the same recursion with generalized impulses.
+inline MatX invMassMatrix(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art) {
+  (void)art;
+  MatX M = massMatrix(m, kin), Minv;
+  spdInverse(M, Minv);
+  return Minv;
+}
+
+// Position-space relative Jacobian column(s) H(q): delta T_rel = T_rel * hat(H dq).
+// Revolute/Prismatic: H = S.  Free: AdTJacFixed(T_cj, blkdiag(expMapJac(q)^T, expMapRot(q)^T))
+// (FreeJoint.cpp:790-823, getRelativeJacobianInPositionSpaceStatic)
+inline void positionJacobian(const Body& b, const s_t* q, Vec6 H[6]) {
+  if (b.jtype != NBL_JOINT_FREE) {
+    for (int k = 0; k < b.ndof; k++) H[k] = b.S[k];
+    return;
+  }
+  Vec3 r = mk3(q[b.dofOff], q[b.dofOff + 1], q[b.dofOff + 2]);
+  Mat3 Jt = transpose(expMapJac(r));
+  Mat3 Rt = transpose(expMapRot(r));
+  for (int k = 0; k < 3; k++) {
+    Vec6 colA = mk6(mk3(Jt(0, k), Jt(1, k), Jt(2, k)), mk3(0, 0, 0));
+    Vec6 colL = mk6(mk3(0, 0, 0), mk3(Rt(0, k), Rt(1, k), Rt(2, k)));
+    H[k] = AdT(b.Tcj, colA);
+    H[3 + k] = AdT(b.Tcj, colL);
+  }
+}
+
+// Directional derivative of inverse dynamics  tau = ID(q, v, a)  along (dq, dv) with a held fixed.
+// This is the column recursion the reference implements in
+//   BodyNode::computeJacobianOfCForward/Backward (BodyNode.cpp:3440-3597, 3832-3962)  [dC/dq, dC/dv]
+//   BodyNode::computeJacobianOfMForward/Backward (BodyNode.cpp:2972-3037, 3111-3205)  [d(M x)/dq]
+// restated as one tangent (forward-mode) sweep per column.  Gravity is carried as the equivalent
+// base acceleration -g (identical value, simpler derivative).
+struct IDNominal {
+  std::vector<Vec6> V, A, F;
+};
+inline void idNominal(const Model& m, const std::vector<Kin>& kin, const s_t* v, const s_t* a, bool withVelocity,
+                      bool withGravity, IDNominal& nom) {
+  nom.V.resize(m.nb); nom.A.resize(m.nb); nom.F.resize(m.nb);
+  Vec6 a0 = withGravity ? mk6(mk3(0, 0, 0), -m.gravity) : zero6();
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    Vec6 Sdq = withVelocity ? jointTwist(b, v) : zero6();
+    Vec6 Vp = (b.parent >= 0) ? AdInvT(kin[i].Trel, nom.V[b.parent]) : zero6();
+    Vec6 Ap = AdInvT(kin[i].Trel, (b.parent >= 0) ? nom.A[b.parent] : a0);
+    nom.V[i] = Vp + Sdq;
+    nom.A[i] = Ap + ad(nom.V[i], Sdq) + jointTwist(b, a);
+  }
+  for (int i = m.nb - 1; i >= 0; i--) {
+    const Body& b = m.bodies[i];
+    Vec6 f = b.G * nom.A[i] - dad(nom.V[i], b.G * nom.V[i]);
+    for (int c : b.children) f = f + dAdInvT(kin[c].Trel, nom.F[c]);
+    nom.F[i] = f;
+  }
+}
+inline void idTangent(const Model& m, const std::vector<Kin>& kin, const IDNominal& nom, const s_t* q, const s_t* v,
+                      bool withVelocity, bool withGravity, const s_t* dq, const s_t* dv, s_t* dtau) {
+  std::vector<Vec6> dV(m.nb), dA(m.nb), dF(m.nb), h(m.nb);
+  Vec6 a0 = withGravity ? mk6(mk3(0, 0, 0), -m.gravity) : zero6();
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    Vec6 H[6];
+    positionJacobian(b, q, H);
+    Vec6 hi = zero6();
+    for (int k = 0; k < b.ndof; k++) hi = hi + H[k] * dq[b.dofOff + k];
+    h[i] = hi;
+    Vec6 Sdq = withVelocity ? jointTwist(b, v) : zero6();
+    Vec6 Sddv = jointTwist(b, dv);
+    Vec6 XVp = (b.parent >= 0) ? AdInvT(kin[i].Trel, nom.V[b.parent]) : zero6();
+    Vec6 XAp = AdInvT(kin[i].Trel, (b.parent >= 0) ? nom.A[b.parent] : a0);
+    Vec6 XdVp = (b.parent >= 0) ? AdInvT(kin[i].Trel, dV[b.parent]) : zero6();
+    Vec6 XdAp = (b.parent >= 0) ? AdInvT(kin[i].Trel, dA[b.parent]) : zero6();
+    dV[i] = XdVp - ad(hi, XVp) + Sddv;
+    dA[i] = XdAp - ad(hi, XAp) + ad(dV[i], Sdq) + ad(nom.V[i], Sddv);
+  }
+  for (int i = m.nb - 1; i >= 0; i--) {
+    const Body& b = m.bodies[i];
+    Vec6 GV = b.G * nom.V[i];
+    Vec6 df = b.G * dA[i] - dad(dV[i], GV) - dad(nom.V[i], b.G * dV[i]);
+    for (int c : b.children) {
+      // d(X_c^T F_c) = X_c^T (dF_c - ad^T(h_c) F_c)
+      df = df + dAdInvT(kin[c].Trel, dF[c] - dad(h[c], nom.F[c]));
+    }
+    dF[i] = df;
+    for (int k = 0; k < b.ndof; k++) dtau[b.dofOff + k] = dot(b.S[k], df);
+  }
+}
+
+// Skeleton::getJacobianOfC(wrt) (Skeleton.cpp:1780-1830), getVelCJacobian (:2264-2269)
+inline MatX jacobianOfC(const Model& m, const std::vector<Kin>& kin, const s_t* q, const s_t* v, bool wrtVelocity) {
+  VecX zero(m.n, 0.0), dir(m.n, 0.0), col(m.n, 0.0);
+  IDNominal nom;
+  idNominal(m, kin, v, zero.data(), true, true, nom);
+  MatX J(m.n, m.n);
+  for (int j = 0; j < m.n; j++) {
+    dir.assign(m.n, 0.0);
+    dir[j] = 1.0;
+    if (wrtVelocity) idTangent(m, kin, nom, q, v, true, true, zero.data(), dir.data(), col.data());
+    else idTangent(m, kin, nom, q, v, true, true, dir.data(), zero.data(), col.data());
+    for (int i = 0; i < m.n; i++) J(i, j) = col[i];
+  }
+  return J;
+}
+// Skeleton::getJacobianOfM(x, POSITION) (Skeleton.cpp:1833-1882): d(M(q) x)/dq
+inline MatX jacobianOfMx(const Model& m, const std::vector<Kin>& kin, const s_t* q, const s_t* x) {
+  VecX zero(m.n, 0.0), dir(m.n, 0.0), col(m.n, 0.0);
+  IDNominal nom;
+  idNominal(m, kin, zero.data(), x, false, false, nom);
+  MatX J(m.n, m.n);
+  for (int j = 0; j < m.n; j++) {
+    dir.assign(m.n, 0.0);
+    dir[j] = 1.0;
+    idTangent(m, kin, nom, q, zero.data(), false, false, dir.data(), zero.data(), col.data());
+    for (int i = 0; i < m.n; i++) J(i, j) = col[i];
+  }
+  return J;
+}
+
+// Position integration per joint: R^n Euler (ConfigurationSpace.hpp:145-180) and
+// FreeJoint::integratePositionsExplicit (FreeJoint.cpp:922-929, identity-Jacobian branch):
+//   Qnext = convertToTransform(pos) * convertToTransform(vel*dt); pos' = [logMap(R); p]
+inline void integratePositions(const Model& m, const s_t* q, const s_t* v, s_t dt, s_t* qn) {
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    if (b.jtype == NBL_JOINT_FREE) {
+      int o = b.dofOff;
+      Iso Q, D;
+      Q.R = expMapRot(mk3(q[o], q[o + 1], q[o + 2]));
+      Q.p = mk3(q[o + 3], q[o + 4], q[o + 5]);
+      D.R = expMapRot(mk3(v[o] * dt, v[o + 1] * dt, v[o + 2] * dt));
+      D.p = mk3(v[o + 3] * dt, v[o + 4] * dt, v[o + 5] * dt);
+      Iso N = Q * D;
+      Vec3 r = logMap(N.R);
+      for (int k = 0; k < 3; k++) { qn[o + k] = r[k]; qn[o + 3 + k] = N.p[k]; }
+    } else {
+      for (int k = 0; k < b.ndof; k++) qn[b.dofOff + k] = q[b.dofOff + k] + v[b.dofOff + k] * dt;
+    }
+  }
+}
+
+// World::getPosPosJacobian / getVelPosJacobian (World.cpp:2415-2446): block diagonal per joint; identity
+// resp. dt*I for R^n joints (GenericJoint.hpp:1428-1444), central finite differences for the free
+// joint (FreeJoint.cpp:950-1007: eps 1e-6 for pos, 1e-7 for vel) — restated literally, FD included.
+inline void posJacobians(const Model& m, const s_t* q, const s_t* v, s_t dt, MatX& posPos, MatX& velPos) {
+  posPos = identityX(m.n);
+  velPos = MatX(m.n, m.n);
+  for (int i = 0; i < m.n; i++) velPos(i, i) = dt;
+  VecX qa(q, q + m.n), va(v, v + m.n), plus(m.n), minus(m.n);
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    if (b.jtype != NBL_JOINT_FREE) continue;
+    int o = b.dofOff;
+    for (int j = 0; j < 6; j++) {
+      s_t EPS = 1e-6;
+      VecX pert = qa;
+      pert[o + j] += EPS;
+      integratePositions(m, pert.data(), v, dt, plus.data());
+      pert = qa;
+      pert[o + j] -= EPS;
+      integratePositions(m, pert.data(), v, dt, minus.data());
+      for (int r = 0; r < 6; r++) posPos(o + r, o + j) = (plus[o + r] - minus[o + r]) / (2 * EPS);
+      EPS = 1e-7;
+      pert = va;
+      pert[o + j] += EPS;
+      integratePositions(m, q, pert.data(), dt, plus.data());
+      pert = va;
+      pert[o + j] -= EPS;
+      integratePositions(m, q, pert.data(), dt, minus.data());
+      for (int r = 0; r < 6; r++) velPos(o + r, o + j) = (plus[o + r] - minus[o + r]) / (2 * EPS);
+    }
+  }
+}
+
+}  // namespace nbo

@@ -1,0 +1,317 @@
+// oracle/oracle.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement ("oracle") of the reference hot path
+//   neural::forwardPass -> World::step            dart/neural/NeuralUtils.cpp:26-66, dart/simulation/World.cpp:221-333
+//   BackpropSnapshot::backpropState               dart/neural/BackpropSnapshot.cpp:121-194, 382-479
+// one world at a time, scalar fp64, dense n x n Jacobians exactly like the reference forms them.
+//
+// PARITY PINNING: the upstream library cannot be built in this image (Eigen, libccd, assimp, ...
+// are absent), and its tests hold no stored expected outputs for the step or its gradients.  The
+// oracle is therefore pinned by the reference's own *property* tests restated in
+// tests/test_oracle_props.py (finite-difference agreement of every Jacobian, VJP == J^T g,
+// multi-step backprop vs brute force, M*Minv = I) and, for the LCP stage, by the literal fixtures of
+// unittests/unit/test_LCPUtils.cpp and by the vendored ODE Dantzig solver compiled from the reference
+// sources (oracle/_ref).  Where neither exists DESIGN.md says "parity unpinned".
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include <cstdio>
+#include <thread>
+
+#include "contact.hpp"
+#include "dynamics.hpp"
+
+using namespace nbo;
+
+namespace {
+
+struct Snapshot {  // what BackpropSnapshot captures (BackpropSnapshot.cpp:33-118)
+  VecX q, v, tau, vPre;
+  ContactResult contact;
+  bool valid = false;
+};
+
+struct Oracle {
+  Model model;
+  Snapshot snap;
+  VecX lcpCache;  // BoxedLcpConstraintSolver::mX, persists across steps (:176-187)
+};
+
+// World::step with gradients enabled.
+void stepWorld(Oracle& o, const s_t* q, const s_t* v, const s_t* tau, s_t* qNext, s_t* vNext, uint32_t* status) {
+  const Model& m = o.model;
+  std::vector<Kin> kin;
+  std::vector<Art> art;
+  kinematics(m, q, v, kin);
+  articulatedInertias(m, kin, art);
+  VecX qdd(m.n, 0.0), vPre(m.n, 0.0);
+  // World.cpp:226-233: computeForwardDynamics(); integrateVelocities(dt)
+  forwardDynamics(m, kin, art, q, v, tau, qdd.data());
+  for (int i = 0; i < m.n; i++) vPre[i] = v[i] + m.dt * qdd[i];  // GenericJoint.hpp:1410-1414
+
+  Snapshot& s = o.snap;
+  s.q.assign(q, q + m.n);
+  s.v.assign(v, v + m.n);
+  s.tau.assign(tau, tau + m.n);
+  s.vPre = vPre;
+  s.valid = true;
+
+  // World.cpp:247 -> ConstraintSolver::solve() -> integrateVelocitiesFromImpulses()
+  VecX vOut = vPre;
+  uint32_t st = 0;
+  solveContacts(m, kin, art, q, vPre.data(), o.lcpCache, s.contact, vOut.data(), &st);
+  for (int i = 0; i < m.n; i++) vNext[i] = vOut[i];
+  // World.cpp:250,307-333: positions integrate with the *initial* velocity (mParallelVelocityAndPositionUpdates)
+  integratePositions(m, q, v, m.dt, qNext);
+  if (status) *status = st;
+}
+
+// BackpropSnapshot::backprop (:121-194) through the dense Jacobians of §3.3 / Appendix A.6–A.7.
+void backpropWorld(Oracle& o, const s_t* gqNext, const s_t* gvNext, s_t* gq, s_t* gv, s_t* gtau) {
+  const Model& m = o.model;
+  const Snapshot& s = o.snap;
+  const int n = m.n;
+  const s_t dt = m.dt;
+  std::vector<Kin> kin;
+  std::vector<Art> art;
+  kinematics(m, s.q.data(), s.v.data(), kin);
+  articulatedInertias(m, kin, art);
+  MatX Minv = invMassMatrix(m, kin, art);
+  VecX zero(n, 0.0), C(n, 0.0);
+  // World::getCoriolisAndGravityAndExternalForces (World.cpp:1958-1971)
+  inverseDynamics(m, kin, s.v.data(), zero.data(), true, true, C.data());
+  MatX dCdq = jacobianOfC(m, kin, s.q.data(), s.v.data(), false);
+  MatX dCdv = jacobianOfC(m, kin, s.q.data(), s.v.data(), true);
+
+  MatX posPos, velPos;
+  posJacobians(m, s.q.data(), s.v.data(), dt, posPos, velPos);  // bounce approximation = identity (restitution 0)
+
+  MatX forceVel(n, n), velVel(n, n), posVel(n, n);
+  const ContactResult& cr = s.contact;
+  if (cr.numClamping == 0) {
+    // no clamping constraints: BackpropSnapshot.cpp:521-524, 686-689, and getVelJacobianWrt with empty A_c
+    VecX r(n);
+    for (int i = 0; i < n; i++)
+      r[i] = dt * (s.tau[i] - C[i] - m.damping[i] * s.v[i] - m.spring[i] * (s.q[i] - m.rest[i] + dt * s.v[i]));
+    VecX w = matvec(Minv, r);
+    MatX dMw = jacobianOfMx(m, kin, s.q.data(), w.data());
+    // getJacobianOfMinv = -Minv * d(M w)/dq  (Skeleton.cpp:2072-2077)
+    MatX dM = matmul(Minv, dMw);
+    MatX MinvdCdq = matmul(Minv, dCdq), MinvdCdv = matmul(Minv, dCdv);
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        forceVel(i, j) = dt * Minv(i, j);
+        velVel(i, j) = (i == j ? 1.0 : 0.0) - dt * Minv(i, j) * m.damping[j] - dt * dt * Minv(i, j) * m.spring[j] -
+                       dt * MinvdCdv(i, j);
+        posVel(i, j) = -dM(i, j) - dt * MinvdCdq(i, j) - dt * Minv(i, j) * m.spring[j];
+      }
+  } else {
+    contactJacobians(m, kin, art, s.q.data(), s.v.data(), s.tau.data(), cr, Minv, C, dCdq, dCdv, forceVel, velVel,
+                     posVel);
+  }
+
+  VecX gqn(gqNext, gqNext + n), gvn(gvNext, gvNext + n);
+  VecX a = matTvec(posPos, gqn), b = matTvec(posVel, gvn), c = matTvec(velPos, gqn), d = matTvec(velVel, gvn),
+       e = matTvec(forceVel, gvn);
+  for (int i = 0; i < n; i++) {
+    gq[i] = a[i] + b[i];
+    gv[i] = c[i] + d[i];
+    gtau[i] = e[i];
+  }
+  // clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479)
+  for (int i = 0; i < n; i++) {
+    if (s.q[i] == m.posLo[i] && gq[i] > 0) gq[i] = 0;
+    if (s.q[i] == m.posHi[i] && gq[i] < 0) gq[i] = 0;
+    if (s.v[i] == m.velLo[i] && gv[i] > 0) gv[i] = 0;
+    if (s.v[i] == m.velHi[i] && gv[i] < 0) gv[i] = 0;
+    if (s.tau[i] == m.forceLo[i] && gtau[i] > 0) gtau[i] = 0;
+    if (s.tau[i] == m.forceHi[i] && gtau[i] < 0) gtau[i] = 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void* nbo_create(const nbl_model_desc* d) {
+  Oracle* o = new Oracle();
+  o->model = buildModel(d);
+  return o;
+}
+void nbo_destroy(void* h) { delete (Oracle*)h; }
+int nbo_num_dofs(void* h) { return ((Oracle*)h)->model.n; }
+
+// state = [q; v] (World::setState), action through the action map (World::setAction)
+static void splitAction(const Model& m, const double* action, VecX& tau) {
+  tau.assign(m.n, 0.0);
+  for (size_t i = 0; i < m.actionMap.size(); i++) tau[m.actionMap[i]] = action[i];
+}
+
+// lcp cache handling: cacheIn may be NULL => keep the handle's persistent cache (reference behaviour);
+// cacheLen < 0 => reset to "wrong size" (forces guessSolution).
+void nbo_set_lcp_cache(void* h, const double* x, int len) {
+  Oracle* o = (Oracle*)h;
+  if (len <= 0) o->lcpCache.clear();
+  else o->lcpCache.assign(x, x + len);
+}
+int nbo_get_lcp_cache(void* h, double* x, int cap) {
+  Oracle* o = (Oracle*)h;
+  int len = (int)o->lcpCache.size();
+  for (int i = 0; i < len && i < cap; i++) x[i] = o->lcpCache[i];
+  return len;
+}
+
+int nbo_step(void* h, const double* state, const double* action, double* nextState, uint32_t* status) {
+  Oracle* o = (Oracle*)h;
+  const Model& m = o->model;
+  VecX tau;
+  splitAction(m, action, tau);
+  stepWorld(*o, state, state + m.n, tau.data(), nextState, nextState + m.n, status);
+  return 0;
+}
+
+int nbo_backprop(void* h, const double* gradNext, double* gradState, double* gradAction) {
+  Oracle* o = (Oracle*)h;
+  const Model& m = o->model;
+  if (!o->snap.valid) return -1;
+  VecX gtau(m.n, 0.0);
+  backpropWorld(*o, gradNext, gradNext + m.n, gradState, gradState + m.n, gtau.data());
+  for (size_t i = 0; i < m.actionMap.size(); i++) gradAction[i] = gtau[m.actionMap[i]];
+  return 0;
+}
+
+// Batched convenience used by the parity tests and by bench.py's cpu_baseline leg: B independent
+// worlds, world-major arrays [B][2n], [B][k]; each world starts from `cold` LCP cache unless
+// lcpIn/lcpLen given ([B][m] + per-world lengths).  `threads` host threads, one cloned world per thread
+// (the reference's own model: MultiShot.cpp:66-70).
+int nbo_step_batch(void* h, int64_t B, const double* state, const double* action, const double* gradNext,
+                   double* nextState, double* gradState, double* gradAction, uint32_t* status, int threads,
+                   const double* lcpIn, const int32_t* lcpLenIn, double* lcpOut, int32_t* lcpLenOut, int lcpStride) {
+  Oracle* base = (Oracle*)h;
+  const Model& m = base->model;
+  const int n = m.n, k = (int)m.actionMap.size();
+  if (threads < 1) threads = 1;
+  auto work = [&](int t) {
+    Oracle o;
+    o.model = m;
+    for (int64_t b = t; b < B; b += threads) {
+      if (lcpIn && lcpLenIn && lcpLenIn[b] > 0) o.lcpCache.assign(lcpIn + b * lcpStride, lcpIn + b * lcpStride + lcpLenIn[b]);
+      else o.lcpCache.clear();
+      VecX tau;
+      splitAction(m, action + b * k, tau);
+      uint32_t st = 0;
+      stepWorld(o, state + b * 2 * n, state + b * 2 * n + n, tau.data(), nextState + b * 2 * n,
+                nextState + b * 2 * n + n, &st);
+      if (status) status[b] = st;
+      if (lcpOut && lcpLenOut) {
+        lcpLenOut[b] = (int32_t)o.lcpCache.size();
+        for (size_t i = 0; i < o.lcpCache.size() && (int)i < lcpStride; i++) lcpOut[b * lcpStride + i] = o.lcpCache[i];
+      }
+      if (gradNext && gradState) {
+        VecX gtau(n, 0.0);
+        backpropWorld(o, gradNext + b * 2 * n, gradNext + b * 2 * n + n, gradState + b * 2 * n,
+                      gradState + b * 2 * n + n, gtau.data());
+        if (gradAction)
+          for (int i = 0; i < k; i++) gradAction[b * k + i] = gtau[m.actionMap[i]];
+      }
+    }
+  };
+  if (threads == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  return 0;
+}
+
+// ---- introspection for the property tests (each returns row-major n x n or n) ----
+static void ctx(Oracle* o, const double* q, const double* v, std::vector<Kin>& kin, std::vector<Art>& art) {
+  kinematics(o->model, q, v, kin);
+  articulatedInertias(o->model, kin, art);
+}
+void nbo_mass_matrix(void* h, const double* q, double* out) {
+  Oracle* o = (Oracle*)h;
+  std::vector<Kin> kin; std::vector<Art> art;
+  VecX z(o->model.n, 0.0);
+  ctx(o, q, z.data(), kin, art);
+  MatX M = massMatrix(o->model, kin);
+  std::copy(M.d.begin(), M.d.end(), out);
+}
+void nbo_coriolis_gravity(void* h, const double* q, const double* v, double* out) {
+  Oracle* o = (Oracle*)h;
+  std::vector<Kin> kin; std::vector<Art> art;
+  ctx(o, q, v, kin, art);
+  VecX z(o->model.n, 0.0);
+  inverseDynamics(o->model, kin, v, z.data(), true, true, out);
+}
+void nbo_forward_dynamics(void* h, const double* q, const double* v, const double* tau, double* qdd) {
+  Oracle* o = (Oracle*)h;
+  std::vector<Kin> kin; std::vector<Art> art;
+  ctx(o, q, v, kin, art);
+  forwardDynamics(o->model, kin, art, q, v, tau, qdd);
+}
+void nbo_jac_C(void* h, const double* q, const double* v, int wrtVel, double* out) {
+  Oracle* o = (Oracle*)h;
+  std::vector<Kin> kin; std::vector<Art> art;
+  ctx(o, q, v, kin, art);
+  MatX J = jacobianOfC(o->model, kin, q, v, wrtVel != 0);
+  std::copy(J.d.begin(), J.d.end(), out);
+}
+void nbo_jac_Mx(void* h, const double* q, const double* x, double* out) {
+  Oracle* o = (Oracle*)h;
+  std::vector<Kin> kin; std::vector<Art> art;
+  VecX z(o->model.n, 0.0);
+  ctx(o, q, z.data(), kin, art);
+  MatX J = jacobianOfMx(o->model, kin, q, x);
+  std::copy(J.d.begin(), J.d.end(), out);
+}
+// impulse test: delta-velocity for a unit impulse `imp` (6) applied on body `body` in its own frame
+void nbo_impulse_response(void* h, const double* q, int body, const double* imp, double* delV) {
+  Oracle* o = (Oracle*)h;
+  std::vector<Kin> kin; std::vector<Art> art;
+  VecX z(o->model.n, 0.0);
+  ctx(o, q, z.data(), kin, art);
+  std::vector<Vec6> imps(o->model.nb, zero6());
+  for (int i = 0; i < 6; i++) imps[body][i] = imp[i];
+  impulseDynamics(o->model, kin, art, imps, delV);
+}
+void nbo_body_world_transform(void* h, const double* q, int body, double* T12) {
+  Oracle* o = (Oracle*)h;
+  std::vector<Kin> kin;
+  VecX z(o->model.n, 0.0);
+  kinematics(o->model, q, z.data(), kin);
+  for (int i = 0; i < 9; i++) T12[i] = kin[body].Tworld.R.m[i];
+  for (int i = 0; i < 3; i++) T12[9 + i] = kin[body].Tworld.p[i];
+}
+void nbo_integrate_positions(void* h, const double* q, const double* v, double* qn) {
+  Oracle* o = (Oracle*)h;
+  integratePositions(o->model, q, v, o->model.dt, qn);
+}
+
+// contact introspection (defined in contact.hpp)
+int nbo_last_contacts(void* h, double* out /* [C][12]: p(3) n(3) depth type bodyA bodyB boxA boxB */, int cap) {
+  Oracle* o = (Oracle*)h;
+  const ContactResult& cr = o->snap.contact;
+  int C = (int)cr.contacts.size();
+  for (int i = 0; i < C && i < cap; i++) {
+    const Contact& c = cr.contacts[i];
+    double* r = out + 12 * i;
+    for (int k = 0; k < 3; k++) { r[k] = c.point[k]; r[3 + k] = c.normal[k]; }
+    r[6] = c.depth; r[7] = c.type; r[8] = c.bodyA; r[9] = c.bodyB; r[10] = c.boxA; r[11] = c.boxB;
+  }
+  return C;
+}
+int nbo_last_lcp(void* h, double* A, double* b, double* x, double* lo, double* hi, int32_t* findex, int32_t* rowClass,
+                 int cap) {
+  Oracle* o = (Oracle*)h;
+  const ContactResult& cr = o->snap.contact;
+  int mrows = cr.m;
+  if (mrows > cap) return -mrows;
+  for (int i = 0; i < mrows; i++) {
+    for (int j = 0; j < mrows; j++) A[i * mrows + j] = cr.A(i, j);
+    b[i] = cr.b[i]; x[i] = cr.x[i]; lo[i] = cr.lo[i]; hi[i] = cr.hi[i]; findex[i] = cr.findex[i];
+    rowClass[i] = cr.rowClass[i];
+  }
+  return mrows;
+}
+}
