@@ -1,0 +1,21 @@
+"""nimblephysics_amd — MI355X-native batched differentiable timestep.
+
+Drop-in for ONE hot path of nimblephysics: `timestep(world, state, action)`
+(python/nimblephysics/timestep.py:63-69).  See DESIGN.md / INTEGRATION.md.
+"""
+from .model import (BodySpec, BoxSpec, ModelDescription, atlas, box_stack, cartpole,  # noqa: F401
+                    make_transform, single_pendulum)
+
+__all__ = ["ModelDescription", "BodySpec", "BoxSpec", "World", "timestep", "TimestepLayer", "single_pendulum", "cartpole",
+           "atlas", "box_stack", "make_transform"]
+
+
+def __getattr__(name):
+    # torch-dependent pieces are imported lazily so that model building works without a GPU stack
+    if name in ("World",):
+        from .world import World
+        return World
+    if name in ("timestep", "TimestepLayer"):
+        from . import timestep as _t
+        return getattr(_t, name)
+    raise AttributeError(name)

@@ -1,0 +1,74 @@
+"""ctypes binding of libnimble_amd.so (the C ABI of include/nimble_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is visible, the
+product path raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from here.)
+"""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnimble_amd.so")
+_lib = None
+
+
+class NimbleAmdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libnimble_amd.so (after torch, so both share one HIP runtime: same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  -- must be loaded first so that its bundled libamdhip64 is the one in the process
+    if not os.path.exists(LIB_PATH):
+        raise NimbleAmdError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "The batched timestep has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    pd, vp = C.POINTER(C.c_double), C.c_void_p
+    L.nbl_last_error.restype = C.c_char_p
+    L.nbl_version.restype = C.c_int32
+    L.nbl_device_count.restype = C.c_int32
+    L.nbl_model_create.argtypes = [C.POINTER(_abi.ModelDesc), C.c_int32, C.POINTER(vp)]
+    L.nbl_model_create.restype = C.c_int32
+    L.nbl_model_destroy.argtypes = [vp]
+    L.nbl_model_destroy.restype = None
+    for f in ("nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = C.c_int32
+    L.nbl_workspace_bytes.argtypes = [vp, C.c_int64]
+    L.nbl_workspace_bytes.restype = C.c_size_t
+    L.nbl_saved_bytes.argtypes = [vp, C.c_int64]
+    L.nbl_saved_bytes.restype = C.c_size_t
+    L.nbl_step_forward.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    L.nbl_step_forward.restype = C.c_int32
+    L.nbl_step_backward.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    L.nbl_step_backward.restype = C.c_int32
+    L.nbl_transpose_to_soa.argtypes = [vp, vp, C.c_int64, C.c_int32, vp]
+    L.nbl_transpose_to_soa.restype = C.c_int32
+    L.nbl_transpose_from_soa.argtypes = [vp, vp, C.c_int64, C.c_int32, vp]
+    L.nbl_transpose_from_soa.restype = C.c_int32
+    L.nbl_set_timing.argtypes = [vp, C.c_int32]
+    L.nbl_set_timing.restype = C.c_int32
+    L.nbl_get_timing.argtypes = [vp, pd, C.POINTER(C.c_int64), pd, C.POINTER(C.c_int64)]
+    L.nbl_get_timing.restype = C.c_int32
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "nbl_last_error", "nbl_version", "nbl_device_count", "nbl_model_create", "nbl_model_destroy",
+    "nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows", "nbl_workspace_bytes", "nbl_saved_bytes",
+    "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing",
+    "nbl_get_timing",
+]
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().nbl_last_error()
+        raise NimbleAmdError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

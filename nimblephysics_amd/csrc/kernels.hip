@@ -1,0 +1,480 @@
+// kernels.hip — hand-written HIP kernels (gfx950) for the batched differentiable timestep.
+//
+// Execution model: ONE WORLD PER LANE.  A wavefront holds 64 consecutive worlds; every per-DOF
+// load/store of a wavefront is one coalesced 512-byte line of the [dof][B] arrays.  The body loop
+// is the (short, sequential) outer loop inside the kernel; its trip count and every branch on the
+// joint type are wave-uniform (all worlds share the model), so the tree sweeps run without
+// divergence and the model constants are fetched with scalar loads.
+//
+// Forward  (k_step_forward):  World::step, dart/simulation/World.cpp:221-333
+//   sweep 1 root->leaf  kinematics                     detail/GenericJoint.hpp:1803-1824
+//   sweep 2 leaf->root  articulated inertia + bias     BodyNode.cpp:2046-2114, GenericJoint.hpp:2168-2185, 2276-2301, 2395-2421, 2554-2571
+//   sweep 3 root->leaf  accelerations                  BodyNode.cpp:2159-2185, GenericJoint.hpp:2656-2676
+//   v' = v + dt*qdd ; q' = integrate(q, v_t, dt)       GenericJoint.hpp:1410-1426, FreeJoint.cpp:922-929
+//
+// Backward (k_step_backward): the vector-Jacobian product that BackpropSnapshot::backprop
+// (dart/neural/BackpropSnapshot.cpp:121-194) obtains from five dense n x n Jacobians is computed
+// here MATRIX-FREE in O(n) per world:
+//   lambda = M^-1 (dt * gv')                           two sweeps reusing the articulated inertias
+//                                                      (same recursion as Skeleton::updateInvMassMatrix, Skeleton.cpp:12573-12660)
+//   (dID/dq)^T lambda, (dID/dv)^T lambda               one reverse-mode sweep of the Newton-Euler
+//                                                      recursion at (q, v, qdd)  — replaces the O(n^2)
+//                                                      column recursions of BodyNode.cpp:2972-3205, 3440-3962
+//   g_tau = lambda
+//   g_v   = gv' + velPos^T gq' - (dID/dv)^T lambda - (D + dt K) lambda
+//   g_q   = posPos^T gq' - (dID/dq)^T lambda - K lambda
+// which is algebraically identical to Appendix A.6 of SURVEY.md (forceVel = dt M^-1, velVel, posVel)
+// because d(qdd) = M^-1 (d tau_eff - dID|_{qdd fixed}).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "model_dev.hpp"
+#include "spatial_dev.hpp"
+
+namespace nbl {
+
+struct Ctx {
+  const DevBody* __restrict__ bodies;
+  const DevDof* __restrict__ dofs;
+  double* __restrict__ ws;
+  int64_t B, b;
+  int nb, n;
+  double dt;
+  V3 g;
+};
+
+DEV double& wsAt(const Ctx& c, int body, int slot) { return c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b]; }
+DEV V6 ldV6(const Ctx& c, int body, int slot) {
+  double a[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) a[k] = wsAt(c, body, slot + k);
+  return fromArr(a);
+}
+DEV void stV6(const Ctx& c, int body, int slot, V6 x) {
+  double a[6];
+  toArr(x, a);
+#pragma unroll
+  for (int k = 0; k < 6; k++) wsAt(c, body, slot + k) = a[k];
+}
+DEV void addV6(const Ctx& c, int body, int slot, V6 x) {
+  double a[6];
+  toArr(x, a);
+#pragma unroll
+  for (int k = 0; k < 6; k++) wsAt(c, body, slot + k) += a[k];
+}
+DEV void zeroN(const Ctx& c, int body, int slot, int cnt) {
+  for (int k = 0; k < cnt; k++) wsAt(c, body, slot + k) = 0.0;
+}
+DEV T12 ldT(const Ctx& c, int body) {
+  T12 T;
+#pragma unroll
+  for (int k = 0; k < 9; k++) T.R.m[k] = wsAt(c, body, WS_T + k);
+  T.p = mk3(wsAt(c, body, WS_T + 9), wsAt(c, body, WS_T + 10), wsAt(c, body, WS_T + 11));
+  return T;
+}
+DEV void stT(const Ctx& c, int body, const T12& T) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) wsAt(c, body, WS_T + k) = T.R.m[k];
+  wsAt(c, body, WS_T + 9) = T.p.x; wsAt(c, body, WS_T + 10) = T.p.y; wsAt(c, body, WS_T + 11) = T.p.z;
+}
+DEV S6 ldS6(const Ctx& c, int body, int slot) {
+  S6 A;
+#pragma unroll
+  for (int k = 0; k < 21; k++) A.a[k] = wsAt(c, body, slot + k);
+  return A;
+}
+DEV void stS6(const Ctx& c, int body, int slot, const S6& A) {
+#pragma unroll
+  for (int k = 0; k < 21; k++) wsAt(c, body, slot + k) = A.a[k];
+}
+DEV void addS6(const Ctx& c, int body, int slot, const S6& A) {
+#pragma unroll
+  for (int k = 0; k < 21; k++) wsAt(c, body, slot + k) += A.a[k];
+}
+
+DEV T12 cT(const double* t) {  // wave-uniform constant -> scalar loads
+  T12 T;
+#pragma unroll
+  for (int k = 0; k < 9; k++) T.R.m[k] = t[k];
+  T.p = mk3(t[9], t[10], t[11]);
+  return T;
+}
+DEV S6 cS6(const double* g) {
+  S6 A;
+#pragma unroll
+  for (int k = 0; k < 21; k++) A.a[k] = g[k];
+  return A;
+}
+DEV V6 cV6(const double* s) { return mk6(mk3(s[0], s[1], s[2]), mk3(s[3], s[4], s[5])); }
+
+// joint twist S*dq in the child frame
+DEV V6 jointTwist(const DevBody& bd, const double* __restrict__ v, int64_t B, int64_t b) {
+  if (bd.jtype == JT_FREE) {
+    V6 x = mk6(mk3(v[(bd.dofOff + 0) * B + b], v[(bd.dofOff + 1) * B + b], v[(bd.dofOff + 2) * B + b]),
+               mk3(v[(bd.dofOff + 3) * B + b], v[(bd.dofOff + 4) * B + b], v[(bd.dofOff + 5) * B + b]));
+    return AdT(cT(bd.Tcj), x);  // S = Ad(T_cj), FreeJoint.cpp:1049-1056
+  }
+  return v[bd.dofOff * B + b] * cV6(bd.S);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The three ABA sweeps.  q, v: [n][B];  tau fetched through tauAt(d).  Leaves T, V, AI, AIS, psi,
+// A in the workspace; joint accelerations are handed to `emit(d, qdd)`.
+// ---------------------------------------------------------------------------------------------
+template <bool BACKWARD, class TauFn, class EmitFn>
+DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
+  const int64_t B = c.B, b = c.b;
+  // ---- sweep 1: kinematics ----
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = c.bodies[i];
+    T12 Q;
+    if (bd.jtype == JT_REVOLUTE) {
+      double qi = q[bd.dofOff * B + b];
+      Q.R = expAngular(mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi));  // RevoluteJoint.cpp:203-211
+      Q.p = mk3(0, 0, 0);
+    } else if (bd.jtype == JT_PRISMATIC) {
+      double qi = q[bd.dofOff * B + b];
+      Q.R = eye3();
+      Q.p = mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi);
+    } else {
+      Q.R = expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b]));  // FreeJoint.cpp:74-81
+      Q.p = mk3(q[(bd.dofOff + 3) * B + b], q[(bd.dofOff + 4) * B + b], q[(bd.dofOff + 5) * B + b]);
+    }
+    T12 T = mulT(mulT(cT(bd.Tpj), Q), cT(bd.TcjInv));
+    V6 V = jointTwist(bd, v, B, b);
+    if (bd.parent >= 0) V = V + AdInvT(T, ldV6(c, bd.parent, WS_V));
+    stT(c, i, T);
+    stV6(c, i, WS_V, V);
+    zeroN(c, i, WS_AI, 21);
+    zeroN(c, i, WS_BACC, 6);
+    if (BACKWARD) zeroN(c, i, WS_BIMP, 6), zeroN(c, i, WS_FACC, 18);  // FACC, ABAR, VBAR are contiguous
+  }
+  // ---- sweep 2: articulated inertias, bias forces, joint-space total force ----
+  for (int i = c.nb - 1; i >= 0; i--) {
+    const DevBody& bd = c.bodies[i];
+    T12 T = ldT(c, i);
+    V6 V = ldV6(c, i, WS_V);
+    S6 G = cS6(bd.G);
+    S6 AI = ldS6(c, i, WS_AI);
+    addTo(AI, G);
+    V6 Sdq = jointTwist(bd, v, B, b);
+    V6 eta = ad(V, Sdq);                                  // GenericJoint.hpp:1803-1824 (dS = 0)
+    V6 Bf = ldV6(c, i, WS_BACC) - dad(V, mul(G, V));      // BodyNode.cpp:2076-2114; gravity rides on the base acceleration
+    V6 AIeta = mul(AI, eta);
+    stS6(c, i, WS_AI, AI);
+    if (bd.jtype != JT_FREE) {
+      const int d = bd.dofOff;
+      const DevDof& df = c.dofs[d];
+      V6 S = cV6(bd.S);
+      V6 AIS = mul(AI, S);
+      double psi = 1.0 / dot(S, AIS);                     // GenericJoint.hpp:2276-2301
+      double qd = q[d * B + b], vd = v[d * B + b];
+      // GenericJoint.hpp:2554-2571: spring uses q - q0 + dt*v, damping explicit
+      double u = tauAt(d) - df.spring * (qd - df.rest + vd * c.dt) - df.damping * vd - dot(S, AIeta + Bf);
+      stV6(c, i, WS_AIS, AIS);
+      wsAt(c, i, WS_PSI) = psi;
+      wsAt(c, i, WS_U) = u;
+      if (bd.parent >= 0) {
+        V6 beta = Bf + AIeta + (psi * u) * AIS;           // GenericJoint.hpp:2395-2421
+        rank1Sub(AI, AIS, psi);                           // PI = AI - AIS psi AIS^T  (GenericJoint.hpp:2168-2185)
+        addS6(c, bd.parent, WS_AI, congruenceToParent(T, AI));
+        addV6(c, bd.parent, WS_BACC, dAdInvT(T, beta));
+      }
+    } else {
+      // free joint as a tree root: projected inertia S^T AI S with S = Ad(T_cj); LDL^T stands in
+      // for math::inverse<SE3Space> (ConfigurationSpace.hpp:48-65)
+      LDL6 f = ldl6(congruenceToParent(cT(bd.TcjInv), AI));
+#pragma unroll
+      for (int k = 0; k < 15; k++) wsAt(c, i, WS_PSI + k) = f.l[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) wsAt(c, i, WS_PSI + 15 + k) = f.d[k];
+      V6 proj = dAdT(cT(bd.Tcj), AIeta + Bf);             // S^T (AI eta + B)
+      double pj[6];
+      toArr(proj, pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int d = bd.dofOff + k;
+        const DevDof& df = c.dofs[d];
+        double qd = q[d * B + b], vd = v[d * B + b];
+        wsAt(c, i, WS_U + k) = tauAt(d) - df.spring * (qd - df.rest + vd * c.dt) - df.damping * vd - pj[k];
+      }
+    }
+  }
+  // ---- sweep 3: accelerations ----
+  const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = c.bodies[i];
+    T12 T = ldT(c, i);
+    V6 V = ldV6(c, i, WS_V);
+    V6 Sdq = jointTwist(bd, v, B, b);
+    V6 eta = ad(V, Sdq);
+    V6 XA = AdInvT(T, bd.parent >= 0 ? ldV6(c, bd.parent, WS_A) : a0);
+    V6 A;
+    if (bd.jtype != JT_FREE) {
+      V6 AIS = ldV6(c, i, WS_AIS);
+      double qdd = wsAt(c, i, WS_PSI) * (wsAt(c, i, WS_U) - dot(AIS, XA));   // GenericJoint.hpp:2656-2676
+      A = XA + eta + qdd * cV6(bd.S);
+      emit(bd.dofOff, qdd);
+    } else {
+      S6 AI = ldS6(c, i, WS_AI);
+      LDL6 f;
+#pragma unroll
+      for (int k = 0; k < 15; k++) f.l[k] = wsAt(c, i, WS_PSI + k);
+#pragma unroll
+      for (int k = 0; k < 6; k++) f.d[k] = wsAt(c, i, WS_PSI + 15 + k);
+      V6 proj = dAdT(cT(bd.Tcj), mul(AI, XA));
+      double r[6], pj[6];
+      toArr(proj, pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) r[k] = wsAt(c, i, WS_U + k) - pj[k];
+      ldl6Solve(f, r);
+#pragma unroll
+      for (int k = 0; k < 6; k++) emit(bd.dofOff + k, r[k]);
+      A = XA + eta + AdT(cT(bd.Tcj), fromArr(r));
+    }
+    stV6(c, i, WS_A, A);
+  }
+}
+
+DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, double* ws, int64_t B, int64_t b) {
+  Ctx c;
+  c.bodies = bodies; c.dofs = dofs; c.ws = ws; c.B = B; c.b = b;
+  c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
+  c.g = mk3(mdl.gravity[0], mdl.gravity[1], mdl.gravity[2]);
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward kernel
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                     const DevDof* __restrict__ dofs, int64_t B,
+                                                     const double* __restrict__ state, const double* __restrict__ action,
+                                                     double* __restrict__ next, double* __restrict__ saved,
+                                                     uint32_t* __restrict__ status, double* __restrict__ ws) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
+  const int n = mdl.n;
+  const double* q = state;
+  const double* v = state + (int64_t)n * B;
+  auto tauAt = [&](int d) -> double {
+    int ai = dofs[d].actionIndex;                       // World::setAction: unmapped control forces are 0 (World.cpp:2061-2086)
+    return ai >= 0 ? action[(int64_t)ai * B + b] : 0.0;
+  };
+  double* nq = next;
+  double* nv = next + (int64_t)n * B;
+  auto emit = [&](int d, double qdd) { nv[(int64_t)d * B + b] = v[(int64_t)d * B + b] + c.dt * qdd; };  // GenericJoint.hpp:1410-1414
+  abaSweeps<false>(c, q, v, tauAt, emit);
+
+  // positions integrate with the PRE-step velocity (World.cpp:307-333, mParallelVelocityAndPositionUpdates)
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = bodies[i];
+    const int o = bd.dofOff;
+    if (bd.jtype == JT_FREE) {
+      V3 r = mk3(q[(o + 0) * B + b], q[(o + 1) * B + b], q[(o + 2) * B + b]);
+      V3 p = mk3(q[(o + 3) * B + b], q[(o + 4) * B + b], q[(o + 5) * B + b]);
+      V3 w = mk3(v[(o + 0) * B + b], v[(o + 1) * B + b], v[(o + 2) * B + b]);
+      V3 vl = mk3(v[(o + 3) * B + b], v[(o + 4) * B + b], v[(o + 5) * B + b]);
+      M3 R = expMapRot(r);
+      M3 E = expMapRot(c.dt * w);                        // FreeJoint.cpp:922-929: Q * convertToTransform(vel*dt)
+      V3 rn = logMap(mul(R, E));
+      V3 pn = p + mul(R, c.dt * vl);
+      nq[(o + 0) * B + b] = rn.x; nq[(o + 1) * B + b] = rn.y; nq[(o + 2) * B + b] = rn.z;
+      nq[(o + 3) * B + b] = pn.x; nq[(o + 4) * B + b] = pn.y; nq[(o + 5) * B + b] = pn.z;
+    } else {
+      nq[(int64_t)o * B + b] = q[(int64_t)o * B + b] + c.dt * v[(int64_t)o * B + b];
+    }
+  }
+  if (saved) {  // what BackpropSnapshot captures: q_t, v_t, tau_t (BackpropSnapshot.cpp:33-118)
+    for (int d = 0; d < n; d++) {
+      saved[(int64_t)d * B + b] = q[(int64_t)d * B + b];
+      saved[(int64_t)(n + d) * B + b] = v[(int64_t)d * B + b];
+      saved[(int64_t)(2 * n + d) * B + b] = tauAt(d);
+    }
+  }
+  if (status) status[b] = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward kernel
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                      const DevDof* __restrict__ dofs, int64_t B,
+                                                      const double* __restrict__ saved, const double* __restrict__ gnext,
+                                                      double* __restrict__ gstate, double* __restrict__ gaction,
+                                                      double* __restrict__ ws) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
+  const int n = mdl.n;
+  const double* q = saved;
+  const double* v = saved + (int64_t)n * B;
+  const double* tau = saved + (int64_t)2 * n * B;
+  const double* gqn = gnext;
+  const double* gvn = gnext + (int64_t)n * B;
+  double* gq = gstate;
+  double* gv = gstate + (int64_t)n * B;
+  auto tauAt = [&](int d) -> double { return tau[(int64_t)d * B + b]; };
+  auto emit = [&](int, double) {};
+  abaSweeps<true>(c, q, v, tauAt, emit);
+
+  // ---- sweep 4 (leaf->root): joint-space impulse dt*gv' pushed up the tree ----
+  for (int i = c.nb - 1; i >= 0; i--) {
+    const DevBody& bd = bodies[i];
+    V6 Bi = ldV6(c, i, WS_BIMP);
+    if (bd.jtype != JT_FREE) {
+      const int d = bd.dofOff;
+      double uimp = c.dt * gvn[(int64_t)d * B + b] - dot(cV6(bd.S), Bi);
+      wsAt(c, i, WS_UIMP) = uimp;
+      if (bd.parent >= 0) {
+        V6 beta = Bi + (wsAt(c, i, WS_PSI) * uimp) * ldV6(c, i, WS_AIS);
+        addV6(c, bd.parent, WS_BIMP, dAdInvT(ldT(c, i), beta));
+      }
+    } else {
+      double pj[6];
+      toArr(dAdT(cT(bd.Tcj), Bi), pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) wsAt(c, i, WS_UIMP + k) = c.dt * gvn[(int64_t)(bd.dofOff + k) * B + b] - pj[k];
+    }
+  }
+  // ---- sweep 5 (root->leaf): lambda = M^-1 (dt gv'), W_i = X W_parent + S lambda_i ----
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = bodies[i];
+    T12 T = ldT(c, i);
+    V6 XW = bd.parent >= 0 ? AdInvT(T, ldV6(c, bd.parent, WS_W)) : zero6();
+    V6 W;
+    if (bd.jtype != JT_FREE) {
+      double lam = wsAt(c, i, WS_PSI) * (wsAt(c, i, WS_UIMP) - dot(ldV6(c, i, WS_AIS), XW));
+      wsAt(c, i, WS_UIMP) = lam;
+      W = XW + lam * cV6(bd.S);
+    } else {
+      S6 AI = ldS6(c, i, WS_AI);
+      LDL6 f;
+#pragma unroll
+      for (int k = 0; k < 15; k++) f.l[k] = wsAt(c, i, WS_PSI + k);
+#pragma unroll
+      for (int k = 0; k < 6; k++) f.d[k] = wsAt(c, i, WS_PSI + 15 + k);
+      double r[6], pj[6];
+      toArr(dAdT(cT(bd.Tcj), mul(AI, XW)), pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) r[k] = wsAt(c, i, WS_UIMP + k) - pj[k];
+      ldl6Solve(f, r);
+#pragma unroll
+      for (int k = 0; k < 6; k++) wsAt(c, i, WS_UIMP + k) = r[k];
+      W = XW + AdT(cT(bd.Tcj), fromArr(r));
+    }
+    stV6(c, i, WS_W, W);
+  }
+  // ---- sweep 6 (leaf->root): reverse-mode Newton-Euler + per-DOF epilogue ----
+  const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
+  for (int i = c.nb - 1; i >= 0; i--) {
+    const DevBody& bd = bodies[i];
+    T12 T = ldT(c, i);
+    V6 V = ldV6(c, i, WS_V), A = ldV6(c, i, WS_A), W = ldV6(c, i, WS_W);
+    S6 G = cS6(bd.G);
+    V6 GV = mul(G, V);
+    V6 F = mul(G, A) - dad(V, GV) + ldV6(c, i, WS_FACC);          // transmitted force at (q, v, qdd)
+    V6 Abar = mul(G, W) + ldV6(c, i, WS_ABAR);
+    V6 Sdq = jointTwist(bd, v, B, b);
+    V6 Vbar = dad(W, GV) - mul(G, ad(V, W)) - dad(Sdq, Abar) + ldV6(c, i, WS_VBAR);
+    V6 tmp = dad(V, Abar) + Vbar;
+    V6 XVp = zero6(), XAp = AdInvT(T, a0), XWp = zero6();
+    if (bd.parent >= 0) {
+      XVp = AdInvT(T, ldV6(c, bd.parent, WS_V));
+      XAp = AdInvT(T, ldV6(c, bd.parent, WS_A));
+      XWp = AdInvT(T, ldV6(c, bd.parent, WS_W));
+      addV6(c, bd.parent, WS_FACC, dAdInvT(T, F));
+      addV6(c, bd.parent, WS_ABAR, dAdInvT(T, Abar));
+      addV6(c, bd.parent, WS_VBAR, dAdInvT(T, Vbar));
+    }
+    V6 xi = dad(XWp, F) + dad(XAp, Abar) + dad(XVp, Vbar);          // adjoint of the joint transform, body frame
+    if (bd.jtype != JT_FREE) {
+      const int d = bd.dofOff;
+      const DevDof& df = dofs[d];
+      V6 S = cV6(bd.S);
+      double lam = wsAt(c, i, WS_UIMP);
+      double vbar = dot(S, tmp), qbar = dot(S, xi);
+      double gqd = gqn[(int64_t)d * B + b], gvd = gvn[(int64_t)d * B + b];
+      double gt = lam;
+      double gvo = gvd + c.dt * gqd - (vbar + df.damping * lam + c.dt * df.spring * lam);
+      double gqo = gqd - (qbar + df.spring * lam);
+      // clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479)
+      double qd = q[(int64_t)d * B + b], vd = v[(int64_t)d * B + b], td = tau[(int64_t)d * B + b];
+      if ((qd == df.posLo && gqo > 0) || (qd == df.posHi && gqo < 0)) gqo = 0;
+      if ((vd == df.velLo && gvo > 0) || (vd == df.velHi && gvo < 0)) gvo = 0;
+      if ((td == df.forceLo && gt > 0) || (td == df.forceHi && gt < 0)) gt = 0;
+      gq[(int64_t)d * B + b] = gqo;
+      gv[(int64_t)d * B + b] = gvo;
+      if (df.actionIndex >= 0) gaction[(int64_t)df.actionIndex * B + b] = gt;
+    } else {
+      const int o = bd.dofOff;
+      double vb[6], yb[6];
+      toArr(dAdT(cT(bd.Tcj), tmp), vb);
+      V6 y = dAdT(cT(bd.Tcj), xi);
+      V3 r = mk3(q[(o + 0) * B + b], q[(o + 1) * B + b], q[(o + 2) * B + b]);
+      V3 w = mk3(v[(o + 0) * B + b], v[(o + 1) * B + b], v[(o + 2) * B + b]);
+      V3 vl = mk3(v[(o + 3) * B + b], v[(o + 4) * B + b], v[(o + 5) * B + b]);
+      M3 R = expMapRot(r);
+      // position-space Jacobian of the free joint: H = Ad(T_cj) blkdiag(expMapJac(r)^T, R^T)  (FreeJoint.cpp:790-823)
+      V3 qbr = mul(expMapJac(r), y.w), qbp = mul(R, y.v);
+      yb[0] = qbr.x; yb[1] = qbr.y; yb[2] = qbr.z; yb[3] = qbp.x; yb[4] = qbp.y; yb[5] = qbp.z;
+      // VJP of q' = [logMap(R E); p + R vl dt]  (exact reverse-mode of FreeJoint.cpp:922-929; the
+      // reference differentiates the same expression by central differences, :950-1007)
+      V3 grn = mk3(gqn[(o + 0) * B + b], gqn[(o + 1) * B + b], gqn[(o + 2) * B + b]);
+      V3 gpn = mk3(gqn[(o + 3) * B + b], gqn[(o + 4) * B + b], gqn[(o + 5) * B + b]);
+      M3 E = expMapRot(c.dt * w);
+      M3 Rn = mul(R, E);
+      M3 Rnb = logMap_vjp(Rn, grn);
+      M3 Rb = mulABt(Rnb, E);                 // dL/dR from R' = R E
+      M3 Eb = mulAtB(R, Rnb);
+      V3 vdt = c.dt * vl;
+      // p' = p + R vdt  ->  dL/dR += gpn vdt^T
+      Rb.m[0] += gpn.x * vdt.x; Rb.m[1] += gpn.x * vdt.y; Rb.m[2] += gpn.x * vdt.z;
+      Rb.m[3] += gpn.y * vdt.x; Rb.m[4] += gpn.y * vdt.y; Rb.m[5] += gpn.y * vdt.z;
+      Rb.m[6] += gpn.z * vdt.x; Rb.m[7] += gpn.z * vdt.y; Rb.m[8] += gpn.z * vdt.z;
+      V3 posr = expMapRot_vjp(r, Rb);
+      V3 velw = c.dt * expMapRot_vjp(c.dt * w, Eb);
+      V3 vell = c.dt * tmul(R, gpn);
+      double pp[6] = {posr.x, posr.y, posr.z, gpn.x, gpn.y, gpn.z};     // posPos^T gq'
+      double vp[6] = {velw.x, velw.y, velw.z, vell.x, vell.y, vell.z};  // velPos^T gq'
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int d = o + k;
+        const DevDof& df = dofs[d];
+        double lam = wsAt(c, i, WS_UIMP + k);
+        double gt = lam;
+        double gvo = gvn[(int64_t)d * B + b] + vp[k] - (vb[k] + df.damping * lam + c.dt * df.spring * lam);
+        double gqo = pp[k] - (yb[k] + df.spring * lam);
+        double qd = q[(int64_t)d * B + b], vd = v[(int64_t)d * B + b], td = tau[(int64_t)d * B + b];
+        if ((qd == df.posLo && gqo > 0) || (qd == df.posHi && gqo < 0)) gqo = 0;
+        if ((vd == df.velLo && gvo > 0) || (vd == df.velHi && gvo < 0)) gvo = 0;
+        if ((td == df.forceLo && gt > 0) || (td == df.forceHi && gt < 0)) gt = 0;
+        gq[(int64_t)d * B + b] = gqo;
+        gv[(int64_t)d * B + b] = gvo;
+        if (df.actionIndex >= 0) gaction[(int64_t)df.actionIndex * B + b] = gt;
+      }
+    }
+  }
+}
+
+// [B][d] <-> [d][B] transposes through LDS (the Python surface stacks the reference's 1-D state
+// vectors world-major; the kernels want DOF-major so a wavefront's loads coalesce).
+__global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ src, double* __restrict__ dst, int64_t rows,
+                                                   int64_t cols) {
+  // src is [rows][cols] row-major; dst is [cols][rows]
+  __shared__ double tile[32][33];
+  int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    int64_t r = r0 + k, cc = c0 + tx;
+    if (r < rows && cc < cols) tile[k][tx] = src[r * cols + cc];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int64_t cc = c0 + k, r = r0 + tx;
+    if (r < rows && cc < cols) dst[cc * rows + r] = tile[tx][k];
+  }
+}
+
+}  // namespace nbl

@@ -1,0 +1,279 @@
+// nimble_amd.hip — host side of the C ABI declared in include/nimble_amd.h.
+//
+// Thin: validates the model description, uploads the constants once, sizes the workspace and
+// launches the kernels of kernels.hip on the caller's stream.  No torch types, no allocation on
+// the hot path, no host<->device synchronisation inside step_forward/step_backward.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nimble_amd.h"
+#include "kernels.hip"
+
+using namespace nbl;
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct TimedLaunch {
+  hipEvent_t start, stop;
+  bool backward;
+};
+}  // namespace
+
+struct nbl_model {
+  int device = 0;
+  DevModel mdl;
+  DevBody* dBodies = nullptr;
+  DevDof* dDofs = nullptr;
+  int nb = 0, n = 0, k = 0, maxContacts = 0;
+  bool timing = false;
+  std::vector<TimedLaunch> pending;
+  double fwdMs = 0, bwdMs = 0;
+  int64_t fwdCount = 0, bwdCount = 0;
+};
+
+extern "C" {
+
+const char* nbl_last_error(void) { return g_err.c_str(); }
+int32_t nbl_version(void) { return (0 << 16) | 1; }
+
+int32_t nbl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** out) {
+  if (!d || !out) return fail(NBL_E_BADARG, "null argument");
+  *out = nullptr;
+  if (d->n_bodies <= 0 || d->n_dofs <= 0) return fail(NBL_E_BADARG, "empty model");
+  int ndev = nbl_device_count();
+  if (ndev <= 0) return fail(NBL_E_NOGPU, "no HIP device visible: the batched timestep has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(NBL_E_BADARG, "device index out of range");
+
+  std::vector<DevBody> hb(d->n_bodies);
+  std::vector<DevDof> hd(d->n_dofs);
+  int off = 0;
+  for (int i = 0; i < d->n_bodies; i++) {
+    DevBody& b = hb[i];
+    std::memset(&b, 0, sizeof(b));
+    b.parent = d->parent[i];
+    b.jtype = d->joint_type[i];
+    if (b.parent < -1 || b.parent >= i) return fail(NBL_E_BADARG, "bodies must be listed parents-before-children");
+    if (b.jtype == NBL_JOINT_WELD)
+      return fail(NBL_E_UNSUPPORTED, "weld joints must be merged into their parent before upload (ModelDescription.merge_welds)");
+    if (b.jtype != NBL_JOINT_REVOLUTE && b.jtype != NBL_JOINT_PRISMATIC && b.jtype != NBL_JOINT_FREE)
+      return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, free)");
+    if (b.jtype == NBL_JOINT_FREE && b.parent != -1)
+      return fail(NBL_E_UNSUPPORTED, "free joints are supported as tree roots only");
+    b.ndof = (b.jtype == NBL_JOINT_FREE) ? 6 : 1;
+    b.dofOff = d->dof_offset[i];
+    if (b.dofOff != off) return fail(NBL_E_BADARG, "dof_offset must be the running sum of joint DOFs");
+    off += b.ndof;
+    for (int k = 0; k < 12; k++) { b.Tpj[k] = d->T_pj[12 * i + k]; b.Tcj[k] = d->T_cj[12 * i + k]; }
+    // inverse of T_cj
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) b.TcjInv[3 * r + c] = b.Tcj[3 * c + r];
+    for (int r = 0; r < 3; r++)
+      b.TcjInv[9 + r] = -(b.Tcj[0 + r] * b.Tcj[9] + b.Tcj[3 + r] * b.Tcj[10] + b.Tcj[6 + r] * b.Tcj[11]);
+    for (int k = 0; k < 3; k++) b.axis[k] = d->axis[3 * i + k];
+    // constant relative Jacobian: AdTAngular / AdTLinear (RevoluteJoint.cpp:141-152, PrismaticJoint.cpp)
+    const double* R = b.Tcj;
+    const double* p = b.Tcj + 9;
+    double Ra[3];
+    for (int r = 0; r < 3; r++) Ra[r] = R[3 * r] * b.axis[0] + R[3 * r + 1] * b.axis[1] + R[3 * r + 2] * b.axis[2];
+    if (b.jtype == NBL_JOINT_REVOLUTE) {
+      b.S[0] = Ra[0]; b.S[1] = Ra[1]; b.S[2] = Ra[2];
+      b.S[3] = p[1] * Ra[2] - p[2] * Ra[1];
+      b.S[4] = p[2] * Ra[0] - p[0] * Ra[2];
+      b.S[5] = p[0] * Ra[1] - p[1] * Ra[0];
+    } else if (b.jtype == NBL_JOINT_PRISMATIC) {
+      b.S[3] = Ra[0]; b.S[4] = Ra[1]; b.S[5] = Ra[2];
+    }
+    // spatial inertia (Inertia.cpp:1368-1383), packed symmetric
+    const double m = d->mass[i];
+    const double* c = d->com + 3 * i;
+    const double* I = d->inertia + 6 * i;
+    double Ic[3][3] = {{I[0], I[3], I[4]}, {I[3], I[1], I[5]}, {I[4], I[5], I[2]}};
+    double C[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
+    double G[6][6];
+    std::memset(G, 0, sizeof(G));
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) {
+        double cct = 0;
+        for (int k = 0; k < 3; k++) cct += C[r][k] * C[cc][k];
+        G[r][cc] = Ic[r][cc] + m * cct;
+        G[r][3 + cc] = m * C[r][cc];
+        G[3 + r][cc] = m * C[cc][r];
+      }
+    G[3][3] = G[4][4] = G[5][5] = m;
+    int idx = 0;
+    for (int r = 0; r < 6; r++)
+      for (int cc = r; cc < 6; cc++) b.G[idx++] = G[r][cc];
+  }
+  if (off != d->n_dofs) return fail(NBL_E_BADARG, "n_dofs does not match the joints");
+  const double inf = INFINITY;
+  for (int j = 0; j < d->n_dofs; j++) {
+    DevDof& f = hd[j];
+    f.damping = d->damping ? d->damping[j] : 0.0;
+    f.spring = d->spring ? d->spring[j] : 0.0;
+    f.rest = d->rest ? d->rest[j] : 0.0;
+    f.posLo = d->pos_lo ? d->pos_lo[j] : -inf; f.posHi = d->pos_hi ? d->pos_hi[j] : inf;
+    f.velLo = d->vel_lo ? d->vel_lo[j] : -inf; f.velHi = d->vel_hi ? d->vel_hi[j] : inf;
+    f.forceLo = d->force_lo ? d->force_lo[j] : -inf; f.forceHi = d->force_hi ? d->force_hi[j] : inf;
+    f.actionIndex = -1;
+    f.pad = 0;
+  }
+  for (int a = 0; a < d->n_action; a++) {
+    int j = d->action_map[a];
+    if (j < 0 || j >= d->n_dofs) return fail(NBL_E_BADARG, "action mapping out of bounds");  // World.cpp:2118-2135
+    if (hd[j].actionIndex != -1) return fail(NBL_E_UNSUPPORTED, "two action entries map to the same DOF");
+    hd[j].actionIndex = a;
+  }
+
+  nbl_model* m = new nbl_model();
+  m->device = device;
+  m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
+  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0;
+  for (int k = 0; k < 3; k++) m->mdl.gravity[k] = d->gravity[k];
+  m->mdl.dt = d->dt;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc((void**)&m->dBodies, sizeof(DevBody) * hb.size());
+  if (e == hipSuccess) e = hipMalloc((void**)&m->dDofs, sizeof(DevDof) * hd.size());
+  if (e == hipSuccess) e = hipMemcpy(m->dBodies, hb.data(), sizeof(DevBody) * hb.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->dDofs, hd.data(), sizeof(DevDof) * hd.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    std::string msg = std::string("model upload failed: ") + hipGetErrorString(e);
+    nbl_model_destroy(m);
+    return fail(NBL_E_HIP, msg);
+  }
+  *out = m;
+  return NBL_OK;
+}
+
+void nbl_model_destroy(nbl_model* m) {
+  if (!m) return;
+  for (auto& t : m->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+  if (m->dBodies) hipFree(m->dBodies);
+  if (m->dDofs) hipFree(m->dDofs);
+  delete m;
+}
+
+int32_t nbl_model_num_dofs(const nbl_model* m) { return m ? m->n : 0; }
+int32_t nbl_model_num_action(const nbl_model* m) { return m ? m->k : 0; }
+int32_t nbl_model_lcp_rows(const nbl_model* m) { return m ? 3 * m->maxContacts : 0; }
+
+size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
+  if (!m || B <= 0) return 0;
+  return (size_t)m->nb * WS_PER_BODY * sizeof(double) * (size_t)B;
+}
+size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
+  if (!m || B <= 0) return 0;
+  return (size_t)3 * m->n * sizeof(double) * (size_t)B;
+}
+
+static void beginTiming(nbl_model* m, hipStream_t s, bool backward) {
+  if (!m->timing) return;
+  TimedLaunch t;
+  hipEventCreate(&t.start);
+  hipEventCreate(&t.stop);
+  t.backward = backward;
+  hipEventRecord(t.start, s);
+  m->pending.push_back(t);
+}
+static void endTiming(nbl_model* m, hipStream_t s) {
+  if (!m->timing) return;
+  hipEventRecord(m->pending.back().stop, s);
+}
+
+int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const double* action, const double* lcp_cache_in,
+                         double* next_state, double* lcp_cache_out, void* saved, uint32_t* status, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  (void)lcp_cache_in; (void)lcp_cache_out;
+  if (!m || !state || !action || !next_state || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
+  if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((B + 63) / 64)), block(64);
+  beginTiming(m, s, false);
+  hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
+                     (double*)saved, status, (double*)workspace);
+  endTiming(m, s);
+  HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+
+int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const double* grad_next_state, double* grad_state,
+                          double* grad_action, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !saved || !grad_next_state || !grad_state || !grad_action || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
+  if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((B + 63) / 64)), block(64);
+  beginTiming(m, s, true);
+  hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+                     grad_next_state, grad_state, grad_action, (double*)workspace);
+  endTiming(m, s);
+  HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+
+int32_t nbl_transpose_to_soa(const double* src_bd, double* dst_db, int64_t B, int32_t d, void* stream) {
+  if (!src_bd || !dst_db || B <= 0 || d <= 0) return fail(NBL_E_BADARG, "bad transpose argument");
+  dim3 grid((unsigned)((d + 31) / 32), (unsigned)((B + 31) / 32)), block(256);
+  hipLaunchKernelGGL(k_transpose, grid, block, 0, (hipStream_t)stream, src_bd, dst_db, B, (int64_t)d);
+  HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, int32_t d, void* stream) {
+  if (!src_db || !dst_bd || B <= 0 || d <= 0) return fail(NBL_E_BADARG, "bad transpose argument");
+  dim3 grid((unsigned)((B + 31) / 32), (unsigned)((d + 31) / 32)), block(256);
+  hipLaunchKernelGGL(k_transpose, grid, block, 0, (hipStream_t)stream, src_db, dst_bd, (int64_t)d, B);
+  HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+
+int32_t nbl_set_timing(nbl_model* m, int32_t enabled) {
+  if (!m) return fail(NBL_E_BADARG, "null model");
+  m->timing = enabled != 0;
+  if (!enabled) {
+    for (auto& t : m->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    m->pending.clear();
+    m->fwdMs = m->bwdMs = 0;
+    m->fwdCount = m->bwdCount = 0;
+  }
+  return NBL_OK;
+}
+int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, double* bwd_ms_sum, int64_t* bwd_count) {
+  if (!m) return fail(NBL_E_BADARG, "null model");
+  for (auto& t : m->pending) {
+    HIP_TRY(hipEventSynchronize(t.stop));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+    if (t.backward) { m->bwdMs += ms; m->bwdCount++; } else { m->fwdMs += ms; m->fwdCount++; }
+    hipEventDestroy(t.start);
+    hipEventDestroy(t.stop);
+  }
+  m->pending.clear();
+  if (fwd_ms_sum) *fwd_ms_sum = m->fwdMs;
+  if (fwd_count) *fwd_count = m->fwdCount;
+  if (bwd_ms_sum) *bwd_ms_sum = m->bwdMs;
+  if (bwd_count) *bwd_count = m->bwdCount;
+  return NBL_OK;
+}
+
+}  // extern "C"

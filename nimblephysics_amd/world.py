@@ -1,0 +1,181 @@
+"""`World`: the host-side mirror of the slice of `nimble.simulation.World` that `timestep` touches.
+
+Reference API mirrored (python/_nimblephysics/simulation_and_neural/World.cpp:401, 502-523;
+dart/simulation/World.cpp:2016-2135): getNumDofs, getStateSize, getActionSize, getActionSpace,
+setActionSpace, setState, getState, setAction, getAction, getTimeStep, getGravity, step.
+
+Differences, all forced by batching:
+  * one World object holds B worlds that share a model; state/action carry a leading batch
+    dimension [B, 2n] / [B, k] (a 1-D tensor behaves as B = 1);
+  * tensors live on the GPU; the library works in DOF-major [d][B] layout internally;
+  * size mismatches raise instead of "print to std::cerr and ignore the call" (World.cpp:2027-2033).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _abi
+from ._lib import NimbleAmdError, check, lib
+from .model import ModelDescription
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class World:
+    def __init__(self, model: ModelDescription, device: Optional[torch.device | int | str] = None):
+        if not torch.cuda.is_available():
+            raise NimbleAmdError("no HIP device visible: nimblephysics_amd has no CPU path (the CPU restatement under "
+                                 "oracle/ is test infrastructure, not a fallback)")
+        self.description = model
+        self.model = model.merge_welds() if model.has_welds() else model
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise NimbleAmdError("World must live on a GPU device")
+        self._L = lib()
+        desc, self._keep = self.model.to_desc()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self._L.nbl_model_create(C.byref(desc), self.device.index or 0, C.byref(h)), "nbl_model_create")
+        self._h = h
+        self.n = self._L.nbl_model_num_dofs(h)
+        self.k = self._L.nbl_model_num_action(h)
+        self.m = self._L.nbl_model_lcp_rows(h)
+        self._ws = None
+        self._ws_B = 0
+        self._state = None   # [2n][B]
+        self._action = None  # [k][B]
+        self.lcp_cache = None  # [m][B] hidden warm start (BoxedLcpConstraintSolver::mX)
+        self.last_status = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.nbl_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- sizes / action space (World.cpp:2016-2135) -------------------------------------------
+    def getNumDofs(self) -> int:
+        return self.n
+
+    def getStateSize(self) -> int:
+        return 2 * self.n
+
+    def getActionSize(self) -> int:
+        return self.k
+
+    def getActionSpace(self) -> List[int]:
+        return self.model.action_map
+
+    def setActionSpace(self, mapping: Sequence[int]):
+        self.model.set_action_space(mapping)
+        self.description.set_action_space(mapping)
+        self.__init__(self.description, self.device)  # re-upload constants
+
+    def removeDofFromActionSpace(self, index: int):
+        self.setActionSpace([a for a in self.getActionSpace() if a != index])
+
+    def getTimeStep(self) -> float:
+        return self.model.dt
+
+    def getGravity(self):
+        return self.model.gravity
+
+    # ---- workspace ------------------------------------------------------------------------------
+    def _workspace(self, B: int) -> torch.Tensor:
+        need = self._L.nbl_workspace_bytes(self._h, B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- layout helpers: [B, d] (reference: stack of 1-D vectors) <-> [d][B] ----------------------
+    def to_soa(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.contiguous()
+        B, d = x.shape
+        out = torch.empty((d, B), dtype=torch.float64, device=self.device)
+        check(self._L.nbl_transpose_to_soa(_ptr(x), _ptr(out), B, d, self._stream()), "nbl_transpose_to_soa")
+        return out
+
+    def from_soa(self, x: torch.Tensor) -> torch.Tensor:
+        d, B = x.shape
+        out = torch.empty((B, d), dtype=torch.float64, device=self.device)
+        check(self._L.nbl_transpose_from_soa(_ptr(x), _ptr(out), B, d, self._stream()), "nbl_transpose_from_soa")
+        return out
+
+    def _prep(self, x: torch.Tensor, width: int, what: str) -> torch.Tensor:
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        if x.dim() != 2 or x.shape[1] != width:
+            raise ValueError(f"World.{what}() called with a tensor of incorrect size {tuple(x.shape)}; expected [B, {width}]")
+        return x.detach().to(device=self.device, dtype=torch.float64)
+
+    # ---- state / action API ---------------------------------------------------------------------
+    def setState(self, state: torch.Tensor):
+        self._state = self.to_soa(self._prep(state, 2 * self.n, "setState"))
+
+    def getState(self) -> torch.Tensor:
+        return self.from_soa(self._state)
+
+    def setAction(self, action: torch.Tensor):
+        self._action = self.to_soa(self._prep(action, self.k, "setAction"))
+
+    def getAction(self) -> torch.Tensor:
+        return self.from_soa(self._action)
+
+    def reset_lcp_cache(self):
+        self.lcp_cache = None
+
+    # ---- raw batched step on DOF-major device tensors ---------------------------------------------
+    def step_soa(self, state: torch.Tensor, action: torch.Tensor, want_saved: bool = True):
+        """state [2n][B], action [k][B] (float64, this device, contiguous) -> (next [2n][B], saved, status[B])."""
+        B = state.shape[1]
+        nxt = torch.empty_like(state)
+        saved = None
+        if want_saved:
+            saved = torch.empty(self._L.nbl_saved_bytes(self._h, B), dtype=torch.uint8, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        ws = self._workspace(B)
+        cache_in = self.lcp_cache if (self.lcp_cache is not None and self.lcp_cache.shape == (self.m, B)) else None
+        cache_out = torch.empty((self.m, B), dtype=torch.float64, device=self.device) if self.m > 0 else None
+        check(self._L.nbl_step_forward(self._h, B, _ptr(state), _ptr(action), _ptr(cache_in), _ptr(nxt), _ptr(cache_out),
+                                       _ptr(saved), _ptr(status), _ptr(ws), ws.numel(), self._stream()), "nbl_step_forward")
+        if cache_out is not None:
+            self.lcp_cache = cache_out
+        self.last_status = status
+        return nxt, saved, status
+
+    def backward_soa(self, saved: torch.Tensor, grad_next: torch.Tensor):
+        """grad_next [2n][B] -> (grad_state [2n][B], grad_action [k][B])."""
+        B = grad_next.shape[1]
+        gs = torch.empty_like(grad_next)
+        ga = torch.empty((self.k, B), dtype=torch.float64, device=self.device)
+        ws = self._workspace(B)
+        check(self._L.nbl_step_backward(self._h, B, _ptr(saved), _ptr(grad_next), _ptr(gs), _ptr(ga), _ptr(ws), ws.numel(),
+                                        self._stream()), "nbl_step_backward")
+        return gs, ga
+
+    def step(self):
+        """World::step on the stored state/action (no gradient bookkeeping kept)."""
+        nxt, _, _ = self.step_soa(self._state, self._action, want_saved=False)
+        self._state = nxt
+
+    # ---- kernel timing (HIP events on the launch stream) ------------------------------------------
+    def set_timing(self, enabled: bool):
+        check(self._L.nbl_set_timing(self._h, 1 if enabled else 0), "nbl_set_timing")
+
+    def get_timing(self):
+        f, b = C.c_double(0), C.c_double(0)
+        fc, bc = C.c_int64(0), C.c_int64(0)
+        check(self._L.nbl_get_timing(self._h, C.byref(f), C.byref(fc), C.byref(b), C.byref(bc)), "nbl_get_timing")
+        return {"fwd_ms_sum": f.value, "fwd_count": fc.value, "bwd_ms_sum": b.value, "bwd_count": bc.value}
