@@ -1,0 +1,233 @@
+// collision_dev.hpp — per-lane box-box narrow phase (device).
+//
+// Same algorithm as the reference's DART detector for box pairs (dart/collision/dart/DARTCollide.cpp:
+// 764-1450 dBoxBox: 15-axis SAT with the 1.05 fudge factor favouring face contacts, incident-face
+// clipping against the reference face :512-575, up to 8 points kept, per-point type VERTEX_FACE /
+// FACE_VERTEX / EDGE_EDGE with edge annotations :1280-1381, pure edge-edge case :1014-1054), written
+// for one world per lane: every lane runs its own branch pattern, the clip polygons live in small
+// private arrays, results are appended to the lane's contact list in HBM.
+#pragma once
+#include "spatial_dev.hpp"
+
+namespace nbl {
+
+constexpr int CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3;
+
+struct DevContact {
+  V3 point, normal;
+  double depth;
+  int type;
+  V3 edgeAClosest, edgeAFixed, edgeADir, edgeBClosest, edgeBFixed, edgeBDir;
+};
+
+DEV V3 colOf(const M3& R, int j) { return mk3(R.m[j], R.m[3 + j], R.m[6 + j]); }
+DEV double norm3(V3 a) { return sqrt(dot(a, a)); }
+DEV V3 unit3(V3 a) { double n = norm3(a); return (1.0 / n) * a; }
+DEV void set3(V3& a, int i, double v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
+
+// clip the quad p against |x| <= h0, |y| <= h1; returns the number of points written to ret (<= 8)
+DEV int intersectRectQuad(double h0, double h1, const double* p, double* ret) {
+  double bufA[16], bufB[16];
+  for (int i = 0; i < 8; i++) bufA[i] = p[i];
+  double* q = bufA;
+  double* r = bufB;
+  int nq = 4, nr = 0;
+  bool done = false;
+  for (int dir = 0; dir <= 1 && !done; dir++) {
+    const double h = dir == 0 ? h0 : h1;
+    for (int sign = -1; sign <= 1 && !done; sign += 2) {
+      nr = 0;
+      for (int i = 0; i < nq; i++) {
+        const double* pq = q + 2 * i;
+        const double* nx = (i + 1 < nq) ? pq + 2 : q;
+        bool in0 = sign * pq[dir] < h, in1 = sign * nx[dir] < h;
+        if (in0) {
+          r[2 * nr] = pq[0]; r[2 * nr + 1] = pq[1];
+          nr++;
+          if (nr & 8) { done = true; break; }
+        }
+        if (in0 != in1) {
+          r[2 * nr + (1 - dir)] = pq[1 - dir] + (nx[1 - dir] - pq[1 - dir]) / (nx[dir] - pq[dir]) * (sign * h - pq[dir]);
+          r[2 * nr + dir] = sign * h;
+          nr++;
+          if (nr & 8) { done = true; break; }
+        }
+      }
+      double* t = q; q = r; r = t;
+      nq = nr;
+    }
+  }
+  for (int i = 0; i < nr * 2; i++) ret[i] = q[i];
+  return nr;
+}
+
+// Returns the number of contacts written to out[0..7].
+DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, DevContact* out) {
+  const double fudge = 1.05;
+  const M3& R1 = T1.R;
+  const M3& R2 = T2.R;
+  V3 p = T2.p - T1.p;
+  V3 pp = tmul(R1, p);
+  M3 R = mulAtB(R1, R2), Q;
+#pragma unroll
+  for (int i = 0; i < 9; i++) Q.m[i] = fabs(R.m[i]);
+  double Aa[3] = {A.x, A.y, A.z}, Bb[3] = {Bh.x, Bh.y, Bh.z}, ppa[3] = {pp.x, pp.y, pp.z};
+  double s = -1e12;
+  int code = 0, normalBox = 0, normalCol = 0;
+  bool invert = false;
+  V3 normalC = mk3(0, 0, 0);
+  for (int k = 0; k < 3; k++) {
+    double e1 = ppa[k], e2 = Aa[k] + Bb[0] * Q.m[3 * k] + Bb[1] * Q.m[3 * k + 1] + Bb[2] * Q.m[3 * k + 2];
+    double s2 = fabs(e1) - e2;
+    if (s2 > s) { s = s2; normalBox = 1; normalCol = k; invert = e1 < 0; code = k + 1; }
+  }
+  for (int k = 0; k < 3; k++) {
+    double e1 = dot(colOf(R2, k), p), e2 = Aa[0] * Q.m[k] + Aa[1] * Q.m[3 + k] + Aa[2] * Q.m[6 + k] + Bb[k];
+    double s2 = fabs(e1) - e2;
+    if (s2 > s) { s = s2; normalBox = 2; normalCol = k; invert = e1 < 0; code = k + 4; }
+  }
+  for (int i = 0; i < 3; i++) {
+    const int i1 = (i == 0) ? 1 : 0, i2 = (i == 2) ? 1 : 2;
+    for (int j = 0; j < 3; j++) {
+      const int j1 = (j == 0) ? 1 : 0, j2 = (j == 2) ? 1 : 2;
+      V3 n;
+      double e1;
+      const double r0 = R.m[j], r1 = R.m[3 + j], r2 = R.m[6 + j];
+      if (i == 0) { n = mk3(0, -r2, r1); e1 = ppa[2] * r1 - ppa[1] * r2; }
+      else if (i == 1) { n = mk3(r2, 0, -r0); e1 = ppa[0] * r2 - ppa[2] * r0; }
+      else { n = mk3(-r1, r0, 0); e1 = ppa[1] * r0 - ppa[0] * r1; }
+      double e2 = Aa[i1] * Q.m[3 * i2 + j] + Aa[i2] * Q.m[3 * i1 + j] + Bb[j1] * Q.m[3 * i + j2] + Bb[j2] * Q.m[3 * i + j1];
+      double s2 = fabs(e1) - e2;
+      double l = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+      if (l > 0) {
+        s2 /= l;
+        if (s2 * fudge > s) { s = s2; normalBox = 0; normalC = (1.0 / l) * n; invert = e1 < 0; code = 7 + 3 * i + j; }
+      }
+    }
+  }
+  if (!code) return 0;
+  if (s > 0.0) return 0;
+  V3 normal;
+  if (normalBox == 1) normal = colOf(R1, normalCol);
+  else if (normalBox == 2) normal = colOf(R2, normalCol);
+  else normal = unit3(mul(R1, normalC));
+  if (invert) normal = -normal;
+
+  if (code > 6) {
+    V3 pa = T1.p;
+    for (int j = 0; j < 3; j++) {
+      double sign = (dot(normal, colOf(R1, j)) > -1e-10) ? 1.0 : -1.0;
+      pa = pa + (sign * Aa[j]) * colOf(R1, j);
+    }
+    V3 pb = T2.p;
+    for (int j = 0; j < 3; j++) {
+      double sign = (dot(normal, colOf(R2, j)) > -1e-3) ? -1.0 : 1.0;
+      pb = pb + (sign * Bb[j]) * colOf(R2, j);
+    }
+    V3 ua = colOf(R1, (code - 7) / 3), ub = colOf(R2, (code - 7) % 3);
+    V3 dp = pb - pa;
+    double uaub = dot(ua, ub), q1 = dot(ua, dp), q2 = -dot(ub, dp), d = 1 - uaub * uaub, alpha = 0, beta = 0;
+    if (d > 0) { d = 1.0 / d; alpha = (q1 + uaub * q2) * d; beta = (uaub * q1 + q2) * d; }
+    V3 fixedA = pa, fixedB = pb;
+    pa = pa + alpha * ua;
+    pb = pb + beta * ub;
+    double pen = -s;
+    if (pen > clippingDepth) return 0;
+    DevContact& c = out[0];
+    c.point = 0.5 * (pa + pb);
+    c.normal = -normal;
+    c.depth = pen;
+    c.type = CT_EDGE_EDGE;
+    c.edgeAClosest = pa; c.edgeAFixed = fixedA; c.edgeADir = unit3(ua);
+    c.edgeBClosest = pb; c.edgeBFixed = fixedB; c.edgeBDir = unit3(ub);
+    return 1;
+  }
+
+  const bool flip = code > 3;
+  const M3& Ra = flip ? R2 : R1;
+  const M3& Rb = flip ? R1 : R2;
+  V3 pa = flip ? T2.p : T1.p, pb = flip ? T1.p : T2.p;
+  const double* Sa = flip ? Bb : Aa;
+  const double* Sb = flip ? Aa : Bb;
+  V3 normal2 = flip ? -normal : normal;
+  V3 nr = tmul(Rb, normal2);
+  double anr0 = fabs(nr.x), anr1 = fabs(nr.y), anr2 = fabs(nr.z);
+  int lanr, a1, a2;
+  if (anr1 > anr0) {
+    if (anr1 > anr2) { a1 = 0; lanr = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; }
+  } else {
+    if (anr0 > anr2) { lanr = 0; a1 = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; }
+  }
+  V3 center;
+  if (get(nr, lanr) < 0) center = pb - pa + Sb[lanr] * colOf(Rb, lanr);
+  else center = pb - pa - Sb[lanr] * colOf(Rb, lanr);
+  const int codeN = flip ? code - 4 : code - 1;
+  int code1, code2;
+  if (codeN == 0) { code1 = 1; code2 = 2; } else if (codeN == 1) { code1 = 0; code2 = 2; } else { code1 = 0; code2 = 1; }
+  double quad[8];
+  double c1 = dot(center, colOf(Ra, code1)), c2 = dot(center, colOf(Ra, code2));
+  double m11 = dot(colOf(Ra, code1), colOf(Rb, a1)), m12 = dot(colOf(Ra, code1), colOf(Rb, a2));
+  double m21 = dot(colOf(Ra, code2), colOf(Rb, a1)), m22 = dot(colOf(Ra, code2), colOf(Rb, a2));
+  {
+    double k1 = m11 * Sb[a1], k2 = m21 * Sb[a1], k3 = m12 * Sb[a2], k4 = m22 * Sb[a2];
+    quad[0] = c1 - k1 - k3; quad[1] = c2 - k2 - k4;
+    quad[2] = c1 - k1 + k3; quad[3] = c2 - k2 + k4;
+    quad[4] = c1 + k1 + k3; quad[5] = c2 + k2 + k4;
+    quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
+  }
+  const double rect0 = Sa[code1], rect1 = Sa[code2];
+  double ret[16];
+  int n = intersectRectQuad(rect0, rect1, quad, ret);
+  if (n < 1) return 0;
+  double det1 = 1.0 / (m11 * m22 - m12 * m21);
+  m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
+  V3 otherNormal = colOf(Rb, lanr);
+  if (dot(otherNormal, normal) < 0) otherNormal = -otherNormal;
+  V3 ortho1 = colOf(Rb, a1), ortho2 = colOf(Rb, a2);
+  V3 faceCenter = pb - Sb[lanr] * otherNormal;
+  int cnum = 0;
+  for (int j = 0; j < n; j++) {
+    double k1 = m22 * (ret[j * 2] - c1) - m12 * (ret[j * 2 + 1] - c2);
+    double k2 = -m21 * (ret[j * 2] - c1) + m11 * (ret[j * 2 + 1] - c2);
+    V3 pt = center + k1 * colOf(Rb, a1) + k2 * colOf(Rb, a2);
+    double dep = Sa[codeN] - dot(normal2, pt);
+    if (!(dep >= 0)) continue;
+    const double x = ret[j * 2], y = ret[j * 2 + 1];
+    DevContact& c = out[cnum];
+    c.point = pt + pa;
+    c.normal = -normal;
+    c.depth = dep;
+    c.edgeAClosest = c.edgeAFixed = c.edgeADir = c.edgeBClosest = c.edgeBFixed = c.edgeBDir = mk3(0, 0, 0);
+    const bool onX = fabs(x) == rect0, onY = fabs(y) == rect1;
+    if (onX && onY) {
+      if (flip) { c.type = CT_FACE_VERTEX; c.point = c.point + c.depth * c.normal; }
+      else { c.type = CT_VERTEX_FACE; c.point = c.point - c.depth * c.normal; }
+    } else if (!onX && !onY) {
+      c.type = flip ? CT_VERTEX_FACE : CT_FACE_VERTEX;
+    } else {
+      c.type = CT_EDGE_EDGE;
+      double faceX = x > 0 ? rect0 : -rect0, faceY = y > 0 ? rect1 : -rect1;
+      V3 faceCenterA = pa + Sa[codeN] * normal;
+      c.edgeAFixed = faceCenterA + faceX * colOf(Ra, code1) + faceY * colOf(Ra, code2);
+      c.edgeADir = unit3(c.point - c.edgeAFixed);
+      c.edgeAClosest = c.point;
+      double incX = dot(ortho1, c.point) - dot(ortho1, pb), incY = dot(ortho2, c.point) - dot(ortho2, pb);
+      double signX = incX == 0 ? 1.0 : (incX / fabs(incX)), signY = incY == 0 ? 1.0 : (incY / fabs(incY));
+      V3 nearestB = (signX * Sb[a1]) * ortho1 + (signY * Sb[a2]) * ortho2 + faceCenter;
+      double distX = fabs(fabs(incX) - Sb[a1]), distY = fabs(fabs(incY) - Sb[a2]);
+      V3 otherB;
+      if (distX < distY) otherB = (signX * Sb[a1]) * ortho1 + (-1 * signY * Sb[a2]) * ortho2 + faceCenter;
+      else otherB = (-1 * signX * Sb[a1]) * ortho1 + (signY * Sb[a2]) * ortho2 + faceCenter;
+      c.edgeBDir = unit3(nearestB - otherB);
+      c.edgeBFixed = nearestB;
+      if (flip) {
+        V3 t = c.edgeADir; c.edgeADir = c.edgeBDir; c.edgeBDir = t;
+        t = c.edgeAFixed; c.edgeAFixed = c.edgeBFixed; c.edgeBFixed = t;
+      }
+    }
+    cnum++;
+  }
+  return cnum;
+}
+
+}  // namespace nbl

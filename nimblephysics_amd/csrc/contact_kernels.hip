@@ -1,0 +1,370 @@
+// contact_kernels.hip — contact stage of the batched step (forward), one world per lane.
+//
+//   k_contact_detect   collision detection at q_t + depth filter      ConstraintSolver.cpp:563-613, DARTCollide.cpp:764-1450
+//   k_contact_rows     per-row body wrenches, b, unit-impulse tests -> A and the massed impulse tests M^-1 J^T
+//                                                                     ContactConstraint.cpp:66-230, 361-514, 517-607; BoxedLcpConstraintSolver.cpp:190-349
+//   k_contact_solve    stage 0 of the LCP cascade: classify the warm start / guess, least-squares
+//                      standardisation on the active set, validity check; v' = v_pre + M^-1 J^T x
+//                                                                     BoxedLcpConstraintSolver.cpp:434-457, CGGM.cpp:218-339, 482-872, LCPUtils.cpp:12-140
+// Lanes whose warm start is not a valid LCP solution need the pivoting / PGS stages
+// (BoxedLcpConstraintSolver.cpp:461-677); they are flagged NBL_ST_LCP_FAILED for now and get zero
+// impulses, exactly what the reference does when every stage fails (:679-687).
+#include "collision_dev.hpp"
+#include "lcp_dev.hpp"
+
+namespace nbl {
+
+DEV double& svAt(double* saved, int row, int64_t B, int64_t b) { return saved[(int64_t)row * B + b]; }
+
+// ContactConstraint::getTangentBasisMatrixODE (ContactConstraint.cpp:734-795)
+DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
+  const double EPS2 = 1e-12;
+  V3 t = cross(mk3(0, 0, 1), n);
+  if (dot(t, t) < EPS2) {
+    t = cross(mk3(1, 0, 0), n);
+    if (dot(t, t) < EPS2) {
+      t = cross(mk3(0, 1, 0), n);
+      if (dot(t, t) < EPS2) t = cross(mk3(0, 0, 1), n);
+    }
+  }
+  t1 = unit3(t);
+  t2 = cross(n, t1);
+}
+
+__global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                       double* __restrict__ saved, SavedLayout lay,
+                                                       uint32_t* __restrict__ status, double* __restrict__ ws) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  Ctx c;
+  c.ws = ws; c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n;
+  int nC = 0;
+  bool overflow = false;
+  for (int pi = 0; pi < cm->nPairs; pi++) {
+    const DevBox& ba = cm->boxes[cm->pairA[pi]];
+    const DevBox& bb = cm->boxes[cm->pairB[pi]];
+    T12 Ta = cT(ba.T), Tb = cT(bb.T);
+    if (ba.body >= 0) Ta = mulT(ldTAt(c, ba.body, WS_TW), Ta);
+    if (bb.body >= 0) Tb = mulT(ldTAt(c, bb.body, WS_TW), Tb);
+    DevContact out[8];
+    int cnt = boxBox(Ta, mk3(ba.half[0], ba.half[1], ba.half[2]), Tb, mk3(bb.half[0], bb.half[1], bb.half[2]),
+                     cm->clippingDepth, out);
+    for (int k = 0; k < cnt; k++) {
+      const DevContact& ct = out[k];
+      // postProcess: skip points within 3e-12 of an accepted contact (DARTCollisionDetector.cpp:360-400)
+      bool close = false;
+      for (int e = 0; e < nC; e++) {
+        const int r0 = lay.contacts + e * CR_SIZE;
+        V3 d = ct.point - mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
+        if (norm3(d) < 3.0e-12) { close = true; break; }
+      }
+      if (close) continue;
+      if (dot(ct.normal, ct.normal) < 1e-12) continue;
+      if (ct.depth < 0.0 || ct.depth > cm->clippingDepth) continue;
+      if (nC >= cm->maxContacts) { overflow = true; continue; }
+      const int r0 = lay.contacts + nC * CR_SIZE;
+      auto st3 = [&](int off, V3 x) { svAt(saved, r0 + off, B, b) = x.x; svAt(saved, r0 + off + 1, B, b) = x.y; svAt(saved, r0 + off + 2, B, b) = x.z; };
+      st3(CR_POINT, ct.point); st3(CR_NORMAL, ct.normal);
+      svAt(saved, r0 + CR_DEPTH, B, b) = ct.depth;
+      svAt(saved, r0 + CR_TYPE, B, b) = (double)ct.type;
+      svAt(saved, r0 + CR_BOXA, B, b) = (double)cm->pairA[pi];
+      svAt(saved, r0 + CR_BOXB, B, b) = (double)cm->pairB[pi];
+      st3(CR_EA_FIXED, ct.edgeAFixed); st3(CR_EA_DIR, ct.edgeADir); st3(CR_EB_FIXED, ct.edgeBFixed); st3(CR_EB_DIR, ct.edgeBDir);
+      nC++;
+    }
+  }
+  // NOTE: the duplicate filter above only sees contacts that were kept; the reference compares against every
+  // contact of the total result including ones later dropped by the depth filter.  Those can only coincide
+  // with a kept point if they are the same point, which the depth filter treats identically.
+  svAt(saved, lay.nc, B, b) = (double)nC;
+  uint32_t st = 0;
+  if (nC > 0) st |= 0x1u;
+  if (overflow) st |= 0x80u;
+  if (status) status[b] = st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows: wrenches, b, impulse tests
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                     const DevContactModel* __restrict__ cm, int64_t B,
+                                                     double* __restrict__ saved, SavedLayout lay, double* __restrict__ ws,
+                                                     double* __restrict__ lws) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  Ctx c;
+  c.bodies = bodies; c.ws = ws; c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
+  LaneMem L;
+  L.base = lws; L.B = B; L.b = b;
+  const int n = mdl.n;
+  const int nC = (int)svAt(saved, lay.nc, B, b);
+  if (!__any(nC > 0)) return;
+  const double* vpre = saved + (int64_t)lay.vpre * B;
+
+  // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_A
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = bodies[i];
+    V6 V = jointTwist(bd, vpre, B, b);
+    if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_A));
+    stV6(c, i, WS_A, V);
+  }
+  // per-row body-frame wrenches (mSpatialNormalA/B) and b = -J^T V
+  int bodyA[MAX_CONTACTS], bodyB[MAX_CONTACTS];
+  for (int ci = 0; ci < MAX_CONTACTS; ci++) {
+    bodyA[ci] = -1; bodyB[ci] = -1;
+    if (ci >= nC) continue;
+    const int r0 = lay.contacts + ci * CR_SIZE;
+    V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
+    V3 nrm = mk3(svAt(saved, r0 + CR_NORMAL, B, b), svAt(saved, r0 + CR_NORMAL + 1, B, b), svAt(saved, r0 + CR_NORMAL + 2, B, b));
+    const int boxA = (int)svAt(saved, r0 + CR_BOXA, B, b), boxB = (int)svAt(saved, r0 + CR_BOXB, B, b);
+    const int bA = cm->boxes[boxA].body, bB = cm->boxes[boxB].body;
+    bodyA[ci] = bA; bodyB[ci] = bB;
+    V3 t1, t2;
+    tangentBasis(nrm, t1, t2);
+    V3 d[3] = {nrm, t1, t2};
+    for (int k = 0; k < 3; k++) {
+      const int row = 3 * ci + k;
+      V6 F = mk6(cross(p, d[k]), d[k]);  // world wrench of a unit impulse along d at p
+      double rel = 0;
+      V6 ja = zero6(), jb = zero6();
+      if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_A)); }
+      if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_A)); }
+      double a6[6];
+      toArr(ja, a6);
+      for (int e = 0; e < 6; e++) L.at(LW_JA + row * 6 + e) = a6[e];
+      toArr(jb, a6);
+      for (int e = 0; e < 6; e++) L.at(LW_JB + row * 6 + e) = a6[e];
+      svAt(saved, lay.b + row, B, b) = rel;   // getRelVelocity; restitution 0, penetration correction off
+      // constraint forces in joint space (DCC::getConstraintForces): A_c[i] = sigma_i s_i . F
+      const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
+      for (int i = 0; i < c.nb; i++) {
+        const DevBody& bd = bodies[i];
+        const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
+        const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
+        if (bd.jtype != JT_FREE) {
+          double val = 0;
+          if (mult != 0.0) val = mult * dot(cV6(bd.S), dAdT(ldTAt(c, i, WS_TW), F));
+          svAt(saved, lay.aall + bd.dofOff * MAX_ROWS + row, B, b) = val;
+        } else {
+          double v6[6] = {0, 0, 0, 0, 0, 0};
+          if (mult != 0.0) toArr(dAdT(cT(bd.Tcj), dAdT(ldTAt(c, i, WS_TW), F)), v6);
+          for (int e = 0; e < 6; e++) svAt(saved, lay.aall + (bd.dofOff + e) * MAX_ROWS + row, B, b) = mult * v6[e];
+        }
+      }
+    }
+  }
+  // ---- unit-impulse tests, three rows (one contact) per pair of sweeps ----
+  for (int ci = 0; ci < MAX_CONTACTS; ci++) {
+    if (!__any(ci < nC)) break;
+    const bool active = ci < nC;
+    const int bA = active ? bodyA[ci] : -1, bB = active ? bodyB[ci] : -1;
+    const int ACC[3] = {WS_BIMP, WS_FACC, WS_ABAR};
+    for (int i = 0; i < c.nb; i++) { zeroN(c, i, WS_BIMP, 6); zeroN(c, i, WS_FACC, 12); }
+    // leaf -> root: BodyNode::updateBiasImpulse (BodyNode.cpp:2117-2138)
+    for (int i = c.nb - 1; i >= 0; i--) {
+      const DevBody& bd = bodies[i];
+      T12 T = ldT(c, i);
+      V6 Bi[3];
+      for (int k = 0; k < 3; k++) {
+        Bi[k] = ldV6(c, i, ACC[k]);
+        const int row = 3 * ci + k;
+        if (i == bA) { double a6[6]; for (int e = 0; e < 6; e++) a6[e] = L.at(LW_JA + row * 6 + e); Bi[k] = Bi[k] - fromArr(a6); }
+        if (i == bB) { double a6[6]; for (int e = 0; e < 6; e++) a6[e] = L.at(LW_JB + row * 6 + e); Bi[k] = Bi[k] - fromArr(a6); }
+      }
+      if (bd.jtype != JT_FREE) {
+        V6 S = cV6(bd.S), AIS = ldV6(c, i, WS_AIS);
+        double psi = wsAt(c, i, WS_PSI);
+        for (int k = 0; k < 3; k++) {
+          double uimp = -dot(S, Bi[k]);                    // GenericJoint.hpp:2607-2613 (no joint constraint impulse)
+          wsAt(c, i, WS_UIMP + k) = uimp;
+          if (bd.parent >= 0) addV6(c, bd.parent, ACC[k], dAdInvT(T, Bi[k] + (psi * uimp) * AIS));  // :2482-2498
+        }
+      } else {
+        const int US[3] = {WS_UIMP, WS_W, WS_VBAR};
+        for (int k = 0; k < 3; k++) {
+          double pj[6];
+          toArr(dAdT(cT(bd.Tcj), Bi[k]), pj);
+          for (int e = 0; e < 6; e++) wsAt(c, i, US[k] + e) = -pj[e];
+        }
+      }
+    }
+    // root -> leaf: BodyNode::updateVelocityChangeFD (BodyNode.cpp:2188-2215)
+    for (int i = 0; i < c.nb; i++) {
+      const DevBody& bd = bodies[i];
+      T12 T = ldT(c, i);
+      if (bd.jtype != JT_FREE) {
+        V6 S = cV6(bd.S), AIS = ldV6(c, i, WS_AIS);
+        double psi = wsAt(c, i, WS_PSI);
+        for (int k = 0; k < 3; k++) {
+          V6 X = bd.parent >= 0 ? AdInvT(T, ldV6(c, bd.parent, ACC[k])) : zero6();
+          double dq = psi * (wsAt(c, i, WS_UIMP + k) - dot(AIS, X));   // GenericJoint.hpp:2713-2725
+          stV6(c, i, ACC[k], X + dq * S);
+          if (active) svAt(saved, lay.massed + bd.dofOff * MAX_ROWS + 3 * ci + k, B, b) = dq;
+        }
+      } else {
+        const int US[3] = {WS_UIMP, WS_W, WS_VBAR};
+        S6 AI = ldS6(c, i, WS_AI);
+        LDL6 f;
+        for (int e = 0; e < 15; e++) f.l[e] = wsAt(c, i, WS_PSI + e);
+        for (int e = 0; e < 6; e++) f.d[e] = wsAt(c, i, WS_PSI + 15 + e);
+        for (int k = 0; k < 3; k++) {
+          V6 X = bd.parent >= 0 ? AdInvT(T, ldV6(c, bd.parent, ACC[k])) : zero6();
+          double r[6], pj[6];
+          toArr(dAdT(cT(bd.Tcj), mul(AI, X)), pj);
+          for (int e = 0; e < 6; e++) r[e] = wsAt(c, i, US[k] + e) - pj[e];
+          ldl6Solve(f, r);
+          stV6(c, i, ACC[k], X + AdT(cT(bd.Tcj), fromArr(r)));
+          if (active) for (int e = 0; e < 6; e++) svAt(saved, lay.massed + (bd.dofOff + e) * MAX_ROWS + 3 * ci + k, B, b) = r[e];
+        }
+      }
+    }
+    // rows 3ci..3ci+2 of A: relative-velocity response of every row of the contacts c2 >= ci; earlier
+    // ones mirrored (BoxedLcpConstraintSolver.cpp:250-320)
+    if (active) {
+      for (int c2 = ci; c2 < nC; c2++) {
+        const int b2A = bodyA[c2], b2B = bodyB[c2];
+        V6 dVA[3], dVB[3];
+        for (int k = 0; k < 3; k++) {
+          dVA[k] = b2A >= 0 ? ldV6(c, b2A, ACC[k]) : zero6();
+          dVB[k] = b2B >= 0 ? ldV6(c, b2B, ACC[k]) : zero6();
+        }
+        for (int k2 = 0; k2 < 3; k2++) {
+          const int col = 3 * c2 + k2;
+          double ja[6], jb[6];
+          for (int e = 0; e < 6; e++) { ja[e] = L.at(LW_JA + col * 6 + e); jb[e] = L.at(LW_JB + col * 6 + e); }
+          V6 JA = fromArr(ja), JB = fromArr(jb);
+          for (int k = 0; k < 3; k++) {
+            double val = 0;
+            if (b2A >= 0) val += dot(JA, dVA[k]);
+            if (b2B >= 0) val += dot(JB, dVB[k]);
+            svAt(saved, lay.A + (3 * ci + k) * MAX_ROWS + col, B, b) = val;
+          }
+        }
+      }
+      for (int c2 = 0; c2 < ci; c2++)
+        for (int k2 = 0; k2 < 3; k2++)
+          for (int k = 0; k < 3; k++)
+            svAt(saved, lay.A + (3 * ci + k) * MAX_ROWS + 3 * c2 + k2, B, b) = svAt(saved, lay.A + (3 * c2 + k2) * MAX_ROWS + 3 * ci + k, B, b);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 0 solve + apply
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_contact_solve(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                      double* __restrict__ saved, SavedLayout lay,
+                                                      const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
+                                                      double* __restrict__ next, uint32_t* __restrict__ status,
+                                                      double* __restrict__ lws) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = mdl.n;
+  const int nC = (int)svAt(saved, lay.nc, B, b);
+  const int m = 3 * nC;
+  LaneMem L;
+  L.base = lws; L.B = B; L.b = b;
+  LaneMem SV;
+  SV.base = saved; SV.B = B; SV.b = b;
+  double* nv = next + (int64_t)n * B;
+  uint32_t st = status ? status[b] : 0u;
+  // cache layout: MAX_ROWS values + the row count they belong to
+  if (m == 0) {
+    if (cacheOut) { for (int r = 0; r < MAX_ROWS; r++) cacheOut[(int64_t)r * B + b] = 0; cacheOut[(int64_t)MAX_ROWS * B + b] = 0; }
+    for (int r = 0; r < MAX_ROWS; r++) { SV.at(lay.x + r) = 0; SV.at(lay.cls + r) = 0; }
+    SV.at(lay.cfm) = 0;
+    for (int d = 0; d < n; d++) SV.at(lay.w + d) = 0;
+    return;
+  }
+  LcpView V;
+  V.mem = SV; V.offA = lay.A; V.m = m;
+  for (int ci = 0; ci < nC; ci++) {
+    const int r0 = lay.contacts + ci * CR_SIZE;
+    const double muA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].mu, muB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].mu;
+    V.mu[ci] = muA < muB ? muA : muB;
+  }
+  double Bv[MAXR], X[MAXR], colNorm[MAXR];
+  for (int r = 0; r < m; r++) Bv[r] = SV.at(lay.b + r);
+  for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
+
+  CodFactor F;
+  F.ld = MAXR; F.offQR = LW_Q; F.offChol = LW_CHOL;
+  // ---- warm start, or LCPUtils::guessSolution when the cache belongs to another row count ----
+  bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
+  if (haveCache) { for (int r = 0; r < m; r++) X[r] = cacheIn[(int64_t)r * B + b]; }
+  else {
+    int idx[MAXR], nc = 0;
+    for (int r = 0; r < m; r++) if ((r % 3) != 0 || Bv[r] > 0) idx[nc++] = r;
+    for (int r = 0; r < m; r++) X[r] = 0;
+    if (nc > 0) {
+      double rhs[MAXR], sol[MAXR];
+      for (int i = 0; i < nc; i++) { rhs[i] = Bv[idx[i]]; for (int j = 0; j < nc; j++) L.at(LW_Q + i * MAXR + j) = V.A(idx[i], idx[j]); }
+      F.c = nc;
+      codFactor(L, F);
+      codSolve(L, F, rhs, sol);
+      for (int i = 0; i < nc; i++) X[idx[i]] = sol[i];
+    }
+  }
+  // ---- classify + standardise (repeat while normal rows drop out of the clamping set) ----
+  Classes K;
+  bool ok = false;
+  for (int iter = 0; iter < MAXR + 1; iter++) {
+    classify(V, X, colNorm, false, K);
+    if (K.nc == 0) {
+      double zero[MAXR];
+      for (int r = 0; r < m; r++) zero[r] = 0;
+      ok = lcpValid(V, zero, Bv, false, 0.0);
+      if (ok) for (int r = 0; r < m; r++) X[r] = 0;
+      break;
+    }
+    double bc[MAXR], fc[MAXR], newX[MAXR], origFc[MAXR];
+    buildQ(V, K, 0.0, L, LW_Q, Bv, bc);
+    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) origFc[K.cidx[r]] = X[r];
+    F.c = K.nc;
+    codFactor(L, F);
+    codSolve(L, F, bc, fc);
+    bool newlyNot = false;
+    for (int i = 0; i < m; i++) {
+      newX[i] = 0;
+      if (K.cls[i] == RC_CLAMPING) {
+        newX[i] = fc[K.cidx[i]];
+        if (fabs(newX[i]) < 1e-6 && fabs(X[i]) > 1e-6 && (i % 3) == 0) newlyNot = true;
+      } else if (K.cls[i] == RC_UPPER_BOUND) {
+        const int fp = i - (i % 3);
+        double om = origFc[K.cidx[fp]] / X[i];
+        double clean = (fabs(om - V.hi(i)) < fabs(om - V.lo(i))) ? V.hi(i) : V.lo(i);
+        newX[i] = fc[K.cidx[fp]] * clean;
+      }
+    }
+    if (!lcpValid(V, newX, Bv, false, 0.0)) { ok = false; break; }
+    for (int i = 0; i < m; i++) X[i] = newX[i];
+    ok = true;
+    if (!newlyNot) break;
+  }
+  if (ok) st |= 0x2u | 0x100u;
+  else {
+    st |= 0x20u;
+    for (int r = 0; r < m; r++) X[r] = 0;
+    classify(V, X, colNorm, false, K);
+  }
+  // ---- outputs ----
+  for (int r = 0; r < MAX_ROWS; r++) {
+    SV.at(lay.x + r) = r < m ? X[r] : 0.0;
+    SV.at(lay.cls + r) = r < m ? (K.cls[r] == RC_UPPER_BOUND ? (K.E[r] > 0 ? 2.0 : -2.0) : (double)K.cls[r]) : 0.0;
+  }
+  SV.at(lay.cfm) = 0.0;
+  if (cacheOut) {
+    for (int r = 0; r < MAX_ROWS; r++) cacheOut[(int64_t)r * B + b] = r < m ? X[r] : 0.0;
+    cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
+  }
+  // v' = v_pre + M^-1 J^T x   (applyImpulse + computeImpulseForwardDynamics)
+  for (int d = 0; d < n; d++) {
+    double w = 0;
+    for (int r = 0; r < m; r++) w += SV.at(lay.massed + d * MAX_ROWS + r) * X[r];
+    SV.at(lay.w + d) = w;
+    nv[(int64_t)d * B + b] = SV.at(lay.vpre + d) + w;
+  }
+  if (status) status[b] = st;
+}
+
+}  // namespace nbl

@@ -77,6 +77,18 @@ DEV void stT(const Ctx& c, int body, const T12& T) {
   for (int k = 0; k < 9; k++) wsAt(c, body, WS_T + k) = T.R.m[k];
   wsAt(c, body, WS_T + 9) = T.p.x; wsAt(c, body, WS_T + 10) = T.p.y; wsAt(c, body, WS_T + 11) = T.p.z;
 }
+DEV T12 ldTAt(const Ctx& c, int body, int slot) {
+  T12 T;
+#pragma unroll
+  for (int k = 0; k < 9; k++) T.R.m[k] = wsAt(c, body, slot + k);
+  T.p = mk3(wsAt(c, body, slot + 9), wsAt(c, body, slot + 10), wsAt(c, body, slot + 11));
+  return T;
+}
+DEV void stTAt(const Ctx& c, int body, int slot, const T12& T) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) wsAt(c, body, slot + k) = T.R.m[k];
+  wsAt(c, body, slot + 9) = T.p.x; wsAt(c, body, slot + 10) = T.p.y; wsAt(c, body, slot + 11) = T.p.z;
+}
 DEV S6 ldS6(const Ctx& c, int body, int slot) {
   S6 A;
 #pragma unroll
@@ -144,6 +156,7 @@ DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __r
     V6 V = jointTwist(bd, v, B, b);
     if (bd.parent >= 0) V = V + AdInvT(T, ldV6(c, bd.parent, WS_V));
     stT(c, i, T);
+    stTAt(c, i, WS_TW, bd.parent >= 0 ? mulT(ldTAt(c, bd.parent, WS_TW), T) : T);  // BodyNode::mWorldTransform
     stV6(c, i, WS_V, V);
     zeroN(c, i, WS_AI, 21);
     zeroN(c, i, WS_BACC, 6);
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
                                                      const DevDof* __restrict__ dofs, int64_t B,
                                                      const double* __restrict__ state, const double* __restrict__ action,
                                                      double* __restrict__ next, double* __restrict__ saved,
-                                                     uint32_t* __restrict__ status, double* __restrict__ ws) {
+                                                     uint32_t* __restrict__ status, double* __restrict__ ws, int vpreRow) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
@@ -291,6 +304,7 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
       saved[(int64_t)d * B + b] = q[(int64_t)d * B + b];
       saved[(int64_t)(n + d) * B + b] = v[(int64_t)d * B + b];
       saved[(int64_t)(2 * n + d) * B + b] = tauAt(d);
+      if (vpreRow >= 0) saved[(int64_t)(vpreRow + d) * B + b] = nv[(int64_t)d * B + b];   // mLastPreConstraintVelocity (World.cpp:236-239)
     }
   }
   if (status) status[b] = 0u;

@@ -13,6 +13,7 @@
 
 #include "../../include/nimble_amd.h"
 #include "kernels.hip"
+#include "contact_kernels.hip"
 
 using namespace nbl;
 
@@ -40,6 +41,9 @@ struct nbl_model {
   DevBody* dBodies = nullptr;
   DevDof* dDofs = nullptr;
   int nb = 0, n = 0, k = 0, maxContacts = 0;
+  bool hasContact = false;
+  DevContactModel* dContact = nullptr;
+  SavedLayout lay;
   bool timing = false;
   std::vector<TimedLaunch> pending;
   double fwdMs = 0, bwdMs = 0;
@@ -145,7 +149,58 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     hd[j].actionIndex = a;
   }
 
+  // ---- contact model: box colliders, candidate pairs (CollisionFilter.cpp:105-154), ancestor masks ----
+  DevContactModel hc;
+  std::memset(&hc, 0, sizeof(hc));
+  bool hasContact = d->n_boxes > 0 && d->max_contacts > 0;
+  if (hasContact) {
+    if (d->n_boxes > MAX_BOXES) return fail(NBL_E_UNSUPPORTED, "too many box colliders for the device path");
+    if (d->max_contacts > MAX_CONTACTS) return fail(NBL_E_UNSUPPORTED, "max_contacts above 8 is not supported by the device path yet");
+    if (d->n_bodies > 64) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 64 bodies");
+    hc.nBoxes = d->n_boxes;
+    hc.maxContacts = d->max_contacts;
+    hc.clippingDepth = d->contact_clipping_depth;
+    hc.fallbackCfm = d->fallback_cfm;
+    auto rootOf = [&](int body) { while (body >= 0 && d->parent[body] >= 0) body = d->parent[body]; return body; };
+    for (int i = 0; i < d->n_boxes; i++) {
+      DevBox& bx = hc.boxes[i];
+      bx.body = d->box_body[i];
+      if (bx.body >= d->n_bodies) return fail(NBL_E_BADARG, "box collider attached to an unknown body");
+      for (int k = 0; k < 12; k++) bx.T[k] = d->box_T[12 * i + k];
+      for (int k = 0; k < 3; k++) bx.half[k] = 0.5 * d->box_size[3 * i + k];
+      bx.mu = d->box_mu[i];
+      if (!(bx.mu > 1e-3)) return fail(NBL_E_UNSUPPORTED, "frictionless colliders (mu <= 1e-3) are outside the device path");
+    }
+    for (int i = 0; i + 1 < d->n_boxes; i++)
+      for (int j = i + 1; j < d->n_boxes; j++) {
+        int bi = d->box_body[i], bj = d->box_body[j];
+        if (bi == bj) continue;                       // same body (or both fixed to the world)
+        if (bi >= 0 && bj >= 0 && rootOf(bi) == rootOf(bj)) continue;  // same skeleton, self-collision disabled
+        if (hc.nPairs >= MAX_PAIRS) return fail(NBL_E_UNSUPPORTED, "too many collider pairs for the device path");
+        hc.pairA[hc.nPairs] = i;
+        hc.pairB[hc.nPairs] = j;
+        hc.nPairs++;
+      }
+    for (int bdy = 0; bdy < d->n_bodies; bdy++) {
+      uint64_t mask = 0;
+      for (int a = bdy; a >= 0; a = d->parent[a]) mask |= (1ull << a);
+      hc.ancestors[bdy] = mask;
+    }
+  }
+
   nbl_model* m = new nbl_model();
+  m->hasContact = hasContact;
+  {
+    SavedLayout& L = m->lay;
+    const int n = d->n_dofs;
+    L.n = n; L.q = 0; L.v = n; L.tau = 2 * n;
+    if (!hasContact) { L.vpre = L.w = L.nc = L.contacts = L.x = L.b = L.cls = L.cfm = L.A = L.massed = L.aall = -1; L.total = 3 * n; }
+    else {
+      L.vpre = 3 * n; L.w = 4 * n; L.nc = 5 * n; L.contacts = L.nc + 1; L.x = L.contacts + MAX_CONTACTS * CR_SIZE;
+      L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.A = L.cfm + 1;
+      L.massed = L.A + MAX_ROWS * MAX_ROWS; L.aall = L.massed + n * MAX_ROWS; L.total = L.aall + n * MAX_ROWS;
+    }
+  }
   m->device = device;
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
   m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0;
@@ -156,6 +211,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess) e = hipMalloc((void**)&m->dDofs, sizeof(DevDof) * hd.size());
   if (e == hipSuccess) e = hipMemcpy(m->dBodies, hb.data(), sizeof(DevBody) * hb.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->dDofs, hd.data(), sizeof(DevDof) * hd.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && hasContact) e = hipMalloc((void**)&m->dContact, sizeof(DevContactModel));
+  if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     std::string msg = std::string("model upload failed: ") + hipGetErrorString(e);
     nbl_model_destroy(m);
@@ -170,20 +227,21 @@ void nbl_model_destroy(nbl_model* m) {
   for (auto& t : m->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   if (m->dBodies) hipFree(m->dBodies);
   if (m->dDofs) hipFree(m->dDofs);
+  if (m->dContact) hipFree(m->dContact);
   delete m;
 }
 
 int32_t nbl_model_num_dofs(const nbl_model* m) { return m ? m->n : 0; }
 int32_t nbl_model_num_action(const nbl_model* m) { return m ? m->k : 0; }
-int32_t nbl_model_lcp_rows(const nbl_model* m) { return m ? 3 * m->maxContacts : 0; }
+int32_t nbl_model_lcp_rows(const nbl_model* m) { return (m && m->hasContact) ? MAX_ROWS + 1 : 0; }
 
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
-  return (size_t)m->nb * WS_PER_BODY * sizeof(double) * (size_t)B;
+  return ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LW_TOTAL : 0)) * sizeof(double) * (size_t)B;
 }
 size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
-  return (size_t)3 * m->n * sizeof(double) * (size_t)B;
+  return (size_t)m->lay.total * sizeof(double) * (size_t)B;
 }
 
 static void beginTiming(nbl_model* m, hipStream_t s, bool backward) {
@@ -203,15 +261,24 @@ static void endTiming(nbl_model* m, hipStream_t s) {
 int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const double* action, const double* lcp_cache_in,
                          double* next_state, double* lcp_cache_out, void* saved, uint32_t* status, void* workspace,
                          size_t workspace_bytes, void* stream) {
-  (void)lcp_cache_in; (void)lcp_cache_out;
   if (!m || !state || !action || !next_state || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved record (it doubles as the contact scratch)");
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((B + 63) / 64)), block(64);
   beginTiming(m, s, false);
   hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
-                     (double*)saved, status, (double*)workspace);
+                     (double*)saved, status, (double*)workspace, m->hasContact ? m->lay.vpre : -1);
+  if (m->hasContact) {
+    double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
+    hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay, status,
+                       (double*)workspace);
+    hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
+                       (double*)workspace, lws);
+    hipLaunchKernelGGL(k_contact_solve, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay, lcp_cache_in,
+                       lcp_cache_out, next_state, status, lws);
+  }
   endTiming(m, s);
   HIP_TRY(hipGetLastError());
   return NBL_OK;

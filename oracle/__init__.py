@@ -21,13 +21,13 @@ _LIB = None
 def build(force: bool = False, native: bool = False, out: str = None) -> str:
     """Compile liboracle.so with g++ (seconds).  `native` adds -march=native for the timed CPU baseline."""
     out = out or os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("oracle.cpp", "dynamics.hpp", "spatial.hpp", "contact.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.cpp", "dynamics.hpp", "spatial.hpp", "contact.hpp", "collision.hpp", "lcp.hpp")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
     flags = ["-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
     if native:
         flags.append("-march=native")
-    subprocess.check_call(["g++", *flags, "-o", out, os.path.join(_HERE, "oracle.cpp"), "-lpthread"])
+    subprocess.check_call(["g++", *flags, "-o", out, os.path.join(_HERE, "oracle.cpp"), "-lpthread", "-ldl"])
     return out
 
 

@@ -1,0 +1,290 @@
+// oracle/collision.hpp — TEST INFRASTRUCTURE ONLY.
+//
+// Box-box narrow phase restated from the reference's DART collision detector
+// (dart/collision/dart/DARTCollide.cpp:764-1450 `dBoxBox`, :422-600 `intersectRectQuad`,
+// :271-300 `dLineClosestApproach`) plus the pair loop / duplicate filter of
+// dart/collision/dart/DARTCollisionDetector.cpp:150-175, 360-400.
+// Same separating-axis order, same fudge factor and tie-breaks, same clipping order, so contact
+// order, count, types and edge annotations match the reference.
+#pragma once
+#include <vector>
+
+#include "dynamics.hpp"
+
+namespace nbo {
+
+enum ContactType { CT_UNSUPPORTED = 0, CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3 };  // Contact.hpp:45-54
+
+struct Contact {
+  Vec3 point, normal;
+  s_t depth;
+  int type;
+  int bodyA, bodyB, boxA, boxB;
+  Vec3 edgeAClosestPoint, edgeAFixedPoint, edgeADir, edgeBClosestPoint, edgeBFixedPoint, edgeBDir;
+};
+
+inline Vec3 col(const Mat3& R, int j) { return mk3(R(0, j), R(1, j), R(2, j)); }
+inline Vec3 normalized(const Vec3& a) { s_t n = norm(a); return (1.0 / n) * a; }
+
+// DARTCollide.cpp:271-300
+inline void lineClosestApproach(const Vec3& pa, const Vec3& ua, const Vec3& pb, const Vec3& ub, s_t* alpha, s_t* beta) {
+  Vec3 p = pb - pa;
+  s_t uaub = dot(ua, ub), q1 = dot(ua, p), q2 = -dot(ub, p);
+  s_t d = 1 - uaub * uaub;
+  if (d <= 0) { *alpha = 0; *beta = 0; }
+  else { d = 1.0 / d; *alpha = (q1 + uaub * q2) * d; *beta = (uaub * q1 + q2) * d; }
+}
+
+// DARTCollide.cpp:512-575: clip the quad p (4 points) against the rectangle |x|<=h[0], |y|<=h[1]
+inline int intersectRectQuad(const s_t h[2], const s_t p[8], s_t ret[16]) {
+  int nq = 4, nr = 0;
+  s_t bufA[16], bufB[16];
+  for (int i = 0; i < 8; i++) bufA[i] = p[i];
+  s_t* q = bufA;
+  s_t* r = bufB;
+  bool done = false;
+  for (int dir = 0; dir <= 1 && !done; dir++) {
+    for (int sign = -1; sign <= 1 && !done; sign += 2) {
+      nr = 0;
+      for (int i = 0; i < nq && !done; i++) {
+        const s_t* pq = q + 2 * i;
+        const s_t* nextq = (i + 1 < nq) ? pq + 2 : q;
+        bool in0 = sign * pq[dir] < h[dir], in1 = sign * nextq[dir] < h[dir];
+        if (in0) {
+          r[2 * nr] = pq[0]; r[2 * nr + 1] = pq[1];
+          nr++;
+          if (nr & 8) { done = true; break; }
+        }
+        if (in0 ^ in1) {
+          r[2 * nr + (1 - dir)] = pq[1 - dir] + (nextq[1 - dir] - pq[1 - dir]) / (nextq[dir] - pq[dir]) * (sign * h[dir] - pq[dir]);
+          r[2 * nr + dir] = sign * h[dir];
+          nr++;
+          if (nr & 8) { done = true; break; }
+        }
+      }
+      // swap
+      s_t* t = q; q = r; r = t;
+      nq = nr;
+    }
+  }
+  for (int i = 0; i < nr * 2; i++) ret[i] = q[i];
+  return nr;
+}
+
+// dBoxBox.  T1/T2 world transforms of the box shapes, A/B half sizes.  Appends to `out`.
+inline int boxBox(const Iso& T1, const Vec3& A, const Iso& T2, const Vec3& B, s_t clippingDepth, std::vector<Contact>& out) {
+  const s_t fudge = 1.05;
+  const Mat3& R1 = T1.R;
+  const Mat3& R2 = T2.R;
+  Vec3 p = T2.p - T1.p;
+  Vec3 pp = tmul(R1, p);
+  Mat3 R = transpose(R1) * R2, Q;
+  for (int i = 0; i < 9; i++) Q.m[i] = std::fabs(R.m[i]);
+
+  s_t s = -1e12;
+  int code = 0, normalBox = 0, normalCol = 0;
+  bool invert = false;
+  Vec3 normalC = mk3(0, 0, 0);
+  // face axes of box 1 (codes 1-3) and box 2 (codes 4-6): strict '>' keeps the first maximum
+  for (int k = 0; k < 3; k++) {
+    s_t e1 = pp[k], e2 = A[k] + B[0] * Q(k, 0) + B[1] * Q(k, 1) + B[2] * Q(k, 2);
+    s_t s2 = std::fabs(e1) - e2;
+    if (s2 > s) { s = s2; normalBox = 1; normalCol = k; invert = e1 < 0; code = k + 1; }
+  }
+  for (int k = 0; k < 3; k++) {
+    s_t e1 = dot(col(R2, k), p), e2 = A[0] * Q(0, k) + A[1] * Q(1, k) + A[2] * Q(2, k) + B[k];
+    s_t s2 = std::fabs(e1) - e2;
+    if (s2 > s) { s = s2; normalBox = 2; normalCol = k; invert = e1 < 0; code = k + 4; }
+  }
+  // edge x edge axes u_i x v_j (codes 7..15), scaled, with the fudge factor favouring face contacts
+  for (int i = 0; i < 3; i++) {
+    int i1 = (i == 0) ? 1 : 0, i2 = (i == 2) ? 1 : 2;
+    for (int j = 0; j < 3; j++) {
+      int j1 = (j == 0) ? 1 : 0, j2 = (j == 2) ? 1 : 2;
+      Vec3 n;
+      s_t e1;
+      if (i == 0) { n = mk3(0, -R(2, j), R(1, j)); e1 = pp[2] * R(1, j) - pp[1] * R(2, j); }
+      else if (i == 1) { n = mk3(R(2, j), 0, -R(0, j)); e1 = pp[0] * R(2, j) - pp[2] * R(0, j); }
+      else { n = mk3(-R(1, j), R(0, j), 0); e1 = pp[1] * R(0, j) - pp[0] * R(1, j); }
+      s_t e2 = A[i1] * Q(i2, j) + A[i2] * Q(i1, j) + B[j1] * Q(i, j2) + B[j2] * Q(i, j1);
+      s_t s2 = std::fabs(e1) - e2;
+      s_t l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (l > 0) {
+        s2 /= l;
+        if (s2 * fudge > s) {
+          s = s2; normalBox = 0; normalC = (1.0 / l) * n; invert = e1 < 0; code = 7 + 3 * i + j;
+        }
+      }
+    }
+  }
+  if (!code) return 0;
+  if (s > 0.0) return 0;
+
+  Vec3 normal;
+  if (normalBox == 1) normal = col(R1, normalCol);
+  else if (normalBox == 2) normal = col(R2, normalCol);
+  else normal = normalized(R1 * normalC);
+  if (invert) normal = -normal;
+
+  if (code > 6) {
+    // edge-edge: one contact at the midpoint of the closest points of the two edges
+    Vec3 pa = T1.p;
+    for (int j = 0; j < 3; j++) {
+      s_t sign = (dot(normal, col(R1, j)) > -1e-10) ? 1.0 : -1.0;
+      pa = pa + (sign * A[j]) * col(R1, j);
+    }
+    Vec3 pb = T2.p;
+    for (int j = 0; j < 3; j++) {
+      s_t sign = (dot(normal, col(R2, j)) > -1e-3) ? -1.0 : 1.0;
+      pb = pb + (sign * B[j]) * col(R2, j);
+    }
+    Vec3 ua = col(R1, (code - 7) / 3), ub = col(R2, (code - 7) % 3);
+    s_t alpha, beta;
+    lineClosestApproach(pa, ua, pb, ub, &alpha, &beta);
+    Vec3 fixedA = pa, fixedB = pb;
+    pa = pa + alpha * ua;
+    pb = pb + beta * ub;
+    s_t penetration = -s;
+    if (penetration > clippingDepth) return 0;
+    Contact c;
+    c.point = 0.5 * (pa + pb);
+    c.normal = -normal;
+    c.depth = penetration;
+    c.type = CT_EDGE_EDGE;
+    c.edgeAClosestPoint = pa; c.edgeAFixedPoint = fixedA; c.edgeADir = normalized(ua);
+    c.edgeBClosestPoint = pb; c.edgeBFixedPoint = fixedB; c.edgeBDir = normalized(ub);
+    out.push_back(c);
+    return 1;
+  }
+
+  // face-something: reference face on box a, incident face on box b
+  const Mat3 *Ra, *Rb;
+  Vec3 pa, pb, Sa, Sb;
+  bool flip;
+  if (code <= 3) { Ra = &R1; Rb = &R2; pa = T1.p; pb = T2.p; Sa = A; Sb = B; flip = false; }
+  else { Ra = &R2; Rb = &R1; pa = T2.p; pb = T1.p; Sa = B; Sb = A; flip = true; }
+  Vec3 normal2 = (code <= 3) ? normal : -normal;
+  Vec3 nr = tmul(*Rb, normal2);
+  Vec3 anr = mk3(std::fabs(nr[0]), std::fabs(nr[1]), std::fabs(nr[2]));
+  int lanr, a1, a2;
+  if (anr[1] > anr[0]) {
+    if (anr[1] > anr[2]) { a1 = 0; lanr = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; }
+  } else {
+    if (anr[0] > anr[2]) { lanr = 0; a1 = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; }
+  }
+  Vec3 center;
+  if (nr[lanr] < 0) center = pb - pa + Sb[lanr] * col(*Rb, lanr);
+  else center = pb - pa - Sb[lanr] * col(*Rb, lanr);
+  int codeN = (code <= 3) ? code - 1 : code - 4, code1, code2;
+  if (codeN == 0) { code1 = 1; code2 = 2; } else if (codeN == 1) { code1 = 0; code2 = 2; } else { code1 = 0; code2 = 1; }
+  s_t quad[8];
+  s_t c1 = dot(center, col(*Ra, code1)), c2 = dot(center, col(*Ra, code2));
+  s_t m11 = dot(col(*Ra, code1), col(*Rb, a1)), m12 = dot(col(*Ra, code1), col(*Rb, a2));
+  s_t m21 = dot(col(*Ra, code2), col(*Rb, a1)), m22 = dot(col(*Ra, code2), col(*Rb, a2));
+  {
+    s_t k1 = m11 * Sb[a1], k2 = m21 * Sb[a1], k3 = m12 * Sb[a2], k4 = m22 * Sb[a2];
+    quad[0] = c1 - k1 - k3; quad[1] = c2 - k2 - k4;
+    quad[2] = c1 - k1 + k3; quad[3] = c2 - k2 + k4;
+    quad[4] = c1 + k1 + k3; quad[5] = c2 + k2 + k4;
+    quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
+  }
+  s_t rect[2] = {Sa[code1], Sa[code2]};
+  s_t ret[16];
+  int n = intersectRectQuad(rect, quad, ret);
+  if (n < 1) return 0;
+  s_t point[24], dep[8];
+  s_t det1 = 1.0 / (m11 * m22 - m12 * m21);
+  m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
+  int cnum = 0;
+  for (int j = 0; j < n; j++) {
+    s_t k1 = m22 * (ret[j * 2] - c1) - m12 * (ret[j * 2 + 1] - c2);
+    s_t k2 = -m21 * (ret[j * 2] - c1) + m11 * (ret[j * 2 + 1] - c2);
+    Vec3 pt = center + k1 * col(*Rb, a1) + k2 * col(*Rb, a2);
+    for (int i = 0; i < 3; i++) point[cnum * 3 + i] = pt[i];
+    dep[cnum] = Sa[codeN] - dot(normal2, pt);
+    if (dep[cnum] >= 0) {
+      ret[cnum * 2] = ret[j * 2];
+      ret[cnum * 2 + 1] = ret[j * 2 + 1];
+      cnum++;
+    }
+  }
+  if (cnum < 1) return 0;
+  Vec3 otherNormal = col(*Rb, lanr);
+  if (dot(otherNormal, normal) < 0) otherNormal = -otherNormal;
+  Vec3 ortho1 = col(*Rb, a1), ortho2 = col(*Rb, a2);
+  Vec3 centerB = pb;
+  Vec3 faceCenter = centerB - Sb[lanr] * otherNormal;
+  for (int j = 0; j < cnum; j++) {
+    Contact c;
+    c.point = mk3(point[j * 3] + pa[0], point[j * 3 + 1] + pa[1], point[j * 3 + 2] + pa[2]);
+    s_t x = ret[j * 2], y = ret[j * 2 + 1];
+    c.normal = -normal;
+    c.depth = dep[j];
+    c.edgeAClosestPoint = c.edgeAFixedPoint = c.edgeADir = c.edgeBClosestPoint = c.edgeBFixedPoint = c.edgeBDir = mk3(0, 0, 0);
+    bool onEdgeX = std::fabs(x) == rect[0], onEdgeY = std::fabs(y) == rect[1];
+    if (onEdgeX && onEdgeY) {
+      // a corner of the reference rectangle: the reference box's vertex touches the incident face
+      if (flip) { c.type = CT_FACE_VERTEX; c.point = c.point + c.depth * c.normal; }
+      else { c.type = CT_VERTEX_FACE; c.point = c.point - c.depth * c.normal; }
+    } else if (!onEdgeX && !onEdgeY) {
+      c.type = flip ? CT_VERTEX_FACE : CT_FACE_VERTEX;
+    } else {
+      c.type = CT_EDGE_EDGE;
+      s_t faceX = x > 0 ? rect[0] : -rect[0], faceY = y > 0 ? rect[1] : -rect[1];
+      Vec3 faceCenterA = pa + Sa[codeN] * normal;
+      Vec3 ortho1A = col(*Ra, code1), ortho2A = col(*Ra, code2);
+      c.edgeAFixedPoint = faceCenterA + faceX * ortho1A + faceY * ortho2A;
+      c.edgeADir = normalized(c.point - c.edgeAFixedPoint);
+      c.edgeAClosestPoint = c.point;
+      s_t incX = dot(ortho1, c.point) - dot(ortho1, centerB), incY = dot(ortho2, c.point) - dot(ortho2, centerB);
+      s_t signX = incX == 0 ? 1.0 : (incX / std::fabs(incX)), signY = incY == 0 ? 1.0 : (incY / std::fabs(incY));
+      Vec3 nearestB = (signX * Sb[a1]) * ortho1 + (signY * Sb[a2]) * ortho2 + faceCenter;
+      s_t distX = std::fabs(std::fabs(incX) - Sb[a1]), distY = std::fabs(std::fabs(incY) - Sb[a2]);
+      Vec3 otherB;
+      if (distX < distY) otherB = (signX * Sb[a1]) * ortho1 + (-1 * signY * Sb[a2]) * ortho2 + faceCenter;
+      else otherB = (-1 * signX * Sb[a1]) * ortho1 + (signY * Sb[a2]) * ortho2 + faceCenter;
+      c.edgeBDir = normalized(nearestB - otherB);
+      c.edgeBFixedPoint = nearestB;
+      if (flip) {
+        Vec3 t = c.edgeADir; c.edgeADir = c.edgeBDir; c.edgeBDir = t;
+        t = c.edgeAFixedPoint; c.edgeAFixedPoint = c.edgeBFixedPoint; c.edgeBFixedPoint = t;
+      }
+    }
+    out.push_back(c);
+  }
+  return cnum;
+}
+
+// Which pairs are tested: all i<j in insertion order, minus CollisionFilter.cpp:105-154
+// (same body, both immobile, same skeleton with self-collision disabled).
+inline int skeletonRoot(const Model& m, int body) {
+  while (body >= 0 && m.bodies[body].parent >= 0) body = m.bodies[body].parent;
+  return body;
+}
+
+inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<Contact>& contacts) {
+  contacts.clear();
+  const int nbx = (int)m.boxes.size();
+  for (int i = 0; i + 1 < nbx; i++)
+    for (int j = i + 1; j < nbx; j++) {
+      const BoxCollider &bi = m.boxes[i], &bj = m.boxes[j];
+      if (bi.body == bj.body) continue;
+      if (bi.body < 0 && bj.body < 0) continue;
+      if (bi.body >= 0 && bj.body >= 0 && skeletonRoot(m, bi.body) == skeletonRoot(m, bj.body)) continue;
+      Iso Ti = bi.body >= 0 ? kin[bi.body].Tworld * bi.T : bi.T;
+      Iso Tj = bj.body >= 0 ? kin[bj.body].Tworld * bj.T : bj.T;
+      std::vector<Contact> pair;
+      boxBox(Ti, 0.5 * bi.size, Tj, 0.5 * bj.size, m.clippingDepth, pair);
+      // postProcess: drop points closer than 3e-12 to an already accepted contact
+      for (Contact& c : pair) {
+        bool close = false;
+        for (const Contact& t : contacts)
+          if (norm(c.point - t.point) < 3.0e-12) { close = true; break; }
+        if (close) continue;
+        c.boxA = i; c.boxB = j; c.bodyA = bi.body; c.bodyB = bj.body;
+        contacts.push_back(c);
+      }
+    }
+}
+
+}  // namespace nbo

@@ -1,41 +1,702 @@
 // oracle/contact.hpp — TEST INFRASTRUCTURE ONLY.
 //
-// Contact stage of World::step (ConstraintSolver::solve, ConstraintSolver.cpp:376-414) and the
-// contact terms of the BackpropSnapshot Jacobians.  STAGE 1 of the build: no collision shapes are
-// processed yet, so every world takes the "no clamping constraints" branches of the reference
-// (BackpropSnapshot.cpp:521-524, 686-689).
+// Contact stage of World::step restated from the reference:
+//   ConstraintSolver::updateConstraints            dart/constraint/ConstraintSolver.cpp:540-613
+//   ContactConstraint ctor / getInformation        dart/constraint/ContactConstraint.cpp:66-230, 361-514, 734-795
+//   BoxedLcpConstraintSolver::buildLcpInputs       dart/constraint/BoxedLcpConstraintSolver.cpp:190-349
+//   BoxedLcpConstraintSolver::solveLcp (cascade)   :352-789
+//   ConstrainedGroupGradientMatrices               dart/neural/ConstrainedGroupGradientMatrices.cpp:177-339, 482-872
+//   DifferentiableContactConstraint::getConstraintForces  dart/neural/DifferentiableContactConstraint.cpp:231-270
+// One constrained group per world (all contacts solved as one LCP): true for every config in
+// BASELINE.json; multi-group worlds (ConstraintSolver.cpp:742-786) are outside the scope.
 #pragma once
+#include "collision.hpp"
 #include "dynamics.hpp"
+#include "lcp.hpp"
 
 namespace nbo {
 
-struct Contact {
-  Vec3 point, normal;
-  s_t depth;
-  int type, bodyA, bodyB, boxA, boxB;
-};
+enum RowClass { RC_NOT_CLAMPING = 0, RC_CLAMPING = 1, RC_UPPER_BOUND = 2, RC_ILLEGAL = 3 };
 
 struct ContactResult {
-  std::vector<Contact> contacts;
+  std::vector<Contact> contacts;   // active contact constraints, in LCP order
+  std::vector<int> rowContact, rowDir;  // LCP row -> (contact, 0 = normal / 1,2 = tangents)
+  std::vector<int> contactOffset;  // first row of each contact
+  std::vector<Vec6> JA, JB;        // per row: ContactConstraint::mSpatialNormalA/B columns (body frames)
+  std::vector<Vec3> dirs;          // per row: world force direction
   int m = 0;
-  MatX A;
+  MatX A;                          // m x m (possibly with the fallback CFM on the diagonal)
   VecX b, x, lo, hi;
-  std::vector<int> findex, rowClass;
-  int numClamping = 0;
+  std::vector<int> findex;
+  MatX massed;                     // n x m: massed impulse tests  M^-1 J^T        (CGGM::measureConstraintImpulse)
+  MatX Aall;                       // n x m: constraint forces in joint space      (DCC::getConstraintForces)
+  // classification (CGGM::constructMatrices)
+  std::vector<int> rowClass, clampingIndex, upperBoundIndex;
+  int numClamping = 0, numUpperBound = 0;
+  MatX E;                          // numUpperBound x numClamping
+  VecX fc;                         // clamping constraint impulses
+  s_t cfm = 0;
+  bool ignoreFriction = false, standardized = false;
+  uint32_t status = 0;
+};
+
+// ContactConstraint::getTangentBasisMatrixODE (ContactConstraint.cpp:734-795), first frictional direction = Z
+inline void tangentBasis(const Vec3& n, Vec3& t1, Vec3& t2) {
+  const s_t EPS2 = 1e-12;
+  Vec3 tangent = cross(mk3(0, 0, 1), n);
+  if (dot(tangent, tangent) < EPS2) {
+    tangent = cross(mk3(1, 0, 0), n);
+    if (dot(tangent, tangent) < EPS2) {
+      tangent = cross(mk3(0, 1, 0), n);
+      if (dot(tangent, tangent) < EPS2) tangent = cross(mk3(0, 0, 1), n);
+    }
+  }
+  t1 = normalized(tangent);
+  t2 = cross(n, t1);
+}
+
+inline bool dofIsParentOf(const Model& m, int dofBody, int body) {
+  while (body >= 0) {
+    if (body == dofBody) return true;
+    body = m.bodies[body].parent;
+  }
+  return false;
+}
+
+// ---- CGGM::constructMatrices + opportunisticallyStandardizeResults ------------------------------
+struct Cggm {
+  const Model* model;
+  const MatX* Minv;
+  ContactResult* cr;
+  // registered LCP results
+  VecX X, Hi, Lo, B, AColNorms;
+  std::vector<int> FIndex;
+  MatX A;
+  s_t cfmConst = 0;
+  bool ignoreFriction = false;
+  bool standardized = false;
+
+  bool isSolutionValid(const VecX& x) const { return isLCPSolutionValid(A, x, B, Hi, Lo, FIndex, ignoreFriction); }
+
+  void constructMatrices() {
+    const s_t CLAMPING_THRESHOLD = 1e-6;
+    const int m = cr->m;
+    std::vector<int>& cls = cr->rowClass;
+    cls.assign(m, RC_NOT_CLAMPING);
+    cr->clampingIndex.assign(m, -1);
+    cr->upperBoundIndex.assign(m, -1);
+    int numClamping = 0, numUpperBound = 0;
+    for (int j = 0; j < m; j++) {
+      if (AColNorms[j] < 1e-9) { cls[j] = RC_NOT_CLAMPING; continue; }
+      const s_t force = X[j];
+      s_t upperBound = Hi[j], lowerBound = Lo[j];
+      const int fp = FIndex[j];
+      if (fp != -1) { upperBound *= X[fp]; lowerBound *= X[fp]; }
+      if (std::fabs(force) < CLAMPING_THRESHOLD) {
+        if (fp != -1) {
+          s_t normalForce = X[fp];
+          if (std::fabs(normalForce) < CLAMPING_THRESHOLD) cls[j] = RC_NOT_CLAMPING;
+          else if (ignoreFriction) cls[j] = RC_NOT_CLAMPING;
+          else { cls[j] = RC_CLAMPING; cr->clampingIndex[j] = numClamping++; }
+        } else cls[j] = RC_NOT_CLAMPING;
+        continue;
+      }
+      const s_t tieBreak = 1e-5;
+      if ((X[j] > lowerBound + tieBreak && X[j] < upperBound - tieBreak) ||
+          (lowerBound - X[j] > 1e-2 || X[j] - upperBound > 1e-2)) {
+        cls[j] = RC_CLAMPING;
+        cr->clampingIndex[j] = numClamping++;
+      } else if (lowerBound - X[j] > 1e-2 || X[j] - upperBound > 1e-2) {
+        cls[j] = RC_ILLEGAL;
+      } else if (fp != -1 && std::fabs(X[fp]) > 1e-9 && AColNorms[fp] > 1e-9 && ((fp > j) || cls[fp] == RC_CLAMPING)) {
+        cls[j] = RC_UPPER_BOUND;
+        cr->upperBoundIndex[j] = numUpperBound++;
+      } else cls[j] = RC_NOT_CLAMPING;
+    }
+    cr->numClamping = numClamping;
+    cr->numUpperBound = numUpperBound;
+    cr->E = MatX(numUpperBound, numClamping);
+    cr->fc.assign(numClamping, 0.0);
+    for (int j = 0; j < m; j++) {
+      if (cls[j] == RC_CLAMPING) cr->fc[cr->clampingIndex[j]] = X[j];
+      if (cls[j] == RC_UPPER_BOUND) {
+        const int fp = FIndex[j];
+        const s_t ub = X[fp] * Hi[j], lb = X[fp] * Lo[j];
+        if (std::fabs(X[j] - ub) < std::fabs(X[j] - lb)) cr->E(cr->upperBoundIndex[j], cr->clampingIndex[fp]) = Hi[j];
+        else cr->E(cr->upperBoundIndex[j], cr->clampingIndex[fp]) = Lo[j];
+      }
+    }
+    cr->cfm = cfmConst;
+    cr->ignoreFriction = ignoreFriction;
+    standardize();
+  }
+
+  // Q = A_c^T Minv (A_c + A_ub E) + cfm I   (or the clamping block of A when there are no upper-bound rows)
+  MatX buildQ() const {
+    const int m = cr->m, nc = cr->numClamping, nu = cr->numUpperBound, n = model->n;
+    MatX Q(nc, nc);
+    if (nu == 0) {
+      for (int r = 0; r < m; r++)
+        if (cr->rowClass[r] == RC_CLAMPING)
+          for (int c = 0; c < m; c++)
+            if (cr->rowClass[c] == RC_CLAMPING) Q(cr->clampingIndex[r], cr->clampingIndex[c]) = A(r, c);
+      return Q;
+    }
+    MatX Ac(n, nc), Aub(n, nu);
+    for (int j = 0; j < m; j++) {
+      if (cr->rowClass[j] == RC_CLAMPING) for (int i = 0; i < n; i++) Ac(i, cr->clampingIndex[j]) = cr->Aall(i, j);
+      if (cr->rowClass[j] == RC_UPPER_BOUND) for (int i = 0; i < n; i++) Aub(i, cr->upperBoundIndex[j]) = cr->Aall(i, j);
+    }
+    MatX AcubE = matmul(Aub, cr->E);
+    for (size_t i = 0; i < AcubE.d.size(); i++) AcubE.d[i] += Ac.d[i];
+    Q = matmul(transposeX(Ac), matmul(*Minv, AcubE));
+    for (int i = 0; i < nc; i++) Q(i, i) += cfmConst;
+    return Q;
+  }
+
+  bool standardize() {
+    const s_t CLAMPING_THRESHOLD = 1e-6;
+    const int m = cr->m;
+    standardized = true;
+    if (m == 0) return true;
+    if (cr->numClamping == 0) {
+      VecX zero(m, 0.0);
+      if (isSolutionValid(zero)) { X = zero; return true; }
+      standardized = false;
+      return false;
+    }
+    MatX Q = buildQ();
+    VecX bc(cr->numClamping, 0.0);
+    for (int j = 0; j < m; j++) if (cr->rowClass[j] == RC_CLAMPING) bc[cr->clampingIndex[j]] = B[j];
+    VecX f_c = codSolve(Q, bc);
+    VecX originalFc = cr->fc;
+    bool anyNewlyNotClamping = false;
+    VecX newX(m, 0.0);
+    for (int i = 0; i < m; i++) {
+      const int ci = cr->clampingIndex[i], ui = cr->upperBoundIndex[i];
+      if (ci != -1) {
+        newX[i] = f_c[ci];
+        if (std::fabs(f_c[ci]) < CLAMPING_THRESHOLD && std::fabs(X[i]) > CLAMPING_THRESHOLD && FIndex[i] == -1) anyNewlyNotClamping = true;
+      }
+      if (ui != -1) {
+        const int fp = FIndex[i];
+        s_t originalMultiple = originalFc[cr->clampingIndex[fp]] / X[i];
+        s_t cleanMultiple = (std::fabs(originalMultiple - Hi[i]) < std::fabs(originalMultiple - Lo[i])) ? Hi[i] : Lo[i];
+        newX[i] = f_c[cr->clampingIndex[fp]] * cleanMultiple;
+      }
+    }
+    if (isSolutionValid(newX)) {
+      X = newX;
+      cr->fc = f_c;
+      if (anyNewlyNotClamping) constructMatrices();
+      return true;
+    }
+    standardized = false;
+    return false;
+  }
 };
 
 inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art, const s_t* q,
                           const s_t* vPre, VecX& lcpCache, ContactResult& out, s_t* vOut, uint32_t* status) {
-  (void)m; (void)kin; (void)art; (void)q; (void)vPre; (void)lcpCache; (void)vOut;
   out = ContactResult();
   *status = 0;
+  if (m.boxes.empty()) return;
+  const int n = m.n;
+  // ---- collision detection at q_t, filter by penetration depth (ConstraintSolver.cpp:563-613) ----
+  std::vector<Contact> all;
+  collideAll(m, kin, all);
+  for (const Contact& c : all) {
+    if (dot(c.normal, c.normal) < 1e-12) continue;           // Contact::isZeroNormal
+    if (c.depth < 0.0 || c.depth > m.clippingDepth) continue;
+    if (c.bodyA < 0 && c.bodyB < 0) continue;                 // neither body reactive -> constraint inactive
+    out.contacts.push_back(c);
+  }
+  const int C = (int)out.contacts.size();
+  if (C == 0) return;
+  *status |= NBL_ST_CONTACT;
+
+  // body velocities at the post-ABA, pre-contact velocity (ContactConstraint::getRelVelocity)
+  std::vector<Kin> kinPre;
+  kinematics(m, q, vPre, kinPre);
+
+  // ---- ContactConstraint ctor: per-row body-frame Jacobians ----
+  std::vector<s_t> mu(C);
+  std::vector<int> dim(C);
+  for (int c = 0; c < C; c++) {
+    const Contact& ct = out.contacts[c];
+    s_t muA = m.boxes[ct.boxA].mu, muB = m.boxes[ct.boxB].mu;
+    mu[c] = muA < muB ? muA : muB;
+    dim[c] = mu[c] > 1e-3 ? 3 : 1;                             // DART_FRICTION_COEFF_THRESHOLD
+    out.contactOffset.push_back((int)out.rowContact.size());
+    Vec3 t1, t2;
+    tangentBasis(ct.normal, t1, t2);
+    Vec3 d[3] = {ct.normal, t1, t2};
+    for (int k = 0; k < dim[c]; k++) {
+      out.rowContact.push_back(c);
+      out.rowDir.push_back(k);
+      out.dirs.push_back(d[k]);
+      Vec6 ja = zero6(), jb = zero6();
+      if (ct.bodyA >= 0) {
+        const Iso& TA = kin[ct.bodyA].Tworld;
+        Vec3 dirA = tmul(TA.R, d[k]), pA = apply(inverse(TA), ct.point);
+        ja = mk6(cross(pA, dirA), dirA);
+      }
+      if (ct.bodyB >= 0) {
+        const Iso& TB = kin[ct.bodyB].Tworld;
+        Vec3 dirB = tmul(TB.R, -d[k]), pB = apply(inverse(TB), ct.point);
+        jb = mk6(cross(pB, dirB), dirB);
+      }
+      out.JA.push_back(ja);
+      out.JB.push_back(jb);
+    }
+  }
+  const int mrows = (int)out.rowContact.size();
+  out.m = mrows;
+  out.A = MatX(mrows, mrows);
+  out.b.assign(mrows, 0.0); out.lo.assign(mrows, 0.0); out.hi.assign(mrows, 0.0);
+  out.findex.assign(mrows, -1);
+  out.massed = MatX(n, mrows);
+  out.Aall = MatX(n, mrows);
+
+  // ---- getInformation: b, lo, hi, findex (restitution 0 and penetration correction off by default) ----
+  for (int r = 0; r < mrows; r++) {
+    const Contact& ct = out.contacts[out.rowContact[r]];
+    s_t rel = 0;
+    if (ct.bodyA >= 0) rel -= dot(out.JA[r], kinPre[ct.bodyA].V);
+    if (ct.bodyB >= 0) rel -= dot(out.JB[r], kinPre[ct.bodyB].V);
+    out.b[r] = rel;
+    if (out.rowDir[r] == 0) { out.lo[r] = 0.0; out.hi[r] = INFINITY; out.findex[r] = -1; }
+    else {
+      s_t f = mu[out.rowContact[r]];
+      out.lo[r] = -f; out.hi[r] = f;
+      out.findex[r] = out.contactOffset[out.rowContact[r]];
+    }
+  }
+
+  // ---- impulse tests: rows of A and massed impulse tests (BoxedLcpConstraintSolver.cpp:250-320) ----
+  for (int c = 0; c < C; c++) {
+    for (int k = 0; k < dim[c]; k++) {
+      const int row = out.contactOffset[c] + k;
+      const Contact& ct = out.contacts[c];
+      std::vector<Vec6> imps(m.nb, zero6()), dV;
+      if (ct.bodyA >= 0) imps[ct.bodyA] = imps[ct.bodyA] + out.JA[row];
+      if (ct.bodyB >= 0) imps[ct.bodyB] = imps[ct.bodyB] + out.JB[row];
+      VecX delV(n, 0.0);
+      impulseDynamics(m, kin, art, imps, delV.data(), &dV);
+      for (int i = 0; i < n; i++) out.massed(i, row) = delV[i];
+      // own block and later constraints computed, earlier ones mirrored
+      for (int c2 = c; c2 < C; c2++)
+        for (int k2 = 0; k2 < dim[c2]; k2++) {
+          const int col = out.contactOffset[c2] + k2;
+          const Contact& ct2 = out.contacts[c2];
+          s_t v = 0;
+          if (ct2.bodyA >= 0) v += dot(out.JA[col], dV[ct2.bodyA]);
+          if (ct2.bodyB >= 0) v += dot(out.JB[col], dV[ct2.bodyB]);
+          out.A(row, col) = v;
+        }
+      for (int c2 = 0; c2 < c; c2++)
+        for (int k2 = 0; k2 < dim[c2]; k2++) {
+          const int col = out.contactOffset[c2] + k2;
+          out.A(row, col) = out.A(col, row);
+        }
+    }
+  }
+
+  // ---- constraint forces in joint space: A_c columns (DCC.cpp:231-270, 2961-2988; Joint.cpp:1176-1181) ----
+  for (int r = 0; r < mrows; r++) {
+    const Contact& ct = out.contacts[out.rowContact[r]];
+    Vec6 F = mk6(cross(ct.point, out.dirs[r]), out.dirs[r]);
+    for (int bi = 0; bi < m.nb; bi++) {
+      const Body& bd = m.bodies[bi];
+      if (bd.ndof == 0) continue;
+      bool pa = ct.bodyA >= 0 && dofIsParentOf(m, bi, ct.bodyA), pb = ct.bodyB >= 0 && dofIsParentOf(m, bi, ct.bodyB);
+      s_t mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
+      for (int k = 0; k < bd.ndof; k++) {
+        if (mult == 0) { out.Aall(bd.dofOff + k, r) = 0; continue; }
+        Vec6 tw = AdT(kin[bi].Tworld, bd.S[k]);
+        out.Aall(bd.dofOff + k, r) = dot(tw, F) * mult;
+      }
+    }
+  }
+
+  // ---- warm start / guess (BoxedLcpConstraintSolver.cpp:202-208, 332-337) ----
+  VecX X;
+  if ((int)lcpCache.size() != mrows) X = guessSolution(out.A, out.b, out.findex);
+  else X = lcpCache;
+  const VecX XBackup = X;
+
+  MatX Minv = invMassMatrix(m, kin, art);
+  Cggm g;
+  g.model = &m; g.Minv = &Minv; g.cr = &out;
+  VecX aColNorms(mrows, 0.0);
+  for (int c = 0; c < mrows; c++) { s_t s = 0; for (int r = 0; r < mrows; r++) s += out.A(r, c) * out.A(r, c); aColNorms[c] = s; }
+  MatX aGrad = out.A;
+
+  // ---- stage 0: classify the cached x and solve the active set in closed form (:434-457) ----
+  s_t cfm = 0.0;
+  g.X = X; g.Hi = out.hi; g.Lo = out.lo; g.FIndex = out.findex; g.B = out.b; g.AColNorms = aColNorms; g.A = aGrad;
+  g.cfmConst = cfm; g.ignoreFriction = false;
+  g.constructMatrices();
+  bool success = g.standardized;
+  bool shortCircuit = success;
+  bool hadToIgnoreFriction = false;
+  if (success) { X = g.X; *status |= NBL_ST_LCP_STAGE0; }
+
+  // ---- stage 1: reduce + Dantzig with early termination (:461-522) ----
+  if (!success) {
+    LcpProblem p;
+    p.A = out.A; p.x = X; p.b = out.b; p.hi = out.hi; p.lo = out.lo; p.findex = out.findex;
+    MatX mapOut = reduceLcp(p);
+    int ok = dantzigSolve(p, true);
+    if (ok == 1) {
+      VecX xr = matvec(mapOut, p.x);
+      X = xr;
+      success = isLCPSolutionValid(aGrad, X, out.b, out.hi, out.lo, out.findex, false);
+      if (success) *status |= NBL_ST_LCP_PIVOT;
+    } else if (ok == -1) {
+      // oracle/_ref not available: behave as a Dantzig failure (goes on to the PGS fallback) and say so
+      *status |= 0x80000000u;
+    }  // on failure mX keeps its pre-solve value (:489 `if (success) mX = mapOut * mXReduced`)
+  }
+  bool nan = false;
+  for (s_t v : X) if (std::isnan(v)) nan = true;
+  if (nan) { success = false; X.assign(mrows, 0.0); *status |= NBL_ST_NAN; }
+
+  MatX ABackup = out.A;
+  if (!success) {
+    cfm = m.fallbackCfm;
+    for (int i = 0; i < mrows; i++) { ABackup(i, i) += cfm; aGrad(i, i) += cfm; }
+  }
+  // ---- stage 2: CFM + PGS (:539-597) ----
+  if (!success) {
+    LcpProblem p;
+    p.A = ABackup; p.x = XBackup; p.b = out.b; p.hi = out.hi; p.lo = out.lo; p.findex = out.findex;
+    MatX mapOut = reduceLcp(p);
+    success = pgsSolve(p);
+    if (success) {
+      X = matvec(mapOut, p.x);
+      if (!isLCPSolutionValid(aGrad, X, out.b, out.hi, out.lo, out.findex, false)) success = false;
+      else *status |= NBL_ST_LCP_PGS;
+    }
+  }
+  // ---- stage 3: drop friction, PGS again (:606-677) ----
+  if (!success) {
+    hadToIgnoreFriction = true;
+    LcpProblem p;
+    p.A = ABackup; p.x = XBackup; p.b = out.b; p.hi = out.hi; p.lo = out.lo; p.findex = out.findex;
+    MatX mapOut = removeFrictionLcp(p);
+    p.x.assign(p.x.size(), 0.0);
+    success = pgsSolve(p);
+    X = matvec(mapOut, p.x);
+    *status |= NBL_ST_LCP_NOFRIC;
+    if (!success) *status |= NBL_ST_LCP_FAILED;
+  }
+  nan = false;
+  for (s_t v : X) if (std::isnan(v)) nan = true;
+  if (nan) { X.assign(mrows, 0.0); *status |= NBL_ST_NAN; }
+
+  // ---- re-register + classify + standardize with the fresh solution (:718-736) ----
+  if (!shortCircuit) {
+    g.X = X; g.A = aGrad; g.cfmConst = cfm; g.ignoreFriction = hadToIgnoreFriction;
+    g.constructMatrices();
+    if (g.standardized) X = g.X;
+  }
+  if (g.standardized) *status |= NBL_ST_STANDARDIZED;
+  out.A = aGrad;
+  out.x = X;
+  out.standardized = g.standardized;
+  lcpCache = X;  // mX persists inside the solver (BoxedLcpConstraintSolver.cpp:176-187)
+
+  // ---- applyImpulse + computeImpulseForwardDynamics (ContactConstraint.cpp:630-684, Skeleton.cpp:13571-13595) ----
+  std::vector<Vec6> imps(m.nb, zero6());
+  bool any = false;
+  for (int r = 0; r < mrows; r++) {
+    const Contact& ct = out.contacts[out.rowContact[r]];
+    if (ct.bodyA >= 0) imps[ct.bodyA] = imps[ct.bodyA] + out.JA[r] * X[r];
+    if (ct.bodyB >= 0) imps[ct.bodyB] = imps[ct.bodyB] + out.JB[r] * X[r];
+    any = true;
+  }
+  if (any) {
+    VecX delV(n, 0.0);
+    impulseDynamics(m, kin, art, imps, delV.data());
+    for (int i = 0; i < n; i++) vOut[i] = vPre[i] + delV[i];
+  }
+  out.status = *status;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward: contact terms of the BackpropSnapshot Jacobians
+// ---------------------------------------------------------------------------------------------
+enum DofContactType { DCT_NONE = 0, DCT_VERTEX, DCT_FACE, DCT_EDGE_A, DCT_EDGE_B, DCT_SELF_COLLISION, DCT_UNSUPPORTED };
+
+// DifferentiableContactConstraint::getDofContactType (DCC.cpp:116-228), box-box contact types only
+inline int dofContactType(const Model& m, const Contact& ct, int dofBody) {
+  bool pa = ct.bodyA >= 0 && dofIsParentOf(m, dofBody, ct.bodyA), pb = ct.bodyB >= 0 && dofIsParentOf(m, dofBody, ct.bodyB);
+  if (pa && pb) return DCT_SELF_COLLISION;
+  if (!pa && !pb) return DCT_NONE;
+  if (pa) {
+    if (ct.type == CT_FACE_VERTEX) return DCT_FACE;
+    if (ct.type == CT_VERTEX_FACE) return DCT_VERTEX;
+    if (ct.type == CT_EDGE_EDGE) return DCT_EDGE_A;
+    return DCT_UNSUPPORTED;
+  }
+  if (ct.type == CT_FACE_VERTEX) return DCT_VERTEX;
+  if (ct.type == CT_VERTEX_FACE) return DCT_FACE;
+  if (ct.type == CT_EDGE_EDGE) return DCT_EDGE_B;
+  return DCT_UNSUPPORTED;
+}
+
+// math::getContactPointGradient (Geometry.cpp:1129-1236) with radiusA = radiusB = 1
+inline Vec3 contactPointGradient(const Vec3& aP, const Vec3& aPg, const Vec3& aD, const Vec3& aDg, const Vec3& bP,
+                                 const Vec3& bPg, const Vec3& bD, const Vec3& bDg) {
+  Vec3 p = bP - aP, d_p = bPg - aPg;
+  s_t uaub = dot(aD, bD), d_uaub = dot(aDg, bD) + dot(aD, bDg);
+  s_t q1 = dot(aD, p), d_q1 = dot(aDg, p) + dot(aD, d_p);
+  s_t q2 = -dot(bD, p), d_q2 = -dot(bDg, p) - dot(bD, d_p);
+  s_t d = 1 - uaub * uaub, d_d = -2 * d_uaub * uaub;
+  if (d <= 0) return 0.5 * (aPg + bPg);
+  s_t e = 1.0 / d, d_e = -(1.0 / (d * d)) * d_d;
+  s_t alpha = (q1 + uaub * q2) * e, d_alpha = (q1 + uaub * q2) * d_e + (d_q1 + d_uaub * q2 + uaub * d_q2) * e;
+  s_t beta = (uaub * q1 + q2) * e, d_beta = (uaub * q1 + q2) * d_e + (d_uaub * q1 + uaub * d_q1 + d_q2) * e;
+  return 0.5 * ((aPg + alpha * aDg + d_alpha * aD) + (bPg + beta * bDg + d_beta * bD));
+}
+
+// ContactConstraint::getTangentBasisMatrixODEGradient (ContactConstraint.cpp:800-876)
+inline void tangentBasisGradient(const Vec3& n, const Vec3& g, Vec3& dt1, Vec3& dt2) {
+  const s_t EPS2 = 1e-12;
+  Vec3 crs = mk3(0, 0, 1);
+  Vec3 tangent = cross(crs, n);
+  if (dot(tangent, tangent) < EPS2) {
+    crs = mk3(1, 0, 0); tangent = cross(crs, n);
+    if (dot(tangent, tangent) < EPS2) {
+      crs = mk3(0, 1, 0); tangent = cross(crs, n);
+      if (dot(tangent, tangent) < EPS2) { crs = mk3(0, 0, 1); tangent = cross(crs, n); }
+    }
+  }
+  s_t tn = norm(tangent);
+  tangent = (1.0 / tn) * tangent;
+  Vec3 gd = (1.0 / tn) * cross(crs, g);
+  Vec3 gradOfTangent = (std::fabs(tn - 1.0) > 1e-6) ? gd - dot(gd, tangent) * tangent : gd;
+  dt1 = gradOfTangent;
+  dt2 = cross(g, tangent) + cross(n, gradOfTangent);
+}
+
+struct ContactGrad {
+  const Model& m;
+  const std::vector<Kin>& kin;
+  const s_t* q;
+  const ContactResult& cr;
+  std::vector<Vec6> axis;     // per dof: Joint::getWorldAxisScrewForVelocity
+  std::vector<Vec6> posTwist; // per dof: Joint::getWorldAxisScrewForPosition
+  std::vector<int> dofBody;
+  ContactGrad(const Model& m_, const std::vector<Kin>& k_, const s_t* q_, const ContactResult& c_) : m(m_), kin(k_), q(q_), cr(c_) {
+    axis.resize(m.n); posTwist.resize(m.n); dofBody.resize(m.n);
+    for (int bi = 0; bi < m.nb; bi++) {
+      const Body& bd = m.bodies[bi];
+      Vec6 H[6];
+      positionJacobian(bd, q, H);
+      for (int k = 0; k < bd.ndof; k++) {
+        axis[bd.dofOff + k] = AdT(kin[bi].Tworld, bd.S[k]);
+        posTwist[bd.dofOff + k] = AdT(kin[bi].Tworld, H[k]);
+        dofBody[bd.dofOff + k] = bi;
+      }
+    }
+  }
+  // getContactPositionGradient (DCC.cpp:328-445)
+  Vec3 positionGradient(const Contact& ct, int dof) const {
+    int type = dofContactType(m, ct, dofBody[dof]);
+    if (type == DCT_FACE || type == DCT_NONE || type == DCT_UNSUPPORTED) return mk3(0, 0, 0);
+    const Vec6& tw = posTwist[dof];
+    Vec3 w = head(tw), v = tail(tw);
+    auto gradTheta = [&](const Vec3& pt) { return (norm(w) > 1e-6) ? cross(w, pt) + v : v; };  // math::gradientWrtTheta(.,.,0)
+    if (type == DCT_VERTEX || type == DCT_SELF_COLLISION) return gradTheta(ct.point);
+    if (type == DCT_EDGE_A)
+      return contactPointGradient(ct.edgeAFixedPoint, gradTheta(ct.edgeAFixedPoint), ct.edgeADir, cross(w, ct.edgeADir),
+                                  ct.edgeBFixedPoint, mk3(0, 0, 0), ct.edgeBDir, mk3(0, 0, 0));
+    return contactPointGradient(ct.edgeAFixedPoint, mk3(0, 0, 0), ct.edgeADir, mk3(0, 0, 0), ct.edgeBFixedPoint,
+                                gradTheta(ct.edgeBFixedPoint), ct.edgeBDir, cross(w, ct.edgeBDir));
+  }
+  // getContactNormalGradient (DCC.cpp:594-735)
+  Vec3 normalGradient(const Contact& ct, int dof) const {
+    int type = dofContactType(m, ct, dofBody[dof]);
+    if (type == DCT_VERTEX || type == DCT_NONE || type == DCT_UNSUPPORTED) return mk3(0, 0, 0);
+    Vec3 w = head(posTwist[dof]);
+    if (type == DCT_FACE || type == DCT_SELF_COLLISION) return cross(w, ct.normal);
+    s_t sign = dot(cross(ct.edgeBDir, ct.edgeADir), ct.normal) < 0 ? -1.0 : 1.0;
+    if (type == DCT_EDGE_A) return sign * cross(ct.edgeBDir, cross(w, ct.edgeADir));
+    return sign * cross(cross(w, ct.edgeBDir), ct.edgeADir);
+  }
+  // getContactForceGradient (DCC.cpp:1092-1111)
+  Vec3 forceGradient(const Contact& ct, int dir, int dof) const {
+    int type = dofContactType(m, ct, dofBody[dof]);
+    if (type == DCT_VERTEX || type == DCT_NONE) return mk3(0, 0, 0);
+    Vec3 ng = normalGradient(ct, dof);
+    if (dir == 0 || dot(ng, ng) <= 1e-12) return ng;
+    Vec3 d1, d2;
+    tangentBasisGradient(ct.normal, ng, d1, d2);
+    return dir == 1 ? d1 : d2;
+  }
+  // getContactWorldForceGradient (DCC.cpp:1115-1128)
+  Vec6 worldForceGradient(int row, int dof) const {
+    const Contact& ct = cr.contacts[cr.rowContact[row]];
+    Vec3 fg = forceGradient(ct, cr.rowDir[row], dof), pg = positionGradient(ct, dof);
+    return mk6(cross(ct.point, fg) + cross(pg, cr.dirs[row]), fg);
+  }
+  // getScrewAxisForForceGradient (DCC.cpp:1226-1316). The FreeJoint intra-joint branch
+  // (FreeJoint.cpp:1195-1237) is the same derivative d/dq_l [Ad(T_world(child)) S_i] = ad(s_l^pos, s_i)
+  // written out explicitly, so one expression covers both.
+  Vec6 screwAxisGradient(int screwDof, int rotateDof) const {
+    int bs = dofBody[screwDof], br = dofBody[rotateDof];
+    if (bs == br) {
+      if (m.bodies[bs].ndof == 1) return zero6();
+    } else if (!dofIsParentOf(m, br, bs)) return zero6();
+    return ad(posTwist[rotateDof], axis[screwDof]);
+  }
+  s_t multiple(int row, int dof) const {
+    const Contact& ct = cr.contacts[cr.rowContact[row]];
+    bool pa = ct.bodyA >= 0 && dofIsParentOf(m, dofBody[dof], ct.bodyA), pb = ct.bodyB >= 0 && dofIsParentOf(m, dofBody[dof], ct.bodyB);
+    return (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
+  }
+  // getConstraintForcesJacobian (DCC.cpp:1505-1649, the "slow, but known to be correct version")
+  MatX constraintForcesJacobian(int row) const {
+    const int n = m.n;
+    MatX J(n, n);
+    const Contact& ct = cr.contacts[cr.rowContact[row]];
+    Vec6 F = mk6(cross(ct.point, cr.dirs[row]), cr.dirs[row]);
+    std::vector<Vec6> fg(n);
+    for (int wrt = 0; wrt < n; wrt++) fg[wrt] = worldForceGradient(row, wrt);
+    for (int r = 0; r < n; r++) {
+      s_t mult = multiple(row, r);
+      if (mult == 0.0) continue;
+      for (int wrt = 0; wrt < n; wrt++) J(r, wrt) = mult * (dot(screwAxisGradient(r, wrt), F) + dot(axis[r], fg[wrt]));
+    }
+    return J;
+  }
+};
+
+inline MatX pinvCod(const MatX& Q) {
+  const int n = Q.r;
+  MatX P(Q.c, n);
+  for (int k = 0; k < n; k++) {
+    VecX e(n, 0.0);
+    e[k] = 1.0;
+    VecX x = codSolve(Q, e);
+    for (int i = 0; i < Q.c; i++) P(i, k) = x[i];
+  }
+  return P;
+}
+inline MatX codSolveMat(const MatX& Q, const MatX& B) {
+  MatX X(Q.c, B.c);
+  for (int k = 0; k < B.c; k++) {
+    VecX b(B.r);
+    for (int i = 0; i < B.r; i++) b[i] = B(i, k);
+    VecX x = codSolve(Q, b);
+    for (int i = 0; i < Q.c; i++) X(i, k) = x[i];
+  }
+  return X;
+}
+inline MatX addX(const MatX& a, const MatX& b, s_t sb = 1.0) { MatX o = a; for (size_t i = 0; i < o.d.size(); i++) o.d[i] += sb * b.d[i]; return o; }
+inline MatX scaleX(const MatX& a, s_t s) { MatX o = a; for (auto& v : o.d) v *= s; return o; }
+
+// getControlForceVelJacobian / getVelVelJacobian / getPosVelJacobian with clamping constraints
+// (BackpropSnapshot.cpp:482-574, 643-759, 762-821, 980-1066, 2723-2774, 2889-3039, 3088-3146, 3657-3747)
 inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art, const s_t* q,
-                             const s_t* v, const s_t* tau, const ContactResult& cr, const MatX& Minv, const VecX& C,
-                             const MatX& dCdq, const MatX& dCdv, MatX& forceVel, MatX& velVel, MatX& posVel) {
-  (void)m; (void)kin; (void)art; (void)q; (void)v; (void)tau; (void)cr; (void)Minv; (void)C; (void)dCdq; (void)dCdv;
-  (void)forceVel; (void)velVel; (void)posVel;
+                             const s_t* v, const s_t* tau, const VecX& vPre, const ContactResult& cr, const MatX& Minv,
+                             const VecX& C, const MatX& dCdq, const MatX& dCdv, MatX& forceVel, MatX& velVel, MatX& posVel) {
+  (void)art;
+  const int n = m.n, nc = cr.numClamping, nu = cr.numUpperBound, mrows = cr.m;
+  const s_t dt = m.dt;
+  ContactGrad cg(m, kin, q, cr);
+  MatX Ac(n, nc), Aub(n, nu);
+  std::vector<int> clampRows(nc), ubRows(nu);
+  for (int j = 0; j < mrows; j++) {
+    if (cr.rowClass[j] == RC_CLAMPING) { clampRows[cr.clampingIndex[j]] = j; for (int i = 0; i < n; i++) Ac(i, cr.clampingIndex[j]) = cr.Aall(i, j); }
+    if (cr.rowClass[j] == RC_UPPER_BOUND) { ubRows[cr.upperBoundIndex[j]] = j; for (int i = 0; i < n; i++) Aub(i, cr.upperBoundIndex[j]) = cr.Aall(i, j); }
+  }
+  const MatX& E = cr.E;
+  MatX AcubE = nu > 0 ? addX(Ac, matmul(Aub, E)) : Ac;
+  const VecX& f_c = cr.fc;
+  MatX D(n, n), K(n, n);
+  for (int i = 0; i < n; i++) { D(i, i) = m.damping[i]; K(i, i) = m.spring[i]; }
+  MatX I = identityX(n);
+  MatX AcT = transposeX(Ac);
+
+  // per-row constraint-force Jacobians (cached like mWorldConstraintJacCache)
+  std::vector<MatX> rowJac(mrows);
+  for (int j = 0; j < mrows; j++) if (cr.rowClass[j] == RC_CLAMPING || cr.rowClass[j] == RC_UPPER_BOUND) rowJac[j] = cg.constraintForcesJacobian(j);
+  auto jacClamping = [&](const VecX& f0) { MatX r(n, n); for (int i = 0; i < nc; i++) r = addX(r, rowJac[clampRows[i]], f0[i]); return r; };
+  auto jacClampingT = [&](const VecX& v0) { MatX r(nc, n); for (int i = 0; i < nc; i++) { VecX row = matTvec(rowJac[clampRows[i]], v0); for (int k = 0; k < n; k++) r(i, k) = row[k]; } return r; };
+  auto jacUpper = [&](const VecX& Ef0) { MatX r(n, n); for (int i = 0; i < nu; i++) r = addX(r, rowJac[ubRows[i]], Ef0[i]); return r; };
+  auto jacUpperT = [&](const VecX& v0) { MatX r(nu, n); for (int i = 0; i < nu; i++) { VecX row = matTvec(rowJac[ubRows[i]], v0); for (int k = 0; k < n; k++) r(i, k) = row[k]; } return r; };
+  // getJacobianOfMinv(f, POSITION) = -Minv * d(M (Minv f))/dq   (Skeleton.cpp:2025-2082)
+  auto jacMinv = [&](const VecX& f) { VecX w = matvec(Minv, f); return scaleX(matmul(Minv, jacobianOfMx(m, kin, q, w.data())), -1.0); };
+
+  // Q and its factorisation
+  MatX Q = matmul(AcT, matmul(Minv, AcubE));
+  for (int i = 0; i < nc; i++) Q(i, i) += cr.cfm;
+  VecX bvec(nc);
+  for (int i = 0; i < nc; i++) bvec[i] = cr.b[clampRows[i]];
+
+  // ---- dB for the three wrts (getJacobianOfLCPOffsetClampingSubset; bounce diagonals = 1) ----
+  MatX dvPre_dv = addX(I, scaleX(matmul(Minv, addX(addX(dCdv, D), K, dt)), dt), -1.0);
+  MatX dB_vel = scaleX(matmul(AcT, dvPre_dv), -1.0);
+  MatX dB_force = scaleX(matmul(AcT, Minv), -dt);
+  VecX f(n);
+  for (int i = 0; i < n; i++) f[i] = tau[i] - C[i] - m.damping[i] * v[i] - m.spring[i] * (q[i] - m.rest[i] + dt * v[i]);
+  MatX dMinv_f = jacMinv(f);
+  MatX dAcT_vf = jacClampingT(vPre);
+  MatX inner = addX(addX(dMinv_f, matmul(Minv, dCdq), -1.0), matmul(Minv, K), -1.0);
+  MatX dB_pos = scaleX(addX(dAcT_vf, scaleX(matmul(AcT, inner), dt)), -1.0);
+
+  // ---- dF_c (getJacobianOfConstraintForce) ----
+  MatX dFc_vel = codSolveMat(Q, dB_vel), dFc_force = codSolveMat(Q, dB_force);
+  // dQ_b for POSITION (getJacobianOfLCPConstraintMatrixClampingSubset)
+  MatX Qinv = pinvCod(Q);
+  auto dQ = [&](const VecX& rhs) {
+    VecX Ar = matvec(AcubE, rhs);
+    MatX t1 = jacClampingT(matvec(Minv, Ar));
+    MatX in2 = jacClamping(rhs);
+    if (nu > 0) in2 = addX(in2, jacUpper(matvec(E, rhs)));
+    MatX t2 = matmul(AcT, addX(jacMinv(Ar), matmul(Minv, in2)));
+    return addX(t1, t2);
+  };
+  auto dQT = [&](const VecX& rhs) {
+    if (nu == 0) return dQ(rhs);
+    VecX Ar = matvec(Ac, rhs);
+    VecX MAr = matvec(Minv, Ar);
+    MatX jm = jacMinv(Ar);
+    MatX jc = jacClamping(rhs);
+    MatX first = addX(jacClampingT(MAr), matmul(AcT, addX(jm, matmul(Minv, jc))));
+    MatX second = matmul(transposeX(E), addX(jacUpperT(MAr), matmul(transposeX(Aub), addX(jm, matmul(Minv, jc)))));
+    return addX(first, second);
+  };
+  VecX Qinv_b = codSolve(Q, bvec);
+  MatX imprecision = addX(identityX(nc), matmul(Q, Qinv), -1.0);
+  s_t impNorm2 = 0;
+  for (s_t x : imprecision.d) impNorm2 += x * x;
+  MatX dQ_b = scaleX(codSolveMat(Q, dQ(Qinv_b)), -1.0);
+  if (!(impNorm2 < 1e-18)) {
+    VecX ib = matvec(imprecision, bvec);
+    dQ_b = addX(dQ_b, codSolveMat(Q, matmul(transposeX(Qinv), dQT(ib))));
+    MatX IQQ = addX(identityX(nc), matmul(Qinv, Q), -1.0);
+    VecX t = matvec(transposeX(Qinv), Qinv_b);
+    dQ_b = addX(dQ_b, matmul(IQQ, dQT(t)));
+  }
+  MatX dFc_pos = addX(dQ_b, codSolveMat(Q, dB_pos));
+
+  // ---- getVelJacobianWrt (:980-1066) ----
+  forceVel = matmul(Minv, addX(matmul(AcubE, dFc_force), scaleX(I, dt)));
+  MatX velJacVel = addX(I, matmul(Minv, addX(matmul(AcubE, dFc_vel), scaleX(dCdv, dt), -1.0)));
+  velVel = addX(addX(velJacVel, scaleX(matmul(Minv, D), dt), -1.0), scaleX(matmul(Minv, K), dt * dt), -1.0);
+  VecX r(n);
+  VecX Af = matvec(AcubE, f_c);
+  for (int i = 0; i < n; i++) r[i] = dt * f[i] + Af[i];
+  MatX dM = jacMinv(r);
+  MatX dA_c = jacClamping(f_c);
+  MatX dA_ubE(n, n);
+  if (nu > 0) dA_ubE = jacUpper(matvec(E, f_c));
+  MatX innerP = addX(addX(addX(matmul(AcubE, dFc_pos), dA_c), dA_ubE), scaleX(dCdq, dt), -1.0);
+  posVel = addX(addX(dM, matmul(Minv, innerP)), scaleX(matmul(Minv, K), dt), -1.0);
 }
 
 }  // namespace nbo

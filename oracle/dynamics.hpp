@@ -267,7 +267,7 @@ inline void forwardDynamics(const Model& m, const std::vector<Kin>& kin, const s
 //  GenericJoint.hpp:2482-2498, 2607-2613, 2713-2725).  impulses[i] is the constraint impulse on body i
 // expressed in its own frame (BodyNode::mConstraintImpulse).  Returns delta joint velocities.
 inline void impulseDynamics(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art,
-                            const std::vector<Vec6>& impulses, s_t* delV) {
+                            const std::vector<Vec6>& impulses, s_t* delV, std::vector<Vec6>* bodyDelV = nullptr) {
   std::vector<Vec6> bias(m.nb), dV(m.nb);
   std::vector<s_t> total(m.n > 0 ? m.n : 1);
   for (int i = m.nb - 1; i >= 0; i--) {
@@ -304,6 +304,7 @@ inline void impulseDynamics(const Model& m, const std::vector<Kin>& kin, const s
     }
     dV[i] = D;
   }
+  if (bodyDelV) *bodyDelV = dV;
 }
 
 // Recursive Newton-Euler inverse dynamics  tau = M(q) a + C(q, v)  (gravity optional).

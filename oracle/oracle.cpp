@@ -105,8 +105,8 @@ void backpropWorld(Oracle& o, const s_t* gqNext, const s_t* gvNext, s_t* gq, s_t
         posVel(i, j) = -dM(i, j) - dt * MinvdCdq(i, j) - dt * Minv(i, j) * m.spring[j];
       }
   } else {
-    contactJacobians(m, kin, art, s.q.data(), s.v.data(), s.tau.data(), cr, Minv, C, dCdq, dCdv, forceVel, velVel,
-                     posVel);
+    contactJacobians(m, kin, art, s.q.data(), s.v.data(), s.tau.data(), s.vPre, cr, Minv, C, dCdq, dCdv, forceVel,
+                     velVel, posVel);
   }
 
   VecX gqn(gqNext, gqNext + n), gvn(gvNext, gvNext + n);
