@@ -58,6 +58,8 @@ extern "C" {
 #define NBL_ST_NAN 0x40u          /* non-finite value seen */
 #define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts than max_contacts; extra ones dropped */
 #define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
+#define NBL_ST_GRAD_PARTIAL 0x200u /* an EDGE_EDGE contact is present: its contact-geometry gradient terms
+                                      (DCC.cpp:397-424, 700-735) are not evaluated by the device backward yet */
 
 /*
  * Model description.  One model is shared by all B worlds of a batch; worlds differ only in

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevCo
   Ctx c;
   c.ws = ws; c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n;
   int nC = 0;
-  bool overflow = false;
+  bool overflow = false, edge = false;
   for (int pi = 0; pi < cm->nPairs; pi++) {
     const DevBox& ba = cm->boxes[cm->pairA[pi]];
     const DevBox& bb = cm->boxes[cm->pairB[pi]];
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevCo
       svAt(saved, r0 + CR_BOXA, B, b) = (double)cm->pairA[pi];
       svAt(saved, r0 + CR_BOXB, B, b) = (double)cm->pairB[pi];
       st3(CR_EA_FIXED, ct.edgeAFixed); st3(CR_EA_DIR, ct.edgeADir); st3(CR_EB_FIXED, ct.edgeBFixed); st3(CR_EB_DIR, ct.edgeBDir);
+      if (ct.type == CT_EDGE_EDGE) edge = true;
       nC++;
     }
   }
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevCo
   uint32_t st = 0;
   if (nC > 0) st |= 0x1u;
   if (overflow) st |= 0x80u;
+  if (edge) st |= 0x200u;   // NBL_ST_GRAD_PARTIAL: edge-edge contact geometry terms are not in the device backward yet
   if (status) status[b] = st;
 }
 

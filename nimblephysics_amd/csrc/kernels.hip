@@ -311,35 +311,22 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward kernel
+// Backward building blocks
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBody* __restrict__ bodies,
-                                                      const DevDof* __restrict__ dofs, int64_t B,
-                                                      const double* __restrict__ saved, const double* __restrict__ gnext,
-                                                      double* __restrict__ gstate, double* __restrict__ gaction,
-                                                      double* __restrict__ ws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
-  const int n = mdl.n;
-  const double* q = saved;
-  const double* v = saved + (int64_t)n * B;
-  const double* tau = saved + (int64_t)2 * n * B;
-  const double* gqn = gnext;
-  const double* gvn = gnext + (int64_t)n * B;
-  double* gq = gstate;
-  double* gv = gstate + (int64_t)n * B;
-  auto tauAt = [&](int d) -> double { return tau[(int64_t)d * B + b]; };
-  auto emit = [&](int, double) {};
-  abaSweeps<true>(c, q, v, tauAt, emit);
-
-  // ---- sweep 4 (leaf->root): joint-space impulse dt*gv' pushed up the tree ----
+// lambda = M^-1 rhs using the articulated inertias left in the workspace by abaSweeps: leaf->root
+// impulse sweep then root->leaf sweep (same recursion as Skeleton::updateInvMassMatrix,
+// Skeleton.cpp:12573-12660).  Leaves lambda per DOF in WS_UIMP (+k) of its body and the body twists
+// W_i = X W_parent + S lambda_i in WS_W.
+template <class RhsFn>
+DEV void minvSweeps(const Ctx& c, RhsFn rhsAt) {
+  const DevBody* bodies = c.bodies;
+  for (int i = 0; i < c.nb; i++) zeroN(c, i, WS_BIMP, 6);
   for (int i = c.nb - 1; i >= 0; i--) {
     const DevBody& bd = bodies[i];
     V6 Bi = ldV6(c, i, WS_BIMP);
     if (bd.jtype != JT_FREE) {
       const int d = bd.dofOff;
-      double uimp = c.dt * gvn[(int64_t)d * B + b] - dot(cV6(bd.S), Bi);
+      double uimp = rhsAt(d) - dot(cV6(bd.S), Bi);
       wsAt(c, i, WS_UIMP) = uimp;
       if (bd.parent >= 0) {
         V6 beta = Bi + (wsAt(c, i, WS_PSI) * uimp) * ldV6(c, i, WS_AIS);
@@ -349,10 +336,9 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
       double pj[6];
       toArr(dAdT(cT(bd.Tcj), Bi), pj);
 #pragma unroll
-      for (int k = 0; k < 6; k++) wsAt(c, i, WS_UIMP + k) = c.dt * gvn[(int64_t)(bd.dofOff + k) * B + b] - pj[k];
+      for (int k = 0; k < 6; k++) wsAt(c, i, WS_UIMP + k) = rhsAt(bd.dofOff + k) - pj[k];
     }
   }
-  // ---- sweep 5 (root->leaf): lambda = M^-1 (dt gv'), W_i = X W_parent + S lambda_i ----
   for (int i = 0; i < c.nb; i++) {
     const DevBody& bd = bodies[i];
     T12 T = ldT(c, i);
@@ -380,7 +366,30 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
     }
     stV6(c, i, WS_W, W);
   }
-  // ---- sweep 6 (leaf->root): reverse-mode Newton-Euler + per-DOF epilogue ----
+}
+
+// Position-space Jacobian transpose of joint i applied to a body-frame adjoint xi:  H_i^T xi
+// (H = S for 1-DOF joints; free joint: Ad(T_cj) blkdiag(expMapJac(r)^T, R^T), FreeJoint.cpp:790-823)
+DEV void applyHt(const DevBody& bd, const double* __restrict__ q, int64_t B, int64_t b, V6 xi, double* out) {
+  if (bd.jtype != JT_FREE) { out[0] = dot(cV6(bd.S), xi); return; }
+  const int o = bd.dofOff;
+  V6 y = dAdT(cT(bd.Tcj), xi);
+  V3 r = mk3(q[(o + 0) * B + b], q[(o + 1) * B + b], q[(o + 2) * B + b]);
+  V3 qbr = mul(expMapJac(r), y.w), qbp = mul(expMapRot(r), y.v);
+  out[0] = qbr.x; out[1] = qbr.y; out[2] = qbr.z; out[3] = qbp.x; out[4] = qbp.y; out[5] = qbp.z;
+}
+
+// Reverse-mode Newton-Euler sweep at (q, v, qdd) with joint adjoint lambda (WS_UIMP/WS_W from
+// minvSweeps) + the per-DOF epilogue.  gvAt(d): cotangent of the pre-contact velocity;
+// qExtraAt(d): additional position cotangent from the contact stage (0 without contact).
+template <class GvFn, class QxFn>
+DEV void reverseSweep(const Ctx& c, const double* __restrict__ q, const double* __restrict__ v,
+                      const double* __restrict__ tau, const double* __restrict__ gqn, GvFn gvAt, QxFn qExtraAt,
+                      double* __restrict__ gq, double* __restrict__ gv, double* __restrict__ gaction) {
+  const DevBody* bodies = c.bodies;
+  const DevDof* dofs = c.dofs;
+  const int64_t B = c.B, b = c.b;
+  for (int i = 0; i < c.nb; i++) zeroN(c, i, WS_FACC, 18);
   const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
   for (int i = c.nb - 1; i >= 0; i--) {
     const DevBody& bd = bodies[i];
@@ -403,36 +412,19 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
       addV6(c, bd.parent, WS_VBAR, dAdInvT(T, Vbar));
     }
     V6 xi = dad(XWp, F) + dad(XAp, Abar) + dad(XVp, Vbar);          // adjoint of the joint transform, body frame
+    double qb[6], vb[6], pp[6], vp[6];
+    applyHt(bd, q, B, b, xi, qb);
+    const int o = bd.dofOff;
     if (bd.jtype != JT_FREE) {
-      const int d = bd.dofOff;
-      const DevDof& df = dofs[d];
-      V6 S = cV6(bd.S);
-      double lam = wsAt(c, i, WS_UIMP);
-      double vbar = dot(S, tmp), qbar = dot(S, xi);
-      double gqd = gqn[(int64_t)d * B + b], gvd = gvn[(int64_t)d * B + b];
-      double gt = lam;
-      double gvo = gvd + c.dt * gqd - (vbar + df.damping * lam + c.dt * df.spring * lam);
-      double gqo = gqd - (qbar + df.spring * lam);
-      // clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479)
-      double qd = q[(int64_t)d * B + b], vd = v[(int64_t)d * B + b], td = tau[(int64_t)d * B + b];
-      if ((qd == df.posLo && gqo > 0) || (qd == df.posHi && gqo < 0)) gqo = 0;
-      if ((vd == df.velLo && gvo > 0) || (vd == df.velHi && gvo < 0)) gvo = 0;
-      if ((td == df.forceLo && gt > 0) || (td == df.forceHi && gt < 0)) gt = 0;
-      gq[(int64_t)d * B + b] = gqo;
-      gv[(int64_t)d * B + b] = gvo;
-      if (df.actionIndex >= 0) gaction[(int64_t)df.actionIndex * B + b] = gt;
+      vb[0] = dot(cV6(bd.S), tmp);
+      pp[0] = gqn[(int64_t)o * B + b];            // posPos = 1, velPos = dt  (GenericJoint.hpp:1428-1444)
+      vp[0] = c.dt * pp[0];
     } else {
-      const int o = bd.dofOff;
-      double vb[6], yb[6];
       toArr(dAdT(cT(bd.Tcj), tmp), vb);
-      V6 y = dAdT(cT(bd.Tcj), xi);
       V3 r = mk3(q[(o + 0) * B + b], q[(o + 1) * B + b], q[(o + 2) * B + b]);
       V3 w = mk3(v[(o + 0) * B + b], v[(o + 1) * B + b], v[(o + 2) * B + b]);
       V3 vl = mk3(v[(o + 3) * B + b], v[(o + 4) * B + b], v[(o + 5) * B + b]);
       M3 R = expMapRot(r);
-      // position-space Jacobian of the free joint: H = Ad(T_cj) blkdiag(expMapJac(r)^T, R^T)  (FreeJoint.cpp:790-823)
-      V3 qbr = mul(expMapJac(r), y.w), qbp = mul(R, y.v);
-      yb[0] = qbr.x; yb[1] = qbr.y; yb[2] = qbr.z; yb[3] = qbp.x; yb[4] = qbp.y; yb[5] = qbp.z;
       // VJP of q' = [logMap(R E); p + R vl dt]  (exact reverse-mode of FreeJoint.cpp:922-929; the
       // reference differentiates the same expression by central differences, :950-1007)
       V3 grn = mk3(gqn[(o + 0) * B + b], gqn[(o + 1) * B + b], gqn[(o + 2) * B + b]);
@@ -443,33 +435,57 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
       M3 Rb = mulABt(Rnb, E);                 // dL/dR from R' = R E
       M3 Eb = mulAtB(R, Rnb);
       V3 vdt = c.dt * vl;
-      // p' = p + R vdt  ->  dL/dR += gpn vdt^T
-      Rb.m[0] += gpn.x * vdt.x; Rb.m[1] += gpn.x * vdt.y; Rb.m[2] += gpn.x * vdt.z;
+      Rb.m[0] += gpn.x * vdt.x; Rb.m[1] += gpn.x * vdt.y; Rb.m[2] += gpn.x * vdt.z;   // p' = p + R vdt
       Rb.m[3] += gpn.y * vdt.x; Rb.m[4] += gpn.y * vdt.y; Rb.m[5] += gpn.y * vdt.z;
       Rb.m[6] += gpn.z * vdt.x; Rb.m[7] += gpn.z * vdt.y; Rb.m[8] += gpn.z * vdt.z;
       V3 posr = expMapRot_vjp(r, Rb);
       V3 velw = c.dt * expMapRot_vjp(c.dt * w, Eb);
       V3 vell = c.dt * tmul(R, gpn);
-      double pp[6] = {posr.x, posr.y, posr.z, gpn.x, gpn.y, gpn.z};     // posPos^T gq'
-      double vp[6] = {velw.x, velw.y, velw.z, vell.x, vell.y, vell.z};  // velPos^T gq'
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const int d = o + k;
-        const DevDof& df = dofs[d];
-        double lam = wsAt(c, i, WS_UIMP + k);
-        double gt = lam;
-        double gvo = gvn[(int64_t)d * B + b] + vp[k] - (vb[k] + df.damping * lam + c.dt * df.spring * lam);
-        double gqo = pp[k] - (yb[k] + df.spring * lam);
-        double qd = q[(int64_t)d * B + b], vd = v[(int64_t)d * B + b], td = tau[(int64_t)d * B + b];
-        if ((qd == df.posLo && gqo > 0) || (qd == df.posHi && gqo < 0)) gqo = 0;
-        if ((vd == df.velLo && gvo > 0) || (vd == df.velHi && gvo < 0)) gvo = 0;
-        if ((td == df.forceLo && gt > 0) || (td == df.forceHi && gt < 0)) gt = 0;
-        gq[(int64_t)d * B + b] = gqo;
-        gv[(int64_t)d * B + b] = gvo;
-        if (df.actionIndex >= 0) gaction[(int64_t)df.actionIndex * B + b] = gt;
-      }
+      pp[0] = posr.x; pp[1] = posr.y; pp[2] = posr.z; pp[3] = gpn.x; pp[4] = gpn.y; pp[5] = gpn.z;   // posPos^T gq'
+      vp[0] = velw.x; vp[1] = velw.y; vp[2] = velw.z; vp[3] = vell.x; vp[4] = vell.y; vp[5] = vell.z;   // velPos^T gq'
+    }
+    for (int k = 0; k < bd.ndof; k++) {
+      const int d = o + k;
+      const DevDof& df = dofs[d];
+      double lam = wsAt(c, i, WS_UIMP + k);
+      double gt = lam;
+      double gvo = gvAt(d) + vp[k] - (vb[k] + df.damping * lam + c.dt * df.spring * lam);
+      double gqo = pp[k] - (qb[k] + df.spring * lam) + qExtraAt(d);
+      // clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479)
+      double qd = q[(int64_t)d * B + b], vd = v[(int64_t)d * B + b], td = tau[(int64_t)d * B + b];
+      if ((qd == df.posLo && gqo > 0) || (qd == df.posHi && gqo < 0)) gqo = 0;
+      if ((vd == df.velLo && gvo > 0) || (vd == df.velHi && gvo < 0)) gvo = 0;
+      if ((td == df.forceLo && gt > 0) || (td == df.forceHi && gt < 0)) gt = 0;
+      gq[(int64_t)d * B + b] = gqo;
+      gv[(int64_t)d * B + b] = gvo;
+      if (df.actionIndex >= 0) gaction[(int64_t)df.actionIndex * B + b] = gt;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward kernel (no clamping contact constraints in the whole batch model)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                      const DevDof* __restrict__ dofs, int64_t B,
+                                                      const double* __restrict__ saved, const double* __restrict__ gnext,
+                                                      double* __restrict__ gstate, double* __restrict__ gaction,
+                                                      double* __restrict__ ws) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
+  const int n = mdl.n;
+  const double* q = saved;
+  const double* v = saved + (int64_t)n * B;
+  const double* tau = saved + (int64_t)2 * n * B;
+  const double* gqn = gnext;
+  const double* gvn = gnext + (int64_t)n * B;
+  auto tauAt = [&](int d) -> double { return tau[(int64_t)d * B + b]; };
+  auto emit = [&](int, double) {};
+  abaSweeps<true>(c, q, v, tauAt, emit);
+  auto gvAt = [&](int d) -> double { return gvn[(int64_t)d * B + b]; };
+  minvSweeps(c, [&](int d) -> double { return c.dt * gvn[(int64_t)d * B + b]; });
+  reverseSweep(c, q, v, tau, gqn, gvAt, [](int) -> double { return 0.0; }, gstate, gstate + (int64_t)n * B, gaction);
 }
 
 // [B][d] <-> [d][B] transposes through LDS (the Python surface stacks the reference's 1-D state

@@ -14,6 +14,7 @@
 #include "../../include/nimble_amd.h"
 #include "kernels.hip"
 #include "contact_kernels.hip"
+#include "contact_backward.hip"
 
 using namespace nbl;
 
@@ -157,6 +158,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (d->n_boxes > MAX_BOXES) return fail(NBL_E_UNSUPPORTED, "too many box colliders for the device path");
     if (d->max_contacts > MAX_CONTACTS) return fail(NBL_E_UNSUPPORTED, "max_contacts above 8 is not supported by the device path yet");
     if (d->n_bodies > 64) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 64 bodies");
+    if (d->n_dofs > MAX_DOF_CONTACT) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 40 DOFs");
     hc.nBoxes = d->n_boxes;
     hc.maxContacts = d->max_contacts;
     hc.clippingDepth = d->contact_clipping_depth;
@@ -237,7 +239,7 @@ int32_t nbl_model_lcp_rows(const nbl_model* m) { return (m && m->hasContact) ? M
 
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
-  return ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LW_TOTAL : 0)) * sizeof(double) * (size_t)B;
+  return ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LB_TOTAL : 0)) * sizeof(double) * (size_t)B;
 }
 size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
@@ -292,8 +294,21 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((B + 63) / 64)), block(64);
   beginTiming(m, s, true);
-  hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
-                     grad_next_state, grad_state, grad_action, (double*)workspace);
+  if (!m->hasContact) {
+    hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+                       grad_next_state, grad_state, grad_action, (double*)workspace);
+  } else {
+    double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
+    double* sv = (double*)const_cast<void*>(saved);
+    hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+                       (double*)workspace);
+    hipLaunchKernelGGL(k_bwd_contact_a, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv, m->lay,
+                       grad_next_state, (double*)workspace, lws);
+    hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv, m->lay,
+                       (double*)workspace, lws, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+                       grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws);
+  }
   endTiming(m, s);
   HIP_TRY(hipGetLastError());
   return NBL_OK;
