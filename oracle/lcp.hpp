@@ -209,10 +209,8 @@ inline MatX removeFrictionLcp(LcpProblem& p) {
 }
 
 // ---- PgsBoxedLcpSolver::solve (PgsBoxedLcpSolver.cpp:79-268) with Option(30, 1e-6, 1e-3, 1e-9, false) ----
-inline bool pgsSolve(LcpProblem& p) {
+inline bool pgsSolve(LcpProblem& p, int maxIteration = 30, s_t deltaXThreshold = 1e-6, s_t relTol = 1e-3, s_t epsDiv = 1e-9) {
   const int n = (int)p.x.size();
-  const int maxIteration = 30;
-  const s_t deltaXThreshold = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
   MatX& A = p.A;
   VecX &x = p.x, &b = p.b, &lo = p.lo, &hi = p.hi;
   std::vector<int>& findex = p.findex;

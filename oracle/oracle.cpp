@@ -314,4 +314,76 @@ int nbo_last_lcp(void* h, double* A, double* b, double* x, double* lo, double* h
   }
   return mrows;
 }
+
+// ---- direct access to the collision / LCP building blocks for the fixture tests ----
+int nbo_box_box(const double* T1, const double* size1, const double* T2, const double* size2, double clip,
+                double* out /* [8][22]: point normal depth type edgeAFixed edgeADir edgeBFixed edgeBDir */) {
+  std::vector<Contact> cs;
+  Vec3 h1 = mk3(0.5 * size1[0], 0.5 * size1[1], 0.5 * size1[2]), h2 = mk3(0.5 * size2[0], 0.5 * size2[1], 0.5 * size2[2]);
+  int n = boxBox(loadIso(T1), h1, loadIso(T2), h2, clip, cs);
+  for (int i = 0; i < n && i < 8; i++) {
+    double* r = out + 22 * i;
+    const Contact& c = cs[i];
+    for (int k = 0; k < 3; k++) {
+      r[k] = c.point[k]; r[3 + k] = c.normal[k]; r[8 + k] = c.edgeAFixedPoint[k]; r[11 + k] = c.edgeADir[k];
+      r[14 + k] = c.edgeBFixedPoint[k]; r[17 + k] = c.edgeBDir[k];
+    }
+    r[6] = c.depth; r[7] = c.type;
+  }
+  return n;
+}
+static LcpProblem mkProblem(int n, const double* A, const double* x, const double* b, const double* lo, const double* hi,
+                            const int32_t* findex) {
+  LcpProblem p;
+  p.A = MatX(n, n);
+  for (int i = 0; i < n * n; i++) p.A.d[i] = A[i];
+  p.x.assign(x, x + n); p.b.assign(b, b + n); p.lo.assign(lo, lo + n); p.hi.assign(hi, hi + n);
+  p.findex.assign(findex, findex + n);
+  return p;
+}
+int nbo_lcp_valid(int n, const double* A, const double* x, const double* b, const double* lo, const double* hi,
+                  const int32_t* findex, int ignoreFriction) {
+  LcpProblem p = mkProblem(n, A, x, b, lo, hi, findex);
+  return isLCPSolutionValid(p.A, p.x, p.b, p.hi, p.lo, p.findex, ignoreFriction != 0) ? 1 : 0;
+}
+void nbo_lcp_guess(int n, const double* A, const double* b, const int32_t* findex, double* x) {
+  MatX Am(n, n);
+  for (int i = 0; i < n * n; i++) Am.d[i] = A[i];
+  VecX g = guessSolution(Am, VecX(b, b + n), std::vector<int>(findex, findex + n));
+  for (int i = 0; i < n; i++) x[i] = g[i];
+}
+int nbo_lcp_pgs(int n, const double* A, double* x, const double* b, const double* lo, const double* hi, const int32_t* findex,
+                int maxIter, double dx, double rel, double eps) {
+  LcpProblem p = mkProblem(n, A, x, b, lo, hi, findex);
+  bool ok = pgsSolve(p, maxIter, dx, rel, eps);
+  for (int i = 0; i < n; i++) x[i] = p.x[i];
+  return ok ? 1 : 0;
+}
+int nbo_lcp_dantzig(int n, const double* A, double* x, const double* b, const double* lo, const double* hi,
+                    const int32_t* findex, int early) {
+  LcpProblem p = mkProblem(n, A, x, b, lo, hi, findex);
+  int ok = dantzigSolve(p, early != 0);
+  for (int i = 0; i < n; i++) x[i] = p.x[i];
+  return ok;
+}
+// reduce / removeFriction: returns reduced size; outputs reduced problem and mapOut [n][nr]
+int nbo_lcp_reduce(int n, const double* A, const double* x, const double* b, const double* lo, const double* hi,
+                   const int32_t* findex, int removeFriction, double* Ar, double* xr, double* br, double* lor, double* hir,
+                   int32_t* fr, double* mapOut) {
+  LcpProblem p = mkProblem(n, A, x, b, lo, hi, findex);
+  MatX mo = removeFriction ? removeFrictionLcp(p) : reduceLcp(p);
+  int nr = (int)p.x.size();
+  for (int i = 0; i < nr * nr; i++) Ar[i] = p.A.d[i];
+  for (int i = 0; i < nr; i++) { xr[i] = p.x[i]; br[i] = p.b[i]; lor[i] = p.lo[i]; hir[i] = p.hi[i]; fr[i] = p.findex[i]; }
+  for (int i = 0; i < n * nr; i++) mapOut[i] = mo.d[i];
+  return nr;
+}
+int nbo_cod_solve(int rows, int cols, const double* A, const double* b, double* x) {
+  MatX Am(rows, cols);
+  for (int i = 0; i < rows * cols; i++) Am.d[i] = A[i];
+  int rank = 0;
+  VecX r = codSolve(Am, VecX(b, b + rows), &rank);
+  for (int i = 0; i < cols; i++) x[i] = r[i];
+  return rank;
+}
 }

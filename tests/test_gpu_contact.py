@@ -1,0 +1,135 @@
+"""GPU parity of the CONTACT path (collision detection, LCP stage 0 + standardisation, contact backward)
+against the CPU oracle, through the C ABI.  Tolerance 1e-7 relative (north_star: 1e-5)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+def _run(name, B, seed, **kw):
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    from util import contact_inputs
+    md, s, a = contact_inputs(name, B, seed, **kw)
+    world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
+    g = np.random.default_rng(seed + 1).normal(0, 1, s.shape)
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    out = timestep(world, st, at)
+    status = world.last_status.cpu().numpy().astype(np.uint32)
+    out.backward(torch.tensor(g, device="cuda:0"))
+    ref = ow.step_batch(s, a, g, threads=8)
+    scale = lambda x: np.abs(x).max()
+    errs = {"next": np.abs(out.detach().cpu().numpy() - ref["next"]).max(1) / scale(ref["next"]),
+            "grad_state": np.abs(st.grad.cpu().numpy() - ref["grad_state"]).max(1) / scale(ref["grad_state"]),
+            "grad_action": np.abs(at.grad.cpu().numpy() - ref["grad_action"]).max(1) / scale(ref["grad_action"])}
+    return errs, status, ref["status"], world
+
+
+@pytest.mark.parametrize("name,B,seed", [("atlas20", 4096, 11), ("atlas33", 1024, 12)])
+def test_standing_atlas_contact_fwd_bwd_vs_oracle(name, B, seed):
+    """Metric config (Atlas-20 + 8 foot-corner contacts, B = 4096) and the 33-DOF Atlas of cfg5."""
+    errs, st, ost, _ = _run(name, B, seed)
+    assert np.all(st & 0x1) and np.all(st & 0x2) and not np.any(st & 0x20)        # contact, stage 0 everywhere
+    assert np.array_equal(st & 0x3, ost & 0x3)
+    for k, e in errs.items():
+        assert e.max() < TOL, (k, e.max())
+
+
+def test_stage0_lane_set_matches_oracle_and_resolved_lanes_agree():
+    """Larger noise: some lanes need the pivoting/PGS stages.  The device path resolves exactly the lanes the
+    reference resolves at stage 0 and flags the others NBL_ST_LCP_FAILED (zero impulses) instead of guessing."""
+    errs, st, ost, _ = _run("atlas20", 512, 13, joint_noise=0.02, vel_noise=0.0, action_noise=0.0)
+    gpu0 = (st & 0x2) != 0
+    ora0 = (ost & 0x2) != 0
+    assert np.array_equal(gpu0, ora0)
+    assert gpu0.mean() > 0.8
+    assert np.all((st[~gpu0] & 0x20) != 0)
+    for k, e in errs.items():
+        assert e[gpu0].max() < TOL, (k, e[gpu0].max())
+
+
+def test_no_contact_when_lifted():
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    from util import contact_inputs, rel_err
+    md, s, a = contact_inputs("atlas20", 64, 14)
+    s[:, 4] = 0.5    # root 0.5 m up in its own frame: no collision
+    world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
+    g = np.random.default_rng(15).normal(0, 1, s.shape)
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    out = timestep(world, st, at)
+    assert not np.any(world.last_status.cpu().numpy() & 0x1)
+    out.backward(torch.tensor(g, device="cuda:0"))
+    ref = ow.step_batch(s, a, g)
+    assert rel_err(out.detach().cpu().numpy(), ref["next"]) < TOL
+    assert rel_err(st.grad.cpu().numpy(), ref["grad_state"]) < TOL
+
+
+def test_contact_trajectory_with_warm_start():
+    """8 chained steps: the LCP warm start (hidden per-world state, BoxedLcpConstraintSolver.cpp:176-187) is carried by
+    the World exactly like the reference's solver carries mX; final state and gradients match the oracle chain."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    from util import contact_inputs, rel_err
+    md, s, a = contact_inputs("atlas20", 16, 16, joint_noise=0.001, vel_noise=0.0, action_noise=0.0)
+    T = 8
+    world = na.World(md, device="cuda:0")
+    st0 = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    st = st0
+    for _ in range(T):
+        st = timestep(world, st, at)
+        assert not np.any(world.last_status.cpu().numpy() & 0x20)
+    (st ** 2).sum().backward()
+    B = s.shape[0]
+    fin = np.zeros_like(s); gs = np.zeros_like(s); ga = np.zeros_like(a)
+    for b in range(B):
+        ws = [OracleWorld(md) for _ in range(T)]
+        x = s[b]
+        cache = None
+        for t in range(T):
+            if cache is not None:
+                ws[t].set_lcp_cache(cache)
+            x = ws[t].step(x, a[b])
+            cache = ws[t].get_lcp_cache()
+        fin[b] = x
+        g = 2 * x
+        for t in reversed(range(T)):
+            g, gat = ws[t].backprop(g)
+            ga[b] += gat
+        gs[b] = g
+    assert rel_err(st.detach().cpu().numpy(), fin) < TOL
+    assert rel_err(st0.grad.cpu().numpy(), gs) < 1e-6
+    assert rel_err(at.grad.cpu().numpy(), ga) < 1e-6
+
+
+def test_contact_backward_vs_finite_differences_of_gpu_step():
+    """Independent of the oracle: GPU analytic VJP vs central differences of the GPU forward (eps 1e-7)."""
+    import torch
+    import nimblephysics_amd as na
+    from util import contact_inputs
+    md, s, a = contact_inputs("atlas20", 1, 17)
+    world = na.World(md, device="cuda:0"); n = world.n
+    s0 = torch.tensor(s, device="cuda:0"); a0 = torch.tensor(a, device="cuda:0")
+
+    def step(x, u):
+        world.reset_lcp_cache()
+        nxt, sv, stt = world.step_soa(world.to_soa(x), world.to_soa(u))
+        return world.from_soa(nxt), sv
+
+    out, sv = step(s0, a0)
+    g = torch.randn(1, 2 * n, device="cuda:0", dtype=torch.float64)
+    gs, ga = world.backward_soa(sv, world.to_soa(g))
+    gs = world.from_soa(gs)[0].cpu().numpy()
+    eps = 1e-7
+    fd = np.zeros(2 * n)
+    for j in range(2 * n):
+        xp, xm = s0.clone(), s0.clone(); xp[0, j] += eps; xm[0, j] -= eps
+        fd[j] = ((step(xp, a0)[0] - step(xm, a0)[0]) * g).sum().item() / (2 * eps)
+    assert np.abs(gs - fd).max() < 1e-5 * max(1.0, np.abs(fd).max())

@@ -33,3 +33,17 @@ def cfg_inputs(name, B, seed):
     else:
         raise KeyError(name)
     return md, np.concatenate([q, v], 1), a
+
+
+def contact_inputs(name, B, seed, joint_noise=0.002, vel_noise=0.001, action_noise=0.1):
+    """Standing Atlas on the ground box (cfg5 / metric config pose: q[0] = -pi/2, q[4] = -0.01,
+    unittests/unit/test_AtlasGradients.cpp:235-236) with small joint noise: both feet flat, 8 foot-corner
+    contacts, contact stays in the sticking regime where the LCP warm start / guess is already valid."""
+    rng = np.random.default_rng(seed)
+    md = na.atlas(name, ground=True)
+    n = md.num_dofs
+    q = np.zeros((B, n)); q[:, 0] = -np.pi / 2; q[:, 4] = -0.01
+    q[:, 6:] = rng.normal(0, joint_noise, (B, n - 6))
+    v = rng.normal(0, vel_noise, (B, n))
+    a = rng.normal(0, action_noise, (B, n))
+    return md, np.concatenate([q, v], 1), a
