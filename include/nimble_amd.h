@@ -127,7 +127,7 @@ void nbl_model_destroy(nbl_model* m);
 
 int32_t nbl_model_num_dofs(const nbl_model* m);
 int32_t nbl_model_num_action(const nbl_model* m);
-int32_t nbl_model_lcp_rows(const nbl_model* m); /* 3 * max_contacts */
+int32_t nbl_model_lcp_rows(const nbl_model* m); /* rows of the LCP warm-start buffer: 24 impulses + 1 row holding the row count they belong to; 0 without colliders */
 
 /* Bytes of scratch the library needs for a batch of B worlds (forward or backward). */
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B);
@@ -179,6 +179,10 @@ int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, 
 int32_t nbl_set_timing(nbl_model* m, int32_t enabled);
 int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, double* bwd_ms_sum,
                        int64_t* bwd_count);
+/* Per-kernel breakdown of the same measurements (names match the rocprofv3 kernel trace). */
+int32_t nbl_kernel_count(void);
+const char* nbl_kernel_name(int32_t i);
+int32_t nbl_kernel_timing(nbl_model* m, int32_t i, double* ms_sum, int64_t* count);
 
 #ifdef __cplusplus
 }

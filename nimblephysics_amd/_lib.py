@@ -56,6 +56,11 @@ def lib():
     L.nbl_set_timing.restype = C.c_int32
     L.nbl_get_timing.argtypes = [vp, pd, C.POINTER(C.c_int64), pd, C.POINTER(C.c_int64)]
     L.nbl_get_timing.restype = C.c_int32
+    L.nbl_kernel_count.restype = C.c_int32
+    L.nbl_kernel_name.argtypes = [C.c_int32]
+    L.nbl_kernel_name.restype = C.c_char_p
+    L.nbl_kernel_timing.argtypes = [vp, C.c_int32, pd, C.POINTER(C.c_int64)]
+    L.nbl_kernel_timing.restype = C.c_int32
     _lib = L
     return L
 
@@ -64,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "nbl_last_error", "nbl_version", "nbl_device_count", "nbl_model_create", "nbl_model_destroy",
     "nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows", "nbl_workspace_bytes", "nbl_saved_bytes",
     "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing",
-    "nbl_get_timing",
+    "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing",
 ]
 
 

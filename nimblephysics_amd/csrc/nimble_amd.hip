@@ -30,9 +30,13 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve",
+                                           "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
+                                           "k_bwd_final"};
 struct TimedLaunch {
   hipEvent_t start, stop;
-  bool backward;
+  int kernel;
 };
 }  // namespace
 
@@ -49,6 +53,8 @@ struct nbl_model {
   std::vector<TimedLaunch> pending;
   double fwdMs = 0, bwdMs = 0;
   int64_t fwdCount = 0, bwdCount = 0;
+  double kMs[K_COUNT] = {0};
+  int64_t kCount[K_COUNT] = {0};
 };
 
 extern "C" {
@@ -246,12 +252,12 @@ size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
   return (size_t)m->lay.total * sizeof(double) * (size_t)B;
 }
 
-static void beginTiming(nbl_model* m, hipStream_t s, bool backward) {
+static void beginTiming(nbl_model* m, hipStream_t s, int kernel) {
   if (!m->timing) return;
   TimedLaunch t;
   hipEventCreate(&t.start);
   hipEventCreate(&t.stop);
-  t.backward = backward;
+  t.kernel = kernel;
   hipEventRecord(t.start, s);
   m->pending.push_back(t);
 }
@@ -259,6 +265,7 @@ static void endTiming(nbl_model* m, hipStream_t s) {
   if (!m->timing) return;
   hipEventRecord(m->pending.back().stop, s);
 }
+#define TIMED(kid, launch) do { beginTiming(m, s, kid); launch; endTiming(m, s); } while (0)
 
 int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const double* action, const double* lcp_cache_in,
                          double* next_state, double* lcp_cache_out, void* saved, uint32_t* status, void* workspace,
@@ -269,19 +276,17 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((B + 63) / 64)), block(64);
-  beginTiming(m, s, false);
-  hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
-                     (double*)saved, status, (double*)workspace, m->hasContact ? m->lay.vpre : -1);
+  TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
+                                  (double*)saved, status, (double*)workspace, m->hasContact ? m->lay.vpre : -1));
   if (m->hasContact) {
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
-    hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay, status,
-                       (double*)workspace);
-    hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
-                       (double*)workspace, lws);
-    hipLaunchKernelGGL(k_contact_solve, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay, lcp_cache_in,
-                       lcp_cache_out, next_state, status, lws);
+    TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay,
+                                       status, (double*)workspace));
+    TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved,
+                                     m->lay, (double*)workspace, lws));
+    TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay,
+                                      lcp_cache_in, lcp_cache_out, next_state, status, lws));
   }
-  endTiming(m, s);
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
@@ -293,23 +298,21 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((B + 63) / 64)), block(64);
-  beginTiming(m, s, true);
   if (!m->hasContact) {
-    hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
-                       grad_next_state, grad_state, grad_action, (double*)workspace);
+    TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+                                    grad_next_state, grad_state, grad_action, (double*)workspace));
   } else {
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
     double* sv = (double*)const_cast<void*>(saved);
-    hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
-                       (double*)workspace);
-    hipLaunchKernelGGL(k_bwd_contact_a, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv, m->lay,
-                       grad_next_state, (double*)workspace, lws);
-    hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv, m->lay,
-                       (double*)workspace, lws, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
-                       grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws);
+    TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B,
+                                          (const double*)saved, (double*)workspace));
+    TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
+                                      m->lay, grad_next_state, (double*)workspace, lws));
+    TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
+                                      m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
+    TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+                                          grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws));
   }
-  endTiming(m, s);
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
@@ -337,6 +340,7 @@ int32_t nbl_set_timing(nbl_model* m, int32_t enabled) {
     m->pending.clear();
     m->fwdMs = m->bwdMs = 0;
     m->fwdCount = m->bwdCount = 0;
+    for (int i = 0; i < K_COUNT; i++) { m->kMs[i] = 0; m->kCount[i] = 0; }
   }
   return NBL_OK;
 }
@@ -346,7 +350,10 @@ int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, dou
     HIP_TRY(hipEventSynchronize(t.stop));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
-    if (t.backward) { m->bwdMs += ms; m->bwdCount++; } else { m->fwdMs += ms; m->fwdCount++; }
+    m->kMs[t.kernel] += ms;
+    m->kCount[t.kernel]++;
+    if (t.kernel >= K_BWD) { m->bwdMs += ms; if (t.kernel == K_BWD || t.kernel == K_BWD_FINAL) m->bwdCount++; }
+    else { m->fwdMs += ms; if (t.kernel == K_FWD) m->fwdCount++; }
     hipEventDestroy(t.start);
     hipEventDestroy(t.stop);
   }
@@ -355,6 +362,17 @@ int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, dou
   if (fwd_count) *fwd_count = m->fwdCount;
   if (bwd_ms_sum) *bwd_ms_sum = m->bwdMs;
   if (bwd_count) *bwd_count = m->bwdCount;
+  return NBL_OK;
+}
+
+int32_t nbl_kernel_count(void) { return K_COUNT; }
+const char* nbl_kernel_name(int32_t i) { return (i >= 0 && i < K_COUNT) ? kKernelNames[i] : ""; }
+int32_t nbl_kernel_timing(nbl_model* m, int32_t i, double* ms_sum, int64_t* count) {
+  if (!m || i < 0 || i >= K_COUNT) return fail(NBL_E_BADARG, "bad kernel index");
+  int32_t rc = nbl_get_timing(m, nullptr, nullptr, nullptr, nullptr);  // drains pending events
+  if (rc != NBL_OK) return rc;
+  if (ms_sum) *ms_sum = m->kMs[i];
+  if (count) *count = m->kCount[i];
   return NBL_OK;
 }
 

@@ -27,9 +27,10 @@ def allgather_sum(partial: torch.Tensor, group=None) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return partial.clone()
     ws = dist.get_world_size(group)
-    buf = torch.empty((ws,) + tuple(partial.shape), dtype=partial.dtype, device=partial.device)
-    dist.all_gather_into_tensor(buf, partial.contiguous(), group=group)
-    return buf.sum(dim=0)
+    flat = partial.contiguous().view(-1)
+    buf = torch.empty(ws * flat.numel(), dtype=partial.dtype, device=partial.device)
+    dist.all_gather_into_tensor(buf, flat, group=group)   # concatenated form: valid for RCCL and gloo
+    return buf.view(ws, *partial.shape).sum(dim=0)
 
 
 def shared_parameter_grad(per_world_grad_soa: torch.Tensor, group=None) -> torch.Tensor:

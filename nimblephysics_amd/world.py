@@ -178,4 +178,10 @@ class World:
         f, b = C.c_double(0), C.c_double(0)
         fc, bc = C.c_int64(0), C.c_int64(0)
         check(self._L.nbl_get_timing(self._h, C.byref(f), C.byref(fc), C.byref(b), C.byref(bc)), "nbl_get_timing")
-        return {"fwd_ms_sum": f.value, "fwd_count": fc.value, "bwd_ms_sum": b.value, "bwd_count": bc.value}
+        out = {"fwd_ms_sum": f.value, "fwd_count": fc.value, "bwd_ms_sum": b.value, "bwd_count": bc.value, "kernels": {}}
+        for i in range(self._L.nbl_kernel_count()):
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            check(self._L.nbl_kernel_timing(self._h, i, C.byref(ms), C.byref(cnt)), "nbl_kernel_timing")
+            if cnt.value:
+                out["kernels"][self._L.nbl_kernel_name(i).decode()] = {"ms_sum": ms.value, "count": cnt.value}
+        return out
