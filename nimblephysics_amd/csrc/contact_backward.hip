@@ -43,13 +43,15 @@ __global__ __launch_bounds__(64) void k_bwd_recompute(DevModel mdl, const DevBod
 }
 
 // ---- kernel A: dense (c x c) part of the adjoint ----
-__global__ __launch_bounds__(64) void k_bwd_contact_a(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const DevBody* __restrict__ bodies,
                                                       const DevDof* __restrict__ dofs, const DevContactModel* __restrict__ cm,
                                                       int64_t B, double* __restrict__ saved, SavedLayout lay,
                                                       const double* __restrict__ gnext, double* __restrict__ ws,
                                                       double* __restrict__ lws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) double ldsq[];   // Q factor + Cholesky factor, LCP_LANES worlds (see k_contact_solve)
+  const int64_t b = (int64_t)blockIdx.x * LCP_LANES + threadIdx.x;
   if (b >= B) return;
+  LaneMem QL; QL.base = ldsq; QL.B = LCP_LANES; QL.b = threadIdx.x;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;
   const double* gvn = gnext + (int64_t)n * B;
@@ -113,13 +115,13 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a(DevModel mdl, const DevBod
   {
     double Bv[MAXR];
     for (int r = 0; r < m; r++) Bv[r] = SV.at(lay.b + r);
-    buildQ(V, K, cfm, L, LW_Q, Bv, bc);   // Q into the lane scratch, bc = clamping entries of b
+    buildQ(V, K, cfm, QL, 0, Bv, bc);   // Q into LDS, bc = clamping entries of b
   }
   CodFactor F;
-  F.ld = MAXR; F.offQR = LW_Q; F.offChol = LW_CHOL; F.c = nc;
-  codFactor(L, F);
+  F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR; F.c = nc;
+  codFactor(QL, F);
   for (int i = 0; i < nc; i++) tmp[i] = fbar[i];
-  codSolveT(L, F, tmp, mu);                                   // mu = (Q^+)^T fbar
+  codSolveT(QL, F, tmp, mu);                                   // mu = (Q^+)^T fbar
   double al[3][MAXR], be[3][MAXR];
   // pair 1: (-mu, f_c)
   for (int i = 0; i < nc; i++) { al[0][i] = -mu[i]; be[0][i] = fc[i]; }
@@ -130,10 +132,10 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a(DevModel mdl, const DevBod
     al[1][i] = bc[i] - s;
   }
   for (int i = 0; i < nc; i++) tmp[i] = mu[i];
-  codSolve(L, F, tmp, be[1]);
+  codSolve(QL, F, tmp, be[1]);
   // pair 3: (Q^+T f_c, fbar - Q^T mu)
   for (int i = 0; i < nc; i++) tmp[i] = fc[i];
-  codSolveT(L, F, tmp, al[2]);
+  codSolveT(QL, F, tmp, al[2]);
   for (int i = 0; i < nc; i++) {
     double s = 0;
     for (int j = 0; j < nc; j++) s += qEntry(V, K, cfm, rowOf[j], rowOf[i]) * mu[j];

@@ -254,18 +254,24 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
 // ---------------------------------------------------------------------------------------------
 // stage 0 solve + apply
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_contact_solve(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+// The dense per-world matrices (Q / its QR factor and the Cholesky factor of R1 R1^T, 2 x 24 x 24 doubles) are
+// staged in LDS: LCP_LANES worlds per workgroup, element e of world l at lds[e * LCP_LANES + l] (conflict-free),
+// 16 x 9216 B = 144 KiB of the CU's 160 KiB.  The factorisation is a chain of dependent accesses, so LDS
+// latency instead of L2 latency is what matters; the 256 workgroups of a B = 4096 launch cover every CU.
+__global__ __launch_bounds__(LCP_LANES) void k_contact_solve(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                       double* __restrict__ saved, SavedLayout lay,
                                                       const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
                                                       double* __restrict__ next, uint32_t* __restrict__ status,
                                                       double* __restrict__ lws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) double ldsq[];
+  const int64_t b = (int64_t)blockIdx.x * LCP_LANES + threadIdx.x;
   if (b >= B) return;
+  (void)lws;
   const int n = mdl.n;
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;
   LaneMem L;
-  L.base = lws; L.B = B; L.b = b;
+  L.base = ldsq; L.B = LCP_LANES; L.b = threadIdx.x;
   LaneMem SV;
   SV.base = saved; SV.B = B; SV.b = b;
   double* nv = next + (int64_t)n * B;
@@ -290,17 +296,18 @@ __global__ __launch_bounds__(64) void k_contact_solve(DevModel mdl, const DevCon
   for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
 
   CodFactor F;
-  F.ld = MAXR; F.offQR = LW_Q; F.offChol = LW_CHOL;
+  F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR;
   // ---- warm start, or LCPUtils::guessSolution when the cache belongs to another row count ----
   bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
+  uint32_t guessMask = 0;   // rows of the guess's clamping set; its factorisation can be reused by the first standardisation
   if (haveCache) { for (int r = 0; r < m; r++) X[r] = cacheIn[(int64_t)r * B + b]; }
   else {
     int idx[MAXR], nc = 0;
-    for (int r = 0; r < m; r++) if ((r % 3) != 0 || Bv[r] > 0) idx[nc++] = r;
+    for (int r = 0; r < m; r++) if ((r % 3) != 0 || Bv[r] > 0) { idx[nc++] = r; guessMask |= 1u << r; }
     for (int r = 0; r < m; r++) X[r] = 0;
     if (nc > 0) {
       double rhs[MAXR], sol[MAXR];
-      for (int i = 0; i < nc; i++) { rhs[i] = Bv[idx[i]]; for (int j = 0; j < nc; j++) L.at(LW_Q + i * MAXR + j) = V.A(idx[i], idx[j]); }
+      for (int i = 0; i < nc; i++) { rhs[i] = Bv[idx[i]]; for (int j = 0; j < nc; j++) L.at(i * MAXR + j) = V.A(idx[i], idx[j]); }
       F.c = nc;
       codFactor(L, F);
       codSolve(L, F, rhs, sol);
@@ -320,11 +327,18 @@ __global__ __launch_bounds__(64) void k_contact_solve(DevModel mdl, const DevCon
       break;
     }
     double bc[MAXR], fc[MAXR], newX[MAXR], origFc[MAXR];
-    buildQ(V, K, 0.0, L, LW_Q, Bv, bc);
     for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) origFc[K.cidx[r]] = X[r];
-    F.c = K.nc;
-    codFactor(L, F);
-    codSolve(L, F, bc, fc);
+    uint32_t clampMask = 0;
+    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) clampMask |= 1u << r;
+    if (iter == 0 && K.nu == 0 && guessMask != 0 && clampMask == guessMask) {
+      // the clamping set is exactly the guess's set: Q and b_c are the system just solved, f_c = that solution
+      for (int i = 0; i < K.nc; i++) fc[i] = origFc[i];
+    } else {
+      buildQ(V, K, 0.0, L, 0, Bv, bc);
+      F.c = K.nc;
+      codFactor(L, F);
+      codSolve(L, F, bc, fc);
+    }
     bool newlyNot = false;
     for (int i = 0; i < m; i++) {
       newX[i] = 0;

@@ -37,27 +37,40 @@ DEV void codFactor(const LaneMem& w, CodFactor& f) {
   const int c = f.c, ld = f.ld, o = f.offQR;
   for (int j = 0; j < c; j++) f.perm[j] = j;
   double maxPivot = 0.0;
-  double diag[MAXR];
+  double diag[MAXR], cn[MAXR], cn0[MAXR];
+  // squared column norms, downdated as the factorisation proceeds (recomputed when cancellation bites)
+  for (int j = 0; j < c; j++) {
+    double s = 0;
+    for (int i = 0; i < c; i++) { double a = w.at(o + i * ld + j); s += a * a; }
+    cn[j] = s; cn0[j] = s;
+  }
   for (int k = 0; k < c; k++) {
     int piv = k;
     double best = -1.0;
     for (int j = k; j < c; j++) {
-      double s = 0;
-      for (int i = k; i < c; i++) { double a = w.at(o + i * ld + j); s += a * a; }
-      if (s > best) { best = s; piv = j; }
+      if (cn[j] < 1e-8 * cn0[j] || cn[j] < 0) {
+        double s = 0;
+        for (int i = k; i < c; i++) { double a = w.at(o + i * ld + j); s += a * a; }
+        cn[j] = s; cn0[j] = s;
+      }
+      if (cn[j] > best) { best = cn[j]; piv = j; }
     }
     if (piv != k) {
       for (int i = 0; i < c; i++) { double t = w.at(o + i * ld + k); w.at(o + i * ld + k) = w.at(o + i * ld + piv); w.at(o + i * ld + piv) = t; }
       int t = f.perm[k]; f.perm[k] = f.perm[piv]; f.perm[piv] = t;
+      double tn = cn[k]; cn[k] = cn[piv]; cn[piv] = tn;
+      tn = cn0[k]; cn0[k] = cn0[piv]; cn0[piv] = tn;
     }
-    double normx = sqrt(best > 0 ? best : 0.0);
-    if (normx == 0.0) { f.tau[k] = 0; diag[k] = 0; continue; }
+    // exact norm of the pivot column below the diagonal
     double akk = w.at(o + k * ld + k);
+    double below = 0;
+    for (int i = k + 1; i < c; i++) { double a = w.at(o + i * ld + k); below += a * a; }
+    double normx = sqrt(akk * akk + below);
+    if (normx == 0.0) { f.tau[k] = 0; diag[k] = 0; continue; }
     double alpha = akk > 0 ? -normx : normx;
     // v = x - alpha e_k, stored scaled so that v_k = 1
     double vk = akk - alpha;
-    double vnorm2 = vk * vk;
-    for (int i = k + 1; i < c; i++) { double a = w.at(o + i * ld + k); vnorm2 += a * a; }
+    double vnorm2 = vk * vk + below;
     f.tau[k] = 2.0 * vk * vk / vnorm2;  // H = I - tau v v^T with v_k = 1
     double inv = 1.0 / vk;
     for (int i = k + 1; i < c; i++) w.at(o + i * ld + k) *= inv;
@@ -66,8 +79,10 @@ DEV void codFactor(const LaneMem& w, CodFactor& f) {
       double d = w.at(o + k * ld + j);
       for (int i = k + 1; i < c; i++) d += w.at(o + i * ld + k) * w.at(o + i * ld + j);
       d *= f.tau[k];
-      w.at(o + k * ld + j) -= d;
+      double rkj = w.at(o + k * ld + j) - d;
+      w.at(o + k * ld + j) = rkj;
       for (int i = k + 1; i < c; i++) w.at(o + i * ld + j) -= d * w.at(o + i * ld + k);
+      cn[j] -= rkj * rkj;
     }
     diag[k] = alpha;
     maxPivot = fmax(maxPivot, fabs(alpha));

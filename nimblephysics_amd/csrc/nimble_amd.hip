@@ -221,6 +221,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess) e = hipMemcpy(m->dDofs, hd.data(), sizeof(DevDof) * hd.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && hasContact) e = hipMalloc((void**)&m->dContact, sizeof(DevContactModel));
   if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_solve, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_a, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e != hipSuccess) {
     std::string msg = std::string("model upload failed: ") + hipGetErrorString(e);
     nbl_model_destroy(m);
@@ -284,8 +286,9 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
                                        status, (double*)workspace));
     TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved,
                                      m->lay, (double*)workspace, lws));
-    TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay,
-                                      lcp_cache_in, lcp_cache_out, next_state, status, lws));
+    dim3 lgrid((unsigned)((B + LCP_LANES - 1) / LCP_LANES)), lblock(LCP_LANES);
+    TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, LCP_LDS_BYTES, s, m->mdl, m->dContact, B, (double*)saved,
+                                      m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws));
   }
   HIP_TRY(hipGetLastError());
   return NBL_OK;
@@ -306,8 +309,9 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
     double* sv = (double*)const_cast<void*>(saved);
     TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B,
                                           (const double*)saved, (double*)workspace));
-    TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
-                                      m->lay, grad_next_state, (double*)workspace, lws));
+    dim3 lgrid((unsigned)((B + LCP_LANES - 1) / LCP_LANES)), lblock(LCP_LANES);
+    TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, LCP_LDS_BYTES, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
+                                      B, sv, m->lay, grad_next_state, (double*)workspace, lws));
     TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
                                       m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
     TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
