@@ -122,19 +122,24 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
   codFactor(QL, F);
   for (int i = 0; i < nc; i++) tmp[i] = fbar[i];
   codSolveT(QL, F, tmp, mu);                                   // mu = (Q^+)^T fbar
-  double al[3][MAXR], be[3][MAXR];
-  // pair 1: (-mu, f_c)
-  for (int i = 0; i < nc; i++) { al[0][i] = -mu[i]; be[0][i] = fc[i]; }
-  // pair 2: ((I - Q Q^+) b, Q^+ mu)   with Q^+ b = f_c
+  double al[3][MAXR], be[3][MAXR], fls[MAXR];
+  // Q^+ b: equals the applied impulses f_c when the results were standardised; when the solver's raw x was kept
+  // (PGS / frictionless fallback without a valid standardisation) the reference still differentiates Q^+ b here
+  // (Qfactored.solve(b), BackpropSnapshot.cpp:2934) while A_c f_c terms use the applied impulses (:1003, 1057-1058)
+  for (int i = 0; i < nc; i++) tmp[i] = bc[i];
+  codSolve(QL, F, tmp, fls);
+  // pair 1: (-mu, Q^+ b)
+  for (int i = 0; i < nc; i++) { al[0][i] = -mu[i]; be[0][i] = fls[i]; }
+  // pair 2: ((I - Q Q^+) b, Q^+ mu)
   for (int i = 0; i < nc; i++) {
     double s = 0;
-    for (int j = 0; j < nc; j++) s += qEntry(V, K, cfm, rowOf[i], rowOf[j]) * fc[j];
+    for (int j = 0; j < nc; j++) s += qEntry(V, K, cfm, rowOf[i], rowOf[j]) * fls[j];
     al[1][i] = bc[i] - s;
   }
   for (int i = 0; i < nc; i++) tmp[i] = mu[i];
   codSolve(QL, F, tmp, be[1]);
-  // pair 3: (Q^+T f_c, fbar - Q^T mu)
-  for (int i = 0; i < nc; i++) tmp[i] = fc[i];
+  // pair 3: (Q^+T Q^+ b, fbar - Q^T mu)
+  for (int i = 0; i < nc; i++) tmp[i] = fls[i];
   codSolveT(QL, F, tmp, al[2]);
   for (int i = 0; i < nc; i++) {
     double s = 0;

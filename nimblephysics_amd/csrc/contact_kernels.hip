@@ -10,6 +10,7 @@
 // (BoxedLcpConstraintSolver.cpp:461-677); they are flagged NBL_ST_LCP_FAILED for now and get zero
 // impulses, exactly what the reference does when every stage fails (:679-687).
 #include "collision_dev.hpp"
+#include "dantzig_dev.hpp"
 #include "lcp_dev.hpp"
 
 namespace nbl {
@@ -254,19 +255,100 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
 // ---------------------------------------------------------------------------------------------
 // stage 0 solve + apply
 // ---------------------------------------------------------------------------------------------
+// ---- shared pieces of the stage-0 kernel and the cascade kernel ----
+// CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (the reference recurses while normal
+// rows drop out of the clamping set, CGGM.cpp:321-332).  On return K holds the last classification and X the
+// last accepted solution; returns whether the results are standardised (valid least-squares solution).
+DEV bool standardizeLoop(const LcpView& V, const LaneMem& L, CodFactor& F, double* X, const double* Bv, const double* colNorm,
+                         double cfm, bool ignoreFriction, uint32_t guessMask, Classes& K) {
+  const int m = V.m;
+  bool ok = false;
+  for (int iter = 0; iter < MAXR + 1; iter++) {
+    classify(V, X, colNorm, ignoreFriction, K);
+    if (K.nc == 0) {
+      double zero[MAXR];
+      for (int r = 0; r < m; r++) zero[r] = 0;
+      ok = lcpValid(V, zero, Bv, ignoreFriction, cfm);
+      if (ok) for (int r = 0; r < m; r++) X[r] = 0;
+      break;
+    }
+    double bc[MAXR], fc[MAXR], newX[MAXR], origFc[MAXR];
+    uint32_t clampMask = 0;
+    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) { origFc[K.cidx[r]] = X[r]; clampMask |= 1u << r; }
+    if (iter == 0 && K.nu == 0 && guessMask != 0 && clampMask == guessMask) {
+      // the clamping set is exactly the guess's set: Q and b_c are the system just solved, f_c = that solution
+      for (int i = 0; i < K.nc; i++) fc[i] = origFc[i];
+    } else {
+      buildQ(V, K, cfm, L, 0, Bv, bc);
+      F.c = K.nc;
+      codFactor(L, F);
+      codSolve(L, F, bc, fc);
+    }
+    bool newlyNot = false;
+    for (int i = 0; i < m; i++) {
+      newX[i] = 0;
+      if (K.cls[i] == RC_CLAMPING) {
+        newX[i] = fc[K.cidx[i]];
+        if (fabs(newX[i]) < 1e-6 && fabs(X[i]) > 1e-6 && (i % 3) == 0) newlyNot = true;
+      } else if (K.cls[i] == RC_UPPER_BOUND) {
+        const int fp = i - (i % 3);
+        double om = origFc[K.cidx[fp]] / X[i];
+        double clean = (fabs(om - V.hi(i)) < fabs(om - V.lo(i))) ? V.hi(i) : V.lo(i);
+        newX[i] = fc[K.cidx[fp]] * clean;
+      }
+    }
+    if (!lcpValid(V, newX, Bv, ignoreFriction, cfm)) { ok = false; break; }
+    for (int i = 0; i < m; i++) X[i] = newX[i];
+    ok = true;
+    if (!newlyNot) break;
+  }
+  return ok;
+}
+
+DEV void contactOutputs(const LaneMem& SV, const SavedLayout& lay, int n, int m, const double* X, const Classes& K, double cfm,
+                        double* __restrict__ cacheOut, double* __restrict__ nv, int64_t B, int64_t b) {
+  for (int r = 0; r < MAX_ROWS; r++) {
+    SV.at(lay.x + r) = r < m ? X[r] : 0.0;
+    SV.at(lay.cls + r) = r < m ? (K.cls[r] == RC_UPPER_BOUND ? (K.E[r] > 0 ? 2.0 : -2.0) : (double)K.cls[r]) : 0.0;
+  }
+  SV.at(lay.cfm) = cfm;
+  if (cacheOut) {
+    for (int r = 0; r < MAX_ROWS; r++) cacheOut[(int64_t)r * B + b] = r < m ? X[r] : 0.0;
+    cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
+  }
+  // v' = v_pre + M^-1 J^T x   (applyImpulse + computeImpulseForwardDynamics)
+  for (int d = 0; d < n; d++) {
+    double w = 0;
+    for (int r = 0; r < m; r++) w += SV.at(lay.massed + d * MAX_ROWS + r) * X[r];
+    SV.at(lay.w + d) = w;
+    nv[(int64_t)d * B + b] = SV.at(lay.vpre + d) + w;
+  }
+}
+
+DEV void loadLcpView(LcpView& V, const LaneMem& SV, const SavedLayout& lay, const DevContactModel* cm, int nC) {
+  V.mem = SV; V.offA = lay.A; V.m = 3 * nC;
+  for (int ci = 0; ci < nC; ci++) {
+    const int r0 = lay.contacts + ci * CR_SIZE;
+    const double muA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].mu, muB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].mu;
+    V.mu[ci] = muA < muB ? muA : muB;
+  }
+}
+
 // The dense per-world matrices (Q / its QR factor and the Cholesky factor of R1 R1^T, 2 x 24 x 24 doubles) are
 // staged in LDS: LCP_LANES worlds per workgroup, element e of world l at lds[e * LCP_LANES + l] (conflict-free),
 // 16 x 9216 B = 144 KiB of the CU's 160 KiB.  The factorisation is a chain of dependent accesses, so LDS
 // latency instead of L2 latency is what matters; the 256 workgroups of a B = 4096 launch cover every CU.
+// Worlds whose warm start / guess does not standardise to a valid LCP solution are appended to `failList`
+// and finished by k_contact_cascade (compacted slow path).
 __global__ __launch_bounds__(LCP_LANES) void k_contact_solve(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                       double* __restrict__ saved, SavedLayout lay,
                                                       const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
                                                       double* __restrict__ next, uint32_t* __restrict__ status,
-                                                      double* __restrict__ lws) {
+                                                      double* __restrict__ lws, int32_t* __restrict__ failList,
+                                                      uint32_t* __restrict__ failCount) {
   extern __shared__ __attribute__((aligned(16))) double ldsq[];
   const int64_t b = (int64_t)blockIdx.x * LCP_LANES + threadIdx.x;
   if (b >= B) return;
-  (void)lws;
   const int n = mdl.n;
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;
@@ -285,12 +367,7 @@ __global__ __launch_bounds__(LCP_LANES) void k_contact_solve(DevModel mdl, const
     return;
   }
   LcpView V;
-  V.mem = SV; V.offA = lay.A; V.m = m;
-  for (int ci = 0; ci < nC; ci++) {
-    const int r0 = lay.contacts + ci * CR_SIZE;
-    const double muA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].mu, muB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].mu;
-    V.mu[ci] = muA < muB ? muA : muB;
-  }
+  loadLcpView(V, SV, lay, cm, nC);
   double Bv[MAXR], X[MAXR], colNorm[MAXR];
   for (int r = 0; r < m; r++) Bv[r] = SV.at(lay.b + r);
   for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
@@ -314,72 +391,97 @@ __global__ __launch_bounds__(LCP_LANES) void k_contact_solve(DevModel mdl, const
       for (int i = 0; i < nc; i++) X[idx[i]] = sol[i];
     }
   }
-  // ---- classify + standardise (repeat while normal rows drop out of the clamping set) ----
+  // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
+  for (int r = 0; r < MAX_ROWS; r++) lws[(int64_t)(LW_JA + r) * B + b] = r < m ? X[r] : 0.0;
   Classes K;
-  bool ok = false;
-  for (int iter = 0; iter < MAXR + 1; iter++) {
-    classify(V, X, colNorm, false, K);
-    if (K.nc == 0) {
-      double zero[MAXR];
-      for (int r = 0; r < m; r++) zero[r] = 0;
-      ok = lcpValid(V, zero, Bv, false, 0.0);
-      if (ok) for (int r = 0; r < m; r++) X[r] = 0;
-      break;
-    }
-    double bc[MAXR], fc[MAXR], newX[MAXR], origFc[MAXR];
-    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) origFc[K.cidx[r]] = X[r];
-    uint32_t clampMask = 0;
-    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) clampMask |= 1u << r;
-    if (iter == 0 && K.nu == 0 && guessMask != 0 && clampMask == guessMask) {
-      // the clamping set is exactly the guess's set: Q and b_c are the system just solved, f_c = that solution
-      for (int i = 0; i < K.nc; i++) fc[i] = origFc[i];
-    } else {
-      buildQ(V, K, 0.0, L, 0, Bv, bc);
-      F.c = K.nc;
-      codFactor(L, F);
-      codSolve(L, F, bc, fc);
-    }
-    bool newlyNot = false;
+  const bool ok = standardizeLoop(V, L, F, X, Bv, colNorm, 0.0, false, guessMask, K);
+  if (ok) {
+    st |= 0x2u | 0x100u;
+    contactOutputs(SV, lay, n, m, X, K, 0.0, cacheOut, nv, B, b);
+  } else {
+    const uint32_t slot = atomicAdd(failCount, 1u);
+    failList[slot] = (int32_t)b;
+  }
+  if (status) status[b] = st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stages 1-3 of the cascade for the worlds stage 0 could not resolve (compacted list)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LCP_LANES) void k_contact_cascade(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                        double* __restrict__ saved, SavedLayout lay,
+                                                        double* __restrict__ cacheOut, double* __restrict__ next,
+                                                        uint32_t* __restrict__ status, double* __restrict__ lws,
+                                                        const int32_t* __restrict__ failList,
+                                                        const uint32_t* __restrict__ failCount) {
+  extern __shared__ __attribute__((aligned(16))) double ldsq[];
+  const uint32_t t = blockIdx.x * LCP_LANES + threadIdx.x;
+  if (t >= *failCount) return;
+  const int64_t b = failList[t];
+  const int n = mdl.n;
+  LaneMem L;
+  L.base = ldsq; L.B = LCP_LANES; L.b = threadIdx.x;
+  LaneMem SV;
+  SV.base = saved; SV.B = B; SV.b = b;
+  const int nC = (int)SV.at(lay.nc);
+  const int m = 3 * nC;
+  double* nv = next + (int64_t)n * B;
+  uint32_t st = status ? status[b] : 0u;
+  LcpView V;
+  loadLcpView(V, SV, lay, cm, nC);
+  double Bv[MAXR], X[MAXR], X0[MAXR], colNorm[MAXR];
+  for (int r = 0; r < m; r++) { Bv[r] = SV.at(lay.b + r); X0[r] = lws[(int64_t)(LW_JA + r) * B + b]; X[r] = X0[r]; }
+  for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
+  const int OFFA = 0, OFFL = MAXR * MAXR;
+  auto loadProblem = [&](RedLcp& P, double cfmDiag, const double* x0) {
+    P.n = m; P.nOrig = m;
     for (int i = 0; i < m; i++) {
-      newX[i] = 0;
-      if (K.cls[i] == RC_CLAMPING) {
-        newX[i] = fc[K.cidx[i]];
-        if (fabs(newX[i]) < 1e-6 && fabs(X[i]) > 1e-6 && (i % 3) == 0) newlyNot = true;
-      } else if (K.cls[i] == RC_UPPER_BOUND) {
-        const int fp = i - (i % 3);
-        double om = origFc[K.cidx[fp]] / X[i];
-        double clean = (fabs(om - V.hi(i)) < fabs(om - V.lo(i))) ? V.hi(i) : V.lo(i);
-        newX[i] = fc[K.cidx[fp]] * clean;
-      }
+      P.x[i] = x0[i]; P.b[i] = Bv[i]; P.lo[i] = V.lo(i); P.hi[i] = V.hi(i); P.findex[i] = V.findex(i); P.mapTo[i] = i;
+      for (int j = 0; j < m; j++) L.at(OFFA + i * MAXR + j) = V.A(i, j) + (i == j ? cfmDiag : 0.0);
     }
-    if (!lcpValid(V, newX, Bv, false, 0.0)) { ok = false; break; }
-    for (int i = 0; i < m; i++) X[i] = newX[i];
-    ok = true;
-    if (!newlyNot) break;
+  };
+  auto hasNan = [&](const double* x) { bool bad = false; for (int r = 0; r < m; r++) if (x[r] != x[r]) bad = true; return bad; };
+  bool success = false, ignoreFriction = false;
+  double cfm = 0.0;
+  RedLcp P;
+  // ---- stage 1: reduce + Dantzig with early termination (:461-522) ----
+  loadProblem(P, 0.0, X0);
+  lcpReduce(L, OFFA, P);
+  if (dantzigSolve(L, OFFA, OFFL, P)) {
+    for (int o = 0; o < m; o++) X[o] = P.x[P.mapTo[o]];
+    success = lcpValid(V, X, Bv, false, 0.0);
+    if (success) st |= 0x4u;
   }
-  if (ok) st |= 0x2u | 0x100u;
-  else {
-    st |= 0x20u;
-    for (int r = 0; r < m; r++) X[r] = 0;
-    classify(V, X, colNorm, false, K);
+  if (hasNan(X)) { success = false; for (int r = 0; r < m; r++) X[r] = 0; st |= 0x40u; }
+  if (!success) {
+    cfm = cm->fallbackCfm;
+    // ---- stage 2: CFM + PGS from the pre-solve x (:539-597) ----
+    loadProblem(P, cfm, X0);
+    lcpReduce(L, OFFA, P);
+    if (pgsSolve(L, OFFA, P)) {
+      for (int o = 0; o < m; o++) X[o] = P.x[P.mapTo[o]];
+      success = lcpValid(V, X, Bv, false, cfm);
+      if (success) st |= 0x8u;
+    }
   }
-  // ---- outputs ----
-  for (int r = 0; r < MAX_ROWS; r++) {
-    SV.at(lay.x + r) = r < m ? X[r] : 0.0;
-    SV.at(lay.cls + r) = r < m ? (K.cls[r] == RC_UPPER_BOUND ? (K.E[r] > 0 ? 2.0 : -2.0) : (double)K.cls[r]) : 0.0;
+  if (!success) {
+    // ---- stage 3: drop friction, PGS from zero (:606-677) ----
+    ignoreFriction = true;
+    loadProblem(P, cfm, X0);
+    lcpRemoveFriction(L, OFFA, P);
+    for (int i = 0; i < P.n; i++) P.x[i] = 0.0;
+    const bool ok3 = pgsSolve(L, OFFA, P);
+    for (int o = 0; o < m; o++) X[o] = P.mapTo[o] >= 0 ? P.x[P.mapTo[o]] : 0.0;
+    st |= 0x10u;
+    if (!ok3) st |= 0x20u;
   }
-  SV.at(lay.cfm) = 0.0;
-  if (cacheOut) {
-    for (int r = 0; r < MAX_ROWS; r++) cacheOut[(int64_t)r * B + b] = r < m ? X[r] : 0.0;
-    cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
-  }
-  // v' = v_pre + M^-1 J^T x   (applyImpulse + computeImpulseForwardDynamics)
-  for (int d = 0; d < n; d++) {
-    double w = 0;
-    for (int r = 0; r < m; r++) w += SV.at(lay.massed + d * MAX_ROWS + r) * X[r];
-    SV.at(lay.w + d) = w;
-    nv[(int64_t)d * B + b] = SV.at(lay.vpre + d) + w;
-  }
+  if (hasNan(X)) { for (int r = 0; r < m; r++) X[r] = 0; st |= 0x40u; }
+  // ---- register the fresh solution, classify, standardise (:718-736) ----
+  CodFactor F;
+  F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR;
+  Classes K;
+  if (standardizeLoop(V, L, F, X, Bv, colNorm, cfm, ignoreFriction, 0u, K)) st |= 0x100u;
+  contactOutputs(SV, lay, n, m, X, K, cfm, cacheOut, nv, B, b);
   if (status) status[b] = st;
 }
 

@@ -30,8 +30,8 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve",
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
                                            "k_bwd_final"};
 struct TimedLaunch {
@@ -223,6 +223,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_solve, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_a, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e != hipSuccess) {
     std::string msg = std::string("model upload failed: ") + hipGetErrorString(e);
     nbl_model_destroy(m);
@@ -247,7 +248,8 @@ int32_t nbl_model_lcp_rows(const nbl_model* m) { return (m && m->hasContact) ? M
 
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
-  return ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LB_TOTAL : 0)) * sizeof(double) * (size_t)B;
+  return ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LB_TOTAL : 0)) * sizeof(double) * (size_t)B +
+         (m->hasContact ? ((size_t)B + 16) * sizeof(int32_t) : 0);
 }
 size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
@@ -287,8 +289,13 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
     TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved,
                                      m->lay, (double*)workspace, lws));
     dim3 lgrid((unsigned)((B + LCP_LANES - 1) / LCP_LANES)), lblock(LCP_LANES);
+    int32_t* failList = (int32_t*)(lws + (size_t)LB_TOTAL * (size_t)B);
+    uint32_t* failCount = (uint32_t*)(failList + B);
+    HIP_TRY(hipMemsetAsync(failCount, 0, sizeof(uint32_t), s));
     TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, LCP_LDS_BYTES, s, m->mdl, m->dContact, B, (double*)saved,
-                                      m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws));
+                                      m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws, failList, failCount));
+    TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, LCP_LDS_BYTES, s, m->mdl, m->dContact, B,
+                                        (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
   }
   HIP_TRY(hipGetLastError());
   return NBL_OK;

@@ -38,17 +38,27 @@ def test_standing_atlas_contact_fwd_bwd_vs_oracle(name, B, seed):
         assert e.max() < TOL, (k, e.max())
 
 
-def test_stage0_lane_set_matches_oracle_and_resolved_lanes_agree():
-    """Larger noise: some lanes need the pivoting/PGS stages.  The device path resolves exactly the lanes the
-    reference resolves at stage 0 and flags the others NBL_ST_LCP_FAILED (zero impulses) instead of guessing."""
-    errs, st, ost, _ = _run("atlas20", 512, 13, joint_noise=0.02, vel_noise=0.0, action_noise=0.0)
+def test_full_lcp_cascade_on_noisy_poses():
+    """Larger noise: ~half of the worlds leave stage 0 and go through reduce + Dantzig, CFM + PGS and the
+    frictionless fallback on the device (k_contact_cascade).  The stage-0 lane set must equal the oracle's; the
+    cascade lanes must agree except where the Dantzig early-termination test (s <= 0) is decided by round-off on
+    rank-deficient A(C,C) (the device restatement refactors A(C,C), the reference updates it incrementally): those
+    lanes are few (< 1 %) and are reported, not hidden."""
+    errs, st, ost, _ = _run("atlas20", 1024, 13, joint_noise=0.02, vel_noise=0.01, action_noise=0.0)
     gpu0 = (st & 0x2) != 0
     ora0 = (ost & 0x2) != 0
     assert np.array_equal(gpu0, ora0)
-    assert gpu0.mean() > 0.8
-    assert np.all((st[~gpu0] & 0x20) != 0)
-    for k, e in errs.items():
-        assert e[gpu0].max() < TOL, (k, e[gpu0].max())
+    assert 0.3 < gpu0.mean() < 0.95                      # the cascade is really exercised
+    assert not np.any((st & 0x1) == 0)
+    stage_bits = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100   # ignore the NaN-seen and partial-gradient flags
+    same_stage = (st & stage_bits) == (ost & stage_bits)
+    assert same_stage.mean() > 0.99
+    agree = errs["next"] < TOL
+    assert agree.mean() > 0.99, agree.mean()
+    assert np.all(agree[same_stage])
+    for k in ("grad_state", "grad_action"):
+        assert errs[k][agree].max() < 1e-5, (k, errs[k][agree].max())   # CFM lanes: Q conditioned ~1e4
+        assert errs[k][agree & gpu0].max() < TOL
 
 
 def test_no_contact_when_lifted():
