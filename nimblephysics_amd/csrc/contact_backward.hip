@@ -253,7 +253,10 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
       V3 nrm = mk3(SV.at(r0 + CR_NORMAL), SV.at(r0 + CR_NORMAL + 1), SV.at(r0 + CR_NORMAL + 2));
       const int type = (int)SV.at(r0 + CR_TYPE);
       const int bA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].body, bB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].body;
-      if (type != CT_VERTEX_FACE && type != CT_FACE_VERTEX) gst |= 0x1u;   // edge-edge geometry terms: next round
+      V3 eAP = mk3(SV.at(r0 + CR_EA_FIXED), SV.at(r0 + CR_EA_FIXED + 1), SV.at(r0 + CR_EA_FIXED + 2));
+      V3 eAD = mk3(SV.at(r0 + CR_EA_DIR), SV.at(r0 + CR_EA_DIR + 1), SV.at(r0 + CR_EA_DIR + 2));
+      V3 eBP = mk3(SV.at(r0 + CR_EB_FIXED), SV.at(r0 + CR_EB_FIXED + 1), SV.at(r0 + CR_EB_FIXED + 2));
+      V3 eBD = mk3(SV.at(r0 + CR_EB_DIR), SV.at(r0 + CR_EB_DIR + 1), SV.at(r0 + CR_EB_DIR + 2));
       if (bA >= 0 && bB >= 0 && (cm->ancestors[bA] & cm->ancestors[bB])) gst |= 0x2u;  // self-collision chains unsupported
       // tangent basis and the pieces of its derivative (ContactConstraint.cpp:734-876)
       V3 crs = mk3(0, 0, 1), tng = cross(crs, nrm);
@@ -294,6 +297,31 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
         else if (k == 1) aFace = t1Adjoint(cc);
         else aFace = cross(nrm, cross(t1, cc)) + t1Adjoint(cross(cc, nrm));
         V6 faceTerm = mk6(aFace, mk3(0, 0, 0));
+        // edge-edge contacts (DCC.cpp:397-424, 700-735; math::getContactPointGradient Geometry.cpp:1129-1236):
+        // the contact point is the midpoint of the closest points of the two edge lines, the normal follows
+        // +-eB x eA.  Both are linear in the position twist [w; u] of the moving DOF; their adjoints:
+        V6 edgeTermA = zero6(), edgeTermB = zero6();
+        if (type == CT_EDGE_EDGE) {
+          V3 hN;   // cc . d(dir) = hN . dn
+          if (k == 0) hN = cc;
+          else if (k == 1) { V3 xp = project ? cc - dot(cc, t1) * t1 : cc; hN = (1.0 / tn) * cross(xp, crs); }
+          else { V3 x2 = cross(cc, nrm); V3 xp = project ? x2 - dot(x2, t1) * t1 : x2; hN = cross(t1, cc) + (1.0 / tn) * cross(xp, crs); }
+          const double sgnN = dot(cross(eBD, eAD), nrm) < 0 ? -1.0 : 1.0;
+          V3 pv = eBP - eAP;
+          const double uaub = dot(eAD, eBD), q1 = dot(eAD, pv), q2 = -dot(eBD, pv), dd = 1 - uaub * uaub;
+          V3 gPa, gDa, gPb, gDb;
+          if (dd <= 0) { gPa = 0.5 * cv; gDa = mk3(0, 0, 0); gPb = 0.5 * cv; gDb = mk3(0, 0, 0); }
+          else {
+            const double e = 1.0 / dd, N1 = q1 + uaub * q2, N2 = uaub * q1 + q2, alpha = N1 * e, beta = N2 * e;
+            const double ca = dot(cv, eAD), cb = dot(cv, eBD), k2 = 2 * uaub * e * e;
+            gPa = 0.5 * (cv + ca * (e * uaub * eBD - e * eAD) + cb * (e * eBD - e * uaub * eAD));
+            gDa = 0.5 * (alpha * cv + ca * ((k2 * N1 + e * q2) * eBD + e * pv) + cb * ((k2 * N2 + e * q1) * eBD + (e * uaub) * pv));
+            gPb = 0.5 * (cv + ca * (e * eAD - e * uaub * eBD) + cb * (e * uaub * eAD - e * eBD));
+            gDb = 0.5 * (beta * cv + ca * ((k2 * N1 + e * q2) * eAD - (e * uaub) * pv) + cb * ((k2 * N2 + e * q1) * eAD - e * pv));
+          }
+          edgeTermA = mk6(cross(eAP, gPa) + cross(eAD, gDa) + sgnN * cross(eAD, cross(hN, eBD)), gPa);
+          edgeTermB = mk6(cross(eBP, gPb) + cross(eBD, gDb) + sgnN * cross(eBD, cross(eAD, hN)), gPb);
+        }
         const bool aIsVertex = (type == CT_VERTEX_FACE);
         for (int side = 0; side < 2; side++) {
           const int start = side == 0 ? bA : bB;
@@ -305,6 +333,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
             V6 Zl = sgn * (Tend - twistOf(par));
             V6 add = -dad(Zl, Fw);
             if (type == CT_VERTEX_FACE || type == CT_FACE_VERTEX) add = add + (vertexSide ? vertexTerm : faceTerm);
+            else if (type == CT_EDGE_EDGE) add = add + (side == 0 ? edgeTermA : edgeTermB);
             addV6(c, l, WS_XI, add);
           }
         }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevCo
   uint32_t st = 0;
   if (nC > 0) st |= 0x1u;
   if (overflow) st |= 0x80u;
-  if (edge) st |= 0x200u;   // NBL_ST_GRAD_PARTIAL: edge-edge contact geometry terms are not in the device backward yet
+  (void)edge;
   if (status) status[b] = st;
 }
 

@@ -47,3 +47,29 @@ def contact_inputs(name, B, seed, joint_noise=0.002, vel_noise=0.001, action_noi
     v = rng.normal(0, vel_noise, (B, n))
     a = rng.normal(0, action_noise, (B, n))
     return md, np.concatenate([q, v], 1), a
+
+
+def box_stack_inputs(B, seed, overhang=False):
+    """cfg4: welded ground box + two FreeJoint cubes (0.2^3, mu = 1).  Default: box 2 stacked on box 1 with the same
+    yaw and a small lateral offset -> 4 + 4 = 8 contacts (FACE_VERTEX below, EDGE_EDGE / FACE_VERTEX / VERTEX_FACE
+    between the cubes), penetration 1e-4..1e-3.  overhang=True: one cube hanging over the rim of the ground box
+    (EDGE_EDGE contacts against the world-fixed box, stage-0 regime), the other cube parked far above."""
+    rng = np.random.default_rng(seed)
+    md = na.box_stack()
+    q = np.zeros((B, 12)); v = np.zeros((B, 12))
+    pen1, pen2 = rng.uniform(1e-4, 1e-3, B), rng.uniform(1e-4, 1e-3, B)
+    yaw = rng.uniform(-np.pi, np.pi, B)
+    if overhang:
+        q[:, 1] = yaw; q[:, 3] = rng.uniform(0.9, 0.99, B) * rng.choice([-1, 1], B); q[:, 4] = 0.1 - pen1; q[:, 5] = rng.uniform(-0.5, 0.5, B)
+        q[:, 10] = 5.0
+        v[:, 0:6] = rng.normal(0, 0.001, (B, 6))
+    else:
+        q[:, 1] = yaw; q[:, 4] = 0.1 - pen1; q[:, 3] = rng.uniform(-0.3, 0.3, B); q[:, 5] = rng.uniform(-0.3, 0.3, B)
+        off = rng.uniform(0.005, 0.03, (B, 2)) * rng.choice([-1, 1], (B, 2))
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        q[:, 7] = yaw
+        q[:, 9] = q[:, 3] + c * off[:, 0] + s_ * off[:, 1]; q[:, 11] = q[:, 5] - s_ * off[:, 0] + c * off[:, 1]
+        q[:, 10] = 0.3 - pen1 - pen2
+        v[:, [3, 5, 9, 11]] = rng.normal(0, 0.05, (B, 4))
+    a = np.zeros((B, 12))
+    return md, np.concatenate([q, v], 1), a
