@@ -176,6 +176,10 @@ int32_t nbl_transpose_to_soa(const double* src_bd, double* dst_db, int64_t B, in
 int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, int32_t d, void* stream);
 
 /* Average duration (ms) of the last timed launches, measured with HIP events on the launch stream. */
+/* Launch shape: worlds per workgroup for the tree kernels (power of two <= 64) and for the LDS-staged dense kernels
+ * (power of two <= 16); 0 = default (16 below 65536 worlds, else 64 / 16).  Results do not depend
+ * on it (one world per lane either way); environment NBL_TREE_LANES / NBL_LCP_LANES set the initial value. */
+int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes);
 int32_t nbl_set_timing(nbl_model* m, int32_t enabled);
 int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, double* bwd_ms_sum,
                        int64_t* bwd_count);

@@ -34,7 +34,7 @@ DEV double qEntry(const LcpView& V, const Classes& K, double cfm, int r, int s) 
 __global__ __launch_bounds__(64) void k_bwd_recompute(DevModel mdl, const DevBody* __restrict__ bodies,
                                                       const DevDof* __restrict__ dofs, int64_t B,
                                                       const double* __restrict__ saved, double* __restrict__ ws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;
@@ -49,14 +49,15 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
                                                       const double* __restrict__ gnext, double* __restrict__ ws,
                                                       double* __restrict__ lws) {
   extern __shared__ __attribute__((aligned(16))) double ldsq[];   // Q factor + Cholesky factor, LCP_LANES worlds (see k_contact_solve)
-  const int64_t b = (int64_t)blockIdx.x * LCP_LANES + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  LaneMem QL; QL.base = ldsq; QL.B = LCP_LANES; QL.b = threadIdx.x;
+  LaneMem QL; QL.base = ldsq; QL.B = (int)blockDim.x; QL.b = threadIdx.x;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;
   const double* gvn = gnext + (int64_t)n * B;
   LaneMem L; L.base = lws; L.B = B; L.b = b;
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
+  const LaneMem DN = denseMem(saved, lay, B, b);
   const int nC = (int)SV.at(lay.nc);
   const int m = 3 * nC;
   // classes as stored by the forward pass
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
     return;
   }
   LcpView V;
-  V.mem = SV; V.offA = lay.A; V.m = m;
+  V.mem = DN; V.offA = lay.A; V.m = m;
   for (int ci = 0; ci < nC; ci++) {
     const int r0 = lay.contacts + ci * CR_SIZE;
     const double muA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].mu, muB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].mu;
@@ -104,10 +105,10 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
     fc[i] = SV.at(lay.x + r);
     double s = 0;
     for (int d = 0; d < n; d++) {
-      double a = SV.at(lay.aall + d * MAX_ROWS + r);
+      double a = DN.at(lay.aall + d * MAX_ROWS + r);
       if (K.nu > 0 && (r % 3) == 0)
         for (int u = r + 1; u < r + 3 && u < m; u++)
-          if (K.cls[u] == RC_UPPER_BOUND) a += K.E[u] * SV.at(lay.aall + d * MAX_ROWS + u);
+          if (K.cls[u] == RC_UPPER_BOUND) a += K.E[u] * DN.at(lay.aall + d * MAX_ROWS + u);
       s += a * L.at(LB_LAM1 + d);
     }
     fbar[i] = s;
@@ -151,13 +152,13 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
     double sk[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, acmu = 0;
     for (int i = 0; i < nc; i++) {
       const int r = rowOf[i];
-      const double ms = SV.at(lay.massed + d * MAX_ROWS + r);
+      const double ms = DN.at(lay.massed + d * MAX_ROWS + r);
       double mb = ms;
       if (K.nu > 0 && (r % 3) == 0)
         for (int u = r + 1; u < r + 3 && u < m; u++)
-          if (K.cls[u] == RC_UPPER_BOUND) mb += K.E[u] * SV.at(lay.massed + d * MAX_ROWS + u);
+          if (K.cls[u] == RC_UPPER_BOUND) mb += K.E[u] * DN.at(lay.massed + d * MAX_ROWS + u);
       for (int k = 0; k < 3; k++) { sk[k] += al[k][i] * ms; pk[k] += be[k][i] * mb; }
-      acmu += mu[i] * SV.at(lay.aall + d * MAX_ROWS + r);
+      acmu += mu[i] * DN.at(lay.aall + d * MAX_ROWS + r);
     }
     for (int k = 0; k < 3; k++) { L.at(LB_S + k * MAX_DOF_CONTACT + d) = sk[k]; L.at(LB_P + k * MAX_DOF_CONTACT + d) = pk[k]; }
     L.at(LB_GVP + d) = gvn[(int64_t)d * B + b] - acmu;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
                                                       int64_t B, double* __restrict__ saved, SavedLayout lay,
                                                       double* __restrict__ ws, double* __restrict__ lws,
                                                       uint32_t* __restrict__ gradStatus) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64) void k_bwd_final(DevModel mdl, const DevBody* _
                                                   const double* __restrict__ saved, const double* __restrict__ gnext,
                                                   double* __restrict__ gstate, double* __restrict__ gaction,
                                                   double* __restrict__ ws, const double* __restrict__ lws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;

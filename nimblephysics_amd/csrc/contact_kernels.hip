@@ -16,6 +16,9 @@
 namespace nbl {
 
 DEV double& svAt(double* saved, int row, int64_t B, int64_t b) { return saved[(int64_t)row * B + b]; }
+// the world-major dense block of world b (SavedLayout)
+DEV double* denseOf(double* saved, const SavedLayout& lay, int64_t B, int64_t b) { return saved + (int64_t)lay.total * B + b * (int64_t)lay.dense; }
+DEV LaneMem denseMem(double* saved, const SavedLayout& lay, int64_t B, int64_t b) { LaneMem m; m.base = denseOf(saved, lay, B, b); m.B = 1; m.b = 0; return m; }
 
 // ContactConstraint::getTangentBasisMatrixODE (ContactConstraint.cpp:734-795)
 DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
@@ -35,7 +38,7 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
 __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                        double* __restrict__ saved, SavedLayout lay,
                                                        uint32_t* __restrict__ status, double* __restrict__ ws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c;
   c.ws = ws; c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
                                                      const DevContactModel* __restrict__ cm, int64_t B,
                                                      double* __restrict__ saved, SavedLayout lay, double* __restrict__ ws,
                                                      double* __restrict__ lws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c;
   c.bodies = bodies; c.ws = ws; c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
   const int nC = (int)svAt(saved, lay.nc, B, b);
   if (!__any(nC > 0)) return;
   const double* vpre = saved + (int64_t)lay.vpre * B;
+  double* dn = denseOf(saved, lay, B, b);
 
   // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_A
   for (int i = 0; i < c.nb; i++) {
@@ -147,11 +151,11 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
         if (bd.jtype != JT_FREE) {
           double val = 0;
           if (mult != 0.0) val = mult * dot(cV6(bd.S), dAdT(ldTAt(c, i, WS_TW), F));
-          svAt(saved, lay.aall + bd.dofOff * MAX_ROWS + row, B, b) = val;
+          dn[lay.aall + bd.dofOff * MAX_ROWS + row] = val;
         } else {
           double v6[6] = {0, 0, 0, 0, 0, 0};
           if (mult != 0.0) toArr(dAdT(cT(bd.Tcj), dAdT(ldTAt(c, i, WS_TW), F)), v6);
-          for (int e = 0; e < 6; e++) svAt(saved, lay.aall + (bd.dofOff + e) * MAX_ROWS + row, B, b) = mult * v6[e];
+          for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
         }
       }
     }
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
           V6 X = bd.parent >= 0 ? AdInvT(T, ldV6(c, bd.parent, ACC[k])) : zero6();
           double dq = psi * (wsAt(c, i, WS_UIMP + k) - dot(AIS, X));   // GenericJoint.hpp:2713-2725
           stV6(c, i, ACC[k], X + dq * S);
-          if (active) svAt(saved, lay.massed + bd.dofOff * MAX_ROWS + 3 * ci + k, B, b) = dq;
+          if (active) dn[lay.massed + bd.dofOff * MAX_ROWS + 3 * ci + k] = dq;
         }
       } else {
         const int US[3] = {WS_UIMP, WS_W, WS_VBAR};
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
           for (int e = 0; e < 6; e++) r[e] = wsAt(c, i, US[k] + e) - pj[e];
           ldl6Solve(f, r);
           stV6(c, i, ACC[k], X + AdT(cT(bd.Tcj), fromArr(r)));
-          if (active) for (int e = 0; e < 6; e++) svAt(saved, lay.massed + (bd.dofOff + e) * MAX_ROWS + 3 * ci + k, B, b) = r[e];
+          if (active) for (int e = 0; e < 6; e++) dn[lay.massed + (bd.dofOff + e) * MAX_ROWS + 3 * ci + k] = r[e];
         }
       }
     }
@@ -240,14 +244,14 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
             double val = 0;
             if (b2A >= 0) val += dot(JA, dVA[k]);
             if (b2B >= 0) val += dot(JB, dVB[k]);
-            svAt(saved, lay.A + (3 * ci + k) * MAX_ROWS + col, B, b) = val;
+            dn[lay.A + (3 * ci + k) * MAX_ROWS + col] = val;
           }
         }
       }
       for (int c2 = 0; c2 < ci; c2++)
         for (int k2 = 0; k2 < 3; k2++)
           for (int k = 0; k < 3; k++)
-            svAt(saved, lay.A + (3 * ci + k) * MAX_ROWS + 3 * c2 + k2, B, b) = svAt(saved, lay.A + (3 * c2 + k2) * MAX_ROWS + 3 * ci + k, B, b);
+            dn[lay.A + (3 * ci + k) * MAX_ROWS + 3 * c2 + k2] = dn[lay.A + (3 * c2 + k2) * MAX_ROWS + 3 * ci + k];
     }
   }
 }
@@ -255,58 +259,9 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
 // ---------------------------------------------------------------------------------------------
 // stage 0 solve + apply
 // ---------------------------------------------------------------------------------------------
-// ---- shared pieces of the stage-0 kernel and the cascade kernel ----
-// CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (the reference recurses while normal
-// rows drop out of the clamping set, CGGM.cpp:321-332).  On return K holds the last classification and X the
-// last accepted solution; returns whether the results are standardised (valid least-squares solution).
-DEV bool standardizeLoop(const LcpView& V, const LaneMem& L, CodFactor& F, double* X, const double* Bv, const double* colNorm,
-                         double cfm, bool ignoreFriction, uint32_t guessMask, Classes& K) {
-  const int m = V.m;
-  bool ok = false;
-  for (int iter = 0; iter < MAXR + 1; iter++) {
-    classify(V, X, colNorm, ignoreFriction, K);
-    if (K.nc == 0) {
-      double zero[MAXR];
-      for (int r = 0; r < m; r++) zero[r] = 0;
-      ok = lcpValid(V, zero, Bv, ignoreFriction, cfm);
-      if (ok) for (int r = 0; r < m; r++) X[r] = 0;
-      break;
-    }
-    double bc[MAXR], fc[MAXR], newX[MAXR], origFc[MAXR];
-    uint32_t clampMask = 0;
-    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) { origFc[K.cidx[r]] = X[r]; clampMask |= 1u << r; }
-    if (iter == 0 && K.nu == 0 && guessMask != 0 && clampMask == guessMask) {
-      // the clamping set is exactly the guess's set: Q and b_c are the system just solved, f_c = that solution
-      for (int i = 0; i < K.nc; i++) fc[i] = origFc[i];
-    } else {
-      buildQ(V, K, cfm, L, 0, Bv, bc);
-      F.c = K.nc;
-      codFactor(L, F);
-      codSolve(L, F, bc, fc);
-    }
-    bool newlyNot = false;
-    for (int i = 0; i < m; i++) {
-      newX[i] = 0;
-      if (K.cls[i] == RC_CLAMPING) {
-        newX[i] = fc[K.cidx[i]];
-        if (fabs(newX[i]) < 1e-6 && fabs(X[i]) > 1e-6 && (i % 3) == 0) newlyNot = true;
-      } else if (K.cls[i] == RC_UPPER_BOUND) {
-        const int fp = i - (i % 3);
-        double om = origFc[K.cidx[fp]] / X[i];
-        double clean = (fabs(om - V.hi(i)) < fabs(om - V.lo(i))) ? V.hi(i) : V.lo(i);
-        newX[i] = fc[K.cidx[fp]] * clean;
-      }
-    }
-    if (!lcpValid(V, newX, Bv, ignoreFriction, cfm)) { ok = false; break; }
-    for (int i = 0; i < m; i++) X[i] = newX[i];
-    ok = true;
-    if (!newlyNot) break;
-  }
-  return ok;
-}
-
-DEV void contactOutputs(const LaneMem& SV, const SavedLayout& lay, int n, int m, const double* X, const Classes& K, double cfm,
+DEV void contactOutputs(const LaneMem& SV, const LaneMem& DN, const SavedLayout& lay, int n, int m, const double* X, const Classes& K, double cfm,
                         double* __restrict__ cacheOut, double* __restrict__ nv, int64_t B, int64_t b) {
+  SV.at(lay.pflag) = 0.0;   // no pseudo-inverse saved by the one-world-per-lane path
   for (int r = 0; r < MAX_ROWS; r++) {
     SV.at(lay.x + r) = r < m ? X[r] : 0.0;
     SV.at(lay.cls + r) = r < m ? (K.cls[r] == RC_UPPER_BOUND ? (K.E[r] > 0 ? 2.0 : -2.0) : (double)K.cls[r]) : 0.0;
@@ -319,14 +274,14 @@ DEV void contactOutputs(const LaneMem& SV, const SavedLayout& lay, int n, int m,
   // v' = v_pre + M^-1 J^T x   (applyImpulse + computeImpulseForwardDynamics)
   for (int d = 0; d < n; d++) {
     double w = 0;
-    for (int r = 0; r < m; r++) w += SV.at(lay.massed + d * MAX_ROWS + r) * X[r];
+    for (int r = 0; r < m; r++) w += DN.at(lay.massed + d * MAX_ROWS + r) * X[r];
     SV.at(lay.w + d) = w;
     nv[(int64_t)d * B + b] = SV.at(lay.vpre + d) + w;
   }
 }
 
-DEV void loadLcpView(LcpView& V, const LaneMem& SV, const SavedLayout& lay, const DevContactModel* cm, int nC) {
-  V.mem = SV; V.offA = lay.A; V.m = 3 * nC;
+DEV void loadLcpView(LcpView& V, const LaneMem& SV, const LaneMem& DN, const SavedLayout& lay, const DevContactModel* cm, int nC) {
+  V.mem = DN; V.offA = lay.A; V.m = 3 * nC;
   for (int ci = 0; ci < nC; ci++) {
     const int r0 = lay.contacts + ci * CR_SIZE;
     const double muA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].mu, muB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].mu;
@@ -347,57 +302,43 @@ __global__ __launch_bounds__(LCP_LANES) void k_contact_solve(DevModel mdl, const
                                                       double* __restrict__ lws, int32_t* __restrict__ failList,
                                                       uint32_t* __restrict__ failCount) {
   extern __shared__ __attribute__((aligned(16))) double ldsq[];
-  const int64_t b = (int64_t)blockIdx.x * LCP_LANES + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int n = mdl.n;
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;
   LaneMem L;
-  L.base = ldsq; L.B = LCP_LANES; L.b = threadIdx.x;
+  L.base = ldsq; L.B = (int)blockDim.x; L.b = threadIdx.x;
   LaneMem SV;
   SV.base = saved; SV.B = B; SV.b = b;
+  const LaneMem DN = denseMem(saved, lay, B, b);
   double* nv = next + (int64_t)n * B;
   uint32_t st = status ? status[b] : 0u;
   // cache layout: MAX_ROWS values + the row count they belong to
   if (m == 0) {
     if (cacheOut) { for (int r = 0; r < MAX_ROWS; r++) cacheOut[(int64_t)r * B + b] = 0; cacheOut[(int64_t)MAX_ROWS * B + b] = 0; }
     for (int r = 0; r < MAX_ROWS; r++) { SV.at(lay.x + r) = 0; SV.at(lay.cls + r) = 0; }
-    SV.at(lay.cfm) = 0;
+    SV.at(lay.cfm) = 0; SV.at(lay.pflag) = 0;
     for (int d = 0; d < n; d++) SV.at(lay.w + d) = 0;
     return;
   }
   LcpView V;
-  loadLcpView(V, SV, lay, cm, nC);
+  loadLcpView(V, SV, DN, lay, cm, nC);
   double Bv[MAXR], X[MAXR], colNorm[MAXR];
   for (int r = 0; r < m; r++) Bv[r] = SV.at(lay.b + r);
   for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
 
-  CodFactor F;
-  F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR;
-  // ---- warm start, or LCPUtils::guessSolution when the cache belongs to another row count ----
-  bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
-  uint32_t guessMask = 0;   // rows of the guess's clamping set; its factorisation can be reused by the first standardisation
+  // ---- warm start, or LCPUtils::guessSolution when the cache belongs to another row count; standardise ----
+  const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
   if (haveCache) { for (int r = 0; r < m; r++) X[r] = cacheIn[(int64_t)r * B + b]; }
-  else {
-    int idx[MAXR], nc = 0;
-    for (int r = 0; r < m; r++) if ((r % 3) != 0 || Bv[r] > 0) { idx[nc++] = r; guessMask |= 1u << r; }
-    for (int r = 0; r < m; r++) X[r] = 0;
-    if (nc > 0) {
-      double rhs[MAXR], sol[MAXR];
-      for (int i = 0; i < nc; i++) { rhs[i] = Bv[idx[i]]; for (int j = 0; j < nc; j++) L.at(i * MAXR + j) = V.A(idx[i], idx[j]); }
-      F.c = nc;
-      codFactor(L, F);
-      codSolve(L, F, rhs, sol);
-      for (int i = 0; i < nc; i++) X[idx[i]] = sol[i];
-    }
-  }
-  // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
-  for (int r = 0; r < MAX_ROWS; r++) lws[(int64_t)(LW_JA + r) * B + b] = r < m ? X[r] : 0.0;
+  double X0[MAXR];
   Classes K;
-  const bool ok = standardizeLoop(V, L, F, X, Bv, colNorm, 0.0, false, guessMask, K);
+  const bool ok = laneStage0(V, L, haveCache, X, X0, Bv, colNorm, K);
+  // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
+  for (int r = 0; r < MAX_ROWS; r++) lws[(int64_t)(LW_JA + r) * B + b] = r < m ? X0[r] : 0.0;
   if (ok) {
     st |= 0x2u | 0x100u;
-    contactOutputs(SV, lay, n, m, X, K, 0.0, cacheOut, nv, B, b);
+    contactOutputs(SV, DN, lay, n, m, X, K, 0.0, cacheOut, nv, B, b);
   } else {
     const uint32_t slot = atomicAdd(failCount, 1u);
     failList[slot] = (int32_t)b;
@@ -415,20 +356,21 @@ __global__ __launch_bounds__(LCP_LANES) void k_contact_cascade(DevModel mdl, con
                                                         const int32_t* __restrict__ failList,
                                                         const uint32_t* __restrict__ failCount) {
   extern __shared__ __attribute__((aligned(16))) double ldsq[];
-  const uint32_t t = blockIdx.x * LCP_LANES + threadIdx.x;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *failCount) return;
   const int64_t b = failList[t];
   const int n = mdl.n;
   LaneMem L;
-  L.base = ldsq; L.B = LCP_LANES; L.b = threadIdx.x;
+  L.base = ldsq; L.B = (int)blockDim.x; L.b = threadIdx.x;
   LaneMem SV;
   SV.base = saved; SV.B = B; SV.b = b;
+  const LaneMem DN = denseMem(saved, lay, B, b);
   const int nC = (int)SV.at(lay.nc);
   const int m = 3 * nC;
   double* nv = next + (int64_t)n * B;
   uint32_t st = status ? status[b] : 0u;
   LcpView V;
-  loadLcpView(V, SV, lay, cm, nC);
+  loadLcpView(V, SV, DN, lay, cm, nC);
   double Bv[MAXR], X[MAXR], X0[MAXR], colNorm[MAXR];
   for (int r = 0; r < m; r++) { Bv[r] = SV.at(lay.b + r); X0[r] = lws[(int64_t)(LW_JA + r) * B + b]; X[r] = X0[r]; }
   for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
@@ -481,7 +423,7 @@ __global__ __launch_bounds__(LCP_LANES) void k_contact_cascade(DevModel mdl, con
   F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR;
   Classes K;
   if (standardizeLoop(V, L, F, X, Bv, colNorm, cfm, ignoreFriction, 0u, K)) st |= 0x100u;
-  contactOutputs(SV, lay, n, m, X, K, cfm, cacheOut, nv, B, b);
+  contactOutputs(SV, DN, lay, n, m, X, K, cfm, cacheOut, nv, B, b);
   if (status) status[b] = st;
 }
 

@@ -1,0 +1,393 @@
+// coop_dev.hpp — wavefront-cooperative dense linear algebra for the contact LCP: ONE WORLD PER WAVEFRONT.
+//
+// The one-world-per-lane kernels (lcp_dev.hpp) are a single long dependent instruction stream per wave (~6e5
+// instructions for a 24-row stage-0 solve) and a B = 4096 launch has only 64..256 of them for 1024 SIMDs.  Here a
+// wavefront owns one world; lane j (< 24) owns column j / row j of the 24 x 24 system, lanes 24..47 carry the
+// identity through the factorisation (they end up holding H^T explicitly, for free), and the serial chain per wave
+// drops to ~1e4 instructions while 4096 waves fill the chip.
+//
+// Same mathematics as lcp_dev.hpp (which remains the host-testable statement of it and the slow-path code):
+//   * column-pivoted Householder QR, rank by Eigen's threshold eps * size * |R_00| (CGGM.cpp:280, LCPUtils.cpp:113)
+//   * complete orthogonal decomposition for rank-deficient systems: a second (unpivoted) Householder QR of R^T,
+//     R = [T^T 0] Z^T, minimum-norm solution Z1 T^-T c1 (what Eigen's completeOrthogonalDecomposition().solve() returns)
+//   * the result is assembled as the explicit pseudo-inverse Q^+ (24 x 24) in LDS: every later solve with Q or Q^T
+//     (1 in the forward pass, 4 in the backward pass) is a 24-term dot product per lane.
+// Sub-matrices are selected by MASKS, not compaction: a row/column that is not in the clamping set is zeroed, which
+// makes the padded pseudo-inverse equal to the compacted one embedded in zeros; the rank threshold uses the true size.
+//
+// Register discipline: a lane's column lives in a[0..23] with compile-time indices only; the k loop is a real loop
+// and the column is SHIFTED down one row per step (row k of the result goes to LDS), so the code stays small
+// (fits the instruction cache) and nothing spills to scratch.
+//
+// The wave primitives come from a policy class W (lane(), maxAll(), ballot(), shfl(), sync()): DevWave on the GPU
+// (coop_wave_dev.hpp), a thread-per-lane emulation in tests/host_shim for the CPU tests.
+#pragma once
+#include "lcp_dev.hpp"
+
+namespace nbl {
+
+constexpr int CLD = MAXR + 1;  // odd leading dimension: row reads and column reads of the LDS matrices are both conflict-free
+
+struct CoopLds {
+  double R[MAXR * CLD];        // rows of R (lane order; perm maps pivot position -> lane), later rows of T
+  double G[MAXR * CLD];        // rows of G = H^T
+  double P[MAXR * CLD];        // rows of Z^T during the second factorisation, then the pseudo-inverse (row-major)
+  double vbuf[2][MAXR + 2];    // reflector broadcast, double-buffered: [1..23] v (v_0 = 1 implied), [24] tau
+  double invd[MAXR];           // reciprocals of the diagonal of R / T
+  double vec[4][MAXR];         // vector broadcast scratch
+  int perm[MAXR];
+  int pad[4];
+};
+static_assert(sizeof(CoopLds) % 16 == 0, "CoopLds must keep 16-byte alignment in an array");
+
+// Householder QR of the matrix whose column j is a[] of lane j (< 24); lanes 24..47 carry extra columns that only
+// receive the reflections.  PIVOT: column pivoting with the rank test, else the pivot of step k is lane k and exactly
+// `steps` reflections are made.  Row k of the triangular factor goes to rowsOut[k * CLD + lane], row k of the carried
+// block to carryOut[k * CLD + lane - 24].  a[] is consumed.  Returns the number of reflections made (the rank).
+template <class W, bool PIVOT>
+DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, double* carryOut, int steps, double thr2) {
+  const int ln = w.lane();
+  bool done = false;
+  double best0 = 0.0;
+  int rank = 0;
+#pragma unroll 1
+  for (int k = 0; k < steps; k++) {
+    double below = 0.0;
+#pragma unroll
+    for (int i = 1; i < MAXR; i++) below = fma(a[i], a[i], below);
+    const double nrm = fma(a[0], a[0], below);
+    int p = k;
+    if (PIVOT) {
+      const double cand = (ln < MAXR && !done) ? nrm : -1.0;
+      const double best = w.maxAll(cand);
+      if (k == 0) best0 = best;
+      if (!(best > thr2 * best0) || !(best > 0.0)) break;
+      p = __builtin_ctzll(w.ballot(cand == best));
+    }
+    double* vb = S.vbuf[k & 1];
+    if (ln == p) {
+      const double akk = a[0];
+      const double normx = sqrt(nrm);
+      const double alpha = akk > 0 ? -normx : normx;
+      const double vk = akk - alpha;                 // v = x - alpha e_k, scaled so that v_k = 1
+      const double vnorm2 = fma(vk, vk, below);
+      const double inv = 1.0 / vk;
+      vb[MAXR] = 2.0 * vk * vk / vnorm2;             // tau:  H = I - tau v v^T
+#pragma unroll
+      for (int i = 1; i < MAXR; i++) { vb[i] = a[i] * inv; a[i] = 0.0; }
+      a[0] = alpha;
+      done = true;
+      if (PIVOT) S.perm[k] = p;
+    }
+    w.sync();
+    const double tau = vb[MAXR];
+    double d = a[0];
+    double v[MAXR];
+#pragma unroll
+    for (int i = 1; i < MAXR; i++) { v[i] = vb[i]; d = fma(v[i], a[i], d); }
+    d = (ln == p) ? 0.0 : d * tau;
+    a[0] -= d;
+#pragma unroll
+    for (int i = 1; i < MAXR; i++) a[i] = fma(-d, v[i], a[i]);
+    if (ln < MAXR) rowsOut[k * CLD + ln] = a[0];
+    else if (ln < 2 * MAXR) carryOut[k * CLD + ln - MAXR] = a[0];
+#pragma unroll
+    for (int i = 0; i < MAXR - 1; i++) a[i] = a[i + 1];
+    a[MAXR - 1] = 0.0;
+    rank = k + 1;
+  }
+  if (PIVOT) {
+    // columns never chosen (dependent or masked) take the remaining pivot positions in lane order
+    const bool un = ln < MAXR && !done;
+    const uint64_t um = w.ballot(un);
+    if (un) S.perm[rank + __builtin_popcountll(um & ((1ull << ln) - 1ull))] = ln;
+  }
+  w.sync();
+  return rank;
+}
+
+// S.P <- pseudo-inverse of the 24 x 24 matrix whose column j is a[] of lane j (< 24) (masked rows/columns zero);
+// cTrue = number of unmasked columns (Eigen's `size` in the rank threshold).  Returns the rank.
+template <class W>
+DEV int coopPinv(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
+  const int ln = w.lane();
+  if (ln >= MAXR) {
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) a[i] = (ln - MAXR == i) ? 1.0 : 0.0;
+  }
+  const double thr = 2.220446049250313e-16 * cTrue;
+  const int r = coopQr<W, true>(w, a, S, S.R, S.G, MAXR, thr * thr);
+  if (r == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.P[i * CLD + ln] = 0.0;
+    w.sync();
+    return 0;
+  }
+  double g[MAXR];
+  if (r >= cTrue) {
+    // full column rank on the unmasked columns (R2 = 0): column j of Q^+ is P R1^-1 G1[:, j], back substitution,
+    // the current unknown always in g[0]
+    if (ln < r) S.invd[ln] = 1.0 / S.R[ln * CLD + S.perm[ln]];
+    w.sync();
+    const int j = ln < MAXR ? ln : 0;
+#pragma unroll
+    for (int m = 0; m < MAXR; m++) g[m] = (m < r) ? S.G[(r - 1 - m) * CLD + j] : 0.0;
+#pragma unroll 1
+    for (int kk = r - 1; kk >= 0; kk--) {
+      const int pk = S.perm[kk];
+      const double yk = g[0] * S.invd[kk];
+      if (ln < MAXR) S.P[pk * CLD + ln] = yk;
+#pragma unroll
+      for (int m = 1; m < MAXR; m++) {
+        const int row = kk - m;
+        const double rv = row >= 0 ? S.R[(row >= 0 ? row : 0) * CLD + pk] : 0.0;
+        g[m - 1] = fma(-rv, yk, g[m]);
+      }
+      g[MAXR - 1] = 0.0;
+    }
+#pragma unroll 1
+    for (int pp = r; pp < MAXR; pp++) if (ln < MAXR) S.P[S.perm[pp] * CLD + ln] = 0.0;
+    w.sync();
+    return r;
+  }
+  // rank deficient: R = [R1 R2] (r x c, pivot order).  Second factorisation R^T = Z [T; 0]: lane i (< r) takes row i
+  // of R as its column (entries in pivot order), lanes 24..47 carry the identity and end as Z^T.
+  if (ln < MAXR) {
+#pragma unroll
+    for (int pp = 0; pp < MAXR; pp++) a[pp] = (ln < r) ? S.R[ln * CLD + S.perm[pp]] : 0.0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) a[i] = (ln - MAXR == i) ? 1.0 : 0.0;
+  }
+  w.sync();   // every row of R is in registers before T overwrites the buffer
+  coopQr<W, false>(w, a, S, S.R, S.P, r, 0.0);
+  if (ln < r) S.invd[ln] = 1.0 / S.R[ln * CLD + ln];
+  w.sync();
+  // column j of Q^+ = P Z1 T^-T G1[:, j]: forward substitution with T^T, accumulating Z1 w on the fly
+  const int j = ln < MAXR ? ln : 0;
+#pragma unroll
+  for (int m = 0; m < MAXR; m++) g[m] = (m < r) ? S.G[m * CLD + j] : 0.0;
+  double y[MAXR];
+#pragma unroll
+  for (int pp = 0; pp < MAXR; pp++) y[pp] = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < r; k++) {
+    const double wk = g[0] * S.invd[k];
+#pragma unroll
+    for (int pp = 0; pp < MAXR; pp++) y[pp] = fma(S.P[k * CLD + pp], wk, y[pp]);   // Z[pp][k] = Z^T[k][pp]
+#pragma unroll
+    for (int m = 1; m < MAXR; m++) {
+      const int col = k + m;
+      const double tv = col < r ? S.R[k * CLD + (col < MAXR ? col : 0)] : 0.0;      // T[k][col]
+      g[m - 1] = fma(-tv, wk, g[m]);
+    }
+    g[MAXR - 1] = 0.0;
+  }
+  w.sync();   // all reads of Z^T done before the buffer becomes Q^+
+#pragma unroll
+  for (int pp = 0; pp < MAXR; pp++) if (ln < MAXR) S.P[S.perm[pp] * CLD + ln] = y[pp];
+  w.sync();
+  return r;
+}
+
+// y_lane = sum_k P[lane][k] x_k (TRANS: P[k][lane]) with x given one entry per lane (lanes >= 24 ignored)
+template <class W, bool TRANS>
+DEV double coopPinvApply(const W& w, CoopLds& S, double xLane, int slot) {
+  const int ln = w.lane();
+  if (ln < MAXR) S.vec[slot][ln] = xLane;
+  w.sync();
+  const int i = ln < MAXR ? ln : 0;
+  double y = 0.0;
+#pragma unroll
+  for (int k = 0; k < MAXR; k++) y = fma(TRANS ? S.P[k * CLD + i] : S.P[i * CLD + k], S.vec[slot][k], y);
+  return y;
+}
+
+// ---- per-row (lane = LCP row) pieces of LCPUtils / CGGM, see lcp_dev.hpp for the one-world-per-lane statement ----
+struct CoopRow {
+  int m;            // rows of this world's LCP (uniform)
+  bool fric;        // this lane's row is a friction row
+  int fp;           // lane of the normal row of this lane's contact
+  double mu, Bv, colNorm;
+  double acol[MAXR];   // column (= row, A is symmetric) `lane` of A, zero beyond m
+};
+
+// A x for this lane's row, x one entry per lane
+template <class W>
+DEV double coopAx(const W& w, CoopLds& S, const CoopRow& R, double xLane, int slot) {
+  const int ln = w.lane();
+  if (ln < MAXR) S.vec[slot][ln] = (ln < R.m) ? xLane : 0.0;
+  w.sync();
+  double v = 0.0;
+#pragma unroll
+  for (int jx = 0; jx < MAXR; jx++) v = fma(R.acol[jx], S.vec[slot][jx], v);
+  return v;
+}
+
+// LCPUtils::isLCPSolutionValid (LCPUtils.cpp:12-80), uniform result
+template <class W>
+DEV bool coopValid(const W& w, CoopLds& S, const CoopRow& R, double X, bool ignoreFriction, double cfm, int slot) {
+  const double tol = 1e-5;
+  const int ln = w.lane();
+  const double v = -R.Bv + cfm * X + coopAx(w, S, R, X, slot);
+  const double Xn = w.shfl(X, R.fp);
+  bool ok = true;
+  if (ln < R.m) {
+    double upper = R.fric ? R.mu : INFINITY, lower = R.fric ? -R.mu : 0.0;
+    bool skip = false;
+    if (R.fric) {
+      if (ignoreFriction) { ok = (X == 0.0); skip = true; }
+      upper *= Xn; lower *= Xn;
+    }
+    if (!skip) {
+      if (fabs(lower) < tol && fabs(upper) < tol && fabs(X) < tol) {}
+      else if (fabs(X - lower) < tol) { if (v < -tol) ok = false; }
+      else if (fabs(X - upper) < tol) { if (v > tol) ok = false; }
+      else if (X > lower && X < upper) { if (fabs(v) > tol) ok = false; }
+      else ok = false;
+    }
+  }
+  return w.ballot(!ok) == 0ull;
+}
+
+struct CoopClasses {
+  int cls;            // this lane's row
+  double E;
+  uint32_t clampMask, ubMask;   // uniform
+  int nc, nu;
+};
+
+// CGGM::constructMatrices classification (CGGM.cpp:535-713), lane = row
+template <class W>
+DEV void coopClassify(const W& w, const CoopRow& R, double X, bool ignoreFriction, CoopClasses& K) {
+  const double TH = 1e-6, tie = 1e-5;
+  const int ln = w.lane();
+  const double Xn = w.shfl(X, R.fp);
+  const double cnN = w.shfl(R.colNorm, R.fp);
+  const double hi = R.fric ? R.mu : INFINITY, lo = R.fric ? -R.mu : 0.0;
+  double upper = hi, lower = lo;
+  if (R.fric) { upper *= Xn; lower *= Xn; }
+  int cls = RC_NOT_CLAMPING;
+  bool inElse = false;
+  if (ln < R.m && !(R.colNorm < 1e-9)) {
+    if (fabs(X) < TH) {
+      if (R.fric && !(fabs(Xn) < TH) && !ignoreFriction) cls = RC_CLAMPING;
+    } else if ((X > lower + tie && X < upper - tie) || (lower - X > 1e-2 || X - upper > 1e-2)) {
+      cls = RC_CLAMPING;
+    } else {
+      inElse = true;
+    }
+  }
+  const uint64_t clampBits = w.ballot(cls == RC_CLAMPING);
+  double E = 0.0;
+  if (inElse && R.fric && fabs(Xn) > 1e-9 && cnN > 1e-9 && ((clampBits >> R.fp) & 1ull)) {
+    cls = RC_UPPER_BOUND;
+    const double ub = Xn * hi, lb = Xn * lo;
+    E = (fabs(X - ub) < fabs(X - lb)) ? hi : lo;
+  }
+  K.cls = cls; K.E = E;
+  K.clampMask = (uint32_t)clampBits;
+  K.ubMask = (uint32_t)w.ballot(cls == RC_UPPER_BOUND);
+  K.nc = __builtin_popcount(K.clampMask);
+  K.nu = __builtin_popcount(K.ubMask);
+}
+
+// lane s (< 24): a[i] = Q[i][s] = A[i][s] + [s normal] sum_{u = s+1, s+2 upper-bound} E[u] A[i][u] + cfm [i == s]
+// for clamping i and s, zero elsewhere (buildQ of lcp_dev.hpp with masks instead of compaction)
+template <class W>
+DEV void coopBuildQ(const W& w, CoopLds& S, const CoopRow& R, const CoopClasses& K, double cfm, double (&a)[MAXR]) {
+  const int ln = w.lane();
+  const bool colOn = ln < MAXR && K.cls == RC_CLAMPING;
+  double e1 = 0.0, e2 = 0.0;
+  if (K.nu > 0) {
+    // stage A in LDS so that a normal column can add its contact's upper-bound friction columns
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.R[i * CLD + ln] = R.acol[i];
+    const double E1 = w.shfl(K.E, ln + 1), E2 = w.shfl(K.E, ln + 2);
+    if (!R.fric && ln + 2 < MAXR) {
+      if ((K.ubMask >> (ln + 1)) & 1u) e1 = E1;
+      if ((K.ubMask >> (ln + 2)) & 1u) e2 = E2;
+    }
+    w.sync();
+  }
+  const int c1 = (ln + 1 < MAXR) ? ln + 1 : 0, c2 = (ln + 2 < MAXR) ? ln + 2 : 0;
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) {
+    double q = R.acol[i];
+    if (K.nu > 0) q = fma(e2, S.R[i * CLD + c2], fma(e1, S.R[i * CLD + c1], q));
+    if (i == ln) q += cfm;
+    a[i] = (colOn && ((K.clampMask >> i) & 1u)) ? q : 0.0;
+  }
+  if (K.nu > 0) w.sync();   // reads of the staged A complete before the factorisation reuses the buffer
+}
+
+struct CoopStage0 {
+  double X, X0;       // solution / pre-solve x of this lane's row
+  CoopClasses K;
+  bool ok;            // standardised valid solution found (uniform)
+  bool pinvValid;     // S.P is the pseudo-inverse of the Q of the final classification (uniform)
+};
+
+// LCPUtils::guessSolution (when there is no matching warm start) + the standardisation loop of
+// CGGM::constructMatrices / opportunisticallyStandardizeResults (standardizeLoop in contact_kernels.hip), stage 0 of
+// the solver cascade (BoxedLcpConstraintSolver.cpp:380-460), cfm = 0, friction kept.
+template <class W>
+DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, double Xcache, CoopStage0& out) {
+  const int ln = w.lane();
+  double a[MAXR];
+  double X = 0.0;
+  uint32_t guessMask = 0;
+  bool pinvValid = false;
+  if (haveCache) X = ln < R.m ? Xcache : 0.0;
+  else {
+    const bool in = ln < R.m && (R.fric || R.Bv > 0);
+    guessMask = (uint32_t)w.ballot(in);
+    if (guessMask != 0) {
+#pragma unroll
+      for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.acol[i] : 0.0;
+      coopPinv(w, a, S, __builtin_popcount(guessMask));
+      X = coopPinvApply<W, false>(w, S, in ? R.Bv : 0.0, 0);
+      if (!in) X = 0.0;
+      pinvValid = true;   // of A restricted to guessMask; stays valid only if the first classification agrees
+    }
+  }
+  out.X0 = X;
+  bool ok = false;
+  CoopClasses K;
+#pragma unroll 1
+  for (int iter = 0; iter < MAXR + 1; iter++) {
+    coopClassify(w, R, X, false, K);
+    if (K.nc == 0) {
+      pinvValid = false;
+      ok = coopValid(w, S, R, 0.0, false, 0.0, 1);
+      if (ok) X = 0.0;
+      break;
+    }
+    double fc;
+    if (iter == 0 && K.nu == 0 && guessMask != 0 && K.clampMask == guessMask) fc = X;
+    else {
+      coopBuildQ(w, S, R, K, 0.0, a);
+      coopPinv(w, a, S, K.nc);
+      fc = coopPinvApply<W, false>(w, S, K.cls == RC_CLAMPING ? R.Bv : 0.0, 0);
+      pinvValid = true;
+    }
+    double newX = 0.0;
+    bool newlyNot = false;
+    const double fcN = w.shfl(fc, R.fp), Xn = w.shfl(X, R.fp);
+    if (K.cls == RC_CLAMPING) {
+      newX = fc;
+      if (fabs(newX) < 1e-6 && fabs(X) > 1e-6 && !R.fric) newlyNot = true;
+    } else if (K.cls == RC_UPPER_BOUND) {
+      const double om = Xn / X;
+      const double clean = (fabs(om - R.mu) < fabs(om + R.mu)) ? R.mu : -R.mu;
+      newX = fcN * clean;
+    }
+    if (!coopValid(w, S, R, newX, false, 0.0, 1)) { ok = false; break; }
+    X = newX;
+    ok = true;
+    if (w.ballot(newlyNot) == 0ull) break;
+  }
+  out.X = X; out.K = K; out.ok = ok; out.pinvValid = ok && pinvValid;
+}
+
+}  // namespace nbl

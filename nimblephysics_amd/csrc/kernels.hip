@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
                                                      const double* __restrict__ state, const double* __restrict__ action,
                                                      double* __restrict__ next, double* __restrict__ saved,
                                                      uint32_t* __restrict__ status, double* __restrict__ ws, int vpreRow) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
                                                       const double* __restrict__ saved, const double* __restrict__ gnext,
                                                       double* __restrict__ gstate, double* __restrict__ gaction,
                                                       double* __restrict__ ws) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;

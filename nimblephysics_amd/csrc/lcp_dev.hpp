@@ -249,4 +249,80 @@ DEV void buildQ(const LcpView& L, const Classes& K, double cfm, const LaneMem& o
   }
 }
 
+// ---- shared pieces of the stage-0 kernel and the cascade kernel ----
+// CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (the reference recurses while normal
+// rows drop out of the clamping set, CGGM.cpp:321-332).  On return K holds the last classification and X the
+// last accepted solution; returns whether the results are standardised (valid least-squares solution).
+DEV bool standardizeLoop(const LcpView& V, const LaneMem& L, CodFactor& F, double* X, const double* Bv, const double* colNorm,
+                         double cfm, bool ignoreFriction, uint32_t guessMask, Classes& K) {
+  const int m = V.m;
+  bool ok = false;
+  for (int iter = 0; iter < MAXR + 1; iter++) {
+    classify(V, X, colNorm, ignoreFriction, K);
+    if (K.nc == 0) {
+      double zero[MAXR];
+      for (int r = 0; r < m; r++) zero[r] = 0;
+      ok = lcpValid(V, zero, Bv, ignoreFriction, cfm);
+      if (ok) for (int r = 0; r < m; r++) X[r] = 0;
+      break;
+    }
+    double bc[MAXR], fc[MAXR], newX[MAXR], origFc[MAXR];
+    uint32_t clampMask = 0;
+    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) { origFc[K.cidx[r]] = X[r]; clampMask |= 1u << r; }
+    if (iter == 0 && K.nu == 0 && guessMask != 0 && clampMask == guessMask) {
+      // the clamping set is exactly the guess's set: Q and b_c are the system just solved, f_c = that solution
+      for (int i = 0; i < K.nc; i++) fc[i] = origFc[i];
+    } else {
+      buildQ(V, K, cfm, L, 0, Bv, bc);
+      F.c = K.nc;
+      codFactor(L, F);
+      codSolve(L, F, bc, fc);
+    }
+    bool newlyNot = false;
+    for (int i = 0; i < m; i++) {
+      newX[i] = 0;
+      if (K.cls[i] == RC_CLAMPING) {
+        newX[i] = fc[K.cidx[i]];
+        if (fabs(newX[i]) < 1e-6 && fabs(X[i]) > 1e-6 && (i % 3) == 0) newlyNot = true;
+      } else if (K.cls[i] == RC_UPPER_BOUND) {
+        const int fp = i - (i % 3);
+        double om = origFc[K.cidx[fp]] / X[i];
+        double clean = (fabs(om - V.hi(i)) < fabs(om - V.lo(i))) ? V.hi(i) : V.lo(i);
+        newX[i] = fc[K.cidx[fp]] * clean;
+      }
+    }
+    if (!lcpValid(V, newX, Bv, ignoreFriction, cfm)) { ok = false; break; }
+    for (int i = 0; i < m; i++) X[i] = newX[i];
+    ok = true;
+    if (!newlyNot) break;
+  }
+  return ok;
+}
+
+// Stage 0 of the solver cascade for one world (BoxedLcpConstraintSolver.cpp:380-460): X is the warm start when
+// haveCache, else LCPUtils::guessSolution (LCPUtils.cpp:86-140) is computed into it; X0 receives the pre-solve x
+// (mXBackup, what the PGS fallback starts from); then the standardisation loop.  L: scratch for 2 x MAXR x MAXR doubles.
+DEV bool laneStage0(const LcpView& V, const LaneMem& L, bool haveCache, double* X, double* X0, const double* Bv,
+                    const double* colNorm, Classes& K) {
+  const int m = V.m;
+  CodFactor F;
+  F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR;
+  uint32_t guessMask = 0;   // rows of the guess's clamping set; its factorisation can be reused by the first standardisation
+  if (!haveCache) {
+    int idx[MAXR], nc = 0;
+    for (int r = 0; r < m; r++) if ((r % 3) != 0 || Bv[r] > 0) { idx[nc++] = r; guessMask |= 1u << r; }
+    for (int r = 0; r < m; r++) X[r] = 0;
+    if (nc > 0) {
+      double rhs[MAXR], sol[MAXR];
+      for (int i = 0; i < nc; i++) { rhs[i] = Bv[idx[i]]; for (int j = 0; j < nc; j++) L.at(i * MAXR + j) = V.A(idx[i], idx[j]); }
+      F.c = nc;
+      codFactor(L, F);
+      codSolve(L, F, rhs, sol);
+      for (int i = 0; i < nc; i++) X[idx[i]] = sol[i];
+    }
+  }
+  for (int r = 0; r < m; r++) X0[r] = X[r];
+  return standardizeLoop(V, L, F, X, Bv, colNorm, 0.0, false, guessMask, K);
+}
+
 }  // namespace nbl

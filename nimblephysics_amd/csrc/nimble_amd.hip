@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,6 +16,7 @@
 #include "kernels.hip"
 #include "contact_kernels.hip"
 #include "contact_backward.hip"
+#include "coop_kernels.hip"
 
 using namespace nbl;
 
@@ -30,10 +32,10 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
-                                           "k_bwd_final"};
+                                           "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -50,6 +52,8 @@ struct nbl_model {
   DevContactModel* dContact = nullptr;
   SavedLayout lay;
   bool timing = false;
+  bool coop = true;                  // dense contact kernels: one world per wavefront (NBL_COOP=0: one world per lane)
+  int treeLanes = 0, lcpLanes = 0;   // worlds per workgroup (0 = pick from B); see nbl_set_launch_lanes
   std::vector<TimedLaunch> pending;
   double fwdMs = 0, bwdMs = 0;
   int64_t fwdCount = 0, bwdCount = 0;
@@ -202,14 +206,19 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     SavedLayout& L = m->lay;
     const int n = d->n_dofs;
     L.n = n; L.q = 0; L.v = n; L.tau = 2 * n;
-    if (!hasContact) { L.vpre = L.w = L.nc = L.contacts = L.x = L.b = L.cls = L.cfm = L.A = L.massed = L.aall = -1; L.total = 3 * n; }
+    if (!hasContact) { L.vpre = L.w = L.nc = L.contacts = L.x = L.b = L.cls = L.cfm = L.pflag = -1; L.total = 3 * n;
+                       L.A = L.massed = L.aall = L.pinv = -1; L.dense = 0; }
     else {
       L.vpre = 3 * n; L.w = 4 * n; L.nc = 5 * n; L.contacts = L.nc + 1; L.x = L.contacts + MAX_CONTACTS * CR_SIZE;
-      L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.A = L.cfm + 1;
-      L.massed = L.A + MAX_ROWS * MAX_ROWS; L.aall = L.massed + n * MAX_ROWS; L.total = L.aall + n * MAX_ROWS;
+      L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.pflag = L.cfm + 1; L.total = L.pflag + 1;
+      L.A = 0; L.massed = L.A + MAX_ROWS * MAX_ROWS; L.aall = L.massed + n * MAX_ROWS; L.pinv = L.aall + n * MAX_ROWS;
+      L.dense = L.pinv + MAX_ROWS * MAX_ROWS;
     }
   }
   m->device = device;
+  if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
+  if (const char* e2 = getenv("NBL_LCP_LANES")) m->lcpLanes = atoi(e2);
+  if (const char* e3 = getenv("NBL_COOP")) m->coop = atoi(e3) != 0;
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
   m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0;
   for (int k = 0; k < 3; k++) m->mdl.gravity[k] = d->gravity[k];
@@ -253,9 +262,19 @@ size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
 }
 size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
-  return (size_t)m->lay.total * sizeof(double) * (size_t)B;
+  return ((size_t)m->lay.total + (size_t)m->lay.dense) * sizeof(double) * (size_t)B;
 }
 
+
+// Worlds per workgroup of the one-world-per-lane kernels.  Measured on MI355X at B = 4096 (tools/sweep_lanes.sh):
+// 16-lane workgroups are marginally faster than 64 for the tree kernels (more CUs busy), smaller ones lose (the
+// kernels are bound by memory transactions per wave-instruction, which do not shrink with the lane count).
+static int pickLanes(int64_t B, int requested, int maxLanes) {
+  int l = requested > 0 ? requested : (maxLanes > 16 && B < 65536 ? 16 : maxLanes);
+  if (l > maxLanes) l = maxLanes;
+  if (l < 1) l = 1;
+  return l;
+}
 static void beginTiming(nbl_model* m, hipStream_t s, int kernel) {
   if (!m->timing) return;
   TimedLaunch t;
@@ -279,7 +298,8 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)((B + 63) / 64)), block(64);
+  const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
+  dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
   TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
                                   (double*)saved, status, (double*)workspace, m->hasContact ? m->lay.vpre : -1));
   if (m->hasContact) {
@@ -288,13 +308,19 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
                                        status, (double*)workspace));
     TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved,
                                      m->lay, (double*)workspace, lws));
-    dim3 lgrid((unsigned)((B + LCP_LANES - 1) / LCP_LANES)), lblock(LCP_LANES);
+    dim3 lgrid((unsigned)((B + ll - 1) / ll)), lblock(ll);
+    const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
     int32_t* failList = (int32_t*)(lws + (size_t)LB_TOTAL * (size_t)B);
     uint32_t* failCount = (uint32_t*)(failList + B);
     HIP_TRY(hipMemsetAsync(failCount, 0, sizeof(uint32_t), s));
-    TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, LCP_LDS_BYTES, s, m->mdl, m->dContact, B, (double*)saved,
+    if (m->coop)
+      TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)B), dim3(64), 0, s, m->mdl, m->dContact, B,
+                                             (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
+                                             failList, failCount));
+    else
+      TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, ldsBytes, s, m->mdl, m->dContact, B, (double*)saved,
                                       m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws, failList, failCount));
-    TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, LCP_LDS_BYTES, s, m->mdl, m->dContact, B,
+    TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, m->mdl, m->dContact, B,
                                         (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
   }
   HIP_TRY(hipGetLastError());
@@ -307,7 +333,8 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)((B + 63) / 64)), block(64);
+  const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
+  dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
   if (!m->hasContact) {
     TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
                                     grad_next_state, grad_state, grad_action, (double*)workspace));
@@ -316,8 +343,9 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
     double* sv = (double*)const_cast<void*>(saved);
     TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B,
                                           (const double*)saved, (double*)workspace));
-    dim3 lgrid((unsigned)((B + LCP_LANES - 1) / LCP_LANES)), lblock(LCP_LANES);
-    TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, LCP_LDS_BYTES, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
+    dim3 lgrid((unsigned)((B + ll - 1) / ll)), lblock(ll);
+    const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
+    TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
                                       B, sv, m->lay, grad_next_state, (double*)workspace, lws));
     TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
                                       m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
@@ -340,6 +368,15 @@ int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, 
   dim3 grid((unsigned)((B + 31) / 32), (unsigned)((d + 31) / 32)), block(256);
   hipLaunchKernelGGL(k_transpose, grid, block, 0, (hipStream_t)stream, src_db, dst_bd, (int64_t)d, B);
   HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+
+int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes) {
+  if (!m) return fail(NBL_E_BADARG, "null model");
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if ((tree_lanes != 0 && (!pow2(tree_lanes) || tree_lanes > 64)) || (lcp_lanes != 0 && (!pow2(lcp_lanes) || lcp_lanes > LCP_LANES)))
+    return fail(NBL_E_BADARG, "lanes must be 0 (auto) or a power of two (tree <= 64, lcp <= 16)");
+  m->treeLanes = tree_lanes; m->lcpLanes = lcp_lanes;
   return NBL_OK;
 }
 

@@ -170,6 +170,10 @@ class World:
         nxt, _, _ = self.step_soa(self._state, self._action, want_saved=False)
         self._state = nxt
 
+    def set_launch_lanes(self, tree_lanes: int = 0, lcp_lanes: int = 0):
+        """Worlds per workgroup (0 = auto); a launch-shape knob, results are independent of it."""
+        check(self._L.nbl_set_launch_lanes(self._h, tree_lanes, lcp_lanes), "nbl_set_launch_lanes")
+
     # ---- kernel timing (HIP events on the launch stream) ------------------------------------------
     def set_timing(self, enabled: bool):
         check(self._L.nbl_set_timing(self._h, 1 if enabled else 0), "nbl_set_timing")

@@ -1,0 +1,67 @@
+// Host build of the product's wave-cooperative LCP code (coop_dev.hpp) on the thread-per-lane wave emulation,
+// next to the one-world-per-lane statement of the same algorithm (lcp_dev.hpp).  Test harness only.
+#include "coop_dev.hpp"
+#include "wave_emu.hpp"
+
+using namespace nbl;
+
+extern "C" {
+// Q: 24 x 24 row-major (masked rows/columns zero), P out 24 x 24 row-major; returns rank
+int shim_coop_pinv(const double* Q, int cTrue, double* Pout) {
+  static CoopLds S;
+  int rank = -1;
+  emuRunWave([&](const EmuWave& w) {
+    double a[MAXR];
+    const int ln = w.lane();
+    for (int i = 0; i < MAXR; i++) a[i] = ln < MAXR ? Q[i * MAXR + ln] : 0.0;
+    const int r = coopPinv(w, a, S, cTrue);
+    if (ln == 0) rank = r;
+  });
+  for (int i = 0; i < MAXR; i++) for (int j = 0; j < MAXR; j++) Pout[i * MAXR + j] = S.P[i * CLD + j];
+  return rank;
+}
+
+static void fillRow(CoopRow& R, int ln, int m, const double* A, const double* b, const double* mu) {
+  R.m = m; R.fric = (ln % 3) != 0; R.fp = ln < MAXR ? ln - (ln % 3) : 0;
+  R.mu = ln < m ? mu[ln / 3] : 0.0; R.Bv = ln < m ? b[ln] : 0.0;
+  double cn = 0;
+  for (int i = 0; i < MAXR; i++) { R.acol[i] = (ln < m && i < m) ? A[i * MAXR + ln] : 0.0; cn += R.acol[i] * R.acol[i]; }
+  R.colNorm = cn;
+}
+
+// A: 24 x 24 row-major (m x m used), b[24], mu[8]; outputs per row.  Returns ok | pinvValid << 1.
+int shim_coop_stage0(int m, const double* A, const double* b, const double* mu, int haveCache, const double* xcache,
+                     double* X, double* X0, int* cls, double* E, double* Pout) {
+  static CoopLds S;
+  int ret = 0;
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopRow R;
+    fillRow(R, ln, m, A, b, mu);
+    CoopStage0 out;
+    coopStage0(w, S, R, haveCache != 0, ln < m ? xcache[ln] : 0.0, out);
+    if (ln < MAXR) { X[ln] = out.X; X0[ln] = out.X0; cls[ln] = out.K.cls; E[ln] = out.K.E; }
+    if (ln == 0) ret = (out.ok ? 1 : 0) | (out.pinvValid ? 2 : 0);
+  });
+  for (int i = 0; i < MAXR; i++) for (int j = 0; j < MAXR; j++) Pout[i * MAXR + j] = S.P[i * CLD + j];
+  return ret;
+}
+
+// the one-world-per-lane statement (laneStage0 of lcp_dev.hpp) on the same problem
+int shim_lane_stage0(int m, const double* A, const double* b, const double* mu, int haveCache, const double* xcache,
+                     double* X, double* X0, int* cls, double* E) {
+  static thread_local double bufA[MAXR * MAXR], bufL[2 * MAXR * MAXR];
+  LcpView V;
+  V.mem.base = bufA; V.mem.B = 1; V.mem.b = 0; V.offA = 0; V.m = m;
+  for (int i = 0; i < MAXR * MAXR; i++) bufA[i] = A[i];
+  for (int c = 0; c < m / 3; c++) V.mu[c] = mu[c];
+  LaneMem L; L.base = bufL; L.B = 1; L.b = 0;
+  double colNorm[MAXR];
+  for (int c = 0; c < m; c++) { double s = 0; for (int r = 0; r < m; r++) s += V.A(r, c) * V.A(r, c); colNorm[c] = s; }
+  for (int r = 0; r < MAXR; r++) { X[r] = (haveCache && r < m) ? xcache[r] : 0.0; X0[r] = 0; cls[r] = 0; E[r] = 0; }
+  Classes K;
+  const bool ok = laneStage0(V, L, haveCache != 0, X, X0, b, colNorm, K);
+  for (int r = 0; r < m; r++) { cls[r] = K.cls[r]; E[r] = K.E[r]; }
+  return ok ? 1 : 0;
+}
+}
