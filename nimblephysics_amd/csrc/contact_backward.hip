@@ -31,15 +31,33 @@ DEV double qEntry(const LcpView& V, const Classes& K, double cfm, int r, int s) 
   return q;
 }
 
+// Recompute the forward tree state, decide whether the contact adjoint is active for this world (any clamping row),
+// and, if so, lambda1 = M^-1 g (two tree sweeps) for the dense kernel that follows.
 __global__ __launch_bounds__(64) void k_bwd_recompute(DevModel mdl, const DevBody* __restrict__ bodies,
                                                       const DevDof* __restrict__ dofs, int64_t B,
-                                                      const double* __restrict__ saved, double* __restrict__ ws) {
+                                                      const double* __restrict__ saved, SavedLayout lay,
+                                                      const double* __restrict__ gnext, double* __restrict__ ws,
+                                                      double* __restrict__ lws) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
   const int n = mdl.n;
   const double* tau = saved + (int64_t)2 * n * B;
   abaSweeps<true>(c, saved, saved + (int64_t)n * B, [&](int d) -> double { return tau[(int64_t)d * B + b]; }, [](int, double) {});
+  const double* gvn = gnext + (int64_t)n * B;
+  LaneMem L; L.base = lws; L.B = B; L.b = b;
+  const int m = 3 * (int)saved[(int64_t)lay.nc * B + b];
+  bool active = false;
+  for (int r = 0; r < m; r++) if (saved[(int64_t)(lay.cls + r) * B + b] == 1.0) active = true;
+  L.at(LB_FLAG) = active ? 1.0 : 0.0;
+  if (!active) for (int d = 0; d < n; d++) { L.at(LB_GVP + d) = gvn[(int64_t)d * B + b]; L.at(LB_QX + d) = 0; }
+  if (!__any(active)) return;
+  // lambda1 = M^-1 g (all lanes of the wave take part in the sweeps)
+  minvSweeps(c, [&](int d) -> double { return gvn[(int64_t)d * B + b]; });
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = bodies[i];
+    for (int k = 0; k < bd.ndof; k++) L.at(LB_LAM1 + bd.dofOff + k) = wsAt(c, i, WS_UIMP + k);
+  }
 }
 
 // ---- kernel A: dense (c x c) part of the adjoint ----
@@ -69,22 +87,7 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
     if (cv == 1.0) { K.cls[r] = RC_CLAMPING; K.cidx[r] = K.nc++; }
     else if (cv == 2.0 || cv == -2.0) { K.cls[r] = RC_UPPER_BOUND; K.uidx[r] = K.nu++; }
   }
-  const bool active = K.nc > 0;
-  L.at(LB_FLAG) = active ? 1.0 : 0.0;
-  if (!__any(active)) {
-    for (int d = 0; d < n; d++) { L.at(LB_GVP + d) = gvn[(int64_t)d * B + b]; L.at(LB_QX + d) = 0; }
-    return;
-  }
-  // lambda1 = M^-1 g (all lanes of the wave take part in the sweeps)
-  minvSweeps(c, [&](int d) -> double { return gvn[(int64_t)d * B + b]; });
-  for (int i = 0; i < c.nb; i++) {
-    const DevBody& bd = bodies[i];
-    for (int k = 0; k < bd.ndof; k++) L.at(LB_LAM1 + bd.dofOff + k) = wsAt(c, i, WS_UIMP + k);
-  }
-  if (!active) {
-    for (int d = 0; d < n; d++) { L.at(LB_GVP + d) = gvn[(int64_t)d * B + b]; L.at(LB_QX + d) = 0; }
-    return;
-  }
+  if (L.at(LB_FLAG) == 0.0) return;   // set by k_bwd_recompute together with lambda1 (LB_LAM1)
   LcpView V;
   V.mem = DN; V.offA = lay.A; V.m = m;
   for (int ci = 0; ci < nC; ci++) {

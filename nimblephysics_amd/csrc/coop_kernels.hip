@@ -88,4 +88,123 @@ __global__ __launch_bounds__(64) void k_contact_solve_coop(DevModel mdl, const D
   }
 }
 
+// Dense part of the contact adjoint, one world per wavefront: the same quantities as k_bwd_contact_a
+// (contact_backward.hip; the header there derives them), with lane = LCP row for the c-vectors and lane = DOF for the
+// n-vectors.  Row-indexed vectors are zero outside the clamping set, which replaces the index compaction:
+//   (Q x)_r   = (A xE)_r + cfm x_r      xE = x on clamping rows, E_u x_normal(u) on upper-bound rows  ("spread")
+//   (Q^T y)_s = t_s + sum_{u in ub(s)} E_u t_u + cfm y_s,  t = A y                                     ("fold")
+// Q^+ is read back from the saved record when the forward pass left it there (pflag), else recomputed.
+__global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                           double* __restrict__ saved, SavedLayout lay,
+                                                           const double* __restrict__ gnext, double* __restrict__ lws) {
+  __shared__ CoopLds S;
+  const DevWave w;
+  const int ln = w.lane();
+  const int64_t b = coopWorld(blockIdx.x, gridDim.x);
+  if (b >= B) return;
+  if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;   // k_bwd_recompute: no clamping row in this world
+  const int n = mdl.n;
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  const double* gvn = gnext + (int64_t)n * B;
+  double* dn = denseOf(saved, lay, B, b);
+  CoopRow R;
+  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  // classes as stored by the forward pass
+  CoopClasses K;
+  const double cv = ln < m ? svAt(saved, lay.cls + ln, B, b) : 0.0;
+  K.cls = cv == 1.0 ? RC_CLAMPING : ((cv == 2.0 || cv == -2.0) ? RC_UPPER_BOUND : RC_NOT_CLAMPING);
+  K.E = K.cls == RC_UPPER_BOUND ? (cv > 0 ? R.mu : -R.mu) : 0.0;
+  K.clampMask = (uint32_t)w.ballot(K.cls == RC_CLAMPING);
+  K.ubMask = (uint32_t)w.ballot(K.cls == RC_UPPER_BOUND);
+  K.nc = __builtin_popcount(K.clampMask);
+  K.nu = __builtin_popcount(K.ubMask);
+  const bool clamp = K.cls == RC_CLAMPING, isUb = K.cls == RC_UPPER_BOUND;
+  const double cfm = svAt(saved, lay.cfm, B, b);
+  const double xRaw = ln < m ? svAt(saved, lay.x + ln, B, b) : 0.0;   // the impulses that were applied
+  auto fold = [&](double t) -> double {   // normal rows collect E_u t_u of their contact's upper-bound rows
+    if (K.nu == 0) return 0.0;
+    const double et = isUb ? K.E * t : 0.0;
+    const double f1 = w.shfl(et, ln + 1), f2 = w.shfl(et, ln + 2);
+    return (!R.fric && ln + 2 < MAXR) ? f1 + f2 : 0.0;
+  };
+  auto spread = [&](double x) -> double {   // upper-bound rows ride on their normal row: E_u x_normal
+    if (K.nu == 0) return clamp ? x : 0.0;
+    const double xn = w.shfl(x, R.fp);
+    return clamp ? x : (isUb ? K.E * xn : 0.0);
+  };
+  // lambda1 -> LDS (n <= MAX_DOF_CONTACT <= 64 entries, in the R buffer which is free until the factorisation)
+  double* bc = S.R;
+  if (ln < n) bc[ln] = lws[(int64_t)(LB_LAM1 + ln) * B + b];
+  w.sync();
+  // fbar = Abar^T lambda1
+  double t = 0.0;
+  if (ln < m) {
+#pragma unroll 4
+    for (int d = 0; d < n; d++) t = fma(dn[lay.aall + d * MAX_ROWS + ln], bc[d], t);
+  }
+  const double tf = fold(t);   // cross-lane: every lane takes part
+  const double fbar = clamp ? t + tf : 0.0;
+  w.sync();
+  // Q^+
+  if (svAt(saved, lay.pflag, B, b) != 0.0 && !mdl.pad) {
+    if (ln < MAXR) {
+#pragma unroll
+      for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = dn[lay.pinv + i * MAX_ROWS + ln];
+    }
+    w.sync();
+  } else {
+    double a[MAXR];
+    coopBuildQ(w, S, R, K, cfm, a);
+    coopPinv(w, a, S, K.nc);
+  }
+  const double bcl = clamp ? R.Bv : 0.0;
+  const double mu = coopPinvApply<DevWave, true>(w, S, fbar, 0);     // (Q^+)^T fbar
+  const double fls = coopPinvApply<DevWave, false>(w, S, bcl, 1);    // Q^+ b (see k_bwd_contact_a on why not the applied x)
+  double al[3], be[3];
+  al[0] = -mu; be[0] = fls;
+  {
+    const double ax = coopAx(w, S, R, spread(fls), 2);
+    al[1] = clamp ? bcl - (ax + cfm * fls) : 0.0;
+  }
+  be[1] = coopPinvApply<DevWave, false>(w, S, mu, 3);
+  al[2] = coopPinvApply<DevWave, true>(w, S, fls, 0);
+  {
+    const double t2 = coopAx(w, S, R, mu, 1);
+    const double t2f = fold(t2);
+    be[2] = clamp ? fbar - (t2 + t2f + cfm * mu) : 0.0;
+  }
+  double beE[3];
+  for (int k = 0; k < 3; k++) beE[k] = spread(be[k]);
+  const double fcE = spread(xRaw);
+  // coefficient vectors for the DOF lanes: [al0 al1 al2 beE0 beE1 beE2 mu] x 24 rows, in the (now free) R buffer
+  w.sync();
+  if (ln < MAXR) {
+    for (int k = 0; k < 3; k++) { bc[k * MAXR + ln] = clamp ? al[k] : 0.0; bc[(3 + k) * MAXR + ln] = beE[k]; }
+    bc[6 * MAXR + ln] = clamp ? mu : 0.0;
+  }
+  w.sync();
+  if (ln < n) {
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) {
+      const double ms = dn[lay.massed + ln * MAX_ROWS + r], aa = dn[lay.aall + ln * MAX_ROWS + r];
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[k] = fma(bc[k * MAXR + r], ms, acc[k]);
+      acc[6] = fma(bc[6 * MAXR + r], aa, acc[6]);
+    }
+    for (int k = 0; k < 3; k++) {
+      lws[(int64_t)(LB_S + k * MAX_DOF_CONTACT + ln) * B + b] = acc[k];
+      lws[(int64_t)(LB_P + k * MAX_DOF_CONTACT + ln) * B + b] = acc[3 + k];
+    }
+    lws[(int64_t)(LB_GVP + ln) * B + b] = gvn[(int64_t)ln * B + b] - acc[6];
+  }
+  // coefficients of z_row on the bases [lambda1, v_pre, p1, p2, p3, s1, s2, s3]
+  if (ln < MAX_ROWS) {
+    double cf[8];
+    cf[0] = fcE; cf[1] = clamp ? -mu : 0.0;
+    for (int k = 0; k < 3; k++) { cf[2 + k] = clamp ? al[k] : 0.0; cf[5 + k] = beE[k]; }
+    for (int k = 0; k < 8; k++) lws[(int64_t)(LB_COEF + ln * 8 + k) * B + b] = cf[k];
+  }
+}
+
 }  // namespace nbl

@@ -221,6 +221,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (const char* e3 = getenv("NBL_COOP")) m->coop = atoi(e3) != 0;
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
   m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0;
+  if (const char* e4 = getenv("NBL_DEBUG_NOPINV")) m->mdl.pad = atoi(e4);
   for (int k = 0; k < 3; k++) m->mdl.gravity[k] = d->gravity[k];
   m->mdl.dt = d->dt;
   hipError_t e = hipSetDevice(device);
@@ -342,10 +343,14 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
     double* sv = (double*)const_cast<void*>(saved);
     TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B,
-                                          (const double*)saved, (double*)workspace));
+                                          (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
     dim3 lgrid((unsigned)((B + ll - 1) / ll)), lblock(ll);
     const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
-    TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
+    if (m->coop)
+      TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop, dim3((unsigned)B), dim3(64), 0, s, m->mdl, m->dContact, B, sv,
+                                             m->lay, grad_next_state, lws));
+    else
+      TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
                                       B, sv, m->lay, grad_next_state, (double*)workspace, lws));
     TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
                                       m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
