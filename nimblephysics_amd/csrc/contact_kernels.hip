@@ -35,7 +35,8 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
   t2 = cross(n, t1);
 }
 
-__global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+__global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                       const DevContactModel* __restrict__ cm, int64_t B,
                                                        double* __restrict__ saved, SavedLayout lay,
                                                        uint32_t* __restrict__ status, double* __restrict__ ws) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,6 +88,16 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevCo
   if (overflow) st |= 0x80u;
   (void)edge;
   if (status) status[b] = st;
+  if (!__any(nC > 0)) return;
+  // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_A,
+  // for the relative velocities b = -J^T V of the contact-row kernel
+  const double* vpre = saved + (int64_t)lay.vpre * B;
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = bodies[i];
+    V6 V = jointTwist(bd, vpre, B, b);
+    if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_A));
+    stV6(c, i, WS_A, V);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,13 +119,8 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
   const double* vpre = saved + (int64_t)lay.vpre * B;
   double* dn = denseOf(saved, lay, B, b);
 
-  // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_A
-  for (int i = 0; i < c.nb; i++) {
-    const DevBody& bd = bodies[i];
-    V6 V = jointTwist(bd, vpre, B, b);
-    if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_A));
-    stV6(c, i, WS_A, V);
-  }
+  // body twists at the pre-contact velocity: WS_A, left by k_contact_detect
+  (void)vpre;
   // per-row body-frame wrenches (mSpatialNormalA/B) and b = -J^T V
   int bodyA[MAX_CONTACTS], bodyB[MAX_CONTACTS];
   for (int ci = 0; ci < MAX_CONTACTS; ci++) {

@@ -207,4 +207,132 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   }
 }
 
+// Contact rows, one world per wavefront, lane = LCP row (k_contact_rows does the same one world per lane, three rows per
+// pair of tree sweeps): per-row body-frame wrenches J, b = -J^T V(v_pre), the constraint-force column A_c[:, row]
+// (DCC::getConstraintForces), one unit-impulse test per lane (BodyNode::updateBiasImpulse / updateVelocityChangeFD,
+// BodyNode.cpp:2117-2215; GenericJoint.hpp:2482-2498, 2607-2613, 2713-2725) giving the column M^-1 J^T e_row ("massed")
+// and the row of the Delassus matrix A (BoxedLcpConstraintSolver.cpp:250-320: entries of later contacts computed,
+// earlier ones mirrored).  The tree state of the world (transforms, articulated inertias; k_step_forward) is the same
+// for all lanes and comes through uniform loads; the per-lane bias-impulse / velocity-change field lives in LDS:
+//   lds: JA[24][6], JB[24][6], acc[nb][6][24]
+__global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                          const DevContactModel* __restrict__ cm, int64_t B,
+                                                          double* __restrict__ saved, SavedLayout lay,
+                                                          const double* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) double ldsRows[];
+  double* JAs = ldsRows;
+  double* JBs = ldsRows + 6 * MAX_ROWS;
+  double* acc = ldsRows + 12 * MAX_ROWS;
+  const DevWave w;
+  const int ln = w.lane();
+  const int64_t b = coopWorld(blockIdx.x, gridDim.x);
+  if (b >= B) return;
+  const int nC = (int)svAt(saved, lay.nc, B, b);
+  const int m = 3 * nC;
+  if (m == 0) return;
+  Ctx c;
+  c.bodies = bodies; c.ws = const_cast<double*>(ws); c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
+  double* dn = denseOf(saved, lay, B, b);
+  const bool on = ln < m;
+  const int row = on ? ln : 0;
+  const int ci = row / 3, kk = row % 3;
+  auto accAt = [&](int body, int e) -> double& { return acc[(body * 6 + e) * MAX_ROWS + row]; };
+  auto ldAcc = [&](int body) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = accAt(body, e); return fromArr(a); };
+  auto stAcc = [&](int body, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) accAt(body, e) = a[e]; };
+  // ---- this row's wrench, b entry and constraint-force column ----
+  const int r0 = lay.contacts + ci * CR_SIZE;
+  const V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
+  const V3 nrm = mk3(svAt(saved, r0 + CR_NORMAL, B, b), svAt(saved, r0 + CR_NORMAL + 1, B, b), svAt(saved, r0 + CR_NORMAL + 2, B, b));
+  const int bA = cm->boxes[(int)svAt(saved, r0 + CR_BOXA, B, b)].body, bB = cm->boxes[(int)svAt(saved, r0 + CR_BOXB, B, b)].body;
+  V3 t1, t2;
+  tangentBasis(nrm, t1, t2);
+  const V3 dir = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
+  const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p
+  V6 ja = zero6(), jb = zero6();
+  double rel = 0;
+  if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_A)); }
+  if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_A)); }
+  const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
+  if (on) {
+    double a6[6];
+    toArr(ja, a6);
+    for (int e = 0; e < 6; e++) JAs[row * 6 + e] = a6[e];
+    toArr(jb, a6);
+    for (int e = 0; e < 6; e++) JBs[row * 6 + e] = a6[e];
+    svAt(saved, lay.b + row, B, b) = rel;   // getRelVelocity; restitution 0, penetration correction off
+  }
+  for (int i = 0; i < c.nb; i++) {
+    const DevBody& bd = bodies[i];
+    const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
+    const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
+    const V6 Fi = dAdT(ldTAt(c, i, WS_TW), F);
+    if (bd.jtype != JT_FREE) {
+      if (on) dn[lay.aall + bd.dofOff * MAX_ROWS + row] = mult * dot(cV6(bd.S), Fi);
+    } else {
+      double v6[6];
+      toArr(dAdT(cT(bd.Tcj), Fi), v6);
+      if (on) for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
+    }
+    if (on) for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
+  }
+  w.sync();
+  if (on) {
+    // ---- unit-impulse test of this row.  leaf -> root: bias impulses along the two ancestor chains ----
+    const uint64_t chain = mA | mB;
+    for (int i = c.nb - 1; i >= 0; i--) {
+      if (!((chain >> i) & 1ull)) continue;
+      const DevBody& bd = bodies[i];
+      V6 Bi = ldAcc(i);
+      if (i == bA) Bi = Bi - ja;
+      if (i == bB) Bi = Bi - jb;
+      stAcc(i, Bi);
+      if (bd.jtype != JT_FREE && bd.parent >= 0) {
+        const double uimp = -dot(cV6(bd.S), Bi);
+        const V6 up = dAdInvT(ldT(c, i), Bi + (wsAt(c, i, WS_PSI) * uimp) * ldV6(c, i, WS_AIS));
+        stAcc(bd.parent, ldAcc(bd.parent) + up);
+      }
+    }
+    // root -> leaf: velocity changes of every body, joint-space response
+    for (int i = 0; i < c.nb; i++) {
+      const DevBody& bd = bodies[i];
+      const V6 X = bd.parent >= 0 ? AdInvT(ldT(c, i), ldAcc(bd.parent)) : zero6();
+      const V6 Bi = ((chain >> i) & 1ull) ? ldAcc(i) : zero6();
+      if (bd.jtype != JT_FREE) {
+        const V6 S = cV6(bd.S);
+        const double dq = wsAt(c, i, WS_PSI) * (-dot(S, Bi) - dot(ldV6(c, i, WS_AIS), X));
+        stAcc(i, X + dq * S);
+        dn[lay.massed + bd.dofOff * MAX_ROWS + row] = dq;
+      } else {
+        const T12 Tcj = cT(bd.Tcj);
+        LDL6 f;
+        for (int e = 0; e < 15; e++) f.l[e] = wsAt(c, i, WS_PSI + e);
+        for (int e = 0; e < 6; e++) f.d[e] = wsAt(c, i, WS_PSI + 15 + e);
+        double r[6], u[6], pj[6];
+        toArr(dAdT(Tcj, Bi), u);
+        toArr(dAdT(Tcj, mul(ldS6(c, i, WS_AI), X)), pj);
+        for (int e = 0; e < 6; e++) r[e] = -u[e] - pj[e];
+        ldl6Solve(f, r);
+        stAcc(i, X + AdT(Tcj, fromArr(r)));
+        for (int e = 0; e < 6; e++) dn[lay.massed + (bd.dofOff + e) * MAX_ROWS + row] = r[e];
+      }
+    }
+    // row of A: relative-velocity response at every row of the contacts c2 >= ci, mirrored into the earlier rows
+    for (int c2 = ci; c2 < nC; c2++) {
+      const int q0 = lay.contacts + c2 * CR_SIZE;
+      const int b2A = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body, b2B = cm->boxes[(int)svAt(saved, q0 + CR_BOXB, B, b)].body;
+      const V6 dVA = b2A >= 0 ? ldAcc(b2A) : zero6(), dVB = b2B >= 0 ? ldAcc(b2B) : zero6();
+      for (int k2 = 0; k2 < 3; k2++) {
+        const int col = 3 * c2 + k2;
+        double a6[6], b6[6];
+        for (int e = 0; e < 6; e++) { a6[e] = JAs[col * 6 + e]; b6[e] = JBs[col * 6 + e]; }
+        double val = 0;
+        if (b2A >= 0) val += dot(fromArr(a6), dVA);
+        if (b2B >= 0) val += dot(fromArr(b6), dVB);
+        dn[lay.A + row * MAX_ROWS + col] = val;
+        if (c2 > ci) dn[lay.A + col * MAX_ROWS + row] = val;
+      }
+    }
+  }
+}
+
 }  // namespace nbl

@@ -32,10 +32,10 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
-                                           "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop"};
+                                           "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -234,6 +234,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_solve, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_a, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     std::string msg = std::string("model upload failed: ") + hipGetErrorString(e);
     nbl_model_destroy(m);
@@ -305,9 +306,14 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
                                   (double*)saved, status, (double*)workspace, m->hasContact ? m->lay.vpre : -1));
   if (m->hasContact) {
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
-    TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dContact, B, (double*)saved, m->lay,
+    TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
                                        status, (double*)workspace));
-    TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved,
+    if (m->coop) {
+      const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 2 * 6 * MAX_ROWS) * sizeof(double);
+      TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)B), dim3(64), rowsLds, s, m->mdl, m->dBodies, m->dContact, B,
+                                            (double*)saved, m->lay, (const double*)workspace));
+    } else
+      TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved,
                                      m->lay, (double*)workspace, lws));
     dim3 lgrid((unsigned)((B + ll - 1) / ll)), lblock(ll);
     const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
