@@ -184,6 +184,86 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
   }
 }
 
+// ---- contact-geometry pieces shared by the one-world-per-lane and the one-world-per-wavefront kernels ----
+struct ContactRec { V3 p, nrm, eAP, eAD, eBP, eBD; int type, bA, bB; };
+DEV ContactRec loadContactRec(const LaneMem& SV, const SavedLayout& lay, const DevContactModel* __restrict__ cm, int ci) {
+  const int r0 = lay.contacts + ci * CR_SIZE;
+  ContactRec R;
+  R.p = mk3(SV.at(r0 + CR_POINT), SV.at(r0 + CR_POINT + 1), SV.at(r0 + CR_POINT + 2));
+  R.nrm = mk3(SV.at(r0 + CR_NORMAL), SV.at(r0 + CR_NORMAL + 1), SV.at(r0 + CR_NORMAL + 2));
+  R.type = (int)SV.at(r0 + CR_TYPE);
+  R.bA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].body; R.bB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].body;
+  R.eAP = mk3(SV.at(r0 + CR_EA_FIXED), SV.at(r0 + CR_EA_FIXED + 1), SV.at(r0 + CR_EA_FIXED + 2));
+  R.eAD = mk3(SV.at(r0 + CR_EA_DIR), SV.at(r0 + CR_EA_DIR + 1), SV.at(r0 + CR_EA_DIR + 2));
+  R.eBP = mk3(SV.at(r0 + CR_EB_FIXED), SV.at(r0 + CR_EB_FIXED + 1), SV.at(r0 + CR_EB_FIXED + 2));
+  R.eBD = mk3(SV.at(r0 + CR_EB_DIR), SV.at(r0 + CR_EB_DIR + 1), SV.at(r0 + CR_EB_DIR + 2));
+  return R;
+}
+// tangent basis and the pieces of its derivative (ContactConstraint.cpp:734-876)
+struct TangentFrame { V3 crs, t1, t2; double tn; bool project; };
+DEV TangentFrame tangentFrameOf(V3 nrm) {
+  TangentFrame F;
+  V3 crs = mk3(0, 0, 1), tng = cross(crs, nrm);
+  if (dot(tng, tng) < 1e-12) { crs = mk3(1, 0, 0); tng = cross(crs, nrm);
+    if (dot(tng, tng) < 1e-12) { crs = mk3(0, 1, 0); tng = cross(crs, nrm);
+      if (dot(tng, tng) < 1e-12) { crs = mk3(0, 0, 1); tng = cross(crs, nrm); } } }
+  F.crs = crs; F.tn = norm3(tng);
+  F.t1 = (1.0 / F.tn) * tng; F.t2 = cross(nrm, F.t1);
+  F.project = fabs(F.tn - 1.0) > 1e-6;
+  return F;
+}
+// Adjoint terms of one contact row (k = 0 normal, 1 / 2 tangents) given Z_all = world twist of body A minus that of
+// body B under the joint rates z_row: what a position twist of a DOF on the vertex side / face side / edge A / edge B
+// contributes through dF/dq.
+struct RowTerms { V6 vertexTerm, faceTerm, edgeTermA, edgeTermB; };
+DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k, V3 d, V6 Zall) {
+  const V3 p = R.p, nrm = R.nrm, t1 = TF.t1, crs = TF.crs;
+  const double tn = TF.tn;
+  const bool project = TF.project;
+  RowTerms out;
+  // vertex-type term: Z_all . dF/dq_l = s_l^pos . [p x cv; cv],  cv = d x Z_all.w
+  V3 cv = cross(d, Zall.w);
+  out.vertexTerm = mk6(cross(p, cv), cv);
+  // face-type term: Z_all . dF/dq_l = w_l . a   (dn = w x n, tangents through the basis derivative)
+  V3 cc = Zall.v + cross(Zall.w, p);
+  V3 aFace;
+  auto t1Adjoint = [&](V3 x) -> V3 {   // a with x . dt1(w) = a . w
+    V3 xp = project ? x - dot(x, t1) * t1 : x;
+    return cross(nrm, (1.0 / tn) * cross(xp, crs));
+  };
+  if (k == 0) aFace = cross(nrm, cc);
+  else if (k == 1) aFace = t1Adjoint(cc);
+  else aFace = cross(nrm, cross(t1, cc)) + t1Adjoint(cross(cc, nrm));
+  out.faceTerm = mk6(aFace, mk3(0, 0, 0));
+  // edge-edge contacts (DCC.cpp:397-424, 700-735; math::getContactPointGradient Geometry.cpp:1129-1236):
+  // the contact point is the midpoint of the closest points of the two edge lines, the normal follows
+  // +-eB x eA.  Both are linear in the position twist [w; u] of the moving DOF; their adjoints:
+  out.edgeTermA = zero6(); out.edgeTermB = zero6();
+  if (R.type == CT_EDGE_EDGE) {
+    const V3 eAP = R.eAP, eAD = R.eAD, eBP = R.eBP, eBD = R.eBD;
+    V3 hN;   // cc . d(dir) = hN . dn
+    if (k == 0) hN = cc;
+    else if (k == 1) { V3 xp = project ? cc - dot(cc, t1) * t1 : cc; hN = (1.0 / tn) * cross(xp, crs); }
+    else { V3 x2 = cross(cc, nrm); V3 xp = project ? x2 - dot(x2, t1) * t1 : x2; hN = cross(t1, cc) + (1.0 / tn) * cross(xp, crs); }
+    const double sgnN = dot(cross(eBD, eAD), nrm) < 0 ? -1.0 : 1.0;
+    V3 pv = eBP - eAP;
+    const double uaub = dot(eAD, eBD), q1 = dot(eAD, pv), q2 = -dot(eBD, pv), dd = 1 - uaub * uaub;
+    V3 gPa, gDa, gPb, gDb;
+    if (dd <= 0) { gPa = 0.5 * cv; gDa = mk3(0, 0, 0); gPb = 0.5 * cv; gDb = mk3(0, 0, 0); }
+    else {
+      const double e = 1.0 / dd, N1 = q1 + uaub * q2, N2 = uaub * q1 + q2, alpha = N1 * e, beta = N2 * e;
+      const double ca = dot(cv, eAD), cb = dot(cv, eBD), k2 = 2 * uaub * e * e;
+      gPa = 0.5 * (cv + ca * (e * uaub * eBD - e * eAD) + cb * (e * eBD - e * uaub * eAD));
+      gDa = 0.5 * (alpha * cv + ca * ((k2 * N1 + e * q2) * eBD + e * pv) + cb * ((k2 * N2 + e * q1) * eBD + (e * uaub) * pv));
+      gPb = 0.5 * (cv + ca * (e * eAD - e * uaub * eBD) + cb * (e * uaub * eAD - e * eBD));
+      gDb = 0.5 * (beta * cv + ca * ((k2 * N1 + e * q2) * eAD - (e * uaub) * pv) + cb * ((k2 * N2 + e * q1) * eAD - e * pv));
+    }
+    out.edgeTermA = mk6(cross(eAP, gPa) + cross(eAD, gDa) + sgnN * cross(eAD, cross(hN, eBD)), gPa);
+    out.edgeTermB = mk6(cross(eBP, gPb) + cross(eBD, gDb) + sgnN * cross(eBD, cross(eAD, hN)), gPb);
+  }
+  return out;
+}
+
 // ---- kernel B: tree part of the adjoint ----
 DEV V6 ldField(const Ctx& c, int body, int base, int f) { return ldV6(c, body, base + 6 * f); }
 
@@ -252,25 +332,12 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
   if (active) {
     const int nC = (int)SV.at(lay.nc);
     for (int ci = 0; ci < nC; ci++) {
-      const int r0 = lay.contacts + ci * CR_SIZE;
-      V3 p = mk3(SV.at(r0 + CR_POINT), SV.at(r0 + CR_POINT + 1), SV.at(r0 + CR_POINT + 2));
-      V3 nrm = mk3(SV.at(r0 + CR_NORMAL), SV.at(r0 + CR_NORMAL + 1), SV.at(r0 + CR_NORMAL + 2));
-      const int type = (int)SV.at(r0 + CR_TYPE);
-      const int bA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].body, bB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].body;
-      V3 eAP = mk3(SV.at(r0 + CR_EA_FIXED), SV.at(r0 + CR_EA_FIXED + 1), SV.at(r0 + CR_EA_FIXED + 2));
-      V3 eAD = mk3(SV.at(r0 + CR_EA_DIR), SV.at(r0 + CR_EA_DIR + 1), SV.at(r0 + CR_EA_DIR + 2));
-      V3 eBP = mk3(SV.at(r0 + CR_EB_FIXED), SV.at(r0 + CR_EB_FIXED + 1), SV.at(r0 + CR_EB_FIXED + 2));
-      V3 eBD = mk3(SV.at(r0 + CR_EB_DIR), SV.at(r0 + CR_EB_DIR + 1), SV.at(r0 + CR_EB_DIR + 2));
+      const ContactRec CR = loadContactRec(SV, lay, cm, ci);
+      const V3 p = CR.p, nrm = CR.nrm;
+      const int type = CR.type, bA = CR.bA, bB = CR.bB;
       if (bA >= 0 && bB >= 0 && (cm->ancestors[bA] & cm->ancestors[bB])) gst |= 0x2u;  // self-collision chains unsupported
-      // tangent basis and the pieces of its derivative (ContactConstraint.cpp:734-876)
-      V3 crs = mk3(0, 0, 1), tng = cross(crs, nrm);
-      if (dot(tng, tng) < 1e-12) { crs = mk3(1, 0, 0); tng = cross(crs, nrm);
-        if (dot(tng, tng) < 1e-12) { crs = mk3(0, 1, 0); tng = cross(crs, nrm);
-          if (dot(tng, tng) < 1e-12) { crs = mk3(0, 0, 1); tng = cross(crs, nrm); } } }
-      const double tn = norm3(tng);
-      V3 t1 = (1.0 / tn) * tng, t2 = cross(nrm, t1);
-      const bool project = fabs(tn - 1.0) > 1e-6;
-      V3 dirs[3] = {nrm, t1, t2};
+      const TangentFrame TF = tangentFrameOf(nrm);
+      V3 dirs[3] = {nrm, TF.t1, TF.t2};
       for (int k = 0; k < 3; k++) {
         const int row = 3 * ci + k;
         double cf[8];
@@ -286,46 +353,8 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
           return z;
         };
         V6 TA = twistOf(bA), TB = twistOf(bB);
-        V6 Zall = TA - TB;
-        // vertex-type term: Z_all . dF/dq_l = s_l^pos . [p x cv; cv],  cv = d x Z_all.w
-        V3 cv = cross(d, Zall.w);
-        V6 vertexTerm = mk6(cross(p, cv), cv);
-        // face-type term: Z_all . dF/dq_l = w_l . a   (dn = w x n, tangents through the basis derivative)
-        V3 cc = Zall.v + cross(Zall.w, p);
-        V3 aFace;
-        auto t1Adjoint = [&](V3 x) -> V3 {   // a with x . dt1(w) = a . w
-          V3 xp = project ? x - dot(x, t1) * t1 : x;
-          return cross(nrm, (1.0 / tn) * cross(xp, crs));
-        };
-        if (k == 0) aFace = cross(nrm, cc);
-        else if (k == 1) aFace = t1Adjoint(cc);
-        else aFace = cross(nrm, cross(t1, cc)) + t1Adjoint(cross(cc, nrm));
-        V6 faceTerm = mk6(aFace, mk3(0, 0, 0));
-        // edge-edge contacts (DCC.cpp:397-424, 700-735; math::getContactPointGradient Geometry.cpp:1129-1236):
-        // the contact point is the midpoint of the closest points of the two edge lines, the normal follows
-        // +-eB x eA.  Both are linear in the position twist [w; u] of the moving DOF; their adjoints:
-        V6 edgeTermA = zero6(), edgeTermB = zero6();
-        if (type == CT_EDGE_EDGE) {
-          V3 hN;   // cc . d(dir) = hN . dn
-          if (k == 0) hN = cc;
-          else if (k == 1) { V3 xp = project ? cc - dot(cc, t1) * t1 : cc; hN = (1.0 / tn) * cross(xp, crs); }
-          else { V3 x2 = cross(cc, nrm); V3 xp = project ? x2 - dot(x2, t1) * t1 : x2; hN = cross(t1, cc) + (1.0 / tn) * cross(xp, crs); }
-          const double sgnN = dot(cross(eBD, eAD), nrm) < 0 ? -1.0 : 1.0;
-          V3 pv = eBP - eAP;
-          const double uaub = dot(eAD, eBD), q1 = dot(eAD, pv), q2 = -dot(eBD, pv), dd = 1 - uaub * uaub;
-          V3 gPa, gDa, gPb, gDb;
-          if (dd <= 0) { gPa = 0.5 * cv; gDa = mk3(0, 0, 0); gPb = 0.5 * cv; gDb = mk3(0, 0, 0); }
-          else {
-            const double e = 1.0 / dd, N1 = q1 + uaub * q2, N2 = uaub * q1 + q2, alpha = N1 * e, beta = N2 * e;
-            const double ca = dot(cv, eAD), cb = dot(cv, eBD), k2 = 2 * uaub * e * e;
-            gPa = 0.5 * (cv + ca * (e * uaub * eBD - e * eAD) + cb * (e * eBD - e * uaub * eAD));
-            gDa = 0.5 * (alpha * cv + ca * ((k2 * N1 + e * q2) * eBD + e * pv) + cb * ((k2 * N2 + e * q1) * eBD + (e * uaub) * pv));
-            gPb = 0.5 * (cv + ca * (e * eAD - e * uaub * eBD) + cb * (e * uaub * eAD - e * eBD));
-            gDb = 0.5 * (beta * cv + ca * ((k2 * N1 + e * q2) * eAD - (e * uaub) * pv) + cb * ((k2 * N2 + e * q1) * eAD - e * pv));
-          }
-          edgeTermA = mk6(cross(eAP, gPa) + cross(eAD, gDa) + sgnN * cross(eAD, cross(hN, eBD)), gPa);
-          edgeTermB = mk6(cross(eBP, gPb) + cross(eBD, gDb) + sgnN * cross(eBD, cross(eAD, hN)), gPb);
-        }
+        const RowTerms RT = contactRowTerms(CR, TF, k, d, TA - TB);
+        const V6 vertexTerm = RT.vertexTerm, faceTerm = RT.faceTerm, edgeTermA = RT.edgeTermA, edgeTermB = RT.edgeTermB;
         const bool aIsVertex = (type == CT_VERTEX_FACE);
         for (int side = 0; side < 2; side++) {
           const int start = side == 0 ? bA : bB;

@@ -335,4 +335,132 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   }
 }
 
+// Tree part of the contact adjoint, one world per wavefront (k_bwd_contact_b one world per lane; the header of
+// contact_backward.hip derives the terms).  Three phases with different lane roles, all state in LDS:
+//   1  lane = joint-rate field f (9: lambda1, v_pre, p1..3, s1..3, w): root->leaf twists, body frame FB and world frame FW
+//   2  lane = mass-matrix pair k (4): leaf->root reverse Newton-Euler (v = 0) of -d(adj^T M acc)/dq, per-lane partial xi
+//   3  lane = LCP row (24): contact-geometry chain walks from the two contact bodies, per-lane accumulators
+//   4  lane = body: sums the partials, projects on the joint (applyHt) and writes the position cotangent LB_QX
+// lds doubles: FB[nb][9][6] FW[nb][8][6] PF[nb][6][4] PA[nb][6][4] X2[nb][6][4] XL[nb][6][24]
+__global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                           const DevContactModel* __restrict__ cm, int64_t B,
+                                                           double* __restrict__ saved, SavedLayout lay,
+                                                           const double* __restrict__ ws, double* __restrict__ lws) {
+  extern __shared__ __attribute__((aligned(16))) double ldsB[];
+  const DevWave w;
+  const int ln = w.lane();
+  const int64_t b = coopWorld(blockIdx.x, gridDim.x);
+  if (b >= B) return;
+  if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;
+  const int nb = mdl.nb, n = mdl.n;
+  double* FB = ldsB;
+  double* FW = FB + nb * 54;
+  double* PF = FW + nb * 48;
+  double* PA = PF + nb * 24;
+  double* X2 = PA + nb * 24;
+  double* XL = X2 + nb * 24;
+  Ctx c;
+  c.bodies = bodies; c.ws = const_cast<double*>(ws); c.B = B; c.b = b; c.nb = nb; c.n = n; c.dt = mdl.dt;
+  LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
+  const double* q = saved;
+  auto ld6 = [](const double* base, int stride) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e * stride]; return fromArr(a); };
+  auto st6 = [](double* base, int stride, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) base[e * stride] = a[e]; };
+  // ---- phase 1 ----
+  if (ln < 9) {
+    const int f = ln;
+    const double* src; int64_t stride = B;
+    if (f == 0) src = lws + (int64_t)LB_LAM1 * B + b;
+    else if (f == 1) src = saved + (int64_t)lay.vpre * B + b;
+    else if (f <= 4) src = lws + (int64_t)(LB_P + (f - 2) * MAX_DOF_CONTACT) * B + b;
+    else if (f <= 7) src = lws + (int64_t)(LB_S + (f - 5) * MAX_DOF_CONTACT) * B + b;
+    else src = saved + (int64_t)lay.w * B + b;
+    for (int i = 0; i < nb; i++) {
+      const DevBody& bd = bodies[i];
+      V6 tw;
+      if (bd.jtype == JT_FREE) {
+        const int o = bd.dofOff;
+        tw = AdT(cT(bd.Tcj), mk6(mk3(src[o * stride], src[(o + 1) * stride], src[(o + 2) * stride]),
+                                 mk3(src[(o + 3) * stride], src[(o + 4) * stride], src[(o + 5) * stride])));
+      } else tw = src[bd.dofOff * stride] * cV6(bd.S);
+      if (bd.parent >= 0) tw = tw + AdInvT(ldT(c, i), ld6(FB + (bd.parent * 9 + f) * 6, 1));
+      st6(FB + (i * 9 + f) * 6, 1, tw);
+      if (f < 8) st6(FW + (i * 8 + f) * 6, 1, AdT(ldTAt(c, i, WS_TW), tw));
+    }
+  }
+  for (int idx = ln; idx < nb * 24; idx += 64) { PF[idx] = 0.0; PA[idx] = 0.0; }
+  for (int idx = ln; idx < nb * 6 * MAX_ROWS; idx += 64) XL[idx] = 0.0;
+  w.sync();
+  // ---- phase 2 ----
+  if (ln < 4) {
+    const int k = ln;
+    const int ADJ = k == 0 ? 0 : 4 + k, ACC = k == 0 ? 8 : 1 + k;   // (lambda1, w), (s_k, p_k)
+    for (int i = nb - 1; i >= 0; i--) {
+      const DevBody& bd = bodies[i];
+      const S6 G = cS6(bd.G);
+      const V6 adj = ld6(FB + (i * 9 + ADJ) * 6, 1), acc = ld6(FB + (i * 9 + ACC) * 6, 1);
+      const V6 Fk = mul(G, acc) + ld6(PF + i * 24 + k, 4);
+      const V6 Ak = mul(G, adj) + ld6(PA + i * 24 + k, 4);
+      V6 xi = zero6();
+      if (bd.parent >= 0) {
+        const T12 T = ldT(c, i);
+        xi = dad(AdInvT(T, ld6(FB + (bd.parent * 9 + ADJ) * 6, 1)), Fk) + dad(AdInvT(T, ld6(FB + (bd.parent * 9 + ACC) * 6, 1)), Ak);
+        st6(PF + bd.parent * 24 + k, 4, ld6(PF + bd.parent * 24 + k, 4) + dAdInvT(T, Fk));
+        st6(PA + bd.parent * 24 + k, 4, ld6(PA + bd.parent * 24 + k, 4) + dAdInvT(T, Ak));
+      }
+      st6(X2 + i * 24 + k, 4, xi);
+    }
+  }
+  // ---- phase 3 (independent of phase 2: different lanes' data) ----
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  if (ln < m) {
+    const int row = ln, ci = row / 3, k = row % 3;
+    double cf[8];
+    bool any = false;
+    for (int e = 0; e < 8; e++) { cf[e] = lws[(int64_t)(LB_COEF + row * 8 + e) * B + b]; any = any || cf[e] != 0.0; }
+    if (any) {
+      const ContactRec CR = loadContactRec(SV, lay, cm, ci);
+      const TangentFrame TF = tangentFrameOf(CR.nrm);
+      const V3 d = k == 0 ? CR.nrm : (k == 1 ? TF.t1 : TF.t2);
+      const V6 Fw = mk6(cross(CR.p, d), d);
+      auto twistOf = [&](int body) -> V6 {   // world twist of `body` under the joint rates z_row
+        V6 z = zero6();
+        if (body < 0) return z;
+        for (int e = 0; e < 8; e++) z = z + cf[e] * ld6(FW + (body * 8 + e) * 6, 1);
+        return z;
+      };
+      const V6 TA = twistOf(CR.bA), TB = twistOf(CR.bB);
+      const RowTerms RT = contactRowTerms(CR, TF, k, d, TA - TB);
+      const bool aIsVertex = (CR.type == CT_VERTEX_FACE);
+      for (int side = 0; side < 2; side++) {
+        const int start = side == 0 ? CR.bA : CR.bB;
+        const V6 Tend = side == 0 ? TA : TB;
+        const double sgn = side == 0 ? 1.0 : -1.0;
+        const bool vertexSide = (side == 0) == aIsVertex;
+        for (int l = start; l >= 0; l = bodies[l].parent) {
+          const V6 Zl = sgn * (Tend - twistOf(bodies[l].parent));
+          V6 add = -dad(Zl, Fw);
+          if (CR.type == CT_VERTEX_FACE || CR.type == CT_FACE_VERTEX) add = add + (vertexSide ? RT.vertexTerm : RT.faceTerm);
+          else if (CR.type == CT_EDGE_EDGE) add = add + (side == 0 ? RT.edgeTermA : RT.edgeTermB);
+          double* x = XL + l * 6 * MAX_ROWS + row;
+          st6(x, MAX_ROWS, ld6(x, MAX_ROWS) + add);
+        }
+      }
+    }
+  }
+  w.sync();
+  // ---- phase 4 ----
+  if (ln < nb) {
+    const int i = ln;
+    const DevBody& bd = bodies[i];
+    V6 xi2 = zero6();
+    for (int k = 0; k < 4; k++) xi2 = xi2 + ld6(X2 + i * 24 + k, 4);
+    double a6[6];
+    for (int e = 0; e < 6; e++) { double sum = 0; for (int r = 0; r < MAX_ROWS; r++) sum += XL[(i * 6 + e) * MAX_ROWS + r]; a6[e] = sum; }
+    double qb2[6], qb3[6];
+    applyHt(bd, q, B, b, xi2, qb2);
+    applyHt(bd, q, B, b, dAdT(ldTAt(c, i, WS_TW), fromArr(a6)), qb3);
+    for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_QX + bd.dofOff + k) * B + b] = qb3[k] - qb2[k];
+  }
+}
+
 }  // namespace nbl

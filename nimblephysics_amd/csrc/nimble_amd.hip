@@ -32,10 +32,10 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
-                                           "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop"};
+                                           "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -235,6 +235,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_a, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     std::string msg = std::string("model upload failed: ") + hipGetErrorString(e);
     nbl_model_destroy(m);
@@ -358,7 +359,12 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
     else
       TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
                                       B, sv, m->lay, grad_next_state, (double*)workspace, lws));
-    TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
+    if (m->coop) {
+      const size_t bLds = (size_t)m->nb * (54 + 48 + 24 + 24 + 24 + 6 * MAX_ROWS) * sizeof(double);
+      TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)B), dim3(64), bLds, s, m->mdl, m->dBodies, m->dContact, B,
+                                             sv, m->lay, (const double*)workspace, lws));
+    } else
+      TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
                                       m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
     TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
                                           grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws));
