@@ -1,0 +1,112 @@
+"""The PRODUCT's wave-cooperative LCP device code (nimblephysics_amd/csrc/coop_dev.hpp: one world per wavefront, lane =
+LCP row / matrix column) compiled for the host on a thread-per-lane wave emulation (tests/host_shim/wave_emu.hpp) and
+checked against
+  * numpy's pseudo-inverse (the role of Eigen's completeOrthogonalDecomposition in CGGM.cpp:280 / LCPUtils.cpp:113),
+  * the one-world-per-lane statement of the same stage-0 algorithm (lcp_dev.hpp: guessSolution + the
+    constructMatrices / opportunisticallyStandardizeResults loop), which test_device_lcp_host.py pins to the reference.
+The emulation deadlocks if lanes disagree on control flow around a cross-lane primitive, so passing also shows that the
+device code is wave-uniform where it has to be.  A checker for device code, not a CPU path of the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+
+
+@pytest.fixture(scope="module")
+def shim():
+    src = os.path.join(HERE, "host_shim", "coop_shim.cpp")
+    out = os.path.join(HERE, "host_shim", "libcoop_shim.so")
+    deps = [src, os.path.join(HERE, "host_shim", "wave_emu.hpp")] + \
+        [os.path.join(ROOT, "nimblephysics_amd", "csrc", f) for f in ("coop_dev.hpp", "lcp_dev.hpp", "spatial_dev.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(HERE, "host_shim"),
+                               "-I", os.path.join(ROOT, "nimblephysics_amd", "csrc"), "-o", out, src])
+    return C.CDLL(out)
+
+
+def _p(a):
+    return a.ctypes.data_as(pd)
+
+
+def _pi(a):
+    return a.ctypes.data_as(pi)
+
+
+def test_coop_pinv_equals_numpy_pinv_on_masked_rank_deficient_systems(shim):
+    """Full-rank and rank-deficient, symmetric and non-symmetric, with rows/columns masked out (zero) the way the
+    kernels select the clamping block: Q^+ to 1e-9, rank exact."""
+    rng = np.random.default_rng(0)
+    for trial in range(80):
+        c = int(rng.integers(1, 25)); k = int(rng.integers(1, c + 1))
+        idx = np.sort(rng.choice(24, c, replace=False))
+        U = rng.normal(0, 1, (c, k)); V = rng.normal(0, 1, (c, k))
+        sub = U @ U.T if trial % 2 == 0 else U @ V.T
+        Q = np.zeros((24, 24)); Q[np.ix_(idx, idx)] = sub
+        P = np.zeros((24, 24))
+        rank = shim.shim_coop_pinv(_p(np.ascontiguousarray(Q)), c, _p(P))
+        ref = np.linalg.pinv(Q, rcond=1e-11)
+        assert rank == k
+        assert np.abs(P - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30)
+    Z = np.zeros((24, 24)); P = np.ones((24, 24))
+    assert shim.shim_coop_pinv(_p(Z), 5, _p(P)) == 0 and not P.any()
+
+
+def _contact_problem(rng, trial):
+    nc = int(rng.integers(1, 9)); m = 3 * nc
+    ndof = int(rng.choice([6, 12, 30]))
+    J = rng.normal(0, 1, (m, ndof))
+    A = np.zeros((24, 24)); A[:m, :m] = J @ np.diag(rng.uniform(0.1, 2, ndof)) @ J.T
+    mu = np.zeros(8); mu[:nc] = rng.choice([0.5, 1.0], nc)
+    xs = np.zeros(24)
+    for c in range(nc):
+        if rng.random() < 0.7:
+            xs[3 * c] = rng.uniform(0.1, 2)
+            xs[3 * c + 1:3 * c + 3] = rng.uniform(-0.5, 0.5, 2) * mu[c] * xs[3 * c]
+            if rng.random() < 0.4:       # sliding: one friction row on its bound
+                xs[3 * c + 1 + int(rng.integers(0, 2))] = rng.choice([-1, 1]) * mu[c] * xs[3 * c]
+    b = np.zeros(24); b[:m] = (A @ xs)[:m]
+    kind = trial % 3
+    if kind == 1:
+        b[:m] += rng.normal(0, 0.05, m)
+    if kind == 2:
+        b[:m] = rng.normal(0, 1, m)
+    have = int(trial % 5 >= 3)
+    xc = np.zeros(24); xc[:m] = xs[:m] + rng.normal(0, 1e-3, m) * (trial % 2)
+    return m, A, b, mu, have, xc
+
+
+def test_coop_stage0_equals_the_one_world_per_lane_statement(shim):
+    """guessSolution / warm start -> classification -> least-squares standardisation -> isLCPSolutionValid, on resting,
+    sliding (upper-bound rows), perturbed and random contact problems of 1..8 contacts with rank-deficient A: same
+    accept/reject decision, same x, same classes, and the pseudo-inverse left in LDS is that of the final Q."""
+    rng = np.random.default_rng(1)
+    n_ok = n_ub = n_fail = 0
+    for trial in range(240):
+        m, A, b, mu, have, xc = _contact_problem(rng, trial)
+        X1 = np.zeros(24); X01 = np.zeros(24); c1 = np.zeros(24, np.int32); E1 = np.zeros(24); P = np.zeros((24, 24))
+        X2 = np.zeros(24); X02 = np.zeros(24); c2 = np.zeros(24, np.int32); E2 = np.zeros(24)
+        r1 = shim.shim_coop_stage0(m, _p(A), _p(b), _p(mu), have, _p(xc), _p(X1), _p(X01), _pi(c1), _p(E1), _p(P))
+        r2 = shim.shim_lane_stage0(m, _p(A), _p(b), _p(mu), have, _p(xc), _p(X2), _p(X02), _pi(c2), _p(E2))
+        assert (r1 & 1) == r2
+        assert np.abs(X01 - X02).max() <= 1e-9 * max(1.0, np.abs(X02).max())          # pre-solve x handed to the cascade
+        if not r2:
+            n_fail += 1
+            continue
+        n_ok += 1
+        assert np.abs(X1 - X2).max() <= 1e-9 * max(1.0, np.abs(X2).max())
+        assert np.array_equal(c1[:m], c2[:m]) and np.array_equal(E1, E2)
+        n_ub += int((c1 == 2).any())
+        if (r1 & 2):
+            cl = c1 == 1
+            Q = np.zeros((24, 24)); Q[np.ix_(cl, cl)] = A[np.ix_(cl, cl)]
+            for u in np.where(c1 == 2)[0]:          # upper-bound rows ride on their normal column
+                Q[cl, u - u % 3] += E1[u] * A[cl, u]
+            ref = np.linalg.pinv(Q, rcond=1e-11)
+            assert np.abs(P - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-30)
+    assert n_ok > 50 and n_ub > 10 and n_fail > 50
