@@ -82,13 +82,12 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
     w.sync();
     const double tau = vb[MAXR];
     double d = a[0];
-    double v[MAXR];
 #pragma unroll
-    for (int i = 1; i < MAXR; i++) { v[i] = vb[i]; d = fma(v[i], a[i], d); }
+    for (int i = 1; i < MAXR; i++) d = fma(vb[i], a[i], d);
     d = (ln == p) ? 0.0 : d * tau;
     a[0] -= d;
 #pragma unroll
-    for (int i = 1; i < MAXR; i++) a[i] = fma(-d, v[i], a[i]);
+    for (int i = 1; i < MAXR; i++) a[i] = fma(-d, vb[i], a[i]);   // v re-read from LDS: cheaper than 48 live VGPRs
     if (ln < MAXR) rowsOut[k * CLD + ln] = a[0];
     else if (ln < 2 * MAXR) carryOut[k * CLD + ln - MAXR] = a[0];
 #pragma unroll
@@ -209,7 +208,10 @@ struct CoopRow {
   bool fric;        // this lane's row is a friction row
   int fp;           // lane of the normal row of this lane's contact
   double mu, Bv, colNorm;
-  double acol[MAXR];   // column (= row, A is symmetric) `lane` of A, zero beyond m
+  const double* Acol;  // &A[0][lane] (stride MAXR): column (= row, A is symmetric) `lane` of A.  Re-read where needed
+                       // instead of being held in 48 VGPRs across the factorisations (it stays in L2).
+  bool on;             // lane < m
+  DEV double a(int i) const { return (on && i < m) ? Acol[i * MAXR] : 0.0; }
 };
 
 // A x for this lane's row, x one entry per lane
@@ -220,7 +222,7 @@ DEV double coopAx(const W& w, CoopLds& S, const CoopRow& R, double xLane, int sl
   w.sync();
   double v = 0.0;
 #pragma unroll
-  for (int jx = 0; jx < MAXR; jx++) v = fma(R.acol[jx], S.vec[slot][jx], v);
+  for (int jx = 0; jx < MAXR; jx++) v = fma(R.a(jx), S.vec[slot][jx], v);
   return v;
 }
 
@@ -302,7 +304,7 @@ DEV void coopBuildQ(const W& w, CoopLds& S, const CoopRow& R, const CoopClasses&
   if (K.nu > 0) {
     // stage A in LDS so that a normal column can add its contact's upper-bound friction columns
 #pragma unroll
-    for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.R[i * CLD + ln] = R.acol[i];
+    for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.R[i * CLD + ln] = R.a(i);
     const double E1 = w.shfl(K.E, ln + 1), E2 = w.shfl(K.E, ln + 2);
     if (!R.fric && ln + 2 < MAXR) {
       if ((K.ubMask >> (ln + 1)) & 1u) e1 = E1;
@@ -313,7 +315,7 @@ DEV void coopBuildQ(const W& w, CoopLds& S, const CoopRow& R, const CoopClasses&
   const int c1 = (ln + 1 < MAXR) ? ln + 1 : 0, c2 = (ln + 2 < MAXR) ? ln + 2 : 0;
 #pragma unroll
   for (int i = 0; i < MAXR; i++) {
-    double q = R.acol[i];
+    double q = R.a(i);
     if (K.nu > 0) q = fma(e2, S.R[i * CLD + c2], fma(e1, S.R[i * CLD + c1], q));
     if (i == ln) q += cfm;
     a[i] = (colOn && ((K.clampMask >> i) & 1u)) ? q : 0.0;
@@ -344,7 +346,7 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
     guessMask = (uint32_t)w.ballot(in);
     if (guessMask != 0) {
 #pragma unroll
-      for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.acol[i] : 0.0;
+      for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(i) : 0.0;
       coopPinv(w, a, S, __builtin_popcount(guessMask));
       X = coopPinvApply<W, false>(w, S, in ? R.Bv : 0.0, 0);
       if (!in) X = 0.0;

@@ -20,16 +20,15 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
     R.mu = muA < muB ? muA : muB;
     R.Bv = saved[(int64_t)(lay.b + ln) * B + b];
   }
+  R.on = on;
+  R.Acol = dn + lay.A + (on ? ln : 0);
   double cn = 0.0;
 #pragma unroll
-  for (int i = 0; i < MAXR; i++) {
-    R.acol[i] = (on && i < m) ? dn[lay.A + i * MAX_ROWS + ln] : 0.0;
-    cn = fma(R.acol[i], R.acol[i], cn);
-  }
+  for (int i = 0; i < MAXR; i++) { const double x = R.a(i); cn = fma(x, x, cn); }
   R.colNorm = cn;
 }
 
-__global__ __launch_bounds__(64) void k_contact_solve_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+__global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
                                                            double* __restrict__ next, uint32_t* __restrict__ status,

@@ -24,8 +24,10 @@ int shim_coop_pinv(const double* Q, int cTrue, double* Pout) {
 static void fillRow(CoopRow& R, int ln, int m, const double* A, const double* b, const double* mu) {
   R.m = m; R.fric = (ln % 3) != 0; R.fp = ln < MAXR ? ln - (ln % 3) : 0;
   R.mu = ln < m ? mu[ln / 3] : 0.0; R.Bv = ln < m ? b[ln] : 0.0;
+  R.on = ln < m;
+  R.Acol = A + (ln < m ? ln : 0);
   double cn = 0;
-  for (int i = 0; i < MAXR; i++) { R.acol[i] = (ln < m && i < m) ? A[i * MAXR + ln] : 0.0; cn += R.acol[i] * R.acol[i]; }
+  for (int i = 0; i < MAXR; i++) cn += R.a(i) * R.a(i);
   R.colNorm = cn;
 }
 
