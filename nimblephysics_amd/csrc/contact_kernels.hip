@@ -41,8 +41,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
                                                        uint32_t* __restrict__ status, double* __restrict__ ws) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c;
-  c.ws = ws; c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n;
+  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, treeOf(saved, lay, B));
   int nC = 0;
   bool overflow = false, edge = false;
   for (int pi = 0; pi < cm->nPairs; pi++) {
@@ -89,14 +88,14 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
   (void)edge;
   if (status) status[b] = st;
   if (!__any(nC > 0)) return;
-  // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_A,
-  // for the relative velocities b = -J^T V of the contact-row kernel
+  // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_FB (scratch;
+  // WS_A keeps the accelerations for the backward pass), for the relative velocities b = -J^T V of the contact-row kernel
   const double* vpre = saved + (int64_t)lay.vpre * B;
   for (int i = 0; i < c.nb; i++) {
     const DevBody& bd = bodies[i];
     V6 V = jointTwist(bd, vpre, B, b);
-    if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_A));
-    stV6(c, i, WS_A, V);
+    if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_FB));
+    stV6(c, i, WS_FB, V);
   }
 }
 
@@ -109,8 +108,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
                                                      double* __restrict__ lws) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c;
-  c.bodies = bodies; c.ws = ws; c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
+  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, treeOf(saved, lay, B));
   LaneMem L;
   L.base = lws; L.B = B; L.b = b;
   const int n = mdl.n;
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
   const double* vpre = saved + (int64_t)lay.vpre * B;
   double* dn = denseOf(saved, lay, B, b);
 
-  // body twists at the pre-contact velocity: WS_A, left by k_contact_detect
+  // body twists at the pre-contact velocity: WS_FB, left by k_contact_detect
   (void)vpre;
   // per-row body-frame wrenches (mSpatialNormalA/B) and b = -J^T V
   int bodyA[MAX_CONTACTS], bodyB[MAX_CONTACTS];
@@ -140,8 +138,8 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
       V6 F = mk6(cross(p, d[k]), d[k]);  // world wrench of a unit impulse along d at p
       double rel = 0;
       V6 ja = zero6(), jb = zero6();
-      if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_A)); }
-      if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_A)); }
+      if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_FB)); }
+      if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_FB)); }
       double a6[6];
       toArr(ja, a6);
       for (int e = 0; e < 6; e++) L.at(LW_JA + row * 6 + e) = a6[e];

@@ -229,8 +229,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;
   if (m == 0) return;
-  Ctx c;
-  c.bodies = bodies; c.ws = const_cast<double*>(ws); c.B = B; c.b = b; c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
+  Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, treeOf(saved, lay, B));
   double* dn = denseOf(saved, lay, B, b);
   const bool on = ln < m;
   const int row = on ? ln : 0;
@@ -249,8 +248,8 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p
   V6 ja = zero6(), jb = zero6();
   double rel = 0;
-  if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_A)); }
-  if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_A)); }
+  if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_FB)); }
+  if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_FB)); }
   const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
   if (on) {
     double a6[6];
@@ -358,8 +357,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   double* PA = PF + nb * 24;
   double* X2 = PA + nb * 24;
   double* XL = X2 + nb * 24;
-  Ctx c;
-  c.bodies = bodies; c.ws = const_cast<double*>(ws); c.B = B; c.b = b; c.nb = nb; c.n = n; c.dt = mdl.dt;
+  Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, treeOf(saved, lay, B));
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
   const double* q = saved;
   auto ld6 = [](const double* base, int stride) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e * stride]; return fromArr(a); };

@@ -37,13 +37,21 @@ struct Ctx {
   const DevBody* __restrict__ bodies;
   const DevDof* __restrict__ dofs;
   double* __restrict__ ws;
+  double* __restrict__ tree;   // slots < WS_KEEP: the saved record's tree block (stride WS_KEEP) or the workspace itself (stride WS_PER_BODY)
+  int treeStride;
   int64_t B, b;
   int nb, n;
   double dt;
   V3 g;
 };
 
-DEV double& wsAt(const Ctx& c, int body, int slot) { return c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b]; }
+DEV double& wsAt(const Ctx& c, int body, int slot) {
+  return slot < WS_KEEP ? c.tree[((int64_t)body * c.treeStride + slot) * c.B + c.b] : c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b];
+}
+// the tree block of the saved record (nullptr when the record carries none)
+DEV double* treeOf(double* saved, const SavedLayout& lay, int64_t B) {
+  return (saved && lay.treeRows > 0) ? saved + ((int64_t)lay.total + lay.dense) * B : nullptr;
+}
 DEV V6 ldV6(const Ctx& c, int body, int slot) {
   double a[6];
 #pragma unroll
@@ -249,9 +257,10 @@ DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __r
   }
 }
 
-DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, double* ws, int64_t B, int64_t b) {
+DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, double* ws, int64_t B, int64_t b, double* tree = nullptr) {
   Ctx c;
   c.bodies = bodies; c.dofs = dofs; c.ws = ws; c.B = B; c.b = b;
+  c.tree = tree ? tree : ws; c.treeStride = tree ? WS_KEEP : WS_PER_BODY;
   c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
   c.g = mk3(mdl.gravity[0], mdl.gravity[1], mdl.gravity[2]);
   return c;
@@ -264,10 +273,10 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
                                                      const DevDof* __restrict__ dofs, int64_t B,
                                                      const double* __restrict__ state, const double* __restrict__ action,
                                                      double* __restrict__ next, double* __restrict__ saved,
-                                                     uint32_t* __restrict__ status, double* __restrict__ ws, int vpreRow) {
+                                                     uint32_t* __restrict__ status, double* __restrict__ ws, SavedLayout lay) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(saved, lay, B));
   const int n = mdl.n;
   const double* q = state;
   const double* v = state + (int64_t)n * B;
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
       nq[(int64_t)o * B + b] = q[(int64_t)o * B + b] + c.dt * v[(int64_t)o * B + b];
     }
   }
+  const int vpreRow = lay.vpre;
   if (saved) {  // what BackpropSnapshot captures: q_t, v_t, tau_t (BackpropSnapshot.cpp:33-118)
     for (int d = 0; d < n; d++) {
       saved[(int64_t)d * B + b] = q[(int64_t)d * B + b];
@@ -468,12 +478,13 @@ DEV void reverseSweep(const Ctx& c, const double* __restrict__ q, const double* 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBody* __restrict__ bodies,
                                                       const DevDof* __restrict__ dofs, int64_t B,
-                                                      const double* __restrict__ saved, const double* __restrict__ gnext,
+                                                      const double* __restrict__ saved, SavedLayout lay,
+                                                      const double* __restrict__ gnext,
                                                       double* __restrict__ gstate, double* __restrict__ gaction,
                                                       double* __restrict__ ws) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b);
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(const_cast<double*>(saved), lay, B));
   const int n = mdl.n;
   const double* q = saved;
   const double* v = saved + (int64_t)n * B;
@@ -482,7 +493,8 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
   const double* gvn = gnext + (int64_t)n * B;
   auto tauAt = [&](int d) -> double { return tau[(int64_t)d * B + b]; };
   auto emit = [&](int, double) {};
-  abaSweeps<true>(c, q, v, tauAt, emit);
+  if (lay.treeRows > 0) { for (int i = 0; i < c.nb; i++) { zeroN(c, i, WS_BIMP, 6); zeroN(c, i, WS_FACC, 18); } }   // forward state comes from the record
+  else abaSweeps<true>(c, q, v, tauAt, emit);
   auto gvAt = [&](int d) -> double { return gvn[(int64_t)d * B + b]; };
   minvSweeps(c, [&](int d) -> double { return c.dt * gvn[(int64_t)d * B + b]; });
   reverseSweep(c, q, v, tau, gqn, gvAt, [](int) -> double { return 0.0; }, gstate, gstate + (int64_t)n * B, gaction);

@@ -214,6 +214,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       L.A = 0; L.massed = L.A + MAX_ROWS * MAX_ROWS; L.aall = L.massed + n * MAX_ROWS; L.pinv = L.aall + n * MAX_ROWS;
       L.dense = L.pinv + MAX_ROWS * MAX_ROWS;
     }
+    bool saveTree = true;   // trade 8 * WS_KEEP * n_bodies bytes per world and step for the ABA re-run of the backward pass
+    if (const char* e0 = getenv("NBL_SAVE_TREE")) saveTree = atoi(e0) != 0;
+    L.treeRows = saveTree ? d->n_bodies * WS_KEEP : 0;
   }
   m->device = device;
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
@@ -265,7 +268,7 @@ size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
 }
 size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
-  return ((size_t)m->lay.total + (size_t)m->lay.dense) * sizeof(double) * (size_t)B;
+  return ((size_t)m->lay.total + (size_t)m->lay.dense + (size_t)m->lay.treeRows) * sizeof(double) * (size_t)B;
 }
 
 
@@ -304,7 +307,7 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
   TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
-                                  (double*)saved, status, (double*)workspace, m->hasContact ? m->lay.vpre : -1));
+                                  (double*)saved, status, (double*)workspace, m->lay));
   if (m->hasContact) {
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
     TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
@@ -344,7 +347,7 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
   if (!m->hasContact) {
-    TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+    TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
                                     grad_next_state, grad_state, grad_action, (double*)workspace));
   } else {
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
@@ -366,7 +369,7 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
     } else
       TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
                                       m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
-    TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved,
+    TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
                                           grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws));
   }
   HIP_TRY(hipGetLastError());
