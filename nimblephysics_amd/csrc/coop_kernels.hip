@@ -334,12 +334,19 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
 }
 
 // Tree part of the contact adjoint, one world per wavefront (k_bwd_contact_b one world per lane; the header of
-// contact_backward.hip derives the terms).  Three phases with different lane roles, all state in LDS:
+// contact_backward.hip derives the terms).  Phases with different lane roles, all state in LDS:
 //   1  lane = joint-rate field f (9: lambda1, v_pre, p1..3, s1..3, w): root->leaf twists, body frame FB and world frame FW
-//   2  lane = mass-matrix pair k (4): leaf->root reverse Newton-Euler (v = 0) of -d(adj^T M acc)/dq, per-lane partial xi
-//   3  lane = LCP row (24): contact-geometry chain walks from the two contact bodies, per-lane accumulators
-//   4  lane = body: sums the partials, projects on the joint (applyHt) and writes the position cotangent LB_QX
-// lds doubles: FB[nb][9][6] FW[nb][8][6] PF[nb][6][4] PA[nb][6][4] X2[nb][6][4] XL[nb][6][24]
+//   2  lane = (mass-matrix pair k, half t) (8): leaf->root reverse Newton-Euler (v = 0) of -d(adj^T M acc)/dq; the
+//      transmitted-force half and the acceleration-adjoint half of a pair are independent chains
+//   3  lane = LCP row (24).  The chain walk of k_bwd_contact_b adds, for every body l between a contact body and the root,
+//          add_l = term - sgn dad(T_end - tw(parent l), F_w),   tw(body) = sum_e cf_e FW[body][e]
+//      which is bilinear: summed over rows,  xi[l] = C[l] + sum_e dad(FW[parent l][e], Phi_e[l])  with
+//          C   = sum over the rows whose contact body lies in the subtree of l of (term - sgn dad(T_end, F_w))
+//          Phi_e = the same subtree sum of sgn cf_e F_w.
+//      So each row only adds 54 numbers to its two contact bodies (deterministic reduction over the three rows of a
+//      contact), one leaf->root pass forms the subtree sums, and no per-row chain walk or per-row accumulator is needed.
+//   4  lane = body: assembles xi, projects on the joint (applyHt) and writes the position cotangent LB_QX
+// lds doubles: FW[nb][8][6] X2[nb][6][8] D[nb][54] | FB[nb][9][6] P8[nb][6][8] (phase 1-2)  aliased by  tmp[54][24] (phase 3)
 __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
@@ -351,12 +358,12 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   if (b >= B) return;
   if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;
   const int nb = mdl.nb, n = mdl.n;
-  double* FB = ldsB;
-  double* FW = FB + nb * 54;
-  double* PF = FW + nb * 48;
-  double* PA = PF + nb * 24;
-  double* X2 = PA + nb * 24;
-  double* XL = X2 + nb * 24;
+  double* FW = ldsB;
+  double* X2 = FW + nb * 48;
+  double* D = X2 + nb * 48;
+  double* FB = D + nb * 54;
+  double* P8 = FB + nb * 54;
+  double* tmp = FB;                       // 54 x 24 doubles, needs nb * 102 >= 1296 or the host pads (bwdBLdsDoubles)
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, treeOf(saved, lay, B));
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
   const double* q = saved;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   // ---- phase 1 ----
   if (ln < 9) {
     const int f = ln;
-    const double* src; int64_t stride = B;
+    const double* src; const int64_t stride = B;
     if (f == 0) src = lws + (int64_t)LB_LAM1 * B + b;
     else if (f == 1) src = saved + (int64_t)lay.vpre * B + b;
     else if (f <= 4) src = lws + (int64_t)(LB_P + (f - 2) * MAX_DOF_CONTACT) * B + b;
@@ -384,64 +391,90 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
       if (f < 8) st6(FW + (i * 8 + f) * 6, 1, AdT(ldTAt(c, i, WS_TW), tw));
     }
   }
-  for (int idx = ln; idx < nb * 24; idx += 64) { PF[idx] = 0.0; PA[idx] = 0.0; }
-  for (int idx = ln; idx < nb * 6 * MAX_ROWS; idx += 64) XL[idx] = 0.0;
+  for (int idx = ln; idx < nb * 48; idx += 64) P8[idx] = 0.0;
+  for (int idx = ln; idx < nb * 54; idx += 64) D[idx] = 0.0;
   w.sync();
   // ---- phase 2 ----
-  if (ln < 4) {
-    const int k = ln;
+  if (ln < 8) {
+    const int k = ln >> 1, t = ln & 1;
     const int ADJ = k == 0 ? 0 : 4 + k, ACC = k == 0 ? 8 : 1 + k;   // (lambda1, w), (s_k, p_k)
+    const int fx = t == 0 ? ACC : ADJ, fo = t == 0 ? ADJ : ACC;     // t = 0: F_k = G acc + ...,  t = 1: A_k = G adj + ...
     for (int i = nb - 1; i >= 0; i--) {
       const DevBody& bd = bodies[i];
-      const S6 G = cS6(bd.G);
-      const V6 adj = ld6(FB + (i * 9 + ADJ) * 6, 1), acc = ld6(FB + (i * 9 + ACC) * 6, 1);
-      const V6 Fk = mul(G, acc) + ld6(PF + i * 24 + k, 4);
-      const V6 Ak = mul(G, adj) + ld6(PA + i * 24 + k, 4);
+      const V6 Xk = mul(cS6(bd.G), ld6(FB + (i * 9 + fx) * 6, 1)) + ld6(P8 + i * 48 + ln, 8);
       V6 xi = zero6();
       if (bd.parent >= 0) {
         const T12 T = ldT(c, i);
-        xi = dad(AdInvT(T, ld6(FB + (bd.parent * 9 + ADJ) * 6, 1)), Fk) + dad(AdInvT(T, ld6(FB + (bd.parent * 9 + ACC) * 6, 1)), Ak);
-        st6(PF + bd.parent * 24 + k, 4, ld6(PF + bd.parent * 24 + k, 4) + dAdInvT(T, Fk));
-        st6(PA + bd.parent * 24 + k, 4, ld6(PA + bd.parent * 24 + k, 4) + dAdInvT(T, Ak));
+        xi = dad(AdInvT(T, ld6(FB + (bd.parent * 9 + fo) * 6, 1)), Xk);
+        double* pp = P8 + bd.parent * 48 + ln;
+        st6(pp, 8, ld6(pp, 8) + dAdInvT(T, Xk));
       }
-      st6(X2 + i * 24 + k, 4, xi);
+      st6(X2 + i * 48 + ln, 8, xi);
     }
   }
-  // ---- phase 3 (independent of phase 2: different lanes' data) ----
+  w.sync();   // FB / P8 are dead from here: tmp takes their place
+  // ---- phase 3: per-row constants, side A then side B ----
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  const int nC = m / 3;
+  double cf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool any = false;
+  ContactRec CR;
+  CR.bA = -1; CR.bB = -1; CR.type = 0;
+  V6 Fw = zero6(), TA = zero6(), TB = zero6();
+  RowTerms RT;
+  RT.vertexTerm = RT.faceTerm = RT.edgeTermA = RT.edgeTermB = zero6();
   if (ln < m) {
     const int row = ln, ci = row / 3, k = row % 3;
-    double cf[8];
-    bool any = false;
     for (int e = 0; e < 8; e++) { cf[e] = lws[(int64_t)(LB_COEF + row * 8 + e) * B + b]; any = any || cf[e] != 0.0; }
     if (any) {
-      const ContactRec CR = loadContactRec(SV, lay, cm, ci);
+      CR = loadContactRec(SV, lay, cm, ci);
       const TangentFrame TF = tangentFrameOf(CR.nrm);
       const V3 d = k == 0 ? CR.nrm : (k == 1 ? TF.t1 : TF.t2);
-      const V6 Fw = mk6(cross(CR.p, d), d);
+      Fw = mk6(cross(CR.p, d), d);
       auto twistOf = [&](int body) -> V6 {   // world twist of `body` under the joint rates z_row
         V6 z = zero6();
         if (body < 0) return z;
         for (int e = 0; e < 8; e++) z = z + cf[e] * ld6(FW + (body * 8 + e) * 6, 1);
         return z;
       };
-      const V6 TA = twistOf(CR.bA), TB = twistOf(CR.bB);
-      const RowTerms RT = contactRowTerms(CR, TF, k, d, TA - TB);
-      const bool aIsVertex = (CR.type == CT_VERTEX_FACE);
-      for (int side = 0; side < 2; side++) {
-        const int start = side == 0 ? CR.bA : CR.bB;
-        const V6 Tend = side == 0 ? TA : TB;
-        const double sgn = side == 0 ? 1.0 : -1.0;
-        const bool vertexSide = (side == 0) == aIsVertex;
-        for (int l = start; l >= 0; l = bodies[l].parent) {
-          const V6 Zl = sgn * (Tend - twistOf(bodies[l].parent));
-          V6 add = -dad(Zl, Fw);
-          if (CR.type == CT_VERTEX_FACE || CR.type == CT_FACE_VERTEX) add = add + (vertexSide ? RT.vertexTerm : RT.faceTerm);
-          else if (CR.type == CT_EDGE_EDGE) add = add + (side == 0 ? RT.edgeTermA : RT.edgeTermB);
-          double* x = XL + l * 6 * MAX_ROWS + row;
-          st6(x, MAX_ROWS, ld6(x, MAX_ROWS) + add);
-        }
+      TA = twistOf(CR.bA); TB = twistOf(CR.bB);
+      RT = contactRowTerms(CR, TF, k, d, TA - TB);
+    }
+  }
+  const bool aIsVertex = (CR.type == CT_VERTEX_FACE);
+  for (int side = 0; side < 2; side++) {
+    if (ln < MAX_ROWS) {
+      const double sgn = side == 0 ? 1.0 : -1.0;
+      const int start = side == 0 ? CR.bA : CR.bB;
+      const bool vertexSide = (side == 0) == aIsVertex;
+      V6 C = zero6();
+      double sc = 0.0;
+      if (any && start >= 0) {
+        C = -sgn * dad(side == 0 ? TA : TB, Fw);
+        if (CR.type == CT_VERTEX_FACE || CR.type == CT_FACE_VERTEX) C = C + (vertexSide ? RT.vertexTerm : RT.faceTerm);
+        else if (CR.type == CT_EDGE_EDGE) C = C + (side == 0 ? RT.edgeTermA : RT.edgeTermB);
+        sc = sgn;
       }
+      double c6[6], f6[6];
+      toArr(C, c6); toArr(Fw, f6);
+      for (int e = 0; e < 6; e++) tmp[e * MAX_ROWS + ln] = c6[e];
+      for (int e = 0; e < 8; e++) for (int x = 0; x < 6; x++) tmp[(6 + e * 6 + x) * MAX_ROWS + ln] = sc * cf[e] * f6[x];
+    }
+    w.sync();
+    if (ln < 54) {
+      for (int ci = 0; ci < nC; ci++) {
+        const int r0 = lay.contacts + ci * CR_SIZE;
+        const int st = cm->boxes[(int)svAt(saved, r0 + (side == 0 ? CR_BOXA : CR_BOXB), B, b)].body;
+        if (st >= 0) D[st * 54 + ln] += (tmp[ln * MAX_ROWS + 3 * ci] + tmp[ln * MAX_ROWS + 3 * ci + 1]) + tmp[ln * MAX_ROWS + 3 * ci + 2];
+      }
+    }
+    w.sync();
+  }
+  // subtree sums, leaf -> root
+  if (ln < 54) {
+    for (int i = nb - 1; i >= 1; i--) {
+      const int par = bodies[i].parent;
+      if (par >= 0) D[par * 54 + ln] += D[i * 54 + ln];
     }
   }
   w.sync();
@@ -450,12 +483,13 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     const int i = ln;
     const DevBody& bd = bodies[i];
     V6 xi2 = zero6();
-    for (int k = 0; k < 4; k++) xi2 = xi2 + ld6(X2 + i * 24 + k, 4);
-    double a6[6];
-    for (int e = 0; e < 6; e++) { double sum = 0; for (int r = 0; r < MAX_ROWS; r++) sum += XL[(i * 6 + e) * MAX_ROWS + r]; a6[e] = sum; }
+    for (int k = 0; k < 8; k++) xi2 = xi2 + ld6(X2 + i * 48 + k, 8);
+    V6 xiW = ld6(D + i * 54, 1);
+    if (bd.parent >= 0)
+      for (int e = 0; e < 8; e++) xiW = xiW + dad(ld6(FW + (bd.parent * 8 + e) * 6, 1), ld6(D + i * 54 + 6 + e * 6, 1));
     double qb2[6], qb3[6];
     applyHt(bd, q, B, b, xi2, qb2);
-    applyHt(bd, q, B, b, dAdT(ldTAt(c, i, WS_TW), fromArr(a6)), qb3);
+    applyHt(bd, q, B, b, dAdT(ldTAt(c, i, WS_TW), xiW), qb3);
     for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_QX + bd.dofOff + k) * B + b] = qb3[k] - qb2[k];
   }
 }

@@ -363,7 +363,9 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
       TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
                                       B, sv, m->lay, grad_next_state, (double*)workspace, lws));
     if (m->coop) {
-      const size_t bLds = (size_t)m->nb * (54 + 48 + 24 + 24 + 24 + 6 * MAX_ROWS) * sizeof(double);
+      size_t bDoubles = (size_t)m->nb * (48 + 48 + 54 + 54 + 48);      // FW X2 D | FB P8
+      if ((size_t)m->nb * 102 < 54 * MAX_ROWS) bDoubles = (size_t)m->nb * 150 + 54 * MAX_ROWS;   // tmp[54][24] aliases FB + P8
+      const size_t bLds = bDoubles * sizeof(double);
       TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)B), dim3(64), bLds, s, m->mdl, m->dBodies, m->dContact, B,
                                              sv, m->lay, (const double*)workspace, lws));
     } else
