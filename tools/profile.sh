@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): kernel-trace stats and the two PMC passes (FETCH_SIZE / WRITE_SIZE need separate
+# passes: TCC slots) of the same bench command.  Outputs under gpurun_out/prof/<tag>_{stats,fetch,write}/.
+#   usage: tools/profile.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+ARGS=${*:---steps 8 --warmup 2 --no-cpu-baseline}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $REPO/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- python $REPO/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1
+find $OUT -name "*.csv" | head -30
+tail -1 $OUT/${TAG}_stats.log | cut -c1-300
