@@ -169,6 +169,31 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
                           size_t workspace_bytes, void* stream);
 
 /*
+ * T-step trajectory rollout on the device: the loop of SingleShot::getStates /
+ * SingleShot::backpropGradientWrt (dart/trajectory/SingleShot.cpp:539-598, 598-700) over forwardPass / backprop, without
+ * a host round trip per step.
+ *   forward:   states[0] = state0;  states[t+1] = step(states[t], actions[t])                       t = 0 .. T-1
+ *     state0   [2n][B]
+ *     actions  [T][k][B], or one [k][B] block used for every step when action_stride == 0 (else action_stride = k*B)
+ *     states   [T+1][2n][B] out
+ *     saved    T * nbl_saved_bytes(m, B) bytes (record t at byte offset t * nbl_saved_bytes), or NULL (no backward wanted)
+ *     status   [T][B] uint32 or NULL
+ *     warm_start != 0: step t starts the LCP from step t-1's solution (the reference's solver carries mX between steps,
+ *                BoxedLcpConstraintSolver.cpp:176-187); 0: LCPUtils::guessSolution every step
+ *   backward:  g_T = grad_states[T];  (g_t', grad_actions[t]) = step_backward(saved[t], g_{t+1});  g_t = g_t' + grad_states[t]
+ *     grad_states  [T+1][2n][B]  dL/dstates[t] as it enters the loss directly (zeros where the loss does not look)
+ *     grad_state0  [2n][B] out,  grad_actions [T][k][B] out
+ * workspace: nbl_rollout_workspace_bytes(m, B) bytes.
+ */
+size_t nbl_rollout_workspace_bytes(const nbl_model* m, int64_t B);
+int32_t nbl_rollout_forward(nbl_model* m, int64_t B, int32_t T, const double* state0, const double* actions,
+                            int64_t action_stride, double* states, void* saved, uint32_t* status, int32_t warm_start,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
+                             double* grad_state0, double* grad_actions, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/*
  * Layout helpers: the Python surface takes world-major tensors [B][d] like a stack of the
  * reference's 1-D state vectors; these transpose to/from the library's [d][B] layout on device.
  */

@@ -6,7 +6,7 @@ Drop-in for ONE hot path of nimblephysics: `timestep(world, state, action)`
 from .model import (BodySpec, BoxSpec, ModelDescription, atlas, box_stack, cartpole,  # noqa: F401
                     make_transform, single_pendulum)
 
-__all__ = ["ModelDescription", "BodySpec", "BoxSpec", "World", "timestep", "TimestepLayer", "single_pendulum", "cartpole",
+__all__ = ["ModelDescription", "BodySpec", "BoxSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
            "atlas", "box_stack", "make_transform"]
 
 
@@ -15,7 +15,7 @@ def __getattr__(name):
     if name in ("World",):
         from .world import World
         return World
-    if name in ("timestep", "TimestepLayer"):
+    if name in ("timestep", "TimestepLayer", "rollout", "RolloutLayer"):
         from . import timestep as _t
         return getattr(_t, name)
     raise AttributeError(name)

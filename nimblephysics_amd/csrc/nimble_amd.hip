@@ -378,6 +378,71 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   return NBL_OK;
 }
 
+// ---- T-step rollout -------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_add_inplace(double* __restrict__ dst, const double* __restrict__ src, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) dst[i] += src[i];
+}
+size_t alignUp(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
+
+size_t nbl_rollout_workspace_bytes(const nbl_model* m, int64_t B) {
+  if (!m || B <= 0) return 0;
+  // step workspace + two LCP warm-start buffers + the running state cotangent
+  return alignUp(nbl_workspace_bytes(m, B)) + 2 * alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double)) +
+         alignUp((size_t)2 * m->n * B * sizeof(double));
+}
+
+int32_t nbl_rollout_forward(nbl_model* m, int64_t B, int32_t T, const double* state0, const double* actions,
+                            int64_t action_stride, double* states, void* saved, uint32_t* status, int32_t warm_start,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !state0 || !actions || !states || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (B <= 0 || T <= 0) return fail(NBL_E_BADARG, "B and T must be positive");
+  if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
+  if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved records");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t stepWs = nbl_workspace_bytes(m, B), cacheBytes = alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
+  char* base = (char*)workspace;
+  double* cache[2] = {(double*)(base + alignUp(stepWs)), (double*)(base + alignUp(stepWs) + cacheBytes)};
+  const size_t stateElems = (size_t)2 * m->n * B, savedBytes = nbl_saved_bytes(m, B);
+  HIP_TRY(hipMemcpyAsync(states, state0, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s));
+  for (int32_t t = 0; t < T; t++) {
+    const bool warm = m->hasContact && warm_start && t > 0;
+    const int32_t rc = nbl_step_forward(m, B, states + (size_t)t * stateElems, actions + (size_t)t * action_stride,
+                                        warm ? cache[(t + 1) & 1] : nullptr, states + (size_t)(t + 1) * stateElems,
+                                        m->hasContact ? cache[t & 1] : nullptr, saved ? (char*)saved + (size_t)t * savedBytes : nullptr,
+                                        status ? status + (size_t)t * B : nullptr, workspace, stepWs, stream);
+    if (rc != NBL_OK) return rc;
+  }
+  return NBL_OK;
+}
+
+int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
+                             double* grad_state0, double* grad_actions, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!m || !saved || !grad_states || !grad_state0 || !grad_actions || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (B <= 0 || T <= 0) return fail(NBL_E_BADARG, "B and T must be positive");
+  if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t stepWs = nbl_workspace_bytes(m, B), cacheBytes = alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
+  double* g = (double*)((char*)workspace + alignUp(stepWs) + 2 * cacheBytes);   // running cotangent of states[t+1]
+  const size_t stateElems = (size_t)2 * m->n * B, savedBytes = nbl_saved_bytes(m, B), actElems = (size_t)m->k * B;
+  HIP_TRY(hipMemcpyAsync(g, grad_states + (size_t)T * stateElems, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s));
+  for (int32_t t = T - 1; t >= 0; t--) {
+    // the kernels of one backward step re-read the incoming cotangent after the first outputs are written, so the
+    // output must not alias it: every step writes into grad_state0 and the running cotangent is copied back
+    const int32_t rc = nbl_step_backward(m, B, (const char*)saved + (size_t)t * savedBytes, g, grad_state0,
+                                         grad_actions + (size_t)t * actElems, workspace, stepWs, stream);
+    if (rc != NBL_OK) return rc;
+    hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((stateElems + 255) / 256)), dim3(256), 0, s, grad_state0,
+                       grad_states + (size_t)t * stateElems, (int64_t)stateElems);
+    if (t > 0) HIP_TRY(hipMemcpyAsync(g, grad_state0, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+
 int32_t nbl_transpose_to_soa(const double* src_bd, double* dst_db, int64_t B, int32_t d, void* stream) {
   if (!src_bd || !dst_db || B <= 0 || d <= 0) return fail(NBL_E_BADARG, "bad transpose argument");
   dim3 grid((unsigned)((d + 31) / 32), (unsigned)((B + 31) / 32)), block(256);

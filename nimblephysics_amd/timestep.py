@@ -60,3 +60,37 @@ class TimestepLayer(torch.autograd.Function):
 def timestep(world: World, state: torch.Tensor, action: torch.Tensor, mass: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Forward pass on `world`, storing what the backward pass needs (reference: timestep.py:63-69)."""
     return TimestepLayer.apply(world, state, action, mass)
+
+
+class RolloutLayer(torch.autograd.Function):
+    """T differentiable timesteps of B worlds in one call (the loop of dart/trajectory/SingleShot.cpp:539-598 over
+    forwardPass, and of backpropGradientWrt over backprop, kept on the device)."""
+
+    @staticmethod
+    def forward(ctx, world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool):
+        in_device = state0.device
+        s = world._prep(state0, 2 * world.n, "setState")
+        if actions.dim() != 3 or actions.shape[0] != s.shape[0] or actions.shape[2] != world.k:
+            raise ValueError(f"rollout() wants actions [B, T, {world.k}]; got {tuple(actions.shape)}")
+        B, T, k = actions.shape
+        a = actions.detach().to(device=world.device, dtype=torch.float64)
+        a_soa = a.permute(1, 2, 0).contiguous()                       # [T][k][B]
+        states, saved, status = world.rollout_soa(world.to_soa(s), a_soa, want_saved=True, warm_start=warm_start)
+        ctx.world, ctx.saved_record, ctx.T = world, saved, T
+        ctx.in_device, ctx.action_device = in_device, actions.device
+        world._state = states[T]
+        world.rollout_status = status
+        return states.permute(2, 0, 1).contiguous().to(in_device)     # [B, T+1, 2n]
+
+    @staticmethod
+    def backward(ctx, grad_states):
+        world: World = ctx.world
+        g = grad_states.detach().to(device=world.device, dtype=torch.float64).permute(1, 2, 0).contiguous()   # [T+1][2n][B]
+        g0, ga = world.rollout_backward_soa(ctx.saved_record, g)
+        return None, world.from_soa(g0).to(ctx.in_device), ga.permute(2, 0, 1).contiguous().to(ctx.action_device), None
+
+
+def rollout(world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool = True) -> torch.Tensor:
+    """states[:, 0] = state0, states[:, t+1] = timestep(world, states[:, t], actions[:, t]).
+    state0 [B, 2n], actions [B, T, k] -> states [B, T+1, 2n]; differentiable wrt state0 and actions."""
+    return RolloutLayer.apply(world, state0, actions, warm_start)

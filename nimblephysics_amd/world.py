@@ -165,6 +165,48 @@ class World:
                                         self._stream()), "nbl_step_backward")
         return gs, ga
 
+    # ---- T-step rollout on the device ---------------------------------------
+    def _rollout_workspace(self, B: int) -> torch.Tensor:
+        need = self._L.nbl_rollout_workspace_bytes(self._h, B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def rollout_soa(self, state0: torch.Tensor, actions: torch.Tensor, T: int = None, want_saved: bool = True,
+                    warm_start: bool = True):
+        """state0 [2n][B]; actions [T][k][B], or one [k][B] block applied at every one of `T` steps
+        -> (states [T+1][2n][B], saved records, status [T][B])."""
+        if actions.dim() == 2:
+            if T is None:
+                raise ValueError("rollout_soa: a single [k][B] action block needs T")
+            stride = 0
+        else:
+            T = actions.shape[0]
+            stride = actions.shape[1] * actions.shape[2]
+        B = state0.shape[1]
+        states = torch.empty((T + 1, 2 * self.n, B), dtype=torch.float64, device=self.device)
+        saved = None
+        if want_saved:
+            saved = torch.empty(T * self._L.nbl_saved_bytes(self._h, B), dtype=torch.uint8, device=self.device)
+        status = torch.empty((T, B), dtype=torch.int32, device=self.device)
+        ws = self._rollout_workspace(B)
+        check(self._L.nbl_rollout_forward(self._h, B, T, _ptr(state0), _ptr(actions), stride, _ptr(states), _ptr(saved),
+                                          _ptr(status), 1 if warm_start else 0, _ptr(ws), ws.numel(), self._stream()),
+              "nbl_rollout_forward")
+        self.last_status = status[-1]
+        return states, saved, status
+
+    def rollout_backward_soa(self, saved: torch.Tensor, grad_states: torch.Tensor):
+        """grad_states [T+1][2n][B] -> (grad_state0 [2n][B], grad_actions [T][k][B])."""
+        T = grad_states.shape[0] - 1
+        B = grad_states.shape[2]
+        g0 = torch.empty((2 * self.n, B), dtype=torch.float64, device=self.device)
+        ga = torch.empty((T, self.k, B), dtype=torch.float64, device=self.device)
+        ws = self._rollout_workspace(B)
+        check(self._L.nbl_rollout_backward(self._h, B, T, _ptr(saved), _ptr(grad_states), _ptr(g0), _ptr(ga), _ptr(ws),
+                                           ws.numel(), self._stream()), "nbl_rollout_backward")
+        return g0, ga
+
     def step(self):
         """World::step on the stored state/action (no gradient bookkeeping kept)."""
         nxt, _, _ = self.step_soa(self._state, self._action, want_saved=False)

@@ -1,0 +1,81 @@
+"""T-step rollout on the device (SingleShot::getStates / backpropGradientWrt,
+dart/trajectory/SingleShot.cpp:539-700): states and gradients must equal the chain of single `timestep` calls through
+torch autograd (same kernels, so bit-exact forward, gradient to round-off), and the oracle's T-step backprop."""
+import numpy as np
+import pytest
+
+from util import contact_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain(world, s0, acts, warm):
+    import torch
+    from nimblephysics_amd.timestep import timestep
+    world.reset_lcp_cache()
+    st = torch.tensor(s0, device="cuda:0", requires_grad=True)
+    at = torch.tensor(acts, device="cuda:0", requires_grad=True)
+    xs = [st]
+    for t in range(acts.shape[1]):
+        if not warm:
+            world.reset_lcp_cache()
+        xs.append(timestep(world, xs[-1], at[:, t]))
+    return st, at, torch.stack(xs, 1)
+
+
+@pytest.mark.parametrize("name,contact,warm", [("atlas20", True, True), ("atlas20", True, False), ("atlas20", False, True)])
+def test_rollout_equals_chain_of_timesteps(name, contact, warm):
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    B, T = 256, 6
+    md, s0, a0 = contact_inputs(name, B, 21 if contact else 22)
+    if not contact:
+        md = na.atlas(name, ground=False)          # same pose, no colliders: free fall
+    rng = np.random.default_rng(3)
+    acts = np.repeat(a0[:, None, :], T, 1) + rng.normal(0, 0.05, (B, T, a0.shape[1]))
+    w = rng.normal(0, 1, (B, T + 1, s0.shape[1]))          # a loss that looks at every state
+    world = na.World(md, device="cuda:0")
+    st, at, xs = _chain(world, s0, acts, warm)
+    (xs * torch.tensor(w, device="cuda:0")).sum().backward()
+    world2 = na.World(md, device="cuda:0")
+    st2 = torch.tensor(s0, device="cuda:0", requires_grad=True)
+    at2 = torch.tensor(acts, device="cuda:0", requires_grad=True)
+    ys = rollout(world2, st2, at2, warm_start=warm)
+    (ys * torch.tensor(w, device="cuda:0")).sum().backward()
+    assert ys.shape == (B, T + 1, s0.shape[1])
+    assert torch.equal(ys, xs.detach())
+    for a, b in ((st2.grad, st.grad), (at2.grad, at.grad)):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-12 * max(scale, 1.0)
+    if contact:
+        assert np.all(world2.rollout_status.cpu().numpy() & 0x1)
+
+
+def test_rollout_vs_oracle_T_steps():
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    from oracle import OracleWorld
+    B, T = 64, 4
+    md, s0, a0 = contact_inputs("atlas20", B, 31)
+    acts = np.repeat(a0[:, None, :], T, 1)
+    world = na.World(md, device="cuda:0")
+    st = torch.tensor(s0, device="cuda:0", requires_grad=True)
+    at = torch.tensor(acts, device="cuda:0", requires_grad=True)
+    ys = rollout(world, st, at, warm_start=False)
+    (ys[:, -1] ** 2).sum().backward()                      # cfg5 loss: |q_T|^2 + |v_T|^2
+    ow = OracleWorld(md)
+    # oracle: chain of single steps, cotangent propagated by hand
+    xs = [s0]
+    for t in range(T):
+        xs.append(ow.step_batch(xs[-1], acts[:, t], np.zeros_like(s0), threads=4)["next"])
+    g = 2.0 * xs[-1]
+    gas = []
+    for t in range(T - 1, -1, -1):
+        r = ow.step_batch(xs[t], acts[:, t], g, threads=4)
+        g = r["grad_state"]; gas.append(r["grad_action"])
+    gas = np.stack(gas[::-1], 1)
+    assert np.abs(ys.detach().cpu().numpy()[:, -1] - xs[-1]).max() <= 1e-7 * np.abs(xs[-1]).max()
+    assert np.abs(st.grad.cpu().numpy() - g).max() <= 1e-6 * np.abs(g).max()
+    assert np.abs(at.grad.cpu().numpy() - gas).max() <= 1e-6 * max(np.abs(gas).max(), 1e-30)
