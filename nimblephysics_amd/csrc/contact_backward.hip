@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void k_bwd_recompute(DevModel mdl, const DevBod
                                                       double* __restrict__ lws) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(const_cast<double*>(saved), lay, B));
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, const_cast<double*>(saved), &lay);
   const int n = mdl.n;
   const double* tau = saved + (int64_t)2 * n * B;
   if (lay.treeRows > 0) { for (int i = 0; i < c.nb; i++) { zeroN(c, i, WS_BIMP, 6); zeroN(c, i, WS_FACC, 18); } }   // forward state comes from the record
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   LaneMem QL; QL.base = ldsq; QL.B = (int)blockDim.x; QL.b = threadIdx.x;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(saved, lay, B));
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
   const int n = mdl.n;
   const double* gvn = gnext + (int64_t)n * B;
   LaneMem L; L.base = lws; L.B = B; L.b = b;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
                                                       uint32_t* __restrict__ gradStatus) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(saved, lay, B));
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
   const int n = mdl.n;
   LaneMem L; L.base = lws; L.B = B; L.b = b;
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
@@ -390,10 +390,11 @@ __global__ __launch_bounds__(64) void k_bwd_final(DevModel mdl, const DevBody* _
                                                   const double* __restrict__ saved, SavedLayout lay,
                                                   const double* __restrict__ gnext,
                                                   double* __restrict__ gstate, double* __restrict__ gaction,
-                                                  double* __restrict__ ws, const double* __restrict__ lws) {
+                                                  double* __restrict__ ws, const double* __restrict__ lws, int treeInWs) {
+  (void)treeInWs;   // kept slots come from the workspace (k_tree_to_lanes) when lay carries no tree block
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(const_cast<double*>(saved), lay, B));
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, const_cast<double*>(saved), &lay);
   const int n = mdl.n;
   const double* q = saved;
   const double* v = saved + (int64_t)n * B;

@@ -38,10 +38,10 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
 __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBody* __restrict__ bodies,
                                                        const DevContactModel* __restrict__ cm, int64_t B,
                                                        double* __restrict__ saved, SavedLayout lay,
-                                                       uint32_t* __restrict__ status, double* __restrict__ ws) {
+                                                       uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, treeOf(saved, lay, B));
+  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);
   int nC = 0;
   bool overflow = false, edge = false;
   for (int pi = 0; pi < cm->nPairs; pi++) {
@@ -87,15 +87,15 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
   if (overflow) st |= 0x80u;
   (void)edge;
   if (status) status[b] = st;
-  if (!__any(nC > 0)) return;
-  // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_FB (scratch;
-  // WS_A keeps the accelerations for the backward pass), for the relative velocities b = -J^T V of the contact-row kernel
+  if (!doTwists || !__any(nC > 0)) return;   // k_step_forward_coop already left the twists
+  // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_VTW (the dead bias
+  // accumulator slot; WS_A keeps the accelerations for the backward pass), for the relative velocities b = -J^T V of the contact-row kernel
   const double* vpre = saved + (int64_t)lay.vpre * B;
   for (int i = 0; i < c.nb; i++) {
     const DevBody& bd = bodies[i];
     V6 V = jointTwist(bd, vpre, B, b);
-    if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_FB));
-    stV6(c, i, WS_FB, V);
+    if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_VTW));
+    stV6(c, i, WS_VTW, V);
   }
 }
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
                                                      double* __restrict__ lws) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, treeOf(saved, lay, B));
+  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);
   LaneMem L;
   L.base = lws; L.B = B; L.b = b;
   const int n = mdl.n;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
   const double* vpre = saved + (int64_t)lay.vpre * B;
   double* dn = denseOf(saved, lay, B, b);
 
-  // body twists at the pre-contact velocity: WS_FB, left by k_contact_detect
+  // body twists at the pre-contact velocity: WS_VTW, left by k_contact_detect / k_step_forward_coop
   (void)vpre;
   // per-row body-frame wrenches (mSpatialNormalA/B) and b = -J^T V
   int bodyA[MAX_CONTACTS], bodyB[MAX_CONTACTS];
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
       V6 F = mk6(cross(p, d[k]), d[k]);  // world wrench of a unit impulse along d at p
       double rel = 0;
       V6 ja = zero6(), jb = zero6();
-      if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_FB)); }
-      if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_FB)); }
+      if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_VTW)); }
+      if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_VTW)); }
       double a6[6];
       toArr(ja, a6);
       for (int e = 0; e < 6; e++) L.at(LW_JA + row * 6 + e) = a6[e];

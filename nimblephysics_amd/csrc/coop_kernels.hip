@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, cons
     if (ln < n) {
       double wd = 0.0;
 #pragma unroll
-      for (int r = 0; r < MAXR; r++) wd = fma(dn[lay.massed + ln * MAX_ROWS + r], S.vec[2][r], wd);
+      for (int r = 0; r < MAXR; r++) wd = fma(r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, S.vec[2][r], wd);   // columns >= m were never written
       svAt(saved, lay.w + ln, B, b) = wd;
       nv[(int64_t)ln * B + b] = svAt(saved, lay.vpre + ln, B, b) + wd;
     }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < MAXR; r++) {
-      const double ms = dn[lay.massed + ln * MAX_ROWS + r], aa = dn[lay.aall + ln * MAX_ROWS + r];
+      const double ms = r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, aa = r < m ? dn[lay.aall + ln * MAX_ROWS + r] : 0.0;   // columns >= m were never written
 #pragma unroll
       for (int k = 0; k < 6; k++) acc[k] = fma(bc[k * MAXR + r], ms, acc[k]);
       acc[6] = fma(bc[6 * MAXR + r], aa, acc[6]);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;
   if (m == 0) return;
-  Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, treeOf(saved, lay, B));
+  Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   double* dn = denseOf(saved, lay, B, b);
   const bool on = ln < m;
   const int row = on ? ln : 0;
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p
   V6 ja = zero6(), jb = zero6();
   double rel = 0;
-  if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_FB)); }
-  if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_FB)); }
+  if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_VTW)); }
+  if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_VTW)); }
   const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
   if (on) {
     double a6[6];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   double* FB = D + nb * 54;
   double* P8 = FB + nb * 54;
   double* tmp = FB;                       // 54 x 24 doubles, needs nb * 102 >= 1296 or the host pads (bwdBLdsDoubles)
-  Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, treeOf(saved, lay, B));
+  Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
   const double* q = saved;
   auto ld6 = [](const double* base, int stride) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e * stride]; return fromArr(a); };

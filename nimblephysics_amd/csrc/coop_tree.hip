@@ -1,0 +1,167 @@
+// coop_tree.hip — the tree sweeps with ONE WORLD PER WAVEFRONT, lane = body.
+//
+// The one-world-per-lane tree kernels (kernels.hip) are a ~2e4-instruction dependent chain per wave whose duration does
+// not depend on the batch size up to B ~ 16k: at B = 4096 they keep < 10 % of the chip busy.  Here a wavefront owns one
+// world, lane i owns body i, the per-body state of the sweeps lives in LDS (lds[slot * nbp + body], conflict-free), the
+// bodies of one tree level run together (level-synchronous) and children add to their parent one sibling rank at a time.
+// The sweep code itself is the single-source code of kernels.hip (abaSweeps / minvSweeps / reverseSweep instantiated for
+// CoopCtx).  The forward tree state is exchanged with the backward pass through the world-major tree block of the saved
+// record ([slot][nbp] per world = the LDS image, copied with coalesced 8-byte-per-lane streams).
+#include "coop_wave_dev.hpp"
+
+namespace nbl {
+
+constexpr int WS_LDS_SLOTS = WS_VBAR + 6;   // every slot the forward / backward sweeps touch
+
+constexpr int TREE_WPB = 4;   // worlds (wavefronts) per workgroup: they share one LDS copy of the model constants
+
+// LDS of a workgroup: [DevBody x nb][DevDof x n][TREE_WPB x (WS_LDS_SLOTS x nbp doubles)].  With lane = body the model
+// constants are indexed per lane, so the scalar-load path of the one-world-per-lane kernels is gone; a per-workgroup LDS
+// copy keeps them at LDS latency instead of 15 divergent global loads per field.  Returns false for a padding world.
+DEV bool coopTreeSetup(CoopCtx& c, const DevModel& mdl, const DevBody* __restrict__ bodies, const DevDof* __restrict__ dofs,
+                       double* lds, int64_t B) {
+  DevBody* lb = reinterpret_cast<DevBody*>(lds);
+  DevDof* ld = reinterpret_cast<DevDof*>(lb + mdl.nb);
+  double* st = reinterpret_cast<double*>(ld + mdl.n);
+  {
+    double* dstB = reinterpret_cast<double*>(lb);
+    const double* srcB = reinterpret_cast<const double*>(bodies);
+    const int cntB = mdl.nb * (int)(sizeof(DevBody) / sizeof(double));
+    for (int idx = threadIdx.x; idx < cntB; idx += blockDim.x) dstB[idx] = srcB[idx];
+    double* dstD = reinterpret_cast<double*>(ld);
+    const double* srcD = reinterpret_cast<const double*>(dofs);
+    const int cntD = mdl.n * (int)(sizeof(DevDof) / sizeof(double));
+    for (int idx = threadIdx.x; idx < cntD; idx += blockDim.x) dstD[idx] = srcD[idx];
+  }
+  __syncthreads();   // the only workgroup-wide barrier: from here on every wavefront runs on its own
+  const int wv = (int)(threadIdx.x >> 6);
+  const int64_t b = coopWorld(blockIdx.x, gridDim.x) * TREE_WPB + wv;
+  c.bodies = lb; c.dofs = ld; c.lds = st + (size_t)wv * WS_LDS_SLOTS * mdl.nbp; c.nbp = mdl.nbp; c.B = B; c.b = b;
+  c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
+  c.g = mk3(mdl.gravity[0], mdl.gravity[1], mdl.gravity[2]);
+  c.lane = (int)(threadIdx.x & 63u);
+  const bool on = c.lane < mdl.nb;
+  c.level = on ? lb[c.lane].level : -1;
+  c.rank = on ? lb[c.lane].rank : -1;
+  c.maxLevel = mdl.maxLevel; c.maxRank = mdl.maxRank;
+  return b < B;
+}
+DEV double* treeBlock(double* saved, const SavedLayout& lay, int64_t B, int64_t b) {
+  return saved + ((int64_t)lay.total + lay.dense) * B + b * (int64_t)lay.treeRows;
+}
+// kept slots: LDS image <-> tree block (identical [slot][nbp] layout)
+DEV void coopStoreTree(const CoopCtx& c, double* saved, const SavedLayout& lay) {
+  double* blk = treeBlock(saved, lay, c.B, c.b);
+  waveFence();
+  for (int idx = c.lane; idx < WS_KEEP * c.nbp; idx += 64) blk[idx] = c.lds[idx];
+}
+DEV void coopLoadTree(const CoopCtx& c, const double* saved, const SavedLayout& lay) {
+  const double* blk = treeBlock(const_cast<double*>(saved), lay, c.B, c.b);
+  for (int idx = c.lane; idx < WS_KEEP * c.nbp; idx += 64) c.lds[idx] = blk[idx];
+  waveFence();
+}
+
+// World::step without contact + (contact models) the body twists at the pre-contact velocity
+__global__ __launch_bounds__(64 * TREE_WPB, 2) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                          const DevDof* __restrict__ dofs, int64_t B,
+                                                          const double* __restrict__ state, const double* __restrict__ action,
+                                                          double* __restrict__ next, double* __restrict__ saved,
+                                                          uint32_t* __restrict__ status, SavedLayout lay, int withTwists) {
+  extern __shared__ __attribute__((aligned(16))) double ldsTree[];
+  CoopCtx c;
+  if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
+  const int64_t b = c.b;
+  bodies = c.bodies; dofs = c.dofs;   // the LDS copies
+  stepForwardCore(c, state, action, next, saved, lay);
+  if (withTwists) {
+    // BodyNode::getSpatialVelocity after integrateVelocities -> WS_VTW, for b = -J^T V of the contact rows.  Each lane
+    // reads back the new velocities of its own body's DOFs, which it stored itself (program order of one lane).
+    const double* nv = next + (int64_t)mdl.n * B;
+    forBodiesDown(c, [&](int i) {
+      const DevBody& bd = bodies[i];
+      V6 V = jointTwist(bd, nv, B, b);
+      if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_VTW));
+      stV6(c, i, WS_VTW, V);
+    });
+  }
+  if (saved && lay.treeRows > 0) coopStoreTree(c, saved, lay);
+  if (status && c.lane == 0) status[b] = 0u;
+}
+
+// contact adjoint activity flag and lambda1 = M^-1 g (k_bwd_recompute)
+__global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_recompute_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                           const DevDof* __restrict__ dofs, int64_t B,
+                                                           const double* __restrict__ saved, SavedLayout lay,
+                                                           const double* __restrict__ gnext, double* __restrict__ lws) {
+  extern __shared__ __attribute__((aligned(16))) double ldsTree[];
+  CoopCtx c;
+  if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
+  const int64_t b = c.b;
+  bodies = c.bodies; dofs = c.dofs;   // the LDS copies
+  const int n = mdl.n;
+  const double* gvn = gnext + (int64_t)n * B;
+  const int m = 3 * (int)saved[(int64_t)lay.nc * B + b];
+  const bool mine = c.lane < m && saved[(int64_t)(lay.cls + c.lane) * B + b] == 1.0;
+  const bool active = __ballot(mine ? 1 : 0) != 0ull;
+  if (c.lane == 0) lws[(int64_t)LB_FLAG * B + b] = active ? 1.0 : 0.0;
+  if (!active) {
+    forDofs(c, [&](int d) { lws[(int64_t)(LB_GVP + d) * B + b] = gvn[(int64_t)d * B + b]; lws[(int64_t)(LB_QX + d) * B + b] = 0.0; });
+    return;
+  }
+  coopLoadTree(c, saved, lay);
+  minvSweeps(c, [&](int d) -> double { return gvn[(int64_t)d * B + b]; });
+  forBodies(c, [&](int i) {
+    const DevBody& bd = bodies[i];
+    for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_LAM1 + bd.dofOff + k) * B + b] = wsAt(c, i, WS_UIMP + k);
+  });
+}
+
+// unconstrained backward sweep driven by g_vpre, plus the contact position cotangent (k_bwd_final); with lws == nullptr
+// the whole backward pass of a model without colliders (k_step_backward)
+__global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_final_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                       const DevDof* __restrict__ dofs, int64_t B,
+                                                       const double* __restrict__ saved, SavedLayout lay,
+                                                       const double* __restrict__ gnext, double* __restrict__ gstate,
+                                                       double* __restrict__ gaction, const double* __restrict__ lws) {
+  extern __shared__ __attribute__((aligned(16))) double ldsTree[];
+  CoopCtx c;
+  if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
+  const int64_t b = c.b;
+  bodies = c.bodies; dofs = c.dofs;   // the LDS copies
+  const int n = mdl.n;
+  const double* q = saved;
+  const double* v = saved + (int64_t)n * B;
+  const double* tau = saved + (int64_t)2 * n * B;
+  const double* gvn = gnext + (int64_t)n * B;
+  coopLoadTree(c, saved, lay);
+  auto gvp = [&](int d) -> double { return lws ? lws[(int64_t)(LB_GVP + d) * B + b] : gvn[(int64_t)d * B + b]; };
+  auto qx = [&](int d) -> double { return lws ? lws[(int64_t)(LB_QX + d) * B + b] : 0.0; };
+  minvSweeps(c, [&](int d) -> double { return c.dt * gvp(d); });
+  reverseSweep(c, q, v, tau, gnext, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
+}
+
+// World-major tree blocks [b][slot][nbp]  ->  the lane-interleaved kept slots of the workspace ws[(body * 288 + slot) * B + b],
+// for the one-world-per-lane k_bwd_final / k_step_backward (the heavy reverse sweep is VALU-issue bound with lane = body:
+// 3 of 64 lanes busy; one world per lane stays the better shape for it).  LDS-tiled transpose, both sides coalesced.
+__global__ __launch_bounds__(256) void k_tree_to_lanes(const double* __restrict__ saved, SavedLayout lay, int nb, int64_t B,
+                                                       double* __restrict__ ws) {
+  __shared__ double tile[32][33];
+  const double* blk = saved + ((int64_t)lay.total + lay.dense) * B;
+  const int64_t cols = lay.treeRows;                     // entries per world
+  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;   // c: entry, r: world
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int64_t r = r0 + k, cc = c0 + tx;
+    if (r < B && cc < cols) tile[k][tx] = blk[r * cols + cc];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int64_t cc = c0 + k, r = r0 + tx;
+    if (r < B && cc < cols) {
+      const int slot = (int)(cc / lay.treeNbp), body = (int)(cc % lay.treeNbp);
+      if (body < nb) ws[((int64_t)body * WS_PER_BODY + slot) * B + r] = tile[tx][k];
+    }
+  }
+}
+
+}  // namespace nbl

@@ -37,8 +37,8 @@ struct Ctx {
   const DevBody* __restrict__ bodies;
   const DevDof* __restrict__ dofs;
   double* __restrict__ ws;
-  double* __restrict__ tree;   // slots < WS_KEEP: the saved record's tree block (stride WS_KEEP) or the workspace itself (stride WS_PER_BODY)
-  int treeStride;
+  double* __restrict__ tree;   // slots < WS_KEEP: element (body, slot) at tree[body * tBody + slot * tSlot] (the saved record's
+  int64_t tBody, tSlot;        // tree block, lane-interleaved or world-major, or the workspace itself)
   int64_t B, b;
   int nb, n;
   double dt;
@@ -46,68 +46,101 @@ struct Ctx {
 };
 
 DEV double& wsAt(const Ctx& c, int body, int slot) {
-  return slot < WS_KEEP ? c.tree[((int64_t)body * c.treeStride + slot) * c.B + c.b] : c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b];
+  return slot < WS_KEEP ? c.tree[body * c.tBody + slot * c.tSlot] : c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b];
 }
-// the tree block of the saved record (nullptr when the record carries none)
-DEV double* treeOf(double* saved, const SavedLayout& lay, int64_t B) {
-  return (saved && lay.treeRows > 0) ? saved + ((int64_t)lay.total + lay.dense) * B : nullptr;
+
+// One world per WAVEFRONT, lane = body: the whole per-body state of the sweeps lives in LDS, lds[slot * nbp + body]
+// (conflict-free), bodies of one tree level are processed together (level-synchronous sweeps) and children add to their
+// parent one sibling rank at a time.  The sweep code below is single-source for both execution models: it is written
+// against the small vocabulary  wsAt / forBodiesDown / forBodiesUp / forBodies / forDofs / parentAdd*.
+struct CoopCtx {
+  const DevBody* __restrict__ bodies;
+  const DevDof* __restrict__ dofs;
+  double* lds;
+  int nbp;
+  int64_t B, b;
+  int nb, n;
+  double dt;
+  V3 g;
+  int lane, level, rank, maxLevel, maxRank;
+};
+DEV double& wsAt(const CoopCtx& c, int body, int slot) { return c.lds[slot * c.nbp + body]; }
+DEV void waveFence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+template <class F> DEV void forBodiesDown(const Ctx& c, F f) { for (int i = 0; i < c.nb; i++) f(i); }        // root -> leaf
+template <class F> DEV void forBodiesUp(const Ctx& c, F f) { for (int i = c.nb - 1; i >= 0; i--) f(i); }    // leaf -> root
+template <class F> DEV void forBodies(const Ctx& c, F f) { for (int i = 0; i < c.nb; i++) f(i); }            // independent
+template <class F> DEV void forDofs(const Ctx& c, F f) { for (int d = 0; d < c.n; d++) f(d); }
+template <class F> DEV void forBodiesDown(const CoopCtx& c, F f) {
+  for (int l = 0; l <= c.maxLevel; l++) { if (c.level == l) f(c.lane); waveFence(); }
 }
-DEV V6 ldV6(const Ctx& c, int body, int slot) {
+template <class F> DEV void forBodiesUp(const CoopCtx& c, F f) {
+  for (int l = c.maxLevel; l >= 0; l--) { if (c.level == l) f(c.lane); waveFence(); }
+}
+template <class F> DEV void forBodies(const CoopCtx& c, F f) { if (c.lane < c.nb) f(c.lane); waveFence(); }
+template <class F> DEV void forDofs(const CoopCtx& c, F f) { if (c.lane < c.n) f(c.lane); }
+// children of one parent that sit in the same level take turns (LDS operations of a wave execute in program order)
+template <class F> DEV void parentTurn(const Ctx&, F f) { f(); }
+template <class F> DEV void parentTurn(const CoopCtx& c, F f) {
+  for (int r = 0; r <= c.maxRank; r++) if (c.rank == r) f();
+}
+
+template <class C> DEV V6 ldV6(const C& c, int body, int slot) {
   double a[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) a[k] = wsAt(c, body, slot + k);
   return fromArr(a);
 }
-DEV void stV6(const Ctx& c, int body, int slot, V6 x) {
+template <class C> DEV void stV6(const C& c, int body, int slot, V6 x) {
   double a[6];
   toArr(x, a);
 #pragma unroll
   for (int k = 0; k < 6; k++) wsAt(c, body, slot + k) = a[k];
 }
-DEV void addV6(const Ctx& c, int body, int slot, V6 x) {
+template <class C> DEV void addV6(const C& c, int body, int slot, V6 x) {
   double a[6];
   toArr(x, a);
 #pragma unroll
   for (int k = 0; k < 6; k++) wsAt(c, body, slot + k) += a[k];
 }
-DEV void zeroN(const Ctx& c, int body, int slot, int cnt) {
+template <class C> DEV void zeroN(const C& c, int body, int slot, int cnt) {
   for (int k = 0; k < cnt; k++) wsAt(c, body, slot + k) = 0.0;
 }
-DEV T12 ldT(const Ctx& c, int body) {
+template <class C> DEV T12 ldT(const C& c, int body) {
   T12 T;
 #pragma unroll
   for (int k = 0; k < 9; k++) T.R.m[k] = wsAt(c, body, WS_T + k);
   T.p = mk3(wsAt(c, body, WS_T + 9), wsAt(c, body, WS_T + 10), wsAt(c, body, WS_T + 11));
   return T;
 }
-DEV void stT(const Ctx& c, int body, const T12& T) {
+template <class C> DEV void stT(const C& c, int body, const T12& T) {
 #pragma unroll
   for (int k = 0; k < 9; k++) wsAt(c, body, WS_T + k) = T.R.m[k];
   wsAt(c, body, WS_T + 9) = T.p.x; wsAt(c, body, WS_T + 10) = T.p.y; wsAt(c, body, WS_T + 11) = T.p.z;
 }
-DEV T12 ldTAt(const Ctx& c, int body, int slot) {
+template <class C> DEV T12 ldTAt(const C& c, int body, int slot) {
   T12 T;
 #pragma unroll
   for (int k = 0; k < 9; k++) T.R.m[k] = wsAt(c, body, slot + k);
   T.p = mk3(wsAt(c, body, slot + 9), wsAt(c, body, slot + 10), wsAt(c, body, slot + 11));
   return T;
 }
-DEV void stTAt(const Ctx& c, int body, int slot, const T12& T) {
+template <class C> DEV void stTAt(const C& c, int body, int slot, const T12& T) {
 #pragma unroll
   for (int k = 0; k < 9; k++) wsAt(c, body, slot + k) = T.R.m[k];
   wsAt(c, body, slot + 9) = T.p.x; wsAt(c, body, slot + 10) = T.p.y; wsAt(c, body, slot + 11) = T.p.z;
 }
-DEV S6 ldS6(const Ctx& c, int body, int slot) {
+template <class C> DEV S6 ldS6(const C& c, int body, int slot) {
   S6 A;
 #pragma unroll
   for (int k = 0; k < 21; k++) A.a[k] = wsAt(c, body, slot + k);
   return A;
 }
-DEV void stS6(const Ctx& c, int body, int slot, const S6& A) {
+template <class C> DEV void stS6(const C& c, int body, int slot, const S6& A) {
 #pragma unroll
   for (int k = 0; k < 21; k++) wsAt(c, body, slot + k) = A.a[k];
 }
-DEV void addS6(const Ctx& c, int body, int slot, const S6& A) {
+template <class C> DEV void addS6(const C& c, int body, int slot, const S6& A) {
 #pragma unroll
   for (int k = 0; k < 21; k++) wsAt(c, body, slot + k) += A.a[k];
 }
@@ -141,11 +174,11 @@ DEV V6 jointTwist(const DevBody& bd, const double* __restrict__ v, int64_t B, in
 // The three ABA sweeps.  q, v: [n][B];  tau fetched through tauAt(d).  Leaves T, V, AI, AIS, psi,
 // A in the workspace; joint accelerations are handed to `emit(d, qdd)`.
 // ---------------------------------------------------------------------------------------------
-template <bool BACKWARD, class TauFn, class EmitFn>
-DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
+template <bool BACKWARD, class C, class TauFn, class EmitFn>
+DEV void abaSweeps(const C& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
   const int64_t B = c.B, b = c.b;
   // ---- sweep 1: kinematics ----
-  for (int i = 0; i < c.nb; i++) {
+  forBodiesDown(c, [&](int i) {
     const DevBody& bd = c.bodies[i];
     T12 Q;
     if (bd.jtype == JT_REVOLUTE) {
@@ -169,9 +202,9 @@ DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __r
     zeroN(c, i, WS_AI, 21);
     zeroN(c, i, WS_BACC, 6);
     if (BACKWARD) zeroN(c, i, WS_BIMP, 6), zeroN(c, i, WS_FACC, 18);  // FACC, ABAR, VBAR are contiguous
-  }
+  });
   // ---- sweep 2: articulated inertias, bias forces, joint-space total force ----
-  for (int i = c.nb - 1; i >= 0; i--) {
+  forBodiesUp(c, [&](int i) {
     const DevBody& bd = c.bodies[i];
     T12 T = ldT(c, i);
     V6 V = ldV6(c, i, WS_V);
@@ -198,8 +231,9 @@ DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __r
       if (bd.parent >= 0) {
         V6 beta = Bf + AIeta + (psi * u) * AIS;           // GenericJoint.hpp:2395-2421
         rank1Sub(AI, AIS, psi);                           // PI = AI - AIS psi AIS^T  (GenericJoint.hpp:2168-2185)
-        addS6(c, bd.parent, WS_AI, congruenceToParent(T, AI));
-        addV6(c, bd.parent, WS_BACC, dAdInvT(T, beta));
+        const S6 toParentAI = congruenceToParent(T, AI);
+        const V6 toParentB = dAdInvT(T, beta);
+        parentTurn(c, [&]() { addS6(c, bd.parent, WS_AI, toParentAI); addV6(c, bd.parent, WS_BACC, toParentB); });
       }
     } else {
       // free joint as a tree root: projected inertia S^T AI S with S = Ad(T_cj); LDL^T stands in
@@ -220,10 +254,10 @@ DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __r
         wsAt(c, i, WS_U + k) = tauAt(d) - df.spring * (qd - df.rest + vd * c.dt) - df.damping * vd - pj[k];
       }
     }
-  }
+  });
   // ---- sweep 3: accelerations ----
   const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
-  for (int i = 0; i < c.nb; i++) {
+  forBodiesDown(c, [&](int i) {
     const DevBody& bd = c.bodies[i];
     T12 T = ldT(c, i);
     V6 V = ldV6(c, i, WS_V);
@@ -254,13 +288,20 @@ DEV void abaSweeps(const Ctx& c, const double* __restrict__ q, const double* __r
       A = XA + eta + AdT(cT(bd.Tcj), fromArr(r));
     }
     stV6(c, i, WS_A, A);
-  }
+  });
 }
 
-DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, double* ws, int64_t B, int64_t b, double* tree = nullptr) {
+// Where the kept slots live: the tree block of the saved record when it has one (lane-interleaved rows, or world-major
+// [slot][nbp] blocks when lay.treeNbp > 0), else the workspace.
+DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, double* ws, int64_t B, int64_t b,
+                double* saved = nullptr, const SavedLayout* lay = nullptr) {
   Ctx c;
   c.bodies = bodies; c.dofs = dofs; c.ws = ws; c.B = B; c.b = b;
-  c.tree = tree ? tree : ws; c.treeStride = tree ? WS_KEEP : WS_PER_BODY;
+  if (saved && lay && lay->treeRows > 0) {
+    double* blk = saved + ((int64_t)lay->total + lay->dense) * B;
+    if (lay->treeNbp > 0) { c.tree = blk + b * (int64_t)lay->treeRows; c.tBody = 1; c.tSlot = lay->treeNbp; }
+    else { c.tree = blk + b; c.tBody = (int64_t)WS_KEEP * B; c.tSlot = B; }
+  } else { c.tree = ws + b; c.tBody = (int64_t)WS_PER_BODY * B; c.tSlot = B; }
   c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
   c.g = mk3(mdl.gravity[0], mdl.gravity[1], mdl.gravity[2]);
   return c;
@@ -269,15 +310,16 @@ DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, 
 // ---------------------------------------------------------------------------------------------
 // Forward kernel
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody* __restrict__ bodies,
-                                                     const DevDof* __restrict__ dofs, int64_t B,
-                                                     const double* __restrict__ state, const double* __restrict__ action,
-                                                     double* __restrict__ next, double* __restrict__ saved,
-                                                     uint32_t* __restrict__ status, double* __restrict__ ws, SavedLayout lay) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(saved, lay, B));
-  const int n = mdl.n;
+// World::step without contact for the world(s) of context c: ABA, v' = v + dt qdd, q' = integrate(q, v_t, dt), and the
+// rows of the saved record BackpropSnapshot captures (q_t, v_t, tau_t, mLastPreConstraintVelocity).  Single source for
+// the one-world-per-lane and the one-world-per-wavefront kernels.
+template <class C>
+DEV void stepForwardCore(const C& c, const double* __restrict__ state, const double* __restrict__ action,
+                         double* __restrict__ next, double* __restrict__ saved, const SavedLayout& lay) {
+  const DevBody* bodies = c.bodies;
+  const DevDof* dofs = c.dofs;
+  const int64_t B = c.B, b = c.b;
+  const int n = c.n;
   const double* q = state;
   const double* v = state + (int64_t)n * B;
   auto tauAt = [&](int d) -> double {
@@ -286,11 +328,16 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
   };
   double* nq = next;
   double* nv = next + (int64_t)n * B;
-  auto emit = [&](int d, double qdd) { nv[(int64_t)d * B + b] = v[(int64_t)d * B + b] + c.dt * qdd; };  // GenericJoint.hpp:1410-1414
+  const int vpreRow = saved ? lay.vpre : -1;
+  auto emit = [&](int d, double qdd) {                  // GenericJoint.hpp:1410-1414
+    const double x = v[(int64_t)d * B + b] + c.dt * qdd;
+    nv[(int64_t)d * B + b] = x;
+    if (vpreRow >= 0) saved[(int64_t)(vpreRow + d) * B + b] = x;   // mLastPreConstraintVelocity (World.cpp:236-239)
+  };
   abaSweeps<false>(c, q, v, tauAt, emit);
 
   // positions integrate with the PRE-step velocity (World.cpp:307-333, mParallelVelocityAndPositionUpdates)
-  for (int i = 0; i < c.nb; i++) {
+  forBodies(c, [&](int i) {
     const DevBody& bd = bodies[i];
     const int o = bd.dofOff;
     if (bd.jtype == JT_FREE) {
@@ -307,16 +354,25 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
     } else {
       nq[(int64_t)o * B + b] = q[(int64_t)o * B + b] + c.dt * v[(int64_t)o * B + b];
     }
-  }
-  const int vpreRow = lay.vpre;
+  });
   if (saved) {  // what BackpropSnapshot captures: q_t, v_t, tau_t (BackpropSnapshot.cpp:33-118)
-    for (int d = 0; d < n; d++) {
+    forDofs(c, [&](int d) {
       saved[(int64_t)d * B + b] = q[(int64_t)d * B + b];
       saved[(int64_t)(n + d) * B + b] = v[(int64_t)d * B + b];
       saved[(int64_t)(2 * n + d) * B + b] = tauAt(d);
-      if (vpreRow >= 0) saved[(int64_t)(vpreRow + d) * B + b] = nv[(int64_t)d * B + b];   // mLastPreConstraintVelocity (World.cpp:236-239)
-    }
+    });
   }
+}
+
+__global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                     const DevDof* __restrict__ dofs, int64_t B,
+                                                     const double* __restrict__ state, const double* __restrict__ action,
+                                                     double* __restrict__ next, double* __restrict__ saved,
+                                                     uint32_t* __restrict__ status, double* __restrict__ ws, SavedLayout lay) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
+  stepForwardCore(c, state, action, next, saved, lay);
   if (status) status[b] = 0u;
 }
 
@@ -327,11 +383,11 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
 // impulse sweep then root->leaf sweep (same recursion as Skeleton::updateInvMassMatrix,
 // Skeleton.cpp:12573-12660).  Leaves lambda per DOF in WS_UIMP (+k) of its body and the body twists
 // W_i = X W_parent + S lambda_i in WS_W.
-template <class RhsFn>
-DEV void minvSweeps(const Ctx& c, RhsFn rhsAt) {
+template <class C, class RhsFn>
+DEV void minvSweeps(const C& c, RhsFn rhsAt) {
   const DevBody* bodies = c.bodies;
-  for (int i = 0; i < c.nb; i++) zeroN(c, i, WS_BIMP, 6);
-  for (int i = c.nb - 1; i >= 0; i--) {
+  forBodies(c, [&](int i) { zeroN(c, i, WS_BIMP, 6); });
+  forBodiesUp(c, [&](int i) {
     const DevBody& bd = bodies[i];
     V6 Bi = ldV6(c, i, WS_BIMP);
     if (bd.jtype != JT_FREE) {
@@ -340,7 +396,8 @@ DEV void minvSweeps(const Ctx& c, RhsFn rhsAt) {
       wsAt(c, i, WS_UIMP) = uimp;
       if (bd.parent >= 0) {
         V6 beta = Bi + (wsAt(c, i, WS_PSI) * uimp) * ldV6(c, i, WS_AIS);
-        addV6(c, bd.parent, WS_BIMP, dAdInvT(ldT(c, i), beta));
+        const V6 up = dAdInvT(ldT(c, i), beta);
+        parentTurn(c, [&]() { addV6(c, bd.parent, WS_BIMP, up); });
       }
     } else {
       double pj[6];
@@ -348,8 +405,8 @@ DEV void minvSweeps(const Ctx& c, RhsFn rhsAt) {
 #pragma unroll
       for (int k = 0; k < 6; k++) wsAt(c, i, WS_UIMP + k) = rhsAt(bd.dofOff + k) - pj[k];
     }
-  }
-  for (int i = 0; i < c.nb; i++) {
+  });
+  forBodiesDown(c, [&](int i) {
     const DevBody& bd = bodies[i];
     T12 T = ldT(c, i);
     V6 XW = bd.parent >= 0 ? AdInvT(T, ldV6(c, bd.parent, WS_W)) : zero6();
@@ -375,7 +432,7 @@ DEV void minvSweeps(const Ctx& c, RhsFn rhsAt) {
       W = XW + AdT(cT(bd.Tcj), fromArr(r));
     }
     stV6(c, i, WS_W, W);
-  }
+  });
 }
 
 // Position-space Jacobian transpose of joint i applied to a body-frame adjoint xi:  H_i^T xi
@@ -392,16 +449,16 @@ DEV void applyHt(const DevBody& bd, const double* __restrict__ q, int64_t B, int
 // Reverse-mode Newton-Euler sweep at (q, v, qdd) with joint adjoint lambda (WS_UIMP/WS_W from
 // minvSweeps) + the per-DOF epilogue.  gvAt(d): cotangent of the pre-contact velocity;
 // qExtraAt(d): additional position cotangent from the contact stage (0 without contact).
-template <class GvFn, class QxFn>
-DEV void reverseSweep(const Ctx& c, const double* __restrict__ q, const double* __restrict__ v,
+template <class C, class GvFn, class QxFn>
+DEV void reverseSweep(const C& c, const double* __restrict__ q, const double* __restrict__ v,
                       const double* __restrict__ tau, const double* __restrict__ gqn, GvFn gvAt, QxFn qExtraAt,
                       double* __restrict__ gq, double* __restrict__ gv, double* __restrict__ gaction) {
   const DevBody* bodies = c.bodies;
   const DevDof* dofs = c.dofs;
   const int64_t B = c.B, b = c.b;
-  for (int i = 0; i < c.nb; i++) zeroN(c, i, WS_FACC, 18);
+  forBodies(c, [&](int i) { zeroN(c, i, WS_FACC, 18); });
   const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
-  for (int i = c.nb - 1; i >= 0; i--) {
+  forBodiesUp(c, [&](int i) {
     const DevBody& bd = bodies[i];
     T12 T = ldT(c, i);
     V6 V = ldV6(c, i, WS_V), A = ldV6(c, i, WS_A), W = ldV6(c, i, WS_W);
@@ -417,9 +474,8 @@ DEV void reverseSweep(const Ctx& c, const double* __restrict__ q, const double* 
       XVp = AdInvT(T, ldV6(c, bd.parent, WS_V));
       XAp = AdInvT(T, ldV6(c, bd.parent, WS_A));
       XWp = AdInvT(T, ldV6(c, bd.parent, WS_W));
-      addV6(c, bd.parent, WS_FACC, dAdInvT(T, F));
-      addV6(c, bd.parent, WS_ABAR, dAdInvT(T, Abar));
-      addV6(c, bd.parent, WS_VBAR, dAdInvT(T, Vbar));
+      const V6 upF = dAdInvT(T, F), upA = dAdInvT(T, Abar), upV = dAdInvT(T, Vbar);
+      parentTurn(c, [&]() { addV6(c, bd.parent, WS_FACC, upF); addV6(c, bd.parent, WS_ABAR, upA); addV6(c, bd.parent, WS_VBAR, upV); });
     }
     V6 xi = dad(XWp, F) + dad(XAp, Abar) + dad(XVp, Vbar);          // adjoint of the joint transform, body frame
     double qb[6], vb[6], pp[6], vp[6];
@@ -470,7 +526,7 @@ DEV void reverseSweep(const Ctx& c, const double* __restrict__ q, const double* 
       gv[(int64_t)d * B + b] = gvo;
       if (df.actionIndex >= 0) gaction[(int64_t)df.actionIndex * B + b] = gt;
     }
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,10 +537,10 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
                                                       const double* __restrict__ saved, SavedLayout lay,
                                                       const double* __restrict__ gnext,
                                                       double* __restrict__ gstate, double* __restrict__ gaction,
-                                                      double* __restrict__ ws) {
+                                                      double* __restrict__ ws, int treeInWs) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, treeOf(const_cast<double*>(saved), lay, B));
+  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, const_cast<double*>(saved), &lay);
   const int n = mdl.n;
   const double* q = saved;
   const double* v = saved + (int64_t)n * B;
@@ -493,7 +549,7 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
   const double* gvn = gnext + (int64_t)n * B;
   auto tauAt = [&](int d) -> double { return tau[(int64_t)d * B + b]; };
   auto emit = [&](int, double) {};
-  if (lay.treeRows > 0) { for (int i = 0; i < c.nb; i++) { zeroN(c, i, WS_BIMP, 6); zeroN(c, i, WS_FACC, 18); } }   // forward state comes from the record
+  if (lay.treeRows > 0 || treeInWs) { for (int i = 0; i < c.nb; i++) { zeroN(c, i, WS_BIMP, 6); zeroN(c, i, WS_FACC, 18); } }   // forward state comes from the record
   else abaSweeps<true>(c, q, v, tauAt, emit);
   auto gvAt = [&](int d) -> double { return gvn[(int64_t)d * B + b]; };
   minvSweeps(c, [&](int d) -> double { return c.dt * gvn[(int64_t)d * B + b]; });

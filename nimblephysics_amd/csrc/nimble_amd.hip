@@ -17,6 +17,7 @@
 #include "contact_kernels.hip"
 #include "contact_backward.hip"
 #include "coop_kernels.hip"
+#include "coop_tree.hip"
 
 using namespace nbl;
 
@@ -32,10 +33,11 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
-                                           "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop"};
+                                           "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop", "k_step_forward_coop", "k_bwd_recompute_coop",
+                                           "k_bwd_final_coop", "k_tree_to_lanes"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -52,6 +54,8 @@ struct nbl_model {
   DevContactModel* dContact = nullptr;
   SavedLayout lay;
   bool timing = false;
+  bool coopFinal = false;            // NBL_COOP_FINAL=1: the reverse sweep too (slower: 3 of 64 lanes busy, VALU-issue bound)
+  bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
   bool coop = true;                  // dense contact kernels: one world per wavefront (NBL_COOP=0: one world per lane)
   int treeLanes = 0, lcpLanes = 0;   // worlds per workgroup (0 = pick from B); see nbl_set_launch_lanes
   std::vector<TimedLaunch> pending;
@@ -95,6 +99,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, free)");
     if (b.jtype == NBL_JOINT_FREE && b.parent != -1)
       return fail(NBL_E_UNSUPPORTED, "free joints are supported as tree roots only");
+    b.level = b.parent < 0 ? 0 : hb[b.parent].level + 1;
+    b.rank = 0;
+    for (int j = 0; j < i; j++) if (hb[j].parent == b.parent) b.rank++;
     b.ndof = (b.jtype == NBL_JOINT_FREE) ? 6 : 1;
     b.dofOff = d->dof_offset[i];
     if (b.dofOff != off) return fail(NBL_E_BADARG, "dof_offset must be the running sum of joint DOFs");
@@ -216,14 +223,27 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     }
     bool saveTree = true;   // trade 8 * WS_KEEP * n_bodies bytes per world and step for the ABA re-run of the backward pass
     if (const char* e0 = getenv("NBL_SAVE_TREE")) saveTree = atoi(e0) != 0;
-    L.treeRows = saveTree ? d->n_bodies * WS_KEEP : 0;
+    bool coop = true, coopTree = true;
+    if (const char* e3 = getenv("NBL_COOP")) coop = atoi(e3) != 0;
+    if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
+    m->coop = coop;
+    if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
+    // measured (MI355X, B = 4096): with colliders the world-major tree block pays off for the wavefront-per-world consumers
+    // (3.93 vs 3.77 M/s); without colliders the one-world-per-lane pair is faster (11.0 vs 10.5 M/s)
+    m->coopTree = coop && coopTree && saveTree && hasContact && d->n_bodies <= 64 && d->n_dofs <= 64;
+    if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
+    const int nbp = (d->n_bodies + 3) & ~3;
+    L.treeNbp = m->coopTree ? nbp : 0;
+    L.treeRows = !saveTree ? 0 : (m->coopTree ? WS_KEEP * nbp : d->n_bodies * WS_KEEP);
+    m->mdl.nbp = nbp;
   }
   m->device = device;
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
   if (const char* e2 = getenv("NBL_LCP_LANES")) m->lcpLanes = atoi(e2);
-  if (const char* e3 = getenv("NBL_COOP")) m->coop = atoi(e3) != 0;
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
-  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0;
+  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0; m->mdl.pad2 = 0;
+  m->mdl.maxLevel = 0; m->mdl.maxRank = 0;
+  for (const DevBody& hbI : hb) { if (hbI.level > m->mdl.maxLevel) m->mdl.maxLevel = hbI.level; if (hbI.parent >= 0 && hbI.rank > m->mdl.maxRank) m->mdl.maxRank = hbI.rank; }
   if (const char* e4 = getenv("NBL_DEBUG_NOPINV")) m->mdl.pad = atoi(e4);
   for (int k = 0; k < 3; k++) m->mdl.gravity[k] = d->gravity[k];
   m->mdl.dt = d->dt;
@@ -239,6 +259,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_step_forward_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_recompute_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_final_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     std::string msg = std::string("model upload failed: ") + hipGetErrorString(e);
     nbl_model_destroy(m);
@@ -306,12 +329,18 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
   hipStream_t s = (hipStream_t)stream;
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
-  TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
-                                  (double*)saved, status, (double*)workspace, m->lay));
+  const size_t treeLds = (size_t)m->nb * sizeof(DevBody) + (size_t)m->n * sizeof(DevDof) + (size_t)TREE_WPB * WS_LDS_SLOTS * m->mdl.nbp * sizeof(double);
+  const dim3 treeGrid((unsigned)((B + TREE_WPB - 1) / TREE_WPB)), treeBlock(64 * TREE_WPB);
+  if (m->coopTree && (saved || !m->hasContact))
+    TIMED(K_FWD_COOP, hipLaunchKernelGGL(k_step_forward_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies, m->dDofs, B,
+                                         state, action, next_state, (double*)saved, status, m->lay, m->hasContact ? 1 : 0));
+  else
+    TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
+                                    (double*)saved, status, (double*)workspace, m->lay));
   if (m->hasContact) {
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
     TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
-                                       status, (double*)workspace));
+                                       status, (double*)workspace, m->coopTree ? 0 : 1));
     if (m->coop) {
       const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 2 * 6 * MAX_ROWS) * sizeof(double);
       TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)B), dim3(64), rowsLds, s, m->mdl, m->dBodies, m->dContact, B,
@@ -346,14 +375,31 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   hipStream_t s = (hipStream_t)stream;
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
-  if (!m->hasContact) {
+  const size_t treeLds = (size_t)m->nb * sizeof(DevBody) + (size_t)m->n * sizeof(DevDof) + (size_t)TREE_WPB * WS_LDS_SLOTS * m->mdl.nbp * sizeof(double);
+  const dim3 treeGrid((unsigned)((B + TREE_WPB - 1) / TREE_WPB)), treeBlock(64 * TREE_WPB);
+  const dim3 t2lGrid((unsigned)((m->lay.treeRows + 31) / 32), (unsigned)((B + 31) / 32));
+  SavedLayout layLanes = m->lay;   // for the one-world-per-lane sweep fed by k_tree_to_lanes: kept slots in the workspace
+  layLanes.treeRows = 0; layLanes.treeNbp = 0;
+  if (!m->hasContact && m->coopTree && !m->coopFinal) {
+    TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, (double*)workspace));
+    TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
+                                    grad_next_state, grad_state, grad_action, (double*)workspace, 1));
+  } else if (!m->hasContact && m->coopTree) {
+    TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies, m->dDofs, B,
+                                               (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
+                                               (const double*)nullptr));
+  } else if (!m->hasContact) {
     TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
-                                    grad_next_state, grad_state, grad_action, (double*)workspace));
+                                    grad_next_state, grad_state, grad_action, (double*)workspace, 0));
   } else {
     double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
     double* sv = (double*)const_cast<void*>(saved);
-    TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B,
-                                          (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
+    if (m->coopTree)
+      TIMED(K_RECOMPUTE_COOP, hipLaunchKernelGGL(k_bwd_recompute_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies,
+                                                 m->dDofs, B, (const double*)saved, m->lay, grad_next_state, lws));
+    else
+      TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B,
+                                            (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
     dim3 lgrid((unsigned)((B + ll - 1) / ll)), lblock(ll);
     const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
     if (m->coop)
@@ -371,8 +417,17 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
     } else
       TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
                                       m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
-    TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
-                                          grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws));
+    if (m->coopTree && !m->coopFinal) {
+      TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, (double*)workspace));
+      TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
+                                            grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 1));
+    } else if (m->coopTree)
+      TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies, m->dDofs,
+                                                 B, (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
+                                                 (const double*)lws));
+    else
+      TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
+                                            grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 0));
   }
   HIP_TRY(hipGetLastError());
   return NBL_OK;
@@ -487,8 +542,10 @@ int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, dou
     HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
     m->kMs[t.kernel] += ms;
     m->kCount[t.kernel]++;
-    if (t.kernel >= K_BWD) { m->bwdMs += ms; if (t.kernel == K_BWD || t.kernel == K_BWD_FINAL) m->bwdCount++; }
-    else { m->fwdMs += ms; if (t.kernel == K_FWD) m->fwdCount++; }
+    const bool isBwd = t.kernel == K_BWD || t.kernel == K_RECOMPUTE || t.kernel == K_BWD_A || t.kernel == K_BWD_B || t.kernel == K_BWD_FINAL ||
+                       t.kernel == K_BWD_A_COOP || t.kernel == K_BWD_B_COOP || t.kernel == K_RECOMPUTE_COOP || t.kernel == K_BWD_FINAL_COOP || t.kernel == K_TREE_TO_LANES;
+    if (isBwd) { m->bwdMs += ms; if (t.kernel == K_BWD || t.kernel == K_BWD_FINAL || t.kernel == K_BWD_FINAL_COOP) m->bwdCount++; }
+    else { m->fwdMs += ms; if (t.kernel == K_FWD || t.kernel == K_FWD_COOP) m->fwdCount++; }
     hipEventDestroy(t.start);
     hipEventDestroy(t.stop);
   }

@@ -171,3 +171,30 @@ def test_cfg4_box_stack_8192_worlds():
     agree = errs["next"] < TOL
     assert same.mean() > 0.97 and agree.mean() > 0.97, (same.mean(), agree.mean())
     assert errs["grad_state"][agree & same].max() < 1e-5
+
+
+def test_results_do_not_depend_on_uninitialised_memory():
+    """The saved record, the workspace and the LDS are never cleared by the library.  Poison the allocator's free blocks
+    with NaN between runs: outputs must stay finite and bit-identical (worlds with fewer than 8 contacts leave columns of
+    the dense block unwritten; a 0 * garbage product there once produced NaNs)."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from util import box_stack_inputs, contact_inputs
+    cases = [contact_inputs("atlas20", 1024, 13, joint_noise=0.02, vel_noise=0.01, action_noise=0.0), box_stack_inputs(1024, 16, overhang=True)]
+    ref = {}
+    for it in range(4):
+        junk = [torch.full(((it + 2) * 3000017,), float("nan"), device="cuda:0", dtype=torch.float64) for _ in range(3)]
+        del junk
+        for ci, (md, s, a) in enumerate(cases):
+            g = np.random.default_rng(5).normal(0, 1, s.shape)
+            world = na.World(md, device="cuda:0")
+            st = torch.tensor(s, device="cuda:0", requires_grad=True)
+            at = torch.tensor(a, device="cuda:0", requires_grad=True)
+            out = timestep(world, st, at)
+            out.backward(torch.tensor(g, device="cuda:0"))
+            res = (out.detach().cpu().numpy(), st.grad.cpu().numpy(), at.grad.cpu().numpy())
+            assert all(np.isfinite(x).all() for x in res)
+            if ci in ref:
+                assert all(np.array_equal(x, y) for x, y in zip(res, ref[ci]))
+            ref[ci] = res
