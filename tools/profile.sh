@@ -12,5 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $REPO/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- python $REPO/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1
+# VALU issue / lane utilisation / occupancy (SQ block: own passes)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_valu -- python $REPO/bench.py $ARGS > $OUT/${TAG}_valu.log 2>&1
+rocprofv3 --pmc VALUUtilization VALUBusy MeanOccupancyPerCU --kernel-trace --output-format csv -d $OUT/${TAG}_util -- python $REPO/bench.py $ARGS > $OUT/${TAG}_util.log 2>&1
 find $OUT -name "*.csv" | head -30
 tail -1 $OUT/${TAG}_stats.log | cut -c1-300
