@@ -153,6 +153,7 @@ class World:
         if cache_out is not None:
             self.lcp_cache = cache_out
         self.last_status = status
+        self._last_saved = saved
         return nxt, saved, status
 
     def backward_soa(self, saved: torch.Tensor, grad_next: torch.Tensor):
@@ -164,6 +165,37 @@ class World:
         check(self._L.nbl_step_backward(self._h, B, _ptr(saved), _ptr(grad_next), _ptr(gs), _ptr(ga), _ptr(ws), ws.numel(),
                                         self._stream()), "nbl_step_backward")
         return gs, ga
+
+    # ---- dense Jacobians of the last step ------------------------------------
+    def step_jacobians_soa(self, saved: torch.Tensor, B: int):
+        """(d next_state / d state [2n][2n][B], d next_state / d action [2n][k][B]) of the step that produced `saved`:
+        row i is the vector-Jacobian product with the unit cotangent e_i (2n backward passes; the path itself never
+        forms a Jacobian)."""
+        n2 = 2 * self.n
+        js = torch.empty((n2, n2, B), dtype=torch.float64, device=self.device)
+        ja = torch.empty((n2, self.k, B), dtype=torch.float64, device=self.device)
+        g = torch.zeros((n2, B), dtype=torch.float64, device=self.device)
+        for i in range(n2):
+            g[i] = 1.0
+            js[i], ja[i] = self.backward_soa(saved, g)
+            g[i] = 0.0
+        return js, ja
+
+    def getStateJacobian(self) -> torch.Tensor:
+        """World::getStateJacobian (World.cpp:2210-2226) of the last step: [B, 2n, 2n], out[b, i, j] = d next[i] / d state[j]."""
+        if getattr(self, "_last_saved", None) is None:
+            raise NimbleAmdError("getStateJacobian(): no step with a saved record has been taken")
+        B = self.last_status.shape[0]
+        self._last_jac = self.step_jacobians_soa(self._last_saved, B)
+        return self._last_jac[0].permute(2, 0, 1).contiguous()
+
+    def getActionJacobian(self) -> torch.Tensor:
+        """World::getActionJacobian (World.cpp:2229-2243) of the last step: [B, 2n, k]."""
+        if getattr(self, "_last_saved", None) is None:
+            raise NimbleAmdError("getActionJacobian(): no step with a saved record has been taken")
+        B = self.last_status.shape[0]
+        jac = self.step_jacobians_soa(self._last_saved, B)
+        return jac[1].permute(2, 0, 1).contiguous()
 
     # ---- T-step rollout on the device (SURVEY.md 8(f) row 1) ---------------------------------------
     def _rollout_workspace(self, B: int) -> torch.Tensor:
