@@ -205,6 +205,8 @@ int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, 
  * (power of two <= 16); 0 = default (16 below 65536 worlds, else 64 / 16).  Results do not depend
  * on it (one world per lane either way); environment NBL_TREE_LANES / NBL_LCP_LANES set the initial value. */
 int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes);
+/* enabled = 0: off (and reset); 1: HIP events around every kernel launch; N > 1: around the launches of every N-th forward /
+ * backward call only (sampling keeps the perturbation of a timed region below 1 %). */
 int32_t nbl_set_timing(nbl_model* m, int32_t enabled);
 int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, double* bwd_ms_sum,
                        int64_t* bwd_count);

@@ -53,7 +53,10 @@ struct nbl_model {
   bool hasContact = false;
   DevContactModel* dContact = nullptr;
   SavedLayout lay;
-  bool timing = false;
+  bool timing = false;      // kernel timing requested
+  bool timingNow = false;   // ... and this call is one of the sampled ones
+  int timingPeriod = 1;     // every timingPeriod-th forward / backward call carries HIP events
+  int64_t fwdCalls = 0, bwdCalls = 0;
   bool coopFinal = false;            // NBL_COOP_FINAL=1: the reverse sweep too (slower: 3 of 64 lanes busy, VALU-issue bound)
   bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
   bool coop = true;                  // dense contact kernels: one world per wavefront (NBL_COOP=0: one world per lane)
@@ -305,7 +308,7 @@ static int pickLanes(int64_t B, int requested, int maxLanes) {
   return l;
 }
 static void beginTiming(nbl_model* m, hipStream_t s, int kernel) {
-  if (!m->timing) return;
+  if (!m->timingNow) return;
   TimedLaunch t;
   hipEventCreate(&t.start);
   hipEventCreate(&t.stop);
@@ -314,7 +317,7 @@ static void beginTiming(nbl_model* m, hipStream_t s, int kernel) {
   m->pending.push_back(t);
 }
 static void endTiming(nbl_model* m, hipStream_t s) {
-  if (!m->timing) return;
+  if (!m->timingNow) return;
   hipEventRecord(m->pending.back().stop, s);
 }
 #define TIMED(kid, launch) do { beginTiming(m, s, kid); launch; endTiming(m, s); } while (0)
@@ -327,6 +330,7 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  m->timingNow = m->timing && (m->fwdCalls++ % m->timingPeriod == 0);
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
   const size_t treeLds = (size_t)m->nb * sizeof(DevBody) + (size_t)m->n * sizeof(DevDof) + (size_t)TREE_WPB * WS_LDS_SLOTS * m->mdl.nbp * sizeof(double);
@@ -373,6 +377,7 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  m->timingNow = m->timing && (m->bwdCalls++ % m->timingPeriod == 0);
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
   const size_t treeLds = (size_t)m->nb * sizeof(DevBody) + (size_t)m->n * sizeof(DevDof) + (size_t)TREE_WPB * WS_LDS_SLOTS * m->mdl.nbp * sizeof(double);
@@ -525,6 +530,8 @@ int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes
 int32_t nbl_set_timing(nbl_model* m, int32_t enabled) {
   if (!m) return fail(NBL_E_BADARG, "null model");
   m->timing = enabled != 0;
+  m->timingPeriod = enabled > 1 ? enabled : 1;
+  m->fwdCalls = m->bwdCalls = 0;
   if (!enabled) {
     for (auto& t : m->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     m->pending.clear();

@@ -249,8 +249,9 @@ class World:
         check(self._L.nbl_set_launch_lanes(self._h, tree_lanes, lcp_lanes), "nbl_set_launch_lanes")
 
     # ---- kernel timing (HIP events on the launch stream) ------------------------------------------
-    def set_timing(self, enabled: bool):
-        check(self._L.nbl_set_timing(self._h, 1 if enabled else 0), "nbl_set_timing")
+    def set_timing(self, enabled, period: int = 1):
+        """HIP-event timing of the kernels; `period` N > 1 times only every N-th forward / backward call."""
+        check(self._L.nbl_set_timing(self._h, (max(1, int(period)) if enabled else 0)), "nbl_set_timing")
 
     def get_timing(self):
         f, b = C.c_double(0), C.c_double(0)
