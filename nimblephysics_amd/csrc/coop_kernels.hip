@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   const double fbar = clamp ? t + tf : 0.0;
   w.sync();
   // Q^+
-  if (svAt(saved, lay.pflag, B, b) != 0.0 && !mdl.pad) {
+  if (svAt(saved, lay.pflag, B, b) != 0.0) {
     if (ln < MAXR) {
 #pragma unroll
       for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = dn[lay.pinv + i * MAX_ROWS + ln];

@@ -247,7 +247,6 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0; m->mdl.pad2 = 0;
   m->mdl.maxLevel = 0; m->mdl.maxRank = 0;
   for (const DevBody& hbI : hb) { if (hbI.level > m->mdl.maxLevel) m->mdl.maxLevel = hbI.level; if (hbI.parent >= 0 && hbI.rank > m->mdl.maxRank) m->mdl.maxRank = hbI.rank; }
-  if (const char* e4 = getenv("NBL_DEBUG_NOPINV")) m->mdl.pad = atoi(e4);
   for (int k = 0; k < 3; k++) m->mdl.gravity[k] = d->gravity[k];
   m->mdl.dt = d->dt;
   hipError_t e = hipSetDevice(device);

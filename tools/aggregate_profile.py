@@ -48,3 +48,21 @@ out["_tag"] = tag
 json.dump(out, open(tf, "w"), indent=1)
 print(json.dumps(out[workload], indent=1))
 print("total per step launch (MB):", sum(v for k, v in out[workload].items() if k != "k_transpose") / 1e6)
+
+
+# ---- VALU utilisation / occupancy passes (optional) ----
+try:
+    va, _ = counter("valu", "SQ_INSTS_VALU")
+    wv, _ = counter("valu", "SQ_WAVES")
+    ut, _ = counter("util", "VALUUtilization")
+    vb, _ = counter("util", "VALUBusy")
+    oc, _ = counter("util", "MeanOccupancyPerCU")
+    vout = {k: {"valu_insts_per_launch": va.get(k), "waves": wv.get(k), "VALUUtilization_pct(lanes active)": round(ut.get(k, 0), 1),
+                "VALUBusy_pct": round(vb.get(k, 0), 1), "MeanOccupancyPerCU": round(oc.get(k, 0), 2)} for k in sorted(va) if k.startswith("k_")}
+    json.dump({"_note": "rocprofv3 --pmc passes of tools/profile.sh (SQ_INSTS_VALU SQ_WAVES | VALUUtilization VALUBusy MeanOccupancyPerCU), "
+                        "per-launch averages. VALUBusy_pct: share of cycles a SIMD issues a VALU instruction; VALUUtilization_pct: share of "
+                        "the 64 lanes active in the VALU instructions issued; MeanOccupancyPerCU: resident waves per CU (max 32).",
+               workload: vout}, open(os.path.join(ROOT, "profiles", f"{tag}_valu_utilisation.json"), "w"), indent=1)
+    print("wrote", f"profiles/{tag}_valu_utilisation.json")
+except SystemExit as e:
+    print("no VALU passes:", e)
