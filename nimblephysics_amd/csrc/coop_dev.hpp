@@ -330,45 +330,27 @@ struct CoopStage0 {
   bool pinvValid;     // S.P is the pseudo-inverse of the Q of the final classification (uniform)
 };
 
-// LCPUtils::guessSolution (when there is no matching warm start) + the standardisation loop of
-// CGGM::constructMatrices / opportunisticallyStandardizeResults (standardizeLoop in contact_kernels.hip), stage 0 of
-// the solver cascade (BoxedLcpConstraintSolver.cpp:380-460), cfm = 0, friction kept.
+// CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (standardizeLoop of lcp_dev.hpp, lane = row).
+// X in: the solver's x, out: the last accepted solution.  guessMask / pinvValid: the rows and state of a pseudo-inverse
+// already in S.P (stage 0's guess), 0 / false otherwise.  Returns whether the results are standardised.
 template <class W>
-DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, double Xcache, CoopStage0& out) {
-  const int ln = w.lane();
+DEV bool coopStandardizeLoop(const W& w, CoopLds& S, const CoopRow& R, double& X, double cfm, bool ignoreFriction,
+                             uint32_t guessMask, bool& pinvValid, CoopClasses& K) {
   double a[MAXR];
-  double X = 0.0;
-  uint32_t guessMask = 0;
-  bool pinvValid = false;
-  if (haveCache) X = ln < R.m ? Xcache : 0.0;
-  else {
-    const bool in = ln < R.m && (R.fric || R.Bv > 0);
-    guessMask = (uint32_t)w.ballot(in);
-    if (guessMask != 0) {
-#pragma unroll
-      for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(i) : 0.0;
-      coopPinv(w, a, S, __builtin_popcount(guessMask));
-      X = coopPinvApply<W, false>(w, S, in ? R.Bv : 0.0, 0);
-      if (!in) X = 0.0;
-      pinvValid = true;   // of A restricted to guessMask; stays valid only if the first classification agrees
-    }
-  }
-  out.X0 = X;
   bool ok = false;
-  CoopClasses K;
 #pragma unroll 1
   for (int iter = 0; iter < MAXR + 1; iter++) {
-    coopClassify(w, R, X, false, K);
+    coopClassify(w, R, X, ignoreFriction, K);
     if (K.nc == 0) {
       pinvValid = false;
-      ok = coopValid(w, S, R, 0.0, false, 0.0, 1);
+      ok = coopValid(w, S, R, 0.0, ignoreFriction, cfm, 1);
       if (ok) X = 0.0;
       break;
     }
     double fc;
     if (iter == 0 && K.nu == 0 && guessMask != 0 && K.clampMask == guessMask) fc = X;
     else {
-      coopBuildQ(w, S, R, K, 0.0, a);
+      coopBuildQ(w, S, R, K, cfm, a);
       coopPinv(w, a, S, K.nc);
       fc = coopPinvApply<W, false>(w, S, K.cls == RC_CLAMPING ? R.Bv : 0.0, 0);
       pinvValid = true;
@@ -384,11 +366,39 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
       const double clean = (fabs(om - R.mu) < fabs(om + R.mu)) ? R.mu : -R.mu;
       newX = fcN * clean;
     }
-    if (!coopValid(w, S, R, newX, false, 0.0, 1)) { ok = false; break; }
+    if (!coopValid(w, S, R, newX, ignoreFriction, cfm, 1)) { ok = false; break; }
     X = newX;
     ok = true;
     if (w.ballot(newlyNot) == 0ull) break;
   }
+  return ok;
+}
+
+// LCPUtils::guessSolution (when there is no matching warm start) + the standardisation loop: stage 0 of the solver cascade
+// (BoxedLcpConstraintSolver.cpp:380-460), cfm = 0, friction kept.
+template <class W>
+DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, double Xcache, CoopStage0& out) {
+  const int ln = w.lane();
+  double X = 0.0;
+  uint32_t guessMask = 0;
+  bool pinvValid = false;
+  if (haveCache) X = ln < R.m ? Xcache : 0.0;
+  else {
+    const bool in = ln < R.m && (R.fric || R.Bv > 0);
+    guessMask = (uint32_t)w.ballot(in);
+    if (guessMask != 0) {
+      double a[MAXR];
+#pragma unroll
+      for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(i) : 0.0;
+      coopPinv(w, a, S, __builtin_popcount(guessMask));
+      X = coopPinvApply<W, false>(w, S, in ? R.Bv : 0.0, 0);
+      if (!in) X = 0.0;
+      pinvValid = true;   // of A restricted to guessMask; stays valid only if the first classification agrees
+    }
+  }
+  out.X0 = X;
+  CoopClasses K;
+  const bool ok = coopStandardizeLoop(w, S, R, X, 0.0, false, guessMask, pinvValid, K);
   out.X = X; out.K = K; out.ok = ok; out.pinvValid = ok && pinvValid;
 }
 

@@ -3,6 +3,7 @@
 //                          compacted slow path (k_contact_cascade, one world per lane) exactly like k_contact_solve
 //   k_bwd_contact_a_coop   the dense (c x c) part of the contact adjoint (k_bwd_contact_a)
 #include "coop_dev.hpp"
+#include "coop_dantzig_dev.hpp"
 #include "coop_wave_dev.hpp"
 
 namespace nbl {
@@ -26,6 +27,34 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
 #pragma unroll
   for (int i = 0; i < MAXR; i++) { const double x = R.a(i); cn = fma(x, x, cn); }
   R.colNorm = cn;
+}
+
+// x, classes, cfm, warm start, v' = v_pre + M^-1 J^T x and (when valid) the pseudo-inverse of the final Q -> saved record
+DEV void coopContactOutputs(const DevWave& w, CoopLds& S, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValid,
+                            double* __restrict__ saved, const SavedLayout& lay, double* __restrict__ dn,
+                            double* __restrict__ cacheOut, double* __restrict__ nv, int64_t B, int64_t b) {
+  const int ln = w.lane();
+  if (ln < MAX_ROWS) {
+    svAt(saved, lay.x + ln, B, b) = X;
+    svAt(saved, lay.cls + ln, B, b) = K.cls == RC_UPPER_BOUND ? (K.E > 0 ? 2.0 : -2.0) : (double)K.cls;
+    if (cacheOut) cacheOut[(int64_t)ln * B + b] = X;
+  }
+  if (ln == MAX_ROWS && cacheOut) cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
+  if (ln == 0) { svAt(saved, lay.cfm, B, b) = cfm; svAt(saved, lay.pflag, B, b) = pinvValid ? 1.0 : 0.0; }
+  // v' = v_pre + M^-1 J^T x  (lane = DOF)
+  if (ln < MAXR) S.vec[2][ln] = X;
+  w.sync();
+  if (ln < n) {
+    double wd = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) wd = fma(r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, S.vec[2][r], wd);   // columns >= m were never written
+    svAt(saved, lay.w + ln, B, b) = wd;
+    nv[(int64_t)ln * B + b] = svAt(saved, lay.vpre + ln, B, b) + wd;
+  }
+  if (pinvValid && ln < MAXR) {
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) dn[lay.pinv + i * MAX_ROWS + ln] = S.P[i * CLD + ln];
+  }
 }
 
 __global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
@@ -58,33 +87,41 @@ __global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, cons
   CoopStage0 out;
   coopStage0(w, S, R, haveCache, Xcache, out);
   if (out.ok) {
-    if (ln < MAX_ROWS) {
-      svAt(saved, lay.x + ln, B, b) = out.X;
-      svAt(saved, lay.cls + ln, B, b) = out.K.cls == RC_UPPER_BOUND ? (out.K.E > 0 ? 2.0 : -2.0) : (double)out.K.cls;
-      if (cacheOut) cacheOut[(int64_t)ln * B + b] = out.X;
-    }
-    if (ln == MAX_ROWS && cacheOut) cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
-    if (ln == 0) { svAt(saved, lay.cfm, B, b) = 0.0; svAt(saved, lay.pflag, B, b) = out.pinvValid ? 1.0 : 0.0; }
-    // v' = v_pre + M^-1 J^T x  (lane = DOF)
-    if (ln < MAXR) S.vec[2][ln] = out.X;
-    w.sync();
-    if (ln < n) {
-      double wd = 0.0;
-#pragma unroll
-      for (int r = 0; r < MAXR; r++) wd = fma(r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, S.vec[2][r], wd);   // columns >= m were never written
-      svAt(saved, lay.w + ln, B, b) = wd;
-      nv[(int64_t)ln * B + b] = svAt(saved, lay.vpre + ln, B, b) + wd;
-    }
-    if (out.pinvValid && ln < MAXR) {
-#pragma unroll
-      for (int i = 0; i < MAXR; i++) dn[lay.pinv + i * MAX_ROWS + ln] = S.P[i * CLD + ln];
-    }
+    coopContactOutputs(w, S, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
     if (ln == 0 && status) status[b] |= 0x2u | 0x100u;
   } else {
     // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
     if (ln < MAX_ROWS) lws[(int64_t)(LW_JA + ln) * B + b] = out.X0;
     if (ln == 0) { const uint32_t slot = atomicAdd(failCount, 1u); failList[slot] = (int32_t)b; }
   }
+}
+
+// Stages 1-3 of the cascade for the worlds stage 0 could not resolve: one WAVEFRONT per failed world (compacted list).
+// k_contact_cascade does the same one world per lane; there ONE unresolved world costs 4-7 ms (a single dependent
+// instruction stream with a fresh LDL^T per pivot), here the wave shares the factorisations and products.
+__global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                             double* __restrict__ saved, SavedLayout lay,
+                                                             double* __restrict__ cacheOut, double* __restrict__ next,
+                                                             uint32_t* __restrict__ status, double* __restrict__ lws,
+                                                             const int32_t* __restrict__ failList,
+                                                             const uint32_t* __restrict__ failCount) {
+  __shared__ CoopLds S;
+  __shared__ CascadeLds C;
+  if (blockIdx.x >= *failCount) return;
+  const DevWave w;
+  const int ln = w.lane();
+  const int64_t b = failList[blockIdx.x];
+  const int n = mdl.n;
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  double* nv = next + (int64_t)n * B;
+  double* dn = denseOf(saved, lay, B, b);
+  CoopRow R;
+  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
+  CoopCascadeOut out;
+  coopCascade(w, S, C, R, X0, cm->fallbackCfm, out);
+  coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+  if (ln == 0 && status) status[b] |= out.st;
 }
 
 // Dense part of the contact adjoint, one world per wavefront: the same quantities as k_bwd_contact_a

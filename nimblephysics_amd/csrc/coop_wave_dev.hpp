@@ -16,6 +16,7 @@ struct DevWave {
   }
   DEV uint64_t ballot(bool p) const { return (uint64_t)__ballot(p ? 1 : 0); }
   DEV double shfl(double v, int src) const { return __shfl(v, src & 63); }
+  DEV int shflI(int v, int src) const { return __shfl(v, src & 63); }
 };
 
 // workgroup -> world: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous range of worlds

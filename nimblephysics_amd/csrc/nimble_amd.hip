@@ -33,11 +33,11 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
                                            "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop", "k_step_forward_coop", "k_bwd_recompute_coop",
-                                           "k_bwd_final_coop", "k_tree_to_lanes"};
+                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_coop"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -57,6 +57,7 @@ struct nbl_model {
   bool timingNow = false;   // ... and this call is one of the sampled ones
   int timingPeriod = 1;     // every timingPeriod-th forward / backward call carries HIP events
   int64_t fwdCalls = 0, bwdCalls = 0;
+  bool coopCascade = true;           // NBL_COOP_CASCADE=0: stages 1-3 one world per lane
   bool coopFinal = false;            // NBL_COOP_FINAL=1: the reverse sweep too (slower: 3 of 64 lanes busy, VALU-issue bound)
   bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
   bool coop = true;                  // dense contact kernels: one world per wavefront (NBL_COOP=0: one world per lane)
@@ -231,6 +232,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
     m->coop = coop;
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
+    if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
     // measured (MI355X, B = 4096): with colliders the world-major tree block pays off for the wavefront-per-world consumers
     // (3.93 vs 3.77 M/s); without colliders the one-world-per-lane pair is faster (11.0 vs 10.5 M/s)
     m->coopTree = coop && coopTree && saveTree && hasContact && d->n_bodies <= 64 && d->n_dofs <= 64;
@@ -363,7 +365,11 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
     else
       TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, ldsBytes, s, m->mdl, m->dContact, B, (double*)saved,
                                       m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws, failList, failCount));
-    TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, m->mdl, m->dContact, B,
+    if (m->coop && m->coopCascade)
+      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_coop, dim3((unsigned)B), dim3(64), 0, s, m->mdl, m->dContact, B,
+                                               (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+    else
+      TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, m->mdl, m->dContact, B,
                                         (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
   }
   HIP_TRY(hipGetLastError());

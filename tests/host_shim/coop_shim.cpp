@@ -1,6 +1,7 @@
 // Host build of the product's wave-cooperative LCP code (coop_dev.hpp) on the thread-per-lane wave emulation,
 // next to the one-world-per-lane statement of the same algorithm (lcp_dev.hpp).  Test harness only.
 #include "coop_dev.hpp"
+#include "coop_dantzig_dev.hpp"
 #include "wave_emu.hpp"
 
 using namespace nbl;
@@ -65,5 +66,60 @@ int shim_lane_stage0(int m, const double* A, const double* b, const double* mu, 
   const bool ok = laneStage0(V, L, haveCache != 0, X, X0, b, colNorm, K);
   for (int r = 0; r < m; r++) { cls[r] = K.cls[r]; E[r] = K.E[r]; }
   return ok ? 1 : 0;
+}
+
+// cooperative Dantzig on an n-row problem (A n x n row-major, only its lower triangle is meaningful); returns 1 / 0 / -1
+int shim_coop_dantzig(int n, const double* A, double* x, const double* b, const double* lo, const double* hi, const int32_t* findex) {
+  static CascadeLds C;
+  int ret = -2;
+  for (int i = 0; i < MAXR * CLD; i++) { C.A[i] = 0; C.L[i] = 0; }
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) C.A[i * CLD + j] = A[i * n + j];
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopLcpRow row;
+    row.x = 0; row.b = ln < n ? b[ln] : 0; row.lo = ln < n ? lo[ln] : 0; row.hi = ln < n ? hi[ln] : 0; row.findex = ln < n ? findex[ln] : -1;
+    const int r = coopDantzig(w, C, n, row);
+    if (ln < n) x[ln] = row.x;
+    if (ln == 0) ret = r;
+  });
+  return ret;
+}
+
+static void loadRows(CascadeLds& C, int n, const double* A, int ln, CoopLcpRow& row, const double* x, const double* b, const double* lo,
+                     const double* hi, const int32_t* findex) {
+  if (ln == 0) { for (int i = 0; i < MAXR * CLD; i++) C.A[i] = 0; for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) C.A[i * CLD + j] = A[i * n + j]; }
+  row.x = ln < n ? x[ln] : 0; row.b = ln < n ? b[ln] : 0; row.lo = ln < n ? lo[ln] : 0; row.hi = ln < n ? hi[ln] : 0; row.findex = ln < n ? findex[ln] : -1;
+}
+int shim_coop_pgs(int n, const double* A, double* x, const double* b, const double* lo, const double* hi, const int32_t* findex) {
+  static CascadeLds C;
+  int ret = -1;
+  emuRunWave([&](const EmuWave& w) {
+    CoopLcpRow row;
+    loadRows(C, n, A, w.lane(), row, x, b, lo, hi, findex);
+    w.sync();
+    const bool ok = coopPgs(w, C, n, row);
+    if (w.lane() < n) x[w.lane()] = row.x;
+    if (w.lane() == 0) ret = ok ? 1 : 0;
+  });
+  return ret;
+}
+// reduce (removeFriction = 0) or removeFriction (= 1); outputs the reduced problem and mapTo
+int shim_coop_reduce(int n, const double* A, const double* x, const double* b, const double* lo, const double* hi, const int32_t* findex,
+                     int removeFriction, double* Ar, double* xr, double* br, double* lor, double* hir, int32_t* fr, int32_t* mapTo) {
+  static CascadeLds C;
+  int nr = -1;
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopLcpRow row;
+    loadRows(C, n, A, ln, row, x, b, lo, hi, findex);
+    w.sync();
+    int mt = ln < n ? ln : -1;
+    const int r = removeFriction ? coopLcpRemoveFriction(w, C, n, row, mt) : coopLcpReduce(w, C, n, row, mt);
+    if (ln < r) { xr[ln] = row.x; br[ln] = row.b; lor[ln] = row.lo; hir[ln] = row.hi; fr[ln] = row.findex; }
+    if (ln < n) mapTo[ln] = mt;
+    if (ln == 0) nr = r;
+  });
+  for (int i = 0; i < nr; i++) for (int j = 0; j < nr; j++) Ar[i * nr + j] = C.A[i * CLD + j];
+  return nr;
 }
 }

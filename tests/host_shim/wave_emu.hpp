@@ -36,6 +36,12 @@ struct EmuWave {
     barrier();
     return m;
   }
+  int shflI(int v, int src) const {
+    sh->bslot[ln] = v; barrier();
+    const int r = sh->bslot[src & 63];
+    barrier();
+    return r;
+  }
   double shfl(double v, int src) const {
     sh->dslot[ln] = v; barrier();
     const double r = sh->dslot[src & 63];
