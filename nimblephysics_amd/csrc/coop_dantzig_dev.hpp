@@ -12,6 +12,8 @@
 
 namespace nbl {
 
+template <int I> struct IntTag { static constexpr int value = I; };
+
 struct CascadeLds {
   double A[MAXR * CLD];    // reduced problem; for Dantzig: symmetrised from the lower triangle, rows/columns in driver order
   double L[MAXR * CLD];    // LDL^T of A(C,C): unit lower factor below the diagonal, D on it
@@ -55,13 +57,16 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   {
     int atEnd = 0;
     for (int k = n - 1; k >= 0; k--) {
-      const int fk = w.shflI(fidx, k);
+      const int fk = w.bcastI(fidx, k);
       if (fk >= 0) { swapProblem(k, n - 1 - atEnd); atEnd++; }
     }
   }
-  // dx(C) = -dir * A(C,C)^-1 A(C,i) via a fresh LDL^T (no pivoting, like dFactorLDLT), all lane-parallel
-  auto solve1 = [&](int i, int dir) {
-    if (nC == 0) return;
+  // LDL^T of A(C,C) (no pivoting, like dFactorLDLT) is kept across pivots: a row entering C at position nC extends it
+  // (what the reference's transfer_i_to_C / transfer_i_from_N_to_C do with ell / Dell, lcp.cpp:533-600); a row leaving C
+  // permutes C, so the factor is rebuilt at the next solve (the reference down-dates with dLDLTRemove instead).
+  bool Lvalid = true;   // C.L factors A(0..nC, 0..nC)
+  double ell = 0.0, Dell = 0.0;
+  auto refactor = [&]() {
     const bool inC = ln < nC;
     if (inC) for (int j = 0; j < nC; j++) if (j <= ln) C.L[ln * CLD + j] = C.A[ln * CLD + j];
     w.sync();
@@ -74,22 +79,52 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
       if (inC && ln > k) C.L[ln * CLD + k] = lik;
       w.sync();
     }
-    // L y = A(C, i);  y /= D;  L^T z = y
-    double y = inC ? C.A[ln * CLD + i] : 0.0;
-    for (int k = 0; k < nC; k++) {
-      const double yk = w.shfl(y, k);
-      if (inC && ln > k) y -= C.L[ln * CLD + k] * yk;
+    Lvalid = true;
+  };
+  // ell = L^-1 A(C, col), Dell = ell / D   (lanes < nC)
+  auto forward = [&](int col) {
+    const bool inC = ln < nC;
+    double y = inC ? C.A[ln * CLD + col] : 0.0;
+    double lrow[MAXR];   // this lane's row of L, fetched up front so that the substitution chain does not wait on LDS
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) lrow[k] = (inC && k < ln) ? C.L[ln * CLD + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) {
+      if (k >= nC) break;
+      const double yk = w.bcast(y, k);
+      if (inC && ln > k) y -= lrow[k] * yk;
     }
-    if (inC) y /= C.L[ln * CLD + ln];
-    for (int k = nC - 1; k >= 0; k--) {
-      const double zk = w.shfl(y, k);
-      if (inC && ln < k) y -= C.L[k * CLD + ln] * zk;
+    ell = y;
+    Dell = inC ? y / C.L[ln * CLD + ln] : 0.0;
+  };
+  // the row now at position nC joins C: L[nC][0..nC) = Dell, D[nC] = A(nC,nC) - ell . Dell  (sequential dot like dDot)
+  auto extend = [&]() {
+    if (!Lvalid) return;   // will be rebuilt anyway
+    if (ln < nC) { C.L[nC * CLD + ln] = Dell; C.v[2][ln] = ell * Dell; }
+    w.sync();
+    if (ln == 0) { double sum = 0; for (int j = 0; j < nC; j++) sum += C.v[2][j]; C.L[nC * CLD + nC] = C.A[nC * CLD + nC] - sum; }
+    w.sync();
+  };
+  auto solve1 = [&](int i, int dir) {
+    if (nC == 0) return;
+    if (!Lvalid) refactor();
+    forward(i);
+    const bool inC = ln < nC;
+    double y = Dell;
+    double lcol[MAXR];   // this lane's column of L
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) lcol[k] = (inC && k > ln && k < nC) ? C.L[k * CLD + ln] : 0.0;
+#pragma unroll
+    for (int k = MAXR - 1; k >= 0; k--) {
+      if (k >= nC) continue;
+      const double zk = w.bcast(y, k);
+      if (inC && ln < k) y -= lcol[k] * zk;
     }
     dx = inC ? (dir > 0 ? -y : y) : dx;
   };
   bool hitFirstFriction = false;
   for (int i = 0; i < n; ++i) {
-    const int fi = w.shflI(fidx, i);
+    const int fi = w.bcastI(fidx, i);
     if (!hitFirstFriction && fi >= 0) {
       // un[p[j]] = x[j]; bounds of the friction rows frozen from the solved normals
       if (on) C.v[0][p] = x;
@@ -107,17 +142,18 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     w.sync();
     {
       double s = -b;
-      for (int j = 0; j < nC + nN; j++) s += C.A[me * CLD + j] * C.v[0][j];
+#pragma unroll
+      for (int j = 0; j < MAXR; j++) s += (j < nC + nN) ? C.A[me * CLD + j] * C.v[0][j] : 0.0;   // static trip count: loads issue together
       if (ln == i) ww = s;
     }
     w.sync();
-    const double wi0 = w.shfl(ww, i), loi = w.shfl(lo, i), hii = w.shfl(hi, i);
+    const double wi0 = w.bcast(ww, i), loi = w.bcast(lo, i), hii = w.bcast(hi, i);
     if (loi == 0 && wi0 >= 0) { if (ln == i) st = 0; nN++; }
     else if (hii == 0 && wi0 <= 0) { if (ln == i) st = 1; nN++; }
-    else if (wi0 == 0) { swapProblem(nC, i); nC++; }
+    else if (wi0 == 0) { swapProblem(nC, i); if (Lvalid && nC > 0) forward(nC); else { ell = 0; Dell = 0; } extend(); nC++; }
     else {
       for (;;) {
-        const double wi = w.shfl(ww, i);
+        const double wi = w.bcast(ww, i);
         const int dir = (wi <= 0) ? 1 : -1;
         const double dirf = dir;
         solve1(i, dir);
@@ -126,7 +162,8 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         w.sync();
         {
           double s = 0;
-          for (int j = 0; j < nC; j++) s += C.A[me * CLD + j] * C.v[1][j];
+#pragma unroll
+          for (int j = 0; j < MAXR; j++) s += (j < nC) ? C.A[me * CLD + j] * C.v[1][j] : 0.0;
           const bool inN = ln >= nC && ln < nC + nN;
           if (inN || ln == i) dw = s + dirf * C.A[me * CLD + i];
         }
@@ -148,7 +185,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         }
         // the reference keeps a candidate only if it is STRICTLY smaller than the running minimum, which starts at lane
         // i's value: arg-min over (s, order)
-        const double sOwn = w.shfl(s, i);
+        const double sOwn = w.bcast(s, i);
         if (sOwn != sOwn) { row.x = 0.0; return -1; }
         const double sMin = -w.maxAll(cmd != 0 ? -s : -INFINITY);
         const uint64_t tie = w.ballot(cmd != 0 && s == sMin);
@@ -163,7 +200,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
           else if (tie & maskN) best = __builtin_ctzll(tie & maskN);
           else best = __builtin_ctzll((tie & maskC) ? (tie & maskC) : tie);
         }
-        const int cmdB = w.shflI(cmd, best);
+        const int cmdB = w.bcastI(cmd, best);
         if (sMin <= 0.0) { row.x = 0.0; return 0; }   // earlyTermination (the caller always has the PGS fallback, BoxedLcpConstraintSolver.cpp:463)
         const int si = best;
         // apply the step
@@ -172,12 +209,12 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         if (ln >= nC && ln < nC + nN) ww += sMin * dw;
         if (ln == i) ww += sMin * dw;
         switch (cmdB) {
-          case 1: if (ln == i) ww = 0; swapProblem(nC, i); nC++; break;
+          case 1: if (ln == i) ww = 0; swapProblem(nC, i); extend(); nC++; break;                              // ell / Dell of solve1(i)
           case 2: if (ln == i) { x = lo; st = 0; } nN++; break;
           case 3: if (ln == i) { x = hi; st = 1; } nN++; break;
-          case 4: if (ln == si) ww = 0; swapProblem(nC, si); nN--; nC++; break;
-          case 5: if (ln == si) { x = lo; st = 0; } swapProblem(si, nC - 1); nN++; nC--; break;
-          case 6: if (ln == si) { x = hi; st = 1; } swapProblem(si, nC - 1); nN++; nC--; break;
+          case 4: if (ln == si) ww = 0; swapProblem(nC, si); if (Lvalid) forward(nC); extend(); nN--; nC++; break;
+          case 5: if (ln == si) { x = lo; st = 0; } swapProblem(si, nC - 1); nN++; nC--; Lvalid = Lvalid && (si == nC); break;   // only the last row of C can leave without a rebuild
+          case 6: if (ln == si) { x = hi; st = 1; } swapProblem(si, nC - 1); nN++; nC--; Lvalid = Lvalid && (si == nC); break;
         }
         if (cmdB <= 3) break;
       }
@@ -216,9 +253,10 @@ DEV int coopLcpReduce(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& ma
     for (int a = 0; a < n - 1; a++) {
       double d2 = 0;
       const int bcol = ln < n ? ln : 0;
-      for (int r = 0; r < n; r++) { const double d = C.A[r * CLD + a] - C.A[r * CLD + bcol]; d2 += d * d; }
-      const double ba = w.shfl(row.b, a), ha = w.shfl(row.hi, a), la = w.shfl(row.lo, a);
-      const int fa = w.shflI(row.findex, a);
+#pragma unroll
+      for (int r = 0; r < MAXR; r++) { const double d = (r < n) ? C.A[r * CLD + a] - C.A[r * CLD + bcol] : 0.0; d2 += d * d; }
+      const double ba = w.bcast(row.b, a), ha = w.bcast(row.hi, a), la = w.bcast(row.lo, a);
+      const int fa = w.bcastI(row.findex, a);
       const bool match = ln > a && ln < n && d2 < TH && fabs(ba - row.b) < TH && fa == row.findex && ha == row.hi && la == row.lo;
       const uint64_t mm = w.ballot(match);
       if (mm) { ma = a; mb = __builtin_ctzll(mm); break; }
@@ -241,7 +279,7 @@ DEV int coopLcpReduce(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& ma
 template <class W>
 DEV int coopLcpRemoveFriction(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& mapTo) {
   for (int i = n - 1; i >= 0; i--) {
-    const int fi = w.shflI(row.findex, i);
+    const int fi = w.bcastI(row.findex, i);
     if (fi == -1) continue;
     if (row.findex > i) row.findex -= 1;
     coopRemoveRow(w, C, n, i, row);
@@ -253,71 +291,77 @@ DEV int coopLcpRemoveFriction(const W& w, CascadeLds& C, int n, CoopLcpRow& row,
 }
 
 // ---- PgsBoxedLcpSolver::solve (PgsBoxedLcpSolver.cpp:79-268), Option(30, 1e-6, 1e-3, 1e-9, false) ----
-// Gauss-Seidel is sequential over the rows; the row whose turn it is works (same summation order as pgsSolve), x lives in
-// LDS.  A is modified (rows normalised), like the reference.  row.x in: start, out: result.
+// Gauss-Seidel is sequential over the rows.  Lane i keeps its row of A in registers and every lane a replica of x, so the
+// row whose turn it is forms its sum from registers in the reference's order (no LDS, no barrier: ~720 row steps are a
+// dependent chain and their latency is the cost) and the new x_i is broadcast with a readlane.  A is modified (rows
+// normalised) only in registers.  row.x in: start, out: result.
 template <class W>
 DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   const int maxIteration = 30;
   const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
   const int ln = w.lane();
   const bool on = ln < n;
-  double* X = C.v[0];
-  if (on) X[ln] = row.x;
-  w.sync();
-  const double aii = on ? C.A[ln * CLD + ln] : 1.0;
+  const int me = on ? ln : 0;
+  double arow[MAXR], xall[MAXR];
+#pragma unroll
+  for (int j = 0; j < MAXR; j++) {
+    arow[j] = (on && j < n) ? C.A[me * CLD + j] : 0.0;
+    xall[j] = j < n ? w.bcast(row.x, j) : 0.0;
+  }
+  const double aii = on ? C.A[me * CLD + me] : 1.0;
   const bool inOrder = on && !(aii < epsDiv);
-  double bb = row.b;
-  bool possible = true;
-  for (int i = 0; i < n; ++i) {
+  double bb = row.b, xOwn = on ? row.x : 0.0;
+  bool bad = false;
+  // one Gauss-Seidel row step for row i (compile-time i): lane i computes, everybody learns the new x_i
+  auto rowStep = [&](auto iTag, bool first) {
+    constexpr int i = decltype(iTag)::value;
+    if (i >= n) return;
+    const int fi = w.bcastI(row.findex, i);
+    const double xf = w.bcast(xOwn, fi >= 0 ? fi : 0);
+    double xi = xOwn;
     if (ln == i) {
-      if (!inOrder) X[i] = 0.0;
+      if (!inOrder) { if (first) xi = 0.0; }
       else {
-        const double old_x = X[i];
+        const double old_x = xOwn;
         double new_x = bb;
-        for (int j = 0; j < i; ++j) new_x -= C.A[i * CLD + j] * X[j];
-        for (int j = i + 1; j < n; ++j) new_x -= C.A[i * CLD + j] * X[j];
-        new_x /= aii;
-        double xi;
-        if (row.findex >= 0) {
-          const double hi_tmp = row.hi * X[row.findex], lo_tmp = -hi_tmp;
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j) if (j != i) new_x -= arow[j] * xall[j];   // j < i, then j > i; entries >= n are zero
+        if (first) new_x /= aii;
+        if (fi >= 0) {
+          const double hi_tmp = row.hi * xf, lo_tmp = -hi_tmp;
           xi = new_x > hi_tmp ? hi_tmp : (new_x < lo_tmp ? lo_tmp : new_x);
         } else xi = new_x > row.hi ? row.hi : (new_x < row.lo ? row.lo : new_x);
-        X[i] = xi;
-        if (fabs(xi - old_x) > dxTh) possible = false;
+        if (first) { if (fabs(xi - old_x) > dxTh) bad = true; }
+        else if (fabs(xi) > epsDiv && fabs(xi - old_x) > relTol * fabs(xi)) bad = true;   // |(x - old) / x| > relTol without the division in the chain
       }
+      xOwn = xi;
     }
-    w.sync();
-  }
-  if (w.ballot(!possible) == 0ull) { row.x = on ? X[ln] : 0.0; w.sync(); return true; }
+    xall[i] = w.bcast(xi, i);
+  };
+  auto sweep = [&](bool first) {
+    rowStep(IntTag<0>{}, first); rowStep(IntTag<1>{}, first); rowStep(IntTag<2>{}, first); rowStep(IntTag<3>{}, first);
+    rowStep(IntTag<4>{}, first); rowStep(IntTag<5>{}, first); rowStep(IntTag<6>{}, first); rowStep(IntTag<7>{}, first);
+    rowStep(IntTag<8>{}, first); rowStep(IntTag<9>{}, first); rowStep(IntTag<10>{}, first); rowStep(IntTag<11>{}, first);
+    rowStep(IntTag<12>{}, first); rowStep(IntTag<13>{}, first); rowStep(IntTag<14>{}, first); rowStep(IntTag<15>{}, first);
+    rowStep(IntTag<16>{}, first); rowStep(IntTag<17>{}, first); rowStep(IntTag<18>{}, first); rowStep(IntTag<19>{}, first);
+    rowStep(IntTag<20>{}, first); rowStep(IntTag<21>{}, first); rowStep(IntTag<22>{}, first); rowStep(IntTag<23>{}, first);
+  };
+  sweep(true);
+  if (w.ballot(bad) == 0ull) { row.x = xOwn; return true; }
   if (inOrder) {
     const double dummy = 1.0 / aii;
     bb *= dummy;
-    for (int j = 0; j < n; ++j) C.A[ln * CLD + j] *= dummy;
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) arow[j] *= dummy;
   }
-  w.sync();
   bool done = false;
+#pragma unroll 1
   for (int iter = 1; iter < maxIteration; ++iter) {
-    possible = true;
-    for (int i = 0; i < n; ++i) {
-      if (ln == i && inOrder) {
-        double new_x = bb;
-        const double old_x = X[i];
-        for (int j = 0; j < i; j++) new_x -= C.A[i * CLD + j] * X[j];
-        for (int j = i + 1; j < n; j++) new_x -= C.A[i * CLD + j] * X[j];
-        double xi;
-        if (row.findex >= 0) {
-          const double hi_tmp = row.hi * X[row.findex], lo_tmp = -hi_tmp;
-          xi = new_x > hi_tmp ? hi_tmp : (new_x < lo_tmp ? lo_tmp : new_x);
-        } else xi = new_x > row.hi ? row.hi : (new_x < row.lo ? row.lo : new_x);
-        X[i] = xi;
-        if (fabs(xi) > epsDiv && fabs((xi - old_x) / xi) > relTol) possible = false;
-      }
-      w.sync();
-    }
-    if (w.ballot(!possible) == 0ull) { done = true; break; }
+    bad = false;
+    sweep(false);
+    if (w.ballot(bad) == 0ull) { done = true; break; }
   }
-  row.x = on ? X[ln] : 0.0;
-  w.sync();
+  row.x = xOwn;
   return done;
 }
 
@@ -328,6 +372,10 @@ struct CoopCascadeOut {
   double cfm;
   uint32_t st;       // NBL_ST_* bits to OR into the world's status
   bool pinvValid;
+#ifdef NBL_CASCADE_TIMING
+  long long t[8];    // cycle stamps: start, after reduce, Dantzig, validity, stage 2, stage 3, standardise
+  int iters;
+#endif
 };
 
 template <class W>
@@ -354,15 +402,27 @@ DEV void coopCascade(const W& w, CoopLds& S, CascadeLds& C, const CoopRow& R, do
   bool success = false, ignoreFriction = false;
   double cfm = 0.0, X = X0;
   // ---- stage 1: reduce + Dantzig with early termination (:461-522) ----
+#ifdef NBL_CASCADE_TIMING
+  out.t[0] = clock64();
+#endif
   loadProblem(0.0, X0);
   int nr = coopLcpReduce(w, C, m, row, mapTo);
+#ifdef NBL_CASCADE_TIMING
+  out.t[1] = clock64();
+#endif
   const int rc = coopDantzig(w, C, nr, row);
+#ifdef NBL_CASCADE_TIMING
+  out.t[2] = clock64();
+#endif
   if (rc == 1) {
     X = mapped(row.x, nr);
     success = coopValid(w, S, R, X, false, 0.0, 1);
     if (success) st |= 0x4u;
   }
   if (rc < 0 || hasNan(X)) { success = false; X = 0.0; st |= 0x40u; }
+#ifdef NBL_CASCADE_TIMING
+  out.t[3] = clock64();
+#endif
   if (!success) {
     // ---- stage 2: CFM + PGS from the pre-solve x (:539-597) ----
     cfm = fallbackCfm;
@@ -374,6 +434,9 @@ DEV void coopCascade(const W& w, CoopLds& S, CascadeLds& C, const CoopRow& R, do
       if (success) st |= 0x8u;
     }
   }
+#ifdef NBL_CASCADE_TIMING
+  out.t[4] = clock64();
+#endif
   if (!success) {
     // ---- stage 3: drop friction, PGS from zero (:606-677) ----
     ignoreFriction = true;
@@ -386,11 +449,17 @@ DEV void coopCascade(const W& w, CoopLds& S, CascadeLds& C, const CoopRow& R, do
     if (!ok3) st |= 0x20u;
   }
   if (hasNan(X)) { X = 0.0; st |= 0x40u; }
+#ifdef NBL_CASCADE_TIMING
+  out.t[5] = clock64();
+#endif
   // ---- register the fresh solution, classify, standardise (:718-736) ----
   bool pinvValid = false;
   const bool std = coopStandardizeLoop(w, S, R, X, cfm, ignoreFriction, 0u, pinvValid, out.K);
   if (std) st |= 0x100u;
   out.X = X; out.cfm = cfm; out.st = st; out.pinvValid = std && pinvValid;
+#ifdef NBL_CASCADE_TIMING
+  out.t[6] = clock64();
+#endif
 }
 
 }  // namespace nbl

@@ -122,6 +122,10 @@ __global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const
   coopCascade(w, S, C, R, X0, cm->fallbackCfm, out);
   coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
   if (ln == 0 && status) status[b] |= out.st;
+#ifdef NBL_CASCADE_TIMING
+  if (ln == 0) for (int k = 0; k < 7; k++) lws[(int64_t)(LW_JB + k) * B + b] = (double)(out.t[k] - out.t[0]);   // debug: cycle stamps
+  if (ln == 0) lws[(int64_t)(LW_JB + 7) * B + b] = (double)(clock64() - out.t[0]);
+#endif
 }
 
 // Dense part of the contact adjoint, one world per wavefront: the same quantities as k_bwd_contact_a

@@ -17,6 +17,12 @@ struct DevWave {
   DEV uint64_t ballot(bool p) const { return (uint64_t)__ballot(p ? 1 : 0); }
   DEV double shfl(double v, int src) const { return __shfl(v, src & 63); }
   DEV int shflI(int v, int src) const { return __shfl(v, src & 63); }
+  // value of lane `src`, src WAVE-UNIFORM: v_readlane (a few cycles) instead of ds_bpermute (an LDS round trip)
+  DEV int bcastI(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }
+  DEV double bcast(double v, int src) const {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+  }
 };
 
 // workgroup -> world: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous range of worlds

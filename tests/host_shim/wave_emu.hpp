@@ -42,6 +42,8 @@ struct EmuWave {
     barrier();
     return r;
   }
+  double bcast(double v, int src) const { return shfl(v, src); }
+  int bcastI(int v, int src) const { return shflI(v, src); }
   double shfl(double v, int src) const {
     sh->dslot[ln] = v; barrier();
     const double r = sh->dslot[src & 63];
