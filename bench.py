@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--workload", default="atlas20_contact")
     ap.add_argument("--joint-noise", type=float, default=0.002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: timed region without the per-kernel HIP events")
     args = ap.parse_args()
 
@@ -124,6 +125,15 @@ def main():
     def run(T):
         ga_total = torch.zeros((k, B), dtype=torch.float64, device=dev)
         status = None
+        if args.rollout > 0:      # cfg5-style: T-step trajectory, loss = |q_T|^2 + |v_T|^2, one shared control vector
+            for _ in range(T):
+                states, sv, st_all = world.rollout_soa(state0, action, T=args.rollout, want_saved=True, warm_start=True)
+                gst = torch.zeros_like(states)
+                gst[-1] = 2.0 * states[-1]
+                g0, ga = world.rollout_backward_soa(sv, gst)
+                ga_total += ga.sum(0)
+                status = st_all[-1]
+            return shared_parameter_grad(ga_total), status
         for _ in range(T):
             world.reset_lcp_cache()                                  # cold start: guess + solve every step
             nxt, sv, status = world.step_soa(state0, action, want_saved=True)
@@ -156,7 +166,7 @@ def main():
     st = status.cpu().numpy().astype(np.uint32)
 
     if rank == 0:
-        total_units = B * world_size * args.steps
+        total_units = B * world_size * args.steps * max(1, args.rollout)
         value = total_units / elapsed
         m_rows = 24 if world.m > 0 else 0
         kern = {kname: v["ms_sum"] / v["count"] for kname, v in tm["kernels"].items()}

@@ -230,14 +230,19 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     bool coop = true, coopTree = true;
     if (const char* e3 = getenv("NBL_COOP")) coop = atoi(e3) != 0;
     if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
+    if ((size_t)d->n_bodies * 252 * sizeof(double) > 160u * 1024u) coop = false;   // k_bwd_contact_b_coop's per-world LDS image
     m->coop = coop;
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
     if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
     // measured (MI355X, B = 4096): with colliders the world-major tree block pays off for the wavefront-per-world consumers
     // (3.93 vs 3.77 M/s); without colliders the one-world-per-lane pair is faster (11.0 vs 10.5 M/s)
     m->coopTree = coop && coopTree && saveTree && hasContact && d->n_bodies <= 64 && d->n_dofs <= 64;
-    if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
+    if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
     const int nbp = (d->n_bodies + 3) & ~3;
+    // the wavefront-per-world tree kernels keep 4 worlds' sweep state + one copy of the model constants in LDS
+    const size_t coopTreeLds = (size_t)d->n_bodies * sizeof(DevBody) + (size_t)d->n_dofs * sizeof(DevDof) +
+                               (size_t)TREE_WPB * WS_LDS_SLOTS * nbp * sizeof(double);
+    if (coopTreeLds > 160u * 1024u) coopTree = false;
     L.treeNbp = m->coopTree ? nbp : 0;
     L.treeRows = !saveTree ? 0 : (m->coopTree ? WS_KEEP * nbp : d->n_bodies * WS_KEEP);
     m->mdl.nbp = nbp;
