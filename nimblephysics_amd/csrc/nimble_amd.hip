@@ -228,8 +228,13 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     bool saveTree = true;   // trade 8 * WS_KEEP * n_bodies bytes per world and step for the ABA re-run of the backward pass
     if (const char* e0 = getenv("NBL_SAVE_TREE")) saveTree = atoi(e0) != 0;
     bool coop = true, coopTree = true;
+    const int nbp = (d->n_bodies + 3) & ~3;
+    // the wavefront-per-world tree kernels keep 4 worlds' sweep state + one copy of the model constants in LDS
+    const size_t coopTreeLds = (size_t)d->n_bodies * sizeof(DevBody) + (size_t)d->n_dofs * sizeof(DevDof) +
+                               (size_t)TREE_WPB * WS_LDS_SLOTS * nbp * sizeof(double);
     if (const char* e3 = getenv("NBL_COOP")) coop = atoi(e3) != 0;
     if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
+    if (coopTreeLds > 160u * 1024u) coopTree = false;
     if ((size_t)d->n_bodies * 252 * sizeof(double) > 160u * 1024u) coop = false;   // k_bwd_contact_b_coop's per-world LDS image
     m->coop = coop;
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
@@ -238,11 +243,6 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     // (3.93 vs 3.77 M/s); without colliders the one-world-per-lane pair is faster (11.0 vs 10.5 M/s)
     m->coopTree = coop && coopTree && saveTree && hasContact && d->n_bodies <= 64 && d->n_dofs <= 64;
     if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
-    const int nbp = (d->n_bodies + 3) & ~3;
-    // the wavefront-per-world tree kernels keep 4 worlds' sweep state + one copy of the model constants in LDS
-    const size_t coopTreeLds = (size_t)d->n_bodies * sizeof(DevBody) + (size_t)d->n_dofs * sizeof(DevDof) +
-                               (size_t)TREE_WPB * WS_LDS_SLOTS * nbp * sizeof(double);
-    if (coopTreeLds > 160u * 1024u) coopTree = false;
     L.treeNbp = m->coopTree ? nbp : 0;
     L.treeRows = !saveTree ? 0 : (m->coopTree ? WS_KEEP * nbp : d->n_bodies * WS_KEEP);
     m->mdl.nbp = nbp;
