@@ -375,19 +375,21 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
 }
 
 // Tree part of the contact adjoint, one world per wavefront (k_bwd_contact_b one world per lane; the header of
-// contact_backward.hip derives the terms).  Phases with different lane roles, all state in LDS:
-//   1  lane = joint-rate field f (9: lambda1, v_pre, p1..3, s1..3, w): root->leaf twists, body frame FB and world frame FW
-//   2  lane = (mass-matrix pair k, half t) (8): leaf->root reverse Newton-Euler (v = 0) of -d(adj^T M acc)/dq; the
-//      transmitted-force half and the acceleration-adjoint half of a pair are independent chains
-//   3  lane = LCP row (24).  The chain walk of k_bwd_contact_b adds, for every body l between a contact body and the root,
+// contact_backward.hip derives the terms).  Everything is carried in the WORLD frame, where transmitted wrenches add up
+// over subtrees without transforms and ad* is equivariant (dAdT(T, dad(V, F)) = dad(AdInvT(T, V), dAdT(T, F))):
+//   1a lane = joint-rate field f (9: lambda1, v_pre, p1..3, s1..3, w): world twists FW[i][f] = FW[parent][f] + Ad(TW_i) S_i rate
+//   1b lane = (body, field): local wrench G_i (twist in the body frame), moved to the world frame -> TF[i][f]
+//   2  lane = LCP row (24): the chain walk of k_bwd_contact_b adds, for every body l between a contact body and the root,
 //          add_l = term - sgn dad(T_end - tw(parent l), F_w),   tw(body) = sum_e cf_e FW[body][e]
 //      which is bilinear: summed over rows,  xi[l] = C[l] + sum_e dad(FW[parent l][e], Phi_e[l])  with
 //          C   = sum over the rows whose contact body lies in the subtree of l of (term - sgn dad(T_end, F_w))
 //          Phi_e = the same subtree sum of sgn cf_e F_w.
-//      So each row only adds 54 numbers to its two contact bodies (deterministic reduction over the three rows of a
-//      contact), one leaf->root pass forms the subtree sums, and no per-row chain walk or per-row accumulator is needed.
-//   4  lane = body: assembles xi, projects on the joint (applyHt) and writes the position cotangent LB_QX
-// lds doubles: FW[nb][8][6] X2[nb][6][8] D[nb][54] | FB[nb][9][6] P8[nb][6][8] (phase 1-2)  aliased by  tmp[54][24] (phase 3)
+//      Each row adds 54 numbers at its two contact bodies (deterministic reduction over the three rows of a contact).
+//   3  lane = component: ONE leaf->root pass forms the subtree sums of D = [C, Phi] and of TF (the transmitted wrenches of
+//      the reverse Newton-Euler pass at v = 0 for the four mass-matrix pairs (lambda1, w), (s_k, p_k))
+//   4  lane = body: xi_W = C + sum_e dad(FW[par][e], Phi_e) - sum_pairs (dad(FW[par][adj], TF[acc]) + dad(FW[par][acc], TF[adj])),
+//      projected on the joint (applyHt) -> the position cotangent LB_QX
+// lds doubles: FW[nb][9][6] TF[nb][9][6] D[nb][54] tmp[54][24]
 __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
@@ -398,19 +400,17 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   const int64_t b = coopWorld(blockIdx.x, gridDim.x);
   if (b >= B) return;
   if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;
-  const int nb = mdl.nb, n = mdl.n;
+  const int nb = mdl.nb;
   double* FW = ldsB;
-  double* X2 = FW + nb * 48;
-  double* D = X2 + nb * 48;
-  double* FB = D + nb * 54;
-  double* P8 = FB + nb * 54;
-  double* tmp = FB;                       // 54 x 24 doubles, needs nb * 102 >= 1296 or the host pads (bwdBLdsDoubles)
+  double* TF = FW + nb * 54;
+  double* D = TF + nb * 54;
+  double* tmp = D + nb * 54;
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
   const double* q = saved;
   auto ld6 = [](const double* base, int stride) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e * stride]; return fromArr(a); };
   auto st6 = [](double* base, int stride, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) base[e * stride] = a[e]; };
-  // ---- phase 1 ----
+  // ---- phase 1a ----
   if (ln < 9) {
     const int f = ln;
     const double* src; const int64_t stride = B;
@@ -427,34 +427,21 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
         tw = AdT(cT(bd.Tcj), mk6(mk3(src[o * stride], src[(o + 1) * stride], src[(o + 2) * stride]),
                                  mk3(src[(o + 3) * stride], src[(o + 4) * stride], src[(o + 5) * stride])));
       } else tw = src[bd.dofOff * stride] * cV6(bd.S);
-      if (bd.parent >= 0) tw = tw + AdInvT(ldT(c, i), ld6(FB + (bd.parent * 9 + f) * 6, 1));
-      st6(FB + (i * 9 + f) * 6, 1, tw);
-      if (f < 8) st6(FW + (i * 8 + f) * 6, 1, AdT(ldTAt(c, i, WS_TW), tw));
+      V6 twW = AdT(ldTAt(c, i, WS_TW), tw);
+      if (bd.parent >= 0) twW = twW + ld6(FW + (bd.parent * 9 + f) * 6, 1);
+      st6(FW + (i * 9 + f) * 6, 1, twW);
     }
   }
-  for (int idx = ln; idx < nb * 48; idx += 64) P8[idx] = 0.0;
   for (int idx = ln; idx < nb * 54; idx += 64) D[idx] = 0.0;
   w.sync();
-  // ---- phase 2 ----
-  if (ln < 8) {
-    const int k = ln >> 1, t = ln & 1;
-    const int ADJ = k == 0 ? 0 : 4 + k, ACC = k == 0 ? 8 : 1 + k;   // (lambda1, w), (s_k, p_k)
-    const int fx = t == 0 ? ACC : ADJ, fo = t == 0 ? ADJ : ACC;     // t = 0: F_k = G acc + ...,  t = 1: A_k = G adj + ...
-    for (int i = nb - 1; i >= 0; i--) {
-      const DevBody& bd = bodies[i];
-      const V6 Xk = mul(cS6(bd.G), ld6(FB + (i * 9 + fx) * 6, 1)) + ld6(P8 + i * 48 + ln, 8);
-      V6 xi = zero6();
-      if (bd.parent >= 0) {
-        const T12 T = ldT(c, i);
-        xi = dad(AdInvT(T, ld6(FB + (bd.parent * 9 + fo) * 6, 1)), Xk);
-        double* pp = P8 + bd.parent * 48 + ln;
-        st6(pp, 8, ld6(pp, 8) + dAdInvT(T, Xk));
-      }
-      st6(X2 + i * 48 + ln, 8, xi);
-    }
+  // ---- phase 1b: local wrenches of the nine fields, world frame ----
+  for (int item = ln; item < nb * 9; item += 64) {
+    const int i = item / 9;
+    const T12 TW = ldTAt(c, i, WS_TW);
+    const V6 twB = AdInvT(TW, ld6(FW + item * 6, 1));
+    st6(TF + item * 6, 1, dAdInvT(TW, mul(cS6(bodies[i].G), twB)));
   }
-  w.sync();   // FB / P8 are dead from here: tmp takes their place
-  // ---- phase 3: per-row constants, side A then side B ----
+  // ---- phase 2: per-row constants, side A then side B ----
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   const int nC = m / 3;
   double cf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -469,17 +456,17 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     for (int e = 0; e < 8; e++) { cf[e] = lws[(int64_t)(LB_COEF + row * 8 + e) * B + b]; any = any || cf[e] != 0.0; }
     if (any) {
       CR = loadContactRec(SV, lay, cm, ci);
-      const TangentFrame TF = tangentFrameOf(CR.nrm);
-      const V3 d = k == 0 ? CR.nrm : (k == 1 ? TF.t1 : TF.t2);
+      const TangentFrame TF_ = tangentFrameOf(CR.nrm);
+      const V3 d = k == 0 ? CR.nrm : (k == 1 ? TF_.t1 : TF_.t2);
       Fw = mk6(cross(CR.p, d), d);
       auto twistOf = [&](int body) -> V6 {   // world twist of `body` under the joint rates z_row
         V6 z = zero6();
         if (body < 0) return z;
-        for (int e = 0; e < 8; e++) z = z + cf[e] * ld6(FW + (body * 8 + e) * 6, 1);
+        for (int e = 0; e < 8; e++) z = z + cf[e] * ld6(FW + (body * 9 + e) * 6, 1);
         return z;
       };
       TA = twistOf(CR.bA); TB = twistOf(CR.bB);
-      RT = contactRowTerms(CR, TF, k, d, TA - TB);
+      RT = contactRowTerms(CR, TF_, k, d, TA - TB);
     }
   }
   const bool aIsVertex = (CR.type == CT_VERTEX_FACE);
@@ -488,16 +475,16 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
       const double sgn = side == 0 ? 1.0 : -1.0;
       const int start = side == 0 ? CR.bA : CR.bB;
       const bool vertexSide = (side == 0) == aIsVertex;
-      V6 C = zero6();
+      V6 Cc = zero6();
       double sc = 0.0;
       if (any && start >= 0) {
-        C = -sgn * dad(side == 0 ? TA : TB, Fw);
-        if (CR.type == CT_VERTEX_FACE || CR.type == CT_FACE_VERTEX) C = C + (vertexSide ? RT.vertexTerm : RT.faceTerm);
-        else if (CR.type == CT_EDGE_EDGE) C = C + (side == 0 ? RT.edgeTermA : RT.edgeTermB);
+        Cc = -sgn * dad(side == 0 ? TA : TB, Fw);
+        if (CR.type == CT_VERTEX_FACE || CR.type == CT_FACE_VERTEX) Cc = Cc + (vertexSide ? RT.vertexTerm : RT.faceTerm);
+        else if (CR.type == CT_EDGE_EDGE) Cc = Cc + (side == 0 ? RT.edgeTermA : RT.edgeTermB);
         sc = sgn;
       }
       double c6[6], f6[6];
-      toArr(C, c6); toArr(Fw, f6);
+      toArr(Cc, c6); toArr(Fw, f6);
       for (int e = 0; e < 6; e++) tmp[e * MAX_ROWS + ln] = c6[e];
       for (int e = 0; e < 8; e++) for (int x = 0; x < 6; x++) tmp[(6 + e * 6 + x) * MAX_ROWS + ln] = sc * cf[e] * f6[x];
     }
@@ -511,11 +498,11 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     }
     w.sync();
   }
-  // subtree sums, leaf -> root
+  // ---- phase 3: subtree sums, leaf -> root (D and the transmitted wrenches) ----
   if (ln < 54) {
     for (int i = nb - 1; i >= 1; i--) {
       const int par = bodies[i].parent;
-      if (par >= 0) D[par * 54 + ln] += D[i * 54 + ln];
+      if (par >= 0) { D[par * 54 + ln] += D[i * 54 + ln]; TF[par * 54 + ln] += TF[i * 54 + ln]; }
     }
   }
   w.sync();
@@ -523,15 +510,18 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   if (ln < nb) {
     const int i = ln;
     const DevBody& bd = bodies[i];
-    V6 xi2 = zero6();
-    for (int k = 0; k < 8; k++) xi2 = xi2 + ld6(X2 + i * 48 + k, 8);
     V6 xiW = ld6(D + i * 54, 1);
-    if (bd.parent >= 0)
-      for (int e = 0; e < 8; e++) xiW = xiW + dad(ld6(FW + (bd.parent * 8 + e) * 6, 1), ld6(D + i * 54 + 6 + e * 6, 1));
-    double qb2[6], qb3[6];
-    applyHt(bd, q, B, b, xi2, qb2);
-    applyHt(bd, q, B, b, dAdT(ldTAt(c, i, WS_TW), xiW), qb3);
-    for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_QX + bd.dofOff + k) * B + b] = qb3[k] - qb2[k];
+    if (bd.parent >= 0) {
+      const double* FWp = FW + bd.parent * 54;
+      for (int e = 0; e < 8; e++) xiW = xiW + dad(ld6(FWp + e * 6, 1), ld6(D + i * 54 + 6 + e * 6, 1));
+      for (int k = 0; k < 4; k++) {
+        const int ADJ = k == 0 ? 0 : 4 + k, ACC = k == 0 ? 8 : 1 + k;   // (lambda1, w), (s_k, p_k)
+        xiW = xiW - dad(ld6(FWp + ADJ * 6, 1), ld6(TF + i * 54 + ACC * 6, 1)) - dad(ld6(FWp + ACC * 6, 1), ld6(TF + i * 54 + ADJ * 6, 1));
+      }
+    }
+    double qb[6];
+    applyHt(bd, q, B, b, dAdT(ldTAt(c, i, WS_TW), xiW), qb);
+    for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_QX + bd.dofOff + k) * B + b] = qb[k];
   }
 }
 

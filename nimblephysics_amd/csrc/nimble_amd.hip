@@ -235,7 +235,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e3 = getenv("NBL_COOP")) coop = atoi(e3) != 0;
     if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
     if (coopTreeLds > 160u * 1024u) coopTree = false;
-    if ((size_t)d->n_bodies * 252 * sizeof(double) > 160u * 1024u) coop = false;   // k_bwd_contact_b_coop's per-world LDS image
+    if (((size_t)d->n_bodies * 162 + 54 * MAX_ROWS) * sizeof(double) > 160u * 1024u) coop = false;   // k_bwd_contact_b_coop's per-world LDS image
     m->coop = coop;
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
     if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
@@ -424,9 +424,7 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
       TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
                                       B, sv, m->lay, grad_next_state, (double*)workspace, lws));
     if (m->coop) {
-      size_t bDoubles = (size_t)m->nb * (48 + 48 + 54 + 54 + 48);      // FW X2 D | FB P8
-      if ((size_t)m->nb * 102 < 54 * MAX_ROWS) bDoubles = (size_t)m->nb * 150 + 54 * MAX_ROWS;   // tmp[54][24] aliases FB + P8
-      const size_t bLds = bDoubles * sizeof(double);
+      const size_t bLds = ((size_t)m->nb * 162 + 54 * MAX_ROWS) * sizeof(double);   // FW TF D tmp
       TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)B), dim3(64), bLds, s, m->mdl, m->dBodies, m->dContact, B,
                                              sv, m->lay, (const double*)workspace, lws));
     } else
