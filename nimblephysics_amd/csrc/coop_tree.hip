@@ -61,6 +61,151 @@ DEV void coopLoadTree(const CoopCtx& c, const double* saved, const SavedLayout& 
   waveFence();
 }
 
+// ---- Featherstone ABA in the WORLD frame (lane = body) -----------------------------------------------------------------
+// In one common frame the articulated inertias and bias forces of the children ADD into the parent without the congruence /
+// coadjoint transforms of the body-frame recursion (GenericJoint.hpp:2168-2185, 2395-2421), and twists / accelerations pass
+// from parent to child unchanged.  The heavy per-body work (joint transform, world inertia Ad*^-1 G Ad^-1, own bias force) is
+// done once per body by all lanes together; what stays inside the level-synchronous loops is ~250 instructions per level
+// instead of ~950.  Scalars (psi, u, qdd) are frame invariant, so the results equal the body-frame sweeps of kernels.hip to
+// round-off; the kept slots are written in the body-frame convention every consumer expects (V, A, AI*S converted once at the
+// end; AI only for the free-joint root, the only body whose AI is read later).  A free joint is a tree root and is handled in
+// its body frame exactly like abaSweeps does.
+//   scratch slots reused for world-frame data of the lane's body: WS_AI = AI^W (accumulated), WS_FACC = B^W (accumulated),
+//   WS_W = twist V^W, WS_VBAR = acceleration A^W  (parent <-> child exchange; everything else lives in registers)
+template <class TauFn, class EmitFn>
+DEV void abaSweepsWorld(const CoopCtx& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
+  const int64_t B = c.B, b = c.b;
+  const int i = c.lane;
+  const bool on = i < c.nb;
+  const DevBody& bd = c.bodies[on ? i : 0];
+  const bool isFree = bd.jtype == JT_FREE;
+  // ---- joint transform (all bodies together) ----
+  T12 T;
+  if (on) {
+    T12 Q;
+    if (bd.jtype == JT_REVOLUTE) {
+      const double qi = q[bd.dofOff * B + b];
+      Q.R = expAngular(mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi));  // RevoluteJoint.cpp:203-211
+      Q.p = mk3(0, 0, 0);
+    } else if (bd.jtype == JT_PRISMATIC) {
+      const double qi = q[bd.dofOff * B + b];
+      Q.R = eye3();
+      Q.p = mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi);
+    } else {
+      Q.R = expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b]));  // FreeJoint.cpp:74-81
+      Q.p = mk3(q[(bd.dofOff + 3) * B + b], q[(bd.dofOff + 4) * B + b], q[(bd.dofOff + 5) * B + b]);
+    }
+    T = mulT(mulT(cT(bd.Tpj), Q), cT(bd.TcjInv));
+    stT(c, i, T);
+  }
+  const V6 SdqB = on ? jointTwist(bd, v, B, b) : zero6();   // S dq in the body frame
+  // ---- sweep 1 (root -> leaf): world transforms and twists ----
+  T12 TW = T;
+  V6 Vw = zero6(), SdqW = zero6();
+  forBodiesDown(c, [&](int) {
+    if (bd.parent >= 0) TW = mulT(ldTAt(c, bd.parent, WS_TW), T);
+    stTAt(c, i, WS_TW, TW);                                  // BodyNode::mWorldTransform
+    SdqW = AdT(TW, SdqB);
+    Vw = bd.parent >= 0 ? ldV6(c, bd.parent, WS_W) + SdqW : SdqW;
+    stV6(c, i, WS_W, Vw);
+  });
+  // ---- own inertia and bias in the world frame (all bodies together) ----
+  const V6 Sw = (on && !isFree) ? AdT(TW, cV6(bd.S)) : zero6();
+  const V6 etaW = ad(Vw, SdqW);                               // GenericJoint.hpp:1803-1824 (dS = 0); zero for the root
+  if (on) {
+    const S6 Gw = congruenceToParent(TW, cS6(bd.G));
+    stS6(c, i, WS_AI, Gw);
+    stV6(c, i, WS_FACC, -dad(Vw, mul(Gw, Vw)));               // BodyNode.cpp:2076-2114; gravity rides on the base acceleration
+  }
+  waveFence();
+  // ---- sweep 2 (leaf -> root): articulated inertias, bias forces, joint-space total force ----
+  V6 AISw = zero6();
+  double psi = 0.0, u = 0.0;
+  forBodiesUp(c, [&](int) {
+    S6 AI = ldS6(c, i, WS_AI);
+    const V6 Bf = ldV6(c, i, WS_FACC);
+    const V6 AIeta = mul(AI, etaW);
+    if (!isFree) {
+      const int d = bd.dofOff;
+      const DevDof& df = c.dofs[d];
+      AISw = mul(AI, Sw);
+      psi = 1.0 / dot(Sw, AISw);                              // GenericJoint.hpp:2276-2301
+      const double qd = q[d * B + b], vd = v[d * B + b];
+      // GenericJoint.hpp:2554-2571: spring uses q - q0 + dt*v, damping explicit
+      u = tauAt(d) - df.spring * (qd - df.rest + vd * c.dt) - df.damping * vd - dot(Sw, AIeta + Bf);
+      wsAt(c, i, WS_PSI) = psi;
+      wsAt(c, i, WS_U) = u;
+      if (bd.parent >= 0) {
+        const V6 beta = Bf + AIeta + (psi * u) * AISw;        // GenericJoint.hpp:2395-2421
+        rank1Sub(AI, AISw, psi);                              // PI = AI - AIS psi AIS^T  (GenericJoint.hpp:2168-2185)
+        parentTurn(c, [&]() { addS6(c, bd.parent, WS_AI, AI); addV6(c, bd.parent, WS_FACC, beta); });
+      }
+    } else {
+      // free joint as a tree root, in its body frame (abaSweeps): projected inertia S^T AI S with S = Ad(T_cj)
+      const T12 TWi = invT(TW);
+      const S6 AIb = congruenceToParent(TWi, AI);
+      stS6(c, i, WS_AI, AIb);
+      const LDL6 f = ldl6(congruenceToParent(cT(bd.TcjInv), AIb));
+#pragma unroll
+      for (int k = 0; k < 15; k++) wsAt(c, i, WS_PSI + k) = f.l[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) wsAt(c, i, WS_PSI + 15 + k) = f.d[k];
+      const V6 proj = dAdT(cT(bd.Tcj), dAdT(TW, AIeta + Bf));   // S^T (AI eta + B), body frame
+      double pj[6];
+      toArr(proj, pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int d = bd.dofOff + k;
+        const DevDof& df = c.dofs[d];
+        const double qd = q[d * B + b], vd = v[d * B + b];
+        wsAt(c, i, WS_U + k) = tauAt(d) - df.spring * (qd - df.rest + vd * c.dt) - df.damping * vd - pj[k];
+      }
+    }
+  });
+  // ---- sweep 3 (root -> leaf): accelerations ----
+  const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
+  V6 Aw = zero6();
+  forBodiesDown(c, [&](int) {
+    const V6 Ap = bd.parent >= 0 ? ldV6(c, bd.parent, WS_VBAR) : a0;
+    if (!isFree) {
+      const double qdd = psi * (u - dot(AISw, Ap));           // GenericJoint.hpp:2656-2676
+      Aw = Ap + etaW + qdd * Sw;
+      emit(bd.dofOff, qdd);
+    } else {
+      const V6 XA = AdInvT(TW, Ap);
+      const S6 AIb = ldS6(c, i, WS_AI);
+      LDL6 f;
+#pragma unroll
+      for (int k = 0; k < 15; k++) f.l[k] = wsAt(c, i, WS_PSI + k);
+#pragma unroll
+      for (int k = 0; k < 6; k++) f.d[k] = wsAt(c, i, WS_PSI + 15 + k);
+      const V6 proj = dAdT(cT(bd.Tcj), mul(AIb, XA));
+      double r[6], pj[6];
+      toArr(proj, pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) r[k] = wsAt(c, i, WS_U + k) - pj[k];
+      ldl6Solve(f, r);
+#pragma unroll
+      for (int k = 0; k < 6; k++) emit(bd.dofOff + k, r[k]);
+      Aw = AdT(TW, XA + AdInvT(TW, etaW) + AdT(cT(bd.Tcj), fromArr(r)));
+    }
+    stV6(c, i, WS_VBAR, Aw);
+  });
+  // ---- kept slots in the body-frame convention of the consumers ----
+  if (on) {
+    stV6(c, i, WS_V, AdInvT(TW, Vw));
+    stV6(c, i, WS_A, AdInvT(TW, Aw));
+    if (!isFree) stV6(c, i, WS_AIS, dAdT(TW, AISw));
+  }
+  waveFence();
+}
+
+// the ABA of the forward step: world frame with lane = body, body frame with lane = world
+template <class TauFn, class EmitFn>
+DEV void stepAba(const CoopCtx& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
+  abaSweepsWorld(c, q, v, tauAt, emit);
+}
+
 // World::step without contact + (contact models) the body twists at the pre-contact velocity
 __global__ __launch_bounds__(64 * TREE_WPB, 2) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                           const DevDof* __restrict__ dofs, int64_t B,

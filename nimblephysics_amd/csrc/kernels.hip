@@ -310,6 +310,11 @@ DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, 
 // ---------------------------------------------------------------------------------------------
 // Forward kernel
 // ---------------------------------------------------------------------------------------------
+template <class TauFn, class EmitFn>
+DEV void stepAba(const Ctx& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
+  abaSweeps<false>(c, q, v, tauAt, emit);
+}
+
 // World::step without contact for the world(s) of context c: ABA, v' = v + dt qdd, q' = integrate(q, v_t, dt), and the
 // rows of the saved record BackpropSnapshot captures (q_t, v_t, tau_t, mLastPreConstraintVelocity).  Single source for
 // the one-world-per-lane and the one-world-per-wavefront kernels.
@@ -334,7 +339,7 @@ DEV void stepForwardCore(const C& c, const double* __restrict__ state, const dou
     nv[(int64_t)d * B + b] = x;
     if (vpreRow >= 0) saved[(int64_t)(vpreRow + d) * B + b] = x;   // mLastPreConstraintVelocity (World.cpp:236-239)
   };
-  abaSweeps<false>(c, q, v, tauAt, emit);
+  stepAba(c, q, v, tauAt, emit);
 
   // positions integrate with the PRE-step velocity (World.cpp:307-333, mParallelVelocityAndPositionUpdates)
   forBodies(c, [&](int i) {
