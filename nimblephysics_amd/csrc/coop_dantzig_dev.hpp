@@ -48,9 +48,10 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     w.sync();
     if (on) { const double t = C.A[ln * CLD + i1]; C.A[ln * CLD + i1] = C.A[ln * CLD + i2]; C.A[ln * CLD + i2] = t; }
     w.sync();
-    const int src = ln == i1 ? i2 : (ln == i2 ? i1 : ln);
-    x = w.shfl(x, src); b = w.shfl(b, src); ww = w.shfl(ww, src); lo = w.shfl(lo, src); hi = w.shfl(hi, src);
-    p = w.shflI(p, src); st = w.shflI(st, src); fidx = w.shflI(fidx, src);
+    // two-lane exchange with readlanes (i1, i2 uniform)
+    auto xd = [&](double& v) { const double a = w.bcast(v, i1), c2 = w.bcast(v, i2); v = ln == i1 ? c2 : (ln == i2 ? a : v); };
+    auto xi = [&](int& v) { const int a = w.bcastI(v, i1), c2 = w.bcastI(v, i2); v = ln == i1 ? c2 : (ln == i2 ? a : v); };
+    xd(x); xd(b); xd(ww); xd(lo); xd(hi); xi(p); xi(st); xi(fidx);
   };
   int nC = 0, nN = 0;
   // contact problems have no unbounded rows (nub = 0); every findex row goes to the end (lcp.cpp:487-498)

@@ -9,10 +9,19 @@ namespace nbl {
 struct DevWave {
   DEV int lane() const { return (int)(threadIdx.x & 63u); }
   DEV void sync() const { __syncthreads(); }
+  // max over the wavefront.  DPP row shifts (register crossbar, a few cycles each) instead of six ds_bpermute round trips:
+  // after row_shr 1, 2, 4, 8 the last lane of every 16-lane row holds the row maximum; four readlanes finish.
   DEV double maxAll(double v) const {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+#define NBL_DPP_MAX_STEP(CTRL)                                                                             \
+    {                                                                                                      \
+      const int lo = __double2loint(v), hi = __double2hiint(v);                                            \
+      const int tlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);                          \
+      const int thi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);                          \
+      v = fmax(v, __hiloint2double(thi, tlo));                                                             \
+    }
+    NBL_DPP_MAX_STEP(0x111) NBL_DPP_MAX_STEP(0x112) NBL_DPP_MAX_STEP(0x114) NBL_DPP_MAX_STEP(0x118)
+#undef NBL_DPP_MAX_STEP
+    return fmax(fmax(bcast(v, 15), bcast(v, 31)), fmax(bcast(v, 47), bcast(v, 63)));
   }
   DEV uint64_t ballot(bool p) const { return (uint64_t)__ballot(p ? 1 : 0); }
   DEV double shfl(double v, int src) const { return __shfl(v, src & 63); }
