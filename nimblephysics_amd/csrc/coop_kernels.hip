@@ -248,21 +248,27 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
 }
 
 // Contact rows, one world per wavefront, lane = LCP row (k_contact_rows does the same one world per lane, three rows per
-// pair of tree sweeps): per-row body-frame wrenches J, b = -J^T V(v_pre), the constraint-force column A_c[:, row]
+// pair of tree sweeps): per-row wrench, b = -J^T V(v_pre), the constraint-force column A_c[:, row]
 // (DCC::getConstraintForces), one unit-impulse test per lane (BodyNode::updateBiasImpulse / updateVelocityChangeFD,
 // BodyNode.cpp:2117-2215; GenericJoint.hpp:2482-2498, 2607-2613, 2713-2725) giving the column M^-1 J^T e_row ("massed")
 // and the row of the Delassus matrix A (BoxedLcpConstraintSolver.cpp:250-320: entries of later contacts computed,
-// earlier ones mirrored).  The tree state of the world (transforms, articulated inertias; k_step_forward) is the same
-// for all lanes and comes through uniform loads; the per-lane bias-impulse / velocity-change field lives in LDS:
-//   lds: JA[24][6], JB[24][6], acc[nb][6][24]
+// earlier ones mirrored).
+// Everything is carried in the WORLD frame: a prologue (lane = body) moves S, AI*S and the twist at v_pre of every body
+// to the world frame once; then the contact wrench F is the same 6-vector at every body, impulses add up the chain and
+// velocity changes pass down it without transforms, and an entry of A is F_col . (dV_A - dV_B).  Only the free-joint root
+// is solved in its body frame like in abaSweeps.
+//   lds doubles: Fw[24][6]  Sw[nb][6]  AISw[nb][6]  Vw[nb][6]  acc[nb][6][24]
 __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                           const DevContactModel* __restrict__ cm, int64_t B,
                                                           double* __restrict__ saved, SavedLayout lay,
                                                           const double* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) double ldsRows[];
-  double* JAs = ldsRows;
-  double* JBs = ldsRows + 6 * MAX_ROWS;
-  double* acc = ldsRows + 12 * MAX_ROWS;
+  const int nb = mdl.nb;
+  double* Fs = ldsRows;
+  double* Sw = Fs + 6 * MAX_ROWS;
+  double* AISw = Sw + 6 * nb;
+  double* Vw = AISw + 6 * nb;
+  double* acc = Vw + 6 * nb;
   const DevWave w;
   const int ln = w.lane();
   const int64_t b = coopWorld(blockIdx.x, gridDim.x);
@@ -272,13 +278,22 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   if (m == 0) return;
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   double* dn = denseOf(saved, lay, B, b);
+  auto ld6 = [](const double* base) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e]; return fromArr(a); };
+  auto st6 = [](double* base, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) base[e] = a[e]; };
+  // ---- prologue, lane = body: world-frame joint axis, AI*S and twist at v_pre ----
+  if (ln < nb) {
+    const DevBody& bd = bodies[ln];
+    const T12 TW = ldTAt(c, ln, WS_TW);
+    st6(Vw + 6 * ln, AdT(TW, ldV6(c, ln, WS_VTW)));
+    if (bd.jtype != JT_FREE) { st6(Sw + 6 * ln, AdT(TW, cV6(bd.S))); st6(AISw + 6 * ln, dAdInvT(TW, ldV6(c, ln, WS_AIS))); }
+  }
   const bool on = ln < m;
   const int row = on ? ln : 0;
   const int ci = row / 3, kk = row % 3;
   auto accAt = [&](int body, int e) -> double& { return acc[(body * 6 + e) * MAX_ROWS + row]; };
   auto ldAcc = [&](int body) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = accAt(body, e); return fromArr(a); };
   auto stAcc = [&](int body, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) accAt(body, e) = a[e]; };
-  // ---- this row's wrench, b entry and constraint-force column ----
+  // ---- this row's wrench ----
   const int r0 = lay.contacts + ci * CR_SIZE;
   const V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
   const V3 nrm = mk3(svAt(saved, r0 + CR_NORMAL, B, b), svAt(saved, r0 + CR_NORMAL + 1, B, b), svAt(saved, r0 + CR_NORMAL + 2, B, b));
@@ -286,72 +301,66 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   V3 t1, t2;
   tangentBasis(nrm, t1, t2);
   const V3 dir = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
-  const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p
-  V6 ja = zero6(), jb = zero6();
-  double rel = 0;
-  if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_VTW)); }
-  if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_VTW)); }
+  const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p (on A; -F on B)
   const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
-  if (on) {
-    double a6[6];
-    toArr(ja, a6);
-    for (int e = 0; e < 6; e++) JAs[row * 6 + e] = a6[e];
-    toArr(jb, a6);
-    for (int e = 0; e < 6; e++) JBs[row * 6 + e] = a6[e];
-    svAt(saved, lay.b + row, B, b) = rel;   // getRelVelocity; restitution 0, penetration correction off
-  }
-  for (int i = 0; i < c.nb; i++) {
-    const DevBody& bd = bodies[i];
-    const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
-    const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
-    const V6 Fi = dAdT(ldTAt(c, i, WS_TW), F);
-    if (bd.jtype != JT_FREE) {
-      if (on) dn[lay.aall + bd.dofOff * MAX_ROWS + row] = mult * dot(cV6(bd.S), Fi);
-    } else {
-      double v6[6];
-      toArr(dAdT(cT(bd.Tcj), Fi), v6);
-      if (on) for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
-    }
-    if (on) for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
-  }
+  if (on) st6(Fs + 6 * row, F);
   w.sync();
   if (on) {
-    // ---- unit-impulse test of this row.  leaf -> root: bias impulses along the two ancestor chains ----
+    // b = -J^T V: relative velocity of the contact point pair along dir (getRelVelocity; restitution 0, no penetration correction)
+    double rel = 0;
+    if (bA >= 0) rel -= dot(F, ld6(Vw + 6 * bA));
+    if (bB >= 0) rel += dot(F, ld6(Vw + 6 * bB));
+    svAt(saved, lay.b + row, B, b) = rel;
+    // constraint forces in joint space (DCC::getConstraintForces): A_c[i] = sigma_i s_i . F
+    for (int i = 0; i < nb; i++) {
+      const DevBody& bd = bodies[i];
+      const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
+      const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
+      if (bd.jtype != JT_FREE) dn[lay.aall + bd.dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), F);
+      else {
+        double v6[6];
+        toArr(dAdT(cT(bd.Tcj), dAdT(ldTAt(c, i, WS_TW), F)), v6);
+        for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
+      }
+      for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
+    }
+    // ---- unit-impulse test of this row.  leaf -> root: bias impulses along the two ancestor chains (world wrenches) ----
     const uint64_t chain = mA | mB;
-    for (int i = c.nb - 1; i >= 0; i--) {
+    for (int i = nb - 1; i >= 0; i--) {
       if (!((chain >> i) & 1ull)) continue;
       const DevBody& bd = bodies[i];
       V6 Bi = ldAcc(i);
-      if (i == bA) Bi = Bi - ja;
-      if (i == bB) Bi = Bi - jb;
+      if (i == bA) Bi = Bi - F;
+      if (i == bB) Bi = Bi + F;
       stAcc(i, Bi);
       if (bd.jtype != JT_FREE && bd.parent >= 0) {
-        const double uimp = -dot(cV6(bd.S), Bi);
-        const V6 up = dAdInvT(ldT(c, i), Bi + (wsAt(c, i, WS_PSI) * uimp) * ldV6(c, i, WS_AIS));
-        stAcc(bd.parent, ldAcc(bd.parent) + up);
+        const double uimp = -dot(ld6(Sw + 6 * i), Bi);
+        stAcc(bd.parent, ldAcc(bd.parent) + Bi + (wsAt(c, i, WS_PSI) * uimp) * ld6(AISw + 6 * i));
       }
     }
-    // root -> leaf: velocity changes of every body, joint-space response
-    for (int i = 0; i < c.nb; i++) {
+    // root -> leaf: velocity changes of every body (world twists), joint-space response
+    for (int i = 0; i < nb; i++) {
       const DevBody& bd = bodies[i];
-      const V6 X = bd.parent >= 0 ? AdInvT(ldT(c, i), ldAcc(bd.parent)) : zero6();
+      const V6 X = bd.parent >= 0 ? ldAcc(bd.parent) : zero6();
       const V6 Bi = ((chain >> i) & 1ull) ? ldAcc(i) : zero6();
       if (bd.jtype != JT_FREE) {
-        const V6 S = cV6(bd.S);
-        const double dq = wsAt(c, i, WS_PSI) * (-dot(S, Bi) - dot(ldV6(c, i, WS_AIS), X));
+        const V6 S = ld6(Sw + 6 * i);
+        const double dq = wsAt(c, i, WS_PSI) * (-dot(S, Bi) - dot(ld6(AISw + 6 * i), X));
         stAcc(i, X + dq * S);
         dn[lay.massed + bd.dofOff * MAX_ROWS + row] = dq;
       } else {
-        const T12 Tcj = cT(bd.Tcj);
+        // the free-joint root in its body frame
+        const T12 Tcj = cT(bd.Tcj), TW = ldTAt(c, i, WS_TW);
         LDL6 f;
         for (int e = 0; e < 15; e++) f.l[e] = wsAt(c, i, WS_PSI + e);
         for (int e = 0; e < 6; e++) f.d[e] = wsAt(c, i, WS_PSI + 15 + e);
+        const V6 Xb = AdInvT(TW, X);
         double r[6], u[6], pj[6];
-        toArr(dAdT(Tcj, Bi), u);
-        toArr(dAdT(Tcj, mul(ldS6(c, i, WS_AI), X)), pj);
+        toArr(dAdT(Tcj, dAdT(TW, Bi)), u);
+        toArr(dAdT(Tcj, mul(ldS6(c, i, WS_AI), Xb)), pj);
         for (int e = 0; e < 6; e++) r[e] = -u[e] - pj[e];
         ldl6Solve(f, r);
-        stAcc(i, X + AdT(Tcj, fromArr(r)));
+        stAcc(i, AdT(TW, Xb + AdT(Tcj, fromArr(r))));
         for (int e = 0; e < 6; e++) dn[lay.massed + (bd.dofOff + e) * MAX_ROWS + row] = r[e];
       }
     }
@@ -359,14 +368,12 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
     for (int c2 = ci; c2 < nC; c2++) {
       const int q0 = lay.contacts + c2 * CR_SIZE;
       const int b2A = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body, b2B = cm->boxes[(int)svAt(saved, q0 + CR_BOXB, B, b)].body;
-      const V6 dVA = b2A >= 0 ? ldAcc(b2A) : zero6(), dVB = b2B >= 0 ? ldAcc(b2B) : zero6();
+      V6 dV = zero6();
+      if (b2A >= 0) dV = dV + ldAcc(b2A);
+      if (b2B >= 0) dV = dV - ldAcc(b2B);
       for (int k2 = 0; k2 < 3; k2++) {
         const int col = 3 * c2 + k2;
-        double a6[6], b6[6];
-        for (int e = 0; e < 6; e++) { a6[e] = JAs[col * 6 + e]; b6[e] = JBs[col * 6 + e]; }
-        double val = 0;
-        if (b2A >= 0) val += dot(fromArr(a6), dVA);
-        if (b2B >= 0) val += dot(fromArr(b6), dVB);
+        const double val = dot(ld6(Fs + 6 * col), dV);
         dn[lay.A + row * MAX_ROWS + col] = val;
         if (c2 > ci) dn[lay.A + col * MAX_ROWS + row] = val;
       }

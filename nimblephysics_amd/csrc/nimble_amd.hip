@@ -352,7 +352,7 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
     TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
                                        status, (double*)workspace, m->coopTree ? 0 : 1));
     if (m->coop) {
-      const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 2 * 6 * MAX_ROWS) * sizeof(double);
+      const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 18 * (size_t)m->nb) * sizeof(double);   // acc, Fw, Sw/AISw/Vw
       TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)B), dim3(64), rowsLds, s, m->mdl, m->dBodies, m->dContact, B,
                                             (double*)saved, m->lay, (const double*)workspace));
     } else
