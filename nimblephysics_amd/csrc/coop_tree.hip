@@ -233,6 +233,171 @@ __global__ __launch_bounds__(64 * TREE_WPB, 2) void k_step_forward_coop(DevModel
   if (status && c.lane == 0) status[b] = 0u;
 }
 
+// ---- backward sweeps in the WORLD frame (lane = body) ---------------------------------------------------------------------
+// The lane's body in world coordinates, built once from the body-frame kept slots of the tree block.
+struct WorldBody {
+  T12 TW;
+  V6 Sw, AISw, Vw, Aw;   // joint axis, AI*S, twist, acceleration (1-DOF joints; Sw / AISw unused for the free root)
+  double psi;
+  bool on, isFree;
+};
+// scratch slots of the backward sweeps (LDS, lane = body): WS_W = W^W (twist of lambda), WS_BIMP = impulse accumulator,
+// WS_FACC / WS_ABAR / WS_VBAR = adjoint accumulators, WS_UIMP = V^W and WS_BACC = A^W for the children's reads
+DEV WorldBody loadWorldBody(const CoopCtx& c) {
+  WorldBody wb;
+  const int i = c.lane;
+  wb.on = i < c.nb;
+  const DevBody& bd = c.bodies[wb.on ? i : 0];
+  wb.isFree = bd.jtype == JT_FREE;
+  wb.Sw = wb.AISw = wb.Vw = wb.Aw = zero6();
+  wb.psi = 0.0;
+  if (wb.on) {
+    wb.TW = ldTAt(c, i, WS_TW);
+    wb.Vw = AdT(wb.TW, ldV6(c, i, WS_V));
+    wb.Aw = AdT(wb.TW, ldV6(c, i, WS_A));
+    if (!wb.isFree) { wb.Sw = AdT(wb.TW, cV6(bd.S)); wb.AISw = dAdInvT(wb.TW, ldV6(c, i, WS_AIS)); wb.psi = wsAt(c, i, WS_PSI); }
+  }
+  return wb;
+}
+
+// lambda = M^-1 rhs (minvSweeps of kernels.hip) in the world frame: impulses add up the tree and twists pass down it
+// without transforms.  lam[k]: the lane's DOFs; W^W is left in WS_W for the children and returned.
+template <class RhsFn>
+DEV V6 minvSweepsWorld(const CoopCtx& c, const WorldBody& wb, RhsFn rhsAt, double (&lam)[6]) {
+  const int i = c.lane;
+  const DevBody& bd = c.bodies[wb.on ? i : 0];
+  forBodies(c, [&](int) { zeroN(c, i, WS_BIMP, 6); });
+  double uimp[6] = {0, 0, 0, 0, 0, 0};
+  forBodiesUp(c, [&](int) {
+    const V6 Bi = ldV6(c, i, WS_BIMP);
+    if (!wb.isFree) {
+      uimp[0] = rhsAt(bd.dofOff) - dot(wb.Sw, Bi);
+      if (bd.parent >= 0) {
+        const V6 up = Bi + (wb.psi * uimp[0]) * wb.AISw;
+        parentTurn(c, [&]() { addV6(c, bd.parent, WS_BIMP, up); });
+      }
+    } else {
+      double pj[6];
+      toArr(dAdT(cT(bd.Tcj), dAdT(wb.TW, Bi)), pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) uimp[k] = rhsAt(bd.dofOff + k) - pj[k];
+    }
+  });
+  V6 Ww = zero6();
+  forBodiesDown(c, [&](int) {
+    const V6 Wp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_W) : zero6();
+    if (!wb.isFree) {
+      lam[0] = wb.psi * (uimp[0] - dot(wb.AISw, Wp));
+      Ww = Wp + lam[0] * wb.Sw;
+    } else {
+      const S6 AI = ldS6(c, i, WS_AI);
+      LDL6 f;
+#pragma unroll
+      for (int k = 0; k < 15; k++) f.l[k] = wsAt(c, i, WS_PSI + k);
+#pragma unroll
+      for (int k = 0; k < 6; k++) f.d[k] = wsAt(c, i, WS_PSI + 15 + k);
+      double r[6], pj[6];
+      toArr(dAdT(cT(bd.Tcj), mul(AI, AdInvT(wb.TW, Wp))), pj);
+#pragma unroll
+      for (int k = 0; k < 6; k++) r[k] = uimp[k] - pj[k];
+      ldl6Solve(f, r);
+#pragma unroll
+      for (int k = 0; k < 6; k++) lam[k] = r[k];
+      Ww = Wp + AdT(wb.TW, AdT(cT(bd.Tcj), fromArr(r)));
+    }
+    stV6(c, i, WS_W, Ww);
+  });
+  return Ww;
+}
+
+// Reverse-mode Newton-Euler sweep at (q, v, qdd) with joint adjoint lambda (reverseSweep of kernels.hip) in the world frame.
+// Everything that does not involve the children's accumulations (three G-products, the ad / dad terms, the projections, the
+// per-DOF epilogue including the free joint's exp/log VJP) is done by all bodies together; the level loop only adds the
+// accumulators, forms F / Abar / Vbar and hands them to the parent.
+template <class GvFn, class QxFn>
+DEV void reverseSweepWorld(const CoopCtx& c, const WorldBody& wb, V6 Ww, const double (&lam)[6], const double* __restrict__ q,
+                           const double* __restrict__ v, const double* __restrict__ tau, const double* __restrict__ gqn, GvFn gvAt,
+                           QxFn qExtraAt, double* __restrict__ gq, double* __restrict__ gv, double* __restrict__ gaction) {
+  const int64_t B = c.B, b = c.b;
+  const int i = c.lane;
+  const DevBody& bd = c.bodies[wb.on ? i : 0];
+  const DevDof* dofs = c.dofs;
+  V6 Floc = zero6(), AbarLoc = zero6(), VbarLoc = zero6(), SdqW = zero6();
+  if (wb.on) {
+    const S6 Gw = congruenceToParent(wb.TW, cS6(bd.G));
+    const V6 GV = mul(Gw, wb.Vw);
+    Floc = mul(Gw, wb.Aw) - dad(wb.Vw, GV);                  // transmitted force at (q, v, qdd), own part
+    AbarLoc = mul(Gw, Ww);
+    VbarLoc = dad(Ww, GV) - mul(Gw, ad(wb.Vw, Ww));
+    SdqW = AdT(wb.TW, jointTwist(bd, v, B, b));
+    zeroN(c, i, WS_FACC, 18);
+    stV6(c, i, WS_UIMP, wb.Vw);
+    stV6(c, i, WS_BACC, wb.Aw);
+  }
+  waveFence();
+  V6 F = zero6(), Abar = zero6(), Vbar = zero6();
+  forBodiesUp(c, [&](int) {
+    F = Floc + ldV6(c, i, WS_FACC);
+    Abar = AbarLoc + ldV6(c, i, WS_ABAR);
+    Vbar = VbarLoc - dad(SdqW, Abar) + ldV6(c, i, WS_VBAR);
+    if (bd.parent >= 0) parentTurn(c, [&]() { addV6(c, bd.parent, WS_FACC, F); addV6(c, bd.parent, WS_ABAR, Abar); addV6(c, bd.parent, WS_VBAR, Vbar); });
+  });
+  if (!wb.on) return;
+  const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
+  const V6 Vp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_UIMP) : zero6();
+  const V6 Ap = bd.parent >= 0 ? ldV6(c, bd.parent, WS_BACC) : a0;
+  const V6 Wp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_W) : zero6();
+  const V6 xi = dAdT(wb.TW, dad(Wp, F) + dad(Ap, Abar) + dad(Vp, Vbar));   // adjoint of the joint transform, body frame
+  const V6 tmp = dAdT(wb.TW, dad(wb.Vw, Abar) + Vbar);                     // body frame
+  double qb[6], vb[6], pp[6], vp[6];
+  applyHt(bd, q, B, b, xi, qb);
+  const int o = bd.dofOff;
+  if (!wb.isFree) {
+    vb[0] = dot(cV6(bd.S), tmp);
+    pp[0] = gqn[(int64_t)o * B + b];            // posPos = 1, velPos = dt  (GenericJoint.hpp:1428-1444)
+    vp[0] = c.dt * pp[0];
+  } else {
+    toArr(dAdT(cT(bd.Tcj), tmp), vb);
+    V3 r = mk3(q[(o + 0) * B + b], q[(o + 1) * B + b], q[(o + 2) * B + b]);
+    V3 w = mk3(v[(o + 0) * B + b], v[(o + 1) * B + b], v[(o + 2) * B + b]);
+    V3 vl = mk3(v[(o + 3) * B + b], v[(o + 4) * B + b], v[(o + 5) * B + b]);
+    M3 R = expMapRot(r);
+    // VJP of q' = [logMap(R E); p + R vl dt]  (exact reverse-mode of FreeJoint.cpp:922-929, see reverseSweep)
+    V3 grn = mk3(gqn[(o + 0) * B + b], gqn[(o + 1) * B + b], gqn[(o + 2) * B + b]);
+    V3 gpn = mk3(gqn[(o + 3) * B + b], gqn[(o + 4) * B + b], gqn[(o + 5) * B + b]);
+    M3 E = expMapRot(c.dt * w);
+    M3 Rn = mul(R, E);
+    M3 Rnb = logMap_vjp(Rn, grn);
+    M3 Rb = mulABt(Rnb, E);                 // dL/dR from R' = R E
+    M3 Eb = mulAtB(R, Rnb);
+    V3 vdt = c.dt * vl;
+    Rb.m[0] += gpn.x * vdt.x; Rb.m[1] += gpn.x * vdt.y; Rb.m[2] += gpn.x * vdt.z;   // p' = p + R vdt
+    Rb.m[3] += gpn.y * vdt.x; Rb.m[4] += gpn.y * vdt.y; Rb.m[5] += gpn.y * vdt.z;
+    Rb.m[6] += gpn.z * vdt.x; Rb.m[7] += gpn.z * vdt.y; Rb.m[8] += gpn.z * vdt.z;
+    V3 posr = expMapRot_vjp(r, Rb);
+    V3 velw = c.dt * expMapRot_vjp(c.dt * w, Eb);
+    V3 vell = c.dt * tmul(R, gpn);
+    pp[0] = posr.x; pp[1] = posr.y; pp[2] = posr.z; pp[3] = gpn.x; pp[4] = gpn.y; pp[5] = gpn.z;   // posPos^T gq'
+    vp[0] = velw.x; vp[1] = velw.y; vp[2] = velw.z; vp[3] = vell.x; vp[4] = vell.y; vp[5] = vell.z;   // velPos^T gq'
+  }
+  for (int k = 0; k < bd.ndof; k++) {
+    const int d = o + k;
+    const DevDof& df = dofs[d];
+    const double lm = lam[k];
+    double gt = lm;
+    double gvo = gvAt(d) + vp[k] - (vb[k] + df.damping * lm + c.dt * df.spring * lm);
+    double gqo = pp[k] - (qb[k] + df.spring * lm) + qExtraAt(d);
+    // clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479)
+    const double qd = q[(int64_t)d * B + b], vd = v[(int64_t)d * B + b], td = tau[(int64_t)d * B + b];
+    if ((qd == df.posLo && gqo > 0) || (qd == df.posHi && gqo < 0)) gqo = 0;
+    if ((vd == df.velLo && gvo > 0) || (vd == df.velHi && gvo < 0)) gvo = 0;
+    if ((td == df.forceLo && gt > 0) || (td == df.forceHi && gt < 0)) gt = 0;
+    gq[(int64_t)d * B + b] = gqo;
+    gv[(int64_t)d * B + b] = gvo;
+    if (df.actionIndex >= 0) gaction[(int64_t)df.actionIndex * B + b] = gt;
+  }
+}
+
 // contact adjoint activity flag and lambda1 = M^-1 g (k_bwd_recompute)
 __global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_recompute_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevDof* __restrict__ dofs, int64_t B,
@@ -254,11 +419,13 @@ __global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_recompute_coop(DevMode
     return;
   }
   coopLoadTree(c, saved, lay);
-  minvSweeps(c, [&](int d) -> double { return gvn[(int64_t)d * B + b]; });
-  forBodies(c, [&](int i) {
-    const DevBody& bd = bodies[i];
-    for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_LAM1 + bd.dofOff + k) * B + b] = wsAt(c, i, WS_UIMP + k);
-  });
+  const WorldBody wb = loadWorldBody(c);
+  double lam[6];
+  minvSweepsWorld(c, wb, [&](int d) -> double { return gvn[(int64_t)d * B + b]; }, lam);
+  if (wb.on) {
+    const DevBody& bd = bodies[c.lane];
+    for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_LAM1 + bd.dofOff + k) * B + b] = lam[k];
+  }
 }
 
 // unconstrained backward sweep driven by g_vpre, plus the contact position cotangent (k_bwd_final); with lws == nullptr
@@ -272,17 +439,18 @@ __global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_final_coop(DevModel md
   CoopCtx c;
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
   const int64_t b = c.b;
-  bodies = c.bodies; dofs = c.dofs;   // the LDS copies
   const int n = mdl.n;
   const double* q = saved;
   const double* v = saved + (int64_t)n * B;
   const double* tau = saved + (int64_t)2 * n * B;
   const double* gvn = gnext + (int64_t)n * B;
   coopLoadTree(c, saved, lay);
+  const WorldBody wb = loadWorldBody(c);
   auto gvp = [&](int d) -> double { return lws ? lws[(int64_t)(LB_GVP + d) * B + b] : gvn[(int64_t)d * B + b]; };
   auto qx = [&](int d) -> double { return lws ? lws[(int64_t)(LB_QX + d) * B + b] : 0.0; };
-  minvSweeps(c, [&](int d) -> double { return c.dt * gvp(d); });
-  reverseSweep(c, q, v, tau, gnext, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
+  double lam[6];
+  const V6 Ww = minvSweepsWorld(c, wb, [&](int d) -> double { return c.dt * gvp(d); }, lam);
+  reverseSweepWorld(c, wb, Ww, lam, q, v, tau, gnext, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
 }
 
 // World-major tree blocks [b][slot][nbp]  ->  the lane-interleaved kept slots of the workspace ws[(body * 288 + slot) * B + b],

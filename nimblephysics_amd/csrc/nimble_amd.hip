@@ -58,7 +58,7 @@ struct nbl_model {
   int timingPeriod = 1;     // every timingPeriod-th forward / backward call carries HIP events
   int64_t fwdCalls = 0, bwdCalls = 0;
   bool coopCascade = true;           // NBL_COOP_CASCADE=0: stages 1-3 one world per lane
-  bool coopFinal = false;            // NBL_COOP_FINAL=1: the reverse sweep too (slower: 3 of 64 lanes busy, VALU-issue bound)
+  bool coopFinal = true;             // the backward sweeps too, in the world frame (NBL_COOP_FINAL=0: one world per lane, fed by k_tree_to_lanes)
   bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
   bool coop = true;                  // dense contact kernels: one world per wavefront (NBL_COOP=0: one world per lane)
   int treeLanes = 0, lcpLanes = 0;   // worlds per workgroup (0 = pick from B); see nbl_set_launch_lanes
@@ -239,9 +239,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     m->coop = coop;
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
     if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
-    // measured (MI355X, B = 4096): with colliders the world-major tree block pays off for the wavefront-per-world consumers
-    // (3.93 vs 3.77 M/s); without colliders the one-world-per-lane pair is faster (11.0 vs 10.5 M/s)
-    m->coopTree = coop && coopTree && saveTree && hasContact && d->n_bodies <= 64 && d->n_dofs <= 64;
+    // measured (MI355X, B = 4096, world-frame sweeps): 5.5 vs 3.8 M/s with colliders, 16.4 vs 11.0 M/s without
+    m->coopTree = coop && coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
     if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
     L.treeNbp = m->coopTree ? nbp : 0;
     L.treeRows = !saveTree ? 0 : (m->coopTree ? WS_KEEP * nbp : d->n_bodies * WS_KEEP);
