@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
 //      the reverse Newton-Euler pass at v = 0 for the four mass-matrix pairs (lambda1, w), (s_k, p_k))
 //   4  lane = body: xi_W = C + sum_e dad(FW[par][e], Phi_e) - sum_pairs (dad(FW[par][adj], TF[acc]) + dad(FW[par][acc], TF[adj])),
 //      projected on the joint (applyHt) -> the position cotangent LB_QX
-// lds doubles: FW[nb][9][6] TF[nb][9][6] D[nb][54] tmp[54][24]
+// lds doubles: FW[nb][9][6] D[nb][54] { tmp[54][24] | TF[nb][9][6] }
 __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
@@ -409,9 +409,9 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;
   const int nb = mdl.nb;
   double* FW = ldsB;
-  double* TF = FW + nb * 54;
-  double* D = TF + nb * 54;
-  double* tmp = D + nb * 54;
+  double* D = FW + nb * 54;
+  double* TF = D + nb * 54;      // written after the row phase: shares its storage with tmp
+  double* tmp = TF;
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
   const double* q = saved;
@@ -441,13 +441,6 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   }
   for (int idx = ln; idx < nb * 54; idx += 64) D[idx] = 0.0;
   w.sync();
-  // ---- phase 1b: local wrenches of the nine fields, world frame ----
-  for (int item = ln; item < nb * 9; item += 64) {
-    const int i = item / 9;
-    const T12 TW = ldTAt(c, i, WS_TW);
-    const V6 twB = AdInvT(TW, ld6(FW + item * 6, 1));
-    st6(TF + item * 6, 1, dAdInvT(TW, mul(cS6(bodies[i].G), twB)));
-  }
   // ---- phase 2: per-row constants, side A then side B ----
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   const int nC = m / 3;
@@ -505,6 +498,14 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     }
     w.sync();
   }
+  // ---- phase 1b (after the rows: TF takes over tmp's storage): local wrenches of the nine fields, world frame ----
+  for (int item = ln; item < nb * 9; item += 64) {
+    const int i = item / 9;
+    const T12 TW = ldTAt(c, i, WS_TW);
+    const V6 twB = AdInvT(TW, ld6(FW + item * 6, 1));
+    st6(TF + item * 6, 1, dAdInvT(TW, mul(cS6(bodies[i].G), twB)));
+  }
+  w.sync();
   // ---- phase 3: subtree sums, leaf -> root (D and the transmitted wrenches) ----
   if (ln < 54) {
     for (int i = nb - 1; i >= 1; i--) {

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -423,7 +424,7 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
       TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
                                       B, sv, m->lay, grad_next_state, (double*)workspace, lws));
     if (m->coop) {
-      const size_t bLds = ((size_t)m->nb * 162 + 54 * MAX_ROWS) * sizeof(double);   // FW TF D tmp
+      const size_t bLds = ((size_t)m->nb * 108 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS)) * sizeof(double);   // FW D {tmp | TF}
       TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)B), dim3(64), bLds, s, m->mdl, m->dBodies, m->dContact, B,
                                              sv, m->lay, (const double*)workspace, lws));
     } else
