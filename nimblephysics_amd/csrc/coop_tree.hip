@@ -11,14 +11,15 @@
 
 namespace nbl {
 
-constexpr int WS_LDS_SLOTS = WS_VBAR + 6;   // every slot the forward / backward sweeps touch
+constexpr int TREE_WPB_MAX = 8;   // worlds (wavefronts) per workgroup: they share one LDS copy of the model constants
 
-constexpr int TREE_WPB = 4;   // worlds (wavefronts) per workgroup: they share one LDS copy of the model constants
-
-// LDS of a workgroup: [DevBody x nb][DevDof x n][TREE_WPB x (WS_LDS_SLOTS x nbp doubles)].  With lane = body the model
-// constants are indexed per lane, so the scalar-load path of the one-world-per-lane kernels is gone; a per-workgroup LDS
-// copy keeps them at LDS latency instead of 15 divergent global loads per field.  Returns false for a padding world.
-DEV bool coopTreeSetup(CoopCtx& c, const DevModel& mdl, const DevBody* __restrict__ bodies, const DevDof* __restrict__ dofs,
+// LDS of a workgroup: [DevBody x nb][DevDof x n][wpb x (coopRows<P> x nbp + nFree x coopFreeExtra<P> doubles)].  With lane = body
+// the model constants are indexed per lane, so the scalar-load path of the one-world-per-lane kernels is gone; a
+// per-workgroup LDS copy keeps them at LDS latency instead of 15 divergent global loads per field.
+template <int P> __host__ __device__ constexpr int coopWorldDoubles(int nbp, int nFree) { return coopRows<P>() * nbp + nFree * coopFreeExtra<P>(); }
+// returns false for a padding world
+template <int P>
+DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __restrict__ bodies, const DevDof* __restrict__ dofs,
                        double* lds, int64_t B) {
   DevBody* lb = reinterpret_cast<DevBody*>(lds);
   DevDof* ld = reinterpret_cast<DevDof*>(lb + mdl.nb);
@@ -34,9 +35,11 @@ DEV bool coopTreeSetup(CoopCtx& c, const DevModel& mdl, const DevBody* __restric
     for (int idx = threadIdx.x; idx < cntD; idx += blockDim.x) dstD[idx] = srcD[idx];
   }
   __syncthreads();   // the only workgroup-wide barrier: from here on every wavefront runs on its own
-  const int wv = (int)(threadIdx.x >> 6);
-  const int64_t b = coopWorld(blockIdx.x, gridDim.x) * TREE_WPB + wv;
-  c.bodies = lb; c.dofs = ld; c.lds = st + (size_t)wv * WS_LDS_SLOTS * mdl.nbp; c.nbp = mdl.nbp; c.B = B; c.b = b;
+  const int wv = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  const int64_t b = coopWorld(blockIdx.x, gridDim.x) * wpb + wv;
+  const int perWorld = coopWorldDoubles<P>(mdl.nbp, mdl.nFree);
+  c.bodies = lb; c.dofs = ld; c.lds = st + (size_t)wv * perWorld; c.ldsFree = c.lds + coopRows<P>() * mdl.nbp;
+  c.nbp = mdl.nbp; c.B = B; c.b = b;
   c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
   c.g = mk3(mdl.gravity[0], mdl.gravity[1], mdl.gravity[2]);
   c.lane = (int)(threadIdx.x & 63u);
@@ -49,15 +52,35 @@ DEV bool coopTreeSetup(CoopCtx& c, const DevModel& mdl, const DevBody* __restric
 DEV double* treeBlock(double* saved, const SavedLayout& lay, int64_t B, int64_t b) {
   return saved + ((int64_t)lay.total + lay.dense) * B + b * (int64_t)lay.treeRows;
 }
-// kept slots: LDS image <-> tree block (identical [slot][nbp] layout)
-DEV void coopStoreTree(const CoopCtx& c, double* saved, const SavedLayout& lay) {
-  double* blk = treeBlock(saved, lay, c.B, c.b);
-  waveFence();
-  for (int idx = c.lane; idx < WS_KEEP * c.nbp; idx += 64) blk[idx] = c.lds[idx];
+// kept slots: LDS image (compact rows + free-joint blocks) <-> tree block ([slot][nbp], every kept slot of every body).
+// Lanes are laid over (row, body) so that a wavefront moves 64 / nbp rows per trip without integer divisions in the loop.
+template <int P, bool STORE>
+DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
+  const int rsub = c.lane / c.nbp, body = c.lane - rsub * c.nbp, rstep = 64 / c.nbp;
+  if (rsub < rstep) {
+    for (int r = rsub; r < coopRows<P>(); r += rstep) {
+      const int slot = coopRowSlot<P>(r);
+      if (slot < 0) continue;
+      if (STORE) blk[slot * c.nbp + body] = c.lds[r * c.nbp + body];
+      else c.lds[r * c.nbp + body] = blk[slot * c.nbp + body];
+    }
+  }
+  for (int fb = 0; fb < c.nb; fb++) {
+    const int fi = c.bodies[fb].freeIdx;
+    if (fi < 0 || c.lane >= coopFreeExtra<P>()) continue;
+    const int slot = coopFreeSlot<P>(c.lane);
+    if (STORE) blk[slot * c.nbp + fb] = c.ldsFree[fi * coopFreeExtra<P>() + c.lane];
+    else c.ldsFree[fi * coopFreeExtra<P>() + c.lane] = blk[slot * c.nbp + fb];
+  }
 }
-DEV void coopLoadTree(const CoopCtx& c, const double* saved, const SavedLayout& lay) {
-  const double* blk = treeBlock(const_cast<double*>(saved), lay, c.B, c.b);
-  for (int idx = c.lane; idx < WS_KEEP * c.nbp; idx += 64) c.lds[idx] = blk[idx];
+template <int P>
+DEV void coopStoreTree(const CoopCtxT<P>& c, double* saved, const SavedLayout& lay) {
+  waveFence();
+  coopCopyTree<P, true>(c, treeBlock(saved, lay, c.B, c.b));
+}
+template <int P>
+DEV void coopLoadTree(const CoopCtxT<P>& c, const double* saved, const SavedLayout& lay) {
+  coopCopyTree<P, false>(c, treeBlock(const_cast<double*>(saved), lay, c.B, c.b));
   waveFence();
 }
 
@@ -73,7 +96,7 @@ DEV void coopLoadTree(const CoopCtx& c, const double* saved, const SavedLayout& 
 //   scratch slots reused for world-frame data of the lane's body: WS_AI = AI^W (accumulated), WS_FACC = B^W (accumulated),
 //   WS_W = twist V^W, WS_VBAR = acceleration A^W  (parent <-> child exchange; everything else lives in registers)
 template <class TauFn, class EmitFn>
-DEV void abaSweepsWorld(const CoopCtx& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
+DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
   const int64_t B = c.B, b = c.b;
   const int i = c.lane;
   const bool on = i < c.nb;
@@ -202,18 +225,18 @@ DEV void abaSweepsWorld(const CoopCtx& c, const double* __restrict__ q, const do
 
 // the ABA of the forward step: world frame with lane = body, body frame with lane = world
 template <class TauFn, class EmitFn>
-DEV void stepAba(const CoopCtx& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
+DEV void stepAba(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ q, const double* __restrict__ v, TauFn tauAt, EmitFn emit) {
   abaSweepsWorld(c, q, v, tauAt, emit);
 }
 
 // World::step without contact + (contact models) the body twists at the pre-contact velocity
-__global__ __launch_bounds__(64 * TREE_WPB, 2) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                           const DevDof* __restrict__ dofs, int64_t B,
                                                           const double* __restrict__ state, const double* __restrict__ action,
                                                           double* __restrict__ next, double* __restrict__ saved,
                                                           uint32_t* __restrict__ status, SavedLayout lay, int withTwists) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
-  CoopCtx c;
+  CoopCtxT<PROF_FWD> c;
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
   const int64_t b = c.b;
   bodies = c.bodies; dofs = c.dofs;   // the LDS copies
@@ -243,7 +266,7 @@ struct WorldBody {
 };
 // scratch slots of the backward sweeps (LDS, lane = body): WS_W = W^W (twist of lambda), WS_BIMP = impulse accumulator,
 // WS_FACC / WS_ABAR / WS_VBAR = adjoint accumulators, WS_UIMP = V^W and WS_BACC = A^W for the children's reads
-DEV WorldBody loadWorldBody(const CoopCtx& c) {
+DEV WorldBody loadWorldBody(const CoopCtxT<PROF_BWD>& c) {
   WorldBody wb;
   const int i = c.lane;
   wb.on = i < c.nb;
@@ -263,7 +286,7 @@ DEV WorldBody loadWorldBody(const CoopCtx& c) {
 // lambda = M^-1 rhs (minvSweeps of kernels.hip) in the world frame: impulses add up the tree and twists pass down it
 // without transforms.  lam[k]: the lane's DOFs; W^W is left in WS_W for the children and returned.
 template <class RhsFn>
-DEV V6 minvSweepsWorld(const CoopCtx& c, const WorldBody& wb, RhsFn rhsAt, double (&lam)[6]) {
+DEV V6 minvSweepsWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, RhsFn rhsAt, double (&lam)[6]) {
   const int i = c.lane;
   const DevBody& bd = c.bodies[wb.on ? i : 0];
   forBodies(c, [&](int) { zeroN(c, i, WS_BIMP, 6); });
@@ -315,7 +338,7 @@ DEV V6 minvSweepsWorld(const CoopCtx& c, const WorldBody& wb, RhsFn rhsAt, doubl
 // per-DOF epilogue including the free joint's exp/log VJP) is done by all bodies together; the level loop only adds the
 // accumulators, forms F / Abar / Vbar and hands them to the parent.
 template <class GvFn, class QxFn>
-DEV void reverseSweepWorld(const CoopCtx& c, const WorldBody& wb, V6 Ww, const double (&lam)[6], const double* __restrict__ q,
+DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 Ww, const double (&lam)[6], const double* __restrict__ q,
                            const double* __restrict__ v, const double* __restrict__ tau, const double* __restrict__ gqn, GvFn gvAt,
                            QxFn qExtraAt, double* __restrict__ gq, double* __restrict__ gv, double* __restrict__ gaction) {
   const int64_t B = c.B, b = c.b;
@@ -399,12 +422,12 @@ DEV void reverseSweepWorld(const CoopCtx& c, const WorldBody& wb, V6 Ww, const d
 }
 
 // contact adjoint activity flag and lambda1 = M^-1 g (k_bwd_recompute)
-__global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_recompute_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_recompute_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevDof* __restrict__ dofs, int64_t B,
                                                            const double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ gnext, double* __restrict__ lws) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
-  CoopCtx c;
+  CoopCtxT<PROF_BWD> c;
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
   const int64_t b = c.b;
   bodies = c.bodies; dofs = c.dofs;   // the LDS copies
@@ -430,13 +453,13 @@ __global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_recompute_coop(DevMode
 
 // unconstrained backward sweep driven by g_vpre, plus the contact position cotangent (k_bwd_final); with lws == nullptr
 // the whole backward pass of a model without colliders (k_step_backward)
-__global__ __launch_bounds__(64 * TREE_WPB, 2) void k_bwd_final_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                        const DevDof* __restrict__ dofs, int64_t B,
                                                        const double* __restrict__ saved, SavedLayout lay,
                                                        const double* __restrict__ gnext, double* __restrict__ gstate,
                                                        double* __restrict__ gaction, const double* __restrict__ lws) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
-  CoopCtx c;
+  CoopCtxT<PROF_BWD> c;
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
   const int64_t b = c.b;
   const int n = mdl.n;

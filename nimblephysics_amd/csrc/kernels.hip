@@ -53,10 +53,73 @@ DEV double& wsAt(const Ctx& c, int body, int slot) {
 // (conflict-free), bodies of one tree level are processed together (level-synchronous sweeps) and children add to their
 // parent one sibling rank at a time.  The sweep code below is single-source for both execution models: it is written
 // against the small vocabulary  wsAt / forBodiesDown / forBodiesUp / forBodies / forDofs / parentAdd*.
-struct CoopCtx {
+// LDS image of a world for the lane = body kernels: rows [row][nbp] for the slots a kernel family touches (compact map,
+// coopSlotMap) plus, per free-joint body, a small block for the slots only a free joint owns (the 6 x 6 LDL^T of its
+// projected inertia, its 6 joint forces, and - in the backward kernels - its articulated inertia).  Two profiles:
+constexpr int PROF_FWD = 0, PROF_BWD = 1;
+template <int P> __host__ __device__ constexpr int coopRows() { return P == PROF_FWD ? 89 : 73; }
+template <int P> __host__ __device__ constexpr int coopFreeExtra() { return P == PROF_FWD ? 25 : 41; }
+constexpr int COOP_UNMAPPED = -1000000;
+// row (>= 0), or -(1 + offset) in the free-joint block, or COOP_UNMAPPED when the profile does not hold the slot
+template <int P> DEV int coopSlotMap(int s) {
+  if (P == PROF_FWD) {
+    if (s <= WS_PSI) return s;                                  // T V AI AIS PSI[0]            rows 0..45
+    if (s < WS_BACC) return -(1 + (s - WS_PSI - 1));            // PSI[1..20]                   free 0..19
+    if (s < WS_U) return 46 + (s - WS_BACC);                    // BACC / VTW                   rows 46..51
+    if (s == WS_U) return 52;                                   // U[0]
+    if (s < WS_A) return -(1 + 20 + (s - WS_U - 1));            // U[1..5]                      free 20..24
+    if (s < WS_TW) return 53 + (s - WS_A);                      // A                            rows 53..58
+    if (s < WS_KEEP) return 59 + (s - WS_TW);                   // TW                           rows 59..70
+    if (s >= WS_W && s < WS_W + 6) return 71 + (s - WS_W);      // scratch of the world-frame ABA
+    if (s >= WS_FACC && s < WS_FACC + 6) return 77 + (s - WS_FACC);
+    if (s >= WS_VBAR && s < WS_VBAR + 6) return 83 + (s - WS_VBAR);
+    return COOP_UNMAPPED;
+  } else {
+    if (s >= WS_TW && s < WS_KEEP) return s - WS_TW;            // TW                           rows 0..11
+    if (s >= WS_V && s < WS_V + 6) return 12 + (s - WS_V);
+    if (s >= WS_A && s < WS_A + 6) return 18 + (s - WS_A);
+    if (s >= WS_AIS && s < WS_AIS + 6) return 24 + (s - WS_AIS);
+    if (s == WS_PSI) return 30;
+    if (s > WS_PSI && s < WS_BACC) return -(1 + (s - WS_PSI - 1));   // PSI[1..20]              free 0..19
+    if (s >= WS_AI && s < WS_AI + 21) return -(1 + 20 + (s - WS_AI)); // AI (free-joint root)   free 20..40
+    if (s >= WS_BACC && s < WS_BACC + 6) return 31 + (s - WS_BACC);
+    if (s >= WS_BIMP && s < WS_VBAR + 6) return 37 + (s - WS_BIMP);  // BIMP UIMP W FACC ABAR VBAR   rows 37..72
+    return COOP_UNMAPPED;
+  }
+}
+
+// inverse maps for the tree-block copies: kept slot held by row r (or -1 for a scratch row) / by entry e of the free-joint block
+template <int P> DEV int coopRowSlot(int r) {
+  if (P == PROF_FWD) {
+    if (r <= 45) return r;
+    if (r < 52) return WS_BACC + (r - 46);
+    if (r == 52) return WS_U;
+    if (r < 59) return WS_A + (r - 53);
+    if (r < 71) return WS_TW + (r - 59);
+    return -1;
+  } else {
+    if (r < 12) return WS_TW + r;
+    if (r < 18) return WS_V + (r - 12);
+    if (r < 24) return WS_A + (r - 18);
+    if (r < 30) return WS_AIS + (r - 24);
+    if (r == 30) return WS_PSI;
+    return -1;   // BACC (A^W exchange) and the accumulators are scratch in the backward kernels
+  }
+}
+template <int P> DEV int coopFreeSlot(int e) {
+  if (P == PROF_FWD) return e < 20 ? WS_PSI + 1 + e : WS_U + 1 + (e - 20);
+  return e < 20 ? WS_PSI + 1 + e : WS_AI + (e - 20);
+}
+
+// One world per WAVEFRONT, lane = body: the bodies of one tree level are processed together (level-synchronous sweeps) and
+// children add to their parent one sibling rank at a time.  The sweep code is written against the small vocabulary
+// wsAt / forBodiesDown / forBodiesUp / forBodies / forDofs / parentTurn shared with the one-world-per-lane Ctx.
+template <int P>
+struct CoopCtxT {
   const DevBody* __restrict__ bodies;
   const DevDof* __restrict__ dofs;
-  double* lds;
+  double* lds;       // rows [coopRows<P>()][nbp]
+  double* ldsFree;   // [nFree][coopFreeExtra<P>()]
   int nbp;
   int64_t B, b;
   int nb, n;
@@ -64,24 +127,28 @@ struct CoopCtx {
   V3 g;
   int lane, level, rank, maxLevel, maxRank;
 };
-DEV double& wsAt(const CoopCtx& c, int body, int slot) { return c.lds[slot * c.nbp + body]; }
+template <int P>
+DEV double& wsAt(const CoopCtxT<P>& c, int body, int slot) {
+  const int r = coopSlotMap<P>(slot);
+  return r >= 0 ? c.lds[r * c.nbp + body] : c.ldsFree[c.bodies[body].freeIdx * coopFreeExtra<P>() + (-1 - r)];
+}
 DEV void waveFence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 template <class F> DEV void forBodiesDown(const Ctx& c, F f) { for (int i = 0; i < c.nb; i++) f(i); }        // root -> leaf
 template <class F> DEV void forBodiesUp(const Ctx& c, F f) { for (int i = c.nb - 1; i >= 0; i--) f(i); }    // leaf -> root
 template <class F> DEV void forBodies(const Ctx& c, F f) { for (int i = 0; i < c.nb; i++) f(i); }            // independent
 template <class F> DEV void forDofs(const Ctx& c, F f) { for (int d = 0; d < c.n; d++) f(d); }
-template <class F> DEV void forBodiesDown(const CoopCtx& c, F f) {
+template <int P, class F> DEV void forBodiesDown(const CoopCtxT<P>& c, F f) {
   for (int l = 0; l <= c.maxLevel; l++) { if (c.level == l) f(c.lane); waveFence(); }
 }
-template <class F> DEV void forBodiesUp(const CoopCtx& c, F f) {
+template <int P, class F> DEV void forBodiesUp(const CoopCtxT<P>& c, F f) {
   for (int l = c.maxLevel; l >= 0; l--) { if (c.level == l) f(c.lane); waveFence(); }
 }
-template <class F> DEV void forBodies(const CoopCtx& c, F f) { if (c.lane < c.nb) f(c.lane); waveFence(); }
-template <class F> DEV void forDofs(const CoopCtx& c, F f) { if (c.lane < c.n) f(c.lane); }
+template <int P, class F> DEV void forBodies(const CoopCtxT<P>& c, F f) { if (c.lane < c.nb) f(c.lane); waveFence(); }
+template <int P, class F> DEV void forDofs(const CoopCtxT<P>& c, F f) { if (c.lane < c.n) f(c.lane); }
 // children of one parent that sit in the same level take turns (LDS operations of a wave execute in program order)
 template <class F> DEV void parentTurn(const Ctx&, F f) { f(); }
-template <class F> DEV void parentTurn(const CoopCtx& c, F f) {
+template <int P, class F> DEV void parentTurn(const CoopCtxT<P>& c, F f) {
   for (int r = 0; r <= c.maxRank; r++) if (c.rank == r) f();
 }
 

@@ -58,6 +58,8 @@ struct nbl_model {
   bool timingNow = false;   // ... and this call is one of the sampled ones
   int timingPeriod = 1;     // every timingPeriod-th forward / backward call carries HIP events
   int64_t fwdCalls = 0, bwdCalls = 0;
+  int wpbFwd = 4, wpbBwd = 4;        // worlds per workgroup of the lane = body tree kernels (chosen for LDS occupancy)
+  size_t ldsFwd = 0, ldsBwd = 0;     // dynamic LDS of those workgroups
   bool coopCascade = true;           // NBL_COOP_CASCADE=0: stages 1-3 one world per lane
   bool coopFinal = true;             // the backward sweeps too, in the world frame (NBL_COOP_FINAL=0: one world per lane, fed by k_tree_to_lanes)
   bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
@@ -104,6 +106,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, free)");
     if (b.jtype == NBL_JOINT_FREE && b.parent != -1)
       return fail(NBL_E_UNSUPPORTED, "free joints are supported as tree roots only");
+    b.freeIdx = -1; b.padb = 0;
     b.level = b.parent < 0 ? 0 : hb[b.parent].level + 1;
     b.rank = 0;
     for (int j = 0; j < i; j++) if (hb[j].parent == b.parent) b.rank++;
@@ -230,9 +233,26 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e0 = getenv("NBL_SAVE_TREE")) saveTree = atoi(e0) != 0;
     bool coop = true, coopTree = true;
     const int nbp = (d->n_bodies + 3) & ~3;
-    // the wavefront-per-world tree kernels keep 4 worlds' sweep state + one copy of the model constants in LDS
-    const size_t coopTreeLds = (size_t)d->n_bodies * sizeof(DevBody) + (size_t)d->n_dofs * sizeof(DevDof) +
-                               (size_t)TREE_WPB * WS_LDS_SLOTS * nbp * sizeof(double);
+    // the lane = body tree kernels keep the sweep state of `wpb` worlds + one copy of the model constants in LDS; pick the
+    // worlds per workgroup that maximise the resident wavefronts per CU (160 kB)
+    int nFree = 0;
+    for (int i = 0; i < d->n_bodies; i++) if (d->joint_type[i] == NBL_JOINT_FREE) hb[i].freeIdx = nFree++;
+    m->mdl.nFree = nFree;
+    const size_t modelLds = (size_t)d->n_bodies * sizeof(DevBody) + (size_t)d->n_dofs * sizeof(DevDof);
+    auto pickWpb = [&](size_t perWorld, int& wpb, size_t& bytes) {
+      int best = 0, bestWaves = 0;
+      for (int w = 1; w <= TREE_WPB_MAX; w++) {
+        const size_t need = modelLds + (size_t)w * perWorld;
+        if (need > 160u * 1024u) break;
+        int waves = (int)((160u * 1024u) / need) * w;
+        if (waves > 8) waves = 8;   // these kernels use 256 VGPRs: two wavefronts per SIMD is all a CU can hold
+        if (waves > bestWaves) { bestWaves = waves; best = w; }
+      }
+      wpb = best; bytes = modelLds + (size_t)best * perWorld;
+    };
+    pickWpb((size_t)coopWorldDoubles<PROF_FWD>(nbp, nFree) * sizeof(double), m->wpbFwd, m->ldsFwd);
+    pickWpb((size_t)coopWorldDoubles<PROF_BWD>(nbp, nFree) * sizeof(double), m->wpbBwd, m->ldsBwd);
+    const size_t coopTreeLds = (m->wpbFwd > 0 && m->wpbBwd > 0) ? 0 : (size_t)1 << 30;
     if (const char* e3 = getenv("NBL_COOP")) coop = atoi(e3) != 0;
     if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
     if (coopTreeLds > 160u * 1024u) coopTree = false;
@@ -251,7 +271,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
   if (const char* e2 = getenv("NBL_LCP_LANES")) m->lcpLanes = atoi(e2);
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
-  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0; m->mdl.pad2 = 0;
+  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0;
   m->mdl.maxLevel = 0; m->mdl.maxRank = 0;
   for (const DevBody& hbI : hb) { if (hbI.level > m->mdl.maxLevel) m->mdl.maxLevel = hbI.level; if (hbI.parent >= 0 && hbI.rank > m->mdl.maxRank) m->mdl.maxRank = hbI.rank; }
   for (int k = 0; k < 3; k++) m->mdl.gravity[k] = d->gravity[k];
@@ -339,8 +359,8 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
   m->timingNow = m->timing && (m->fwdCalls++ % m->timingPeriod == 0);
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
-  const size_t treeLds = (size_t)m->nb * sizeof(DevBody) + (size_t)m->n * sizeof(DevDof) + (size_t)TREE_WPB * WS_LDS_SLOTS * m->mdl.nbp * sizeof(double);
-  const dim3 treeGrid((unsigned)((B + TREE_WPB - 1) / TREE_WPB)), treeBlock(64 * TREE_WPB);
+  const size_t treeLds = m->ldsFwd;
+  const dim3 treeGrid((unsigned)((B + m->wpbFwd - 1) / std::max(1, m->wpbFwd))), treeBlock(64 * std::max(1, m->wpbFwd));
   if (m->coopTree && (saved || !m->hasContact))
     TIMED(K_FWD_COOP, hipLaunchKernelGGL(k_step_forward_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies, m->dDofs, B,
                                          state, action, next_state, (double*)saved, status, m->lay, m->hasContact ? 1 : 0));
@@ -390,8 +410,8 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   m->timingNow = m->timing && (m->bwdCalls++ % m->timingPeriod == 0);
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
-  const size_t treeLds = (size_t)m->nb * sizeof(DevBody) + (size_t)m->n * sizeof(DevDof) + (size_t)TREE_WPB * WS_LDS_SLOTS * m->mdl.nbp * sizeof(double);
-  const dim3 treeGrid((unsigned)((B + TREE_WPB - 1) / TREE_WPB)), treeBlock(64 * TREE_WPB);
+  const size_t treeLds = m->ldsBwd;
+  const dim3 treeGrid((unsigned)((B + m->wpbBwd - 1) / std::max(1, m->wpbBwd))), treeBlock(64 * std::max(1, m->wpbBwd));
   const dim3 t2lGrid((unsigned)((m->lay.treeRows + 31) / 32), (unsigned)((B + 31) / 32));
   SavedLayout layLanes = m->lay;   // for the one-world-per-lane sweep fed by k_tree_to_lanes: kept slots in the workspace
   layLanes.treeRows = 0; layLanes.treeNbp = 0;
