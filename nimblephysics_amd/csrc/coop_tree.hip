@@ -245,12 +245,16 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_step_forward_coop(DevMode
     // BodyNode::getSpatialVelocity after integrateVelocities -> WS_VTW, for b = -J^T V of the contact rows.  Each lane
     // reads back the new velocities of its own body's DOFs, which it stored itself (program order of one lane).
     const double* nv = next + (int64_t)mdl.n * B;
-    forBodiesDown(c, [&](int i) {
-      const DevBody& bd = bodies[i];
-      V6 V = jointTwist(bd, nv, B, b);
-      if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_VTW));
-      stV6(c, i, WS_VTW, V);
+    const int i = c.lane;
+    const bool on = i < c.nb;
+    const T12 TW = on ? ldTAt(c, i, WS_TW) : T12();
+    V6 Vw = on ? AdT(TW, jointTwist(bodies[i], nv, B, b)) : zero6();   // own joint twist, world frame
+    forBodiesDown(c, [&](int) {                                          // world twists are prefix sums down the tree
+      if (bodies[i].parent >= 0) Vw = Vw + ldV6(c, bodies[i].parent, WS_W);
+      stV6(c, i, WS_W, Vw);
     });
+    if (on) stV6(c, i, WS_VTW, AdInvT(TW, Vw));
+    waveFence();
   }
   if (saved && lay.treeRows > 0) coopStoreTree(c, saved, lay);
   if (status && c.lane == 0) status[b] = 0u;
