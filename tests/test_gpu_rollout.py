@@ -79,3 +79,34 @@ def test_rollout_vs_oracle_T_steps():
     assert np.abs(ys.detach().cpu().numpy()[:, -1] - xs[-1]).max() <= 1e-7 * np.abs(xs[-1]).max()
     assert np.abs(st.grad.cpu().numpy() - g).max() <= 1e-6 * np.abs(g).max()
     assert np.abs(at.grad.cpu().numpy() - gas).max() <= 1e-6 * max(np.abs(gas).max(), 1e-30)
+
+
+def test_cfg5_length_rollout_T64_vs_oracle():
+    """cfg5's trajectory length (T = 64, loss = |q_T|^2 + |v_T|^2) on a small batch: 64 chained GPU steps and 64 chained
+    backward steps against the oracle's chain.  Errors of a chaotic contact trajectory grow with T, hence 1e-5 here."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    from oracle import OracleWorld
+    B, T = 16, 64
+    md, s0, a0 = contact_inputs("atlas20", B, 33)
+    acts = np.repeat(a0[:, None, :], T, 1)
+    world = na.World(md, device="cuda:0")
+    st = torch.tensor(s0, device="cuda:0", requires_grad=True)
+    at = torch.tensor(acts, device="cuda:0", requires_grad=True)
+    ys = rollout(world, st, at, warm_start=False)
+    (ys[:, -1] ** 2).sum().backward()
+    assert np.all(world.rollout_status.cpu().numpy() & 0x1)           # in contact all the way
+    ow = OracleWorld(md)
+    xs = [s0]
+    for t in range(T):
+        xs.append(ow.step_batch(xs[-1], acts[:, t], np.zeros_like(s0), threads=4)["next"])
+    g = 2.0 * xs[-1]
+    gas = []
+    for t in range(T - 1, -1, -1):
+        r = ow.step_batch(xs[t], acts[:, t], g, threads=4)
+        g = r["grad_state"]; gas.append(r["grad_action"])
+    gas = np.stack(gas[::-1], 1)
+    assert np.abs(ys.detach().cpu().numpy()[:, -1] - xs[-1]).max() <= 1e-6 * np.abs(xs[-1]).max()
+    assert np.abs(st.grad.cpu().numpy() - g).max() <= 1e-5 * np.abs(g).max()
+    assert np.abs(at.grad.cpu().numpy() - gas).max() <= 1e-5 * max(np.abs(gas).max(), 1e-30)
