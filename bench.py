@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--workload", default="atlas20_contact")
     ap.add_argument("--joint-noise", type=float, default=0.002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=0, help="slices of the per-GPU batch, each a World on its own HIP stream (0 = auto: 4 from 4096 worlds, 2 from 2048)")
     ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: timed region without the per-kernel HIP events")
     args = ap.parse_args()
@@ -117,29 +118,47 @@ def main():
 
     B = args.batch
     md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, args.joint_noise)
-    world = na.World(md, device=dev)
+    # The kernels of the step are latency / occupancy bound, so the forward of one slice of the batch overlaps the backward
+    # of another when every slice owns a HIP stream (+16 % at B = 4096; the library cannot do this inside a call because a
+    # call must join before it returns): one World per slice, all slices of one step issued before the next step.
+    nstreams = args.streams if args.streams > 0 else (4 if B >= 4096 else (2 if B >= 2048 else 1))
+    if args.rollout > 0:
+        nstreams = 1
+    per = (B + nstreams - 1) // nstreams
+    bounds = [(i * per, min(B, (i + 1) * per)) for i in range(nstreams) if i * per < B]
+    worlds = [na.World(md, device=dev) for _ in bounds]
+    world = worlds[0]
     n, k = world.n, world.k
-    state0 = world.to_soa(torch.tensor(s_np, device=dev))
-    action = world.to_soa(torch.tensor(a_np, device=dev))
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in bounds[1:]]
+    state0 = [w.to_soa(torch.tensor(s_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
+    action = [w.to_soa(torch.tensor(a_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
+    torch.cuda.synchronize(dev)
 
     def run(T):
-        ga_total = torch.zeros((k, B), dtype=torch.float64, device=dev)
-        status = None
+        ga_total = [torch.zeros((k, hi - lo), dtype=torch.float64, device=dev) for (lo, hi) in bounds]
+        status = [None] * len(bounds)
         if args.rollout > 0:      # cfg5-style: T-step trajectory, loss = |q_T|^2 + |v_T|^2, one shared control vector
             for _ in range(T):
-                states, sv, st_all = world.rollout_soa(state0, action, T=args.rollout, want_saved=True, warm_start=True)
+                states, sv, st_all = world.rollout_soa(state0[0], action[0], T=args.rollout, want_saved=True, warm_start=True)
                 gst = torch.zeros_like(states)
                 gst[-1] = 2.0 * states[-1]
                 g0, ga = world.rollout_backward_soa(sv, gst)
-                ga_total += ga.sum(0)
-                status = st_all[-1]
-            return shared_parameter_grad(ga_total), status
+                ga_total[0] += ga.sum(0)
+                status[0] = st_all[-1]
+            return shared_parameter_grad(ga_total[0]), status[0]
+        main = streams[0]
+        for st in streams[1:]:
+            st.wait_stream(main)
         for _ in range(T):
-            world.reset_lcp_cache()                                  # cold start: guess + solve every step
-            nxt, sv, status = world.step_soa(state0, action, want_saved=True)
-            gs, ga = world.backward_soa(sv, 2.0 * nxt)               # d/ds' of |s'|^2
-            ga_total += ga                                           # the control vector is shared by all steps
-        return shared_parameter_grad(ga_total), status               # ONE all-gather per timed region
+            for i, (w, st) in enumerate(zip(worlds, streams)):
+                with torch.cuda.stream(st):
+                    w.reset_lcp_cache()                                        # cold start: guess + solve every step
+                    nxt, sv, status[i] = w.step_soa(state0[i], action[i], want_saved=True)
+                    gs, ga = w.backward_soa(sv, 2.0 * nxt)                     # d/ds' of |s'|^2
+                    ga_total[i] += ga                                          # the control vector is shared by all steps
+        for st in streams[1:]:
+            main.wait_stream(st)
+        return shared_parameter_grad(torch.cat(ga_total, 1)), torch.cat(status)   # ONE all-gather per timed region
 
     def sync():
         if world_size > 1:
@@ -177,11 +196,13 @@ def main():
         # Per launch of the step (all kernels of one forward + one backward): that figure x B worlds.
         dom = max(kern, key=kern.get)
         alg_step_bytes = (104 * n + 16 * m_rows) * B
+        slices = len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))   # the batch is processed as slices on overlapping HIP streams:
+        alg_launch_bytes = alg_step_bytes / slices  # one kernel launch covers B / slices worlds (timed on slice 0)
         step_kernel_ms = sum(kern.values())
         # the dominant kernel is credited with the whole step's algorithmic traffic share it is responsible for:
         # state/cotangent I/O is spread over the kernels, so the conservative per-kernel figure is
         # (algorithmic bytes of one step) / (duration of the dominant kernel) -- an upper bound on its fraction.
-        achieved = alg_step_bytes / (kern[dom] * 1e-3) / 1e9
+        achieved = alg_launch_bytes / (kern[dom] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -202,9 +223,10 @@ def main():
                        "collective": "1 all-gather of the shared-control gradient per timed region"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_step_launch": alg_step_bytes, "avg_launch_ms": kern[dom],
+                         "algorithmic_bytes_per_launch": alg_launch_bytes, "worlds_per_launch": B // slices, "stream_slices": slices,
+                         "algorithmic_bytes_per_step": alg_step_bytes, "avg_launch_ms": kern[dom],
                          "kernels_avg_ms": kern, "step_kernel_ms": step_kernel_ms, "timed_every_nth_step": timing_period,
-                         "whole_step_achieved_GBs": alg_step_bytes / (step_kernel_ms * 1e-3) / 1e9,
+                         "whole_step_achieved_GBs": alg_step_bytes / (elapsed / args.steps) / 1e9,
                          "note": "the path is fp64-ALU/latency bound, not HBM bound (~1e2-1e3 flop/byte, SURVEY.md 8d); "
                                  "the HBM fraction is reported because north_star asks for it"},
         }

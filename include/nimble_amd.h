@@ -205,6 +205,11 @@ int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, 
  * (power of two <= 16); 0 = default (16 below 65536 worlds, else 64 / 16).  Results do not depend
  * on it (one world per lane either way); environment NBL_TREE_LANES / NBL_LCP_LANES set the initial value. */
 int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes);
+/* Batch slicing: the worlds of a call are processed as `slices` contiguous ranges whose kernels overlap on internal HIP
+ * streams forked from / joined into the caller's stream (0 = default = 1; max 8; environment NBL_SLICES).  Results do not
+ * depend on it; on MI355X it does not pay inside one call (the per-call join), see DESIGN.md.  nbl_slices_for: the number a call with B worlds will use. */
+int32_t nbl_set_slices(nbl_model* m, int32_t slices);
+int32_t nbl_slices_for(const nbl_model* m, int64_t B);
 /* enabled = 0: off (and reset); 1: HIP events around every kernel launch; N > 1: around the launches of every N-th forward /
  * backward call only (sampling keeps the perturbation of a timed region below 1 %). */
 int32_t nbl_set_timing(nbl_model* m, int32_t enabled);

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(64) void k_bwd_recompute(DevModel mdl, const DevBod
                                                       const double* __restrict__ saved, SavedLayout lay,
                                                       const double* __restrict__ gnext, double* __restrict__ ws,
                                                       double* __restrict__ lws) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, const_cast<double*>(saved), &lay);
   const int n = mdl.n;
   const double* tau = saved + (int64_t)2 * n * B;
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const
                                                       const double* __restrict__ gnext, double* __restrict__ ws,
                                                       double* __restrict__ lws) {
   extern __shared__ __attribute__((aligned(16))) double ldsq[];   // Q factor + Cholesky factor, LCP_LANES worlds (see k_contact_solve)
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   LaneMem QL; QL.base = ldsq; QL.B = (int)blockDim.x; QL.b = threadIdx.x;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
   const int n = mdl.n;
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
                                                       int64_t B, double* __restrict__ saved, SavedLayout lay,
                                                       double* __restrict__ ws, double* __restrict__ lws,
                                                       uint32_t* __restrict__ gradStatus) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
   const int n = mdl.n;
   LaneMem L; L.base = lws; L.B = B; L.b = b;
@@ -392,8 +392,8 @@ __global__ __launch_bounds__(64) void k_bwd_final(DevModel mdl, const DevBody* _
                                                   double* __restrict__ gstate, double* __restrict__ gaction,
                                                   double* __restrict__ ws, const double* __restrict__ lws, int treeInWs) {
   (void)treeInWs;   // kept slots come from the workspace (k_tree_to_lanes) when lay carries no tree block
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, const_cast<double*>(saved), &lay);
   const int n = mdl.n;
   const double* q = saved;

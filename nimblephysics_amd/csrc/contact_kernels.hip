@@ -39,8 +39,8 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
                                                        const DevContactModel* __restrict__ cm, int64_t B,
                                                        double* __restrict__ saved, SavedLayout lay,
                                                        uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);
   int nC = 0;
   bool overflow = false, edge = false;
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody
                                                      const DevContactModel* __restrict__ cm, int64_t B,
                                                      double* __restrict__ saved, SavedLayout lay, double* __restrict__ ws,
                                                      double* __restrict__ lws) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);
   LaneMem L;
   L.base = lws; L.B = B; L.b = b;
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(LCP_LANES) void k_contact_solve(DevModel mdl, const
                                                       double* __restrict__ lws, int32_t* __restrict__ failList,
                                                       uint32_t* __restrict__ failCount) {
   extern __shared__ __attribute__((aligned(16))) double ldsq[];
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   const int n = mdl.n;
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, cons
   __shared__ CoopLds S;
   const DevWave w;
   const int ln = w.lane();
-  const int64_t b = coopWorld(blockIdx.x, gridDim.x);
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
+  if (b >= mdl.b1) return;
   const int n = mdl.n;
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   __shared__ CoopLds S;
   const DevWave w;
   const int ln = w.lane();
-  const int64_t b = coopWorld(blockIdx.x, gridDim.x);
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
+  if (b >= mdl.b1) return;
   if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;   // k_bwd_recompute: no clamping row in this world
   const int n = mdl.n;
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   double* acc = Vw + 6 * nb;
   const DevWave w;
   const int ln = w.lane();
-  const int64_t b = coopWorld(blockIdx.x, gridDim.x);
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
+  if (b >= mdl.b1) return;
   const int nC = (int)svAt(saved, lay.nc, B, b);
   const int m = 3 * nC;
   if (m == 0) return;
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   extern __shared__ __attribute__((aligned(16))) double ldsB[];
   const DevWave w;
   const int ln = w.lane();
-  const int64_t b = coopWorld(blockIdx.x, gridDim.x);
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
+  if (b >= mdl.b1) return;
   if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;
   const int nb = mdl.nb;
   double* FW = ldsB;

@@ -36,7 +36,7 @@ DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __res
   }
   __syncthreads();   // the only workgroup-wide barrier: from here on every wavefront runs on its own
   const int wv = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-  const int64_t b = coopWorld(blockIdx.x, gridDim.x) * wpb + wv;
+  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x) * wpb + wv;
   const int perWorld = coopWorldDoubles<P>(mdl.nbp, mdl.nFree);
   c.bodies = lb; c.dofs = ld; c.lds = st + (size_t)wv * perWorld; c.ldsFree = c.lds + coopRows<P>() * mdl.nbp;
   c.nbp = mdl.nbp; c.B = B; c.b = b;
@@ -47,7 +47,7 @@ DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __res
   c.level = on ? lb[c.lane].level : -1;
   c.rank = on ? lb[c.lane].rank : -1;
   c.maxLevel = mdl.maxLevel; c.maxRank = mdl.maxRank;
-  return b < B;
+  return b < mdl.b1;
 }
 DEV double* treeBlock(double* saved, const SavedLayout& lay, int64_t B, int64_t b) {
   return saved + ((int64_t)lay.total + lay.dense) * B + b * (int64_t)lay.treeRows;
@@ -484,20 +484,20 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel m
 // for the one-world-per-lane k_bwd_final / k_step_backward (the heavy reverse sweep is VALU-issue bound with lane = body:
 // 3 of 64 lanes busy; one world per lane stays the better shape for it).  LDS-tiled transpose, both sides coalesced.
 __global__ __launch_bounds__(256) void k_tree_to_lanes(const double* __restrict__ saved, SavedLayout lay, int nb, int64_t B,
-                                                       double* __restrict__ ws) {
+                                                       int64_t b0, int64_t b1, double* __restrict__ ws) {
   __shared__ double tile[32][33];
   const double* blk = saved + ((int64_t)lay.total + lay.dense) * B;
   const int64_t cols = lay.treeRows;                     // entries per world
-  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;   // c: entry, r: world
+  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = b0 + (int64_t)blockIdx.y * 32;   // c: entry, r: world
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {
     const int64_t r = r0 + k, cc = c0 + tx;
-    if (r < B && cc < cols) tile[k][tx] = blk[r * cols + cc];
+    if (r < b1 && cc < cols) tile[k][tx] = blk[r * cols + cc];
   }
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const int64_t cc = c0 + k, r = r0 + tx;
-    if (r < B && cc < cols) {
+    if (r < b1 && cc < cols) {
       const int slot = (int)(cc / lay.treeNbp), body = (int)(cc % lay.treeNbp);
       if (body < nb) ws[((int64_t)body * WS_PER_BODY + slot) * B + r] = tile[tx][k];
     }

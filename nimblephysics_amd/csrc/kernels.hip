@@ -441,8 +441,8 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
                                                      const double* __restrict__ state, const double* __restrict__ action,
                                                      double* __restrict__ next, double* __restrict__ saved,
                                                      uint32_t* __restrict__ status, double* __restrict__ ws, SavedLayout lay) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
   stepForwardCore(c, state, action, next, saved, lay);
   if (status) status[b] = 0u;
@@ -610,8 +610,8 @@ __global__ __launch_bounds__(64) void k_step_backward(DevModel mdl, const DevBod
                                                       const double* __restrict__ gnext,
                                                       double* __restrict__ gstate, double* __restrict__ gaction,
                                                       double* __restrict__ ws, int treeInWs) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, const_cast<double*>(saved), &lay);
   const int n = mdl.n;
   const double* q = saved;

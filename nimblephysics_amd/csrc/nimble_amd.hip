@@ -34,6 +34,7 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(NBL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+constexpr int NBL_MAX_SLICES = 8;
 enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
@@ -58,6 +59,10 @@ struct nbl_model {
   bool timingNow = false;   // ... and this call is one of the sampled ones
   int timingPeriod = 1;     // every timingPeriod-th forward / backward call carries HIP events
   int64_t fwdCalls = 0, bwdCalls = 0;
+  int slices = 0;                    // batch slices over HIP streams (0 = auto), nbl_set_slices / NBL_SLICES
+  std::vector<hipStream_t> side;     // internal streams of slices 1..
+  std::vector<hipEvent_t> sideDone;
+  hipEvent_t fork = nullptr;
   int wpbFwd = 4, wpbBwd = 4;        // worlds per workgroup of the lane = body tree kernels (chosen for LDS occupancy)
   size_t ldsFwd = 0, ldsBwd = 0;     // dynamic LDS of those workgroups
   bool coopCascade = true;           // NBL_COOP_CASCADE=0: stages 1-3 one world per lane
@@ -71,6 +76,51 @@ struct nbl_model {
   double kMs[K_COUNT] = {0};
   int64_t kCount[K_COUNT] = {0};
 };
+
+// ---- batch slicing over HIP streams ----------------------------------------------------------------------------------
+// A call can process its worlds as several contiguous slices whose kernels overlap on internal HIP streams (slice 0 on the
+// caller's stream, the others fork from / join into it with events, so the call keeps stream semantics and stays capturable
+// in a hipGraph).  Measured on MI355X at B = 4096: NO gain inside one call (1 slice 5.93, 2 slices 5.88, 4 slices 5.35 M/s) -
+// the join at the end of every forward / backward call is what prevents the useful overlap, which is between the FORWARD of
+// one slice and the BACKWARD of another: callers that own the whole fwd+bwd loop get +16 % by running one World per slice on
+// its own stream (bench.py --streams, tools/batch_slicing_experiment.py).  Default: 1 slice; NBL_SLICES / nbl_set_slices.
+static int slicesFor(const nbl_model* m, int64_t B) {
+  int sl = m->slices > 0 ? m->slices : 1;
+  if (sl > NBL_MAX_SLICES) sl = NBL_MAX_SLICES;
+  while (sl > 1 && B / sl < 256) sl--;
+  return sl;
+}
+static int32_t ensureSideStreams(nbl_model* m, int need) {
+  while ((int)m->side.size() < need) {
+    hipStream_t st; hipEvent_t ev;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    m->side.push_back(st); m->sideDone.push_back(ev);
+  }
+  if (!m->fork) HIP_TRY(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
+  return NBL_OK;
+}
+// run fn(slice index, first world, one-past-last world, stream) for every slice, fork/join around the caller's stream
+template <class Fn>
+static int32_t forSlices(nbl_model* m, int64_t B, hipStream_t s, Fn fn) {
+  const int sl = slicesFor(m, B);
+  if (sl > 1) {
+    const int32_t rc = ensureSideStreams(m, sl - 1);
+    if (rc != NBL_OK) return rc;
+    HIP_TRY(hipEventRecord(m->fork, s));
+  }
+  const int64_t per = (((B + sl - 1) / sl) + 15) & ~(int64_t)15;
+  for (int i = 0; i < sl; i++) {
+    const int64_t b0 = (int64_t)i * per, b1 = std::min(B, b0 + per);
+    if (b0 >= b1) break;
+    hipStream_t st = i == 0 ? s : m->side[i - 1];
+    if (i > 0) HIP_TRY(hipStreamWaitEvent(st, m->fork, 0));
+    const int32_t rc = fn(i, b0, b1, st);
+    if (rc != NBL_OK) return rc;
+    if (i > 0) { HIP_TRY(hipEventRecord(m->sideDone[i - 1], st)); HIP_TRY(hipStreamWaitEvent(s, m->sideDone[i - 1], 0)); }
+  }
+  return NBL_OK;
+}
 
 extern "C" {
 
@@ -271,7 +321,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
   if (const char* e2 = getenv("NBL_LCP_LANES")) m->lcpLanes = atoi(e2);
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
-  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0;
+  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0; m->mdl.b0 = 0; m->mdl.b1 = 0;
+  if (const char* e9 = getenv("NBL_SLICES")) m->slices = atoi(e9);
   m->mdl.maxLevel = 0; m->mdl.maxRank = 0;
   for (const DevBody& hbI : hb) { if (hbI.level > m->mdl.maxLevel) m->mdl.maxLevel = hbI.level; if (hbI.parent >= 0 && hbI.rank > m->mdl.maxRank) m->mdl.maxRank = hbI.rank; }
   for (int k = 0; k < 3; k++) m->mdl.gravity[k] = d->gravity[k];
@@ -303,6 +354,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
 void nbl_model_destroy(nbl_model* m) {
   if (!m) return;
   for (auto& t : m->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+  for (auto st : m->side) hipStreamDestroy(st);
+  for (auto ev : m->sideDone) hipEventDestroy(ev);
+  if (m->fork) hipEventDestroy(m->fork);
   if (m->dBodies) hipFree(m->dBodies);
   if (m->dDofs) hipFree(m->dDofs);
   if (m->dContact) hipFree(m->dContact);
@@ -355,48 +409,56 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
   if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved record (it doubles as the contact scratch)");
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
-  hipStream_t s = (hipStream_t)stream;
   m->timingNow = m->timing && (m->fwdCalls++ % m->timingPeriod == 0);
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
-  dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
-  const size_t treeLds = m->ldsFwd;
-  const dim3 treeGrid((unsigned)((B + m->wpbFwd - 1) / std::max(1, m->wpbFwd))), treeBlock(64 * std::max(1, m->wpbFwd));
-  if (m->coopTree && (saved || !m->hasContact))
-    TIMED(K_FWD_COOP, hipLaunchKernelGGL(k_step_forward_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies, m->dDofs, B,
-                                         state, action, next_state, (double*)saved, status, m->lay, m->hasContact ? 1 : 0));
-  else
-    TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, state, action, next_state,
-                                    (double*)saved, status, (double*)workspace, m->lay));
-  if (m->hasContact) {
-    double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
-    TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
-                                       status, (double*)workspace, m->coopTree ? 0 : 1));
-    if (m->coop) {
-      const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 18 * (size_t)m->nb) * sizeof(double);   // acc, Fw, Sw/AISw/Vw
-      TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)B), dim3(64), rowsLds, s, m->mdl, m->dBodies, m->dContact, B,
-                                            (double*)saved, m->lay, (const double*)workspace));
-    } else
-      TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, m->mdl, m->dBodies, m->dContact, B, (double*)saved,
-                                     m->lay, (double*)workspace, lws));
-    dim3 lgrid((unsigned)((B + ll - 1) / ll)), lblock(ll);
-    const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
-    int32_t* failList = (int32_t*)(lws + (size_t)LB_TOTAL * (size_t)B);
-    uint32_t* failCount = (uint32_t*)(failList + B);
-    HIP_TRY(hipMemsetAsync(failCount, 0, sizeof(uint32_t), s));
-    if (m->coop)
-      TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)B), dim3(64), 0, s, m->mdl, m->dContact, B,
-                                             (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
-                                             failList, failCount));
+  double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
+  int32_t* failListAll = (int32_t*)(lws + (size_t)LB_TOTAL * (size_t)B);
+  uint32_t* failCountAll = (uint32_t*)(failListAll + B);
+  const int32_t rc = forSlices(m, B, (hipStream_t)stream, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    const int64_t cnt = b1 - b0;
+    DevModel mdl = m->mdl;
+    mdl.b0 = b0; mdl.b1 = b1;
+    dim3 grid((unsigned)((cnt + tl - 1) / tl)), block(tl);
+    const size_t treeLds = m->ldsFwd;
+    const dim3 treeGrid((unsigned)((cnt + m->wpbFwd - 1) / std::max(1, m->wpbFwd))), treeBlock(64 * std::max(1, m->wpbFwd));
+    if (m->coopTree && (saved || !m->hasContact))
+      TIMED(K_FWD_COOP, hipLaunchKernelGGL(k_step_forward_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies, m->dDofs, B,
+                                           state, action, next_state, (double*)saved, status, m->lay, m->hasContact ? 1 : 0));
     else
-      TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, ldsBytes, s, m->mdl, m->dContact, B, (double*)saved,
-                                      m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws, failList, failCount));
-    if (m->coop && m->coopCascade)
-      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_coop, dim3((unsigned)B), dim3(64), 0, s, m->mdl, m->dContact, B,
-                                               (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
-    else
-      TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, m->mdl, m->dContact, B,
-                                        (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
-  }
+      TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, state, action, next_state,
+                                      (double*)saved, status, (double*)workspace, m->lay));
+    if (m->hasContact) {
+      TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
+                                         status, (double*)workspace, m->coopTree ? 0 : 1));
+      if (m->coop) {
+        const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 18 * (size_t)m->nb) * sizeof(double);   // acc, Fw, Sw/AISw/Vw
+        TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)cnt), dim3(64), rowsLds, s, mdl, m->dBodies, m->dContact, B,
+                                              (double*)saved, m->lay, (const double*)workspace));
+      } else
+        TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, mdl, m->dBodies, m->dContact, B, (double*)saved,
+                                         m->lay, (double*)workspace, lws));
+      dim3 lgrid((unsigned)((cnt + ll - 1) / ll)), lblock(ll);
+      const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
+      int32_t* failList = failListAll + b0;          // the slice's own compacted list and counter
+      uint32_t* failCount = failCountAll + si;
+      HIP_TRY(hipMemsetAsync(failCount, 0, sizeof(uint32_t), s));
+      if (m->coop)
+        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+                                               (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
+                                               failList, failCount));
+      else
+        TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, ldsBytes, s, mdl, m->dContact, B, (double*)saved,
+                                          m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws, failList, failCount));
+      if (m->coop && m->coopCascade)
+        TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+                                                 (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+      else
+        TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, mdl, m->dContact, B,
+                                            (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+    }
+    return NBL_OK;
+  });
+  if (rc != NBL_OK) return rc;
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
@@ -406,62 +468,68 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   if (!m || !saved || !grad_next_state || !grad_state || !grad_action || !workspace) return fail(NBL_E_BADARG, "null argument");
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
-  hipStream_t s = (hipStream_t)stream;
   m->timingNow = m->timing && (m->bwdCalls++ % m->timingPeriod == 0);
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
-  dim3 grid((unsigned)((B + tl - 1) / tl)), block(tl);
-  const size_t treeLds = m->ldsBwd;
-  const dim3 treeGrid((unsigned)((B + m->wpbBwd - 1) / std::max(1, m->wpbBwd))), treeBlock(64 * std::max(1, m->wpbBwd));
-  const dim3 t2lGrid((unsigned)((m->lay.treeRows + 31) / 32), (unsigned)((B + 31) / 32));
   SavedLayout layLanes = m->lay;   // for the one-world-per-lane sweep fed by k_tree_to_lanes: kept slots in the workspace
   layLanes.treeRows = 0; layLanes.treeNbp = 0;
-  if (!m->hasContact && m->coopTree && !m->coopFinal) {
-    TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, (double*)workspace));
-    TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
-                                    grad_next_state, grad_state, grad_action, (double*)workspace, 1));
-  } else if (!m->hasContact && m->coopTree) {
-    TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies, m->dDofs, B,
-                                               (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
-                                               (const double*)nullptr));
-  } else if (!m->hasContact) {
-    TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
-                                    grad_next_state, grad_state, grad_action, (double*)workspace, 0));
-  } else {
-    double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
-    double* sv = (double*)const_cast<void*>(saved);
-    if (m->coopTree)
-      TIMED(K_RECOMPUTE_COOP, hipLaunchKernelGGL(k_bwd_recompute_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies,
-                                                 m->dDofs, B, (const double*)saved, m->lay, grad_next_state, lws));
-    else
-      TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B,
-                                            (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
-    dim3 lgrid((unsigned)((B + ll - 1) / ll)), lblock(ll);
-    const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
-    if (m->coop)
-      TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop, dim3((unsigned)B), dim3(64), 0, s, m->mdl, m->dContact, B, sv,
-                                             m->lay, grad_next_state, lws));
-    else
-      TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, m->mdl, m->dBodies, m->dDofs, m->dContact,
-                                      B, sv, m->lay, grad_next_state, (double*)workspace, lws));
-    if (m->coop) {
-      const size_t bLds = ((size_t)m->nb * 108 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS)) * sizeof(double);   // FW D {tmp | TF}
-      TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)B), dim3(64), bLds, s, m->mdl, m->dBodies, m->dContact, B,
-                                             sv, m->lay, (const double*)workspace, lws));
-    } else
-      TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
-                                      m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
-    if (m->coopTree && !m->coopFinal) {
-      TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, (double*)workspace));
-      TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
-                                            grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 1));
-    } else if (m->coopTree)
-      TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, m->mdl, m->dBodies, m->dDofs,
-                                                 B, (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
-                                                 (const double*)lws));
-    else
-      TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, m->mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
-                                            grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 0));
-  }
+  double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
+  double* sv = (double*)const_cast<void*>(saved);
+  const int32_t rc = forSlices(m, B, (hipStream_t)stream, [&](int, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    const int64_t cnt = b1 - b0;
+    DevModel mdl = m->mdl;
+    mdl.b0 = b0; mdl.b1 = b1;
+    dim3 grid((unsigned)((cnt + tl - 1) / tl)), block(tl);
+    const size_t treeLds = m->ldsBwd;
+    const dim3 treeGrid((unsigned)((cnt + m->wpbBwd - 1) / std::max(1, m->wpbBwd))), treeBlock(64 * std::max(1, m->wpbBwd));
+    const dim3 t2lGrid((unsigned)((m->lay.treeRows + 31) / 32), (unsigned)((cnt + 31) / 32));
+    if (!m->hasContact && m->coopTree && !m->coopFinal) {
+      TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace));
+      TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
+                                      grad_next_state, grad_state, grad_action, (double*)workspace, 1));
+    } else if (!m->hasContact && m->coopTree) {
+      TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies, m->dDofs, B,
+                                                 (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
+                                                 (const double*)nullptr));
+    } else if (!m->hasContact) {
+      TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
+                                      grad_next_state, grad_state, grad_action, (double*)workspace, 0));
+    } else {
+      if (m->coopTree)
+        TIMED(K_RECOMPUTE_COOP, hipLaunchKernelGGL(k_bwd_recompute_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies,
+                                                   m->dDofs, B, (const double*)saved, m->lay, grad_next_state, lws));
+      else
+        TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B,
+                                              (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
+      dim3 lgrid((unsigned)((cnt + ll - 1) / ll)), lblock(ll);
+      const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
+      if (m->coop)
+        TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
+                                               m->lay, grad_next_state, lws));
+      else
+        TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, mdl, m->dBodies, m->dDofs, m->dContact,
+                                          B, sv, m->lay, grad_next_state, (double*)workspace, lws));
+      if (m->coop) {
+        const size_t bLds = ((size_t)m->nb * 108 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS)) * sizeof(double);   // FW D {tmp | TF}
+        TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
+                                               sv, m->lay, (const double*)workspace, lws));
+      } else
+        TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
+                                          m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
+      if (m->coopTree && !m->coopFinal) {
+        TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace));
+        TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
+                                              grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 1));
+      } else if (m->coopTree)
+        TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies, m->dDofs,
+                                                   B, (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
+                                                   (const double*)lws));
+      else
+        TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
+                                              grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 0));
+    }
+    return NBL_OK;
+  });
+  if (rc != NBL_OK) return rc;
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
@@ -545,6 +613,14 @@ int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, 
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
+
+int32_t nbl_set_slices(nbl_model* m, int32_t slices) {
+  if (!m) return fail(NBL_E_BADARG, "null model");
+  if (slices < 0 || slices > NBL_MAX_SLICES) return fail(NBL_E_BADARG, "slices must be 0 (auto) .. 8");
+  m->slices = slices;
+  return NBL_OK;
+}
+int32_t nbl_slices_for(const nbl_model* m, int64_t B) { return (m && B > 0) ? slicesFor(m, B) : 0; }
 
 int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes) {
   if (!m) return fail(NBL_E_BADARG, "null model");

@@ -244,6 +244,13 @@ class World:
         nxt, _, _ = self.step_soa(self._state, self._action, want_saved=False)
         self._state = nxt
 
+    def set_slices(self, slices: int = 0):
+        """Batch slices over HIP streams (0 = auto); results are independent of it."""
+        check(self._L.nbl_set_slices(self._h, slices), "nbl_set_slices")
+
+    def slices_for(self, B: int) -> int:
+        return self._L.nbl_slices_for(self._h, B)
+
     def set_launch_lanes(self, tree_lanes: int = 0, lcp_lanes: int = 0):
         """Worlds per workgroup (0 = auto); a launch-shape knob, results are independent of it."""
         check(self._L.nbl_set_launch_lanes(self._h, tree_lanes, lcp_lanes), "nbl_set_launch_lanes")
