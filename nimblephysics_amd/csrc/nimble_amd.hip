@@ -84,6 +84,14 @@ struct nbl_model {
 // the join at the end of every forward / backward call is what prevents the useful overlap, which is between the FORWARD of
 // one slice and the BACKWARD of another: callers that own the whole fwd+bwd loop get +16 % by running one World per slice on
 // its own stream (bench.py --streams, tools/batch_slicing_experiment.py).  Default: 1 slice; NBL_SLICES / nbl_set_slices.
+// slices of a rollout: every slice runs ALL its steps on its stream and the slices join only at the end, so the steps of
+// different slices overlap (the per-call join is what makes in-call slicing useless for a single step)
+static int rolloutSlicesFor(const nbl_model* m, int64_t B) {
+  int sl = m->slices > 0 ? m->slices : (B >= 4096 ? 4 : (B >= 2048 ? 2 : 1));
+  if (sl > NBL_MAX_SLICES) sl = NBL_MAX_SLICES;
+  while (sl > 1 && B / sl < 256) sl--;
+  return sl;
+}
 static int slicesFor(const nbl_model* m, int64_t B) {
   int sl = m->slices > 0 ? m->slices : 1;
   if (sl > NBL_MAX_SLICES) sl = NBL_MAX_SLICES;
@@ -102,8 +110,7 @@ static int32_t ensureSideStreams(nbl_model* m, int need) {
 }
 // run fn(slice index, first world, one-past-last world, stream) for every slice, fork/join around the caller's stream
 template <class Fn>
-static int32_t forSlices(nbl_model* m, int64_t B, hipStream_t s, Fn fn) {
-  const int sl = slicesFor(m, B);
+static int32_t forSlices(nbl_model* m, int64_t B, int sl, hipStream_t s, Fn fn) {
   if (sl > 1) {
     const int32_t rc = ensureSideStreams(m, sl - 1);
     if (rc != NBL_OK) return rc;
@@ -402,19 +409,15 @@ static void endTiming(nbl_model* m, hipStream_t s) {
 }
 #define TIMED(kid, launch) do { beginTiming(m, s, kid); launch; endTiming(m, s); } while (0)
 
-int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const double* action, const double* lcp_cache_in,
-                         double* next_state, double* lcp_cache_out, void* saved, uint32_t* status, void* workspace,
-                         size_t workspace_bytes, void* stream) {
-  if (!m || !state || !action || !next_state || !workspace) return fail(NBL_E_BADARG, "null argument");
-  if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved record (it doubles as the contact scratch)");
-  if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
-  if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
-  m->timingNow = m->timing && (m->fwdCalls++ % m->timingPeriod == 0);
+// the kernels of one forward step for the worlds [b0, b1) on stream s (slice si owns fail list / counter si)
+static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_t b1, hipStream_t s, const double* state,
+                             const double* action, const double* lcp_cache_in, double* next_state, double* lcp_cache_out,
+                             void* saved, uint32_t* status, void* workspace) {
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
   int32_t* failListAll = (int32_t*)(lws + (size_t)LB_TOTAL * (size_t)B);
   uint32_t* failCountAll = (uint32_t*)(failListAll + B);
-  const int32_t rc = forSlices(m, B, (hipStream_t)stream, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+
     const int64_t cnt = b1 - b0;
     DevModel mdl = m->mdl;
     mdl.b0 = b0; mdl.b1 = b1;
@@ -456,25 +459,34 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
         TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, mdl, m->dContact, B,
                                             (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
     }
-    return NBL_OK;
+  return NBL_OK;
+}
+
+int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const double* action, const double* lcp_cache_in,
+                         double* next_state, double* lcp_cache_out, void* saved, uint32_t* status, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!m || !state || !action || !next_state || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved record (it doubles as the contact scratch)");
+  if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
+  if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
+  m->timingNow = m->timing && (m->fwdCalls++ % m->timingPeriod == 0);
+  const int32_t rc = forSlices(m, B, slicesFor(m, B), (hipStream_t)stream, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    return launchForward(m, B, si, b0, b1, s, state, action, lcp_cache_in, next_state, lcp_cache_out, saved, status, workspace);
   });
   if (rc != NBL_OK) return rc;
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
 
-int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const double* grad_next_state, double* grad_state,
-                          double* grad_action, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!m || !saved || !grad_next_state || !grad_state || !grad_action || !workspace) return fail(NBL_E_BADARG, "null argument");
-  if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
-  if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
-  m->timingNow = m->timing && (m->bwdCalls++ % m->timingPeriod == 0);
+// the kernels of one backward step for the worlds [b0, b1) on stream s
+static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, hipStream_t s, const void* saved,
+                              const double* grad_next_state, double* grad_state, double* grad_action, void* workspace) {
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   SavedLayout layLanes = m->lay;   // for the one-world-per-lane sweep fed by k_tree_to_lanes: kept slots in the workspace
   layLanes.treeRows = 0; layLanes.treeNbp = 0;
   double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
   double* sv = (double*)const_cast<void*>(saved);
-  const int32_t rc = forSlices(m, B, (hipStream_t)stream, [&](int, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+
     const int64_t cnt = b1 - b0;
     DevModel mdl = m->mdl;
     mdl.b0 = b0; mdl.b1 = b1;
@@ -527,7 +539,17 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
         TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
                                               grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 0));
     }
-    return NBL_OK;
+  return NBL_OK;
+}
+
+int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const double* grad_next_state, double* grad_state,
+                          double* grad_action, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !saved || !grad_next_state || !grad_state || !grad_action || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
+  if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
+  m->timingNow = m->timing && (m->bwdCalls++ % m->timingPeriod == 0);
+  const int32_t rc = forSlices(m, B, slicesFor(m, B), (hipStream_t)stream, [&](int, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    return launchBackward(m, B, b0, b1, s, saved, grad_next_state, grad_state, grad_action, workspace);
   });
   if (rc != NBL_OK) return rc;
   HIP_TRY(hipGetLastError());
@@ -536,10 +558,6 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
 
 // ---- T-step rollout -------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void k_add_inplace(double* __restrict__ dst, const double* __restrict__ src, int64_t count) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < count) dst[i] += src[i];
-}
 size_t alignUp(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
@@ -557,22 +575,46 @@ int32_t nbl_rollout_forward(nbl_model* m, int64_t B, int32_t T, const double* st
   if (B <= 0 || T <= 0) return fail(NBL_E_BADARG, "B and T must be positive");
   if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
   if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved records");
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s0 = (hipStream_t)stream;
   const size_t stepWs = nbl_workspace_bytes(m, B), cacheBytes = alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
   char* base = (char*)workspace;
   double* cache[2] = {(double*)(base + alignUp(stepWs)), (double*)(base + alignUp(stepWs) + cacheBytes)};
   const size_t stateElems = (size_t)2 * m->n * B, savedBytes = nbl_saved_bytes(m, B);
-  HIP_TRY(hipMemcpyAsync(states, state0, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int32_t t = 0; t < T; t++) {
-    const bool warm = m->hasContact && warm_start && t > 0;
-    const int32_t rc = nbl_step_forward(m, B, states + (size_t)t * stateElems, actions + (size_t)t * action_stride,
-                                        warm ? cache[(t + 1) & 1] : nullptr, states + (size_t)(t + 1) * stateElems,
-                                        m->hasContact ? cache[t & 1] : nullptr, saved ? (char*)saved + (size_t)t * savedBytes : nullptr,
-                                        status ? status + (size_t)t * B : nullptr, workspace, stepWs, stream);
-    if (rc != NBL_OK) return rc;
-  }
+  HIP_TRY(hipMemcpyAsync(states, state0, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s0));
+  m->timingNow = false;
+  // slice-major: every slice runs its T steps on its own stream; the slices only join at the end
+  const int32_t rc = forSlices(m, B, rolloutSlicesFor(m, B), s0, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    for (int32_t t = 0; t < T; t++) {
+      const bool warm = m->hasContact && warm_start && t > 0;
+      const int32_t r = launchForward(m, B, si, b0, b1, s, states + (size_t)t * stateElems, actions + (size_t)t * action_stride,
+                                      warm ? cache[(t + 1) & 1] : nullptr, states + (size_t)(t + 1) * stateElems,
+                                      m->hasContact ? cache[t & 1] : nullptr, saved ? (char*)saved + (size_t)t * savedBytes : nullptr,
+                                      status ? status + (size_t)t * B : nullptr, workspace);
+      if (r != NBL_OK) return r;
+    }
+    return NBL_OK;
+  });
+  if (rc != NBL_OK) return rc;
+  HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
+
+namespace {
+__global__ __launch_bounds__(256) void k_add_rows(double* __restrict__ dst, const double* __restrict__ src, int64_t B, int64_t b0,
+                                                  int64_t b1, int rows) {   // dst[r][b] += src[r][b] for b in [b0, b1)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, cnt = b1 - b0;
+  if (i >= cnt * rows) return;
+  const int64_t r = i / cnt, b = b0 + (i - r * cnt);
+  dst[r * B + b] += src[r * B + b];
+}
+__global__ __launch_bounds__(256) void k_copy_rows(double* __restrict__ dst, const double* __restrict__ src, int64_t B, int64_t b0,
+                                                   int64_t b1, int rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, cnt = b1 - b0;
+  if (i >= cnt * rows) return;
+  const int64_t r = i / cnt, b = b0 + (i - r * cnt);
+  dst[r * B + b] = src[r * B + b];
+}
+}  // namespace
 
 int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
                              double* grad_state0, double* grad_actions, void* workspace, size_t workspace_bytes,
@@ -580,21 +622,27 @@ int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* sav
   if (!m || !saved || !grad_states || !grad_state0 || !grad_actions || !workspace) return fail(NBL_E_BADARG, "null argument");
   if (B <= 0 || T <= 0) return fail(NBL_E_BADARG, "B and T must be positive");
   if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s0 = (hipStream_t)stream;
   const size_t stepWs = nbl_workspace_bytes(m, B), cacheBytes = alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
   double* g = (double*)((char*)workspace + alignUp(stepWs) + 2 * cacheBytes);   // running cotangent of states[t+1]
   const size_t stateElems = (size_t)2 * m->n * B, savedBytes = nbl_saved_bytes(m, B), actElems = (size_t)m->k * B;
-  HIP_TRY(hipMemcpyAsync(g, grad_states + (size_t)T * stateElems, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int32_t t = T - 1; t >= 0; t--) {
-    // the kernels of one backward step re-read the incoming cotangent after the first outputs are written, so the
-    // output must not alias it: every step writes into grad_state0 and the running cotangent is copied back
-    const int32_t rc = nbl_step_backward(m, B, (const char*)saved + (size_t)t * savedBytes, g, grad_state0,
-                                         grad_actions + (size_t)t * actElems, workspace, stepWs, stream);
-    if (rc != NBL_OK) return rc;
-    hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((stateElems + 255) / 256)), dim3(256), 0, s, grad_state0,
-                       grad_states + (size_t)t * stateElems, (int64_t)stateElems);
-    if (t > 0) HIP_TRY(hipMemcpyAsync(g, grad_state0, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s));
-  }
+  const int rows = 2 * m->n;
+  m->timingNow = false;
+  const int32_t rc = forSlices(m, B, rolloutSlicesFor(m, B), s0, [&](int, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    const unsigned blocks = (unsigned)(((b1 - b0) * rows + 255) / 256);
+    hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, grad_states + (size_t)T * stateElems, B, b0, b1, rows);
+    for (int32_t t = T - 1; t >= 0; t--) {
+      // the kernels of one backward step re-read the incoming cotangent after the first outputs are written, so the
+      // output must not alias it: every step writes into grad_state0 and the running cotangent is copied back
+      const int32_t r = launchBackward(m, B, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, g, grad_state0,
+                                       grad_actions + (size_t)t * actElems, workspace);
+      if (r != NBL_OK) return r;
+      hipLaunchKernelGGL(k_add_rows, dim3(blocks), dim3(256), 0, s, grad_state0, grad_states + (size_t)t * stateElems, B, b0, b1, rows);
+      if (t > 0) hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, (const double*)grad_state0, B, b0, b1, rows);
+    }
+    return NBL_OK;
+  });
+  if (rc != NBL_OK) return rc;
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
