@@ -169,6 +169,28 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
                           size_t workspace_bytes, void* stream);
 
 /*
+ * Inertia ("mass") parameters: World::tuneMass / setMasses / lossWrtMass
+ * (dart/simulation/World.cpp:1027-1035, 1821-1824; dart/neural/WithRespectToMass.cpp:50-140;
+ *  dart/neural/BackpropSnapshot.cpp:153, 167-179, 580-640).
+ *
+ * nbl_set_body_inertia   replaces the inertial constants of one body (host pointers; com[3]; inertia[6] = Ixx Iyy Izz Ixy
+ *                        Ixz Iyz about the COM, as in nbl_model_desc).  Synchronises the device: call it between steps.
+ * nbl_set_inertia_params registers `count` scalar parameters theta_p: parameter p moves the spatial inertia of body
+ *                        bodies[p] along dG[p] (6x6 row-major, symmetrised) - e.g. G/m for WrtMassBodyNodeEntryType::
+ *                        INERTIA_MASS, whose setter scales the whole tensor (Inertia.cpp:157-179).  count = 0 clears them.
+ * nbl_backward_inertia   grad_params [count][B]: dL/dtheta_p of every world for the step recorded in `saved`.  Call it
+ *                        right after nbl_step_backward of the same record on the same stream and workspace (it uses the
+ *                        adjoint joint rates that call leaves in the workspace).  accumulate != 0 adds to grad_params.
+ *                        The reference finite-differences M^-1 and C for these parameters (Skeleton.cpp:1826-1829,
+ *                        2078-2081); this is the closed form (csrc/inertia_backward.hip).
+ */
+int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const double* com, const double* inertia);
+int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG);
+int32_t nbl_num_inertia_params(const nbl_model* m);
+int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double* grad_params, int32_t accumulate,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * T-step trajectory rollout on the device: the loop of SingleShot::getStates /
  * SingleShot::backpropGradientWrt (dart/trajectory/SingleShot.cpp:539-598, 598-700) over forwardPass / backprop, without
  * a host round trip per step.

@@ -7,10 +7,13 @@ from .model import (BodySpec, BoxSpec, ModelDescription, atlas, box_stack, cartp
                     make_transform, single_pendulum)
 
 __all__ = ["ModelDescription", "BodySpec", "BoxSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
-           "atlas", "box_stack", "make_transform", "load_urdf", "with_ground"]
+           "atlas", "box_stack", "make_transform", "load_urdf", "with_ground", "WrtMassBodyNodeEntryType"]
 
 
 def __getattr__(name):
+    if name == "WrtMassBodyNodeEntryType":
+        from .mass import WrtMassBodyNodeEntryType
+        return WrtMassBodyNodeEntryType
     if name in ("load_urdf", "with_ground"):
         from . import loaders as _l
         return getattr(_l, name)

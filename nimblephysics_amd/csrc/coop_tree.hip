@@ -461,7 +461,8 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel m
                                                        const DevDof* __restrict__ dofs, int64_t B,
                                                        const double* __restrict__ saved, SavedLayout lay,
                                                        const double* __restrict__ gnext, double* __restrict__ gstate,
-                                                       double* __restrict__ gaction, const double* __restrict__ lws) {
+                                                       double* __restrict__ gaction, const double* __restrict__ lws,
+                                                       double* __restrict__ lamOut) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
   CoopCtxT<PROF_BWD> c;
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
@@ -478,6 +479,10 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel m
   double lam[6];
   const V6 Ww = minvSweepsWorld(c, wb, [&](int d) -> double { return c.dt * gvp(d); }, lam);
   reverseSweepWorld(c, wb, Ww, lam, q, v, tau, gnext, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
+  if (lamOut && wb.on) {   // lambda = dL/dtau on every DOF, where the one-world-per-lane kernels leave it (k_bwd_inertia reads it)
+    const int nd = c.bodies[c.lane].ndof;
+    for (int k = 0; k < nd; k++) lamOut[((int64_t)c.lane * WS_PER_BODY + WS_UIMP + k) * B + b] = lam[k];
+  }
 }
 
 // World-major tree blocks [b][slot][nbp]  ->  the lane-interleaved kept slots of the workspace ws[(body * 288 + slot) * B + b],

@@ -19,6 +19,7 @@
 #include "contact_backward.hip"
 #include "coop_kernels.hip"
 #include "coop_tree.hip"
+#include "inertia_backward.hip"
 
 using namespace nbl;
 
@@ -70,12 +71,35 @@ struct nbl_model {
   bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
   bool coop = true;                  // dense contact kernels: one world per wavefront (NBL_COOP=0: one world per lane)
   int treeLanes = 0, lcpLanes = 0;   // worlds per workgroup (0 = pick from B); see nbl_set_launch_lanes
+  std::vector<DevBody> hBodies;      // host copy of the body constants (nbl_set_body_inertia patches one entry)
+  DevInertiaParam* dParams = nullptr; // registered inertia parameters (nbl_set_inertia_params)
+  int nParams = 0;
   std::vector<TimedLaunch> pending;
   double fwdMs = 0, bwdMs = 0;
   int64_t fwdCount = 0, bwdCount = 0;
   double kMs[K_COUNT] = {0};
   int64_t kCount[K_COUNT] = {0};
 };
+
+// spatial inertia (Inertia.cpp:1368-1383), packed symmetric (upper triangle, row by row)
+static void packSpatialInertia(double m, const double* c, const double* I, double* out21) {
+  double Ic[3][3] = {{I[0], I[3], I[4]}, {I[3], I[1], I[5]}, {I[4], I[5], I[2]}};
+  double C[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
+  double G[6][6];
+  std::memset(G, 0, sizeof(G));
+  for (int r = 0; r < 3; r++)
+    for (int cc = 0; cc < 3; cc++) {
+      double cct = 0;
+      for (int k = 0; k < 3; k++) cct += C[r][k] * C[cc][k];
+      G[r][cc] = Ic[r][cc] + m * cct;
+      G[r][3 + cc] = m * C[r][cc];
+      G[3 + r][cc] = m * C[cc][r];
+    }
+  G[3][3] = G[4][4] = G[5][5] = m;
+  int idx = 0;
+  for (int r = 0; r < 6; r++)
+    for (int cc = r; cc < 6; cc++) out21[idx++] = G[r][cc];
+}
 
 // ---- batch slicing over HIP streams ----------------------------------------------------------------------------------
 // A call can process its worlds as several contiguous slices whose kernels overlap on internal HIP streams (slice 0 on the
@@ -191,26 +215,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     } else if (b.jtype == NBL_JOINT_PRISMATIC) {
       b.S[3] = Ra[0]; b.S[4] = Ra[1]; b.S[5] = Ra[2];
     }
-    // spatial inertia (Inertia.cpp:1368-1383), packed symmetric
-    const double m = d->mass[i];
-    const double* c = d->com + 3 * i;
-    const double* I = d->inertia + 6 * i;
-    double Ic[3][3] = {{I[0], I[3], I[4]}, {I[3], I[1], I[5]}, {I[4], I[5], I[2]}};
-    double C[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
-    double G[6][6];
-    std::memset(G, 0, sizeof(G));
-    for (int r = 0; r < 3; r++)
-      for (int cc = 0; cc < 3; cc++) {
-        double cct = 0;
-        for (int k = 0; k < 3; k++) cct += C[r][k] * C[cc][k];
-        G[r][cc] = Ic[r][cc] + m * cct;
-        G[r][3 + cc] = m * C[r][cc];
-        G[3 + r][cc] = m * C[cc][r];
-      }
-    G[3][3] = G[4][4] = G[5][5] = m;
-    int idx = 0;
-    for (int r = 0; r < 6; r++)
-      for (int cc = r; cc < 6; cc++) b.G[idx++] = G[r][cc];
+    packSpatialInertia(d->mass[i], d->com + 3 * i, d->inertia + 6 * i, b.G);
   }
   if (off != d->n_dofs) return fail(NBL_E_BADARG, "n_dofs does not match the joints");
   const double inf = INFINITY;
@@ -337,6 +342,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc((void**)&m->dBodies, sizeof(DevBody) * hb.size());
   if (e == hipSuccess) e = hipMalloc((void**)&m->dDofs, sizeof(DevDof) * hd.size());
+  m->hBodies = hb;
   if (e == hipSuccess) e = hipMemcpy(m->dBodies, hb.data(), sizeof(DevBody) * hb.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->dDofs, hd.data(), sizeof(DevDof) * hd.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && hasContact) e = hipMalloc((void**)&m->dContact, sizeof(DevContactModel));
@@ -367,6 +373,7 @@ void nbl_model_destroy(nbl_model* m) {
   if (m->dBodies) hipFree(m->dBodies);
   if (m->dDofs) hipFree(m->dDofs);
   if (m->dContact) hipFree(m->dContact);
+  if (m->dParams) hipFree(m->dParams);
   delete m;
 }
 
@@ -501,7 +508,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, h
     } else if (!m->hasContact && m->coopTree) {
       TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies, m->dDofs, B,
                                                  (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
-                                                 (const double*)nullptr));
+                                                 (const double*)nullptr, m->nParams > 0 ? (double*)workspace : (double*)nullptr));
     } else if (!m->hasContact) {
       TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
                                       grad_next_state, grad_state, grad_action, (double*)workspace, 0));
@@ -534,7 +541,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, h
       } else if (m->coopTree)
         TIMED(K_BWD_FINAL_COOP, hipLaunchKernelGGL(k_bwd_final_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies, m->dDofs,
                                                    B, (const double*)saved, m->lay, grad_next_state, grad_state, grad_action,
-                                                   (const double*)lws));
+                                                   (const double*)lws, m->nParams > 0 ? (double*)workspace : (double*)nullptr));
       else
         TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
                                               grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 0));
@@ -552,6 +559,59 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
     return launchBackward(m, B, b0, b1, s, saved, grad_next_state, grad_state, grad_action, workspace);
   });
   if (rc != NBL_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+
+// ---- inertia ("mass") parameters: World::setMasses / lossWrtMass (World.cpp:1821-1824, BackpropSnapshot.cpp:167-179) ----
+int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const double* com, const double* inertia) {
+  if (!m || !com || !inertia) return fail(NBL_E_BADARG, "null argument");
+  if (body < 0 || body >= m->nb) return fail(NBL_E_BADARG, "body index out of range");
+  if (!(mass > 0)) return fail(NBL_E_BADARG, "mass must be positive");
+  packSpatialInertia(mass, com, inertia, m->hBodies[body].G);
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipDeviceSynchronize());   // no launch in flight may see a half-written body
+  HIP_TRY(hipMemcpy(m->dBodies + body, &m->hBodies[body], sizeof(DevBody), hipMemcpyHostToDevice));
+  return NBL_OK;
+}
+
+int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG) {
+  if (!m || count < 0 || (count > 0 && (!bodies || !dG))) return fail(NBL_E_BADARG, "bad argument");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (m->dParams) { hipFree(m->dParams); m->dParams = nullptr; }
+  m->nParams = 0;
+  if (count == 0) return NBL_OK;
+  std::vector<DevInertiaParam> hp(count);
+  for (int p = 0; p < count; p++) {
+    if (bodies[p] < 0 || bodies[p] >= m->nb) return fail(NBL_E_BADARG, "inertia parameter on an unknown body");
+    hp[p].body = bodies[p]; hp[p].pad = 0;
+    const double* D = dG + 36 * (size_t)p;
+    int idx = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c = r; c < 6; c++) hp[p].dG[idx++] = 0.5 * (D[6 * r + c] + D[6 * c + r]);
+  }
+  HIP_TRY(hipMalloc((void**)&m->dParams, sizeof(DevInertiaParam) * (size_t)count));
+  HIP_TRY(hipMemcpy(m->dParams, hp.data(), sizeof(DevInertiaParam) * (size_t)count, hipMemcpyHostToDevice));
+  m->nParams = count;
+  return NBL_OK;
+}
+
+int32_t nbl_num_inertia_params(const nbl_model* m) { return m ? m->nParams : 0; }
+
+int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double* grad_params, int32_t accumulate, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!m || !saved || !grad_params || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
+  if (m->nParams <= 0) return fail(NBL_E_BADARG, "no inertia parameters registered (nbl_set_inertia_params)");
+  if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  DevModel mdl = m->mdl;
+  mdl.b0 = 0; mdl.b1 = B;
+  SavedLayout lay = m->lay;
+  if (m->coopTree && !m->coopFinal) { lay.treeRows = 0; lay.treeNbp = 0; }   // k_tree_to_lanes left the kept slots in the workspace
+  hipLaunchKernelGGL(k_bwd_inertia, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, mdl, m->dBodies, m->dDofs, B,
+                     (const double*)saved, lay, m->dParams, m->nParams, grad_params, accumulate, (double*)workspace);
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }

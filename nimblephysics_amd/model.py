@@ -225,6 +225,19 @@ class ModelDescription:
                              self.contact_clipping_depth, self.fallback_cfm)
         return m
 
+    def weld_targets(self):
+        """For every body: (index of the body of merge_welds() that carries it, or -1 for the world; its frame in that body)."""
+        target, T_in, keep = list(range(len(self.bodies))), [np.eye(4) for _ in self.bodies], []
+        for i, b in enumerate(self.bodies):
+            if b.joint_type == "weld":
+                T = b.T_pj @ _inv(b.T_cj)
+                target[i] = -1 if b.parent < 0 else target[b.parent]
+                T_in[i] = T if b.parent < 0 else T_in[b.parent] @ T
+            else:
+                keep.append(i)
+        new_index = {old: k for k, old in enumerate(keep)}
+        return [(-1 if t < 0 else new_index[t]) for t in target], T_in
+
     def has_welds(self) -> bool:
         return any(b.joint_type == "weld" for b in self.bodies)
 

@@ -21,10 +21,13 @@ class TimestepLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, world: World, state: torch.Tensor, action: torch.Tensor, mass: Optional[torch.Tensor]):
-        if mass is not None:
-            # reference: world.setMasses(mass); gradient wrt mass falls back to finite differences there
-            # (Skeleton.cpp:1826-1829). Out of the hot-path scope (dart/neural row).
-            raise NotImplementedError("timestep(..., mass=...) is outside the accelerated hot path")
+        ctx.use_mass = mass is not None
+        if ctx.use_mass:
+            # world.setMasses(mass): the mass vector is a property of the (shared) model, one value for the whole batch
+            if mass.dim() != 1 or mass.shape[0] != world.getMassDims():
+                raise ValueError(f"mass must be a 1-D tensor of world.getMassDims() = {world.getMassDims()} entries")
+            world.setMasses(mass)
+            ctx.mass_device = mass.device
         one_d = state.dim() == 1
         in_device = state.device
         s = world._prep(state, 2 * world.n, "setState")      # world.setState(state)
@@ -52,9 +55,13 @@ class TimestepLayer(torch.autograd.Function):
         g = g.to(device=world.device, dtype=torch.float64).contiguous()
         gs, ga = world.backward_soa(ctx.saved_record, world.to_soa(g))     # snapshot.backpropState(world, grad)
         d_state, d_action = world.from_soa(gs), world.from_soa(ga)
+        d_mass = None
+        if ctx.use_mass:
+            # grads.lossWrtMass; the mass vector is shared by the B worlds, so their gradients add up
+            d_mass = world.backward_inertia_soa(ctx.saved_record, g.shape[0]).sum(dim=1).to(ctx.mass_device)
         if ctx.one_d:
             d_state, d_action = d_state[0], d_action[0]
-        return None, d_state.to(ctx.in_device), d_action.to(ctx.action_device), None
+        return None, d_state.to(ctx.in_device), d_action.to(ctx.action_device), d_mass
 
 
 def timestep(world: World, state: torch.Tensor, action: torch.Tensor, mass: Optional[torch.Tensor] = None) -> torch.Tensor:

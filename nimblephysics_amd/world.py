@@ -19,6 +19,7 @@ import torch
 
 from . import _abi
 from ._lib import NimbleAmdError, check, lib
+from .mass import WithRespectToMass, WrtMassBodyNodeEntryType
 from .model import ModelDescription
 
 
@@ -31,8 +32,11 @@ class World:
         if not torch.cuda.is_available():
             raise NimbleAmdError("no HIP device visible: nimblephysics_amd has no CPU path (the CPU restatement under "
                                  "oracle/ is test infrastructure, not a fallback)")
-        self.description = model
+        import copy
+        self.description = copy.deepcopy(model)   # setMasses edits it
+        model = self.description
         self.model = model.merge_welds() if model.has_welds() else model
+        self._wrt_mass = WithRespectToMass(self.description)
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
@@ -165,6 +169,64 @@ class World:
         check(self._L.nbl_step_backward(self._h, B, _ptr(saved), _ptr(grad_next), _ptr(gs), _ptr(ga), _ptr(ws), ws.numel(),
                                         self._stream()), "nbl_step_backward")
         return gs, ga
+
+    # ---- inertia ("mass") parameters (World.cpp:1014-1053, 1821-1824; WithRespectToMass.cpp) ------------
+    def getWrtMass(self) -> WithRespectToMass:
+        return self._wrt_mass
+
+    def tuneMass(self, body, type=WrtMassBodyNodeEntryType.INERTIA_MASS, upperBound=None, lowerBound=None):
+        """Register a body (name or index in the model description) whose inertial parameters become part of the mass vector."""
+        self._wrt_mass.registerNode(body, type, upperBound, lowerBound)
+        self._push_inertia_params()
+
+    def getMassDims(self) -> int:
+        return self._wrt_mass.dim()
+
+    def getMasses(self) -> torch.Tensor:
+        return torch.from_numpy(self._wrt_mass.get())
+
+    def getMassUpperLimits(self) -> torch.Tensor:
+        return torch.from_numpy(self._wrt_mass.upperBound())
+
+    def getMassLowerLimits(self) -> torch.Tensor:
+        return torch.from_numpy(self._wrt_mass.lowerBound())
+
+    def setMasses(self, masses):
+        """World::setMasses: writes the registered parameters into the model (host) and re-uploads the touched bodies."""
+        import numpy as np
+        if isinstance(masses, torch.Tensor):
+            masses = masses.detach().cpu().numpy()
+        self._wrt_mass.set(np.asarray(masses, dtype=np.float64))
+        new = self.description.merge_welds() if self.description.has_welds() else self.description
+        for i, (old_b, new_b) in enumerate(zip(self.model.bodies, new.bodies)):
+            if old_b.mass != new_b.mass or tuple(old_b.com) != tuple(new_b.com) or tuple(old_b.inertia) != tuple(new_b.inertia) \
+                    or new is self.model:
+                com = (C.c_double * 3)(*[float(x) for x in new_b.com])
+                ine = (C.c_double * 6)(*[float(x) for x in new_b.inertia])
+                check(self._L.nbl_set_body_inertia(self._h, i, float(new_b.mass), com, ine), "nbl_set_body_inertia")
+        if new is not self.model:
+            new._action_map = self.model._action_map
+            self.model = new
+        self._push_inertia_params()
+
+    def _push_inertia_params(self):
+        bodies, dG = self._wrt_mass.device_table()
+        cnt = int(bodies.shape[0])
+        check(self._L.nbl_set_inertia_params(self._h, cnt, bodies.ctypes.data_as(C.c_void_p) if cnt else None,
+                                             dG.ctypes.data_as(C.c_void_p) if cnt else None), "nbl_set_inertia_params")
+
+    def backward_inertia_soa(self, saved: torch.Tensor, B: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dL/dmass of every world, [massDims][B], for the record whose backward_soa was the LAST call on this world
+        (BackpropSnapshot::backprop, lossWrtMass = massVel^T lossWrtVelocity, BackpropSnapshot.cpp:153, 167-179).
+        `out`: accumulate into an existing [massDims][B] tensor."""
+        d = self.getMassDims()
+        if d == 0:
+            return torch.zeros((0, B), dtype=torch.float64, device=self.device)
+        g = out if out is not None else torch.empty((d, B), dtype=torch.float64, device=self.device)
+        ws = self._workspace(B)
+        check(self._L.nbl_backward_inertia(self._h, B, _ptr(saved), _ptr(g), 1 if out is not None else 0, _ptr(ws), ws.numel(),
+                                           self._stream()), "nbl_backward_inertia")
+        return g
 
     # ---- dense Jacobians of the last step (SURVEY.md 8(f) row 3) ------------------------------------
     def step_jacobians_soa(self, saved: torch.Tensor, B: int):
