@@ -269,6 +269,12 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   double* AISw = Sw + 6 * nb;
   double* Vw = AISw + 6 * nb;
   double* acc = Vw + 6 * nb;
+  // what the serial body loops below read per body, staged once (a global load inside those loops is waited for per body):
+  // psi of the 1-DOF joints; per free joint its LDL^T (21), articulated inertia (21) and world transform (12); the two
+  // bodies of every contact
+  double* psiL = acc + 6 * nb * MAX_ROWS;
+  double* freeL = psiL + nb;                       // [nFree][54]
+  int* cbody = reinterpret_cast<int*>(freeL + 54 * mdl.nFree);   // [2][MAX_CONTACTS]
   const DevWave w;
   const int ln = w.lane();
   const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
@@ -278,6 +284,17 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   if (m == 0) return;
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   double* dn = denseOf(saved, lay, B, b);
+  if (ln < nC) {
+    const int q0 = lay.contacts + ln * CR_SIZE;
+    cbody[ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body;
+    cbody[MAX_CONTACTS + ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXB, B, b)].body;
+  }
+  for (int fb = 0; fb < nb; fb++) {                // wave-uniform scan; free joints are few
+    const int fi = bodies[fb].freeIdx;
+    if (fi < 0 || ln >= 54) continue;
+    const int slot = ln < 21 ? WS_PSI + ln : (ln < 42 ? WS_AI + (ln - 21) : WS_TW + (ln - 42));
+    freeL[54 * fi + ln] = wsAt(c, fb, slot);
+  }
   auto ld6 = [](const double* base) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e]; return fromArr(a); };
   auto st6 = [](double* base, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) base[e] = a[e]; };
   // ---- prologue, lane = body: world-frame joint axis, AI*S and twist at v_pre ----
@@ -285,7 +302,11 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
     const DevBody& bd = bodies[ln];
     const T12 TW = ldTAt(c, ln, WS_TW);
     st6(Vw + 6 * ln, AdT(TW, ldV6(c, ln, WS_VTW)));
-    if (bd.jtype != JT_FREE) { st6(Sw + 6 * ln, AdT(TW, cV6(bd.S))); st6(AISw + 6 * ln, dAdInvT(TW, ldV6(c, ln, WS_AIS))); }
+    if (bd.jtype != JT_FREE) {
+      st6(Sw + 6 * ln, AdT(TW, cV6(bd.S)));
+      st6(AISw + 6 * ln, dAdInvT(TW, ldV6(c, ln, WS_AIS)));
+      psiL[ln] = wsAt(c, ln, WS_PSI);
+    }
   }
   const bool on = ln < m;
   const int row = on ? ln : 0;
@@ -297,14 +318,14 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   const int r0 = lay.contacts + ci * CR_SIZE;
   const V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
   const V3 nrm = mk3(svAt(saved, r0 + CR_NORMAL, B, b), svAt(saved, r0 + CR_NORMAL + 1, B, b), svAt(saved, r0 + CR_NORMAL + 2, B, b));
-  const int bA = cm->boxes[(int)svAt(saved, r0 + CR_BOXA, B, b)].body, bB = cm->boxes[(int)svAt(saved, r0 + CR_BOXB, B, b)].body;
   V3 t1, t2;
   tangentBasis(nrm, t1, t2);
   const V3 dir = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
   const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p (on A; -F on B)
-  const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
   if (on) st6(Fs + 6 * row, F);
   w.sync();
+  const int bA = cbody[ci], bB = cbody[MAX_CONTACTS + ci];
+  const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
   if (on) {
     // b = -J^T V: relative velocity of the contact point pair along dir (getRelVelocity; restitution 0, no penetration correction)
     double rel = 0;
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
       if (bd.jtype != JT_FREE) dn[lay.aall + bd.dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), F);
       else {
         double v6[6];
-        toArr(dAdT(cT(bd.Tcj), dAdT(ldTAt(c, i, WS_TW), F)), v6);
+        toArr(dAdT(cT(bd.Tcj), dAdT(cT(freeL + 54 * bd.freeIdx + 42), F)), v6);
         for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
       }
       for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
       stAcc(i, Bi);
       if (bd.jtype != JT_FREE && bd.parent >= 0) {
         const double uimp = -dot(ld6(Sw + 6 * i), Bi);
-        stAcc(bd.parent, ldAcc(bd.parent) + Bi + (wsAt(c, i, WS_PSI) * uimp) * ld6(AISw + 6 * i));
+        stAcc(bd.parent, ldAcc(bd.parent) + Bi + (psiL[i] * uimp) * ld6(AISw + 6 * i));
       }
     }
     // root -> leaf: velocity changes of every body (world twists), joint-space response
@@ -345,19 +366,22 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
       const V6 Bi = ((chain >> i) & 1ull) ? ldAcc(i) : zero6();
       if (bd.jtype != JT_FREE) {
         const V6 S = ld6(Sw + 6 * i);
-        const double dq = wsAt(c, i, WS_PSI) * (-dot(S, Bi) - dot(ld6(AISw + 6 * i), X));
+        const double dq = psiL[i] * (-dot(S, Bi) - dot(ld6(AISw + 6 * i), X));
         stAcc(i, X + dq * S);
         dn[lay.massed + bd.dofOff * MAX_ROWS + row] = dq;
       } else {
         // the free-joint root in its body frame
-        const T12 Tcj = cT(bd.Tcj), TW = ldTAt(c, i, WS_TW);
+        const double* fl = freeL + 54 * bd.freeIdx;
+        const T12 Tcj = cT(bd.Tcj), TW = cT(fl + 42);
         LDL6 f;
-        for (int e = 0; e < 15; e++) f.l[e] = wsAt(c, i, WS_PSI + e);
-        for (int e = 0; e < 6; e++) f.d[e] = wsAt(c, i, WS_PSI + 15 + e);
+        for (int e = 0; e < 15; e++) f.l[e] = fl[e];
+        for (int e = 0; e < 6; e++) f.d[e] = fl[15 + e];
+        S6 AIb;
+        for (int e = 0; e < 21; e++) AIb.a[e] = fl[21 + e];
         const V6 Xb = AdInvT(TW, X);
         double r[6], u[6], pj[6];
         toArr(dAdT(Tcj, dAdT(TW, Bi)), u);
-        toArr(dAdT(Tcj, mul(ldS6(c, i, WS_AI), Xb)), pj);
+        toArr(dAdT(Tcj, mul(AIb, Xb)), pj);
         for (int e = 0; e < 6; e++) r[e] = -u[e] - pj[e];
         ldl6Solve(f, r);
         stAcc(i, AdT(TW, Xb + AdT(Tcj, fromArr(r))));
@@ -366,8 +390,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
     }
     // row of A: relative-velocity response at every row of the contacts c2 >= ci, mirrored into the earlier rows
     for (int c2 = ci; c2 < nC; c2++) {
-      const int q0 = lay.contacts + c2 * CR_SIZE;
-      const int b2A = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body, b2B = cm->boxes[(int)svAt(saved, q0 + CR_BOXB, B, b)].body;
+      const int b2A = cbody[c2], b2B = cbody[MAX_CONTACTS + c2];
       V6 dV = zero6();
       if (b2A >= 0) dV = dV + ldAcc(b2A);
       if (b2B >= 0) dV = dV - ldAcc(b2B);
@@ -412,38 +435,52 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   double* D = FW + nb * 54;
   double* TF = D + nb * 54;      // written after the row phase: shares its storage with tmp
   double* tmp = TF;
+  double* TWs = TF + (nb * 54 > 54 * MAX_ROWS ? nb * 54 : 54 * MAX_ROWS);   // [nb][12] world transforms
+  int* cbody = reinterpret_cast<int*>(TWs + nb * 12);                        // [2][MAX_CONTACTS]
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
   const double* q = saved;
   auto ld6 = [](const double* base, int stride) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e * stride]; return fromArr(a); };
   auto st6 = [](double* base, int stride, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) base[e * stride] = a[e]; };
-  // ---- phase 1a ----
-  if (ln < 9) {
-    const int f = ln;
+  // ---- staging: world transforms of all bodies and the bodies of every contact (read many times below) ----
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  const int nC = m / 3;
+  for (int idx = ln; idx < nb * 12; idx += 64) TWs[idx] = wsAt(c, idx / 12, WS_TW + idx % 12);
+  if (ln < nC) {
+    const int q0 = lay.contacts + ln * CR_SIZE;
+    cbody[ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body;
+    cbody[MAX_CONTACTS + ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXB, B, b)].body;
+  }
+  for (int idx = ln; idx < nb * 54; idx += 64) D[idx] = 0.0;
+  w.sync();
+  // ---- phase 1a: world twists of the nine joint-rate fields.  lane = (body, field): own joint twist in the world frame,
+  //      then lane = (field, component): prefix sums down the tree (bodies are listed parents first) ----
+  for (int item = ln; item < nb * 9; item += 64) {
+    const int i = item / 9, f = item - 9 * i;
     const double* src; const int64_t stride = B;
     if (f == 0) src = lws + (int64_t)LB_LAM1 * B + b;
     else if (f == 1) src = saved + (int64_t)lay.vpre * B + b;
     else if (f <= 4) src = lws + (int64_t)(LB_P + (f - 2) * MAX_DOF_CONTACT) * B + b;
     else if (f <= 7) src = lws + (int64_t)(LB_S + (f - 5) * MAX_DOF_CONTACT) * B + b;
     else src = saved + (int64_t)lay.w * B + b;
-    for (int i = 0; i < nb; i++) {
-      const DevBody& bd = bodies[i];
-      V6 tw;
-      if (bd.jtype == JT_FREE) {
-        const int o = bd.dofOff;
-        tw = AdT(cT(bd.Tcj), mk6(mk3(src[o * stride], src[(o + 1) * stride], src[(o + 2) * stride]),
-                                 mk3(src[(o + 3) * stride], src[(o + 4) * stride], src[(o + 5) * stride])));
-      } else tw = src[bd.dofOff * stride] * cV6(bd.S);
-      V6 twW = AdT(ldTAt(c, i, WS_TW), tw);
-      if (bd.parent >= 0) twW = twW + ld6(FW + (bd.parent * 9 + f) * 6, 1);
-      st6(FW + (i * 9 + f) * 6, 1, twW);
+    const DevBody& bd = bodies[i];
+    V6 tw;
+    if (bd.jtype == JT_FREE) {
+      const int o = bd.dofOff;
+      tw = AdT(cT(bd.Tcj), mk6(mk3(src[o * stride], src[(o + 1) * stride], src[(o + 2) * stride]),
+                               mk3(src[(o + 3) * stride], src[(o + 4) * stride], src[(o + 5) * stride])));
+    } else tw = src[bd.dofOff * stride] * cV6(bd.S);
+    st6(FW + item * 6, 1, AdT(cT(TWs + 12 * i), tw));
+  }
+  w.sync();
+  if (ln < 54) {
+    for (int i = 1; i < nb; i++) {
+      const int par = bodies[i].parent;
+      if (par >= 0) FW[i * 54 + ln] += FW[par * 54 + ln];
     }
   }
-  for (int idx = ln; idx < nb * 54; idx += 64) D[idx] = 0.0;
   w.sync();
   // ---- phase 2: per-row constants, side A then side B ----
-  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
-  const int nC = m / 3;
   double cf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool any = false;
   ContactRec CR;
@@ -491,8 +528,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     w.sync();
     if (ln < 54) {
       for (int ci = 0; ci < nC; ci++) {
-        const int r0 = lay.contacts + ci * CR_SIZE;
-        const int st = cm->boxes[(int)svAt(saved, r0 + (side == 0 ? CR_BOXA : CR_BOXB), B, b)].body;
+        const int st = cbody[side * MAX_CONTACTS + ci];
         if (st >= 0) D[st * 54 + ln] += (tmp[ln * MAX_ROWS + 3 * ci] + tmp[ln * MAX_ROWS + 3 * ci + 1]) + tmp[ln * MAX_ROWS + 3 * ci + 2];
       }
     }
@@ -501,7 +537,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   // ---- phase 1b (after the rows: TF takes over tmp's storage): local wrenches of the nine fields, world frame ----
   for (int item = ln; item < nb * 9; item += 64) {
     const int i = item / 9;
-    const T12 TW = ldTAt(c, i, WS_TW);
+    const T12 TW = cT(TWs + 12 * i);
     const V6 twB = AdInvT(TW, ld6(FW + item * 6, 1));
     st6(TF + item * 6, 1, dAdInvT(TW, mul(cS6(bodies[i].G), twB)));
   }
@@ -528,7 +564,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
       }
     }
     double qb[6];
-    applyHt(bd, q, B, b, dAdT(ldTAt(c, i, WS_TW), xiW), qb);
+    applyHt(bd, q, B, b, dAdT(cT(TWs + 12 * i), xiW), qb);
     for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_QX + bd.dofOff + k) * B + b] = qb[k];
   }
 }

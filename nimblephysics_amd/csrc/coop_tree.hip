@@ -28,11 +28,23 @@ DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __res
     double* dstB = reinterpret_cast<double*>(lb);
     const double* srcB = reinterpret_cast<const double*>(bodies);
     const int cntB = mdl.nb * (int)(sizeof(DevBody) / sizeof(double));
-    for (int idx = threadIdx.x; idx < cntB; idx += blockDim.x) dstB[idx] = srcB[idx];
-    double* dstD = reinterpret_cast<double*>(ld);
-    const double* srcD = reinterpret_cast<const double*>(dofs);
     const int cntD = mdl.n * (int)(sizeof(DevDof) / sizeof(double));
-    for (int idx = threadIdx.x; idx < cntD; idx += blockDim.x) dstD[idx] = srcD[idx];
+    // DevBody[] and DevDof[] are contiguous in LDS: one copy loop, 4 loads in flight per thread (their latency is paid once)
+    const double* srcD = reinterpret_cast<const double*>(dofs);
+    const int cnt = cntB + cntD, step = (int)blockDim.x;
+    for (int i0 = (int)threadIdx.x; i0 < cnt; i0 += 4 * step) {
+      double tmp[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = i0 + u * step;
+        if (idx < cnt) tmp[u] = idx < cntB ? srcB[idx] : srcD[idx - cntB];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = i0 + u * step;
+        if (idx < cnt) dstB[idx] = tmp[u];
+      }
+    }
   }
   __syncthreads();   // the only workgroup-wide barrier: from here on every wavefront runs on its own
   const int wv = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
@@ -57,12 +69,25 @@ DEV double* treeBlock(double* saved, const SavedLayout& lay, int64_t B, int64_t 
 template <int P, bool STORE>
 DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
   const int rsub = c.lane / c.nbp, body = c.lane - rsub * c.nbp, rstep = 64 / c.nbp;
+  // kept rows of the profile: FWD rows 0..70, BWD rows 0..30 (coopRowSlot); U rows in flight per lane so that the
+  // global-load (LDS-read) latency is paid once per U rows instead of once per row
+  constexpr int KEPT = P == PROF_FWD ? 71 : 31, U = 8;
   if (rsub < rstep) {
-    for (int r = rsub; r < coopRows<P>(); r += rstep) {
-      const int slot = coopRowSlot<P>(r);
-      if (slot < 0) continue;
-      if (STORE) blk[slot * c.nbp + body] = c.lds[r * c.nbp + body];
-      else c.lds[r * c.nbp + body] = blk[slot * c.nbp + body];
+    for (int r0 = rsub; r0 < KEPT; r0 += U * rstep) {
+      double tmp[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = r0 + u * rstep;
+        if (r < KEPT) tmp[u] = STORE ? c.lds[r * c.nbp + body] : blk[coopRowSlot<P>(r) * c.nbp + body];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = r0 + u * rstep;
+        if (r < KEPT) {
+          if (STORE) blk[coopRowSlot<P>(r) * c.nbp + body] = tmp[u];
+          else c.lds[r * c.nbp + body] = tmp[u];
+        }
+      }
     }
   }
   for (int fb = 0; fb < c.nb; fb++) {
@@ -102,6 +127,7 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
   const bool on = i < c.nb;
   const DevBody& bd = c.bodies[on ? i : 0];
   const bool isFree = bd.jtype == JT_FREE;
+  NBL_PHASE(1);
   // ---- joint transform (all bodies together) ----
   T12 T;
   if (on) {
@@ -122,6 +148,7 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
     stT(c, i, T);
   }
   const V6 SdqB = on ? jointTwist(bd, v, B, b) : zero6();   // S dq in the body frame
+  NBL_PHASE(2);
   // ---- sweep 1 (root -> leaf): world transforms and twists ----
   T12 TW = T;
   V6 Vw = zero6(), SdqW = zero6();
@@ -132,6 +159,7 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
     Vw = bd.parent >= 0 ? ldV6(c, bd.parent, WS_W) + SdqW : SdqW;
     stV6(c, i, WS_W, Vw);
   });
+  NBL_PHASE(3);
   // ---- own inertia and bias in the world frame (all bodies together) ----
   const V6 Sw = (on && !isFree) ? AdT(TW, cV6(bd.S)) : zero6();
   const V6 etaW = ad(Vw, SdqW);                               // GenericJoint.hpp:1803-1824 (dS = 0); zero for the root
@@ -141,21 +169,27 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
     stV6(c, i, WS_FACC, -dad(Vw, mul(Gw, Vw)));               // BodyNode.cpp:2076-2114; gravity rides on the base acceleration
   }
   waveFence();
+  NBL_PHASE(4);
   // ---- sweep 2 (leaf -> root): articulated inertias, bias forces, joint-space total force ----
   V6 AISw = zero6();
   double psi = 0.0, u = 0.0;
+  // joint-space applied force of the lane's 1-DOF joint, fetched before the level loop (a global load inside it would be
+  // waited for once per level).  GenericJoint.hpp:2554-2571: spring uses q - q0 + dt*v, damping explicit
+  double u0 = 0.0;
+  if (on && !isFree) {
+    const int d = bd.dofOff;
+    const DevDof& df = c.dofs[d];
+    const double qd = q[d * B + b], vd = v[d * B + b];
+    u0 = tauAt(d) - df.spring * (qd - df.rest + vd * c.dt) - df.damping * vd;
+  }
   forBodiesUp(c, [&](int) {
     S6 AI = ldS6(c, i, WS_AI);
     const V6 Bf = ldV6(c, i, WS_FACC);
     const V6 AIeta = mul(AI, etaW);
     if (!isFree) {
-      const int d = bd.dofOff;
-      const DevDof& df = c.dofs[d];
       AISw = mul(AI, Sw);
       psi = 1.0 / dot(Sw, AISw);                              // GenericJoint.hpp:2276-2301
-      const double qd = q[d * B + b], vd = v[d * B + b];
-      // GenericJoint.hpp:2554-2571: spring uses q - q0 + dt*v, damping explicit
-      u = tauAt(d) - df.spring * (qd - df.rest + vd * c.dt) - df.damping * vd - dot(Sw, AIeta + Bf);
+      u = u0 - dot(Sw, AIeta + Bf);
       wsAt(c, i, WS_PSI) = psi;
       wsAt(c, i, WS_U) = u;
       if (bd.parent >= 0) {
@@ -185,15 +219,16 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
       }
     }
   });
+  NBL_PHASE(5);
   // ---- sweep 3 (root -> leaf): accelerations ----
   const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
   V6 Aw = zero6();
+  double qdd = 0.0;
   forBodiesDown(c, [&](int) {
     const V6 Ap = bd.parent >= 0 ? ldV6(c, bd.parent, WS_VBAR) : a0;
     if (!isFree) {
-      const double qdd = psi * (u - dot(AISw, Ap));           // GenericJoint.hpp:2656-2676
+      qdd = psi * (u - dot(AISw, Ap));                        // GenericJoint.hpp:2656-2676
       Aw = Ap + etaW + qdd * Sw;
-      emit(bd.dofOff, qdd);
     } else {
       const V6 XA = AdInvT(TW, Ap);
       const S6 AIb = ldS6(c, i, WS_AI);
@@ -214,6 +249,8 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
     }
     stV6(c, i, WS_VBAR, Aw);
   });
+  if (on && !isFree) emit(bd.dofOff, qdd);                    // all 1-DOF joints together: the load of v is waited for once
+  NBL_PHASE(6);
   // ---- kept slots in the body-frame convention of the consumers ----
   if (on) {
     stV6(c, i, WS_V, AdInvT(TW, Vw));
@@ -237,10 +274,12 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_step_forward_coop(DevMode
                                                           uint32_t* __restrict__ status, SavedLayout lay, int withTwists) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
   CoopCtxT<PROF_FWD> c;
+  NBL_PHASE(0);
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
   const int64_t b = c.b;
   bodies = c.bodies; dofs = c.dofs;   // the LDS copies
   stepForwardCore(c, state, action, next, saved, lay);
+  NBL_PHASE(8);
   if (withTwists) {
     // BodyNode::getSpatialVelocity after integrateVelocities -> WS_VTW, for b = -J^T V of the contact rows.  Each lane
     // reads back the new velocities of its own body's DOFs, which it stored itself (program order of one lane).
@@ -256,8 +295,10 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_step_forward_coop(DevMode
     if (on) stV6(c, i, WS_VTW, AdInvT(TW, Vw));
     waveFence();
   }
+  NBL_PHASE(9);
   if (saved && lay.treeRows > 0) coopStoreTree(c, saved, lay);
   if (status && c.lane == 0) status[b] = 0u;
+  NBL_PHASE(10);
 }
 
 // ---- backward sweeps in the WORLD frame (lane = body) ---------------------------------------------------------------------
@@ -295,10 +336,18 @@ DEV V6 minvSweepsWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, RhsFn r
   const DevBody& bd = c.bodies[wb.on ? i : 0];
   forBodies(c, [&](int) { zeroN(c, i, WS_BIMP, 6); });
   double uimp[6] = {0, 0, 0, 0, 0, 0};
+  double rhs[6] = {0, 0, 0, 0, 0, 0};                   // the lane's right-hand sides, fetched before the level loop
+  if (wb.on) {
+    if (!wb.isFree) rhs[0] = rhsAt(bd.dofOff);
+    else {
+#pragma unroll
+      for (int k = 0; k < 6; k++) rhs[k] = rhsAt(bd.dofOff + k);
+    }
+  }
   forBodiesUp(c, [&](int) {
     const V6 Bi = ldV6(c, i, WS_BIMP);
     if (!wb.isFree) {
-      uimp[0] = rhsAt(bd.dofOff) - dot(wb.Sw, Bi);
+      uimp[0] = rhs[0] - dot(wb.Sw, Bi);
       if (bd.parent >= 0) {
         const V6 up = Bi + (wb.psi * uimp[0]) * wb.AISw;
         parentTurn(c, [&]() { addV6(c, bd.parent, WS_BIMP, up); });
@@ -307,7 +356,7 @@ DEV V6 minvSweepsWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, RhsFn r
       double pj[6];
       toArr(dAdT(cT(bd.Tcj), dAdT(wb.TW, Bi)), pj);
 #pragma unroll
-      for (int k = 0; k < 6; k++) uimp[k] = rhsAt(bd.dofOff + k) - pj[k];
+      for (int k = 0; k < 6; k++) uimp[k] = rhs[k] - pj[k];
     }
   });
   V6 Ww = zero6();
@@ -362,6 +411,7 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
     stV6(c, i, WS_BACC, wb.Aw);
   }
   waveFence();
+  NBL_PHASE(25);
   V6 F = zero6(), Abar = zero6(), Vbar = zero6();
   forBodiesUp(c, [&](int) {
     F = Floc + ldV6(c, i, WS_FACC);
@@ -369,6 +419,7 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
     Vbar = VbarLoc - dad(SdqW, Abar) + ldV6(c, i, WS_VBAR);
     if (bd.parent >= 0) parentTurn(c, [&]() { addV6(c, bd.parent, WS_FACC, F); addV6(c, bd.parent, WS_ABAR, Abar); addV6(c, bd.parent, WS_VBAR, Vbar); });
   });
+  NBL_PHASE(26);
   if (!wb.on) return;
   const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
   const V6 Vp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_UIMP) : zero6();
@@ -432,27 +483,35 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_recompute_coop(DevMod
                                                            const double* __restrict__ gnext, double* __restrict__ lws) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
   CoopCtxT<PROF_BWD> c;
+  NBL_PHASE(11);
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
+  NBL_PHASE(12);
   const int64_t b = c.b;
   bodies = c.bodies; dofs = c.dofs;   // the LDS copies
   const int n = mdl.n;
   const double* gvn = gnext + (int64_t)n * B;
+  const double clsMine = c.lane < MAX_ROWS ? saved[(int64_t)(lay.cls + c.lane) * B + b] : 0.0;   // both loads in flight together
   const int m = 3 * (int)saved[(int64_t)lay.nc * B + b];
-  const bool mine = c.lane < m && saved[(int64_t)(lay.cls + c.lane) * B + b] == 1.0;
+  const bool mine = c.lane < m && clsMine == 1.0;
   const bool active = __ballot(mine ? 1 : 0) != 0ull;
   if (c.lane == 0) lws[(int64_t)LB_FLAG * B + b] = active ? 1.0 : 0.0;
   if (!active) {
     forDofs(c, [&](int d) { lws[(int64_t)(LB_GVP + d) * B + b] = gvn[(int64_t)d * B + b]; lws[(int64_t)(LB_QX + d) * B + b] = 0.0; });
     return;
   }
+  NBL_PHASE(13);
   coopLoadTree(c, saved, lay);
+  NBL_PHASE(14);
   const WorldBody wb = loadWorldBody(c);
+  NBL_PHASE(15);
   double lam[6];
   minvSweepsWorld(c, wb, [&](int d) -> double { return gvn[(int64_t)d * B + b]; }, lam);
+  NBL_PHASE(16);
   if (wb.on) {
     const DevBody& bd = bodies[c.lane];
     for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_LAM1 + bd.dofOff + k) * B + b] = lam[k];
   }
+  NBL_PHASE(17);
 }
 
 // unconstrained backward sweep driven by g_vpre, plus the contact position cotangent (k_bwd_final); with lws == nullptr
@@ -465,7 +524,9 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel m
                                                        double* __restrict__ lamOut) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
   CoopCtxT<PROF_BWD> c;
+  NBL_PHASE(20);
   if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
+  NBL_PHASE(21);
   const int64_t b = c.b;
   const int n = mdl.n;
   const double* q = saved;
@@ -473,12 +534,16 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel m
   const double* tau = saved + (int64_t)2 * n * B;
   const double* gvn = gnext + (int64_t)n * B;
   coopLoadTree(c, saved, lay);
+  NBL_PHASE(22);
   const WorldBody wb = loadWorldBody(c);
+  NBL_PHASE(23);
   auto gvp = [&](int d) -> double { return lws ? lws[(int64_t)(LB_GVP + d) * B + b] : gvn[(int64_t)d * B + b]; };
   auto qx = [&](int d) -> double { return lws ? lws[(int64_t)(LB_QX + d) * B + b] : 0.0; };
   double lam[6];
   const V6 Ww = minvSweepsWorld(c, wb, [&](int d) -> double { return c.dt * gvp(d); }, lam);
+  NBL_PHASE(24);
   reverseSweepWorld(c, wb, Ww, lam, q, v, tau, gnext, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
+  NBL_PHASE(27);
   if (lamOut && wb.on) {   // lambda = dL/dtau on every DOF, where the one-world-per-lane kernels leave it (k_bwd_inertia reads it)
     const int nd = c.bodies[c.lane].ndof;
     for (int k = 0; k < nd; k++) lamOut[((int64_t)c.lane * WS_PER_BODY + WS_UIMP + k) * B + b] = lam[k];

@@ -6,6 +6,8 @@
 
 namespace nbl {
 
+
+
 struct DevWave {
   DEV int lane() const { return (int)(threadIdx.x & 63u); }
   DEV void sync() const { __syncthreads(); }

@@ -146,10 +146,15 @@ template <int P, class F> DEV void forBodiesUp(const CoopCtxT<P>& c, F f) {
 }
 template <int P, class F> DEV void forBodies(const CoopCtxT<P>& c, F f) { if (c.lane < c.nb) f(c.lane); waveFence(); }
 template <int P, class F> DEV void forDofs(const CoopCtxT<P>& c, F f) { if (c.lane < c.n) f(c.lane); }
-// children of one parent that sit in the same level take turns (LDS operations of a wave execute in program order)
+// Children add into their parent's accumulators.  One world per lane: plain read-modify-write.  Lane = body: the siblings of
+// one level add TOGETHER with LDS atomics (ds_add_f64, no return value: nothing to wait for); lanes that hit the same
+// address are serialised by the LDS unit in a fixed order, so the sums are reproducible.  (The earlier scheme - siblings
+// taking turns by rank with read / add / write - cost maxRank + 1 exposed LDS round trips per level.)
 template <class F> DEV void parentTurn(const Ctx&, F f) { f(); }
-template <int P, class F> DEV void parentTurn(const CoopCtxT<P>& c, F f) {
-  for (int r = 0; r <= c.maxRank; r++) if (c.rank == r) f();
+template <int P, class F> DEV void parentTurn(const CoopCtxT<P>&, F f) { f(); }
+DEV void accAdd(double& dst, double x, const Ctx&) { dst += x; }
+template <int P> DEV void accAdd(double& dst, double x, const CoopCtxT<P>&) {
+  __hip_atomic_fetch_add(&dst, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 template <class C> DEV V6 ldV6(const C& c, int body, int slot) {
@@ -168,7 +173,7 @@ template <class C> DEV void addV6(const C& c, int body, int slot, V6 x) {
   double a[6];
   toArr(x, a);
 #pragma unroll
-  for (int k = 0; k < 6; k++) wsAt(c, body, slot + k) += a[k];
+  for (int k = 0; k < 6; k++) accAdd(wsAt(c, body, slot + k), a[k], c);
 }
 template <class C> DEV void zeroN(const C& c, int body, int slot, int cnt) {
   for (int k = 0; k < cnt; k++) wsAt(c, body, slot + k) = 0.0;
@@ -209,7 +214,7 @@ template <class C> DEV void stS6(const C& c, int body, int slot, const S6& A) {
 }
 template <class C> DEV void addS6(const C& c, int body, int slot, const S6& A) {
 #pragma unroll
-  for (int k = 0; k < 21; k++) wsAt(c, body, slot + k) += A.a[k];
+  for (int k = 0; k < 21; k++) accAdd(wsAt(c, body, slot + k), A.a[k], c);
 }
 
 DEV T12 cT(const double* t) {  // wave-uniform constant -> scalar loads
@@ -407,6 +412,7 @@ DEV void stepForwardCore(const C& c, const double* __restrict__ state, const dou
     if (vpreRow >= 0) saved[(int64_t)(vpreRow + d) * B + b] = x;   // mLastPreConstraintVelocity (World.cpp:236-239)
   };
   stepAba(c, q, v, tauAt, emit);
+  NBL_PHASE(7);
 
   // positions integrate with the PRE-step velocity (World.cpp:307-333, mParallelVelocityAndPositionUpdates)
   forBodies(c, [&](int i) {

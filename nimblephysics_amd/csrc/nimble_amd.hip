@@ -318,7 +318,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e3 = getenv("NBL_COOP")) coop = atoi(e3) != 0;
     if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
     if (coopTreeLds > 160u * 1024u) coopTree = false;
-    if (((size_t)d->n_bodies * 162 + 54 * MAX_ROWS) * sizeof(double) > 160u * 1024u) coop = false;   // k_bwd_contact_b_coop's per-world LDS image
+    if (((size_t)d->n_bodies * 174 + 54 * MAX_ROWS + MAX_CONTACTS) * sizeof(double) > 160u * 1024u) coop = false;   // k_bwd_contact_b_coop's per-world LDS image
     m->coop = coop;
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
     if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
@@ -441,7 +441,8 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
                                          status, (double*)workspace, m->coopTree ? 0 : 1));
       if (m->coop) {
-        const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 18 * (size_t)m->nb) * sizeof(double);   // acc, Fw, Sw/AISw/Vw
+        const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
+                               sizeof(double);   // acc, Fw, Sw/AISw/Vw/psi, free-joint blocks, contact bodies
         TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)cnt), dim3(64), rowsLds, s, mdl, m->dBodies, m->dContact, B,
                                               (double*)saved, m->lay, (const double*)workspace));
       } else
@@ -528,7 +529,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, h
         TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, mdl, m->dBodies, m->dDofs, m->dContact,
                                           B, sv, m->lay, grad_next_state, (double*)workspace, lws));
       if (m->coop) {
-        const size_t bLds = ((size_t)m->nb * 108 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS)) * sizeof(double);   // FW D {tmp | TF}
+        const size_t bLds = ((size_t)m->nb * 120 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS) + MAX_CONTACTS) * sizeof(double);   // FW D {tmp | TF} TW contact bodies
         TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
                                                sv, m->lay, (const double*)workspace, lws));
       } else
@@ -615,6 +616,14 @@ int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double*
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
+
+#ifdef NBL_PHASE_TIMING
+int32_t nbl_debug_phase_stamps(unsigned long long* out32) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phaseStamp), sizeof(unsigned long long) * 32));
+  return NBL_OK;
+}
+#endif
 
 // ---- T-step rollout -------------------------------------------------------------------
 namespace {

@@ -1,0 +1,41 @@
+"""Developer tool: where does one wavefront of k_step_forward_coop spend its cycles?
+Builds a -DNBL_PHASE_TIMING copy of the library into gpurun_out/, runs a few steps and prints the cycle stamps
+(clock64 = s_memtime, 100 MHz constant clock on gfx950: 10 ns per tick) between the phase boundaries."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+out = os.path.join(ROOT, "tools", "libnimble_amd_phase.so")     # git-ignored (*.so); build it here, it travels with gpurun
+if "--build" in sys.argv or not os.path.exists(out):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNBL_PHASE_TIMING",
+                           os.path.join(ROOT, "nimblephysics_amd/csrc/nimble_amd.hip"), "-o", out, "-w"])
+    if "--build" in sys.argv:
+        sys.exit(0)
+import torch
+import nimblephysics_amd as na
+from nimblephysics_amd import _lib
+_lib.LIB_PATH = out
+from util import contact_inputs
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
+md, s, a = contact_inputs("atlas20", B, 1000)
+w = na.World(md, device="cuda:0")
+x = w.to_soa(torch.tensor(s, device="cuda:0")); u = w.to_soa(torch.tensor(a, device="cuda:0"))
+L = _lib.lib()
+names = {0: "kernel entry", 1: "setup (model -> LDS, barrier)", 2: "joint transforms (q, v loads)", 3: "sweep 1 (TW, V down)", 4: "own inertia / bias",
+         5: "sweep 2 (AI, bias up)", 6: "sweep 3 (acc down)", 7: "kept slots", 8: "integrate + saved rows", 9: "pre-contact twists", 10: "store tree"}
+bnames = {12: "recompute: setup", 13: "recompute: flag loads", 14: "recompute: load tree", 15: "recompute: world body", 16: "recompute: minv sweeps",
+          17: "recompute: store lambda1", 21: "final: setup", 22: "final: load tree", 23: "final: world body", 24: "final: minv sweeps",
+          25: "final: reverse, local part", 26: "final: reverse, level loop", 27: "final: epilogue (VJPs, stores)"}
+g = torch.randn_like(x)
+for it in range(3):
+    nxt, saved, _ = w.step_soa(x, u)
+    w.backward_soa(saved, g)
+    buf = (C.c_ulonglong * 32)()
+    L.nbl_debug_phase_stamps.argtypes = [C.c_void_p]
+    L.nbl_debug_phase_stamps(buf)
+    t = list(buf)
+    print(f"-- step {it}: total {t[10] - t[0]} ticks")
+    for k in range(1, 11):
+        print(f"   {names[k]:34s} {t[k] - t[k - 1]:8d}")
+    print(f"   recompute total {t[17] - t[11]}, final total {t[27] - t[20]}")
+    for k in sorted(bnames):
+        print(f"   {bnames[k]:34s} {t[k] - t[k - 1]:8d}")
