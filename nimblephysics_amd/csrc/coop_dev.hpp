@@ -24,6 +24,10 @@
 #pragma once
 #include "lcp_dev.hpp"
 
+#ifndef NBL_PHASE
+#define NBL_PHASE(k) do { } while (0)   // developer phase stamps (model_dev.hpp), compiled out
+#endif
+
 namespace nbl {
 
 constexpr int CLD = MAXR + 1;  // odd leading dimension: row reads and column reads of the LDS matrices are both conflict-free
@@ -52,9 +56,15 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
   int rank = 0;
 #pragma unroll 1
   for (int k = 0; k < steps; k++) {
-    double below = 0.0;
+    // four partial sums: a 23-deep chain of dependent FMAs would cost ~23 x the FMA latency with nothing to overlap
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
 #pragma unroll
-    for (int i = 1; i < MAXR; i++) below = fma(a[i], a[i], below);
+    for (int i = 1; i + 3 < MAXR; i += 4) {
+      b0 = fma(a[i], a[i], b0); b1 = fma(a[i + 1], a[i + 1], b1); b2 = fma(a[i + 2], a[i + 2], b2); b3 = fma(a[i + 3], a[i + 3], b3);
+    }
+#pragma unroll
+    for (int i = 1 + 4 * ((MAXR - 1) / 4); i < MAXR; i++) b0 = fma(a[i], a[i], b0);
+    const double below = (b0 + b1) + (b2 + b3);
     const double nrm = fma(a[0], a[0], below);
     int p = k;
     if (PIVOT) {
@@ -81,9 +91,14 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
     }
     w.sync();
     const double tau = vb[MAXR];
-    double d = a[0];
+    double d0 = a[0], d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-    for (int i = 1; i < MAXR; i++) d = fma(vb[i], a[i], d);
+    for (int i = 1; i + 3 < MAXR; i += 4) {
+      d0 = fma(vb[i], a[i], d0); d1 = fma(vb[i + 1], a[i + 1], d1); d2 = fma(vb[i + 2], a[i + 2], d2); d3 = fma(vb[i + 3], a[i + 3], d3);
+    }
+#pragma unroll
+    for (int i = 1 + 4 * ((MAXR - 1) / 4); i < MAXR; i++) d0 = fma(vb[i], a[i], d0);
+    double d = (d0 + d1) + (d2 + d3);
     d = (ln == p) ? 0.0 : d * tau;
     a[0] -= d;
 #pragma unroll
@@ -196,9 +211,15 @@ DEV double coopPinvApply(const W& w, CoopLds& S, double xLane, int slot) {
   if (ln < MAXR) S.vec[slot][ln] = xLane;
   w.sync();
   const int i = ln < MAXR ? ln : 0;
-  double y = 0.0;
+  double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;   // four partial sums instead of one 24-deep dependent chain
 #pragma unroll
-  for (int k = 0; k < MAXR; k++) y = fma(TRANS ? S.P[k * CLD + i] : S.P[i * CLD + k], S.vec[slot][k], y);
+  for (int k = 0; k < MAXR; k += 4) {
+    y0 = fma(TRANS ? S.P[k * CLD + i] : S.P[i * CLD + k], S.vec[slot][k], y0);
+    y1 = fma(TRANS ? S.P[(k + 1) * CLD + i] : S.P[i * CLD + k + 1], S.vec[slot][k + 1], y1);
+    y2 = fma(TRANS ? S.P[(k + 2) * CLD + i] : S.P[i * CLD + k + 2], S.vec[slot][k + 2], y2);
+    y3 = fma(TRANS ? S.P[(k + 3) * CLD + i] : S.P[i * CLD + k + 3], S.vec[slot][k + 3], y3);
+  }
+  const double y = (y0 + y1) + (y2 + y3);
   return y;
 }
 
@@ -390,8 +411,11 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
       double a[MAXR];
 #pragma unroll
       for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(i) : 0.0;
+      NBL_PHASE(43);
       coopPinv(w, a, S, __builtin_popcount(guessMask));
+      NBL_PHASE(44);
       X = coopPinvApply<W, false>(w, S, in ? R.Bv : 0.0, 0);
+      NBL_PHASE(45);
       if (!in) X = 0.0;
       pinvValid = true;   // of A restricted to guessMask; stays valid only if the first classification agrees
     }
@@ -399,6 +423,7 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
   out.X0 = X;
   CoopClasses K;
   const bool ok = coopStandardizeLoop(w, S, R, X, 0.0, false, guessMask, pinvValid, K);
+  NBL_PHASE(46);
   out.X = X; out.K = K; out.ok = ok; out.pinvValid = ok && pinvValid;
 }
 

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, cons
   __shared__ CoopLds S;
   const DevWave w;
   const int ln = w.lane();
+  NBL_PHASE(40);
   const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
   if (b >= mdl.b1) return;
   const int n = mdl.n;
@@ -82,13 +83,16 @@ __global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, cons
   }
   CoopRow R;
   coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  NBL_PHASE(41);
   const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
   const double Xcache = (haveCache && ln < m) ? cacheIn[(int64_t)ln * B + b] : 0.0;
+  NBL_PHASE(42);
   CoopStage0 out;
   coopStage0(w, S, R, haveCache, Xcache, out);
   if (out.ok) {
     coopContactOutputs(w, S, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
     if (ln == 0 && status) status[b] |= 0x2u | 0x100u;
+    NBL_PHASE(47);
   } else {
     // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
     if (ln < MAX_ROWS) lws[(int64_t)(LW_JA + ln) * B + b] = out.X0;
@@ -134,6 +138,15 @@ __global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const
 //   (Q x)_r   = (A xE)_r + cfm x_r      xE = x on clamping rows, E_u x_normal(u) on upper-bound rows  ("spread")
 //   (Q^T y)_s = t_s + sum_{u in ub(s)} E_u t_u + cfm y_s,  t = A y                                     ("fold")
 // Q^+ is read back from the saved record when the forward pass left it there (pflag), else recomputed.
+// the rare path of k_bwd_contact_a_coop (no pseudo-inverse in the record): kept out of line so that its register needs
+// (three 24-entry arrays of the factorisation) do not set the occupancy of the common path
+__attribute__((noinline)) DEV void coopPinvFromRecord(CoopLds& S, const CoopRow& R, const CoopClasses& K, double cfm) {
+  const DevWave w;
+  double a[MAXR];
+  coopBuildQ(w, S, R, K, cfm, a);
+  coopPinv(w, a, S, K.nc);
+}
+
 __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ gnext, double* __restrict__ lws) {
@@ -142,16 +155,43 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   const int ln = w.lane();
   const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
   if (b >= mdl.b1) return;
-  if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;   // k_bwd_recompute: no clamping row in this world
   const int n = mdl.n;
-  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   const double* gvn = gnext + (int64_t)n * B;
   double* dn = denseOf(saved, lay, B, b);
+  // ---- every global load that does not depend on another, in one batch (one memory round trip instead of ~8):
+  //      rows beyond m / DOFs beyond n read valid memory with unused (possibly stale) values, masked below ----
+  const int row = ln < MAXR ? ln : 0, dof = ln < n ? ln : 0;
+  const double flagD = lws[(int64_t)LB_FLAG * B + b];
+  const double ncD = svAt(saved, lay.nc, B, b);
+  const double pflagD = svAt(saved, lay.pflag, B, b);
+  const double cfm = svAt(saved, lay.cfm, B, b);
+  const double cvRaw = svAt(saved, lay.cls + row, B, b);
+  const double xRaw0 = svAt(saved, lay.x + row, B, b);
+  const double bvRaw = svAt(saved, lay.b + row, B, b);
+  const int r0c = lay.contacts + (row / 3) * CR_SIZE;
+  const int bxA = (int)svAt(saved, r0c + CR_BOXA, B, b), bxB = (int)svAt(saved, r0c + CR_BOXB, B, b);
+  const double muTab = cm->boxes[ln < MAX_BOXES ? ln : 0].mu;       // collider -> mu, looked up with ds_bpermute
+  const double lam1 = lws[(int64_t)(LB_LAM1 + dof) * B + b];
+  double Acol[MAXR], Pcol[MAXR];
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) { Acol[i] = dn[lay.A + i * MAX_ROWS + row]; Pcol[i] = dn[lay.pinv + i * MAX_ROWS + row]; }
+  if (flagD == 0.0) return;   // k_bwd_recompute: no clamping row in this world
+  const int m = 3 * (int)ncD;
+  const bool rowOn = ln < m;
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) Acol[i] = (rowOn && i < m) ? Acol[i] : 0.0;   // columns / rows >= m were never written
   CoopRow R;
-  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  R.m = m; R.fric = (ln % 3) != 0; R.fp = ln < MAXR ? ln - (ln % 3) : 0; R.on = rowOn;
+  {
+    const double muA = w.shfl(muTab, bxA), muB = w.shfl(muTab, bxB);
+    R.mu = rowOn ? (muA < muB ? muA : muB) : 0.0;
+  }
+  R.Bv = rowOn ? bvRaw : 0.0;
+  R.Acol = dn + lay.A + (rowOn ? ln : 0);
+  R.colNorm = 0.0;   // only the forward solver's validity test uses it
   // classes as stored by the forward pass
   CoopClasses K;
-  const double cv = ln < m ? svAt(saved, lay.cls + ln, B, b) : 0.0;
+  const double cv = rowOn ? cvRaw : 0.0;
   K.cls = cv == 1.0 ? RC_CLAMPING : ((cv == 2.0 || cv == -2.0) ? RC_UPPER_BOUND : RC_NOT_CLAMPING);
   K.E = K.cls == RC_UPPER_BOUND ? (cv > 0 ? R.mu : -R.mu) : 0.0;
   K.clampMask = (uint32_t)w.ballot(K.cls == RC_CLAMPING);
@@ -159,8 +199,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   K.nc = __builtin_popcount(K.clampMask);
   K.nu = __builtin_popcount(K.ubMask);
   const bool clamp = K.cls == RC_CLAMPING, isUb = K.cls == RC_UPPER_BOUND;
-  const double cfm = svAt(saved, lay.cfm, B, b);
-  const double xRaw = ln < m ? svAt(saved, lay.x + ln, B, b) : 0.0;   // the impulses that were applied
+  const double xRaw = rowOn ? xRaw0 : 0.0;   // the impulses that were applied
   auto fold = [&](double t) -> double {   // normal rows collect E_u t_u of their contact's upper-bound rows
     if (K.nu == 0) return 0.0;
     const double et = isUb ? K.E * t : 0.0;
@@ -174,42 +213,53 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   };
   // lambda1 -> LDS (n <= MAX_DOF_CONTACT <= 64 entries, in the R buffer which is free until the factorisation)
   double* bc = S.R;
-  if (ln < n) bc[ln] = lws[(int64_t)(LB_LAM1 + ln) * B + b];
+  if (ln < n) bc[ln] = lam1;
   w.sync();
   // fbar = Abar^T lambda1
   double t = 0.0;
-  if (ln < m) {
-#pragma unroll 4
-    for (int d = 0; d < n; d++) t = fma(dn[lay.aall + d * MAX_ROWS + ln], bc[d], t);
+  {
+    double ta = 0.0, tb = 0.0;   // all loads of the column in flight together (d < n <= MAX_DOF_CONTACT), two partial sums
+#pragma unroll
+    for (int d = 0; d < MAX_DOF_CONTACT; d += 2) {
+      const double v0 = d < n ? dn[lay.aall + d * MAX_ROWS + row] : 0.0, v1 = d + 1 < n ? dn[lay.aall + (d + 1) * MAX_ROWS + row] : 0.0;
+      ta = fma(v0, d < n ? bc[d] : 0.0, ta);
+      tb = fma(v1, d + 1 < n ? bc[d + 1] : 0.0, tb);
+    }
+    t = rowOn ? ta + tb : 0.0;
   }
   const double tf = fold(t);   // cross-lane: every lane takes part
   const double fbar = clamp ? t + tf : 0.0;
   w.sync();
   // Q^+
-  if (svAt(saved, lay.pflag, B, b) != 0.0) {
+  if (pflagD != 0.0) {
     if (ln < MAXR) {
 #pragma unroll
-      for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = dn[lay.pinv + i * MAX_ROWS + ln];
+      for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = Pcol[i];
     }
     w.sync();
-  } else {
-    double a[MAXR];
-    coopBuildQ(w, S, R, K, cfm, a);
-    coopPinv(w, a, S, K.nc);
-  }
+  } else coopPinvFromRecord(S, R, K, cfm);
+  // A x for this lane's row from the column held in registers (A is symmetric), x one entry per lane
+  auto ax = [&](double xLane, int slot) -> double {
+    if (ln < MAXR) S.vec[slot][ln] = rowOn ? xLane : 0.0;
+    w.sync();
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int jx = 0; jx < MAXR; jx += 2) { v0 = fma(Acol[jx], S.vec[slot][jx], v0); v1 = fma(Acol[jx + 1], S.vec[slot][jx + 1], v1); }
+    return v0 + v1;
+  };
   const double bcl = clamp ? R.Bv : 0.0;
   const double mu = coopPinvApply<DevWave, true>(w, S, fbar, 0);     // (Q^+)^T fbar
   const double fls = coopPinvApply<DevWave, false>(w, S, bcl, 1);    // Q^+ b (see k_bwd_contact_a on why not the applied x)
   double al[3], be[3];
   al[0] = -mu; be[0] = fls;
   {
-    const double ax = coopAx(w, S, R, spread(fls), 2);
-    al[1] = clamp ? bcl - (ax + cfm * fls) : 0.0;
+    const double axv = ax(spread(fls), 2);
+    al[1] = clamp ? bcl - (axv + cfm * fls) : 0.0;
   }
   be[1] = coopPinvApply<DevWave, false>(w, S, mu, 3);
   al[2] = coopPinvApply<DevWave, true>(w, S, fls, 0);
   {
-    const double t2 = coopAx(w, S, R, mu, 1);
+    const double t2 = ax(mu, 1);
     const double t2f = fold(t2);
     be[2] = clamp ? fbar - (t2 + t2f + cfm * mu) : 0.0;
   }
@@ -277,55 +327,76 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   int* cbody = reinterpret_cast<int*>(freeL + 54 * mdl.nFree);   // [2][MAX_CONTACTS]
   const DevWave w;
   const int ln = w.lane();
+  NBL_PHASE(32);
   const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
   if (b >= mdl.b1) return;
-  const int nC = (int)svAt(saved, lay.nc, B, b);
-  const int m = 3 * nC;
-  if (m == 0) return;
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   double* dn = denseOf(saved, lay, B, b);
-  if (ln < nC) {
-    const int q0 = lay.contacts + ln * CR_SIZE;
-    cbody[ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body;
-    cbody[MAX_CONTACTS + ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXB, B, b)].body;
-  }
-  for (int fb = 0; fb < nb; fb++) {                // wave-uniform scan; free joints are few
-    const int fi = bodies[fb].freeIdx;
-    if (fi < 0 || ln >= 54) continue;
-    const int slot = ln < 21 ? WS_PSI + ln : (ln < 42 ? WS_AI + (ln - 21) : WS_TW + (ln - 42));
-    freeL[54 * fi + ln] = wsAt(c, fb, slot);
-  }
   auto ld6 = [](const double* base) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e]; return fromArr(a); };
   auto st6 = [](double* base, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) base[e] = a[e]; };
-  // ---- prologue, lane = body: world-frame joint axis, AI*S and twist at v_pre ----
-  if (ln < nb) {
-    const DevBody& bd = bodies[ln];
-    const T12 TW = ldTAt(c, ln, WS_TW);
-    st6(Vw + 6 * ln, AdT(TW, ldV6(c, ln, WS_VTW)));
-    if (bd.jtype != JT_FREE) {
-      st6(Sw + 6 * ln, AdT(TW, cV6(bd.S)));
-      st6(AISw + 6 * ln, dAdInvT(TW, ldV6(c, ln, WS_AIS)));
-      psiL[ln] = wsAt(c, ln, WS_PSI);
-    }
-  }
-  const bool on = ln < m;
-  const int row = on ? ln : 0;
+  // ---- every global load of the prologue in ONE batch: none depends on another (lanes beyond nb / beyond the rows in use
+  //      read body 0 / stale contact slots - valid memory, unused values), so their latency is paid once ----
+  const double ncD = svAt(saved, lay.nc, B, b);
+  const int bl = ln < nb ? ln : 0;
+  const DevBody& bdL = bodies[bl];
+  // topology of body `ln` in the lane's registers: the serial body loops below fetch it with v_readlane (no memory access)
+  const int myParent = ln < nb ? bdL.parent : -1, myJtype = ln < nb ? bdL.jtype : 0;
+  const int myDofOff = ln < nb ? bdL.dofOff : 0, myFreeIdx = ln < nb ? bdL.freeIdx : -1;
+  const T12 TWl = ldTAt(c, bl, WS_TW);
+  const V6 vtwL = ldV6(c, bl, WS_VTW), aisL = ldV6(c, bl, WS_AIS), SL = cV6(bdL.S);
+  const double psiMine = wsAt(c, bl, WS_PSI);
+  const int myBoxBody = cm->boxes[ln < MAX_BOXES ? ln : 0].body;      // collider -> body and body -> ancestor mask tables,
+  const uint64_t myAnc = cm->ancestors[bl];                           // looked up with ds_bpermute below
+  const int row = ln < MAX_ROWS ? ln : 0;
   const int ci = row / 3, kk = row % 3;
-  auto accAt = [&](int body, int e) -> double& { return acc[(body * 6 + e) * MAX_ROWS + row]; };
-  auto ldAcc = [&](int body) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = accAt(body, e); return fromArr(a); };
-  auto stAcc = [&](int body, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) accAt(body, e) = a[e]; };
-  // ---- this row's wrench ----
   const int r0 = lay.contacts + ci * CR_SIZE;
   const V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
   const V3 nrm = mk3(svAt(saved, r0 + CR_NORMAL, B, b), svAt(saved, r0 + CR_NORMAL + 1, B, b), svAt(saved, r0 + CR_NORMAL + 2, B, b));
+  const int bxA = (int)svAt(saved, r0 + CR_BOXA, B, b), bxB = (int)svAt(saved, r0 + CR_BOXB, B, b);
+  const int nC = (int)ncD;
+  const int m = 3 * nC;
+  if (m == 0) return;
+  {
+    uint64_t fm = w.ballot(myFreeIdx >= 0);          // the (few) free-joint bodies
+    while (fm) {
+      const int fb = __builtin_ctzll(fm);
+      fm &= fm - 1;
+      if (ln < 54) {
+        const int slot = ln < 21 ? WS_PSI + ln : (ln < 42 ? WS_AI + (ln - 21) : WS_TW + (ln - 42));
+        freeL[54 * w.bcastI(myFreeIdx, fb) + ln] = wsAt(c, fb, slot);
+      }
+    }
+  }
+  // ---- lane = body: world-frame joint axis, AI*S and twist at v_pre ----
+  if (ln < nb) {
+    st6(Vw + 6 * ln, AdT(TWl, vtwL));
+    if (myJtype != JT_FREE) {
+      st6(Sw + 6 * ln, AdT(TWl, SL));
+      st6(AISw + 6 * ln, dAdInvT(TWl, aisL));
+      psiL[ln] = psiMine;
+    }
+  }
+  NBL_PHASE(33);
+  const bool on = ln < m;
+  auto accAt = [&](int body, int e) -> double& { return acc[(body * 6 + e) * MAX_ROWS + row]; };
+  auto ldAcc = [&](int body) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = accAt(body, e); return fromArr(a); };
+  auto stAcc = [&](int body, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) accAt(body, e) = a[e]; };
+  // ---- this row's wrench and the two bodies it acts on ----
   V3 t1, t2;
   tangentBasis(nrm, t1, t2);
   const V3 dir = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
   const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p (on A; -F on B)
-  if (on) st6(Fs + 6 * row, F);
+  const int bA = w.shflI(myBoxBody, bxA), bB = w.shflI(myBoxBody, bxB);
+  const int ancLoA = w.shflI((int)(uint32_t)myAnc, bA), ancHiA = w.shflI((int)(uint32_t)(myAnc >> 32), bA);
+  const int ancLoB = w.shflI((int)(uint32_t)myAnc, bB), ancHiB = w.shflI((int)(uint32_t)(myAnc >> 32), bB);
+  const uint64_t mA = bA >= 0 ? ((uint64_t)(uint32_t)ancHiA << 32) | (uint32_t)ancLoA : 0ull;
+  const uint64_t mB = bB >= 0 ? ((uint64_t)(uint32_t)ancHiB << 32) | (uint32_t)ancLoB : 0ull;
+  if (on) {
+    st6(Fs + 6 * row, F);
+    if (kk == 0) { cbody[ci] = bA; cbody[MAX_CONTACTS + ci] = bB; }
+  }
   w.sync();
-  const int bA = cbody[ci], bB = cbody[MAX_CONTACTS + ci];
-  const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
+  NBL_PHASE(34);
   if (on) {
     // b = -J^T V: relative velocity of the contact point pair along dir (getRelVelocity; restitution 0, no penetration correction)
     double rel = 0;
@@ -334,45 +405,47 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
     svAt(saved, lay.b + row, B, b) = rel;
     // constraint forces in joint space (DCC::getConstraintForces): A_c[i] = sigma_i s_i . F
     for (int i = 0; i < nb; i++) {
-      const DevBody& bd = bodies[i];
+      const int jt = w.bcastI(myJtype, i), dofOff = w.bcastI(myDofOff, i);
       const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
       const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
-      if (bd.jtype != JT_FREE) dn[lay.aall + bd.dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), F);
+      if (jt != JT_FREE) dn[lay.aall + dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), F);
       else {
         double v6[6];
-        toArr(dAdT(cT(bd.Tcj), dAdT(cT(freeL + 54 * bd.freeIdx + 42), F)), v6);
-        for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
+        toArr(dAdT(cT(bodies[i].Tcj), dAdT(cT(freeL + 54 * w.bcastI(myFreeIdx, i) + 42), F)), v6);
+        for (int e = 0; e < 6; e++) dn[lay.aall + (dofOff + e) * MAX_ROWS + row] = mult * v6[e];
       }
       for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
     }
+    NBL_PHASE(35);
     // ---- unit-impulse test of this row.  leaf -> root: bias impulses along the two ancestor chains (world wrenches) ----
     const uint64_t chain = mA | mB;
     for (int i = nb - 1; i >= 0; i--) {
       if (!((chain >> i) & 1ull)) continue;
-      const DevBody& bd = bodies[i];
+      const int jt = w.bcastI(myJtype, i), par = w.bcastI(myParent, i);
       V6 Bi = ldAcc(i);
       if (i == bA) Bi = Bi - F;
       if (i == bB) Bi = Bi + F;
       stAcc(i, Bi);
-      if (bd.jtype != JT_FREE && bd.parent >= 0) {
+      if (jt != JT_FREE && par >= 0) {
         const double uimp = -dot(ld6(Sw + 6 * i), Bi);
-        stAcc(bd.parent, ldAcc(bd.parent) + Bi + (psiL[i] * uimp) * ld6(AISw + 6 * i));
+        stAcc(par, ldAcc(par) + Bi + (psiL[i] * uimp) * ld6(AISw + 6 * i));
       }
     }
+    NBL_PHASE(36);
     // root -> leaf: velocity changes of every body (world twists), joint-space response
     for (int i = 0; i < nb; i++) {
-      const DevBody& bd = bodies[i];
-      const V6 X = bd.parent >= 0 ? ldAcc(bd.parent) : zero6();
+      const int jt = w.bcastI(myJtype, i), par = w.bcastI(myParent, i), dofOff = w.bcastI(myDofOff, i);
+      const V6 X = par >= 0 ? ldAcc(par) : zero6();
       const V6 Bi = ((chain >> i) & 1ull) ? ldAcc(i) : zero6();
-      if (bd.jtype != JT_FREE) {
+      if (jt != JT_FREE) {
         const V6 S = ld6(Sw + 6 * i);
         const double dq = psiL[i] * (-dot(S, Bi) - dot(ld6(AISw + 6 * i), X));
         stAcc(i, X + dq * S);
-        dn[lay.massed + bd.dofOff * MAX_ROWS + row] = dq;
+        dn[lay.massed + dofOff * MAX_ROWS + row] = dq;
       } else {
         // the free-joint root in its body frame
-        const double* fl = freeL + 54 * bd.freeIdx;
-        const T12 Tcj = cT(bd.Tcj), TW = cT(fl + 42);
+        const double* fl = freeL + 54 * w.bcastI(myFreeIdx, i);
+        const T12 Tcj = cT(bodies[i].Tcj), TW = cT(fl + 42);
         LDL6 f;
         for (int e = 0; e < 15; e++) f.l[e] = fl[e];
         for (int e = 0; e < 6; e++) f.d[e] = fl[15 + e];
@@ -385,9 +458,10 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
         for (int e = 0; e < 6; e++) r[e] = -u[e] - pj[e];
         ldl6Solve(f, r);
         stAcc(i, AdT(TW, Xb + AdT(Tcj, fromArr(r))));
-        for (int e = 0; e < 6; e++) dn[lay.massed + (bd.dofOff + e) * MAX_ROWS + row] = r[e];
+        for (int e = 0; e < 6; e++) dn[lay.massed + (dofOff + e) * MAX_ROWS + row] = r[e];
       }
     }
+    NBL_PHASE(37);
     // row of A: relative-velocity response at every row of the contacts c2 >= ci, mirrored into the earlier rows
     for (int c2 = ci; c2 < nC; c2++) {
       const int b2A = cbody[c2], b2B = cbody[MAX_CONTACTS + c2];
@@ -401,6 +475,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
         if (c2 > ci) dn[lay.A + col * MAX_ROWS + row] = val;
       }
     }
+    NBL_PHASE(38);
   }
 }
 
@@ -442,6 +517,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   const double* q = saved;
   auto ld6 = [](const double* base, int stride) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e * stride]; return fromArr(a); };
   auto st6 = [](double* base, int stride, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) base[e * stride] = a[e]; };
+  const int myParent = ln < nb ? bodies[ln].parent : -1;   // topology in lane registers, fetched with v_readlane in the serial loops
   // ---- staging: world transforms of all bodies and the bodies of every contact (read many times below) ----
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   const int nC = m / 3;
@@ -475,7 +551,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   w.sync();
   if (ln < 54) {
     for (int i = 1; i < nb; i++) {
-      const int par = bodies[i].parent;
+      const int par = w.bcastI(myParent, i);
       if (par >= 0) FW[i * 54 + ln] += FW[par * 54 + ln];
     }
   }
@@ -545,7 +621,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   // ---- phase 3: subtree sums, leaf -> root (D and the transmitted wrenches) ----
   if (ln < 54) {
     for (int i = nb - 1; i >= 1; i--) {
-      const int par = bodies[i].parent;
+      const int par = w.bcastI(myParent, i);
       if (par >= 0) { D[par * 54 + ln] += D[i * 54 + ln]; TF[par * 54 + ln] += TF[i * 54 + ln]; }
     }
   }

@@ -618,9 +618,9 @@ int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double*
 }
 
 #ifdef NBL_PHASE_TIMING
-int32_t nbl_debug_phase_stamps(unsigned long long* out32) {
+int32_t nbl_debug_phase_stamps(unsigned long long* out64) {
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phaseStamp), sizeof(unsigned long long) * 32));
+  HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phaseStamp), sizeof(unsigned long long) * 64));
   return NBL_OK;
 }
 #endif

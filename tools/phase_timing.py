@@ -29,7 +29,7 @@ g = torch.randn_like(x)
 for it in range(3):
     nxt, saved, _ = w.step_soa(x, u)
     w.backward_soa(saved, g)
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 64)()
     L.nbl_debug_phase_stamps.argtypes = [C.c_void_p]
     L.nbl_debug_phase_stamps(buf)
     t = list(buf)
@@ -37,5 +37,15 @@ for it in range(3):
     for k in range(1, 11):
         print(f"   {names[k]:34s} {t[k] - t[k - 1]:8d}")
     print(f"   recompute total {t[17] - t[11]}, final total {t[27] - t[20]}")
+    rn = {33: "rows: prologue (staging, lane = body)", 34: "rows: row wrench + sync", 35: "rows: b, A_c column, zero acc", 36: "rows: leaf->root chain",
+          37: "rows: root->leaf all bodies", 38: "rows: row of A"}
+    print(f"   rows total {t[38] - t[32]}")
+    for k in sorted(rn):
+        print(f"   {rn[k]:38s} {t[k] - t[k - 1]:8d}")
+    sn = {41: "solve: nc + load row (mu, b, |A col|)", 42: "solve: warm-start check", 43: "solve: guess mask + A column", 44: "solve: pinv (QR + COD)",
+          45: "solve: pinv apply", 46: "solve: standardise loop", 47: "solve: outputs"}
+    print(f"   solve total {t[47] - t[40]}")
+    for k in sorted(sn):
+        print(f"   {sn[k]:38s} {t[k] - t[k - 1]:8d}")
     for k in sorted(bnames):
         print(f"   {bnames[k]:34s} {t[k] - t[k - 1]:8d}")
