@@ -25,12 +25,19 @@ DEV double norm3(V3 a) { return sqrt(dot(a, a)); }
 DEV V3 unit3(V3 a) { double n = norm3(a); return (1.0 / n) * a; }
 DEV void set3(V3& a, int i, double v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
 
-// clip the quad p against |x| <= h0, |y| <= h1; returns the number of points written to ret (<= 8)
-DEV int intersectRectQuad(double h0, double h1, const double* p, double* ret) {
-  double bufA[16], bufB[16];
+// A small per-lane array in LDS, element i of the lane at base[i * 64] (conflict-free): the clip polygons are indexed
+// dynamically, which in private memory means scratch (= global memory) round trips.
+struct LaneBuf {
+  double* base;
+  DEV double& operator[](int i) const { return base[i * 64]; }
+  DEV LaneBuf at(int i) const { LaneBuf r; r.base = base + i * 64; return r; }
+};
+
+// clip the quad p against |x| <= h0, |y| <= h1; returns the number of points written to ret (<= 8).
+// bufA, bufB, ret: 16 doubles each
+DEV int intersectRectQuad(double h0, double h1, const double* p, LaneBuf bufA, LaneBuf bufB, LaneBuf ret) {
   for (int i = 0; i < 8; i++) bufA[i] = p[i];
-  double* q = bufA;
-  double* r = bufB;
+  LaneBuf q = bufA, r = bufB;
   int nq = 4, nr = 0;
   bool done = false;
   for (int dir = 0; dir <= 1 && !done; dir++) {
@@ -38,31 +45,35 @@ DEV int intersectRectQuad(double h0, double h1, const double* p, double* ret) {
     for (int sign = -1; sign <= 1 && !done; sign += 2) {
       nr = 0;
       for (int i = 0; i < nq; i++) {
-        const double* pq = q + 2 * i;
-        const double* nx = (i + 1 < nq) ? pq + 2 : q;
-        bool in0 = sign * pq[dir] < h, in1 = sign * nx[dir] < h;
+        const LaneBuf pq = q.at(2 * i);
+        const LaneBuf nx = (i + 1 < nq) ? q.at(2 * i + 2) : q;
+        const double pq0 = pq[0], pq1 = pq[1], nx0 = nx[0], nx1 = nx[1];
+        const double pqd = dir == 0 ? pq0 : pq1, nxd = dir == 0 ? nx0 : nx1, pqo = dir == 0 ? pq1 : pq0, nxo = dir == 0 ? nx1 : nx0;
+        bool in0 = sign * pqd < h, in1 = sign * nxd < h;
         if (in0) {
-          r[2 * nr] = pq[0]; r[2 * nr + 1] = pq[1];
+          r[2 * nr] = pq0; r[2 * nr + 1] = pq1;
           nr++;
           if (nr & 8) { done = true; break; }
         }
         if (in0 != in1) {
-          r[2 * nr + (1 - dir)] = pq[1 - dir] + (nx[1 - dir] - pq[1 - dir]) / (nx[dir] - pq[dir]) * (sign * h - pq[dir]);
+          r[2 * nr + (1 - dir)] = pqo + (nxo - pqo) / (nxd - pqd) * (sign * h - pqd);
           r[2 * nr + dir] = sign * h;
           nr++;
           if (nr & 8) { done = true; break; }
         }
       }
-      double* t = q; q = r; r = t;
+      LaneBuf t = q; q = r; r = t;
       nq = nr;
     }
   }
-  for (int i = 0; i < nr * 2; i++) ret[i] = q[i];
+  for (int i = 0; i < nr * 2; i++) { const double v = q[i]; ret[i] = v; }
   return nr;
 }
 
-// Returns the number of contacts written to out[0..7].
-DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, DevContact* out) {
+// Calls emit(contact) for every contact point (at most 8), in the reference's order; returns their number.  The contacts are
+// handed over one at a time so that they stay in registers (an out[8] array of 26-double records lived in scratch memory).
+template <class Emit>
+DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, LaneBuf clip, Emit emit) {
   const double fudge = 1.05;
   const M3& R1 = T1.R;
   const M3& R2 = T2.R;
@@ -133,13 +144,14 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
     pb = pb + beta * ub;
     double pen = -s;
     if (pen > clippingDepth) return 0;
-    DevContact& c = out[0];
+    DevContact c;
     c.point = 0.5 * (pa + pb);
     c.normal = -normal;
     c.depth = pen;
     c.type = CT_EDGE_EDGE;
     c.edgeAClosest = pa; c.edgeAFixed = fixedA; c.edgeADir = unit3(ua);
     c.edgeBClosest = pb; c.edgeBFixed = fixedB; c.edgeBDir = unit3(ub);
+    emit(c);
     return 1;
   }
 
@@ -176,8 +188,8 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
     quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
   }
   const double rect0 = Sa[code1], rect1 = Sa[code2];
-  double ret[16];
-  int n = intersectRectQuad(rect0, rect1, quad, ret);
+  const LaneBuf ret = clip.at(32);   // clip: 48 doubles per lane (two polygon buffers + the result)
+  int n = intersectRectQuad(rect0, rect1, quad, clip, clip.at(16), ret);
   if (n < 1) return 0;
   double det1 = 1.0 / (m11 * m22 - m12 * m21);
   m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
@@ -193,7 +205,7 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
     double dep = Sa[codeN] - dot(normal2, pt);
     if (!(dep >= 0)) continue;
     const double x = ret[j * 2], y = ret[j * 2 + 1];
-    DevContact& c = out[cnum];
+    DevContact c;
     c.point = pt + pa;
     c.normal = -normal;
     c.depth = dep;
@@ -225,6 +237,7 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
         t = c.edgeAFixed; c.edgeAFixed = c.edgeBFixed; c.edgeBFixed = t;
       }
     }
+    emit(c);
     cnum++;
   }
   return cnum;

@@ -42,6 +42,9 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
   const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);
+  __shared__ double keptP[MAX_CONTACTS * 3 * 64];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
+  __shared__ double clipBuf[48 * 64];               // clip polygons of boxBox, [entry][lane]
+  LaneBuf clip; clip.base = clipBuf + threadIdx.x;
   int nC = 0;
   bool overflow = false, edge = false;
   for (int pi = 0; pi < cm->nPairs; pi++) {
@@ -50,25 +53,23 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
     T12 Ta = cT(ba.T), Tb = cT(bb.T);
     if (ba.body >= 0) Ta = mulT(ldTAt(c, ba.body, WS_TW), Ta);
     if (bb.body >= 0) Tb = mulT(ldTAt(c, bb.body, WS_TW), Tb);
-    DevContact out[8];
-    int cnt = boxBox(Ta, mk3(ba.half[0], ba.half[1], ba.half[2]), Tb, mk3(bb.half[0], bb.half[1], bb.half[2]),
-                     cm->clippingDepth, out);
-    for (int k = 0; k < cnt; k++) {
-      const DevContact& ct = out[k];
-      // postProcess: skip points within 3e-12 of an accepted contact (DARTCollisionDetector.cpp:360-400)
+    boxBox(Ta, mk3(ba.half[0], ba.half[1], ba.half[2]), Tb, mk3(bb.half[0], bb.half[1], bb.half[2]), cm->clippingDepth, clip,
+           [&](const DevContact& ct) {
+      // postProcess: skip points within 3e-12 of an accepted contact (DARTCollisionDetector.cpp:360-400); the accepted
+      // points are kept in LDS (reading them back from the record would be a global round trip per comparison)
       bool close = false;
       for (int e = 0; e < nC; e++) {
-        const int r0 = lay.contacts + e * CR_SIZE;
-        V3 d = ct.point - mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
+        const V3 d = ct.point - mk3(keptP[(e * 3 + 0) * 64 + threadIdx.x], keptP[(e * 3 + 1) * 64 + threadIdx.x], keptP[(e * 3 + 2) * 64 + threadIdx.x]);
         if (norm3(d) < 3.0e-12) { close = true; break; }
       }
-      if (close) continue;
-      if (dot(ct.normal, ct.normal) < 1e-12) continue;
-      if (ct.depth < 0.0 || ct.depth > cm->clippingDepth) continue;
-      if (nC >= cm->maxContacts) { overflow = true; continue; }
+      if (close) return;
+      if (dot(ct.normal, ct.normal) < 1e-12) return;
+      if (ct.depth < 0.0 || ct.depth > cm->clippingDepth) return;
+      if (nC >= cm->maxContacts) { overflow = true; return; }
       const int r0 = lay.contacts + nC * CR_SIZE;
       auto st3 = [&](int off, V3 x) { svAt(saved, r0 + off, B, b) = x.x; svAt(saved, r0 + off + 1, B, b) = x.y; svAt(saved, r0 + off + 2, B, b) = x.z; };
       st3(CR_POINT, ct.point); st3(CR_NORMAL, ct.normal);
+      keptP[(nC * 3 + 0) * 64 + threadIdx.x] = ct.point.x; keptP[(nC * 3 + 1) * 64 + threadIdx.x] = ct.point.y; keptP[(nC * 3 + 2) * 64 + threadIdx.x] = ct.point.z;
       svAt(saved, r0 + CR_DEPTH, B, b) = ct.depth;
       svAt(saved, r0 + CR_TYPE, B, b) = (double)ct.type;
       svAt(saved, r0 + CR_BOXA, B, b) = (double)cm->pairA[pi];
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
       st3(CR_EA_FIXED, ct.edgeAFixed); st3(CR_EA_DIR, ct.edgeADir); st3(CR_EB_FIXED, ct.edgeBFixed); st3(CR_EB_DIR, ct.edgeBDir);
       if (ct.type == CT_EDGE_EDGE) edge = true;
       nC++;
-    }
+    });
   }
   // NOTE: the duplicate filter above only sees contacts that were kept; the reference compares against every
   // contact of the total result including ones later dropped by the depth filter.  Those can only coincide

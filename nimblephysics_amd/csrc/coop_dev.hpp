@@ -66,6 +66,15 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
     for (int i = 1 + 4 * ((MAXR - 1) / 4); i < MAXR; i++) b0 = fma(a[i], a[i], b0);
     const double below = (b0 + b1) + (b2 + b3);
     const double nrm = fma(a[0], a[0], below);
+    // Every lane prepares the reflector scalars of ITS column before the pivot is known: the sqrt -> divide chain
+    // (~60 dependent instructions) then overlaps with the wave-wide arg-max below instead of following it on one lane.
+    const double akk = a[0];
+    const double normx = sqrt(nrm);
+    const double alpha = akk > 0 ? -normx : normx;
+    const double vk = akk - alpha;                   // v = x - alpha e_k, scaled so that v_k = 1
+    const double vnorm2 = fma(vk, vk, below);
+    const double inv = 1.0 / vk;
+    const double tauMine = 2.0 * vk * vk / vnorm2;   // tau:  H = I - tau v v^T   (unused lanes may hold inf / NaN)
     int p = k;
     if (PIVOT) {
       const double cand = (ln < MAXR && !done) ? nrm : -1.0;
@@ -76,13 +85,7 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
     }
     double* vb = S.vbuf[k & 1];
     if (ln == p) {
-      const double akk = a[0];
-      const double normx = sqrt(nrm);
-      const double alpha = akk > 0 ? -normx : normx;
-      const double vk = akk - alpha;                 // v = x - alpha e_k, scaled so that v_k = 1
-      const double vnorm2 = fma(vk, vk, below);
-      const double inv = 1.0 / vk;
-      vb[MAXR] = 2.0 * vk * vk / vnorm2;             // tau:  H = I - tau v v^T
+      vb[MAXR] = tauMine;
 #pragma unroll
       for (int i = 1; i < MAXR; i++) { vb[i] = a[i] * inv; a[i] = 0.0; }
       a[0] = alpha;
