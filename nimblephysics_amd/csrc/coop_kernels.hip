@@ -502,6 +502,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   extern __shared__ __attribute__((aligned(16))) double ldsB[];
   const DevWave w;
   const int ln = w.lane();
+  NBL_PHASE(48);
   const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
   if (b >= mdl.b1) return;
   if (lws[(int64_t)LB_FLAG * B + b] == 0.0) return;
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
   }
   for (int idx = ln; idx < nb * 54; idx += 64) D[idx] = 0.0;
   w.sync();
+  NBL_PHASE(49);
   // ---- phase 1a: world twists of the nine joint-rate fields.  lane = (body, field): own joint twist in the world frame,
   //      then lane = (field, component): prefix sums down the tree (bodies are listed parents first) ----
   for (int item = ln; item < nb * 9; item += 64) {
@@ -556,6 +558,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     }
   }
   w.sync();
+  NBL_PHASE(50);
   // ---- phase 2: per-row constants, side A then side B ----
   double cf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool any = false;
@@ -582,6 +585,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
       RT = contactRowTerms(CR, TF_, k, d, TA - TB);
     }
   }
+  NBL_PHASE(51);
   const bool aIsVertex = (CR.type == CT_VERTEX_FACE);
   for (int side = 0; side < 2; side++) {
     if (ln < MAX_ROWS) {
@@ -610,6 +614,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     }
     w.sync();
   }
+  NBL_PHASE(52);
   // ---- phase 1b (after the rows: TF takes over tmp's storage): local wrenches of the nine fields, world frame ----
   for (int item = ln; item < nb * 9; item += 64) {
     const int i = item / 9;
@@ -618,6 +623,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     st6(TF + item * 6, 1, dAdInvT(TW, mul(cS6(bodies[i].G), twB)));
   }
   w.sync();
+  NBL_PHASE(53);
   // ---- phase 3: subtree sums, leaf -> root (D and the transmitted wrenches) ----
   if (ln < 54) {
     for (int i = nb - 1; i >= 1; i--) {
@@ -626,6 +632,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     }
   }
   w.sync();
+  NBL_PHASE(54);
   // ---- phase 4 ----
   if (ln < nb) {
     const int i = ln;
@@ -643,6 +650,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
     applyHt(bd, q, B, b, dAdT(cT(TWs + 12 * i), xiW), qb);
     for (int k = 0; k < bd.ndof; k++) lws[(int64_t)(LB_QX + bd.dofOff + k) * B + b] = qb[k];
   }
+  NBL_PHASE(55);
 }
 
 }  // namespace nbl

@@ -181,7 +181,7 @@ DEV M3 expMapRot(V3 q) {
   M3 S = skew(q), S2 = mul(S, S), R;
   double A, B;
   if (theta < 1.0e-3) { A = 1.0; B = 0.5; }
-  else { A = sin(theta) / theta; B = (1 - cos(theta)) / (theta * theta); }
+  else { double st, ct; sincos(theta, &st, &ct); A = st / theta; B = (1 - ct) / (theta * theta); }   // one range reduction for both
   M3 I = eye3();
 #pragma unroll
   for (int i = 0; i < 9; i++) R.m[i] = I.m[i] + A * S.m[i] + B * S2.m[i];
@@ -192,7 +192,7 @@ DEV M3 expMapJac(V3 q) {
   M3 S = skew(q), S2 = mul(S, S), J;
   double A, B;
   if (theta < 1.0e-3) { A = 0.5; B = 1.0 / 6.0; }
-  else { A = (1 - cos(theta)) / (theta * theta); B = (theta - sin(theta)) / (theta * theta * theta); }
+  else { double st, ct; sincos(theta, &st, &ct); A = (1 - ct) / (theta * theta); B = (theta - st) / (theta * theta * theta); }
   M3 I = eye3();
 #pragma unroll
   for (int i = 0; i < 9; i++) J.m[i] = I.m[i] + A * S.m[i] + B * S2.m[i];
@@ -210,14 +210,16 @@ DEV V3 logMap(const M3& R) {
     double d = theta * sqrt(1.0 + (R.m[8] - 1.0) * delta);
     return mk3(R.m[7] > R.m[5] ? a : -a, R.m[2] > R.m[6] ? b : -b, R.m[3] > R.m[1] ? d : -d);
   }
-  double alpha = (theta > 1e-6) ? 0.5 * theta / sin(theta) : 0.5 + (1.0 / 12.0) * theta * theta;
+  // sin(acos(c)) = sqrt((1 - c)(1 + c)): both factors are exact near |c| = 1, no second transcendental
+  double alpha = (theta > 1e-6) ? 0.5 * theta / sqrt((1.0 - c) * (1.0 + c)) : 0.5 + (1.0 / 12.0) * theta * theta;
   return mk3(alpha * (R.m[7] - R.m[5]), alpha * (R.m[2] - R.m[6]), alpha * (R.m[3] - R.m[1]));
 }
 DEV M3 expAngular(V3 s) {
   double s2x = s.x * s.x, s2y = s.y * s.y, s2z = s.z * s.z;
   double s3x = s.x * s.y, s3y = s.y * s.z, s3z = s.z * s.x;
-  double theta = sqrt(s2x + s2y + s2z), cos_t = cos(theta), alpha, beta;
-  if (theta > 1e-6) { alpha = sin(theta) / theta; beta = (1.0 - cos_t) / theta / theta; }
+  double theta = sqrt(s2x + s2y + s2z), sin_t, cos_t, alpha, beta;
+  sincos(theta, &sin_t, &cos_t);
+  if (theta > 1e-6) { alpha = sin_t / theta; beta = (1.0 - cos_t) / theta / theta; }
   else { alpha = 1.0 - theta * theta / 6.0; beta = 0.5 - theta * theta / 24.0; }
   M3 r;
   r.m[0] = beta * s2x + cos_t;       r.m[1] = beta * s3x - alpha * s.z; r.m[2] = beta * s3z + alpha * s.y;
@@ -235,7 +237,8 @@ DEV V3 expMapRot_vjp(V3 q, const M3& Rb) {
   bool taylor = theta < 1.0e-3;
   if (taylor) { A = 1.0; B = 0.5; }
   else {
-    double st = sin(theta), ct = cos(theta);
+    double st, ct;
+    sincos(theta, &st, &ct);
     A = st / theta; B = (1 - ct) / th2;
     dA = (theta * ct - st) / th2;
     dB = (theta * st - 2 * (1 - ct)) / (th2 * theta);
@@ -264,7 +267,7 @@ DEV M3 logMap_vjp(const M3& R, V3 rb) {
   V3 w = mk3(R.m[7] - R.m[5], R.m[2] - R.m[6], R.m[3] - R.m[1]);
   double alpha, dalpha;
   if (theta > 1e-6) {
-    double st = sin(theta), ct = cos(theta);
+    const double st = sqrt((1.0 - c) * (1.0 + c)), ct = c;   // sin / cos of acos(c)
     alpha = 0.5 * theta / st;
     dalpha = 0.5 * (st - theta * ct) / (st * st);
   } else { alpha = 0.5 + (1.0 / 12.0) * theta * theta; dalpha = (1.0 / 6.0) * theta; }

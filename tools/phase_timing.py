@@ -47,5 +47,10 @@ for it in range(3):
     print(f"   solve total {t[47] - t[40]}")
     for k in sorted(sn):
         print(f"   {sn[k]:38s} {t[k] - t[k - 1]:8d}")
+    bb = {49: "bwd_b: staging (TW, contact bodies)", 50: "bwd_b: 1a twist fields + prefix", 51: "bwd_b: 2 row constants (loads, terms)",
+          52: "bwd_b: 2 sides A/B scatter", 53: "bwd_b: 1b local wrenches", 54: "bwd_b: 3 subtree sums", 55: "bwd_b: 4 projection + stores"}
+    print(f"   bwd_b total {t[55] - t[48]}")
+    for k in sorted(bb):
+        print(f"   {bb[k]:38s} {t[k] - t[k - 1]:8d}")
     for k in sorted(bnames):
         print(f"   {bnames[k]:34s} {t[k] - t[k - 1]:8d}")
