@@ -124,7 +124,17 @@ __global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const
   const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
   CoopCascadeOut out;
   coopCascade(w, S, C, R, X0, cm->fallbackCfm, out);
-  coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+  // The record always carries Q^+ of the final classification when there is a clamping row, so that the backward pass never
+  // has to factorise (its fallback cost k_bwd_contact_a_coop half its occupancy).  Stages that end without one (PGS results
+  // accepted as they are) pay for it here, on the few worlds that reach this kernel.
+  bool pinvValid = out.pinvValid;
+  if (!pinvValid && out.K.nc > 0) {
+    double a[MAXR];
+    coopBuildQ(w, S, R, out.K, out.cfm, a);
+    coopPinv(w, a, S, out.K.nc);
+    pinvValid = true;
+  }
+  coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
   if (ln == 0 && status) status[b] |= out.st;
 #ifdef NBL_CASCADE_TIMING
   if (ln == 0) for (int k = 0; k < 7; k++) lws[(int64_t)(LW_JB + k) * B + b] = (double)(out.t[k] - out.t[0]);   // debug: cycle stamps
@@ -147,6 +157,9 @@ __attribute__((noinline)) DEV void coopPinvFromRecord(CoopLds& S, const CoopRow&
   coopPinv(w, a, S, K.nc);
 }
 
+// FALLBACK: records whose forward pass did not leave Q^+ (one-world-per-lane cascade, NBL_COOP_CASCADE=0) are factorised here;
+// the wavefront-per-world forward kernels always store it, and the variant without the fallback needs half the registers.
+template <bool FALLBACK>
 __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ gnext, double* __restrict__ lws) {
@@ -172,9 +185,19 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   const int bxA = (int)svAt(saved, r0c + CR_BOXA, B, b), bxB = (int)svAt(saved, r0c + CR_BOXB, B, b);
   const double muTab = cm->boxes[ln < MAX_BOXES ? ln : 0].mu;       // collider -> mu, looked up with ds_bpermute
   const double lam1 = lws[(int64_t)(LB_LAM1 + dof) * B + b];
-  double Acol[MAXR], Pcol[MAXR];
+  double Acol[MAXR];
 #pragma unroll
-  for (int i = 0; i < MAXR; i++) { Acol[i] = dn[lay.A + i * MAX_ROWS + row]; Pcol[i] = dn[lay.pinv + i * MAX_ROWS + row]; }
+  for (int i = 0; i < MAXR; i++) Acol[i] = dn[lay.A + i * MAX_ROWS + row];
+  {
+    // Q^+ of the record goes straight to LDS (its registers are free again as soon as the values have arrived)
+    double Pcol[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) Pcol[i] = dn[lay.pinv + i * MAX_ROWS + row];
+    if (ln < MAXR) {
+#pragma unroll
+      for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = Pcol[i];
+    }
+  }
   if (flagD == 0.0) return;   // k_bwd_recompute: no clamping row in this world
   const int m = 3 * (int)ncD;
   const bool rowOn = ln < m;
@@ -231,20 +254,29 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   const double fbar = clamp ? t + tf : 0.0;
   w.sync();
   // Q^+
-  if (pflagD != 0.0) {
+  if (pflagD != 0.0) w.sync();   // S.P was filled from the record at the top
+  else if (FALLBACK) coopPinvFromRecord(S, R, K, cfm);
+  else {
+    // cannot happen with records of the wavefront-per-world forward kernels; make it loud instead of silently wrong
     if (ln < MAXR) {
 #pragma unroll
-      for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = Pcol[i];
+      for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = __builtin_nan("");
     }
     w.sync();
-  } else coopPinvFromRecord(S, R, K, cfm);
-  // A x for this lane's row from the column held in registers (A is symmetric), x one entry per lane
+  }
+  // A (masked to the rows in use) moves to the G buffer, free once Q^+ exists: 48 registers less for the rest of the kernel
+  if (ln < MAXR) {
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) S.G[i * CLD + ln] = Acol[i];
+  }
+  w.sync();
+  // A x for this lane's row (A is symmetric: row = column), x one entry per lane
   auto ax = [&](double xLane, int slot) -> double {
     if (ln < MAXR) S.vec[slot][ln] = rowOn ? xLane : 0.0;
     w.sync();
     double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-    for (int jx = 0; jx < MAXR; jx += 2) { v0 = fma(Acol[jx], S.vec[slot][jx], v0); v1 = fma(Acol[jx + 1], S.vec[slot][jx + 1], v1); }
+    for (int jx = 0; jx < MAXR; jx += 2) { v0 = fma(S.G[jx * CLD + row], S.vec[slot][jx], v0); v1 = fma(S.G[(jx + 1) * CLD + row], S.vec[slot][jx + 1], v1); }
     return v0 + v1;
   };
   const double bcl = clamp ? R.Bv : 0.0;

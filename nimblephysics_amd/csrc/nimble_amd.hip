@@ -522,8 +522,11 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, h
                                               (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
       dim3 lgrid((unsigned)((cnt + ll - 1) / ll)), lblock(ll);
       const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
-      if (m->coop)
-        TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
+      if (m->coop && m->coopCascade)
+        TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
+                                               m->lay, grad_next_state, lws));
+      else if (m->coop)
+        TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop<true>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
                                                m->lay, grad_next_state, lws));
       else
         TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, mdl, m->dBodies, m->dDofs, m->dContact,
