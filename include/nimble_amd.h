@@ -214,6 +214,11 @@ int32_t nbl_rollout_forward(nbl_model* m, int64_t B, int32_t T, const double* st
 int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
                              double* grad_state0, double* grad_actions, void* workspace, size_t workspace_bytes,
                              void* stream);
+/* The same with the inertia ("mass") parameters of nbl_set_inertia_params: grad_params [count][B] receives the sum over the T
+ * steps of dL/dtheta_p (the masses are constant along the trajectory); NULL = nbl_rollout_backward. */
+int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
+                                     double* grad_state0, double* grad_actions, double* grad_params, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 
 /*
  * Layout helpers: the Python surface takes world-major tensors [B][d] like a stack of the

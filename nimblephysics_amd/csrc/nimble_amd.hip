@@ -603,19 +603,23 @@ int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodie
 
 int32_t nbl_num_inertia_params(const nbl_model* m) { return m ? m->nParams : 0; }
 
+static void launchInertia(nbl_model* m, int64_t B, int64_t b0, int64_t b1, hipStream_t s, const void* saved, double* grad_params,
+                          int accumulate, void* workspace) {
+  DevModel mdl = m->mdl;
+  mdl.b0 = b0; mdl.b1 = b1;
+  SavedLayout lay = m->lay;
+  if (m->coopTree && !m->coopFinal) { lay.treeRows = 0; lay.treeNbp = 0; }   // k_tree_to_lanes left the kept slots in the workspace
+  hipLaunchKernelGGL(k_bwd_inertia, dim3((unsigned)((b1 - b0 + 63) / 64)), dim3(64), 0, s, mdl, m->dBodies, m->dDofs, B,
+                     (const double*)saved, lay, m->dParams, m->nParams, grad_params, accumulate, (double*)workspace);
+}
+
 int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double* grad_params, int32_t accumulate, void* workspace,
                              size_t workspace_bytes, void* stream) {
   if (!m || !saved || !grad_params || !workspace) return fail(NBL_E_BADARG, "null argument");
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (m->nParams <= 0) return fail(NBL_E_BADARG, "no inertia parameters registered (nbl_set_inertia_params)");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
-  hipStream_t s = (hipStream_t)stream;
-  DevModel mdl = m->mdl;
-  mdl.b0 = 0; mdl.b1 = B;
-  SavedLayout lay = m->lay;
-  if (m->coopTree && !m->coopFinal) { lay.treeRows = 0; lay.treeNbp = 0; }   // k_tree_to_lanes left the kept slots in the workspace
-  hipLaunchKernelGGL(k_bwd_inertia, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, mdl, m->dBodies, m->dDofs, B,
-                     (const double*)saved, lay, m->dParams, m->nParams, grad_params, accumulate, (double*)workspace);
+  launchInertia(m, B, 0, B, (hipStream_t)stream, saved, grad_params, accumulate, workspace);
   HIP_TRY(hipGetLastError());
   return NBL_OK;
 }
@@ -691,7 +695,14 @@ __global__ __launch_bounds__(256) void k_copy_rows(double* __restrict__ dst, con
 int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
                              double* grad_state0, double* grad_actions, void* workspace, size_t workspace_bytes,
                              void* stream) {
+  return nbl_rollout_backward_inertia(m, B, T, saved, grad_states, grad_state0, grad_actions, nullptr, workspace, workspace_bytes, stream);
+}
+
+int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
+                                     double* grad_state0, double* grad_actions, double* grad_params, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   if (!m || !saved || !grad_states || !grad_state0 || !grad_actions || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (grad_params && m->nParams <= 0) return fail(NBL_E_BADARG, "no inertia parameters registered (nbl_set_inertia_params)");
   if (B <= 0 || T <= 0) return fail(NBL_E_BADARG, "B and T must be positive");
   if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
   hipStream_t s0 = (hipStream_t)stream;
@@ -709,6 +720,7 @@ int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* sav
       const int32_t r = launchBackward(m, B, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, g, grad_state0,
                                        grad_actions + (size_t)t * actElems, workspace);
       if (r != NBL_OK) return r;
+      if (grad_params) launchInertia(m, B, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, grad_params, t != T - 1, workspace);
       hipLaunchKernelGGL(k_add_rows, dim3(blocks), dim3(256), 0, s, grad_state0, grad_states + (size_t)t * stateElems, B, b0, b1, rows);
       if (t > 0) hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, (const double*)grad_state0, B, b0, b1, rows);
     }

@@ -74,7 +74,13 @@ class RolloutLayer(torch.autograd.Function):
     forwardPass, and of backpropGradientWrt over backprop, kept on the device)."""
 
     @staticmethod
-    def forward(ctx, world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool):
+    def forward(ctx, world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool, mass: Optional[torch.Tensor] = None):
+        ctx.use_mass = mass is not None
+        if ctx.use_mass:
+            if mass.dim() != 1 or mass.shape[0] != world.getMassDims():
+                raise ValueError(f"mass must be a 1-D tensor of world.getMassDims() = {world.getMassDims()} entries")
+            world.setMasses(mass)                                     # constant along the trajectory
+            ctx.mass_device = mass.device
         in_device = state0.device
         s = world._prep(state0, 2 * world.n, "setState")
         if actions.dim() != 3 or actions.shape[0] != s.shape[0] or actions.shape[2] != world.k:
@@ -93,11 +99,18 @@ class RolloutLayer(torch.autograd.Function):
     def backward(ctx, grad_states):
         world: World = ctx.world
         g = grad_states.detach().to(device=world.device, dtype=torch.float64).permute(1, 2, 0).contiguous()   # [T+1][2n][B]
-        g0, ga = world.rollout_backward_soa(ctx.saved_record, g)
-        return None, world.from_soa(g0).to(ctx.in_device), ga.permute(2, 0, 1).contiguous().to(ctx.action_device), None
+        d_mass = None
+        if ctx.use_mass:
+            g0, ga, gm = world.rollout_backward_soa(ctx.saved_record, g, want_mass=True)
+            d_mass = gm.sum(dim=1).to(ctx.mass_device)                # one mass vector for all worlds and steps
+        else:
+            g0, ga = world.rollout_backward_soa(ctx.saved_record, g)
+        return None, world.from_soa(g0).to(ctx.in_device), ga.permute(2, 0, 1).contiguous().to(ctx.action_device), None, d_mass
 
 
-def rollout(world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool = True) -> torch.Tensor:
-    """states[:, 0] = state0, states[:, t+1] = timestep(world, states[:, t], actions[:, t]).
-    state0 [B, 2n], actions [B, T, k] -> states [B, T+1, 2n]; differentiable wrt state0 and actions."""
-    return RolloutLayer.apply(world, state0, actions, warm_start)
+def rollout(world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool = True,
+            mass: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """states[:, 0] = state0, states[:, t+1] = timestep(world, states[:, t], actions[:, t][, mass]).
+    state0 [B, 2n], actions [B, T, k] -> states [B, T+1, 2n]; differentiable wrt state0, actions and (when given) the
+    world's registered mass vector."""
+    return RolloutLayer.apply(world, state0, actions, warm_start, mass)

@@ -290,15 +290,23 @@ class World:
         self.last_status = status[-1]
         return states, saved, status
 
-    def rollout_backward_soa(self, saved: torch.Tensor, grad_states: torch.Tensor):
-        """grad_states [T+1][2n][B] -> (grad_state0 [2n][B], grad_actions [T][k][B])."""
+    def rollout_backward_soa(self, saved: torch.Tensor, grad_states: torch.Tensor, want_mass: bool = False):
+        """grad_states [T+1][2n][B] -> (grad_state0 [2n][B], grad_actions [T][k][B]) and, with want_mass, the gradient with
+        respect to the registered mass vector summed over the T steps, [massDims][B]."""
         T = grad_states.shape[0] - 1
         B = grad_states.shape[2]
         g0 = torch.empty((2 * self.n, B), dtype=torch.float64, device=self.device)
         ga = torch.empty((T, self.k, B), dtype=torch.float64, device=self.device)
         ws = self._rollout_workspace(B)
+        if want_mass and self.getMassDims() > 0:
+            gm = torch.empty((self.getMassDims(), B), dtype=torch.float64, device=self.device)
+            check(self._L.nbl_rollout_backward_inertia(self._h, B, T, _ptr(saved), _ptr(grad_states), _ptr(g0), _ptr(ga), _ptr(gm),
+                                                       _ptr(ws), ws.numel(), self._stream()), "nbl_rollout_backward_inertia")
+            return g0, ga, gm
         check(self._L.nbl_rollout_backward(self._h, B, T, _ptr(saved), _ptr(grad_states), _ptr(g0), _ptr(ga), _ptr(ws),
                                            ws.numel(), self._stream()), "nbl_rollout_backward")
+        if want_mass:
+            return g0, ga, torch.zeros((0, B), dtype=torch.float64, device=self.device)
         return g0, ga
 
     def step(self):

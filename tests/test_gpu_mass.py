@@ -146,3 +146,37 @@ def test_timestep_mass_argument_autograd():
     ref = _oracle_fd(md2, [(1, T.INERTIA_MASS), (0, T.INERTIA_MASS)], s, a, g).sum(0)
     assert mass.grad.shape == (2,)
     assert np.abs(mass.grad.numpy() - ref).max() < 2e-6 * np.abs(ref).max()
+
+
+def test_rollout_mass_gradient_equals_the_chain_of_timesteps():
+    """rollout(..., mass=) sums the per-step inertia gradients on the device (nbl_rollout_backward_inertia); the chain of
+    timestep(..., mass) calls through autograd must give the same state / action / mass gradients."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.mass import WrtMassBodyNodeEntryType as T
+    from nimblephysics_amd.timestep import rollout, timestep
+    from util import contact_inputs
+    md, s, a = contact_inputs("atlas20", 128, 41)
+    Tn = 6
+    rng = np.random.default_rng(42)
+    acts = rng.normal(0, 0.1, (128, Tn, a.shape[1]))
+    gT = rng.normal(0, 1, (128, Tn + 1, s.shape[1]))
+    res = []
+    for mode in ("rollout", "chain"):
+        world = na.World(md, device="cuda:0")
+        world.tuneMass(0, T.INERTIA_MASS); world.tuneMass(3, T.INERTIA_COM)
+        mass = world.getMasses().clone().requires_grad_(True)
+        st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(acts, device="cuda:0", requires_grad=True)
+        if mode == "rollout":
+            states = rollout(world, st, at, warm_start=False, mass=mass)
+        else:
+            xs = [st]
+            for t in range(Tn):
+                world.reset_lcp_cache()
+                xs.append(timestep(world, xs[-1], at[:, t], mass))
+            states = torch.stack(xs, 1)
+        (states * torch.tensor(gT, device="cuda:0")).sum().backward()
+        res.append((states.detach().cpu().numpy(), st.grad.cpu().numpy(), at.grad.cpu().numpy(), mass.grad.numpy()))
+    for x, y in zip(res[0], res[1]):
+        assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(y).max())
+    assert np.abs(res[0][3]).max() > 0
