@@ -94,7 +94,7 @@ typedef struct nbl_model_desc {
   int32_t n_action;
   const int32_t* action_map; /* [n_action] */
 
-  /* ---- contact: box colliders only (dBoxBox path, DARTCollide.cpp:764-1450) ---- */
+  /* ---- contact: box colliders (dBoxBox, DARTCollide.cpp:764-1450) and spheres (box_shape below) ---- */
   int32_t n_boxes;
   const int32_t* box_body;  /* [n_boxes] body index, -1 = fixed to the world (immobile skeleton) */
   const double* box_T;      /* [n_boxes][12] shape transform in the body frame */
@@ -105,7 +105,15 @@ typedef struct nbl_model_desc {
   /* ---- options mirrored from the reference defaults ---- */
   double contact_clipping_depth; /* 0.03  World.cpp:86 */
   double fallback_cfm;           /* 1e-4  World.cpp:85 */
+
+  /* ---- collider shapes (appended; NULL = every collider is a box) ----
+   * [n_boxes] NBL_SHAPE_BOX | NBL_SHAPE_SPHERE.  A sphere's radius is box_size[3*i]; sphere-box, box-sphere and
+   * sphere-sphere pairs follow collideSphereBox / collideBoxSphere / collideSphereSphere (DARTCollide.cpp:1482-1880). */
+  const int32_t* box_shape;
 } nbl_model_desc;
+
+#define NBL_SHAPE_BOX 0
+#define NBL_SHAPE_SPHERE 1
 
 typedef struct nbl_model nbl_model; /* opaque */
 

@@ -66,4 +66,5 @@ class ModelDesc(C.Structure):
         ("max_contacts", C.c_int32),
         ("contact_clipping_depth", C.c_double),
         ("fallback_cfm", C.c_double),
+        ("box_shape", _pi),
     ]

@@ -11,7 +11,7 @@
 
 namespace nbl {
 
-constexpr int CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3;
+constexpr int CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3, CT_SPHERE_BOX = 4, CT_BOX_SPHERE = 5, CT_SPHERE_SPHERE = 6;   // Contact.hpp:45-61
 
 struct DevContact {
   V3 point, normal;
@@ -241,6 +241,75 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
     cnum++;
   }
   return cnum;
+}
+
+// collideBoxSphere (DARTCollide.cpp:1482-1653; the box is the first object) / collideSphereBox (:1655-1810; the sphere is):
+// the sphere centre is clamped to the box, every clamped axis locks that face normal; the normal points from the second
+// object towards the first; a centre inside the box is a plain FACE_VERTEX / VERTEX_FACE contact at the centre.
+// Annotations in the edge slots: edgeAFixed = sphere centre, edgeADir / edgeBFixed / edgeBDir = the locked face normals.
+template <class Emit>
+DEV int sphereBoxPair(bool sphereFirst, double r, const T12& Ts, V3 half, const T12& Tb, double clippingDepth, Emit emit) {
+  const V3 c0 = Ts.p;
+  const V3 pl = tmul(Tb.R, c0 - Tb.p);
+  const double px = fmin(fmax(pl.x, -half.x), half.x), py = fmin(fmax(pl.y, -half.y), half.y), pz = fmin(fmax(pl.z, -half.z), half.z);
+  const bool lx = pl.x < -half.x || pl.x > half.x, ly = pl.y < -half.y || pl.y > half.y, lz = pl.z < -half.z || pl.z > half.z;
+  const bool inside = !(lx || ly || lz);
+  DevContact c;
+  c.edgeAClosest = c.edgeBClosest = mk3(0, 0, 0);
+  c.edgeAFixed = c0;
+  c.edgeADir = lx ? colOf(Tb.R, 0) : mk3(0, 0, 0);
+  c.edgeBFixed = ly ? colOf(Tb.R, 1) : mk3(0, 0, 0);
+  c.edgeBDir = lz ? colOf(Tb.R, 2) : mk3(0, 0, 0);
+  c.type = sphereFirst ? CT_SPHERE_BOX : CT_BOX_SPHERE;
+  const double outward = sphereFirst ? 1.0 : -1.0;
+  // nearest side of the (clamped) point, in the reference's comparison order
+  double mn = half.x - fabs(px);
+  int idx = 0;
+  double t = half.y - fabs(py);
+  if (t < mn) { mn = t; idx = 1; }
+  t = half.z - fabs(pz);
+  if (t < mn) { mn = t; idx = 2; }
+  const double pidx = idx == 0 ? px : (idx == 1 ? py : pz);
+  const V3 sideNormal = ((pidx > 0.0 ? 1.0 : -1.0) * outward) * colOf(Tb.R, idx);
+  if (inside) {
+    const double pen = mn + r;
+    if (pen > clippingDepth) return 0;
+    c.type = sphereFirst ? CT_VERTEX_FACE : CT_FACE_VERTEX;
+    c.point = c0; c.normal = sideNormal; c.depth = pen;
+    emit(c);
+    return 1;
+  }
+  const V3 contactpt = mul(Tb.R, mk3(px, py, pz)) + Tb.p;
+  V3 normal = sphereFirst ? c0 - contactpt : contactpt - c0;
+  const double mag = norm3(normal), pen = r - mag;
+  if (pen > clippingDepth) return 0;
+  if (pen < 0.0) return 0;
+  if (mag > 1e-6) normal = (1.0 / mag) * normal;     // DART_COLLISION_EPS
+  else normal = sideNormal;
+  c.point = contactpt; c.normal = normal; c.depth = pen;
+  emit(c);
+  return 1;
+}
+
+// collideSphereSphere (DARTCollide.cpp:1812-1880).  Annotations: edgeAFixed = centre A, edgeBFixed = centre B, edgeADir = (rA, rB, 0)
+template <class Emit>
+DEV int sphereSphere(double r0, const T12& T0, double r1, const T12& T1, double clippingDepth, Emit emit) {
+  const double rsum = r0 + r1;
+  V3 normal = T0.p - T1.p;
+  const double nsq = dot(normal, normal);
+  if (nsq > rsum * rsum) return 0;
+  DevContact c;
+  c.edgeAClosest = c.edgeBClosest = c.edgeBDir = mk3(0, 0, 0);
+  c.type = CT_SPHERE_SPHERE;
+  c.edgeAFixed = T0.p; c.edgeBFixed = T1.p;
+  const double w0 = r0 / rsum, w1 = r1 / rsum;
+  c.edgeADir = mk3(w0 * rsum, w1 * rsum, 0);
+  c.point = w1 * T0.p + w0 * T1.p;
+  if (nsq < 1e-6) { c.normal = mk3(0, 0, 0); c.depth = rsum; }
+  else { const double len = sqrt(nsq); c.normal = (1.0 / len) * normal; c.depth = rsum - len; }
+  if (c.depth > clippingDepth) return 0;
+  emit(c);
+  return 1;
 }
 
 }  // namespace nbl

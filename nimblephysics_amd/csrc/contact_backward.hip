@@ -240,12 +240,42 @@ DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k,
   // the contact point is the midpoint of the closest points of the two edge lines, the normal follows
   // +-eB x eA.  Both are linear in the position twist [w; u] of the moving DOF; their adjoints:
   out.edgeTermA = zero6(); out.edgeTermB = zero6();
-  if (R.type == CT_EDGE_EDGE) {
-    const V3 eAP = R.eAP, eAD = R.eAD, eBP = R.eBP, eBD = R.eBD;
-    V3 hN;   // cc . d(dir) = hN . dn
+  V3 hN = mk3(0, 0, 0);   // cc . d(dir) = hN . dn for a normal that moves by dn (direction k follows through the tangent basis)
+  if (R.type >= CT_EDGE_EDGE) {
     if (k == 0) hN = cc;
     else if (k == 1) { V3 xp = project ? cc - dot(cc, t1) * t1 : cc; hN = (1.0 / tn) * cross(xp, crs); }
     else { V3 x2 = cross(cc, nrm); V3 xp = project ? x2 - dot(x2, t1) * t1 : x2; hN = cross(t1, cc) + (1.0 / tn) * cross(xp, crs); }
+  }
+  // Sphere contacts (DCC.cpp:116-228 types, :328-403 point, :626-709 normal).  Both the contact point and the normal are linear
+  // in the position twist s = [w; u] of the moving DOF, dp = Mp s and dn = Mn s, so its share is Mp^T cv + Mn^T hN.  With
+  // g_x(s) = w x x + u, whose adjoint is x -> [x_pt x x; x]:
+  //   sphere side of a sphere-box contact:  dp = P g_c,                dn = sigma (1 - n n^T)(P - 1) g_c / |c - p|
+  //   box side:                             dp = g_p - P g_c,          dn = sigma (1 - n n^T) dp / |c - p|
+  //   (c the sphere centre, P removes the locked face normals, sigma = +1 for BOX_SPHERE: n = p - c, -1 for SPHERE_BOX)
+  //   sphere A of a sphere-sphere contact:  dp = rB/(rA+rB) g_cA,      dn = +(1 - n n^T) g_cA / |cA - cB|   (B: mirrored, -)
+  if (R.type == CT_SPHERE_BOX || R.type == CT_BOX_SPHERE) {
+    const V3 c = R.eAP, n0 = R.eAD, n1 = R.eBP, n2 = R.eBD;
+    auto P = [&](V3 x) -> V3 { return x - dot(n0, x) * n0 - dot(n1, x) * n1 - dot(n2, x) * n2; };
+    auto adj = [&](V3 pt, V3 x) -> V6 { return mk6(cross(pt, x), x); };
+    const double len = norm3(c - p), invLen = len > 1e-5 ? 1.0 / len : 1.0;
+    const double sigma = R.type == CT_BOX_SPHERE ? 1.0 : -1.0;
+    const V3 y = (sigma * invLen) * (hN - dot(nrm, hN) * nrm);
+    const V6 sphereSide = adj(c, P(cv)) + adj(c, P(y) - y);
+    const V6 boxSide = adj(p, cv) - adj(c, P(cv)) + adj(p, y) - adj(c, P(y));
+    const bool aIsSphere = R.type == CT_SPHERE_BOX;
+    out.edgeTermA = aIsSphere ? sphereSide : boxSide;
+    out.edgeTermB = aIsSphere ? boxSide : sphereSide;
+  }
+  if (R.type == CT_SPHERE_SPHERE) {
+    const V3 cA = R.eAP, cB = R.eBP;
+    const double rA = R.eAD.x, rB = R.eAD.y, invL = 1.0 / norm3(cA - cB);
+    const V3 y = invL * (hN - dot(nrm, hN) * nrm);
+    const V3 xa = (rB / (rA + rB)) * cv + y, xb = (rA / (rA + rB)) * cv - y;
+    out.edgeTermA = mk6(cross(cA, xa), xa);
+    out.edgeTermB = mk6(cross(cB, xb), xb);
+  }
+  if (R.type == CT_EDGE_EDGE) {
+    const V3 eAP = R.eAP, eAD = R.eAD, eBP = R.eBP, eBD = R.eBD;
     const double sgnN = dot(cross(eBD, eAD), nrm) < 0 ? -1.0 : 1.0;
     V3 pv = eBP - eAP;
     const double uaub = dot(eAD, eBD), q1 = dot(eAD, pv), q2 = -dot(eBD, pv), dd = 1 - uaub * uaub;
@@ -367,7 +397,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBod
             V6 Zl = sgn * (Tend - twistOf(par));
             V6 add = -dad(Zl, Fw);
             if (type == CT_VERTEX_FACE || type == CT_FACE_VERTEX) add = add + (vertexSide ? vertexTerm : faceTerm);
-            else if (type == CT_EDGE_EDGE) add = add + (side == 0 ? edgeTermA : edgeTermB);
+            else if (type >= CT_EDGE_EDGE) add = add + (side == 0 ? edgeTermA : edgeTermB);   // edge-edge and the sphere types
             addV6(c, l, WS_XI, add);
           }
         }

@@ -53,8 +53,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
     T12 Ta = cT(ba.T), Tb = cT(bb.T);
     if (ba.body >= 0) Ta = mulT(ldTAt(c, ba.body, WS_TW), Ta);
     if (bb.body >= 0) Tb = mulT(ldTAt(c, bb.body, WS_TW), Tb);
-    boxBox(Ta, mk3(ba.half[0], ba.half[1], ba.half[2]), Tb, mk3(bb.half[0], bb.half[1], bb.half[2]), cm->clippingDepth, clip,
-           [&](const DevContact& ct) {
+    auto accept = [&](const DevContact& ct) {
       // postProcess: skip points within 3e-12 of an accepted contact (DARTCollisionDetector.cpp:360-400); the accepted
       // points are kept in LDS (reading them back from the record would be a global round trip per comparison)
       bool close = false;
@@ -77,7 +76,14 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
       st3(CR_EA_FIXED, ct.edgeAFixed); st3(CR_EA_DIR, ct.edgeADir); st3(CR_EB_FIXED, ct.edgeBFixed); st3(CR_EB_DIR, ct.edgeBDir);
       if (ct.type == CT_EDGE_EDGE) edge = true;
       nC++;
-    });
+    };
+    // dispatch on the two shape types (collide(), DARTCollide.cpp:5030-5260)
+    const V3 ha = mk3(ba.half[0], ba.half[1], ba.half[2]), hb = mk3(bb.half[0], bb.half[1], bb.half[2]);
+    const bool sa = ba.shape == SHAPE_SPHERE, sb = bb.shape == SHAPE_SPHERE;
+    if (sa && sb) sphereSphere(ba.half[0], Ta, bb.half[0], Tb, cm->clippingDepth, accept);
+    else if (sa) sphereBoxPair(true, ba.half[0], Ta, hb, Tb, cm->clippingDepth, accept);
+    else if (sb) sphereBoxPair(false, bb.half[0], Tb, ha, Ta, cm->clippingDepth, accept);
+    else boxBox(Ta, ha, Tb, hb, cm->clippingDepth, clip, accept);
   }
   // NOTE: the duplicate filter above only sees contacts that were kept; the reference compares against every
   // contact of the total result including ones later dropped by the depth filter.  Those can only coincide

@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const D
       if (any && start >= 0) {
         Cc = -sgn * dad(side == 0 ? TA : TB, Fw);
         if (CR.type == CT_VERTEX_FACE || CR.type == CT_FACE_VERTEX) Cc = Cc + (vertexSide ? RT.vertexTerm : RT.faceTerm);
-        else if (CR.type == CT_EDGE_EDGE) Cc = Cc + (side == 0 ? RT.edgeTermA : RT.edgeTermB);
+        else if (CR.type >= CT_EDGE_EDGE) Cc = Cc + (side == 0 ? RT.edgeTermA : RT.edgeTermB);   // edge-edge and the sphere types
         sc = sgn;
       }
       double c6[6], f6[6];

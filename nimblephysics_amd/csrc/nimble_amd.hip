@@ -256,7 +256,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       bx.body = d->box_body[i];
       if (bx.body >= d->n_bodies) return fail(NBL_E_BADARG, "box collider attached to an unknown body");
       for (int k = 0; k < 12; k++) bx.T[k] = d->box_T[12 * i + k];
-      for (int k = 0; k < 3; k++) bx.half[k] = 0.5 * d->box_size[3 * i + k];
+      bx.shape = d->box_shape ? d->box_shape[i] : NBL_SHAPE_BOX;
+      if (bx.shape != NBL_SHAPE_BOX && bx.shape != NBL_SHAPE_SPHERE) return fail(NBL_E_UNSUPPORTED, "collider shape outside the device path (box, sphere)");
+      for (int k = 0; k < 3; k++) bx.half[k] = bx.shape == NBL_SHAPE_SPHERE ? d->box_size[3 * i] : 0.5 * d->box_size[3 * i + k];   // sphere: radius
       bx.mu = d->box_mu[i];
       if (!(bx.mu > 1e-3)) return fail(NBL_E_UNSUPPORTED, "frictionless colliders (mu <= 1e-3) are outside the device path");
     }

@@ -69,9 +69,13 @@ def load_urdf(path, name=None, weld_joints=()):
         for col in links[ln].findall("collision"):
             geom = col.find("geometry")
             box = geom.find("box") if geom is not None else None
-            if box is None:
-                continue  # mesh / other primitives: outside the dBoxBox path
-            boxes.append(BoxSpec(body_index, _origin(col), tuple(_floats(box.get("size"))), 1.0))
+            sph = geom.find("sphere") if geom is not None else None
+            if box is not None:
+                boxes.append(BoxSpec(body_index, _origin(col), tuple(_floats(box.get("size"))), 1.0))
+            elif sph is not None:
+                r = float(sph.get("radius"))
+                boxes.append(BoxSpec(body_index, _origin(col), (r, r, r), 1.0, "sphere"))
+            # mesh / capsule / cylinder: outside the analytic box / sphere narrow phase
 
     def recurse(ln, parent_index):
         for jn in children[ln]:
@@ -133,7 +137,7 @@ def with_ground(model, ground):
         nbdy.parent = b.parent + nb if b.parent >= 0 else -1
         bodies.append(nbdy)
     for bx in ground.boxes:
-        boxes.append(BoxSpec(bx.body + nb if bx.body >= 0 else -1, bx.T, bx.size, bx.mu))
+        boxes.append(BoxSpec(bx.body + nb if bx.body >= 0 else -1, bx.T, bx.size, bx.mu, bx.shape))
     return ModelDescription(model.name + "_ground", bodies, boxes, model.gravity, model.dt, None, max_contacts=8)
 
 

@@ -86,10 +86,19 @@ class BodySpec:
 
 @dataclass
 class BoxSpec:
+    """A collider: a box (full side lengths `size`) or, with shape = "sphere", a sphere of radius size[0]."""
     body: int  # -1 = fixed to the world
     T: np.ndarray
     size: Sequence[float]
     mu: float = 1.0
+    shape: str = "box"
+
+
+def SphereSpec(body: int, T: np.ndarray, radius: float, mu: float = 1.0) -> "BoxSpec":
+    return BoxSpec(body, T, (float(radius),) * 3, mu, "sphere")
+
+
+SHAPE_CODES = {"box": 0, "sphere": 1}
 
 
 def _inertia_matrix(i6) -> np.ndarray:
@@ -216,11 +225,11 @@ class ModelDescription:
         boxes = []
         for bx in self.boxes:
             if bx.body < 0:
-                boxes.append(BoxSpec(-1, bx.T.copy(), tuple(bx.size), bx.mu))
+                boxes.append(BoxSpec(-1, bx.T.copy(), tuple(bx.size), bx.mu, bx.shape))
             else:
                 t = target[bx.body]
                 Tb = T_in_target[bx.body] @ bx.T
-                boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu))
+                boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu, bx.shape))
         m = ModelDescription(self.name, out, boxes, self.gravity, self.dt, self._action_map, self.max_contacts,
                              self.contact_clipping_depth, self.fallback_cfm)
         return m
@@ -281,6 +290,7 @@ class ModelDescription:
         a["box_T"] = np.array([_t12(bx.T) for bx in self.boxes], np.float64).reshape(nbx, 12)
         a["box_size"] = np.array([bx.size for bx in self.boxes], np.float64).reshape(nbx, 3)
         a["box_mu"] = np.array([bx.mu for bx in self.boxes], np.float64).reshape(nbx)
+        a["box_shape"] = np.array([SHAPE_CODES[bx.shape] for bx in self.boxes], np.int32).reshape(nbx)
         a["action_map"] = np.array(self.action_map, np.int32)
         return a
 
@@ -299,7 +309,7 @@ class ModelDescription:
         def pi(x):
             return x.ctypes.data_as(C.POINTER(C.c_int32))
 
-        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map"):
+        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape"):
             setattr(d, k, pi(a[k]))
         for k in ("T_pj", "T_cj", "axis", "mass", "com", "inertia", "damping", "spring", "rest", "pos_lo", "pos_hi",
                   "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu"):
@@ -322,7 +332,8 @@ class ModelDescription:
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,
             "max_contacts": self.max_contacts, "contact_clipping_depth": self.contact_clipping_depth,
             "fallback_cfm": self.fallback_cfm, "bodies": [body(b) for b in self.bodies],
-            "boxes": [{"body": bx.body, "T": np.asarray(bx.T).tolist(), "size": list(bx.size), "mu": bx.mu} for bx in self.boxes],
+            "boxes": [{"body": bx.body, "T": np.asarray(bx.T).tolist(), "size": list(bx.size), "mu": bx.mu,
+                       **({} if bx.shape == "box" else {"shape": bx.shape})} for bx in self.boxes],
         }
 
     @staticmethod
@@ -333,7 +344,7 @@ class ModelDescription:
             b["T_pj"] = np.array(b["T_pj"], dtype=np.float64)
             b["T_cj"] = np.array(b["T_cj"], dtype=np.float64)
             bodies.append(BodySpec(**b))
-        boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0)) for bx in d.get("boxes", [])]
+        boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0), bx.get("shape", "box")) for bx in d.get("boxes", [])]
         return ModelDescription(d["name"], bodies, boxes, d.get("gravity", (0, -9.81, 0)), d.get("dt", 1e-3),
                                 d.get("action_map"), d.get("max_contacts", 0), d.get("contact_clipping_depth", 0.03),
                                 d.get("fallback_cfm", 1e-4))

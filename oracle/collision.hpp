@@ -13,7 +13,8 @@
 
 namespace nbo {
 
-enum ContactType { CT_UNSUPPORTED = 0, CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3 };  // Contact.hpp:45-54
+enum ContactType { CT_UNSUPPORTED = 0, CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3,   // Contact.hpp:45-61
+                   CT_SPHERE_BOX = 4, CT_BOX_SPHERE = 5, CT_SPHERE_SPHERE = 6 };
 
 struct Contact {
   Vec3 point, normal;
@@ -21,6 +22,11 @@ struct Contact {
   int type;
   int bodyA, bodyB, boxA, boxB;
   Vec3 edgeAClosestPoint, edgeAFixedPoint, edgeADir, edgeBClosestPoint, edgeBFixedPoint, edgeBDir;
+  // sphere contacts (Contact.hpp: sphereCenter, face{1,2,3}{Locked,Normal}, center{A,B}, radius{A,B})
+  Vec3 sphereCenter = mk3(0, 0, 0), faceNormal[3] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+  bool faceLocked[3] = {false, false, false};
+  Vec3 centerA = mk3(0, 0, 0), centerB = mk3(0, 0, 0);
+  s_t radiusA = 0, radiusB = 0;
 };
 
 inline Vec3 col(const Mat3& R, int j) { return mk3(R(0, j), R(1, j), R(2, j)); }
@@ -257,6 +263,98 @@ inline int boxBox(const Iso& T1, const Vec3& A, const Iso& T2, const Vec3& B, s_
 
 // Which pairs are tested: all i<j in insertion order, minus CollisionFilter.cpp:105-154
 // (same body, both immobile, same skeleton with self-collision disabled).
+// collideBoxSphere (DARTCollide.cpp:1482-1653; box = object 1) and collideSphereBox (:1655-1810; sphere = object 1):
+// the sphere centre is clamped to the box, every clamped axis "locks" that face normal; the normal points from the second
+// object towards the first.  A centre inside the box gives a plain FACE_VERTEX / VERTEX_FACE contact at the centre.
+inline int sphereBoxPair(bool sphereFirst, s_t r, const Iso& Ts, const Vec3& half, const Iso& Tb, s_t clippingDepth,
+                         std::vector<Contact>& out) {
+  const s_t EPS = 1e-6;   // DART_COLLISION_EPS
+  bool inside = true;
+  Vec3 c0 = Ts.p;
+  Vec3 p = apply(inverse(Tb), c0);
+  s_t pa[3] = {p[0], p[1], p[2]};
+  const s_t h[3] = {half[0], half[1], half[2]};
+  Contact ct;
+  ct.edgeAClosestPoint = ct.edgeAFixedPoint = ct.edgeADir = ct.edgeBClosestPoint = ct.edgeBFixedPoint = ct.edgeBDir = mk3(0, 0, 0);
+  ct.sphereCenter = c0;
+  ct.type = sphereFirst ? CT_SPHERE_BOX : CT_BOX_SPHERE;
+  for (int k = 0; k < 3; k++) {
+    if (pa[k] < -h[k]) { ct.faceNormal[k] = col(Tb.R, k); ct.faceLocked[k] = true; pa[k] = -h[k]; inside = false; }
+    if (pa[k] > h[k]) { ct.faceNormal[k] = col(Tb.R, k); ct.faceLocked[k] = true; pa[k] = h[k]; inside = false; }
+  }
+  auto nearestSide = [&](s_t& mn) {
+    mn = h[0] - std::fabs(pa[0]);
+    int idx = 0;
+    s_t t = h[1] - std::fabs(pa[1]);
+    if (t < mn) { mn = t; idx = 1; }
+    t = h[2] - std::fabs(pa[2]);
+    if (t < mn) { mn = t; idx = 2; }
+    return idx;
+  };
+  const s_t outward = sphereFirst ? 1.0 : -1.0;   // SphereBox: normal[idx] = p > 0 ? 1 : -1;  BoxSphere: the opposite
+  if (inside) {
+    s_t mn;
+    int idx = nearestSide(mn);
+    s_t nl[3] = {0, 0, 0};
+    nl[idx] = (pa[idx] > 0.0 ? 1.0 : -1.0) * outward;
+    s_t pen = mn + r;
+    if (pen > clippingDepth) return 0;
+    ct.type = sphereFirst ? CT_VERTEX_FACE : CT_FACE_VERTEX;
+    ct.point = c0;
+    ct.normal = Tb.R * mk3(nl[0], nl[1], nl[2]);
+    ct.depth = pen;
+    out.push_back(ct);
+    return 1;
+  }
+  Vec3 contactpt = apply(Tb, mk3(pa[0], pa[1], pa[2]));
+  Vec3 normal = sphereFirst ? c0 - contactpt : contactpt - c0;
+  s_t mag = norm(normal);
+  s_t pen = r - mag;
+  if (pen > clippingDepth) return 0;
+  if (pen < 0.0) return 0;
+  if (mag > EPS) normal = (1.0 / mag) * normal;
+  else {
+    s_t mn;
+    int idx = nearestSide(mn);
+    s_t nl[3] = {0, 0, 0};
+    nl[idx] = (pa[idx] > 0.0 ? 1.0 : -1.0) * outward;
+    normal = Tb.R * mk3(nl[0], nl[1], nl[2]);
+  }
+  ct.point = contactpt;
+  ct.normal = normal;
+  ct.depth = pen;
+  out.push_back(ct);
+  return 1;
+}
+
+// collideSphereSphere (DARTCollide.cpp:1812-1880)
+inline int sphereSphere(s_t r0in, const Iso& T0, s_t r1in, const Iso& T1, s_t clippingDepth, std::vector<Contact>& out) {
+  const s_t EPS = 1e-6;
+  s_t r0 = r0in, r1 = r1in, rsum = r0 + r1;
+  Vec3 normal = T0.p - T1.p;
+  s_t nsq = dot(normal, normal);
+  if (nsq > rsum * rsum) return 0;
+  r0 /= rsum; r1 /= rsum;
+  Contact ct;
+  ct.edgeAClosestPoint = ct.edgeAFixedPoint = ct.edgeADir = ct.edgeBClosestPoint = ct.edgeBFixedPoint = ct.edgeBDir = mk3(0, 0, 0);
+  ct.type = CT_SPHERE_SPHERE;
+  ct.centerA = T0.p; ct.radiusA = r0 * rsum; ct.centerB = T1.p; ct.radiusB = r1 * rsum;
+  ct.point = r1 * T0.p + r0 * T1.p;
+  if (nsq < EPS) {
+    ct.normal = mk3(0, 0, 0);
+    ct.depth = rsum;
+    if (ct.depth > clippingDepth) return 0;
+    out.push_back(ct);
+    return 1;
+  }
+  s_t len = std::sqrt(nsq);
+  ct.normal = (1.0 / len) * normal;
+  ct.depth = rsum - len;
+  if (ct.depth > clippingDepth) return 0;
+  out.push_back(ct);
+  return 1;
+}
+
 inline int skeletonRoot(const Model& m, int body) {
   while (body >= 0 && m.bodies[body].parent >= 0) body = m.bodies[body].parent;
   return body;
@@ -274,7 +372,12 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
       Iso Ti = bi.body >= 0 ? kin[bi.body].Tworld * bi.T : bi.T;
       Iso Tj = bj.body >= 0 ? kin[bj.body].Tworld * bj.T : bj.T;
       std::vector<Contact> pair;
-      boxBox(Ti, 0.5 * bi.size, Tj, 0.5 * bj.size, m.clippingDepth, pair);
+      // dispatch on the two shape types (collide(), DARTCollide.cpp:5030-5260)
+      const bool si = bi.shape == NBL_SHAPE_SPHERE, sj = bj.shape == NBL_SHAPE_SPHERE;
+      if (si && sj) sphereSphere(bi.size[0], Ti, bj.size[0], Tj, m.clippingDepth, pair);
+      else if (si) sphereBoxPair(true, bi.size[0], Ti, 0.5 * bj.size, Tj, m.clippingDepth, pair);
+      else if (sj) sphereBoxPair(false, bj.size[0], Tj, 0.5 * bi.size, Ti, m.clippingDepth, pair);
+      else boxBox(Ti, 0.5 * bi.size, Tj, 0.5 * bj.size, m.clippingDepth, pair);
       // postProcess: drop points closer than 3e-12 to an already accepted contact
       for (Contact& c : pair) {
         bool close = false;

@@ -427,7 +427,8 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
 // ---------------------------------------------------------------------------------------------
 // Backward: contact terms of the BackpropSnapshot Jacobians
 // ---------------------------------------------------------------------------------------------
-enum DofContactType { DCT_NONE = 0, DCT_VERTEX, DCT_FACE, DCT_EDGE_A, DCT_EDGE_B, DCT_SELF_COLLISION, DCT_UNSUPPORTED };
+enum DofContactType { DCT_NONE = 0, DCT_VERTEX, DCT_FACE, DCT_EDGE_A, DCT_EDGE_B, DCT_SELF_COLLISION, DCT_UNSUPPORTED,
+                      DCT_SPHERE_TO_BOX, DCT_BOX_TO_SPHERE, DCT_SPHERE_A, DCT_SPHERE_B };
 
 // DifferentiableContactConstraint::getDofContactType (DCC.cpp:116-228), box-box contact types only
 inline int dofContactType(const Model& m, const Contact& ct, int dofBody) {
@@ -438,11 +439,17 @@ inline int dofContactType(const Model& m, const Contact& ct, int dofBody) {
     if (ct.type == CT_FACE_VERTEX) return DCT_FACE;
     if (ct.type == CT_VERTEX_FACE) return DCT_VERTEX;
     if (ct.type == CT_EDGE_EDGE) return DCT_EDGE_A;
+    if (ct.type == CT_SPHERE_BOX) return DCT_SPHERE_TO_BOX;
+    if (ct.type == CT_BOX_SPHERE) return DCT_BOX_TO_SPHERE;
+    if (ct.type == CT_SPHERE_SPHERE) return DCT_SPHERE_A;
     return DCT_UNSUPPORTED;
   }
   if (ct.type == CT_FACE_VERTEX) return DCT_VERTEX;
   if (ct.type == CT_VERTEX_FACE) return DCT_FACE;
   if (ct.type == CT_EDGE_EDGE) return DCT_EDGE_B;
+  if (ct.type == CT_SPHERE_BOX) return DCT_BOX_TO_SPHERE;
+  if (ct.type == CT_BOX_SPHERE) return DCT_SPHERE_TO_BOX;
+  if (ct.type == CT_SPHERE_SPHERE) return DCT_SPHERE_B;
   return DCT_UNSUPPORTED;
 }
 
@@ -510,6 +517,14 @@ struct ContactGrad {
     Vec3 w = head(tw), v = tail(tw);
     auto gradTheta = [&](const Vec3& pt) { return (norm(w) > 1e-6) ? cross(w, pt) + v : v; };  // math::gradientWrtTheta(.,.,0)
     if (type == DCT_VERTEX || type == DCT_SELF_COLLISION) return gradTheta(ct.point);
+    auto unlock = [&](Vec3 g) {   // remove the motion along every locked face normal (DCC.cpp:351-369)
+      for (int k = 0; k < 3; k++) if (ct.faceLocked[k]) g = g - dot(ct.faceNormal[k], g) * ct.faceNormal[k];
+      return g;
+    };
+    if (type == DCT_SPHERE_A) return (ct.radiusB / (ct.radiusA + ct.radiusB)) * gradTheta(ct.centerA);   // DCC.cpp:342-346
+    if (type == DCT_SPHERE_B) return (ct.radiusA / (ct.radiusA + ct.radiusB)) * gradTheta(ct.centerB);
+    if (type == DCT_SPHERE_TO_BOX) return unlock(gradTheta(ct.sphereCenter));                              // :352-373
+    if (type == DCT_BOX_TO_SPHERE) return gradTheta(ct.point) + unlock(-1.0 * gradTheta(ct.sphereCenter)); // :374-403
     if (type == DCT_EDGE_A)
       return contactPointGradient(ct.edgeAFixedPoint, gradTheta(ct.edgeAFixedPoint), ct.edgeADir, cross(w, ct.edgeADir),
                                   ct.edgeBFixedPoint, mk3(0, 0, 0), ct.edgeBDir, mk3(0, 0, 0));
@@ -522,6 +537,25 @@ struct ContactGrad {
     if (type == DCT_VERTEX || type == DCT_NONE || type == DCT_UNSUPPORTED) return mk3(0, 0, 0);
     Vec3 w = head(posTwist[dof]);
     if (type == DCT_FACE || type == DCT_SELF_COLLISION) return cross(w, ct.normal);
+    if (type == DCT_SPHERE_A || type == DCT_SPHERE_B) {                                                   // DCC.cpp:626-645
+      Vec3 v = tail(posTwist[dof]);
+      auto gradTheta = [&](const Vec3& pt) { return (norm(w) > 1e-6) ? cross(w, pt) + v : v; };
+      s_t nrm = norm(ct.centerA - ct.centerB);
+      Vec3 pg = (1.0 / nrm) * gradTheta(type == DCT_SPHERE_A ? ct.centerA : ct.centerB);
+      pg = pg - dot(ct.normal, pg) * ct.normal;
+      return type == DCT_SPHERE_A ? pg : -1.0 * pg;
+    }
+    if (type == DCT_SPHERE_TO_BOX || type == DCT_BOX_TO_SPHERE) {                                         // DCC.cpp:646-709
+      Vec3 v = tail(posTwist[dof]);
+      auto gradTheta = [&](const Vec3& pt) { return (norm(w) > 1e-6) ? cross(w, pt) + v : v; };
+      s_t nrm = norm(ct.sphereCenter - ct.point);
+      Vec3 cpg = positionGradient(ct, dof);
+      Vec3 spg = type == DCT_SPHERE_TO_BOX ? gradTheta(ct.sphereCenter) : mk3(0, 0, 0);
+      if (nrm > 1e-5) { cpg = (1.0 / nrm) * cpg; spg = (1.0 / nrm) * spg; }
+      // BOX_SPHERE: normal = contact point - sphere centre; SPHERE_BOX: the opposite
+      Vec3 total = ct.type == CT_BOX_SPHERE ? cpg - spg : spg - cpg;
+      return total - dot(total, ct.normal) * ct.normal;
+    }
     s_t sign = dot(cross(ct.edgeBDir, ct.edgeADir), ct.normal) < 0 ? -1.0 : 1.0;
     if (type == DCT_EDGE_A) return sign * cross(ct.edgeBDir, cross(w, ct.edgeADir));
     return sign * cross(cross(w, ct.edgeBDir), ct.edgeADir);

@@ -24,6 +24,7 @@ struct BoxCollider {
   Iso T;     // in body frame
   Vec3 size;
   s_t mu;
+  int shape;  // NBL_SHAPE_BOX | NBL_SHAPE_SPHERE (radius = size.x)
 };
 
 struct Model {
@@ -111,6 +112,7 @@ inline Model buildModel(const nbl_model_desc* d) {
     bc.T = loadIso(d->box_T + 12 * i);
     bc.size = mk3(d->box_size[3 * i], d->box_size[3 * i + 1], d->box_size[3 * i + 2]);
     bc.mu = d->box_mu[i];
+    bc.shape = d->box_shape ? d->box_shape[i] : NBL_SHAPE_BOX;
     m.boxes.push_back(bc);
   }
   m.maxContacts = d->max_contacts;

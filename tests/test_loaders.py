@@ -90,3 +90,13 @@ def test_committed_atlas_descriptions_are_reproducible_from_the_reference_urdf()
     both = na.with_ground(md, ground)
     here = os.path.join(os.path.dirname(na.__file__), "data", "atlas20_ground.json")
     assert json.loads(json.dumps(both.to_json())) == json.load(open(here))
+
+
+def test_urdf_sphere_collision_geometry(tmp_path):
+    """<sphere radius=...> collision geometry becomes a sphere collider (SphereShape of DartLoader.cpp createShape)."""
+    f = tmp_path / "ball.urdf"
+    f.write_text(URDF.replace('<geometry><box size="0.4 0.1 0.4"/></geometry>', '<geometry><sphere radius="0.25"/></geometry>'))
+    md = na.load_urdf(str(f))
+    assert len(md.boxes) == 1 and md.boxes[0].shape == "sphere" and md.boxes[0].size == (0.25, 0.25, 0.25)
+    assert md.flat()["box_shape"].tolist() == [1]
+    assert ModelDescription.from_json(json.loads(json.dumps(md.to_json()))).boxes[0].shape == "sphere"

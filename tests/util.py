@@ -73,3 +73,32 @@ def box_stack_inputs(B, seed, overhang=False):
         v[:, [3, 5, 9, 11]] = rng.normal(0, 0.05, (B, 4))
     a = np.zeros((B, 12))
     return md, np.concatenate([q, v], 1), a
+
+
+# ---- sphere colliders (tests/test_oracle_spheres.py, tests/test_gpu_spheres.py) ----
+def ball_world(order="box_first", n_balls=1, radius=0.1, arm=False):
+    """Free-joint balls over a welded ground box (top face at y = 0)."""
+    bodies, cols = [], []
+    ground = na.BoxSpec(-1, na.make_transform((0, -0.5, 0)), (4.0, 1.0, 4.0), 1.0)
+    for i in range(n_balls):
+        I = 0.4 * 1.0 * radius * radius
+        bodies.append(na.BodySpec(f"ball{i}", -1, "free", f"ball{i}_joint", mass=1.0, inertia=(I, I, I, 0, 0, 0)))
+        cols.append(na.SphereSpec(i, np.eye(4), radius, 0.8))
+    if arm:   # a revolute link carrying a second sphere, hinged on ball 0
+        bodies.append(na.BodySpec("arm", 0, "revolute", "arm_joint", axis=(0, 0, 1), T_pj=na.make_transform((0.15, 0, 0)),
+                                  T_cj=na.make_transform((-0.15, 0, 0)), mass=0.5, inertia=(0.002, 0.002, 0.002, 0, 0, 0)))
+        cols.append(na.SphereSpec(len(bodies) - 1, np.eye(4), radius, 0.8))
+    boxes = [ground] + cols if order == "box_first" else cols + [ground]
+    return na.ModelDescription("balls", bodies, boxes, max_contacts=8)
+
+
+def ball_state(md, centres, seed, pen=2e-3, radius=0.1):
+    rng = np.random.default_rng(seed)
+    n = md.num_dofs
+    q = np.zeros(n); v = rng.normal(0, 0.02, n)
+    for i, (x, z) in enumerate(centres):
+        q[6 * i + 0:6 * i + 3] = rng.normal(0, 0.3, 3)
+        q[6 * i + 3] = x; q[6 * i + 4] = radius - pen; q[6 * i + 5] = z
+    return np.concatenate([q, v]), rng.normal(0, 0.1, n)
+
+
