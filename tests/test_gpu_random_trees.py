@@ -22,7 +22,7 @@ def _T(rng, scale):
     return T
 
 
-def random_tree(rng, nb, shape, free_root, welds=0, colliders=0):
+def random_tree(rng, nb, shape, free_root, welds=0, colliders=0, spheres=False):
     import nimblephysics_amd as na
     bodies = []
     for i in range(nb):
@@ -51,8 +51,11 @@ def random_tree(rng, nb, shape, free_root, welds=0, colliders=0):
     if colliders:
         boxes.append(na.BoxSpec(-1, na.make_transform((0, -0.005, 0)), (20.0, 0.01, 20.0), 1.0))
         movable = [i for i, b in enumerate(bodies)]
-        for i in rng.choice(movable, size=min(colliders, len(movable)), replace=False):
-            boxes.append(na.BoxSpec(int(i), na.make_transform((0, 0, 0)), tuple(rng.uniform(0.1, 0.3, 3)), float(rng.uniform(0.5, 1.0))))
+        for j, i in enumerate(rng.choice(movable, size=min(colliders, len(movable)), replace=False)):
+            if spheres and j % 2 == 1:
+                boxes.append(na.SphereSpec(int(i), na.make_transform(tuple(rng.normal(0, 0.03, 3))), float(rng.uniform(0.08, 0.2)), float(rng.uniform(0.5, 1.0))))
+            else:
+                boxes.append(na.BoxSpec(int(i), na.make_transform((0, 0, 0)), tuple(rng.uniform(0.1, 0.3, 3)), float(rng.uniform(0.5, 1.0))))
     md = na.ModelDescription("random_tree", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=8 if colliders else 0)
     return md
 
@@ -102,8 +105,9 @@ def test_random_trees_with_welds_and_partial_action_space(seed, nb, shape):
     _compare(md, 64, seed, action_dofs=dofs)
 
 
-@pytest.mark.parametrize("seed,nb,shape", [(31, 4, "chain"), (32, 8, "random"), (33, 11, "star")])
-def test_random_trees_resting_on_the_ground(seed, nb, shape):
+@pytest.mark.parametrize("seed,nb,shape,spheres", [(31, 4, "chain", False), (32, 8, "random", False), (33, 11, "star", False),
+                                                    (34, 6, "random", True), (35, 10, "chain", True)])
+def test_random_trees_resting_on_the_ground(seed, nb, shape, spheres):
     """A free-root tree dropped so that some of its box colliders penetrate the ground box slightly: whatever contact set comes
     out (0..8 contacts, any mix of vertex / edge types), device and oracle must agree on state and gradients of the worlds
     whose LCP both resolved in stage 0 (the cascade's tie-breaks are compared in test_gpu_contact.py)."""
@@ -112,7 +116,7 @@ def test_random_trees_resting_on_the_ground(seed, nb, shape):
     from nimblephysics_amd.timestep import timestep
     from oracle import OracleWorld
     rng = np.random.default_rng(3000 + seed)
-    md = random_tree(rng, nb, shape, free_root=True, colliders=3)
+    md = random_tree(rng, nb, shape, free_root=True, colliders=4 if spheres else 3, spheres=spheres)
     n = md.num_dofs
     B = 128
     q = rng.normal(0, 0.2, (B, n)); q[:, 3] = rng.normal(0, 0.3, B); q[:, 5] = rng.normal(0, 0.3, B)
