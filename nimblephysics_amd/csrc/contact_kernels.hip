@@ -38,7 +38,11 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
 __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBody* __restrict__ bodies,
                                                        const DevContactModel* __restrict__ cm, int64_t B,
                                                        double* __restrict__ saved, SavedLayout lay,
-                                                       uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists) {
+                                                       uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists,
+                                                       uint32_t* __restrict__ failCount) {
+  // the counter of the unresolved-worlds list of this slice starts at zero for the solve kernel that follows on the stream
+  // (a separate hipMemsetAsync node cost ~6 us of every forward step)
+  if (failCount && blockIdx.x == 0 && threadIdx.x == 0) *failCount = 0u;
   const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);

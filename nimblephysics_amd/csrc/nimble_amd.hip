@@ -441,7 +441,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
                                       (double*)saved, status, (double*)workspace, m->lay));
     if (m->hasContact) {
       TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
-                                         status, (double*)workspace, m->coopTree ? 0 : 1));
+                                         status, (double*)workspace, m->coopTree ? 0 : 1, failCountAll + si));
       if (m->coop) {
         const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
                                sizeof(double);   // acc, Fw, Sw/AISw/Vw/psi, free-joint blocks, contact bodies
@@ -453,8 +453,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       dim3 lgrid((unsigned)((cnt + ll - 1) / ll)), lblock(ll);
       const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
       int32_t* failList = failListAll + b0;          // the slice's own compacted list and counter
-      uint32_t* failCount = failCountAll + si;
-      HIP_TRY(hipMemsetAsync(failCount, 0, sizeof(uint32_t), s));
+      uint32_t* failCount = failCountAll + si;   // zeroed by k_contact_detect
       if (m->coop)
         TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
                                                (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
