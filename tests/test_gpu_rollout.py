@@ -110,3 +110,34 @@ def test_cfg5_length_rollout_T64_vs_oracle():
     assert np.abs(ys.detach().cpu().numpy()[:, -1] - xs[-1]).max() <= 1e-6 * np.abs(xs[-1]).max()
     assert np.abs(st.grad.cpu().numpy() - g).max() <= 1e-5 * np.abs(g).max()
     assert np.abs(at.grad.cpu().numpy() - gas).max() <= 1e-5 * max(np.abs(gas).max(), 1e-30)
+
+
+def test_cfg5_full_size_rollout_properties():
+    """cfg5 at its per-GPU size: Atlas-33 on the ground, B = 8192 (one GPU's share of 65536), T = 64, loss |q_T|^2 + |v_T|^2.
+    The oracle cannot run this in seconds, so size-independent properties: two runs are bit-identical; the first 64 worlds
+    of the big batch equal a separate 64-world rollout bit for bit (batch independence through all 64 steps and the whole
+    backward chain); the backward pass is linear in the loss scale; everything is finite and stays in contact."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    B, T = 8192, 64
+    md, s0, a0 = contact_inputs("atlas33", B, 5, joint_noise=0.002, vel_noise=0.001, action_noise=0.1)
+
+    def run(s, a, scale=1.0):
+        world = na.World(md, device="cuda:0")
+        st = torch.tensor(s, device="cuda:0", requires_grad=True)
+        at = torch.tensor(np.repeat(a[:, None, :], T, 1), device="cuda:0", requires_grad=True)
+        ys = rollout(world, st, at, warm_start=True)
+        (scale * (ys[:, -1] ** 2).sum()).backward()
+        return ys[:, -1].detach().cpu().numpy(), st.grad.cpu().numpy(), at.grad.cpu().numpy(), world.rollout_status.cpu().numpy()
+
+    y1, gs1, ga1, status = run(s0, a0)
+    assert np.isfinite(y1).all() and np.isfinite(gs1).all() and np.isfinite(ga1).all()
+    assert np.all(status & 0x1)
+    y2, gs2, ga2, _ = run(s0, a0)
+    assert np.array_equal(y1, y2) and np.array_equal(gs1, gs2) and np.array_equal(ga1, ga2)
+    ys, gss, gas, _ = run(s0[:64], a0[:64])
+    assert np.array_equal(y1[:64], ys) and np.array_equal(gs1[:64], gss) and np.array_equal(ga1[:64], gas)
+    y3, gs3, ga3, _ = run(s0[:512], a0[:512], scale=-2.0)
+    assert np.abs(gs3 + 2.0 * gs1[:512]).max() <= 1e-12 * np.abs(gs1).max()
+    assert np.abs(ga3 + 2.0 * ga1[:512]).max() <= 1e-12 * np.abs(ga1).max()
