@@ -66,6 +66,16 @@ class World:
         except Exception:
             pass
 
+    def clone(self) -> "World":
+        """World::clone (World.cpp:114-172): an independent world with the same model, action space, registered mass parameters
+        and current masses - the reference's unit of concurrency (one clone per thread), here one clone per HIP stream."""
+        w = World(self.description, self.device)       # the description carries the action space and the current masses
+        for e in self._wrt_mass.entries:
+            w._wrt_mass.registerNode(e.body, e.type, e.upper, e.lower)
+        if self._wrt_mass.entries:
+            w._push_inertia_params()
+        return w
+
     # ---- sizes / action space (World.cpp:2016-2135) -------------------------------------------
     def getNumDofs(self) -> int:
         return self.n
@@ -82,7 +92,12 @@ class World:
     def setActionSpace(self, mapping: Sequence[int]):
         self.model.set_action_space(mapping)
         self.description.set_action_space(mapping)
+        entries = list(self._wrt_mass.entries)
         self.__init__(self.description, self.device)  # re-upload constants
+        for e in entries:                              # the registered mass parameters survive the re-upload
+            self._wrt_mass.registerNode(e.body, e.type, e.upper, e.lower)
+        if entries:
+            self._push_inertia_params()
 
     def removeDofFromActionSpace(self, index: int):
         self.setActionSpace([a for a in self.getActionSpace() if a != index])

@@ -180,3 +180,31 @@ def test_rollout_mass_gradient_equals_the_chain_of_timesteps():
     for x, y in zip(res[0], res[1]):
         assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(y).max())
     assert np.abs(res[0][3]).max() > 0
+
+
+def test_clone_and_action_space_keep_the_mass_registration():
+    """World::clone copies model, action space, registered mass parameters and current masses; setActionSpace re-uploads the
+    model without losing the registration."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.mass import WrtMassBodyNodeEntryType as T
+    from util import cfg_inputs
+    md, s, a = cfg_inputs("cartpole", 8, 51)
+    w = na.World(md, device="cuda:0")
+    w.tuneMass(1, T.INERTIA_MASS)
+    w.setMasses([2.5])
+    w.setActionSpace([0])
+    assert w.getMassDims() == 1 and float(w.getMasses()[0]) == 2.5 and w.getActionSize() == 1
+    c = w.clone()
+    assert c.getMassDims() == 1 and float(c.getMasses()[0]) == 2.5 and c.getActionSpace() == [0]
+    st = torch.tensor(s, device="cuda:0"); at = torch.tensor(a[:, :1], device="cuda:0")
+    g = torch.randn(2 * w.n, 8, dtype=torch.float64, device="cuda:0")
+    outs = []
+    for world in (w, c):
+        nxt, saved, _ = world.step_soa(world.to_soa(st), world.to_soa(at))
+        gs, ga = world.backward_soa(saved, g)
+        gm = world.backward_inertia_soa(saved, 8)
+        outs.append((nxt, gs, ga, gm))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert outs[0][3].abs().max() > 0
