@@ -174,7 +174,6 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   // ---- every global load that does not depend on another, in one batch (one memory round trip instead of ~8):
   //      rows beyond m / DOFs beyond n read valid memory with unused (possibly stale) values, masked below ----
   const int row = ln < MAXR ? ln : 0, dof = ln < n ? ln : 0;
-  const double flagD = lws[(int64_t)LB_FLAG * B + b];
   const double ncD = svAt(saved, lay.nc, B, b);
   const double pflagD = svAt(saved, lay.pflag, B, b);
   const double cfm = svAt(saved, lay.cfm, B, b);
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   const int r0c = lay.contacts + (row / 3) * CR_SIZE;
   const int bxA = (int)svAt(saved, r0c + CR_BOXA, B, b), bxB = (int)svAt(saved, r0c + CR_BOXB, B, b);
   const double muTab = cm->boxes[ln < MAX_BOXES ? ln : 0].mu;       // collider -> mu, looked up with ds_bpermute
-  const double lam1 = lws[(int64_t)(LB_LAM1 + dof) * B + b];
+  const double gMine = gvn[(int64_t)dof * B + b];   // cotangent of v' for this lane's DOF
   double Acol[MAXR];
 #pragma unroll
   for (int i = 0; i < MAXR; i++) Acol[i] = dn[lay.A + i * MAX_ROWS + row];
@@ -198,9 +197,11 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
       for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = Pcol[i];
     }
   }
-  if (flagD == 0.0) return;   // k_bwd_recompute: no clamping row in this world
   const int m = 3 * (int)ncD;
   const bool rowOn = ln < m;
+  // contact adjoint active <=> some row is clamping (the same test k_bwd_recompute_coop makes for LB_FLAG; computed here so
+  // that this kernel does not wait for it: the two run concurrently on two streams)
+  if (w.ballot(rowOn && cvRaw == 1.0) == 0ull) return;
 #pragma unroll
   for (int i = 0; i < MAXR; i++) Acol[i] = (rowOn && i < m) ? Acol[i] : 0.0;   // columns / rows >= m were never written
   CoopRow R;
@@ -234,17 +235,18 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
     const double xn = w.shfl(x, R.fp);
     return clamp ? x : (isUb ? K.E * xn : 0.0);
   };
-  // lambda1 -> LDS (n <= MAX_DOF_CONTACT <= 64 entries, in the R buffer which is free until the factorisation)
+  // g -> LDS (n <= MAX_DOF_CONTACT <= 64 entries, in the R buffer which is free until the factorisation)
   double* bc = S.R;
-  if (ln < n) bc[ln] = lam1;
+  if (ln < n) bc[ln] = gMine;
   w.sync();
-  // fbar = Abar^T lambda1
+  // fbar = Abar^T lambda1 with lambda1 = M^-1 g:  A_c^T M^-1 g = (M^-1 A_c)^T g, i.e. the saved impulse tests applied to g -
+  // no M^-1 solve needed here (k_bwd_recompute_coop computes lambda1 for the tree part meanwhile)
   double t = 0.0;
   {
     double ta = 0.0, tb = 0.0;   // all loads of the column in flight together (d < n <= MAX_DOF_CONTACT), two partial sums
 #pragma unroll
     for (int d = 0; d < MAX_DOF_CONTACT; d += 2) {
-      const double v0 = d < n ? dn[lay.aall + d * MAX_ROWS + row] : 0.0, v1 = d + 1 < n ? dn[lay.aall + (d + 1) * MAX_ROWS + row] : 0.0;
+      const double v0 = d < n ? dn[lay.massed + d * MAX_ROWS + row] : 0.0, v1 = d + 1 < n ? dn[lay.massed + (d + 1) * MAX_ROWS + row] : 0.0;
       ta = fma(v0, d < n ? bc[d] : 0.0, ta);
       tb = fma(v1, d + 1 < n ? bc[d + 1] : 0.0, tb);
     }

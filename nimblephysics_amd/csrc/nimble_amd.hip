@@ -64,8 +64,15 @@ struct nbl_model {
   std::vector<hipStream_t> side;     // internal streams of slices 1..
   std::vector<hipEvent_t> sideDone;
   hipEvent_t fork = nullptr;
+  // one auxiliary stream per slice: k_bwd_recompute_coop (lambda1 for the tree part) runs there while k_bwd_contact_a_coop runs
+  // on the slice's own stream - neither needs the other's result
+  std::vector<hipStream_t> aux;
+  std::vector<hipEvent_t> auxFork, auxJoin;
   int wpbFwd = 4, wpbBwd = 4;        // worlds per workgroup of the lane = body tree kernels (chosen for LDS occupancy)
   size_t ldsFwd = 0, ldsBwd = 0;     // dynamic LDS of those workgroups
+  bool auxOverlap = false;           // NBL_AUX_OVERLAP=1: k_bwd_recompute_coop on an auxiliary stream next to k_bwd_contact_a_coop.
+                                     // Measured: no gain (1 slice 7.65 vs 7.68 M/s, 2 slices 8.52 vs 8.57) and a loss once the
+                                     // streams exceed four (4 slices 7.4 vs 9.0 M/s): the chip is already shared by the slices.
   bool coopCascade = true;           // NBL_COOP_CASCADE=0: stages 1-3 one world per lane
   bool coopFinal = true;             // the backward sweeps too, in the world frame (NBL_COOP_FINAL=0: one world per lane, fed by k_tree_to_lanes)
   bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
@@ -130,6 +137,16 @@ static int32_t ensureSideStreams(nbl_model* m, int need) {
     m->side.push_back(st); m->sideDone.push_back(ev);
   }
   if (!m->fork) HIP_TRY(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
+  return NBL_OK;
+}
+static int32_t ensureAux(nbl_model* m, int need) {
+  while ((int)m->aux.size() < need) {
+    hipStream_t st; hipEvent_t e1, e2;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    m->aux.push_back(st); m->auxFork.push_back(e1); m->auxJoin.push_back(e2);
+  }
   return NBL_OK;
 }
 // run fn(slice index, first world, one-past-last world, stream) for every slice, fork/join around the caller's stream
@@ -324,6 +341,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     m->coop = coop;
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
     if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
+    if (const char* e10 = getenv("NBL_AUX_OVERLAP")) m->auxOverlap = atoi(e10) != 0;
     // measured (MI355X, B = 4096, world-frame sweeps): 5.5 vs 3.8 M/s with colliders, 16.4 vs 11.0 M/s without
     m->coopTree = coop && coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
     if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
@@ -370,6 +388,9 @@ void nbl_model_destroy(nbl_model* m) {
   if (!m) return;
   for (auto& t : m->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto st : m->side) hipStreamDestroy(st);
+  for (auto st : m->aux) hipStreamDestroy(st);
+  for (auto ev : m->auxFork) hipEventDestroy(ev);
+  for (auto ev : m->auxJoin) hipEventDestroy(ev);
   for (auto ev : m->sideDone) hipEventDestroy(ev);
   if (m->fork) hipEventDestroy(m->fork);
   if (m->dBodies) hipFree(m->dBodies);
@@ -488,7 +509,7 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
 }
 
 // the kernels of one backward step for the worlds [b0, b1) on stream s
-static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, hipStream_t s, const void* saved,
+static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64_t b1, hipStream_t s, const void* saved,
                               const double* grad_next_state, double* grad_state, double* grad_action, void* workspace) {
   const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
   SavedLayout layLanes = m->lay;   // for the one-world-per-lane sweep fed by k_tree_to_lanes: kept slots in the workspace
@@ -515,7 +536,22 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, h
       TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, m->lay,
                                       grad_next_state, grad_state, grad_action, (double*)workspace, 0));
     } else {
-      if (m->coopTree)
+      // lambda1 = M^-1 g (tree kernel) and the dense contact adjoint do not depend on each other: with the wavefront-per-world
+      // kernels the first runs on the slice's auxiliary stream, the second on its own stream, and they join before
+      // k_bwd_contact_b_coop, which needs both.  (The one-world-per-lane k_bwd_contact_a reads lambda1: no fork there.)
+      const bool forkRecompute = m->coopTree && m->coop && m->auxOverlap;
+      if (forkRecompute) {
+        const int32_t rc = ensureAux(m, si + 1);
+        if (rc != NBL_OK) return rc;
+        HIP_TRY(hipEventRecord(m->auxFork[si], s));
+        HIP_TRY(hipStreamWaitEvent(m->aux[si], m->auxFork[si], 0));
+        {
+          hipStream_t s = m->aux[si];   // shadows the slice's stream for the launch and its timing events
+          TIMED(K_RECOMPUTE_COOP, hipLaunchKernelGGL(k_bwd_recompute_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies,
+                                                     m->dDofs, B, (const double*)saved, m->lay, grad_next_state, lws));
+        }
+        HIP_TRY(hipEventRecord(m->auxJoin[si], m->aux[si]));
+      } else if (m->coopTree)
         TIMED(K_RECOMPUTE_COOP, hipLaunchKernelGGL(k_bwd_recompute_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies,
                                                    m->dDofs, B, (const double*)saved, m->lay, grad_next_state, lws));
       else
@@ -532,6 +568,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int64_t b0, int64_t b1, h
       else
         TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, mdl, m->dBodies, m->dDofs, m->dContact,
                                           B, sv, m->lay, grad_next_state, (double*)workspace, lws));
+      if (forkRecompute) HIP_TRY(hipStreamWaitEvent(s, m->auxJoin[si], 0));
       if (m->coop) {
         const size_t bLds = ((size_t)m->nb * 120 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS) + MAX_CONTACTS) * sizeof(double);   // FW D {tmp | TF} TW contact bodies
         TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
@@ -560,8 +597,8 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
   if (B <= 0) return fail(NBL_E_BADARG, "B must be positive");
   if (workspace_bytes < nbl_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "workspace too small");
   m->timingNow = m->timing && (m->bwdCalls++ % m->timingPeriod == 0);
-  const int32_t rc = forSlices(m, B, slicesFor(m, B), (hipStream_t)stream, [&](int, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
-    return launchBackward(m, B, b0, b1, s, saved, grad_next_state, grad_state, grad_action, workspace);
+  const int32_t rc = forSlices(m, B, slicesFor(m, B), (hipStream_t)stream, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    return launchBackward(m, B, si, b0, b1, s, saved, grad_next_state, grad_state, grad_action, workspace);
   });
   if (rc != NBL_OK) return rc;
   HIP_TRY(hipGetLastError());
@@ -712,13 +749,13 @@ int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const v
   const size_t stateElems = (size_t)2 * m->n * B, savedBytes = nbl_saved_bytes(m, B), actElems = (size_t)m->k * B;
   const int rows = 2 * m->n;
   m->timingNow = false;
-  const int32_t rc = forSlices(m, B, rolloutSlicesFor(m, B), s0, [&](int, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+  const int32_t rc = forSlices(m, B, rolloutSlicesFor(m, B), s0, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
     const unsigned blocks = (unsigned)(((b1 - b0) * rows + 255) / 256);
     hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, grad_states + (size_t)T * stateElems, B, b0, b1, rows);
     for (int32_t t = T - 1; t >= 0; t--) {
       // the kernels of one backward step re-read the incoming cotangent after the first outputs are written, so the
       // output must not alias it: every step writes into grad_state0 and the running cotangent is copied back
-      const int32_t r = launchBackward(m, B, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, g, grad_state0,
+      const int32_t r = launchBackward(m, B, si, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, g, grad_state0,
                                        grad_actions + (size_t)t * actElems, workspace);
       if (r != NBL_OK) return r;
       if (grad_params) launchInertia(m, B, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, grad_params, t != T - 1, workspace);
