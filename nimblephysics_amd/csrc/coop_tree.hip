@@ -47,19 +47,30 @@ DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __res
     }
   }
   __syncthreads();   // the only workgroup-wide barrier: from here on every wavefront runs on its own
-  const int wv = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x) * wpb + wv;
+  // A wavefront carries wpw = mdl.pad worlds (host: 64 / nbp, e.g. 4 for a 16-body model): lanes [s * nbp, (s + 1) * nbp) are
+  // the bodies of its s-th world, each world with its own LDS image.  The sweeps only ever talk to LDS through (c.lds, body)
+  // and to HBM through (c.b, dof), so they are unaware of the packing; it divides the wave-instructions per world by wpw
+  // (with one world per wave 15 of 64 lanes did the arithmetic of the metric model).
+  const int tl = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  const int wpw = mdl.pad > 0 ? mdl.pad : 1;
+  int sub = tl / mdl.nbp;
+  const bool spare = sub >= wpw;            // lanes beyond the last packed world (64 not a multiple of nbp): idle
+  if (spare) sub = wpw - 1;
+  const int64_t first = mdl.b0 + (coopWorld(blockIdx.x, gridDim.x) * wpb + wv) * wpw;
+  // worlds past the end of the slice repeat its last world (same inputs, same values stored to the same addresses) instead of
+  // branching around every store
+  const int64_t b = first + sub < mdl.b1 ? first + sub : mdl.b1 - 1;
   const int perWorld = coopWorldDoubles<P>(mdl.nbp, mdl.nFree);
-  c.bodies = lb; c.dofs = ld; c.lds = st + (size_t)wv * perWorld; c.ldsFree = c.lds + coopRows<P>() * mdl.nbp;
+  c.bodies = lb; c.dofs = ld; c.lds = st + (size_t)(wv * wpw + sub) * perWorld; c.ldsFree = c.lds + coopRows<P>() * mdl.nbp;
   c.nbp = mdl.nbp; c.B = B; c.b = b;
   c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
   c.g = mk3(mdl.gravity[0], mdl.gravity[1], mdl.gravity[2]);
-  c.lane = (int)(threadIdx.x & 63u);
+  c.lane = spare ? 63 + mdl.nb : tl - sub * mdl.nbp;   // body index; >= nb: no body
   const bool on = c.lane < mdl.nb;
   c.level = on ? lb[c.lane].level : -1;
   c.rank = on ? lb[c.lane].rank : -1;
   c.maxLevel = mdl.maxLevel; c.maxRank = mdl.maxRank;
-  return b < mdl.b1;
+  return first < mdl.b1;
 }
 DEV double* treeBlock(double* saved, const SavedLayout& lay, int64_t B, int64_t b) {
   return saved + ((int64_t)lay.total + lay.dense) * B + b * (int64_t)lay.treeRows;
@@ -68,21 +79,21 @@ DEV double* treeBlock(double* saved, const SavedLayout& lay, int64_t B, int64_t 
 // Lanes are laid over (row, body) so that a wavefront moves 64 / nbp rows per trip without integer divisions in the loop.
 template <int P, bool STORE>
 DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
-  const int rsub = c.lane / c.nbp, body = c.lane - rsub * c.nbp, rstep = 64 / c.nbp;
-  // kept rows of the profile: FWD rows 0..70, BWD rows 0..30 (coopRowSlot); U rows in flight per lane so that the
-  // global-load (LDS-read) latency is paid once per U rows instead of once per row
+  // every packed world moves its own image: lane = body, U rows in flight per lane so that the global-load (LDS-read) latency
+  // is paid once per U rows.  Kept rows of the profile: FWD rows 0..70, BWD rows 0..30 (coopRowSlot).
   constexpr int KEPT = P == PROF_FWD ? 71 : 31, U = 8;
-  if (rsub < rstep) {
-    for (int r0 = rsub; r0 < KEPT; r0 += U * rstep) {
+  const int body = c.lane;
+  if (body < c.nbp) {
+    for (int r0 = 0; r0 < KEPT; r0 += U) {
       double tmp[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = r0 + u * rstep;
+        const int r = r0 + u;
         if (r < KEPT) tmp[u] = STORE ? c.lds[r * c.nbp + body] : blk[coopRowSlot<P>(r) * c.nbp + body];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = r0 + u * rstep;
+        const int r = r0 + u;
         if (r < KEPT) {
           if (STORE) blk[coopRowSlot<P>(r) * c.nbp + body] = tmp[u];
           else c.lds[r * c.nbp + body] = tmp[u];
@@ -92,10 +103,12 @@ DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
   }
   for (int fb = 0; fb < c.nb; fb++) {
     const int fi = c.bodies[fb].freeIdx;
-    if (fi < 0 || c.lane >= coopFreeExtra<P>()) continue;
-    const int slot = coopFreeSlot<P>(c.lane);
-    if (STORE) blk[slot * c.nbp + fb] = c.ldsFree[fi * coopFreeExtra<P>() + c.lane];
-    else c.ldsFree[fi * coopFreeExtra<P>() + c.lane] = blk[slot * c.nbp + fb];
+    if (fi < 0 || body >= c.nbp) continue;
+    for (int e = body; e < coopFreeExtra<P>(); e += c.nbp) {
+      const int slot = coopFreeSlot<P>(e);
+      if (STORE) blk[slot * c.nbp + fb] = c.ldsFree[fi * coopFreeExtra<P>() + e];
+      else c.ldsFree[fi * coopFreeExtra<P>() + e] = blk[slot * c.nbp + fb];
+    }
   }
 }
 template <int P>
@@ -490,10 +503,14 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_recompute_coop(DevMod
   bodies = c.bodies; dofs = c.dofs;   // the LDS copies
   const int n = mdl.n;
   const double* gvn = gnext + (int64_t)n * B;
-  const double clsMine = c.lane < MAX_ROWS ? saved[(int64_t)(lay.cls + c.lane) * B + b] : 0.0;   // both loads in flight together
+  // any clamping row in this lane's world?  The lanes of a world share the rows out, vote, and read their group's bits
   const int m = 3 * (int)saved[(int64_t)lay.nc * B + b];
-  const bool mine = c.lane < m && clsMine == 1.0;
-  const bool active = __ballot(mine ? 1 : 0) != 0ull;
+  bool mine = false;
+  if (c.lane < c.nbp) for (int r = c.lane; r < MAX_ROWS; r += c.nbp) mine = mine || (r < m && saved[(int64_t)(lay.cls + r) * B + b] == 1.0);
+  const uint64_t votes = (uint64_t)__ballot(mine ? 1 : 0);
+  const int grp = (int)(threadIdx.x & 63u) / c.nbp;
+  const uint64_t gmask = c.nbp >= 64 ? ~0ull : ((1ull << c.nbp) - 1ull) << (grp * c.nbp);
+  const bool active = c.lane < c.nbp && (votes & gmask) != 0ull;
   if (c.lane == 0) lws[(int64_t)LB_FLAG * B + b] = active ? 1.0 : 0.0;
   if (!active) {
     forDofs(c, [&](int d) { lws[(int64_t)(LB_GVP + d) * B + b] = gvn[(int64_t)d * B + b]; lws[(int64_t)(LB_QX + d) * B + b] = 0.0; });

@@ -145,7 +145,7 @@ template <int P, class F> DEV void forBodiesUp(const CoopCtxT<P>& c, F f) {
   for (int l = c.maxLevel; l >= 0; l--) { if (c.level == l) f(c.lane); waveFence(); }
 }
 template <int P, class F> DEV void forBodies(const CoopCtxT<P>& c, F f) { if (c.lane < c.nb) f(c.lane); waveFence(); }
-template <int P, class F> DEV void forDofs(const CoopCtxT<P>& c, F f) { if (c.lane < c.n) f(c.lane); }
+template <int P, class F> DEV void forDofs(const CoopCtxT<P>& c, F f) { if (c.lane < c.nb) for (int d = c.lane; d < c.n; d += c.nb) f(d); }
 // Children add into their parent's accumulators.  One world per lane: plain read-modify-write.  Lane = body: the siblings of
 // one level add TOGETHER with LDS atomics (ds_add_f64, no return value: nothing to wait for); lanes that hit the same
 // address are serialised by the LDS unit in a fixed order, so the sums are reproducible.  (The earlier scheme - siblings

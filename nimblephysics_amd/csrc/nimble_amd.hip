@@ -320,16 +320,25 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     for (int i = 0; i < d->n_bodies; i++) if (d->joint_type[i] == NBL_JOINT_FREE) hb[i].freeIdx = nFree++;
     m->mdl.nFree = nFree;
     const size_t modelLds = (size_t)d->n_bodies * sizeof(DevBody) + (size_t)d->n_dofs * sizeof(DevDof);
-    auto pickWpb = [&](size_t perWorld, int& wpb, size_t& bytes) {
+    // worlds packed into one wavefront of the tree kernels (lane = body of one of them): 64 / nbp, e.g. 4 for the 16-body metric
+    // model.  NBL_TREE_PACK caps it (1 = one world per wavefront).  The packed worlds of a wave need their LDS images together.
+    int wpw = std::max(1, 64 / nbp);
+    if (const char* e11 = getenv("NBL_TREE_PACK")) wpw = std::max(1, std::min(wpw, atoi(e11)));
+    {
+      const size_t worst = (size_t)std::max(coopWorldDoubles<PROF_FWD>(nbp, nFree), coopWorldDoubles<PROF_BWD>(nbp, nFree)) * sizeof(double);
+      while (wpw > 1 && modelLds + (size_t)wpw * worst > 160u * 1024u) wpw--;
+    }
+    m->mdl.pad = wpw;
+    auto pickWpb = [&](size_t perWorld, int& wpb, size_t& bytes) {   // wavefronts per workgroup
       int best = 0, bestWaves = 0;
       for (int w = 1; w <= TREE_WPB_MAX; w++) {
-        const size_t need = modelLds + (size_t)w * perWorld;
+        const size_t need = modelLds + (size_t)w * wpw * perWorld;
         if (need > 160u * 1024u) break;
         int waves = (int)((160u * 1024u) / need) * w;
         if (waves > 8) waves = 8;   // these kernels use 256 VGPRs: two wavefronts per SIMD is all a CU can hold
         if (waves > bestWaves) { bestWaves = waves; best = w; }
       }
-      wpb = best; bytes = modelLds + (size_t)best * perWorld;
+      wpb = best; bytes = modelLds + (size_t)best * wpw * perWorld;
     };
     pickWpb((size_t)coopWorldDoubles<PROF_FWD>(nbp, nFree) * sizeof(double), m->wpbFwd, m->ldsFwd);
     pickWpb((size_t)coopWorldDoubles<PROF_BWD>(nbp, nFree) * sizeof(double), m->wpbBwd, m->ldsBwd);
@@ -353,7 +362,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
   if (const char* e2 = getenv("NBL_LCP_LANES")) m->lcpLanes = atoi(e2);
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
-  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.pad = 0; m->mdl.b0 = 0; m->mdl.b1 = 0;
+  m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.b0 = 0; m->mdl.b1 = 0;   // mdl.pad: worlds per wavefront, set above
   if (const char* e9 = getenv("NBL_SLICES")) m->slices = atoi(e9);
   m->mdl.maxLevel = 0; m->mdl.maxRank = 0;
   for (const DevBody& hbI : hb) { if (hbI.level > m->mdl.maxLevel) m->mdl.maxLevel = hbI.level; if (hbI.parent >= 0 && hbI.rank > m->mdl.maxRank) m->mdl.maxRank = hbI.rank; }
@@ -453,7 +462,8 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     mdl.b0 = b0; mdl.b1 = b1;
     dim3 grid((unsigned)((cnt + tl - 1) / tl)), block(tl);
     const size_t treeLds = m->ldsFwd;
-    const dim3 treeGrid((unsigned)((cnt + m->wpbFwd - 1) / std::max(1, m->wpbFwd))), treeBlock(64 * std::max(1, m->wpbFwd));
+    const int64_t perBlockF = (int64_t)std::max(1, m->wpbFwd) * std::max(1, (int)m->mdl.pad);   // worlds per workgroup
+    const dim3 treeGrid((unsigned)((cnt + perBlockF - 1) / perBlockF)), treeBlock(64 * std::max(1, m->wpbFwd));
     if (m->coopTree && (saved || !m->hasContact))
       TIMED(K_FWD_COOP, hipLaunchKernelGGL(k_step_forward_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies, m->dDofs, B,
                                            state, action, next_state, (double*)saved, status, m->lay, m->hasContact ? 1 : 0));
@@ -522,7 +532,8 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
     mdl.b0 = b0; mdl.b1 = b1;
     dim3 grid((unsigned)((cnt + tl - 1) / tl)), block(tl);
     const size_t treeLds = m->ldsBwd;
-    const dim3 treeGrid((unsigned)((cnt + m->wpbBwd - 1) / std::max(1, m->wpbBwd))), treeBlock(64 * std::max(1, m->wpbBwd));
+    const int64_t perBlockB = (int64_t)std::max(1, m->wpbBwd) * std::max(1, (int)m->mdl.pad);   // worlds per workgroup
+    const dim3 treeGrid((unsigned)((cnt + perBlockB - 1) / perBlockB)), treeBlock(64 * std::max(1, m->wpbBwd));
     const dim3 t2lGrid((unsigned)((m->lay.treeRows + 31) / 32), (unsigned)((cnt + 31) / 32));
     if (!m->hasContact && m->coopTree && !m->coopFinal) {
       TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace));
