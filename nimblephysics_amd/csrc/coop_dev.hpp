@@ -83,30 +83,38 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
       if (!(best > thr2 * best0) || !(best > 0.0)) break;
       p = __builtin_ctzll(w.ballot(cand == best));
     }
+    // The pivot lane is on everybody's critical path (all lanes wait for its reflector at the sync), so it does the minimum:
+    // it publishes its column UNSCALED plus the two scalars (tau, 1 / v_k); the scaling v = x / v_k is folded into each
+    // lane's own dot product and update (two extra multiplies per lane instead of 23 on the pivot lane).  Its own column is
+    // not zeroed either: a finished column is never a candidate again and its rows of the triangular factor are written as
+    // zeros below (one select instead of 23 moves).
+    const bool wasDone = done;
     double* vb = S.vbuf[k & 1];
     if (ln == p) {
       vb[MAXR] = tauMine;
+      vb[MAXR + 1] = inv;
 #pragma unroll
-      for (int i = 1; i < MAXR; i++) { vb[i] = a[i] * inv; a[i] = 0.0; }
+      for (int i = 1; i < MAXR; i++) vb[i] = a[i];
       a[0] = alpha;
       done = true;
       if (PIVOT) S.perm[k] = p;
     }
     w.sync();
-    const double tau = vb[MAXR];
-    double d0 = a[0], d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    const double tau = vb[MAXR], vinv = vb[MAXR + 1];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
     for (int i = 1; i + 3 < MAXR; i += 4) {
       d0 = fma(vb[i], a[i], d0); d1 = fma(vb[i + 1], a[i + 1], d1); d2 = fma(vb[i + 2], a[i + 2], d2); d3 = fma(vb[i + 3], a[i + 3], d3);
     }
 #pragma unroll
     for (int i = 1 + 4 * ((MAXR - 1) / 4); i < MAXR; i++) d0 = fma(vb[i], a[i], d0);
-    double d = (d0 + d1) + (d2 + d3);
+    double d = fma(vinv, (d0 + d1) + (d2 + d3), a[0]);
     d = (ln == p) ? 0.0 : d * tau;
     a[0] -= d;
+    const double dv = d * vinv;
 #pragma unroll
-    for (int i = 1; i < MAXR; i++) a[i] = fma(-d, vb[i], a[i]);   // v re-read from LDS: cheaper than 48 live VGPRs
-    if (ln < MAXR) rowsOut[k * CLD + ln] = a[0];
+    for (int i = 1; i < MAXR; i++) a[i] = fma(-dv, vb[i], a[i]);   // v re-read from LDS: cheaper than 48 live VGPRs
+    if (ln < MAXR) rowsOut[k * CLD + ln] = wasDone ? 0.0 : a[0];
     else if (ln < 2 * MAXR) carryOut[k * CLD + ln - MAXR] = a[0];
 #pragma unroll
     for (int i = 0; i < MAXR - 1; i++) a[i] = a[i + 1];
