@@ -39,56 +39,109 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
                                                        const DevContactModel* __restrict__ cm, int64_t B,
                                                        double* __restrict__ saved, SavedLayout lay,
                                                        uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists,
-                                                       uint32_t* __restrict__ failCount) {
+                                                       uint32_t* __restrict__ failCount, int ppw) {
   // the counter of the unresolved-worlds list of this slice starts at zero for the solve kernel that follows on the stream
   // (a separate hipMemsetAsync node cost ~6 us of every forward step)
   if (failCount && blockIdx.x == 0 && threadIdx.x == 0) *failCount = 0u;
-  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= mdl.b1) return;
-  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);
+  NBL_PHASE(56);
+  // ppw lanes per world (1, 2 or 4): the narrow phases of ppw collider pairs of a world run side by side, each lane parks its
+  // candidate contacts in LDS, and the world's first lane then accepts them in pair order - exactly the order and the filters
+  // of the one-lane loop, at about 1 / ppw of its dependent chain (two foot-ground pairs: 74k -> ~40k cycles).
+  extern __shared__ __attribute__((aligned(16))) double stage[];   // [thread][8 candidates][CR_SIZE] + counts (ppw > 1 only)
+  const int pl = (int)threadIdx.x % ppw, wl = (int)blockDim.x / ppw;
+  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * wl + (int)threadIdx.x / ppw;
+  const bool valid = b < mdl.b1;
+  if (!valid && ppw == 1) return;
+  const int64_t bs = valid ? b : mdl.b1 - 1;       // lanes of a padding world repeat the last world's narrow phase, store nothing
+  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, bs, saved, &lay);
   __shared__ double keptP[MAX_CONTACTS * 3 * 64];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
   __shared__ double clipBuf[48 * 64];               // clip polygons of boxBox, [entry][lane]
   LaneBuf clip; clip.base = clipBuf + threadIdx.x;
   int nC = 0;
   bool overflow = false, edge = false;
-  for (int pi = 0; pi < cm->nPairs; pi++) {
+  // accept one candidate (lane pl == 0 of the world, or the only lane): postProcess + depth filter + append to the record
+  auto acceptRec = [&](const double* ct, int stride, int pi) {   // ct: CR layout, element e at ct[e * stride]
+    const V3 pt = mk3(ct[(CR_POINT + 0) * stride], ct[(CR_POINT + 1) * stride], ct[(CR_POINT + 2) * stride]);
+    const V3 nr = mk3(ct[(CR_NORMAL + 0) * stride], ct[(CR_NORMAL + 1) * stride], ct[(CR_NORMAL + 2) * stride]);
+    const double depth = ct[CR_DEPTH * stride];
+    // skip points within 3e-12 of an accepted contact (DARTCollisionDetector.cpp:360-400); the accepted points are kept in
+    // LDS (reading them back from the record would be a global round trip per comparison)
+    bool close = false;
+    for (int e = 0; e < nC; e++) {
+      const V3 d = pt - mk3(keptP[(e * 3 + 0) * 64 + threadIdx.x], keptP[(e * 3 + 1) * 64 + threadIdx.x], keptP[(e * 3 + 2) * 64 + threadIdx.x]);
+      if (norm3(d) < 3.0e-12) { close = true; break; }
+    }
+    if (close) return;
+    if (dot(nr, nr) < 1e-12) return;
+    if (depth < 0.0 || depth > cm->clippingDepth) return;
+    if (nC >= cm->maxContacts) { overflow = true; return; }
+    const int r0 = lay.contacts + nC * CR_SIZE;
+    keptP[(nC * 3 + 0) * 64 + threadIdx.x] = pt.x; keptP[(nC * 3 + 1) * 64 + threadIdx.x] = pt.y; keptP[(nC * 3 + 2) * 64 + threadIdx.x] = pt.z;
+#pragma unroll
+    for (int e = 0; e < CR_SIZE; e++) {
+      double v = ct[e * stride];
+      if (e == CR_BOXA) v = (double)cm->pairA[pi];
+      if (e == CR_BOXB) v = (double)cm->pairB[pi];
+      svAt(saved, r0 + e, B, b) = v;
+    }
+    if ((int)ct[CR_TYPE * stride] == CT_EDGE_EDGE) edge = true;
+    nC++;
+  };
+  auto toRec = [&](const DevContact& ct, double* out) {   // DevContact -> CR layout (collider indices are filled in by acceptRec)
+    out[CR_POINT] = ct.point.x; out[CR_POINT + 1] = ct.point.y; out[CR_POINT + 2] = ct.point.z;
+    out[CR_NORMAL] = ct.normal.x; out[CR_NORMAL + 1] = ct.normal.y; out[CR_NORMAL + 2] = ct.normal.z;
+    out[CR_DEPTH] = ct.depth; out[CR_TYPE] = (double)ct.type; out[CR_BOXA] = 0.0; out[CR_BOXB] = 0.0;
+    out[CR_EA_FIXED] = ct.edgeAFixed.x; out[CR_EA_FIXED + 1] = ct.edgeAFixed.y; out[CR_EA_FIXED + 2] = ct.edgeAFixed.z;
+    out[CR_EA_DIR] = ct.edgeADir.x; out[CR_EA_DIR + 1] = ct.edgeADir.y; out[CR_EA_DIR + 2] = ct.edgeADir.z;
+    out[CR_EB_FIXED] = ct.edgeBFixed.x; out[CR_EB_FIXED + 1] = ct.edgeBFixed.y; out[CR_EB_FIXED + 2] = ct.edgeBFixed.z;
+    out[CR_EB_DIR] = ct.edgeBDir.x; out[CR_EB_DIR + 1] = ct.edgeBDir.y; out[CR_EB_DIR + 2] = ct.edgeBDir.z;
+  };
+  // narrow phase of collider pair pi, every contact handed to emit(ct)
+  auto runPair = [&](int pi, auto emit) {
     const DevBox& ba = cm->boxes[cm->pairA[pi]];
     const DevBox& bb = cm->boxes[cm->pairB[pi]];
     T12 Ta = cT(ba.T), Tb = cT(bb.T);
     if (ba.body >= 0) Ta = mulT(ldTAt(c, ba.body, WS_TW), Ta);
     if (bb.body >= 0) Tb = mulT(ldTAt(c, bb.body, WS_TW), Tb);
-    auto accept = [&](const DevContact& ct) {
-      // postProcess: skip points within 3e-12 of an accepted contact (DARTCollisionDetector.cpp:360-400); the accepted
-      // points are kept in LDS (reading them back from the record would be a global round trip per comparison)
-      bool close = false;
-      for (int e = 0; e < nC; e++) {
-        const V3 d = ct.point - mk3(keptP[(e * 3 + 0) * 64 + threadIdx.x], keptP[(e * 3 + 1) * 64 + threadIdx.x], keptP[(e * 3 + 2) * 64 + threadIdx.x]);
-        if (norm3(d) < 3.0e-12) { close = true; break; }
-      }
-      if (close) return;
-      if (dot(ct.normal, ct.normal) < 1e-12) return;
-      if (ct.depth < 0.0 || ct.depth > cm->clippingDepth) return;
-      if (nC >= cm->maxContacts) { overflow = true; return; }
-      const int r0 = lay.contacts + nC * CR_SIZE;
-      auto st3 = [&](int off, V3 x) { svAt(saved, r0 + off, B, b) = x.x; svAt(saved, r0 + off + 1, B, b) = x.y; svAt(saved, r0 + off + 2, B, b) = x.z; };
-      st3(CR_POINT, ct.point); st3(CR_NORMAL, ct.normal);
-      keptP[(nC * 3 + 0) * 64 + threadIdx.x] = ct.point.x; keptP[(nC * 3 + 1) * 64 + threadIdx.x] = ct.point.y; keptP[(nC * 3 + 2) * 64 + threadIdx.x] = ct.point.z;
-      svAt(saved, r0 + CR_DEPTH, B, b) = ct.depth;
-      svAt(saved, r0 + CR_TYPE, B, b) = (double)ct.type;
-      svAt(saved, r0 + CR_BOXA, B, b) = (double)cm->pairA[pi];
-      svAt(saved, r0 + CR_BOXB, B, b) = (double)cm->pairB[pi];
-      st3(CR_EA_FIXED, ct.edgeAFixed); st3(CR_EA_DIR, ct.edgeADir); st3(CR_EB_FIXED, ct.edgeBFixed); st3(CR_EB_DIR, ct.edgeBDir);
-      if (ct.type == CT_EDGE_EDGE) edge = true;
-      nC++;
-    };
     // dispatch on the two shape types (collide(), DARTCollide.cpp:5030-5260)
     const V3 ha = mk3(ba.half[0], ba.half[1], ba.half[2]), hb = mk3(bb.half[0], bb.half[1], bb.half[2]);
     const bool sa = ba.shape == SHAPE_SPHERE, sb = bb.shape == SHAPE_SPHERE;
-    if (sa && sb) sphereSphere(ba.half[0], Ta, bb.half[0], Tb, cm->clippingDepth, accept);
-    else if (sa) sphereBoxPair(true, ba.half[0], Ta, hb, Tb, cm->clippingDepth, accept);
-    else if (sb) sphereBoxPair(false, bb.half[0], Tb, ha, Ta, cm->clippingDepth, accept);
-    else boxBox(Ta, ha, Tb, hb, cm->clippingDepth, clip, accept);
+    if (sa && sb) sphereSphere(ba.half[0], Ta, bb.half[0], Tb, cm->clippingDepth, emit);
+    else if (sa) sphereBoxPair(true, ba.half[0], Ta, hb, Tb, cm->clippingDepth, emit);
+    else if (sb) sphereBoxPair(false, bb.half[0], Tb, ha, Ta, cm->clippingDepth, emit);
+    else boxBox(Ta, ha, Tb, hb, cm->clippingDepth, clip, emit);
+  };
+  const int nPairs = cm->nPairs;
+  if (ppw == 1) {
+    for (int pi = 0; pi < nPairs; pi++)
+      runPair(pi, [&](const DevContact& ct) { double rec[CR_SIZE]; toRec(ct, rec); acceptRec(rec, 1, pi); });
+  } else {
+    // the world's first lane accepts the contacts of ITS pair directly (it is the first pair of the group, so the order holds);
+    // only the other lanes park theirs: (ppw - 1) staging slots per world
+    const int wI = (int)threadIdx.x / ppw;
+    double* mine = stage + (size_t)(wI * (ppw - 1) + (pl > 0 ? pl - 1 : 0)) * (8 * CR_SIZE);
+    int* counts = reinterpret_cast<int*>(stage + (size_t)wl * (ppw - 1) * (8 * CR_SIZE));
+    for (int p0 = 0; p0 < nPairs; p0 += ppw) {       // ppw pairs of every world at a time
+      int cnt = 0;
+      if (pl == 0) {
+        if (valid) runPair(p0, [&](const DevContact& ct) { double rec[CR_SIZE]; toRec(ct, rec); acceptRec(rec, 1, p0); });
+      } else {
+        if (p0 + pl < nPairs) runPair(p0 + pl, [&](const DevContact& ct) { if (cnt < 8) { toRec(ct, mine + cnt * CR_SIZE); cnt++; } });
+        counts[wI * (ppw - 1) + pl - 1] = cnt;
+      }
+      __syncthreads();
+      if (pl == 0 && valid) {
+        for (int q = 1; q < ppw && p0 + q < nPairs; q++) {
+          const double* src = stage + (size_t)(wI * (ppw - 1) + q - 1) * (8 * CR_SIZE);
+          const int cq = counts[wI * (ppw - 1) + q - 1];
+          for (int k = 0; k < cq; k++) acceptRec(src + k * CR_SIZE, 1, p0 + q);
+        }
+      }
+      __syncthreads();
+    }
+    if (pl != 0 || !valid) return;
   }
+  NBL_PHASE(59);
   // NOTE: the duplicate filter above only sees contacts that were kept; the reference compares against every
   // contact of the total result including ones later dropped by the depth filter.  Those can only coincide
   // with a kept point if they are the same point, which the depth filter treats identically.
@@ -98,6 +151,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
   if (overflow) st |= 0x80u;
   (void)edge;
   if (status) status[b] = st;
+  NBL_PHASE(60);
   if (!doTwists || !__any(nC > 0)) return;   // k_step_forward_coop already left the twists
   // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_VTW (the dead bias
   // accumulator slot; WS_A keeps the accelerations for the backward pass), for the relative velocities b = -J^T V of the contact-row kernel

@@ -73,6 +73,8 @@ struct nbl_model {
   bool auxOverlap = false;           // NBL_AUX_OVERLAP=1: k_bwd_recompute_coop on an auxiliary stream next to k_bwd_contact_a_coop.
                                      // Measured: no gain (1 slice 7.65 vs 7.68 M/s, 2 slices 8.52 vs 8.57) and a loss once the
                                      // streams exceed four (4 slices 7.4 vs 9.0 M/s): the chip is already shared by the slices.
+  bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
+  int nPairs = 0;                    // candidate collider pairs of the model
   bool coopCascade = true;           // NBL_COOP_CASCADE=0: stages 1-3 one world per lane
   bool coopFinal = true;             // the backward sweeps too, in the world frame (NBL_COOP_FINAL=0: one world per lane, fed by k_tree_to_lanes)
   bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
@@ -351,6 +353,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
     if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
     if (const char* e10 = getenv("NBL_AUX_OVERLAP")) m->auxOverlap = atoi(e10) != 0;
+    if (const char* e13 = getenv("NBL_DETECT_SPLIT")) m->detectSplit = atoi(e13) != 0;
+    m->nPairs = hc.nPairs;
     // measured (MI355X, B = 4096, world-frame sweeps): 5.5 vs 3.8 M/s with colliders, 16.4 vs 11.0 M/s without
     m->coopTree = coop && coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
     if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
@@ -379,6 +383,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_solve, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_a, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_step_forward_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -471,8 +476,15 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, state, action, next_state,
                                       (double*)saved, status, (double*)workspace, m->lay));
     if (m->hasContact) {
-      TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, grid, block, 0, s, mdl, m->dBodies, m->dContact, B, (double*)saved, m->lay,
-                                         status, (double*)workspace, m->coopTree ? 0 : 1, failCountAll + si));
+      {
+        // lanes per world of the narrow phase: the collider pairs of a world side by side (k_contact_detect)
+        const int ppw = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
+        const int wl = std::min(tl, 64 / ppw);                       // worlds per workgroup
+        const size_t stageBytes = ppw > 1 ? (size_t)wl * (ppw - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wl * (ppw - 1) * sizeof(int) : 0;
+        TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, dim3((unsigned)((cnt + wl - 1) / wl)), dim3(wl * ppw), stageBytes, s, mdl, m->dBodies,
+                                           m->dContact, B, (double*)saved, m->lay, status, (double*)workspace, m->coopTree ? 0 : 1,
+                                           failCountAll + si, ppw));
+      }
       if (m->coop) {
         const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
                                sizeof(double);   // acc, Fw, Sw/AISw/Vw/psi, free-joint blocks, contact bodies

@@ -52,5 +52,9 @@ for it in range(3):
     print(f"   bwd_b total {t[55] - t[48]}")
     for k in sorted(bb):
         print(f"   {bb[k]:38s} {t[k] - t[k - 1]:8d}")
+    dn_ = {57: "detect: world transforms of pair 0", 58: "detect: narrow phase + accept, pair 0", 59: "detect: remaining pairs", 60: "detect: count, status"}
+    print(f"   detect total {t[60] - t[56]}")
+    for k in sorted(dn_):
+        print(f"   {dn_[k]:38s} {t[k] - t[k - 1]:8d}")
     for k in sorted(bnames):
         print(f"   {bnames[k]:34s} {t[k] - t[k - 1]:8d}")
