@@ -74,6 +74,28 @@ def test_cabi_exports_every_declared_symbol():
     assert L.nbl_version() >= 1
 
 
+def test_header_is_plain_c_and_the_python_mirror_matches_its_layout(tmp_path):
+    """The drop-in boundary is a C ABI: include/nimble_amd.h must compile as C99 (a cgo / JNI / ctypes binding sees exactly
+    this), and the ctypes mirror of nbl_model_desc must have the size and field offsets the C compiler gives the struct."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "nimble_amd.h")
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-pedantic", "-Werror", hdr])
+    from nimblephysics_amd import _abi
+    fields = [f[0] for f in _abi.ModelDesc._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nimble_amd.h"\nint main(void) {\n  printf("%zu\\n", sizeof(nbl_model_desc));\n'
+                   + "".join(f'  printf("%zu\\n", offsetof(nbl_model_desc, {f}));\n' for f in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_abi.ModelDesc)
+    for name, off in zip(fields, out[1:]):
+        assert getattr(_abi.ModelDesc, name).offset == off, name
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
