@@ -303,31 +303,42 @@ DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   const int ln = w.lane();
   const bool on = ln < n;
   const int me = on ? ln : 0;
-  double arow[MAXR], xall[MAXR];
+  // Residual form of the projected Gauss-Seidel sweep.  Every lane keeps ITS row of A, scaled by 1 / a_ii (the reference divides
+  // in its first sweep and pre-scales the rows for the later ones, PgsBoxedLcpSolver.cpp:150-200), and the scaled residual
+  // r = b' - sum_k a'_k x_k of its row.  The step of row i is then  x_i <- clamp(x_i + r_i)  on lane i, one broadcast of the
+  // change, and one FMA per lane (A is symmetric: lane j's a'_j[i] is its share of column i).  The reference's own order - a
+  // 23-term dot product per row - would be a 23-deep chain of dependent FMAs on one lane, 720 times per stage; the two
+  // orders agree to round-off, the clamps, the convergence tests and the iteration cap are the reference's.
+  double arow[MAXR];
 #pragma unroll
-  for (int j = 0; j < MAXR; j++) {
-    arow[j] = (on && j < n) ? C.A[me * CLD + j] : 0.0;
-    xall[j] = j < n ? w.bcast(row.x, j) : 0.0;
-  }
+  for (int j = 0; j < MAXR; j++) arow[j] = (on && j < n) ? C.A[me * CLD + j] : 0.0;
   const double aii = on ? C.A[me * CLD + me] : 1.0;
-  const bool inOrder = on && !(aii < epsDiv);
-  double bb = row.b, xOwn = on ? row.x : 0.0;
+  const bool inOrder = on && !(aii < epsDiv);          // rows with a_ii ~ 0 are set to 0 once and then left alone
+  const double sc = inOrder ? 1.0 / aii : 1.0;
+#pragma unroll
+  for (int j = 0; j < MAXR; j++) arow[j] *= sc;
+  double xOwn = on ? row.x : 0.0;
+  double r0 = row.b * sc, r1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < MAXR; j += 2) {
+    r0 = fma(-arow[j], j < n ? w.bcast(xOwn, j) : 0.0, r0);
+    r1 = fma(-arow[j + 1], j + 1 < n ? w.bcast(xOwn, j + 1) : 0.0, r1);
+  }
+  double r = r0 + r1;
   bool bad = false;
-  // one Gauss-Seidel row step for row i (compile-time i): lane i computes, everybody learns the new x_i
+  // one Gauss-Seidel row step for row i (compile-time i): lane i computes, everybody's residual follows
   auto rowStep = [&](auto iTag, bool first) {
     constexpr int i = decltype(iTag)::value;
     if (i >= n) return;
     const int fi = w.bcastI(row.findex, i);
     const double xf = w.bcast(xOwn, fi >= 0 ? fi : 0);
-    double xi = xOwn;
+    double delta = 0.0;
     if (ln == i) {
+      const double old_x = xOwn;
+      double xi = old_x;
       if (!inOrder) { if (first) xi = 0.0; }
       else {
-        const double old_x = xOwn;
-        double new_x = bb;
-#pragma unroll
-        for (int j = 0; j < MAXR; ++j) if (j != i) new_x -= arow[j] * xall[j];   // j < i, then j > i; entries >= n are zero
-        if (first) new_x /= aii;
+        const double new_x = old_x + r;
         if (fi >= 0) {
           const double hi_tmp = row.hi * xf, lo_tmp = -hi_tmp;
           xi = new_x > hi_tmp ? hi_tmp : (new_x < lo_tmp ? lo_tmp : new_x);
@@ -335,9 +346,10 @@ DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         if (first) { if (fabs(xi - old_x) > dxTh) bad = true; }
         else if (fabs(xi) > epsDiv && fabs(xi - old_x) > relTol * fabs(xi)) bad = true;   // |(x - old) / x| > relTol without the division in the chain
       }
+      delta = xi - old_x;
       xOwn = xi;
     }
-    xall[i] = w.bcast(xi, i);
+    r = fma(-arow[i], w.bcast(delta, i), r);
   };
   auto sweep = [&](bool first) {
     rowStep(IntTag<0>{}, first); rowStep(IntTag<1>{}, first); rowStep(IntTag<2>{}, first); rowStep(IntTag<3>{}, first);
@@ -349,12 +361,6 @@ DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   };
   sweep(true);
   if (w.ballot(bad) == 0ull) { row.x = xOwn; return true; }
-  if (inOrder) {
-    const double dummy = 1.0 / aii;
-    bb *= dummy;
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j) arow[j] *= dummy;
-  }
   bool done = false;
 #pragma unroll 1
   for (int iter = 1; iter < maxIteration; ++iter) {
