@@ -392,7 +392,16 @@ DEV void coopCascade(const W& w, CoopLds& S, CascadeLds& C, const CoopRow& R, do
   CoopLcpRow row;
   int mapTo = -1;
   auto loadProblem = [&](double cfmDiag, double x0) {
-    if (ln < m) for (int j = 0; j < m; j++) C.A[ln * CLD + j] = R.a(j) + (ln == j ? cfmDiag : 0.0);   // A is symmetric: row = column
+    {
+      // all 24 loads of the lane's column in flight together (in a rolled loop every load was waited for before the next)
+      double col[MAXR];
+#pragma unroll
+      for (int j = 0; j < MAXR; j++) col[j] = R.a(j);
+      if (ln < m) {
+#pragma unroll
+        for (int j = 0; j < MAXR; j++) if (j < m) C.A[ln * CLD + j] = col[j] + (ln == j ? cfmDiag : 0.0);   // A is symmetric: row = column
+      }
+    }
     row.x = x0; row.b = R.Bv;
     row.lo = R.fric ? -R.mu : 0.0; row.hi = R.fric ? R.mu : INFINITY; row.findex = R.fric ? R.fp : -1;
     mapTo = ln < m ? ln : -1;
