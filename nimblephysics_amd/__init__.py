@@ -7,10 +7,13 @@ from .model import (BodySpec, BoxSpec, ModelDescription, SphereSpec, atlas, box_
                     make_transform, single_pendulum)
 
 __all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
-           "atlas", "box_stack", "make_transform", "load_urdf", "with_ground", "WrtMassBodyNodeEntryType"]
+           "atlas", "box_stack", "make_transform", "load_urdf", "with_ground", "WrtMassBodyNodeEntryType", "GraphedStep"]
 
 
 def __getattr__(name):
+    if name == "GraphedStep":
+        from .graph import GraphedStep
+        return GraphedStep
     if name == "WrtMassBodyNodeEntryType":
         from .mass import WrtMassBodyNodeEntryType
         return WrtMassBodyNodeEntryType
