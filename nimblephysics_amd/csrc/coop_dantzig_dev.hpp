@@ -144,7 +144,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     {
       double s = -b;
 #pragma unroll
-      for (int j = 0; j < MAXR; j++) s += (j < nC + nN) ? C.A[me * CLD + j] * C.v[0][j] : 0.0;   // static trip count: loads issue together
+      for (int j = 0; j < MAXR; j++) { const double pr = C.A[me * CLD + j] * C.v[0][j]; s += (j < nC + nN) ? pr : 0.0; }   // unconditional reads: they issue together
       if (ln == i) ww = s;
     }
     w.sync();
@@ -164,7 +164,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         {
           double s = 0;
 #pragma unroll
-          for (int j = 0; j < MAXR; j++) s += (j < nC) ? C.A[me * CLD + j] * C.v[1][j] : 0.0;
+          for (int j = 0; j < MAXR; j++) { const double pr = C.A[me * CLD + j] * C.v[1][j]; s += (j < nC) ? pr : 0.0; }
           const bool inN = ln >= nC && ln < nC + nN;
           if (inN || ln == i) dw = s + dirf * C.A[me * CLD + i];
         }
@@ -255,7 +255,11 @@ DEV int coopLcpReduce(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& ma
       double d2 = 0;
       const int bcol = ln < n ? ln : 0;
 #pragma unroll
-      for (int r = 0; r < MAXR; r++) { const double d = (r < n) ? C.A[r * CLD + a] - C.A[r * CLD + bcol] : 0.0; d2 += d * d; }
+      for (int r = 0; r < MAXR; r++) {   // unconditional reads (in bounds), rows >= n discarded by the select
+        const double dr = C.A[r * CLD + a] - C.A[r * CLD + bcol];
+        const double d = (r < n) ? dr : 0.0;
+        d2 += d * d;
+      }
       const double ba = w.bcast(row.b, a), ha = w.bcast(row.hi, a), la = w.bcast(row.lo, a);
       const int fa = w.bcastI(row.findex, a);
       const bool match = ln > a && ln < n && d2 < TH && fabs(ba - row.b) < TH && fa == row.findex && ha == row.hi && la == row.lo;
@@ -311,7 +315,7 @@ DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   // orders agree to round-off, the clamps, the convergence tests and the iteration cap are the reference's.
   double arow[MAXR];
 #pragma unroll
-  for (int j = 0; j < MAXR; j++) arow[j] = (on && j < n) ? C.A[me * CLD + j] : 0.0;
+  for (int j = 0; j < MAXR; j++) { const double av = C.A[me * CLD + j]; arow[j] = (on && j < n) ? av : 0.0; }
   const double aii = on ? C.A[me * CLD + me] : 1.0;
   const bool inOrder = on && !(aii < epsDiv);          // rows with a_ii ~ 0 are set to 0 once and then left alone
   const double sc = inOrder ? 1.0 / aii : 1.0;
