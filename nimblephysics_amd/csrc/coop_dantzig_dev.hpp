@@ -329,31 +329,29 @@ DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     r1 = fma(-arow[j + 1], j + 1 < n ? w.bcast(xOwn, j + 1) : 0.0, r1);
   }
   double r = r0 + r1;
+  // friction rows follow the current impulse of their normal row: every lane keeps it up to date itself
+  const int fiOwn = on ? row.findex : -1;
+  double xfOwn = w.shfl(xOwn, fiOwn >= 0 ? fiOwn : 0);
   bool bad = false;
-  // one Gauss-Seidel row step for row i (compile-time i): lane i computes, everybody's residual follows
+  // One Gauss-Seidel row step for row i (compile-time i), branch-free: EVERY lane evaluates the update of its own row from its
+  // own (x, r, bounds) - only lane i's result is kept, broadcast, and folded into everybody's residual.  (A divergent
+  // `if (lane == i)` costs EXEC bookkeeping and a scalar branch per row step, 720 times per stage.)
   auto rowStep = [&](auto iTag, bool first) {
     constexpr int i = decltype(iTag)::value;
     if (i >= n) return;
-    const int fi = w.bcastI(row.findex, i);
-    const double xf = w.bcast(xOwn, fi >= 0 ? fi : 0);
-    double delta = 0.0;
-    if (ln == i) {
-      const double old_x = xOwn;
-      double xi = old_x;
-      if (!inOrder) { if (first) xi = 0.0; }
-      else {
-        const double new_x = old_x + r;
-        if (fi >= 0) {
-          const double hi_tmp = row.hi * xf, lo_tmp = -hi_tmp;
-          xi = new_x > hi_tmp ? hi_tmp : (new_x < lo_tmp ? lo_tmp : new_x);
-        } else xi = new_x > row.hi ? row.hi : (new_x < row.lo ? row.lo : new_x);
-        if (first) { if (fabs(xi - old_x) > dxTh) bad = true; }
-        else if (fabs(xi) > epsDiv && fabs(xi - old_x) > relTol * fabs(xi)) bad = true;   // |(x - old) / x| > relTol without the division in the chain
-      }
-      delta = xi - old_x;
-      xOwn = xi;
-    }
-    r = fma(-arow[i], w.bcast(delta, i), r);
+    const double old_x = xOwn;
+    const double new_x = old_x + r;
+    const double hi_tmp = fiOwn >= 0 ? row.hi * xfOwn : row.hi, lo_tmp = fiOwn >= 0 ? -hi_tmp : row.lo;
+    double xi = new_x > hi_tmp ? hi_tmp : (new_x < lo_tmp ? lo_tmp : new_x);
+    if (!inOrder) xi = first ? 0.0 : old_x;
+    const double dOwn = xi - old_x;
+    const bool badOwn = inOrder && (first ? fabs(dOwn) > dxTh : (fabs(xi) > epsDiv && fabs(dOwn) > relTol * fabs(xi)));
+    const bool mineNow = ln == i;
+    bad = bad || (mineNow && badOwn);
+    const double delta = w.bcast(dOwn, i);
+    xOwn = mineNow ? xi : xOwn;
+    xfOwn = fiOwn == i ? xfOwn + delta : xfOwn;
+    r = fma(-arow[i], delta, r);
   };
   auto sweep = [&](bool first) {
     rowStep(IntTag<0>{}, first); rowStep(IntTag<1>{}, first); rowStep(IntTag<2>{}, first); rowStep(IntTag<3>{}, first);
