@@ -342,7 +342,7 @@ DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     const double old_x = xOwn;
     const double new_x = old_x + r;
     const double hi_tmp = fiOwn >= 0 ? row.hi * xfOwn : row.hi, lo_tmp = fiOwn >= 0 ? -hi_tmp : row.lo;
-    double xi = new_x > hi_tmp ? hi_tmp : (new_x < lo_tmp ? lo_tmp : new_x);
+    double xi = fmin(fmax(new_x, lo_tmp), hi_tmp);   // = the reference's nested comparisons for lo <= hi (two ops, no VCC round trip)
     if (!inOrder) xi = first ? 0.0 : old_x;
     const double dOwn = xi - old_x;
     const bool badOwn = inOrder && (first ? fabs(dOwn) > dxTh : (fabs(xi) > epsDiv && fabs(dOwn) > relTol * fabs(xi)));
