@@ -6,7 +6,13 @@
         bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json metric config): 20-DOF Atlas (free root + 14 revolutes, arms welded) standing
-on the ground box with 8 frictional foot-corner contacts (24 LCP rows), batch = 4096 worlds per GPU.
+on the ground box with 8 frictional foot-corner contacts (24 LCP rows), batch = 4096 worlds per GPU, pose
+noise N(0, 0.02^2) as SURVEY.md 8(d) / BASELINE.md specify ("same distributions as cfg5"): about half of the
+worlds leave LCP stage 0 and run the Dantzig / PGS cascade.  The same line carries, as `secondary.stage0_only`,
+the rate on the easy distribution (noise 0.002: every world short-circuits at stage 0).
+`--workload atlas33_contact --rollout 64 --batch 8192` is cfg5's per-GPU share (Atlas-33, T = 64 trajectory).
+With `--gpus N` > 1 and no WORLD_SIZE in the environment the script re-launches itself under
+torch.distributed.run (one process per GPU, RCCL).
 A "step" is one differentiable timestep — forward (ABA, collision detection, LCP build by impulse tests,
 stage-0 solve + standardisation) and backward (matrix-free adjoint incl. the contact terms) — of every
 world of the batch through the C ABI (nbl_step_forward / nbl_step_backward), inputs resident in HBM in
@@ -93,7 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4096, help="worlds per GPU (weak scaling)")
     ap.add_argument("--workload", default="atlas20_contact")
-    ap.add_argument("--joint-noise", type=float, default=0.002)
+    ap.add_argument("--joint-noise", type=float, default=0.02, help="pose noise of the metric distribution (SURVEY.md 8d: N(0, 0.02^2))")
+    ap.add_argument("--easy-noise", type=float, default=0.002, help="pose noise of the secondary stage-0-only measurement (0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="slices of the per-GPU batch, each a World on its own HIP stream (0 = auto: 4 from 4096 worlds, 2 from 2048)")
     ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
@@ -105,8 +112,17 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world_size and world_size > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
-    if args.gpus > 1 and world_size == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher (one process per GPU over RCCL) and relay rank 0's line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
@@ -117,7 +133,6 @@ def main():
     from nimblephysics_amd.parallel import shared_parameter_grad
 
     B = args.batch
-    md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, args.joint_noise)
     # The kernels of the step are latency / occupancy bound, so the forward of one slice of the batch overlaps the backward
     # of another when every slice owns a HIP stream (+16 % at B = 4096; the library cannot do this inside a call because a
     # call must join before it returns): one World per slice, all slices of one step issued before the next step.
@@ -126,66 +141,82 @@ def main():
         nstreams = 1
     per = (B + nstreams - 1) // nstreams
     bounds = [(i * per, min(B, (i + 1) * per)) for i in range(nstreams) if i * per < B]
-    worlds = [na.World(md, device=dev) for _ in bounds]
-    world = worlds[0]
-    n, k = world.n, world.k
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in bounds[1:]]
-    state0 = [w.to_soa(torch.tensor(s_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
-    action = [w.to_soa(torch.tensor(a_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
-    torch.cuda.synchronize(dev)
-
-    def run(T):
-        ga_total = [torch.zeros((k, hi - lo), dtype=torch.float64, device=dev) for (lo, hi) in bounds]
-        status = [None] * len(bounds)
-        if args.rollout > 0:      # cfg5-style: T-step trajectory, loss = |q_T|^2 + |v_T|^2, one shared control vector
-            for _ in range(T):
-                states, sv, st_all = world.rollout_soa(state0[0], action[0], T=args.rollout, want_saved=True, warm_start=True)
-                gst = torch.zeros_like(states)
-                gst[-1] = 2.0 * states[-1]
-                g0, ga = world.rollout_backward_soa(sv, gst)
-                ga_total[0] += ga.sum(0)
-                status[0] = st_all[-1]
-            return shared_parameter_grad(ga_total[0]), status[0]
-        main = streams[0]
-        for st in streams[1:]:
-            st.wait_stream(main)
-        for _ in range(T):
-            for i, (w, st) in enumerate(zip(worlds, streams)):
-                with torch.cuda.stream(st):
-                    w.reset_lcp_cache()                                        # cold start: guess + solve every step
-                    nxt, sv, status[i] = w.step_soa(state0[i], action[i], want_saved=True)
-                    gs, ga = w.backward_soa(sv, 2.0 * nxt)                     # d/ds' of |s'|^2
-                    ga_total[i] += ga                                          # the control vector is shared by all steps
-        for st in streams[1:]:
-            main.wait_stream(st)
-        return shared_parameter_grad(torch.cat(ga_total, 1)), torch.cat(status)   # ONE all-gather per timed region
 
     def sync():
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.warmup > 0:
-        run(args.warmup)
-    sync()
-    # per-kernel HIP events on a sample of the timed steps (every 8th): events around all ~12 launches of every step cost 8 %
-    timing_period = 8 if args.steps >= 32 else (4 if args.steps >= 8 else 1)
-    world.set_timing(not args.no_kernel_timing, timing_period)
-    t0 = time.perf_counter()
-    grad, status = run(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    tm = world.get_timing()
-    world.set_timing(False)
-    if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(grad).all()
-    st = status.cpu().numpy().astype(np.uint32)
+    def measure(noise, steps, warmup, kernel_timing):
+        """W untimed + K timed fwd+bwd steps on a fresh synthetic batch of the workload at pose noise `noise`."""
+        md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, noise)
+        worlds = [na.World(md, device=dev) for _ in bounds]
+        world = worlds[0]
+        k = world.k
+        state0 = [w.to_soa(torch.tensor(s_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
+        action = [w.to_soa(torch.tensor(a_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
+        torch.cuda.synchronize(dev)
+
+        def run(T):
+            ga_total = [torch.zeros((k, hi - lo), dtype=torch.float64, device=dev) for (lo, hi) in bounds]
+            status = [None] * len(bounds)
+            if args.rollout > 0:      # cfg5-style: T-step trajectory, loss = |q_T|^2 + |v_T|^2, one shared control vector
+                for _ in range(T):
+                    states, sv, st_all = world.rollout_soa(state0[0], action[0], T=args.rollout, want_saved=True, warm_start=True)
+                    gst = torch.zeros_like(states)
+                    gst[-1] = 2.0 * states[-1]
+                    g0, ga = world.rollout_backward_soa(sv, gst)
+                    ga_total[0] += ga.sum(0)
+                    status[0] = st_all[0]        # the cold-start step (later steps are warm-started and resolve at stage 0)
+                return shared_parameter_grad(ga_total[0]), status[0]
+            main = streams[0]
+            for st in streams[1:]:
+                st.wait_stream(main)
+            for _ in range(T):
+                for i, (w, st) in enumerate(zip(worlds, streams)):
+                    with torch.cuda.stream(st):
+                        w.reset_lcp_cache()                                        # cold start: guess + solve every step
+                        nxt, sv, status[i] = w.step_soa(state0[i], action[i], want_saved=True)
+                        gs, ga = w.backward_soa(sv, 2.0 * nxt)                     # d/ds' of |s'|^2
+                        ga_total[i] += ga                                          # the control vector is shared by all steps
+            for st in streams[1:]:
+                main.wait_stream(st)
+            return shared_parameter_grad(torch.cat(ga_total, 1)), torch.cat(status)   # ONE all-gather per timed region
+
+        if warmup > 0:
+            run(warmup)
+        sync()
+        # per-kernel HIP events on a sample of the timed steps (every 8th): events around all ~12 launches of every step cost 8 %
+        timing_period = 8 if steps >= 32 else (4 if steps >= 8 else 1)
+        world.set_timing(kernel_timing, timing_period)
+        t0 = time.perf_counter()
+        grad, status = run(steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        tm = world.get_timing()
+        world.set_timing(False)
+        if world_size > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(grad).all()
+        st = status.cpu().numpy().astype(np.uint32)
+        return {"elapsed": elapsed, "status": st, "timing": tm, "timing_period": timing_period, "md": md, "s": s_np, "a": a_np,
+                "desc": wl_desc, "world": world, "slices": len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))}
+
+    has_contact = args.workload.endswith("_contact")
+    R = measure(args.joint_noise, args.steps, args.warmup, not args.no_kernel_timing)
+    easy = None
+    if has_contact and args.easy_noise > 0 and args.easy_noise != args.joint_noise:
+        # the easy distribution: every world resolves at LCP stage 0 (round 1's headline), half the steps, no kernel events
+        easy = measure(args.easy_noise, max(1, args.steps // 2), min(args.warmup, 4), False)
+    elapsed, st, tm, timing_period, md, s_np, a_np, wl_desc, world = (R[x] for x in ("elapsed", "status", "timing", "timing_period", "md", "s", "a", "desc", "world"))
+    n = world.n
 
     if rank == 0:
-        total_units = B * world_size * args.steps * max(1, args.rollout)
+        units_per_step = B * world_size * max(1, args.rollout)
+        total_units = units_per_step * args.steps
         value = total_units / elapsed
         m_rows = 24 if world.m > 0 else 0
         kern = {kname: v["ms_sum"] / v["count"] for kname, v in tm["kernels"].items()}
@@ -196,7 +227,7 @@ def main():
         # Per launch of the step (all kernels of one forward + one backward): that figure x B worlds.
         dom = max(kern, key=kern.get)
         alg_step_bytes = (104 * n + 16 * m_rows) * B
-        slices = len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))   # the batch is processed as slices on overlapping HIP streams:
+        slices = R["slices"]   # the batch is processed as slices on overlapping HIP streams:
         alg_launch_bytes = alg_step_bytes / slices  # one kernel launch covers B / slices worlds (timed on slice 0)
         step_kernel_ms = sum(kern.values())
         # the dominant kernel is credited with the whole step's algorithmic traffic share it is responsible for:
@@ -204,19 +235,40 @@ def main():
         # (algorithmic bytes of one step) / (duration of the dominant kernel) -- an upper bound on its fraction.
         achieved = alg_launch_bytes / (kern[dom] * 1e-3) / 1e9
         traffic = None
+        prof_key = f"{args.workload}@{args.joint_noise:g}"
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+                tj = json.load(open(tfile))
+                traffic = tj.get(prof_key, tj.get(args.workload, {})).get(dom)
             except Exception:
                 traffic = None
+        # fp64 roofline: flop COUNTED by the SQ instruction counters (tools/profile.sh pass `fp64`, aggregated by
+        # tools/aggregate_profile.py into profiles/fp64_flops.json): 2 x FMA + ADD + MUL + TRANS wave-instructions x active lanes
+        fp64 = None
+        ffile = os.path.join(ROOT, "profiles", "fp64_flops.json")
+        if os.path.exists(ffile):
+            try:
+                fj = json.load(open(ffile)).get(prof_key)
+                if fj:
+                    fl = float(fj["flops_per_world_step"])
+                    per_gpu_rate = value / world_size
+                    fp64 = {"flops_per_world_step": fl, "counted_by": fj.get("counted_by"), "achieved_TFs": fl * per_gpu_rate / 1e12,
+                            "peak_TFs": FP64_PEAK_TFLOPS, "frac": fl * per_gpu_rate / 1e12 / FP64_PEAK_TFLOPS,
+                            "mfma_f64_wave_instr_per_world_step": fj.get("mfma_f64_wave_instr_per_world_step"),
+                            "valu_lane_utilisation": fj.get("valu_lane_utilisation")}
+            except Exception:
+                fp64 = None
         out = {
             "metric": "worlds*timesteps/sec fwd+bwd", "value": value, "unit": "worlds*timesteps/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{wl_desc}; batch={B} worlds/GPU; fwd+bwd through the C ABI, cold LCP start each step",
+            "config": {"workload": f"{wl_desc}; batch={B} worlds/GPU; fwd+bwd through the C ABI, cold LCP start each step" +
+                                   (f"; one step = one {args.rollout}-step rollout fwd+bwd (warm-started after its first step)" if args.rollout else ""),
                        "n_dofs": n, "contacts": m_rows // 3, "lcp_rows": m_rows, "worlds_per_gpu": B, "dt": md.dt,
+                       "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None,
+                       "rccl_world_size": world_size,
                        "lanes_with_contact": float((st & 0x1).astype(bool).mean()),
                        "lanes_resolved_at_lcp_stage0": float((st & 0x2).astype(bool).mean()) if m_rows else None,
                        "lanes_unresolved": float((st & 0x20).astype(bool).mean()),
@@ -226,10 +278,19 @@ def main():
                          "algorithmic_bytes_per_launch": alg_launch_bytes, "worlds_per_launch": B // slices, "stream_slices": slices,
                          "algorithmic_bytes_per_step": alg_step_bytes, "avg_launch_ms": kern[dom],
                          "kernels_avg_ms": kern, "step_kernel_ms": step_kernel_ms, "timed_every_nth_step": timing_period,
-                         "whole_step_achieved_GBs": alg_step_bytes / (elapsed / args.steps) / 1e9,
+                         "whole_step_achieved_GBs": alg_step_bytes * max(1, args.rollout) / (elapsed / args.steps) / 1e9,
+                         "fp64": fp64,
                          "note": "the path is fp64-ALU/latency bound, not HBM bound (~1e2-1e3 flop/byte, SURVEY.md 8d); "
-                                 "the HBM fraction is reported because north_star asks for it"},
+                                 "the HBM fraction is reported because north_star asks for it, the fp64 fraction next to it"},
         }
+        if easy is not None:
+            est = easy["status"]
+            esteps = max(1, args.steps // 2)
+            out["secondary"] = {"stage0_only": {
+                "joint_noise": args.easy_noise, "value": units_per_step * esteps / easy["elapsed"], "unit": "worlds*timesteps/s",
+                "steps": esteps, "ms_per_step": easy["elapsed"] / esteps * 1e3,
+                "lanes_resolved_at_lcp_stage0": float((est & 0x2).astype(bool).mean()),
+                "note": "same workload on the easy pose distribution (every world short-circuits at LCP stage 0): round 1's headline regime"}}
         if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(md, s_np, a_np)

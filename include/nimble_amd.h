@@ -228,6 +228,16 @@ int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const v
                                      double* grad_state0, double* grad_actions, double* grad_params, void* workspace,
                                      size_t workspace_bytes, void* stream);
 
+/* ---- self-test ----
+ * Runs the library's device restatement of the reference's Dantzig driver (dSolveLCP, dart/external/odelcpsolver/lcp.cpp:780-1113,
+ * nub = 0, earlyTermination = true; the stage-1 code of the LCP cascade) on `count` caller-supplied n-row problems, one wavefront
+ * per problem.  HOST pointers: A [count][n*n] row-major (only the lower triangles are read), b / lo / hi / findex [count][n] with
+ * the bounds as DantzigBoxedLcpSolver::solve hands them over (friction rows: lo = -mu, hi = mu, findex = their normal row);
+ * outputs x [count][n] and rc [count] (1 solved, 0 early termination, -1 NaN step).  Synchronous; for tests: on identical
+ * inputs x and rc are bit-identical to the reference solver's. */
+int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
+                                 const int32_t* findex, double* x, int32_t* rc);
+
 /*
  * Layout helpers: the Python surface takes world-major tensors [B][d] like a stack of the
  * reference's 1-D state vectors; these transpose to/from the library's [d][B] layout on device.

@@ -83,6 +83,8 @@ def lib():
     L.nbl_kernel_name.restype = C.c_char_p
     L.nbl_kernel_timing.argtypes = [vp, C.c_int32, pd, C.POINTER(C.c_int64)]
     L.nbl_kernel_timing.restype = C.c_int32
+    L.nbl_selftest_lcp_dantzig.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.nbl_selftest_lcp_dantzig.restype = C.c_int32
     _lib = L
     return L
 
@@ -92,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows", "nbl_workspace_bytes", "nbl_saved_bytes",
     "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing", "nbl_set_launch_lanes", "nbl_set_slices", "nbl_slices_for", "nbl_rollout_workspace_bytes", "nbl_rollout_forward", "nbl_rollout_backward",
     "nbl_set_body_inertia", "nbl_set_inertia_params", "nbl_num_inertia_params", "nbl_backward_inertia", "nbl_rollout_backward_inertia",
-    "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing",
+    "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing", "nbl_selftest_lcp_dantzig",
 ]
 
 

@@ -16,8 +16,9 @@ template <int I> struct IntTag { static constexpr int value = I; };
 
 struct CascadeLds {
   double A[MAXR * CLD];    // reduced problem; for Dantzig: symmetrised from the lower triangle, rows/columns in driver order
-  double L[MAXR * CLD];    // LDL^T of A(C,C): unit lower factor below the diagonal, D on it
+  double L[MAXR * CLD];    // LDL^T of a permutation of A(C,C): unit lower factor by rows (the reference's m_L), pivots in d[]
   double v[4][MAXR];       // broadcast vectors
+  double d[MAXR];          // reciprocal pivots of the factor (the reference's m_d)
   int iv[2][MAXR];
 };
 
@@ -27,12 +28,28 @@ struct CoopLcpRow {
   int findex;
 };
 
-// The Dantzig driver.  In: the reduced problem (n rows) with its matrix in C.A (only the lower triangle is meaningful,
-// lcp.cpp:138-140) and one row per lane in `row`.  Out: row.x = solution in the ORIGINAL reduced order; returns false on
-// early termination (s <= 0), like dantzigSolve.  Returns 1 (solved), 0 (early termination) or -1 (a NaN step length:
-// the one-world-per-lane code would carry the NaN into x and its caller would reset x and flag the world).
+// The Dantzig driver: dSolveLCP (dart/external/odelcpsolver/lcp.cpp:780-1113) with nub = 0, earlyTermination = true, restated
+// OPERATION BY OPERATION: the factor of A(C,C) is the reference's L / d (unit lower factor by rows, RECIPROCAL pivots) kept in
+// the reference's own row order through the index vector C[] (lcp.cpp:100-108); a row entering C appends ell / Dell to it
+// (transfer_i_to_C / transfer_i_from_N_to_C, lcp.cpp:520-600), a row leaving C down-dates it with dLDLTRemove -> dLDLTAddTL
+// (lcp.cpp:603-650, matrix.cpp:286-426) - no refactorisation anywhere.  Every floating-point expression keeps the reference's
+// association: the blocked accumulation order of dSolveL1 / dSolveL1T (fastlsolve.cpp, fastltsolve.cpp: a row of a full
+// 4-block sums the columns left of its block into Z, x = b - Z, then subtracts the in-block terms one by one; tail rows sum
+// everything into Z), dDot's running sum from 0 (fastdot.cpp), products and sums never fused (contraction is switched off for
+// this function: the reference build has no FMA).  On identical inputs the result is therefore BIT-identical to the
+// reference's, success flag included, also where A(C,C) is singular and the s <= 0 exit is decided by round-off
+// (tests/test_coop_host.py pins it against oracle/_ref on the host emulation, tests/test_gpu_lcp_selftest.py on the GPU).
+//
+// Lane k owns POSITION k of the permuted problem (x, w, b, lo, hi, dx, dw, state, findex, p) and, for the factor, ROW k of
+// L / entry k of d / C[k].  In: the reduced problem (n rows) with its matrix in C.A (only the lower triangle is meaningful,
+// lcp.cpp:138-140) and one row per lane in `row`.  Out: row.x = solution in the ORIGINAL reduced order.  Returns 1 (solved),
+// 0 (early termination, s <= 0) or -1 (a NaN step length of the driving row: the reference would carry the NaN into x and
+// its caller resets x and flags the world, BoxedLcpConstraintSolver.cpp:500-520).
 template <class W>
 DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   const int ln = w.lane();
   const bool on = ln < n;
   const int me = on ? ln : 0;
@@ -41,6 +58,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   w.sync();
   double x = 0.0, ww = 0.0, b = on ? row.b : 0.0, lo = on ? row.lo : 0.0, hi = on ? row.hi : 0.0, dx = 0.0, dw = 0.0;
   int st = 0, fidx = on ? row.findex : -1, p = me;
+  int Cv = 0;                      // C[ln]: position of the problem row that factor row ln belongs to (lanes < nC)
+  double ell = 0.0, Dell = 0.0;    // lanes < nC, factor order
+  int nC = 0, nN = 0;
   auto swapProblem = [&](int i1, int i2) {   // uniform arguments
     if (i1 == i2) return;
     // rows, then columns of the permuted matrix
@@ -53,7 +73,6 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     auto xi = [&](int& v) { const int a = w.bcastI(v, i1), c2 = w.bcastI(v, i2); v = ln == i1 ? c2 : (ln == i2 ? a : v); };
     xd(x); xd(b); xd(ww); xd(lo); xd(hi); xi(p); xi(st); xi(fidx);
   };
-  int nC = 0, nN = 0;
   // contact problems have no unbounded rows (nub = 0); every findex row goes to the end (lcp.cpp:487-498)
   {
     int atEnd = 0;
@@ -62,72 +81,181 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
       if (fk >= 0) { swapProblem(k, n - 1 - atEnd); atEnd++; }
     }
   }
-  // LDL^T of A(C,C) (no pivoting, like dFactorLDLT) is kept across pivots: a row entering C at position nC extends it
-  // (what the reference's transfer_i_to_C / transfer_i_from_N_to_C do with ell / Dell, lcp.cpp:533-600); a row leaving C
-  // permutes C, so the factor is rebuilt at the next solve (the reference down-dates with dLDLTRemove instead).
-  bool Lvalid = true;   // C.L factors A(0..nC, 0..nC)
-  double ell = 0.0, Dell = 0.0;
-  auto refactor = [&]() {
-    const bool inC = ln < nC;
-    if (inC) for (int j = 0; j < nC; j++) if (j <= ln) C.L[ln * CLD + j] = C.A[ln * CLD + j];
-    w.sync();
-    for (int k = 0; k < nC; k++) {
-      const double dk = C.L[k * CLD + k];
-      const double aik = (inC && ln > k) ? C.L[ln * CLD + k] : 0.0;
-      const double lik = aik / dk;
-      if (inC && ln > k) for (int j = k + 1; j < nC; j++) if (j <= ln) C.L[ln * CLD + j] -= lik * C.L[j * CLD + k];
-      w.sync();
-      if (inC && ln > k) C.L[ln * CLD + k] = lik;
-      w.sync();
-    }
-    Lvalid = true;
-  };
-  // ell = L^-1 A(C, col), Dell = ell / D   (lanes < nC)
-  auto forward = [&](int col) {
-    const bool inC = ln < nC;
-    double y = inC ? C.A[ln * CLD + col] : 0.0;
-    double lrow[MAXR];   // this lane's row of L, fetched up front so that the substitution chain does not wait on LDS
+  // dDot over lanes [from, to): the running sum from 0 in lane order (fastdot.cpp); every lane gets the result
+  auto seqSum = [&](double prod, int from, int to) -> double {
+    double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXR; k++) lrow[k] = (inC && k < ln) ? C.L[ln * CLD + k] : 0.0;
+    for (int k = 0; k < MAXR; k++) { const double pk = w.bcast(prod, k); s = (k >= from && k < to) ? s + pk : s; }
+    return s;
+  };
+  // dSolveL1 (fastlsolve.cpp): L y = rhs over the factor rows, lane = row
+  auto solveL1 = [&](double rhs) -> double {
+    const bool act = ln < nC;
+    const int nb4 = nC & ~3;
+    const int i0 = (ln < nb4) ? (ln & ~3) : ln;     // columns < i0 go into Z, the rest is subtracted term by term
+    double lrow[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) lrow[k] = C.L[me * CLD + k];
+    double Z = 0.0, y = rhs;
 #pragma unroll
     for (int k = 0; k < MAXR; k++) {
       if (k >= nC) break;
-      const double yk = w.bcast(y, k);
-      if (inC && ln > k) y -= lrow[k] * yk;
+      if (k == i0) y = rhs - Z;
+      const double xk = w.bcast(y, k);
+      const double t = lrow[k] * xk;
+      if (act && k < ln) { if (k < i0) Z = Z + t; else y = y - t; }
     }
-    ell = y;
-    Dell = inC ? y / C.L[ln * CLD + ln] : 0.0;
+    return y;
   };
-  // the row now at position nC joins C: L[nC][0..nC) = Dell, D[nC] = A(nC,nC) - ell . Dell  (sequential dot like dDot)
-  auto extend = [&]() {
-    if (!Lvalid) return;   // will be rebuilt anyway
-    if (ln < nC) { C.L[nC * CLD + ln] = Dell; C.v[2][ln] = ell * Dell; }
-    w.sync();
-    if (ln == 0) { double sum = 0; for (int j = 0; j < nC; j++) sum += C.v[2][j]; C.L[nC * CLD + nC] = C.A[nC * CLD + nC] - sum; }
-    w.sync();
+  // dSolveL1T (fastltsolve.cpp): L^T y = rhs, the same blocking on the reversed index
+  auto solveL1T = [&](double rhs) -> double {
+    const bool act = ln < nC;
+    const int jr = nC - 1 - ln;
+    const int nb4 = nC & ~3;
+    const int i0 = (jr < nb4) ? (jr & ~3) : jr;
+    double Z = 0.0, y = rhs;
+#pragma unroll 1
+    for (int kr = 0; kr < nC; kr++) {
+      const int k = nC - 1 - kr;
+      if (kr == i0) y = rhs - Z;
+      const double xk = w.bcast(y, k);
+      const double t = C.L[k * CLD + me] * xk;
+      if (act && kr < jr) { if (kr < i0) Z = Z + t; else y = y - t; }
+    }
+    return y;
+  };
+  // Dell = L^-1 A(i, C[.]), ell = Dell * d      (first half of dLCP::solve1, lcp.cpp:700-730)
+  auto solveEll = [&](int i) {
+    const double rhs = ln < nC ? C.A[i * CLD + Cv] : 0.0;
+    Dell = solveL1(rhs);
+    ell = ln < nC ? Dell * C.d[me] : 0.0;
   };
   auto solve1 = [&](int i, int dir) {
     if (nC == 0) return;
-    if (!Lvalid) refactor();
-    forward(i);
-    const bool inC = ln < nC;
-    double y = Dell;
-    double lcol[MAXR];   // this lane's column of L
-#pragma unroll
-    for (int k = 0; k < MAXR; k++) lcol[k] = (inC && k > ln && k < nC) ? C.L[k * CLD + ln] : 0.0;
-#pragma unroll
-    for (int k = MAXR - 1; k >= 0; k--) {
-      if (k >= nC) continue;
-      const double zk = w.bcast(y, k);
-      if (inC && ln < k) y -= lcol[k] * zk;
+    solveEll(i);
+    const double t = solveL1T(ell);
+    w.sync();
+    if (ln < nC) C.v[1][Cv] = dir > 0 ? -t : t;      // a[C[j]] = -/+ tmp[j]
+    w.sync();
+    dx = ln < nC ? C.v[1][me] : dx;
+  };
+  // the row at position i (with ell / Dell of the last solveEll(i)) becomes factor row nC   (transfer_i_to_C, lcp.cpp:520-553)
+  auto appendFactorRow = [&](int i) {
+    const double aii = C.A[i * CLD + i];
+    if (nC > 0) {
+      if (ln < nC) C.L[nC * CLD + ln] = ell;
+      const double dot = seqSum(ell * Dell, 0, nC);
+      if (ln == 0) C.d[nC] = 1.0 / (aii - dot);
+    } else if (ln == 0) C.d[0] = 1.0 / aii;
+    w.sync();
+  };
+  // dLDLTAddTL (matrix.cpp:286-359) on the trailing block [r, n2) of the factor with the vector a (lane = factor row)
+  auto ldltAddTL = [&](int r, int n2, double a) {
+    const int nn = n2 - r;
+    if (nn < 2) return;
+    const bool act = ln >= r && ln < n2;
+    const int pl = ln - r;
+    const double SQ = 0.70710678118654752440;   // M_SQRT1_2
+    double W1 = (act && pl >= 1) ? a * SQ : 0.0, W2 = W1;
+    const double a0 = w.bcast(a, r);
+    const double W11 = (0.5 * a0 + 1.0) * SQ, W21 = (0.5 * a0 - 1.0) * SQ;
+    double alpha1 = 1.0, alpha2 = 1.0;
+    {
+      double dee = C.d[r];
+      double alphanew = alpha1 + (W11 * W11) * dee;
+      dee /= alphanew;
+      const double gamma1 = W11 * dee;
+      dee *= alpha1;
+      alpha1 = alphanew;
+      alphanew = alpha2 - (W21 * W21) * dee;
+      dee /= alphanew;
+      alpha2 = alphanew;
+      const double k1 = 1.0 - W21 * gamma1;
+      const double k2 = W21 * gamma1 * W11 - W21;
+      if (act && pl >= 1) {
+        const double Wp = W1, el = C.L[me * CLD + r];
+        W1 = Wp - W11 * el;
+        W2 = k1 * Wp + k2 * el;
+      }
     }
-    dx = inC ? (dir > 0 ? -y : y) : dx;
+#pragma unroll 1
+    for (int j = 1; j < nn; j++) {
+      const double k1 = w.bcast(W1, r + j), k2 = w.bcast(W2, r + j);
+      double dee = C.d[r + j];
+      double alphanew = alpha1 + (k1 * k1) * dee;
+      dee /= alphanew;
+      const double gamma1 = k1 * dee;
+      dee *= alpha1;
+      alpha1 = alphanew;
+      alphanew = alpha2 - (k2 * k2) * dee;
+      dee /= alphanew;
+      const double gamma2 = k2 * dee;
+      dee *= alpha2;
+      w.sync();
+      if (ln == 0) C.d[r + j] = dee;
+      alpha2 = alphanew;
+      if (act && pl > j) {
+        double el = C.L[me * CLD + r + j];
+        double Wp = W1 - k1 * el;
+        el += gamma1 * Wp;
+        W1 = Wp;
+        Wp = W2 - k2 * el;
+        el -= gamma2 * Wp;
+        W2 = Wp;
+        C.L[me * CLD + r + j] = el;
+      }
+    }
+    w.sync();
+  };
+  // dLDLTRemove (matrix.cpp:374-426): factor row / column r leaves the n2-row factor
+  auto ldltRemove = [&](int n2, int r) {
+    if (r == n2 - 1) return;    // deleting the last row / column is easy
+    const bool act = ln >= r && ln < n2;
+    const int Cr = w.bcastI(Cv, r);
+    const double ga = C.A[(act ? Cv : 0) * CLD + Cr];    // GETA(p[r + i], p[r]) (the permuted matrix is kept symmetric)
+    double a;
+    if (r == 0) a = -ga;
+    else {
+      if (ln < r) C.v[2][ln] = C.L[r * CLD + ln] / C.d[ln];   // t[i] = L[r][i] / d[i]
+      w.sync();
+      double s = 0.0;
+#pragma unroll 1
+      for (int k = 0; k < r; k++) s = s + C.L[me * CLD + k] * C.v[2][k];    // dDot(L[r + i], t, r)
+      a = s - ga;
+    }
+    if (ln == r) a += 1.0;
+    ldltAddTL(r, n2, act ? a : 0.0);
+    // dRemoveRowCol: snip row / column r out of L and d
+    double lrow[MAXR];
+    const int src = ln >= r ? ln + 1 : ln;
+    const int srcc = src < MAXR ? src : MAXR - 1;
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) lrow[k] = C.L[srcc * CLD + (k >= r ? (k + 1 < MAXR ? k + 1 : MAXR - 1) : k)];
+    const double dsrc = C.d[srcc];
+    w.sync();
+    if (ln < n2 - 1) {
+#pragma unroll
+      for (int k = 0; k < MAXR; k++) C.L[ln * CLD + k] = lrow[k];
+      C.d[ln] = dsrc;
+    }
+    w.sync();
+  };
+  // transfer_i_from_C_to_N (lcp.cpp:603-650): position i leaves C
+  auto removeFromC = [&](int i) {
+    const int j = __builtin_ctzll(w.ballot(ln < nC && Cv == i));
+    ldltRemove(nC, j);
+    const int k = __builtin_ctzll(w.ballot(ln < nC && Cv == nC - 1));
+    if (ln == k) Cv = i;
+    const int cNext = w.shflI(Cv, ln + 1);
+    if (ln >= j) Cv = cNext;
+    swapProblem(i, nC - 1);
+    nN++; nC--;
   };
   bool hitFirstFriction = false;
   for (int i = 0; i < n; ++i) {
     const int fi = w.bcastI(fidx, i);
     if (!hitFirstFriction && fi >= 0) {
-      // un[p[j]] = x[j]; bounds of the friction rows frozen from the solved normals
+      // un[p[j]] = x[j]; bounds of the friction rows frozen from the solved normals (lcp.cpp:856-873)
       if (on) C.v[0][p] = x;
       w.sync();
       if (on && ln >= i) {
@@ -138,60 +266,60 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
       w.sync();
       hitFirstFriction = true;
     }
-    // w[i] = A(i, C+N) x - b[i]
-    if (on) C.v[0][ln] = x;
-    w.sync();
+    // w[i] = A(i,C) x(C) + A(i,N) x(N) - b[i]: two running sums (lcp.cpp:877)
     {
-      double s = -b;
-#pragma unroll
-      for (int j = 0; j < MAXR; j++) { const double pr = C.A[me * CLD + j] * C.v[0][j]; s += (j < nC + nN) ? pr : 0.0; }   // unconditional reads: they issue together
+      const double pr = on ? C.A[i * CLD + me] * x : 0.0;
+      const double s = seqSum(pr, 0, nC) + seqSum(pr, nC, nC + nN) - w.bcast(b, i);
       if (ln == i) ww = s;
     }
-    w.sync();
     const double wi0 = w.bcast(ww, i), loi = w.bcast(lo, i), hii = w.bcast(hi, i);
     if (loi == 0 && wi0 >= 0) { if (ln == i) st = 0; nN++; }
     else if (hii == 0 && wi0 <= 0) { if (ln == i) st = 1; nN++; }
-    else if (wi0 == 0) { swapProblem(nC, i); if (Lvalid && nC > 0) forward(nC); else { ell = 0; Dell = 0; } extend(); nC++; }
-    else {
+    else if (wi0 == 0) {
+      if (nC > 0) solveEll(i);                 // solve1(delta_x, i, 0, only_transfer)
+      appendFactorRow(i); swapProblem(nC, i); if (ln == nC) Cv = nC; nC++;
+    } else {
       for (;;) {
         const double wi = w.bcast(ww, i);
         const int dir = (wi <= 0) ? 1 : -1;
         const double dirf = dir;
         solve1(i, dir);
-        // dw(N) = A(N,C) dx(C) + dir A(N,i);  dw[i] likewise
-        if (on) C.v[1][ln] = dx;
-        w.sync();
+        // dw(N) = A(N,C) dx(C) +/- A(i,N);  dw[i] = A(i,C) dx(C) + A(i,i) dirf   (lcp.cpp:926-928)
         {
-          double s = 0;
+          double arow[MAXR];
 #pragma unroll
-          for (int j = 0; j < MAXR; j++) { const double pr = C.A[me * CLD + j] * C.v[1][j]; s += (j < nC) ? pr : 0.0; }
+          for (int j = 0; j < MAXR; j++) arow[j] = C.A[me * CLD + j];
+          double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < MAXR; j++) { const double pr = arow[j] * w.bcast(dx, j); s = (j < nC) ? s + pr : s; }
           const bool inN = ln >= nC && ln < nC + nN;
-          if (inN || ln == i) dw = s + dirf * C.A[me * CLD + i];
+          const double ai = C.A[me * CLD + i];
+          if (inN) dw = dir > 0 ? s + ai : s - ai;
+          if (ln == i) dw = s + ai * dirf;
         }
-        w.sync();
         // step length: first minimum in the reference's scan order (i's own events, N rows, C rows)
         double s = INFINITY;
-        int cmd = 0, order = 1 << 20;
+        int cmd = 0;
         if (ln == i) {
-          s = -ww / dw; cmd = 1; order = 0;
+          s = -ww / dw; cmd = 1;
           if (dir > 0) { if (hi < INFINITY) { const double s2 = (hi - x) * dirf; if (s2 < s) { s = s2; cmd = 3; } } }
           else { if (lo > -INFINITY) { const double s2 = (lo - x) * dirf; if (s2 < s) { s = s2; cmd = 2; } } }
         } else if (ln >= nC && ln < nC + nN) {
           if ((st == 0) ? dw < 0 : dw > 0) {
-            if (!(lo == 0 && hi == 0)) { s = -ww / dw; cmd = 4; order = 1 + (ln - nC); }
+            if (!(lo == 0 && hi == 0)) { s = -ww / dw; cmd = 4; }
           }
         } else if (ln < nC) {
-          if (dx < 0 && lo > -INFINITY) { s = (lo - x) / dx; cmd = 5; order = 100 + 2 * ln; }
-          if (dx > 0 && hi < INFINITY) { s = (hi - x) / dx; cmd = 6; order = 101 + 2 * ln; }
+          if (dx < 0 && lo > -INFINITY) { s = (lo - x) / dx; cmd = 5; }
+          if (dx > 0 && hi < INFINITY) { s = (hi - x) / dx; cmd = 6; }
         }
         // the reference keeps a candidate only if it is STRICTLY smaller than the running minimum, which starts at lane
-        // i's value: arg-min over (s, order)
+        // i's value: arg-min over (s, scan position)
         const double sOwn = w.bcast(s, i);
         if (sOwn != sOwn) { row.x = 0.0; return -1; }
         const double sMin = -w.maxAll(cmd != 0 ? -s : -INFINITY);
         const uint64_t tie = w.ballot(cmd != 0 && s == sMin);
         if (tie == 0ull) { row.x = 0.0; return -1; }
-        // smallest order among the ties: lane i (order 0) < N lanes by position < C lanes by position
+        // first of the ties in scan order: lane i, then the N lanes by position, then the C lanes by position
         int best;
         {
           const uint64_t mi = tie & (1ull << i);
@@ -204,24 +332,28 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         const int cmdB = w.bcastI(cmd, best);
         if (sMin <= 0.0) { row.x = 0.0; return 0; }   // earlyTermination (the caller always has the PGS fallback, BoxedLcpConstraintSolver.cpp:463)
         const int si = best;
-        // apply the step
-        if (ln < nC) x += sMin * dx;
-        if (ln == i) x += sMin * dirf;
-        if (ln >= nC && ln < nC + nN) ww += sMin * dw;
-        if (ln == i) ww += sMin * dw;
+        // apply the step (lcp.cpp:1031-1036)
+        if (ln < nC) x = x + sMin * dx;
+        if (ln == i) x = x + sMin * dirf;
+        if (ln >= nC && ln < nC + nN) ww = ww + sMin * dw;
+        if (ln == i) ww = ww + sMin * dw;
         switch (cmdB) {
-          case 1: if (ln == i) ww = 0; swapProblem(nC, i); extend(); nC++; break;                              // ell / Dell of solve1(i)
+          case 1: if (ln == i) ww = 0; appendFactorRow(i); swapProblem(nC, i); if (ln == nC) Cv = nC; nC++; break;   // ell / Dell of solve1(i)
           case 2: if (ln == i) { x = lo; st = 0; } nN++; break;
           case 3: if (ln == i) { x = hi; st = 1; } nN++; break;
-          case 4: if (ln == si) ww = 0; swapProblem(nC, si); if (Lvalid) forward(nC); extend(); nN--; nC++; break;
-          case 5: if (ln == si) { x = lo; st = 0; } swapProblem(si, nC - 1); nN++; nC--; Lvalid = Lvalid && (si == nC); break;   // only the last row of C can leave without a rebuild
-          case 6: if (ln == si) { x = hi; st = 1; } swapProblem(si, nC - 1); nN++; nC--; Lvalid = Lvalid && (si == nC); break;
+          case 4:                                                                                                  // transfer_i_from_N_to_C
+            if (ln == si) ww = 0;
+            if (nC > 0) solveEll(si);
+            appendFactorRow(si); swapProblem(nC, si); if (ln == nC) Cv = nC; nN--; nC++; break;
+          case 5: if (ln == si) { x = lo; st = 0; } removeFromC(si); break;
+          case 6: if (ln == si) { x = hi; st = 1; } removeFromC(si); break;
         }
         if (cmdB <= 3) break;
       }
     }
   }
   // back to the original (reduced) order: P.x[p[j]] = x[j]
+  w.sync();
   if (on) C.v[0][p] = x;
   w.sync();
   row.x = on ? C.v[0][ln] : 0.0;

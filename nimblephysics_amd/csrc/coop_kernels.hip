@@ -142,6 +142,29 @@ __global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const
 #endif
 }
 
+// Self-test of the device Dantzig driver (nbl_selftest_lcp_dantzig): one wavefront per problem of a batch of n-row boxed LCPs
+// with explicit bounds, exactly the code k_contact_cascade_coop runs in its stage 1.  Problems are dense [count][n * n] / [count][n].
+__global__ __launch_bounds__(64) void k_selftest_dantzig(int count, int n, const double* __restrict__ A, const double* __restrict__ b,
+                                                        const double* __restrict__ lo, const double* __restrict__ hi,
+                                                        const int32_t* __restrict__ findex, double* __restrict__ x, int32_t* __restrict__ rc) {
+  __shared__ CascadeLds C;
+  const DevWave w;
+  const int ln = w.lane();
+  const int64_t pb = blockIdx.x;
+  if (pb >= count) return;
+  for (int i = ln; i < MAXR * CLD; i += 64) { C.A[i] = 0.0; C.L[i] = 0.0; }
+  w.sync();
+  if (ln < n) for (int j = 0; j < n; j++) C.A[ln * CLD + j] = A[(pb * n + ln) * n + j];
+  w.sync();
+  CoopLcpRow row;
+  const bool on = ln < n;
+  row.x = 0.0; row.b = on ? b[pb * n + ln] : 0.0; row.lo = on ? lo[pb * n + ln] : 0.0; row.hi = on ? hi[pb * n + ln] : 0.0;
+  row.findex = on ? findex[pb * n + ln] : -1;
+  const int r = coopDantzig(w, C, n, row);
+  if (on) x[pb * n + ln] = row.x;
+  if (ln == 0) rc[pb] = r;
+}
+
 // Dense part of the contact adjoint, one world per wavefront: the same quantities as k_bwd_contact_a
 // (contact_backward.hip; the header there derives them), with lane = LCP row for the c-vectors and lane = DOF for the
 // n-vectors.  Row-indexed vectors are zero outside the clamping set, which replaces the index compaction:

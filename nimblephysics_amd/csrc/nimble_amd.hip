@@ -685,6 +685,37 @@ int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double*
   return NBL_OK;
 }
 
+// ---- self-test: the device Dantzig driver on caller-supplied problems (host pointers) ----------------------------------
+int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
+                                 const int32_t* findex, double* x, int32_t* rc) {
+  if (!A || !b || !lo || !hi || !findex || !x || !rc) return fail(NBL_E_BADARG, "null argument");
+  if (count <= 0 || n <= 0 || n > MAX_ROWS) return fail(NBL_E_BADARG, "count must be positive and 1 <= n <= 24");
+  if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
+  const size_t nv = (size_t)count * n, nm = nv * n;
+  double *dA = nullptr, *dv = nullptr;
+  int32_t* di = nullptr;
+  hipError_t e = hipMalloc((void**)&dA, nm * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dv, 4 * nv * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&di, (nv + count) * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(dA, A, nm * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv, b, nv * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv + nv, lo, nv * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv + 2 * nv, hi, nv * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(di, findex, nv * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv,
+                       di + nv);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(x, dv + 3 * nv, nv * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(rc, di + nv, count * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (dA) hipFree(dA);
+  if (dv) hipFree(dv);
+  if (di) hipFree(di);
+  if (e != hipSuccess) return fail(NBL_E_HIP, std::string("nbl_selftest_lcp_dantzig: ") + hipGetErrorString(e));
+  return NBL_OK;
+}
+
 #ifdef NBL_PHASE_TIMING
 int32_t nbl_debug_phase_stamps(unsigned long long* out64) {
   HIP_TRY(hipDeviceSynchronize());

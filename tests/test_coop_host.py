@@ -25,7 +25,7 @@ def shim():
     deps = [src, os.path.join(HERE, "host_shim", "wave_emu.hpp")] + \
         [os.path.join(ROOT, "nimblephysics_amd", "csrc", f) for f in ("coop_dev.hpp", "coop_dantzig_dev.hpp", "lcp_dev.hpp", "spatial_dev.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(HERE, "host_shim"),
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(HERE, "host_shim"),
                                "-I", os.path.join(ROOT, "nimblephysics_amd", "csrc"), "-o", out, src])
     return C.CDLL(out)
 
@@ -120,30 +120,31 @@ OL = oracle._lib()
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
-def test_coop_dantzig_equals_the_reference_dsolvelcp(shim):
-    """The wave-cooperative Dantzig driver (lane = position of the permuted problem, LDL^T / solves / products
-    lane-parallel, step-length events by a wave arg-min with the reference's scan order as tie-break) against the
-    reference's own dSolveLCP (oracle/_ref): identical success flag and x on full-rank problems; on rank-deficient A(C,C)
-    the early-termination test s <= 0 can be decided by round-off (as for the one-world-per-lane restatement), so there
-    the flags must agree on > 95 % of the problems and x wherever both solve."""
+def test_coop_dantzig_is_bit_identical_to_the_reference_dsolvelcp(shim):
+    """The wave-cooperative Dantzig driver restates dSolveLCP operation by operation (the reference's L / d factor in its own
+    row order, dLDLTAddTL / dLDLTRemove down-dates, the blocked summation order of dSolveL1 / dSolveL1T, dDot's running sum, no
+    fused multiply-adds): against the reference's own solver (oracle/_ref) the success flag and EVERY BIT of x must be equal,
+    on full-rank problems and on rank-deficient ones (6- and 3-DOF bodies with up to 8 frictional contacts) where A(C,C)
+    goes singular and the s <= 0 early exit is decided by round-off."""
     rng = np.random.default_rng(0)
-    solved = 0
-    disagree = 0
-    for trial in range(50):
+    solved = failed = 0
+    for trial in range(40):
         nc = int(rng.integers(1, 9)); n = 3 * nc
-        ndof = n + int(rng.integers(0, 6)) if trial % 2 == 0 else 6          # odd trials: rank-deficient A(C,C)
+        ndof = n + int(rng.integers(0, 6)) if trial % 3 == 0 else int(rng.choice([3, 6, 12]))   # 2 of 3: rank-deficient A
         A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
         xr = np.zeros(n); xd = np.zeros(n)
         okr = OL.nbo_lcp_dantzig(n, _p(A), _p(xr), _p(b.copy()), _p(lo.copy()), _p(hi.copy()), _pi(fi.copy()), 1)
         okd = shim.shim_coop_dantzig(n, _p(A), _p(xd), _p(b), _p(lo), _p(hi), _pi(fi))
-        if okr != (1 if okd == 1 else 0):
-            assert ndof == 6, (trial, okr, okd)
-            disagree += 1
+        if okd == -1:                      # NaN step: the reference carries the NaN into x (its caller then resets x)
+            assert okr == 0 or not np.all(np.isfinite(xr)), (trial, okr)
             continue
-        if okr == 1 and np.all(np.isfinite(xr)):
+        assert okr == okd, (trial, n, ndof, okr, okd)
+        if okr == 1:
             solved += 1
-            assert np.allclose(xr, xd, rtol=1e-6 if ndof == 6 else 1e-9, atol=1e-9)
-    assert solved > 20 and disagree <= 2
+            assert np.array_equal(xr, xd), (trial, n, ndof, np.abs(xr - xd).max())
+        else:
+            failed += 1
+    assert solved > 20 and failed > 0
 
 
 def test_coop_pgs_and_reduce_equal_the_oracle_restatement(shim):

@@ -24,11 +24,33 @@ def _run(name, B, seed, **kw):
     status = world.last_status.cpu().numpy().astype(np.uint32)
     out.backward(torch.tensor(g, device="cuda:0"))
     ref = ow.step_batch(s, a, g, threads=8)
-    scale = lambda x: np.abs(x).max()
-    errs = {"next": np.abs(out.detach().cpu().numpy() - ref["next"]).max(1) / scale(ref["next"]),
-            "grad_state": np.abs(st.grad.cpu().numpy() - ref["grad_state"]).max(1) / scale(ref["grad_state"]),
-            "grad_action": np.abs(at.grad.cpu().numpy() - ref["grad_action"]).max(1) / scale(ref["grad_action"])}
+    dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
+    scales = {k: np.abs(ref[k]).max() for k in dev}
+    errs = {k: np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev}
+    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref_next": ref["next"]}
     return errs, status, ref["status"], world
+
+
+def _assert_all_worlds_match_or_reference_is_unstable(tag, errs, world, tol, n_perturb=64):
+    """Every world within `tol` of the oracle - or, for the few that are not, PROOF that the reference algorithm itself has no
+    stable answer there: re-run the oracle on that world with +-1-ulp perturbations of the input state; its own results must
+    scatter by more than `tol` (on singular A(C,C) the Dantzig early exit s <= 0, and with it friction-or-no-friction, is
+    decided by round-off) AND the device result must coincide, to `tol`, with one of the reference's own outcomes (next state
+    and both gradients of the SAME perturbed run).  Returns the number of such reference-unstable worlds."""
+    P = world._parity
+    bad = np.where(np.maximum.reduce([errs[k] for k in ("next", "grad_state", "grad_action")]) > tol)[0]
+    rng = np.random.default_rng(12345)
+    for wd in bad:
+        s0 = P["s"][wd]
+        sp = s0[None, :] * (1.0 + rng.choice([-1.0, 0.0, 1.0], (n_perturb, s0.size)) * 2.220446049250313e-16)
+        r = P["ow"].step_batch(sp, np.repeat(P["a"][wd][None], n_perturb, 0), np.repeat(P["g"][wd][None], n_perturb, 0), threads=8)
+        dist = np.maximum.reduce([np.abs(r[k] - P["dev"][k][wd][None]).max(1) / P["scales"][k] for k in ("next", "grad_state", "grad_action")])
+        spread = np.abs(r["next"] - P["ref_next"][wd][None]).max() / P["scales"]["next"]      # vs the unperturbed reference run
+        assert spread > tol, (tag, int(wd), "the reference is stable here but the device differs", float(dist.min()))
+        assert dist.min() <= tol, (tag, int(wd), "device result is none of the reference's own outcomes", float(dist.min()))
+    print(f"[{tag}] reference-unstable worlds (oracle flips under 1-ulp input perturbations; device equals one of its outcomes): "
+          f"{len(bad)} of {len(errs['next'])}")
+    return len(bad)
 
 
 @pytest.mark.parametrize("name,B,seed", [("atlas20", 4096, 11), ("atlas33", 1024, 12)])
@@ -41,27 +63,34 @@ def test_standing_atlas_contact_fwd_bwd_vs_oracle(name, B, seed):
         assert e.max() < TOL, (k, e.max())
 
 
-def test_full_lcp_cascade_on_noisy_poses():
-    """Larger noise: ~half of the worlds leave stage 0 and go through reduce + Dantzig, CFM + PGS and the
-    frictionless fallback on the device (k_contact_cascade).  The stage-0 lane set must equal the oracle's; the
-    cascade lanes must agree except where the Dantzig early-termination test (s <= 0) is decided by round-off on
-    rank-deficient A(C,C) (the device restatement refactors A(C,C), the reference updates it incrementally): those
-    lanes are few (< 1 %) and are reported, not hidden."""
-    errs, st, ost, _ = _run("atlas20", 1024, 13, joint_noise=0.02, vel_noise=0.01, action_noise=0.0)
+NORTH_STAR_TOL = 1e-5
+
+
+def _report(tag, errs):
+    print(f"[{tag}] worlds above 1e-7 / above 1e-5 (of {len(errs['next'])}): " +
+          ", ".join(f"{k}: {(e > TOL).sum()} / {(e > NORTH_STAR_TOL).sum()} (max {e.max():.2e})" for k, e in errs.items()))
+
+
+@pytest.mark.parametrize("B,seed", [(1024, 13), (4096, 23)])
+def test_full_lcp_cascade_on_noisy_poses(B, seed):
+    """The metric distribution (joint noise N(0, 0.02^2)): about half of the worlds leave stage 0 and go through reduce +
+    Dantzig, CFM + PGS and the frictionless fallback on the device (k_contact_cascade_coop).  The stage-0 world set must
+    equal the oracle's.  Next state AND gradients of EVERY world within north_star's 1e-5 of the oracle, none masked out -
+    except worlds where the reference algorithm itself is proven unstable (see the helper; ~0.2 % here), which must equal
+    one of the reference's own outcomes.  The device Dantzig is bit-identical to the reference's on identical inputs
+    (test_gpu_lcp_selftest.py); what differs are the last bits of A (world-frame vs body-frame impulse tests)."""
+    errs, st, ost, world = _run("atlas20", B, seed, joint_noise=0.02, vel_noise=0.01, action_noise=0.0)
     gpu0 = (st & 0x2) != 0
     ora0 = (ost & 0x2) != 0
     assert np.array_equal(gpu0, ora0)
-    assert 0.3 < gpu0.mean() < 0.95                      # the cascade is really exercised
+    assert 0.3 < gpu0.mean() < 0.7                      # the cascade is really exercised
     assert not np.any((st & 0x1) == 0)
-    stage_bits = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100   # ignore the NaN-seen and partial-gradient flags
-    same_stage = (st & stage_bits) == (ost & stage_bits)
-    assert same_stage.mean() > 0.99
-    agree = errs["next"] < TOL
-    assert agree.mean() > 0.99, agree.mean()
-    assert np.all(agree[same_stage])
+    _report(f"atlas20 sigma=0.02 B={B}", errs)
+    unstable = _assert_all_worlds_match_or_reference_is_unstable(f"atlas20 sigma=0.02 B={B}", errs, world, NORTH_STAR_TOL)
+    assert unstable <= 0.01 * B
+    assert (errs["next"][gpu0] > TOL).sum() == 0
     for k in ("grad_state", "grad_action"):
-        assert errs[k][agree].max() < 1e-5, (k, errs[k][agree].max())   # CFM lanes: Q conditioned ~1e4
-        assert errs[k][agree & gpu0].max() < TOL
+        assert errs[k][gpu0].max() < TOL
 
 
 def test_no_contact_when_lifted():
@@ -162,15 +191,18 @@ def test_edge_edge_contact_gradients_box_over_the_rim():
 
 
 def test_cfg4_box_stack_8192_worlds():
-    """cfg4: two stacked cubes on the ground box, 8 frictional contacts (24 LCP rows), B = 8192.  Cold start: the
-    reference's guess leaves out the cube-cube normals (relative velocity 0), so these worlds run the whole cascade."""
-    errs, st, ost, _ = _run("box_stack", 8192, 32)
+    """cfg4 (BASELINE config): two stacked cubes on the ground box, 8 frictional contacts (24 LCP rows), B = 8192.  Cold
+    start: the reference's guess leaves out the cube-cube normals (relative velocity 0), so EVERY world runs the cascade.
+    Next state and gradients of every world within north_star's 1e-5 of the oracle - no world masked out; the stage that
+    resolved a world may differ where the Dantzig early exit is decided by round-off (see the noisy-pose test)."""
+    errs, st, ost, world = _run("box_stack", 8192, 32)
     assert np.all(st & 0x1)
+    assert not np.any(st & 0x2) and not np.any(ost & 0x2)            # nobody short-circuits at stage 0
+    _report("cfg4 box stack B=8192", errs)
     stage_bits = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100
-    same = (st & stage_bits) == (ost & stage_bits)
-    agree = errs["next"] < TOL
-    assert same.mean() > 0.97 and agree.mean() > 0.97, (same.mean(), agree.mean())
-    assert errs["grad_state"][agree & same].max() < 1e-5
+    print("[cfg4] worlds resolved by a different stage than in the oracle:", int(((st & stage_bits) != (ost & stage_bits)).sum()))
+    unstable = _assert_all_worlds_match_or_reference_is_unstable("cfg4 box stack B=8192", errs, world, NORTH_STAR_TOL)
+    assert unstable <= 0.005 * 8192
 
 
 def test_results_do_not_depend_on_uninitialised_memory():
