@@ -14,6 +14,29 @@ namespace nbl {
 
 template <int I> struct IntTag { static constexpr int value = I; };
 
+// Developer instrumentation of the Dantzig driver (tools/cascade_timing.py builds with -DNBL_CASCADE_TIMING): cycles per phase
+// summed over all worlds.  Compiled out of the shipped library.
+#if defined(NBL_CASCADE_TIMING) && defined(__HIPCC__)
+__device__ unsigned long long g_dzStat[16];
+#endif
+#if defined(NBL_CASCADE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define DZ_T0() long long dzT = clock64(); long long dzAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define DZ_ADD(k) do { const long long dzN = clock64(); dzAcc[k] += dzN - dzT; dzT = dzN; } while (0)
+#define DZ_CNT(k) do { dzAcc[k] += 1; } while (0)
+#define DZ_FLUSH() do { if (ln == 0) for (int dzK = 0; dzK < 12; dzK++) atomicAdd(&g_dzStat[dzK], (unsigned long long)dzAcc[dzK]); } while (0)
+#else
+#define DZ_T0() do { } while (0)
+#define DZ_ADD(k) do { } while (0)
+#define DZ_CNT(k) do { } while (0)
+#define DZ_FLUSH() do { } while (0)
+#endif
+
+// PGS / reduce only need the matrix and the broadcast vectors
+struct PgsLds {
+  double A[MAXR * CLD];
+  double v[4][MAXR];
+};
+
 struct CascadeLds {
   double A[MAXR * CLD];    // reduced problem; for Dantzig: symmetrised from the lower triangle, rows/columns in driver order
   double L[MAXR * CLD];    // LDL^T of a permutation of A(C,C): unit lower factor by rows (the reference's m_L), pivots in d[]
@@ -53,6 +76,8 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   const int ln = w.lane();
   const bool on = ln < n;
   const int me = on ? ln : 0;
+  DZ_T0();
+  DZ_CNT(8);
   // ---- symmetrise in place: A[u][v] (u < v) <- A[v][u]; lane = column v ----
   if (on) for (int u = 0; u < n; u++) if (u < ln) C.A[u * CLD + ln] = C.A[ln * CLD + u];
   w.sync();
@@ -68,10 +93,10 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     w.sync();
     if (on) { const double t = C.A[ln * CLD + i1]; C.A[ln * CLD + i1] = C.A[ln * CLD + i2]; C.A[ln * CLD + i2] = t; }
     w.sync();
-    // two-lane exchange with readlanes (i1, i2 uniform)
-    auto xd = [&](double& v) { const double a = w.bcast(v, i1), c2 = w.bcast(v, i2); v = ln == i1 ? c2 : (ln == i2 ? a : v); };
-    auto xi = [&](int& v) { const int a = w.bcastI(v, i1), c2 = w.bcastI(v, i2); v = ln == i1 ? c2 : (ln == i2 ? a : v); };
-    xd(x); xd(b); xd(ww); xd(lo); xd(hi); xi(p); xi(st); xi(fidx);
+    // the two lanes trade their values: every lane reads from its source lane (itself unless it is i1 / i2)
+    const int src = ln == i1 ? i2 : (ln == i2 ? i1 : ln);
+    x = w.shfl(x, src); b = w.shfl(b, src); ww = w.shfl(ww, src); lo = w.shfl(lo, src); hi = w.shfl(hi, src);
+    p = w.shflI(p, src); st = w.shflI(st, src); fidx = w.shflI(fidx, src);
   };
   // contact problems have no unbounded rows (nub = 0); every findex row goes to the end (lcp.cpp:487-498)
   {
@@ -85,7 +110,12 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   auto seqSum = [&](double prod, int from, int to) -> double {
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXR; k++) { const double pk = w.bcast(prod, k); s = (k >= from && k < to) ? s + pk : s; }
+    for (int k = 0; k < MAXR; k++) {
+      if (k < to) {
+        const double pk = w.bcast(prod, k);
+        s = (k >= from) ? s + pk : s;
+      }
+    }
     return s;
   };
   // dSolveL1 (fastlsolve.cpp): L y = rhs over the factor rows, lane = row
@@ -99,11 +129,12 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     double Z = 0.0, y = rhs;
 #pragma unroll
     for (int k = 0; k < MAXR; k++) {
-      if (k >= nC) break;
-      if (k == i0) y = rhs - Z;
-      const double xk = w.bcast(y, k);
-      const double t = lrow[k] * xk;
-      if (act && k < ln) { if (k < i0) Z = Z + t; else y = y - t; }
+      if (k < nC) {          // a guard, not a break: the loop must stay fully unrolled (lrow[] in registers, not in scratch)
+        if (k == i0) y = rhs - Z;
+        const double xk = w.bcast(y, k);
+        const double t = lrow[k] * xk;
+        if (act && k < ln) { if (k < i0) Z = Z + t; else y = y - t; }
+      }
     }
     return y;
   };
@@ -113,14 +144,19 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     const int jr = nC - 1 - ln;
     const int nb4 = nC & ~3;
     const int i0 = (jr < nb4) ? (jr & ~3) : jr;
+    double lcol[MAXR];   // this lane's column of L, fetched up front so that the substitution chain does not wait on LDS
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) lcol[k] = C.L[k * CLD + me];
     double Z = 0.0, y = rhs;
-#pragma unroll 1
-    for (int kr = 0; kr < nC; kr++) {
-      const int k = nC - 1 - kr;
-      if (kr == i0) y = rhs - Z;
-      const double xk = w.bcast(y, k);
-      const double t = C.L[k * CLD + me] * xk;
-      if (act && kr < jr) { if (kr < i0) Z = Z + t; else y = y - t; }
+#pragma unroll
+    for (int k = MAXR - 1; k >= 0; k--) {
+      if (k < nC) {
+        const int kr = nC - 1 - k;
+        if (kr == i0) y = rhs - Z;
+        const double xk = w.bcast(y, k);
+        const double t = lcol[k] * xk;
+        if (act && kr < jr) { if (kr < i0) Z = Z + t; else y = y - t; }
+      }
     }
     return y;
   };
@@ -252,7 +288,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     nN++; nC--;
   };
   bool hitFirstFriction = false;
+  DZ_ADD(0);   // setup
   for (int i = 0; i < n; ++i) {
+    DZ_CNT(9);
     const int fi = w.bcastI(fidx, i);
     if (!hitFirstFriction && fi >= 0) {
       // un[p[j]] = x[j]; bounds of the friction rows frozen from the solved normals (lcp.cpp:856-873)
@@ -272,6 +310,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
       const double s = seqSum(pr, 0, nC) + seqSum(pr, nC, nC + nN) - w.bcast(b, i);
       if (ln == i) ww = s;
     }
+    DZ_ADD(1);   // w[i]
     const double wi0 = w.bcast(ww, i), loi = w.bcast(lo, i), hii = w.bcast(hi, i);
     if (loi == 0 && wi0 >= 0) { if (ln == i) st = 0; nN++; }
     else if (hii == 0 && wi0 <= 0) { if (ln == i) st = 1; nN++; }
@@ -283,7 +322,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         const double wi = w.bcast(ww, i);
         const int dir = (wi <= 0) ? 1 : -1;
         const double dirf = dir;
+        DZ_CNT(10);
         solve1(i, dir);
+        DZ_ADD(2);   // solve1
         // dw(N) = A(N,C) dx(C) +/- A(i,N);  dw[i] = A(i,C) dx(C) + A(i,i) dirf   (lcp.cpp:926-928)
         {
           double arow[MAXR];
@@ -291,34 +332,40 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
           for (int j = 0; j < MAXR; j++) arow[j] = C.A[me * CLD + j];
           double s = 0.0;
 #pragma unroll
-          for (int j = 0; j < MAXR; j++) { const double pr = arow[j] * w.bcast(dx, j); s = (j < nC) ? s + pr : s; }
+          for (int j = 0; j < MAXR; j++) { if (j < nC) { const double pr = arow[j] * w.bcast(dx, j); s = s + pr; } }   // guard, not break: arow[] stays in registers
           const bool inN = ln >= nC && ln < nC + nN;
           const double ai = C.A[me * CLD + i];
           if (inN) dw = dir > 0 ? s + ai : s - ai;
           if (ln == i) dw = s + ai * dirf;
         }
         // step length: first minimum in the reference's scan order (i's own events, N rows, C rows)
+        DZ_ADD(3);   // dw
+        // every lane's candidate is one quotient (lcp.cpp:938-998): -w / dw for the driving row and the N rows, (lo - x) / dx or
+        // (hi - x) / dx for the C rows - formed with ONE division for the whole wave (the same operands, so the same bits)
+        const bool inN = ln >= nC && ln < nC + nN, inC = ln < nC, isI = ln == i;
+        const bool dn = dx < 0;
+        const double num = (isI || inN) ? -ww : ((dn ? lo : hi) - x);
+        const double den = (isI || inN) ? dw : dx;
+        const double q = num / den;
         double s = INFINITY;
         int cmd = 0;
-        if (ln == i) {
-          s = -ww / dw; cmd = 1;
+        if (isI) {
+          s = q; cmd = 1;
           if (dir > 0) { if (hi < INFINITY) { const double s2 = (hi - x) * dirf; if (s2 < s) { s = s2; cmd = 3; } } }
           else { if (lo > -INFINITY) { const double s2 = (lo - x) * dirf; if (s2 < s) { s = s2; cmd = 2; } } }
-        } else if (ln >= nC && ln < nC + nN) {
-          if ((st == 0) ? dw < 0 : dw > 0) {
-            if (!(lo == 0 && hi == 0)) { s = -ww / dw; cmd = 4; }
-          }
-        } else if (ln < nC) {
-          if (dx < 0 && lo > -INFINITY) { s = (lo - x) / dx; cmd = 5; }
-          if (dx > 0 && hi < INFINITY) { s = (hi - x) / dx; cmd = 6; }
+        } else if (inN) {
+          if (((st == 0) ? dw < 0 : dw > 0) && !(lo == 0 && hi == 0)) { s = q; cmd = 4; }
+        } else if (inC) {
+          if (dn && lo > -INFINITY) { s = q; cmd = 5; }
+          if (dx > 0 && hi < INFINITY) { s = q; cmd = 6; }
         }
         // the reference keeps a candidate only if it is STRICTLY smaller than the running minimum, which starts at lane
         // i's value: arg-min over (s, scan position)
         const double sOwn = w.bcast(s, i);
-        if (sOwn != sOwn) { row.x = 0.0; return -1; }
+        if (sOwn != sOwn) { row.x = 0.0; DZ_FLUSH(); return -1; }
         const double sMin = -w.maxAll(cmd != 0 ? -s : -INFINITY);
         const uint64_t tie = w.ballot(cmd != 0 && s == sMin);
-        if (tie == 0ull) { row.x = 0.0; return -1; }
+        if (tie == 0ull) { row.x = 0.0; DZ_FLUSH(); return -1; }
         // first of the ties in scan order: lane i, then the N lanes by position, then the C lanes by position
         int best;
         {
@@ -330,8 +377,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
           else best = __builtin_ctzll((tie & maskC) ? (tie & maskC) : tie);
         }
         const int cmdB = w.bcastI(cmd, best);
-        if (sMin <= 0.0) { row.x = 0.0; return 0; }   // earlyTermination (the caller always has the PGS fallback, BoxedLcpConstraintSolver.cpp:463)
+        if (sMin <= 0.0) { row.x = 0.0; DZ_FLUSH(); return 0; }   // earlyTermination (the caller always has the PGS fallback, BoxedLcpConstraintSolver.cpp:463)
         const int si = best;
+        DZ_ADD(4);   // step selection
         // apply the step (lcp.cpp:1031-1036)
         if (ln < nC) x = x + sMin * dx;
         if (ln == i) x = x + sMin * dirf;
@@ -348,9 +396,12 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
           case 5: if (ln == si) { x = lo; st = 0; } removeFromC(si); break;
           case 6: if (ln == si) { x = hi; st = 1; } removeFromC(si); break;
         }
+        if (cmdB >= 5) DZ_CNT(11);
+        DZ_ADD(5);   // apply + transfer
         if (cmdB <= 3) break;
       }
     }
+    DZ_ADD(6);
   }
   // back to the original (reduced) order: P.x[p[j]] = x[j]
   w.sync();
@@ -358,13 +409,14 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   w.sync();
   row.x = on ? C.v[0][ln] : 0.0;
   w.sync();
+  DZ_FLUSH();
   return 1;
 }
 
 // ---- LCPUtils::reduce / removeFriction (LCPUtils.cpp:144-247, 346-520), lane = reduced row / column ----
 // delete row + column `col` of the n x n problem; lanes >= col take the row data of their right neighbour
-template <class W>
-DEV void coopRemoveRow(const W& w, CascadeLds& C, int n, int col, CoopLcpRow& row) {
+template <class W, class LDS>
+DEV void coopRemoveRow(const W& w, LDS& C, int n, int col, CoopLcpRow& row) {
   const int ln = w.lane();
   if (ln < n) for (int j = col; j + 1 < n; j++) C.A[ln * CLD + j] = C.A[ln * CLD + j + 1];     // columns left, lane = row
   w.sync();
@@ -377,13 +429,19 @@ DEV void coopRemoveRow(const W& w, CascadeLds& C, int n, int col, CoopLcpRow& ro
 
 // merge near-identical columns (squared distance < 1e-4, |b_a - b_b| < 1e-4, same findex / hi / lo).  mapTo: this lane's
 // ORIGINAL row -> reduced column.  Returns the reduced size.
-template <class W>
-DEV int coopLcpReduce(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& mapTo) {
+template <class W, class LDS>
+DEV int coopLcpReduce(const W& w, LDS& C, int n, CoopLcpRow& row, int& mapTo) {
   const double TH = 1e-4;
   const int ln = w.lane();
   for (;;) {
     int ma = -1, mb = -1;
     for (int a = 0; a < n - 1; a++) {
+      // the cheap conditions first (equal findex / bounds, b within the threshold): they rule out most pairs, and the 24-term
+      // column distance is only formed when some column b > a passes them (wave-uniform skip)
+      const double ba = w.bcast(row.b, a), ha = w.bcast(row.hi, a), la = w.bcast(row.lo, a);
+      const int fa = w.bcastI(row.findex, a);
+      const bool cand = ln > a && ln < n && fabs(ba - row.b) < TH && fa == row.findex && ha == row.hi && la == row.lo;
+      if (w.ballot(cand) == 0ull) continue;
       double d2 = 0;
       const int bcol = ln < n ? ln : 0;
 #pragma unroll
@@ -392,10 +450,7 @@ DEV int coopLcpReduce(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& ma
         const double d = (r < n) ? dr : 0.0;
         d2 += d * d;
       }
-      const double ba = w.bcast(row.b, a), ha = w.bcast(row.hi, a), la = w.bcast(row.lo, a);
-      const int fa = w.bcastI(row.findex, a);
-      const bool match = ln > a && ln < n && d2 < TH && fabs(ba - row.b) < TH && fa == row.findex && ha == row.hi && la == row.lo;
-      const uint64_t mm = w.ballot(match);
+      const uint64_t mm = w.ballot(cand && d2 < TH);
       if (mm) { ma = a; mb = __builtin_ctzll(mm); break; }
     }
     if (ma < 0) break;
@@ -413,8 +468,8 @@ DEV int coopLcpReduce(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& ma
 }
 
 // drop every friction row (from the last one down)
-template <class W>
-DEV int coopLcpRemoveFriction(const W& w, CascadeLds& C, int n, CoopLcpRow& row, int& mapTo) {
+template <class W, class LDS>
+DEV int coopLcpRemoveFriction(const W& w, LDS& C, int n, CoopLcpRow& row, int& mapTo) {
   for (int i = n - 1; i >= 0; i--) {
     const int fi = w.bcastI(row.findex, i);
     if (fi == -1) continue;
@@ -428,23 +483,107 @@ DEV int coopLcpRemoveFriction(const W& w, CascadeLds& C, int n, CoopLcpRow& row,
 }
 
 // ---- PgsBoxedLcpSolver::solve (PgsBoxedLcpSolver.cpp:79-268), Option(30, 1e-6, 1e-3, 1e-9, false) ----
-// Gauss-Seidel is sequential over the rows.  Lane i keeps its row of A in registers and every lane a replica of x, so the
-// row whose turn it is forms its sum from registers in the reference's order (no LDS, no barrier: ~720 row steps are a
-// dependent chain and their latency is the cost) and the new x_i is broadcast with a readlane.  A is modified (rows
-// normalised) only in registers.  row.x in: start, out: result.
-template <class W>
-DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
+// Gauss-Seidel is sequential over the rows: up to 30 sweeps x 24 row steps are one dependent chain and its length is the cost.
+// Residual form: every lane keeps ITS row of A scaled by 1 / a_ii (the reference divides in its first sweep and pre-scales the
+// rows for the later ones, PgsBoxedLcpSolver.cpp:150-200) and the scaled residual r = b' - sum_k a'_k x_k of its row.  The step
+// of row i is  x_i <- clamp(x_i + r_i)  on lane i, one broadcast of the change, one FMA per lane (A is symmetric: lane j's
+// a'_j[i] is its share of column i).  The reference's own order - a 23-term dot product per row - would be a 23-deep chain on
+// one lane, 720 times per stage; the two orders agree to round-off, the clamps, the convergence tests and the iteration cap are
+// the reference's.
+//
+// The row step is written to compile to ~25 instructions (it was 131: selects on every lane, 64-bit mask bookkeeping, NaN
+// canonicalisation around fmin / fmax, a row-count test per step):
+//   * only lane i executes the update of row i (one EXEC region), no selects;
+//   * bounds as products  lo = cL * xf, hi = cH * xf:  friction rows (cL, cH) = (-mu, mu) and xf = the current impulse of their
+//     normal row; other rows (cL, cH) = (lo, hi) and xf = 1; rows left out (a_ii < eps, lanes >= n) cL = cH = 0, which pins them to
+//     0 exactly like the reference's "x[i] = 0; continue";
+//   * xf follows the normal row through the broadcast change, and only after NORMAL rows (a wave-uniform bit test);
+//   * the sweep is instantiated for 8, 16 or 24 rows (the frictionless stage has 8).
+// One row step = two hand-scheduled blocks around the broadcast.  In C++ the step compiled to 42-86 instructions (lane masks
+// hoisted and spilled to VGPR lanes, boolean bookkeeping in 64-bit scalar masks, selects instead of the uniform skip); written
+// out it is 18 (first sweep) / 21 instructions.  Both blocks run in wave-uniform control flow and restore EXEC themselves.
+//   pgsOwnRow<I>:    on lane I only:  xi = min(max(x + r, cL xf), cH xf);  d = xi - x;  bad |= test(d, xi);  x = xi
+//   pgsFollowRow<I>: on the lanes whose findex is I:  xf += ds   (ds = d of lane I, wave-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int I, bool FIRST>
+DEV double pgsOwnRow(double& x, double r, double xf, double cL, double cH, double thrFirst, double relTol, double epsDiv,
+                     unsigned long long& bad) {
+  double d, t0, t2;
+  unsigned long long sv, sc;
+  if (FIRST) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[lane]\n\t"
+        "v_add_f64 %[t0], %[x], %[r]\n\t"
+        "v_mul_f64 %[d], %[cL], %[xf]\n\t"
+        "v_max_f64 %[t0], %[t0], %[d]\n\t"
+        "v_mul_f64 %[d], %[cH], %[xf]\n\t"
+        "v_min_f64 %[t0], %[t0], %[d]\n\t"
+        "v_add_f64 %[d], %[t0], -%[x]\n\t"
+        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[thr]\n\t"
+        "s_or_b64 %[bad], %[bad], vcc\n\t"
+        "v_mov_b64 %[x], %[t0]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [sv] "=&s"(sv)
+        : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [thr] "v"(thrFirst), [lane] "n"(1u << I)
+        : "vcc", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[lane]\n\t"
+        "v_add_f64 %[t0], %[x], %[r]\n\t"
+        "v_mul_f64 %[d], %[cL], %[xf]\n\t"
+        "v_max_f64 %[t0], %[t0], %[d]\n\t"
+        "v_mul_f64 %[d], %[cH], %[xf]\n\t"
+        "v_min_f64 %[t0], %[t0], %[d]\n\t"
+        "v_add_f64 %[d], %[t0], -%[x]\n\t"
+        "v_mul_f64 %[t2], |%[t0]|, %[rel]\n\t"
+        "v_cmp_gt_f64_e64 %[sc], |%[t0]|, %[eps]\n\t"
+        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[t2]\n\t"
+        "s_and_b64 vcc, vcc, %[sc]\n\t"
+        "s_or_b64 %[bad], %[bad], vcc\n\t"
+        "v_mov_b64 %[x], %[t0]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [t2] "=&v"(t2), [sv] "=&s"(sv), [sc] "=&s"(sc)
+        : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [rel] "v"(relTol), [eps] "v"(epsDiv), [lane] "n"(1u << I)
+        : "vcc", "scc");
+  }
+  return d;   // defined on lane I only
+}
+template <int I>
+DEV void pgsFollowRow(double& xf, int fi, double ds) {
+  unsigned long long sv;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_eq_u32_e32 vcc, %[row], %[fi]\n\t"
+      "v_add_f64 %[xf], %[xf], %[ds]\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [xf] "+v"(xf), [sv] "=&s"(sv)
+      : [fi] "v"(fi), [ds] "s"(ds), [row] "n"(I)
+      : "vcc");
+}
+#else
+template <int I, bool FIRST>
+DEV double pgsOwnRow(double& x, double r, double xf, double cL, double cH, double thrFirst, double relTol, double epsDiv,
+                     unsigned long long& bad) {
+  // host statement of the same step (wave emulation: `bad` is this lane's own flag, the caller ballots it)
+  const double xi = fmin(fmax(x + r, cL * xf), cH * xf);
+  const double d = xi - x;
+  if (FIRST ? fabs(d) > thrFirst : (fabs(xi) > epsDiv && fabs(d) > relTol * fabs(xi))) bad |= 1ull;
+  x = xi;
+  return d;
+}
+template <int I>
+DEV void pgsFollowRow(double& xf, int fi, double ds) { if (fi == I) xf += ds; }
+#endif
+
+template <class W, class LDS>
+DEV bool coopPgs(const W& w, LDS& C, int n, CoopLcpRow& row) {
   const int maxIteration = 30;
   const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
   const int ln = w.lane();
   const bool on = ln < n;
   const int me = on ? ln : 0;
-  // Residual form of the projected Gauss-Seidel sweep.  Every lane keeps ITS row of A, scaled by 1 / a_ii (the reference divides
-  // in its first sweep and pre-scales the rows for the later ones, PgsBoxedLcpSolver.cpp:150-200), and the scaled residual
-  // r = b' - sum_k a'_k x_k of its row.  The step of row i is then  x_i <- clamp(x_i + r_i)  on lane i, one broadcast of the
-  // change, and one FMA per lane (A is symmetric: lane j's a'_j[i] is its share of column i).  The reference's own order - a
-  // 23-term dot product per row - would be a 23-deep chain of dependent FMAs on one lane, 720 times per stage; the two
-  // orders agree to round-off, the clamps, the convergence tests and the iteration cap are the reference's.
   double arow[MAXR];
 #pragma unroll
   for (int j = 0; j < MAXR; j++) { const double av = C.A[me * CLD + j]; arow[j] = (on && j < n) ? av : 0.0; }
@@ -453,163 +592,200 @@ DEV bool coopPgs(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   const double sc = inOrder ? 1.0 / aii : 1.0;
 #pragma unroll
   for (int j = 0; j < MAXR; j++) arow[j] *= sc;
-  double xOwn = on ? row.x : 0.0;
+  double x = on ? row.x : 0.0;
   double r0 = row.b * sc, r1 = 0.0;
 #pragma unroll
   for (int j = 0; j < MAXR; j += 2) {
-    r0 = fma(-arow[j], j < n ? w.bcast(xOwn, j) : 0.0, r0);
-    r1 = fma(-arow[j + 1], j + 1 < n ? w.bcast(xOwn, j + 1) : 0.0, r1);
+    r0 = fma(-arow[j], j < n ? w.bcast(x, j) : 0.0, r0);
+    r1 = fma(-arow[j + 1], j + 1 < n ? w.bcast(x, j + 1) : 0.0, r1);
   }
   double r = r0 + r1;
-  // friction rows follow the current impulse of their normal row: every lane keeps it up to date itself
-  const int fiOwn = on ? row.findex : -1;
-  double xfOwn = w.shfl(xOwn, fiOwn >= 0 ? fiOwn : 0);
-  bool bad = false;
-  // One Gauss-Seidel row step for row i (compile-time i), branch-free: EVERY lane evaluates the update of its own row from its
-  // own (x, r, bounds) - only lane i's result is kept, broadcast, and folded into everybody's residual.  (A divergent
-  // `if (lane == i)` costs EXEC bookkeeping and a scalar branch per row step, 720 times per stage.)
-  auto rowStep = [&](auto iTag, bool first) {
+  const int fi = on ? row.findex : -1;
+  const bool fric = fi >= 0;
+  const double cH = !inOrder ? 0.0 : row.hi, cL = !inOrder ? 0.0 : (fric ? -row.hi : row.lo);
+  const double xNormal = w.shfl(x, fric ? fi : 0);
+  double xf = fric ? xNormal : 1.0;
+  const double thrFirst = inOrder ? dxTh : INFINITY;
+  // bad: on the device a 64-bit lane mask in SGPRs (bit i set by row i's own step), on the host emulation this lane's flag
+  unsigned long long bad = 0ull;
+  const double relTolV = relTol, epsDivV = epsDiv;
+  auto rowStep = [&](auto iTag, auto firstTag) {
     constexpr int i = decltype(iTag)::value;
-    if (i >= n) return;
-    const double old_x = xOwn;
-    const double new_x = old_x + r;
-    const double hi_tmp = fiOwn >= 0 ? row.hi * xfOwn : row.hi, lo_tmp = fiOwn >= 0 ? -hi_tmp : row.lo;
-    double xi = fmin(fmax(new_x, lo_tmp), hi_tmp);   // = the reference's nested comparisons for lo <= hi (two ops, no VCC round trip)
-    if (!inOrder) xi = first ? 0.0 : old_x;
-    const double dOwn = xi - old_x;
-    const bool badOwn = inOrder && (first ? fabs(dOwn) > dxTh : (fabs(xi) > epsDiv && fabs(dOwn) > relTol * fabs(xi)));
-    const bool mineNow = ln == i;
-    bad = bad || (mineNow && badOwn);
-    const double delta = w.bcast(dOwn, i);
-    xOwn = mineNow ? xi : xOwn;
-    xfOwn = fiOwn == i ? xfOwn + delta : xfOwn;
-    r = fma(-arow[i], delta, r);
+    constexpr bool first = decltype(firstTag)::value != 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double d = pgsOwnRow<i, first>(x, r, xf, cL, cH, thrFirst, relTolV, epsDivV, bad);
+#else
+    double d = 0.0;
+    if (ln == i) d = pgsOwnRow<i, first>(x, r, xf, cL, cH, thrFirst, relTolV, epsDivV, bad);
+#endif
+    const double ds = w.bcast(d, i);
+    r = fma(-arow[i], ds, r);
+    pgsFollowRow<i>(xf, fi, ds);
   };
-  auto sweep = [&](bool first) {
-    rowStep(IntTag<0>{}, first); rowStep(IntTag<1>{}, first); rowStep(IntTag<2>{}, first); rowStep(IntTag<3>{}, first);
-    rowStep(IntTag<4>{}, first); rowStep(IntTag<5>{}, first); rowStep(IntTag<6>{}, first); rowStep(IntTag<7>{}, first);
-    rowStep(IntTag<8>{}, first); rowStep(IntTag<9>{}, first); rowStep(IntTag<10>{}, first); rowStep(IntTag<11>{}, first);
-    rowStep(IntTag<12>{}, first); rowStep(IntTag<13>{}, first); rowStep(IntTag<14>{}, first); rowStep(IntTag<15>{}, first);
-    rowStep(IntTag<16>{}, first); rowStep(IntTag<17>{}, first); rowStep(IntTag<18>{}, first); rowStep(IntTag<19>{}, first);
-    rowStep(IntTag<20>{}, first); rowStep(IntTag<21>{}, first); rowStep(IntTag<22>{}, first); rowStep(IntTag<23>{}, first);
+  auto sweep = [&](auto nTag, auto firstTag) {
+    constexpr int NR = decltype(nTag)::value;
+    rowStep(IntTag<0>{}, firstTag); rowStep(IntTag<1>{}, firstTag); rowStep(IntTag<2>{}, firstTag); rowStep(IntTag<3>{}, firstTag);
+    rowStep(IntTag<4>{}, firstTag); rowStep(IntTag<5>{}, firstTag); rowStep(IntTag<6>{}, firstTag); rowStep(IntTag<7>{}, firstTag);
+    if (NR > 8) {
+      rowStep(IntTag<8>{}, firstTag); rowStep(IntTag<9>{}, firstTag); rowStep(IntTag<10>{}, firstTag); rowStep(IntTag<11>{}, firstTag);
+      rowStep(IntTag<12>{}, firstTag); rowStep(IntTag<13>{}, firstTag); rowStep(IntTag<14>{}, firstTag); rowStep(IntTag<15>{}, firstTag);
+    }
+    if (NR > 16) {
+      rowStep(IntTag<16>{}, firstTag); rowStep(IntTag<17>{}, firstTag); rowStep(IntTag<18>{}, firstTag); rowStep(IntTag<19>{}, firstTag);
+      rowStep(IntTag<20>{}, firstTag); rowStep(IntTag<21>{}, firstTag); rowStep(IntTag<22>{}, firstTag); rowStep(IntTag<23>{}, firstTag);
+    }
   };
-  sweep(true);
-  if (w.ballot(bad) == 0ull) { row.x = xOwn; return true; }
-  bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto noneBad = [&]() -> bool { return bad == 0ull; };                 // "no row moved by more than the tolerance"
+#else
+  auto noneBad = [&]() -> bool { return w.ballot(bad != 0ull) == 0ull; };
+#endif
+  auto solve = [&](auto nTag) -> bool {
+    sweep(nTag, IntTag<1>{});
+    if (noneBad()) return true;
+    bool done = false;
 #pragma unroll 1
-  for (int iter = 1; iter < maxIteration; ++iter) {
-    bad = false;
-    sweep(false);
-    if (w.ballot(bad) == 0ull) { done = true; break; }
-  }
-  row.x = xOwn;
+    for (int iter = 1; iter < maxIteration; ++iter) {
+      bad = 0ull;
+      sweep(nTag, IntTag<0>{});
+      if (noneBad()) { done = true; break; }
+    }
+    return done;
+  };
+  const bool done = n <= 8 ? solve(IntTag<8>{}) : (n <= 16 ? solve(IntTag<16>{}) : solve(IntTag<24>{}));
+  row.x = x;
   return done;
 }
 
 // ---- stages 1-3 of BoxedLcpConstraintSolver::solveLcp (:461-677) + registration / standardisation (:718-736) ----
+// The three fallback stages read the same inputs (A, b, the pre-solve x) and none reads another's result - only WHICH result
+// is kept depends on the earlier stages' success flags.  They are therefore written as three independent functions that the
+// kernel runs on three wavefronts of a workgroup AT THE SAME TIME (k_contact_cascade_stages); coopCascadeSelect then applies
+// the reference's order of preference.  A world that falls through to the frictionless stage (two thirds of the worlds that
+// reach the cascade on the metric distribution) used to pay reduce + Dantzig + reduce + 30 PGS sweeps + 30 PGS sweeps one after
+// the other (5.2e5 cycles); now it pays the longest of the three.
+struct CoopStageResult {
+  double X;        // this lane's row of the stage's solution, mapped back to the world's rows
+  int flags;       // uniform, CS_*
+};
+constexpr int CS_SOLVED = 1;   // the solver reported success (Dantzig: no early termination; PGS: converged)
+constexpr int CS_VALID = 2;    // ... and isLCPSolutionValid accepted it
+constexpr int CS_NAN = 4;      // Dantzig: NaN step length
+
+template <class W, class LDS>
+DEV void coopLoadProblem(const W& w, LDS& C, const CoopRow& R, double cfmDiag, double x0, CoopLcpRow& row, int& mapTo) {
+  const int ln = w.lane();
+  const int m = R.m;
+  {
+    // all 24 loads of the lane's column in flight together (in a rolled loop every load was waited for before the next)
+    double col[MAXR];
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) col[j] = R.a(j);
+    if (ln < m) {
+#pragma unroll
+      for (int j = 0; j < MAXR; j++) if (j < m) C.A[ln * CLD + j] = col[j] + (ln == j ? cfmDiag : 0.0);   // A is symmetric: row = column
+    }
+  }
+  row.x = x0; row.b = R.Bv;
+  row.lo = R.fric ? -R.mu : 0.0; row.hi = R.fric ? R.mu : INFINITY; row.findex = R.fric ? R.fp : -1;
+  mapTo = ln < m ? ln : -1;
+  w.sync();
+}
+// X[o] = x_reduced[mapTo[o]]
+template <class W, class LDS>
+DEV double coopMapOut(const W& w, LDS& C, int m, int mapTo, double xred, int nred) {
+  const int ln = w.lane();
+  w.sync();
+  if (ln < nred) C.v[3][ln] = xred;
+  w.sync();
+  return (ln < m && mapTo >= 0) ? C.v[3][mapTo] : 0.0;
+}
+
+// stage 1: reduce + Dantzig with early termination (:461-522)
+template <class W>
+DEV void coopCascadeStage1(const W& w, CascadeLds& C, const CoopRow& R, double X0, CoopStageResult& out) {
+  CoopLcpRow row;
+  int mapTo;
+  coopLoadProblem(w, C, R, 0.0, X0, row, mapTo);
+  const int nr = coopLcpReduce(w, C, R.m, row, mapTo);
+  const int rc = coopDantzig(w, C, nr, row);
+  out.X = 0.0; out.flags = 0;
+  if (rc == 1) {
+    out.X = coopMapOut(w, C, R.m, mapTo, row.x, nr);
+    out.flags = CS_SOLVED | (coopValid(w, C.v[0], R, out.X, false, 0.0) ? CS_VALID : 0);
+  } else if (rc < 0) out.flags = CS_NAN;
+}
+// stage 2: CFM + PGS from the pre-solve x (:539-597)
+template <class W, class LDS>
+DEV void coopCascadeStage2(const W& w, LDS& C, const CoopRow& R, double X0, double cfm, CoopStageResult& out) {
+  CoopLcpRow row;
+  int mapTo;
+  coopLoadProblem(w, C, R, cfm, X0, row, mapTo);
+  const int nr = coopLcpReduce(w, C, R.m, row, mapTo);
+  out.X = 0.0; out.flags = 0;
+  if (coopPgs(w, C, nr, row)) {
+    out.X = coopMapOut(w, C, R.m, mapTo, row.x, nr);
+    out.flags = CS_SOLVED | (coopValid(w, C.v[0], R, out.X, false, cfm) ? CS_VALID : 0);
+  }
+}
+// stage 3: drop friction, PGS from zero (:606-677); its result is used whatever the solver says
+template <class W, class LDS>
+DEV void coopCascadeStage3(const W& w, LDS& C, const CoopRow& R, double X0, double cfm, CoopStageResult& out) {
+  CoopLcpRow row;
+  int mapTo;
+  coopLoadProblem(w, C, R, cfm, X0, row, mapTo);
+  const int nr = coopLcpRemoveFriction(w, C, R.m, row, mapTo);
+  row.x = 0.0;
+  const bool ok3 = coopPgs(w, C, nr, row);
+  out.X = coopMapOut(w, C, R.m, mapTo, row.x, nr);
+  out.flags = ok3 ? CS_SOLVED : 0;
+}
+
 struct CoopCascadeOut {
   double X;          // impulses of this lane's row
   CoopClasses K;
   double cfm;
   uint32_t st;       // NBL_ST_* bits to OR into the world's status
   bool pinvValid;
-#ifdef NBL_CASCADE_TIMING
-  long long t[8];    // cycle stamps: start, after reduce, Dantzig, validity, stage 2, stage 3, standardise
-  int iters;
-#endif
 };
 
+// The reference's order of preference over the three stage results (BoxedLcpConstraintSolver.cpp:461-687), then registration,
+// classification and standardisation of the chosen solution (:718-736).  X0: the pre-solve x.
 template <class W>
-DEV void coopCascade(const W& w, CoopLds& S, CascadeLds& C, const CoopRow& R, double X0, double fallbackCfm, CoopCascadeOut& out) {
+DEV void coopCascadeSelect(const W& w, CoopLds& S, const CoopRow& R, double X0, double fallbackCfm, const CoopStageResult& r1,
+                           const CoopStageResult& r2, const CoopStageResult& r3, CoopCascadeOut& out) {
   const int ln = w.lane();
   const int m = R.m;
-  CoopLcpRow row;
-  int mapTo = -1;
-  auto loadProblem = [&](double cfmDiag, double x0) {
-    {
-      // all 24 loads of the lane's column in flight together (in a rolled loop every load was waited for before the next)
-      double col[MAXR];
-#pragma unroll
-      for (int j = 0; j < MAXR; j++) col[j] = R.a(j);
-      if (ln < m) {
-#pragma unroll
-        for (int j = 0; j < MAXR; j++) if (j < m) C.A[ln * CLD + j] = col[j] + (ln == j ? cfmDiag : 0.0);   // A is symmetric: row = column
-      }
-    }
-    row.x = x0; row.b = R.Bv;
-    row.lo = R.fric ? -R.mu : 0.0; row.hi = R.fric ? R.mu : INFINITY; row.findex = R.fric ? R.fp : -1;
-    mapTo = ln < m ? ln : -1;
-    w.sync();
-  };
-  auto mapped = [&](double xred, int nred) -> double {   // X[o] = x_reduced[mapTo[o]]
-    w.sync();
-    if (ln < nred) C.v[3][ln] = xred;
-    w.sync();
-    return (ln < m && mapTo >= 0) ? C.v[3][mapTo] : 0.0;
-  };
   auto hasNan = [&](double x) -> bool { return w.ballot(ln < m && x != x) != 0ull; };
   uint32_t st = 0;
   bool success = false, ignoreFriction = false;
   double cfm = 0.0, X = X0;
-  // ---- stage 1: reduce + Dantzig with early termination (:461-522) ----
-#ifdef NBL_CASCADE_TIMING
-  out.t[0] = clock64();
-#endif
-  loadProblem(0.0, X0);
-  int nr = coopLcpReduce(w, C, m, row, mapTo);
-#ifdef NBL_CASCADE_TIMING
-  out.t[1] = clock64();
-#endif
-  const int rc = coopDantzig(w, C, nr, row);
-#ifdef NBL_CASCADE_TIMING
-  out.t[2] = clock64();
-#endif
-  if (rc == 1) {
-    X = mapped(row.x, nr);
-    success = coopValid(w, S, R, X, false, 0.0, 1);
+  if (r1.flags & CS_SOLVED) {
+    X = r1.X;
+    success = (r1.flags & CS_VALID) != 0;
     if (success) st |= 0x4u;
   }
-  if (rc < 0 || hasNan(X)) { success = false; X = 0.0; st |= 0x40u; }
-#ifdef NBL_CASCADE_TIMING
-  out.t[3] = clock64();
-#endif
+  if ((r1.flags & CS_NAN) || hasNan(X)) { success = false; X = 0.0; st |= 0x40u; }
   if (!success) {
-    // ---- stage 2: CFM + PGS from the pre-solve x (:539-597) ----
     cfm = fallbackCfm;
-    loadProblem(cfm, X0);
-    nr = coopLcpReduce(w, C, m, row, mapTo);
-    if (coopPgs(w, C, nr, row)) {
-      X = mapped(row.x, nr);
-      success = coopValid(w, S, R, X, false, cfm, 1);
+    if (r2.flags & CS_SOLVED) {
+      X = r2.X;
+      success = (r2.flags & CS_VALID) != 0;
       if (success) st |= 0x8u;
     }
   }
-#ifdef NBL_CASCADE_TIMING
-  out.t[4] = clock64();
-#endif
   if (!success) {
-    // ---- stage 3: drop friction, PGS from zero (:606-677) ----
     ignoreFriction = true;
-    loadProblem(cfm, X0);
-    nr = coopLcpRemoveFriction(w, C, m, row, mapTo);
-    row.x = 0.0;
-    const bool ok3 = coopPgs(w, C, nr, row);
-    X = mapped(row.x, nr);
+    X = r3.X;
     st |= 0x10u;
-    if (!ok3) st |= 0x20u;
+    if (!(r3.flags & CS_SOLVED)) st |= 0x20u;
   }
   if (hasNan(X)) { X = 0.0; st |= 0x40u; }
-#ifdef NBL_CASCADE_TIMING
-  out.t[5] = clock64();
-#endif
   // ---- register the fresh solution, classify, standardise (:718-736) ----
   bool pinvValid = false;
   const bool std = coopStandardizeLoop(w, S, R, X, cfm, ignoreFriction, 0u, pinvValid, out.K);
   if (std) st |= 0x100u;
   out.X = X; out.cfm = cfm; out.st = st; out.pinvValid = std && pinvValid;
-#ifdef NBL_CASCADE_TIMING
-  out.t[6] = clock64();
-#endif
 }
 
 }  // namespace nbl

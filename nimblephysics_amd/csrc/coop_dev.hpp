@@ -246,24 +246,24 @@ struct CoopRow {
   DEV double a(int i) const { return (on && i < m) ? Acol[i * MAXR] : 0.0; }
 };
 
-// A x for this lane's row, x one entry per lane
+// A x for this lane's row, x one entry per lane; vec: MAXR doubles of LDS scratch
 template <class W>
-DEV double coopAx(const W& w, CoopLds& S, const CoopRow& R, double xLane, int slot) {
+DEV double coopAx(const W& w, double* vec, const CoopRow& R, double xLane) {
   const int ln = w.lane();
-  if (ln < MAXR) S.vec[slot][ln] = (ln < R.m) ? xLane : 0.0;
+  if (ln < MAXR) vec[ln] = (ln < R.m) ? xLane : 0.0;
   w.sync();
   double v = 0.0;
 #pragma unroll
-  for (int jx = 0; jx < MAXR; jx++) v = fma(R.a(jx), S.vec[slot][jx], v);
+  for (int jx = 0; jx < MAXR; jx++) v = fma(R.a(jx), vec[jx], v);
   return v;
 }
 
 // LCPUtils::isLCPSolutionValid (LCPUtils.cpp:12-80), uniform result
 template <class W>
-DEV bool coopValid(const W& w, CoopLds& S, const CoopRow& R, double X, bool ignoreFriction, double cfm, int slot) {
+DEV bool coopValid(const W& w, double* vec, const CoopRow& R, double X, bool ignoreFriction, double cfm) {
   const double tol = 1e-5;
   const int ln = w.lane();
-  const double v = -R.Bv + cfm * X + coopAx(w, S, R, X, slot);
+  const double v = -R.Bv + cfm * X + coopAx(w, vec, R, X);
   const double Xn = w.shfl(X, R.fp);
   bool ok = true;
   if (ln < R.m) {
@@ -282,6 +282,10 @@ DEV bool coopValid(const W& w, CoopLds& S, const CoopRow& R, double X, bool igno
     }
   }
   return w.ballot(!ok) == 0ull;
+}
+template <class W>
+DEV bool coopValid(const W& w, CoopLds& S, const CoopRow& R, double X, bool ignoreFriction, double cfm, int slot) {
+  return coopValid(w, S.vec[slot], R, X, ignoreFriction, cfm);
 }
 
 struct CoopClasses {

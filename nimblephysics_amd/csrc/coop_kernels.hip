@@ -100,18 +100,57 @@ __global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, cons
   }
 }
 
-// Stages 1-3 of the cascade for the worlds stage 0 could not resolve: one WAVEFRONT per failed world (compacted list).
-// k_contact_cascade does the same one world per lane; there ONE unresolved world costs 4-7 ms (a single dependent
-// instruction stream with a fresh LDL^T per pivot), here the wave shares the factorisations and products.
-__global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
-                                                             double* __restrict__ saved, SavedLayout lay,
-                                                             double* __restrict__ cacheOut, double* __restrict__ next,
-                                                             uint32_t* __restrict__ status, double* __restrict__ lws,
-                                                             const int32_t* __restrict__ failList,
-                                                             const uint32_t* __restrict__ failCount) {
-  __shared__ CoopLds S;
-  __shared__ CascadeLds C;
+// Stages 1-3 of the cascade for the worlds stage 0 could not resolve (compacted list): one WORKGROUP OF THREE WAVEFRONTS per
+// failed world, wavefront s runs stage s + 1 (reduce + Dantzig | CFM + reduce + PGS | friction dropped + PGS) - the stages only
+// share their inputs, see coop_dantzig_dev.hpp - and leaves its candidate solution and flags in the world's scratch rows;
+// k_contact_cascade_final picks one in the reference's order of preference and standardises it.  The wavefronts of a group never
+// wait for each other (DevWaveInGroup::sync is a wave-level fence, not a workgroup barrier).
+constexpr int LW_STAGE_X = LW_JB;                 // 3 x MAX_ROWS candidate solutions
+constexpr int LW_STAGE_FLAGS = LW_JB + 3 * MAX_ROWS;   // 3 flag words (as doubles)
+constexpr int LW_STAGE_CYCLES = LW_STAGE_FLAGS + 3;    // NBL_CASCADE_TIMING: cycles of the three stage waves and of the final kernel
+static_assert(LW_STAGE_CYCLES + 4 <= LW_TOTAL, "stage results must fit the contact scratch rows");
+
+__global__ __launch_bounds__(192) void k_contact_cascade_stages(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                               double* __restrict__ saved, SavedLayout lay,
+                                                               double* __restrict__ lws, const int32_t* __restrict__ failList,
+                                                               const uint32_t* __restrict__ failCount) {
+  __shared__ CascadeLds C1;
+  __shared__ PgsLds C2, C3;
   if (blockIdx.x >= *failCount) return;
+#ifdef NBL_CASCADE_TIMING
+  const long long t0 = clock64();
+#endif
+  const DevWaveInGroup w;
+  const int ln = w.lane();
+  const int stage = (int)(threadIdx.x >> 6);
+  const int64_t b = failList[blockIdx.x];
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  double* dn = denseOf(saved, lay, B, b);
+  CoopRow R;
+  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
+  CoopStageResult r;
+  if (stage == 0) coopCascadeStage1(w, C1, R, X0, r);
+  else if (stage == 1) coopCascadeStage2(w, C2, R, X0, cm->fallbackCfm, r);
+  else coopCascadeStage3(w, C3, R, X0, cm->fallbackCfm, r);
+  if (ln < MAX_ROWS) lws[(int64_t)(LW_STAGE_X + stage * MAX_ROWS + ln) * B + b] = r.X;
+  if (ln == 0) lws[(int64_t)(LW_STAGE_FLAGS + stage) * B + b] = (double)r.flags;
+#ifdef NBL_CASCADE_TIMING
+  if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + stage) * B + b] = (double)(clock64() - t0);
+#endif
+}
+
+__global__ __launch_bounds__(64) void k_contact_cascade_final(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                              double* __restrict__ saved, SavedLayout lay,
+                                                              double* __restrict__ cacheOut, double* __restrict__ next,
+                                                              uint32_t* __restrict__ status, double* __restrict__ lws,
+                                                              const int32_t* __restrict__ failList,
+                                                              const uint32_t* __restrict__ failCount) {
+  __shared__ CoopLds S;
+  if (blockIdx.x >= *failCount) return;
+#ifdef NBL_CASCADE_TIMING
+  const long long t0 = clock64();
+#endif
   const DevWave w;
   const int ln = w.lane();
   const int64_t b = failList[blockIdx.x];
@@ -119,11 +158,20 @@ __global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   double* nv = next + (int64_t)n * B;
   double* dn = denseOf(saved, lay, B, b);
+  const int row = ln < MAX_ROWS ? ln : 0;
+  CoopStageResult r1, r2, r3;
+  r1.X = lws[(int64_t)(LW_STAGE_X + row) * B + b];
+  r2.X = lws[(int64_t)(LW_STAGE_X + MAX_ROWS + row) * B + b];
+  r3.X = lws[(int64_t)(LW_STAGE_X + 2 * MAX_ROWS + row) * B + b];
+  r1.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 0) * B + b];
+  r2.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 1) * B + b];
+  r3.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 2) * B + b];
+  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
+  if (ln >= m) { r1.X = 0.0; r2.X = 0.0; r3.X = 0.0; }
   CoopRow R;
   coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
-  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
   CoopCascadeOut out;
-  coopCascade(w, S, C, R, X0, cm->fallbackCfm, out);
+  coopCascadeSelect(w, S, R, X0, cm->fallbackCfm, r1, r2, r3, out);
   // The record always carries Q^+ of the final classification when there is a clamping row, so that the backward pass never
   // has to factorise (its fallback cost k_bwd_contact_a_coop half its occupancy).  Stages that end without one (PGS results
   // accepted as they are) pay for it here, on the few worlds that reach this kernel.
@@ -137,8 +185,7 @@ __global__ __launch_bounds__(64) void k_contact_cascade_coop(DevModel mdl, const
   coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
   if (ln == 0 && status) status[b] |= out.st;
 #ifdef NBL_CASCADE_TIMING
-  if (ln == 0) for (int k = 0; k < 7; k++) lws[(int64_t)(LW_JB + k) * B + b] = (double)(out.t[k] - out.t[0]);   // debug: cycle stamps
-  if (ln == 0) lws[(int64_t)(LW_JB + 7) * B + b] = (double)(clock64() - out.t[0]);
+  if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
 #endif
 }
 

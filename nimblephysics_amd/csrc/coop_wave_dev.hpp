@@ -36,6 +36,16 @@ struct DevWave {
   }
 };
 
+// The same primitives for kernels whose workgroups hold SEVERAL independent wavefronts (k_contact_cascade_stages: one stage per
+// wavefront): "sync" orders the wave's own LDS traffic (a wave's LDS instructions execute in order; the fence only stops the
+// compiler from moving accesses across it) and never waits for the other wavefronts of the group.
+struct DevWaveInGroup : DevWave {
+  DEV void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
 // workgroup -> world: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous range of worlds
 // (neighbouring worlds share the cache lines of the lane-interleaved rows of the saved record, which then meet in one L2)
 DEV int64_t coopWorld(uint32_t bid, uint32_t nblk) {

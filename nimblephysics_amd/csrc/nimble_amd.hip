@@ -36,11 +36,11 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int NBL_MAX_SLICES = 8;
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
                                            "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop", "k_step_forward_coop", "k_bwd_recompute_coop",
-                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_coop"};
+                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -504,10 +504,12 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       else
         TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, ldsBytes, s, mdl, m->dContact, B, (double*)saved,
                                           m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws, failList, failCount));
-      if (m->coop && m->coopCascade)
-        TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
-                                                 (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
-      else
+      if (m->coop && m->coopCascade) {
+        TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_stages, dim3((unsigned)cnt), dim3(192), 0, s, mdl, m->dContact, B,
+                                                 (double*)saved, m->lay, lws, failList, failCount));
+        TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(k_contact_cascade_final, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+                                                  (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+      } else
         TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, mdl, m->dContact, B,
                                             (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
     }
@@ -715,6 +717,15 @@ int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, cons
   if (e != hipSuccess) return fail(NBL_E_HIP, std::string("nbl_selftest_lcp_dantzig: ") + hipGetErrorString(e));
   return NBL_OK;
 }
+
+#ifdef NBL_CASCADE_TIMING
+int32_t nbl_debug_dantzig_stats(unsigned long long* out16, int32_t reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dzStat), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dzStat), z, sizeof(z))); }
+  return NBL_OK;
+}
+#endif
 
 #ifdef NBL_PHASE_TIMING
 int32_t nbl_debug_phase_stamps(unsigned long long* out64) {

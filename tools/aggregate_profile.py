@@ -1,12 +1,15 @@
 """Aggregate the rocprofv3 outputs of tools/profile.sh (merged back under gpurun_out/prof/) into profiles/:
    profiles/<tag>_kernel_stats_<workload>.csv   (copy of the --stats kernel summary)
    profiles/pmc_traffic.json                    (per-kernel HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) kB x 1024)
-usage: python tools/aggregate_profile.py <tag> <workload>"""
+   profiles/fp64_flops.json                     (fp64 flop per world-step COUNTED by the SQ instruction counters, pass `fp64`)
+   profiles/<tag>_wave_cycles.json              (issue / wait split of the wave cycles, pass `wait`)
+usage: python tools/aggregate_profile.py <tag> <workload>[@noise] [worlds per launch = 1024]"""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, workload = sys.argv[1], sys.argv[2]
+WPL = int(sys.argv[3]) if len(sys.argv) > 3 else 1024   # worlds covered by one kernel launch of the profiled bench
 P = os.path.join(ROOT, "gpurun_out", "prof")
 
 
@@ -18,7 +21,7 @@ def find(sub, pat):
 
 
 stats = find("stats", "*kernel_stats.csv")
-dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_{workload}.csv")
+dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_{workload.replace('@', '_noise')}.csv")
 shutil.copy(stats, dst)
 print("copied", dst)
 
@@ -66,3 +69,57 @@ try:
     print("wrote", f"profiles/{tag}_valu_utilisation.json")
 except SystemExit as e:
     print("no VALU passes:", e)
+
+
+# ---- fp64 flop count (pass `fp64`) ----
+try:
+    names = ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_MFMA_F64",
+             "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"]
+    C = {nm: counter("fp64", nm)[0] for nm in names}
+    per = {}
+    tot_flops = tot_wave_f64 = tot_mfma = 0.0
+    lanes_w = 0.0
+    for k in sorted(C["SQ_INSTS_VALU"]):
+        if not k.startswith("k_") or k == "k_transpose":
+            continue
+        fma, add, mul, tr, mf = (C[nm].get(k, 0.0) for nm in names[:5])
+        act = C["SQ_ACTIVE_INST_VALU"].get(k, 0.0)
+        # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = average active lanes per VALU instruction cycle (both in quad-cycles), max 64
+        lanes = C["SQ_THREAD_CYCLES_VALU"].get(k, 0.0) / act if act else 0.0
+        lanes = min(lanes, 64.0)
+        flops = (2 * fma + add + mul + tr) * lanes          # lane-level flop of one launch (WPL worlds)
+        per[k] = {"fma_f64": fma, "add_f64": add, "mul_f64": mul, "trans_f64": tr, "mfma_f64": mf, "valu_total": C["SQ_INSTS_VALU"].get(k, 0.0),
+                  "avg_active_lanes": round(lanes, 1), "flops_per_world": flops / WPL}
+        tot_flops += flops / WPL; tot_wave_f64 += (fma + add + mul + tr) / WPL; tot_mfma += mf / WPL
+        lanes_w += lanes * (fma + add + mul + tr)
+    ff = os.path.join(ROOT, "profiles", "fp64_flops.json")
+    fo = json.load(open(ff)) if os.path.exists(ff) else {}
+    fo["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS,MFMA}_F64 SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU (tools/profile.sh pass "
+                   "`fp64`), per launch of WPL worlds.  flop = (2 FMA + ADD + MUL + TRANS wave-instructions) x average active lanes of the kernel's VALU "
+                   "instructions (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU); summed over the kernels of one forward + one backward step.")
+    fo[workload] = {"flops_per_world_step": tot_flops, "f64_wave_instr_per_world_step": tot_wave_f64, "mfma_f64_wave_instr_per_world_step": tot_mfma,
+                    "valu_lane_utilisation": (lanes_w / (tot_wave_f64 * WPL) / 64.0) if tot_wave_f64 else None,
+                    "counted_by": f"SQ_INSTS_VALU_*_F64 x active lanes, profiles tag {tag}", "worlds_per_launch": WPL, "kernels": per}
+    json.dump(fo, open(ff, "w"), indent=1)
+    print("fp64 flop per world-step:", tot_flops, " f64 wave-instr per world-step:", tot_wave_f64, " MFMA f64:", tot_mfma)
+except SystemExit as e:
+    print("no fp64 pass:", e)
+
+# ---- wave cycles: issue vs wait (pass `wait`) ----
+try:
+    names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SALU", "SQ_INSTS_LDS"]
+    C = {nm: counter("wait", nm)[0] for nm in names}
+    wo = {}
+    for k in sorted(C["SQ_WAVE_CYCLES"]):
+        if not k.startswith("k_"):
+            continue
+        wc = C["SQ_WAVE_CYCLES"][k] or 1.0
+        wo[k] = {nm: C[nm].get(k, 0.0) for nm in names}
+        wo[k].update({"wait_any_frac": C["SQ_WAIT_ANY"].get(k, 0) / wc, "wait_inst_frac": C["SQ_WAIT_INST_ANY"].get(k, 0) / wc,
+                      "active_frac": C["SQ_ACTIVE_INST_ANY"].get(k, 0) / wc})
+    json.dump({"_note": "rocprofv3 --pmc pass `wait` of tools/profile.sh, per-launch averages; WAIT_ANY (parked on s_waitcnt / barrier) + WAIT_INST_ANY "
+                        "(issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles)", workload: wo},
+              open(os.path.join(ROOT, "profiles", f"{tag}_wave_cycles.json"), "w"), indent=1)
+    print("wrote", f"profiles/{tag}_wave_cycles.json")
+except SystemExit as e:
+    print("no wait pass:", e)

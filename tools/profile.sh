@@ -4,7 +4,7 @@
 #   usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---steps 8 --warmup 2 --no-cpu-baseline}
+ARGS=${*:---steps 8 --warmup 2 --no-cpu-baseline --easy-noise 0}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
@@ -15,5 +15,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_wri
 # VALU issue / lane utilisation / occupancy (SQ block: own passes)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_valu -- python $REPO/bench.py $ARGS > $OUT/${TAG}_valu.log 2>&1
 rocprofv3 --pmc VALUUtilization VALUBusy MeanOccupancyPerCU --kernel-trace --output-format csv -d $OUT/${TAG}_util -- python $REPO/bench.py $ARGS > $OUT/${TAG}_util.log 2>&1
-find $OUT -name "*.csv" | head -30
+# fp64 flop count (SQ instruction counters by type; lanes active from SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) and MFMA use
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/${TAG}_fp64 -- python $REPO/bench.py $ARGS > $OUT/${TAG}_fp64.log 2>&1
+# where a wave's cycles go: issue vs wait
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/${TAG}_wait -- python $REPO/bench.py $ARGS > $OUT/${TAG}_wait.log 2>&1
+find $OUT -name "*.csv" | head -40
 tail -1 $OUT/${TAG}_stats.log | cut -c1-300
