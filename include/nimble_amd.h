@@ -58,8 +58,8 @@ extern "C" {
 #define NBL_ST_NAN 0x40u          /* non-finite value seen */
 #define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts than max_contacts; extra ones dropped */
 #define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
-#define NBL_ST_GRAD_PARTIAL 0x200u /* an EDGE_EDGE contact is present: its contact-geometry gradient terms
-                                      (DCC.cpp:397-424, 700-735) are not evaluated by the device backward yet */
+#define NBL_ST_GRAD_PARTIAL 0x200u /* reserved (never set: the EDGE_EDGE contact-geometry gradient terms, DCC.cpp:397-424,
+                                      700-735, are evaluated by the device backward) */
 
 /*
  * Model description.  One model is shared by all B worlds of a batch; worlds differ only in
@@ -193,6 +193,12 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
  *                        2078-2081); this is the closed form (csrc/inertia_backward.hip).
  */
 int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const double* com, const double* inertia);
+/* The same for `count` bodies at once (host pointers: bodies[count], mass[count], com[count][3], inertia[count][6]) as ONE
+ * stream-ordered copy on `stream`: launches issued on that stream afterwards see the new constants; no device synchronisation
+ * and the calling thread's current device is left as it was.  A backward pass reads the model's CURRENT constants: run the
+ * backward of a step before changing the masses for the next one. */
+int32_t nbl_set_body_inertias(nbl_model* m, int32_t count, const int32_t* bodies, const double* mass, const double* com,
+                              const double* inertia, void* stream);
 int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG);
 int32_t nbl_num_inertia_params(const nbl_model* m);
 int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double* grad_params, int32_t accumulate,

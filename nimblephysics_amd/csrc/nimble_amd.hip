@@ -83,6 +83,9 @@ struct nbl_model {
   std::vector<DevBody> hBodies;      // host copy of the body constants (nbl_set_body_inertia patches one entry)
   DevInertiaParam* dParams = nullptr; // registered inertia parameters (nbl_set_inertia_params)
   int nParams = 0;
+  void* staging = nullptr;           // pinned host staging area of the stream-ordered uploads (nbl_set_body_inertias)
+  size_t stagingBytes = 0;
+  hipEvent_t staged = nullptr;       // recorded after the last upload that reads the staging area
   std::vector<TimedLaunch> pending;
   double fwdMs = 0, bwdMs = 0;
   int64_t fwdCount = 0, bwdCount = 0;
@@ -411,6 +414,8 @@ void nbl_model_destroy(nbl_model* m) {
   if (m->dDofs) hipFree(m->dDofs);
   if (m->dContact) hipFree(m->dContact);
   if (m->dParams) hipFree(m->dParams);
+  if (m->staging) hipHostFree(m->staging);
+  if (m->staged) hipEventDestroy(m->staged);
   delete m;
 }
 
@@ -631,36 +636,87 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
 }
 
 // ---- inertia ("mass") parameters: World::setMasses / lossWrtMass (World.cpp:1821-1824, BackpropSnapshot.cpp:167-179) ----
+namespace {
+// keeps the calling thread's current device across an entry point that has to work on the model's device
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+// pinned staging area of a model (stream-ordered uploads read from it; `staged` marks the last upload still reading it)
+int32_t ensureStaging(nbl_model* m, size_t bytes) {
+  if (m->stagingBytes >= bytes) return NBL_OK;
+  if (m->staging) { HIP_TRY(hipEventSynchronize(m->staged)); HIP_TRY(hipHostFree(m->staging)); m->staging = nullptr; m->stagingBytes = 0; }
+  HIP_TRY(hipHostMalloc(&m->staging, bytes, hipHostMallocDefault));
+  m->stagingBytes = bytes;
+  if (!m->staged) HIP_TRY(hipEventCreateWithFlags(&m->staged, hipEventDisableTiming));
+  return NBL_OK;
+}
+}  // namespace
+
+// Replaces the inertial constants of `count` bodies with ONE stream-ordered copy on `stream`: launches issued on that stream
+// afterwards see the new values, launches issued before it the old ones; no device synchronisation.
+int32_t nbl_set_body_inertias(nbl_model* m, int32_t count, const int32_t* bodies, const double* mass, const double* com,
+                              const double* inertia, void* stream) {
+  if (!m || count < 0 || (count > 0 && (!bodies || !mass || !com || !inertia))) return fail(NBL_E_BADARG, "bad argument");
+  if (count == 0) return NBL_OK;
+  for (int i = 0; i < count; i++) {
+    if (bodies[i] < 0 || bodies[i] >= m->nb) return fail(NBL_E_BADARG, "body index out of range");
+    if (!(mass[i] > 0)) return fail(NBL_E_BADARG, "mass must be positive");
+  }
+  DeviceGuard guard(m->device);
+  if (!guard.ok) return fail(NBL_E_HIP, "hipSetDevice failed");
+  const size_t bytes = sizeof(DevBody) * (size_t)m->nb;
+  const int32_t rc = ensureStaging(m, bytes + sizeof(DevInertiaParam) * 64);
+  if (rc != NBL_OK) return rc;
+  HIP_TRY(hipEventSynchronize(m->staged));   // the previous upload has finished reading the staging area (normally long ago)
+  for (int i = 0; i < count; i++) packSpatialInertia(mass[i], com + 3 * i, inertia + 6 * i, m->hBodies[bodies[i]].G);
+  std::memcpy(m->staging, m->hBodies.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(m->dBodies, m->staging, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipEventRecord(m->staged, (hipStream_t)stream));
+  return NBL_OK;
+}
+
 int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const double* com, const double* inertia) {
   if (!m || !com || !inertia) return fail(NBL_E_BADARG, "null argument");
-  if (body < 0 || body >= m->nb) return fail(NBL_E_BADARG, "body index out of range");
-  if (!(mass > 0)) return fail(NBL_E_BADARG, "mass must be positive");
-  packSpatialInertia(mass, com, inertia, m->hBodies[body].G);
-  HIP_TRY(hipSetDevice(m->device));
-  HIP_TRY(hipDeviceSynchronize());   // no launch in flight may see a half-written body
-  HIP_TRY(hipMemcpy(m->dBodies + body, &m->hBodies[body], sizeof(DevBody), hipMemcpyHostToDevice));
+  DeviceGuard guard(m->device);
+  HIP_TRY(hipDeviceSynchronize());   // this entry point keeps its documented semantics: no launch in flight sees a half-written body
+  const int32_t rc = nbl_set_body_inertias(m, 1, &body, &mass, com, inertia, nullptr);
+  if (rc != NBL_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return NBL_OK;
 }
 
 int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG) {
   if (!m || count < 0 || (count > 0 && (!bodies || !dG))) return fail(NBL_E_BADARG, "bad argument");
-  HIP_TRY(hipSetDevice(m->device));
-  HIP_TRY(hipDeviceSynchronize());
-  if (m->dParams) { hipFree(m->dParams); m->dParams = nullptr; }
-  m->nParams = 0;
-  if (count == 0) return NBL_OK;
+  for (int p = 0; p < count; p++)
+    if (bodies[p] < 0 || bodies[p] >= m->nb) return fail(NBL_E_BADARG, "inertia parameter on an unknown body");
+  DeviceGuard guard(m->device);
+  if (!guard.ok) return fail(NBL_E_HIP, "hipSetDevice failed");
   std::vector<DevInertiaParam> hp(count);
   for (int p = 0; p < count; p++) {
-    if (bodies[p] < 0 || bodies[p] >= m->nb) return fail(NBL_E_BADARG, "inertia parameter on an unknown body");
     hp[p].body = bodies[p]; hp[p].pad = 0;
     const double* D = dG + 36 * (size_t)p;
     int idx = 0;
     for (int r = 0; r < 6; r++)
       for (int c = r; c < 6; c++) hp[p].dG[idx++] = 0.5 * (D[6 * r + c] + D[6 * c + r]);
   }
-  HIP_TRY(hipMalloc((void**)&m->dParams, sizeof(DevInertiaParam) * (size_t)count));
+  if (count != m->nParams) {
+    // the table changes size (registration time, not the per-step path): wait for the launches that read the old one
+    HIP_TRY(hipDeviceSynchronize());
+    if (m->dParams) { HIP_TRY(hipFree(m->dParams)); m->dParams = nullptr; }
+    m->nParams = 0;
+    if (count == 0) return NBL_OK;
+    HIP_TRY(hipMalloc((void**)&m->dParams, sizeof(DevInertiaParam) * (size_t)count));
+    HIP_TRY(hipMemcpy(m->dParams, hp.data(), sizeof(DevInertiaParam) * (size_t)count, hipMemcpyHostToDevice));
+    m->nParams = count;
+    return NBL_OK;
+  }
+  if (count == 0) return NBL_OK;
+  // same size (setMasses with new values): a blocking copy on the legacy stream orders it after the work already issued there;
+  // callers that drive other streams pass through World.setMasses, which changes the masses between steps
   HIP_TRY(hipMemcpy(m->dParams, hp.data(), sizeof(DevInertiaParam) * (size_t)count, hipMemcpyHostToDevice));
-  m->nParams = count;
   return NBL_OK;
 }
 

@@ -42,15 +42,13 @@ class World:
         self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         if self.device.type != "cuda":
             raise NimbleAmdError("World must live on a GPU device")
+        if self.device.index is None:                      # a bare "cuda": the current device, like torch does
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._L = lib()
-        desc, self._keep = self.model.to_desc()
-        h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            check(self._L.nbl_model_create(C.byref(desc), self.device.index or 0, C.byref(h)), "nbl_model_create")
-        self._h = h
-        self.n = self._L.nbl_model_num_dofs(h)
-        self.k = self._L.nbl_model_num_action(h)
-        self.m = self._L.nbl_model_lcp_rows(h)
+        self._create_handle()
+        self.n = self._L.nbl_model_num_dofs(self._h)
+        self.k = self._L.nbl_model_num_action(self._h)
+        self.m = self._L.nbl_model_lcp_rows(self._h)
         self._ws = None
         self._ws_B = 0
         self._state = None   # [2n][B]
@@ -58,11 +56,25 @@ class World:
         self.lcp_cache = None  # [m][B] hidden warm start (BoxedLcpConstraintSolver::mX)
         self.last_status = None
 
+    def _create_handle(self):
+        """(Re-)upload the model constants; an existing handle (device buffers, side streams, events) is released first."""
+        self._destroy_handle()
+        desc, self._keep = self.model.to_desc()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self._L.nbl_model_create(C.byref(desc), self.device.index, C.byref(h)), "nbl_model_create")
+        self._h = h
+        self._uploaded_inertia = [(float(b.mass), tuple(float(x) for x in b.com), tuple(float(x) for x in b.inertia)) for b in self.model.bodies]
+
+    def _destroy_handle(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)            # nothing in flight may still read the model buffers
+            self._L.nbl_model_destroy(self._h)
+            self._h = None
+
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                self._L.nbl_model_destroy(self._h)
-                self._h = None
+            self._destroy_handle()
         except Exception:
             pass
 
@@ -92,11 +104,10 @@ class World:
     def setActionSpace(self, mapping: Sequence[int]):
         self.model.set_action_space(mapping)
         self.description.set_action_space(mapping)
-        entries = list(self._wrt_mass.entries)
-        self.__init__(self.description, self.device)  # re-upload constants
-        for e in entries:                              # the registered mass parameters survive the re-upload
-            self._wrt_mass.registerNode(e.body, e.type, e.upper, e.lower)
-        if entries:
+        self._create_handle()                              # re-upload the constants (the old handle is destroyed, not leaked)
+        self.k = self._L.nbl_model_num_action(self._h)
+        self._action = None
+        if self._wrt_mass.entries:                         # the registered mass parameters survive the re-upload
             self._push_inertia_params()
 
     def removeDofFromActionSpace(self, index: int):
@@ -163,6 +174,13 @@ class World:
         saved = None
         if want_saved:
             saved = torch.empty(self._L.nbl_saved_bytes(self._h, B), dtype=torch.uint8, device=self.device)
+        elif self.m > 0:
+            # models with colliders use the record as their contact scratch even when no backward pass is wanted (World.step):
+            # one reusable buffer per World
+            need = self._L.nbl_saved_bytes(self._h, B)
+            if getattr(self, "_scratch_saved", None) is None or self._scratch_saved.numel() < need:
+                self._scratch_saved = torch.empty(need, dtype=torch.uint8, device=self.device)
+            saved = self._scratch_saved
         status = torch.empty(B, dtype=torch.int32, device=self.device)
         ws = self._workspace(B)
         cache_in = self.lcp_cache if (self.lcp_cache is not None and self.lcp_cache.shape == (self.m, B)) else None
@@ -172,8 +190,8 @@ class World:
         if cache_out is not None:
             self.lcp_cache = cache_out
         self.last_status = status
-        self._last_saved = saved
-        return nxt, saved, status
+        self._last_saved = saved if want_saved else None
+        return nxt, (saved if want_saved else None), status
 
     def backward_soa(self, saved: torch.Tensor, grad_next: torch.Tensor):
         """grad_next [2n][B] -> (grad_state [2n][B], grad_action [k][B])."""
@@ -207,22 +225,37 @@ class World:
         return torch.from_numpy(self._wrt_mass.lowerBound())
 
     def setMasses(self, masses):
-        """World::setMasses: writes the registered parameters into the model (host) and re-uploads the touched bodies."""
+        """World::setMasses: writes the registered parameters into the model (host) and uploads the bodies whose inertial
+        constants actually changed, in ONE stream-ordered copy on the current stream (no device synchronisation; an unchanged
+        mass vector costs nothing).  Like the reference, a backward pass reads the world's CURRENT masses: run the backward of
+        a step before changing the masses for the next one (BackpropSnapshot.cpp:142-146 restores the world's state, not its
+        masses)."""
         import numpy as np
         if isinstance(masses, torch.Tensor):
             masses = masses.detach().cpu().numpy()
         self._wrt_mass.set(np.asarray(masses, dtype=np.float64))
         new = self.description.merge_welds() if self.description.has_welds() else self.description
-        for i, (old_b, new_b) in enumerate(zip(self.model.bodies, new.bodies)):
-            if old_b.mass != new_b.mass or tuple(old_b.com) != tuple(new_b.com) or tuple(old_b.inertia) != tuple(new_b.inertia) \
-                    or new is self.model:
-                com = (C.c_double * 3)(*[float(x) for x in new_b.com])
-                ine = (C.c_double * 6)(*[float(x) for x in new_b.inertia])
-                check(self._L.nbl_set_body_inertia(self._h, i, float(new_b.mass), com, ine), "nbl_set_body_inertia")
+        changed = []
+        for i, new_b in enumerate(new.bodies):
+            cur = (float(new_b.mass), tuple(float(x) for x in new_b.com), tuple(float(x) for x in new_b.inertia))
+            if cur != self._uploaded_inertia[i]:
+                changed.append(i)
+                self._uploaded_inertia[i] = cur
+        if changed:
+            import numpy as np
+            idx = np.asarray(changed, dtype=np.int32)
+            mass = np.asarray([self._uploaded_inertia[i][0] for i in changed], dtype=np.float64)
+            com = np.asarray([self._uploaded_inertia[i][1] for i in changed], dtype=np.float64).reshape(-1, 3)
+            ine = np.asarray([self._uploaded_inertia[i][2] for i in changed], dtype=np.float64).reshape(-1, 6)
+            with torch.cuda.device(self.device):
+                check(self._L.nbl_set_body_inertias(self._h, len(changed), idx.ctypes.data_as(C.c_void_p), mass.ctypes.data_as(C.c_void_p),
+                                                    com.ctypes.data_as(C.c_void_p), ine.ctypes.data_as(C.c_void_p), self._stream()),
+                      "nbl_set_body_inertias")
         if new is not self.model:
             new._action_map = self.model._action_map
             self.model = new
-        self._push_inertia_params()
+        if changed:
+            self._push_inertia_params()
 
     def _push_inertia_params(self):
         bodies, dG = self._wrt_mass.device_table()

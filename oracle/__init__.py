@@ -53,6 +53,8 @@ def _declare(lib):
     lib.nbo_backprop.argtypes = [C.c_void_p, pd, pd, pd]
     lib.nbo_step_batch.argtypes = [C.c_void_p, C.c_int64, pd, pd, pd, pd, pd, pd, C.POINTER(C.c_uint32), C.c_int,
                                    pd, C.POINTER(C.c_int32), pd, C.POINTER(C.c_int32), C.c_int]
+    lib.nbo_state_jacobian.argtypes = [C.c_void_p, pd]
+    lib.nbo_action_jacobian.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int, pd]
     lib.nbo_set_lcp_cache.argtypes = [C.c_void_p, pd, C.c_int]
     lib.nbo_get_lcp_cache.argtypes = [C.c_void_p, pd, C.c_int]
     lib.nbo_get_lcp_cache.restype = C.c_int
@@ -134,6 +136,19 @@ class OracleWorld:
         rc = self._lib.nbo_backprop(self._h, _p(g), _p(gs), _p(ga))
         assert rc == 0
         return gs, ga
+
+    def getStateJacobian(self):
+        """World::getStateJacobian of the last step() (World.cpp:2210-2226): [2n, 2n], out[i, j] = d next[i] / d state[j]."""
+        out = np.zeros((2 * self.n, 2 * self.n))
+        assert self._lib.nbo_state_jacobian(self._h, _p(out)) == 0
+        return out
+
+    def getActionJacobian(self):
+        """World::getActionJacobian of the last step() (World.cpp:2229-2243): [2n, k]."""
+        amap = np.ascontiguousarray(self.model.action_map, dtype=np.int32)
+        out = np.zeros((2 * self.n, self.k))
+        assert self._lib.nbo_action_jacobian(self._h, amap.ctypes.data_as(C.POINTER(C.c_int32)), self.k, _p(out)) == 0
+        return out
 
     def step_batch(self, state, action, grad_next=None, threads=1, lcp_in=None, lcp_len_in=None, want_lcp=False):
         """state [B,2n], action [B,k] world-major.  Returns dict(next, grad_state, grad_action, status[, lcp, lcp_len])."""

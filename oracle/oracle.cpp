@@ -65,8 +65,10 @@ void stepWorld(Oracle& o, const s_t* q, const s_t* v, const s_t* tau, s_t* qNext
   if (status) *status = st;
 }
 
-// BackpropSnapshot::backprop (:121-194) through the dense Jacobians of §3.3 / Appendix A.6–A.7.
-void backpropWorld(Oracle& o, const s_t* gqNext, const s_t* gvNext, s_t* gq, s_t* gv, s_t* gtau) {
+// The five dense step Jacobians of the last step (BackpropSnapshot::getPosPosJacobian :1263-1335, getVelPosJacobian :1338-1400,
+// getPosVelJacobian :762-821, getVelVelJacobian :643-759, getControlForceVelJacobian :482-574; §3.3 / Appendix A.6-A.7).
+// Naming as in the reference: "XY" = d(Y at t+1) / d(X at t).
+void stepJacobians(Oracle& o, MatX& posPos, MatX& velPos, MatX& posVel, MatX& velVel, MatX& forceVel) {
   const Model& m = o.model;
   const Snapshot& s = o.snap;
   const int n = m.n;
@@ -82,10 +84,9 @@ void backpropWorld(Oracle& o, const s_t* gqNext, const s_t* gvNext, s_t* gq, s_t
   MatX dCdq = jacobianOfC(m, kin, s.q.data(), s.v.data(), false);
   MatX dCdv = jacobianOfC(m, kin, s.q.data(), s.v.data(), true);
 
-  MatX posPos, velPos;
   posJacobians(m, s.q.data(), s.v.data(), dt, posPos, velPos);  // bounce approximation = identity (restitution 0)
 
-  MatX forceVel(n, n), velVel(n, n), posVel(n, n);
+  forceVel = MatX(n, n); velVel = MatX(n, n); posVel = MatX(n, n);
   const ContactResult& cr = s.contact;
   if (cr.numClamping == 0) {
     // no clamping constraints: BackpropSnapshot.cpp:521-524, 686-689, and getVelJacobianWrt with empty A_c
@@ -109,6 +110,15 @@ void backpropWorld(Oracle& o, const s_t* gqNext, const s_t* gvNext, s_t* gq, s_t
                      velVel, posVel);
   }
 
+}
+
+// BackpropSnapshot::backprop (:121-194): the loss gradient through the dense Jacobians, then clipLossGradientsToBounds.
+void backpropWorld(Oracle& o, const s_t* gqNext, const s_t* gvNext, s_t* gq, s_t* gv, s_t* gtau) {
+  const Model& m = o.model;
+  const Snapshot& s = o.snap;
+  const int n = m.n;
+  MatX posPos, velPos, posVel, velVel, forceVel;
+  stepJacobians(o, posPos, velPos, posVel, velVel, forceVel);
   VecX gqn(gqNext, gqNext + n), gvn(gvNext, gvNext + n);
   VecX a = matTvec(posPos, gqn), b = matTvec(posVel, gvn), c = matTvec(velPos, gqn), d = matTvec(velVel, gvn),
        e = matTvec(forceVel, gvn);
@@ -183,6 +193,35 @@ int nbo_backprop(void* h, const double* gradNext, double* gradState, double* gra
 // worlds, world-major arrays [B][2n], [B][k]; each world starts from `cold` LCP cache unless
 // lcpIn/lcpLen given ([B][m] + per-world lengths).  `threads` host threads, one cloned world per thread
 // (the reference's own model: MultiShot.cpp:66-70).
+// World::getStateJacobian / getActionJacobian of the LAST step (World.cpp:2210-2243): out row-major [2n][2n] / [2n][k]
+// (the action Jacobian takes the columns of forceVel of the DOFs in the action space, actionMap[k]).
+int nbo_state_jacobian(void* h, double* out) {
+  Oracle& o = *(Oracle*)h;
+  if (!o.snap.valid) return -1;
+  const int n = o.model.n;
+  MatX posPos, velPos, posVel, velVel, forceVel;
+  stepJacobians(o, posPos, velPos, posVel, velVel, forceVel);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      out[(size_t)i * 2 * n + j] = posPos(i, j);
+      out[(size_t)i * 2 * n + n + j] = velPos(i, j);
+      out[(size_t)(n + i) * 2 * n + j] = posVel(i, j);
+      out[(size_t)(n + i) * 2 * n + n + j] = velVel(i, j);
+    }
+  return 0;
+}
+int nbo_action_jacobian(void* h, const int32_t* actionMap, int k, double* out) {
+  Oracle& o = *(Oracle*)h;
+  if (!o.snap.valid) return -1;
+  const int n = o.model.n;
+  MatX posPos, velPos, posVel, velVel, forceVel;
+  stepJacobians(o, posPos, velPos, posVel, velVel, forceVel);
+  for (int i = 0; i < 2 * n * k; i++) out[i] = 0.0;
+  for (int a = 0; a < k; a++)
+    for (int i = 0; i < n; i++) out[(size_t)(n + i) * k + a] = forceVel(i, actionMap[a]);
+  return 0;
+}
+
 int nbo_step_batch(void* h, int64_t B, const double* state, const double* action, const double* gradNext,
                    double* nextState, double* gradState, double* gradAction, uint32_t* status, int threads,
                    const double* lcpIn, const int32_t* lcpLenIn, double* lcpOut, int32_t* lcpLenOut, int lcpStride) {
