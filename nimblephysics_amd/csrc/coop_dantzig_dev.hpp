@@ -749,17 +749,14 @@ struct CoopCascadeOut {
   bool pinvValid;
 };
 
-// The reference's order of preference over the three stage results (BoxedLcpConstraintSolver.cpp:461-687), then registration,
-// classification and standardisation of the chosen solution (:718-736).  X0: the pre-solve x.
+// The reference's order of preference over the three stage results (BoxedLcpConstraintSolver.cpp:461-687).  X0: the pre-solve x.
 template <class W>
-DEV void coopCascadeSelect(const W& w, CoopLds& S, const CoopRow& R, double X0, double fallbackCfm, const CoopStageResult& r1,
-                           const CoopStageResult& r2, const CoopStageResult& r3, CoopCascadeOut& out) {
+DEV void coopCascadeChoose(const W& w, int m, double X0, double fallbackCfm, const CoopStageResult& r1, const CoopStageResult& r2,
+                           const CoopStageResult& r3, double& X, double& cfm, bool& ignoreFriction, uint32_t& st) {
   const int ln = w.lane();
-  const int m = R.m;
   auto hasNan = [&](double x) -> bool { return w.ballot(ln < m && x != x) != 0ull; };
-  uint32_t st = 0;
-  bool success = false, ignoreFriction = false;
-  double cfm = 0.0, X = X0;
+  bool success = false;
+  st = 0; ignoreFriction = false; cfm = 0.0; X = X0;
   if (r1.flags & CS_SOLVED) {
     X = r1.X;
     success = (r1.flags & CS_VALID) != 0;
@@ -781,7 +778,16 @@ DEV void coopCascadeSelect(const W& w, CoopLds& S, const CoopRow& R, double X0, 
     if (!(r3.flags & CS_SOLVED)) st |= 0x20u;
   }
   if (hasNan(X)) { X = 0.0; st |= 0x40u; }
-  // ---- register the fresh solution, classify, standardise (:718-736) ----
+}
+
+// ... then registration, classification and standardisation of the chosen solution (:718-736)
+template <class W>
+DEV void coopCascadeSelect(const W& w, CoopLds& S, const CoopRow& R, double X0, double fallbackCfm, const CoopStageResult& r1,
+                           const CoopStageResult& r2, const CoopStageResult& r3, CoopCascadeOut& out) {
+  double X, cfm;
+  bool ignoreFriction;
+  uint32_t st;
+  coopCascadeChoose(w, R.m, X0, fallbackCfm, r1, r2, r3, X, cfm, ignoreFriction, st);
   bool pinvValid = false;
   const bool std = coopStandardizeLoop(w, S, R, X, cfm, ignoreFriction, 0u, pinvValid, out.K);
   if (std) st |= 0x100u;

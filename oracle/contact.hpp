@@ -196,6 +196,70 @@ struct Cggm {
   }
 };
 
+// Stages 1-3 of BoxedLcpConstraintSolver::solveLcp (:461-687) on a boxed LCP given as plain arrays: reduce + Dantzig with early
+// termination -> (on failure) CFM on the diagonal + reduce + PGS from the pre-solve x -> (on failure) friction dropped + PGS from
+// zero, with the reference's validity checks between the stages.  xBackup: the pre-solve x (mXBackup).  Out: X, the CFM that
+// ended up on the diagonal (0 when stage 1 succeeded), whether friction was dropped, NBL_ST_* bits.
+inline void lcpCascade(const MatX& A, const VecX& b, const VecX& lo, const VecX& hi, const std::vector<int>& findex, const VecX& xBackup,
+                       s_t fallbackCfm, VecX& X, s_t& cfm, bool& hadToIgnoreFriction, uint32_t& status) {
+  const int mrows = (int)b.size();
+  bool success = false;
+  cfm = 0.0; hadToIgnoreFriction = false; status = 0;
+  X = xBackup;
+  // ---- stage 1: reduce + Dantzig with early termination (:461-522) ----
+  {
+    LcpProblem p;
+    p.A = A; p.x = X; p.b = b; p.hi = hi; p.lo = lo; p.findex = findex;
+    MatX mapOut = reduceLcp(p);
+    int ok = dantzigSolve(p, true);
+    if (ok == 1) {
+      VecX xr = matvec(mapOut, p.x);
+      X = xr;
+      success = isLCPSolutionValid(A, X, b, hi, lo, findex, false);
+      if (success) status |= NBL_ST_LCP_PIVOT;
+    } else if (ok == -1) {
+      // oracle/_ref not available: behave as a Dantzig failure (goes on to the PGS fallback) and say so
+      status |= 0x80000000u;
+    }  // on failure mX keeps its pre-solve value (:489 `if (success) mX = mapOut * mXReduced`)
+  }
+  bool nan = false;
+  for (s_t v : X) if (std::isnan(v)) nan = true;
+  if (nan) { success = false; X.assign(mrows, 0.0); status |= NBL_ST_NAN; }
+
+  MatX ABackup = A;
+  if (!success) {
+    cfm = fallbackCfm;
+    for (int i = 0; i < mrows; i++) ABackup(i, i) += cfm;
+  }
+  // ---- stage 2: CFM + PGS (:539-597) ----
+  if (!success) {
+    LcpProblem p;
+    p.A = ABackup; p.x = xBackup; p.b = b; p.hi = hi; p.lo = lo; p.findex = findex;
+    MatX mapOut = reduceLcp(p);
+    success = pgsSolve(p);
+    if (success) {
+      X = matvec(mapOut, p.x);
+      if (!isLCPSolutionValid(ABackup, X, b, hi, lo, findex, false)) success = false;
+      else status |= NBL_ST_LCP_PGS;
+    }
+  }
+  // ---- stage 3: drop friction, PGS again (:606-677) ----
+  if (!success) {
+    hadToIgnoreFriction = true;
+    LcpProblem p;
+    p.A = ABackup; p.x = xBackup; p.b = b; p.hi = hi; p.lo = lo; p.findex = findex;
+    MatX mapOut = removeFrictionLcp(p);
+    p.x.assign(p.x.size(), 0.0);
+    success = pgsSolve(p);
+    X = matvec(mapOut, p.x);
+    status |= NBL_ST_LCP_NOFRIC;
+    if (!success) status |= NBL_ST_LCP_FAILED;
+  }
+  nan = false;
+  for (s_t v : X) if (std::isnan(v)) nan = true;
+  if (nan) { X.assign(mrows, 0.0); status |= NBL_ST_NAN; }
+}
+
 inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art, const s_t* q,
                           const s_t* vPre, VecX& lcpCache, ContactResult& out, s_t* vOut, uint32_t* status) {
   out = ContactResult();
@@ -342,58 +406,13 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   bool hadToIgnoreFriction = false;
   if (success) { X = g.X; *status |= NBL_ST_LCP_STAGE0; }
 
-  // ---- stage 1: reduce + Dantzig with early termination (:461-522) ----
+  // ---- stages 1-3 (:461-687) ----
   if (!success) {
-    LcpProblem p;
-    p.A = out.A; p.x = X; p.b = out.b; p.hi = out.hi; p.lo = out.lo; p.findex = out.findex;
-    MatX mapOut = reduceLcp(p);
-    int ok = dantzigSolve(p, true);
-    if (ok == 1) {
-      VecX xr = matvec(mapOut, p.x);
-      X = xr;
-      success = isLCPSolutionValid(aGrad, X, out.b, out.hi, out.lo, out.findex, false);
-      if (success) *status |= NBL_ST_LCP_PIVOT;
-    } else if (ok == -1) {
-      // oracle/_ref not available: behave as a Dantzig failure (goes on to the PGS fallback) and say so
-      *status |= 0x80000000u;
-    }  // on failure mX keeps its pre-solve value (:489 `if (success) mX = mapOut * mXReduced`)
+    uint32_t st13 = 0;
+    lcpCascade(out.A, out.b, out.lo, out.hi, out.findex, XBackup, m.fallbackCfm, X, cfm, hadToIgnoreFriction, st13);
+    *status |= st13;
+    if (cfm != 0.0) for (int i = 0; i < mrows; i++) aGrad(i, i) += cfm;
   }
-  bool nan = false;
-  for (s_t v : X) if (std::isnan(v)) nan = true;
-  if (nan) { success = false; X.assign(mrows, 0.0); *status |= NBL_ST_NAN; }
-
-  MatX ABackup = out.A;
-  if (!success) {
-    cfm = m.fallbackCfm;
-    for (int i = 0; i < mrows; i++) { ABackup(i, i) += cfm; aGrad(i, i) += cfm; }
-  }
-  // ---- stage 2: CFM + PGS (:539-597) ----
-  if (!success) {
-    LcpProblem p;
-    p.A = ABackup; p.x = XBackup; p.b = out.b; p.hi = out.hi; p.lo = out.lo; p.findex = out.findex;
-    MatX mapOut = reduceLcp(p);
-    success = pgsSolve(p);
-    if (success) {
-      X = matvec(mapOut, p.x);
-      if (!isLCPSolutionValid(aGrad, X, out.b, out.hi, out.lo, out.findex, false)) success = false;
-      else *status |= NBL_ST_LCP_PGS;
-    }
-  }
-  // ---- stage 3: drop friction, PGS again (:606-677) ----
-  if (!success) {
-    hadToIgnoreFriction = true;
-    LcpProblem p;
-    p.A = ABackup; p.x = XBackup; p.b = out.b; p.hi = out.hi; p.lo = out.lo; p.findex = out.findex;
-    MatX mapOut = removeFrictionLcp(p);
-    p.x.assign(p.x.size(), 0.0);
-    success = pgsSolve(p);
-    X = matvec(mapOut, p.x);
-    *status |= NBL_ST_LCP_NOFRIC;
-    if (!success) *status |= NBL_ST_LCP_FAILED;
-  }
-  nan = false;
-  for (s_t v : X) if (std::isnan(v)) nan = true;
-  if (nan) { X.assign(mrows, 0.0); *status |= NBL_ST_NAN; }
 
   // ---- re-register + classify + standardize with the fresh solution (:718-736) ----
   if (!shortCircuit) {

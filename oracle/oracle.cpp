@@ -405,6 +405,23 @@ int nbo_lcp_dantzig(int n, const double* A, double* x, const double* b, const do
   for (int i = 0; i < n; i++) x[i] = p.x[i];
   return ok;
 }
+// stages 1-3 of the solver cascade (contact.hpp lcpCascade) on plain arrays; returns isLCPSolutionValid of the result on the
+// matrix the solver ended with (CFM on the diagonal when a fallback stage was used), friction ignored when it was dropped
+int nbo_lcp_cascade(int n, const double* A, const double* x0, const double* b, const double* lo, const double* hi,
+                    const int32_t* findex, double fallbackCfm, double* xOut, uint32_t* statusOut, double* cfmOut) {
+  LcpProblem p = mkProblem(n, A, x0, b, lo, hi, findex);
+  VecX X;
+  s_t cfm = 0;
+  bool noFric = false;
+  uint32_t st = 0;
+  lcpCascade(p.A, p.b, p.lo, p.hi, p.findex, p.x, fallbackCfm, X, cfm, noFric, st);
+  for (int i = 0; i < n; i++) xOut[i] = X[i];
+  if (statusOut) *statusOut = st;
+  if (cfmOut) *cfmOut = cfm;
+  MatX Ac = p.A;
+  for (int i = 0; i < n; i++) Ac(i, i) += cfm;
+  return isLCPSolutionValid(Ac, X, p.b, p.hi, p.lo, p.findex, noFric) ? 1 : 0;
+}
 // reduce / removeFriction: returns reduced size; outputs reduced problem and mapOut [n][nr]
 int nbo_lcp_reduce(int n, const double* A, const double* x, const double* b, const double* lo, const double* hi,
                    const int32_t* findex, int removeFriction, double* Ar, double* xr, double* br, double* lor, double* hir,

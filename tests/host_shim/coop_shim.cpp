@@ -122,4 +122,31 @@ int shim_coop_reduce(int n, const double* A, const double* x, const double* b, c
   for (int i = 0; i < nr; i++) for (int j = 0; j < nr; j++) Ar[i * nr + j] = C.A[i * CLD + j];
   return nr;
 }
+
+// stages 1-3 of the solver cascade exactly as k_contact_cascade_stages / _final run them (three independent stage functions, then
+// the reference's order of preference), on one problem: A 24 x 24 row-major (m x m used), b[24], mu[8], x0[24] = the pre-solve x.
+// Outputs the chosen x (before standardisation), the NBL_ST_* bits and the CFM the solver ended with.
+int shim_coop_cascade(int m, const double* A, const double* b, const double* mu, const double* x0, double fallbackCfm, double* X,
+                      double* cfmOut) {
+  static CascadeLds C1;
+  static PgsLds C2, C3;
+  uint32_t stOut = 0;
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopRow R;
+    fillRow(R, ln, m, A, b, mu);
+    const double X0 = ln < m ? x0[ln] : 0.0;
+    CoopStageResult r1, r2, r3;
+    coopCascadeStage1(w, C1, R, X0, r1);
+    coopCascadeStage2(w, C2, R, X0, fallbackCfm, r2);
+    coopCascadeStage3(w, C3, R, X0, fallbackCfm, r3);
+    double x, cfm;
+    bool noFric;
+    uint32_t st;
+    coopCascadeChoose(w, m, X0, fallbackCfm, r1, r2, r3, x, cfm, noFric, st);
+    if (ln < MAXR) X[ln] = x;
+    if (ln == 0) { stOut = st; *cfmOut = cfm; }
+  });
+  return (int)stOut;
+}
 }
