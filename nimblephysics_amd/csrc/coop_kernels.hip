@@ -19,6 +19,7 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
     const int r0 = lay.contacts + (ln / 3) * CR_SIZE;
     const double muA = cm->boxes[(int)saved[(int64_t)(r0 + CR_BOXA) * B + b]].mu, muB = cm->boxes[(int)saved[(int64_t)(r0 + CR_BOXB) * B + b]].mu;
     R.mu = muA < muB ? muA : muB;
+    if (!(R.mu > 1e-3)) R.mu = 0.0;   // frictionless contact: its tangent rows are empty (k_contact_rows_coop) and pinned to 0
     R.Bv = saved[(int64_t)(lay.b + ln) * B + b];
   }
   R.on = on;
@@ -488,7 +489,14 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   // ---- this row's wrench and the two bodies it acts on ----
   V3 t1, t2;
   tangentBasis(nrm, t1, t2);
-  const V3 dir = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
+  // A frictionless contact (mu = min(mu_A, mu_B) <= DART_FRICTION_COEFF_THRESHOLD = 1e-3) has ONE row in the reference
+  // (ContactConstraint.cpp:107-118, 229: mIsFrictionOn false -> dim 1).  Here it keeps its three row slots and the two tangent
+  // rows are EMPTY: zero wrench -> zero row / column of A, b = 0, zero A_c column, bounds 0.  Every stage leaves such rows at
+  // x = 0 and they add exact zeros to the sums of the other rows, so the result equals the reference's one-row problem.
+  // (rows beyond the contacts in use read stale record slots: clamp the collider indices before using them as addresses)
+  const double muRow = fmin(cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].mu, cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].mu);
+  const V3 dirOn = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
+  const V3 dir = (kk != 0 && !(muRow > 1e-3)) ? mk3(0.0, 0.0, 0.0) : dirOn;
   const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p (on A; -F on B)
   const int bA = w.shflI(myBoxBody, bxA), bB = w.shflI(myBoxBody, bxB);
   const int ancLoA = w.shflI((int)(uint32_t)myAnc, bA), ancHiA = w.shflI((int)(uint32_t)(myAnc >> 32), bA);

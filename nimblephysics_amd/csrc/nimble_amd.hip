@@ -282,7 +282,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       if (bx.shape != NBL_SHAPE_BOX && bx.shape != NBL_SHAPE_SPHERE) return fail(NBL_E_UNSUPPORTED, "collider shape outside the device path (box, sphere)");
       for (int k = 0; k < 3; k++) bx.half[k] = bx.shape == NBL_SHAPE_SPHERE ? d->box_size[3 * i] : 0.5 * d->box_size[3 * i + k];   // sphere: radius
       bx.mu = d->box_mu[i];
-      if (!(bx.mu > 1e-3)) return fail(NBL_E_UNSUPPORTED, "frictionless colliders (mu <= 1e-3) are outside the device path");
+      if (!(bx.mu >= 0.0)) return fail(NBL_E_BADARG, "negative friction coefficient");   // mu <= 1e-3: frictionless contacts (one live row)
     }
     for (int i = 0; i + 1 < d->n_boxes; i++)
       for (int j = i + 1; j < d->n_boxes; j++) {

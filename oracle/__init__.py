@@ -27,7 +27,7 @@ def build(force: bool = False, native: bool = False, out: str = None) -> str:
     flags = ["-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
     if native:
         flags.append("-march=native")
-    subprocess.check_call(["g++", *flags, "-o", out, os.path.join(_HERE, "oracle.cpp"), "-lpthread", "-ldl"])
+    subprocess.check_call(["g++", *flags, "-Wl,-Bsymbolic", "-o", out, os.path.join(_HERE, "oracle.cpp"), "-lpthread", "-ldl"])
     return out
 
 

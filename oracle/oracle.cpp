@@ -14,8 +14,51 @@
 // sources (oracle/_ref).  Where neither exists DESIGN.md says "parity unpinned".
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <new>
 #include <thread>
+
+// ---- per-thread bump arena for the timed batch path ---------------------------------------------------------------------
+// The restatement allocates dozens of small std::vector / MatX temporaries per world-step; with one cloned world per host
+// thread (the reference's own concurrency model, MultiShot.cpp:66-70) on a 256-thread box the allocator, not the arithmetic,
+// bounded the contact path (11x speed-up on 256 threads against 49x without contacts).  Inside nbo_step_batch every worker
+// thread serves `operator new` from a private arena that is rewound after each world-step; everything else (and every other
+// thread) falls through to malloc.  The library is linked with -Bsymbolic so that only ITS allocations come here.
+namespace {
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool active = false;
+};
+thread_local Arena* tlArena = nullptr;
+inline void* arenaAlloc(size_t n) {
+  Arena* a = tlArena;
+  if (a && a->active) {
+    n = (n + 15) & ~(size_t)15;
+    if (a->off + n <= a->cap) {
+      void* p = a->base + a->off;
+      a->off += n;
+      return p;
+    }
+  }
+  void* p = std::malloc(n ? n : 1);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+inline void arenaFree(void* p) noexcept {
+  Arena* a = tlArena;
+  if (a && p >= (void*)a->base && p < (void*)(a->base + a->cap)) return;   // rewound wholesale after the world-step
+  std::free(p);
+}
+}  // namespace
+void* operator new(size_t n) { return arenaAlloc(n); }
+void* operator new[](size_t n) { return arenaAlloc(n); }
+void operator delete(void* p) noexcept { arenaFree(p); }
+void operator delete[](void* p) noexcept { arenaFree(p); }
+void operator delete(void* p, size_t) noexcept { arenaFree(p); }
+void operator delete[](void* p, size_t) noexcept { arenaFree(p); }
 
 #include "contact.hpp"
 #include "dynamics.hpp"
@@ -229,30 +272,52 @@ int nbo_step_batch(void* h, int64_t B, const double* state, const double* action
   const Model& m = base->model;
   const int n = m.n, k = (int)m.actionMap.size();
   if (threads < 1) threads = 1;
+  const char* arenaEnv = std::getenv("NBO_ARENA");
+  const bool useArena = !(arenaEnv && arenaEnv[0] == '0');
   auto work = [&](int t) {
     Oracle o;
     o.model = m;
-    for (int64_t b = t; b < B; b += threads) {
-      if (lcpIn && lcpLenIn && lcpLenIn[b] > 0) o.lcpCache.assign(lcpIn + b * lcpStride, lcpIn + b * lcpStride + lcpLenIn[b]);
-      else o.lcpCache.clear();
-      VecX tau;
-      splitAction(m, action + b * k, tau);
-      uint32_t st = 0;
-      stepWorld(o, state + b * 2 * n, state + b * 2 * n + n, tau.data(), nextState + b * 2 * n,
-                nextState + b * 2 * n + n, &st);
-      if (status) status[b] = st;
-      if (lcpOut && lcpLenOut) {
-        lcpLenOut[b] = (int32_t)o.lcpCache.size();
-        for (size_t i = 0; i < o.lcpCache.size() && (int)i < lcpStride; i++) lcpOut[b * lcpStride + i] = o.lcpCache[i];
-      }
-      if (gradNext && gradState) {
-        VecX gtau(n, 0.0);
-        backpropWorld(o, gradNext + b * 2 * n, gradNext + b * 2 * n + n, gradState + b * 2 * n,
-                      gradState + b * 2 * n + n, gtau.data());
-        if (gradAction)
-          for (int i = 0; i < k; i++) gradAction[b * k + i] = gtau[m.actionMap[i]];
-      }
+    Arena arena;
+    if (useArena) {
+      arena.cap = (size_t)64 << 20;
+      arena.base = (char*)std::malloc(arena.cap);
+      if (!arena.base) arena.cap = 0;
+      tlArena = &arena;
     }
+    // contiguous chunk of worlds per thread (one cloned world per thread stepping its share)
+    const int64_t per = (B + threads - 1) / threads, b0 = t * per, b1 = std::min<int64_t>(B, b0 + per);
+    for (int64_t b = b0; b < b1; b++) {
+      arena.off = 0;
+      arena.active = arena.cap > 0;
+      {
+        if (lcpIn && lcpLenIn && lcpLenIn[b] > 0) o.lcpCache.assign(lcpIn + b * lcpStride, lcpIn + b * lcpStride + lcpLenIn[b]);
+        else o.lcpCache.clear();
+        VecX tau;
+        splitAction(m, action + b * k, tau);
+        uint32_t st = 0;
+        stepWorld(o, state + b * 2 * n, state + b * 2 * n + n, tau.data(), nextState + b * 2 * n,
+                  nextState + b * 2 * n + n, &st);
+        if (status) status[b] = st;
+        if (lcpOut && lcpLenOut) {
+          lcpLenOut[b] = (int32_t)o.lcpCache.size();
+          for (size_t i = 0; i < o.lcpCache.size() && (int)i < lcpStride; i++) lcpOut[b * lcpStride + i] = o.lcpCache[i];
+        }
+        if (gradNext && gradState) {
+          VecX gtau(n, 0.0);
+          backpropWorld(o, gradNext + b * 2 * n, gradNext + b * 2 * n + n, gradState + b * 2 * n,
+                        gradState + b * 2 * n + n, gtau.data());
+          if (gradAction)
+            for (int i = 0; i < k; i++) gradAction[b * k + i] = gtau[m.actionMap[i]];
+        }
+        // nothing allocated during this world-step may outlive it: drop the snapshot and the warm start before the rewind
+        o.snap = Snapshot();
+        o.lcpCache = VecX();
+      }
+      if (arena.off > arena.peak) arena.peak = arena.off;
+      arena.active = false;
+    }
+    tlArena = nullptr;
+    if (arena.base) std::free(arena.base);
   };
   if (threads == 1) work(0);
   else {
