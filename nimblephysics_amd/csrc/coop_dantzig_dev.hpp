@@ -673,7 +673,7 @@ constexpr int CS_VALID = 2;    // ... and isLCPSolutionValid accepted it
 constexpr int CS_NAN = 4;      // Dantzig: NaN step length
 
 template <class W, class LDS>
-DEV void coopLoadProblem(const W& w, LDS& C, const CoopRow& R, double cfmDiag, double x0, CoopLcpRow& row, int& mapTo) {
+DEV void coopLoadProblem(const W& w, LDS& C, const CoopRow& R, double cfmDiag, double x0, CoopLcpRow& row, int& mapTo, int& nOut) {
   const int ln = w.lane();
   const int m = R.m;
   {
@@ -690,6 +690,21 @@ DEV void coopLoadProblem(const W& w, LDS& C, const CoopRow& R, double cfmDiag, d
   row.lo = R.fric ? -R.mu : 0.0; row.hi = R.fric ? R.mu : INFINITY; row.findex = R.fric ? R.fp : -1;
   mapTo = ln < m ? ln : -1;
   w.sync();
+  // The empty tangent rows of frictionless contacts (mu <= 1e-3, k_contact_rows_coop) do not exist in the reference's problem
+  // (ContactConstraint dimension 1): take them out, from the last one down, so that the solvers see the reference's rows in the
+  // reference's order - the initial permutation of dSolveLCP and with it the whole pivot sequence depend on it.
+  const uint32_t dead = (uint32_t)w.ballot(ln < m && R.fric && R.mu == 0.0);
+  nOut = m;
+  if (dead != 0u) {
+    for (int i = m - 1; i >= 0; i--) {
+      if (!((dead >> i) & 1u)) continue;
+      if (row.findex > i) row.findex -= 1;
+      coopRemoveRow(w, C, nOut, i, row);
+      nOut -= 1;
+      if (mapTo == i) mapTo = -1;
+      else if (mapTo > i) mapTo -= 1;
+    }
+  }
 }
 // X[o] = x_reduced[mapTo[o]]
 template <class W, class LDS>
@@ -706,8 +721,9 @@ template <class W>
 DEV void coopCascadeStage1(const W& w, CascadeLds& C, const CoopRow& R, double X0, CoopStageResult& out) {
   CoopLcpRow row;
   int mapTo;
-  coopLoadProblem(w, C, R, 0.0, X0, row, mapTo);
-  const int nr = coopLcpReduce(w, C, R.m, row, mapTo);
+  int n0;
+  coopLoadProblem(w, C, R, 0.0, X0, row, mapTo, n0);
+  const int nr = coopLcpReduce(w, C, n0, row, mapTo);
   const int rc = coopDantzig(w, C, nr, row);
   out.X = 0.0; out.flags = 0;
   if (rc == 1) {
@@ -720,8 +736,9 @@ template <class W, class LDS>
 DEV void coopCascadeStage2(const W& w, LDS& C, const CoopRow& R, double X0, double cfm, CoopStageResult& out) {
   CoopLcpRow row;
   int mapTo;
-  coopLoadProblem(w, C, R, cfm, X0, row, mapTo);
-  const int nr = coopLcpReduce(w, C, R.m, row, mapTo);
+  int n0;
+  coopLoadProblem(w, C, R, cfm, X0, row, mapTo, n0);
+  const int nr = coopLcpReduce(w, C, n0, row, mapTo);
   out.X = 0.0; out.flags = 0;
   if (coopPgs(w, C, nr, row)) {
     out.X = coopMapOut(w, C, R.m, mapTo, row.x, nr);
@@ -733,8 +750,9 @@ template <class W, class LDS>
 DEV void coopCascadeStage3(const W& w, LDS& C, const CoopRow& R, double X0, double cfm, CoopStageResult& out) {
   CoopLcpRow row;
   int mapTo;
-  coopLoadProblem(w, C, R, cfm, X0, row, mapTo);
-  const int nr = coopLcpRemoveFriction(w, C, R.m, row, mapTo);
+  int n0;
+  coopLoadProblem(w, C, R, cfm, X0, row, mapTo, n0);
+  const int nr = coopLcpRemoveFriction(w, C, n0, row, mapTo);
   row.x = 0.0;
   const bool ok3 = coopPgs(w, C, nr, row);
   out.X = coopMapOut(w, C, R.m, mapTo, row.x, nr);

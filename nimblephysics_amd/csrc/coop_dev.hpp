@@ -420,7 +420,7 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
   bool pinvValid = false;
   if (haveCache) X = ln < R.m ? Xcache : 0.0;
   else {
-    const bool in = ln < R.m && (R.fric || R.Bv > 0);
+    const bool in = ln < R.m && (R.fric ? R.mu != 0.0 : R.Bv > 0);   // (the empty tangent rows of frictionless contacts are not rows of the reference's problem)
     guessMask = (uint32_t)w.ballot(in);
     if (guessMask != 0) {
       double a[MAXR];

@@ -352,6 +352,46 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
     for (int jx = 0; jx < MAXR; jx += 2) { v0 = fma(S.G[jx * CLD + row], S.vec[slot][jx], v0); v1 = fma(S.G[(jx + 1) * CLD + row], S.vec[slot][jx + 1], v1); }
     return v0 + v1;
   };
+  // ---- was Q inverted precisely?  The reference switches between two formulas for the derivative of Q^+ b
+  // (BackpropSnapshot.cpp:2964-2984): when ||I - Q Q^+||_F^2 < 1e-18 it uses  -Q^+ dQ Q^+ b  alone, otherwise the full derivative
+  // of the pseudo-inverse, whose two extra terms carry (I - Q Q^+) b and (I - Q^+ Q) next to Q^+T Q^+.  For an exactly rank
+  // deficient Q (four coplanar corners) the extra terms are the correct ones; for a full-rank but ill-conditioned Q (the CFM
+  // fallback: cond ~ 1e6) they are round-off amplified by |Q^+|^2 - the reference drops them there and so must we (measured on
+  // cfg4 with the 0.1 kg cubes of box_stacking.skel: 2.7e-4 relative gradient error with them, 1e-9 without).
+  // Lane r forms row r of Q Q^+ on the clamping block: (Q X)_r = (A spread(X))_r + cfm X_r for the columns X of Q^+.
+  bool precise;
+  {
+    double* XE = S.R;                        // spread(Q^+) row by row (the buffer is free between g and the coefficient vectors)
+    if (ln < MAXR) {
+      const int src = clamp ? row : (isUb ? R.fp : row);
+      const double sc = clamp ? 1.0 : (isUb ? K.E : 0.0);
+#pragma unroll
+      for (int j = 0; j < MAXR; j++) XE[row * CLD + j] = sc * S.P[src * CLD + j];
+    }
+    w.sync();
+    double arow[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) arow[k] = S.G[k * CLD + row];
+    double acc = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < MAXR; j++) {
+      double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXR; k += 2) { y0 = fma(arow[k], XE[k * CLD + j], y0); y1 = fma(arow[k + 1], XE[(k + 1) * CLD + j], y1); }
+      const double y = (y0 + y1) + cfm * S.P[row * CLD + j];
+      const double dlt = ((row == j) ? 1.0 : 0.0) - y;
+      const bool inBlock = clamp && ((K.clampMask >> j) & 1u);
+      acc = fma(inBlock ? dlt : 0.0, inBlock ? dlt : 0.0, acc);
+    }
+    w.sync();
+    if (ln < MAXR) S.vec[0][ln] = clamp ? acc : 0.0;
+    w.sync();
+    double imp2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) imp2 += S.vec[0][k];
+    precise = imp2 < 1e-18;
+    w.sync();
+  }
   const double bcl = clamp ? R.Bv : 0.0;
   const double mu = coopPinvApply<DevWave, true>(w, S, fbar, 0);     // (Q^+)^T fbar
   const double fls = coopPinvApply<DevWave, false>(w, S, bcl, 1);    // Q^+ b (see k_bwd_contact_a on why not the applied x)
@@ -368,6 +408,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
     const double t2f = fold(t2);
     be[2] = clamp ? fbar - (t2 + t2f + cfm * mu) : 0.0;
   }
+  if (precise) { al[1] = 0.0; be[1] = 0.0; al[2] = 0.0; be[2] = 0.0; }   // -Q^+ dQ Q^+ b alone
   double beE[3];
   for (int k = 0; k < 3; k++) beE[k] = spread(be[k]);
   const double fcE = spread(xRaw);

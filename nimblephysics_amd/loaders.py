@@ -11,6 +11,7 @@ Conventions follow the reference's dart/utils/urdf/DartLoader.cpp (parameters on
     mesh / sphere / capsule colliders (libccd path, not vendored) are dropped
 Revolute, continuous, prismatic and fixed joints; joint Coulomb friction and other joint types raise.
 """
+import os
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -141,3 +142,164 @@ def with_ground(model, ground):
     return ModelDescription(model.name + "_ground", bodies, boxes, model.gravity, model.dt, None, max_contacts=8)
 
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SKEL subset loader (conventions of dart/utils/SkelParser.cpp; parameters only, nothing is copied)
+# ---------------------------------------------------------------------------------------------------------------------
+def euler_xyz_to_matrix(a):
+    """math::eulerXYZToMatrix (dart/math/Geometry.cpp:1767-1797): R = Rx(a0) Ry(a1) Rz(a2), the rotation part of every
+    <transformation>x y z a0 a1 a2</transformation> of a SKEL file (XmlHelpers.cpp:346-379)."""
+    cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+    return np.array([[cy * cz, -cy * sz, sy],
+                     [cx * sz + cz * sx * sy, cx * cz - sx * sy * sz, -cy * sx],
+                     [sx * sz - cx * cz * sy, cz * sx + cx * sy * sz, cx * cy]])
+
+
+def _skel_T(el, tag="transformation"):
+    t = el.find(tag) if el is not None else None
+    if t is None or t.text is None:
+        return np.eye(4)
+    v = [float(x) for x in t.text.split()]
+    return make_transform(v[:3], R=euler_xyz_to_matrix(v[3:6]))
+
+
+def _text(el, tag, default=None, cast=float):
+    t = el.find(tag) if el is not None else None
+    return default if t is None or t.text is None else cast(t.text.strip())
+
+
+def load_skel(path, name=None, skeletons=None, max_contacts=8):
+    """Parse a SKEL world (`<skel><world>`: physics + skeletons) into ONE ModelDescription (all skeletons of the world in one
+    model, like `with_ground`).  `skeletons`: names of the skeletons to keep (default: all), in file order.
+
+    Subset, following SkelParser.cpp: <physics> time_step / gravity (:520-560); per <body> name, <transformation> = the body's
+    WORLD transform at the zero configuration (:1082-1092), <inertia> mass / offset / moment_of_inertia (:1095-1128; without a
+    moment the first shape's inertia for that mass, :618-645; without <inertia> the BodyNode defaults mass 1, I = 1),
+    <collision_shape> box / isotropic ellipsoid (= sphere) with its <transformation> in the body frame; per <joint> type
+    weld / revolute / prismatic / free, <parent> ("world" = none) / <child>, <transformation> = T_ChildBodyToJoint and
+    T_ParentBodyToJoint = parentWorld^-1 childWorld childToJoint (:1540-1552), <axis> xyz, damping (under <axis> or
+    <axis><dynamics>), spring_stiffness / spring_rest_position, <limit> lower / upper (:1870-1960).  Bodies are emitted
+    parents-before-children in the file's joint order, which is the skeleton's DOF order.  Soft bodies, meshes, the other
+    joint types and <init_pos> / <init_vel> (a state, not a model constant) are outside the subset: unsupported joints raise."""
+    root = ET.parse(path).getroot()
+    world = root.find("world")
+    if world is None:
+        raise ValueError(f"{path}: no <world>")
+    phys = world.find("physics")
+    dt = _text(phys, "time_step", 1e-3)
+    g = phys.find("gravity") if phys is not None else None
+    gravity = tuple(float(x) for x in g.text.split()) if g is not None else (0.0, -9.81, 0.0)
+    bodies, boxes = [], []
+    for sk in world.findall("skeleton"):
+        if skeletons is not None and sk.get("name") not in skeletons:
+            continue
+        skel_T = _skel_T(sk)                                     # optional skeleton frame (:948-955)
+        bel = {b.get("name"): b for b in sk.findall("body")}
+        Tw = {n: skel_T @ _skel_T(b) for n, b in bel.items()}
+        joints = sk.findall("joint")
+        child_joint = {j.find("child").text.strip(): j for j in joints}
+        index = {}
+
+        def shapes_of(b):
+            out = []
+            for cs in b.findall("collision_shape"):
+                geom = cs.find("geometry")
+                box = geom.find("box") if geom is not None else None
+                ell = geom.find("ellipsoid") if geom is not None else None
+                sph = geom.find("sphere") if geom is not None else None
+                if box is not None:
+                    out.append(("box", tuple(float(x) for x in box.find("size").text.split()), _skel_T(cs)))
+                elif sph is not None:
+                    r = float(sph.find("radius").text)
+                    out.append(("sphere", (r, r, r), _skel_T(cs)))
+                elif ell is not None:
+                    d = tuple(float(x) for x in ell.find("size").text.split())
+                    if max(d) - min(d) > 1e-12 * max(d):
+                        raise ValueError(f"{path}: anisotropic ellipsoid collider outside the analytic narrow phase")
+                    out.append(("sphere", (d[0] / 2,) * 3, _skel_T(cs)))
+            return out
+
+        def inertial(b):
+            ine = b.find("inertia")
+            if ine is None:
+                return 1.0, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0, 0.0, 0.0, 0.0)
+            mass = _text(ine, "mass", 1.0)
+            off = ine.find("offset")
+            com = tuple(float(x) for x in off.text.split()) if off is not None else (0.0, 0.0, 0.0)
+            moi = ine.find("moment_of_inertia")
+            if moi is not None:
+                I6 = tuple(_text(moi, k, 0.0) for k in ("ixx", "iyy", "izz", "ixy", "ixz", "iyz"))
+            else:
+                I6 = (1.0, 1.0, 1.0, 0.0, 0.0, 0.0)
+                shp = shapes_of(b)                               # the first shape's inertia for this mass (:618-645)
+                vis = b.find("visualization_shape")
+                if not shp and vis is not None and vis.find("geometry/box") is not None:
+                    shp = [("box", tuple(float(x) for x in vis.find("geometry/box/size").text.split()), np.eye(4))]
+                if shp:
+                    kind, size, _ = shp[0]
+                    if kind == "box":                            # BoxShape::computeInertia (BoxShape.cpp:74-83)
+                        I6 = (mass / 12.0 * (size[1] ** 2 + size[2] ** 2), mass / 12.0 * (size[0] ** 2 + size[2] ** 2),
+                              mass / 12.0 * (size[0] ** 2 + size[1] ** 2), 0.0, 0.0, 0.0)
+                    else:                                        # sphere: 2/5 m r^2
+                        I6 = (0.4 * mass * size[0] ** 2,) * 3 + (0.0, 0.0, 0.0)
+            return mass, com, I6
+
+        pending = list(joints)
+        while pending:
+            progressed = False
+            for j in list(pending):
+                pn = j.find("parent").text.strip()
+                cn = j.find("child").text.strip()
+                if pn != "world" and pn not in index:
+                    continue
+                jt = j.get("type")
+                c2j = _skel_T(j)
+                parentW = np.eye(4) if pn == "world" else Tw[pn]
+                T_pj = np.linalg.inv(parentW) @ Tw[cn] @ c2j
+                kw = {}
+                if jt in ("revolute", "prismatic"):
+                    ax = j.find("axis")
+                    axis = tuple(float(x) for x in ax.find("xyz").text.split())
+                    damp = _text(ax, "damping", None)
+                    dyn = ax.find("dynamics")
+                    if dyn is not None:
+                        damp = _text(dyn, "damping", damp)
+                        if _text(dyn, "friction", 0.0) != 0.0:
+                            raise ValueError(f"{j.get('name')}: joint Coulomb friction is outside the hot-path scope")
+                        if dyn.find("spring_stiffness") is not None:
+                            kw["spring"] = (_text(dyn, "spring_stiffness"),)
+                        if dyn.find("spring_rest_position") is not None:
+                            kw["rest"] = (_text(dyn, "spring_rest_position"),)
+                    if damp is not None:
+                        kw["damping"] = (damp,)
+                    lim = ax.find("limit")
+                    if lim is not None:
+                        if lim.find("lower") is not None:
+                            kw["pos_lo"] = (_text(lim, "lower"),)
+                        if lim.find("upper") is not None:
+                            kw["pos_hi"] = (_text(lim, "upper"),)
+                    jtype = jt
+                elif jt == "weld":
+                    jtype, axis = "weld", (0.0, 0.0, 1.0)
+                elif jt == "free":
+                    jtype, axis = "free", (0.0, 0.0, 1.0)
+                else:
+                    raise ValueError(f"{j.get('name')}: joint type {jt} outside scope")
+                mass, com, I6 = inertial(bel[cn])
+                base = len(bodies)
+                bodies.append(BodySpec(cn, -1 if pn == "world" else index[pn], jtype, j.get("name"), axis=axis, T_pj=T_pj, T_cj=c2j,
+                                       mass=mass, com=com, inertia=I6, **kw))
+                index[cn] = base
+                for kind, size, Ts in shapes_of(bel[cn]):
+                    boxes.append(BoxSpec(base, Ts, size, 1.0, kind))
+                pending.remove(j)
+                progressed = True
+            if not progressed:
+                raise ValueError(f"{path}: joints of skeleton {sk.get('name')} do not form a tree rooted in the world")
+        missing = set(bel) - set(child_joint)
+        if missing:
+            raise ValueError(f"{path}: bodies without a parent joint: {sorted(missing)}")
+    if name is None:
+        name = os.path.splitext(os.path.basename(path))[0]
+    return ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=max_contacts if boxes else 0)

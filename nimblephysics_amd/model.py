@@ -360,13 +360,10 @@ class ModelDescription:
 # The BASELINE.json configs
 # ---------------------------------------------------------------------------------------------
 def single_pendulum() -> ModelDescription:
-    """cfg1: data/skel/test/single_pendulum.skel — revolute z, m=5, I=diag(1,2,3), damping 10.
-
-    Body world transform (0.1,0,0), joint frame (-0.1,0,0) in the child => T_pj = identity.
-    """
-    b = BodySpec("link 1", -1, "revolute", "joint 1", axis=(0, 0, 1), T_pj=np.eye(4), T_cj=make_transform((-0.1, 0, 0)),
-                 mass=5.0, com=(0, 0, 0), inertia=(1, 2, 3, 0, 0, 0), damping=(10.0,))
-    return ModelDescription("single_pendulum", [b], gravity=(0, -9.81, 0), dt=1e-3)
+    """cfg1: data/skel/test/single_pendulum.skel - revolute z, m = 5, I = diag(1, 2, 3), damping 10 - as parsed by
+    nimblephysics_amd.loaders.load_skel (SkelParser conventions) and committed as data/single_pendulum.json by
+    tools/urdf_to_model.py (body world transform (0.1, 0, 0), joint frame (-0.1, 0, 0) in the child => T_pj = identity)."""
+    return ModelDescription.load("single_pendulum")
 
 
 def cartpole() -> ModelDescription:
@@ -389,16 +386,7 @@ def atlas(variant: str = "atlas33", ground: bool = False) -> ModelDescription:
 
 
 def box_stack() -> ModelDescription:
-    """cfg4: welded ground box 2 x 0.01 x 2 + two FreeJoint cubes of side 0.2, mu = 1."""
-    cube_I = 1.0 * (0.2 ** 2 + 0.2 ** 2) / 12.0
-    bodies = [
-        BodySpec("ground", -1, "weld", "ground_joint", mass=1.0),
-        BodySpec("box1", -1, "free", "box1_joint", mass=1.0, inertia=(cube_I, cube_I, cube_I, 0, 0, 0)),
-        BodySpec("box2", -1, "free", "box2_joint", mass=1.0, inertia=(cube_I, cube_I, cube_I, 0, 0, 0)),
-    ]
-    boxes = [
-        BoxSpec(0, make_transform((0, -0.005, 0)), (2.0, 0.01, 2.0), 1.0),
-        BoxSpec(1, np.eye(4), (0.2, 0.2, 0.2), 1.0),
-        BoxSpec(2, np.eye(4), (0.2, 0.2, 0.2), 1.0),
-    ]
-    return ModelDescription("box_stack", bodies, boxes, max_contacts=8)
+    """cfg4: data/skel/test/box_stacking.skel restricted to the welded ground box (2 x 0.01 x 2 at y = -0.5) and its first two
+    FreeJoint cubes (side 0.2, mass 0.1, shape inertia), mu = 1 - parsed by load_skel and committed as data/box_stack.json by
+    tools/urdf_to_model.py.  Two cubes = 8 contacts = the device path's row budget."""
+    return ModelDescription.load("box_stack")

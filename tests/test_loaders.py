@@ -100,3 +100,103 @@ def test_urdf_sphere_collision_geometry(tmp_path):
     assert len(md.boxes) == 1 and md.boxes[0].shape == "sphere" and md.boxes[0].size == (0.25, 0.25, 0.25)
     assert md.flat()["box_shape"].tolist() == [1]
     assert ModelDescription.from_json(json.loads(json.dumps(md.to_json()))).boxes[0].shape == "sphere"
+
+
+# ---- SKEL subset loader (dart/utils/SkelParser.cpp conventions) --------------------------------------------------------
+SKEL = """<?xml version="1.0" ?>
+<skel version="1.0">
+  <world name="w">
+    <physics><time_step>0.002</time_step><gravity>0 -9.81 0</gravity></physics>
+    <skeleton name="floor">
+      <body name="slab"><transformation>0 -0.5 0 0 0 0</transformation>
+        <collision_shape><transformation>0 0 0 0 0 0</transformation><geometry><box><size>4 0.2 4</size></box></geometry></collision_shape></body>
+      <joint type="weld" name="fix"><parent>world</parent><child>slab</child></joint>
+    </skeleton>
+    <skeleton name="arm">
+      <body name="b2"><transformation>0.5 0.3 0 0 0 0</transformation>
+        <inertia><mass>2</mass><offset>0.1 0 0</offset></inertia>
+        <collision_shape><transformation>0.1 0 0 0 0 0.2</transformation><geometry><box><size>0.4 0.1 0.2</size></box></geometry></collision_shape></body>
+      <body name="b1"><transformation>0 0.3 0 0 0 0.5</transformation>
+        <inertia><mass>3</mass><moment_of_inertia><ixx>0.1</ixx><iyy>0.2</iyy><izz>0.3</izz><ixy>0.01</ixy><ixz>0</ixz><iyz>0</iyz></moment_of_inertia></inertia>
+        <collision_shape><geometry><ellipsoid><size>0.2 0.2 0.2</size></ellipsoid></geometry></collision_shape></body>
+      <joint type="revolute" name="j2"><parent>b1</parent><child>b2</child><transformation>-0.2 0 0 0 0 0</transformation>
+        <axis><xyz>0 0 1</xyz><dynamics><damping>0.3</damping><spring_stiffness>2.5</spring_stiffness><spring_rest_position>0.1</spring_rest_position></dynamics>
+          <limit><lower>-1.5</lower><upper>1.0</upper></limit></axis></joint>
+      <joint type="prismatic" name="j1"><parent>world</parent><child>b1</child><axis><xyz>1 0 0</xyz><damping>0.7</damping></axis></joint>
+    </skeleton>
+  </world>
+</skel>
+"""
+
+
+def test_skel_subset_loader_builds_the_expected_model(tmp_path):
+    from nimblephysics_amd.loaders import euler_xyz_to_matrix
+    f = tmp_path / "w.skel"
+    f.write_text(SKEL)
+    md = na.load_skel(str(f))
+    assert md.dt == 0.002 and tuple(md.gravity) == (0.0, -9.81, 0.0)
+    # parents before children, whatever the order of the <body> / <joint> elements: j1 (world -> b1) before j2 (b1 -> b2)
+    assert [b.name for b in md.bodies] == ["slab", "b1", "b2"]
+    assert [b.joint_type for b in md.bodies] == ["weld", "prismatic", "revolute"]
+    assert [b.parent for b in md.bodies] == [-1, -1, 1]
+    slab, b1, b2 = md.bodies
+    Rz = euler_xyz_to_matrix((0, 0, 0.5))
+    Tw1 = make_transform((0, 0.3, 0), R=Rz); Tw2 = make_transform((0.5, 0.3, 0))
+    c2j = make_transform((-0.2, 0, 0))
+    assert np.allclose(b1.T_pj, Tw1) and np.allclose(b1.T_cj, np.eye(4))                  # parent = world, no joint transformation
+    assert np.allclose(b2.T_pj, np.linalg.inv(Tw1) @ Tw2 @ c2j) and np.allclose(b2.T_cj, c2j)   # SkelParser.cpp:1540-1552
+    assert b1.damping == (0.7,) and b2.damping == (0.3,) and b2.spring == (2.5,) and b2.rest == (0.1,)
+    assert b2.pos_lo == (-1.5,) and b2.pos_hi == (1.0,)
+    assert b1.mass == 3.0 and tuple(b1.inertia) == (0.1, 0.2, 0.3, 0.01, 0.0, 0.0)
+    # no <moment_of_inertia>: the first shape's inertia for that mass (BoxShape::computeInertia)
+    assert np.allclose(b2.inertia, (2 / 12 * (0.1 ** 2 + 0.2 ** 2), 2 / 12 * (0.4 ** 2 + 0.2 ** 2), 2 / 12 * (0.4 ** 2 + 0.1 ** 2), 0, 0, 0))
+    assert tuple(b2.com) == (0.1, 0.0, 0.0)
+    assert (slab.mass, tuple(slab.inertia)) == (1.0, (1.0, 1.0, 1.0, 0.0, 0.0, 0.0))      # BodyNode defaults
+    assert [(bx.body, bx.shape) for bx in md.boxes] == [(0, "box"), (1, "sphere"), (2, "box")]
+    assert md.boxes[1].size == (0.1, 0.1, 0.1)                                              # ellipsoid diameters -> radius
+    assert np.allclose(md.boxes[2].T, make_transform((0.1, 0, 0), R=euler_xyz_to_matrix((0, 0, 0.2))))
+    only_arm = na.load_skel(str(f), skeletons=["arm"])
+    assert [b.name for b in only_arm.bodies] == ["b1", "b2"] and len(only_arm.boxes) == 2
+    bad = tmp_path / "bad.skel"
+    bad.write_text(SKEL.replace('type="prismatic"', 'type="ball"'))
+    with pytest.raises(ValueError):
+        na.load_skel(str(bad))
+
+
+def test_skel_model_steps_like_the_hand_built_one(tmp_path):
+    """The loaded model is a working model: the oracle steps it, and the mass matrix of the two-link arm equals the
+    closed form of the same arm written by hand."""
+    from oracle import OracleWorld
+    f = tmp_path / "w.skel"
+    f.write_text(SKEL)
+    md = na.load_skel(str(f), skeletons=["arm"])
+    ow = OracleWorld(md)
+    q = np.array([0.2, -0.4])
+    M = ow.mass_matrix(q)
+    assert M.shape == (2, 2) and np.allclose(M, M.T) and np.all(np.linalg.eigvalsh(M) > 0)
+    assert abs(M[0, 0] - (3.0 + 2.0)) < 1e-12                                              # prismatic root carries both masses
+    s = np.concatenate([q, [0.1, -0.2]])
+    nxt = ow.step(s, np.zeros(2))
+    assert np.all(np.isfinite(nxt)) and not np.allclose(nxt, s)
+
+
+REF_SKEL = "/root/reference/data/skel/test"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SKEL), reason="reference tree not present (GPU box)")
+def test_committed_cfg1_cfg4_descriptions_are_reproducible_from_the_reference_skel_files():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from urdf_to_model import skel_models
+    pend, stack = skel_models()
+    data = os.path.join(os.path.dirname(na.__file__), "data")
+    assert json.loads(json.dumps(pend.to_json())) == json.load(open(os.path.join(data, "single_pendulum.json")))
+    assert json.loads(json.dumps(stack.to_json())) == json.load(open(os.path.join(data, "box_stack.json")))
+    # what the files say (single_pendulum.skel / box_stacking.skel)
+    p = na.single_pendulum()
+    assert p.num_dofs == 1 and p.bodies[0].mass == 5.0 and tuple(p.bodies[0].inertia) == (1.0, 2.0, 3.0, 0.0, 0.0, 0.0) and tuple(p.bodies[0].damping) == (10.0,)
+    assert np.allclose(p.bodies[0].T_pj, np.eye(4)) and np.allclose(p.bodies[0].T_cj, make_transform((-0.1, 0, 0)))
+    bs = na.box_stack()
+    assert [b.joint_type for b in bs.bodies] == ["weld", "free", "free"] and bs.num_dofs == 12 and bs.max_contacts == 8
+    assert [b.mass for b in bs.bodies[1:]] == [0.1, 0.1] and np.allclose(bs.bodies[2].T_pj[:3, 3], (0, 0.2, 0))
+    assert [tuple(bx.size) for bx in bs.boxes] == [(2.0, 0.01, 2.0), (0.2, 0.2, 0.2), (0.2, 0.2, 0.2)]

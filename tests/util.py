@@ -56,20 +56,25 @@ def box_stack_inputs(B, seed, overhang=False):
     (EDGE_EDGE contacts against the world-fixed box, stage-0 regime), the other cube parked far above."""
     rng = np.random.default_rng(seed)
     md = na.box_stack()
+    # geometry of the loaded model: top face of the ground box and the zero-configuration centres of the two cubes
+    gb = md.boxes[0]
+    top = (md.bodies[0].T_pj @ gb.T)[1, 3] + 0.5 * gb.size[1]
+    c1, c2 = md.bodies[1].T_pj[:3, 3], md.bodies[2].T_pj[:3, 3]
     q = np.zeros((B, 12)); v = np.zeros((B, 12))
     pen1, pen2 = rng.uniform(1e-4, 1e-3, B), rng.uniform(1e-4, 1e-3, B)
     yaw = rng.uniform(-np.pi, np.pi, B)
     if overhang:
-        q[:, 1] = yaw; q[:, 3] = rng.uniform(0.9, 0.99, B) * rng.choice([-1, 1], B); q[:, 4] = 0.1 - pen1; q[:, 5] = rng.uniform(-0.5, 0.5, B)
+        q[:, 1] = yaw; q[:, 3] = rng.uniform(0.9, 0.99, B) * rng.choice([-1, 1], B) - c1[0]; q[:, 4] = top + 0.1 - pen1 - c1[1]; q[:, 5] = rng.uniform(-0.5, 0.5, B) - c1[2]
         q[:, 10] = 5.0
         v[:, 0:6] = rng.normal(0, 0.001, (B, 6))
     else:
-        q[:, 1] = yaw; q[:, 4] = 0.1 - pen1; q[:, 3] = rng.uniform(-0.3, 0.3, B); q[:, 5] = rng.uniform(-0.3, 0.3, B)
+        x1, z1 = rng.uniform(-0.3, 0.3, B), rng.uniform(-0.3, 0.3, B)
+        q[:, 1] = yaw; q[:, 4] = top + 0.1 - pen1 - c1[1]; q[:, 3] = x1 - c1[0]; q[:, 5] = z1 - c1[2]
         off = rng.uniform(0.005, 0.03, (B, 2)) * rng.choice([-1, 1], (B, 2))
         c, s_ = np.cos(yaw), np.sin(yaw)
         q[:, 7] = yaw
-        q[:, 9] = q[:, 3] + c * off[:, 0] + s_ * off[:, 1]; q[:, 11] = q[:, 5] - s_ * off[:, 0] + c * off[:, 1]
-        q[:, 10] = 0.3 - pen1 - pen2
+        q[:, 9] = x1 + c * off[:, 0] + s_ * off[:, 1] - c2[0]; q[:, 11] = z1 - s_ * off[:, 0] + c * off[:, 1] - c2[2]
+        q[:, 10] = top + 0.3 - pen1 - pen2 - c2[1]
         v[:, [3, 5, 9, 11]] = rng.normal(0, 0.05, (B, 4))
     a = np.zeros((B, 12))
     return md, np.concatenate([q, v], 1), a

@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 REF = os.environ.get("NIMBLE_REFERENCE", "/root/reference")
 
 
-from nimblephysics_amd.loaders import load_urdf, with_ground  # noqa: E402
+from nimblephysics_amd.loaders import load_skel, load_urdf, with_ground  # noqa: E402
 
 
 def main():
@@ -45,6 +45,30 @@ def main():
             with open(os.path.join(out_dir, mdl.name + ".json"), "w") as f:
                 json.dump(mdl.to_json(), f, indent=1)
             print(mdl.name, "bodies", len(mdl.bodies), "dofs", mdl.num_dofs, "boxes", len(mdl.boxes))
+    # cfg1 / cfg4 from the reference's SKEL worlds (SkelParser conventions, nimblephysics_amd.loaders.load_skel)
+    skel = {
+        "single_pendulum": skel_models()[0],
+        "box_stack": skel_models()[1],
+    }
+    for name, mdl in skel.items():
+        with open(os.path.join(out_dir, name + ".json"), "w") as f:
+            json.dump(mdl.to_json(), f, indent=1)
+        print(name, "bodies", len(mdl.bodies), "dofs", mdl.num_dofs, "boxes", len(mdl.boxes))
+
+
+def skel_models():
+    """cfg1: data/skel/test/single_pendulum.skel (its collision box dropped: one body, nothing to collide with).
+    cfg4: data/skel/test/box_stacking.skel restricted to the ground and the first two cubes (8 contacts = the
+    device path's row budget), bodies renamed ground / box1 / box2."""
+    pend = load_skel(os.path.join(REF, "data/skel/test/single_pendulum.skel"), "single_pendulum", max_contacts=0)
+    pend.boxes = []
+    stack = load_skel(os.path.join(REF, "data/skel/test/box_stacking.skel"), "box_stack",
+                      skeletons=["ground skeleton", "box skeleton1", "box skeleton2"], max_contacts=8)
+    for b, nm in zip(stack.bodies, ("ground", "box1", "box2")):
+        b.name = nm
+    for b, jn in zip(stack.bodies, ("ground_joint", "box1_joint", "box2_joint")):
+        b.joint_name = jn
+    return pend, stack
 
 
 if __name__ == "__main__":
