@@ -67,6 +67,25 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
+def _cpu_quota():
+    """CPUs this container may actually use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota / cfs_period), None if unlimited.
+    On the GPU boxes 256 logical CPUs are visible but the quota is 16: threads beyond it only time-share."""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            return max(1, int(int(txt[0]) // int(txt[1])))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(md, state, action, target_seconds=20.0):
     """Time the CPU oracle (restated reference algorithm, scalar C++ -O3 -march=native) on this box's host cores on a bounded
     sample of the same workload: one cloned world per thread (the reference's own concurrency model, MultiShot.cpp:66-70),
@@ -74,8 +93,14 @@ def cpu_baseline(md, state, action, target_seconds=20.0):
     instead of malloc in the timed path.  Reported, never used by the product."""
     import tempfile
     import oracle
-    threads = _physical_cores()
-    logical = os.cpu_count() or threads
+    physical = _physical_cores()
+    quota = _cpu_quota()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = os.cpu_count() or physical
+    threads = max(1, min(physical, affinity, quota or physical))       # the cores the box really gives this process
+    logical = threads
     so = os.path.join(tempfile.gettempdir(), "liboracle_native.so")
     try:
         oracle.build(force=True, native=True, out=so)
@@ -92,28 +117,30 @@ def cpu_baseline(md, state, action, target_seconds=20.0):
     ow.step_batch(state[:n1], action[:n1], g[:n1], threads=1)
     one = n1 / (time.perf_counter() - t0)
 
-    def rate(nthreads):
-        per_thread = int(max(256, min(4096, target_seconds / 4 * one)))        # world-steps per thread and repetition
+    def rate(nthreads, reps_n):
+        per_thread = 256                                          # world-steps per thread and repetition
         n_sample = per_thread * nthreads
         reps_of_batch = (n_sample + len(state) - 1) // len(state)
         S = np.tile(state, (reps_of_batch, 1))[:n_sample]; A = np.tile(action, (reps_of_batch, 1))[:n_sample]; G = 2.0 * S
         ow.step_batch(S[:nthreads * 8], A[:nthreads * 8], G[:nthreads * 8], threads=nthreads)   # warm-up (thread creation, arenas)
         reps = []
-        for _ in range(3):
+        for _ in range(reps_n):
             t0 = time.perf_counter()
             ow.step_batch(S, A, G, threads=nthreads)
             reps.append(time.perf_counter() - t0)
-        return n_sample / sorted(reps)[1], n_sample
+        return n_sample / sorted(reps)[len(reps) // 2], n_sample
 
-    val, n_sample = rate(threads)
+    val, n_sample = rate(threads, 3)
     extra = ""
     if logical != threads:
-        val_l, _ = rate(logical)
+        val_l, _ = rate(logical, 1)
         extra = f"; {logical} logical threads: {val_l:.0f}/s"
     return {"value": val, "unit": "worlds*timesteps/s", "cores": threads, "kind": "port",
             "one_thread_value": one, "speedup_over_one_thread": val / one,
+            "host": {"logical_cpus": os.cpu_count(), "physical_cores": physical, "cgroup_cpu_quota": quota},
             "sample": f"{n_sample} world-steps fwd+bwd ({n_sample // threads} per thread, the batch tiled), median of 3, {threads} threads = "
-                      f"physical cores (one cloned world per thread, per-thread arena); 1 thread: {one:.1f}/s{extra}; restated reference "
+                      f"usable cores (min of physical cores {physical} and the container's CPU quota {quota}; one cloned world per thread, "
+                      f"per-thread arena); 1 thread: {one:.1f}/s{extra}; restated reference "
                       "algorithm (oracle/, dense n x n Jacobians like BackpropSnapshot), not the upstream binary"}
 
 
@@ -130,6 +157,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="slices of the per-GPU batch, each a World on its own HIP stream (0 = auto: 4 from 4096 worlds, 2 from 2048)")
     ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: timed region without the per-kernel HIP events")
+    ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (torch.distributed.run, one process per GPU, RCCL) even for --gpus 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +165,7 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world_size and world_size > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: become the launcher (one process per GPU over RCCL) and relay rank 0's line
         import socket
         import subprocess
@@ -145,12 +173,13 @@ def main():
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn"]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.call(cmd, env=env))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    use_dist = "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run (any N, also 1)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -169,7 +198,7 @@ def main():
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in bounds[1:]]
 
     def sync():
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -221,7 +250,7 @@ def main():
         elapsed = time.perf_counter() - t0
         tm = world.get_timing()
         world.set_timing(False)
-        if world_size > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -245,9 +274,8 @@ def main():
         value = total_units / elapsed
         m_rows = 24 if world.m > 0 else 0
         kern = {kname: v["ms_sum"] / v["count"] for kname, v in tm["kernels"].items()}
-        if not kern:   # --no-kernel-timing diagnostic run
-            print(json.dumps({"value": total_units / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "note": "no kernel timing"}))
-            return
+        if not kern:   # no per-kernel events (--no-kernel-timing, or the rollout entry points, which own their streams): whole-step figures
+            kern = {"whole_step": elapsed / args.steps * 1e3 / max(1, args.rollout)}
         # algorithmic HBM bytes per world-step fwd+bwd (fp64) = 104 n + 16 m.
         # Per launch of the step (all kernels of one forward + one backward): that figure x B worlds.
         dom = max(kern, key=kern.get)
@@ -293,7 +321,7 @@ def main():
                                    (f"; one step = one {args.rollout}-step rollout fwd+bwd (warm-started after its first step)" if args.rollout else ""),
                        "n_dofs": n, "contacts": m_rows // 3, "lcp_rows": m_rows, "worlds_per_gpu": B, "dt": md.dt,
                        "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None,
-                       "rccl_world_size": world_size,
+                       "rccl_world_size": (dist.get_world_size() if use_dist else 0),
                        "lanes_with_contact": float((st & 0x1).astype(bool).mean()),
                        "lanes_resolved_at_lcp_stage0": float((st & 0x2).astype(bool).mean()) if m_rows else None,
                        "lanes_unresolved": float((st & 0x20).astype(bool).mean()),
@@ -323,7 +351,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "worlds*timesteps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world_size > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -24,23 +24,29 @@
 // The restatement allocates dozens of small std::vector / MatX temporaries per world-step; with one cloned world per host
 // thread (the reference's own concurrency model, MultiShot.cpp:66-70) on a 256-thread box the allocator, not the arithmetic,
 // bounded the contact path (11x speed-up on 256 threads against 49x without contacts).  Inside nbo_step_batch every worker
-// thread serves `operator new` from a private arena that is rewound after each world-step; everything else (and every other
-// thread) falls through to malloc.  The library is linked with -Bsymbolic so that only ITS allocations come here.
+// thread serves `operator new` from a private arena with per-size free lists (no lock, no system call, blocks reused while
+// they are still in cache); everything else (and every other thread) falls through to malloc.  The library is linked with -Bsymbolic so that only ITS allocations come here.
 namespace {
+// size-class free lists on top of a bump region: a freed block is the next one handed out for its class, so the temporaries of
+// a world-step keep reusing the same few hundred kB of (cache-resident) memory instead of streaming through megabytes
 struct Arena {
+  static constexpr int GRAIN = 64, NCLS = 1024;   // classes of 64 B up to 64 kB; larger requests go to malloc
   char* base = nullptr;
-  size_t cap = 0, off = 0, peak = 0;
+  size_t cap = 0, off = 0;
+  void* freeList[NCLS + 1];
   bool active = false;
 };
 thread_local Arena* tlArena = nullptr;
 inline void* arenaAlloc(size_t n) {
   Arena* a = tlArena;
   if (a && a->active) {
-    n = (n + 15) & ~(size_t)15;
-    if (a->off + n <= a->cap) {
-      void* p = a->base + a->off;
-      a->off += n;
-      return p;
+    const size_t need = n + 16;                    // 16-byte header: the block's class
+    const size_t cls = (need + Arena::GRAIN - 1) / Arena::GRAIN;
+    if (cls <= (size_t)Arena::NCLS) {
+      char* blk = (char*)a->freeList[cls];
+      if (blk) a->freeList[cls] = *(void**)(blk + 16);
+      else if (a->off + cls * Arena::GRAIN <= a->cap) { blk = a->base + a->off; a->off += cls * Arena::GRAIN; }
+      if (blk) { *(size_t*)blk = cls; return blk + 16; }
     }
   }
   void* p = std::malloc(n ? n : 1);
@@ -48,8 +54,15 @@ inline void* arenaAlloc(size_t n) {
   return p;
 }
 inline void arenaFree(void* p) noexcept {
+  if (!p) return;
   Arena* a = tlArena;
-  if (a && p >= (void*)a->base && p < (void*)(a->base + a->cap)) return;   // rewound wholesale after the world-step
+  if (a && p >= (void*)a->base && p < (void*)(a->base + a->cap)) {
+    char* blk = (char*)p - 16;
+    const size_t cls = *(size_t*)blk;
+    *(void**)(blk + 16) = a->freeList[cls];
+    a->freeList[cls] = blk;
+    return;
+  }
   std::free(p);
 }
 }  // namespace
@@ -275,21 +288,21 @@ int nbo_step_batch(void* h, int64_t B, const double* state, const double* action
   const char* arenaEnv = std::getenv("NBO_ARENA");
   const bool useArena = !(arenaEnv && arenaEnv[0] == '0');
   auto work = [&](int t) {
-    Oracle o;
-    o.model = m;
     Arena arena;
     if (useArena) {
       arena.cap = (size_t)64 << 20;
       arena.base = (char*)std::malloc(arena.cap);
       if (!arena.base) arena.cap = 0;
+      for (auto& f : arena.freeList) f = nullptr;
+      arena.active = arena.cap > 0;
       tlArena = &arena;
     }
-    // contiguous chunk of worlds per thread (one cloned world per thread stepping its share)
-    const int64_t per = (B + threads - 1) / threads, b0 = t * per, b1 = std::min<int64_t>(B, b0 + per);
-    for (int64_t b = b0; b < b1; b++) {
-      arena.off = 0;
-      arena.active = arena.cap > 0;
-      {
+    {
+      Oracle o;                                   // everything it allocates lives (and dies) inside the arena's lifetime
+      o.model = m;
+      // contiguous chunk of worlds per thread (one cloned world per thread stepping its share)
+      const int64_t per = (B + threads - 1) / threads, b0 = t * per, b1 = std::min<int64_t>(B, b0 + per);
+      for (int64_t b = b0; b < b1; b++) {
         if (lcpIn && lcpLenIn && lcpLenIn[b] > 0) o.lcpCache.assign(lcpIn + b * lcpStride, lcpIn + b * lcpStride + lcpLenIn[b]);
         else o.lcpCache.clear();
         VecX tau;
@@ -309,13 +322,10 @@ int nbo_step_batch(void* h, int64_t B, const double* state, const double* action
           if (gradAction)
             for (int i = 0; i < k; i++) gradAction[b * k + i] = gtau[m.actionMap[i]];
         }
-        // nothing allocated during this world-step may outlive it: drop the snapshot and the warm start before the rewind
-        o.snap = Snapshot();
-        o.lcpCache = VecX();
       }
-      if (arena.off > arena.peak) arena.peak = arena.off;
-      arena.active = false;
     }
+    if (std::getenv("NBO_ARENA_STATS") && t == 0) std::fprintf(stderr, "[oracle] arena high-water mark: %zu bytes\n", arena.off);
+    arena.active = false;
     tlArena = nullptr;
     if (arena.base) std::free(arena.base);
   };

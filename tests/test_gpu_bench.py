@@ -1,0 +1,35 @@
+"""bench.py through its self-launch path: `python bench.py --gpus N` without a launcher re-executes itself under
+torch.distributed.run (one process per GPU, RCCL); --spawn forces that path for N = 1 so that a 1-GPU box can test it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_path_one_gpu():
+    d = _run(["--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--batch", "512", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_world_size"] == 1           # RCCL process group of one rank was initialised
+    assert d["value"] > 0 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["joint_noise"] == 0.02 and 0.3 < d["config"]["lanes_resolved_at_lcp_stage0"] < 0.7
+    assert d["secondary"]["stage0_only"]["lanes_resolved_at_lcp_stage0"] == 1.0
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "fp64"}
+
+
+def test_bench_cfg5_workload_is_selectable():
+    """cfg5's per-GPU share: Atlas-33 on the ground, T = 64 trajectory (a short batch here)."""
+    d = _run(["--workload", "atlas33_contact", "--rollout", "8", "--steps", "1", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--easy-noise", "0"])
+    assert d["config"]["n_dofs"] == 33 and d["config"]["rollout_T"] == 8 and d["value"] > 0
