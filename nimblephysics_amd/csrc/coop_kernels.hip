@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   // deficient Q (four coplanar corners) the extra terms are the correct ones; for a full-rank but ill-conditioned Q (the CFM
   // fallback: cond ~ 1e6) they are round-off amplified by |Q^+|^2 - the reference drops them there and so must we (measured on
   // cfg4 with the 0.1 kg cubes of box_stacking.skel: 2.7e-4 relative gradient error with them, 1e-9 without).
-  // Lane r forms row r of Q Q^+ on the clamping block: (Q X)_r = (A spread(X))_r + cfm X_r for the columns X of Q^+.
+  // Q Q^+ on the clamping block: (Q X)_r = (A spread(X))_r + cfm X_r for the columns X of Q^+.
   bool precise;
   {
     double* XE = S.R;                        // spread(Q^+) row by row (the buffer is free between g and the coefficient vectors)
@@ -369,26 +369,40 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
       for (int j = 0; j < MAXR; j++) XE[row * CLD + j] = sc * S.P[src * CLD + j];
     }
     w.sync();
-    double arow[MAXR];
-#pragma unroll
-    for (int k = 0; k < MAXR; k++) arow[k] = S.G[k * CLD + row];
+    // Q Q^+ = A spread(Q^+) + cfm Q^+ is the one true GEMM of the contact adjoint (24 x 24 x 24): on the matrix cores.
+    // v_mfma_f64_16x16x4_f64: A operand lane l = A[l & 15][l >> 4], B operand lane l = B[l >> 4][l & 15], D register g of lane l =
+    // D[(l >> 4) + 4 g][l & 15].  Output padded to 32 x 32 (2 x 2 tiles), K = 24 in 6 steps: 24 MFMAs instead of 576 FMAs per lane.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int li = ln & 15, lk = ln >> 4;
     double acc = 0.0;
-#pragma unroll 1
-    for (int j = 0; j < MAXR; j++) {
-      double y0 = 0.0, y1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < MAXR; k += 2) { y0 = fma(arow[k], XE[k * CLD + j], y0); y1 = fma(arow[k + 1], XE[(k + 1) * CLD + j], y1); }
-      const double y = (y0 + y1) + cfm * S.P[row * CLD + j];
-      const double dlt = ((row == j) ? 1.0 : 0.0) - y;
-      const bool inBlock = clamp && ((K.clampMask >> j) & 1u);
-      acc = fma(inBlock ? dlt : 0.0, inBlock ? dlt : 0.0, acc);
+    for (int tr = 0; tr < 2; tr++) {
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++) {
+        v4d d = {0.0, 0.0, 0.0, 0.0};
+        const int r = 16 * tr + li, j = 16 * tj + li;
+#pragma unroll
+        for (int ks = 0; ks < MAXR / 4; ks++) {
+          const int k = 4 * ks + lk;
+          const double av = S.G[k * CLD + (r < MAXR ? r : 0)], bv = XE[k * CLD + (j < MAXR ? j : 0)];   // A is symmetric: A[r][k] = G[k][r]
+          d = __builtin_amdgcn_mfma_f64_16x16x4f64(r < MAXR ? av : 0.0, j < MAXR ? bv : 0.0, d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int rr = 16 * tr + lk + 4 * g, jj = 16 * tj + li;
+          const bool inBlock = rr < MAXR && jj < MAXR && ((K.clampMask >> rr) & 1u) && ((K.clampMask >> jj) & 1u);
+          const double y = d[g] + cfm * S.P[(rr < MAXR ? rr : 0) * CLD + (jj < MAXR ? jj : 0)];
+          const double dlt = inBlock ? ((rr == jj) ? 1.0 : 0.0) - y : 0.0;
+          acc = fma(dlt, dlt, acc);
+        }
+      }
     }
     w.sync();
-    if (ln < MAXR) S.vec[0][ln] = clamp ? acc : 0.0;
+    S.vec[0][ln] = acc;                      // 64 partial sums in the 96 doubles of S.vec
     w.sync();
     double imp2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXR; k++) imp2 += S.vec[0][k];
+    for (int k = 0; k < 64; k++) imp2 += S.vec[0][k];
     precise = imp2 < 1e-18;
     w.sync();
   }
