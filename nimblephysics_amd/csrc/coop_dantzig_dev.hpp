@@ -106,17 +106,28 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
       if (fk >= 0) { swapProblem(k, n - 1 - atEnd); atEnd++; }
     }
   }
-  // dDot over lanes [from, to): the running sum from 0 in lane order (fastdot.cpp); every lane gets the result
-  auto seqSum = [&](double prod, int from, int to) -> double {
-    double s = 0.0;
+  // dDot over lanes [from, to): the running sum from 0 in lane order (fastdot.cpp); every lane gets the result.  The products
+  // go through LDS: 24 broadcast reads issued together and two branch-free chains of adds (a term outside its range enters as
+  // +0.0, which leaves the sum unchanged bit for bit) instead of 24 x (branch + two readlanes + select) per sum.
+  // seqSum2: s1 = sum over [0, mid), s2 = sum over [mid, to).
+  auto seqSum2 = [&](double prod, int mid, int to, double& s1, double& s2) {
+    w.sync();
+    if (ln < MAXR) C.v[2][ln] = prod;
+    w.sync();
+    double pk[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) pk[k] = C.v[2][k];
+    s1 = 0.0; s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < MAXR; k++) {
-      if (k < to) {
-        const double pk = w.bcast(prod, k);
-        s = (k >= from) ? s + pk : s;
-      }
+      s1 = s1 + (k < mid ? pk[k] : 0.0);
+      s2 = s2 + ((k >= mid && k < to) ? pk[k] : 0.0);
     }
-    return s;
+  };
+  auto seqSum = [&](double prod, int from, int to) -> double {   // from == 0 at every call site
+    double s1, s2;
+    seqSum2(prod, to, to, s1, s2);
+    return s1;
   };
   // dSolveL1 (fastlsolve.cpp): L y = rhs over the factor rows, lane = row
   auto solveL1 = [&](double rhs) -> double {
@@ -307,7 +318,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     // w[i] = A(i,C) x(C) + A(i,N) x(N) - b[i]: two running sums (lcp.cpp:877)
     {
       const double pr = on ? C.A[i * CLD + me] * x : 0.0;
-      const double s = seqSum(pr, 0, nC) + seqSum(pr, nC, nC + nN) - w.bcast(b, i);
+      double sC, sN;
+      seqSum2(pr, nC, nC + nN, sC, sN);
+      const double s = sC + sN - w.bcast(b, i);
       if (ln == i) ww = s;
     }
     DZ_ADD(1);   // w[i]
