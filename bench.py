@@ -321,6 +321,7 @@ def main():
                                    (f"; one step = one {args.rollout}-step rollout fwd+bwd (warm-started after its first step)" if args.rollout else ""),
                        "n_dofs": n, "contacts": m_rows // 3, "lcp_rows": m_rows, "worlds_per_gpu": B, "dt": md.dt,
                        "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None,
+                       "saved_record_bytes_per_world_step": int(world._L.nbl_saved_bytes(world._h, B) // B),
                        "rccl_world_size": (dist.get_world_size() if use_dist else 0),
                        "lanes_with_contact": float((st & 0x1).astype(bool).mean()),
                        "lanes_resolved_at_lcp_stage0": float((st & 0x2).astype(bool).mean()) if m_rows else None,

@@ -87,7 +87,7 @@ try:
         # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = average active lanes per VALU instruction cycle (both in quad-cycles), max 64
         lanes = C["SQ_THREAD_CYCLES_VALU"].get(k, 0.0) / act if act else 0.0
         lanes = min(lanes, 64.0)
-        flops = (2 * fma + add + mul + tr) * lanes          # lane-level flop of one launch (WPL worlds)
+        flops = (2 * fma + add + mul + tr) * lanes + mf * 2048.0    # lane-level VALU flop of one launch (WPL worlds) + 2 x 16 x 16 x 4 per f64 MFMA
         per[k] = {"fma_f64": fma, "add_f64": add, "mul_f64": mul, "trans_f64": tr, "mfma_f64": mf, "valu_total": C["SQ_INSTS_VALU"].get(k, 0.0),
                   "avg_active_lanes": round(lanes, 1), "flops_per_world": flops / WPL}
         tot_flops += flops / WPL; tot_wave_f64 += (fma + add + mul + tr) / WPL; tot_mfma += mf / WPL
