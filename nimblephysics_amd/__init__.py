@@ -7,7 +7,7 @@ from .model import (BodySpec, BoxSpec, ModelDescription, SphereSpec, atlas, box_
                     make_transform, single_pendulum)
 
 __all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
-           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "WrtMassBodyNodeEntryType", "GraphedStep"]
+           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep"]
 
 
 def __getattr__(name):
@@ -17,6 +17,9 @@ def __getattr__(name):
     if name == "WrtMassBodyNodeEntryType":
         from .mass import WrtMassBodyNodeEntryType
         return WrtMassBodyNodeEntryType
+    if name == "model_from_nimble_world":
+        from .extract import model_from_nimble_world
+        return model_from_nimble_world
     if name in ("load_urdf", "load_skel", "with_ground"):
         from . import loaders as _l
         return getattr(_l, name)

@@ -1,0 +1,121 @@
+"""Model extraction from a LIVE `nimblephysics.simulation.World`: walk the world through the
+reference's own Python bindings and build the `ModelDescription` that `nimblephysics_amd.World` uploads - so that a user who
+already holds a `nimble.simulation.World` (loaded by the reference's SkelParser / DartLoader) can switch the timestep over
+without describing the model again:
+
+    import nimblephysics as nimble, nimblephysics_amd as na
+    ref_world = nimble.loadWorld("half_cheetah.skel")
+    world = na.World(na.model_from_nimble_world(ref_world))
+
+Only bound methods are used (python/_nimblephysics/{simulation_and_neural/World.cpp, dynamics/{Skeleton,BodyNode,Joint,
+RevoluteJoint,PrismaticJoint,ShapeNode,Shape}.cpp}):
+  World      getNumSkeletons, getSkeleton, getTimeStep, getGravity, getActionSpace, getContactClippingDepth,
+             getFallbackConstraintForceMixingConstant, clone, tuneMass, getMasses
+  Skeleton   getNumBodyNodes, getBodyNode
+  BodyNode   getName, getParentBodyNode, getParentJoint, getMass, getLocalCOM, getFrictionCoeff, getNumShapeNodes, getShapeNode
+  Joint      getType, getName, getNumDofs, getTransformFromParentBodyNode, getTransformFromChildBodyNode, getAxis (revolute /
+             prismatic), getDampingCoefficient, getSpringStiffness, getRestPosition, get{Position,Velocity,ControlForce}{Lower,Upper}Limit
+  ShapeNode  getShape, getRelativeTranslation, getRelativeRotation;  Shape getType, getSize (BoxShape), getRadius (SphereShape)
+The bindings expose no getter for a body's moment of inertia (`getMomentOfInertia` takes six C++ reference arguments), so it
+is read the way the reference's own Python users read it: on a CLONE of the world every body is registered with
+`tuneMass(body, WrtMassBodyNodeEntryType.INERTIA_FULL, ...)` and `getMasses()` returns [mass, com (3), Ixx, Iyy, Izz, Ixy, Ixz,
+Iyz] per body (dart/neural/WithRespectToMass.cpp:25-140); the caller's world is left untouched.
+The nimblephysics package cannot be built in this repo's environment; tests/test_extract.py drives this walk with a duck-typed
+stand-in that exposes exactly the methods above."""
+from __future__ import annotations
+
+import numpy as np
+
+from .model import BodySpec, BoxSpec, ModelDescription
+
+_JOINT_TYPES = {"RevoluteJoint": "revolute", "PrismaticJoint": "prismatic", "FreeJoint": "free", "WeldJoint": "weld"}
+
+
+def _mat4(T) -> np.ndarray:
+    """Eigen::Isometry3s as bound by eigen_geometry_pybind.cpp (.matrix()) or a plain 4 x 4 array."""
+    M = T.matrix() if hasattr(T, "matrix") and callable(T.matrix) else T
+    return np.asarray(M, dtype=np.float64).reshape(4, 4)
+
+
+def _limit(v, lo: bool):
+    v = float(v)
+    return v if np.isfinite(v) else (-np.inf if lo else np.inf)
+
+
+def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 8, inertia_entry_type=None) -> ModelDescription:
+    """`world`: a live nimblephysics.simulation.World (or anything exposing the methods listed in the module docstring).
+    inertia_entry_type: nimblephysics.neural.WrtMassBodyNodeEntryType.INERTIA_FULL (looked up when nimblephysics is importable)."""
+    if inertia_entry_type is None:
+        try:
+            import nimblephysics as _nimble       # only when the reference package is installed
+            inertia_entry_type = _nimble.neural.WrtMassBodyNodeEntryType.INERTIA_FULL
+        except Exception:
+            inertia_entry_type = "INERTIA_FULL"
+    # moments of inertia through the mass vector of a clone (see the docstring)
+    probe = world.clone()
+    order = []
+    for si in range(probe.getNumSkeletons()):
+        sk = probe.getSkeleton(si)
+        for bi in range(sk.getNumBodyNodes()):
+            b = sk.getBodyNode(bi)
+            probe.tuneMass(b, inertia_entry_type, np.full(10, np.inf), np.full(10, -np.inf))
+            order.append((si, bi))
+    masses = np.asarray(probe.getMasses(), dtype=np.float64).reshape(len(order), 10)
+    inertia_of = {key: masses[i] for i, key in enumerate(order)}
+
+    bodies, boxes = [], []
+    for si in range(world.getNumSkeletons()):
+        sk = world.getSkeleton(si)
+        index = {}
+        for bi in range(sk.getNumBodyNodes()):                 # skeleton order = parents before children = DOF order
+            b = sk.getBodyNode(bi)
+            j = b.getParentJoint()
+            jt = j.getType()
+            if jt not in _JOINT_TYPES:
+                raise ValueError(f"{b.getName()}: joint type {jt} outside the hot-path scope (revolute, prismatic, free, weld)")
+            jtype = _JOINT_TYPES[jt]
+            parent = b.getParentBodyNode()
+            pidx = -1 if parent is None else index[parent.getName()]
+            nd = int(j.getNumDofs())
+            kw = {}
+            if jtype in ("revolute", "prismatic"):
+                axis = tuple(float(x) for x in np.asarray(j.getAxis()).reshape(3))
+                kw = dict(damping=(float(j.getDampingCoefficient(0)),), spring=(float(j.getSpringStiffness(0)),),
+                          rest=(float(j.getRestPosition(0)),),
+                          pos_lo=(_limit(j.getPositionLowerLimit(0), True),), pos_hi=(_limit(j.getPositionUpperLimit(0), False),),
+                          vel_lo=(_limit(j.getVelocityLowerLimit(0), True),), vel_hi=(_limit(j.getVelocityUpperLimit(0), False),),
+                          force_lo=(_limit(j.getControlForceLowerLimit(0), True),), force_hi=(_limit(j.getControlForceUpperLimit(0), False),))
+            else:
+                axis = (0.0, 0.0, 1.0)
+                if jtype == "free":
+                    kw = dict(damping=tuple(float(j.getDampingCoefficient(k)) for k in range(nd)),
+                              spring=tuple(float(j.getSpringStiffness(k)) for k in range(nd)),
+                              rest=tuple(float(j.getRestPosition(k)) for k in range(nd)))
+            m = inertia_of[(si, bi)]
+            bodies.append(BodySpec(b.getName(), pidx, jtype, j.getName(), axis=axis,
+                                   T_pj=_mat4(j.getTransformFromParentBodyNode()), T_cj=_mat4(j.getTransformFromChildBodyNode()),
+                                   mass=float(b.getMass()), com=tuple(float(x) for x in np.asarray(b.getLocalCOM()).reshape(3)),
+                                   inertia=tuple(float(x) for x in m[4:10]), **kw))
+            gidx = len(bodies) - 1
+            index[b.getName()] = gidx
+            for k in range(int(b.getNumShapeNodes())):
+                sn = b.getShapeNode(k)
+                shp = sn.getShape()
+                T = np.eye(4)
+                T[:3, :3] = np.asarray(sn.getRelativeRotation(), dtype=np.float64).reshape(3, 3)
+                T[:3, 3] = np.asarray(sn.getRelativeTranslation(), dtype=np.float64).reshape(3)
+                mu = float(b.getFrictionCoeff())
+                if shp.getType() == "BoxShape":
+                    boxes.append(BoxSpec(gidx, T, tuple(float(x) for x in np.asarray(shp.getSize()).reshape(3)), mu, "box"))
+                elif shp.getType() == "SphereShape":
+                    r = float(shp.getRadius())
+                    boxes.append(BoxSpec(gidx, T, (r, r, r), mu, "sphere"))
+                # meshes, capsules, ...: outside the analytic box / sphere narrow phase (dropped, like in the loaders)
+    g = tuple(float(x) for x in np.asarray(world.getGravity()).reshape(3))
+    md = ModelDescription(name, bodies, boxes, g, float(world.getTimeStep()), None, max_contacts=max_contacts if boxes else 0,
+                          contact_clipping_depth=float(world.getContactClippingDepth()),
+                          fallback_cfm=float(world.getFallbackConstraintForceMixingConstant()))
+    aspace = [int(a) for a in world.getActionSpace()]
+    if aspace != list(range(md.num_dofs)):
+        md.set_action_space(aspace)
+    return md

@@ -1,0 +1,160 @@
+"""Model extraction from a live `nimblephysics.simulation.World` (nimblephysics_amd/extract.py).  The reference package cannot be
+built here, so the walk is driven by a duck-typed stand-in that exposes EXACTLY the bound methods the walk uses (names and
+call shapes taken from python/_nimblephysics/**): a world built from one of our own descriptions must come back unchanged."""
+import copy
+
+import numpy as np
+import pytest
+
+import nimblephysics_amd as na
+from nimblephysics_amd.extract import model_from_nimble_world
+
+
+class _Iso:                      # Eigen::Isometry3s as bound by eigen_geometry_pybind.cpp
+    def __init__(self, T): self._T = np.array(T, dtype=np.float64)
+    def matrix(self): return self._T.copy()
+
+
+class _Shape:
+    def __init__(self, bx): self._bx = bx
+    def getType(self): return "SphereShape" if self._bx.shape == "sphere" else "BoxShape"
+    def getSize(self): return np.array(self._bx.size, dtype=np.float64)
+    def getRadius(self): return float(self._bx.size[0])
+
+
+class _ShapeNode:
+    def __init__(self, bx): self._bx = bx
+    def getShape(self): return _Shape(self._bx)
+    def getRelativeTranslation(self): return np.array(self._bx.T)[:3, 3].copy()
+    def getRelativeRotation(self): return np.array(self._bx.T)[:3, :3].copy()
+
+
+class _Joint:
+    TYPES = {"revolute": "RevoluteJoint", "prismatic": "PrismaticJoint", "free": "FreeJoint", "weld": "WeldJoint"}
+
+    def __init__(self, b): self._b = b
+    def getType(self): return self.TYPES[self._b.joint_type]
+    def getName(self): return self._b.joint_name
+    def getNumDofs(self): return {"free": 6, "weld": 0}.get(self._b.joint_type, 1)
+    def getTransformFromParentBodyNode(self): return _Iso(self._b.T_pj)
+    def getTransformFromChildBodyNode(self): return _Iso(self._b.T_cj)
+    def getAxis(self): return np.array(self._b.axis, dtype=np.float64)
+    def _get(self, field, k, default): v = getattr(self._b, field); return float(v[k]) if len(v) > k else default
+    def getDampingCoefficient(self, k): return self._get("damping", k, 0.0)
+    def getSpringStiffness(self, k): return self._get("spring", k, 0.0)
+    def getRestPosition(self, k): return self._get("rest", k, 0.0)
+    def getPositionLowerLimit(self, k): return self._get("pos_lo", k, -np.inf)
+    def getPositionUpperLimit(self, k): return self._get("pos_hi", k, np.inf)
+    def getVelocityLowerLimit(self, k): return self._get("vel_lo", k, -np.inf)
+    def getVelocityUpperLimit(self, k): return self._get("vel_hi", k, np.inf)
+    def getControlForceLowerLimit(self, k): return self._get("force_lo", k, -np.inf)
+    def getControlForceUpperLimit(self, k): return self._get("force_hi", k, np.inf)
+
+
+class _Body:
+    def __init__(self, md, i): self._md, self._i = md, i
+    @property
+    def _b(self): return self._md.bodies[self._i]
+    def getName(self): return self._b.name
+    def getParentJoint(self): return _Joint(self._b)
+    def getParentBodyNode(self): return None if self._b.parent < 0 else _Body(self._md, self._b.parent)
+    def getMass(self): return float(self._b.mass)
+    def getLocalCOM(self): return np.array(self._b.com, dtype=np.float64)
+    def getFrictionCoeff(self):
+        mus = [bx.mu for bx in self._md.boxes if bx.body == self._i]
+        return float(mus[0]) if mus else 1.0
+    def getNumShapeNodes(self): return sum(1 for bx in self._md.boxes if bx.body == self._i)
+    def getShapeNode(self, k): return _ShapeNode([bx for bx in self._md.boxes if bx.body == self._i][k])
+
+
+class _Skeleton:
+    def __init__(self, md, idxs): self._md, self._idxs = md, idxs
+    def getNumBodyNodes(self): return len(self._idxs)
+    def getBodyNode(self, i): return _Body(self._md, self._idxs[i])
+
+
+class StandInWorld:
+    """The slice of nimblephysics.simulation.World the extraction walks, backed by one of our descriptions: every root body
+    starts a skeleton."""
+
+    def __init__(self, md):
+        self._md = md
+        root_of = {}
+        for i, b in enumerate(md.bodies):
+            root_of[i] = i if b.parent < 0 else root_of[b.parent]
+        roots = sorted(set(root_of.values()))
+        self._skels = [[i for i in range(len(md.bodies)) if root_of[i] == r] for r in roots]
+        self._tuned = []
+
+    def clone(self): return StandInWorld(copy.deepcopy(self._md))
+    def getNumSkeletons(self): return len(self._skels)
+    def getSkeleton(self, i): return _Skeleton(self._md, self._skels[i])
+    def getTimeStep(self): return self._md.dt
+    def getGravity(self): return np.array(self._md.gravity)
+    def getActionSpace(self): return list(self._md.action_map)
+    def getContactClippingDepth(self): return self._md.contact_clipping_depth
+    def getFallbackConstraintForceMixingConstant(self): return self._md.fallback_cfm
+    def tuneMass(self, body, entry_type, upper, lower):
+        assert entry_type == "INERTIA_FULL" and len(upper) == 10 and len(lower) == 10
+        self._tuned.append(body._i)
+
+    def getMasses(self):           # WithRespectToMass::get for INERTIA_FULL entries: mass, com, Ixx Iyy Izz Ixy Ixz Iyz
+        out = []
+        for i in self._tuned:
+            b = self._md.bodies[i]
+            out += [b.mass, *b.com, *b.inertia]
+        return np.array(out, dtype=np.float64)
+
+
+def _same(a, b):
+    fa, fb = a.flat(), b.flat()
+    assert fa.keys() == fb.keys()
+    for k in fa:
+        x, y = fa[k], fb[k]
+        if isinstance(x, (str, type(None))) or isinstance(y, (str, type(None))):
+            assert x == y, k
+        else:
+            assert np.allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True), k
+
+
+@pytest.mark.parametrize("make", [lambda: na.cartpole(), lambda: na.single_pendulum(), lambda: na.box_stack(),
+                                  lambda: na.atlas("atlas20", ground=True), lambda: na.atlas("atlas33")])
+def test_extraction_round_trip(make):
+    md = make()
+    got = model_from_nimble_world(StandInWorld(md), name=md.name, max_contacts=md.max_contacts)
+    assert [b.name for b in got.bodies] == [b.name for b in md.bodies]
+    assert [b.joint_type for b in got.bodies] == [b.joint_type for b in md.bodies]
+    _same(got, md)
+    if md.has_welds():
+        _same(got.merge_welds(), md.merge_welds())
+
+
+def test_extraction_keeps_spheres_friction_action_space_and_leaves_the_world_untouched():
+    from nimblephysics_amd.model import BodySpec, BoxSpec, ModelDescription, SphereSpec, make_transform
+    I = 0.4 * 0.1 * 0.1
+    bodies = [BodySpec("slab", -1, "weld", "fix", T_pj=make_transform((0, -0.5, 0))),
+              BodySpec("ball0", -1, "free", "ball0_joint", mass=1.0, inertia=(I, I, I, 0, 0, 0)),
+              BodySpec("arm", 1, "revolute", "arm_joint", axis=(0, 0, 1), T_pj=make_transform((0.15, 0, 0)), T_cj=make_transform((-0.15, 0, 0)),
+                       mass=0.5, inertia=(0.002, 0.002, 0.002, 0, 0, 0), damping=(0.2,), pos_lo=(-1.0,), pos_hi=(2.0,)),
+              BodySpec("ball1", -1, "free", "ball1_joint", mass=2.0, inertia=(2 * I, 2 * I, 2 * I, 0, 0, 0))]
+    boxes = [BoxSpec(0, np.eye(4), (4.0, 1.0, 4.0), 0.3), SphereSpec(1, np.eye(4), 0.1, 0.8), SphereSpec(2, make_transform((0.05, 0, 0)), 0.1, 0.8),
+             SphereSpec(3, np.eye(4), 0.1, 0.8)]
+    md = ModelDescription("balls", bodies, boxes, max_contacts=8)
+    md.set_action_space([5, 6, 12])
+    w = StandInWorld(md)
+    got = model_from_nimble_world(w, name=md.name, max_contacts=md.max_contacts)
+    assert w._tuned == []                                   # the mass vector was registered on a clone only
+    assert [bx.shape for bx in got.boxes] == [bx.shape for bx in md.boxes] and got.boxes[0].mu == 0.3
+    assert list(got.action_map) == [5, 6, 12]
+    _same(got, md)
+
+
+def test_unsupported_joint_types_raise():
+    md = na.cartpole()
+    w = StandInWorld(md)
+    _Joint.TYPES = dict(_Joint.TYPES, revolute="BallJoint")
+    try:
+        with pytest.raises(ValueError):
+            model_from_nimble_world(w)
+    finally:
+        _Joint.TYPES = dict(_Joint.TYPES, revolute="RevoluteJoint")
