@@ -110,6 +110,13 @@ typedef struct nbl_model_desc {
    * [n_boxes] NBL_SHAPE_BOX | NBL_SHAPE_SPHERE.  A sphere's radius is box_size[3*i]; sphere-box, box-sphere and
    * sphere-sphere pairs follow collideSphereBox / collideBoxSphere / collideSphereSphere (DARTCollide.cpp:1482-1880). */
   const int32_t* box_shape;
+
+  /* ---- restitution (appended; NULL = 0 everywhere, the reference's default BodyNodeAspect.hpp:48) ----
+   * [n_boxes] restitution coefficient of the owning body.  A contact bounces when e = e_A * e_B > 1e-3 and e times its approach
+   * speed exceeds 0.1 m/s: b_normal += min(e * b_normal, 100) (ContactConstraint.cpp:95-110, 395-442); the backward pass carries
+   * the bounce diagonals 1 + e and the reference's bounce approximation of the position Jacobians
+   * (BackpropSnapshot.cpp:1131-1226). */
+  const double* box_restitution;
 } nbl_model_desc;
 
 #define NBL_SHAPE_BOX 0

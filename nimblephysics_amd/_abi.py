@@ -67,4 +67,5 @@ class ModelDesc(C.Structure):
         ("contact_clipping_depth", C.c_double),
         ("fallback_cfm", C.c_double),
         ("box_shape", _pi),
+        ("box_restitution", _pd),
     ]

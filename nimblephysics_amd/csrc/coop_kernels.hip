@@ -255,6 +255,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   const int bxA = (int)svAt(saved, r0c + CR_BOXA, B, b), bxB = (int)svAt(saved, r0c + CR_BOXB, B, b);
   const double muTab = cm->boxes[ln < MAX_BOXES ? ln : 0].mu;       // collider -> mu, looked up with ds_bpermute
   const double gMine = gvn[(int64_t)dof * B + b];   // cotangent of v' for this lane's DOF
+  const double restRaw = svAt(saved, lay.rest + row / 3, B, b);   // restitution coefficient of this row's contact if it bounced
   double Acol[MAXR];
 #pragma unroll
   for (int i = 0; i < MAXR; i++) Acol[i] = dn[lay.A + i * MAX_ROWS + row];
@@ -423,6 +424,9 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
     be[2] = clamp ? fbar - (t2 + t2f + cfm * mu) : 0.0;
   }
   if (precise) { al[1] = 0.0; be[1] = 0.0; al[2] = 0.0; be[2] = 0.0; }   // -Q^+ dQ Q^+ b alone
+  // bounce diagonals (CGGM.cpp:770, BackpropSnapshot.cpp:3099-3146): b = -beta A_c^T v_pre with beta = 1 + e on the normal rows that
+  // bounced, so the adjoint of b reaches v_pre (and the contact geometry through A_c^T v_pre) scaled by beta; the pairs of dQ are not
+  const double muB = (rowOn && (ln % 3) == 0) ? mu * (1.0 + restRaw) : mu;
   double beE[3];
   for (int k = 0; k < 3; k++) beE[k] = spread(be[k]);
   const double fcE = spread(xRaw);
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   w.sync();
   if (ln < MAXR) {
     for (int k = 0; k < 3; k++) { bc[k * MAXR + ln] = clamp ? al[k] : 0.0; bc[(3 + k) * MAXR + ln] = beE[k]; }
-    bc[6 * MAXR + ln] = clamp ? mu : 0.0;
+    bc[6 * MAXR + ln] = clamp ? muB : 0.0;
   }
   w.sync();
   if (ln < n) {
@@ -451,9 +455,111 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   // coefficients of z_row on the bases [lambda1, v_pre, p1, p2, p3, s1, s2, s3]
   if (ln < MAX_ROWS) {
     double cf[8];
-    cf[0] = fcE; cf[1] = clamp ? -mu : 0.0;
+    cf[0] = fcE; cf[1] = clamp ? -muB : 0.0;
     for (int k = 0; k < 3; k++) { cf[2 + k] = clamp ? al[k] : 0.0; cf[5 + k] = beE[k]; }
     for (int k = 0; k < 8; k++) lws[(int64_t)(LB_COEF + ln * 8 + k) * B + b] = cf[k];
+  }
+}
+
+// The reference's bounce approximation of the position Jacobians (BackpropSnapshot::getBounceApproximationJacobian :1131-1226):
+// posPos and velPos are multiplied from the right by X, the matrix closest to the identity with a_i^T X a_i = -e_i for the
+// bouncing constraints (clamping normal rows whose contact bounced; a_i = their column of A_c, e_i their restitution coefficient).
+// The reference sets this up as a least-squares problem with an (n^2 x nb) matrix W, W[:, i] = vec(a_i a_i^T), and solves it with a
+// complete orthogonal decomposition; its minimum-norm solution has the closed form
+//      X = I - sum_i c_i a_i a_i^T,   c = G^+ (e + |a|^2),   G_ij = (a_i . a_j)^2   (G = W^T W, |a_i|^2 = W[:, i] . vec(I)),
+// so that X y = y - A_b (c o (A_b^T y)): two small products and one pseudo-inverse of at most 8 x 8 (coopPinv on masked lanes).
+// One world per wavefront: computes y_q = posPos^T gq' and y_v = velPos^T gq' of the position integration (lane = DOF; the free
+// joints' exp / log VJP like in the reverse sweep), and ADDS  X y_q - y_q  to the extra position cotangent LB_QX, writes
+// X y_v - y_v to the extra velocity cotangent LB_VX; k_bwd_final_coop folds both in before clipLossGradientsToBounds.
+__global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* __restrict__ bodies, int64_t B,
+                                                   const double* __restrict__ savedC, SavedLayout lay,
+                                                   const double* __restrict__ gnext, double* __restrict__ lws) {
+  double* saved = const_cast<double*>(savedC);   // read only here (svAt / denseOf take the writable type)
+  __shared__ CoopLds S;
+  __shared__ double yq[MAX_DOF_CONTACT], yv[MAX_DOF_CONTACT];
+  const DevWave w;
+  const int ln = w.lane();
+  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
+  if (b >= mdl.b1) return;
+  const int n = mdl.n;
+  const int row = ln < MAXR ? ln : 0;
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  const double cv = svAt(saved, lay.cls + row, B, b);
+  const double eRow = svAt(saved, lay.rest + row / 3, B, b);
+  const bool bouncing = ln < m && (ln % 3) == 0 && cv == 1.0 && eRow > 0.0;
+  const uint32_t bmask = (uint32_t)w.ballot(bouncing);
+  if (bmask == 0u) {                                    // nothing bounced in this world: X = I
+    if (ln < n) lws[(int64_t)(LB_VX + ln) * B + b] = 0.0;
+    return;
+  }
+  const double* dn = denseOf(saved, lay, B, b);
+  const double* q = saved;
+  const double* v = saved + (int64_t)n * B;
+  // ---- y_q = posPos^T gq', y_v = velPos^T gq' (GenericJoint.hpp:1428-1444: identity and dt; FreeJoint.cpp:922-929 by reverse mode) ----
+  if (ln < mdl.nb) {
+    const DevBody& bd = bodies[ln];
+    const int o = bd.dofOff;
+    if (bd.jtype != JT_FREE) {
+      const double g = gnext[(int64_t)o * B + b];
+      yq[o] = g; yv[o] = mdl.dt * g;
+    } else {
+      const V3 r = mk3(q[(int64_t)(o + 0) * B + b], q[(int64_t)(o + 1) * B + b], q[(int64_t)(o + 2) * B + b]);
+      const V3 wv = mk3(v[(int64_t)(o + 0) * B + b], v[(int64_t)(o + 1) * B + b], v[(int64_t)(o + 2) * B + b]);
+      const V3 vl = mk3(v[(int64_t)(o + 3) * B + b], v[(int64_t)(o + 4) * B + b], v[(int64_t)(o + 5) * B + b]);
+      const V3 grn = mk3(gnext[(int64_t)(o + 0) * B + b], gnext[(int64_t)(o + 1) * B + b], gnext[(int64_t)(o + 2) * B + b]);
+      const V3 gpn = mk3(gnext[(int64_t)(o + 3) * B + b], gnext[(int64_t)(o + 4) * B + b], gnext[(int64_t)(o + 5) * B + b]);
+      const M3 R = expMapRot(r), E = expMapRot(mdl.dt * wv);
+      const M3 Rn = mul(R, E);
+      const M3 Rnb = logMap_vjp(Rn, grn);
+      M3 Rb = mulABt(Rnb, E);
+      const M3 Eb = mulAtB(R, Rnb);
+      const V3 vdt = mdl.dt * vl;
+      Rb.m[0] += gpn.x * vdt.x; Rb.m[1] += gpn.x * vdt.y; Rb.m[2] += gpn.x * vdt.z;
+      Rb.m[3] += gpn.y * vdt.x; Rb.m[4] += gpn.y * vdt.y; Rb.m[5] += gpn.y * vdt.z;
+      Rb.m[6] += gpn.z * vdt.x; Rb.m[7] += gpn.z * vdt.y; Rb.m[8] += gpn.z * vdt.z;
+      const V3 posr = expMapRot_vjp(r, Rb);
+      const V3 velw = mdl.dt * expMapRot_vjp(mdl.dt * wv, Eb);
+      const V3 vell = mdl.dt * tmul(R, gpn);
+      yq[o] = posr.x; yq[o + 1] = posr.y; yq[o + 2] = posr.z; yq[o + 3] = gpn.x; yq[o + 4] = gpn.y; yq[o + 5] = gpn.z;
+      yv[o] = velw.x; yv[o + 1] = velw.y; yv[o + 2] = velw.z; yv[o + 3] = vell.x; yv[o + 4] = vell.y; yv[o + 5] = vell.z;
+    }
+  }
+  w.sync();
+  // ---- lane = bouncing row i: t = a_i . y, |a_i|^2, and its column of G ----
+  double tq = 0.0, tv = 0.0, nrm2 = 0.0;
+  double gcol[MAXR];
+#pragma unroll
+  for (int k = 0; k < MAXR; k++) gcol[k] = 0.0;
+  if (bouncing) {
+    for (int d = 0; d < n; d++) {
+      const double a = dn[lay.aall + d * MAX_ROWS + row];
+      tq = fma(a, yq[d], tq); tv = fma(a, yv[d], tv); nrm2 = fma(a, a, nrm2);
+    }
+  }
+#pragma unroll 1
+  for (int k = 0; k < MAXR; k += 3) {                 // candidates: the normal rows
+    if (!((bmask >> k) & 1u)) continue;
+    double dotik = 0.0;
+    if (bouncing) for (int d = 0; d < n; d++) dotik = fma(dn[lay.aall + d * MAX_ROWS + row], dn[lay.aall + d * MAX_ROWS + k], dotik);
+#pragma unroll
+    for (int kk = 0; kk < MAXR; kk++) if (kk == k) gcol[kk] = bouncing ? dotik * dotik : 0.0;     // G[k][i] (symmetric)
+  }
+  coopPinv(w, gcol, S, __builtin_popcount(bmask));
+  const double cRow = coopPinvApply<DevWave, false>(w, S, bouncing ? eRow + nrm2 : 0.0, 0);
+  // ---- (X - I) y = -A_b (c o t)   (lane = DOF) ----
+  w.sync();
+  if (ln < MAXR) { S.vec[1][ln] = bouncing ? cRow * tq : 0.0; S.vec[2][ln] = bouncing ? cRow * tv : 0.0; }
+  w.sync();
+  if (ln < n) {
+    double dq = 0.0, dv = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < MAXR; k += 3) {
+      if (!((bmask >> k) & 1u)) continue;
+      const double a = dn[lay.aall + ln * MAX_ROWS + k];
+      dq = fma(-a, S.vec[1][k], dq); dv = fma(-a, S.vec[2][k], dv);
+    }
+    lws[(int64_t)(LB_QX + ln) * B + b] += dq;
+    lws[(int64_t)(LB_VX + ln) * B + b] = dv;
   }
 }
 
@@ -569,6 +675,18 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
     double rel = 0;
     if (bA >= 0) rel -= dot(F, ld6(Vw + 6 * bA));
     if (bB >= 0) rel += dot(F, ld6(Vw + 6 * bB));
+    if (kk == 0) {
+      // restitution (ContactConstraint.cpp:95-110, 395-442 / 470-512; penetration correction off): e = e_A e_B; the contact bounces
+      // when e > 1e-3 and e * (approach speed) > 0.1: b_0 += min(e b_0, 100).  The coefficient of the contacts that bounced
+      // (ContactConstraint::getCoefficientOfRestitution, 0 otherwise) goes to the record for the backward pass.
+      const double eR = cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].restitution * cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].restitution;
+      double coeff = 0.0;
+      if (eR > 1e-3) {
+        const double rv = rel * eR;
+        if (rv > 1e-1) { rel += rv > 1e+2 ? 1e+2 : rv; coeff = eR; }
+      }
+      svAt(saved, lay.rest + ci, B, b) = coeff;
+    }
     svAt(saved, lay.b + row, B, b) = rel;
     // constraint forces in joint space (DCC::getConstraintForces): A_c[i] = sigma_i s_i . F
     for (int i = 0; i < nb; i++) {

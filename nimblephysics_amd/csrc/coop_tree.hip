@@ -559,7 +559,10 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel m
   double lam[6];
   const V6 Ww = minvSweepsWorld(c, wb, [&](int d) -> double { return c.dt * gvp(d); }, lam);
   NBL_PHASE(24);
-  reverseSweepWorld(c, wb, Ww, lam, q, v, tau, gnext, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
+  // with bouncing contacts the reference multiplies velPos by its bounce approximation: the correction to velPos^T gq' comes from
+  // k_bwd_bounce as an extra velocity cotangent (the one to posPos^T gq' is already inside LB_QX)
+  auto gvFinal = [&](int d) -> double { return gvp(d) + ((lws && mdl.hasBounce) ? lws[(int64_t)(LB_VX + d) * B + b] : 0.0); };
+  reverseSweepWorld(c, wb, Ww, lam, q, v, tau, gnext, gvFinal, qx, gstate, gstate + (int64_t)n * B, gaction);
   NBL_PHASE(27);
   if (lamOut && wb.on) {   // lambda = dL/dtau on every DOF, where the one-world-per-lane kernels leave it (k_bwd_inertia reads it)
     const int nd = c.bodies[c.lane].ndof;

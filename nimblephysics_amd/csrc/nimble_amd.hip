@@ -36,11 +36,11 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int NBL_MAX_SLICES = 8;
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_BWD_BOUNCE, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
                                            "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
                                            "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop", "k_step_forward_coop", "k_bwd_recompute_coop",
-                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final"};
+                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final", "k_bwd_bounce"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -282,6 +282,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       if (bx.shape != NBL_SHAPE_BOX && bx.shape != NBL_SHAPE_SPHERE) return fail(NBL_E_UNSUPPORTED, "collider shape outside the device path (box, sphere)");
       for (int k = 0; k < 3; k++) bx.half[k] = bx.shape == NBL_SHAPE_SPHERE ? d->box_size[3 * i] : 0.5 * d->box_size[3 * i + k];   // sphere: radius
       bx.mu = d->box_mu[i];
+      bx.restitution = d->box_restitution ? d->box_restitution[i] : 0.0;
+      if (!(bx.restitution >= 0.0)) return fail(NBL_E_BADARG, "negative restitution coefficient");
       if (!(bx.mu >= 0.0)) return fail(NBL_E_BADARG, "negative friction coefficient");   // mu <= 1e-3: frictionless contacts (one live row)
     }
     for (int i = 0; i + 1 < d->n_boxes; i++)
@@ -307,11 +309,11 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     SavedLayout& L = m->lay;
     const int n = d->n_dofs;
     L.n = n; L.q = 0; L.v = n; L.tau = 2 * n;
-    if (!hasContact) { L.vpre = L.w = L.nc = L.contacts = L.x = L.b = L.cls = L.cfm = L.pflag = -1; L.total = 3 * n;
+    if (!hasContact) { L.vpre = L.w = L.nc = L.contacts = L.x = L.b = L.cls = L.cfm = L.pflag = L.rest = -1; L.total = 3 * n;
                        L.A = L.massed = L.aall = L.pinv = -1; L.dense = 0; }
     else {
       L.vpre = 3 * n; L.w = 4 * n; L.nc = 5 * n; L.contacts = L.nc + 1; L.x = L.contacts + MAX_CONTACTS * CR_SIZE;
-      L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.pflag = L.cfm + 1; L.total = L.pflag + 1;
+      L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.pflag = L.cfm + 1; L.rest = L.pflag + 1; L.total = L.rest + MAX_CONTACTS;
       L.A = 0; L.massed = L.A + MAX_ROWS * MAX_ROWS; L.aall = L.massed + n * MAX_ROWS; L.pinv = L.aall + n * MAX_ROWS;
       L.dense = L.pinv + MAX_ROWS * MAX_ROWS;
     }
@@ -369,6 +371,14 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
   if (const char* e2 = getenv("NBL_LCP_LANES")) m->lcpLanes = atoi(e2);
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
+  m->mdl.hasBounce = 0; m->mdl.pad2 = 0;
+  if (hasContact)
+    for (int pi = 0; pi < hc.nPairs; pi++)
+      if (hc.boxes[hc.pairA[pi]].restitution * hc.boxes[hc.pairB[pi]].restitution > 1e-3) m->mdl.hasBounce = 1;
+  if (m->mdl.hasBounce && !(m->coopTree && m->coop && m->coopFinal && m->coopCascade)) {
+    nbl_model_destroy(m);
+    return fail(NBL_E_UNSUPPORTED, "restitution needs the wavefront-per-world kernels (the NBL_COOP* switches are off or the model does not fit them)");
+  }
   m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.b0 = 0; m->mdl.b1 = 0;   // mdl.pad: worlds per wavefront, set above
   if (const char* e9 = getenv("NBL_SLICES")) m->slices = atoi(e9);
   m->mdl.maxLevel = 0; m->mdl.maxRank = 0;
@@ -606,6 +616,9 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
       } else
         TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
                                           m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
+      if (mdl.hasBounce)
+        TIMED(K_BWD_BOUNCE, hipLaunchKernelGGL(k_bwd_bounce, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dBodies, B, (const double*)saved, m->lay,
+                                               grad_next_state, lws));
       if (m->coopTree && !m->coopFinal) {
         TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace));
         TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,

@@ -12,7 +12,7 @@ RevoluteJoint,PrismaticJoint,ShapeNode,Shape}.cpp}):
   World      getNumSkeletons, getSkeleton, getTimeStep, getGravity, getActionSpace, getContactClippingDepth,
              getFallbackConstraintForceMixingConstant, clone, tuneMass, getMasses
   Skeleton   getNumBodyNodes, getBodyNode
-  BodyNode   getName, getParentBodyNode, getParentJoint, getMass, getLocalCOM, getFrictionCoeff, getNumShapeNodes, getShapeNode
+  BodyNode   getName, getParentBodyNode, getParentJoint, getMass, getLocalCOM, getFrictionCoeff, getRestitutionCoeff, getNumShapeNodes, getShapeNode
   Joint      getType, getName, getNumDofs, getTransformFromParentBodyNode, getTransformFromChildBodyNode, getAxis (revolute /
              prismatic), getDampingCoefficient, getSpringStiffness, getRestPosition, get{Position,Velocity,ControlForce}{Lower,Upper}Limit
   ShapeNode  getShape, getRelativeTranslation, getRelativeRotation;  Shape getType, getSize (BoxShape), getRadius (SphereShape)
@@ -105,11 +105,12 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
                 T[:3, :3] = np.asarray(sn.getRelativeRotation(), dtype=np.float64).reshape(3, 3)
                 T[:3, 3] = np.asarray(sn.getRelativeTranslation(), dtype=np.float64).reshape(3)
                 mu = float(b.getFrictionCoeff())
+                e = float(b.getRestitutionCoeff())
                 if shp.getType() == "BoxShape":
-                    boxes.append(BoxSpec(gidx, T, tuple(float(x) for x in np.asarray(shp.getSize()).reshape(3)), mu, "box"))
+                    boxes.append(BoxSpec(gidx, T, tuple(float(x) for x in np.asarray(shp.getSize()).reshape(3)), mu, "box", e))
                 elif shp.getType() == "SphereShape":
                     r = float(shp.getRadius())
-                    boxes.append(BoxSpec(gidx, T, (r, r, r), mu, "sphere"))
+                    boxes.append(BoxSpec(gidx, T, (r, r, r), mu, "sphere", e))
                 # meshes, capsules, ...: outside the analytic box / sphere narrow phase (dropped, like in the loaders)
     g = tuple(float(x) for x in np.asarray(world.getGravity()).reshape(3))
     md = ModelDescription(name, bodies, boxes, g, float(world.getTimeStep()), None, max_contacts=max_contacts if boxes else 0,

@@ -138,7 +138,7 @@ def with_ground(model, ground):
         nbdy.parent = b.parent + nb if b.parent >= 0 else -1
         bodies.append(nbdy)
     for bx in ground.boxes:
-        boxes.append(BoxSpec(bx.body + nb if bx.body >= 0 else -1, bx.T, bx.size, bx.mu, bx.shape))
+        boxes.append(BoxSpec(bx.body + nb if bx.body >= 0 else -1, bx.T, bx.size, bx.mu, bx.shape, bx.restitution))
     return ModelDescription(model.name + "_ground", bodies, boxes, model.gravity, model.dt, None, max_contacts=8)
 
 

@@ -92,6 +92,7 @@ class BoxSpec:
     size: Sequence[float]
     mu: float = 1.0
     shape: str = "box"
+    restitution: float = 0.0   # BodyNode restitution coefficient of the owning body (default 0: no bounce)
 
 
 def SphereSpec(body: int, T: np.ndarray, radius: float, mu: float = 1.0) -> "BoxSpec":
@@ -225,11 +226,11 @@ class ModelDescription:
         boxes = []
         for bx in self.boxes:
             if bx.body < 0:
-                boxes.append(BoxSpec(-1, bx.T.copy(), tuple(bx.size), bx.mu, bx.shape))
+                boxes.append(BoxSpec(-1, bx.T.copy(), tuple(bx.size), bx.mu, bx.shape, bx.restitution))
             else:
                 t = target[bx.body]
                 Tb = T_in_target[bx.body] @ bx.T
-                boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu, bx.shape))
+                boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu, bx.shape, bx.restitution))
         m = ModelDescription(self.name, out, boxes, self.gravity, self.dt, self._action_map, self.max_contacts,
                              self.contact_clipping_depth, self.fallback_cfm)
         return m
@@ -291,6 +292,7 @@ class ModelDescription:
         a["box_size"] = np.array([bx.size for bx in self.boxes], np.float64).reshape(nbx, 3)
         a["box_mu"] = np.array([bx.mu for bx in self.boxes], np.float64).reshape(nbx)
         a["box_shape"] = np.array([SHAPE_CODES[bx.shape] for bx in self.boxes], np.int32).reshape(nbx)
+        a["box_restitution"] = np.array([bx.restitution for bx in self.boxes], np.float64).reshape(nbx)
         a["action_map"] = np.array(self.action_map, np.int32)
         return a
 
@@ -312,7 +314,7 @@ class ModelDescription:
         for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape"):
             setattr(d, k, pi(a[k]))
         for k in ("T_pj", "T_cj", "axis", "mass", "com", "inertia", "damping", "spring", "rest", "pos_lo", "pos_hi",
-                  "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu"):
+                  "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu", "box_restitution"):
             setattr(d, k, pd(a[k]))
         d.gravity = (C.c_double * 3)(*self.gravity)
         d.dt = self.dt
@@ -333,7 +335,8 @@ class ModelDescription:
             "max_contacts": self.max_contacts, "contact_clipping_depth": self.contact_clipping_depth,
             "fallback_cfm": self.fallback_cfm, "bodies": [body(b) for b in self.bodies],
             "boxes": [{"body": bx.body, "T": np.asarray(bx.T).tolist(), "size": list(bx.size), "mu": bx.mu,
-                       **({} if bx.shape == "box" else {"shape": bx.shape})} for bx in self.boxes],
+                       **({} if bx.shape == "box" else {"shape": bx.shape}),
+                       **({} if bx.restitution == 0.0 else {"restitution": bx.restitution})} for bx in self.boxes],
         }
 
     @staticmethod
@@ -344,7 +347,7 @@ class ModelDescription:
             b["T_pj"] = np.array(b["T_pj"], dtype=np.float64)
             b["T_cj"] = np.array(b["T_cj"], dtype=np.float64)
             bodies.append(BodySpec(**b))
-        boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0), bx.get("shape", "box")) for bx in d.get("boxes", [])]
+        boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0), bx.get("shape", "box"), bx.get("restitution", 0.0)) for bx in d.get("boxes", [])]
         return ModelDescription(d["name"], bodies, boxes, d.get("gravity", (0, -9.81, 0)), d.get("dt", 1e-3),
                                 d.get("action_map"), d.get("max_contacts", 0), d.get("contact_clipping_depth", 0.03),
                                 d.get("fallback_cfm", 1e-4))

@@ -36,6 +36,7 @@ struct ContactResult {
   MatX E;                          // numUpperBound x numClamping
   VecX fc;                         // clamping constraint impulses
   s_t cfm = 0;
+  VecX restCoeff;                  // per LCP row: ContactConstraint::getCoefficientOfRestitution (e if the contact bounced, else 0; 0 on friction rows)
   bool ignoreFriction = false, standardized = false;
   uint32_t status = 0;
 };
@@ -318,6 +319,7 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   out.m = mrows;
   out.A = MatX(mrows, mrows);
   out.b.assign(mrows, 0.0); out.lo.assign(mrows, 0.0); out.hi.assign(mrows, 0.0);
+  out.restCoeff.clear();
   out.findex.assign(mrows, -1);
   out.massed = MatX(n, mrows);
   out.Aall = MatX(n, mrows);
@@ -329,6 +331,19 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     if (ct.bodyA >= 0) rel -= dot(out.JA[r], kinPre[ct.bodyA].V);
     if (ct.bodyB >= 0) rel -= dot(out.JB[r], kinPre[ct.bodyB].V);
     out.b[r] = rel;
+    out.restCoeff.push_back(0.0);
+    if (out.rowDir[r] == 0) {
+      // restitution (ContactConstraint.cpp:95-110 ctor, :395-442 / :470-512 getInformation; penetration correction off,
+      // World.cpp:87): e = e_A e_B; the contact bounces when e > 1e-3 and e * (approach speed) > 0.1, b_0 += min(e b_0, 100)
+      const s_t e = m.boxes[ct.boxA].restitution * m.boxes[ct.boxB].restitution;
+      if (e > 1e-3) {
+        const s_t restitutionVel = rel * e;
+        if (restitutionVel > 1e-1) {
+          out.b[r] += restitutionVel > 1e+2 ? 1e+2 : restitutionVel;
+          out.restCoeff[r] = e;                               // getCoefficientOfRestitution(): only when it really bounced
+        }
+      }
+    }
     if (out.rowDir[r] == 0) { out.lo[r] = 0.0; out.hi[r] = INFINITY; out.findex[r] = -1; }
     else {
       s_t f = mu[out.rowContact[r]];
@@ -651,6 +666,33 @@ inline MatX codSolveMat(const MatX& Q, const MatX& B) {
 inline MatX addX(const MatX& a, const MatX& b, s_t sb = 1.0) { MatX o = a; for (size_t i = 0; i < o.d.size(); i++) o.d[i] += sb * b.d[i]; return o; }
 inline MatX scaleX(const MatX& a, s_t s) { MatX o = a; for (auto& v : o.d) v *= s; return o; }
 
+
+// BackpropSnapshot::getBounceApproximationJacobian (:1131-1226), restated literally: with A_b = the A_c columns of the clamping
+// rows that bounced (restitution coefficient > 0), W[(j n + k), i] = a_i(j) a_i(k), center = vec(I):
+//   q = center - (W^T).completeOrthogonalDecomposition().solve(restitutionDiagonals + W^T center),  X.col(i) = q[i n .. i n + n).
+// posPos and velPos are multiplied by X from the right (:1304-1305, :1372-1373).  Identity when nothing bounced.
+inline MatX bounceApproximationJacobian(const Model& m, const ContactResult& cr) {
+  const int n = m.n;
+  std::vector<int> rows;
+  for (int j = 0; j < cr.m; j++) if (cr.rowClass.size() && cr.rowClass[j] == RC_CLAMPING && cr.restCoeff[j] > 0) rows.push_back(j);
+  const int nb = (int)rows.size();
+  if (nb == 0) return identityX(n);
+  MatX Wt(nb, n * n);
+  VecX rhs(nb, 0.0), center(n * n, 0.0);
+  for (int i = 0; i < n; i++) center[i * n + i] = 1.0;
+  for (int i = 0; i < nb; i++) {
+    for (int j = 0; j < n; j++)
+      for (int k = 0; k < n; k++) Wt(i, j * n + k) = cr.Aall(j, rows[i]) * cr.Aall(k, rows[i]);
+    s_t wc = 0;
+    for (int j = 0; j < n * n; j++) wc += Wt(i, j) * center[j];
+    rhs[i] = cr.restCoeff[rows[i]] + wc;
+  }
+  VecX y = codSolve(Wt, rhs);          // minimum-norm solution of the under-determined system, like Eigen's COD
+  MatX X(n, n);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) X(j, i) = center[i * n + j] - y[i * n + j];
+  return X;
+}
 // getControlForceVelJacobian / getVelVelJacobian / getPosVelJacobian with clamping constraints
 // (BackpropSnapshot.cpp:482-574, 643-759, 762-821, 980-1066, 2723-2774, 2889-3039, 3088-3146, 3657-3747)
 inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art, const s_t* q,
@@ -690,16 +732,20 @@ inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const 
   VecX bvec(nc);
   for (int i = 0; i < nc; i++) bvec[i] = cr.b[clampRows[i]];
 
-  // ---- dB for the three wrts (getJacobianOfLCPOffsetClampingSubset; bounce diagonals = 1) ----
+  // ---- dB for the three wrts (getJacobianOfLCPOffsetClampingSubset :3088-3146) ----
+  // bounce diagonals: 1 + restitution coefficient of the clamping row (CGGM.cpp:770, getBounceDiagonals)
+  VecX bounce(nc, 1.0);
+  for (int i = 0; i < nc; i++) bounce[i] = 1.0 + cr.restCoeff[clampRows[i]];
+  auto scaleRows = [&](MatX M_) { for (int i = 0; i < M_.r; i++) for (int k = 0; k < M_.c; k++) M_(i, k) *= bounce[i]; return M_; };
   MatX dvPre_dv = addX(I, scaleX(matmul(Minv, addX(addX(dCdv, D), K, dt)), dt), -1.0);
-  MatX dB_vel = scaleX(matmul(AcT, dvPre_dv), -1.0);
-  MatX dB_force = scaleX(matmul(AcT, Minv), -dt);
+  MatX dB_vel = scaleRows(scaleX(matmul(AcT, dvPre_dv), -1.0));
+  MatX dB_force = scaleRows(scaleX(matmul(AcT, Minv), -dt));
   VecX f(n);
   for (int i = 0; i < n; i++) f[i] = tau[i] - C[i] - m.damping[i] * v[i] - m.spring[i] * (q[i] - m.rest[i] + dt * v[i]);
   MatX dMinv_f = jacMinv(f);
   MatX dAcT_vf = jacClampingT(vPre);
   MatX inner = addX(addX(dMinv_f, matmul(Minv, dCdq), -1.0), matmul(Minv, K), -1.0);
-  MatX dB_pos = scaleX(addX(dAcT_vf, scaleX(matmul(AcT, inner), dt)), -1.0);
+  MatX dB_pos = scaleRows(scaleX(addX(dAcT_vf, scaleX(matmul(AcT, inner), dt)), -1.0));
 
   // ---- dF_c (getJacobianOfConstraintForce) ----
   MatX dFc_vel = codSolveMat(Q, dB_vel), dFc_force = codSolveMat(Q, dB_force);

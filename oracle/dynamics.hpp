@@ -25,6 +25,7 @@ struct BoxCollider {
   Vec3 size;
   s_t mu;
   int shape;  // NBL_SHAPE_BOX | NBL_SHAPE_SPHERE (radius = size.x)
+  s_t restitution = 0;   // BodyNode::getRestitutionCoeff of the owning body
 };
 
 struct Model {
@@ -113,6 +114,7 @@ inline Model buildModel(const nbl_model_desc* d) {
     bc.size = mk3(d->box_size[3 * i], d->box_size[3 * i + 1], d->box_size[3 * i + 2]);
     bc.mu = d->box_mu[i];
     bc.shape = d->box_shape ? d->box_shape[i] : NBL_SHAPE_BOX;
+    bc.restitution = d->box_restitution ? d->box_restitution[i] : 0.0;
     m.boxes.push_back(bc);
   }
   m.maxContacts = d->max_contacts;

@@ -140,7 +140,12 @@ void stepJacobians(Oracle& o, MatX& posPos, MatX& velPos, MatX& posVel, MatX& ve
   MatX dCdq = jacobianOfC(m, kin, s.q.data(), s.v.data(), false);
   MatX dCdv = jacobianOfC(m, kin, s.q.data(), s.v.data(), true);
 
-  posJacobians(m, s.q.data(), s.v.data(), dt, posPos, velPos);  // bounce approximation = identity (restitution 0)
+  posJacobians(m, s.q.data(), s.v.data(), dt, posPos, velPos);
+  if (s.contact.m > 0 && !s.contact.restCoeff.empty()) {   // BackpropSnapshot.cpp:1304-1305, 1372-1373
+    MatX X = bounceApproximationJacobian(m, s.contact);
+    posPos = matmul(posPos, X);
+    velPos = matmul(velPos, X);
+  }
 
   forceVel = MatX(n, n); velVel = MatX(n, n); posVel = MatX(n, n);
   const ContactResult& cr = s.contact;

@@ -63,6 +63,9 @@ class _Body:
     def getFrictionCoeff(self):
         mus = [bx.mu for bx in self._md.boxes if bx.body == self._i]
         return float(mus[0]) if mus else 1.0
+    def getRestitutionCoeff(self):
+        es = [bx.restitution for bx in self._md.boxes if bx.body == self._i]
+        return float(es[0]) if es else 0.0
     def getNumShapeNodes(self): return sum(1 for bx in self._md.boxes if bx.body == self._i)
     def getShapeNode(self, k): return _ShapeNode([bx for bx in self._md.boxes if bx.body == self._i][k])
 
@@ -137,7 +140,7 @@ def test_extraction_keeps_spheres_friction_action_space_and_leaves_the_world_unt
               BodySpec("arm", 1, "revolute", "arm_joint", axis=(0, 0, 1), T_pj=make_transform((0.15, 0, 0)), T_cj=make_transform((-0.15, 0, 0)),
                        mass=0.5, inertia=(0.002, 0.002, 0.002, 0, 0, 0), damping=(0.2,), pos_lo=(-1.0,), pos_hi=(2.0,)),
               BodySpec("ball1", -1, "free", "ball1_joint", mass=2.0, inertia=(2 * I, 2 * I, 2 * I, 0, 0, 0))]
-    boxes = [BoxSpec(0, np.eye(4), (4.0, 1.0, 4.0), 0.3), SphereSpec(1, np.eye(4), 0.1, 0.8), SphereSpec(2, make_transform((0.05, 0, 0)), 0.1, 0.8),
+    boxes = [BoxSpec(0, np.eye(4), (4.0, 1.0, 4.0), 0.3, "box", 0.9), SphereSpec(1, np.eye(4), 0.1, 0.8), SphereSpec(2, make_transform((0.05, 0, 0)), 0.1, 0.8),
              SphereSpec(3, np.eye(4), 0.1, 0.8)]
     md = ModelDescription("balls", bodies, boxes, max_contacts=8)
     md.set_action_space([5, 6, 12])

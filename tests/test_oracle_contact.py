@@ -209,3 +209,36 @@ def test_warm_start_is_carried_and_reused():
     assert len(c1) == 24 and np.allclose(c1, w.last_lcp()["x"])
     w.step(s1, a[0])
     assert w.last_status & 0x2
+
+
+def test_restitution_bounce_and_its_jacobians():
+    """ContactConstraint.cpp:95-110, 395-442: e = e_A e_B, bounce when e > 1e-3 and e * approach speed > 0.1; velVel (through the
+    bounce diagonals 1 + e) against central differences; posPos / velPos carry the reference's bounce APPROXIMATION
+    (BackpropSnapshot.cpp:1131-1226): in the contact direction the position Jacobian becomes -e (X = I - (1 + e) a a^T / |a|^2 for one
+    bouncing contact), which is not the derivative of the explicit position update - by design."""
+    from oracle import OracleWorld
+    from util import ball_state, ball_world
+    md = ball_world("box_first", n_balls=1)
+    md.boxes[0].restitution = 0.9; md.boxes[1].restitution = 0.8
+    s, a = ball_state(md, [(0.2, 0.1)], 3, pen=1e-3)
+    n = md.num_dofs
+    s[0:3] = 0.0; s[n:] = 0.0; s[n + 4] = -1.0
+    ow = OracleWorld(md)
+    nx = ow.step(s, a)
+    assert abs(nx[n + 4] - (0.72 * 1.0)) < 0.02 and nx[n + 4] > 0          # leaves with ~e times the approach speed (gravity aside)
+    J = ow.getStateJacobian()
+    assert np.allclose(np.diag(J[:n, :n]), [1, 1, 1, 1, -0.72, 1], atol=1e-9)
+    assert np.allclose(np.diag(J[:n, n:]) / md.dt, [1, 1, 1, 1, -0.72, 1], atol=1e-6)
+    eps = 1e-6
+    fd = np.zeros((2 * n, n))
+    for k in range(n):
+        sp = s.copy(); sm = s.copy(); sp[n + k] += eps; sm[n + k] -= eps
+        fd[:, k] = (OracleWorld(md).step(sp, a) - OracleWorld(md).step(sm, a)) / (2 * eps)
+    assert np.abs(J[n:, n:] - fd[n:, :]).max() < 1e-7
+    g = np.random.default_rng(0).normal(0, 1, 2 * n)
+    gs, ga = ow.backprop(g)
+    assert np.abs(J.T @ g - gs).max() < 1e-12
+    # below the bounce threshold: inelastic, identity position Jacobians
+    s2 = s.copy(); s2[n + 4] = -0.1
+    ow2 = OracleWorld(md); nx2 = ow2.step(s2, a)
+    assert abs(nx2[n + 4]) < 1e-9 and np.allclose(np.diag(ow2.getStateJacobian()[:n, :n]), 1.0)
