@@ -259,9 +259,10 @@ int32_t nbl_transpose_to_soa(const double* src_bd, double* dst_db, int64_t B, in
 int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, int32_t d, void* stream);
 
 /* Average duration (ms) of the last timed launches, measured with HIP events on the launch stream. */
-/* Launch shape: worlds per workgroup for the tree kernels (power of two <= 64) and for the LDS-staged dense kernels
- * (power of two <= 16); 0 = default (16 below 65536 worlds, else 64 / 16).  Results do not depend
- * on it (one world per lane either way); environment NBL_TREE_LANES / NBL_LCP_LANES set the initial value. */
+/* Launch shape of the one-world-per-lane tree kernels (models over 64 bodies / DOFs, NBL_COOP_TREE=0, the narrow phase):
+ * worlds per workgroup, a power of two <= 64; 0 = default (16 below 65536 worlds, else 64).  Results do not depend on it;
+ * environment NBL_TREE_LANES sets the initial value.  lcp_lanes is accepted for source compatibility and ignored: the
+ * dense contact kernels are one world per wavefront. */
 int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes);
 /* Batch slicing: the worlds of a call are processed as `slices` contiguous ranges whose kernels overlap on internal HIP
  * streams forked from / joined into the caller's stream (0 = default = 1; max 8; environment NBL_SLICES).  Results do not

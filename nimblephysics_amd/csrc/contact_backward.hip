@@ -1,4 +1,5 @@
-// contact_backward.hip — matrix-free adjoint of the contact stage (one world per lane).
+// contact_backward.hip — matrix-free adjoint of the contact stage: the derivation, the contact-geometry pieces shared with the
+// wavefront-per-world kernels (coop_kernels.hip), and the one-world-per-lane tree sweeps of the memory-lean mode (NBL_SAVE_TREE=0).
 //
 // The reference differentiates  v' = v_pre + M^-1 Abar f_c,  f_c = Q^+ b,  Q = A_c^T M^-1 Abar + cfm I,
 // b = -A_c^T v_pre  by forming dense Jacobians (BackpropSnapshot::getVelJacobianWrt :980-1066,
@@ -21,15 +22,6 @@
 #include "lcp_dev.hpp"
 
 namespace nbl {
-
-DEV double qEntry(const LcpView& V, const Classes& K, double cfm, int r, int s) {  // Q[cidx r][cidx s], r and s clamping rows
-  double q = V.A(r, s);
-  if (K.nu > 0 && (s % 3) == 0)
-    for (int u = s + 1; u < s + 3 && u < V.m; u++)
-      if (K.cls[u] == RC_UPPER_BOUND) q += K.E[u] * V.A(r, u);
-  if (r == s) q += cfm;
-  return q;
-}
 
 // Recompute the forward tree state, decide whether the contact adjoint is active for this world (any clamping row),
 // and, if so, lambda1 = M^-1 g (two tree sweeps) for the dense kernel that follows.
@@ -61,131 +53,7 @@ __global__ __launch_bounds__(64) void k_bwd_recompute(DevModel mdl, const DevBod
   }
 }
 
-// ---- kernel A: dense (c x c) part of the adjoint ----
-__global__ __launch_bounds__(LCP_LANES) void k_bwd_contact_a(DevModel mdl, const DevBody* __restrict__ bodies,
-                                                      const DevDof* __restrict__ dofs, const DevContactModel* __restrict__ cm,
-                                                      int64_t B, double* __restrict__ saved, SavedLayout lay,
-                                                      const double* __restrict__ gnext, double* __restrict__ ws,
-                                                      double* __restrict__ lws) {
-  extern __shared__ __attribute__((aligned(16))) double ldsq[];   // Q factor + Cholesky factor, LCP_LANES worlds (see k_contact_solve)
-  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= mdl.b1) return;
-  LaneMem QL; QL.base = ldsq; QL.B = (int)blockDim.x; QL.b = threadIdx.x;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
-  const int n = mdl.n;
-  const double* gvn = gnext + (int64_t)n * B;
-  LaneMem L; L.base = lws; L.B = B; L.b = b;
-  LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
-  const LaneMem DN = denseMem(saved, lay, B, b);
-  const int nC = (int)SV.at(lay.nc);
-  const int m = 3 * nC;
-  // classes as stored by the forward pass
-  Classes K;
-  K.nc = 0; K.nu = 0;
-  for (int r = 0; r < m; r++) {
-    const double cv = SV.at(lay.cls + r);
-    K.cidx[r] = -1; K.uidx[r] = -1; K.E[r] = 0; K.cls[r] = RC_NOT_CLAMPING;
-    if (cv == 1.0) { K.cls[r] = RC_CLAMPING; K.cidx[r] = K.nc++; }
-    else if (cv == 2.0 || cv == -2.0) { K.cls[r] = RC_UPPER_BOUND; K.uidx[r] = K.nu++; }
-  }
-  if (L.at(LB_FLAG) == 0.0) return;   // set by k_bwd_recompute together with lambda1 (LB_LAM1)
-  LcpView V;
-  V.mem = DN; V.offA = lay.A; V.m = m;
-  for (int ci = 0; ci < nC; ci++) {
-    const int r0 = lay.contacts + ci * CR_SIZE;
-    const double muA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].mu, muB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].mu;
-    V.mu[ci] = muA < muB ? muA : muB;
-  }
-  for (int r = 0; r < m; r++) if (K.cls[r] == RC_UPPER_BOUND) K.E[r] = SV.at(lay.cls + r) > 0 ? V.hi(r) : V.lo(r);
-  const double cfm = SV.at(lay.cfm);
-  const int nc = K.nc;
-  int rowOf[MAXR];
-  for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) rowOf[K.cidx[r]] = r;
-
-  double fc[MAXR], bc[MAXR], fbar[MAXR], mu[MAXR], tmp[MAXR];
-  // fbar = Abar^T lambda1
-  for (int i = 0; i < nc; i++) {
-    const int r = rowOf[i];
-    fc[i] = SV.at(lay.x + r);
-    double s = 0;
-    for (int d = 0; d < n; d++) {
-      double a = DN.at(lay.aall + d * MAX_ROWS + r);
-      if (K.nu > 0 && (r % 3) == 0)
-        for (int u = r + 1; u < r + 3 && u < m; u++)
-          if (K.cls[u] == RC_UPPER_BOUND) a += K.E[u] * DN.at(lay.aall + d * MAX_ROWS + u);
-      s += a * L.at(LB_LAM1 + d);
-    }
-    fbar[i] = s;
-  }
-  {
-    double Bv[MAXR];
-    for (int r = 0; r < m; r++) Bv[r] = SV.at(lay.b + r);
-    buildQ(V, K, cfm, QL, 0, Bv, bc);   // Q into LDS, bc = clamping entries of b
-  }
-  CodFactor F;
-  F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR; F.c = nc;
-  codFactor(QL, F);
-  for (int i = 0; i < nc; i++) tmp[i] = fbar[i];
-  codSolveT(QL, F, tmp, mu);                                   // mu = (Q^+)^T fbar
-  double al[3][MAXR], be[3][MAXR], fls[MAXR];
-  // Q^+ b: equals the applied impulses f_c when the results were standardised; when the solver's raw x was kept
-  // (PGS / frictionless fallback without a valid standardisation) the reference still differentiates Q^+ b here
-  // (Qfactored.solve(b), BackpropSnapshot.cpp:2934) while A_c f_c terms use the applied impulses (:1003, 1057-1058)
-  for (int i = 0; i < nc; i++) tmp[i] = bc[i];
-  codSolve(QL, F, tmp, fls);
-  // pair 1: (-mu, Q^+ b)
-  for (int i = 0; i < nc; i++) { al[0][i] = -mu[i]; be[0][i] = fls[i]; }
-  // pair 2: ((I - Q Q^+) b, Q^+ mu)
-  for (int i = 0; i < nc; i++) {
-    double s = 0;
-    for (int j = 0; j < nc; j++) s += qEntry(V, K, cfm, rowOf[i], rowOf[j]) * fls[j];
-    al[1][i] = bc[i] - s;
-  }
-  for (int i = 0; i < nc; i++) tmp[i] = mu[i];
-  codSolve(QL, F, tmp, be[1]);
-  // pair 3: (Q^+T Q^+ b, fbar - Q^T mu)
-  for (int i = 0; i < nc; i++) tmp[i] = fls[i];
-  codSolveT(QL, F, tmp, al[2]);
-  for (int i = 0; i < nc; i++) {
-    double s = 0;
-    for (int j = 0; j < nc; j++) s += qEntry(V, K, cfm, rowOf[j], rowOf[i]) * mu[j];
-    be[2][i] = fbar[i] - s;
-  }
-  // s_k = M^-1 A_c alpha_k, p_k = M^-1 Abar beta_k from the saved massed impulse tests; g_vpre = g - A_c mu
-  for (int d = 0; d < n; d++) {
-    double sk[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, acmu = 0;
-    for (int i = 0; i < nc; i++) {
-      const int r = rowOf[i];
-      const double ms = DN.at(lay.massed + d * MAX_ROWS + r);
-      double mb = ms;
-      if (K.nu > 0 && (r % 3) == 0)
-        for (int u = r + 1; u < r + 3 && u < m; u++)
-          if (K.cls[u] == RC_UPPER_BOUND) mb += K.E[u] * DN.at(lay.massed + d * MAX_ROWS + u);
-      for (int k = 0; k < 3; k++) { sk[k] += al[k][i] * ms; pk[k] += be[k][i] * mb; }
-      acmu += mu[i] * DN.at(lay.aall + d * MAX_ROWS + r);
-    }
-    for (int k = 0; k < 3; k++) { L.at(LB_S + k * MAX_DOF_CONTACT + d) = sk[k]; L.at(LB_P + k * MAX_DOF_CONTACT + d) = pk[k]; }
-    L.at(LB_GVP + d) = gvn[(int64_t)d * B + b] - acmu;
-  }
-  // coefficients of z_row on the bases [lambda1, v_pre, p1, p2, p3, s1, s2, s3]
-  for (int r = 0; r < MAX_ROWS; r++) {
-    double cf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < m) {
-      if (K.cls[r] == RC_CLAMPING) {
-        const int i = K.cidx[r];
-        cf[0] = fc[i]; cf[1] = -mu[i];
-        for (int k = 0; k < 3; k++) { cf[2 + k] = al[k][i]; cf[5 + k] = be[k][i]; }
-      } else if (K.cls[r] == RC_UPPER_BOUND) {
-        const int i = K.cidx[r - (r % 3)];
-        cf[0] = K.E[r] * fc[i];
-        for (int k = 0; k < 3; k++) cf[5 + k] = K.E[r] * be[k][i];
-      }
-    }
-    for (int k = 0; k < 8; k++) L.at(LB_COEF + r * 8 + k) = cf[k];
-  }
-}
-
-// ---- contact-geometry pieces shared by the one-world-per-lane and the one-world-per-wavefront kernels ----
+// ---- contact-geometry pieces of k_bwd_contact_b_coop ----
 struct ContactRec { V3 p, nrm, eAP, eAD, eBP, eBD; int type, bA, bB; };
 DEV ContactRec loadContactRec(const LaneMem& SV, const SavedLayout& lay, const DevContactModel* __restrict__ cm, int ci) {
   const int r0 = lay.contacts + ci * CR_SIZE;
@@ -295,124 +163,7 @@ DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k,
   return out;
 }
 
-// ---- kernel B: tree part of the adjoint ----
 DEV V6 ldField(const Ctx& c, int body, int base, int f) { return ldV6(c, body, base + 6 * f); }
-
-__global__ __launch_bounds__(64) void k_bwd_contact_b(DevModel mdl, const DevBody* __restrict__ bodies,
-                                                      const DevDof* __restrict__ dofs, const DevContactModel* __restrict__ cm,
-                                                      int64_t B, double* __restrict__ saved, SavedLayout lay,
-                                                      double* __restrict__ ws, double* __restrict__ lws,
-                                                      uint32_t* __restrict__ gradStatus) {
-  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= mdl.b1) return;
-  Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
-  const int n = mdl.n;
-  LaneMem L; L.base = lws; L.B = B; L.b = b;
-  LaneMem SV; SV.base = saved; SV.B = B; SV.b = b;
-  const bool active = L.at(LB_FLAG) != 0.0;
-  if (!__any(active)) return;
-  const double* q = saved;
-  // ---- pass 1 (root->leaf): twist fields of the nine joint-rate vectors ----
-  for (int i = 0; i < c.nb; i++) {
-    const DevBody& bd = bodies[i];
-    T12 T = ldT(c, i), TW = ldTAt(c, i, WS_TW);
-    for (int f = 0; f < NFIELD; f++) {
-      auto rate = [&](int d) -> double {
-        if (f == 0) return L.at(LB_LAM1 + d);
-        if (f == 1) return SV.at(lay.vpre + d);
-        if (f <= 4) return L.at(LB_P + (f - 2) * MAX_DOF_CONTACT + d);
-        if (f <= 7) return L.at(LB_S + (f - 5) * MAX_DOF_CONTACT + d);
-        return SV.at(lay.w + d);
-      };
-      V6 tw;
-      if (bd.jtype == JT_FREE) {
-        const int o = bd.dofOff;
-        tw = AdT(cT(bd.Tcj), mk6(mk3(rate(o), rate(o + 1), rate(o + 2)), mk3(rate(o + 3), rate(o + 4), rate(o + 5))));
-      } else tw = rate(bd.dofOff) * cV6(bd.S);
-      if (bd.parent >= 0) tw = tw + AdInvT(T, ldField(c, bd.parent, WS_FB, f));
-      stV6(c, i, WS_FB + 6 * f, tw);
-      if (f < 8) stV6(c, i, WS_FW + 6 * f, AdT(TW, tw));
-    }
-    zeroN(c, i, WS_PAIRF, 48);
-    zeroN(c, i, WS_XI, 6);
-  }
-  // ---- pass 2 (leaf->root): -d(adj^T M acc)/dq for (lambda1, w), (s_k, p_k) ----
-  const int ADJ[4] = {0, 5, 6, 7}, ACC[4] = {8, 2, 3, 4};
-  for (int d = 0; d < n; d++) L.at(LB_QX + d) = 0.0;
-  for (int i = c.nb - 1; i >= 0; i--) {
-    const DevBody& bd = bodies[i];
-    T12 T = ldT(c, i);
-    S6 G = cS6(bd.G);
-    V6 xi = zero6();
-    for (int k = 0; k < 4; k++) {
-      V6 adj = ldField(c, i, WS_FB, ADJ[k]), acc = ldField(c, i, WS_FB, ACC[k]);
-      V6 Fk = mul(G, acc) + ldV6(c, i, WS_PAIRF + 6 * k);
-      V6 Ak = mul(G, adj) + ldV6(c, i, WS_PAIRA + 6 * k);
-      if (bd.parent >= 0) {
-        xi = xi + dad(AdInvT(T, ldField(c, bd.parent, WS_FB, ADJ[k])), Fk) + dad(AdInvT(T, ldField(c, bd.parent, WS_FB, ACC[k])), Ak);
-        addV6(c, bd.parent, WS_PAIRF + 6 * k, dAdInvT(T, Fk));
-        addV6(c, bd.parent, WS_PAIRA + 6 * k, dAdInvT(T, Ak));
-      }
-    }
-    double qb[6];
-    applyHt(bd, q, B, b, xi, qb);
-    if (active) for (int k = 0; k < bd.ndof; k++) L.at(LB_QX + bd.dofOff + k) -= qb[k];
-  }
-  // ---- pass 3: contact geometry, per row walk up from body A and body B ----
-  uint32_t gst = 0;
-  if (active) {
-    const int nC = (int)SV.at(lay.nc);
-    for (int ci = 0; ci < nC; ci++) {
-      const ContactRec CR = loadContactRec(SV, lay, cm, ci);
-      const V3 p = CR.p, nrm = CR.nrm;
-      const int type = CR.type, bA = CR.bA, bB = CR.bB;
-      if (bA >= 0 && bB >= 0 && (cm->ancestors[bA] & cm->ancestors[bB])) gst |= 0x2u;  // self-collision chains unsupported
-      const TangentFrame TF = tangentFrameOf(nrm);
-      V3 dirs[3] = {nrm, TF.t1, TF.t2};
-      for (int k = 0; k < 3; k++) {
-        const int row = 3 * ci + k;
-        double cf[8];
-        bool any = false;
-        for (int e = 0; e < 8; e++) { cf[e] = L.at(LB_COEF + row * 8 + e); any = any || cf[e] != 0.0; }
-        if (!any) continue;
-        V3 d = dirs[k];
-        V6 Fw = mk6(cross(p, d), d);
-        auto twistOf = [&](int body) -> V6 {   // world twist of `body` under the joint rates z_row
-          V6 z = zero6();
-          if (body < 0) return z;
-          for (int e = 0; e < 8; e++) if (cf[e] != 0.0) z = z + cf[e] * ldField(c, body, WS_FW, e);
-          return z;
-        };
-        V6 TA = twistOf(bA), TB = twistOf(bB);
-        const RowTerms RT = contactRowTerms(CR, TF, k, d, TA - TB);
-        const V6 vertexTerm = RT.vertexTerm, faceTerm = RT.faceTerm, edgeTermA = RT.edgeTermA, edgeTermB = RT.edgeTermB;
-        const bool aIsVertex = (type == CT_VERTEX_FACE);
-        for (int side = 0; side < 2; side++) {
-          const int start = side == 0 ? bA : bB;
-          const V6 Tend = side == 0 ? TA : TB;
-          const double sgn = side == 0 ? 1.0 : -1.0;
-          const bool vertexSide = (side == 0) == aIsVertex;
-          for (int l = start; l >= 0; l = bodies[l].parent) {
-            const int par = bodies[l].parent;
-            V6 Zl = sgn * (Tend - twistOf(par));
-            V6 add = -dad(Zl, Fw);
-            if (type == CT_VERTEX_FACE || type == CT_FACE_VERTEX) add = add + (vertexSide ? vertexTerm : faceTerm);
-            else if (type >= CT_EDGE_EDGE) add = add + (side == 0 ? edgeTermA : edgeTermB);   // edge-edge and the sphere types
-            addV6(c, l, WS_XI, add);
-          }
-        }
-      }
-    }
-  }
-  for (int i = 0; i < c.nb; i++) {
-    const DevBody& bd = bodies[i];
-    V6 xiW = ldV6(c, i, WS_XI);
-    double qb[6];
-    applyHt(bd, q, B, b, dAdT(ldTAt(c, i, WS_TW), xiW), qb);
-    if (active) for (int k = 0; k < bd.ndof; k++) L.at(LB_QX + bd.dofOff + k) += qb[k];
-  }
-  if (gradStatus && gst) atomicOr(gradStatus, gst);
-}
 
 // ---- kernel C: unconstrained backward sweep driven by g_vpre, plus the contact position cotangent ----
 __global__ __launch_bounds__(64) void k_bwd_final(DevModel mdl, const DevBody* __restrict__ bodies,

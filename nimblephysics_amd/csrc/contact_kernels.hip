@@ -1,16 +1,8 @@
-// contact_kernels.hip — contact stage of the batched step (forward), one world per lane.
+// contact_kernels.hip — the narrow phase of the batched step (forward), a few lanes per world.
 //
 //   k_contact_detect   collision detection at q_t + depth filter      ConstraintSolver.cpp:563-613, DARTCollide.cpp:764-1450
-//   k_contact_rows     per-row body wrenches, b, unit-impulse tests -> A and the massed impulse tests M^-1 J^T
-//                                                                     ContactConstraint.cpp:66-230, 361-514, 517-607; BoxedLcpConstraintSolver.cpp:190-349
-//   k_contact_solve    stage 0 of the LCP cascade: classify the warm start / guess, least-squares
-//                      standardisation on the active set, validity check; v' = v_pre + M^-1 J^T x
-//                                                                     BoxedLcpConstraintSolver.cpp:434-457, CGGM.cpp:218-339, 482-872, LCPUtils.cpp:12-140
-// Lanes whose warm start is not a valid LCP solution need the pivoting / PGS stages
-// (BoxedLcpConstraintSolver.cpp:461-677); they are flagged NBL_ST_LCP_FAILED for now and get zero
-// impulses, exactly what the reference does when every stage fails (:679-687).
+// The rest of the contact stage (rows, LCP stage 0, the fallback cascade) is one world per wavefront: coop_kernels.hip.
 #include "collision_dev.hpp"
-#include "dantzig_dev.hpp"
 #include "lcp_dev.hpp"
 
 namespace nbl {
@@ -162,338 +154,6 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
     if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_VTW));
     stV6(c, i, WS_VTW, V);
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// rows: wrenches, b, impulse tests
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_contact_rows(DevModel mdl, const DevBody* __restrict__ bodies,
-                                                     const DevContactModel* __restrict__ cm, int64_t B,
-                                                     double* __restrict__ saved, SavedLayout lay, double* __restrict__ ws,
-                                                     double* __restrict__ lws) {
-  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= mdl.b1) return;
-  Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, b, saved, &lay);
-  LaneMem L;
-  L.base = lws; L.B = B; L.b = b;
-  const int n = mdl.n;
-  const int nC = (int)svAt(saved, lay.nc, B, b);
-  if (!__any(nC > 0)) return;
-  const double* vpre = saved + (int64_t)lay.vpre * B;
-  double* dn = denseOf(saved, lay, B, b);
-
-  // body twists at the pre-contact velocity: WS_VTW, left by k_contact_detect / k_step_forward_coop
-  (void)vpre;
-  // per-row body-frame wrenches (mSpatialNormalA/B) and b = -J^T V
-  int bodyA[MAX_CONTACTS], bodyB[MAX_CONTACTS];
-  for (int ci = 0; ci < MAX_CONTACTS; ci++) {
-    bodyA[ci] = -1; bodyB[ci] = -1;
-    if (ci >= nC) continue;
-    const int r0 = lay.contacts + ci * CR_SIZE;
-    V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
-    V3 nrm = mk3(svAt(saved, r0 + CR_NORMAL, B, b), svAt(saved, r0 + CR_NORMAL + 1, B, b), svAt(saved, r0 + CR_NORMAL + 2, B, b));
-    const int boxA = (int)svAt(saved, r0 + CR_BOXA, B, b), boxB = (int)svAt(saved, r0 + CR_BOXB, B, b);
-    const int bA = cm->boxes[boxA].body, bB = cm->boxes[boxB].body;
-    bodyA[ci] = bA; bodyB[ci] = bB;
-    V3 t1, t2;
-    tangentBasis(nrm, t1, t2);
-    V3 d[3] = {nrm, t1, t2};
-    for (int k = 0; k < 3; k++) {
-      const int row = 3 * ci + k;
-      V6 F = mk6(cross(p, d[k]), d[k]);  // world wrench of a unit impulse along d at p
-      double rel = 0;
-      V6 ja = zero6(), jb = zero6();
-      if (bA >= 0) { ja = dAdT(ldTAt(c, bA, WS_TW), F); rel -= dot(ja, ldV6(c, bA, WS_VTW)); }
-      if (bB >= 0) { jb = dAdT(ldTAt(c, bB, WS_TW), -F); rel -= dot(jb, ldV6(c, bB, WS_VTW)); }
-      double a6[6];
-      toArr(ja, a6);
-      for (int e = 0; e < 6; e++) L.at(LW_JA + row * 6 + e) = a6[e];
-      toArr(jb, a6);
-      for (int e = 0; e < 6; e++) L.at(LW_JB + row * 6 + e) = a6[e];
-      svAt(saved, lay.b + row, B, b) = rel;   // getRelVelocity; restitution 0, penetration correction off
-      // constraint forces in joint space (DCC::getConstraintForces): A_c[i] = sigma_i s_i . F
-      const uint64_t mA = bA >= 0 ? cm->ancestors[bA] : 0ull, mB = bB >= 0 ? cm->ancestors[bB] : 0ull;
-      for (int i = 0; i < c.nb; i++) {
-        const DevBody& bd = bodies[i];
-        const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
-        const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
-        if (bd.jtype != JT_FREE) {
-          double val = 0;
-          if (mult != 0.0) val = mult * dot(cV6(bd.S), dAdT(ldTAt(c, i, WS_TW), F));
-          dn[lay.aall + bd.dofOff * MAX_ROWS + row] = val;
-        } else {
-          double v6[6] = {0, 0, 0, 0, 0, 0};
-          if (mult != 0.0) toArr(dAdT(cT(bd.Tcj), dAdT(ldTAt(c, i, WS_TW), F)), v6);
-          for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
-        }
-      }
-    }
-  }
-  // ---- unit-impulse tests, three rows (one contact) per pair of sweeps ----
-  for (int ci = 0; ci < MAX_CONTACTS; ci++) {
-    if (!__any(ci < nC)) break;
-    const bool active = ci < nC;
-    const int bA = active ? bodyA[ci] : -1, bB = active ? bodyB[ci] : -1;
-    const int ACC[3] = {WS_BIMP, WS_FACC, WS_ABAR};
-    for (int i = 0; i < c.nb; i++) { zeroN(c, i, WS_BIMP, 6); zeroN(c, i, WS_FACC, 12); }
-    // leaf -> root: BodyNode::updateBiasImpulse (BodyNode.cpp:2117-2138)
-    for (int i = c.nb - 1; i >= 0; i--) {
-      const DevBody& bd = bodies[i];
-      T12 T = ldT(c, i);
-      V6 Bi[3];
-      for (int k = 0; k < 3; k++) {
-        Bi[k] = ldV6(c, i, ACC[k]);
-        const int row = 3 * ci + k;
-        if (i == bA) { double a6[6]; for (int e = 0; e < 6; e++) a6[e] = L.at(LW_JA + row * 6 + e); Bi[k] = Bi[k] - fromArr(a6); }
-        if (i == bB) { double a6[6]; for (int e = 0; e < 6; e++) a6[e] = L.at(LW_JB + row * 6 + e); Bi[k] = Bi[k] - fromArr(a6); }
-      }
-      if (bd.jtype != JT_FREE) {
-        V6 S = cV6(bd.S), AIS = ldV6(c, i, WS_AIS);
-        double psi = wsAt(c, i, WS_PSI);
-        for (int k = 0; k < 3; k++) {
-          double uimp = -dot(S, Bi[k]);                    // GenericJoint.hpp:2607-2613 (no joint constraint impulse)
-          wsAt(c, i, WS_UIMP + k) = uimp;
-          if (bd.parent >= 0) addV6(c, bd.parent, ACC[k], dAdInvT(T, Bi[k] + (psi * uimp) * AIS));  // :2482-2498
-        }
-      } else {
-        const int US[3] = {WS_UIMP, WS_W, WS_VBAR};
-        for (int k = 0; k < 3; k++) {
-          double pj[6];
-          toArr(dAdT(cT(bd.Tcj), Bi[k]), pj);
-          for (int e = 0; e < 6; e++) wsAt(c, i, US[k] + e) = -pj[e];
-        }
-      }
-    }
-    // root -> leaf: BodyNode::updateVelocityChangeFD (BodyNode.cpp:2188-2215)
-    for (int i = 0; i < c.nb; i++) {
-      const DevBody& bd = bodies[i];
-      T12 T = ldT(c, i);
-      if (bd.jtype != JT_FREE) {
-        V6 S = cV6(bd.S), AIS = ldV6(c, i, WS_AIS);
-        double psi = wsAt(c, i, WS_PSI);
-        for (int k = 0; k < 3; k++) {
-          V6 X = bd.parent >= 0 ? AdInvT(T, ldV6(c, bd.parent, ACC[k])) : zero6();
-          double dq = psi * (wsAt(c, i, WS_UIMP + k) - dot(AIS, X));   // GenericJoint.hpp:2713-2725
-          stV6(c, i, ACC[k], X + dq * S);
-          if (active) dn[lay.massed + bd.dofOff * MAX_ROWS + 3 * ci + k] = dq;
-        }
-      } else {
-        const int US[3] = {WS_UIMP, WS_W, WS_VBAR};
-        S6 AI = ldS6(c, i, WS_AI);
-        LDL6 f;
-        for (int e = 0; e < 15; e++) f.l[e] = wsAt(c, i, WS_PSI + e);
-        for (int e = 0; e < 6; e++) f.d[e] = wsAt(c, i, WS_PSI + 15 + e);
-        for (int k = 0; k < 3; k++) {
-          V6 X = bd.parent >= 0 ? AdInvT(T, ldV6(c, bd.parent, ACC[k])) : zero6();
-          double r[6], pj[6];
-          toArr(dAdT(cT(bd.Tcj), mul(AI, X)), pj);
-          for (int e = 0; e < 6; e++) r[e] = wsAt(c, i, US[k] + e) - pj[e];
-          ldl6Solve(f, r);
-          stV6(c, i, ACC[k], X + AdT(cT(bd.Tcj), fromArr(r)));
-          if (active) for (int e = 0; e < 6; e++) dn[lay.massed + (bd.dofOff + e) * MAX_ROWS + 3 * ci + k] = r[e];
-        }
-      }
-    }
-    // rows 3ci..3ci+2 of A: relative-velocity response of every row of the contacts c2 >= ci; earlier
-    // ones mirrored (BoxedLcpConstraintSolver.cpp:250-320)
-    if (active) {
-      for (int c2 = ci; c2 < nC; c2++) {
-        const int b2A = bodyA[c2], b2B = bodyB[c2];
-        V6 dVA[3], dVB[3];
-        for (int k = 0; k < 3; k++) {
-          dVA[k] = b2A >= 0 ? ldV6(c, b2A, ACC[k]) : zero6();
-          dVB[k] = b2B >= 0 ? ldV6(c, b2B, ACC[k]) : zero6();
-        }
-        for (int k2 = 0; k2 < 3; k2++) {
-          const int col = 3 * c2 + k2;
-          double ja[6], jb[6];
-          for (int e = 0; e < 6; e++) { ja[e] = L.at(LW_JA + col * 6 + e); jb[e] = L.at(LW_JB + col * 6 + e); }
-          V6 JA = fromArr(ja), JB = fromArr(jb);
-          for (int k = 0; k < 3; k++) {
-            double val = 0;
-            if (b2A >= 0) val += dot(JA, dVA[k]);
-            if (b2B >= 0) val += dot(JB, dVB[k]);
-            dn[lay.A + (3 * ci + k) * MAX_ROWS + col] = val;
-          }
-        }
-      }
-      for (int c2 = 0; c2 < ci; c2++)
-        for (int k2 = 0; k2 < 3; k2++)
-          for (int k = 0; k < 3; k++)
-            dn[lay.A + (3 * ci + k) * MAX_ROWS + 3 * c2 + k2] = dn[lay.A + (3 * c2 + k2) * MAX_ROWS + 3 * ci + k];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// stage 0 solve + apply
-// ---------------------------------------------------------------------------------------------
-DEV void contactOutputs(const LaneMem& SV, const LaneMem& DN, const SavedLayout& lay, int n, int m, const double* X, const Classes& K, double cfm,
-                        double* __restrict__ cacheOut, double* __restrict__ nv, int64_t B, int64_t b) {
-  SV.at(lay.pflag) = 0.0;   // no pseudo-inverse saved by the one-world-per-lane path
-  for (int r = 0; r < MAX_ROWS; r++) {
-    SV.at(lay.x + r) = r < m ? X[r] : 0.0;
-    SV.at(lay.cls + r) = r < m ? (K.cls[r] == RC_UPPER_BOUND ? (K.E[r] > 0 ? 2.0 : -2.0) : (double)K.cls[r]) : 0.0;
-  }
-  SV.at(lay.cfm) = cfm;
-  if (cacheOut) {
-    for (int r = 0; r < MAX_ROWS; r++) cacheOut[(int64_t)r * B + b] = r < m ? X[r] : 0.0;
-    cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
-  }
-  // v' = v_pre + M^-1 J^T x   (applyImpulse + computeImpulseForwardDynamics)
-  for (int d = 0; d < n; d++) {
-    double w = 0;
-    for (int r = 0; r < m; r++) w += DN.at(lay.massed + d * MAX_ROWS + r) * X[r];
-    SV.at(lay.w + d) = w;
-    nv[(int64_t)d * B + b] = SV.at(lay.vpre + d) + w;
-  }
-}
-
-DEV void loadLcpView(LcpView& V, const LaneMem& SV, const LaneMem& DN, const SavedLayout& lay, const DevContactModel* cm, int nC) {
-  V.mem = DN; V.offA = lay.A; V.m = 3 * nC;
-  for (int ci = 0; ci < nC; ci++) {
-    const int r0 = lay.contacts + ci * CR_SIZE;
-    const double muA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].mu, muB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].mu;
-    V.mu[ci] = muA < muB ? muA : muB;
-  }
-}
-
-// The dense per-world matrices (Q / its QR factor and the Cholesky factor of R1 R1^T, 2 x 24 x 24 doubles) are
-// staged in LDS: LCP_LANES worlds per workgroup, element e of world l at lds[e * LCP_LANES + l] (conflict-free),
-// 16 x 9216 B = 144 KiB of the CU's 160 KiB.  The factorisation is a chain of dependent accesses, so LDS
-// latency instead of L2 latency is what matters; the 256 workgroups of a B = 4096 launch cover every CU.
-// Worlds whose warm start / guess does not standardise to a valid LCP solution are appended to `failList`
-// and finished by k_contact_cascade (compacted slow path).
-__global__ __launch_bounds__(LCP_LANES) void k_contact_solve(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
-                                                      double* __restrict__ saved, SavedLayout lay,
-                                                      const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
-                                                      double* __restrict__ next, uint32_t* __restrict__ status,
-                                                      double* __restrict__ lws, int32_t* __restrict__ failList,
-                                                      uint32_t* __restrict__ failCount) {
-  extern __shared__ __attribute__((aligned(16))) double ldsq[];
-  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= mdl.b1) return;
-  const int n = mdl.n;
-  const int nC = (int)svAt(saved, lay.nc, B, b);
-  const int m = 3 * nC;
-  LaneMem L;
-  L.base = ldsq; L.B = (int)blockDim.x; L.b = threadIdx.x;
-  LaneMem SV;
-  SV.base = saved; SV.B = B; SV.b = b;
-  const LaneMem DN = denseMem(saved, lay, B, b);
-  double* nv = next + (int64_t)n * B;
-  uint32_t st = status ? status[b] : 0u;
-  // cache layout: MAX_ROWS values + the row count they belong to
-  if (m == 0) {
-    if (cacheOut) { for (int r = 0; r < MAX_ROWS; r++) cacheOut[(int64_t)r * B + b] = 0; cacheOut[(int64_t)MAX_ROWS * B + b] = 0; }
-    for (int r = 0; r < MAX_ROWS; r++) { SV.at(lay.x + r) = 0; SV.at(lay.cls + r) = 0; }
-    SV.at(lay.cfm) = 0; SV.at(lay.pflag) = 0;
-    for (int d = 0; d < n; d++) SV.at(lay.w + d) = 0;
-    return;
-  }
-  LcpView V;
-  loadLcpView(V, SV, DN, lay, cm, nC);
-  double Bv[MAXR], X[MAXR], colNorm[MAXR];
-  for (int r = 0; r < m; r++) Bv[r] = SV.at(lay.b + r);
-  for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
-
-  // ---- warm start, or LCPUtils::guessSolution when the cache belongs to another row count; standardise ----
-  const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
-  if (haveCache) { for (int r = 0; r < m; r++) X[r] = cacheIn[(int64_t)r * B + b]; }
-  double X0[MAXR];
-  Classes K;
-  const bool ok = laneStage0(V, L, haveCache, X, X0, Bv, colNorm, K);
-  // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
-  for (int r = 0; r < MAX_ROWS; r++) lws[(int64_t)(LW_JA + r) * B + b] = r < m ? X0[r] : 0.0;
-  if (ok) {
-    st |= 0x2u | 0x100u;
-    contactOutputs(SV, DN, lay, n, m, X, K, 0.0, cacheOut, nv, B, b);
-  } else {
-    const uint32_t slot = atomicAdd(failCount, 1u);
-    failList[slot] = (int32_t)b;
-  }
-  if (status) status[b] = st;
-}
-
-// ---------------------------------------------------------------------------------------------
-// stages 1-3 of the cascade for the worlds stage 0 could not resolve (compacted list)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LCP_LANES) void k_contact_cascade(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
-                                                        double* __restrict__ saved, SavedLayout lay,
-                                                        double* __restrict__ cacheOut, double* __restrict__ next,
-                                                        uint32_t* __restrict__ status, double* __restrict__ lws,
-                                                        const int32_t* __restrict__ failList,
-                                                        const uint32_t* __restrict__ failCount) {
-  extern __shared__ __attribute__((aligned(16))) double ldsq[];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= *failCount) return;
-  const int64_t b = failList[t];
-  const int n = mdl.n;
-  LaneMem L;
-  L.base = ldsq; L.B = (int)blockDim.x; L.b = threadIdx.x;
-  LaneMem SV;
-  SV.base = saved; SV.B = B; SV.b = b;
-  const LaneMem DN = denseMem(saved, lay, B, b);
-  const int nC = (int)SV.at(lay.nc);
-  const int m = 3 * nC;
-  double* nv = next + (int64_t)n * B;
-  uint32_t st = status ? status[b] : 0u;
-  LcpView V;
-  loadLcpView(V, SV, DN, lay, cm, nC);
-  double Bv[MAXR], X[MAXR], X0[MAXR], colNorm[MAXR];
-  for (int r = 0; r < m; r++) { Bv[r] = SV.at(lay.b + r); X0[r] = lws[(int64_t)(LW_JA + r) * B + b]; X[r] = X0[r]; }
-  for (int cc = 0; cc < m; cc++) { double s = 0; for (int r = 0; r < m; r++) { double a = V.A(r, cc); s += a * a; } colNorm[cc] = s; }
-  const int OFFA = 0, OFFL = MAXR * MAXR;
-  auto loadProblem = [&](RedLcp& P, double cfmDiag, const double* x0) {
-    P.n = m; P.nOrig = m;
-    for (int i = 0; i < m; i++) {
-      P.x[i] = x0[i]; P.b[i] = Bv[i]; P.lo[i] = V.lo(i); P.hi[i] = V.hi(i); P.findex[i] = V.findex(i); P.mapTo[i] = i;
-      for (int j = 0; j < m; j++) L.at(OFFA + i * MAXR + j) = V.A(i, j) + (i == j ? cfmDiag : 0.0);
-    }
-  };
-  auto hasNan = [&](const double* x) { bool bad = false; for (int r = 0; r < m; r++) if (x[r] != x[r]) bad = true; return bad; };
-  bool success = false, ignoreFriction = false;
-  double cfm = 0.0;
-  RedLcp P;
-  // ---- stage 1: reduce + Dantzig with early termination (:461-522) ----
-  loadProblem(P, 0.0, X0);
-  lcpReduce(L, OFFA, P);
-  if (dantzigSolve(L, OFFA, OFFL, P)) {
-    for (int o = 0; o < m; o++) X[o] = P.x[P.mapTo[o]];
-    success = lcpValid(V, X, Bv, false, 0.0);
-    if (success) st |= 0x4u;
-  }
-  if (hasNan(X)) { success = false; for (int r = 0; r < m; r++) X[r] = 0; st |= 0x40u; }
-  if (!success) {
-    cfm = cm->fallbackCfm;
-    // ---- stage 2: CFM + PGS from the pre-solve x (:539-597) ----
-    loadProblem(P, cfm, X0);
-    lcpReduce(L, OFFA, P);
-    if (pgsSolve(L, OFFA, P)) {
-      for (int o = 0; o < m; o++) X[o] = P.x[P.mapTo[o]];
-      success = lcpValid(V, X, Bv, false, cfm);
-      if (success) st |= 0x8u;
-    }
-  }
-  if (!success) {
-    // ---- stage 3: drop friction, PGS from zero (:606-677) ----
-    ignoreFriction = true;
-    loadProblem(P, cfm, X0);
-    lcpRemoveFriction(L, OFFA, P);
-    for (int i = 0; i < P.n; i++) P.x[i] = 0.0;
-    const bool ok3 = pgsSolve(L, OFFA, P);
-    for (int o = 0; o < m; o++) X[o] = P.mapTo[o] >= 0 ? P.x[P.mapTo[o]] : 0.0;
-    st |= 0x10u;
-    if (!ok3) st |= 0x20u;
-  }
-  if (hasNan(X)) { for (int r = 0; r < m; r++) X[r] = 0; st |= 0x40u; }
-  // ---- register the fresh solution, classify, standardise (:718-736) ----
-  CodFactor F;
-  F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR;
-  Classes K;
-  if (standardizeLoop(V, L, F, X, Bv, colNorm, cfm, ignoreFriction, 0u, K)) st |= 0x100u;
-  contactOutputs(SV, DN, lay, n, m, X, K, cfm, cacheOut, nv, B, b);
-  if (status) status[b] = st;
 }
 
 }  // namespace nbl

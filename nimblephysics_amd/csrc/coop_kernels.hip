@@ -1,7 +1,9 @@
 // coop_kernels.hip — one world per WAVEFRONT for the dense part of the contact stage (see coop_dev.hpp).
-//   k_contact_solve_coop   stage 0 of the LCP cascade + v' = v_pre + M^-1 J^T x; worlds it cannot resolve go to the
-//                          compacted slow path (k_contact_cascade, one world per lane) exactly like k_contact_solve
-//   k_bwd_contact_a_coop   the dense (c x c) part of the contact adjoint (k_bwd_contact_a)
+//   k_contact_rows_coop      contact Jacobians, b, the unit-impulse tests and A
+//   k_contact_solve_coop     stage 0 of the LCP cascade + v' = v_pre + M^-1 J^T x; worlds it cannot resolve go to the
+//                            compacted list of k_contact_cascade_stages / k_contact_cascade_final (stages 1-3)
+//   k_bwd_contact_a_coop     the dense (c x c) part of the contact adjoint;  k_bwd_contact_b_coop  its tree part
+//   k_bwd_bounce             the reference's bounce approximation (restitution)
 #include "coop_dev.hpp"
 #include "coop_dantzig_dev.hpp"
 #include "coop_wave_dev.hpp"
@@ -213,24 +215,12 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig(int count, int n, const
   if (ln == 0) rc[pb] = r;
 }
 
-// Dense part of the contact adjoint, one world per wavefront: the same quantities as k_bwd_contact_a
-// (contact_backward.hip; the header there derives them), with lane = LCP row for the c-vectors and lane = DOF for the
+// Dense part of the contact adjoint, one world per wavefront (the header of contact_backward.hip derives the
+// quantities), with lane = LCP row for the c-vectors and lane = DOF for the
 // n-vectors.  Row-indexed vectors are zero outside the clamping set, which replaces the index compaction:
 //   (Q x)_r   = (A xE)_r + cfm x_r      xE = x on clamping rows, E_u x_normal(u) on upper-bound rows  ("spread")
 //   (Q^T y)_s = t_s + sum_{u in ub(s)} E_u t_u + cfm y_s,  t = A y                                     ("fold")
 // Q^+ is read back from the saved record when the forward pass left it there (pflag), else recomputed.
-// the rare path of k_bwd_contact_a_coop (no pseudo-inverse in the record): kept out of line so that its register needs
-// (three 24-entry arrays of the factorisation) do not set the occupancy of the common path
-__attribute__((noinline)) DEV void coopPinvFromRecord(CoopLds& S, const CoopRow& R, const CoopClasses& K, double cfm) {
-  const DevWave w;
-  double a[MAXR];
-  coopBuildQ(w, S, R, K, cfm, a);
-  coopPinv(w, a, S, K.nc);
-}
-
-// FALLBACK: records whose forward pass did not leave Q^+ (one-world-per-lane cascade, NBL_COOP_CASCADE=0) are factorised here;
-// the wavefront-per-world forward kernels always store it, and the variant without the fallback needs half the registers.
-template <bool FALLBACK>
 __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ gnext, double* __restrict__ lws) {
@@ -329,9 +319,8 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   w.sync();
   // Q^+
   if (pflagD != 0.0) w.sync();   // S.P was filled from the record at the top
-  else if (FALLBACK) coopPinvFromRecord(S, R, K, cfm);
   else {
-    // cannot happen with records of the wavefront-per-world forward kernels; make it loud instead of silently wrong
+    // cannot happen: the forward kernels always leave Q^+ of the final classification in the record; make it loud instead of silently wrong
     if (ln < MAXR) {
 #pragma unroll
       for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = __builtin_nan("");
@@ -409,7 +398,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const D
   }
   const double bcl = clamp ? R.Bv : 0.0;
   const double mu = coopPinvApply<DevWave, true>(w, S, fbar, 0);     // (Q^+)^T fbar
-  const double fls = coopPinvApply<DevWave, false>(w, S, bcl, 1);    // Q^+ b (see k_bwd_contact_a on why not the applied x)
+  const double fls = coopPinvApply<DevWave, false>(w, S, bcl, 1);    // Q^+ b, the reference's least-squares f_c (not the applied x: they differ when the cascade's answer is not standardised)
   double al[3], be[3];
   al[0] = -mu; be[0] = fls;
   {
@@ -563,8 +552,7 @@ __global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* 
   }
 }
 
-// Contact rows, one world per wavefront, lane = LCP row (k_contact_rows does the same one world per lane, three rows per
-// pair of tree sweeps): per-row wrench, b = -J^T V(v_pre), the constraint-force column A_c[:, row]
+// Contact rows, one world per wavefront, lane = LCP row: per-row wrench, b = -J^T V(v_pre), the constraint-force column A_c[:, row]
 // (DCC::getConstraintForces), one unit-impulse test per lane (BodyNode::updateBiasImpulse / updateVelocityChangeFD,
 // BodyNode.cpp:2117-2215; GenericJoint.hpp:2482-2498, 2607-2613, 2713-2725) giving the column M^-1 J^T e_row ("massed")
 // and the row of the Delassus matrix A (BoxedLcpConstraintSolver.cpp:250-320: entries of later contacts computed,
@@ -764,12 +752,11 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   }
 }
 
-// Tree part of the contact adjoint, one world per wavefront (k_bwd_contact_b one world per lane; the header of
-// contact_backward.hip derives the terms).  Everything is carried in the WORLD frame, where transmitted wrenches add up
+// Tree part of the contact adjoint, one world per wavefront (the header of contact_backward.hip derives the terms).  Everything is carried in the WORLD frame, where transmitted wrenches add up
 // over subtrees without transforms and ad* is equivariant (dAdT(T, dad(V, F)) = dad(AdInvT(T, V), dAdT(T, F))):
 //   1a lane = joint-rate field f (9: lambda1, v_pre, p1..3, s1..3, w): world twists FW[i][f] = FW[parent][f] + Ad(TW_i) S_i rate
 //   1b lane = (body, field): local wrench G_i (twist in the body frame), moved to the world frame -> TF[i][f]
-//   2  lane = LCP row (24): the chain walk of k_bwd_contact_b adds, for every body l between a contact body and the root,
+//   2  lane = LCP row (24): a walk up the ancestor chains would add, for every body l between a contact body and the root,
 //          add_l = term - sgn dad(T_end - tw(parent l), F_w),   tw(body) = sum_e cf_e FW[body][e]
 //      which is bilinear: summed over rows,  xi[l] = C[l] + sum_e dad(FW[parent l][e], Phi_e[l])  with
 //          C   = sum over the rows whose contact body lies in the subtree of l of (term - sgn dad(T_end, F_w))

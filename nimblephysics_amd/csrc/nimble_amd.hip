@@ -36,9 +36,9 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int NBL_MAX_SLICES = 8;
-enum KernelId { K_FWD = 0, K_DETECT, K_ROWS, K_SOLVE, K_CASCADE, K_BWD, K_RECOMPUTE, K_BWD_A, K_BWD_B, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_BWD_BOUNCE, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect", "k_contact_rows", "k_contact_solve", "k_contact_cascade",
-                                           "k_step_backward", "k_bwd_recompute", "k_bwd_contact_a", "k_bwd_contact_b",
+enum KernelId { K_FWD = 0, K_DETECT, K_BWD, K_RECOMPUTE, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_BWD_BOUNCE, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect",
+                                           "k_step_backward", "k_bwd_recompute",
                                            "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop", "k_step_forward_coop", "k_bwd_recompute_coop",
                                            "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final", "k_bwd_bounce"};
 struct TimedLaunch {
@@ -75,11 +75,9 @@ struct nbl_model {
                                      // streams exceed four (4 slices 7.4 vs 9.0 M/s): the chip is already shared by the slices.
   bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
   int nPairs = 0;                    // candidate collider pairs of the model
-  bool coopCascade = true;           // NBL_COOP_CASCADE=0: stages 1-3 one world per lane
   bool coopFinal = true;             // the backward sweeps too, in the world frame (NBL_COOP_FINAL=0: one world per lane, fed by k_tree_to_lanes)
-  bool coopTree = false;             // tree sweeps one world per wavefront (needs coop, the saved tree block, nb and n <= 64)
-  bool coop = true;                  // dense contact kernels: one world per wavefront (NBL_COOP=0: one world per lane)
-  int treeLanes = 0, lcpLanes = 0;   // worlds per workgroup (0 = pick from B); see nbl_set_launch_lanes
+  bool coopTree = false;             // tree sweeps one world per wavefront (needs the saved tree block, nb and n <= 64)
+  int treeLanes = 0;                 // worlds per workgroup of the one-world-per-lane tree kernels (0 = pick from B); nbl_set_launch_lanes
   std::vector<DevBody> hBodies;      // host copy of the body constants (nbl_set_body_inertia patches one entry)
   DevInertiaParam* dParams = nullptr; // registered inertia parameters (nbl_set_inertia_params)
   int nParams = 0;
@@ -319,7 +317,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     }
     bool saveTree = true;   // trade 8 * WS_KEEP * n_bodies bytes per world and step for the ABA re-run of the backward pass
     if (const char* e0 = getenv("NBL_SAVE_TREE")) saveTree = atoi(e0) != 0;
-    bool coop = true, coopTree = true;
+    bool coopTree = true;
     const int nbp = (d->n_bodies + 3) & ~3;
     // the lane = body tree kernels keep the sweep state of `wpb` worlds + one copy of the model constants in LDS; pick the
     // worlds per workgroup that maximise the resident wavefronts per CU (160 kB)
@@ -350,18 +348,15 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     pickWpb((size_t)coopWorldDoubles<PROF_FWD>(nbp, nFree) * sizeof(double), m->wpbFwd, m->ldsFwd);
     pickWpb((size_t)coopWorldDoubles<PROF_BWD>(nbp, nFree) * sizeof(double), m->wpbBwd, m->ldsBwd);
     const size_t coopTreeLds = (m->wpbFwd > 0 && m->wpbBwd > 0) ? 0 : (size_t)1 << 30;
-    if (const char* e3 = getenv("NBL_COOP")) coop = atoi(e3) != 0;
     if (const char* e5 = getenv("NBL_COOP_TREE")) coopTree = atoi(e5) != 0;
     if (coopTreeLds > 160u * 1024u) coopTree = false;
-    if (((size_t)d->n_bodies * 174 + 54 * MAX_ROWS + MAX_CONTACTS) * sizeof(double) > 160u * 1024u) coop = false;   // k_bwd_contact_b_coop's per-world LDS image
-    m->coop = coop;
+    // (k_bwd_contact_b_coop's per-world LDS image, (174 n_bodies + 54 * 24 + 8) doubles, fits 160 kB for every model the contact path accepts: <= 64 bodies)
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
-    if (const char* e8 = getenv("NBL_COOP_CASCADE")) m->coopCascade = atoi(e8) != 0;
     if (const char* e10 = getenv("NBL_AUX_OVERLAP")) m->auxOverlap = atoi(e10) != 0;
     if (const char* e13 = getenv("NBL_DETECT_SPLIT")) m->detectSplit = atoi(e13) != 0;
     m->nPairs = hc.nPairs;
     // measured (MI355X, B = 4096, world-frame sweeps): 5.5 vs 3.8 M/s with colliders, 16.4 vs 11.0 M/s without
-    m->coopTree = coop && coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
+    m->coopTree = coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
     if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
     L.treeNbp = m->coopTree ? nbp : 0;
     L.treeRows = !saveTree ? 0 : (m->coopTree ? WS_KEEP * nbp : d->n_bodies * WS_KEEP);
@@ -369,15 +364,14 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   }
   m->device = device;
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
-  if (const char* e2 = getenv("NBL_LCP_LANES")) m->lcpLanes = atoi(e2);
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
   m->mdl.hasBounce = 0; m->mdl.pad2 = 0;
   if (hasContact)
     for (int pi = 0; pi < hc.nPairs; pi++)
       if (hc.boxes[hc.pairA[pi]].restitution * hc.boxes[hc.pairB[pi]].restitution > 1e-3) m->mdl.hasBounce = 1;
-  if (m->mdl.hasBounce && !(m->coopTree && m->coop && m->coopFinal && m->coopCascade)) {
+  if (m->mdl.hasBounce && !(m->coopTree && m->coopFinal)) {
     nbl_model_destroy(m);
-    return fail(NBL_E_UNSUPPORTED, "restitution needs the wavefront-per-world kernels (the NBL_COOP* switches are off or the model does not fit them)");
+    return fail(NBL_E_UNSUPPORTED, "restitution needs the wavefront-per-world kernels (NBL_COOP_TREE / NBL_COOP_FINAL are off or the model does not fit them)");
   }
   m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.b0 = 0; m->mdl.b1 = 0;   // mdl.pad: worlds per wavefront, set above
   if (const char* e9 = getenv("NBL_SLICES")) m->slices = atoi(e9);
@@ -393,9 +387,6 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess) e = hipMemcpy(m->dDofs, hd.data(), sizeof(DevDof) * hd.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && hasContact) e = hipMalloc((void**)&m->dContact, sizeof(DevContactModel));
   if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
-  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_solve, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
-  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_a, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
-  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_cascade, hipFuncAttributeMaxDynamicSharedMemorySize, LCP_LDS_BYTES);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -444,7 +435,7 @@ size_t nbl_saved_bytes(const nbl_model* m, int64_t B) {
 }
 
 
-// Worlds per workgroup of the one-world-per-lane kernels.  Measured on MI355X at B = 4096 (tools/sweep_lanes.sh):
+// Worlds per workgroup of the one-world-per-lane kernels.  Measured on MI355X at B = 4096 (a sweep over nbl_set_launch_lanes):
 // 16-lane workgroups are marginally faster than 64 for the tree kernels (more CUs busy), smaller ones lose (the
 // kernels are bound by memory transactions per wave-instruction, which do not shrink with the lane count).
 static int pickLanes(int64_t B, int requested, int maxLanes) {
@@ -472,7 +463,7 @@ static void endTiming(nbl_model* m, hipStream_t s) {
 static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_t b1, hipStream_t s, const double* state,
                              const double* action, const double* lcp_cache_in, double* next_state, double* lcp_cache_out,
                              void* saved, uint32_t* status, void* workspace) {
-  const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
+  const int tl = pickLanes(B, m->treeLanes, 64);
   double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
   int32_t* failListAll = (int32_t*)(lws + (size_t)LB_TOTAL * (size_t)B);
   uint32_t* failCountAll = (uint32_t*)(failListAll + B);
@@ -500,33 +491,21 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
                                            m->dContact, B, (double*)saved, m->lay, status, (double*)workspace, m->coopTree ? 0 : 1,
                                            failCountAll + si, ppw));
       }
-      if (m->coop) {
+      {
         const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
                                sizeof(double);   // acc, Fw, Sw/AISw/Vw/psi, free-joint blocks, contact bodies
         TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)cnt), dim3(64), rowsLds, s, mdl, m->dBodies, m->dContact, B,
                                               (double*)saved, m->lay, (const double*)workspace));
-      } else
-        TIMED(K_ROWS, hipLaunchKernelGGL(k_contact_rows, grid, block, 0, s, mdl, m->dBodies, m->dContact, B, (double*)saved,
-                                         m->lay, (double*)workspace, lws));
-      dim3 lgrid((unsigned)((cnt + ll - 1) / ll)), lblock(ll);
-      const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
+      }
       int32_t* failList = failListAll + b0;          // the slice's own compacted list and counter
       uint32_t* failCount = failCountAll + si;   // zeroed by k_contact_detect
-      if (m->coop)
-        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
-                                               (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
-                                               failList, failCount));
-      else
-        TIMED(K_SOLVE, hipLaunchKernelGGL(k_contact_solve, lgrid, lblock, ldsBytes, s, mdl, m->dContact, B, (double*)saved,
-                                          m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws, failList, failCount));
-      if (m->coop && m->coopCascade) {
-        TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_stages, dim3((unsigned)cnt), dim3(192), 0, s, mdl, m->dContact, B,
-                                                 (double*)saved, m->lay, lws, failList, failCount));
-        TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(k_contact_cascade_final, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
-                                                  (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
-      } else
-        TIMED(K_CASCADE, hipLaunchKernelGGL(k_contact_cascade, lgrid, lblock, ldsBytes, s, mdl, m->dContact, B,
-                                            (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+      TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+                                             (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
+                                             failList, failCount));
+      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_stages, dim3((unsigned)cnt), dim3(192), 0, s, mdl, m->dContact, B,
+                                               (double*)saved, m->lay, lws, failList, failCount));
+      TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(k_contact_cascade_final, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+                                                (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
     }
   return NBL_OK;
 }
@@ -550,7 +529,7 @@ int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const dou
 // the kernels of one backward step for the worlds [b0, b1) on stream s
 static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64_t b1, hipStream_t s, const void* saved,
                               const double* grad_next_state, double* grad_state, double* grad_action, void* workspace) {
-  const int tl = pickLanes(B, m->treeLanes, 64), ll = pickLanes(B, m->lcpLanes, LCP_LANES);
+  const int tl = pickLanes(B, m->treeLanes, 64);
   SavedLayout layLanes = m->lay;   // for the one-world-per-lane sweep fed by k_tree_to_lanes: kept slots in the workspace
   layLanes.treeRows = 0; layLanes.treeNbp = 0;
   double* lws = (double*)workspace + (size_t)m->nb * WS_PER_BODY * (size_t)B;
@@ -578,8 +557,8 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
     } else {
       // lambda1 = M^-1 g (tree kernel) and the dense contact adjoint do not depend on each other: with the wavefront-per-world
       // kernels the first runs on the slice's auxiliary stream, the second on its own stream, and they join before
-      // k_bwd_contact_b_coop, which needs both.  (The one-world-per-lane k_bwd_contact_a reads lambda1: no fork there.)
-      const bool forkRecompute = m->coopTree && m->coop && m->auxOverlap;
+      // k_bwd_contact_b_coop, which needs both.
+      const bool forkRecompute = m->coopTree && m->auxOverlap;
       if (forkRecompute) {
         const int32_t rc = ensureAux(m, si + 1);
         if (rc != NBL_OK) return rc;
@@ -597,25 +576,14 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
       else
         TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B,
                                               (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
-      dim3 lgrid((unsigned)((cnt + ll - 1) / ll)), lblock(ll);
-      const size_t ldsBytes = (size_t)2 * MAX_ROWS * MAX_ROWS * 8 * ll;
-      if (m->coop && m->coopCascade)
-        TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
-                                               m->lay, grad_next_state, lws));
-      else if (m->coop)
-        TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop<true>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
-                                               m->lay, grad_next_state, lws));
-      else
-        TIMED(K_BWD_A, hipLaunchKernelGGL(k_bwd_contact_a, lgrid, lblock, ldsBytes, s, mdl, m->dBodies, m->dDofs, m->dContact,
-                                          B, sv, m->lay, grad_next_state, (double*)workspace, lws));
+      TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
+                                             m->lay, grad_next_state, lws));
       if (forkRecompute) HIP_TRY(hipStreamWaitEvent(s, m->auxJoin[si], 0));
-      if (m->coop) {
+      {
         const size_t bLds = ((size_t)m->nb * 120 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS) + MAX_CONTACTS) * sizeof(double);   // FW D {tmp | TF} TW contact bodies
         TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
                                                sv, m->lay, (const double*)workspace, lws));
-      } else
-        TIMED(K_BWD_B, hipLaunchKernelGGL(k_bwd_contact_b, grid, block, 0, s, mdl, m->dBodies, m->dDofs, m->dContact, B, sv,
-                                          m->lay, (double*)workspace, lws, (uint32_t*)nullptr));
+      }
       if (mdl.hasBounce)
         TIMED(K_BWD_BOUNCE, hipLaunchKernelGGL(k_bwd_bounce, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dBodies, B, (const double*)saved, m->lay,
                                                grad_next_state, lws));
@@ -931,7 +899,7 @@ int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   if ((tree_lanes != 0 && (!pow2(tree_lanes) || tree_lanes > 64)) || (lcp_lanes != 0 && (!pow2(lcp_lanes) || lcp_lanes > LCP_LANES)))
     return fail(NBL_E_BADARG, "lanes must be 0 (auto) or a power of two (tree <= 64, lcp <= 16)");
-  m->treeLanes = tree_lanes; m->lcpLanes = lcp_lanes;
+  m->treeLanes = tree_lanes; (void)lcp_lanes;   // the dense kernels are one world per wavefront: nothing to choose
   return NBL_OK;
 }
 
@@ -957,7 +925,7 @@ int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, dou
     HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
     m->kMs[t.kernel] += ms;
     m->kCount[t.kernel]++;
-    const bool isBwd = t.kernel == K_BWD || t.kernel == K_RECOMPUTE || t.kernel == K_BWD_A || t.kernel == K_BWD_B || t.kernel == K_BWD_FINAL ||
+    const bool isBwd = t.kernel == K_BWD || t.kernel == K_RECOMPUTE || t.kernel == K_BWD_FINAL ||
                        t.kernel == K_BWD_A_COOP || t.kernel == K_BWD_B_COOP || t.kernel == K_RECOMPUTE_COOP || t.kernel == K_BWD_FINAL_COOP || t.kernel == K_TREE_TO_LANES;
     if (isBwd) { m->bwdMs += ms; if (t.kernel == K_BWD || t.kernel == K_BWD_FINAL || t.kernel == K_BWD_FINAL_COOP) m->bwdCount++; }
     else { m->fwdMs += ms; if (t.kernel == K_FWD || t.kernel == K_FWD_COOP) m->fwdCount++; }

@@ -1,7 +1,8 @@
 // Host build of the product's wave-cooperative LCP code (coop_dev.hpp) on the thread-per-lane wave emulation,
-// next to the one-world-per-lane statement of the same algorithm (lcp_dev.hpp).  Test harness only.
+// next to the one-world-per-lane statement of the same algorithm (lane_lcp_statement.hpp).  Test harness only.
 #include "coop_dev.hpp"
 #include "coop_dantzig_dev.hpp"
+#include "lane_lcp_statement.hpp"
 #include "wave_emu.hpp"
 
 using namespace nbl;

@@ -2,8 +2,8 @@
 LCP row / matrix column) compiled for the host on a thread-per-lane wave emulation (tests/host_shim/wave_emu.hpp) and
 checked against
   * numpy's pseudo-inverse (the role of Eigen's completeOrthogonalDecomposition in CGGM.cpp:280 / LCPUtils.cpp:113),
-  * the one-world-per-lane statement of the same stage-0 algorithm (lcp_dev.hpp: guessSolution + the
-    constructMatrices / opportunisticallyStandardizeResults loop), which test_device_lcp_host.py pins to the reference.
+  * the one-world-per-lane statement of the same stage-0 algorithm (tests/host_shim/lane_lcp_statement.hpp: guessSolution +
+    the constructMatrices / opportunisticallyStandardizeResults loop, plain sequential code).
 The emulation deadlocks if lanes disagree on control flow around a cross-lane primitive, so passing also shows that the
 device code is wave-uniform where it has to be.  A checker for device code, not a CPU path of the product."""
 import ctypes as C
@@ -23,7 +23,7 @@ def shim():
     src = os.path.join(HERE, "host_shim", "coop_shim.cpp")
     out = os.path.join(HERE, "host_shim", "libcoop_shim.so")
     deps = [src, os.path.join(HERE, "host_shim", "wave_emu.hpp")] + \
-        [os.path.join(ROOT, "nimblephysics_amd", "csrc", f) for f in ("coop_dev.hpp", "coop_dantzig_dev.hpp", "lcp_dev.hpp", "spatial_dev.hpp")]
+        [os.path.join(ROOT, "nimblephysics_amd", "csrc", f) for f in ("coop_dev.hpp", "coop_dantzig_dev.hpp", "lcp_dev.hpp", "spatial_dev.hpp")] + [os.path.join(HERE, "host_shim", "lane_lcp_statement.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(HERE, "host_shim"),
                                "-I", os.path.join(ROOT, "nimblephysics_amd", "csrc"), "-o", out, src])
@@ -114,7 +114,7 @@ def test_coop_stage0_equals_the_one_world_per_lane_statement(shim):
 
 # ---- stages 1-3 of the solver cascade, cooperative (coop_dantzig_dev.hpp) ----
 import oracle  # noqa: E402
-from test_device_lcp_host import contact_lcp, have_ref, _d  # noqa: E402
+from util import contact_lcp, have_ref  # noqa: E402
 
 OL = oracle._lib()
 

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _problems(rng, count, nc, ndof):
-    from test_device_lcp_host import contact_lcp
+    from util import contact_lcp
     n = 3 * nc
     A = np.zeros((count, n, n)); b = np.zeros((count, n)); lo = np.zeros((count, n)); hi = np.zeros((count, n)); fi = np.zeros((count, n), np.int32)
     for i in range(count):

@@ -1,0 +1,59 @@
+"""The one-world-per-lane TREE kernels (k_step_forward, k_step_backward, k_bwd_recompute, k_bwd_final, k_tree_to_lanes) are the
+path of models that do not fit a wavefront (more than 64 bodies or DOFs) and of the memory-lean mode.  The default path of every
+named config is one world per wavefront, so these kernels only run when a switch or the model size selects them: this file runs
+them — each switch on a tree without contact and on the Atlas contact config, plus a 70-body chain — against the CPU oracle to
+the same tolerance as the default path."""
+import numpy as np
+import pytest
+
+from test_gpu_random_trees import random_tree, _compare
+from util import contact_inputs
+
+pytestmark = pytest.mark.gpu
+
+MODES = [{"NBL_COOP_TREE": "0"}, {"NBL_COOP_FINAL": "0"}, {"NBL_SAVE_TREE": "0"}, {"NBL_COOP_TREE": "0", "NBL_SAVE_TREE": "0"},
+         {"NBL_TREE_PACK": "1"}, {"NBL_DETECT_SPLIT": "0"}, {"NBL_AUX_OVERLAP": "1"}]
+IDS = ["-".join(f"{k[4:]}={v}" for k, v in m.items()) for m in MODES]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=IDS)
+def test_tree_without_contact_in_every_mode(mode, monkeypatch):
+    for k, v in mode.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(77)
+    md = random_tree(rng, 17, "random", True)
+    _compare(md, 96, 5)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=IDS)
+def test_atlas_contact_in_every_mode(mode, monkeypatch):
+    """Atlas-20 on the ground (8 contacts, easy distribution: every world resolves at stage 0), forward and backward."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    for k, v in mode.items():
+        monkeypatch.setenv(k, v)
+    B = 128
+    md, s, a = contact_inputs("atlas20", B, 3)
+    g = np.random.default_rng(4).normal(0, 1, s.shape)
+    world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    out = timestep(world, st, at)
+    status = world.last_status.cpu().numpy().astype(np.uint32)
+    out.backward(torch.tensor(g, device="cuda:0"))
+    ref = ow.step_batch(s, a, g, threads=8)
+    ok = ((status & 0x2) != 0) & ((ref["status"] & 0x2) != 0)
+    assert ok.mean() > 0.9
+    sc = lambda x: max(np.abs(x[ok]).max(), 1e-30)
+    for name, dev, r in (("next", out.detach().cpu().numpy(), ref["next"]), ("grad_state", st.grad.cpu().numpy(), ref["grad_state"]),
+                         ("grad_action", at.grad.cpu().numpy(), ref["grad_action"])):
+        assert np.abs(dev[ok] - r[ok]).max() / sc(r) < 1e-7, (mode, name)
+
+
+@pytest.mark.parametrize("shape,free_root", [("chain", False), ("random", True)])
+def test_a_70_body_tree_runs_one_world_per_lane(shape, free_root):
+    """More bodies than a wavefront has lanes: the library must pick the one-world-per-lane tree kernels by itself."""
+    rng = np.random.default_rng(4242)
+    md = random_tree(rng, 70, shape, free_root)
+    _compare(md, 64, 11, tol=1e-6 if shape == "chain" else 1e-7)

@@ -15,7 +15,7 @@ import pytest
 
 import oracle
 from test_coop_host import shim  # noqa: F401  (fixture: builds tests/host_shim/libcoop_shim.so)
-from test_device_lcp_host import contact_lcp, have_ref
+from util import contact_lcp, have_ref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = json.load(open(os.path.join(HERE, "golden", "lcp_fixtures.json")))

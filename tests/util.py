@@ -107,3 +107,26 @@ def ball_state(md, centres, seed, pen=2e-3, radius=0.1):
     return np.concatenate([q, v]), rng.normal(0, 0.1, n)
 
 
+
+
+# ---- random frictional-contact LCPs for the solver tests (host emulation and GPU self-test) ----
+def contact_lcp(rng, nc, ndof, cfm=0.0):
+    """A = J D J^T (+ cfm I) of nc frictional contacts on an ndof-DOF system (rank-deficient when ndof < 3 nc), random b,
+    bounds as DantzigBoxedLcpSolver::solve receives them (friction rows: lo = -mu, hi = mu, findex = their normal row)."""
+    n = 3 * nc
+    J = rng.normal(0, 1, (n, ndof))
+    A = J @ np.diag(rng.uniform(0.1, 2, ndof)) @ J.T + cfm * np.eye(n)
+    b = rng.normal(0, 1, n) * rng.choice([1, 0.01])
+    mu = rng.choice([0.5, 1.0], nc)
+    lo = np.zeros(n); hi = np.full(n, np.inf); fi = np.full(n, -1, np.int32)
+    for c in range(nc):
+        for k in (1, 2):
+            lo[3 * c + k] = -mu[c]; hi[3 * c + k] = mu[c]; fi[3 * c + k] = 3 * c
+    return np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64), lo, hi, fi
+
+
+def have_ref():
+    """oracle/_ref (the reference's own Dantzig solver compiled from its vendored sources) is present."""
+    import os
+    import oracle
+    return os.path.exists(os.path.join(os.path.dirname(oracle.__file__), "_ref", "libodelcp_ref.so"))
