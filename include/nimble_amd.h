@@ -117,6 +117,12 @@ typedef struct nbl_model_desc {
    * the bounce diagonals 1 + e and the reference's bounce approximation of the position Jacobians
    * (BackpropSnapshot.cpp:1131-1226). */
   const double* box_restitution;
+
+  /* ---- penetration correction (appended; 0 = off, the reference's default: ConstraintSolver.cpp:69-71, "it breaks our gradients") ----
+   * World::setPenetrationCorrectionEnabled(true): b_normal += min(max(depth - 0, 0) * 0.01 / dt, 1e-3), unless the contact bounces
+   * harder than that (ContactConstraint.cpp:393-441 with DART_ERROR_ALLOWANCE / DART_ERP / DART_MAX_ERV, :45-47).  Like the
+   * reference's analytical Jacobians the backward pass treats the correction velocity as a constant. */
+  int32_t penetration_correction;
 } nbl_model_desc;
 
 #define NBL_SHAPE_BOX 0

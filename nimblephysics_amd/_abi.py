@@ -68,4 +68,5 @@ class ModelDesc(C.Structure):
         ("fallback_cfm", C.c_double),
         ("box_shape", _pi),
         ("box_restitution", _pd),
+        ("penetration_correction", C.c_int32),
     ]

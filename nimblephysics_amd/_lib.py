@@ -10,7 +10,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnimble_amd.so")
+# NBL_LIB_PATH: load another build of the same library (tools/occupancy_sweep.py A/Bs register caps this way)
+LIB_PATH = os.environ.get("NBL_LIB_PATH") or os.path.join(_HERE, "libnimble_amd.so")
 _lib = None
 
 

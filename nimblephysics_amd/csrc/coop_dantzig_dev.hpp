@@ -78,9 +78,6 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   const int me = on ? ln : 0;
   DZ_T0();
   DZ_CNT(8);
-  // ---- symmetrise in place: A[u][v] (u < v) <- A[v][u]; lane = column v ----
-  if (on) for (int u = 0; u < n; u++) if (u < ln) C.A[u * CLD + ln] = C.A[ln * CLD + u];
-  w.sync();
   double x = 0.0, ww = 0.0, b = on ? row.b : 0.0, lo = on ? row.lo : 0.0, hi = on ? row.hi : 0.0, dx = 0.0, dw = 0.0;
   int st = 0, fidx = on ? row.findex : -1, p = me;
   int Cv = 0;                      // C[ln]: position of the problem row that factor row ln belongs to (lanes < nC)
@@ -98,31 +95,45 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     x = w.shfl(x, src); b = w.shfl(b, src); ww = w.shfl(ww, src); lo = w.shfl(lo, src); hi = w.shfl(hi, src);
     p = w.shflI(p, src); st = w.shflI(st, src); fidx = w.shflI(fidx, src);
   };
-  // contact problems have no unbounded rows (nub = 0); every findex row goes to the end (lcp.cpp:487-498)
+  // Contact problems have no unbounded rows (nub = 0); every findex row goes to the end by the reference's sequence of swaps
+  // (lcp.cpp:487-498).  The swaps are played on the index vectors only (p[j] = the row that ends at position j); the matrix is
+  // symmetrised from its lower triangle (lcp.cpp:138-140) and permuted in ONE pass, the row data follows with one shuffle each.
   {
     int atEnd = 0;
     for (int k = n - 1; k >= 0; k--) {
       const int fk = w.bcastI(fidx, k);
-      if (fk >= 0) { swapProblem(k, n - 1 - atEnd); atEnd++; }
+      if (fk >= 0) {
+        const int i2 = n - 1 - atEnd;
+        if (k != i2) {
+          const int src = ln == k ? i2 : (ln == i2 ? k : ln);
+          p = w.shflI(p, src); fidx = w.shflI(fidx, src);
+        }
+        atEnd++;
+      }
     }
+    double col[MAXR];    // column ln of the permuted matrix: A'[r][ln] = Asym[p_r][p_ln]
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) {
+      const int pr = w.bcastI(p, r < n ? r : 0);
+      col[r] = (on && r < n) ? (pr >= p ? C.A[pr * CLD + p] : C.A[p * CLD + pr]) : 0.0;
+    }
+    w.sync();
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) if (on && r < n) C.A[r * CLD + ln] = col[r];
+    b = w.shfl(b, p); lo = w.shfl(lo, p); hi = w.shfl(hi, p);
+    w.sync();
   }
   // dDot over lanes [from, to): the running sum from 0 in lane order (fastdot.cpp); every lane gets the result.  The products
-  // go through LDS: 24 broadcast reads issued together and two branch-free chains of adds (a term outside its range enters as
-  // +0.0, which leaves the sum unchanged bit for bit) instead of 24 x (branch + two readlanes + select) per sum.
+  // go through LDS, already masked to their range by the lane that owns them (a term outside its range enters as +0.0, which
+  // leaves the sum unchanged bit for bit): broadcast reads issued together and two chains of adds with no branch or select.
   // seqSum2: s1 = sum over [0, mid), s2 = sum over [mid, to).
   auto seqSum2 = [&](double prod, int mid, int to, double& s1, double& s2) {
     w.sync();
-    if (ln < MAXR) C.v[2][ln] = prod;
+    if (ln < MAXR) { C.v[2][ln] = ln < mid ? prod : 0.0; C.v[3][ln] = (ln >= mid && ln < to) ? prod : 0.0; }
     w.sync();
-    double pk[MAXR];
-#pragma unroll
-    for (int k = 0; k < MAXR; k++) pk[k] = C.v[2][k];
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXR; k++) {
-      s1 = s1 + (k < mid ? pk[k] : 0.0);
-      s2 = s2 + ((k >= mid && k < to) ? pk[k] : 0.0);
-    }
+    for (int k = 0; k < MAXR; k++) { s1 = s1 + C.v[2][k]; s2 = s2 + C.v[3][k]; }
   };
   auto seqSum = [&](double prod, int from, int to) -> double {   // from == 0 at every call site
     double s1, s2;

@@ -60,7 +60,7 @@ DEV void coopContactOutputs(const DevWave& w, CoopLds& S, int n, int m, double X
   }
 }
 
-__global__ __launch_bounds__(64, 2) void k_contact_solve_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
                                                            double* __restrict__ next, uint32_t* __restrict__ status,
@@ -113,7 +113,7 @@ constexpr int LW_STAGE_FLAGS = LW_JB + 3 * MAX_ROWS;   // 3 flag words (as doubl
 constexpr int LW_STAGE_CYCLES = LW_STAGE_FLAGS + 3;    // NBL_CASCADE_TIMING: cycles of the three stage waves and of the final kernel
 static_assert(LW_STAGE_CYCLES + 4 <= LW_TOTAL, "stage results must fit the contact scratch rows");
 
-__global__ __launch_bounds__(192) void k_contact_cascade_stages(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+__global__ __launch_bounds__(192) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade_stages(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                                double* __restrict__ saved, SavedLayout lay,
                                                                double* __restrict__ lws, const int32_t* __restrict__ failList,
                                                                const uint32_t* __restrict__ failCount) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(192) void k_contact_cascade_stages(DevModel mdl, co
 #endif
 }
 
-__global__ __launch_bounds__(64) void k_contact_cascade_final(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_final(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                               double* __restrict__ saved, SavedLayout lay,
                                                               double* __restrict__ cacheOut, double* __restrict__ next,
                                                               uint32_t* __restrict__ status, double* __restrict__ lws,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig(int count, int n, const
 //   (Q x)_r   = (A xE)_r + cfm x_r      xE = x on clamping rows, E_u x_normal(u) on upper-bound rows  ("spread")
 //   (Q^T y)_s = t_s + sum_{u in ub(s)} E_u t_u + cfm y_s,  t = A y                                     ("fold")
 // Q^+ is read back from the saved record when the forward pass left it there (pflag), else recomputed.
-__global__ __launch_bounds__(64) void k_bwd_contact_a_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ gnext, double* __restrict__ lws) {
   __shared__ CoopLds S;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* 
 // velocity changes pass down it without transforms, and an entry of A is F_col . (dV_A - dV_B).  Only the free-joint root
 // is solved in its body frame like in abaSweeps.
 //   lds doubles: Fw[24][6]  Sw[nb][6]  AISw[nb][6]  Vw[nb][6]  acc[nb][6][24]
-__global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                           const DevContactModel* __restrict__ cm, int64_t B,
                                                           double* __restrict__ saved, SavedLayout lay,
                                                           const double* __restrict__ ws) {
@@ -659,20 +659,33 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
   w.sync();
   NBL_PHASE(34);
   if (on) {
-    // b = -J^T V: relative velocity of the contact point pair along dir (getRelVelocity; restitution 0, no penetration correction)
+    // b = -J^T V: relative velocity of the contact point pair along dir (getRelVelocity)
     double rel = 0;
     if (bA >= 0) rel -= dot(F, ld6(Vw + 6 * bA));
     if (bB >= 0) rel += dot(F, ld6(Vw + 6 * bB));
     if (kk == 0) {
-      // restitution (ContactConstraint.cpp:95-110, 395-442 / 470-512; penetration correction off): e = e_A e_B; the contact bounces
-      // when e > 1e-3 and e * (approach speed) > 0.1: b_0 += min(e b_0, 100).  The coefficient of the contacts that bounced
-      // (ContactConstraint::getCoefficientOfRestitution, 0 otherwise) goes to the record for the backward pass.
+      // "Bouncing" (ContactConstraint.cpp:393-441 / 470-512).  A: penetration correction (off by default, ConstraintSolver.cpp:69):
+      // (depth - allowance) * ERP / dt, capped (DART_ERROR_ALLOWANCE 0, DART_ERP 0.01, DART_MAX_ERV 1e-3).  B: restitution, e = e_A e_B:
+      // the contact bounces when e > 1e-3 and e * (approach speed) > 0.1 and then the larger of the two velocities is used, the
+      // restitution one capped at 100.  The coefficient of the contacts that bounced (ContactConstraint::getCoefficientOfRestitution,
+      // 0 otherwise) goes to the record for the backward pass.
+      double bouncing = 0.0;
+      if (cm->penetrationCorrection) {
+        double bv = svAt(saved, r0 + CR_DEPTH, B, b) - 0.0;
+        if (bv < 0.0) bv = 0.0;
+        else { bv *= 0.01 * (1.0 / mdl.dt); if (bv > 1e-3) bv = 1e-3; }
+        bouncing = bv;
+      }
       const double eR = cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].restitution * cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].restitution;
       double coeff = 0.0;
       if (eR > 1e-3) {
         const double rv = rel * eR;
-        if (rv > 1e-1) { rel += rv > 1e+2 ? 1e+2 : rv; coeff = eR; }
+        if (rv > 1e-1) {
+          coeff = eR;
+          if (rv > bouncing) bouncing = rv > 1e+2 ? 1e+2 : rv;
+        }
       }
+      rel += bouncing;
       svAt(saved, lay.rest + ci, B, b) = coeff;
     }
     svAt(saved, lay.b + row, B, b) = rel;
@@ -767,7 +780,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_coop(DevModel mdl, const De
 //   4  lane = body: xi_W = C + sum_e dad(FW[par][e], Phi_e) - sum_pairs (dad(FW[par][adj], TF[acc]) + dad(FW[par][acc], TF[adj])),
 //      projected on the joint (applyHt) -> the position cotangent LB_QX
 // lds doubles: FW[nb][9][6] D[nb][54] { tmp[54][24] | TF[nb][9][6] }
-__global__ __launch_bounds__(64) void k_bwd_contact_b_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ ws, double* __restrict__ lws) {

@@ -280,7 +280,7 @@ DEV void stepAba(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ q, cons
 }
 
 // World::step without contact + (contact models) the body twists at the pre-contact velocity
-__global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                           const DevDof* __restrict__ dofs, int64_t B,
                                                           const double* __restrict__ state, const double* __restrict__ action,
                                                           double* __restrict__ next, double* __restrict__ saved,
@@ -490,7 +490,7 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
 }
 
 // contact adjoint activity flag and lambda1 = M^-1 g (k_bwd_recompute)
-__global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_recompute_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_RECOMP) void k_bwd_recompute_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevDof* __restrict__ dofs, int64_t B,
                                                            const double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ gnext, double* __restrict__ lws) {
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_recompute_coop(DevMod
 
 // unconstrained backward sweep driven by g_vpre, plus the contact position cotangent (k_bwd_final); with lws == nullptr
 // the whole backward pass of a model without colliders (k_step_backward)
-__global__ __launch_bounds__(64 * TREE_WPB_MAX) void k_bwd_final_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_BFINAL) void k_bwd_final_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                        const DevDof* __restrict__ dofs, int64_t B,
                                                        const double* __restrict__ saved, SavedLayout lay,
                                                        const double* __restrict__ gnext, double* __restrict__ gstate,

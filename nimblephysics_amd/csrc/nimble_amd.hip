@@ -270,6 +270,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     hc.maxContacts = d->max_contacts;
     hc.clippingDepth = d->contact_clipping_depth;
     hc.fallbackCfm = d->fallback_cfm;
+    hc.penetrationCorrection = d->penetration_correction != 0;
     auto rootOf = [&](int body) { while (body >= 0 && d->parent[body] >= 0) body = d->parent[body]; return body; };
     for (int i = 0; i < d->n_boxes; i++) {
       DevBox& bx = hc.boxes[i];

@@ -115,7 +115,8 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
     g = tuple(float(x) for x in np.asarray(world.getGravity()).reshape(3))
     md = ModelDescription(name, bodies, boxes, g, float(world.getTimeStep()), None, max_contacts=max_contacts if boxes else 0,
                           contact_clipping_depth=float(world.getContactClippingDepth()),
-                          fallback_cfm=float(world.getFallbackConstraintForceMixingConstant()))
+                          fallback_cfm=float(world.getFallbackConstraintForceMixingConstant()),
+                          penetration_correction=bool(world.getPenetrationCorrectionEnabled()))
     aspace = [int(a) for a in world.getActionSpace()]
     if aspace != list(range(md.num_dofs)):
         md.set_action_space(aspace)

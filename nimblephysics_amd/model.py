@@ -116,7 +116,8 @@ class ModelDescription:
 
     def __init__(self, name: str, bodies: List[BodySpec], boxes: Optional[List[BoxSpec]] = None,
                  gravity=(0.0, -9.81, 0.0), dt: float = 1e-3, action_map: Optional[Sequence[int]] = None,
-                 max_contacts: int = 0, contact_clipping_depth: float = 0.03, fallback_cfm: float = 1e-4):
+                 max_contacts: int = 0, contact_clipping_depth: float = 0.03, fallback_cfm: float = 1e-4,
+                 penetration_correction: bool = False):
         self.name = name
         self.bodies = list(bodies)
         self.boxes = list(boxes or [])
@@ -126,6 +127,7 @@ class ModelDescription:
         self.max_contacts = int(max_contacts)
         self.contact_clipping_depth = float(contact_clipping_depth)
         self.fallback_cfm = float(fallback_cfm)
+        self.penetration_correction = bool(penetration_correction)   # World::setPenetrationCorrectionEnabled, off by default
         for i, b in enumerate(self.bodies):
             if not (-1 <= b.parent < i):
                 raise ValueError(f"body {i} ({b.name}): parent {b.parent} must precede it")
@@ -232,7 +234,7 @@ class ModelDescription:
                 Tb = T_in_target[bx.body] @ bx.T
                 boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu, bx.shape, bx.restitution))
         m = ModelDescription(self.name, out, boxes, self.gravity, self.dt, self._action_map, self.max_contacts,
-                             self.contact_clipping_depth, self.fallback_cfm)
+                             self.contact_clipping_depth, self.fallback_cfm, self.penetration_correction)
         return m
 
     def weld_targets(self):
@@ -323,6 +325,7 @@ class ModelDescription:
         d.max_contacts = self.max_contacts
         d.contact_clipping_depth = self.contact_clipping_depth
         d.fallback_cfm = self.fallback_cfm
+        d.penetration_correction = 1 if self.penetration_correction else 0
         return d, a
 
     # ---- (de)serialisation ------------------------------------------------------------------
@@ -333,7 +336,7 @@ class ModelDescription:
         return {
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,
             "max_contacts": self.max_contacts, "contact_clipping_depth": self.contact_clipping_depth,
-            "fallback_cfm": self.fallback_cfm, "bodies": [body(b) for b in self.bodies],
+            "fallback_cfm": self.fallback_cfm, **({"penetration_correction": True} if self.penetration_correction else {}), "bodies": [body(b) for b in self.bodies],
             "boxes": [{"body": bx.body, "T": np.asarray(bx.T).tolist(), "size": list(bx.size), "mu": bx.mu,
                        **({} if bx.shape == "box" else {"shape": bx.shape}),
                        **({} if bx.restitution == 0.0 else {"restitution": bx.restitution})} for bx in self.boxes],
@@ -350,7 +353,7 @@ class ModelDescription:
         boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0), bx.get("shape", "box"), bx.get("restitution", 0.0)) for bx in d.get("boxes", [])]
         return ModelDescription(d["name"], bodies, boxes, d.get("gravity", (0, -9.81, 0)), d.get("dt", 1e-3),
                                 d.get("action_map"), d.get("max_contacts", 0), d.get("contact_clipping_depth", 0.03),
-                                d.get("fallback_cfm", 1e-4))
+                                d.get("fallback_cfm", 1e-4), d.get("penetration_correction", False))
 
     @staticmethod
     def load(name_or_path: str) -> "ModelDescription":

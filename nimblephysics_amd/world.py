@@ -110,6 +110,19 @@ class World:
         if self._wrt_mass.entries:                         # the registered mass parameters survive the re-upload
             self._push_inertia_params()
 
+    def setPenetrationCorrectionEnabled(self, enable: bool):
+        """World::setPenetrationCorrectionEnabled (World.cpp:1227; off by default because the reference's analytical Jacobians
+        ignore the correction velocity - so does the backward pass here)."""
+        if bool(enable) != self.description.penetration_correction:
+            self.description.penetration_correction = bool(enable)
+            self.model.penetration_correction = bool(enable)
+            self._create_handle()
+            if self._wrt_mass.entries:
+                self._push_inertia_params()
+
+    def getPenetrationCorrectionEnabled(self) -> bool:
+        return self.description.penetration_correction
+
     def removeDofFromActionSpace(self, index: int):
         self.setActionSpace([a for a in self.getActionSpace() if a != index])
 

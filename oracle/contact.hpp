@@ -333,16 +333,25 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     out.b[r] = rel;
     out.restCoeff.push_back(0.0);
     if (out.rowDir[r] == 0) {
-      // restitution (ContactConstraint.cpp:95-110 ctor, :395-442 / :470-512 getInformation; penetration correction off,
-      // World.cpp:87): e = e_A e_B; the contact bounces when e > 1e-3 and e * (approach speed) > 0.1, b_0 += min(e b_0, 100)
+      // "Bouncing" of getInformation (ContactConstraint.cpp:393-441, ctor :95-110).  A: penetration correction, only when the
+      // world enables it (ConstraintSolver.cpp:69-71: off by default; DART_ERROR_ALLOWANCE 0, DART_ERP 0.01, DART_MAX_ERV 1e-3, :45-47)
+      s_t bouncingVelocity = ct.depth - 0.0;
+      if (bouncingVelocity < 0.0) bouncingVelocity = 0.0;
+      else {
+        bouncingVelocity *= 0.01 * (1.0 / m.dt);
+        if (bouncingVelocity > 1e-3) bouncingVelocity = 1e-3;
+      }
+      if (!m.penetrationCorrection) bouncingVelocity = 0;
+      // B: restitution, e = e_A e_B; the contact bounces when e > 1e-3 and e * (approach speed) > 0.1
       const s_t e = m.boxes[ct.boxA].restitution * m.boxes[ct.boxB].restitution;
       if (e > 1e-3) {
         const s_t restitutionVel = rel * e;
         if (restitutionVel > 1e-1) {
-          out.b[r] += restitutionVel > 1e+2 ? 1e+2 : restitutionVel;
+          if (restitutionVel > bouncingVelocity) bouncingVelocity = restitutionVel > 1e+2 ? 1e+2 : restitutionVel;
           out.restCoeff[r] = e;                               // getCoefficientOfRestitution(): only when it really bounced
         }
       }
+      out.b[r] += bouncingVelocity;
     }
     if (out.rowDir[r] == 0) { out.lo[r] = 0.0; out.hi[r] = INFINITY; out.findex[r] = -1; }
     else {

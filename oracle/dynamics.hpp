@@ -38,6 +38,7 @@ struct Model {
   std::vector<BoxCollider> boxes;
   int maxContacts;
   s_t clippingDepth, fallbackCfm;
+  bool penetrationCorrection = false;   // World::setPenetrationCorrectionEnabled (off by default)
 };
 
 inline Iso loadIso(const double* t) {
@@ -120,6 +121,7 @@ inline Model buildModel(const nbl_model_desc* d) {
   m.maxContacts = d->max_contacts;
   m.clippingDepth = d->contact_clipping_depth;
   m.fallbackCfm = d->fallback_cfm;
+  m.penetrationCorrection = d->penetration_correction != 0;
   return m;
 }
 

@@ -97,6 +97,7 @@ class StandInWorld:
     def getActionSpace(self): return list(self._md.action_map)
     def getContactClippingDepth(self): return self._md.contact_clipping_depth
     def getFallbackConstraintForceMixingConstant(self): return self._md.fallback_cfm
+    def getPenetrationCorrectionEnabled(self): return self._md.penetration_correction
     def tuneMass(self, body, entry_type, upper, lower):
         assert entry_type == "INERTIA_FULL" and len(upper) == 10 and len(lower) == 10
         self._tuned.append(body._i)

@@ -99,3 +99,33 @@ def test_restitution_off_is_bitwise_the_default_path():
         w = na.World(m, device="cuda:0")
         outs.append(timestep(w, torch.tensor(s, device="cuda:0"), torch.tensor(a, device="cuda:0")))
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("e_ball", [0.0, 0.8])
+def test_penetration_correction_fwd_bwd_vs_oracle(e_ball):
+    """World::setPenetrationCorrectionEnabled(true) (ContactConstraint.cpp:393-441): the normal row gets min(depth * 0.01 / dt, 1e-3)
+    unless the restitution velocity is larger; the backward pass treats it as a constant, like the reference.  Slow balls (below the
+    bounce threshold: the correction applies) and fast ones (restitution wins) against the oracle, and the World-mirror switch."""
+    import torch
+    import nimblephysics_amd as na
+    md, s, a = _balls(128, 9, 1, 0.9, e_ball, 0.05)
+    md2, s2, a2 = _balls(128, 10, 1, 0.9, e_ball, 1.5)
+    s = np.concatenate([s, s2]); a = np.concatenate([a, a2])
+    off, _, _, _, world = _fwd_bwd(md, s, a, 6)
+    assert not world.getPenetrationCorrectionEnabled()
+    md.penetration_correction = True
+    dev, ref, errs, status, world = _fwd_bwd(md, s, a, 6)
+    assert world.getPenetrationCorrectionEnabled() and (status & 0x1).all()
+    for k, v in errs.items():
+        assert v.max() < TOL, (k, v.max())
+    # the correction changed the step of the slow balls (depth 0.5-3 mm -> capped at 1e-3 m/s of extra separation speed) ...
+    d = np.abs(dev["next"] - off["next"]).max(1)
+    assert d[:128].min() > 1e-5 and d[:128].max() < 5e-2
+    # ... and where the ball bounces harder than the correction, restitution overrides it (the step is unchanged)
+    if e_ball > 0:
+        assert d[128:].max() == 0.0
+    # the switch on the World mirror re-uploads the constants
+    world.setPenetrationCorrectionEnabled(False)
+    st = torch.tensor(s, device="cuda:0"); at = torch.tensor(a, device="cuda:0")
+    from nimblephysics_amd.timestep import timestep
+    assert np.array_equal(timestep(world, st, at).cpu().numpy(), off["next"])

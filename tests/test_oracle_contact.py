@@ -242,3 +242,20 @@ def test_restitution_bounce_and_its_jacobians():
     s2 = s.copy(); s2[n + 4] = -0.1
     ow2 = OracleWorld(md); nx2 = ow2.step(s2, a)
     assert abs(nx2[n + 4]) < 1e-9 and np.allclose(np.diag(ow2.getStateJacobian()[:n, :n]), 1.0)
+
+
+def test_penetration_correction_adds_the_capped_velocity_to_the_normal_rows():
+    """ContactConstraint.cpp:393-415 with the defaults of :45-47 (allowance 0, ERP 0.01, max ERV 1e-3): off by default; when the
+    world enables it b_normal grows by min(depth * 0.01 / dt, 1e-3) and nothing else of the problem changes."""
+    from oracle import OracleWorld
+    from util import box_stack_inputs
+    md, s, a = box_stack_inputs(4, 3)
+    ow = OracleWorld(md)
+    md.penetration_correction = True
+    ow2 = OracleWorld(md)
+    r0 = ow.step_batch(s, a, np.zeros_like(s), threads=1)
+    r1 = ow2.step_batch(s, a, np.zeros_like(s), threads=1)
+    assert (r0["status"] & 1).all()
+    # the cubes separate faster with the correction on: by at most 1e-3 m/s * dt per step and contact
+    dv = np.abs(r1["next"] - r0["next"]).max(1)
+    assert dv.min() > 0 and dv.max() < 5e-3
