@@ -30,6 +30,15 @@
 
 namespace nbl {
 
+// A value the optimiser must treat as new at this point: keeps loop-invariant 24-entry constants (the identity columns of the
+// carried block, ...) from being hoisted out of the standardisation loop and parked in 48 VGPRs across both factorisations.
+DEV int opaqueI(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+
 constexpr int CLD = MAXR + 1;  // odd leading dimension: row reads and column reads of the LDS matrices are both conflict-free
 
 struct CoopLds {
@@ -137,8 +146,9 @@ template <class W>
 DEV int coopPinv(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
   const int ln = w.lane();
   if (ln >= MAXR) {
+    const int e = opaqueI(ln - MAXR);
 #pragma unroll
-    for (int i = 0; i < MAXR; i++) a[i] = (ln - MAXR == i) ? 1.0 : 0.0;
+    for (int i = 0; i < MAXR; i++) a[i] = (e == i) ? 1.0 : 0.0;
   }
   const double thr = 2.220446049250313e-16 * cTrue;
   const int r = coopQr<W, true>(w, a, S, S.R, S.G, MAXR, thr * thr);
@@ -181,25 +191,24 @@ DEV int coopPinv(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
 #pragma unroll
     for (int pp = 0; pp < MAXR; pp++) a[pp] = (ln < r) ? S.R[ln * CLD + S.perm[pp]] : 0.0;
   } else {
+    const int e = opaqueI(ln - MAXR);
 #pragma unroll
-    for (int i = 0; i < MAXR; i++) a[i] = (ln - MAXR == i) ? 1.0 : 0.0;
+    for (int i = 0; i < MAXR; i++) a[i] = (e == i) ? 1.0 : 0.0;
   }
   w.sync();   // every row of R is in registers before T overwrites the buffer
   coopQr<W, false>(w, a, S, S.R, S.P, r, 0.0);
   if (ln < r) S.invd[ln] = 1.0 / S.R[ln * CLD + ln];
   w.sync();
-  // column j of Q^+ = P Z1 T^-T G1[:, j]: forward substitution with T^T, accumulating Z1 w on the fly
+  // column j of Q^+ = P Z1 T^-T G1[:, j] in two passes, so that the 24 substitution registers and the 24 accumulators are never
+  // live together: (1) forward substitution with T^T, w_k parked in this lane's own column of the G buffer (its entries are
+  // all in registers by then), (2) y = Z1 w.
   const int j = ln < MAXR ? ln : 0;
 #pragma unroll
   for (int m = 0; m < MAXR; m++) g[m] = (m < r) ? S.G[m * CLD + j] : 0.0;
-  double y[MAXR];
-#pragma unroll
-  for (int pp = 0; pp < MAXR; pp++) y[pp] = 0.0;
 #pragma unroll 1
   for (int k = 0; k < r; k++) {
     const double wk = g[0] * S.invd[k];
-#pragma unroll
-    for (int pp = 0; pp < MAXR; pp++) y[pp] = fma(S.P[k * CLD + pp], wk, y[pp]);   // Z[pp][k] = Z^T[k][pp]
+    if (ln < MAXR) S.G[k * CLD + j] = wk;
 #pragma unroll
     for (int m = 1; m < MAXR; m++) {
       const int col = k + m;
@@ -207,6 +216,15 @@ DEV int coopPinv(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
       g[m - 1] = fma(-tv, wk, g[m]);
     }
     g[MAXR - 1] = 0.0;
+  }
+  double y[MAXR];
+#pragma unroll
+  for (int pp = 0; pp < MAXR; pp++) y[pp] = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < r; k++) {
+    const double wk = S.G[k * CLD + j];
+#pragma unroll
+    for (int pp = 0; pp < MAXR; pp++) y[pp] = fma(S.P[k * CLD + pp], wk, y[pp]);   // Z[pp][k] = Z^T[k][pp]
   }
   w.sync();   // all reads of Z^T done before the buffer becomes Q^+
 #pragma unroll
@@ -244,6 +262,16 @@ struct CoopRow {
                        // instead of being held in 48 VGPRs across the factorisations (it stays in L2).
   bool on;             // lane < m
   DEV double a(int i) const { return (on && i < m) ? Acol[i * MAXR] : 0.0; }
+  // The same column through a pointer the optimiser cannot see through: without it the 24 loads are hoisted out of the
+  // standardisation loop and kept in 48 VGPRs across both factorisations (which is exactly what re-reading is meant to avoid).
+  DEV const double* fresh() const {
+    const double* p = Acol;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(p));
+#endif
+    return p;
+  }
+  DEV double a(const double* p, int i) const { return (on && i < m) ? p[i * MAXR] : 0.0; }
 };
 
 // A x for this lane's row, x one entry per lane; vec: MAXR doubles of LDS scratch
@@ -253,8 +281,9 @@ DEV double coopAx(const W& w, double* vec, const CoopRow& R, double xLane) {
   if (ln < MAXR) vec[ln] = (ln < R.m) ? xLane : 0.0;
   w.sync();
   double v = 0.0;
+  const double* Ac = R.fresh();
 #pragma unroll
-  for (int jx = 0; jx < MAXR; jx++) v = fma(R.a(jx), vec[jx], v);
+  for (int jx = 0; jx < MAXR; jx++) v = fma(R.a(Ac, jx), vec[jx], v);
   return v;
 }
 
@@ -336,11 +365,12 @@ template <class W>
 DEV void coopBuildQ(const W& w, CoopLds& S, const CoopRow& R, const CoopClasses& K, double cfm, double (&a)[MAXR]) {
   const int ln = w.lane();
   const bool colOn = ln < MAXR && K.cls == RC_CLAMPING;
+  const double* Ac = R.fresh();
   double e1 = 0.0, e2 = 0.0;
   if (K.nu > 0) {
     // stage A in LDS so that a normal column can add its contact's upper-bound friction columns
 #pragma unroll
-    for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.R[i * CLD + ln] = R.a(i);
+    for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.R[i * CLD + ln] = R.a(Ac, i);
     const double E1 = w.shfl(K.E, ln + 1), E2 = w.shfl(K.E, ln + 2);
     if (!R.fric && ln + 2 < MAXR) {
       if ((K.ubMask >> (ln + 1)) & 1u) e1 = E1;
@@ -351,7 +381,7 @@ DEV void coopBuildQ(const W& w, CoopLds& S, const CoopRow& R, const CoopClasses&
   const int c1 = (ln + 1 < MAXR) ? ln + 1 : 0, c2 = (ln + 2 < MAXR) ? ln + 2 : 0;
 #pragma unroll
   for (int i = 0; i < MAXR; i++) {
-    double q = R.a(i);
+    double q = R.a(Ac, i);
     if (K.nu > 0) q = fma(e2, S.R[i * CLD + c2], fma(e1, S.R[i * CLD + c1], q));
     if (i == ln) q += cfm;
     a[i] = (colOn && ((K.clampMask >> i) & 1u)) ? q : 0.0;
@@ -424,8 +454,9 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
     guessMask = (uint32_t)w.ballot(in);
     if (guessMask != 0) {
       double a[MAXR];
+      const double* Ac = R.fresh();
 #pragma unroll
-      for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(i) : 0.0;
+      for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(Ac, i) : 0.0;
       NBL_PHASE(43);
       coopPinv(w, a, S, __builtin_popcount(guessMask));
       NBL_PHASE(44);

@@ -33,7 +33,8 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
 }
 
 // x, classes, cfm, warm start, v' = v_pre + M^-1 J^T x and (when valid) the pseudo-inverse of the final Q -> saved record
-DEV void coopContactOutputs(const DevWave& w, CoopLds& S, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValid,
+template <class W>
+DEV void coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValid,
                             double* __restrict__ saved, const SavedLayout& lay, double* __restrict__ dn,
                             double* __restrict__ cacheOut, double* __restrict__ nv, int64_t B, int64_t b) {
   const int ln = w.lane();
@@ -143,6 +144,37 @@ __global__ __launch_bounds__(192) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade
 #endif
 }
 
+// Select + standardise + outputs for one unresolved world, given the candidates of its three stages (one wavefront).
+template <class W>
+DEV void cascadeFinalBody(const W& w, CoopLds& S, const DevModel& mdl, const DevContactModel* __restrict__ cm, int64_t B, int64_t b,
+                          double* __restrict__ saved, const SavedLayout& lay, double* __restrict__ cacheOut, double* __restrict__ next,
+                          uint32_t* __restrict__ status, double* __restrict__ lws, CoopStageResult r1, CoopStageResult r2,
+                          CoopStageResult r3) {
+  const int ln = w.lane();
+  const int n = mdl.n;
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  double* nv = next + (int64_t)n * B;
+  double* dn = denseOf(saved, lay, B, b);
+  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
+  if (ln >= m) { r1.X = 0.0; r2.X = 0.0; r3.X = 0.0; }
+  CoopRow R;
+  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  CoopCascadeOut out;
+  coopCascadeSelect(w, S, R, X0, cm->fallbackCfm, r1, r2, r3, out);
+  // The record always carries Q^+ of the final classification when there is a clamping row, so that the backward pass never
+  // has to factorise.  Stages that end without one (PGS results accepted as they are) pay for it here, on the few worlds that
+  // get this far.
+  bool pinvValid = out.pinvValid;
+  if (!pinvValid && out.K.nc > 0) {
+    double a[MAXR];
+    coopBuildQ(w, S, R, out.K, out.cfm, a);
+    coopPinv(w, a, S, out.K.nc);
+    pinvValid = true;
+  }
+  coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+  if (ln == 0 && status) status[b] |= out.st;
+}
+
 __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_final(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                               double* __restrict__ saved, SavedLayout lay,
                                                               double* __restrict__ cacheOut, double* __restrict__ next,
@@ -155,13 +187,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
   const long long t0 = clock64();
 #endif
   const DevWave w;
-  const int ln = w.lane();
   const int64_t b = failList[blockIdx.x];
-  const int n = mdl.n;
-  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
-  double* nv = next + (int64_t)n * B;
-  double* dn = denseOf(saved, lay, B, b);
-  const int row = ln < MAX_ROWS ? ln : 0;
+  const int row = w.lane() < MAX_ROWS ? w.lane() : 0;
   CoopStageResult r1, r2, r3;
   r1.X = lws[(int64_t)(LW_STAGE_X + row) * B + b];
   r2.X = lws[(int64_t)(LW_STAGE_X + MAX_ROWS + row) * B + b];
@@ -169,26 +196,9 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
   r1.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 0) * B + b];
   r2.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 1) * B + b];
   r3.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 2) * B + b];
-  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
-  if (ln >= m) { r1.X = 0.0; r2.X = 0.0; r3.X = 0.0; }
-  CoopRow R;
-  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
-  CoopCascadeOut out;
-  coopCascadeSelect(w, S, R, X0, cm->fallbackCfm, r1, r2, r3, out);
-  // The record always carries Q^+ of the final classification when there is a clamping row, so that the backward pass never
-  // has to factorise (its fallback cost k_bwd_contact_a_coop half its occupancy).  Stages that end without one (PGS results
-  // accepted as they are) pay for it here, on the few worlds that reach this kernel.
-  bool pinvValid = out.pinvValid;
-  if (!pinvValid && out.K.nc > 0) {
-    double a[MAXR];
-    coopBuildQ(w, S, R, out.K, out.cfm, a);
-    coopPinv(w, a, S, out.K.nc);
-    pinvValid = true;
-  }
-  coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
-  if (ln == 0 && status) status[b] |= out.st;
+  cascadeFinalBody(w, S, mdl, cm, B, b, saved, lay, cacheOut, next, status, lws, r1, r2, r3);
 #ifdef NBL_CASCADE_TIMING
-  if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
+  if (w.lane() == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
 #endif
 }
 
