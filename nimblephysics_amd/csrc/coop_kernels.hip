@@ -104,9 +104,11 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   }
 }
 
-// Stages 1-3 of the cascade for the worlds stage 0 could not resolve (compacted list): one WORKGROUP OF THREE WAVEFRONTS per
-// failed world, wavefront s runs stage s + 1 (reduce + Dantzig | CFM + reduce + PGS | friction dropped + PGS) - the stages only
-// share their inputs, see coop_dantzig_dev.hpp - and leaves its candidate solution and flags in the world's scratch rows;
+// Stages 1-3 of the cascade for the worlds stage 0 could not resolve (compacted list): one WORKGROUP OF TWO WAVEFRONTS per
+// failed world.  Wavefront 0 runs stage 1 (reduce + Dantzig); wavefront 1 runs stage 2 (CFM + reduce + PGS) and then, unless
+// stage 2 already produced a valid solution (stage 3 is only ever consulted when it did not), stage 3 (friction dropped + PGS).
+// The stages only share their inputs, see coop_dantzig_dev.hpp, so the Dantzig solve - the longest of the three - overlaps with
+// both PGS stages; each wavefront leaves its candidate solutions and flags in the world's scratch rows and
 // k_contact_cascade_final picks one in the reference's order of preference and standardises it.  The wavefronts of a group never
 // wait for each other (DevWaveInGroup::sync is a wave-level fence, not a workgroup barrier).
 constexpr int LW_STAGE_X = LW_JB;                 // 3 x MAX_ROWS candidate solutions
@@ -114,34 +116,51 @@ constexpr int LW_STAGE_FLAGS = LW_JB + 3 * MAX_ROWS;   // 3 flag words (as doubl
 constexpr int LW_STAGE_CYCLES = LW_STAGE_FLAGS + 3;    // NBL_CASCADE_TIMING: cycles of the three stage waves and of the final kernel
 static_assert(LW_STAGE_CYCLES + 4 <= LW_TOTAL, "stage results must fit the contact scratch rows");
 
-__global__ __launch_bounds__(192) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade_stages(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+__global__ __launch_bounds__(128) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade_stages(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                                double* __restrict__ saved, SavedLayout lay,
                                                                double* __restrict__ lws, const int32_t* __restrict__ failList,
                                                                const uint32_t* __restrict__ failCount) {
   __shared__ CascadeLds C1;
-  __shared__ PgsLds C2, C3;
+  __shared__ PgsLds C2;
   if (blockIdx.x >= *failCount) return;
 #ifdef NBL_CASCADE_TIMING
   const long long t0 = clock64();
 #endif
   const DevWaveInGroup w;
   const int ln = w.lane();
-  const int stage = (int)(threadIdx.x >> 6);
+  const int wave = (int)(threadIdx.x >> 6);
   const int64_t b = failList[blockIdx.x];
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   double* dn = denseOf(saved, lay, B, b);
   CoopRow R;
   coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
   const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
+  auto publish = [&](int stage, const CoopStageResult& r) {
+    if (ln < MAX_ROWS) lws[(int64_t)(LW_STAGE_X + stage * MAX_ROWS + ln) * B + b] = r.X;
+    if (ln == 0) lws[(int64_t)(LW_STAGE_FLAGS + stage) * B + b] = (double)r.flags;
+  };
   CoopStageResult r;
-  if (stage == 0) coopCascadeStage1(w, C1, R, X0, r);
-  else if (stage == 1) coopCascadeStage2(w, C2, R, X0, cm->fallbackCfm, r);
-  else coopCascadeStage3(w, C3, R, X0, cm->fallbackCfm, r);
-  if (ln < MAX_ROWS) lws[(int64_t)(LW_STAGE_X + stage * MAX_ROWS + ln) * B + b] = r.X;
-  if (ln == 0) lws[(int64_t)(LW_STAGE_FLAGS + stage) * B + b] = (double)r.flags;
+  if (wave == 0) {
+    coopCascadeStage1(w, C1, R, X0, r);
+    publish(0, r);
 #ifdef NBL_CASCADE_TIMING
-  if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + stage) * B + b] = (double)(clock64() - t0);
+    if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 0) * B + b] = (double)(clock64() - t0);
 #endif
+  } else {
+    coopCascadeStage2(w, C2, R, X0, cm->fallbackCfm, r);
+    publish(1, r);
+#ifdef NBL_CASCADE_TIMING
+    const long long t1 = clock64();
+    if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 1) * B + b] = (double)(t1 - t0);
+#endif
+    const bool stage2Valid = (r.flags & (CS_SOLVED | CS_VALID)) == (CS_SOLVED | CS_VALID);
+    r.X = 0.0; r.flags = 0;
+    if (!stage2Valid) coopCascadeStage3(w, C2, R, X0, cm->fallbackCfm, r);
+    publish(2, r);
+#ifdef NBL_CASCADE_TIMING
+    if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 2) * B + b] = (double)(clock64() - t1);
+#endif
+  }
 }
 
 // Select + standardise + outputs for one unresolved world, given the candidates of its three stages (one wavefront).

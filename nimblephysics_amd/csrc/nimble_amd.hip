@@ -503,7 +503,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
                                              (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
                                              failList, failCount));
-      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_stages, dim3((unsigned)cnt), dim3(192), 0, s, mdl, m->dContact, B,
+      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_stages, dim3((unsigned)cnt), dim3(128), 0, s, mdl, m->dContact, B,
                                                (double*)saved, m->lay, lws, failList, failCount));
       TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(k_contact_cascade_final, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
                                                 (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));

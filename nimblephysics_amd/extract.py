@@ -14,7 +14,8 @@ RevoluteJoint,PrismaticJoint,ShapeNode,Shape}.cpp}):
   Skeleton   getNumBodyNodes, getBodyNode
   BodyNode   getName, getParentBodyNode, getParentJoint, getMass, getLocalCOM, getFrictionCoeff, getRestitutionCoeff, getNumShapeNodes, getShapeNode
   Joint      getType, getName, getNumDofs, getTransformFromParentBodyNode, getTransformFromChildBodyNode, getAxis (revolute /
-             prismatic), getDampingCoefficient, getSpringStiffness, getRestPosition, get{Position,Velocity,ControlForce}{Lower,Upper}Limit
+             prismatic), getAxisOrder / getFlipAxisMap (Euler), getAxis1 / getAxis2 (universal), getTranslationalAxis1 / 2 (planar,
+             translational-2D), getDampingCoefficient, getSpringStiffness, getRestPosition, get{Position,Velocity,ControlForce}{Lower,Upper}Limit
   ShapeNode  getShape, getRelativeTranslation, getRelativeRotation;  Shape getType, getSize (BoxShape), getRadius (SphereShape)
 The bindings expose no getter for a body's moment of inertia (`getMomentOfInertia` takes six C++ reference arguments), so it
 is read the way the reference's own Python users read it: on a CLONE of the world every body is registered with
@@ -29,6 +30,8 @@ import numpy as np
 from .model import BodySpec, BoxSpec, ModelDescription
 
 _JOINT_TYPES = {"RevoluteJoint": "revolute", "PrismaticJoint": "prismatic", "FreeJoint": "free", "WeldJoint": "weld"}
+_COMPOUND_TYPES = ("EulerJoint", "UniversalJoint", "TranslationalJoint", "TranslationalJoint2D", "PlanarJoint")
+_UNIT = {"x": (1.0, 0.0, 0.0), "y": (0.0, 1.0, 0.0), "z": (0.0, 0.0, 1.0)}
 
 
 def _mat4(T) -> np.ndarray:
@@ -71,26 +74,49 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
             b = sk.getBodyNode(bi)
             j = b.getParentJoint()
             jt = j.getType()
-            if jt not in _JOINT_TYPES:
-                raise ValueError(f"{b.getName()}: joint type {jt} outside the hot-path scope (revolute, prismatic, free, weld)")
-            jtype = _JOINT_TYPES[jt]
+            if jt not in _JOINT_TYPES and jt not in _COMPOUND_TYPES:
+                raise ValueError(f"{b.getName()}: joint type {jt} outside the hot-path scope (revolute, prismatic, free, weld, "
+                                 "Euler, universal, translational, translational-2D, planar)")
             parent = b.getParentBodyNode()
             pidx = -1 if parent is None else index[parent.getName()]
             nd = int(j.getNumDofs())
             kw = {}
-            if jtype in ("revolute", "prismatic"):
-                axis = tuple(float(x) for x in np.asarray(j.getAxis()).reshape(3))
-                kw = dict(damping=(float(j.getDampingCoefficient(0)),), spring=(float(j.getSpringStiffness(0)),),
-                          rest=(float(j.getRestPosition(0)),),
-                          pos_lo=(_limit(j.getPositionLowerLimit(0), True),), pos_hi=(_limit(j.getPositionUpperLimit(0), False),),
-                          vel_lo=(_limit(j.getVelocityLowerLimit(0), True),), vel_hi=(_limit(j.getVelocityUpperLimit(0), False),),
-                          force_lo=(_limit(j.getControlForceLowerLimit(0), True),), force_hi=(_limit(j.getControlForceUpperLimit(0), False),))
+            axis = (0.0, 0.0, 1.0)
+            vec3 = lambda x: tuple(float(c) for c in np.asarray(x).reshape(3))
+
+            def per_dof():
+                return dict(damping=tuple(float(j.getDampingCoefficient(k)) for k in range(nd)),
+                            spring=tuple(float(j.getSpringStiffness(k)) for k in range(nd)),
+                            rest=tuple(float(j.getRestPosition(k)) for k in range(nd)),
+                            pos_lo=tuple(_limit(j.getPositionLowerLimit(k), True) for k in range(nd)),
+                            pos_hi=tuple(_limit(j.getPositionUpperLimit(k), False) for k in range(nd)),
+                            vel_lo=tuple(_limit(j.getVelocityLowerLimit(k), True) for k in range(nd)),
+                            vel_hi=tuple(_limit(j.getVelocityUpperLimit(k), False) for k in range(nd)),
+                            force_lo=tuple(_limit(j.getControlForceLowerLimit(k), True) for k in range(nd)),
+                            force_hi=tuple(_limit(j.getControlForceUpperLimit(k), False) for k in range(nd)))
+            if jt in _COMPOUND_TYPES:
+                # expanded into 1-DOF chains by ModelDescription (model.py); only the axes differ per class
+                kw = per_dof()
+                if jt == "EulerJoint":
+                    order = j.getAxisOrder()
+                    order = getattr(order, "name", str(order)).split(".")[-1].lower()      # AxisOrder.XYZ -> "xyz"
+                    flip = np.asarray(j.getFlipAxisMap(), dtype=np.float64).reshape(3)
+                    jtype = "euler_" + order
+                    kw["axes"] = [tuple(float(flip[k]) * e for e in _UNIT[c]) for k, c in enumerate(order)]
+                elif jt == "UniversalJoint":
+                    jtype, kw["axes"] = "universal", [vec3(j.getAxis1()), vec3(j.getAxis2())]
+                elif jt == "TranslationalJoint":
+                    jtype = "translational"
+                else:
+                    jtype = "planar" if jt == "PlanarJoint" else "translational2d"
+                    kw["axes"] = [vec3(j.getTranslationalAxis1()), vec3(j.getTranslationalAxis2())]
             else:
-                axis = (0.0, 0.0, 1.0)
-                if jtype == "free":
-                    kw = dict(damping=tuple(float(j.getDampingCoefficient(k)) for k in range(nd)),
-                              spring=tuple(float(j.getSpringStiffness(k)) for k in range(nd)),
-                              rest=tuple(float(j.getRestPosition(k)) for k in range(nd)))
+                jtype = _JOINT_TYPES[jt]
+                if jtype in ("revolute", "prismatic"):
+                    axis = vec3(j.getAxis())
+                    kw = per_dof()
+                elif jtype == "free":
+                    kw = {k_: v for k_, v in per_dof().items() if k_ in ("damping", "spring", "rest")}
             m = inertia_of[(si, bi)]
             bodies.append(BodySpec(b.getName(), pidx, jtype, j.getName(), axis=axis,
                                    T_pj=_mat4(j.getTransformFromParentBodyNode()), T_cj=_mat4(j.getTransformFromChildBodyNode()),

@@ -177,11 +177,12 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8):
     WORLD transform at the zero configuration (:1082-1092), <inertia> mass / offset / moment_of_inertia (:1095-1128; without a
     moment the first shape's inertia for that mass, :618-645; without <inertia> the BodyNode defaults mass 1, I = 1),
     <collision_shape> box / isotropic ellipsoid (= sphere) with its <transformation> in the body frame; per <joint> type
-    weld / revolute / prismatic / free, <parent> ("world" = none) / <child>, <transformation> = T_ChildBodyToJoint and
+    weld / revolute / prismatic / free and the compound types euler (xyz, zyx) / universal / translational / translational2d /
+    planar (expanded into 1-DOF chains by ModelDescription), <parent> ("world" = none) / <child>, <transformation> = T_ChildBodyToJoint and
     T_ParentBodyToJoint = parentWorld^-1 childWorld childToJoint (:1540-1552), <axis> xyz, damping (under <axis> or
     <axis><dynamics>), spring_stiffness / spring_rest_position, <limit> lower / upper (:1870-1960).  Bodies are emitted
-    parents-before-children in the file's joint order, which is the skeleton's DOF order.  Soft bodies, meshes, the other
-    joint types and <init_pos> / <init_vel> (a state, not a model constant) are outside the subset: unsupported joints raise."""
+    parents-before-children in the file's joint order, which is the skeleton's DOF order.  Soft bodies, meshes, ball / screw
+    joints and <init_pos> / <init_vel> (a state, not a model constant) are outside the subset: unsupported joints raise."""
     root = ET.parse(path).getroot()
     world = root.find("world")
     if world is None:
@@ -258,32 +259,69 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8):
                 parentW = np.eye(4) if pn == "world" else Tw[pn]
                 T_pj = np.linalg.inv(parentW) @ Tw[cn] @ c2j
                 kw = {}
+
+                def axis_props(k):
+                    """damping / spring / rest / limits of <axis>, <axis2>, ... (readJointDynamicsAndLimit, :1870-1960): per-DOF
+                    lists of length k with the reference's defaults where an element is missing."""
+                    inf = float("inf")
+                    P = {"damping": [0.0] * k, "spring": [0.0] * k, "rest": [0.0] * k, "pos_lo": [-inf] * k, "pos_hi": [inf] * k}
+                    for i in range(k):
+                        ax = j.find("axis" if i == 0 else f"axis{i + 1}")
+                        if ax is None:
+                            continue
+                        damp = _text(ax, "damping", None)
+                        dyn = ax.find("dynamics")
+                        if dyn is not None:
+                            damp = _text(dyn, "damping", damp)
+                            if _text(dyn, "friction", 0.0) != 0.0:
+                                raise ValueError(f"{j.get('name')}: joint Coulomb friction is outside the hot-path scope")
+                            P["spring"][i] = _text(dyn, "spring_stiffness", 0.0)
+                            P["rest"][i] = _text(dyn, "spring_rest_position", 0.0)
+                        if damp is not None:
+                            P["damping"][i] = damp
+                        lim = ax.find("limit")
+                        if lim is not None:
+                            P["pos_lo"][i] = _text(lim, "lower", -inf)
+                            P["pos_hi"][i] = _text(lim, "upper", inf)
+                    dflt = {"damping": 0.0, "spring": 0.0, "rest": 0.0, "pos_lo": -inf, "pos_hi": inf}
+                    return {key: tuple(v) for key, v in P.items() if any(x != dflt[key] for x in v)}   # all-default: leave unset
+
+                def plane_axes():
+                    """<plane type="xy|yz|zx|arbitrary"> of planar / translational2d joints (:2351-2500; missing: the XY plane)"""
+                    pl = j.find("plane")
+                    kind = pl.get("type") if pl is not None else "xy"
+                    E = {"x": (1.0, 0.0, 0.0), "y": (0.0, 1.0, 0.0), "z": (0.0, 0.0, 1.0)}
+                    if kind == "arbitrary":
+                        return [tuple(float(x) for x in pl.find(f"translation_axis{i}/xyz").text.split()) for i in (1, 2)]
+                    return [E[kind[0]], E[kind[1]]] if kind in ("xy", "yz", "zx") else [E["x"], E["y"]]
+
+                axis = (0.0, 0.0, 1.0)
                 if jt in ("revolute", "prismatic"):
                     ax = j.find("axis")
                     axis = tuple(float(x) for x in ax.find("xyz").text.split())
-                    damp = _text(ax, "damping", None)
-                    dyn = ax.find("dynamics")
-                    if dyn is not None:
-                        damp = _text(dyn, "damping", damp)
-                        if _text(dyn, "friction", 0.0) != 0.0:
-                            raise ValueError(f"{j.get('name')}: joint Coulomb friction is outside the hot-path scope")
-                        if dyn.find("spring_stiffness") is not None:
-                            kw["spring"] = (_text(dyn, "spring_stiffness"),)
-                        if dyn.find("spring_rest_position") is not None:
-                            kw["rest"] = (_text(dyn, "spring_rest_position"),)
-                    if damp is not None:
-                        kw["damping"] = (damp,)
-                    lim = ax.find("limit")
-                    if lim is not None:
-                        if lim.find("lower") is not None:
-                            kw["pos_lo"] = (_text(lim, "lower"),)
-                        if lim.find("upper") is not None:
-                            kw["pos_hi"] = (_text(lim, "upper"),)
+                    kw.update(axis_props(1))
                     jtype = jt
+                elif jt == "euler":
+                    order = j.find("axis_order").text.strip().lower()
+                    if order not in ("xyz", "zyx"):
+                        raise ValueError(f"{j.get('name')}: Euler axis order {order} (the reference's SKEL reader knows xyz and zyx, :2259-2283)")
+                    jtype = "euler_" + order
+                    kw.update(axis_props(3))
+                elif jt == "universal":
+                    jtype = "universal"
+                    kw["axes"] = [tuple(float(x) for x in j.find(a).find("xyz").text.split()) for a in ("axis", "axis2")]
+                    kw.update(axis_props(2))
+                elif jt == "translational":
+                    jtype = "translational"
+                    kw.update(axis_props(3))
+                elif jt in ("translational2d", "planar"):
+                    jtype = jt
+                    kw["axes"] = plane_axes()
+                    kw.update(axis_props(2 if jt == "translational2d" else 3))
                 elif jt == "weld":
-                    jtype, axis = "weld", (0.0, 0.0, 1.0)
+                    jtype = "weld"
                 elif jt == "free":
-                    jtype, axis = "free", (0.0, 0.0, 1.0)
+                    jtype = "free"
                 else:
                     raise ValueError(f"{j.get('name')}: joint type {jt} outside scope")
                 mass, com, I6 = inertial(bel[cn])

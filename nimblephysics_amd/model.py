@@ -7,6 +7,14 @@ needs (reference: dart/simulation/World.cpp:93-172, dart/utils/urdf/DartLoader.c
 dart/utils/SkelParser.cpp).  It carries no dynamics; it only produces the flat arrays of
 `struct nbl_model_desc` (include/nimble_amd.h).
 
+Multi-DOF joints whose transform is a product of one-parameter motions - Euler (any axis order), universal, translational,
+translational-2D and planar joints - are expanded at construction time into chains of revolute / prismatic joints through
+MASSLESS virtual links (`compound_chain`): T_pj * M_1(q_0) ... M_k(q_{k-1}) * T_cj^-1 is literally the reference's
+updateRelativeTransform for these joints (EulerJoint.cpp:1333-1340 with Geometry.cpp:1767-1797, UniversalJoint.cpp:193-201,
+TranslationalJoint.cpp:127-135, TranslationalJoint2D.cpp:232-242, PlanarJoint.cpp:296-307), the generalized coordinates and
+their order are the same, positions integrate the same way (q += dt v), so the dynamics and every derivative are the
+reference's - the kernels only ever see 1-DOF joints.  Ball joints (exponential coordinates) cannot be written this way.
+
 Weld joints are merged into their parents at build time (`merge_welds`): a welded body and its
 parent are one rigid body, so the merged model is mathematically identical to the reference's
 0-DOF WeldJoint treatment (dart/dynamics/WeldJoint.cpp, Skeleton.cpp:12588-12608) while the GPU
@@ -64,9 +72,9 @@ def _t12(T: np.ndarray) -> np.ndarray:
 class BodySpec:
     name: str
     parent: int  # index into the body list, -1 = world
-    joint_type: str  # revolute | prismatic | free | weld
+    joint_type: str  # revolute | prismatic | free | weld, or a compound type (COMPOUND_JOINTS) expanded by ModelDescription
     joint_name: str = ""
-    axis: Sequence[float] = (0.0, 0.0, 1.0)
+    axis: Sequence[float] = (0.0, 0.0, 1.0)   # 1-DOF joints; compound joints: `axes`
     T_pj: np.ndarray = field(default_factory=lambda: np.eye(4))
     T_cj: np.ndarray = field(default_factory=lambda: np.eye(4))
     mass: float = 1.0
@@ -82,7 +90,80 @@ class BodySpec:
     force_lo: Sequence[float] = ()
     force_hi: Sequence[float] = ()
     friction: float = 1.0  # BodyNodeAspect.hpp:47
+    axes: Sequence[Sequence[float]] = ()   # compound joints with free axes (universal: 2, translational2d: 2, planar: 2 in-plane axes)
 
+
+# ---- compound joints: (kind of each one-parameter motion, default axes) ------------------------------------------------
+_E = {"x": (1.0, 0.0, 0.0), "y": (0.0, 1.0, 0.0), "z": (0.0, 0.0, 1.0)}
+COMPOUND_JOINTS = {"universal": 2, "translational": 3, "translational2d": 2, "planar": 3,
+                   **{"euler_" + o: 3 for o in ("xyz", "zyx", "zxy", "xzy", "yxz", "yzx")}}
+
+
+def compound_chain(b: "BodySpec"):
+    """[(joint type, axis)] of the one-parameter motions of compound joint b, in DOF order."""
+    jt = b.joint_type
+    ax = [tuple(float(x) for x in a) for a in b.axes]
+    if jt.startswith("euler_"):
+        # R = R_a(q0) R_b(q1) R_c(q2) for order "abc" (eulerXYZToMatrix = Rx Ry Rz, Geometry.cpp:1767-1797); `axes` may carry the
+        # flipped unit axes of EulerJoint's flipAxisMap (R_a(f q) = R_{f a}(q))
+        return [("revolute", tuple(ax[k]) if ax else _E[c]) for k, c in enumerate(jt[6:])]
+    if jt == "universal":
+        if len(ax) != 2:
+            raise ValueError(f"{b.name}: a universal joint needs two axes")
+        return [("revolute", ax[0]), ("revolute", ax[1])]
+    if jt == "translational":
+        return [("prismatic", _E["x"]), ("prismatic", _E["y"]), ("prismatic", _E["z"])]
+    if jt in ("translational2d", "planar"):
+        if not ax:
+            ax = [_E["x"], _E["y"]]                       # the XY plane (both joints' default)
+        if len(ax) != 2:
+            raise ValueError(f"{b.name}: {jt} needs two in-plane axes")
+        a1 = np.asarray(ax[0], dtype=np.float64); a1 = a1 / np.linalg.norm(a1)
+        a2 = np.asarray(ax[1], dtype=np.float64); a2 = a2 / np.linalg.norm(a2)
+        if jt == "translational2d":
+            return [("prismatic", tuple(float(x) for x in a1)), ("prismatic", tuple(float(x) for x in a2))]
+        d = float(a1 @ a2)                                 # setArbitraryPlane (PlanarJointAspect.cpp:115-136)
+        if abs(d) > 1e-6:
+            a2 = a2 - d * a1; a2 = a2 / np.linalg.norm(a2)
+        rot = np.cross(a1, a2); rot = rot / np.linalg.norm(rot)
+        return [("prismatic", tuple(float(x) for x in a1)), ("prismatic", tuple(float(x) for x in a2)), ("revolute", tuple(float(x) for x in rot))]
+    raise ValueError(f"{b.name}: unknown compound joint {jt}")
+
+
+def expand_compound_joints(bodies, boxes):
+    """Replace every compound joint by its chain of 1-DOF joints through massless virtual links.  Returns (bodies, boxes, index
+    of each input body in the output list)."""
+    if not any(b.joint_type in COMPOUND_JOINTS for b in bodies):
+        return list(bodies), list(boxes), list(range(len(bodies)))
+    out, where = [], []
+    for b in bodies:
+        parent = -1 if b.parent < 0 else where[b.parent]
+        if b.joint_type not in COMPOUND_JOINTS:
+            nb = BodySpec(**{**b.__dict__}); nb.parent = parent
+            where.append(len(out)); out.append(nb)
+            continue
+        chain = compound_chain(b)
+        k = len(chain)
+
+        def dof(vals, i):
+            vals = tuple(vals)
+            if len(vals) not in (0, k):
+                raise ValueError(f"{b.name}: per-DOF property with {len(vals)} entries on a {k}-DOF joint")
+            return (vals[i],) if vals else ()
+        for i, (jt, axis) in enumerate(chain):
+            last = i == k - 1
+            nb = BodySpec(
+                b.name if last else f"{b.name}#v{i}", parent, jt, f"{b.joint_name or b.name}_{i}", axis=axis,
+                T_pj=np.array(b.T_pj, dtype=np.float64) if i == 0 else np.eye(4), T_cj=np.array(b.T_cj, dtype=np.float64) if last else np.eye(4),
+                mass=b.mass if last else 0.0, com=tuple(b.com) if last else (0.0, 0.0, 0.0),
+                inertia=tuple(b.inertia) if last else (0.0,) * 6,
+                **{key: dof(getattr(b, key), i) for key in ("damping", "spring", "rest", "pos_lo", "pos_hi", "vel_lo", "vel_hi", "force_lo", "force_hi")},
+                friction=b.friction)
+            parent = len(out)
+            out.append(nb)
+        where.append(len(out) - 1)
+    nboxes = [BoxSpec(bx.body if bx.body < 0 else where[bx.body], bx.T, tuple(bx.size), bx.mu, bx.shape, bx.restitution) for bx in boxes]
+    return out, nboxes, where
 
 @dataclass
 class BoxSpec:
@@ -119,8 +200,8 @@ class ModelDescription:
                  max_contacts: int = 0, contact_clipping_depth: float = 0.03, fallback_cfm: float = 1e-4,
                  penetration_correction: bool = False):
         self.name = name
-        self.bodies = list(bodies)
-        self.boxes = list(boxes or [])
+        # compound joints -> chains of 1-DOF joints (module docstring); body_index[i] = where input body i ended up
+        self.bodies, self.boxes, self.body_index = expand_compound_joints(list(bodies), list(boxes or []))
         self.gravity = tuple(float(g) for g in gravity)
         self.dt = float(dt)
         self._action_map = None if action_map is None else [int(a) for a in action_map]
@@ -331,7 +412,8 @@ class ModelDescription:
     # ---- (de)serialisation ------------------------------------------------------------------
     def to_json(self) -> dict:
         def body(b: BodySpec):
-            d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()}
+            d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()
+                 if k != "axes"}       # compound joints are already expanded: every stored joint has its single `axis`
             return d
         return {
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,

@@ -30,12 +30,26 @@ class _ShapeNode:
 
 
 class _Joint:
-    TYPES = {"revolute": "RevoluteJoint", "prismatic": "PrismaticJoint", "free": "FreeJoint", "weld": "WeldJoint"}
+    TYPES = {"revolute": "RevoluteJoint", "prismatic": "PrismaticJoint", "free": "FreeJoint", "weld": "WeldJoint",
+             "universal": "UniversalJoint", "translational": "TranslationalJoint", "translational2d": "TranslationalJoint2D",
+             "planar": "PlanarJoint"}
 
     def __init__(self, b): self._b = b
-    def getType(self): return self.TYPES[self._b.joint_type]
+    def getType(self): return "EulerJoint" if self._b.joint_type.startswith("euler_") else self.TYPES[self._b.joint_type]
     def getName(self): return self._b.joint_name
-    def getNumDofs(self): return {"free": 6, "weld": 0}.get(self._b.joint_type, 1)
+    def getNumDofs(self):
+        from nimblephysics_amd.model import COMPOUND_JOINTS
+        return COMPOUND_JOINTS.get(self._b.joint_type, {"free": 6, "weld": 0}.get(self._b.joint_type, 1))
+    # the class-specific getters of the compound joints (python/_nimblephysics/dynamics/{Euler,Universal,Planar,TranslationalJoint2D}Joint.cpp)
+    def getAxisOrder(self):
+        import enum
+        return enum.Enum("AxisOrder", "XYZ XZY ZYX ZXY")[self._b.joint_type[6:].upper()]
+    def getFlipAxisMap(self): return np.array(self._flip)
+    _flip = (1.0, 1.0, 1.0)
+    def getAxis1(self): return np.array(self._b.axes[0], dtype=np.float64)
+    def getAxis2(self): return np.array(self._b.axes[1], dtype=np.float64)
+    def getTranslationalAxis1(self): return np.array(self._b.axes[0], dtype=np.float64)
+    def getTranslationalAxis2(self): return np.array(self._b.axes[1], dtype=np.float64)
     def getTransformFromParentBodyNode(self): return _Iso(self._b.T_pj)
     def getTransformFromChildBodyNode(self): return _Iso(self._b.T_cj)
     def getAxis(self): return np.array(self._b.axis, dtype=np.float64)
@@ -162,3 +176,26 @@ def test_unsupported_joint_types_raise():
             model_from_nimble_world(w)
     finally:
         _Joint.TYPES = dict(_Joint.TYPES, revolute="RevoluteJoint")
+
+
+def test_compound_joints_are_extracted_through_their_class_getters():
+    """Euler (axis order + flip map), universal, planar, translational-2D and translational joints of a live world come back as
+    the same 1-DOF chains the SKEL loader builds for them."""
+    import os
+    import types
+    from test_compound_joints import _skel_bodies
+    raw, md = _skel_bodies()
+    shell = types.SimpleNamespace(bodies=raw, boxes=[], dt=md.dt, gravity=md.gravity, action_map=list(range(md.num_dofs)),
+                                  contact_clipping_depth=md.contact_clipping_depth, fallback_cfm=md.fallback_cfm,
+                                  penetration_correction=False)
+    got = model_from_nimble_world(StandInWorld(shell), name=md.name, max_contacts=0)
+    assert [b.joint_type for b in got.bodies] == [b.joint_type for b in md.bodies] and got.num_dofs == md.num_dofs
+    _same(got, md)
+    # EulerJoint's flipAxisMap: R_a(f q) = R_{f a}(q) -> the chain rotates about the flipped unit axis
+    _Joint._flip = (1.0, -1.0, 1.0)
+    try:
+        flipped = model_from_nimble_world(StandInWorld(shell), name=md.name, max_contacts=0)
+    finally:
+        _Joint._flip = (1.0, 1.0, 1.0)
+    k = [i for i, b in enumerate(flipped.bodies) if b.name == "upper#v1"][0]
+    assert tuple(flipped.bodies[k].axis) == (0.0, -1.0, 0.0) and tuple(got.bodies[k].axis) == (0.0, 1.0, 0.0)
