@@ -279,6 +279,9 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   const int C = (int)out.contacts.size();
   if (C == 0) return;
   *status |= NBL_ST_CONTACT;
+  // The reference has no contact cap; the device path keeps max_contacts and flags the world.  The oracle solves with all of
+  // them (like the reference) and raises the same flag, so that a comparison knows which worlds the device truncated.
+  if (m.maxContacts > 0 && C > m.maxContacts) *status |= 0x80u;   // NBL_ST_CONTACT_OVERFLOW
 
   // body velocities at the post-ABA, pre-contact velocity (ContactConstraint::getRelVelocity)
   std::vector<Kin> kinPre;

@@ -1,0 +1,77 @@
+"""Randomised parity soak (GPU box): random articulated trees with random colliders (boxes / spheres, random friction incl.
+frictionless, restitution, penetration correction on/off) dropped on the ground; every world's next state and gradients are
+compared with the CPU oracle.  A world above 1e-5 must be one where the oracle itself flips under 1-ulp input perturbations
+(the criterion of tests/test_gpu_contact.py), otherwise it is reported as a MISMATCH.
+  usage: python tools/soak_parity.py [first seed] [count] [B] [big]      (big: 8-21 bodies, 3-7 colliders)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import nimblephysics_amd as na  # noqa: E402
+from nimblephysics_amd.timestep import timestep  # noqa: E402
+from oracle import OracleWorld  # noqa: E402
+from test_gpu_random_trees import random_tree  # noqa: E402
+
+
+
+def run(first=0, count=20, B=256, verbose=True, big=False):
+  tot = {"worlds": 0, "contact": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "MISMATCH": 0}
+  for seed in range(first, first + count):
+      rng = np.random.default_rng(50000 + seed)
+      nb = int(rng.integers(8, 22)) if big else int(rng.integers(1, 10))
+      md = random_tree(rng, nb, rng.choice(["chain", "star", "random"]), True, welds=0.2 if rng.random() < 0.3 else 0,
+                       colliders=int(rng.integers(3, 8)) if big else int(rng.integers(1, 4)), spheres=bool(rng.random() < 0.4))
+      for bx in md.boxes:
+          r = rng.random()
+          bx.mu = 0.0 if r < 0.15 else (float(rng.uniform(0.05, 1.5)))
+          bx.restitution = float(rng.uniform(0.3, 1.0)) if rng.random() < 0.3 else 0.0
+      md.penetration_correction = bool(rng.random() < 0.3)
+      n = md.num_dofs
+      if n > 40:
+          continue
+      q = rng.normal(0, 0.25, (B, n)); q[:, 3] = rng.normal(0, 0.3, B); q[:, 5] = rng.normal(0, 0.3, B)
+      q[:, 4] = rng.uniform(0.02, 0.5, B)
+      v = rng.normal(0, rng.choice([0.05, 0.5, 2.0]), (B, n))
+      s = np.concatenate([q, v], 1); a = rng.normal(0, 0.5, (B, len(md.action_map))); g = rng.normal(0, 1, s.shape)
+      world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
+      st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+      out = timestep(world, st, at)
+      status = world.last_status.cpu().numpy().astype(np.uint32)
+      out.backward(torch.tensor(g, device="cuda:0"))
+      ref = ow.step_batch(s, a, g, threads=8)
+      dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
+      scales = {k: max(np.abs(ref[k]).max(), 1e-30) for k in dev}
+      err = np.maximum.reduce([np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev])
+      overflow = ((status | ref["status"]) & 0x80) != 0
+      err[overflow] = 0.0                                   # more than 8 contacts: flagged by both, results undefined
+      assert np.array_equal(status & 0x81, ref["status"] & 0x81), ("contact / overflow flags differ", seed)
+      bad = np.where(err > 1e-5)[0]
+      unstable = mismatch = 0
+      prng = np.random.default_rng(1)
+      for wd in bad:
+          sp = s[wd][None] * (1.0 + prng.choice([-1.0, 0.0, 1.0], (64, s.shape[1])) * 2.220446049250313e-16)
+          r = ow.step_batch(sp, np.repeat(a[wd][None], 64, 0), np.repeat(g[wd][None], 64, 0), threads=8)
+          dist = np.maximum.reduce([np.abs(r[k] - dev[k][wd][None]).max(1) / scales[k] for k in dev])
+          spread = max(np.abs(r[k] - ref[k][wd][None]).max() / scales[k] for k in dev)
+          if spread > 1e-5 and dist.min() <= max(1e-5, 0.1 * spread):
+              unstable += 1
+          else:
+              mismatch += 1
+              print(f"  MISMATCH seed {seed} world {wd}: err {err[wd]:.2e} spread {spread:.2e} nearest {dist.min():.2e} status dev {status[wd]:#x} ref {ref['status'][wd]:#x}")
+      c = (status & 1) != 0
+      tot["worlds"] += B; tot["contact"] += int(c.sum()); tot["cascade"] += int((c & ((status & 2) == 0)).sum())
+      tot["gt1e-7"] += int((err > 1e-7).sum()); tot["gt1e-5"] += len(bad); tot["unstable"] += unstable; tot["MISMATCH"] += mismatch
+      if verbose:
+          print(f"seed {seed}: nb {nb} n {n} colliders {len(md.boxes) - 1} contact {c.mean():.2f} cascade {(c & ((status & 2) == 0)).mean():.2f} "
+              f"max err {err.max():.1e} >1e-7 {(err > 1e-7).sum()} >1e-5 {len(bad)} (unstable {unstable}, mismatch {mismatch})", flush=True)
+  return tot
+
+
+if __name__ == "__main__":
+    print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 20,
+              int(sys.argv[3]) if len(sys.argv) > 3 else 256, big=len(sys.argv) > 4 and sys.argv[4] == "big"))
