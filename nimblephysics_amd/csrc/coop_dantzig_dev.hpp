@@ -684,10 +684,10 @@ DEV bool coopPgs(const W& w, LDS& C, int n, CoopLcpRow& row) {
 // ---- stages 1-3 of BoxedLcpConstraintSolver::solveLcp (:461-677) + registration / standardisation (:718-736) ----
 // The three fallback stages read the same inputs (A, b, the pre-solve x) and none reads another's result - only WHICH result
 // is kept depends on the earlier stages' success flags.  They are therefore written as three independent functions that the
-// kernel runs on three wavefronts of a workgroup AT THE SAME TIME (k_contact_cascade_stages); coopCascadeSelect then applies
+// kernel runs on two wavefronts of a workgroup AT THE SAME TIME (stage 1 | stages 2 and 3, k_contact_cascade_stages); coopCascadeSelect then applies
 // the reference's order of preference.  A world that falls through to the frictionless stage (two thirds of the worlds that
 // reach the cascade on the metric distribution) used to pay reduce + Dantzig + reduce + 30 PGS sweeps + 30 PGS sweeps one after
-// the other (5.2e5 cycles); now it pays the longest of the three.
+// the other (5.2e5 cycles); now it pays the longer of stage 1 and stages 2 + 3.
 struct CoopStageResult {
   double X;        // this lane's row of the stage's solution, mapped back to the world's rows
   int flags;       // uniform, CS_*

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
 }
 
 // Self-test of the device Dantzig driver (nbl_selftest_lcp_dantzig): one wavefront per problem of a batch of n-row boxed LCPs
-// with explicit bounds, exactly the code k_contact_cascade_coop runs in its stage 1.  Problems are dense [count][n * n] / [count][n].
+// with explicit bounds, exactly the code k_contact_cascade_stages runs in its stage 1.  Problems are dense [count][n * n] / [count][n].
 __global__ __launch_bounds__(64) void k_selftest_dantzig(int count, int n, const double* __restrict__ A, const double* __restrict__ b,
                                                         const double* __restrict__ lo, const double* __restrict__ hi,
                                                         const int32_t* __restrict__ findex, double* __restrict__ x, int32_t* __restrict__ rc) {

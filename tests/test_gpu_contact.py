@@ -76,7 +76,7 @@ def _report(tag, errs):
 @pytest.mark.parametrize("B,seed", [(1024, 13), (4096, 23)])
 def test_full_lcp_cascade_on_noisy_poses(B, seed):
     """The metric distribution (joint noise N(0, 0.02^2)): about half of the worlds leave stage 0 and go through reduce +
-    Dantzig, CFM + PGS and the frictionless fallback on the device (k_contact_cascade_coop).  The stage-0 world set must
+    Dantzig, CFM + PGS and the frictionless fallback on the device (k_contact_cascade_stages / k_contact_cascade_final).  The stage-0 world set must
     equal the oracle's.  Next state AND gradients of EVERY world within north_star's 1e-5 of the oracle, none masked out -
     except worlds where the reference algorithm itself is proven unstable (see the helper; ~0.2 % here), which must equal
     one of the reference's own outcomes.  The device Dantzig is bit-identical to the reference's on identical inputs
