@@ -123,6 +123,13 @@ typedef struct nbl_model_desc {
    * harder than that (ContactConstraint.cpp:393-441 with DART_ERROR_ALLOWANCE / DART_ERP / DART_MAX_ERV, :45-47).  Like the
    * reference's analytical Jacobians the backward pass treats the correction velocity as a constant. */
   int32_t penetration_correction;
+
+  /* ---- skeletons (appended; NULL = every tree of the model is its own skeleton) ----
+   * [n_bodies] index of the dart::dynamics::Skeleton a body belongs to.  The reference solves one LCP per CONSTRAINED GROUP: the
+   * skeletons connected by contacts between two reactive bodies (ConstraintSolver.cpp:724-780, ContactConstraint.cpp:879-907;
+   * contacts with world-fixed colliders do not connect anything).  Each group runs the solver cascade on its own, so one
+   * object that needs the fallback stages does not change the solution of the others. */
+  const int32_t* body_skeleton;
 } nbl_model_desc;
 
 #define NBL_SHAPE_BOX 0

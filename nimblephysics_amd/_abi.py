@@ -69,4 +69,5 @@ class ModelDesc(C.Structure):
         ("box_shape", _pi),
         ("box_restitution", _pd),
         ("penetration_correction", C.c_int32),
+        ("body_skeleton", _pi),
     ]

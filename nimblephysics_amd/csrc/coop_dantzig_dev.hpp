@@ -717,7 +717,7 @@ DEV void coopLoadProblem(const W& w, LDS& C, const CoopRow& R, double cfmDiag, d
   // The empty tangent rows of frictionless contacts (mu <= 1e-3, k_contact_rows_coop) do not exist in the reference's problem
   // (ContactConstraint dimension 1): take them out, from the last one down, so that the solvers see the reference's rows in the
   // reference's order - the initial permutation of dSolveLCP and with it the whole pivot sequence depend on it.
-  const uint32_t dead = (uint32_t)w.ballot(ln < m && R.fric && R.mu == 0.0);
+  const uint32_t dead = (uint32_t)w.ballot(ln < m && (!R.on || (R.fric && R.mu == 0.0)));   // ... and the rows of the world's other constrained groups
   nOut = m;
   if (dead != 0u) {
     for (int i = m - 1; i >= 0; i--) {

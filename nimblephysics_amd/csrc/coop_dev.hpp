@@ -260,7 +260,8 @@ struct CoopRow {
   double mu, Bv, colNorm;
   const double* Acol;  // &A[0][lane] (stride MAXR): column (= row, A is symmetric) `lane` of A.  Re-read where needed
                        // instead of being held in 48 VGPRs across the factorisations (it stays in L2).
-  bool on;             // lane < m
+  bool on;             // this lane's row exists in the problem being solved: lane < m and, where a world has several
+                       // constrained groups, its row belongs to the group at hand (rows that are off are inert everywhere)
   DEV double a(int i) const { return (on && i < m) ? Acol[i * MAXR] : 0.0; }
   // The same column through a pointer the optimiser cannot see through: without it the 24 loads are hoisted out of the
   // standardisation loop and kept in 48 VGPRs across both factorisations (which is exactly what re-reading is meant to avoid).
@@ -278,7 +279,7 @@ struct CoopRow {
 template <class W>
 DEV double coopAx(const W& w, double* vec, const CoopRow& R, double xLane) {
   const int ln = w.lane();
-  if (ln < MAXR) vec[ln] = (ln < R.m) ? xLane : 0.0;
+  if (ln < MAXR) vec[ln] = R.on ? xLane : 0.0;
   w.sync();
   double v = 0.0;
   const double* Ac = R.fresh();
@@ -295,7 +296,7 @@ DEV bool coopValid(const W& w, double* vec, const CoopRow& R, double X, bool ign
   const double v = -R.Bv + cfm * X + coopAx(w, vec, R, X);
   const double Xn = w.shfl(X, R.fp);
   bool ok = true;
-  if (ln < R.m) {
+  if (R.on) {
     double upper = R.fric ? R.mu : INFINITY, lower = R.fric ? -R.mu : 0.0;
     bool skip = false;
     if (R.fric) {
@@ -336,7 +337,7 @@ DEV void coopClassify(const W& w, const CoopRow& R, double X, bool ignoreFrictio
   if (R.fric) { upper *= Xn; lower *= Xn; }
   int cls = RC_NOT_CLAMPING;
   bool inElse = false;
-  if (ln < R.m && !(R.colNorm < 1e-9)) {
+  if (R.on && !(R.colNorm < 1e-9)) {
     if (fabs(X) < TH) {
       if (R.fric && !(fabs(Xn) < TH) && !ignoreFriction) cls = RC_CLAMPING;
     } else if ((X > lower + tie && X < upper - tie) || (lower - X > 1e-2 || X - upper > 1e-2)) {
@@ -448,9 +449,9 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
   double X = 0.0;
   uint32_t guessMask = 0;
   bool pinvValid = false;
-  if (haveCache) X = ln < R.m ? Xcache : 0.0;
+  if (haveCache) X = R.on ? Xcache : 0.0;
   else {
-    const bool in = ln < R.m && (R.fric ? R.mu != 0.0 : R.Bv > 0);   // (the empty tangent rows of frictionless contacts are not rows of the reference's problem)
+    const bool in = R.on && (R.fric ? R.mu != 0.0 : R.Bv > 0);   // (the empty tangent rows of frictionless contacts are not rows of the reference's problem)
     guessMask = (uint32_t)w.ballot(in);
     if (guessMask != 0) {
       double a[MAXR];

@@ -10,6 +10,17 @@
 
 namespace nbl {
 
+// Scratch rows of an unresolved world between k_contact_solve_coop, k_contact_cascade_stages and k_contact_cascade_final
+// (rows LW_JA .. of the per-world contact scratch):
+constexpr int LW_X0 = LW_JA;                            // MAX_ROWS: the pre-solve x (mXBackup) of every row
+constexpr int LW_OKX = LW_JA + MAX_ROWS;                // MAX_ROWS: x of the rows whose constrained group stage 0 resolved ...
+constexpr int LW_OKCLS = LW_JA + 2 * MAX_ROWS;          // MAX_ROWS: ... and their row class (+-2 = upper bound with E = +-mu)
+constexpr int LW_STAGE_X = LW_JB;                       // 3 x MAX_ROWS candidate solutions (a group's rows only hold its own)
+constexpr int LW_STAGE_FLAGS = LW_JB + 3 * MAX_ROWS;    // 3 x MAX_CONTACTS flag words [stage][group] (as doubles)
+constexpr int LW_FAILMASK = LW_STAGE_FLAGS + 3 * MAX_CONTACTS;   // bit g: constrained group g was not resolved by stage 0
+constexpr int LW_STAGE_CYCLES = LW_FAILMASK + 1;        // NBL_CASCADE_TIMING: cycles of the stage waves and of the final kernel
+static_assert(LW_STAGE_CYCLES + 4 <= LW_TOTAL, "stage results must fit the contact scratch rows");
+
 DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved, const double* __restrict__ dn,
                      const SavedLayout& lay, const DevContactModel* __restrict__ cm, int64_t B, int64_t b) {
   R.m = m;
@@ -32,6 +43,45 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
   R.colNorm = cn;
 }
 
+// Constrained groups of a world's contacts (ConstraintSolver::buildConstrainedGroups :724-780, ContactConstraint::uniteSkeletons
+// :879-907): skeletons connected by a contact between two reactive bodies are one group, contacts with world-fixed colliders connect
+// nothing; groups are numbered by their first contact.  Returns the number of groups, gid = the group of this lane's row.  The
+// reference runs its whole solver cascade once per group; almost every world has one.
+template <class W>
+DEV int coopGroups(const W& w, const DevContactModel* __restrict__ cm, const double* __restrict__ saved, const SavedLayout& lay,
+                   int64_t B, int64_t b, int m, int& gid) {
+  const int ln = w.lane();
+  const int nC = m / 3;
+  int u = 0, v = 0;                       // lane c < nC: the skeleton(s) contact c acts on
+  if (ln < nC) {
+    const int r0 = lay.contacts + ln * CR_SIZE;
+    const int bxA = (int)saved[(int64_t)(r0 + CR_BOXA) * B + b], bxB = (int)saved[(int64_t)(r0 + CR_BOXB) * B + b];
+    const int bA = cm->boxes[bxA].body, bB = cm->boxes[bxB].body;
+    const int sA = bA >= 0 ? cm->skelOf[bA] : -1, sB = bB >= 0 ? cm->skelOf[bB] : -1;
+    u = sA >= 0 ? sA : sB;
+    v = (sA >= 0 && sB >= 0) ? sB : u;
+    if (u < 0) { u = 0; v = 0; }
+  }
+  // the usual case first: every contact acts on one and the same skeleton (a robot standing on the ground)
+  const int u0 = w.bcastI(u, 0);
+  if (w.ballot(ln < nC && (u != u0 || v != u0)) == 0ull) { gid = 0; return 1; }
+  int lab = ln;                           // lane s: label of skeleton s; uniting relabels a whole component, so one pass over the contacts is enough
+  for (int c = 0; c < nC; c++) {
+    const int uc = w.bcastI(u, c), vc = w.bcastI(v, c);
+    const int lu = w.bcastI(lab, uc), lv = w.bcastI(lab, vc);
+    const int mn = lu < lv ? lu : lv;
+    if (lab == lu || lab == lv) lab = mn;
+  }
+  const int myLab = w.shflI(lab, u);      // lane c: the component of contact c
+  uint32_t eq = 0;
+  for (int c = 0; c < nC; c++) { const int lc = w.bcastI(myLab, c); if (myLab == lc) eq |= 1u << c; }
+  const int firstOf = (ln < nC && eq != 0u) ? __builtin_ctz(eq) : 0;
+  const uint32_t firstMask = (uint32_t)w.ballot(ln < nC && firstOf == ln);
+  const int g = __builtin_popcount(firstMask & ((1u << firstOf) - 1u));
+  gid = w.shflI(g, ln < MAXR ? ln / 3 : 0);
+  return __builtin_popcount(firstMask);
+}
+
 // x, classes, cfm, warm start, v' = v_pre + M^-1 J^T x and (when valid) the pseudo-inverse of the final Q -> saved record
 template <class W>
 DEV void coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValid,
@@ -44,7 +94,8 @@ DEV void coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, cons
     if (cacheOut) cacheOut[(int64_t)ln * B + b] = X;
   }
   if (ln == MAX_ROWS && cacheOut) cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
-  if (ln == 0) { svAt(saved, lay.cfm, B, b) = cfm; svAt(saved, lay.pflag, B, b) = pinvValid ? 1.0 : 0.0; }
+  if (ln < MAX_ROWS) svAt(saved, lay.cfm + ln, B, b) = cfm;     // this row's constant (its group's, CFM_CONSTANTS)
+  if (ln == 0) svAt(saved, lay.pflag, B, b) = pinvValid ? 1.0 : 0.0;
   // v' = v_pre + M^-1 J^T x  (lane = DOF)
   if (ln < MAXR) S.vec[2][ln] = X;
   w.sync();
@@ -61,6 +112,9 @@ DEV void coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, cons
   }
 }
 
+// MULTI: the model has colliders on more than one skeleton, so a world can hold several constrained groups (decided when the model
+// is created; the single-skeleton instantiation carries none of the group code).
+template <bool MULTI>
 __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
                                                            const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
@@ -81,7 +135,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   if (m == 0) {
     if (cacheOut && ln <= MAX_ROWS) cacheOut[(int64_t)ln * B + b] = 0.0;
     if (ln < MAX_ROWS) { svAt(saved, lay.x + ln, B, b) = 0.0; svAt(saved, lay.cls + ln, B, b) = 0.0; }
-    if (ln == 0) { svAt(saved, lay.cfm, B, b) = 0.0; svAt(saved, lay.pflag, B, b) = 0.0; }
+    if (ln < MAX_ROWS) svAt(saved, lay.cfm + ln, B, b) = 0.0;
+    if (ln == 0) svAt(saved, lay.pflag, B, b) = 0.0;
     if (ln < n) svAt(saved, lay.w + ln, B, b) = 0.0;
     return;
   }
@@ -91,16 +146,57 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
   const double Xcache = (haveCache && ln < m) ? cacheIn[(int64_t)ln * B + b] : 0.0;
   NBL_PHASE(42);
-  CoopStage0 out;
-  coopStage0(w, S, R, haveCache, Xcache, out);
-  if (out.ok) {
-    coopContactOutputs(w, S, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+  int gid = 0;
+  const int nGroups = MULTI ? coopGroups(w, cm, saved, lay, B, b, m, gid) : 1;
+  if (!MULTI || nGroups == 1) {
+    CoopStage0 out;
+    coopStage0(w, S, R, haveCache, Xcache, out);
+    if (out.ok) {
+      coopContactOutputs(w, S, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+      if (ln == 0 && status) status[b] |= 0x2u | 0x100u;
+      NBL_PHASE(47);
+    } else {
+      // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
+      if (ln < MAX_ROWS) lws[(int64_t)(LW_X0 + ln) * B + b] = out.X0;
+      if (ln == 0) { lws[(int64_t)LW_FAILMASK * B + b] = 1.0; const uint32_t slot = atomicAdd(failCount, 1u); failList[slot] = (int32_t)b; }
+    }
+    return;
+  }
+  // Several constrained groups: stage 0 group by group (rows of the other groups switched off).  Groups that resolve keep their
+  // result whatever happens to the others; the world goes to the cascade kernels with the mask of the groups that did not.
+  double X = 0.0, X0 = 0.0, E = 0.0;
+  int cls = RC_NOT_CLAMPING;
+  uint32_t failMask = 0u;
+  for (int g = 0; g < nGroups; g++) {
+    CoopRow Rg = R;
+    Rg.on = R.on && gid == g;
+    CoopStage0 out;
+    coopStage0(w, S, Rg, haveCache, Xcache, out);
+    if (Rg.on) { X = out.X; X0 = out.X0; cls = out.K.cls; E = out.K.E; }
+    if (!out.ok) failMask |= 1u << g;
+  }
+  if (failMask == 0u) {
+    CoopClasses K;
+    K.cls = cls; K.E = E;
+    K.clampMask = (uint32_t)w.ballot(cls == RC_CLAMPING); K.ubMask = (uint32_t)w.ballot(cls == RC_UPPER_BOUND);
+    K.nc = __builtin_popcount(K.clampMask); K.nu = __builtin_popcount(K.ubMask);
+    bool pinvValid = false;
+    if (K.nc > 0) {                                       // Q^+ of the whole clamping set (block diagonal over the groups) for the record
+      double a[MAXR];
+      coopBuildQ(w, S, R, K, 0.0, a);
+      coopPinv(w, a, S, K.nc);
+      pinvValid = true;
+    }
+    coopContactOutputs(w, S, n, m, X, K, 0.0, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
     if (ln == 0 && status) status[b] |= 0x2u | 0x100u;
-    NBL_PHASE(47);
   } else {
-    // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
-    if (ln < MAX_ROWS) lws[(int64_t)(LW_JA + ln) * B + b] = out.X0;
-    if (ln == 0) { const uint32_t slot = atomicAdd(failCount, 1u); failList[slot] = (int32_t)b; }
+    // rows of resolved groups: their result (x, class) waits in the scratch rows for k_contact_cascade_final
+    if (ln < MAX_ROWS) {
+      lws[(int64_t)(LW_X0 + ln) * B + b] = X0;
+      lws[(int64_t)(LW_OKX + ln) * B + b] = X;
+      lws[(int64_t)(LW_OKCLS + ln) * B + b] = cls == RC_UPPER_BOUND ? (E > 0 ? 2.0 : -2.0) : (double)cls;
+    }
+    if (ln == 0) { lws[(int64_t)LW_FAILMASK * B + b] = (double)failMask; const uint32_t slot = atomicAdd(failCount, 1u); failList[slot] = (int32_t)b; }
   }
 }
 
@@ -111,11 +207,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
 // both PGS stages; each wavefront leaves its candidate solutions and flags in the world's scratch rows and
 // k_contact_cascade_final picks one in the reference's order of preference and standardises it.  The wavefronts of a group never
 // wait for each other (DevWaveInGroup::sync is a wave-level fence, not a workgroup barrier).
-constexpr int LW_STAGE_X = LW_JB;                 // 3 x MAX_ROWS candidate solutions
-constexpr int LW_STAGE_FLAGS = LW_JB + 3 * MAX_ROWS;   // 3 flag words (as doubles)
-constexpr int LW_STAGE_CYCLES = LW_STAGE_FLAGS + 3;    // NBL_CASCADE_TIMING: cycles of the three stage waves and of the final kernel
-static_assert(LW_STAGE_CYCLES + 4 <= LW_TOTAL, "stage results must fit the contact scratch rows");
 
+template <bool MULTI>
 __global__ __launch_bounds__(128) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade_stages(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                                double* __restrict__ saved, SavedLayout lay,
                                                                double* __restrict__ lws, const int32_t* __restrict__ failList,
@@ -134,66 +227,49 @@ __global__ __launch_bounds__(128) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade
   double* dn = denseOf(saved, lay, B, b);
   CoopRow R;
   coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
-  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
-  auto publish = [&](int stage, const CoopStageResult& r) {
-    if (ln < MAX_ROWS) lws[(int64_t)(LW_STAGE_X + stage * MAX_ROWS + ln) * B + b] = r.X;
-    if (ln == 0) lws[(int64_t)(LW_STAGE_FLAGS + stage) * B + b] = (double)r.flags;
-  };
-  CoopStageResult r;
-  if (wave == 0) {
-    coopCascadeStage1(w, C1, R, X0, r);
-    publish(0, r);
+  const double X0 = ln < m ? lws[(int64_t)(LW_X0 + ln) * B + b] : 0.0;
+  // the constrained groups stage 0 left unresolved, one after the other (almost always: the world's only group)
+  const uint32_t failMask = MULTI ? (uint32_t)lws[(int64_t)LW_FAILMASK * B + b] : 1u;
+  int gid = 0;
+  if (MULTI) coopGroups(w, cm, saved, lay, B, b, m, gid);
+  const bool rowOn = R.on;
+#pragma unroll 1
+  for (int g = 0; g < (MULTI ? MAX_CONTACTS : 1); g++) {
+    if (!((failMask >> g) & 1u)) continue;
+    R.on = rowOn && gid == g;
+    CoopRow& Rg = R;
+    auto publish = [&](int stage, const CoopStageResult& r) {
+      if (Rg.on) lws[(int64_t)(LW_STAGE_X + stage * MAX_ROWS + ln) * B + b] = r.X;
+      if (ln == 0) lws[(int64_t)(LW_STAGE_FLAGS + stage * MAX_CONTACTS + g) * B + b] = (double)r.flags;
+    };
+    CoopStageResult r;
+    if (wave == 0) {
+      coopCascadeStage1(w, C1, Rg, X0, r);
+      publish(0, r);
 #ifdef NBL_CASCADE_TIMING
-    if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 0) * B + b] = (double)(clock64() - t0);
+      if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 0) * B + b] = (double)(clock64() - t0);
 #endif
-  } else {
-    coopCascadeStage2(w, C2, R, X0, cm->fallbackCfm, r);
-    publish(1, r);
+    } else {
+      coopCascadeStage2(w, C2, Rg, X0, cm->fallbackCfm, r);
+      publish(1, r);
 #ifdef NBL_CASCADE_TIMING
-    const long long t1 = clock64();
-    if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 1) * B + b] = (double)(t1 - t0);
+      const long long t1 = clock64();
+      if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 1) * B + b] = (double)(t1 - t0);
 #endif
-    const bool stage2Valid = (r.flags & (CS_SOLVED | CS_VALID)) == (CS_SOLVED | CS_VALID);
-    r.X = 0.0; r.flags = 0;
-    if (!stage2Valid) coopCascadeStage3(w, C2, R, X0, cm->fallbackCfm, r);
-    publish(2, r);
+      const bool stage2Valid = (r.flags & (CS_SOLVED | CS_VALID)) == (CS_SOLVED | CS_VALID);
+      r.X = 0.0; r.flags = 0;
+      if (!stage2Valid) coopCascadeStage3(w, C2, Rg, X0, cm->fallbackCfm, r);
+      publish(2, r);
 #ifdef NBL_CASCADE_TIMING
-    if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 2) * B + b] = (double)(clock64() - t1);
+      if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 2) * B + b] = (double)(clock64() - t1);
 #endif
+    }
+    w.sync();
   }
 }
 
-// Select + standardise + outputs for one unresolved world, given the candidates of its three stages (one wavefront).
-template <class W>
-DEV void cascadeFinalBody(const W& w, CoopLds& S, const DevModel& mdl, const DevContactModel* __restrict__ cm, int64_t B, int64_t b,
-                          double* __restrict__ saved, const SavedLayout& lay, double* __restrict__ cacheOut, double* __restrict__ next,
-                          uint32_t* __restrict__ status, double* __restrict__ lws, CoopStageResult r1, CoopStageResult r2,
-                          CoopStageResult r3) {
-  const int ln = w.lane();
-  const int n = mdl.n;
-  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
-  double* nv = next + (int64_t)n * B;
-  double* dn = denseOf(saved, lay, B, b);
-  const double X0 = ln < m ? lws[(int64_t)(LW_JA + ln) * B + b] : 0.0;
-  if (ln >= m) { r1.X = 0.0; r2.X = 0.0; r3.X = 0.0; }
-  CoopRow R;
-  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
-  CoopCascadeOut out;
-  coopCascadeSelect(w, S, R, X0, cm->fallbackCfm, r1, r2, r3, out);
-  // The record always carries Q^+ of the final classification when there is a clamping row, so that the backward pass never
-  // has to factorise.  Stages that end without one (PGS results accepted as they are) pay for it here, on the few worlds that
-  // get this far.
-  bool pinvValid = out.pinvValid;
-  if (!pinvValid && out.K.nc > 0) {
-    double a[MAXR];
-    coopBuildQ(w, S, R, out.K, out.cfm, a);
-    coopPinv(w, a, S, out.K.nc);
-    pinvValid = true;
-  }
-  coopContactOutputs(w, S, n, m, out.X, out.K, out.cfm, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
-  if (ln == 0 && status) status[b] |= out.st;
-}
-
+// Select + standardise (per unresolved constrained group) + outputs for one unresolved world (one wavefront).
+template <bool MULTI>
 __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_final(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                               double* __restrict__ saved, SavedLayout lay,
                                                               double* __restrict__ cacheOut, double* __restrict__ next,
@@ -206,18 +282,67 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
   const long long t0 = clock64();
 #endif
   const DevWave w;
+  const int ln = w.lane();
   const int64_t b = failList[blockIdx.x];
-  const int row = w.lane() < MAX_ROWS ? w.lane() : 0;
-  CoopStageResult r1, r2, r3;
-  r1.X = lws[(int64_t)(LW_STAGE_X + row) * B + b];
-  r2.X = lws[(int64_t)(LW_STAGE_X + MAX_ROWS + row) * B + b];
-  r3.X = lws[(int64_t)(LW_STAGE_X + 2 * MAX_ROWS + row) * B + b];
-  r1.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 0) * B + b];
-  r2.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 1) * B + b];
-  r3.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 2) * B + b];
-  cascadeFinalBody(w, S, mdl, cm, B, b, saved, lay, cacheOut, next, status, lws, r1, r2, r3);
+  const int n = mdl.n;
+  const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+  double* nv = next + (int64_t)n * B;
+  double* dn = denseOf(saved, lay, B, b);
+  const int row = ln < MAX_ROWS ? ln : 0;
+  const double X0 = ln < m ? lws[(int64_t)(LW_X0 + ln) * B + b] : 0.0;
+  CoopRow R;
+  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  const uint32_t failMask = MULTI ? (uint32_t)lws[(int64_t)LW_FAILMASK * B + b] : 1u;
+  int gid = 0;
+  const int nGroups = MULTI ? coopGroups(w, cm, saved, lay, B, b, m, gid) : 1;
+  // rows of the groups stage 0 resolved come with their result; the others are filled in below, group by group
+  double X = 0.0, cfmRow = 0.0, E = 0.0;
+  int cls = RC_NOT_CLAMPING;
+  if (nGroups > 1 && R.on && !((failMask >> gid) & 1u)) {   // (R.on: still every row of the world here)
+    X = lws[(int64_t)(LW_OKX + row) * B + b];
+    const double cv = lws[(int64_t)(LW_OKCLS + row) * B + b];
+    cls = cv == 1.0 ? RC_CLAMPING : ((cv == 2.0 || cv == -2.0) ? RC_UPPER_BOUND : RC_NOT_CLAMPING);
+    E = cls == RC_UPPER_BOUND ? (cv > 0 ? R.mu : -R.mu) : 0.0;
+  }
+  uint32_t st = 0x100u;          // standardised unless a group says otherwise
+  bool pinvValid = false;
+  const bool rowOn = R.on;
+#pragma unroll 1
+  for (int g = 0; g < (MULTI ? MAX_CONTACTS : 1); g++) {
+    if (!((failMask >> g) & 1u)) continue;
+    R.on = rowOn && gid == g;
+    CoopRow& Rg = R;
+    CoopStageResult r1, r2, r3;
+    r1.X = Rg.on ? lws[(int64_t)(LW_STAGE_X + row) * B + b] : 0.0;
+    r2.X = Rg.on ? lws[(int64_t)(LW_STAGE_X + MAX_ROWS + row) * B + b] : 0.0;
+    r3.X = Rg.on ? lws[(int64_t)(LW_STAGE_X + 2 * MAX_ROWS + row) * B + b] : 0.0;
+    r1.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 0 * MAX_CONTACTS + g) * B + b];
+    r2.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 1 * MAX_CONTACTS + g) * B + b];
+    r3.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 2 * MAX_CONTACTS + g) * B + b];
+    CoopCascadeOut out;
+    coopCascadeSelect(w, S, Rg, Rg.on ? X0 : 0.0, cm->fallbackCfm, r1, r2, r3, out);
+    if (Rg.on) { X = out.X; cfmRow = out.cfm; cls = out.K.cls; E = out.K.E; }
+    st = (st & ~0x100u) | (out.st & ~0x100u) | (st & out.st & 0x100u);
+    pinvValid = nGroups == 1 && out.pinvValid;
+  }
+  R.on = rowOn;
+  CoopClasses K;
+  K.cls = cls; K.E = E;
+  K.clampMask = (uint32_t)w.ballot(cls == RC_CLAMPING); K.ubMask = (uint32_t)w.ballot(cls == RC_UPPER_BOUND);
+  K.nc = __builtin_popcount(K.clampMask); K.nu = __builtin_popcount(K.ubMask);
+  // The record always carries Q^+ of the final classification when there is a clamping row (of the whole world: block diagonal
+  // over its groups, each block with its group's CFM), so that the backward pass never has to factorise.  Stages that end without
+  // one (PGS results accepted as they are) and worlds with several groups pay for it here.
+  if (!pinvValid && K.nc > 0) {
+    double a[MAXR];
+    coopBuildQ(w, S, R, K, cfmRow, a);
+    coopPinv(w, a, S, K.nc);
+    pinvValid = true;
+  }
+  coopContactOutputs(w, S, n, m, X, K, cfmRow, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+  if (ln == 0 && status) status[b] |= st;
 #ifdef NBL_CASCADE_TIMING
-  if (w.lane() == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
+  if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
 #endif
 }
 
@@ -247,8 +372,8 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig(int count, int n, const
 // Dense part of the contact adjoint, one world per wavefront (the header of contact_backward.hip derives the
 // quantities), with lane = LCP row for the c-vectors and lane = DOF for the
 // n-vectors.  Row-indexed vectors are zero outside the clamping set, which replaces the index compaction:
-//   (Q x)_r   = (A xE)_r + cfm x_r      xE = x on clamping rows, E_u x_normal(u) on upper-bound rows  ("spread")
-//   (Q^T y)_s = t_s + sum_{u in ub(s)} E_u t_u + cfm y_s,  t = A y                                     ("fold")
+//   (Q x)_r   = (A xE)_r + cfm_r x_r      xE = x on clamping rows, E_u x_normal(u) on upper-bound rows  ("spread")
+//   (Q^T y)_s = t_s + sum_{u in ub(s)} E_u t_u + cfm_s y_s,  t = A y                                     ("fold")
 // Q^+ is read back from the saved record when the forward pass left it there (pflag), else recomputed.
 __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
@@ -266,7 +391,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
   const int row = ln < MAXR ? ln : 0, dof = ln < n ? ln : 0;
   const double ncD = svAt(saved, lay.nc, B, b);
   const double pflagD = svAt(saved, lay.pflag, B, b);
-  const double cfm = svAt(saved, lay.cfm, B, b);
+  const double cfmRaw = svAt(saved, lay.cfm + row, B, b);   // this row's constraint-force-mixing constant (its constrained group's)
   const double cvRaw = svAt(saved, lay.cls + row, B, b);
   const double xRaw0 = svAt(saved, lay.x + row, B, b);
   const double bvRaw = svAt(saved, lay.b + row, B, b);
@@ -307,6 +432,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
   // classes as stored by the forward pass
   CoopClasses K;
   const double cv = rowOn ? cvRaw : 0.0;
+  const double cfm = rowOn ? cfmRaw : 0.0;
   K.cls = cv == 1.0 ? RC_CLAMPING : ((cv == 2.0 || cv == -2.0) ? RC_UPPER_BOUND : RC_NOT_CLAMPING);
   K.E = K.cls == RC_UPPER_BOUND ? (cv > 0 ? R.mu : -R.mu) : 0.0;
   K.clampMask = (uint32_t)w.ballot(K.cls == RC_CLAMPING);
@@ -382,6 +508,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
   {
     double* XE = S.R;                        // spread(Q^+) row by row (the buffer is free between g and the coefficient vectors)
     if (ln < MAXR) {
+      S.vec[3][ln] = cfm;                    // cfm_r by row index for the tiles below
       const int src = clamp ? row : (isUb ? R.fp : row);
       const double sc = clamp ? 1.0 : (isUb ? K.E : 0.0);
 #pragma unroll
@@ -410,7 +537,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
         for (int g = 0; g < 4; g++) {
           const int rr = 16 * tr + lk + 4 * g, jj = 16 * tj + li;
           const bool inBlock = rr < MAXR && jj < MAXR && ((K.clampMask >> rr) & 1u) && ((K.clampMask >> jj) & 1u);
-          const double y = d[g] + cfm * S.P[(rr < MAXR ? rr : 0) * CLD + (jj < MAXR ? jj : 0)];
+          const double y = d[g] + S.vec[3][rr < MAXR ? rr : 0] * S.P[(rr < MAXR ? rr : 0) * CLD + (jj < MAXR ? jj : 0)];
           const double dlt = inBlock ? ((rr == jj) ? 1.0 : 0.0) - y : 0.0;
           acc = fma(dlt, dlt, acc);
         }

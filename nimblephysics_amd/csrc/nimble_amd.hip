@@ -75,6 +75,7 @@ struct nbl_model {
                                      // streams exceed four (4 slices 7.4 vs 9.0 M/s): the chip is already shared by the slices.
   bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
   int nPairs = 0;                    // candidate collider pairs of the model
+  bool multiGroup = false;           // colliders on more than one skeleton: a world can hold several constrained groups
   bool coopFinal = true;             // the backward sweeps too, in the world frame (NBL_COOP_FINAL=0: one world per lane, fed by k_tree_to_lanes)
   bool coopTree = false;             // tree sweeps one world per wavefront (needs the saved tree block, nb and n <= 64)
   int treeLanes = 0;                 // worlds per workgroup of the one-world-per-lane tree kernels (0 = pick from B); nbl_set_launch_lanes
@@ -261,6 +262,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   DevContactModel hc;
   std::memset(&hc, 0, sizeof(hc));
   bool hasContact = d->n_boxes > 0 && d->max_contacts > 0;
+  bool multiGroupModel = false;
   if (hasContact) {
     if (d->n_boxes > MAX_BOXES) return fail(NBL_E_UNSUPPORTED, "too many box colliders for the device path");
     if (d->max_contacts > MAX_CONTACTS) return fail(NBL_E_UNSUPPORTED, "max_contacts above 8 is not supported by the device path yet");
@@ -272,6 +274,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     hc.fallbackCfm = d->fallback_cfm;
     hc.penetrationCorrection = d->penetration_correction != 0;
     auto rootOf = [&](int body) { while (body >= 0 && d->parent[body] >= 0) body = d->parent[body]; return body; };
+    auto skelOf = [&](int body) { return d->body_skeleton ? (int)d->body_skeleton[body] : rootOf(body); };   // default: one skeleton per tree
     for (int i = 0; i < d->n_boxes; i++) {
       DevBox& bx = hc.boxes[i];
       bx.body = d->box_body[i];
@@ -289,13 +292,18 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       for (int j = i + 1; j < d->n_boxes; j++) {
         int bi = d->box_body[i], bj = d->box_body[j];
         if (bi == bj) continue;                       // same body (or both fixed to the world)
-        if (bi >= 0 && bj >= 0 && rootOf(bi) == rootOf(bj)) continue;  // same skeleton, self-collision disabled
+        if (bi >= 0 && bj >= 0 && skelOf(bi) == skelOf(bj)) continue;  // same skeleton, self-collision disabled
         if (hc.nPairs >= MAX_PAIRS) return fail(NBL_E_UNSUPPORTED, "too many collider pairs for the device path");
         hc.pairA[hc.nPairs] = i;
         hc.pairB[hc.nPairs] = j;
         hc.nPairs++;
       }
+    for (int i = 0; i < d->n_boxes; i++)
+      for (int j = i + 1; j < d->n_boxes; j++)
+        if (d->box_body[i] >= 0 && d->box_body[j] >= 0 && skelOf(d->box_body[i]) != skelOf(d->box_body[j])) multiGroupModel = true;
     for (int bdy = 0; bdy < d->n_bodies; bdy++) {
+      hc.skelOf[bdy] = skelOf(bdy);
+      if (hc.skelOf[bdy] < 0 || hc.skelOf[bdy] >= 64) return fail(NBL_E_BADARG, "body_skeleton must lie in [0, 64)");
       uint64_t mask = 0;
       for (int a = bdy; a >= 0; a = d->parent[a]) mask |= (1ull << a);
       hc.ancestors[bdy] = mask;
@@ -304,6 +312,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
 
   nbl_model* m = new nbl_model();
   m->hasContact = hasContact;
+  m->multiGroup = multiGroupModel;
   {
     SavedLayout& L = m->lay;
     const int n = d->n_dofs;
@@ -312,7 +321,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
                        L.A = L.massed = L.aall = L.pinv = -1; L.dense = 0; }
     else {
       L.vpre = 3 * n; L.w = 4 * n; L.nc = 5 * n; L.contacts = L.nc + 1; L.x = L.contacts + MAX_CONTACTS * CR_SIZE;
-      L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.pflag = L.cfm + 1; L.rest = L.pflag + 1; L.total = L.rest + MAX_CONTACTS;
+      L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.pflag = L.cfm + MAX_ROWS; L.rest = L.pflag + 1; L.total = L.rest + MAX_CONTACTS;   // cfm: one constant per row (its group's)
       L.A = 0; L.massed = L.A + MAX_ROWS * MAX_ROWS; L.aall = L.massed + n * MAX_ROWS; L.pinv = L.aall + n * MAX_ROWS;
       L.dense = L.pinv + MAX_ROWS * MAX_ROWS;
     }
@@ -500,12 +509,13 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       }
       int32_t* failList = failListAll + b0;          // the slice's own compacted list and counter
       uint32_t* failCount = failCountAll + si;   // zeroed by k_contact_detect
-      TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+      const bool mg = m->multiGroup;
+      TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(mg ? k_contact_solve_coop<true> : k_contact_solve_coop<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
                                              (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
                                              failList, failCount));
-      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(k_contact_cascade_stages, dim3((unsigned)cnt), dim3(128), 0, s, mdl, m->dContact, B,
+      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(mg ? k_contact_cascade_stages<true> : k_contact_cascade_stages<false>, dim3((unsigned)cnt), dim3(128), 0, s, mdl, m->dContact, B,
                                                (double*)saved, m->lay, lws, failList, failCount));
-      TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(k_contact_cascade_final, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+      TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(mg ? k_contact_cascade_final<true> : k_contact_cascade_final<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
                                                 (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
     }
   return NBL_OK;

@@ -121,7 +121,7 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
             bodies.append(BodySpec(b.getName(), pidx, jtype, j.getName(), axis=axis,
                                    T_pj=_mat4(j.getTransformFromParentBodyNode()), T_cj=_mat4(j.getTransformFromChildBodyNode()),
                                    mass=float(b.getMass()), com=tuple(float(x) for x in np.asarray(b.getLocalCOM()).reshape(3)),
-                                   inertia=tuple(float(x) for x in m[4:10]), **kw))
+                                   inertia=tuple(float(x) for x in m[4:10]), skeleton=si, **kw))
             gidx = len(bodies) - 1
             index[b.getName()] = gidx
             for k in range(int(b.getNumShapeNodes())):

@@ -192,7 +192,7 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8):
     g = phys.find("gravity") if phys is not None else None
     gravity = tuple(float(x) for x in g.text.split()) if g is not None else (0.0, -9.81, 0.0)
     bodies, boxes = [], []
-    for sk in world.findall("skeleton"):
+    for sk_index, sk in enumerate(world.findall("skeleton")):
         if skeletons is not None and sk.get("name") not in skeletons:
             continue
         skel_T = _skel_T(sk)                                     # optional skeleton frame (:948-955)
@@ -327,7 +327,7 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8):
                 mass, com, I6 = inertial(bel[cn])
                 base = len(bodies)
                 bodies.append(BodySpec(cn, -1 if pn == "world" else index[pn], jtype, j.get("name"), axis=axis, T_pj=T_pj, T_cj=c2j,
-                                       mass=mass, com=com, inertia=I6, **kw))
+                                       mass=mass, com=com, inertia=I6, skeleton=sk_index, **kw))
                 index[cn] = base
                 for kind, size, Ts in shapes_of(bel[cn]):
                     boxes.append(BoxSpec(base, Ts, size, 1.0, kind))

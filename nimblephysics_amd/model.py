@@ -91,6 +91,7 @@ class BodySpec:
     force_hi: Sequence[float] = ()
     friction: float = 1.0  # BodyNodeAspect.hpp:47
     axes: Sequence[Sequence[float]] = ()   # compound joints with free axes (universal: 2, translational2d: 2, planar: 2 in-plane axes)
+    skeleton: int = -1   # index of the dart Skeleton the body belongs to; -1 (every body of the model) = one skeleton per tree
 
 
 # ---- compound joints: (kind of each one-parameter motion, default axes) ------------------------------------------------
@@ -158,7 +159,7 @@ def expand_compound_joints(bodies, boxes):
                 mass=b.mass if last else 0.0, com=tuple(b.com) if last else (0.0, 0.0, 0.0),
                 inertia=tuple(b.inertia) if last else (0.0,) * 6,
                 **{key: dof(getattr(b, key), i) for key in ("damping", "spring", "rest", "pos_lo", "pos_hi", "vel_lo", "vel_hi", "force_lo", "force_hi")},
-                friction=b.friction)
+                friction=b.friction, skeleton=b.skeleton)
             parent = len(out)
             out.append(nb)
         where.append(len(out) - 1)
@@ -331,6 +332,17 @@ class ModelDescription:
         new_index = {old: k for k, old in enumerate(keep)}
         return [(-1 if t < 0 else new_index[t]) for t in target], T_in
 
+    def body_skeletons(self) -> List[int]:
+        """Per body: the dart Skeleton it belongs to - the ids the loaders recorded, or (none recorded) the index of its tree's root.
+        The reference solves one LCP per constrained group of skeletons (ConstraintSolver.cpp:724-780) and never collides two
+        bodies of one skeleton."""
+        if all(b.skeleton >= 0 for b in self.bodies):
+            return [int(b.skeleton) for b in self.bodies]
+        out = []
+        for i, b in enumerate(self.bodies):
+            out.append(i if b.parent < 0 else out[b.parent])
+        return out
+
     def has_welds(self) -> bool:
         return any(b.joint_type == "weld" for b in self.bodies)
 
@@ -377,6 +389,7 @@ class ModelDescription:
         a["box_shape"] = np.array([SHAPE_CODES[bx.shape] for bx in self.boxes], np.int32).reshape(nbx)
         a["box_restitution"] = np.array([bx.restitution for bx in self.boxes], np.float64).reshape(nbx)
         a["action_map"] = np.array(self.action_map, np.int32)
+        a["body_skeleton"] = np.array(self.body_skeletons(), np.int32).reshape(nb)
         return a
 
     def to_desc(self):
@@ -394,7 +407,7 @@ class ModelDescription:
         def pi(x):
             return x.ctypes.data_as(C.POINTER(C.c_int32))
 
-        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape"):
+        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape", "body_skeleton"):
             setattr(d, k, pi(a[k]))
         for k in ("T_pj", "T_cj", "axis", "mass", "com", "inertia", "damping", "spring", "rest", "pos_lo", "pos_hi",
                   "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu", "box_restitution"):
@@ -413,7 +426,7 @@ class ModelDescription:
     def to_json(self) -> dict:
         def body(b: BodySpec):
             d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()
-                 if k != "axes"}       # compound joints are already expanded: every stored joint has its single `axis`
+                 if k != "axes" and not (k == "skeleton" and v < 0)}   # compound joints are already expanded: every stored joint has its single `axis`
             return d
         return {
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,

@@ -368,7 +368,7 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
       const BoxCollider &bi = m.boxes[i], &bj = m.boxes[j];
       if (bi.body == bj.body) continue;
       if (bi.body < 0 && bj.body < 0) continue;
-      if (bi.body >= 0 && bj.body >= 0 && skeletonRoot(m, bi.body) == skeletonRoot(m, bj.body)) continue;
+      if (bi.body >= 0 && bj.body >= 0 && m.skeleton[bi.body] == m.skeleton[bj.body]) continue;   // same skeleton: self-collision is off
       Iso Ti = bi.body >= 0 ? kin[bi.body].Tworld * bi.T : bi.T;
       Iso Tj = bj.body >= 0 ? kin[bj.body].Tworld * bj.T : bj.T;
       std::vector<Contact> pair;

@@ -35,7 +35,10 @@ struct ContactResult {
   int numClamping = 0, numUpperBound = 0;
   MatX E;                          // numUpperBound x numClamping
   VecX fc;                         // clamping constraint impulses
-  s_t cfm = 0;
+  s_t cfm = 0;                     // (single-group worlds; the backward pass reads cfmRow)
+  VecX cfmRow;                     // per LCP row: the constraint-force-mixing constant its constrained group ended with (CFM_CONSTANTS)
+  std::vector<int> rowGroup;       // per LCP row: index of its constrained group
+  int numGroups = 0;
   VecX restCoeff;                  // per LCP row: ContactConstraint::getCoefficientOfRestitution (e if the contact bounced, else 0; 0 on friction rows)
   bool ignoreFriction = false, standardized = false;
   uint32_t status = 0;
@@ -410,47 +413,123 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     }
   }
 
-  // ---- warm start / guess (BoxedLcpConstraintSolver.cpp:202-208, 332-337) ----
-  VecX X;
-  if ((int)lcpCache.size() != mrows) X = guessSolution(out.A, out.b, out.findex);
-  else X = lcpCache;
-  const VecX XBackup = X;
+  // ---- constrained groups (ConstraintSolver::buildConstrainedGroups :724-780, ContactConstraint::uniteSkeletons :879-907) ----
+  // Skeletons connected by a contact between two reactive bodies form one group; a contact with a world-fixed collider connects
+  // nothing.  Groups are numbered by their first constraint, a group's rows keep the world's constraint order.
+  {
+    std::vector<int> parentOf;                                   // union-find over skeleton ids
+    auto find = [&](int s_) { while (parentOf[s_] != s_) s_ = parentOf[s_]; return s_; };
+    int maxSk = 0;
+    for (int i = 0; i < m.nb; i++) maxSk = std::max(maxSk, m.skeleton[i]);
+    parentOf.resize(maxSk + 1);
+    for (int i = 0; i <= maxSk; i++) parentOf[i] = i;
+    // BodyNode::isReactive (BodyNode.cpp:2394-2418): the body depends on at least one generalized coordinate
+    auto reactive = [&](int body) { for (; body >= 0; body = m.bodies[body].parent) if (m.bodies[body].ndof > 0) return true; return false; };
+    for (const Contact& ct : out.contacts) {
+      if (!reactive(ct.bodyA) || !reactive(ct.bodyB)) continue;
+      const int ra = find(m.skeleton[ct.bodyA]), rb = find(m.skeleton[ct.bodyB]);
+      if (ra != rb) parentOf[rb] = ra;
+    }
+    std::vector<int> groupOfRoot(maxSk + 1, -1);
+    out.rowGroup.assign(mrows, 0);
+    out.numGroups = 0;
+    for (int r = 0; r < mrows; r++) {
+      const Contact& ct = out.contacts[out.rowContact[r]];
+      const int root = find(m.skeleton[reactive(ct.bodyA) ? ct.bodyA : ct.bodyB]);
+      if (groupOfRoot[root] < 0) groupOfRoot[root] = out.numGroups++;
+      out.rowGroup[r] = groupOfRoot[root];
+    }
+  }
 
+  // ---- per group: warm start / guess, stage 0, stages 1-3, registration (BoxedLcpConstraintSolver.cpp:190-789 runs once per
+  //      constrained group, ConstraintSolver.cpp:800-811) ----
   MatX Minv = invMassMatrix(m, kin, art);
-  Cggm g;
-  g.model = &m; g.Minv = &Minv; g.cr = &out;
-  VecX aColNorms(mrows, 0.0);
-  for (int c = 0; c < mrows; c++) { s_t s = 0; for (int r = 0; r < mrows; r++) s += out.A(r, c) * out.A(r, c); aColNorms[c] = s; }
-  MatX aGrad = out.A;
-
-  // ---- stage 0: classify the cached x and solve the active set in closed form (:434-457) ----
-  s_t cfm = 0.0;
-  g.X = X; g.Hi = out.hi; g.Lo = out.lo; g.FIndex = out.findex; g.B = out.b; g.AColNorms = aColNorms; g.A = aGrad;
-  g.cfmConst = cfm; g.ignoreFriction = false;
-  g.constructMatrices();
-  bool success = g.standardized;
-  bool shortCircuit = success;
-  bool hadToIgnoreFriction = false;
-  if (success) { X = g.X; *status |= NBL_ST_LCP_STAGE0; }
-
-  // ---- stages 1-3 (:461-687) ----
-  if (!success) {
-    uint32_t st13 = 0;
-    lcpCascade(out.A, out.b, out.lo, out.hi, out.findex, XBackup, m.fallbackCfm, X, cfm, hadToIgnoreFriction, st13);
-    *status |= st13;
-    if (cfm != 0.0) for (int i = 0; i < mrows; i++) aGrad(i, i) += cfm;
-  }
-
-  // ---- re-register + classify + standardize with the fresh solution (:718-736) ----
-  if (!shortCircuit) {
-    g.X = X; g.A = aGrad; g.cfmConst = cfm; g.ignoreFriction = hadToIgnoreFriction;
+  const bool haveCache = (int)lcpCache.size() == mrows;
+  VecX X(mrows, 0.0);
+  out.cfmRow.assign(mrows, 0.0);
+  out.rowClass.assign(mrows, RC_NOT_CLAMPING);
+  VecX eRow(mrows, 0.0), fcRow(mrows, 0.0);                      // per row: its entry of E / of f_c (merged below)
+  MatX aGradAll = out.A;
+  bool allStage0 = true, allStandardized = true;
+  for (int gi = 0; gi < out.numGroups; gi++) {
+    std::vector<int> idx, local(mrows, -1);
+    for (int r = 0; r < mrows; r++) if (out.rowGroup[r] == gi) { local[r] = (int)idx.size(); idx.push_back(r); }
+    const int mg = (int)idx.size();
+    ContactResult sub;
+    sub.m = mg;
+    sub.A = MatX(mg, mg); sub.b.assign(mg, 0.0); sub.lo.assign(mg, 0.0); sub.hi.assign(mg, 0.0); sub.findex.assign(mg, -1);
+    sub.Aall = MatX(n, mg);
+    for (int i = 0; i < mg; i++) {
+      for (int j = 0; j < mg; j++) sub.A(i, j) = out.A(idx[i], idx[j]);
+      sub.b[i] = out.b[idx[i]]; sub.lo[i] = out.lo[idx[i]]; sub.hi[i] = out.hi[idx[i]];
+      sub.findex[i] = out.findex[idx[i]] < 0 ? -1 : local[out.findex[idx[i]]];
+      for (int d_ = 0; d_ < n; d_++) sub.Aall(d_, i) = out.Aall(d_, idx[i]);
+    }
+    // warm start / guess (:202-208, 332-337)
+    VecX Xg(mg, 0.0);
+    if (haveCache) for (int i = 0; i < mg; i++) Xg[i] = lcpCache[idx[i]];
+    else Xg = guessSolution(sub.A, sub.b, sub.findex);
+    const VecX XBackup = Xg;
+    Cggm g;
+    g.model = &m; g.Minv = &Minv; g.cr = &sub;
+    VecX aColNorms(mg, 0.0);
+    for (int c = 0; c < mg; c++) { s_t s_ = 0; for (int r = 0; r < mg; r++) s_ += sub.A(r, c) * sub.A(r, c); aColNorms[c] = s_; }
+    MatX aGrad = sub.A;
+    // stage 0: classify the cached x and solve the active set in closed form (:434-457)
+    s_t cfm = 0.0;
+    g.X = Xg; g.Hi = sub.hi; g.Lo = sub.lo; g.FIndex = sub.findex; g.B = sub.b; g.AColNorms = aColNorms; g.A = aGrad;
+    g.cfmConst = cfm; g.ignoreFriction = false;
     g.constructMatrices();
-    if (g.standardized) X = g.X;
+    bool success = g.standardized;
+    const bool shortCircuit = success;
+    bool hadToIgnoreFriction = false;
+    if (success) Xg = g.X;
+    else allStage0 = false;
+    // stages 1-3 (:461-687)
+    if (!success) {
+      uint32_t st13 = 0;
+      lcpCascade(sub.A, sub.b, sub.lo, sub.hi, sub.findex, XBackup, m.fallbackCfm, Xg, cfm, hadToIgnoreFriction, st13);
+      *status |= st13;
+      if (cfm != 0.0) for (int i = 0; i < mg; i++) aGrad(i, i) += cfm;
+    }
+    // re-register + classify + standardize with the fresh solution (:718-736)
+    if (!shortCircuit) {
+      g.X = Xg; g.A = aGrad; g.cfmConst = cfm; g.ignoreFriction = hadToIgnoreFriction;
+      g.constructMatrices();
+      if (g.standardized) Xg = g.X;
+    }
+    if (!g.standardized) allStandardized = false;
+    // merge the group's rows into the world's vectors
+    for (int i = 0; i < mg; i++) {
+      const int r = idx[i];
+      X[r] = Xg[i];
+      out.cfmRow[r] = cfm;
+      aGradAll(r, r) = aGrad(i, i);
+      out.rowClass[r] = sub.rowClass[i];
+      if (sub.rowClass[i] == RC_CLAMPING) fcRow[r] = sub.fc[sub.clampingIndex[i]];
+      if (sub.rowClass[i] == RC_UPPER_BOUND) eRow[r] = sub.E(sub.upperBoundIndex[i], sub.clampingIndex[sub.findex[i]]);
+    }
+    if (out.numGroups == 1) { out.cfm = cfm; out.ignoreFriction = hadToIgnoreFriction; }
   }
-  if (g.standardized) *status |= NBL_ST_STANDARDIZED;
-  out.A = aGrad;
+  if (allStage0) *status |= NBL_ST_LCP_STAGE0;
+  if (allStandardized) *status |= NBL_ST_STANDARDIZED;
+  // the world-level classification vectors of the backward pass (BackpropSnapshot assembles the groups' matrices, :4215-4409;
+  // clamping / upper-bound rows are numbered in row order here, which is a permutation of the reference's group-major order)
+  out.clampingIndex.assign(mrows, -1); out.upperBoundIndex.assign(mrows, -1);
+  out.numClamping = 0; out.numUpperBound = 0;
+  for (int r = 0; r < mrows; r++) {
+    if (out.rowClass[r] == RC_CLAMPING) out.clampingIndex[r] = out.numClamping++;
+    if (out.rowClass[r] == RC_UPPER_BOUND) out.upperBoundIndex[r] = out.numUpperBound++;
+  }
+  out.E = MatX(out.numUpperBound, out.numClamping);
+  out.fc.assign(out.numClamping, 0.0);
+  for (int r = 0; r < mrows; r++) {
+    if (out.rowClass[r] == RC_CLAMPING) out.fc[out.clampingIndex[r]] = fcRow[r];
+    if (out.rowClass[r] == RC_UPPER_BOUND) out.E(out.upperBoundIndex[r], out.clampingIndex[out.findex[r]]) = eRow[r];
+  }
+  out.A = aGradAll;
   out.x = X;
-  out.standardized = g.standardized;
+  out.standardized = allStandardized;
   lcpCache = X;  // mX persists inside the solver (BoxedLcpConstraintSolver.cpp:176-187)
 
   // ---- applyImpulse + computeImpulseForwardDynamics (ContactConstraint.cpp:630-684, Skeleton.cpp:13571-13595) ----
@@ -740,7 +819,7 @@ inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const 
 
   // Q and its factorisation
   MatX Q = matmul(AcT, matmul(Minv, AcubE));
-  for (int i = 0; i < nc; i++) Q(i, i) += cr.cfm;
+  for (int i = 0; i < nc; i++) Q(i, i) += cr.cfmRow[clampRows[i]];   // getConstraintForceMixingDiagonal: every group's own constant
   VecX bvec(nc);
   for (int i = 0; i < nc; i++) bvec[i] = cr.b[clampRows[i]];
 

@@ -36,6 +36,7 @@ struct Model {
   s_t dt;
   std::vector<int> actionMap;
   std::vector<BoxCollider> boxes;
+  std::vector<int> skeleton;            // per body: the dart Skeleton it belongs to (constrained groups unite skeletons)
   int maxContacts;
   s_t clippingDepth, fallbackCfm;
   bool penetrationCorrection = false;   // World::setPenetrationCorrectionEnabled (off by default)
@@ -122,6 +123,11 @@ inline Model buildModel(const nbl_model_desc* d) {
   m.clippingDepth = d->contact_clipping_depth;
   m.fallbackCfm = d->fallback_cfm;
   m.penetrationCorrection = d->penetration_correction != 0;
+  m.skeleton.resize(m.nb);
+  for (int i = 0; i < m.nb; i++) {
+    if (d->body_skeleton) m.skeleton[i] = d->body_skeleton[i];
+    else { int r = i; while (m.bodies[r].parent >= 0) r = m.bodies[r].parent; m.skeleton[i] = r; }   // default: one skeleton per tree
+  }
   return m;
 }
 

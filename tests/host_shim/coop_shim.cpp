@@ -51,6 +51,54 @@ int shim_coop_stage0(int m, const double* A, const double* b, const double* mu, 
   return ret;
 }
 
+// stages 1-3 + the order of preference + standardisation on the rows of `mask` only; outputs like shim_coop_cascade plus the
+// standardised x and the row classes
+int shim_coop_cascade_masked(int m, const double* A, const double* b, const double* mu, const double* x0, unsigned mask, double fallbackCfm,
+                             double* X, double* cfmOut, double* Xstd, int* cls) {
+  static CascadeLds C1;
+  static PgsLds C2, C3;
+  static CoopLds S;
+  uint32_t stOut = 0;
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopRow R;
+    fillRow(R, ln, m, A, b, mu);
+    R.on = R.on && ((mask >> ln) & 1u);
+    const double X0 = R.on ? x0[ln] : 0.0;
+    CoopStageResult r1, r2, r3;
+    coopCascadeStage1(w, C1, R, X0, r1);
+    coopCascadeStage2(w, C2, R, X0, fallbackCfm, r2);
+    coopCascadeStage3(w, C3, R, X0, fallbackCfm, r3);
+    double x, cfm;
+    bool noFric;
+    uint32_t st;
+    coopCascadeChoose(w, m, X0, fallbackCfm, r1, r2, r3, x, cfm, noFric, st);
+    if (ln < MAXR) X[ln] = x;
+    CoopCascadeOut out;
+    coopCascadeSelect(w, S, R, X0, fallbackCfm, r1, r2, r3, out);
+    if (ln < MAXR) { Xstd[ln] = out.X; cls[ln] = out.K.cls; }
+    if (ln == 0) { stOut = out.st; *cfmOut = cfm; }
+  });
+  return (int)stOut;
+}
+
+// stage 0 on the rows of `mask` only (the rows of a world's other constrained groups switched off, as the kernels run it)
+int shim_coop_stage0_masked(int m, const double* A, const double* b, const double* mu, unsigned mask, double* X, double* X0, int* cls, double* E) {
+  static CoopLds S;
+  int ret = 0;
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopRow R;
+    fillRow(R, ln, m, A, b, mu);
+    R.on = R.on && ((mask >> ln) & 1u);
+    CoopStage0 out;
+    coopStage0(w, S, R, false, 0.0, out);
+    if (ln < MAXR) { X[ln] = out.X; X0[ln] = out.X0; cls[ln] = out.K.cls; E[ln] = out.K.E; }
+    if (ln == 0) ret = (out.ok ? 1 : 0) | (out.pinvValid ? 2 : 0);
+  });
+  return ret;
+}
+
 // the one-world-per-lane statement (laneStage0 of lcp_dev.hpp) on the same problem
 int shim_lane_stage0(int m, const double* A, const double* b, const double* mu, int haveCache, const double* xcache,
                      double* X, double* X0, int* cls, double* E) {

@@ -170,3 +170,78 @@ def test_coop_pgs_and_reduce_equal_the_oracle_restatement(shim):
             M = mo[:n * nr].reshape(n, nr)
             for o in range(n):
                 assert (M[o].sum() == 0 and mt[o] == -1) or (M[o, mt[o]] == 1 and M[o].sum() == 1)
+
+
+def test_stage0_on_one_constrained_group_equals_stage0_of_that_group_alone(shim):
+    """A world with two constrained groups is a block-diagonal LCP; the kernels run stage 0 group by group with the other group's
+    rows switched off (CoopRow::on).  The result on a group's rows must be what stage 0 gives on that group's own problem, whatever
+    position its rows have in the world (first or second group, 3 + 4 or 4 + 3 contacts)."""
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        nA, nB = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        parts = []
+        for nc in (nA, nB):
+            m = 3 * nc
+            ndof = int(rng.choice([6, 12]))
+            J = rng.normal(0, 1, (m, ndof))
+            A = J @ np.diag(rng.uniform(0.1, 2, ndof)) @ J.T
+            xs = np.zeros(m)
+            for c in range(nc):
+                if rng.random() < 0.8:
+                    xs[3 * c] = rng.uniform(0.1, 2); xs[3 * c + 1:3 * c + 3] = rng.uniform(-0.4, 0.4, 2) * xs[3 * c]
+            b = A @ xs + (rng.normal(0, 0.05, m) if trial % 2 else 0.0)
+            parts.append((m, A, b))
+        mT = parts[0][0] + parts[1][0]
+        A = np.zeros((24, 24)); b = np.zeros(24); mu = np.ones(8)
+        A[:parts[0][0], :parts[0][0]] = parts[0][1]; A[parts[0][0]:mT, parts[0][0]:mT] = parts[1][1]
+        b[:parts[0][0]] = parts[0][2]; b[parts[0][0]:mT] = parts[1][2]
+        off = 0
+        for (m, Ag, bg) in parts:
+            mask = ((1 << m) - 1) << off
+            X = np.zeros(24); X0 = np.zeros(24); cls = np.zeros(24, np.int32); E = np.zeros(24)
+            ret = shim.shim_coop_stage0_masked(mT, _p(np.ascontiguousarray(A)), _p(b), _p(mu), C.c_uint(mask), _p(X), _p(X0), _pi(cls), _p(E))
+            A1 = np.zeros((24, 24)); A1[:m, :m] = Ag; b1 = np.zeros(24); b1[:m] = bg
+            X1 = np.zeros(24); X01 = np.zeros(24); cls1 = np.zeros(24, np.int32); E1 = np.zeros(24); P1 = np.zeros((24, 24))
+            ret1 = shim.shim_coop_stage0(m, _p(np.ascontiguousarray(A1)), _p(b1), _p(mu), 0, _p(np.zeros(24)), _p(X1), _p(X01), _pi(cls1), _p(E1), _p(P1))
+            assert (ret & 1) == (ret1 & 1), (trial, off, ret, ret1)
+            assert np.array_equal(cls[off:off + m], cls1[:m]), (trial, off)
+            assert np.abs(X[off:off + m] - X1[:m]).max() <= 1e-10 * max(np.abs(X1).max(), 1e-30), (trial, off)
+            assert np.abs(X0[off:off + m] - X01[:m]).max() <= 1e-10 * max(np.abs(X01).max(), 1e-30)
+            assert not X[:off].any() and not X[off + m:].any()
+            off += m
+
+
+def test_cascade_on_one_constrained_group_equals_the_cascade_of_that_group_alone(shim):
+    """The same for stages 1-3, the order of preference and the standardisation that follows (CFM on the diagonal included):
+    problems that stage 0 cannot resolve (random b, rank-deficient A), as the second and as the first group of a two-group world."""
+    rng = np.random.default_rng(12)
+    seen = set()
+    for trial in range(18):
+        parts = []
+        for nc in (int(rng.integers(1, 5)), int(rng.integers(1, 5))):
+            m = 3 * nc
+            ndof = int(rng.choice([3, 6, 12]))
+            J = rng.normal(0, 1, (m, ndof))
+            A = J @ np.diag(rng.uniform(0.1, 2, ndof)) @ J.T
+            b = rng.normal(0, 1, m) if trial % 3 else A @ np.abs(rng.normal(0, 1, m))
+            parts.append((m, A, b, rng.normal(0, 0.1, m)))
+        mT = parts[0][0] + parts[1][0]
+        A = np.zeros((24, 24)); b = np.zeros(24); x0 = np.zeros(24); mu = np.ones(8)
+        o = 0
+        for (m, Ag, bg, xg) in parts:
+            A[o:o + m, o:o + m] = Ag; b[o:o + m] = bg; x0[o:o + m] = xg; o += m
+        off = 0
+        for (m, Ag, bg, xg) in parts:
+            mask = ((1 << m) - 1) << off
+            X = np.zeros(24); Xs = np.zeros(24); cls = np.zeros(24, np.int32); cfm = C.c_double(0)
+            st = shim.shim_coop_cascade_masked(mT, _p(np.ascontiguousarray(A)), _p(b), _p(mu), _p(x0), C.c_uint(mask), C.c_double(1e-4), _p(X), C.byref(cfm), _p(Xs), _pi(cls))
+            A1 = np.zeros((24, 24)); A1[:m, :m] = Ag; b1 = np.zeros(24); b1[:m] = bg; x1 = np.zeros(24); x1[:m] = xg
+            X1 = np.zeros(24); Xs1 = np.zeros(24); cls1 = np.zeros(24, np.int32); cfm1 = C.c_double(0)
+            st1 = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A1)), _p(b1), _p(mu), _p(x1), C.c_uint((1 << m) - 1), C.c_double(1e-4), _p(X1), C.byref(cfm1), _p(Xs1), _pi(cls1))
+            assert st == st1 and cfm.value == cfm1.value, (trial, off, hex(st), hex(st1))
+            assert np.array_equal(X[off:off + m], X1[:m]), (trial, off)                  # the solvers see the same problem: bit for bit
+            assert np.array_equal(cls[off:off + m], cls1[:m]) and np.abs(Xs[off:off + m] - Xs1[:m]).max() <= 1e-10 * max(np.abs(Xs1).max(), 1e-30)
+            assert not X[:off].any() and not X[off + m:].any()
+            seen.add(st & 0x13c)
+            off += m
+    assert len(seen) >= 3, seen      # the trials reach several exits of the cascade

@@ -31,7 +31,7 @@ def _run(name, B, seed, **kw):
     return errs, status, ref["status"], world
 
 
-def _assert_all_worlds_match_or_reference_is_unstable(tag, errs, world, tol, n_perturb=64):
+def _assert_all_worlds_match_or_reference_is_unstable(tag, errs, world, tol, n_perturb=64, closeness=0.1, ulps=1):
     """Every world within `tol` of the oracle - or, for the few that are not, PROOF that the reference algorithm itself has no
     stable answer there: re-run the oracle on that world with +-1-ulp perturbations of the input state; its own results (next state or
     gradients) must scatter by more than `tol` (on singular A(C,C) the Dantzig early exit s <= 0, and with it friction-or-no-friction, is
@@ -42,15 +42,15 @@ def _assert_all_worlds_match_or_reference_is_unstable(tag, errs, world, tol, n_p
     rng = np.random.default_rng(12345)
     for wd in bad:
         s0 = P["s"][wd]
-        sp = s0[None, :] * (1.0 + rng.choice([-1.0, 0.0, 1.0], (n_perturb, s0.size)) * 2.220446049250313e-16)
+        sp = s0[None, :] * (1.0 + rng.integers(-ulps, ulps + 1, (n_perturb, s0.size)) * 2.220446049250313e-16)
         r = P["ow"].step_batch(sp, np.repeat(P["a"][wd][None], n_perturb, 0), np.repeat(P["g"][wd][None], n_perturb, 0), threads=8)
         dist = np.maximum.reduce([np.abs(r[k] - P["dev"][k][wd][None]).max(1) / P["scales"][k] for k in ("next", "grad_state", "grad_action")])
         spread = max(np.abs(r[k] - P["ref"][k][wd][None]).max() / P["scales"][k] for k in ("next", "grad_state", "grad_action"))   # vs the unperturbed run
         assert spread > tol, (tag, int(wd), "the reference is stable here but the device differs", float(dist.min()))
         # ... one of its outcomes: within tol of a perturbed run, or - where the reference's outcomes form a continuum (its
         # gradient amplifies round-off by 1e11+) - at least 10 x closer to one of them than they scatter around the unperturbed run
-        assert dist.min() <= max(tol, 0.1 * spread), (tag, int(wd), "device result is none of the reference's own outcomes", float(dist.min()), float(spread))
-    print(f"[{tag}] reference-unstable worlds (oracle flips under 1-ulp input perturbations; device equals one of its outcomes): "
+        assert dist.min() <= max(tol, closeness * spread), (tag, int(wd), "device result is none of the reference's own outcomes", float(dist.min()), float(spread))
+    print(f"[{tag}] reference-unstable worlds (oracle flips under {ulps}-ulp input perturbations; device equals one of its outcomes): "
           f"{len(bad)} of {len(errs['next'])}")
     return len(bad)
 
@@ -303,3 +303,78 @@ def test_frictionless_single_contacts_are_well_posed_and_match():
     assert np.array_equal(world.last_status.cpu().numpy().astype(np.uint32) & 0x3, ref["status"] & 0x3)
     for name, d, r_ in (("next", nx, ref["next"]), ("grad_state", st.grad.cpu().numpy(), ref["grad_state"]), ("grad_action", at.grad.cpu().numpy(), ref["grad_action"])):
         assert np.abs(d - r_).max() / max(np.abs(r_).max(), 1e-30) < TOL, name
+
+
+def test_independent_objects_are_solved_as_separate_constrained_groups():
+    """Two cubes resting SIDE BY SIDE on the ground are two constrained groups in the reference (ConstraintSolver.cpp:724-780: only
+    contacts between two reactive bodies unite skeletons): each runs the solver cascade on its own, so a cube whose LCP needs the
+    fallback stages (a corner over the edge of the ground box) must not change how the other one is solved.  Every world vs the
+    oracle, which restates the grouping; worlds where only ONE of the two groups went through the cascade must exist."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    md = na.box_stack()
+    n = md.num_dofs
+    B = 2048
+    rng = np.random.default_rng(21)
+    gb = md.boxes[0]                                               # geometry of the loaded model (box_stacking.skel)
+    top = (md.bodies[0].T_pj @ gb.T)[1, 3] + 0.5 * gb.size[1]
+    half = 0.5 * gb.size[0]
+    s = np.zeros((B, 2 * n))
+    for k, x0 in enumerate((-0.4, 0.4)):
+        o = 6 * k
+        c0 = md.bodies[1 + k].T_pj[:3, 3]
+        s[:, o + 1] = rng.uniform(-1.0, 1.0, B)                    # yaw (kept away from pi: the oracle finite-differences the free joint's exp / log map like the reference)
+        tilt = rng.random(B) < 0.3
+        s[:, o + 0] = rng.normal(0, 0.01, B) * tilt; s[:, o + 2] = rng.normal(0, 0.01, B) * tilt
+        over = rng.random(B) < 0.3                                 # some hang over the rim of the ground box
+        x = np.where(over, np.sign(x0) * half * rng.uniform(0.93, 0.99, B), x0 * half + rng.uniform(-0.15, 0.15, B) * half)
+        s[:, o + 3] = x - c0[0]
+        s[:, o + 4] = top + 0.1 - rng.uniform(1e-4, 1e-3, B) - c0[1]
+        s[:, o + 5] = rng.uniform(-0.5, 0.5, B) * half - c0[2]
+        s[:, n + o:n + o + 6] = rng.normal(0, 0.05, (B, 6))
+    a = rng.normal(0, 0.1, (B, n)); g = rng.normal(0, 1, s.shape)
+    world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    out = timestep(world, st, at)
+    status = world.last_status.cpu().numpy().astype(np.uint32)
+    out.backward(torch.tensor(g, device="cuda:0"))
+    ref = ow.step_batch(s, a, g, threads=8)
+    dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
+    scales = {k: np.abs(ref[k]).max() for k in dev}
+    errs = {k: np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev}
+    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}}
+    assert (status & 0x1).mean() > 0.99
+    assert np.array_equal(status & 0x81, ref["status"] & 0x81)               # contact, contact overflow
+    ovf = (status & 0x80) != 0                                                # a ninth contact (cube on the rim): truncated by the device, flagged by both
+    assert ovf.mean() < 0.25
+    errs = {k: np.where(ovf, 0.0, e) for k, e in errs.items()}
+    same = (status & 0x13e) == (ref["status"] & 0x13e)                        # every group ended in the same stage, standardised or not
+    assert same[~ovf].mean() > 0.95
+    _report("two cubes side by side", errs)
+    # A world with one cube on the CFM fallback (full-rank, ill-conditioned block: status bit 0x8) next to one on four coplanar
+    # corners (rank-deficient block) makes the reference's JOINT precise-inverse test (BackpropSnapshot.cpp:2964-2984) choose the full
+    # pseudo-inverse derivative for both blocks; its extra terms are round-off amplified by |Q^+|^2 ~ 1e8 on the CFM block, so the
+    # reference's gradient carries ~1e-4 of arithmetic noise there (it takes a few discrete values under 1-ulp perturbations, none
+    # of them privileged).  Those worlds are held to the next state strictly and to 2e-3 on the gradients; all others to the
+    # strict criterion.
+    noisy = (status & 0x18) != 0          # a group ended in stage 2 or 3: both carry the fallback CFM on their block
+    assert (errs["next"][same] < TOL).all()
+    loose = noisy & same
+    gerr = np.maximum(errs["grad_state"], errs["grad_action"])
+    worse = np.where(loose & (gerr >= 2e-3))[0]
+    assert len(worse) <= 3                     # ... except where the oracle's own gradient scatters by more than that (non-standardised PGS results)
+    prng = np.random.default_rng(3)
+    for wd in worse:
+        sp = s[wd][None] * (1.0 + prng.choice([-1.0, 0.0, 1.0], (64, s.shape[1])) * 2.220446049250313e-16)
+        r = ow.step_batch(sp, np.repeat(a[wd][None], 64, 0), np.repeat(g[wd][None], 64, 0), threads=8)
+        spread = max(np.abs(r[k] - ref[k][wd][None]).max() / scales[k] for k in ("grad_state", "grad_action"))
+        assert spread > 1e-3 and gerr[wd] < 5 * spread, (int(wd), float(gerr[wd]), float(spread))
+    strict = {k: np.where(loose, 0.0, e) for k, e in errs.items()}
+    # (perturbations of up to 16 ulps here: the device's A differs from the oracle's in the last bits - world-frame against body-frame
+    # impulse tests - and a Dantzig early exit that a 1-ulp change of the STATE does not reach can still be decided by those bits)
+    n_unstable = _assert_all_worlds_match_or_reference_is_unstable("two cubes side by side", strict, world, NORTH_STAR_TOL, n_perturb=128, ulps=16)
+    assert n_unstable < 0.02 * B
+    cascade = (status & 0x2) == 0
+    assert 0.05 < cascade.mean() < 0.95
