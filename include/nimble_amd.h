@@ -48,7 +48,9 @@ extern "C" {
 #define NBL_E_WORKSPACE -4   /* workspace too small for this B */
 #define NBL_E_NOGPU -5
 
-/* ---- per-lane status bits written to status[b] by nbl_step_forward ---- */
+/* ---- per-lane status bits written to status[b] by nbl_step_forward ----
+ * A world with several constrained groups (body_skeleton below) runs the solver once per group: STAGE0 and STANDARDIZED are set
+ * when they hold for EVERY group, the other bits when they hold for ANY group. */
 #define NBL_ST_CONTACT 0x1u       /* >=1 contact constraint was active */
 #define NBL_ST_LCP_STAGE0 0x2u    /* warm-start / guess classification was a valid LCP solution (BoxedLcpConstraintSolver.cpp:434-457) */
 #define NBL_ST_LCP_PIVOT 0x4u     /* pivoting (Dantzig-equivalent) stage used */
