@@ -163,3 +163,37 @@ def test_hip_graph_replay_equals_the_eager_step():
             n2, sv, _ = ref.step_soa(st, at)
             d2, a2 = ref.backward_soa(sv, gt)
             assert torch.equal(nxt, n2) and torch.equal(dstate, d2) and torch.equal(daction, a2)
+
+
+def test_rollout_with_two_constrained_groups_equals_chain_of_timesteps_and_oracle():
+    """Two balls on the ground = two constrained groups (the MULTI instantiation of the contact kernels) through the rollout entry
+    points: warm-started T-step rollout bit-identical to the chain of single steps, first step against the oracle."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    from oracle import OracleWorld
+    from util import ball_state, ball_world
+    md = ball_world("box_first", n_balls=2)
+    B, T = 128, 5
+    S, A = [], []
+    for i in range(B):
+        r = np.random.default_rng(900 + i)
+        s1, a1 = ball_state(md, [(r.uniform(-1.5, -0.3), r.uniform(-1, 1)), (r.uniform(0.3, 1.5), r.uniform(-1, 1))], 900 + i, pen=float(r.uniform(5e-4, 3e-3)))
+        S.append(s1); A.append(a1)
+    s0, a0 = np.array(S), np.array(A)
+    acts = np.repeat(a0[:, None, :], T, 1) + np.random.default_rng(4).normal(0, 0.05, (B, T, a0.shape[1]))
+    w = np.random.default_rng(5).normal(0, 1, (B, T + 1, s0.shape[1]))
+    world = na.World(md, device="cuda:0")
+    st, at, xs = _chain(world, s0, acts, True)
+    (xs * torch.tensor(w, device="cuda:0")).sum().backward()
+    world2 = na.World(md, device="cuda:0")
+    st2 = torch.tensor(s0, device="cuda:0", requires_grad=True); at2 = torch.tensor(acts, device="cuda:0", requires_grad=True)
+    ys = rollout(world2, st2, at2, warm_start=True)
+    (ys * torch.tensor(w, device="cuda:0")).sum().backward()
+    assert torch.equal(ys, xs.detach())
+    for a, b in ((st2.grad, st.grad), (at2.grad, at.grad)):
+        assert (a - b).abs().max().item() <= 1e-12 * max(b.abs().max().item(), 1.0)
+    ow = OracleWorld(md)
+    ref = ow.step_batch(s0, acts[:, 0], None, threads=4)
+    assert (ref["status"] & 1).all()
+    assert np.abs(ys[:, 1].detach().cpu().numpy() - ref["next"]).max() <= 1e-7 * np.abs(ref["next"]).max()
