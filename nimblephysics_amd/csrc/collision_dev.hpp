@@ -22,7 +22,7 @@ struct DevContact {
 
 DEV V3 colOf(const M3& R, int j) { return mk3(R.m[j], R.m[3 + j], R.m[6 + j]); }
 DEV double norm3(V3 a) { return sqrt(dot(a, a)); }
-DEV V3 unit3(V3 a) { double n = norm3(a); return (1.0 / n) * a; }
+DEV V3 unit3(V3 a) { double n = norm3(a); return mk3(a.x / n, a.y / n, a.z / n); }   // like Eigen's normalized(): divisions, no reciprocal
 DEV void set3(V3& a, int i, double v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
 
 // A small per-lane array in LDS, element i of the lane at base[i * 64] (conflict-free): the clip polygons are indexed
@@ -112,7 +112,7 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
       double l = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
       if (l > 0) {
         s2 /= l;
-        if (s2 * fudge > s) { s = s2; normalBox = 0; normalC = (1.0 / l) * n; invert = e1 < 0; code = 7 + 3 * i + j; }
+        if (s2 * fudge > s) { s = s2; normalBox = 0; normalC = mk3(n.x / l, n.y / l, n.z / l); invert = e1 < 0; code = 7 + 3 * i + j; }
       }
     }
   }

@@ -30,7 +30,8 @@ struct Contact {
 };
 
 inline Vec3 col(const Mat3& R, int j) { return mk3(R(0, j), R(1, j), R(2, j)); }
-inline Vec3 normalized(const Vec3& a) { s_t n = norm(a); return (1.0 / n) * a; }
+// Eigen's normalized() / normalize() (3.3 and later): every component DIVIDED by the norm, no reciprocal
+inline Vec3 normalized(const Vec3& a) { s_t n = norm(a); return mk3(a[0] / n, a[1] / n, a[2] / n); }
 
 // DARTCollide.cpp:271-300
 inline void lineClosestApproach(const Vec3& pa, const Vec3& ua, const Vec3& pb, const Vec3& ub, s_t* alpha, s_t* beta) {
@@ -118,7 +119,7 @@ inline int boxBox(const Iso& T1, const Vec3& A, const Iso& T2, const Vec3& B, s_
       if (l > 0) {
         s2 /= l;
         if (s2 * fudge > s) {
-          s = s2; normalBox = 0; normalC = (1.0 / l) * n; invert = e1 < 0; code = 7 + 3 * i + j;
+          s = s2; normalBox = 0; normalC = mk3(n[0] / l, n[1] / l, n[2] / l);   /* (n1) / l ..., DARTCollide.cpp:867-869 */ invert = e1 < 0; code = 7 + 3 * i + j;
         }
       }
     }

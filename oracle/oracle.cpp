@@ -11,7 +11,9 @@
 // tests/test_oracle_props.py (finite-difference agreement of every Jacobian, VJP == J^T g,
 // multi-step backprop vs brute force, M*Minv = I) and, for the LCP stage, by the literal fixtures of
 // unittests/unit/test_LCPUtils.cpp and by the vendored ODE Dantzig solver compiled from the reference
-// sources (oracle/_ref).  Where neither exists DESIGN.md says "parity unpinned".
+// sources (oracle/_ref); for the narrow phase by the reference's own dBoxBox / box-sphere / sphere-sphere functions compiled from
+// DARTCollide.cpp (oracle/ref_build.py, tests/test_oracle_contact.py: bit for bit on random pairs).  Where neither exists
+// DESIGN.md says "parity unpinned".
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 #include <algorithm>
@@ -448,6 +450,26 @@ int nbo_box_box(const double* T1, const double* size1, const double* T2, const d
       r[14 + k] = c.edgeBFixedPoint[k]; r[17 + k] = c.edgeBDir[k];
     }
     r[6] = c.depth; r[7] = c.type;
+  }
+  return n;
+}
+// which: 0 = box (T1, size1) vs sphere (T2, radius size2[0]), 1 = sphere vs box, 2 = sphere vs sphere.  out: up to 4 contacts of 32
+// doubles: point normal depth type sphereCenter face1..3Normal locked(3) centerA centerB radiusA radiusB
+int nbo_sphere_pair(int which, const double* T1, const double* size1, const double* T2, const double* size2, double clip, double* out) {
+  std::vector<Contact> cs;
+  int n;
+  if (which == 0) n = sphereBoxPair(false, size2[0], loadIso(T2), mk3(0.5 * size1[0], 0.5 * size1[1], 0.5 * size1[2]), loadIso(T1), clip, cs);
+  else if (which == 1) n = sphereBoxPair(true, size1[0], loadIso(T1), mk3(0.5 * size2[0], 0.5 * size2[1], 0.5 * size2[2]), loadIso(T2), clip, cs);
+  else n = sphereSphere(size1[0], loadIso(T1), size2[0], loadIso(T2), clip, cs);
+  for (int i = 0; i < n && i < 4; i++) {
+    double* r = out + 32 * i;
+    const Contact& c = cs[i];
+    for (int k = 0; k < 3; k++) {
+      r[k] = c.point[k]; r[3 + k] = c.normal[k]; r[8 + k] = c.sphereCenter[k];
+      r[11 + k] = c.faceNormal[0][k]; r[14 + k] = c.faceNormal[1][k]; r[17 + k] = c.faceNormal[2][k];
+      r[23 + k] = c.centerA[k]; r[26 + k] = c.centerB[k];
+    }
+    r[6] = c.depth; r[7] = c.type; r[20] = c.faceLocked[0]; r[21] = c.faceLocked[1]; r[22] = c.faceLocked[2]; r[29] = c.radiusA; r[30] = c.radiusB; r[31] = 0;
   }
   return n;
 }

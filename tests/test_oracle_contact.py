@@ -295,3 +295,115 @@ def test_constrained_groups_are_solved_independently():
         assert np.array_equal(both["next"][ok][:, sl], alone["next"][ok][:, sl])
         mixed += int((((alone["status"] & 0x2) != 0) & ((both["status"] & 0x2) == 0) & ok).sum())
     assert mixed > 10        # worlds where this cube resolves at stage 0 while the other one sends the world through the cascade
+
+
+def _ref_boxbox():
+    import os
+    import oracle
+    path = os.path.join(os.path.dirname(oracle.__file__), "_ref", "libdboxbox_ref.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.ref_collide_box_box.restype = C.c_int
+    return lib
+
+
+@pytest.mark.skipif(_ref_boxbox() is None, reason="oracle/_ref/libdboxbox_ref.so not built (needs the reference tree once: oracle/ref_build.py)")
+def test_box_box_equals_the_references_own_dboxbox_on_random_pairs():
+    """The reference's OWN box-box narrow phase (DARTCollide.cpp: dBoxBox + helpers + collideBoxBox, compiled from the reference's file
+    by oracle/ref_build.py into oracle/_ref/libdboxbox_ref.so) against the oracle's restatement on thousands of random box pairs -
+    touching face to face, edge to edge, corner to face, deep, barely, separated, aligned and tilted: same number of contacts in the
+    same order, same contact types, points / normals / depths and the edge metadata bit for bit."""
+    ref = _ref_boxbox()
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(2024)
+    n_pairs = n_contacts = 0
+    kinds = {}
+    for trial in range(6000):
+        s1 = rng.uniform(0.1, 1.0, 3); s2 = rng.uniform(0.1, 1.0, 3)
+        mode = trial % 6
+        if mode == 0:      # random orientations, centres at about touching distance
+            R1 = Rotation.random(random_state=rng.integers(1 << 31)).as_matrix(); R2 = Rotation.random(random_state=rng.integers(1 << 31)).as_matrix()
+            d = rng.normal(0, 1, 3); d /= np.linalg.norm(d)
+            p2 = d * rng.uniform(0.2, 0.9) * 0.5 * (np.linalg.norm(s1) + np.linalg.norm(s2))
+        elif mode in (1, 2):  # box 2 resting on top of box 1, yawed, slightly penetrating (face-face: 4..8 clipped points)
+            R1 = np.eye(3); R2 = Rotation.from_euler("y", rng.uniform(-np.pi, np.pi)).as_matrix()
+            if mode == 2: R2 = R2 @ Rotation.from_rotvec(rng.normal(0, 0.02, 3)).as_matrix()
+            p2 = np.array([rng.uniform(-0.5, 0.5) * s1[0], 0.5 * (s1[1] + s2[1]) - rng.uniform(1e-4, 2e-2), rng.uniform(-0.5, 0.5) * s1[2]])
+        elif mode == 3:    # edge over edge
+            R1 = np.eye(3); R2 = Rotation.from_euler("zx", [np.pi / 4 + rng.normal(0, 0.1), rng.uniform(0.3, 1.2)]).as_matrix()
+            p2 = np.array([rng.uniform(-0.3, 0.3) * s1[0], 0.5 * s1[1] + 0.5 * np.hypot(s2[0], s2[1]) - rng.uniform(1e-3, 2e-2), rng.uniform(-0.3, 0.3) * s1[2]])
+        elif mode == 4:    # corner into a face
+            R1 = np.eye(3); R2 = Rotation.from_euler("xz", [np.arctan(np.sqrt(2)) + rng.normal(0, 0.1), np.pi / 4 + rng.normal(0, 0.1)]).as_matrix()
+            p2 = np.array([rng.uniform(-0.2, 0.2), 0.5 * s1[1] + 0.5 * np.linalg.norm(s2) - rng.uniform(1e-3, 3e-2), rng.uniform(-0.2, 0.2)])
+        else:              # axis aligned, overlapping by a little along one axis
+            R1 = np.eye(3); R2 = np.eye(3)
+            ax = trial % 3
+            p2 = rng.uniform(-0.3, 0.3, 3) * 0.5 * (s1 + s2); p2[ax] = 0.5 * (s1[ax] + s2[ax]) - rng.uniform(-1e-3, 2e-2)
+        p1 = rng.normal(0, 1, 3)
+        T1 = np.concatenate([R1.reshape(9), p1]); T2 = np.concatenate([R2.reshape(9), p1 + R1 @ p2 if mode == 0 else p1 + p2])
+        o = np.zeros(16 * 22); r = np.zeros(16 * 22)
+        no = L.nbo_box_box(_p(_d(T1)), _p(_d(s1)), _p(_d(T2)), _p(_d(s2)), C.c_double(0.03), _p(o))
+        nr = ref.ref_collide_box_box(_p(_d(s1)), _p(_d(T1)), _p(_d(s2)), _p(_d(T2)), C.c_double(0.03), _p(r), 16)
+        assert no == nr, (trial, mode, no, nr)
+        if nr:
+            n_pairs += 1; n_contacts += nr
+            a, b = o[:22 * min(nr, 8)].reshape(-1, 22), r[:22 * min(nr, 8)].reshape(-1, 22)
+            assert np.array_equal(a[:, 7], b[:, 7]), (trial, mode, a[:, 7], b[:, 7])           # contact types
+            assert np.array_equal(a[:, :7], b[:, :7]), (trial, mode, np.abs(a[:, :7] - b[:, :7]).max())   # point, normal, depth: bit for bit
+            edge = a[:, 7] == 3
+            # edge fixed points and directions (unit vectors: Eigen's normalized() divides by the norm, and so do the stand-in and the oracle)
+            assert np.abs(a[edge, 8:20] - b[edge, 8:20]).max(initial=0.0) <= 0.0, (trial, mode, np.abs(a[edge, 8:20] - b[edge, 8:20]).max(0))
+            for t in a[:, 7]: kinds[int(t)] = kinds.get(int(t), 0) + 1
+    assert n_pairs > 3000 and n_contacts > 8000 and set(kinds) == {1, 2, 3}, (n_pairs, n_contacts, kinds)
+
+
+@pytest.mark.skipif(_ref_boxbox() is None, reason="oracle/_ref/libdboxbox_ref.so not built (needs the reference tree once: oracle/ref_build.py)")
+def test_sphere_narrow_phases_equal_the_references_own_functions_on_random_pairs():
+    """collideBoxSphere / collideSphereBox / collideSphereSphere of the reference (DARTCollide.cpp:1482-1882, compiled from the reference's
+    file into oracle/_ref/libdboxbox_ref.so) against the oracle's restatement: sphere centre outside the box (face, edge and corner
+    regions: one, two or three locked faces), inside the box, touching, too deep, separated; sphere pairs.  Same count and type,
+    same locked faces and face normals; point, normal, depth and the sphere data to 1e-15 (the box-frame transforms go through Eigen's
+    products in the reference, whose summation order the stand-in follows but cannot prove)."""
+    ref = _ref_boxbox()
+    ref.ref_collide_sphere.restype = C.c_int
+    L.nbo_sphere_pair.restype = C.c_int
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(77)
+    seen = {}
+    for trial in range(9000):
+        which = trial % 3
+        Rb = Rotation.random(random_state=rng.integers(1 << 31)).as_matrix()
+        pb = rng.normal(0, 1, 3)
+        half = rng.uniform(0.1, 0.8, 3)
+        rad = rng.uniform(0.05, 0.5)
+        if which < 2:
+            region = trial % 7                                       # how many coordinates of the centre lie outside the box
+            loc = rng.uniform(-1, 1, 3) * half
+            out_axes = rng.permutation(3)[: (region % 4)]
+            for ax in out_axes:
+                loc[ax] = np.sign(rng.normal()) * (half[ax] + rad * rng.uniform(0.3, 1.05) / np.sqrt(max(len(out_axes), 1)))
+            if region == 6:                                         # centre just inside a face, small sphere (deeper ones exceed the clipping depth)
+                loc = rng.uniform(-0.9, 0.9, 3) * half; ax = int(rng.integers(3))
+                rad = rng.uniform(0.002, 0.012); loc[ax] = np.sign(rng.normal()) * (half[ax] - rng.uniform(0.001, 0.012))
+            cs = pb + Rb @ loc
+            Tb = np.concatenate([Rb.reshape(9), pb]); Ts = np.concatenate([np.eye(3).reshape(9), cs])
+            sb = 2 * half; ss = np.array([rad, rad, rad])
+            args = (Tb, sb, Ts, ss) if which == 0 else (Ts, ss, Tb, sb)
+        else:
+            r2 = rng.uniform(0.05, 0.5)
+            d = rng.normal(0, 1, 3); d /= np.linalg.norm(d)
+            c2 = pb + d * (rad + r2) * rng.uniform(0.9, 1.03)
+            args = (np.concatenate([np.eye(3).reshape(9), pb]), np.array([rad] * 3), np.concatenate([np.eye(3).reshape(9), c2]), np.array([r2] * 3))
+        o = np.zeros(4 * 32); r = np.zeros(4 * 32)
+        no = L.nbo_sphere_pair(which, _p(_d(args[0])), _p(_d(args[1])), _p(_d(args[2])), _p(_d(args[3])), C.c_double(0.03), _p(o))
+        nr = ref.ref_collide_sphere(which, _p(_d(args[1])), _p(_d(args[0])), _p(_d(args[3])), _p(_d(args[2])), C.c_double(0.03), _p(r), 4)
+        assert no == nr, (trial, which, no, nr)
+        if nr:
+            a, b = o[:32], r[:32]
+            assert a[7] == b[7] and np.array_equal(a[20:23], b[20:23]), (trial, which, a[7], b[7], a[20:23], b[20:23])   # type, locked faces
+            assert np.abs(a - b).max() <= 1e-15 * max(1.0, np.abs(b).max()), (trial, which, np.abs(a - b).max())
+            seen[(which, int(b[7]), int(b[20:23].sum()))] = seen.get((which, int(b[7]), int(b[20:23].sum())), 0) + 1
+    # box-sphere and sphere-box with 1, 2, 3 locked faces, the centre-inside cases (plain vertex-face types), sphere-sphere
+    for key in [(0, 5, 1), (0, 5, 2), (0, 5, 3), (1, 4, 1), (1, 4, 2), (1, 4, 3), (0, 2, 0), (1, 1, 0), (2, 6, 0)]:
+        assert seen.get(key, 0) > 5, (key, seen)
