@@ -5,8 +5,10 @@ The shipped product (nimblephysics_amd) never does; it fails loudly when its HIP
 
 PARITY PINNING (see oracle/oracle.cpp header and DESIGN.md): pinned by the reference's property
 tests restated in tests/test_oracle_props.py, by the literal LCP fixtures of
-unittests/unit/test_LCPUtils.cpp, and by the vendored ODE Dantzig solver built from the reference
-sources into oracle/_ref.  There are no stored step/gradient outputs in the reference to compare to.
+unittests/unit/test_LCPUtils.cpp, and by the reference's own code where it compiles without Eigen, built
+from the reference sources where they lie into oracle/_ref (oracle/ref_build.py): the vendored ODE Dantzig
+solver, PgsBoxedLcpSolver::solve, dBoxBox and the box-sphere / sphere-sphere narrow phases.  There are no
+stored step/gradient outputs in the reference to compare to.
 """
 import ctypes as C
 import os

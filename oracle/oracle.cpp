@@ -11,7 +11,7 @@
 // tests/test_oracle_props.py (finite-difference agreement of every Jacobian, VJP == J^T g,
 // multi-step backprop vs brute force, M*Minv = I) and, for the LCP stage, by the literal fixtures of
 // unittests/unit/test_LCPUtils.cpp and by the vendored ODE Dantzig solver compiled from the reference
-// sources (oracle/_ref); for the narrow phase by the reference's own dBoxBox / box-sphere / sphere-sphere functions compiled from
+// sources (oracle/_ref), by the reference's own PgsBoxedLcpSolver::solve compiled the same way (bit for bit); for the narrow phase by the reference's own dBoxBox / box-sphere / sphere-sphere functions compiled from
 // DARTCollide.cpp (oracle/ref_build.py, tests/test_oracle_contact.py: bit for bit on random pairs).  Where neither exists
 // DESIGN.md says "parity unpinned".
 //

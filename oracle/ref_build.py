@@ -6,7 +6,8 @@ lies: that line range is read at build time into oracle/_ref/ (git-ignored) betw
 collision types the range uses) and ref_boxbox_epilogue.hpp (a C entry point).  Nothing of the reference is stored in this repo.
 libodelcp_ref.so: the reference's vendored ODE Dantzig LCP solver
 (dart/external/odelcpsolver, 9 self-contained .cpp files, no external dependency) compiled with g++
-directly from /root/reference — the rest of the reference needs Eigen/libccd/assimp/... and is
+directly from /root/reference, plus the reference's projected Gauss-Seidel solver: PgsBoxedLcpSolver::solve read from
+dart/constraint/PgsBoxedLcpSolver.cpp at build time between ref_pgs_prelude.hpp (the class shell) and ref_pgs_epilogue.hpp (a C entry point) — the rest of the reference needs Eigen/libccd/assimp/... and is
 unbuildable here.  Output goes to oracle/_ref/ only (git-ignored, shipped by gpurun)."""
 import glob
 import os
@@ -15,6 +16,22 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("NIMBLE_REFERENCE", "/root/reference")
+
+
+def _pgs_translation_unit(out_dir):
+    """PgsBoxedLcpSolver::solve read from the reference's file between ref_pgs_prelude.hpp and ref_pgs_epilogue.hpp (deleted after the build)."""
+    src = os.path.join(REF, "dart", "constraint", "PgsBoxedLcpSolver.cpp")
+    lines = open(src).read().split("\n")
+    first = next(i for i, l in enumerate(lines) if l.startswith("bool PgsBoxedLcpSolver::solve("))
+    last = next(i for i in range(first, len(lines)) if lines[i] == "}")
+    tu = os.path.join(out_dir, "pgs_tu.cpp")
+    with open(tu, "w") as f:
+        f.write(open(os.path.join(HERE, "ref_pgs_prelude.hpp")).read())
+        f.write(f'#line {first + 1} "{src}"\n')
+        f.write("\n".join(lines[first:last + 1]) + "\n")
+        f.write('#line 1 "ref_pgs_epilogue.hpp"\n')
+        f.write(open(os.path.join(HERE, "ref_pgs_epilogue.hpp")).read())
+    return tu, src
 
 
 def main():
@@ -26,9 +43,13 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "libodelcp_ref.so")
     srcs = sorted(glob.glob(os.path.join(src_dir, "*.cpp"))) + [os.path.join(HERE, "ref_shim.cpp")]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+    deps = srcs + [os.path.join(HERE, "ref_pgs_prelude.hpp"), os.path.join(HERE, "ref_pgs_epilogue.hpp"),
+                   os.path.join(REF, "dart", "constraint", "PgsBoxedLcpSolver.cpp"), __file__]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in deps):
         return 0
-    cmd = ["g++", "-O2", "-fPIC", "-shared", "-w", "-I", REF, "-o", out] + srcs
+    tu, _ = _pgs_translation_unit(out_dir)
+    # -ffp-contract=off: the reference's build has no fused multiply-adds
+    cmd = ["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-I", REF, "-o", out] + srcs + [tu]
     print("[ref_build]", " ".join(cmd))
     try:
         subprocess.check_call(cmd)

@@ -103,6 +103,46 @@ def test_reference_dantzig_solves_random_spd_normal_only_lcps():
         assert lcp_valid(A, x, b, lo, hi, fi)
 
 
+def _ref_lcp_lib():
+    path = os.path.join(os.path.dirname(oracle.__file__), "_ref", "libodelcp_ref.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    return lib if hasattr(lib, "nbo_ref_pgs") else None
+
+
+@pytest.mark.skipif(_ref_lcp_lib() is None, reason="oracle/_ref/libodelcp_ref.so with the reference's PGS not built (oracle/ref_build.py)")
+def test_pgs_equals_the_references_own_pgs_solver_bit_for_bit():
+    """The reference's PgsBoxedLcpSolver::solve itself (dart/constraint/PgsBoxedLcpSolver.cpp:79-268, compiled from where it lies into
+    oracle/_ref by oracle/ref_build.py) against the oracle's restatement: contact LCPs (full rank, rank deficient, with the fallback CFM
+    on the diagonal), the eight LCP fixtures of the reference's unit tests, zero-diagonal rows (skipped by the epsilon-for-division rule),
+    with the default options the cascade uses and with tight ones: return value and x are identical."""
+    R = _ref_lcp_lib()
+    from util import contact_lcp
+    rng = np.random.default_rng(11)
+    problems = []
+    for trial in range(300):
+        nc = int(rng.integers(1, 9))
+        A, b, lo, hi, fi = contact_lcp(rng, nc, int(rng.integers(2, 26)), cfm=[0.0, 1e-4, 1e-3][trial % 3])
+        if trial % 7 == 0:                      # a dead row: zero diagonal
+            k = int(rng.integers(0, 3 * nc)); A[k, :] = 0.0; A[:, k] = 0.0
+        problems.append((3 * nc, A, rng.normal(0, 0.1, 3 * nc) * (trial % 2), b, lo, hi, fi))
+    for name in sorted(FIX):
+        n, A, x, b, lo, hi, fi = _fixture(name)
+        problems.append((n, A, x, b, lo, hi, fi))
+    iterated = 0
+    for n, A, x0, b, lo, hi, fi in problems:
+        for opts in ((30, 1e-6, 1e-3, 1e-9), (2000, 1e-15, 1e-12, 1e-10)):
+            Ao, Ar = _d(A).copy(), _d(A).copy(); xo, xr = _d(x0).copy(), _d(x0).copy(); bo, br = _d(b).copy(), _d(b).copy()
+            args = (opts[0], C.c_double(opts[1]), C.c_double(opts[2]), C.c_double(opts[3]))
+            oko = L.nbo_lcp_pgs(n, _p(Ao), _p(xo), _p(bo), _p(_d(lo)), _p(_d(hi)), fi.ctypes.data_as(pi), *args)
+            okr = R.nbo_ref_pgs(n, _p(Ar), _p(xr), _p(br), _p(_d(lo)), _p(_d(hi)), fi.ctypes.data_as(pi), *args)
+            assert oko == okr
+            assert np.array_equal(xo, xr)
+            iterated += int(not np.array_equal(br, _d(b)))
+    assert iterated > 100          # the sweep loop ran (the first pass normalises A and b only when it did not converge at once)
+
+
 def test_cod_solve_is_min_norm_least_squares():
     """Stand-in for Eigen completeOrthogonalDecomposition().solve(): equals numpy's pinv solution, rank revealed."""
     rng = np.random.default_rng(4)
