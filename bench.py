@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--easy-noise", type=float, default=0.002, help="pose noise of the secondary stage-0-only measurement (0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="slices of the per-GPU batch, each a World on its own HIP stream (0 = auto: 4 from 4096 worlds, 2 from 2048)")
+    ap.add_argument("--checkpoint-every", type=int, default=0, help="with --rollout: keep the backward records of K steps instead of T (the backward pass recomputes the other segments)")
     ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: timed region without the per-kernel HIP events")
     ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (torch.distributed.run, one process per GPU, RCCL) even for --gpus 1")
@@ -217,7 +218,7 @@ def main():
             status = [None] * len(bounds)
             if args.rollout > 0:      # cfg5-style: T-step trajectory, loss = |q_T|^2 + |v_T|^2, one shared control vector
                 for _ in range(T):
-                    states, sv, st_all = world.rollout_soa(state0[0], action[0], T=args.rollout, want_saved=True, warm_start=True)
+                    states, sv, st_all = world.rollout_soa(state0[0], action[0], T=args.rollout, want_saved=True, warm_start=True, checkpoint_every=args.checkpoint_every)
                     gst = torch.zeros_like(states)
                     gst[-1] = 2.0 * states[-1]
                     g0, ga = world.rollout_backward_soa(sv, gst)
@@ -320,7 +321,7 @@ def main():
             "config": {"workload": f"{wl_desc}; batch={B} worlds/GPU; fwd+bwd through the C ABI, cold LCP start each step" +
                                    (f"; one step = one {args.rollout}-step rollout fwd+bwd (warm-started after its first step)" if args.rollout else ""),
                        "n_dofs": n, "contacts": m_rows // 3, "lcp_rows": m_rows, "worlds_per_gpu": B, "dt": md.dt,
-                       "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None,
+                       "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None, "rollout_checkpoint_every": (args.checkpoint_every or None) if args.rollout else None,
                        "saved_record_bytes_per_world_step": int(world._L.nbl_saved_bytes(world._h, B) // B),
                        "rccl_world_size": (dist.get_world_size() if use_dist else 0),
                        "lanes_with_contact": float((st & 0x1).astype(bool).mean()),

@@ -256,6 +256,29 @@ int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const v
                                      double* grad_state0, double* grad_actions, double* grad_params, void* workspace,
                                      size_t workspace_bytes, void* stream);
 
+/*
+ * Checkpointed rollout: the saved records of `segment` steps are resident instead of T (a record is ~32 kB per world-step on the
+ * metric model, the states 16 n bytes).  The forward pass writes record t into slot t % segment of `saved`
+ * (segment * nbl_saved_bytes(m, B) bytes) and keeps the LCP warm start entering every segment in `checkpoints`
+ * (nbl_rollout_checkpoint_bytes(m, B, T, segment) bytes; may be NULL when warm_start == 0 or the model has no colliders).  The
+ * backward pass walks the segments from the last to the first: it runs the steps of a segment again from states[k * segment] -
+ * the forward kernels are bit-reproducible, so the records are the ones the forward call produced and the gradients are bit for
+ * bit those of the unsegmented rollout - and then backpropagates through them.  The last segment is still resident and is not
+ * recomputed; cost: one extra forward pass over the other T - segment steps.  (The role of the reference's re-simulation from
+ * a stored state, RestorableSnapshot + forwardPass, for trajectories that do not fit.)
+ *   segment == 0 (or >= T): exactly nbl_rollout_forward / nbl_rollout_backward_inertia.
+ *   backward: `states`, `actions`, `action_stride`, `warm_start` as passed to / returned by the forward call (states[t0+1 .. t1] of
+ *   a recomputed segment are rewritten with identical values); grad_params may be NULL.
+ */
+size_t nbl_rollout_checkpoint_bytes(const nbl_model* m, int64_t B, int32_t T, int32_t segment);
+int32_t nbl_rollout_forward_checkpointed(nbl_model* m, int64_t B, int32_t T, int32_t segment, const double* state0, const double* actions,
+                                         int64_t action_stride, double* states, void* saved, void* checkpoints, uint32_t* status,
+                                         int32_t warm_start, void* workspace, size_t workspace_bytes, void* stream);
+int32_t nbl_rollout_backward_checkpointed(nbl_model* m, int64_t B, int32_t T, int32_t segment, double* states, const double* actions,
+                                          int64_t action_stride, void* saved, const void* checkpoints, int32_t warm_start,
+                                          const double* grad_states, double* grad_state0, double* grad_actions, double* grad_params,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- self-test ----
  * Runs the library's device restatement of the reference's Dantzig driver (dSolveLCP, dart/external/odelcpsolver/lcp.cpp:780-1113,
  * nub = 0, earlyTermination = true; the stage-1 code of the LCP cascade) on `count` caller-supplied n-row problems, one wavefront

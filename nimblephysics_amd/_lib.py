@@ -71,6 +71,12 @@ def lib():
     L.nbl_rollout_backward.restype = C.c_int32
     L.nbl_rollout_backward_inertia.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.nbl_rollout_backward_inertia.restype = C.c_int32
+    L.nbl_rollout_checkpoint_bytes.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32]
+    L.nbl_rollout_checkpoint_bytes.restype = C.c_size_t
+    L.nbl_rollout_forward_checkpointed.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, C.c_size_t, vp]
+    L.nbl_rollout_forward_checkpointed.restype = C.c_int32
+    L.nbl_rollout_backward_checkpointed.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    L.nbl_rollout_backward_checkpointed.restype = C.c_int32
     L.nbl_set_slices.argtypes = [vp, C.c_int32]
     L.nbl_set_slices.restype = C.c_int32
     L.nbl_slices_for.argtypes = [vp, C.c_int64]
@@ -97,6 +103,7 @@ EXPORTED_SYMBOLS = [
     "nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows", "nbl_workspace_bytes", "nbl_saved_bytes",
     "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing", "nbl_set_launch_lanes", "nbl_set_slices", "nbl_slices_for", "nbl_rollout_workspace_bytes", "nbl_rollout_forward", "nbl_rollout_backward",
     "nbl_set_body_inertia", "nbl_set_body_inertias", "nbl_set_inertia_params", "nbl_num_inertia_params", "nbl_backward_inertia", "nbl_rollout_backward_inertia",
+    "nbl_rollout_checkpoint_bytes", "nbl_rollout_forward_checkpointed", "nbl_rollout_backward_checkpointed",
     "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing", "nbl_selftest_lcp_dantzig",
 ]
 

@@ -795,37 +795,6 @@ size_t nbl_rollout_workspace_bytes(const nbl_model* m, int64_t B) {
          alignUp((size_t)2 * m->n * B * sizeof(double));
 }
 
-int32_t nbl_rollout_forward(nbl_model* m, int64_t B, int32_t T, const double* state0, const double* actions,
-                            int64_t action_stride, double* states, void* saved, uint32_t* status, int32_t warm_start,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-  if (!m || !state0 || !actions || !states || !workspace) return fail(NBL_E_BADARG, "null argument");
-  if (B <= 0 || T <= 0) return fail(NBL_E_BADARG, "B and T must be positive");
-  if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
-  if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved records");
-  hipStream_t s0 = (hipStream_t)stream;
-  const size_t stepWs = nbl_workspace_bytes(m, B), cacheBytes = alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
-  char* base = (char*)workspace;
-  double* cache[2] = {(double*)(base + alignUp(stepWs)), (double*)(base + alignUp(stepWs) + cacheBytes)};
-  const size_t stateElems = (size_t)2 * m->n * B, savedBytes = nbl_saved_bytes(m, B);
-  HIP_TRY(hipMemcpyAsync(states, state0, stateElems * sizeof(double), hipMemcpyDeviceToDevice, s0));
-  m->timingNow = false;
-  // slice-major: every slice runs its T steps on its own stream; the slices only join at the end
-  const int32_t rc = forSlices(m, B, rolloutSlicesFor(m, B), s0, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
-    for (int32_t t = 0; t < T; t++) {
-      const bool warm = m->hasContact && warm_start && t > 0;
-      const int32_t r = launchForward(m, B, si, b0, b1, s, states + (size_t)t * stateElems, actions + (size_t)t * action_stride,
-                                      warm ? cache[(t + 1) & 1] : nullptr, states + (size_t)(t + 1) * stateElems,
-                                      m->hasContact ? cache[t & 1] : nullptr, saved ? (char*)saved + (size_t)t * savedBytes : nullptr,
-                                      status ? status + (size_t)t * B : nullptr, workspace);
-      if (r != NBL_OK) return r;
-    }
-    return NBL_OK;
-  });
-  if (rc != NBL_OK) return rc;
-  HIP_TRY(hipGetLastError());
-  return NBL_OK;
-}
-
 namespace {
 __global__ __launch_bounds__(256) void k_add_rows(double* __restrict__ dst, const double* __restrict__ src, int64_t B, int64_t b0,
                                                   int64_t b1, int rows) {   // dst[r][b] += src[r][b] for b in [b0, b1)
@@ -841,7 +810,87 @@ __global__ __launch_bounds__(256) void k_copy_rows(double* __restrict__ dst, con
   const int64_t r = i / cnt, b = b0 + (i - r * cnt);
   dst[r * B + b] = src[r * B + b];
 }
+
+// The trajectory buffers of one rollout call.  segment == 0: record t lives at saved + t * savedBytes (all T resident);
+// segment > 0 (checkpointed): only `segment` records are resident, record t at slot t % segment, and the LCP warm start that
+// enters step k * segment is kept in checkpoints[k] so that the segment can be run again, bit for bit, by the backward pass.
+struct RolloutBufs {
+  int32_t T, segment;
+  const double* actions;
+  int64_t actionStride;
+  double* states;
+  char* saved;
+  char* checkpoints;
+  uint32_t* status;
+  bool warm;
+  double* cache[2];
+  size_t stateElems, savedBytes, cacheBytes;
+  char* record(int32_t t) const { return saved ? saved + (size_t)(segment > 0 ? t % segment : t) * savedBytes : nullptr; }
+};
+
+// steps [t0, t1) of one batch slice on its stream
+int32_t rolloutStepsOfSlice(nbl_model* m, int64_t B, int si, int64_t b0, int64_t b1, hipStream_t s, const RolloutBufs& r, int32_t t0,
+                            int32_t t1, bool recompute, void* workspace) {
+  const unsigned cblocks = (unsigned)(((b1 - b0) * (MAX_ROWS + 1) + 255) / 256);
+  for (int32_t t = t0; t < t1; t++) {
+    const bool warm = m->hasContact && r.warm && t > 0;
+    const int32_t rc = launchForward(m, B, si, b0, b1, s, r.states + (size_t)t * r.stateElems, r.actions + (size_t)t * r.actionStride,
+                                     warm ? r.cache[(t + 1) & 1] : nullptr, r.states + (size_t)(t + 1) * r.stateElems,
+                                     m->hasContact ? r.cache[t & 1] : nullptr, r.record(t),
+                                     (r.status && !recompute) ? r.status + (size_t)t * B : nullptr, workspace);
+    if (rc != NBL_OK) return rc;
+    if (!recompute && r.segment > 0 && m->hasContact && r.warm && (t + 1) % r.segment == 0 && t + 1 < r.T)   // the warm start step t+1 reads
+      hipLaunchKernelGGL(k_copy_rows, dim3(cblocks), dim3(256), 0, s, (double*)(r.checkpoints + (size_t)((t + 1) / r.segment) * r.cacheBytes),
+                         (const double*)r.cache[t & 1], B, b0, b1, MAX_ROWS + 1);
+  }
+  return NBL_OK;
+}
+
+RolloutBufs rolloutBufs(const nbl_model* m, int64_t B, int32_t T, int32_t segment, const double* actions, int64_t action_stride,
+                        double* states, void* saved, void* checkpoints, uint32_t* status, int32_t warm_start, void* workspace) {
+  RolloutBufs r;
+  r.T = T; r.segment = segment; r.actions = actions; r.actionStride = action_stride; r.states = states;
+  r.saved = (char*)saved; r.checkpoints = (char*)checkpoints; r.status = status; r.warm = warm_start != 0;
+  r.cacheBytes = alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
+  char* base = (char*)workspace + alignUp(nbl_workspace_bytes(m, B));
+  r.cache[0] = (double*)base; r.cache[1] = (double*)(base + r.cacheBytes);
+  r.stateElems = (size_t)2 * m->n * B; r.savedBytes = nbl_saved_bytes(m, B);
+  return r;
+}
 }  // namespace
+
+size_t nbl_rollout_checkpoint_bytes(const nbl_model* m, int64_t B, int32_t T, int32_t segment) {
+  if (!m || B <= 0 || T <= 0 || segment <= 0) return 0;
+  return (size_t)((T + segment - 1) / segment) * alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
+}
+
+int32_t nbl_rollout_forward_checkpointed(nbl_model* m, int64_t B, int32_t T, int32_t segment, const double* state0, const double* actions,
+                                         int64_t action_stride, double* states, void* saved, void* checkpoints, uint32_t* status,
+                                         int32_t warm_start, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !state0 || !actions || !states || !workspace) return fail(NBL_E_BADARG, "null argument");
+  if (B <= 0 || T <= 0 || segment < 0) return fail(NBL_E_BADARG, "B and T must be positive, segment >= 0");
+  if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
+  if (m->hasContact && !saved) return fail(NBL_E_BADARG, "models with colliders need the saved records");
+  if (segment > 0 && m->hasContact && warm_start && !checkpoints) return fail(NBL_E_BADARG, "a checkpointed warm-started rollout needs the checkpoint buffer");
+  hipStream_t s0 = (hipStream_t)stream;
+  const RolloutBufs r = rolloutBufs(m, B, T, segment, actions, action_stride, states, saved, checkpoints, status, warm_start, workspace);
+  HIP_TRY(hipMemcpyAsync(states, state0, r.stateElems * sizeof(double), hipMemcpyDeviceToDevice, s0));
+  m->timingNow = false;
+  // slice-major: every slice runs its T steps on its own stream; the slices only join at the end
+  const int32_t rc = forSlices(m, B, rolloutSlicesFor(m, B), s0, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
+    return rolloutStepsOfSlice(m, B, si, b0, b1, s, r, 0, T, false, workspace);
+  });
+  if (rc != NBL_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  return NBL_OK;
+}
+
+int32_t nbl_rollout_forward(nbl_model* m, int64_t B, int32_t T, const double* state0, const double* actions,
+                            int64_t action_stride, double* states, void* saved, uint32_t* status, int32_t warm_start,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  return nbl_rollout_forward_checkpointed(m, B, T, 0, state0, actions, action_stride, states, saved, nullptr, status, warm_start, workspace,
+                                          workspace_bytes, stream);
+}
 
 int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
                              double* grad_state0, double* grad_actions, void* workspace, size_t workspace_bytes,
@@ -852,28 +901,51 @@ int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* sav
 int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states,
                                      double* grad_state0, double* grad_actions, double* grad_params, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  return nbl_rollout_backward_checkpointed(m, B, T, 0, nullptr, nullptr, 0, (void*)saved, nullptr, 0, grad_states, grad_state0, grad_actions,
+                                           grad_params, workspace, workspace_bytes, stream);
+}
+
+int32_t nbl_rollout_backward_checkpointed(nbl_model* m, int64_t B, int32_t T, int32_t segment, double* states, const double* actions,
+                                          int64_t action_stride, void* saved, const void* checkpoints, int32_t warm_start,
+                                          const double* grad_states, double* grad_state0, double* grad_actions, double* grad_params,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
   if (!m || !saved || !grad_states || !grad_state0 || !grad_actions || !workspace) return fail(NBL_E_BADARG, "null argument");
   if (grad_params && m->nParams <= 0) return fail(NBL_E_BADARG, "no inertia parameters registered (nbl_set_inertia_params)");
-  if (B <= 0 || T <= 0) return fail(NBL_E_BADARG, "B and T must be positive");
+  if (B <= 0 || T <= 0 || segment < 0) return fail(NBL_E_BADARG, "B and T must be positive, segment >= 0");
+  if (segment > 0 && segment < T && (!states || !actions)) return fail(NBL_E_BADARG, "a checkpointed backward pass needs the states and actions of the forward call");
+  if (segment > 0 && segment < T && m->hasContact && warm_start && !checkpoints) return fail(NBL_E_BADARG, "a checkpointed warm-started rollout needs the checkpoint buffer");
   if (workspace_bytes < nbl_rollout_workspace_bytes(m, B)) return fail(NBL_E_WORKSPACE, "rollout workspace too small");
   hipStream_t s0 = (hipStream_t)stream;
-  const size_t stepWs = nbl_workspace_bytes(m, B), cacheBytes = alignUp((size_t)(MAX_ROWS + 1) * B * sizeof(double));
-  double* g = (double*)((char*)workspace + alignUp(stepWs) + 2 * cacheBytes);   // running cotangent of states[t+1]
-  const size_t stateElems = (size_t)2 * m->n * B, savedBytes = nbl_saved_bytes(m, B), actElems = (size_t)m->k * B;
+  const RolloutBufs r = rolloutBufs(m, B, T, segment, actions, action_stride, states, saved, (void*)checkpoints, nullptr, warm_start, workspace);
+  double* g = (double*)((char*)workspace + alignUp(nbl_workspace_bytes(m, B)) + 2 * r.cacheBytes);   // running cotangent of states[t+1]
+  const size_t actElems = (size_t)m->k * B;
   const int rows = 2 * m->n;
+  const int32_t seg = segment > 0 ? segment : T, nSeg = (T + seg - 1) / seg;
   m->timingNow = false;
   const int32_t rc = forSlices(m, B, rolloutSlicesFor(m, B), s0, [&](int si, int64_t b0, int64_t b1, hipStream_t s) -> int32_t {
-    const unsigned blocks = (unsigned)(((b1 - b0) * rows + 255) / 256);
-    hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, grad_states + (size_t)T * stateElems, B, b0, b1, rows);
-    for (int32_t t = T - 1; t >= 0; t--) {
-      // the kernels of one backward step re-read the incoming cotangent after the first outputs are written, so the
-      // output must not alias it: every step writes into grad_state0 and the running cotangent is copied back
-      const int32_t r = launchBackward(m, B, si, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, g, grad_state0,
-                                       grad_actions + (size_t)t * actElems, workspace);
-      if (r != NBL_OK) return r;
-      if (grad_params) launchInertia(m, B, b0, b1, s, (const char*)saved + (size_t)t * savedBytes, grad_params, t != T - 1, workspace);
-      hipLaunchKernelGGL(k_add_rows, dim3(blocks), dim3(256), 0, s, grad_state0, grad_states + (size_t)t * stateElems, B, b0, b1, rows);
-      if (t > 0) hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, (const double*)grad_state0, B, b0, b1, rows);
+    const unsigned blocks = (unsigned)(((b1 - b0) * rows + 255) / 256), cblocks = (unsigned)(((b1 - b0) * (MAX_ROWS + 1) + 255) / 256);
+    hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, grad_states + (size_t)T * r.stateElems, B, b0, b1, rows);
+    for (int32_t k = nSeg - 1; k >= 0; k--) {
+      const int32_t t0 = k * seg, t1 = std::min(T, t0 + seg);
+      if (k != nSeg - 1) {
+        // the records of this segment were overwritten by later ones: run its steps again from states[t0] and the checkpointed
+        // warm start (the forward kernels are bit-reproducible, so the records - and states[t0+1 .. t1], rewritten in passing -
+        // are the ones the forward call produced).  The last segment's records are still resident.
+        if (m->hasContact && r.warm && t0 > 0)
+          hipLaunchKernelGGL(k_copy_rows, dim3(cblocks), dim3(256), 0, s, r.cache[(t0 + 1) & 1], (const double*)(r.checkpoints + (size_t)k * r.cacheBytes),
+                             B, b0, b1, MAX_ROWS + 1);
+        const int32_t rf = rolloutStepsOfSlice(m, B, si, b0, b1, s, r, t0, t1, true, workspace);
+        if (rf != NBL_OK) return rf;
+      }
+      for (int32_t t = t1 - 1; t >= t0; t--) {
+        // the kernels of one backward step re-read the incoming cotangent after the first outputs are written, so the
+        // output must not alias it: every step writes into grad_state0 and the running cotangent is copied back
+        const int32_t rb = launchBackward(m, B, si, b0, b1, s, r.record(t), g, grad_state0, grad_actions + (size_t)t * actElems, workspace);
+        if (rb != NBL_OK) return rb;
+        if (grad_params) launchInertia(m, B, b0, b1, s, r.record(t), grad_params, t != T - 1, workspace);
+        hipLaunchKernelGGL(k_add_rows, dim3(blocks), dim3(256), 0, s, grad_state0, grad_states + (size_t)t * r.stateElems, B, b0, b1, rows);
+        if (t > 0) hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(256), 0, s, g, (const double*)grad_state0, B, b0, b1, rows);
+      }
     }
     return NBL_OK;
   });

@@ -74,7 +74,8 @@ class RolloutLayer(torch.autograd.Function):
     forwardPass, and of backpropGradientWrt over backprop, kept on the device)."""
 
     @staticmethod
-    def forward(ctx, world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool, mass: Optional[torch.Tensor] = None):
+    def forward(ctx, world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool, mass: Optional[torch.Tensor] = None,
+                checkpoint_every: int = 0):
         ctx.use_mass = mass is not None
         if ctx.use_mass:
             if mass.dim() != 1 or mass.shape[0] != world.getMassDims():
@@ -88,11 +89,13 @@ class RolloutLayer(torch.autograd.Function):
         B, T, k = actions.shape
         a = actions.detach().to(device=world.device, dtype=torch.float64)
         a_soa = a.permute(1, 2, 0).contiguous()                       # [T][k][B]
-        states, saved, status = world.rollout_soa(world.to_soa(s), a_soa, want_saved=True, warm_start=warm_start)
+        states, saved, status = world.rollout_soa(world.to_soa(s), a_soa, want_saved=True, warm_start=warm_start,
+                                                  checkpoint_every=checkpoint_every)
         ctx.world, ctx.saved_record, ctx.T = world, saved, T
         ctx.in_device, ctx.action_device = in_device, actions.device
         world._state = states[T]
         world.rollout_status = status
+        world.rollout_record = saved          # what stays resident for the backward pass (a RolloutRecord when checkpointed)
         return states.permute(2, 0, 1).contiguous().to(in_device)     # [B, T+1, 2n]
 
     @staticmethod
@@ -105,12 +108,14 @@ class RolloutLayer(torch.autograd.Function):
             d_mass = gm.sum(dim=1).to(ctx.mass_device)                # one mass vector for all worlds and steps
         else:
             g0, ga = world.rollout_backward_soa(ctx.saved_record, g)
-        return None, world.from_soa(g0).to(ctx.in_device), ga.permute(2, 0, 1).contiguous().to(ctx.action_device), None, d_mass
+        return None, world.from_soa(g0).to(ctx.in_device), ga.permute(2, 0, 1).contiguous().to(ctx.action_device), None, d_mass, None
 
 
 def rollout(world: World, state0: torch.Tensor, actions: torch.Tensor, warm_start: bool = True,
-            mass: Optional[torch.Tensor] = None) -> torch.Tensor:
+            mass: Optional[torch.Tensor] = None, checkpoint_every: int = 0) -> torch.Tensor:
     """states[:, 0] = state0, states[:, t+1] = timestep(world, states[:, t], actions[:, t][, mass]).
     state0 [B, 2n], actions [B, T, k] -> states [B, T+1, 2n]; differentiable wrt state0, actions and (when given) the
-    world's registered mass vector."""
-    return RolloutLayer.apply(world, state0, actions, warm_start, mass)
+    world's registered mass vector.  checkpoint_every = K > 0 keeps the backward records of K steps instead of T (a record is
+    ~32 kB per world-step on Atlas-20 with contacts): the backward pass re-runs the other segments from their stored start states;
+    the forward kernels are bit-reproducible, so the gradients are bit for bit those of checkpoint_every = 0."""
+    return RolloutLayer.apply(world, state0, actions, warm_start, mass, checkpoint_every)

@@ -27,6 +27,18 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class RolloutRecord:
+    """What the backward pass of a checkpointed rollout needs (World.rollout_soa(checkpoint_every=K)): the K resident saved records,
+    the LCP warm starts at the segment boundaries, and the states / actions of the forward call to run the other segments again."""
+
+    def __init__(self, saved, segment, checkpoints, states, actions, stride, warm_start):
+        self.saved, self.segment, self.checkpoints = saved, segment, checkpoints
+        self.states, self.actions, self.stride, self.warm_start = states, actions, stride, warm_start
+
+    def resident_bytes(self) -> int:
+        return self.saved.numel() + self.checkpoints.numel()
+
+
 class World:
     def __init__(self, model: ModelDescription, device: Optional[torch.device | int | str] = None):
         if not torch.cuda.is_available():
@@ -328,9 +340,11 @@ class World:
         return self._ws
 
     def rollout_soa(self, state0: torch.Tensor, actions: torch.Tensor, T: int = None, want_saved: bool = True,
-                    warm_start: bool = True):
+                    warm_start: bool = True, checkpoint_every: int = 0):
         """state0 [2n][B]; actions [T][k][B], or one [k][B] block applied at every one of `T` steps
-        -> (states [T+1][2n][B], saved records, status [T][B])."""
+        -> (states [T+1][2n][B], saved records, status [T][B]).  checkpoint_every = K > 0: only K records stay resident and the
+        backward pass recomputes the others segment by segment (nbl_rollout_forward_checkpointed); `saved` is then the RolloutRecord
+        rollout_backward_soa wants."""
         if actions.dim() == 2:
             if T is None:
                 raise ValueError("rollout_soa: a single [k][B] action block needs T")
@@ -339,33 +353,53 @@ class World:
             T = actions.shape[0]
             stride = actions.shape[1] * actions.shape[2]
         B = state0.shape[1]
+        K = int(checkpoint_every or 0)
+        if K < 0:
+            raise ValueError("checkpoint_every must be >= 0")
+        if K >= T:
+            K = 0
         states = torch.empty((T + 1, 2 * self.n, B), dtype=torch.float64, device=self.device)
         saved = None
         if want_saved:
-            saved = torch.empty(T * self._L.nbl_saved_bytes(self._h, B), dtype=torch.uint8, device=self.device)
+            saved = torch.empty((K if K else T) * self._L.nbl_saved_bytes(self._h, B), dtype=torch.uint8, device=self.device)
         status = torch.empty((T, B), dtype=torch.int32, device=self.device)
         ws = self._rollout_workspace(B)
-        check(self._L.nbl_rollout_forward(self._h, B, T, _ptr(state0), _ptr(actions), stride, _ptr(states), _ptr(saved),
-                                          _ptr(status), 1 if warm_start else 0, _ptr(ws), ws.numel(), self._stream()),
-              "nbl_rollout_forward")
+        if K and want_saved:
+            ckpt = torch.empty(self._L.nbl_rollout_checkpoint_bytes(self._h, B, T, K), dtype=torch.uint8, device=self.device)
+            check(self._L.nbl_rollout_forward_checkpointed(self._h, B, T, K, _ptr(state0), _ptr(actions), stride, _ptr(states), _ptr(saved),
+                                                           _ptr(ckpt), _ptr(status), 1 if warm_start else 0, _ptr(ws), ws.numel(),
+                                                           self._stream()), "nbl_rollout_forward_checkpointed")
+            saved = RolloutRecord(saved, K, ckpt, states, actions, stride, bool(warm_start))
+        else:
+            check(self._L.nbl_rollout_forward(self._h, B, T, _ptr(state0), _ptr(actions), stride, _ptr(states), _ptr(saved),
+                                              _ptr(status), 1 if warm_start else 0, _ptr(ws), ws.numel(), self._stream()),
+                  "nbl_rollout_forward")
         self.last_status = status[-1]
         return states, saved, status
 
-    def rollout_backward_soa(self, saved: torch.Tensor, grad_states: torch.Tensor, want_mass: bool = False):
+    def rollout_backward_soa(self, saved, grad_states: torch.Tensor, want_mass: bool = False):
         """grad_states [T+1][2n][B] -> (grad_state0 [2n][B], grad_actions [T][k][B]) and, with want_mass, the gradient with
-        respect to the registered mass vector summed over the T steps, [massDims][B]."""
+        respect to the registered mass vector summed over the T steps, [massDims][B].  `saved`: what rollout_soa returned."""
         T = grad_states.shape[0] - 1
         B = grad_states.shape[2]
         g0 = torch.empty((2 * self.n, B), dtype=torch.float64, device=self.device)
         ga = torch.empty((T, self.k, B), dtype=torch.float64, device=self.device)
         ws = self._rollout_workspace(B)
-        if want_mass and self.getMassDims() > 0:
-            gm = torch.empty((self.getMassDims(), B), dtype=torch.float64, device=self.device)
+        mass = want_mass and self.getMassDims() > 0
+        gm = torch.empty((self.getMassDims(), B), dtype=torch.float64, device=self.device) if mass else None
+        if isinstance(saved, RolloutRecord):
+            r = saved
+            check(self._L.nbl_rollout_backward_checkpointed(self._h, B, T, r.segment, _ptr(r.states), _ptr(r.actions), r.stride, _ptr(r.saved),
+                                                            _ptr(r.checkpoints), 1 if r.warm_start else 0, _ptr(grad_states), _ptr(g0), _ptr(ga),
+                                                            _ptr(gm), _ptr(ws), ws.numel(), self._stream()), "nbl_rollout_backward_checkpointed")
+        elif mass:
             check(self._L.nbl_rollout_backward_inertia(self._h, B, T, _ptr(saved), _ptr(grad_states), _ptr(g0), _ptr(ga), _ptr(gm),
                                                        _ptr(ws), ws.numel(), self._stream()), "nbl_rollout_backward_inertia")
+        else:
+            check(self._L.nbl_rollout_backward(self._h, B, T, _ptr(saved), _ptr(grad_states), _ptr(g0), _ptr(ga), _ptr(ws),
+                                               ws.numel(), self._stream()), "nbl_rollout_backward")
+        if mass:
             return g0, ga, gm
-        check(self._L.nbl_rollout_backward(self._h, B, T, _ptr(saved), _ptr(grad_states), _ptr(g0), _ptr(ga), _ptr(ws),
-                                           ws.numel(), self._stream()), "nbl_rollout_backward")
         if want_mass:
             return g0, ga, torch.zeros((0, B), dtype=torch.float64, device=self.device)
         return g0, ga

@@ -197,3 +197,39 @@ def test_rollout_with_two_constrained_groups_equals_chain_of_timesteps_and_oracl
     ref = ow.step_batch(s0, acts[:, 0], None, threads=4)
     assert (ref["status"] & 1).all()
     assert np.abs(ys[:, 1].detach().cpu().numpy() - ref["next"]).max() <= 1e-7 * np.abs(ref["next"]).max()
+
+
+@pytest.mark.parametrize("contact,warm,K", [(True, True, 4), (True, True, 5), (True, False, 3), (False, True, 4), (True, True, 1)])
+def test_checkpointed_rollout_is_bit_identical_and_keeps_only_K_records(contact, warm, K):
+    """rollout(checkpoint_every=K): K saved records resident instead of T; the backward pass re-runs the other segments from their
+    stored start states and checkpointed LCP warm starts.  The forward kernels are bit-reproducible, so states AND gradients (state0,
+    actions, masses) equal the unsegmented rollout bit for bit - with K dividing T or not, with and without warm start, K = 1."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    from nimblephysics_amd.world import RolloutRecord
+    B, T = 192, 14
+    md, s0, a0 = contact_inputs("atlas20", B, 31)
+    if not contact:
+        md = na.atlas("atlas20", ground=False)
+    rng = np.random.default_rng(5)
+    acts = np.repeat(a0[:, None, :], T, 1) + rng.normal(0, 0.05, (B, T, a0.shape[1]))
+    w = torch.tensor(rng.normal(0, 1, (B, T + 1, s0.shape[1])), device="cuda:0")
+    out = []
+    for k in (0, K):
+        world = na.World(md, device="cuda:0")
+        world.tuneMass(1, na.WrtMassBodyNodeEntryType.INERTIA_MASS)
+        st = torch.tensor(s0, device="cuda:0", requires_grad=True)
+        at = torch.tensor(acts, device="cuda:0", requires_grad=True)
+        ms = world.getMasses().clone().requires_grad_(True)
+        ys = rollout(world, st, at, warm_start=warm, mass=ms, checkpoint_every=k)
+        rec = world.rollout_record
+        (ys * w).sum().backward()
+        out.append((ys.detach(), st.grad, at.grad, ms.grad, rec, world))
+    (y0, gs0, ga0, gm0, rec0, w0), (y1, gs1, ga1, gm1, rec1, w1) = out
+    assert torch.equal(y0, y1) and torch.equal(gs0, gs1) and torch.equal(ga0, ga1) and torch.equal(gm0, gm1)
+    assert gs0.abs().max().item() > 0 and gm0.abs().max().item() > 0
+    # what stays resident: K records (+ the warm starts at the segment boundaries) against T records
+    per = w1._L.nbl_saved_bytes(w1._h, B)
+    assert isinstance(rec1, RolloutRecord) and rec1.saved.numel() == K * per and rec0.numel() == T * per
+    assert rec1.resident_bytes() < (K + 1) * per
