@@ -39,6 +39,12 @@ extern "C" {
 #define NBL_JOINT_FREE 2 /* DART_USE_IDENTITY_JACOBIAN build: S = Ad(T_cj), FreeJoint.cpp:1049-1056 */
 #define NBL_JOINT_WELD 3 /* 0 DOF. The GPU library requires welds to be merged into the parent
                             (host model builder does this); the CPU oracle accepts them. */
+#define NBL_JOINT_BALL 4 /* 3 DOF, BallJoint.cpp (DART_USE_IDENTITY_JACOBIAN build): positions = exponential-map vector of the joint
+                            rotation, velocities = angular velocity in the child joint frame, S = Ad(T_cj)[:, 0:3] (:441-452),
+                            q' = log(exp(q) exp(v dt)) (:333-349).  Anywhere in the tree.  The library runs it as three coincident
+                            single-axis joints (x, y, z at zero angle, the first carrying exp(q)) - identical velocity-level dynamics -
+                            and takes position derivatives through H(q) = [expMapJac(q)^T; 0] (:282-289); body indices of the
+                            description stay valid in every entry point. */
 
 /* ---- error codes ---- */
 #define NBL_OK 0

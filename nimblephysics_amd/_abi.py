@@ -8,8 +8,9 @@ JOINT_REVOLUTE = 0
 JOINT_PRISMATIC = 1
 JOINT_FREE = 2
 JOINT_WELD = 3
-JOINT_NAMES = {"revolute": JOINT_REVOLUTE, "prismatic": JOINT_PRISMATIC, "free": JOINT_FREE, "weld": JOINT_WELD}
-JOINT_NDOF = {JOINT_REVOLUTE: 1, JOINT_PRISMATIC: 1, JOINT_FREE: 6, JOINT_WELD: 0}
+JOINT_BALL = 4
+JOINT_NAMES = {"revolute": JOINT_REVOLUTE, "prismatic": JOINT_PRISMATIC, "free": JOINT_FREE, "weld": JOINT_WELD, "ball": JOINT_BALL}
+JOINT_NDOF = {JOINT_REVOLUTE: 1, JOINT_PRISMATIC: 1, JOINT_FREE: 6, JOINT_WELD: 0, JOINT_BALL: 3}
 
 NBL_OK = 0
 NBL_E_BADARG = -1

@@ -1076,11 +1076,12 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
   NBL_PHASE(54);
   // ---- phase 4 ----
   if (ln < nb) {
-    const int i = ln;
-    const DevBody& bd = bodies[i];
+    const DevBody& bd = bodies[ln];
+    const int i = bd.jtype == JT_BALL ? ln - bd.ballComp : ln;   // a ball joint's positions act through the x body of its triple
+    const int par = bodies[i].parent;
     V6 xiW = ld6(D + i * 54, 1);
-    if (bd.parent >= 0) {
-      const double* FWp = FW + bd.parent * 54;
+    if (par >= 0) {
+      const double* FWp = FW + par * 54;
       for (int e = 0; e < 8; e++) xiW = xiW + dad(ld6(FWp + e * 6, 1), ld6(D + i * 54 + 6 + e * 6, 1));
       for (int k = 0; k < 4; k++) {
         const int ADJ = k == 0 ? 0 : 4 + k, ACC = k == 0 ? 8 : 1 + k;   // (lambda1, w), (s_k, p_k)

@@ -153,6 +153,10 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
       const double qi = q[bd.dofOff * B + b];
       Q.R = eye3();
       Q.p = mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi);
+    } else if (bd.jtype == JT_BALL) {
+      // the x body of the triple carries the joint rotation exp(q) (BallJoint.cpp:91-95, 422-438); the y and z bodies sit on it at zero angle
+      Q.R = bd.ballComp == 0 ? expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b])) : eye3();
+      Q.p = mk3(0, 0, 0);
     } else {
       Q.R = expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b]));  // FreeJoint.cpp:74-81
       Q.p = mk3(q[(bd.dofOff + 3) * B + b], q[(bd.dofOff + 4) * B + b], q[(bd.dofOff + 5) * B + b]);
@@ -262,7 +266,17 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
     }
     stV6(c, i, WS_VBAR, Aw);
   });
-  if (on && !isFree) emit(bd.dofOff, qdd);                    // all 1-DOF joints together: the load of v is waited for once
+  if (on && !isFree) {                                        // all 1-DOF joints together: the load of v is waited for once
+    double acc = qdd;
+    if (bd.jtype == JT_BALL) {
+      // the chain's axes turn with its own rates, the ball joint's do not (constant S in the child frame): the child accelerates
+      // equally in both when qdd_ball = qdd_chain + (wy wz, -wx wz, wx wy), the Lie brackets of the chain's own axis velocities
+      const int d0 = bd.dofOff - bd.ballComp;
+      const double wx = v[(int64_t)d0 * B + b], wy = v[(int64_t)(d0 + 1) * B + b], wz = v[(int64_t)(d0 + 2) * B + b];
+      acc += bd.ballComp == 0 ? wy * wz : (bd.ballComp == 1 ? -wx * wz : wx * wy);
+    }
+    emit(bd.dofOff, acc);
+  }
   NBL_PHASE(6);
   // ---- kept slots in the body-frame convention of the consumers ----
   if (on) {
@@ -403,10 +417,10 @@ DEV V6 minvSweepsWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, RhsFn r
 // Everything that does not involve the children's accumulations (three G-products, the ad / dad terms, the projections, the
 // per-DOF epilogue including the free joint's exp/log VJP) is done by all bodies together; the level loop only adds the
 // accumulators, forms F / Abar / Vbar and hands them to the parent.
-template <class GvFn, class QxFn>
+template <class GvFn, class GvPreFn, class QxFn>
 DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 Ww, const double (&lam)[6], const double* __restrict__ q,
                            const double* __restrict__ v, const double* __restrict__ tau, const double* __restrict__ gqn, GvFn gvAt,
-                           QxFn qExtraAt, double* __restrict__ gq, double* __restrict__ gv, double* __restrict__ gaction) {
+                           GvPreFn gvPreAt, QxFn qExtraAt, double* __restrict__ gq, double* __restrict__ gv, double* __restrict__ gaction) {
   const int64_t B = c.B, b = c.b;
   const int i = c.lane;
   const DevBody& bd = c.bodies[wb.on ? i : 0];
@@ -433,17 +447,43 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
     if (bd.parent >= 0) parentTurn(c, [&]() { addV6(c, bd.parent, WS_FACC, F); addV6(c, bd.parent, WS_ABAR, Abar); addV6(c, bd.parent, WS_VBAR, Vbar); });
   });
   NBL_PHASE(26);
-  if (!wb.on) return;
   const V6 a0 = mk6(mk3(0, 0, 0), -c.g);
-  const V6 Vp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_UIMP) : zero6();
-  const V6 Ap = bd.parent >= 0 ? ldV6(c, bd.parent, WS_BACC) : a0;
-  const V6 Wp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_W) : zero6();
-  const V6 xi = dAdT(wb.TW, dad(Wp, F) + dad(Ap, Abar) + dad(Vp, Vbar));   // adjoint of the joint transform, body frame
-  const V6 tmp = dAdT(wb.TW, dad(wb.Vw, Abar) + Vbar);                     // body frame
+  V6 xi = zero6(), tmp = zero6();
+  if (wb.on) {
+    const V6 Vp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_UIMP) : zero6();
+    const V6 Ap = bd.parent >= 0 ? ldV6(c, bd.parent, WS_BACC) : a0;
+    const V6 Wp = bd.parent >= 0 ? ldV6(c, bd.parent, WS_W) : zero6();
+    xi = dAdT(wb.TW, dad(Wp, F) + dad(Ap, Abar) + dad(Vp, Vbar));   // adjoint of the joint transform, body frame
+    tmp = dAdT(wb.TW, dad(wb.Vw, Abar) + Vbar);                     // body frame
+  }
+  // a ball joint's positions act through the transform of the x body of its triple only: the y and z bodies take its adjoint
+  // (handed over in the accumulator slots, which the sweep above has consumed)
+  const bool isBall = wb.on && bd.jtype == JT_BALL;
+  if (isBall && bd.ballComp == 0) stV6(c, i, WS_FACC, xi);
+  waveFence();
+  if (isBall && bd.ballComp > 0) xi = ldV6(c, i - bd.ballComp, WS_FACC);
+  if (!wb.on) return;
   double qb[6], vb[6], pp[6], vp[6];
   applyHt(bd, q, B, b, xi, qb);
   const int o = bd.dofOff;
-  if (!wb.isFree) {
+  double ballExtra = 0.0;                       // velocity cotangent through the closed-form acceleration term of a ball joint
+  if (isBall) {
+    vb[0] = dot(cV6(bd.S), tmp);
+    const int d0 = o - bd.ballComp, cmp = bd.ballComp;
+    const V3 r = mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b]);
+    const V3 w = mk3(v[(int64_t)(d0 + 0) * B + b], v[(int64_t)(d0 + 1) * B + b], v[(int64_t)(d0 + 2) * B + b]);
+    const V3 grn = mk3(gqn[(int64_t)(d0 + 0) * B + b], gqn[(int64_t)(d0 + 1) * B + b], gqn[(int64_t)(d0 + 2) * B + b]);
+    // VJP of q' = logMap(R(q) R(w dt))  (exact reverse mode of BallJoint.cpp:333-349; the reference finite-differences it, :351-408)
+    const M3 R = expMapRot(r), E = expMapRot(c.dt * w);
+    const M3 Rnb = logMap_vjp(mul(R, E), grn);
+    const V3 posr = expMapRot_vjp(r, mulABt(Rnb, E));
+    const V3 velw = c.dt * expMapRot_vjp(c.dt * w, mulAtB(R, Rnb));
+    pp[0] = cmp == 0 ? posr.x : (cmp == 1 ? posr.y : posr.z);
+    vp[0] = cmp == 0 ? velw.x : (cmp == 1 ? velw.y : velw.z);
+    // v' = v + dt (qdd_chain + delta(w)),  delta = (wy wz, -wx wz, wx wy)
+    const double g0 = gvPreAt(d0), g1 = gvPreAt(d0 + 1), g2 = gvPreAt(d0 + 2);
+    ballExtra = c.dt * (cmp == 0 ? (-w.z * g1 + w.y * g2) : (cmp == 1 ? (w.z * g0 + w.x * g2) : (w.y * g0 - w.x * g1)));
+  } else if (!wb.isFree) {
     vb[0] = dot(cV6(bd.S), tmp);
     pp[0] = gqn[(int64_t)o * B + b];            // posPos = 1, velPos = dt  (GenericJoint.hpp:1428-1444)
     vp[0] = c.dt * pp[0];
@@ -476,7 +516,7 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
     const DevDof& df = dofs[d];
     const double lm = lam[k];
     double gt = lm;
-    double gvo = gvAt(d) + vp[k] - (vb[k] + df.damping * lm + c.dt * df.spring * lm);
+    double gvo = gvAt(d) + vp[k] + ballExtra - (vb[k] + df.damping * lm + c.dt * df.spring * lm);
     double gqo = pp[k] - (qb[k] + df.spring * lm) + qExtraAt(d);
     // clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479)
     const double qd = q[(int64_t)d * B + b], vd = v[(int64_t)d * B + b], td = tau[(int64_t)d * B + b];
@@ -562,7 +602,7 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_BFINAL) void k_b
   // with bouncing contacts the reference multiplies velPos by its bounce approximation: the correction to velPos^T gq' comes from
   // k_bwd_bounce as an extra velocity cotangent (the one to posPos^T gq' is already inside LB_QX)
   auto gvFinal = [&](int d) -> double { return gvp(d) + ((lws && mdl.hasBounce) ? lws[(int64_t)(LB_VX + d) * B + b] : 0.0); };
-  reverseSweepWorld(c, wb, Ww, lam, q, v, tau, gnext, gvFinal, qx, gstate, gstate + (int64_t)n * B, gaction);
+  reverseSweepWorld(c, wb, Ww, lam, q, v, tau, gnext, gvFinal, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
   NBL_PHASE(27);
   if (lamOut && wb.on) {   // lambda = dL/dtau on every DOF, where the one-world-per-lane kernels leave it (k_bwd_inertia reads it)
     const int nd = c.bodies[c.lane].ndof;

@@ -429,6 +429,13 @@ DEV void stepForwardCore(const C& c, const double* __restrict__ state, const dou
       V3 pn = p + mul(R, c.dt * vl);
       nq[(o + 0) * B + b] = rn.x; nq[(o + 1) * B + b] = rn.y; nq[(o + 2) * B + b] = rn.z;
       nq[(o + 3) * B + b] = pn.x; nq[(o + 4) * B + b] = pn.y; nq[(o + 5) * B + b] = pn.z;
+    } else if (bd.jtype == JT_BALL) {
+      // BallJoint::integratePositionsExplicit (BallJoint.cpp:333-349): R' = R(q) R(w dt); each of the triple's bodies writes its component
+      const int d0 = o - bd.ballComp;
+      const V3 r = mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b]);
+      const V3 w = mk3(v[(int64_t)(d0 + 0) * B + b], v[(int64_t)(d0 + 1) * B + b], v[(int64_t)(d0 + 2) * B + b]);
+      const V3 rn = logMap(mul(expMapRot(r), expMapRot(c.dt * w)));
+      nq[(int64_t)o * B + b] = bd.ballComp == 0 ? rn.x : (bd.ballComp == 1 ? rn.y : rn.z);
     } else {
       nq[(int64_t)o * B + b] = q[(int64_t)o * B + b] + c.dt * v[(int64_t)o * B + b];
     }
@@ -516,6 +523,13 @@ DEV void minvSweeps(const C& c, RhsFn rhsAt) {
 // Position-space Jacobian transpose of joint i applied to a body-frame adjoint xi:  H_i^T xi
 // (H = S for 1-DOF joints; free joint: Ad(T_cj) blkdiag(expMapJac(r)^T, R^T), FreeJoint.cpp:790-823)
 DEV void applyHt(const DevBody& bd, const double* __restrict__ q, int64_t B, int64_t b, V6 xi, double* out) {
+  if (bd.jtype == JT_BALL) {
+    // ball joint (BallJoint.cpp:282-289): H = [expMapJac(q)^T; 0] in the frame of the x body of the triple; xi = THAT body's adjoint
+    const int d0 = bd.dofOff - bd.ballComp;
+    const V3 y = mul(expMapJac(mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b])), xi.w);
+    out[0] = bd.ballComp == 0 ? y.x : (bd.ballComp == 1 ? y.y : y.z);
+    return;
+  }
   if (bd.jtype != JT_FREE) { out[0] = dot(cV6(bd.S), xi); return; }
   const int o = bd.dofOff;
   V6 y = dAdT(cT(bd.Tcj), xi);

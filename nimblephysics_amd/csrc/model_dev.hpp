@@ -51,7 +51,7 @@ __device__ unsigned long long g_phaseStamp[64];
 #define NBL_PHASE(k) do { } while (0)
 #endif
 
-constexpr int JT_REVOLUTE = 0, JT_PRISMATIC = 1, JT_FREE = 2;
+constexpr int JT_REVOLUTE = 0, JT_PRISMATIC = 1, JT_FREE = 2, JT_BALL = 4;   // = NBL_JOINT_*; JT_BALL: one of the three coincident axes of a ball joint
 
 struct DevBody {
   int32_t parent, jtype, dofOff, ndof;
@@ -62,7 +62,9 @@ struct DevBody {
   double S[6];        // 1-DOF joints: constant relative Jacobian column in the child frame
   double G[21];       // spatial inertia, packed symmetric
   int32_t level, rank; // depth in the tree, index among the children of the parent (coop tree kernels)
-  int32_t freeIdx, padb; // index among the free-joint bodies (-1 otherwise): their extra LDS block in the coop tree kernels
+  int32_t freeIdx;     // index among the free-joint bodies (-1 otherwise): their extra LDS block in the coop tree kernels
+  int32_t ballComp;    // JT_BALL: 0, 1, 2 = the x, y, z body of a ball joint's triple (consecutive body indices and DOFs; the x body
+                       // carries T_pj exp(q), the z body T_cj, mass and children).  1-DOF code treats all three as revolute joints
 };
 
 struct DevDof {

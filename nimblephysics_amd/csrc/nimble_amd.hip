@@ -80,6 +80,9 @@ struct nbl_model {
   bool coopTree = false;             // tree sweeps one world per wavefront (needs the saved tree block, nb and n <= 64)
   int treeLanes = 0;                 // worlds per workgroup of the one-world-per-lane tree kernels (0 = pick from B); nbl_set_launch_lanes
   std::vector<DevBody> hBodies;      // host copy of the body constants (nbl_set_body_inertia patches one entry)
+  int userBodies = 0;                // bodies of the caller's description; bodyMap: caller's body index -> device body (empty: identity;
+  std::vector<int32_t> bodyMap;      // models with ball joints carry two extra massless bodies per ball joint, expandBallJoints)
+  int deviceBody(int body) const { return bodyMap.empty() ? body : bodyMap[body]; }
   DevInertiaParam* dParams = nullptr; // registered inertia parameters (nbl_set_inertia_params)
   int nParams = 0;
   void* staging = nullptr;           // pinned host staging area of the stream-ordered uploads (nbl_set_body_inertias)
@@ -174,6 +177,65 @@ static int32_t forSlices(nbl_model* m, int64_t B, int sl, hipStream_t s, Fn fn) 
   return NBL_OK;
 }
 
+namespace {
+// Ball joints (NBL_JOINT_BALL, BallJoint.cpp) run on the device as three coincident single-axis joints x, y, z at zero angle, the first
+// one carrying exp(q): two massless bodies are inserted before every ball-jointed body.  Mass matrix, impulse tests and contact
+// Jacobians of that chain are the ball joint's; the joint accelerations differ by the closed-form term (wy wz, -wx wz, wx wy) (the
+// chain's axes turn with its own rates, the ball's do not; tests/test_ball_joint.py), positions integrate on SO(3) and position
+// derivatives go through H(q) = [expMapJac(q)^T; 0] of the first of the three.  DOF numbering is unchanged; body indices of the
+// caller's description are mapped to the last body of each triple (the one that carries mass, colliders and children).
+struct ExpandedDesc {
+  nbl_model_desc desc;
+  std::vector<int32_t> parent, jointType, dofOffset, boxBody, bodySkeleton, bodyMap, ballComp;
+  std::vector<double> Tpj, Tcj, axis, mass, com, inertia;
+};
+bool hasBallJoints(const nbl_model_desc* d) {
+  for (int i = 0; i < d->n_bodies; i++) if (d->joint_type[i] == NBL_JOINT_BALL) return true;
+  return false;
+}
+void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
+  static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  e.bodyMap.assign(d->n_bodies, -1);
+  auto push = [&](int parent, int jt, int dofOff, const double* Tpj, const double* Tcj, const double* ax, double mass, const double* com,
+                  const double* inertia, int skel, int comp) {
+    static const double z6[6] = {0, 0, 0, 0, 0, 0};
+    e.parent.push_back(parent); e.jointType.push_back(jt); e.dofOffset.push_back(dofOff);
+    e.Tpj.insert(e.Tpj.end(), Tpj, Tpj + 12); e.Tcj.insert(e.Tcj.end(), Tcj, Tcj + 12); e.axis.insert(e.axis.end(), ax, ax + 3);
+    e.mass.push_back(mass); e.com.insert(e.com.end(), com ? com : z6, (com ? com : z6) + 3);
+    e.inertia.insert(e.inertia.end(), inertia ? inertia : z6, (inertia ? inertia : z6) + 6);
+    e.bodySkeleton.push_back(skel); e.ballComp.push_back(comp);
+  };
+  // skeleton ids: the caller's, or (default: one skeleton per tree) the root of the tree in the CALLER's numbering - any id shared by
+  // exactly the bodies of one tree will do
+  auto rootOf = [&](int body) { while (d->parent[body] >= 0) body = d->parent[body]; return body; };
+  for (int i = 0; i < d->n_bodies; i++) {
+    const int par = d->parent[i] < 0 ? -1 : e.bodyMap[d->parent[i]];
+    const int skel = d->body_skeleton ? d->body_skeleton[i] : rootOf(i);
+    if (d->joint_type[i] != NBL_JOINT_BALL) {
+      push(par, d->joint_type[i], d->dof_offset[i], d->T_pj + 12 * i, d->T_cj + 12 * i, d->axis + 3 * i, d->mass[i], d->com + 3 * i,
+           d->inertia + 6 * i, skel, 0);
+    } else {
+      for (int k = 0; k < 3; k++) {
+        const double ax[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
+        const bool last = k == 2;
+        push(k == 0 ? par : (int)e.parent.size() - 1, NBL_JOINT_BALL, d->dof_offset[i] + k, k == 0 ? d->T_pj + 12 * i : I12,
+             last ? d->T_cj + 12 * i : I12, ax, last ? d->mass[i] : 0.0, last ? d->com + 3 * i : nullptr, last ? d->inertia + 6 * i : nullptr,
+             skel, k);
+      }
+    }
+    e.bodyMap[i] = (int)e.parent.size() - 1;
+  }
+  e.boxBody.resize(d->n_boxes > 0 ? d->n_boxes : 0);
+  for (int i = 0; i < d->n_boxes; i++) e.boxBody[i] = d->box_body[i] < 0 ? d->box_body[i] : (d->box_body[i] < d->n_bodies ? e.bodyMap[d->box_body[i]] : 1 << 20);
+  e.desc = *d;
+  e.desc.n_bodies = (int32_t)e.parent.size();
+  e.desc.parent = e.parent.data(); e.desc.joint_type = e.jointType.data(); e.desc.dof_offset = e.dofOffset.data();
+  e.desc.T_pj = e.Tpj.data(); e.desc.T_cj = e.Tcj.data(); e.desc.axis = e.axis.data();
+  e.desc.mass = e.mass.data(); e.desc.com = e.com.data(); e.desc.inertia = e.inertia.data();
+  e.desc.box_body = e.boxBody.data(); e.desc.body_skeleton = e.bodySkeleton.data();
+}
+}  // namespace
+
 extern "C" {
 
 const char* nbl_last_error(void) { return g_err.c_str(); }
@@ -192,6 +254,18 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   int ndev = nbl_device_count();
   if (ndev <= 0) return fail(NBL_E_NOGPU, "no HIP device visible: the batched timestep has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(NBL_E_BADARG, "device index out of range");
+  for (int i = 0; i < d->n_bodies; i++)
+    if (d->parent[i] < -1 || d->parent[i] >= i) return fail(NBL_E_BADARG, "bodies must be listed parents-before-children");
+  ExpandedDesc expanded;
+  const int userBodies = d->n_bodies;
+  const bool ballModel = hasBallJoints(d);
+  if (ballModel) {
+    if (d->body_skeleton)
+      for (int i = 0; i < d->n_bodies; i++)
+        if (d->body_skeleton[i] < 0 || d->body_skeleton[i] >= 64) return fail(NBL_E_BADARG, "body_skeleton must lie in [0, 64)");
+    expandBallJoints(d, expanded);
+    d = &expanded.desc;
+  }
 
   std::vector<DevBody> hb(d->n_bodies);
   std::vector<DevDof> hd(d->n_dofs);
@@ -204,11 +278,11 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (b.parent < -1 || b.parent >= i) return fail(NBL_E_BADARG, "bodies must be listed parents-before-children");
     if (b.jtype == NBL_JOINT_WELD)
       return fail(NBL_E_UNSUPPORTED, "weld joints must be merged into their parent before upload (ModelDescription.merge_welds)");
-    if (b.jtype != NBL_JOINT_REVOLUTE && b.jtype != NBL_JOINT_PRISMATIC && b.jtype != NBL_JOINT_FREE)
-      return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, free)");
+    if (b.jtype != NBL_JOINT_REVOLUTE && b.jtype != NBL_JOINT_PRISMATIC && b.jtype != NBL_JOINT_FREE && b.jtype != NBL_JOINT_BALL)
+      return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, free, ball)");
     if (b.jtype == NBL_JOINT_FREE && b.parent != -1)
       return fail(NBL_E_UNSUPPORTED, "free joints are supported as tree roots only");
-    b.freeIdx = -1; b.padb = 0;
+    b.freeIdx = -1; b.ballComp = ballModel ? expanded.ballComp[i] : 0;
     b.level = b.parent < 0 ? 0 : hb[b.parent].level + 1;
     b.rank = 0;
     for (int j = 0; j < i; j++) if (hb[j].parent == b.parent) b.rank++;
@@ -228,7 +302,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     const double* p = b.Tcj + 9;
     double Ra[3];
     for (int r = 0; r < 3; r++) Ra[r] = R[3 * r] * b.axis[0] + R[3 * r + 1] * b.axis[1] + R[3 * r + 2] * b.axis[2];
-    if (b.jtype == NBL_JOINT_REVOLUTE) {
+    if (b.jtype == NBL_JOINT_REVOLUTE || b.jtype == NBL_JOINT_BALL) {   // ball: one of the three coincident axes (expandBallJoints)
       b.S[0] = Ra[0]; b.S[1] = Ra[1]; b.S[2] = Ra[2];
       b.S[3] = p[1] * Ra[2] - p[2] * Ra[1];
       b.S[4] = p[2] * Ra[0] - p[0] * Ra[2];
@@ -383,6 +457,12 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     nbl_model_destroy(m);
     return fail(NBL_E_UNSUPPORTED, "restitution needs the wavefront-per-world kernels (NBL_COOP_TREE / NBL_COOP_FINAL are off or the model does not fit them)");
   }
+  if (ballModel && !(m->coopTree && m->coopFinal)) {
+    nbl_model_destroy(m);
+    return fail(NBL_E_UNSUPPORTED, "ball joints need the wavefront-per-world kernels (NBL_COOP_TREE / NBL_COOP_FINAL / NBL_SAVE_TREE are off or the model, three device bodies per ball joint, does not fit them)");
+  }
+  m->userBodies = userBodies;
+  if (ballModel) m->bodyMap = expanded.bodyMap;
   m->mdl.nb = m->nb; m->mdl.n = m->n; m->mdl.nAction = m->k; m->mdl.b0 = 0; m->mdl.b1 = 0;   // mdl.pad: worlds per wavefront, set above
   if (const char* e9 = getenv("NBL_SLICES")) m->slices = atoi(e9);
   m->mdl.maxLevel = 0; m->mdl.maxRank = 0;
@@ -654,7 +734,7 @@ int32_t nbl_set_body_inertias(nbl_model* m, int32_t count, const int32_t* bodies
   if (!m || count < 0 || (count > 0 && (!bodies || !mass || !com || !inertia))) return fail(NBL_E_BADARG, "bad argument");
   if (count == 0) return NBL_OK;
   for (int i = 0; i < count; i++) {
-    if (bodies[i] < 0 || bodies[i] >= m->nb) return fail(NBL_E_BADARG, "body index out of range");
+    if (bodies[i] < 0 || bodies[i] >= m->userBodies) return fail(NBL_E_BADARG, "body index out of range");
     if (!(mass[i] > 0)) return fail(NBL_E_BADARG, "mass must be positive");
   }
   DeviceGuard guard(m->device);
@@ -663,7 +743,7 @@ int32_t nbl_set_body_inertias(nbl_model* m, int32_t count, const int32_t* bodies
   const int32_t rc = ensureStaging(m, bytes + sizeof(DevInertiaParam) * 64);
   if (rc != NBL_OK) return rc;
   HIP_TRY(hipEventSynchronize(m->staged));   // the previous upload has finished reading the staging area (normally long ago)
-  for (int i = 0; i < count; i++) packSpatialInertia(mass[i], com + 3 * i, inertia + 6 * i, m->hBodies[bodies[i]].G);
+  for (int i = 0; i < count; i++) packSpatialInertia(mass[i], com + 3 * i, inertia + 6 * i, m->hBodies[m->deviceBody(bodies[i])].G);
   std::memcpy(m->staging, m->hBodies.data(), bytes);
   HIP_TRY(hipMemcpyAsync(m->dBodies, m->staging, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipEventRecord(m->staged, (hipStream_t)stream));
@@ -683,12 +763,12 @@ int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const doub
 int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG) {
   if (!m || count < 0 || (count > 0 && (!bodies || !dG))) return fail(NBL_E_BADARG, "bad argument");
   for (int p = 0; p < count; p++)
-    if (bodies[p] < 0 || bodies[p] >= m->nb) return fail(NBL_E_BADARG, "inertia parameter on an unknown body");
+    if (bodies[p] < 0 || bodies[p] >= m->userBodies) return fail(NBL_E_BADARG, "inertia parameter on an unknown body");
   DeviceGuard guard(m->device);
   if (!guard.ok) return fail(NBL_E_HIP, "hipSetDevice failed");
   std::vector<DevInertiaParam> hp(count);
   for (int p = 0; p < count; p++) {
-    hp[p].body = bodies[p]; hp[p].pad = 0;
+    hp[p].body = m->deviceBody(bodies[p]); hp[p].pad = 0;
     const double* D = dG + 36 * (size_t)p;
     int idx = 0;
     for (int r = 0; r < 6; r++)

@@ -1,7 +1,7 @@
 // oracle/dynamics.hpp — TEST INFRASTRUCTURE ONLY.
 //
 // Scalar restatement of the reference's articulated-body dynamics for the joint
-// types on the hot path (Revolute, Prismatic, Free [identity-Jacobian build], Weld).
+// types on the hot path (Revolute, Prismatic, Free and Ball [identity-Jacobian build], Weld).
 // One world at a time, no batching, written to follow the reference's recursion
 // order so that each routine can be read next to the file:line it cites.
 #pragma once
@@ -59,7 +59,7 @@ inline Model buildModel(const nbl_model_desc* d) {
     b.parent = d->parent[i];
     b.jtype = d->joint_type[i];
     b.dofOff = d->dof_offset[i];
-    b.ndof = (b.jtype == NBL_JOINT_FREE) ? 6 : (b.jtype == NBL_JOINT_WELD ? 0 : 1);
+    b.ndof = (b.jtype == NBL_JOINT_FREE) ? 6 : (b.jtype == NBL_JOINT_BALL ? 3 : (b.jtype == NBL_JOINT_WELD ? 0 : 1));
     b.Tpj = loadIso(d->T_pj + 12 * i);
     b.Tcj = loadIso(d->T_cj + 12 * i);
     b.TcjInv = inverse(b.Tcj);
@@ -93,6 +93,11 @@ inline Model buildModel(const nbl_model_desc* d) {
       // getAdTMatrix(T_cj)      FreeJoint.cpp:1049-1056 (DART_USE_IDENTITY_JACOBIAN)
       Mat6 A = AdTMatrix(b.Tcj);
       for (int k = 0; k < 6; k++)
+        for (int r = 0; r < 6; r++) b.S[k][r] = A(r, k);
+    } else if (b.jtype == NBL_JOINT_BALL) {
+      // getAdTMatrix(T_cj).leftCols<3>()      BallJoint.cpp:441-452 (DART_USE_IDENTITY_JACOBIAN)
+      Mat6 A = AdTMatrix(b.Tcj);
+      for (int k = 0; k < 3; k++)
         for (int r = 0; r < 6; r++) b.S[k][r] = A(r, k);
     }
     if (b.parent >= 0) m.bodies[b.parent].children.push_back(i);
@@ -145,6 +150,8 @@ inline Iso jointQ(const Body& b, const s_t* q) {
   else if (b.jtype == NBL_JOINT_FREE) {
     Q.R = expMapRot(mk3(q[b.dofOff], q[b.dofOff + 1], q[b.dofOff + 2]));
     Q.p = mk3(q[b.dofOff + 3], q[b.dofOff + 4], q[b.dofOff + 5]);
+  } else if (b.jtype == NBL_JOINT_BALL) {
+    Q.R = expMapRot(mk3(q[b.dofOff], q[b.dofOff + 1], q[b.dofOff + 2]));   // BallJoint.cpp:91-95, 422-438
   }
   return Q;
 }
@@ -377,12 +384,16 @@ inline MatX invMassMatrix(const Model& m, const std::vector<Kin>& kin, const std
 // Revolute/Prismatic: H = S.  Free: AdTJacFixed(T_cj, blkdiag(expMapJac(q)^T, expMapRot(q)^T))
 // (FreeJoint.cpp:790-823, getRelativeJacobianInPositionSpaceStatic)
 inline void positionJacobian(const Body& b, const s_t* q, Vec6 H[6]) {
-  if (b.jtype != NBL_JOINT_FREE) {
+  if (b.jtype != NBL_JOINT_FREE && b.jtype != NBL_JOINT_BALL) {
     for (int k = 0; k < b.ndof; k++) H[k] = b.S[k];
     return;
   }
   Vec3 r = mk3(q[b.dofOff], q[b.dofOff + 1], q[b.dofOff + 2]);
   Mat3 Jt = transpose(expMapJac(r));
+  if (b.jtype == NBL_JOINT_BALL) {   // BallJoint.cpp:282-289: AdTJacFixed(T_cj, [expMapJac(q)^T; 0])
+    for (int k = 0; k < 3; k++) H[k] = AdT(b.Tcj, mk6(mk3(Jt(0, k), Jt(1, k), Jt(2, k)), mk3(0, 0, 0)));
+    return;
+  }
   Mat3 Rt = transpose(expMapRot(r));
   for (int k = 0; k < 3; k++) {
     Vec6 colA = mk6(mk3(Jt(0, k), Jt(1, k), Jt(2, k)), mk3(0, 0, 0));
@@ -499,6 +510,11 @@ inline void integratePositions(const Model& m, const s_t* q, const s_t* v, s_t d
       Iso N = Q * D;
       Vec3 r = logMap(N.R);
       for (int k = 0; k < 3; k++) { qn[o + k] = r[k]; qn[o + 3 + k] = N.p[k]; }
+    } else if (b.jtype == NBL_JOINT_BALL) {
+      // BallJoint::integratePositionsExplicit (BallJoint.cpp:333-349, identity-Jacobian branch): Rnext = R(q) R(dq dt)
+      int o = b.dofOff;
+      Vec3 r = logMap(expMapRot(mk3(q[o], q[o + 1], q[o + 2])) * expMapRot(mk3(v[o] * dt, v[o + 1] * dt, v[o + 2] * dt)));
+      for (int k = 0; k < 3; k++) qn[o + k] = r[k];
     } else {
       for (int k = 0; k < b.ndof; k++) qn[b.dofOff + k] = q[b.dofOff + k] + v[b.dofOff + k] * dt;
     }
@@ -515,9 +531,10 @@ inline void posJacobians(const Model& m, const s_t* q, const s_t* v, s_t dt, Mat
   VecX qa(q, q + m.n), va(v, v + m.n), plus(m.n), minus(m.n);
   for (int i = 0; i < m.nb; i++) {
     const Body& b = m.bodies[i];
-    if (b.jtype != NBL_JOINT_FREE) continue;
+    if (b.jtype != NBL_JOINT_FREE && b.jtype != NBL_JOINT_BALL) continue;   // BallJoint.cpp:351-408: the same finite differences
     int o = b.dofOff;
-    for (int j = 0; j < 6; j++) {
+    const int nd = b.ndof;
+    for (int j = 0; j < nd; j++) {
       s_t EPS = 1e-6;
       VecX pert = qa;
       pert[o + j] += EPS;
@@ -525,7 +542,7 @@ inline void posJacobians(const Model& m, const s_t* q, const s_t* v, s_t dt, Mat
       pert = qa;
       pert[o + j] -= EPS;
       integratePositions(m, pert.data(), v, dt, minus.data());
-      for (int r = 0; r < 6; r++) posPos(o + r, o + j) = (plus[o + r] - minus[o + r]) / (2 * EPS);
+      for (int r = 0; r < nd; r++) posPos(o + r, o + j) = (plus[o + r] - minus[o + r]) / (2 * EPS);
       EPS = 1e-7;
       pert = va;
       pert[o + j] += EPS;
@@ -533,7 +550,7 @@ inline void posJacobians(const Model& m, const s_t* q, const s_t* v, s_t dt, Mat
       pert = va;
       pert[o + j] -= EPS;
       integratePositions(m, q, pert.data(), dt, minus.data());
-      for (int r = 0; r < 6; r++) velPos(o + r, o + j) = (plus[o + r] - minus[o + r]) / (2 * EPS);
+      for (int r = 0; r < nd; r++) velPos(o + r, o + j) = (plus[o + r] - minus[o + r]) / (2 * EPS);
     }
   }
 }
