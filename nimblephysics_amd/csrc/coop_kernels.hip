@@ -644,7 +644,15 @@ __global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* 
   if (ln < mdl.nb) {
     const DevBody& bd = bodies[ln];
     const int o = bd.dofOff;
-    if (bd.jtype != JT_FREE) {
+    if (bd.jtype == JT_BALL) {                          // BallJoint.cpp:351-408: the 3 x 3 blocks of the SO(3) integration
+      const int d0 = o - bd.ballComp, cmp = bd.ballComp;
+      V3 posr, velw;
+      so3IntegrationVjp(mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b]),
+                        mk3(v[(int64_t)(d0 + 0) * B + b], v[(int64_t)(d0 + 1) * B + b], v[(int64_t)(d0 + 2) * B + b]), mdl.dt,
+                        mk3(gnext[(int64_t)(d0 + 0) * B + b], gnext[(int64_t)(d0 + 1) * B + b], gnext[(int64_t)(d0 + 2) * B + b]), posr, velw);
+      yq[o] = cmp == 0 ? posr.x : (cmp == 1 ? posr.y : posr.z);
+      yv[o] = cmp == 0 ? velw.x : (cmp == 1 ? velw.y : velw.z);
+    } else if (bd.jtype != JT_FREE) {
       const double g = gnext[(int64_t)o * B + b];
       yq[o] = g; yv[o] = mdl.dt * g;
     } else {

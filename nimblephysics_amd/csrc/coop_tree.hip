@@ -473,11 +473,8 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
     const V3 r = mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b]);
     const V3 w = mk3(v[(int64_t)(d0 + 0) * B + b], v[(int64_t)(d0 + 1) * B + b], v[(int64_t)(d0 + 2) * B + b]);
     const V3 grn = mk3(gqn[(int64_t)(d0 + 0) * B + b], gqn[(int64_t)(d0 + 1) * B + b], gqn[(int64_t)(d0 + 2) * B + b]);
-    // VJP of q' = logMap(R(q) R(w dt))  (exact reverse mode of BallJoint.cpp:333-349; the reference finite-differences it, :351-408)
-    const M3 R = expMapRot(r), E = expMapRot(c.dt * w);
-    const M3 Rnb = logMap_vjp(mul(R, E), grn);
-    const V3 posr = expMapRot_vjp(r, mulABt(Rnb, E));
-    const V3 velw = c.dt * expMapRot_vjp(c.dt * w, mulAtB(R, Rnb));
+    V3 posr, velw;
+    so3IntegrationVjp(r, w, c.dt, grn, posr, velw);
     pp[0] = cmp == 0 ? posr.x : (cmp == 1 ? posr.y : posr.z);
     vp[0] = cmp == 0 ? velw.x : (cmp == 1 ? velw.y : velw.z);
     // v' = v + dt (qdd_chain + delta(w)),  delta = (wy wz, -wx wz, wx wy)

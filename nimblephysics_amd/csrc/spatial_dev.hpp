@@ -328,4 +328,13 @@ DEV V3 solve3(const M3& A, V3 b) {  // Cramer
   return mk3(id * (c00 * b.x + c10 * b.y + c20 * b.z), id * (c01 * b.x + c11 * b.y + c21 * b.z), id * (c02 * b.x + c12 * b.y + c22 * b.z));
 }
 
+// VJP of the ball joint's position integration q' = logMap(R(q) R(w dt)) (BallJoint.cpp:333-349; the reference finite-differences it,
+// :351-408): posPos^T g and velPos^T g of the 3 x 3 block.
+DEV void so3IntegrationVjp(V3 q, V3 w, double dt, V3 g, V3& posT, V3& velT) {
+  const M3 R = expMapRot(q), E = expMapRot(dt * w);
+  const M3 Rnb = logMap_vjp(mul(R, E), g);
+  posT = expMapRot_vjp(q, mulABt(Rnb, E));
+  velT = dt * expMapRot_vjp(dt * w, mulAtB(R, Rnb));
+}
+
 }  // namespace nbl

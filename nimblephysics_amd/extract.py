@@ -29,7 +29,7 @@ import numpy as np
 
 from .model import BodySpec, BoxSpec, ModelDescription
 
-_JOINT_TYPES = {"RevoluteJoint": "revolute", "PrismaticJoint": "prismatic", "FreeJoint": "free", "WeldJoint": "weld"}
+_JOINT_TYPES = {"RevoluteJoint": "revolute", "PrismaticJoint": "prismatic", "FreeJoint": "free", "WeldJoint": "weld", "BallJoint": "ball"}
 _COMPOUND_TYPES = ("EulerJoint", "UniversalJoint", "TranslationalJoint", "TranslationalJoint2D", "PlanarJoint")
 _UNIT = {"x": (1.0, 0.0, 0.0), "y": (0.0, 1.0, 0.0), "z": (0.0, 0.0, 1.0)}
 
@@ -117,6 +117,8 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
                     kw = per_dof()
                 elif jtype == "free":
                     kw = {k_: v for k_, v in per_dof().items() if k_ in ("damping", "spring", "rest")}
+                elif jtype == "ball":
+                    kw = per_dof()
             m = inertia_of[(si, bi)]
             bodies.append(BodySpec(b.getName(), pidx, jtype, j.getName(), axis=axis,
                                    T_pj=_mat4(j.getTransformFromParentBodyNode()), T_cj=_mat4(j.getTransformFromChildBodyNode()),

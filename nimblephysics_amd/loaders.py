@@ -322,8 +322,46 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8):
                     jtype = "weld"
                 elif jt == "free":
                     jtype = "free"
+                elif jt == "ball":
+                    jtype = "ball"              # readBallJoint (:2226-2256): init_pos / init_vel (states are the caller's here) + <dof> elements
                 else:
                     raise ValueError(f"{j.get('name')}: joint type {jt} outside scope")
+                # <dof local_index="i"> elements (readAllDegreesOfFreedom / readDegreeOfFreedom, :1713-1866) are read last and override the
+                # per-axis values: limits as attributes of <position> / <velocity> / <force>, damping / spring as child elements
+                ndofs = {"weld": 0, "free": 6, "ball": 3, "universal": 2, "translational": 3, "translational2d": 2, "planar": 3}.get(
+                    jtype, 3 if jtype.startswith("euler_") else 1)
+                dofs = j.findall("dof")
+                if dofs and ndofs > 0:
+                    inf = float("inf")
+                    dflt = {"damping": 0.0, "spring": 0.0, "rest": 0.0, "pos_lo": -inf, "pos_hi": inf, "vel_lo": -inf, "vel_hi": inf,
+                            "force_lo": -inf, "force_hi": inf}
+                    P = {key: list(kw.get(key, ())) or [dflt[key]] * ndofs for key in dflt}
+                    for de in dofs:
+                        li = de.get("local_index")
+                        if li is None:
+                            if ndofs > 1:
+                                continue                                  # the reference reports an error and skips the element
+                            li = 0
+                        li = int(li)
+                        if li >= ndofs:
+                            continue
+                        for tag, lo, hi in (("position", "pos_lo", "pos_hi"), ("velocity", "vel_lo", "vel_hi"), ("force", "force_lo", "force_hi")):
+                            el = de.find(tag)
+                            if el is not None:
+                                if el.get("lower") is not None:
+                                    P[lo][li] = float(el.get("lower"))
+                                if el.get("upper") is not None:
+                                    P[hi][li] = float(el.get("upper"))
+                        for tag, key in (("damping", "damping"), ("spring_rest_position", "rest"), ("spring_stiffness", "spring")):
+                            if de.find(tag) is not None:
+                                P[key][li] = float(de.find(tag).text)
+                        if de.find("friction") is not None and float(de.find("friction").text) != 0.0:
+                            raise ValueError(f"{j.get('name')}: joint Coulomb friction is outside the hot-path scope")
+                    for key, vals in P.items():
+                        if any(x != dflt[key] for x in vals):
+                            kw[key] = tuple(vals)
+                        else:
+                            kw.pop(key, None)
                 mass, com, I6 = inertial(bel[cn])
                 base = len(bodies)
                 bodies.append(BodySpec(cn, -1 if pn == "world" else index[pn], jtype, j.get("name"), axis=axis, T_pj=T_pj, T_cj=c2j,

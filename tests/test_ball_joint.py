@@ -30,7 +30,8 @@ def ball_model(seed=0, free_root=True, ground=False, properties=True):
         if properties and jt == "ball":
             extra = dict(damping=tuple(rng.uniform(0.1, 1.0, nd)), spring=tuple(rng.uniform(0.5, 3.0, nd)), rest=tuple(rng.normal(0, 0.1, nd)))
         root = parent < 0 and jt == "free"
-        return na.BodySpec(name, parent, jt, name + "_joint", axis=tuple(np.eye(3)[int(rng.integers(0, 3))]),
+        ax = tuple(np.eye(3)[int(rng.integers(0, 3))])
+        return na.BodySpec(name, parent, jt, name + "_joint", axis=ax if jt == "revolute" else (0.0, 0.0, 1.0),
                            T_pj=np.eye(4) if root else _T(rng, 0.25), T_cj=np.eye(4) if root else _T(rng, 0.1),
                            mass=float(rng.uniform(0.5, 2.0)), com=tuple(rng.normal(0, 0.04, 3)),
                            inertia=(I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]), **extra, **kw)

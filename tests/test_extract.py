@@ -32,14 +32,14 @@ class _ShapeNode:
 class _Joint:
     TYPES = {"revolute": "RevoluteJoint", "prismatic": "PrismaticJoint", "free": "FreeJoint", "weld": "WeldJoint",
              "universal": "UniversalJoint", "translational": "TranslationalJoint", "translational2d": "TranslationalJoint2D",
-             "planar": "PlanarJoint"}
+             "planar": "PlanarJoint", "ball": "BallJoint"}
 
     def __init__(self, b): self._b = b
     def getType(self): return "EulerJoint" if self._b.joint_type.startswith("euler_") else self.TYPES[self._b.joint_type]
     def getName(self): return self._b.joint_name
     def getNumDofs(self):
         from nimblephysics_amd.model import COMPOUND_JOINTS
-        return COMPOUND_JOINTS.get(self._b.joint_type, {"free": 6, "weld": 0}.get(self._b.joint_type, 1))
+        return COMPOUND_JOINTS.get(self._b.joint_type, {"free": 6, "weld": 0, "ball": 3}.get(self._b.joint_type, 1))
     # the class-specific getters of the compound joints (python/_nimblephysics/dynamics/{Euler,Universal,Planar,TranslationalJoint2D}Joint.cpp)
     def getAxisOrder(self):
         import enum
@@ -139,7 +139,8 @@ def _same(a, b):
 
 
 @pytest.mark.parametrize("make", [lambda: na.cartpole(), lambda: na.single_pendulum(), lambda: na.box_stack(),
-                                  lambda: na.atlas("atlas20", ground=True), lambda: na.atlas("atlas33")])
+                                  lambda: na.atlas("atlas20", ground=True), lambda: na.atlas("atlas33"),
+                                  lambda: __import__("test_ball_joint").ball_model(0, True)])
 def test_extraction_round_trip(make):
     md = make()
     got = model_from_nimble_world(StandInWorld(md), name=md.name, max_contacts=md.max_contacts)
@@ -173,7 +174,7 @@ def test_extraction_keeps_spheres_friction_action_space_and_leaves_the_world_unt
 def test_unsupported_joint_types_raise():
     md = na.cartpole()
     w = StandInWorld(md)
-    _Joint.TYPES = dict(_Joint.TYPES, revolute="BallJoint")
+    _Joint.TYPES = dict(_Joint.TYPES, revolute="ScrewJoint")
     try:
         with pytest.raises(ValueError):
             model_from_nimble_world(w)

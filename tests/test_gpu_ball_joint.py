@@ -55,3 +55,61 @@ def test_ball_joints_in_contact_equal_the_oracle():
     assert np.array_equal(status & 1, rstatus & 1) and (status & 1).mean() > 0.25
     ok = ((status | rstatus) & 0x80) == 0
     assert (err[ok] > 1e-5).sum() == 0 and np.median(err[ok]) < TOL, (np.sort(err[ok])[-5:], (err[ok] > TOL).sum())
+
+
+def test_mass_gradients_use_the_callers_body_indices():
+    """The device model carries two extra massless bodies per ball joint; tuneMass / setMasses / the mass gradient keep the body indices of
+    the description (nbl_model's body map): dL/dmass against central differences of the oracle step, bodies before and after ball joints."""
+    from nimblephysics_amd.mass import WrtMassBodyNodeEntryType as T
+    from test_gpu_mass import _check
+    md = ball_model(6, True)
+    rng = np.random.default_rng(40)
+    n = md.num_dofs
+    s = np.concatenate([rng.normal(0, 0.5, (32, n)), rng.normal(0, 1.0, (32, n))], 1); a = rng.normal(0, 1, (32, len(md.action_map)))
+    _check(md, [(0, T.INERTIA_MASS), (1, T.INERTIA_FULL), (3, T.INERTIA_COM), (4, T.INERTIA_DIAGONAL)], s, a, 41, tol=5e-6)
+
+
+def test_rollout_through_ball_joints_equals_the_oracle_and_its_checkpointed_form():
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    from oracle import OracleWorld
+    md = ball_model(7, True, ground=True)
+    B, T = 32, 6
+    rng = np.random.default_rng(50)
+    n = md.num_dofs; k = len(md.action_map)
+    q = rng.normal(0, 0.4, (B, n)); q[:, 3] = 0; q[:, 5] = 0; q[:, 4] = rng.uniform(0.15, 0.4, B)
+    s0 = np.concatenate([q, rng.normal(0, 0.3, (B, n))], 1)
+    acts = rng.normal(0, 0.5, (B, T, k)); w = rng.normal(0, 1, (B, T + 1, 2 * n))
+    outs = []
+    for K in (0, 4):
+        world = na.World(md, device="cuda:0")
+        st = torch.tensor(s0, device="cuda:0", requires_grad=True); at = torch.tensor(acts, device="cuda:0", requires_grad=True)
+        ys = rollout(world, st, at, warm_start=False, checkpoint_every=K)
+        (ys * torch.tensor(w, device="cuda:0")).sum().backward()
+        outs.append((ys.detach().cpu().numpy(), st.grad.cpu().numpy(), at.grad.cpu().numpy()))
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x, y)
+    ow = OracleWorld(md)
+    worst = 0.0
+    for b in range(B):
+        worlds = [OracleWorld(md) for _ in range(T)]
+        xs = [s0[b]]
+        for t in range(T):
+            xs.append(worlds[t].step(xs[-1], acts[b, t]))
+        g = w[b, T].copy(); ga = np.zeros((T, k))
+        for t in reversed(range(T)):
+            g, ga[t] = worlds[t].backprop(g)
+            g = g + w[b, t]
+        sc = lambda r: max(np.abs(r).max(), 1e-30)
+        worst = max(worst, np.abs(outs[0][0][b] - np.array(xs)).max() / sc(np.array(xs)), np.abs(outs[0][1][b] - g).max() / sc(g),
+                    np.abs(outs[0][2][b] - ga).max() / sc(ga))
+    assert worst < 1e-6, worst
+
+
+def test_c_abi_rejects_ball_models_the_wavefront_kernels_cannot_hold(monkeypatch):
+    import nimblephysics_amd as na
+    from nimblephysics_amd._lib import NimbleAmdError
+    monkeypatch.setenv("NBL_COOP_TREE", "0")
+    with pytest.raises(NimbleAmdError):
+        na.World(ball_model(8, True), device="cuda:0")

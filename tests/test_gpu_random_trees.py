@@ -22,7 +22,7 @@ def _T(rng, scale):
     return T
 
 
-def random_tree(rng, nb, shape, free_root, welds=0, colliders=0, spheres=False):
+def random_tree(rng, nb, shape, free_root, welds=0, colliders=0, spheres=False, balls=0.0):
     import nimblephysics_amd as na
     bodies = []
     for i in range(nb):
@@ -37,8 +37,10 @@ def random_tree(rng, nb, shape, free_root, welds=0, colliders=0, spheres=False):
         jt = "free" if (i == 0 and free_root) else ("prismatic" if rng.random() < 0.25 else "revolute")
         if welds and i > 0 and rng.random() < welds:
             jt = "weld"
+        elif balls and i > 0 and rng.random() < balls:
+            jt = "ball"
         axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
-        nd = {"free": 6, "weld": 0}.get(jt, 1)
+        nd = {"free": 6, "weld": 0, "ball": 3}.get(jt, 1)
         A = rng.normal(size=(3, 3)); I = A @ A.T * 0.05 + 0.05 * np.eye(3)
         bodies.append(na.BodySpec(
             f"b{i}", parent, jt, f"j{i}", axis=tuple(axis),

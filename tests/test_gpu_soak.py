@@ -42,3 +42,14 @@ def test_random_worlds_with_several_skeletons_all_worlds_vs_oracle():
     print(tot)
     assert tot["MISMATCH"] == 0, tot
     assert tot["contact"] > 0.2 * tot["worlds"] and tot["cascade"] > 0.1 * tot["worlds"], tot
+
+
+def test_random_models_with_ball_joints_all_worlds_vs_oracle():
+    """40 % of the joints below the free root are ball joints (three device bodies each + the closed-form acceleration term; the oracle
+    runs the reference's 3-DOF joint), colliders on random bodies."""
+    import soak_parity
+    tot = soak_parity.run(9000, 40, 256, verbose=False, balls=True)
+    print(tot)
+    assert tot["MISMATCH"] == 0, tot
+    assert tot["contact"] > 0.1 * tot["worlds"], tot
+    assert tot["gt1e-7"] <= 0.002 * tot["worlds"], tot

@@ -158,9 +158,18 @@ def test_skel_subset_loader_builds_the_expected_model(tmp_path):
     only_arm = na.load_skel(str(f), skeletons=["arm"])
     assert [b.name for b in only_arm.bodies] == ["b1", "b2"] and len(only_arm.boxes) == 2
     bad = tmp_path / "bad.skel"
-    bad.write_text(SKEL.replace('type="prismatic"', 'type="ball"'))
+    bad.write_text(SKEL.replace('type="prismatic"', 'type="screw"'))
     with pytest.raises(ValueError):
         na.load_skel(str(bad))
+    ball = tmp_path / "ball.skel"           # a ball joint with <dof> elements (readBallJoint + readAllDegreesOfFreedom)
+    ball.write_text(SKEL.replace('type="prismatic"', 'type="ball"').replace(
+        "<child>b1</child>", '<child>b1</child><dof local_index="1"><position lower="-1" upper="2"/><damping>0.3</damping></dof>'
+                             '<dof local_index="2"><force lower="-5" upper="5"/><spring_stiffness>4</spring_stiffness></dof>'))
+    mb = na.load_skel(str(ball))
+    bb = [b for b in mb.bodies if b.name == "b1"][0]
+    assert bb.joint_type == "ball" and mb.num_dofs == md.num_dofs + 2
+    assert bb.pos_lo == (-np.inf, -1.0, -np.inf) and bb.pos_hi == (np.inf, 2.0, np.inf) and bb.damping == (0.0, 0.3, 0.0)
+    assert bb.force_lo == (-np.inf, -np.inf, -5.0) and bb.spring == (0.0, 0.0, 4.0)
 
 
 def test_skel_model_steps_like_the_hand_built_one(tmp_path):

@@ -2,7 +2,8 @@
 frictionless, restitution, penetration correction on/off) dropped on the ground; every world's next state and gradients are
 compared with the CPU oracle.  A world above 1e-5 must be one where the oracle itself flips under 1-ulp input perturbations
 (the criterion of tests/test_gpu_contact.py), otherwise it is reported as a MISMATCH.
-  usage: python tools/soak_parity.py [first seed] [count] [B] [big|multi]      (big: 8-21 bodies, 3-7 colliders; multi: 2-3 separate skeletons)"""
+  usage: python tools/soak_parity.py [first seed] [count] [B] [big|multi|balls]      (big: 8-21 bodies, 3-7 colliders; multi: 2-3 separate skeletons;
+  balls: 40 % of the joints below the root are ball joints)"""
 import os
 import sys
 
@@ -19,49 +20,60 @@ from test_gpu_random_trees import random_tree  # noqa: E402
 
 
 
-def run(first=0, count=20, B=256, verbose=True, big=False, multi=False):
+def make_case(seed, B=256, big=False, multi=False, balls=False):
+    """The model, states, actions and cotangents of one soak seed (None when the model has more than 40 DOFs)."""
+    rng = np.random.default_rng(50000 + seed)
+    nb = int(rng.integers(8, 22)) if big else int(rng.integers(1, 10))
+    if multi:
+        # two or three separate skeletons (free roots), each a small random tree with its own colliders: several constrained groups
+        parts = [random_tree(rng, int(rng.integers(1, 4)), rng.choice(["chain", "star", "random"]), True, colliders=int(rng.integers(1, 3)),
+                             spheres=bool(rng.random() < 0.4)) for _ in range(int(rng.integers(2, 4)))]
+        bodies, boxes = [], [parts[0].boxes[0]]
+        for k_, pm in enumerate(parts):
+            off = len(bodies)
+            for b_ in pm.bodies:
+                b_.parent = b_.parent if b_.parent < 0 else b_.parent + off
+                b_.name = f"s{k_}_{b_.name}"; b_.joint_name = f"s{k_}_{b_.joint_name}"
+                bodies.append(b_)
+            for bx in pm.boxes[1:]:
+                bx.body += off
+                boxes.append(bx)
+        md = na.ModelDescription("multi", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=8)
+        nb = len(bodies)
+    else:
+        md = random_tree(rng, nb, rng.choice(["chain", "star", "random"]), True, welds=0.2 if rng.random() < 0.3 else 0,
+                         colliders=int(rng.integers(3, 8)) if big else int(rng.integers(1, 4)), spheres=bool(rng.random() < 0.4),
+                         balls=0.4 if balls else 0.0)
+    for bx in md.boxes:
+        r = rng.random()
+        bx.mu = 0.0 if r < 0.15 else (float(rng.uniform(0.05, 1.5)))
+        bx.restitution = float(rng.uniform(0.3, 1.0)) if rng.random() < 0.3 else 0.0
+    md.penetration_correction = bool(rng.random() < 0.3)
+    n = md.num_dofs
+    if n > 40:
+        return None
+    q = rng.normal(0, 0.25, (B, n)); q[:, 3] = rng.normal(0, 0.3, B); q[:, 5] = rng.normal(0, 0.3, B)
+    q[:, 4] = rng.uniform(0.02, 0.5, B)
+    if multi:        # every free root: its own spot on the ground (x spread so that the skeletons rarely touch each other) and height
+        off = 0
+        for k_, bd in enumerate(md.bodies):
+            if bd.joint_type == "free":
+                q[:, off + 3] = 1.5 * (k_ % 7) - 2.0 + rng.normal(0, 0.2, B); q[:, off + 5] = rng.normal(0, 0.3, B)
+                q[:, off + 4] = rng.uniform(0.02, 0.4, B)
+            off += {"free": 6, "weld": 0, "ball": 3}.get(bd.joint_type, 1)
+    v = rng.normal(0, rng.choice([0.05, 0.5, 2.0]), (B, n))
+    s = np.concatenate([q, v], 1); a = rng.normal(0, 0.5, (B, len(md.action_map))); g = rng.normal(0, 1, s.shape)
+
+    return md, s, a, g
+
+
+def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False):
   tot = {"worlds": 0, "contact": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "MISMATCH": 0}
   for seed in range(first, first + count):
-      rng = np.random.default_rng(50000 + seed)
-      nb = int(rng.integers(8, 22)) if big else int(rng.integers(1, 10))
-      if multi:
-          # two or three separate skeletons (free roots), each a small random tree with its own colliders: several constrained groups
-          parts = [random_tree(rng, int(rng.integers(1, 4)), rng.choice(["chain", "star", "random"]), True, colliders=int(rng.integers(1, 3)),
-                               spheres=bool(rng.random() < 0.4)) for _ in range(int(rng.integers(2, 4)))]
-          bodies, boxes = [], [parts[0].boxes[0]]
-          for k_, pm in enumerate(parts):
-              off = len(bodies)
-              for b_ in pm.bodies:
-                  b_.parent = b_.parent if b_.parent < 0 else b_.parent + off
-                  b_.name = f"s{k_}_{b_.name}"; b_.joint_name = f"s{k_}_{b_.joint_name}"
-                  bodies.append(b_)
-              for bx in pm.boxes[1:]:
-                  bx.body += off
-                  boxes.append(bx)
-          md = na.ModelDescription("multi", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=8)
-          nb = len(bodies)
-      else:
-          md = random_tree(rng, nb, rng.choice(["chain", "star", "random"]), True, welds=0.2 if rng.random() < 0.3 else 0,
-                           colliders=int(rng.integers(3, 8)) if big else int(rng.integers(1, 4)), spheres=bool(rng.random() < 0.4))
-      for bx in md.boxes:
-          r = rng.random()
-          bx.mu = 0.0 if r < 0.15 else (float(rng.uniform(0.05, 1.5)))
-          bx.restitution = float(rng.uniform(0.3, 1.0)) if rng.random() < 0.3 else 0.0
-      md.penetration_correction = bool(rng.random() < 0.3)
-      n = md.num_dofs
-      if n > 40:
+      case = make_case(seed, B, big, multi, balls)
+      if case is None:
           continue
-      q = rng.normal(0, 0.25, (B, n)); q[:, 3] = rng.normal(0, 0.3, B); q[:, 5] = rng.normal(0, 0.3, B)
-      q[:, 4] = rng.uniform(0.02, 0.5, B)
-      if multi:        # every free root: its own spot on the ground (x spread so that the skeletons rarely touch each other) and height
-          off = 0
-          for k_, bd in enumerate(md.bodies):
-              if bd.joint_type == "free":
-                  q[:, off + 3] = 1.5 * (k_ % 7) - 2.0 + rng.normal(0, 0.2, B); q[:, off + 5] = rng.normal(0, 0.3, B)
-                  q[:, off + 4] = rng.uniform(0.02, 0.4, B)
-              off += {"free": 6, "weld": 0}.get(bd.joint_type, 1)
-      v = rng.normal(0, rng.choice([0.05, 0.5, 2.0]), (B, n))
-      s = np.concatenate([q, v], 1); a = rng.normal(0, 0.5, (B, len(md.action_map))); g = rng.normal(0, 1, s.shape)
+      md, s, a, g = case
       world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
       st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
       out = timestep(world, st, at)
@@ -91,11 +103,12 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False):
       tot["worlds"] += B; tot["contact"] += int(c.sum()); tot["cascade"] += int((c & ((status & 2) == 0)).sum())
       tot["gt1e-7"] += int((err > 1e-7).sum()); tot["gt1e-5"] += len(bad); tot["unstable"] += unstable; tot["MISMATCH"] += mismatch
       if verbose:
-          print(f"seed {seed}: nb {nb} n {n} colliders {len(md.boxes) - 1} contact {c.mean():.2f} cascade {(c & ((status & 2) == 0)).mean():.2f} "
+          print(f"seed {seed}: nb {len(md.bodies)} n {md.num_dofs} colliders {len(md.boxes) - 1} contact {c.mean():.2f} cascade {(c & ((status & 2) == 0)).mean():.2f} "
               f"max err {err.max():.1e} >1e-7 {(err > 1e-7).sum()} >1e-5 {len(bad)} (unstable {unstable}, mismatch {mismatch})", flush=True)
   return tot
 
 
 if __name__ == "__main__":
     print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 20,
-              int(sys.argv[3]) if len(sys.argv) > 3 else 256, big=len(sys.argv) > 4 and sys.argv[4] == "big", multi=len(sys.argv) > 4 and sys.argv[4] == "multi"))
+              int(sys.argv[3]) if len(sys.argv) > 3 else 256, big=len(sys.argv) > 4 and sys.argv[4] == "big", multi=len(sys.argv) > 4 and sys.argv[4] == "multi",
+              balls=len(sys.argv) > 4 and sys.argv[4] == "balls"))
