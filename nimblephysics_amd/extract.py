@@ -75,7 +75,7 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
             j = b.getParentJoint()
             jt = j.getType()
             if jt not in _JOINT_TYPES and jt not in _COMPOUND_TYPES:
-                raise ValueError(f"{b.getName()}: joint type {jt} outside the hot-path scope (revolute, prismatic, free, weld, "
+                raise ValueError(f"{b.getName()}: joint type {jt} outside the hot-path scope (revolute, prismatic, free, ball, weld, "
                                  "Euler, universal, translational, translational-2D, planar)")
             parent = b.getParentBodyNode()
             pidx = -1 if parent is None else index[parent.getName()]

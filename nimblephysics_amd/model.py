@@ -214,7 +214,7 @@ class ModelDescription:
             if not (-1 <= b.parent < i):
                 raise ValueError(f"body {i} ({b.name}): parent {b.parent} must precede it")
             if b.joint_type not in _abi.JOINT_NAMES:
-                raise ValueError(f"unsupported joint type {b.joint_type!r} (hot-path scope: revolute, prismatic, free, weld)")
+                raise ValueError(f"unsupported joint type {b.joint_type!r} (hot-path scope: revolute, prismatic, free, ball, weld and the compound joints)")
 
     # ---- sizes ------------------------------------------------------------------------------
     def joint_ndof(self, i: int) -> int:

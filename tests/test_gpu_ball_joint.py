@@ -113,3 +113,17 @@ def test_c_abi_rejects_ball_models_the_wavefront_kernels_cannot_hold(monkeypatch
     monkeypatch.setenv("NBL_COOP_TREE", "0")
     with pytest.raises(NimbleAmdError):
         na.World(ball_model(8, True), device="cuda:0")
+
+
+@pytest.mark.parametrize("name", ["serial_chain_ball_joint", "tree_structure_ball_joint"])
+def test_the_references_ball_joint_test_worlds_equal_the_oracle(name):
+    """data/skel/test/serial_chain_ball_joint.skel (10 ball joints in a row, 30 DOFs) and tree_structure_ball_joint.skel (13 ball joints, 39
+    DOFs), transcribed by tools/urdf_to_model.py (tests/test_loaders.py checks the transcription against the reference's files)."""
+    import json
+    import os
+    import nimblephysics_amd as na
+    path = os.path.join(os.path.dirname(na.__file__), "data", name + ".json")
+    md = na.ModelDescription.from_json(json.load(open(path)))
+    assert all(b.joint_type == "ball" for b in md.bodies)
+    err, _, _ = _compare(md, 64, 60, vel=2.0)
+    assert err.max() < TOL, err.max()

@@ -201,6 +201,10 @@ def test_committed_cfg1_cfg4_descriptions_are_reproducible_from_the_reference_sk
     data = os.path.join(os.path.dirname(na.__file__), "data")
     assert json.loads(json.dumps(pend.to_json())) == json.load(open(os.path.join(data, "single_pendulum.json")))
     assert json.loads(json.dumps(stack.to_json())) == json.load(open(os.path.join(data, "box_stack.json")))
+    from urdf_to_model import ball_joint_models
+    for nm, mdl in ball_joint_models().items():
+        assert json.loads(json.dumps(mdl.to_json())) == json.load(open(os.path.join(data, nm + ".json"))), nm
+        assert all(b.joint_type == "ball" for b in mdl.bodies)
     # what the files say (single_pendulum.skel / box_stacking.skel)
     p = na.single_pendulum()
     assert p.num_dofs == 1 and p.bodies[0].mass == 5.0 and tuple(p.bodies[0].inertia) == (1.0, 2.0, 3.0, 0.0, 0.0, 0.0) and tuple(p.bodies[0].damping) == (10.0,)

@@ -50,6 +50,7 @@ def main():
         "single_pendulum": skel_models()[0],
         "box_stack": skel_models()[1],
     }
+    skel.update(ball_joint_models())
     for name, mdl in skel.items():
         with open(os.path.join(out_dir, name + ".json"), "w") as f:
             json.dump(mdl.to_json(), f, indent=1)
@@ -69,6 +70,13 @@ def skel_models():
     for b, jn in zip(stack.bodies, ("ground_joint", "box1_joint", "box2_joint")):
         b.joint_name = jn
     return pend, stack
+
+
+def ball_joint_models():
+    """The reference's ball-joint test worlds (data/skel/test, used by its dynamics / joint unit tests): a serial chain of 10 ball joints
+    and a 13-body tree of ball joints."""
+    return {nm: load_skel(os.path.join(REF, "data/skel/test", nm + ".skel"), nm, max_contacts=0)
+            for nm in ("serial_chain_ball_joint", "tree_structure_ball_joint")}
 
 
 if __name__ == "__main__":
