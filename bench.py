@@ -294,7 +294,8 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                traffic = tj.get(prof_key, tj.get(args.workload, {})).get(dom)
+                per_kernel = tj.get(prof_key, tj.get(args.workload, {}))
+                traffic = next((v for kname, v in per_kernel.items() if kname.split("<")[0] == dom), None)   # template suffixes: k<false>
             except Exception:
                 traffic = None
         # fp64 roofline: flop COUNTED by the SQ instruction counters (tools/profile.sh pass `fp64`, aggregated by
