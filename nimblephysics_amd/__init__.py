@@ -7,7 +7,8 @@ from .model import (BodySpec, BoxSpec, ModelDescription, SphereSpec, atlas, box_
                     make_transform, single_pendulum)
 
 __all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
-           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep"]
+           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep", "neural", "forwardPass", "BackpropSnapshot",
+           "LossGradient", "LossGradientHighLevelAPI"]
 
 
 def __getattr__(name):
@@ -23,6 +24,10 @@ def __getattr__(name):
     if name in ("load_urdf", "load_skel", "with_ground"):
         from . import loaders as _l
         return getattr(_l, name)
+    if name in ("neural", "forwardPass", "BackpropSnapshot", "LossGradient", "LossGradientHighLevelAPI"):
+        import importlib
+        mod = importlib.import_module(".neural", __name__)
+        return mod if name == "neural" else getattr(mod, name)
     # torch-dependent pieces are imported lazily so that model building works without a GPU stack
     if name in ("World",):
         from .world import World

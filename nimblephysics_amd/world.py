@@ -177,6 +177,7 @@ class World:
 
     # ---- state / action API ---------------------------------------------------------------------
     def setState(self, state: torch.Tensor):
+        self._one_d = state.dim() == 1                  # one world given as the reference's 1-D vector (neural.forwardPass answers alike)
         self._state = self.to_soa(self._prep(state, 2 * self.n, "setState"))
 
     def getState(self) -> torch.Tensor:
