@@ -732,8 +732,9 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
                                                           const double* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) double ldsRows[];
   const int nb = mdl.nb;
-  double* Fs = ldsRows;
-  double* Sw = Fs + 6 * MAX_ROWS;
+  double* Fs = ldsRows;                            // the row's wrench about the frame origin of body A's tree ...
+  double* FsB = Fs + 6 * MAX_ROWS;                 // ... and of body B's tree
+  double* Sw = FsB + 6 * MAX_ROWS;
   double* AISw = Sw + 6 * nb;
   double* Vw = AISw + 6 * nb;
   double* acc = Vw + 6 * nb;
@@ -760,7 +761,13 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   // topology of body `ln` in the lane's registers: the serial body loops below fetch it with v_readlane (no memory access)
   const int myParent = ln < nb ? bdL.parent : -1, myJtype = ln < nb ? bdL.jtype : 0;
   const int myDofOff = ln < nb ? bdL.dofOff : 0, myFreeIdx = ln < nb ? bdL.freeIdx : -1;
-  const T12 TWl = ldTAt(c, bl, WS_TW);
+  // The "world frame" of the spatial quantities has its origin at the root of each body's tree instead of the world's (one pure translation
+  // per tree: within a tree one wrench still serves every body; a row between two trees has one wrench per side).  Moments about a far
+  // origin would blur A's singular structure with the square of the distance and flip the rank decisions of the solver.
+  const int myRoot = ln < nb ? bdL.root : 0;
+  const V3 myOrigin = ldTAt(c, myRoot, WS_TW).p;
+  T12 TWl = ldTAt(c, bl, WS_TW);
+  TWl.p = TWl.p - myOrigin;
   const V6 vtwL = ldV6(c, bl, WS_VTW), aisL = ldV6(c, bl, WS_AIS), SL = cV6(bdL.S);
   const double psiMine = wsAt(c, bl, WS_PSI);
   const int myBoxBody = cm->boxes[ln < MAX_BOXES ? ln : 0].body;      // collider -> body and body -> ancestor mask tables,
@@ -781,7 +788,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
       fm &= fm - 1;
       if (ln < 54) {
         const int slot = ln < 21 ? WS_PSI + ln : (ln < 42 ? WS_AI + (ln - 21) : WS_TW + (ln - 42));
-        freeL[54 * w.bcastI(myFreeIdx, fb) + ln] = wsAt(c, fb, slot);
+        // a free joint is the root of its tree: in the frame of its own origin its world transform has no translation
+        freeL[54 * w.bcastI(myFreeIdx, fb) + ln] = ln >= 51 ? 0.0 : wsAt(c, fb, slot);
       }
     }
   }
@@ -810,14 +818,17 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   const double muRow = fmin(cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].mu, cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].mu);
   const V3 dirOn = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
   const V3 dir = (kk != 0 && !(muRow > 1e-3)) ? mk3(0.0, 0.0, 0.0) : dirOn;
-  const V6 F = mk6(cross(p, dir), dir);   // world wrench of a unit impulse along dir at p (on A; -F on B)
   const int bA = w.shflI(myBoxBody, bxA), bB = w.shflI(myBoxBody, bxB);
+  // wrench of a unit impulse along dir at p (on A; minus it on B), about the origin of A's tree and about the origin of B's
+  const V3 oA = mk3(w.shfl(myOrigin.x, bA < 0 ? 0 : bA), w.shfl(myOrigin.y, bA < 0 ? 0 : bA), w.shfl(myOrigin.z, bA < 0 ? 0 : bA));
+  const V3 oB = mk3(w.shfl(myOrigin.x, bB < 0 ? 0 : bB), w.shfl(myOrigin.y, bB < 0 ? 0 : bB), w.shfl(myOrigin.z, bB < 0 ? 0 : bB));
+  const V6 F = mk6(cross(p - oA, dir), dir), FB = mk6(cross(p - oB, dir), dir);
   const int ancLoA = w.shflI((int)(uint32_t)myAnc, bA), ancHiA = w.shflI((int)(uint32_t)(myAnc >> 32), bA);
   const int ancLoB = w.shflI((int)(uint32_t)myAnc, bB), ancHiB = w.shflI((int)(uint32_t)(myAnc >> 32), bB);
   const uint64_t mA = bA >= 0 ? ((uint64_t)(uint32_t)ancHiA << 32) | (uint32_t)ancLoA : 0ull;
   const uint64_t mB = bB >= 0 ? ((uint64_t)(uint32_t)ancHiB << 32) | (uint32_t)ancLoB : 0ull;
   if (on) {
-    st6(Fs + 6 * row, F);
+    st6(Fs + 6 * row, F); st6(FsB + 6 * row, FB);
     if (kk == 0) { cbody[ci] = bA; cbody[MAX_CONTACTS + ci] = bB; }
   }
   w.sync();
@@ -826,7 +837,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
     // b = -J^T V: relative velocity of the contact point pair along dir (getRelVelocity)
     double rel = 0;
     if (bA >= 0) rel -= dot(F, ld6(Vw + 6 * bA));
-    if (bB >= 0) rel += dot(F, ld6(Vw + 6 * bB));
+    if (bB >= 0) rel += dot(FB, ld6(Vw + 6 * bB));
     if (kk == 0) {
       // "Bouncing" (ContactConstraint.cpp:393-441 / 470-512).  A: penetration correction (off by default, ConstraintSolver.cpp:69):
       // (depth - allowance) * ERP / dt, capped (DART_ERROR_ALLOWANCE 0, DART_ERP 0.01, DART_MAX_ERV 1e-3).  B: restitution, e = e_A e_B:
@@ -858,10 +869,11 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
       const int jt = w.bcastI(myJtype, i), dofOff = w.bcastI(myDofOff, i);
       const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
       const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
-      if (jt != JT_FREE) dn[lay.aall + dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), F);
+      const V6 Fi = pb ? FB : F;                       // the wrench about the origin of body i's tree (pa && pb: mult = 0)
+      if (jt != JT_FREE) dn[lay.aall + dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), Fi);
       else {
         double v6[6];
-        toArr(dAdT(cT(bodies[i].Tcj), dAdT(cT(freeL + 54 * w.bcastI(myFreeIdx, i) + 42), F)), v6);
+        toArr(dAdT(cT(bodies[i].Tcj), dAdT(cT(freeL + 54 * w.bcastI(myFreeIdx, i) + 42), Fi)), v6);
         for (int e = 0; e < 6; e++) dn[lay.aall + (dofOff + e) * MAX_ROWS + row] = mult * v6[e];
       }
       for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
@@ -874,7 +886,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
       const int jt = w.bcastI(myJtype, i), par = w.bcastI(myParent, i);
       V6 Bi = ldAcc(i);
       if (i == bA) Bi = Bi - F;
-      if (i == bB) Bi = Bi + F;
+      if (i == bB) Bi = Bi + FB;
       stAcc(i, Bi);
       if (jt != JT_FREE && par >= 0) {
         const double uimp = -dot(ld6(Sw + 6 * i), Bi);
@@ -915,12 +927,10 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
     // row of A: relative-velocity response at every row of the contacts c2 >= ci, mirrored into the earlier rows
     for (int c2 = ci; c2 < nC; c2++) {
       const int b2A = cbody[c2], b2B = cbody[MAX_CONTACTS + c2];
-      V6 dV = zero6();
-      if (b2A >= 0) dV = dV + ldAcc(b2A);
-      if (b2B >= 0) dV = dV - ldAcc(b2B);
+      const V6 dVA = b2A >= 0 ? ldAcc(b2A) : zero6(), dVB = b2B >= 0 ? ldAcc(b2B) : zero6();
       for (int k2 = 0; k2 < 3; k2++) {
         const int col = 3 * c2 + k2;
-        const double val = dot(ld6(Fs + 6 * col), dV);
+        const double val = dot(ld6(Fs + 6 * col), dVA) - dot(ld6(FsB + 6 * col), dVB);
         dn[lay.A + row * MAX_ROWS + col] = val;
         if (c2 > ci) dn[lay.A + col * MAX_ROWS + row] = val;
       }
@@ -971,7 +981,12 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
   // ---- staging: world transforms of all bodies and the bodies of every contact (read many times below) ----
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   const int nC = m / 3;
-  for (int idx = ln; idx < nb * 12; idx += 64) TWs[idx] = wsAt(c, idx / 12, WS_TW + idx % 12);
+  // frame origin at body 0 (see k_contact_rows_coop): world transforms and every POSITION of the contact records are shifted
+  const V3 worldOrigin = mk3(wsAt(c, 0, WS_TW + 9), wsAt(c, 0, WS_TW + 10), wsAt(c, 0, WS_TW + 11));
+  for (int idx = ln; idx < nb * 12; idx += 64) {
+    const int e = idx % 12;
+    TWs[idx] = wsAt(c, idx / 12, WS_TW + e) - (e == 9 ? worldOrigin.x : (e == 10 ? worldOrigin.y : (e == 11 ? worldOrigin.z : 0.0)));
+  }
   if (ln < nC) {
     const int q0 = lay.contacts + ln * CR_SIZE;
     cbody[ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body;
@@ -1021,6 +1036,9 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
     for (int e = 0; e < 8; e++) { cf[e] = lws[(int64_t)(LB_COEF + row * 8 + e) * B + b]; any = any || cf[e] != 0.0; }
     if (any) {
       CR = loadContactRec(SV, lay, cm, ci);
+      CR.p = CR.p - worldOrigin;
+      if (CR.type >= CT_EDGE_EDGE) CR.eAP = CR.eAP - worldOrigin;                                        // edge A's point / the sphere centre (A's)
+      if (CR.type == CT_EDGE_EDGE || CR.type == CT_SPHERE_SPHERE) CR.eBP = CR.eBP - worldOrigin;          // edge B's point / sphere B's centre
       const TangentFrame TF_ = tangentFrameOf(CR.nrm);
       const V3 d = k == 0 ? CR.nrm : (k == 1 ? TF_.t1 : TF_.t2);
       Fw = mk6(cross(CR.p, d), d);

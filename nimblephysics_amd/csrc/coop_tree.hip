@@ -167,11 +167,19 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
   const V6 SdqB = on ? jointTwist(bd, v, B, b) : zero6();   // S dq in the body frame
   NBL_PHASE(2);
   // ---- sweep 1 (root -> leaf): world transforms and twists ----
+  // The "world frame" of every spatial quantity below has its origin at the ROOT of the lane's tree, not at the world's: moments about
+  // a far origin would cost digits with the SQUARE of the distance (inertias m p^2 against the body's own, which the joint projections
+  // must recover by cancellation; 1 km from the origin: 1e-7).  A pure translation of the frame, one per tree (trees do not exchange
+  // anything here): sums over bodies, twists passed down and wrenches passed up stay transform-free.  BodyNode::mWorldTransform itself
+  // is kept as it is (WS_TW).
+  waveFence();
+  const V3 worldOrigin = ldT(c, bd.root).p;
   T12 TW = T;
   V6 Vw = zero6(), SdqW = zero6();
   forBodiesDown(c, [&](int) {
     if (bd.parent >= 0) TW = mulT(ldTAt(c, bd.parent, WS_TW), T);
     stTAt(c, i, WS_TW, TW);                                  // BodyNode::mWorldTransform
+    TW.p = TW.p - worldOrigin;                               // from here on: the lane's body in the shifted frame
     SdqW = AdT(TW, SdqB);
     Vw = bd.parent >= 0 ? ldV6(c, bd.parent, WS_W) + SdqW : SdqW;
     stV6(c, i, WS_W, Vw);
@@ -313,7 +321,8 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_step
     const double* nv = next + (int64_t)mdl.n * B;
     const int i = c.lane;
     const bool on = i < c.nb;
-    const T12 TW = on ? ldTAt(c, i, WS_TW) : T12();
+    T12 TW = on ? ldTAt(c, i, WS_TW) : T12();
+    if (on) TW.p = TW.p - ldTAt(c, bodies[i].root, WS_TW).p;           // frame origin at the root of the tree (see abaSweepsWorld)
     V6 Vw = on ? AdT(TW, jointTwist(bodies[i], nv, B, b)) : zero6();   // own joint twist, world frame
     forBodiesDown(c, [&](int) {                                          // world twists are prefix sums down the tree
       if (bodies[i].parent >= 0) Vw = Vw + ldV6(c, bodies[i].parent, WS_W);
@@ -348,6 +357,7 @@ DEV WorldBody loadWorldBody(const CoopCtxT<PROF_BWD>& c) {
   wb.psi = 0.0;
   if (wb.on) {
     wb.TW = ldTAt(c, i, WS_TW);
+    wb.TW.p = wb.TW.p - ldTAt(c, bd.root, WS_TW).p;          // frame origin at the root of the tree (see abaSweepsWorld)
     wb.Vw = AdT(wb.TW, ldV6(c, i, WS_V));
     wb.Aw = AdT(wb.TW, ldV6(c, i, WS_A));
     if (!wb.isFree) { wb.Sw = AdT(wb.TW, cV6(bd.S)); wb.AISw = dAdInvT(wb.TW, ldV6(c, i, WS_AIS)); wb.psi = wsAt(c, i, WS_PSI); }

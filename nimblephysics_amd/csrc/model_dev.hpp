@@ -63,6 +63,7 @@ struct DevBody {
   double G[21];       // spatial inertia, packed symmetric
   int32_t level, rank; // depth in the tree, index among the children of the parent (coop tree kernels)
   int32_t freeIdx;     // index among the free-joint bodies (-1 otherwise): their extra LDS block in the coop tree kernels
+  int32_t root, padr;  // the root body of this body's tree: origin of the translated "world" frame its spatial quantities are carried in
   int32_t ballComp;    // JT_BALL: 0, 1, 2 = the x, y, z body of a ball joint's triple (consecutive body indices and DOFs; the x body
                        // carries T_pj exp(q), the z body T_cj, mass and children).  1-DOF code treats all three as revolute joints
 };

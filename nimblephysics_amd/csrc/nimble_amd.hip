@@ -283,6 +283,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (b.jtype == NBL_JOINT_FREE && b.parent != -1)
       return fail(NBL_E_UNSUPPORTED, "free joints are supported as tree roots only");
     b.freeIdx = -1; b.ballComp = ballModel ? expanded.ballComp[i] : 0;
+    b.root = b.parent < 0 ? i : hb[b.parent].root; b.padr = 0;
     b.level = b.parent < 0 ? 0 : hb[b.parent].level + 1;
     b.rank = 0;
     for (int j = 0; j < i; j++) if (hb[j].parent == b.parent) b.rank++;
@@ -582,7 +583,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
                                            failCountAll + si, ppw));
       }
       {
-        const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 6 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
+        const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 12 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
                                sizeof(double);   // acc, Fw, Sw/AISw/Vw/psi, free-joint blocks, contact bodies
         TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)cnt), dim3(64), rowsLds, s, mdl, m->dBodies, m->dContact, B,
                                               (double*)saved, m->lay, (const double*)workspace));
