@@ -3,7 +3,7 @@ frictionless, restitution, penetration correction on/off) dropped on the ground;
 compared with the CPU oracle.  A world above 1e-5 must be one where the oracle itself flips under 1-ulp input perturbations
 (the criterion of tests/test_gpu_contact.py), otherwise it is reported as a MISMATCH.
   usage: python tools/soak_parity.py [first seed] [count] [B] [big|multi|balls]      (big: 8-21 bodies, 3-7 colliders; multi: 2-3 separate skeletons;
-  balls: 40 % of the joints below the root are ball joints)"""
+  balls: 40 % of the joints below the root are ball joints; far: the same, the scene ~10 m from the world origin)"""
 import os
 import sys
 
@@ -20,7 +20,7 @@ from test_gpu_random_trees import random_tree  # noqa: E402
 
 
 
-def make_case(seed, B=256, big=False, multi=False, balls=False):
+def make_case(seed, B=256, big=False, multi=False, balls=False, far=False):
     """The model, states, actions and cotangents of one soak seed (None when the model has more than 40 DOFs)."""
     rng = np.random.default_rng(50000 + seed)
     nb = int(rng.integers(8, 22)) if big else int(rng.integers(1, 10))
@@ -61,16 +61,22 @@ def make_case(seed, B=256, big=False, multi=False, balls=False):
                 q[:, off + 3] = 1.5 * (k_ % 7) - 2.0 + rng.normal(0, 0.2, B); q[:, off + 5] = rng.normal(0, 0.3, B)
                 q[:, off + 4] = rng.uniform(0.02, 0.4, B)
             off += {"free": 6, "weld": 0, "ball": 3}.get(bd.joint_type, 1)
+    if far:          # the whole scene in a corner of the 20 m ground plate, ~10 m from the world origin
+        off = 0
+        for bd in md.bodies:
+            if bd.joint_type == "free" and bd.parent < 0:
+                q[:, off + 3] += 7.5; q[:, off + 5] -= 6.5
+            off += {"free": 6, "weld": 0, "ball": 3}.get(bd.joint_type, 1)
     v = rng.normal(0, rng.choice([0.05, 0.5, 2.0]), (B, n))
     s = np.concatenate([q, v], 1); a = rng.normal(0, 0.5, (B, len(md.action_map))); g = rng.normal(0, 1, s.shape)
 
     return md, s, a, g
 
 
-def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False):
+def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False, far=False):
   tot = {"worlds": 0, "contact": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "MISMATCH": 0}
   for seed in range(first, first + count):
-      case = make_case(seed, B, big, multi, balls)
+      case = make_case(seed, B, big, multi, balls, far)
       if case is None:
           continue
       md, s, a, g = case
@@ -111,4 +117,4 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=Fa
 if __name__ == "__main__":
     print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 20,
               int(sys.argv[3]) if len(sys.argv) > 3 else 256, big=len(sys.argv) > 4 and sys.argv[4] == "big", multi=len(sys.argv) > 4 and sys.argv[4] == "multi",
-              balls=len(sys.argv) > 4 and sys.argv[4] == "balls"))
+              balls=len(sys.argv) > 4 and sys.argv[4] in ("balls", "far"), far=len(sys.argv) > 4 and sys.argv[4] == "far"))
