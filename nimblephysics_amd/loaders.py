@@ -181,12 +181,17 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8):
     planar (expanded into 1-DOF chains by ModelDescription), <parent> ("world" = none) / <child>, <transformation> = T_ChildBodyToJoint and
     T_ParentBodyToJoint = parentWorld^-1 childWorld childToJoint (:1540-1552), <axis> xyz, damping (under <axis> or
     <axis><dynamics>), spring_stiffness / spring_rest_position, <limit> lower / upper (:1870-1960).  Bodies are emitted
-    parents-before-children in the file's joint order, which is the skeleton's DOF order.  Soft bodies, meshes, ball / screw
-    joints and <init_pos> / <init_vel> (a state, not a model constant) are outside the subset: unsupported joints raise."""
+    parents-before-children in the file's joint order, which is the skeleton's DOF order.  Ball joints and the
+    <dof> elements of every joint type are read too; a file without <world> is a skeleton file.  Soft bodies, meshes, screw joints and
+    <init_pos> / <init_vel> (a state, not a model constant) are outside the subset: unsupported joints raise."""
     root = ET.parse(path).getroot()
     world = root.find("world")
     if world is None:
-        raise ValueError(f"{path}: no <world>")
+        # a skeleton file (SkelParser::readSkeleton, :433-460): <skeleton> elements directly under <skel>; the world they are added to has the
+        # defaults of World's constructor (dt 1e-3, gravity (0, -9.81, 0), World.cpp:76-99)
+        if root.find("skeleton") is None:
+            raise ValueError(f"{path}: neither a <world> nor a <skeleton>")
+        world = root
     phys = world.find("physics")
     dt = _text(phys, "time_step", 1e-3)
     g = phys.find("gravity") if phys is not None else None
