@@ -8,7 +8,7 @@ Conventions follow the reference's dart/utils/urdf/DartLoader.cpp (parameters on
   * children are visited depth-first in joint-NAME order (urdfdom keeps joints in a std::map and builds child_links
     from it), which fixes the DOF order of the skeleton
   * collision boxes -> box colliders with the collision origin as the shape's relative transform (:612-616);
-    mesh / sphere / capsule colliders (libccd path, not vendored) are dropped
+    mesh / capsule / cylinder colliders (libccd path, not vendored) raise, or are dropped on request
 Revolute, continuous, prismatic and fixed joints; joint Coulomb friction and other joint types raise.
 """
 import os
@@ -32,8 +32,9 @@ def _origin(el):
     return make_transform(_floats(o.get("xyz")), _floats(o.get("rpy")))
 
 
-def load_urdf(path, name=None, weld_joints=()):
-    """Parse `path`; joints named in `weld_joints` are frozen at 0 (welded), e.g. the arms of the 20-DOF Atlas."""
+def load_urdf(path, name=None, weld_joints=(), drop_unsupported_colliders=False):
+    """Parse `path`; joints named in `weld_joints` are frozen at 0 (welded), e.g. the arms of the 20-DOF Atlas.  Collision geometry other
+    than boxes and spheres raises unless `drop_unsupported_colliders` (the link is then loaded without that collider)."""
     root = ET.parse(path).getroot()
     if name is None:
         name = root.get("name", "model")
@@ -76,7 +77,10 @@ def load_urdf(path, name=None, weld_joints=()):
             elif sph is not None:
                 r = float(sph.get("radius"))
                 boxes.append(BoxSpec(body_index, _origin(col), (r, r, r), 1.0, "sphere"))
-            # mesh / capsule / cylinder: outside the analytic box / sphere narrow phase
+            elif geom is not None and len(geom) and not drop_unsupported_colliders:
+                # mesh / capsule / cylinder: outside the analytic box / sphere narrow phases (the reference: libccd / its mesh code)
+                raise ValueError(f"{path}: {geom[0].tag} collider on link {ln} is outside the analytic narrow phases (box, sphere); "
+                                 "drop_unsupported_colliders=True loads the model without it")
 
     def recurse(ln, parent_index):
         for jn in children[ln]:
@@ -169,9 +173,10 @@ def _text(el, tag, default=None, cast=float):
     return default if t is None or t.text is None else cast(t.text.strip())
 
 
-def load_skel(path, name=None, skeletons=None, max_contacts=8):
+def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_colliders=False):
     """Parse a SKEL world (`<skel><world>`: physics + skeletons) into ONE ModelDescription (all skeletons of the world in one
-    model, like `with_ground`).  `skeletons`: names of the skeletons to keep (default: all), in file order.
+    model, like `with_ground`).  `skeletons`: names of the skeletons to keep (default: all), in file order.  Collision shapes other than
+    boxes and spheres (isotropic ellipsoids) raise unless `drop_unsupported_colliders` (the body is then loaded without that collider).
 
     Subset, following SkelParser.cpp: <physics> time_step / gravity (:520-560); per <body> name, <transformation> = the body's
     WORLD transform at the zero configuration (:1082-1092), <inertia> mass / offset / moment_of_inertia (:1095-1128; without a
@@ -224,6 +229,11 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8):
                     if max(d) - min(d) > 1e-12 * max(d):
                         raise ValueError(f"{path}: anisotropic ellipsoid collider outside the analytic narrow phase")
                     out.append(("sphere", (d[0] / 2,) * 3, _skel_T(cs)))
+                elif geom is not None and len(geom) and not drop_unsupported_colliders:
+                    # capsule / cylinder / mesh / ...: the reference collides them through libccd or its mesh code; loading the body without
+                    # its collider would silently change the physics (it falls through the ground)
+                    raise ValueError(f"{path}: {geom[0].tag} collider on body {b.get('name')} is outside the analytic narrow phases (box, sphere); "
+                                     "drop_unsupported_colliders=True loads the model without it")
             return out
 
         def inertial(b):
