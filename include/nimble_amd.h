@@ -39,6 +39,8 @@ extern "C" {
 #define NBL_JOINT_FREE 2 /* DART_USE_IDENTITY_JACOBIAN build: S = Ad(T_cj), FreeJoint.cpp:1049-1056 */
 #define NBL_JOINT_WELD 3 /* 0 DOF. The GPU library requires welds to be merged into the parent
                             (host model builder does this); the CPU oracle accepts them. */
+#define NBL_JOINT_SCREW 5 /* 1 DOF, ScrewJoint.cpp:160-232: rotation about `axis` coupled with a translation of `pitch` per turn along it,
+                             S = Ad(T_cj) [axis; axis pitch / 2 pi], T = T_pj expMap(S_local q) T_cj^-1 */
 #define NBL_JOINT_BALL 4 /* 3 DOF, BallJoint.cpp (DART_USE_IDENTITY_JACOBIAN build): positions = exponential-map vector of the joint
                             rotation, velocities = angular velocity in the child joint frame, S = Ad(T_cj)[:, 0:3] (:441-452),
                             q' = log(exp(q) exp(v dt)) (:333-349).  Anywhere in the tree.  The library runs it as three coincident
@@ -138,6 +140,10 @@ typedef struct nbl_model_desc {
    * contacts with world-fixed colliders do not connect anything).  Each group runs the solver cascade on its own, so one
    * object that needs the fallback stages does not change the solution of the others. */
   const int32_t* body_skeleton;
+
+  /* ---- screw joints (appended; NULL = 0.1 for every screw joint, ScrewJointAspect's default) ----
+   * [n_bodies] ScrewJoint::mPitch: translation along the axis per full turn; read for NBL_JOINT_SCREW bodies only. */
+  const double* pitch;
 } nbl_model_desc;
 
 #define NBL_SHAPE_BOX 0

@@ -9,8 +9,10 @@ JOINT_PRISMATIC = 1
 JOINT_FREE = 2
 JOINT_WELD = 3
 JOINT_BALL = 4
-JOINT_NAMES = {"revolute": JOINT_REVOLUTE, "prismatic": JOINT_PRISMATIC, "free": JOINT_FREE, "weld": JOINT_WELD, "ball": JOINT_BALL}
-JOINT_NDOF = {JOINT_REVOLUTE: 1, JOINT_PRISMATIC: 1, JOINT_FREE: 6, JOINT_WELD: 0, JOINT_BALL: 3}
+JOINT_SCREW = 5
+JOINT_NAMES = {"revolute": JOINT_REVOLUTE, "prismatic": JOINT_PRISMATIC, "free": JOINT_FREE, "weld": JOINT_WELD, "ball": JOINT_BALL,
+               "screw": JOINT_SCREW}
+JOINT_NDOF = {JOINT_REVOLUTE: 1, JOINT_PRISMATIC: 1, JOINT_FREE: 6, JOINT_WELD: 0, JOINT_BALL: 3, JOINT_SCREW: 1}
 
 NBL_OK = 0
 NBL_E_BADARG = -1
@@ -71,4 +73,5 @@ class ModelDesc(C.Structure):
         ("box_restitution", _pd),
         ("penetration_correction", C.c_int32),
         ("body_skeleton", _pi),
+        ("pitch", _pd),
     ]

@@ -153,6 +153,10 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
       const double qi = q[bd.dofOff * B + b];
       Q.R = eye3();
       Q.p = mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi);
+    } else if (bd.jtype == JT_SCREW) {                   // expMap([axis; h axis] q) = (R(axis q), h axis q), ScrewJoint.cpp:217-232
+      const double qi = q[bd.dofOff * B + b], hq = bd.screwRate * qi;
+      Q.R = expAngular(mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi));
+      Q.p = mk3(bd.axis[0] * hq, bd.axis[1] * hq, bd.axis[2] * hq);
     } else if (bd.jtype == JT_BALL) {
       // the x body of the triple carries the joint rotation exp(q) (BallJoint.cpp:91-95, 422-438); the y and z bodies sit on it at zero angle
       Q.R = bd.ballComp == 0 ? expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b])) : eye3();

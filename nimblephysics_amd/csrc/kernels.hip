@@ -261,6 +261,10 @@ DEV void abaSweeps(const C& c, const double* __restrict__ q, const double* __res
       double qi = q[bd.dofOff * B + b];
       Q.R = eye3();
       Q.p = mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi);
+    } else if (bd.jtype == JT_SCREW) {                   // expMap([axis; h axis] q) = (R(axis q), h axis q), ScrewJoint.cpp:217-232
+      const double qi = q[bd.dofOff * B + b], hq = bd.screwRate * qi;
+      Q.R = expAngular(mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi));
+      Q.p = mk3(bd.axis[0] * hq, bd.axis[1] * hq, bd.axis[2] * hq);
     } else {
       Q.R = expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b]));  // FreeJoint.cpp:74-81
       Q.p = mk3(q[(bd.dofOff + 3) * B + b], q[(bd.dofOff + 4) * B + b], q[(bd.dofOff + 5) * B + b]);

@@ -51,7 +51,7 @@ __device__ unsigned long long g_phaseStamp[64];
 #define NBL_PHASE(k) do { } while (0)
 #endif
 
-constexpr int JT_REVOLUTE = 0, JT_PRISMATIC = 1, JT_FREE = 2, JT_BALL = 4;   // = NBL_JOINT_*; JT_BALL: one of the three coincident axes of a ball joint
+constexpr int JT_REVOLUTE = 0, JT_PRISMATIC = 1, JT_FREE = 2, JT_BALL = 4, JT_SCREW = 5;   // = NBL_JOINT_*; JT_BALL: one of the three coincident axes of a ball joint
 
 struct DevBody {
   int32_t parent, jtype, dofOff, ndof;
@@ -61,6 +61,7 @@ struct DevBody {
   double axis[3];
   double S[6];        // 1-DOF joints: constant relative Jacobian column in the child frame
   double G[21];       // spatial inertia, packed symmetric
+  double screwRate;    // JT_SCREW: translation along the axis per radian (pitch / 2 pi)
   int32_t level, rank; // depth in the tree, index among the children of the parent (coop tree kernels)
   int32_t freeIdx;     // index among the free-joint bodies (-1 otherwise): their extra LDS block in the coop tree kernels
   int32_t root, padr;  // the root body of this body's tree: origin of the translated "world" frame its spatial quantities are carried in

@@ -187,7 +187,7 @@ namespace {
 struct ExpandedDesc {
   nbl_model_desc desc;
   std::vector<int32_t> parent, jointType, dofOffset, boxBody, bodySkeleton, bodyMap, ballComp;
-  std::vector<double> Tpj, Tcj, axis, mass, com, inertia;
+  std::vector<double> Tpj, Tcj, axis, mass, com, inertia, pitch;
 };
 bool hasBallJoints(const nbl_model_desc* d) {
   for (int i = 0; i < d->n_bodies; i++) if (d->joint_type[i] == NBL_JOINT_BALL) return true;
@@ -196,6 +196,7 @@ bool hasBallJoints(const nbl_model_desc* d) {
 void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
   static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
   e.bodyMap.assign(d->n_bodies, -1);
+  int srcBody = 0;
   auto push = [&](int parent, int jt, int dofOff, const double* Tpj, const double* Tcj, const double* ax, double mass, const double* com,
                   const double* inertia, int skel, int comp) {
     static const double z6[6] = {0, 0, 0, 0, 0, 0};
@@ -204,11 +205,13 @@ void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
     e.mass.push_back(mass); e.com.insert(e.com.end(), com ? com : z6, (com ? com : z6) + 3);
     e.inertia.insert(e.inertia.end(), inertia ? inertia : z6, (inertia ? inertia : z6) + 6);
     e.bodySkeleton.push_back(skel); e.ballComp.push_back(comp);
+    e.pitch.push_back(jt == NBL_JOINT_SCREW && d->pitch ? d->pitch[srcBody] : 0.1);
   };
   // skeleton ids: the caller's, or (default: one skeleton per tree) the root of the tree in the CALLER's numbering - any id shared by
   // exactly the bodies of one tree will do
   auto rootOf = [&](int body) { while (d->parent[body] >= 0) body = d->parent[body]; return body; };
   for (int i = 0; i < d->n_bodies; i++) {
+    srcBody = i;
     const int par = d->parent[i] < 0 ? -1 : e.bodyMap[d->parent[i]];
     const int skel = d->body_skeleton ? d->body_skeleton[i] : rootOf(i);
     if (d->joint_type[i] != NBL_JOINT_BALL) {
@@ -232,7 +235,7 @@ void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
   e.desc.parent = e.parent.data(); e.desc.joint_type = e.jointType.data(); e.desc.dof_offset = e.dofOffset.data();
   e.desc.T_pj = e.Tpj.data(); e.desc.T_cj = e.Tcj.data(); e.desc.axis = e.axis.data();
   e.desc.mass = e.mass.data(); e.desc.com = e.com.data(); e.desc.inertia = e.inertia.data();
-  e.desc.box_body = e.boxBody.data(); e.desc.body_skeleton = e.bodySkeleton.data();
+  e.desc.box_body = e.boxBody.data(); e.desc.body_skeleton = e.bodySkeleton.data(); e.desc.pitch = e.pitch.data();
 }
 }  // namespace
 
@@ -278,8 +281,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (b.parent < -1 || b.parent >= i) return fail(NBL_E_BADARG, "bodies must be listed parents-before-children");
     if (b.jtype == NBL_JOINT_WELD)
       return fail(NBL_E_UNSUPPORTED, "weld joints must be merged into their parent before upload (ModelDescription.merge_welds)");
-    if (b.jtype != NBL_JOINT_REVOLUTE && b.jtype != NBL_JOINT_PRISMATIC && b.jtype != NBL_JOINT_FREE && b.jtype != NBL_JOINT_BALL)
-      return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, free, ball)");
+    if (b.jtype != NBL_JOINT_REVOLUTE && b.jtype != NBL_JOINT_PRISMATIC && b.jtype != NBL_JOINT_FREE && b.jtype != NBL_JOINT_BALL &&
+        b.jtype != NBL_JOINT_SCREW)
+      return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, screw, free, ball)");
     if (b.jtype == NBL_JOINT_FREE && b.parent != -1)
       return fail(NBL_E_UNSUPPORTED, "free joints are supported as tree roots only");
     b.freeIdx = -1; b.ballComp = ballModel ? expanded.ballComp[i] : 0;
@@ -310,6 +314,12 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       b.S[5] = p[0] * Ra[1] - p[1] * Ra[0];
     } else if (b.jtype == NBL_JOINT_PRISMATIC) {
       b.S[3] = Ra[0]; b.S[4] = Ra[1]; b.S[5] = Ra[2];
+    } else if (b.jtype == NBL_JOINT_SCREW) {            // Ad(T_cj) [axis; h axis], ScrewJoint.cpp:160-179
+      b.screwRate = (d->pitch ? d->pitch[i] : 0.1) / (2.0 * M_PI);
+      b.S[0] = Ra[0]; b.S[1] = Ra[1]; b.S[2] = Ra[2];
+      b.S[3] = p[1] * Ra[2] - p[2] * Ra[1] + b.screwRate * Ra[0];
+      b.S[4] = p[2] * Ra[0] - p[0] * Ra[2] + b.screwRate * Ra[1];
+      b.S[5] = p[0] * Ra[1] - p[1] * Ra[0] + b.screwRate * Ra[2];
     }
     packSpatialInertia(d->mass[i], d->com + 3 * i, d->inertia + 6 * i, b.G);
   }

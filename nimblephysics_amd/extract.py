@@ -29,7 +29,7 @@ import numpy as np
 
 from .model import BodySpec, BoxSpec, ModelDescription
 
-_JOINT_TYPES = {"RevoluteJoint": "revolute", "PrismaticJoint": "prismatic", "FreeJoint": "free", "WeldJoint": "weld", "BallJoint": "ball"}
+_JOINT_TYPES = {"RevoluteJoint": "revolute", "PrismaticJoint": "prismatic", "FreeJoint": "free", "WeldJoint": "weld", "BallJoint": "ball", "ScrewJoint": "screw"}
 _COMPOUND_TYPES = ("EulerJoint", "UniversalJoint", "TranslationalJoint", "TranslationalJoint2D", "PlanarJoint")
 _UNIT = {"x": (1.0, 0.0, 0.0), "y": (0.0, 1.0, 0.0), "z": (0.0, 0.0, 1.0)}
 
@@ -112,9 +112,11 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
                     kw["axes"] = [vec3(j.getTranslationalAxis1()), vec3(j.getTranslationalAxis2())]
             else:
                 jtype = _JOINT_TYPES[jt]
-                if jtype in ("revolute", "prismatic"):
+                if jtype in ("revolute", "prismatic", "screw"):
                     axis = vec3(j.getAxis())
                     kw = per_dof()
+                    if jtype == "screw":
+                        kw["pitch"] = float(j.getPitch())
                 elif jtype == "free":
                     kw = {k_: v for k_, v in per_dof().items() if k_ in ("damping", "spring", "rest")}
                 elif jtype == "ball":

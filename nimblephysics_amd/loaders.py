@@ -337,6 +337,13 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                     jtype = "weld"
                 elif jt == "free":
                     jtype = "free"
+                elif jt == "screw":
+                    ax = j.find("axis")                      # readScrewJoint (:2085-2150): <axis><xyz/><pitch/> + the per-axis dynamics
+                    axis = tuple(float(x) for x in ax.find("xyz").text.split())
+                    kw.update(axis_props(1))
+                    if ax.find("pitch") is not None:
+                        kw["pitch"] = float(ax.find("pitch").text)
+                    jtype = "screw"
                 elif jt == "ball":
                     jtype = "ball"              # readBallJoint (:2226-2256): init_pos / init_vel (states are the caller's here) + <dof> elements
                 else:

@@ -92,6 +92,7 @@ class BodySpec:
     friction: float = 1.0  # BodyNodeAspect.hpp:47
     axes: Sequence[Sequence[float]] = ()   # compound joints with free axes (universal: 2, translational2d: 2, planar: 2 in-plane axes)
     skeleton: int = -1   # index of the dart Skeleton the body belongs to; -1 (every body of the model) = one skeleton per tree
+    pitch: float = 0.1   # screw joints: translation along the axis per turn (ScrewJoint::mPitch, default 0.1)
 
 
 # ---- compound joints: (kind of each one-parameter motion, default axes) ------------------------------------------------
@@ -390,6 +391,7 @@ class ModelDescription:
         a["box_restitution"] = np.array([bx.restitution for bx in self.boxes], np.float64).reshape(nbx)
         a["action_map"] = np.array(self.action_map, np.int32)
         a["body_skeleton"] = np.array(self.body_skeletons(), np.int32).reshape(nb)
+        a["pitch"] = np.array([b.pitch for b in self.bodies], np.float64).reshape(nb)
         return a
 
     def to_desc(self):
@@ -410,7 +412,7 @@ class ModelDescription:
         for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape", "body_skeleton"):
             setattr(d, k, pi(a[k]))
         for k in ("T_pj", "T_cj", "axis", "mass", "com", "inertia", "damping", "spring", "rest", "pos_lo", "pos_hi",
-                  "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu", "box_restitution"):
+                  "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu", "box_restitution", "pitch"):
             setattr(d, k, pd(a[k]))
         d.gravity = (C.c_double * 3)(*self.gravity)
         d.dt = self.dt
@@ -426,7 +428,7 @@ class ModelDescription:
     def to_json(self) -> dict:
         def body(b: BodySpec):
             d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()
-                 if k != "axes" and not (k == "skeleton" and v < 0)}   # compound joints are already expanded: every stored joint has its single `axis`
+                 if k != "axes" and not (k == "skeleton" and v < 0) and not (k == "pitch" and b.joint_type != "screw")}   # compound joints are already expanded: every stored joint has its single `axis`
             return d
         return {
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,

@@ -14,6 +14,7 @@ struct Body {
   int parent, jtype, dofOff, ndof;
   Iso Tpj, Tcj, TcjInv;
   Vec3 axis;
+  s_t pitch = 0;   // screw joints: translation per turn
   Mat6 G;     // spatial inertia, Inertia.cpp:1368-1383
   Vec6 S[6];  // constant relative Jacobian columns in the child frame
   std::vector<int> children;
@@ -60,6 +61,7 @@ inline Model buildModel(const nbl_model_desc* d) {
     b.jtype = d->joint_type[i];
     b.dofOff = d->dof_offset[i];
     b.ndof = (b.jtype == NBL_JOINT_FREE) ? 6 : (b.jtype == NBL_JOINT_BALL ? 3 : (b.jtype == NBL_JOINT_WELD ? 0 : 1));
+    b.pitch = (b.jtype == NBL_JOINT_SCREW) ? (d->pitch ? d->pitch[i] : 0.1) : 0.0;
     b.Tpj = loadIso(d->T_pj + 12 * i);
     b.Tcj = loadIso(d->T_cj + 12 * i);
     b.TcjInv = inverse(b.Tcj);
@@ -94,6 +96,9 @@ inline Model buildModel(const nbl_model_desc* d) {
       Mat6 A = AdTMatrix(b.Tcj);
       for (int k = 0; k < 6; k++)
         for (int r = 0; r < 6; r++) b.S[k][r] = A(r, k);
+    } else if (b.jtype == NBL_JOINT_SCREW) {
+      // AdT(T_cj, [axis; axis pitch / 2 pi])   ScrewJoint.cpp:160-179
+      b.S[0] = AdT(b.Tcj, mk6(b.axis, b.axis * (b.pitch / (2.0 * M_PI))));
     } else if (b.jtype == NBL_JOINT_BALL) {
       // getAdTMatrix(T_cj).leftCols<3>()      BallJoint.cpp:441-452 (DART_USE_IDENTITY_JACOBIAN)
       Mat6 A = AdTMatrix(b.Tcj);
@@ -152,6 +157,10 @@ inline Iso jointQ(const Body& b, const s_t* q) {
     Q.p = mk3(q[b.dofOff + 3], q[b.dofOff + 4], q[b.dofOff + 5]);
   } else if (b.jtype == NBL_JOINT_BALL) {
     Q.R = expMapRot(mk3(q[b.dofOff], q[b.dofOff + 1], q[b.dofOff + 2]));   // BallJoint.cpp:91-95, 422-438
+  } else if (b.jtype == NBL_JOINT_SCREW) {
+    // math::expMap([axis; h axis] q), ScrewJoint.cpp:217-232: translation parallel to the rotation axis, so exp = (R(axis q), h axis q)
+    Q.R = expAngular(b.axis * q[b.dofOff]);
+    Q.p = b.axis * (b.pitch / (2.0 * M_PI) * q[b.dofOff]);
   }
   return Q;
 }

@@ -174,7 +174,7 @@ def test_extraction_keeps_spheres_friction_action_space_and_leaves_the_world_unt
 def test_unsupported_joint_types_raise():
     md = na.cartpole()
     w = StandInWorld(md)
-    _Joint.TYPES = dict(_Joint.TYPES, revolute="ScrewJoint")
+    _Joint.TYPES = dict(_Joint.TYPES, revolute="CustomJoint1")
     try:
         with pytest.raises(ValueError):
             model_from_nimble_world(w)

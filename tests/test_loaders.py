@@ -158,7 +158,7 @@ def test_skel_subset_loader_builds_the_expected_model(tmp_path):
     only_arm = na.load_skel(str(f), skeletons=["arm"])
     assert [b.name for b in only_arm.bodies] == ["b1", "b2"] and len(only_arm.boxes) == 2
     bad = tmp_path / "bad.skel"
-    bad.write_text(SKEL.replace('type="prismatic"', 'type="screw"'))
+    bad.write_text(SKEL.replace('type="prismatic"', 'type="hinge2"'))
     with pytest.raises(ValueError):
         na.load_skel(str(bad))
     ball = tmp_path / "ball.skel"           # a ball joint with <dof> elements (readBallJoint + readAllDegreesOfFreedom)
