@@ -36,7 +36,8 @@ extern "C" {
 /* ---- joint types (dart/dynamics/{Revolute,Prismatic,Free,Weld}Joint.cpp) ---- */
 #define NBL_JOINT_REVOLUTE 0
 #define NBL_JOINT_PRISMATIC 1
-#define NBL_JOINT_FREE 2 /* DART_USE_IDENTITY_JACOBIAN build: S = Ad(T_cj), FreeJoint.cpp:1049-1056 */
+#define NBL_JOINT_FREE 2 /* DART_USE_IDENTITY_JACOBIAN build: S = Ad(T_cj), FreeJoint.cpp:1049-1056.  Anywhere in the tree (as a tree root: the
+                            fast path; below other bodies: six coincident single-axis joints internally, like NBL_JOINT_BALL) */
 #define NBL_JOINT_WELD 3 /* 0 DOF. The GPU library requires welds to be merged into the parent
                             (host model builder does this); the CPU oracle accepts them. */
 #define NBL_JOINT_SCREW 5 /* 1 DOF, ScrewJoint.cpp:160-232: rotation about `axis` coupled with a translation of `pitch` per turn along it,

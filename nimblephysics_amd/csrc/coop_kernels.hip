@@ -644,7 +644,14 @@ __global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* 
   if (ln < mdl.nb) {
     const DevBody& bd = bodies[ln];
     const int o = bd.dofOff;
-    if (bd.jtype == JT_BALL) {                          // BallJoint.cpp:351-408: the 3 x 3 blocks of the SO(3) integration
+    if (bd.jtype == JT_FREEC) {                         // a free joint below the root: the 6 x 6 blocks of the SE(3) integration
+      const int d0 = o - bd.ballComp, cmp = bd.ballComp;
+      auto at3 = [&](const double* x, int k0) { return mk3(x[(int64_t)(d0 + k0) * B + b], x[(int64_t)(d0 + k0 + 1) * B + b], x[(int64_t)(d0 + k0 + 2) * B + b]); };
+      double posT[6], velT[6];
+      se3IntegrationVjp(at3(q, 0), at3(v, 0), at3(v, 3), mdl.dt, at3(gnext, 0), at3(gnext, 3), posT, velT);
+#pragma unroll
+      for (int k = 0; k < 6; k++) if (k == cmp) { yq[o] = posT[k]; yv[o] = velT[k]; }
+    } else if (bd.jtype == JT_BALL) {                   // BallJoint.cpp:351-408: the 3 x 3 blocks of the SO(3) integration
       const int d0 = o - bd.ballComp, cmp = bd.ballComp;
       V3 posr, velw;
       so3IntegrationVjp(mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b]),
@@ -1103,7 +1110,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
   // ---- phase 4 ----
   if (ln < nb) {
     const DevBody& bd = bodies[ln];
-    const int i = bd.jtype == JT_BALL ? ln - bd.ballComp : ln;   // a ball joint's positions act through the x body of its triple
+    const int i = (bd.jtype == JT_BALL || bd.jtype == JT_FREEC) ? ln - bd.ballComp : ln;   // a ball joint's (non-root free joint's) positions act through the first body of its triple (sextuple)
     const int par = bodies[i].parent;
     V6 xiW = ld6(D + i * 54, 1);
     if (par >= 0) {

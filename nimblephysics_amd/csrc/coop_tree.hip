@@ -157,6 +157,11 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
       const double qi = q[bd.dofOff * B + b], hq = bd.screwRate * qi;
       Q.R = expAngular(mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi));
       Q.p = mk3(bd.axis[0] * hq, bd.axis[1] * hq, bd.axis[2] * hq);
+    } else if (bd.jtype == JT_FREEC) {
+      // a free joint below the root: six coincident axes at zero displacement, the first body carries [exp(q_r), q_p] (FreeJoint.cpp:74-81)
+      const int o = bd.dofOff;
+      Q.R = bd.ballComp == 0 ? expMapRot(mk3(q[(o + 0) * B + b], q[(o + 1) * B + b], q[(o + 2) * B + b])) : eye3();
+      Q.p = bd.ballComp == 0 ? mk3(q[(o + 3) * B + b], q[(o + 4) * B + b], q[(o + 5) * B + b]) : mk3(0, 0, 0);
     } else if (bd.jtype == JT_BALL) {
       // the x body of the triple carries the joint rotation exp(q) (BallJoint.cpp:91-95, 422-438); the y and z bodies sit on it at zero angle
       Q.R = bd.ballComp == 0 ? expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b])) : eye3();
@@ -286,6 +291,12 @@ DEV void abaSweepsWorld(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ 
       const int d0 = bd.dofOff - bd.ballComp;
       const double wx = v[(int64_t)d0 * B + b], wy = v[(int64_t)(d0 + 1) * B + b], wz = v[(int64_t)(d0 + 2) * B + b];
       acc += bd.ballComp == 0 ? wy * wz : (bd.ballComp == 1 ? -wx * wz : wx * wy);
+    } else if (bd.jtype == JT_FREEC) {
+      // the same for the six axes of a free joint: the angular brackets, and w x u for the translations (all rotations come first)
+      const int d0 = bd.dofOff - bd.ballComp, cmp = bd.ballComp;
+      const V3 wv = mk3(v[(int64_t)d0 * B + b], v[(int64_t)(d0 + 1) * B + b], v[(int64_t)(d0 + 2) * B + b]);
+      const V3 uv = mk3(v[(int64_t)(d0 + 3) * B + b], v[(int64_t)(d0 + 4) * B + b], v[(int64_t)(d0 + 5) * B + b]);
+      acc += cmp < 3 ? pick3(mk3(wv.y * wv.z, -wv.x * wv.z, wv.x * wv.y), cmp) : pick3(cross(wv, uv), cmp - 3);
     }
     emit(bd.dofOff, acc);
   }
@@ -472,10 +483,10 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
   }
   // a ball joint's positions act through the transform of the x body of its triple only: the y and z bodies take its adjoint
   // (handed over in the accumulator slots, which the sweep above has consumed)
-  const bool isBall = wb.on && bd.jtype == JT_BALL;
-  if (isBall && bd.ballComp == 0) stV6(c, i, WS_FACC, xi);
+  const bool isBall = wb.on && bd.jtype == JT_BALL, isFreeC = wb.on && bd.jtype == JT_FREEC;
+  if ((isBall || isFreeC) && bd.ballComp == 0) stV6(c, i, WS_FACC, xi);
   waveFence();
-  if (isBall && bd.ballComp > 0) xi = ldV6(c, i - bd.ballComp, WS_FACC);
+  if ((isBall || isFreeC) && bd.ballComp > 0) xi = ldV6(c, i - bd.ballComp, WS_FACC);
   if (!wb.on) return;
   double qb[6], vb[6], pp[6], vp[6];
   applyHt(bd, q, B, b, xi, qb);
@@ -494,6 +505,20 @@ DEV void reverseSweepWorld(const CoopCtxT<PROF_BWD>& c, const WorldBody& wb, V6 
     // v' = v + dt (qdd_chain + delta(w)),  delta = (wy wz, -wx wz, wx wy)
     const double g0 = gvPreAt(d0), g1 = gvPreAt(d0 + 1), g2 = gvPreAt(d0 + 2);
     ballExtra = c.dt * (cmp == 0 ? (-w.z * g1 + w.y * g2) : (cmp == 1 ? (w.z * g0 + w.x * g2) : (w.y * g0 - w.x * g1)));
+  } else if (isFreeC) {
+    vb[0] = dot(cV6(bd.S), tmp);
+    const int d0 = o - bd.ballComp, cmp = bd.ballComp;
+    auto at3 = [&](const double* x, int k0) { return mk3(x[(int64_t)(d0 + k0) * B + b], x[(int64_t)(d0 + k0 + 1) * B + b], x[(int64_t)(d0 + k0 + 2) * B + b]); };
+    const V3 wv = at3(v, 0), uv = at3(v, 3);
+    double posT[6], velT[6];
+    se3IntegrationVjp(at3(q, 0), wv, uv, c.dt, at3(gqn, 0), at3(gqn, 3), posT, velT);
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k == cmp) { pp[0] = posT[k]; vp[0] = velT[k]; }
+    // v' = v + dt (qdd_chain + delta),  delta = [(wy wz, -wx wz, wx wy); w x u]
+    const V3 ga = mk3(gvPreAt(d0), gvPreAt(d0 + 1), gvPreAt(d0 + 2)), gl = mk3(gvPreAt(d0 + 3), gvPreAt(d0 + 4), gvPreAt(d0 + 5));
+    const V3 dW = mk3(-wv.z * ga.y + wv.y * ga.z, wv.z * ga.x + wv.x * ga.z, wv.y * ga.x - wv.x * ga.y) + cross(uv, gl);
+    const V3 dU = cross(gl, wv);
+    ballExtra = c.dt * (cmp < 3 ? pick3(dW, cmp) : pick3(dU, cmp - 3));
   } else if (!wb.isFree) {
     vb[0] = dot(cV6(bd.S), tmp);
     pp[0] = gqn[(int64_t)o * B + b];            // posPos = 1, velPos = dt  (GenericJoint.hpp:1428-1444)

@@ -433,6 +433,13 @@ DEV void stepForwardCore(const C& c, const double* __restrict__ state, const dou
       V3 pn = p + mul(R, c.dt * vl);
       nq[(o + 0) * B + b] = rn.x; nq[(o + 1) * B + b] = rn.y; nq[(o + 2) * B + b] = rn.z;
       nq[(o + 3) * B + b] = pn.x; nq[(o + 4) * B + b] = pn.y; nq[(o + 5) * B + b] = pn.z;
+    } else if (bd.jtype == JT_FREEC) {
+      // FreeJoint::integratePositionsExplicit (FreeJoint.cpp:922-929) of a free joint below the root: each of its six bodies writes its component
+      const int d0 = o - bd.ballComp, cmp = bd.ballComp;
+      auto at3 = [&](const double* x, int k0) { return mk3(x[(int64_t)(d0 + k0) * B + b], x[(int64_t)(d0 + k0 + 1) * B + b], x[(int64_t)(d0 + k0 + 2) * B + b]); };
+      const M3 R = expMapRot(at3(q, 0));
+      const V3 rn = logMap(mul(R, expMapRot(c.dt * at3(v, 0)))), pn = at3(q, 3) + mul(R, c.dt * at3(v, 3));
+      nq[(int64_t)o * B + b] = cmp < 3 ? pick3(rn, cmp) : pick3(pn, cmp - 3);
     } else if (bd.jtype == JT_BALL) {
       // BallJoint::integratePositionsExplicit (BallJoint.cpp:333-349): R' = R(q) R(w dt); each of the triple's bodies writes its component
       const int d0 = o - bd.ballComp;
@@ -532,6 +539,13 @@ DEV void applyHt(const DevBody& bd, const double* __restrict__ q, int64_t B, int
     const int d0 = bd.dofOff - bd.ballComp;
     const V3 y = mul(expMapJac(mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b])), xi.w);
     out[0] = bd.ballComp == 0 ? y.x : (bd.ballComp == 1 ? y.y : y.z);
+    return;
+  }
+  if (bd.jtype == JT_FREEC) {
+    // free joint below the root (FreeJoint.cpp:790-823): H = blkdiag(expMapJac(r)^T, R^T) in the frame of the first of its six bodies
+    const int d0 = bd.dofOff - bd.ballComp, cmp = bd.ballComp;
+    const V3 r = mk3(q[(int64_t)(d0 + 0) * B + b], q[(int64_t)(d0 + 1) * B + b], q[(int64_t)(d0 + 2) * B + b]);
+    out[0] = cmp < 3 ? pick3(mul(expMapJac(r), xi.w), cmp) : pick3(mul(expMapRot(r), xi.v), cmp - 3);
     return;
   }
   if (bd.jtype != JT_FREE) { out[0] = dot(cV6(bd.S), xi); return; }

@@ -189,8 +189,10 @@ struct ExpandedDesc {
   std::vector<int32_t> parent, jointType, dofOffset, boxBody, bodySkeleton, bodyMap, ballComp;
   std::vector<double> Tpj, Tcj, axis, mass, com, inertia, pitch;
 };
-bool hasBallJoints(const nbl_model_desc* d) {
-  for (int i = 0; i < d->n_bodies; i++) if (d->joint_type[i] == NBL_JOINT_BALL) return true;
+constexpr int NBL_JOINT_FREE_CHAIN = 6;   // internal (= JT_FREEC): one of the six coincident axes of a free joint below the root
+bool hasBallJoints(const nbl_model_desc* d) {   // ... or free joints below the root, which are expanded the same way
+  for (int i = 0; i < d->n_bodies; i++)
+    if (d->joint_type[i] == NBL_JOINT_BALL || (d->joint_type[i] == NBL_JOINT_FREE && d->parent[i] >= 0)) return true;
   return false;
 }
 void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
@@ -214,7 +216,19 @@ void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
     srcBody = i;
     const int par = d->parent[i] < 0 ? -1 : e.bodyMap[d->parent[i]];
     const int skel = d->body_skeleton ? d->body_skeleton[i] : rootOf(i);
-    if (d->joint_type[i] != NBL_JOINT_BALL) {
+    const bool freeBelowRoot = d->joint_type[i] == NBL_JOINT_FREE && d->parent[i] >= 0;
+    if (freeBelowRoot) {
+      // six coincident axes at zero displacement behind T_pj [exp(q_r), q_p]: rotations x, y, z, then translations x, y, z (the order of the
+      // free joint's DOFs; S = Ad(T_cj) is constant in the child frame, FreeJoint.cpp:1049-1056), the first five bodies massless.
+      // qdd_free = qdd_chain + [(wy wz, -wx wz, wx wy); w x u]
+      for (int k = 0; k < 6; k++) {
+        const double ax[3] = {k % 3 == 0 ? 1.0 : 0.0, k % 3 == 1 ? 1.0 : 0.0, k % 3 == 2 ? 1.0 : 0.0};
+        const bool last = k == 5;
+        push(k == 0 ? par : (int)e.parent.size() - 1, NBL_JOINT_FREE_CHAIN, d->dof_offset[i] + k, k == 0 ? d->T_pj + 12 * i : I12,
+             last ? d->T_cj + 12 * i : I12, ax, last ? d->mass[i] : 0.0, last ? d->com + 3 * i : nullptr, last ? d->inertia + 6 * i : nullptr,
+             skel, k);
+      }
+    } else if (d->joint_type[i] != NBL_JOINT_BALL) {
       push(par, d->joint_type[i], d->dof_offset[i], d->T_pj + 12 * i, d->T_cj + 12 * i, d->axis + 3 * i, d->mass[i], d->com + 3 * i,
            d->inertia + 6 * i, skel, 0);
     } else {
@@ -282,10 +296,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (b.jtype == NBL_JOINT_WELD)
       return fail(NBL_E_UNSUPPORTED, "weld joints must be merged into their parent before upload (ModelDescription.merge_welds)");
     if (b.jtype != NBL_JOINT_REVOLUTE && b.jtype != NBL_JOINT_PRISMATIC && b.jtype != NBL_JOINT_FREE && b.jtype != NBL_JOINT_BALL &&
-        b.jtype != NBL_JOINT_SCREW)
+        b.jtype != NBL_JOINT_SCREW && !(ballModel && b.jtype == NBL_JOINT_FREE_CHAIN))
       return fail(NBL_E_UNSUPPORTED, "joint type outside the hot-path scope (revolute, prismatic, screw, free, ball)");
-    if (b.jtype == NBL_JOINT_FREE && b.parent != -1)
-      return fail(NBL_E_UNSUPPORTED, "free joints are supported as tree roots only");
+    if (b.jtype == NBL_JOINT_FREE && b.parent != -1) return fail(NBL_E_BADARG, "internal: a free joint below the root was not expanded");
     b.freeIdx = -1; b.ballComp = ballModel ? expanded.ballComp[i] : 0;
     b.root = b.parent < 0 ? i : hb[b.parent].root; b.padr = 0;
     b.level = b.parent < 0 ? 0 : hb[b.parent].level + 1;
@@ -307,12 +320,13 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     const double* p = b.Tcj + 9;
     double Ra[3];
     for (int r = 0; r < 3; r++) Ra[r] = R[3 * r] * b.axis[0] + R[3 * r + 1] * b.axis[1] + R[3 * r + 2] * b.axis[2];
-    if (b.jtype == NBL_JOINT_REVOLUTE || b.jtype == NBL_JOINT_BALL) {   // ball: one of the three coincident axes (expandBallJoints)
+    const bool chainRot = b.jtype == NBL_JOINT_FREE_CHAIN && b.ballComp < 3, chainLin = b.jtype == NBL_JOINT_FREE_CHAIN && b.ballComp >= 3;
+    if (b.jtype == NBL_JOINT_REVOLUTE || b.jtype == NBL_JOINT_BALL || chainRot) {   // ball / free below the root: one of the coincident axes (expandBallJoints)
       b.S[0] = Ra[0]; b.S[1] = Ra[1]; b.S[2] = Ra[2];
       b.S[3] = p[1] * Ra[2] - p[2] * Ra[1];
       b.S[4] = p[2] * Ra[0] - p[0] * Ra[2];
       b.S[5] = p[0] * Ra[1] - p[1] * Ra[0];
-    } else if (b.jtype == NBL_JOINT_PRISMATIC) {
+    } else if (b.jtype == NBL_JOINT_PRISMATIC || chainLin) {
       b.S[3] = Ra[0]; b.S[4] = Ra[1]; b.S[5] = Ra[2];
     } else if (b.jtype == NBL_JOINT_SCREW) {            // Ad(T_cj) [axis; h axis], ScrewJoint.cpp:160-179
       b.screwRate = (d->pitch ? d->pitch[i] : 0.1) / (2.0 * M_PI);

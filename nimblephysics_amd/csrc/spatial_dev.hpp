@@ -337,4 +337,19 @@ DEV void so3IntegrationVjp(V3 q, V3 w, double dt, V3 g, V3& posT, V3& velT) {
   velT = dt * expMapRot_vjp(dt * w, mulAtB(R, Rnb));
 }
 
+// The same for the free joint's q' = [logMap(R(r) R(w dt)); p + R(r) vl dt] (FreeJoint.cpp:922-929): posPos^T g and velPos^T g, 6 entries each.
+DEV void se3IntegrationVjp(V3 r, V3 w, V3 vl, double dt, V3 grn, V3 gpn, double (&posT)[6], double (&velT)[6]) {
+  const M3 R = expMapRot(r), E = expMapRot(dt * w);
+  const M3 Rnb = logMap_vjp(mul(R, E), grn);
+  M3 Rb = mulABt(Rnb, E);
+  const V3 vdt = dt * vl;
+  Rb.m[0] += gpn.x * vdt.x; Rb.m[1] += gpn.x * vdt.y; Rb.m[2] += gpn.x * vdt.z;   // p' = p + R vdt
+  Rb.m[3] += gpn.y * vdt.x; Rb.m[4] += gpn.y * vdt.y; Rb.m[5] += gpn.y * vdt.z;
+  Rb.m[6] += gpn.z * vdt.x; Rb.m[7] += gpn.z * vdt.y; Rb.m[8] += gpn.z * vdt.z;
+  const V3 posr = expMapRot_vjp(r, Rb), velw = dt * expMapRot_vjp(dt * w, mulAtB(R, Rnb)), vell = dt * tmul(R, gpn);
+  posT[0] = posr.x; posT[1] = posr.y; posT[2] = posr.z; posT[3] = gpn.x; posT[4] = gpn.y; posT[5] = gpn.z;
+  velT[0] = velw.x; velT[1] = velw.y; velT[2] = velw.z; velT[3] = vell.x; velT[4] = vell.y; velT[5] = vell.z;
+}
+DEV double pick3(V3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
 }  // namespace nbl

@@ -127,3 +127,44 @@ def test_the_references_ball_joint_test_worlds_equal_the_oracle(name):
     assert all(b.joint_type == "ball" for b in md.bodies)
     err, _, _ = _compare(md, 64, 60, vel=2.0)
     assert err.max() < TOL, err.max()
+
+
+def free_below_root_model(seed, ground=False):
+    """A free joint BELOW other bodies (a pallet carried by an arm) and a second one below a free root; frames, inertias and joint
+    properties random."""
+    import nimblephysics_amd as na
+    from test_ball_joint import _T
+    rng = np.random.default_rng(400 + seed)
+    def body(name, parent, jt, **kw):
+        A = rng.normal(size=(3, 3)); I = A @ A.T * 0.02 + 0.03 * np.eye(3)
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        root = parent < 0 and jt == "free"
+        return na.BodySpec(name, parent, jt, name + "_joint", axis=tuple(ax) if jt == "revolute" else (0.0, 0.0, 1.0),
+                           T_pj=np.eye(4) if root else _T(rng, 0.25), T_cj=np.eye(4) if root else _T(rng, 0.1), mass=float(rng.uniform(0.5, 2.0)),
+                           com=tuple(rng.normal(0, 0.04, 3)), inertia=(I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]), **kw)
+    bodies = [body("base", -1, "free"), body("arm", 0, "revolute"),
+              body("pallet", 1, "free", damping=tuple(rng.uniform(0.1, 1.0, 6)), spring=tuple(rng.uniform(0.5, 3.0, 6)), rest=tuple(rng.normal(0, 0.1, 6))),
+              body("box", 2, "revolute"), body("drone", 0, "free")]
+    boxes = []
+    if ground:
+        boxes = [na.BoxSpec(-1, na.make_transform((0, -0.005, 0)), (20.0, 0.01, 20.0), 1.0), na.SphereSpec(2, np.eye(4), 0.12, 0.8),
+                 na.BoxSpec(4, np.eye(4), (0.2, 0.15, 0.1), 0.9), na.SphereSpec(0, np.eye(4), 0.1, 0.7)]
+    return na.ModelDescription("free_below_root", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=8 if ground else 0)
+
+
+@pytest.mark.parametrize("vel", [1.0, 12.0])
+def test_free_joints_below_the_root_equal_the_oracle(vel):
+    """FreeJoint anywhere in the tree (the reference's joint is not tied to the root): on the device six coincident axes (3 rotations,
+    3 translations) behind T_pj [exp(q_r), q_p] plus the closed-form term [(wy wz, -wx wz, wx wy); w x u]."""
+    md = free_below_root_model(0)
+    assert md.num_dofs == 6 + 1 + 6 + 1 + 6
+    err, _, _ = _compare(md, 64, 70, vel=vel)
+    assert err.max() < TOL, err.max()
+
+
+def test_free_joints_below_the_root_in_contact_and_through_a_rollout():
+    md = free_below_root_model(1, ground=True)
+    err, status, rstatus = _compare(md, 256, 71, on_ground=True, vel=0.3)
+    assert np.array_equal(status & 1, rstatus & 1) and (status & 1).mean() > 0.2
+    ok = ((status | rstatus) & 0x80) == 0
+    assert (err[ok] > 1e-5).sum() == 0 and np.median(err[ok]) < TOL, (np.sort(err[ok])[-5:], (err[ok] > TOL).sum())

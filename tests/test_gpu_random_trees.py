@@ -38,7 +38,7 @@ def random_tree(rng, nb, shape, free_root, welds=0, colliders=0, spheres=False, 
         if welds and i > 0 and rng.random() < welds:
             jt = "weld"
         elif balls and i > 0 and rng.random() < balls:
-            jt = "ball"
+            jt = "ball" if rng.random() < 0.8 else "free"          # ... and free joints below the root
         axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
         nd = {"free": 6, "weld": 0, "ball": 3}.get(jt, 1)
         A = rng.normal(size=(3, 3)); I = A @ A.T * 0.05 + 0.05 * np.eye(3)
