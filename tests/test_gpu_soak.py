@@ -65,3 +65,14 @@ def test_random_models_ten_metres_from_the_world_origin_all_worlds_vs_oracle():
     assert tot["MISMATCH"] == 0, tot
     assert tot["contact"] > 0.1 * tot["worlds"], tot
     assert tot["gt1e-7"] <= 0.002 * tot["worlds"], tot
+
+
+def test_dense_step_jacobians_of_random_models_vs_oracle():
+    """tools/soak_jacobians.py: every column of d next / d state and d next / d action (2n vector-Jacobian products through the snapshot
+    interface) against the oracle's World::getStateJacobian / getActionJacobian on random models with ball and free joints, in and out of
+    contact.  Soak of the round: 150 models x 4 worlds: worst 1.9e-9."""
+    import soak_jacobians
+    tot = soak_jacobians.run(12000, 25, 4, "balls", verbose=False)
+    print(tot)
+    assert tot["worlds"] >= 80 and tot["contact"] > 0
+    assert tot["gt1e-5"] == 0 and tot["gt1e-7"] <= 1, tot
