@@ -76,3 +76,14 @@ def test_dense_step_jacobians_of_random_models_vs_oracle():
     print(tot)
     assert tot["worlds"] >= 80 and tot["contact"] > 0
     assert tot["gt1e-5"] == 0 and tot["gt1e-7"] <= 1, tot
+
+
+def test_warm_started_second_step_of_random_models_vs_oracle():
+    """tools/soak_warm.py: a cold step, then a second step whose LCP starts from the first step's solution (the reference's solver carries
+    mX between steps), device and oracle each with their own; every world of the second step against the oracle.  Soak of the round: 600
+    models (balls + multi) x 256: 0 mismatches."""
+    import soak_warm
+    tot = soak_warm.run(13000, 30, 256, "balls", verbose=False)
+    print(tot)
+    assert tot["MISMATCH"] == 0, tot
+    assert tot["contact2"] > 0.1 * tot["worlds"] and tot["stage0"] > 0.3 * tot["contact2"], tot      # the warm start does resolve worlds at stage 0
