@@ -9,7 +9,7 @@ Conventions follow the reference's dart/utils/urdf/DartLoader.cpp (parameters on
     from it), which fixes the DOF order of the skeleton
   * collision boxes -> box colliders with the collision origin as the shape's relative transform (:612-616);
     mesh / capsule / cylinder colliders (libccd path, not vendored) raise, or are dropped on request
-Revolute, continuous, prismatic and fixed joints; joint Coulomb friction and other joint types raise.
+Revolute, continuous, prismatic, fixed, floating and planar joints (every type DartLoader::createDartJoint knows); joint Coulomb friction raises.
 """
 import os
 import xml.etree.ElementTree as ET
@@ -113,6 +113,11 @@ def load_urdf(path, name=None, weld_joints=(), drop_unsupported_colliders=False)
                 axis = _floats(j.find("axis").get("xyz")) if j.find("axis") is not None else [1, 0, 0]
             elif jt == "fixed" or jn in weld_joints:
                 jtype, axis = "weld", [0, 0, 1]
+            elif jt == "floating":                       # FreeJoint with the basic properties only (DartLoader.cpp:487-494)
+                jtype, axis = "free", [0, 0, 1]
+            elif jt == "planar":                         # PlanarJoint with its default XY plane; URDF limits are not read (:495-503)
+                jtype, axis = "planar", [0, 0, 1]
+                kw["axes"] = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0)]
             else:
                 raise ValueError(f"{jn}: joint type {jt} outside scope")
             bodies.append(BodySpec(c, parent_index, jtype, jn, axis=tuple(axis), T_pj=_origin(j), mass=mass, com=com,

@@ -74,9 +74,26 @@ def test_urdf_subset_loader_builds_the_expected_model(tmp_path):
 
 def test_unsupported_urdf_features_raise(tmp_path):
     f = tmp_path / "bad.urdf"
-    f.write_text(URDF.replace('type="continuous"', 'type="floating"'))
+    f.write_text(URDF.replace('type="continuous"', 'type="spherical"'))
     with pytest.raises(ValueError):
         na.load_urdf(str(f))
+    f.write_text(URDF.replace("</robot>", '<link name="hull"><collision><geometry><mesh filename="hull.stl"/></geometry></collision></link>'
+                                          '<joint name="hull_fixed" type="fixed"><parent link="base"/><child link="hull"/></joint></robot>'))
+    with pytest.raises(ValueError):                      # a collider outside the analytic narrow phases is not dropped silently ...
+        na.load_urdf(str(f))
+    assert len(na.load_urdf(str(f), drop_unsupported_colliders=True).bodies) == 6          # ... unless asked to
+
+
+def test_urdf_floating_and_planar_joints_like_dart_loader(tmp_path):
+    """DartLoader::createDartJoint (DartLoader.cpp:487-503): floating -> FreeJoint (here below another body: six coincident axes on the
+    device), planar -> PlanarJoint in its default XY plane (a translational-x, translational-y, rotational-z chain)."""
+    f = tmp_path / "fp.urdf"
+    f.write_text(URDF.replace('type="continuous"', 'type="floating"').replace('name="a_slide" type="prismatic"', 'name="a_slide" type="planar"'))
+    md = na.load_urdf(str(f))
+    types = {b.name: b.joint_type for b in md.bodies}
+    assert types["lower"] == "free" and md.bodies[[b.name for b in md.bodies].index("lower")].parent >= 0
+    assert [types[k] for k in ("slider#v0", "slider#v1", "slider")] == ["prismatic", "prismatic", "revolute"]
+    assert md.num_dofs == 6 + 3 + 1 + 6
 
 
 REF_URDF = "/root/reference/data/sdf/atlas/atlas_v3_box_colliders.urdf"
