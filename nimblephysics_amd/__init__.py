@@ -7,7 +7,7 @@ from .model import (BodySpec, BoxSpec, ModelDescription, SphereSpec, atlas, box_
                     make_transform, single_pendulum)
 
 __all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
-           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep", "neural", "forwardPass", "BackpropSnapshot",
+           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "load_model", "loadWorld", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep", "neural", "forwardPass", "BackpropSnapshot",
            "LossGradient", "LossGradientHighLevelAPI"]
 
 
@@ -21,7 +21,7 @@ def __getattr__(name):
     if name == "model_from_nimble_world":
         from .extract import model_from_nimble_world
         return model_from_nimble_world
-    if name in ("load_urdf", "load_skel", "with_ground"):
+    if name in ("load_urdf", "load_skel", "with_ground", "load_model", "loadWorld", "load_model", "loadWorld"):
         from . import loaders as _l
         return getattr(_l, name)
     if name in ("neural", "forwardPass", "BackpropSnapshot", "LossGradient", "LossGradientHighLevelAPI"):

@@ -406,3 +406,20 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
     if name is None:
         name = os.path.splitext(os.path.basename(path))[0]
     return ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=max_contacts if boxes else 0)
+
+
+def load_model(path, **kw):
+    """A ModelDescription from a .skel or .urdf file, by extension (the file kinds nimble.loadWorld / UniversalLoader accept on this path)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".skel":
+        return load_skel(path, **kw)
+    if ext == ".urdf":
+        return load_urdf(path, **kw)
+    raise ValueError(f"{path}: unknown model file type {ext!r} (.skel, .urdf)")
+
+
+def loadWorld(path, device="cuda:0", **kw):
+    """nimble.loadWorld(path) for this path: the batched World of the file's model on `device`."""
+    from .world import World
+    return World(load_model(path, **kw), device=device)
+

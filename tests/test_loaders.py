@@ -230,3 +230,13 @@ def test_committed_cfg1_cfg4_descriptions_are_reproducible_from_the_reference_sk
     assert [b.joint_type for b in bs.bodies] == ["weld", "free", "free"] and bs.num_dofs == 12 and bs.max_contacts == 8
     assert [b.mass for b in bs.bodies[1:]] == [0.1, 0.1] and np.allclose(bs.bodies[2].T_pj[:3, 3], (0, 0.2, 0))
     assert [tuple(bx.size) for bx in bs.boxes] == [(2.0, 0.01, 2.0), (0.2, 0.2, 0.2), (0.2, 0.2, 0.2)]
+
+
+def test_load_model_dispatches_on_the_file_type(tmp_path):
+    u = tmp_path / "a.urdf"; u.write_text(URDF)
+    k = tmp_path / "w.skel"; k.write_text(SKEL)
+    assert na.load_model(str(u)).num_dofs == na.load_urdf(str(u)).num_dofs
+    assert [b.name for b in na.load_model(str(k)).bodies] == [b.name for b in na.load_skel(str(k)).bodies]
+    with pytest.raises(ValueError):
+        na.load_model(str(tmp_path / "x.sdf"))
+
