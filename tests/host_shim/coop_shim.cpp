@@ -199,3 +199,14 @@ int shim_coop_cascade(int m, const double* A, const double* b, const double* mu,
   return (int)stOut;
 }
 }
+
+// the exact reverse mode of the SO(3) / SE(3) position integration (spatial_dev.hpp), for the CPU test against finite differences
+extern "C" void shim_so3_integration_vjp(const double* q, const double* w, double dt, const double* g, double* posT, double* velT) {
+  V3 p, v;
+  so3IntegrationVjp(mk3(q[0], q[1], q[2]), mk3(w[0], w[1], w[2]), dt, mk3(g[0], g[1], g[2]), p, v);
+  posT[0] = p.x; posT[1] = p.y; posT[2] = p.z; velT[0] = v.x; velT[1] = v.y; velT[2] = v.z;
+}
+extern "C" void shim_so3_integrate(const double* q, const double* w, double dt, double* out) {
+  const V3 r = logMap(mul(expMapRot(mk3(q[0], q[1], q[2])), expMapRot(dt * mk3(w[0], w[1], w[2]))));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}

@@ -245,3 +245,23 @@ def test_cascade_on_one_constrained_group_equals_the_cascade_of_that_group_alone
             seen.add(st & 0x13c)
             off += m
     assert len(seen) >= 3, seen      # the trials reach several exits of the cascade
+
+
+def test_reverse_mode_of_the_so3_integration_is_exact_up_to_the_log_map_singularity(shim):
+    """spatial_dev.hpp so3IntegrationVjp (the VJP of q' = logMap(exp(q) exp(w dt)) the device uses where the reference finite-differences,
+    BallJoint.cpp:351-408 / FreeJoint.cpp:950-1007) against a five-point stencil of the same function in 80-bit arithmetic, from a generic
+    rotation down to 2e-3 rad short of pi, where logMap in doubles loses digits like 1e-16 / gap^2 (and a quotient in doubles with eps 1e-6,
+    the reference's, is off by 1e-4)."""
+    import sys
+    sys.path.insert(0, HERE)
+    from test_gpu_ball_joint import _so3_vjp_extended_precision
+    rng = np.random.default_rng(21)
+    dt = 1e-3
+    for gap, tol in ((2.0, 1e-9), (0.5, 1e-9), (1e-1, 1e-9), (1e-2, 1e-7), (2e-3, 1e-6)):
+        for _ in range(8):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            q = ax * (np.pi - gap); w = rng.normal(0, 0.5, 3) * rng.choice([1.0, 10.0]); g = rng.normal(0, 1, 3)
+            pT = np.zeros(3); vT = np.zeros(3)
+            shim.shim_so3_integration_vjp(_p(q), _p(w), C.c_double(dt), _p(g), _p(pT), _p(vT))
+            x = _so3_vjp_extended_precision(q, w, dt, g)
+            assert np.abs(np.concatenate([pT, vT]) - x).max() <= tol * np.abs(x).max(), (gap, np.abs(np.concatenate([pT, vT]) - x).max())

@@ -168,3 +168,63 @@ def test_free_joints_below_the_root_in_contact_and_through_a_rollout():
     assert np.array_equal(status & 1, rstatus & 1) and (status & 1).mean() > 0.2
     ok = ((status | rstatus) & 0x80) == 0
     assert (err[ok] > 1e-5).sum() == 0 and np.median(err[ok]) < TOL, (np.sort(err[ok])[-5:], (err[ok] > TOL).sum())
+
+
+def _so3_vjp_extended_precision(q, w, dt, g, h=1e-6):
+    """posPos^T g and velPos^T g of q' = logMap(exp(q) exp(w dt)) by a five-point stencil in 80-bit arithmetic: logMap itself loses digits
+    like 1e-16 / gap^2 next to pi, which a difference quotient in doubles divides by its step."""
+    ld = np.longdouble
+    def expm(r):
+        th = np.sqrt((r * r).sum())
+        K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]], dtype=ld)
+        if th < 1.0e-3:                                  # the reference's Taylor branch (Geometry.cpp:539-553): part of the function
+            return np.eye(3, dtype=ld) + K + ld(0.5) * (K @ K)
+        return np.eye(3, dtype=ld) + (np.sin(th) / th) * K + ((1 - np.cos(th)) / (th * th)) * (K @ K)
+    def logm(R):
+        th = np.arccos((np.trace(R) - 1) / 2)
+        return (th / (2 * np.sin(th))) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]], dtype=ld)
+    q, w, g = (np.asarray(x, dtype=ld) for x in (q, w, g))
+    f = lambda qq, ww: (logm(expm(qq) @ expm(ww * ld(dt))) * g).sum()
+    out = np.zeros(6)
+    for j in range(3):
+        e = np.zeros(3, dtype=ld); e[j] = ld(h)
+        out[j] = float((-f(q + 2 * e, w) + 8 * f(q + e, w) - 8 * f(q - e, w) + f(q - 2 * e, w)) / (12 * ld(h)))
+        out[3 + j] = float((-f(q, w + 2 * e) + 8 * f(q, w + e) - 8 * f(q, w - e) + f(q, w - 2 * e)) / (12 * ld(h)))
+    return out
+
+
+def test_near_the_log_map_singularity_the_device_is_exact_where_the_references_finite_differences_are_not():
+    """The reference finite-differences the position integration of free and ball joints (FreeJoint.cpp:950-1007, BallJoint.cpp:351-408:
+    central differences in doubles, eps 1e-6).  Where the next rotation angle comes within ~1e-2 rad of pi, logMap loses digits like
+    1e-16 / gap^2 and the quotient divides that by 1e-6: off by 1e-6 .. 1e-4 (measured).  The device carries the exact reverse mode.  With
+    a cotangent on the next POSITIONS only, the state gradient of a ball joint's DOFs is exactly posPos^T g / velPos^T g of its
+    integration: device and oracle against a five-point stencil in 80-bit arithmetic."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    from test_ball_joint import _ball_offsets
+    md = ball_model(10, False, properties=False)
+    n = md.num_dofs; B = 32
+    rng = np.random.default_rng(90)
+    q = rng.normal(0, 0.4, (B, n)); v = rng.normal(0, 0.5, (B, n))
+    offs = _ball_offsets(md)
+    for o in offs:                                                  # every ball joint 2e-3 .. 2e-2 rad short of pi
+        ax = rng.normal(size=(B, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+        q[:, o:o + 3] = ax * (np.pi - rng.uniform(2e-3, 2e-2, (B, 1)))
+    s = np.concatenate([q, v], 1); a = np.zeros((B, len(md.action_map)))
+    g = np.concatenate([rng.normal(0, 1, (B, n)), np.zeros((B, n))], 1)
+    world = na.World(md, device="cuda:0")
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    timestep(world, st, at).backward(torch.tensor(g, device="cuda:0"))
+    dev = st.grad.cpu().numpy()
+    ref = OracleWorld(md).step_batch(s, a, g, threads=8)["grad_state"]
+    e_dev = e_ref = 0.0
+    for w in range(B):
+        for o in offs:
+            x = _so3_vjp_extended_precision(q[w, o:o + 3], v[w, o:o + 3], md.dt, g[w, o:o + 3])
+            idx = list(range(o, o + 3)) + list(range(n + o, n + o + 3))
+            sc = np.abs(x).max()
+            e_dev = max(e_dev, np.abs(dev[w, idx] - x).max() / sc); e_ref = max(e_ref, np.abs(ref[w, idx] - x).max() / sc)
+    print(f"vs the extended-precision stencil: device {e_dev:.1e}, oracle (the reference's quotient in doubles) {e_ref:.1e}")
+    assert e_dev < 1e-6 and e_ref > 20 * e_dev, (e_dev, e_ref)
