@@ -1,5 +1,5 @@
-"""Stress variants of tools/soak_parity.py (balls mode): dt = 5 ms, 8 x the velocities, body masses scaled by 1e-2 .. 1e2, 200 x the torques.
-usage (GPU box): python tools/dbg/stress_soak.py <dt|fast|mass|torque> <first seed> <count>      (round 2: 150 models each, 0 mismatches)"""
+"""Stress variants of tools/soak_parity.py (balls mode): dt = 5 ms, 8 x the velocities, body masses scaled by 1e-2 .. 1e2, 200 x the torques; geom: collider sizes x 0.1 .. 5 per axis; mu: friction 1.01e-3 .. 10; tinydt: dt = 1e-5; nograv.
+usage (GPU box): python tools/dbg/stress_soak.py <dt|fast|mass|torque|geom|mu|tinydt|nograv> <first seed> <count>      (round 2: 150 models each, 0 mismatches)"""
 import os, sys
 ROOT = "/root/repo" if os.path.isdir("/root/repo/tools") else os.environ.get("GRAFT_REPO_ROOT", ".")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -22,6 +22,17 @@ def make_case(seed, B=256, big=False, multi=False, balls=False, far=False):
             f = float(10 ** rng.uniform(-2, 2)); b.mass *= f; b.inertia = tuple(x * f for x in b.inertia)
     if mode == "torque":
         a = a * 200.0
+    if mode == "geom":            # thin plates, sticks, tiny and big colliders
+        for bx in md.boxes[1:]:
+            f = tuple(float(10 ** rng.uniform(-1, 0.7)) for _ in range(3))
+            bx.size = tuple(x * (f[0] if bx.shape == "sphere" else f[k]) for k, x in enumerate(bx.size))
+    if mode == "mu":              # just above the frictionless threshold, and very rough
+        for bx in md.boxes:
+            bx.mu = float(rng.choice([1.01e-3, 2e-3, 5.0, 10.0]))
+    if mode == "tinydt":
+        md.dt = 1e-5
+    if mode == "nograv":
+        md.gravity = (0.0, 0.0, 0.0)
     return md, s, a, g
 soak_parity.make_case = make_case
 print(mode, soak_parity.run(int(sys.argv[2]), int(sys.argv[3]), 256, verbose=False, balls=True))
