@@ -66,7 +66,7 @@ extern "C" {
 #define NBL_ST_LCP_PGS 0x8u       /* CFM + PGS fallback used */
 #define NBL_ST_LCP_NOFRIC 0x10u   /* friction dropped fallback used */
 #define NBL_ST_LCP_FAILED 0x20u   /* every stage failed: impulses zeroed (BoxedLcpConstraintSolver.cpp:679-687) */
-#define NBL_ST_NAN 0x40u          /* non-finite value seen */
+#define NBL_ST_NAN 0x40u          /* non-finite value seen: in the LCP stages, or in the world's next state (NaN / Inf inputs); other worlds are unaffected */
 #define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts than max_contacts; extra ones dropped */
 #define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
 #define NBL_ST_GRAD_PARTIAL 0x200u /* reserved (never set: the EDGE_EDGE contact-geometry gradient terms, DCC.cpp:397-424,

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
   if (nC > 0) st |= 0x1u;
   if (overflow) st |= 0x80u;
   (void)edge;
-  if (status) status[b] = st;
+  if (status) status[b] |= st;          // the forward tree kernel initialised the word (0, or NBL_ST_NAN for a non-finite unconstrained step)
   NBL_PHASE(60);
   if (!doTwists || !__any(nC > 0)) return;   // k_step_forward_coop already left the twists
   // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_VTW (the dead bias

@@ -84,7 +84,7 @@ DEV int coopGroups(const W& w, const DevContactModel* __restrict__ cm, const dou
 
 // x, classes, cfm, warm start, v' = v_pre + M^-1 J^T x and (when valid) the pseudo-inverse of the final Q -> saved record
 template <class W>
-DEV void coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValid,
+DEV uint32_t coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValid,
                             double* __restrict__ saved, const SavedLayout& lay, double* __restrict__ dn,
                             double* __restrict__ cacheOut, double* __restrict__ nv, int64_t B, int64_t b) {
   const int ln = w.lane();
@@ -97,6 +97,7 @@ DEV void coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, cons
   if (ln < MAX_ROWS) svAt(saved, lay.cfm + ln, B, b) = cfm;     // this row's constant (its group's, CFM_CONSTANTS)
   if (ln == 0) svAt(saved, lay.pflag, B, b) = pinvValid ? 1.0 : 0.0;
   // v' = v_pre + M^-1 J^T x  (lane = DOF)
+  double vNext = 0.0;
   if (ln < MAXR) S.vec[2][ln] = X;
   w.sync();
   if (ln < n) {
@@ -104,12 +105,14 @@ DEV void coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, cons
 #pragma unroll
     for (int r = 0; r < MAXR; r++) wd = fma(r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, S.vec[2][r], wd);   // columns >= m were never written
     svAt(saved, lay.w + ln, B, b) = wd;
-    nv[(int64_t)ln * B + b] = svAt(saved, lay.vpre + ln, B, b) + wd;
+    vNext = svAt(saved, lay.vpre + ln, B, b) + wd;
+    nv[(int64_t)ln * B + b] = vNext;
   }
   if (pinvValid && ln < MAXR) {
 #pragma unroll
     for (int i = 0; i < MAXR; i++) dn[lay.pinv + i * MAX_ROWS + ln] = S.P[i * CLD + ln];
   }
+  return w.ballot(!__builtin_isfinite(vNext)) != 0ull ? 0x40u : 0u;   // NBL_ST_NAN: a non-finite next velocity (poisoned inputs end up here)
 }
 
 // MULTI: the model has colliders on more than one skeleton, so a world can hold several constrained groups (decided when the model
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
     CoopStage0 out;
     coopStage0(w, S, R, haveCache, Xcache, out);
     if (out.ok) {
-      coopContactOutputs(w, S, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
-      if (ln == 0 && status) status[b] |= 0x2u | 0x100u;
+      const uint32_t nanBit = coopContactOutputs(w, S, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+      if (ln == 0 && status) status[b] |= 0x2u | 0x100u | nanBit;
       NBL_PHASE(47);
     } else {
       // the pre-solve x (mXBackup) is what the PGS fallback starts from (BoxedLcpConstraintSolver.cpp:541-547)
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
       coopPinv(w, a, S, K.nc);
       pinvValid = true;
     }
-    coopContactOutputs(w, S, n, m, X, K, 0.0, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
-    if (ln == 0 && status) status[b] |= 0x2u | 0x100u;
+    const uint32_t nanBit = coopContactOutputs(w, S, n, m, X, K, 0.0, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+    if (ln == 0 && status) status[b] |= 0x2u | 0x100u | nanBit;
   } else {
     // rows of resolved groups: their result (x, class) waits in the scratch rows for k_contact_cascade_final
     if (ln < MAX_ROWS) {
@@ -339,8 +342,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
     coopPinv(w, a, S, K.nc);
     pinvValid = true;
   }
-  coopContactOutputs(w, S, n, m, X, K, cfmRow, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
-  if (ln == 0 && status) status[b] |= st;
+  const uint32_t nanBit = coopContactOutputs(w, S, n, m, X, K, cfmRow, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+  if (ln == 0 && status) status[b] |= st | nanBit;
 #ifdef NBL_CASCADE_TIMING
   if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
 #endif

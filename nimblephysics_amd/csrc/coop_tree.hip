@@ -348,7 +348,22 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_step
   }
   NBL_PHASE(9);
   if (saved && lay.treeRows > 0) coopStoreTree(c, saved, lay);
-  if (status && c.lane == 0) status[b] = 0u;
+  if (status) {
+    // NBL_ST_NAN for worlds whose unconstrained step is not finite (poisoned inputs, a singular model): every lane looks at what it wrote
+    // for its own body's DOFs, the lanes of a world vote
+    bool bad = false;
+    if (c.lane < c.nb) {
+      const DevBody& bd = bodies[c.lane];
+      for (int k = 0; k < bd.ndof; k++) {
+        const int64_t d = bd.dofOff + k;
+        bad = bad || !__builtin_isfinite(next[d * B + b]) || !__builtin_isfinite(next[((int64_t)mdl.n + d) * B + b]);
+      }
+    }
+    const uint64_t votes = (uint64_t)__ballot(bad ? 1 : 0);
+    const int grp = (int)(threadIdx.x & 63u) / c.nbp;
+    const uint64_t gmask = c.nbp >= 64 ? ~0ull : ((1ull << c.nbp) - 1ull) << (grp * c.nbp);
+    if (c.lane == 0) status[b] = (votes & gmask) != 0ull ? 0x40u : 0u;
+  }
   NBL_PHASE(10);
 }
 

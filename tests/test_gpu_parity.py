@@ -216,3 +216,26 @@ def test_results_do_not_depend_on_the_distance_from_the_world_origin(contact, sh
         res[sh] = (nv, st.grad.cpu().numpy()[:, n:], at.grad.cpu().numpy())
     for x0, x1 in zip(res[0.0], res[shift]):            # the device against itself: velocities and the velocity / action gradients
         assert np.abs(x0 - x1).max() / np.abs(x0).max() < 1e-9
+
+
+def test_poisoned_worlds_are_flagged_and_do_not_touch_their_neighbours():
+    """NaN position, Inf velocity and NaN torque in single worlds of a batch: those worlds carry NBL_ST_NAN, every other world's result is bit for
+    bit what it is without them (with and without colliders)."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from util import cfg_inputs, contact_inputs
+    for contact in (True, False):
+        md, s, a = contact_inputs("atlas20", 64, 1, joint_noise=0.02) if contact else cfg_inputs("atlas20", 64, 1)
+        sp, ap = s.copy(), a.copy()
+        sp[3, 7] = np.nan; sp[5, 25] = np.inf; ap[9, 2] = np.nan
+        bad = [3, 5, 9]; good = [i for i in range(64) if i not in bad]
+        outs = []
+        for x, u in ((s, a), (sp, ap)):
+            world = na.World(md, device="cuda:0")
+            st = torch.tensor(x, device="cuda:0", requires_grad=True); at = torch.tensor(u, device="cuda:0", requires_grad=True)
+            out = timestep(world, st, at); out.sum().backward()
+            outs.append((out.detach().cpu().numpy(), st.grad.cpu().numpy(), world.last_status.cpu().numpy().astype(np.uint32)))
+        (o0, g0, s0), (o1, g1, s1) = outs
+        assert (s1[bad] & 0x40).all() and not (s0[bad] & 0x40).any()         # (the bit also reports a NaN inside the LCP stages: healthy worlds may carry it)
+        assert np.array_equal(o0[good], o1[good]) and np.array_equal(g0[good], g1[good]) and np.array_equal(s0[good], s1[good])
