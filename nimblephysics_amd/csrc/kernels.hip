@@ -469,7 +469,11 @@ __global__ __launch_bounds__(64) void k_step_forward(DevModel mdl, const DevBody
   if (b >= mdl.b1) return;
   Ctx c = makeCtx(mdl, bodies, dofs, ws, B, b, saved, &lay);
   stepForwardCore(c, state, action, next, saved, lay);
-  if (status) status[b] = 0u;
+  if (status) {                                         // NBL_ST_NAN for a non-finite unconstrained step (like k_step_forward_coop)
+    bool bad = false;
+    for (int d = 0; d < 2 * mdl.n; d++) bad = bad || !__builtin_isfinite(next[(int64_t)d * B + b]);
+    status[b] = bad ? 0x40u : 0u;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
