@@ -42,6 +42,19 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # fp64 vector peak = 1/2 of the 157.3 TF fp32 vector peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 
 
+def csrc_sha16():
+    """Tag of the built kernels: sha256 over nimblephysics_amd/csrc/* and include/nimble_amd.h (sorted by name), first 16 hex digits.
+    profiles/fp64_flops.json and pmc_traffic.json carry the tag of the sources they were counted on (tools/profile.sh writes it on the
+    GPU box); counters of other sources are stale and are not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nimblephysics_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "nimble_amd.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def make_workload(name, B, seed, joint_noise):
     from util import cfg_inputs, contact_inputs
     if name == "atlas20_contact":
@@ -50,7 +63,8 @@ def make_workload(name, B, seed, joint_noise):
                           f"foot-corner contacts (24 LCP rows), pose q[0]=-pi/2 q[4]=-0.01 + N(0,{joint_noise}^2) joint noise")
     if name == "atlas33_contact":
         md, s, a = contact_inputs("atlas33", B, seed, joint_noise=joint_noise, vel_noise=joint_noise / 2, action_noise=0.1)
-        return md, s, a, "Atlas 33-DOF standing on the ground box, 8 frictional contacts (cfg5 pose)"
+        return md, s, a, ("Atlas 33-DOF standing on the ground box, 8 frictional foot-corner contacts (24 LCP rows), cfg5 pose "
+                          f"q[0]=-pi/2 q[4]=-0.01 + N(0,{joint_noise}^2) joint noise")
     key = {"atlas20_freefall": "atlas20", "atlas33_freefall": "atlas33", "cartpole": "cartpole"}[name]
     md, s, a = cfg_inputs(key, B, seed)
     return md, s, a, f"{key} without contact"
@@ -159,6 +173,8 @@ def main():
     ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: timed region without the per-kernel HIP events")
     ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (torch.distributed.run, one process per GPU, RCCL) even for --gpus 1")
+    ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed region until this much time has been timed; the median repetition is reported")
+    ap.add_argument("--max-reps", type=int, default=25)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,7 +219,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(noise, steps, warmup, kernel_timing):
+    def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0):
         """W untimed + K timed fwd+bwd steps on a fresh synthetic batch of the workload at pose noise `noise`."""
         md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, noise)
         worlds = [na.World(md, device=dev) for _ in bounds]
@@ -245,23 +261,32 @@ def main():
         # per-kernel HIP events on a sample of the timed steps (every 8th): events around all ~12 launches of every step cost 8 %
         timing_period = 8 if steps >= 32 else (4 if steps >= 8 else 1)
         world.set_timing(kernel_timing, timing_period)
-        t0 = time.perf_counter()
-        grad, status = run(steps)
-        sync()
-        elapsed = time.perf_counter() - t0
+        # The timed region = EXACTLY `steps` steps between barrier + synchronize on both sides, max over ranks.  A short region (the
+        # driver's --steps 20 is 12 ms) is a noisy sample: it is repeated until `min_seconds` have been timed (every rank takes the
+        # same decision from the max-over-ranks time) and the MEDIAN repetition is reported.
+        reps = []
+        while True:
+            t0 = time.perf_counter()
+            grad, status = run(steps)
+            sync()
+            el = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            reps.append(el)
+            assert torch.isfinite(grad).all()
+            if sum(reps) >= min_seconds or len(reps) >= args.max_reps:
+                break
+        elapsed = sorted(reps)[len(reps) // 2]
         tm = world.get_timing()
         world.set_timing(False)
-        if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        assert torch.isfinite(grad).all()
         st = status.cpu().numpy().astype(np.uint32)
-        return {"elapsed": elapsed, "status": st, "timing": tm, "timing_period": timing_period, "md": md, "s": s_np, "a": a_np,
+        return {"elapsed": elapsed, "reps": reps, "status": st, "timing": tm, "timing_period": timing_period, "md": md, "s": s_np, "a": a_np,
                 "desc": wl_desc, "world": world, "slices": len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))}
 
     has_contact = args.workload.endswith("_contact")
-    R = measure(args.joint_noise, args.steps, args.warmup, not args.no_kernel_timing)
+    R = measure(args.joint_noise, args.steps, args.warmup, not args.no_kernel_timing, args.min_seconds)
     easy = None
     if has_contact and args.easy_noise > 0 and args.easy_noise != args.joint_noise:
         # the easy distribution: every world resolves at LCP stage 0 (round 1's headline), half the steps, no kernel events
@@ -290,35 +315,69 @@ def main():
         achieved = alg_launch_bytes / (kern[dom] * 1e-3) / 1e9
         traffic = None
         prof_key = f"{args.workload}@{args.joint_noise:g}"
+        built = csrc_sha16()
+        stale = []
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                per_kernel = tj.get(prof_key, tj.get(args.workload, {}))
-                traffic = next((v for kname, v in per_kernel.items() if kname.split("<")[0] == dom), None)   # template suffixes: k<false>
+                if tj.get("_csrc_sha16", {}).get(prof_key) == built:
+                    per_kernel = tj.get(prof_key, {})
+                    traffic = next((v for kname, v in per_kernel.items() if kname.split("<")[0] == dom), None)   # template suffixes: k<false>
+                elif prof_key in tj:
+                    stale.append("pmc_traffic.json")
             except Exception:
                 traffic = None
         # fp64 roofline: flop COUNTED by the SQ instruction counters (tools/profile.sh pass `fp64`, aggregated by
-        # tools/aggregate_profile.py into profiles/fp64_flops.json): 2 x FMA + ADD + MUL + TRANS wave-instructions x active lanes
+        # tools/aggregate_profile.py into profiles/fp64_flops.json): 2 x FMA + ADD + MUL + TRANS wave-instructions x active lanes.
+        # Only counters taken on the kernels that are built right now are used (tag = hash of csrc/).
         fp64 = None
         ffile = os.path.join(ROOT, "profiles", "fp64_flops.json")
         if os.path.exists(ffile):
             try:
                 fj = json.load(open(ffile)).get(prof_key)
-                if fj:
+                if fj and fj.get("csrc_sha16") == built:
                     fl = float(fj["flops_per_world_step"])
                     per_gpu_rate = value / world_size
-                    fp64 = {"flops_per_world_step": fl, "counted_by": fj.get("counted_by"), "achieved_TFs": fl * per_gpu_rate / 1e12,
+                    fp64 = {"flops_per_world_step": fl, "counted_by": fj.get("counted_by"), "csrc_sha16": built,
+                            "achieved_TFs": fl * per_gpu_rate / 1e12,
                             "peak_TFs": FP64_PEAK_TFLOPS, "frac": fl * per_gpu_rate / 1e12 / FP64_PEAK_TFLOPS,
                             "mfma_f64_wave_instr_per_world_step": fj.get("mfma_f64_wave_instr_per_world_step"),
                             "valu_lane_utilisation": fj.get("valu_lane_utilisation")}
+                    # the dominant kernel on its own: its counted flop per launch / its average launch duration (HIP events)
+                    kd = next((v for kname, v in fj.get("kernels", {}).items() if kname.split("<")[0] == dom), None)
+                    if kd:
+                        k_tfs = kd["flops_per_world"] * (B // slices) / (kern[dom] * 1e-3) / 1e12
+                        fp64["dominant_kernel"] = {"kernel": dom, "flops_per_launch": kd["flops_per_world"] * (B // slices), "avg_launch_ms": kern[dom],
+                                                   "achieved_TFs": k_tfs, "frac": k_tfs / FP64_PEAK_TFLOPS, "avg_active_lanes": kd.get("avg_active_lanes")}
+                elif fj:
+                    stale.append("fp64_flops.json")
             except Exception:
                 fp64 = None
+        hbm = {"kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+               "algorithmic_bytes_per_launch": alg_launch_bytes, "worlds_per_launch": B // slices,
+               "algorithmic_bytes_per_step": alg_step_bytes, "avg_launch_ms": kern[dom],
+               "whole_step_achieved_GBs": alg_step_bytes * max(1, args.rollout) / (elapsed / args.steps) / 1e9,
+               "whole_step_frac": alg_step_bytes * max(1, args.rollout) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
+        common = {"stream_slices": slices, "kernels_avg_ms": kern, "step_kernel_ms": step_kernel_ms, "timed_every_nth_step": timing_period,
+                  "csrc_sha16": built, "stale_counter_files_ignored": stale}
+        if fp64 is not None:
+            # ~300 flop per algorithmic byte - the fp64 vector ALU is the roof that binds, so it is the primary fraction
+            # (whole step: counted flop per world-step x measured rate); the HBM figures north_star asks for ride along under `hbm`.
+            roof = {"bound": "fp64", "kernel": "whole step (all kernels of one forward + one backward)", "achieved": fp64["achieved_TFs"],
+                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64["frac"], "traffic": traffic, "fp64": fp64, "hbm": hbm, **common,
+                    "note": "fp64-ALU / latency bound (SURVEY.md 8d); peak = fp64 vector peak 78.6 TF (v_fma_f64 measured at 62.5 TF, "
+                            "v_mfma_f64 at 49.0 TF on this chip: profiles/r02c_fp64_rate.jsonl); flop counted by SQ_INSTS_VALU_*_F64"}
+        else:
+            roof = {"bound": "hbm", **hbm, "fp64": None, **common,
+                    "note": "no fp64 flop count for the kernels built right now (profiles/fp64_flops.json is absent or was counted on other "
+                            "sources: run tools/profile.sh + tools/aggregate_profile.py): HBM fraction only; the path is fp64-ALU / latency bound"}
         out = {
             "metric": "worlds*timesteps/sec fwd+bwd", "value": value, "unit": "worlds*timesteps/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "reps": len(R["reps"]), "reps_ms_per_step": [round(r / args.steps * 1e3, 4) for r in R["reps"]], "timed_seconds": sum(R["reps"]),
             "config": {"workload": f"{wl_desc}; batch={B} worlds/GPU; fwd+bwd through the C ABI, cold LCP start each step" +
                                    (f"; one step = one {args.rollout}-step rollout fwd+bwd (warm-started after its first step)" if args.rollout else ""),
                        "n_dofs": n, "contacts": m_rows // 3, "lcp_rows": m_rows, "worlds_per_gpu": B, "dt": md.dt,
@@ -329,15 +388,7 @@ def main():
                        "lanes_resolved_at_lcp_stage0": float((st & 0x2).astype(bool).mean()) if m_rows else None,
                        "lanes_unresolved": float((st & 0x20).astype(bool).mean()),
                        "collective": "1 all-gather of the shared-control gradient per timed region"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_launch_bytes, "worlds_per_launch": B // slices, "stream_slices": slices,
-                         "algorithmic_bytes_per_step": alg_step_bytes, "avg_launch_ms": kern[dom],
-                         "kernels_avg_ms": kern, "step_kernel_ms": step_kernel_ms, "timed_every_nth_step": timing_period,
-                         "whole_step_achieved_GBs": alg_step_bytes * max(1, args.rollout) / (elapsed / args.steps) / 1e9,
-                         "fp64": fp64,
-                         "note": "the path is fp64-ALU/latency bound, not HBM bound (~1e2-1e3 flop/byte, SURVEY.md 8d); "
-                                 "the HBM fraction is reported because north_star asks for it, the fp64 fraction next to it"},
+            "roofline": roof,
         }
         if easy is not None:
             est = easy["status"]

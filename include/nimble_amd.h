@@ -235,6 +235,11 @@ int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const doub
 int32_t nbl_set_body_inertias(nbl_model* m, int32_t count, const int32_t* bodies, const double* mass, const double* com,
                               const double* inertia, void* stream);
 int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG);
+/* The same, stream-ordered: a table of the size already registered (World::setMasses with new values) is ONE asynchronous copy on
+ * `stream` - launches issued on that stream before the call read the old table, later ones the new one, no device synchronisation;
+ * a table of another size is registration-time work and synchronises the device.  (nbl_set_inertia_params synchronises the device
+ * around the copy in every case.) */
+int32_t nbl_set_inertia_params_on(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG, void* stream);
 int32_t nbl_num_inertia_params(const nbl_model* m);
 int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double* grad_params, int32_t accumulate,
                              void* workspace, size_t workspace_bytes, void* stream);

@@ -55,6 +55,8 @@ def lib():
     L.nbl_set_body_inertias.restype = C.c_int32
     L.nbl_set_inertia_params.argtypes = [vp, C.c_int32, vp, vp]
     L.nbl_set_inertia_params.restype = C.c_int32
+    L.nbl_set_inertia_params_on.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.nbl_set_inertia_params_on.restype = C.c_int32
     L.nbl_num_inertia_params.argtypes = [vp]
     L.nbl_num_inertia_params.restype = C.c_int32
     L.nbl_backward_inertia.argtypes = [vp, C.c_int64, vp, vp, C.c_int32, vp, C.c_size_t, vp]
@@ -102,7 +104,7 @@ EXPORTED_SYMBOLS = [
     "nbl_last_error", "nbl_version", "nbl_device_count", "nbl_model_create", "nbl_model_destroy",
     "nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows", "nbl_workspace_bytes", "nbl_saved_bytes",
     "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing", "nbl_set_launch_lanes", "nbl_set_slices", "nbl_slices_for", "nbl_rollout_workspace_bytes", "nbl_rollout_forward", "nbl_rollout_backward",
-    "nbl_set_body_inertia", "nbl_set_body_inertias", "nbl_set_inertia_params", "nbl_num_inertia_params", "nbl_backward_inertia", "nbl_rollout_backward_inertia",
+    "nbl_set_body_inertia", "nbl_set_body_inertias", "nbl_set_inertia_params", "nbl_set_inertia_params_on", "nbl_num_inertia_params", "nbl_backward_inertia", "nbl_rollout_backward_inertia",
     "nbl_rollout_checkpoint_bytes", "nbl_rollout_forward_checkpointed", "nbl_rollout_backward_checkpointed",
     "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing", "nbl_selftest_lcp_dantzig",
 ]

@@ -765,7 +765,7 @@ int32_t nbl_set_body_inertias(nbl_model* m, int32_t count, const int32_t* bodies
   DeviceGuard guard(m->device);
   if (!guard.ok) return fail(NBL_E_HIP, "hipSetDevice failed");
   const size_t bytes = sizeof(DevBody) * (size_t)m->nb;
-  const int32_t rc = ensureStaging(m, bytes + sizeof(DevInertiaParam) * 64);
+  const int32_t rc = ensureStaging(m, bytes + sizeof(DevInertiaParam) * (size_t)std::max(64, m->nParams));
   if (rc != NBL_OK) return rc;
   HIP_TRY(hipEventSynchronize(m->staged));   // the previous upload has finished reading the staging area (normally long ago)
   for (int i = 0; i < count; i++) packSpatialInertia(mass[i], com + 3 * i, inertia + 6 * i, m->hBodies[m->deviceBody(bodies[i])].G);
@@ -785,7 +785,10 @@ int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const doub
   return NBL_OK;
 }
 
-int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG) {
+// The registered inertia parameters.  A table of another size is registration-time work (device synchronisation, reallocation); a
+// table of the SAME size - every World.setMasses with new values - is one stream-ordered copy on `stream` through the pinned staging
+// area, like nbl_set_body_inertias: launches issued on that stream before the call read the old table, later ones the new one.
+int32_t nbl_set_inertia_params_on(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG, void* stream) {
   if (!m || count < 0 || (count > 0 && (!bodies || !dG))) return fail(NBL_E_BADARG, "bad argument");
   for (int p = 0; p < count; p++)
     if (bodies[p] < 0 || bodies[p] >= m->userBodies) return fail(NBL_E_BADARG, "inertia parameter on an unknown body");
@@ -811,9 +814,25 @@ int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodie
     return NBL_OK;
   }
   if (count == 0) return NBL_OK;
-  // same size (setMasses with new values): a blocking copy on the legacy stream orders it after the work already issued there;
-  // callers that drive other streams pass through World.setMasses, which changes the masses between steps
-  HIP_TRY(hipMemcpy(m->dParams, hp.data(), sizeof(DevInertiaParam) * (size_t)count, hipMemcpyHostToDevice));
+  const size_t bodyBytes = sizeof(DevBody) * (size_t)m->nb, tableBytes = sizeof(DevInertiaParam) * (size_t)count;
+  const int32_t rc = ensureStaging(m, bodyBytes + std::max(tableBytes, sizeof(DevInertiaParam) * 64));
+  if (rc != NBL_OK) return rc;
+  HIP_TRY(hipEventSynchronize(m->staged));   // the previous upload has finished reading the staging area
+  std::memcpy((char*)m->staging + bodyBytes, hp.data(), tableBytes);
+  HIP_TRY(hipMemcpyAsync(m->dParams, (char*)m->staging + bodyBytes, tableBytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipEventRecord(m->staged, (hipStream_t)stream));
+  return NBL_OK;
+}
+
+// The same without a stream: ordered against EVERYTHING in flight on the device (synchronises it before and after the copy).
+int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG) {
+  if (!m) return fail(NBL_E_BADARG, "bad argument");
+  DeviceGuard guard(m->device);
+  if (!guard.ok) return fail(NBL_E_HIP, "hipSetDevice failed");
+  HIP_TRY(hipDeviceSynchronize());
+  const int32_t rc = nbl_set_inertia_params_on(m, count, bodies, dG, nullptr);
+  if (rc != NBL_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return NBL_OK;
 }
 

@@ -130,6 +130,11 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
             index[b.getName()] = gidx
             for k in range(int(b.getNumShapeNodes())):
                 sn = b.getShapeNode(k)
+                # the loaders of the reference create separate visual-only and collision shape nodes for the same geometry
+                # (SkelParser.cpp:612-640 createShapeNodeWith<VisualAspect> / <CollisionAspect, DynamicsAspect>, DartLoader.cpp): only
+                # nodes with a CollisionAspect are collision objects (ShapeFrame.cpp: DARTPY_DEFINE_SPECIALIZED_ASPECT(CollisionAspect))
+                if not sn.hasCollisionAspect():
+                    continue
                 shp = sn.getShape()
                 T = np.eye(4)
                 T[:3, :3] = np.asarray(sn.getRelativeRotation(), dtype=np.float64).reshape(3, 3)

@@ -140,11 +140,21 @@ def load_urdf(path, name=None, weld_joints=(), drop_unsupported_colliders=False)
 def with_ground(model, ground):
     """One world from two skeletons (the reference loads the robot and the ground URDF into the same World)."""
     nb = len(model.bodies)
-    bodies = list(model.bodies)
     boxes = list(model.boxes)
-    for b in ground.bodies:
+    # skeleton ids: both descriptions number their skeletons from 0 (or not at all): resolve each on its own, then put the ground's
+    # after the model's - otherwise two mobile skeletons with the same id would never collide (CollisionFilter.cpp:105-154)
+    ids_m, ids_g = model.body_skeletons(), ground.body_skeletons()
+    dense_m = {v: k for k, v in enumerate(sorted(set(ids_m)))}
+    dense_g = {v: k + len(dense_m) for k, v in enumerate(sorted(set(ids_g)))}
+    bodies = []
+    for b, sk in zip(model.bodies, ids_m):
+        nbdy = BodySpec(**{**b.__dict__})
+        nbdy.skeleton = dense_m[sk]
+        bodies.append(nbdy)
+    for b, sk in zip(ground.bodies, ids_g):
         nbdy = BodySpec(**{**b.__dict__})
         nbdy.parent = b.parent + nb if b.parent >= 0 else -1
+        nbdy.skeleton = dense_g[sk]
         bodies.append(nbdy)
     for bx in ground.boxes:
         boxes.append(BoxSpec(bx.body + nb if bx.body >= 0 else -1, bx.T, bx.size, bx.mu, bx.shape, bx.restitution))
@@ -253,10 +263,24 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                 I6 = tuple(_text(moi, k, 0.0) for k in ("ixx", "iyy", "izz", "ixy", "ixz", "iyz"))
             else:
                 I6 = (1.0, 1.0, 1.0, 0.0, 0.0, 0.0)
-                shp = shapes_of(b)                               # the first shape's inertia for this mass (:618-645)
+                # the inertia of the body's FIRST ShapeNode for this mass (:618-645); visualization shapes are read before collision
+                # shapes (:612-616), so that is the first <visualization_shape> when there is one
+                shp = []
                 vis = b.find("visualization_shape")
-                if not shp and vis is not None and vis.find("geometry/box") is not None:
-                    shp = [("box", tuple(float(x) for x in vis.find("geometry/box/size").text.split()), np.eye(4))]
+                if vis is not None:
+                    vg = vis.find("geometry")
+                    if vg is not None and vg.find("box") is not None:
+                        shp = [("box", tuple(float(x) for x in vg.find("box/size").text.split()), np.eye(4))]
+                    elif vg is not None and vg.find("ellipsoid") is not None:
+                        d = [float(x) for x in vg.find("ellipsoid/size").text.split()]
+                        if abs(d[0] - d[1]) <= 1e-12 and abs(d[0] - d[2]) <= 1e-12:
+                            shp = [("sphere", (d[0] / 2,) * 3, np.eye(4))]
+                        else:
+                            raise ValueError(f"{path}: default inertia of body {b.get('name')} from an anisotropic ellipsoid is outside the subset")
+                    elif vg is not None and len(vg):
+                        raise ValueError(f"{path}: default inertia of body {b.get('name')} from a {vg[0].tag} visualization shape is outside the subset")
+                if not shp:
+                    shp = shapes_of(b)
                 if shp:
                     kind, size, _ = shp[0]
                     if kind == "box":                            # BoxShape::computeInertia (BoxShape.cpp:74-83)
@@ -266,14 +290,26 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                         I6 = (0.4 * mass * size[0] ** 2,) * 3 + (0.0, 0.0, 0.0)
             return mass, com, I6
 
+        # Assembly order = body and DOF order of the reference (readSkeleton :999-1040 with getNextJointAndNodePair :753-805): take the
+        # lowest remaining joint in file order; if its parent body does not exist yet, create the parent's joint first (and that one's
+        # missing ancestors before it), then go on from the lowest remaining joint.
         pending = list(joints)
+        creating = set()
         while pending:
-            progressed = False
-            for j in list(pending):
+            j = pending[0]
+            while True:                                          # hoist the missing ancestors
+                pn = j.find("parent").text.strip()
+                if pn == "world" or pn in index:
+                    break
+                if pn not in child_joint or pn in creating:
+                    raise ValueError(f"{path}: joints of skeleton {sk.get('name')} do not form a tree rooted in the world "
+                                     f"(parent body {pn} of joint {j.get('name')})")
+                creating.add(pn)
+                j = child_joint[pn]
+            creating.clear()
+            if True:
                 pn = j.find("parent").text.strip()
                 cn = j.find("child").text.strip()
-                if pn != "world" and pn not in index:
-                    continue
                 jt = j.get("type")
                 c2j = _skel_T(j)
                 parentW = np.eye(4) if pn == "world" else Tw[pn]
@@ -397,9 +433,6 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                 for kind, size, Ts in shapes_of(bel[cn]):
                     boxes.append(BoxSpec(base, Ts, size, 1.0, kind))
                 pending.remove(j)
-                progressed = True
-            if not progressed:
-                raise ValueError(f"{path}: joints of skeleton {sk.get('name')} do not form a tree rooted in the world")
         missing = set(bel) - set(child_joint)
         if missing:
             raise ValueError(f"{path}: bodies without a parent joint: {sorted(missing)}")

@@ -339,9 +339,18 @@ class ModelDescription:
         bodies of one skeleton."""
         if all(b.skeleton >= 0 for b in self.bodies):
             return [int(b.skeleton) for b in self.bodies]
-        out = []
+        # untagged bodies (-1): one skeleton per tree, numbered after the recorded ids so that a tagged and an untagged model
+        # merged into one world (loaders.with_ground) neither share a skeleton nor split one
+        base = max([int(b.skeleton) for b in self.bodies if b.skeleton >= 0], default=-1) + 1
+        out, tree_id = [], {}
         for i, b in enumerate(self.bodies):
-            out.append(i if b.parent < 0 else out[b.parent])
+            if b.skeleton >= 0:
+                out.append(int(b.skeleton))
+            elif b.parent < 0 or self.bodies[b.parent].skeleton >= 0:
+                tree_id[i] = base + len(tree_id)        # the root of an untagged (sub)tree
+                out.append(tree_id[i])
+            else:
+                out.append(out[b.parent])
         return out
 
     def has_welds(self) -> bool:

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import numpy as np
 import torch
 
 from ._lib import NimbleAmdError
@@ -113,8 +114,26 @@ class BackpropSnapshot:
     def getStatus(self): return self._out(self._status)                                              # NBL_ST_* word per world
 
     def _check(self, world):
-        if world is not self._world and world.md is not self._world.md:
+        """The record is read against the model constants of the world that is passed in: the world that took the snapshot, or one
+        with the same model on the same device (a `clone()`; the reference's snapshots are likewise used with clones of their world,
+        MultiShot.cpp:66-70)."""
+        if world is self._world:
+            return
+        same = (isinstance(world, World) and world.device == self._world.device and _same_model(world.model, self._world.model))
+        if not same:
             raise NimbleAmdError("this snapshot was taken on another world")
+
+
+def _same_model(a, b) -> bool:
+    if a is b:
+        return True
+    if (tuple(a.gravity), a.dt, a.max_contacts, a.contact_clipping_depth, a.fallback_cfm, bool(a.penetration_correction)) != \
+            (tuple(b.gravity), b.dt, b.max_contacts, b.contact_clipping_depth, b.fallback_cfm, bool(b.penetration_correction)):
+        return False
+    fa, fb = a.flat(), b.flat()
+    if fa.keys() != fb.keys():
+        return False
+    return all(np.array_equal(np.asarray(fa[k]), np.asarray(fb[k])) for k in fa)
 
 
 def forwardPass(world: World, idempotent: bool = False) -> BackpropSnapshot:

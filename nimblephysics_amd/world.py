@@ -261,22 +261,23 @@ class World:
             masses = masses.detach().cpu().numpy()
         self._wrt_mass.set(np.asarray(masses, dtype=np.float64))
         new = self.description.merge_welds() if self.description.has_welds() else self.description
-        changed = []
+        changed, values = [], {}
         for i, new_b in enumerate(new.bodies):
             cur = (float(new_b.mass), tuple(float(x) for x in new_b.com), tuple(float(x) for x in new_b.inertia))
             if cur != self._uploaded_inertia[i]:
                 changed.append(i)
-                self._uploaded_inertia[i] = cur
+                values[i] = cur
         if changed:
-            import numpy as np
             idx = np.asarray(changed, dtype=np.int32)
-            mass = np.asarray([self._uploaded_inertia[i][0] for i in changed], dtype=np.float64)
-            com = np.asarray([self._uploaded_inertia[i][1] for i in changed], dtype=np.float64).reshape(-1, 3)
-            ine = np.asarray([self._uploaded_inertia[i][2] for i in changed], dtype=np.float64).reshape(-1, 6)
+            mass = np.asarray([values[i][0] for i in changed], dtype=np.float64)
+            com = np.asarray([values[i][1] for i in changed], dtype=np.float64).reshape(-1, 3)
+            ine = np.asarray([values[i][2] for i in changed], dtype=np.float64).reshape(-1, 6)
             with torch.cuda.device(self.device):
                 check(self._L.nbl_set_body_inertias(self._h, len(changed), idx.ctypes.data_as(C.c_void_p), mass.ctypes.data_as(C.c_void_p),
                                                     com.ctypes.data_as(C.c_void_p), ine.ctypes.data_as(C.c_void_p), self._stream()),
                       "nbl_set_body_inertias")
+            for i in changed:                     # only now: a failed upload leaves host and device views in step
+                self._uploaded_inertia[i] = values[i]
         if new is not self.model:
             new._action_map = self.model._action_map
             self.model = new
@@ -286,8 +287,9 @@ class World:
     def _push_inertia_params(self):
         bodies, dG = self._wrt_mass.device_table()
         cnt = int(bodies.shape[0])
-        check(self._L.nbl_set_inertia_params(self._h, cnt, bodies.ctypes.data_as(C.c_void_p) if cnt else None,
-                                             dG.ctypes.data_as(C.c_void_p) if cnt else None), "nbl_set_inertia_params")
+        with torch.cuda.device(self.device):     # stream-ordered like the body constants it belongs to (same stream)
+            check(self._L.nbl_set_inertia_params_on(self._h, cnt, bodies.ctypes.data_as(C.c_void_p) if cnt else None,
+                                                    dG.ctypes.data_as(C.c_void_p) if cnt else None, self._stream()), "nbl_set_inertia_params_on")
 
     def backward_inertia_soa(self, saved: torch.Tensor, B: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """dL/dmass of every world, [massDims][B], for the record whose backward_soa was the LAST call on this world

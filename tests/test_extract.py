@@ -23,7 +23,11 @@ class _Shape:
 
 
 class _ShapeNode:
-    def __init__(self, bx): self._bx = bx
+    """The reference's loaders give a body one visual-only ShapeNode AND one collision ShapeNode per geometry (SkelParser.cpp:612-640,
+    DartLoader.cpp createShapeNodeWith<VisualAspect> / <CollisionAspect, DynamicsAspect>): the stand-in does the same."""
+    def __init__(self, bx, collision=True): self._bx, self._collision = bx, collision
+    def hasCollisionAspect(self): return self._collision
+    def hasVisualAspect(self): return not self._collision
     def getShape(self): return _Shape(self._bx)
     def getRelativeTranslation(self): return np.array(self._bx.T)[:3, 3].copy()
     def getRelativeRotation(self): return np.array(self._bx.T)[:3, :3].copy()
@@ -80,8 +84,11 @@ class _Body:
     def getRestitutionCoeff(self):
         es = [bx.restitution for bx in self._md.boxes if bx.body == self._i]
         return float(es[0]) if es else 0.0
-    def getNumShapeNodes(self): return sum(1 for bx in self._md.boxes if bx.body == self._i)
-    def getShapeNode(self, k): return _ShapeNode([bx for bx in self._md.boxes if bx.body == self._i][k])
+    def _shape_nodes(self):        # visual-only nodes first, like the loaders create them
+        mine = [bx for bx in self._md.boxes if bx.body == self._i]
+        return [_ShapeNode(bx, collision=False) for bx in mine] + [_ShapeNode(bx) for bx in mine]
+    def getNumShapeNodes(self): return len(self._shape_nodes())
+    def getShapeNode(self, k): return self._shape_nodes()[k]
 
 
 class _Skeleton:

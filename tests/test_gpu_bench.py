@@ -26,10 +26,17 @@ def test_bench_self_launch_path_one_gpu():
     assert d["value"] > 0 and d["steps"] == 2 and d["scaling"] == "weak"
     assert d["config"]["joint_noise"] == 0.02 and 0.3 < d["config"]["lanes_resolved_at_lcp_stage0"] < 0.7
     assert d["secondary"]["stage0_only"]["lanes_resolved_at_lcp_stage0"] == 1.0
-    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "fp64"}
+    r = d["roofline"]
+    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "fp64", "csrc_sha16"}
+    # the fp64 fraction is the primary one only when the flop count was taken on the kernels that are built right now
+    assert (r["bound"] == "fp64" and r["fp64"]["csrc_sha16"] == r["csrc_sha16"] and r["unit"] == "TFLOP/s" and "hbm" in r) or \
+           (r["bound"] == "hbm" and r["fp64"] is None and r["unit"] == "GB/s")
+    assert 0 < r["frac"] < 1
+    assert d["reps"] >= 2 and d["timed_seconds"] >= 0.25 and len(d["reps_ms_per_step"]) == d["reps"]     # a 2-step region is repeated
 
 
 def test_bench_cfg5_workload_is_selectable():
     """cfg5's per-GPU share: Atlas-33 on the ground, T = 64 trajectory (a short batch here)."""
     d = _run(["--workload", "atlas33_contact", "--rollout", "8", "--steps", "1", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--easy-noise", "0"])
     assert d["config"]["n_dofs"] == 33 and d["config"]["rollout_T"] == 8 and d["value"] > 0
+    assert "N(0,0.02^2)" in d["config"]["workload"]

@@ -1,0 +1,123 @@
+"""cfg5 on its OWN distribution (BASELINE.json configs[4]): Atlas-33 standing on the ground box, pose of
+unittests/unit/test_AtlasGradients.cpp:235-236 (q[0] = -pi/2, q[4] = -0.01) plus joint noise N(0, 0.02^2): about half of the worlds
+leave LCP stage 0 and run the fallback cascade of BoxedLcpConstraintSolver.cpp:461-677 on the 33-DOF model.  Every world's next state
+and both gradients against the oracle; a warm-started T = 8 trajectory against the oracle's chain."""
+import numpy as np
+import pytest
+
+from parity import KEYS, assert_match_or_reference_unstable, world_errors
+from util import contact_inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+NORTH_STAR_TOL = 1e-5
+STAGE_BITS = 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100
+
+
+def _cfg5_inputs(B, seed):
+    return contact_inputs("atlas33", B, seed, joint_noise=0.02, vel_noise=0.01, action_noise=0.1)
+
+
+@pytest.mark.parametrize("B,seed", [(1024, 5), (2048, 55)])
+def test_cfg5_atlas33_cascade_every_world_vs_oracle(B, seed):
+    """Cold start, one step fwd+bwd: the criterion of test_full_lcp_cascade_on_noisy_poses on the 33-DOF model."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    md, s, a = _cfg5_inputs(B, seed)
+    g = np.random.default_rng(seed + 1).normal(0, 1, s.shape)
+    world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    out = timestep(world, st, at)
+    status = world.last_status.cpu().numpy().astype(np.uint32)
+    out.backward(torch.tensor(g, device="cuda:0"))
+    ref = ow.step_batch(s, a, g, threads=8)
+    dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
+    gpu0, ora0 = (status & 0x2) != 0, (ref["status"] & 0x2) != 0
+    assert np.all(status & 0x1) and not np.any(status & 0x80)          # 8 contacts everywhere, none dropped
+    assert np.array_equal(gpu0, ora0)                                   # the same worlds short-circuit at stage 0
+    assert 0.2 < gpu0.mean() < 0.8, gpu0.mean()                         # the cascade is really exercised on this model
+    print(f"[cfg5 atlas33 sigma=0.02 B={B}] stage 0: {gpu0.mean():.3f}; ended in another stage than in the oracle: "
+          f"{int(((status & STAGE_BITS) != (ref['status'] & STAGE_BITS)).sum())}; fell through every stage: {((status & 0x20) != 0).mean():.3f}")
+    errs, _ = world_errors(dev, ref)
+    unstable, _ = assert_match_or_reference_unstable(f"cfg5 atlas33 sigma=0.02 B={B}", ow, s, a, g, dev, ref, NORTH_STAR_TOL,
+                                                     max_unstable=0.01 * B)
+    for k in KEYS:                                                      # stage-0 worlds: 1e-7
+        assert errs[k][gpu0].max() < TOL, (k, errs[k][gpu0].max())
+
+
+def test_cfg5_atlas33_warm_started_trajectory_vs_oracle_chain():
+    """T = 8 warm-started steps at sigma = 0.02 (the reference's solver carries mX between steps, BoxedLcpConstraintSolver.cpp:176-187).
+    (1) `rollout` equals the chain of `timestep` calls bit for bit.  (2) EVERY step of the trajectory against the oracle started from
+    the same state and the same warm start (the device's: on the rank-deficient A of two flat feet two valid solutions differ in the
+    null space of A and the next step depends on which one it starts from), next state and both gradients of every world, criterion
+    as above.  (3) The trajectory gradient (loss |q_T|^2 + |v_T|^2) against the oracle's backward chain over the same records: every
+    world within 1e-5, except worlds that step (2) proved reference-unstable at some step."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout, timestep
+    from oracle import OracleWorld
+    B, T = 512, 8
+    md, s0, a0 = _cfg5_inputs(B, 57)
+    rng = np.random.default_rng(58)
+    acts = np.repeat(a0[:, None, :], T, 1) + rng.normal(0, 0.05, (B, T, a0.shape[1]))
+    ow = OracleWorld(md)
+    stride = 3 * md.max_contacts
+
+    # the chain of single steps, keeping what entered every step
+    world = na.World(md, device="cuda:0")
+    world.reset_lcp_cache()
+    x = torch.tensor(s0, device="cuda:0")
+    states, caches, statuses, per_step = [s0], [], [], []
+    for t in range(T):
+        cache = world.lcp_cache.clone().cpu().numpy() if world.lcp_cache is not None else None
+        caches.append(cache)
+        xt = x.detach().clone().requires_grad_(True); at = torch.tensor(acts[:, t], device="cuda:0", requires_grad=True)
+        y = timestep(world, xt, at)
+        statuses.append(world.last_status.cpu().numpy().astype(np.uint32))
+        g = np.random.default_rng(100 + t).normal(0, 1, s0.shape)
+        y.backward(torch.tensor(g, device="cuda:0"))
+        per_step.append({"g": g, "dev": {"next": y.detach().cpu().numpy(), "grad_state": xt.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}})
+        x = y.detach()
+        states.append(x.cpu().numpy())
+
+    def warm(t):
+        if t == 0 or caches[t] is None:
+            return {}
+        c = caches[t]                                                     # [25][B]: 24 impulses + the row count they belong to
+        return {"lcp_in": np.ascontiguousarray(c[:stride].T), "lcp_len_in": c[-1].astype(np.int32)}
+
+    ever_unstable = np.zeros(B, bool)
+    stage0_warm = []
+    for t in range(T):
+        kw = warm(t)
+        ref = ow.step_batch(states[t], acts[:, t], per_step[t]["g"], threads=8, **kw)
+        assert np.all(statuses[t] & 0x1) and not np.any(statuses[t] & 0x80)
+        errs, _ = world_errors(per_step[t]["dev"], ref)
+        ever_unstable |= np.maximum.reduce([errs[k] for k in KEYS]) > NORTH_STAR_TOL
+        assert_match_or_reference_unstable(f"cfg5 trajectory step {t}", ow, states[t], acts[:, t], per_step[t]["g"], per_step[t]["dev"], ref,
+                                           NORTH_STAR_TOL, lcp=kw.get("lcp_in"), lcp_len=kw.get("lcp_len_in"), max_unstable=0.02 * B)
+        stage0_warm.append(float(((statuses[t] & 0x2) != 0).mean()))
+    print("[cfg5 trajectory] share of worlds resolved at stage 0 per step (step 0 cold, then warm-started):", [round(v, 3) for v in stage0_warm])
+    assert stage0_warm[0] < 0.8
+
+    # the rollout entry points: bit-identical states, trajectory gradient vs the oracle's backward chain
+    world2 = na.World(md, device="cuda:0")
+    st = torch.tensor(s0, device="cuda:0", requires_grad=True); at = torch.tensor(acts, device="cuda:0", requires_grad=True)
+    ys = rollout(world2, st, at, warm_start=True)
+    assert np.array_equal(ys.detach().cpu().numpy(), np.stack(states, 1))
+    (ys[:, -1] ** 2).sum().backward()
+    gcot = 2.0 * states[T]
+    gas = []
+    for t in range(T - 1, -1, -1):
+        r = ow.step_batch(states[t], acts[:, t], gcot, threads=8, **warm(t))
+        gcot = r["grad_state"]; gas.append(r["grad_action"])
+    gas = np.stack(gas[::-1], 1)
+    e_s = np.abs(st.grad.cpu().numpy() - gcot).max(1) / np.abs(gcot).max()
+    e_a = np.abs(at.grad.cpu().numpy() - gas).reshape(B, -1).max(1) / max(np.abs(gas).max(), 1e-30)
+    off = (e_s > NORTH_STAR_TOL) | (e_a > NORTH_STAR_TOL)
+    print(f"[cfg5 trajectory] T = {T} gradient: worlds above 1e-5: {int(off.sum())} of {B} (max state {e_s.max():.2e}, action {e_a.max():.2e}); "
+          f"worlds with a reference-unstable step: {int(ever_unstable.sum())}")
+    assert not np.any(off & ~ever_unstable), np.where(off & ~ever_unstable)[0][:10]
+    assert off.mean() <= 0.05

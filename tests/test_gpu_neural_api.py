@@ -79,3 +79,23 @@ def test_snapshot_jacobians_are_the_blocks_of_the_oracles_dense_jacobians():
     assert np.array_equal(snap.getPosPosJacobian(world).cpu().numpy(), Js[:, :n, :n]) and np.array_equal(snap.getVelPosJacobian(world).cpu().numpy(), Js[:, :n, n:])
     assert np.array_equal(snap.getPosVelJacobian(world).cpu().numpy(), Js[:, n:, :n]) and np.array_equal(snap.getVelVelJacobian(world).cpu().numpy(), Js[:, n:, n:])
     assert np.array_equal(snap.getControlForceVelJacobian(world).cpu().numpy(), Ja[:, n:, :])
+
+
+def test_a_snapshot_serves_a_clone_of_its_world_and_refuses_another_model():
+    """BackpropSnapshot._check: the world that took the snapshot or one with the same model (a clone(): the reference hands its
+    snapshots to clones of the world, MultiShot.cpp:66-70); a world of another model raises NimbleAmdError, not AttributeError."""
+    import torch
+    import nimblephysics_amd as nimble
+    md, s, a = contact_inputs("atlas20", 16, 75)
+    world = nimble.World(md, device="cuda:0")
+    world.setState(torch.tensor(s)); world.setAction(torch.tensor(a))
+    snap = nimble.neural.forwardPass(world, idempotent=True)
+    g = torch.tensor(np.random.default_rng(76).normal(0, 1, s.shape))
+    r1 = snap.backpropState(world, g)
+    r2 = snap.backpropState(world.clone(), g)
+    assert torch.equal(r1.lossWrtState, r2.lossWrtState) and torch.equal(r1.lossWrtAction, r2.lossWrtAction)
+    other = nimble.World(nimble.atlas("atlas20", ground=False), device="cuda:0")
+    with pytest.raises(nimble.neural.NimbleAmdError):
+        snap.backpropState(other, g)
+    with pytest.raises(nimble.neural.NimbleAmdError):
+        snap.getStateJacobian(other)

@@ -240,3 +240,60 @@ def test_load_model_dispatches_on_the_file_type(tmp_path):
     with pytest.raises(ValueError):
         na.load_model(str(tmp_path / "x.sdf"))
 
+
+
+SKEL_ORDER = """<?xml version="1.0" ?>
+<skel version="1.0"><world name="w">
+  <skeleton name="s">
+    <body name="A"><transformation>0 0 0 0 0 0</transformation></body>
+    <body name="B"><transformation>1 0 0 0 0 0</transformation>
+      <inertia><mass>2</mass></inertia>
+      <visualization_shape><geometry><box><size>0.3 0.2 0.1</size></box></geometry></visualization_shape>
+      <collision_shape><geometry><box><size>1 1 1</size></box></geometry></collision_shape></body>
+    <body name="C"><transformation>2 0 0 0 0 0</transformation></body>
+    <body name="D"><transformation>3 0 0 0 0 0</transformation></body>
+    <joint type="revolute" name="jD"><parent>C</parent><child>D</child><axis><xyz>0 0 1</xyz></axis></joint>
+    <joint type="revolute" name="jC"><parent>B</parent><child>C</child><axis><xyz>0 0 1</xyz></axis></joint>
+    <joint type="revolute" name="jB"><parent>world</parent><child>B</child><axis><xyz>0 0 1</xyz></axis></joint>
+    <joint type="revolute" name="jA"><parent>world</parent><child>A</child><axis><xyz>0 0 1</xyz></axis></joint>
+  </skeleton>
+</world></skel>
+"""
+
+
+def test_skel_assembly_order_and_default_inertia_follow_the_reference(tmp_path):
+    """readSkeleton (SkelParser.cpp:999-1040, getNextJointAndNodePair :753-805): the lowest remaining joint in file order is created next,
+    after its missing ancestors - jD needs C needs B: B, C, D, and only then jA - which is the skeleton's body and DOF order.  A body
+    with a mass but no moment takes the inertia of its FIRST shape node, and visualization shapes are read before collision shapes
+    (:612-645)."""
+    f = tmp_path / "o.skel"
+    f.write_text(SKEL_ORDER)
+    md = na.load_skel(str(f))
+    assert [b.name for b in md.bodies] == ["B", "C", "D", "A"]
+    assert [b.parent for b in md.bodies] == [-1, 0, 1, -1]
+    B = md.bodies[0]
+    assert np.allclose(B.inertia, (2 / 12 * (0.2 ** 2 + 0.1 ** 2), 2 / 12 * (0.3 ** 2 + 0.1 ** 2), 2 / 12 * (0.3 ** 2 + 0.2 ** 2), 0, 0, 0))
+    loop = tmp_path / "loop.skel"
+    loop.write_text(SKEL_ORDER.replace("<parent>world</parent><child>B</child>", "<parent>D</parent><child>B</child>"))
+    with pytest.raises(ValueError):
+        na.load_skel(str(loop))
+
+
+def test_with_ground_keeps_the_skeletons_of_both_models_apart(tmp_path):
+    """Both descriptions number their skeletons from 0: merged as they are, the ground's mobile bodies would share skeleton 0 with the
+    model's and never collide with it (CollisionFilter.cpp:105-154).  An untagged model (one skeleton per tree) merged with a tagged one
+    must neither split the tagged skeleton nor join it."""
+    f = tmp_path / "w.skel"; f.write_text(SKEL)
+    a = na.load_skel(str(f), skeletons=["arm"]); b = na.load_skel(str(f), skeletons=["arm"])
+    assert set(a.body_skeletons()) == {1}                                   # the file's skeleton index
+    both = na.with_ground(a, b)
+    assert both.body_skeletons() == [0, 0, 1, 1]
+    u = tmp_path / "a.urdf"; u.write_text(URDF)
+    untagged = na.load_urdf(str(u))
+    assert all(bd.skeleton < 0 for bd in untagged.bodies)
+    mixed = na.with_ground(a, untagged)
+    sk = mixed.body_skeletons()
+    assert sk[:2] == [0, 0] and len(set(sk[2:])) == len({i for i, bd in enumerate(untagged.bodies) if bd.parent < 0}) and 0 not in sk[2:]
+    for i, bd in enumerate(mixed.bodies[2:], start=2):                       # a tree of the untagged model stays one skeleton
+        if bd.parent >= 0:
+            assert sk[i] == sk[bd.parent]

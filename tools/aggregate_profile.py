@@ -11,6 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, workload = sys.argv[1], sys.argv[2]
 WPL = int(sys.argv[3]) if len(sys.argv) > 3 else 1024   # worlds covered by one kernel launch of the profiled bench
 P = os.path.join(ROOT, "gpurun_out", "prof")
+# the kernels the counters were taken on: tools/profile.sh writes the hash of csrc/ it saw on the GPU box (bench.csrc_sha16)
+_tagfile = os.path.join(P, f"{tag}_csrc_sha16.txt")
+CSRC_SHA16 = open(_tagfile).read().strip() if os.path.exists(_tagfile) else None
 
 
 def find(sub, pat):
@@ -48,6 +51,7 @@ out[workload] = {k: (fetch.get(k, 0) + write.get(k, 0)) * 1024 for k in sorted(s
 out.setdefault("_detail", {})[workload] = {k: {"fetch_kb_per_launch": fetch.get(k, 0), "write_kb_per_launch": write.get(k, 0),
                                                "launches_profiled": cf.get(k, 0)} for k in out[workload]}
 out["_tag"] = tag
+out.setdefault("_csrc_sha16", {})[workload] = CSRC_SHA16
 json.dump(out, open(tf, "w"), indent=1)
 print(json.dumps(out[workload], indent=1))
 print("total per step launch (MB):", sum(v for k, v in out[workload].items() if k != "k_transpose") / 1e6)
@@ -99,7 +103,7 @@ try:
                    "instructions (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU); summed over the kernels of one forward + one backward step.")
     fo[workload] = {"flops_per_world_step": tot_flops, "f64_wave_instr_per_world_step": tot_wave_f64, "mfma_f64_wave_instr_per_world_step": tot_mfma,
                     "valu_lane_utilisation": (lanes_w / (tot_wave_f64 * WPL) / 64.0) if tot_wave_f64 else None,
-                    "counted_by": f"SQ_INSTS_VALU_*_F64 x active lanes, profiles tag {tag}", "worlds_per_launch": WPL, "kernels": per}
+                    "counted_by": f"SQ_INSTS_VALU_*_F64 x active lanes, profiles tag {tag}", "csrc_sha16": CSRC_SHA16, "worlds_per_launch": WPL, "kernels": per}
     json.dump(fo, open(ff, "w"), indent=1)
     print("fp64 flop per world-step:", tot_flops, " f64 wave-instr per world-step:", tot_wave_f64, " MFMA f64:", tot_mfma)
 except SystemExit as e:

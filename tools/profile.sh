@@ -4,10 +4,11 @@
 #   usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---steps 8 --warmup 2 --no-cpu-baseline --easy-noise 0}
+ARGS=${*:---steps 8 --warmup 2 --no-cpu-baseline --easy-noise 0 --min-seconds 0}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
+python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.csrc_sha16())" > $OUT/${TAG}_csrc_sha16.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $REPO/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1

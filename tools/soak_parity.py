@@ -73,13 +73,16 @@ def make_case(seed, B=256, big=False, multi=False, balls=False, far=False):
     return md, s, a, g
 
 
-def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False, far=False):
+def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False, far=False, mutate=None):
+  """mutate(seed, md, s, a, g) -> (md, s, a, g): a stress variant applied to every case (tools/soak_stress.py)."""
   tot = {"worlds": 0, "contact": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "MISMATCH": 0}
   for seed in range(first, first + count):
       case = make_case(seed, B, big, multi, balls, far)
       if case is None:
           continue
       md, s, a, g = case
+      if mutate is not None:
+          md, s, a, g = mutate(seed, md, s, a, g)
       world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
       st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
       out = timestep(world, st, at)

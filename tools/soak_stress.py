@@ -1,0 +1,75 @@
+"""Stress variants of the randomised parity soak (tools/soak_parity.py, ball-joint mode): the same random models pushed to the edges of
+the parameter space, every world's next state and both gradients against the oracle with the soak's criterion.  In the GPU suite at
+reduced size as tests/test_gpu_stress.py.
+  dt      time step 5 ms                       tinydt  time step 1e-5
+  fast    8 x the velocities                   torque  200 x the torques
+  mass    body masses scaled by 1e-2 .. 1e2    nograv  no gravity
+  geom    collider sizes x 0.1 .. 5 per axis (thin plates, sticks, tiny and big colliders)
+  mu      friction from 1.01e-3 (just above the frictionless threshold) to 10
+  subset  a random third of the DOFs actuated (World::setActionSpace; unmapped torques are zero)
+  atlimit positions, velocities and torques exactly at their limits in half of the worlds (clipLossGradientsToBounds)
+usage (GPU box): python tools/soak_stress.py <mode> [first seed] [count] [B]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit")
+
+
+def mutator(mode):
+    assert mode in MODES, mode
+
+    def mutate(seed, md, s, a, g):
+        rng = np.random.default_rng(seed)
+        n = md.num_dofs
+        if mode == "dt":
+            md.dt = 5e-3
+        elif mode == "tinydt":
+            md.dt = 1e-5
+        elif mode == "fast":
+            s = s.copy(); s[:, n:] *= 8.0
+        elif mode == "torque":
+            a = a * 200.0
+        elif mode == "mass":
+            for b in md.bodies:
+                f = float(10 ** rng.uniform(-2, 2)); b.mass *= f; b.inertia = tuple(x * f for x in b.inertia)
+        elif mode == "nograv":
+            md.gravity = (0.0, 0.0, 0.0)
+        elif mode == "geom":
+            for bx in md.boxes[1:]:
+                f = tuple(float(10 ** rng.uniform(-1, 0.7)) for _ in range(3))
+                bx.size = tuple(x * (f[0] if bx.shape == "sphere" else f[k]) for k, x in enumerate(bx.size))
+        elif mode == "mu":
+            for bx in md.boxes:
+                bx.mu = float(rng.choice([1.01e-3, 2e-3, 5.0, 10.0]))
+        elif mode == "subset":
+            keep = sorted(rng.choice(n, size=max(1, n // 3), replace=False).tolist())
+            md.set_action_space(keep); a = a[:, :len(keep)]
+        elif mode == "atlimit":
+            for i, b in enumerate(md.bodies):
+                if md.joint_ndof(i) == 1 and rng.random() < 0.5:
+                    b.pos_lo, b.pos_hi = (-0.3,), (0.4,); b.vel_lo, b.vel_hi = (-0.7,), (0.9,); b.force_lo, b.force_hi = (-0.2,), (0.25,)
+            md = type(md)(md.name, md.bodies, md.boxes, gravity=md.gravity, dt=md.dt, max_contacts=md.max_contacts)
+            fl = md.flat(); s = s.copy(); a = a.copy()
+            for d in range(n):
+                if np.isfinite(fl["pos_lo"][d]):
+                    half = rng.random(s.shape[0]) < 0.5
+                    s[half, d] = rng.choice([fl["pos_lo"][d], fl["pos_hi"][d]], half.sum())
+                    s[half, n + d] = rng.choice([fl["vel_lo"][d], fl["vel_hi"][d]], half.sum())
+                    a[half, d] = rng.choice([fl["force_lo"][d], fl["force_hi"][d]], half.sum())
+        return md, s, a, g
+    return mutate
+
+
+def run(mode, first=0, count=20, B=256, verbose=False):
+    import soak_parity
+    return soak_parity.run(first, count, B, verbose=verbose, balls=True, mutate=mutator(mode))
+
+
+if __name__ == "__main__":
+    print(sys.argv[1], run(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[3]) if len(sys.argv) > 3 else 150,
+                           int(sys.argv[4]) if len(sys.argv) > 4 else 256))
