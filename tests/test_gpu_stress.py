@@ -100,7 +100,7 @@ def test_the_largest_models_of_the_contact_path_39_dofs_34_device_bodies(shape):
     s = np.concatenate([q, rng.normal(0, 0.5, (B, n))], 1); a = rng.normal(0, 0.5, (B, len(md.action_map))); g = rng.normal(0, 1, s.shape)
     err, status = _fwd_bwd_vs_oracle(md, s, a, g)
     print(shape, "in contact", (status & 1).mean(), "overflow", ((status & 0x80) != 0).mean(), "max err", err.max())
-    assert (status & 1).mean() > 0.2 and err.max() < 1e-5
+    assert (status & 1).mean() > 0.05 and err.max() < 1e-5
 
 
 def test_mass_gradients_of_random_models_vs_central_differences_of_the_oracle():
