@@ -606,8 +606,9 @@ inline void tangentBasisGradient(const Vec3& n, const Vec3& g, Vec3& dt1, Vec3& 
     }
   }
   s_t tn = norm(tangent);
-  tangent = (1.0 / tn) * tangent;
-  Vec3 gd = (1.0 / tn) * cross(crs, g);
+  tangent = mk3(tangent[0] / tn, tangent[1] / tn, tangent[2] / tn);          // Eigen's normalize() and `/= tangentNorm` divide (no reciprocal):
+  Vec3 gd = cross(crs, g);                                                    // pinned against the reference's own function,
+  gd = mk3(gd[0] / tn, gd[1] / tn, gd[2] / tn);                               // tests/test_oracle_ref_geometry.py
   Vec3 gradOfTangent = (std::fabs(tn - 1.0) > 1e-6) ? gd - dot(gd, tangent) * tangent : gd;
   dt1 = gradOfTangent;
   dt2 = cross(g, tangent) + cross(n, gradOfTangent);

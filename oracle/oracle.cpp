@@ -544,4 +544,39 @@ int nbo_cod_solve(int rows, int cols, const double* A, const double* b, double* 
   for (int i = 0; i < cols; i++) x[i] = r[i];
   return rank;
 }
+// The spatial-algebra primitives of oracle/spatial.hpp by name, for the comparison with the reference's own functions compiled into
+// oracle/_ref/libgeometry_ref.so (tests/test_oracle_ref_geometry.py).  in0 / in1: the arguments in the layouts of that library's entry
+// points (3 x 3 / 6 x 6 row-major; transforms 12 doubles R row-major then p; 6-vectors [omega; v]).  Returns the number of outputs.
+int nbo_prim(const char* name, const double* in0, const double* in1, double* out) {
+  const std::string f(name);
+  auto iso = [](const double* t) { Iso T; for (int i = 0; i < 9; i++) T.R.m[i] = t[i]; T.p = mk3(t[9], t[10], t[11]); return T; };
+  auto v3 = [](const double* x) { return mk3(x[0], x[1], x[2]); };
+  auto v6 = [](const double* x) { Vec6 r; for (int i = 0; i < 6; i++) r.v[i] = x[i]; return r; };
+  auto o3 = [&](const Vec3& v) { for (int i = 0; i < 3; i++) out[i] = v[i]; return 3; };
+  auto o6 = [&](const Vec6& v) { for (int i = 0; i < 6; i++) out[i] = v[i]; return 6; };
+  auto o33 = [&](const Mat3& v) { for (int i = 0; i < 9; i++) out[i] = v.m[i]; return 9; };
+  if (f == "expMapRot") return o33(expMapRot(v3(in0)));
+  if (f == "expMapJac") return o33(expMapJac(v3(in0)));
+  if (f == "expAngular") return o33(expAngular(v3(in0)));
+  if (f == "makeSkewSymmetric") return o33(skew(v3(in0)));
+  if (f == "logMap") { Mat3 R; for (int i = 0; i < 9; i++) R.m[i] = in0[i]; return o3(logMap(R)); }
+  if (f == "AdT") return o6(AdT(iso(in0), v6(in1)));
+  if (f == "AdInvT") return o6(AdInvT(iso(in0), v6(in1)));
+  if (f == "AdInvRLinear") return o6(AdInvRLinear(iso(in0), v3(in1)));
+  if (f == "ad") return o6(ad(v6(in0), v6(in1)));
+  if (f == "dad") return o6(dad(v6(in0), v6(in1)));
+  if (f == "dAdT") return o6(dAdT(iso(in0), v6(in1)));
+  if (f == "dAdInvT") return o6(dAdInvT(iso(in0), v6(in1)));
+  if (f == "tangentBasis") { Vec3 t1, t2; tangentBasis(v3(in0), t1, t2); for (int i = 0; i < 3; i++) { out[i] = t1[i]; out[3 + i] = t2[i]; } return 6; }
+  if (f == "tangentBasisGradient") { Vec3 t1, t2; tangentBasisGradient(v3(in0), v3(in1), t1, t2); for (int i = 0; i < 3; i++) { out[i] = t1[i]; out[3 + i] = t2[i]; } return 6; }
+  if (f == "contactPointGradient")
+    return o3(contactPointGradient(v3(in0), v3(in0 + 3), v3(in0 + 6), v3(in0 + 9), v3(in0 + 12), v3(in0 + 15), v3(in0 + 18), v3(in0 + 21)));
+  if (f == "transformInertia") {
+    Mat6 I; for (int i = 0; i < 36; i++) I.m[i] = in1[i];
+    const Mat6 r = transformInertia(iso(in0), I);
+    for (int i = 0; i < 36; i++) out[i] = r.m[i];
+    return 36;
+  }
+  return -1;
+}
 }

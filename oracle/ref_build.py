@@ -95,6 +95,95 @@ def build_boxbox():
     return 0
 
 
+GEOMETRY_FUNCTIONS = [   # signature prefix at column 0 of dart/math/Geometry.cpp; each body runs to the next "}" at column 0
+    "Eigen::Matrix3s makeSkewSymmetric(", "Eigen::Matrix3s expMapRot(", "Eigen::Matrix3s expMapJac(", "Eigen::Vector3s logMap(const Eigen::Matrix3s& _R)",
+    "Eigen::Vector6s AdT(", "Eigen::Vector6s AdR(", "Eigen::Vector6s AdTAngular(", "Eigen::Vector6s AdTLinear(", "Eigen::Vector6s AdInvT(",
+    "Eigen::Vector6s AdInvRLinear(", "Eigen::Vector6s ad(", "Eigen::Vector6s dAdT(", "Eigen::Vector6s dAdInvT(", "Eigen::Vector6s dAdInvR(",
+    "Eigen::Matrix3s eulerXYZToMatrix(", "Eigen::Matrix3s eulerZYXToMatrix(", "Eigen::Isometry3s expMap(", "Eigen::Isometry3s expAngular(",
+    "Eigen::Isometry3s expMapDart(", "Eigen::Vector6s dad(", "Inertia transformInertia(",
+    "void dLineClosestApproach(", "Eigen::Vector3s getContactPoint(", "Eigen::Vector3s getContactPointGradient(",
+]
+
+
+def _function(lines, prefix):
+    first = next(i for i, l in enumerate(lines) if l.startswith(prefix))
+    last = next(i for i in range(first, len(lines)) if lines[i] == "}")
+    return first, last
+
+
+def build_geometry():
+    """libgeometry_ref.so: the reference's own spatial-algebra primitives (the functions of dart/math/Geometry.cpp listed above, SURVEY.md
+    row a19) and its flat-array articulated-body algorithm (dart/dynamics/SimpleFeatherstone.hpp: the three structs / the class;
+    SimpleFeatherstone.cpp: emplaceBack, len, forwardDynamics) compiled from the reference's files where they lie, between
+    ref_geometry_prelude.hpp (a small fixed-size matrix class under Eigen's names - Eigen itself is not on this machine) and
+    ref_geometry_epilogue.hpp (C entry points).  The generated translation unit is deleted after the build."""
+    geo = os.path.join(REF, "dart", "math", "Geometry.cpp")
+    sfh = os.path.join(REF, "dart", "dynamics", "SimpleFeatherstone.hpp")
+    sfc = os.path.join(REF, "dart", "dynamics", "SimpleFeatherstone.cpp")
+    if not (os.path.exists(geo) and os.path.exists(sfh) and os.path.exists(sfc)):
+        return 0
+    out_dir = os.path.join(HERE, "_ref")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libgeometry_ref.so")
+    parts = [os.path.join(HERE, "ref_geometry_prelude.hpp"), os.path.join(HERE, "ref_geometry_epilogue.hpp")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in parts + [geo, sfh, sfc, __file__, os.path.join(HERE, "ref_geometry_shells.hpp")]):
+        return 0
+    tu = os.path.join(out_dir, "geometry_tu.cpp")
+    with open(tu, "w") as f:
+        f.write(open(parts[0]).read())
+        lines = open(geo).read().split("\n")
+        f.write("namespace dart {\nnamespace math {\n")
+        eps = next(i for i, l in enumerate(lines) if l.startswith("#define EPSILON_EXPMAP_THETA"))     # the Taylor-branch threshold, as the file has it
+        f.write(f'#line {eps + 1} "{geo}"\n' + lines[eps] + "\n")
+        for prefix in GEOMETRY_FUNCTIONS:
+            a, b = _function(lines, prefix)
+            f.write(f'#line {a + 1} "{geo}"\n' + "\n".join(lines[a:b + 1]) + "\n")
+        f.write("}  // namespace math\n")
+        # SimpleFeatherstone.hpp: `struct JointAndBody` .. the end of `class SimpleFeatherstone` (populateFromSkeleton is only declared)
+        lines = open(sfh).read().split("\n")
+        a = next(i for i, l in enumerate(lines) if l.startswith("struct JointAndBody"))
+        c = next(i for i, l in enumerate(lines) if l.startswith("class SimpleFeatherstone"))
+        b = next(i for i in range(c, len(lines)) if lines[i] == "};")
+        f.write("namespace dynamics {\nclass Skeleton;\n")
+        f.write(f'#line {a + 1} "{sfh}"\n' + "\n".join(lines[a:b + 1]) + "\n")
+        # SimpleFeatherstone.cpp: emplaceBack .. the end of forwardDynamics
+        lines = open(sfc).read().split("\n")
+        a = next(i for i, l in enumerate(lines) if l.startswith("JointAndBody& SimpleFeatherstone::emplaceBack()"))
+        c = next(i for i, l in enumerate(lines) if l.startswith("void SimpleFeatherstone::forwardDynamics("))
+        b = next(i for i in range(c, len(lines)) if lines[i] == "}")
+        f.write(f'#line {a + 1} "{sfc}"\n' + "\n".join(lines[a:b + 1]) + "\n")
+        f.write("}  // namespace dynamics\n}  // namespace dart\n")
+        # member functions behind class shells: the free joint's SE(3) position integration, the contact tangent basis
+        f.write('#line 1 "ref_geometry_shells.hpp"\n' + open(os.path.join(HERE, "ref_geometry_shells.hpp")).read())
+        fj = os.path.join(REF, "dart", "dynamics", "FreeJoint.cpp")
+        lines = open(fj).read().split("\n")
+        f.write("namespace dart {\nnamespace dynamics {\n")
+        for prefix in ("Eigen::Vector6s FreeJoint::convertToPositions(", "Eigen::Isometry3s FreeJoint::convertToTransform(",
+                       "Eigen::VectorXs FreeJoint::integratePositionsExplicit("):
+            a, b = _function(lines, prefix)
+            f.write(f'#line {a + 1} "{fj}"\n' + "\n".join(lines[a:b + 1]) + "\n")
+        f.write("}  // namespace dynamics\nnamespace constraint {\n")
+        cc = os.path.join(REF, "dart", "constraint", "ContactConstraint.cpp")
+        lines = open(cc).read().split("\n")
+        eps = next(i for i, l in enumerate(lines) if l.startswith("#define DART_CONTACT_CONSTRAINT_EPSILON_SQUARED"))
+        f.write(f'#line {eps + 1} "{cc}"\n' + lines[eps] + "\n")
+        for sig in ("ContactConstraint::getTangentBasisMatrixODE(", "ContactConstraint::getTangentBasisMatrixODEGradient("):
+            a = next(i for i, l in enumerate(lines) if l.startswith(sig)) - 1   # the return type is on the line above
+            b = next(i for i in range(a, len(lines)) if lines[i] == "}")
+            f.write(f'#line {a + 1} "{cc}"\n' + "\n".join(lines[a:b + 1]) + "\n")
+        f.write("}  // namespace constraint\n}  // namespace dart\n")
+        f.write('#line 1 "ref_geometry_epilogue.hpp"\n')
+        f.write(open(parts[1]).read())
+    # -ffp-contract=off: the reference's build has no fused multiply-adds
+    cmd = ["g++", "-O2", "-DNDEBUG", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-o", out, tu]
+    print("[ref_build]", " ".join(cmd))
+    try:
+        subprocess.check_call(cmd)
+    finally:
+        os.remove(tu)      # the generated translation unit holds reference source: only the shared object stays
+    return 0
+
+
 if __name__ == "__main__":
     rc = main()
-    sys.exit(rc or build_boxbox())
+    sys.exit(rc or build_boxbox() or build_geometry())
