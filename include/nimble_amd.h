@@ -306,6 +306,10 @@ int32_t nbl_rollout_backward_checkpointed(nbl_model* m, int64_t B, int32_t T, in
  * inputs x and rc are bit-identical to the reference solver's. */
 int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                  const int32_t* findex, double* x, int32_t* rc);
+/* The same, launched `reps` times back to back between two HIP events (after one untimed launch): *ms_per_launch = average duration of
+ * one launch over the `count` problems (NULL: not timed).  The micro-benchmark of the stage-1 solver (tools/dantzig_bench.py). */
+int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
+                                       const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch);
 
 /*
  * Layout helpers: the Python surface takes world-major tensors [B][d] like a stack of the

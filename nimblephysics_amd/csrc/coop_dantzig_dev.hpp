@@ -14,6 +14,18 @@ namespace nbl {
 
 template <int I> struct IntTag { static constexpr int value = I; };
 
+// Values the optimiser must treat as produced HERE (in VGPRs on the device): keeps a block of LDS loads together and ahead of the
+// dependent chain that consumes them instead of being sunk, one by one, into the predicated code that uses them.  One statement per
+// eight values: a statement waits for its own operands only, so the 24 loads of a row stay in flight together.
+DEV void coopPin24(double (&a)[MAXR]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(MAXR == 24, "three groups of eight");
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+  asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+  asm volatile("" : "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]));
+#endif
+}
+
 // Developer instrumentation of the Dantzig driver (tools/cascade_timing.py builds with -DNBL_CASCADE_TIMING): cycles per phase
 // summed over all worlds.  Compiled out of the shipped library.
 #if defined(NBL_CASCADE_TIMING) && defined(__HIPCC__)
@@ -115,7 +127,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
 #pragma unroll
     for (int r = 0; r < MAXR; r++) {
       const int pr = w.bcastI(p, r < n ? r : 0);
-      col[r] = (on && r < n) ? (pr >= p ? C.A[pr * CLD + p] : C.A[p * CLD + pr]) : 0.0;
+      const int hiI = pr >= p ? pr : p, loI = pr >= p ? p : pr;          // ONE load through a selected address (a select between two
+      const double av = C.A[hiI * CLD + loI];                            // loads compiles to two divergent branches with an LDS wait each)
+      col[r] = (on && r < n) ? av : 0.0;
     }
     w.sync();
 #pragma unroll
@@ -140,7 +154,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     seqSum2(prod, to, to, s1, s2);
     return s1;
   };
-  // dSolveL1 (fastlsolve.cpp): L y = rhs over the factor rows, lane = row
+  // dSolveL1 (fastlsolve.cpp): L y = rhs over the factor rows, lane = row.  Step k: y_k (final on lane k) is broadcast, every lane forms
+  // its product with column k of its row UNCONDITIONALLY and only the one-instruction updates are predicated - written any other way
+  // the compiler sinks the LDS loads of the factor into the divergent branches (an LDS round trip per step: 250 cycles instead of 40).
   auto solveL1 = [&](double rhs) -> double {
     const bool act = ln < nC;
     const int nb4 = nC & ~3;
@@ -148,6 +164,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     double lrow[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; k++) lrow[k] = C.L[me * CLD + k];
+    coopPin24(lrow);
     double Z = 0.0, y = rhs;
 #pragma unroll
     for (int k = 0; k < MAXR; k++) {
@@ -155,7 +172,8 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         if (k == i0) y = rhs - Z;
         const double xk = w.bcast(y, k);
         const double t = lrow[k] * xk;
-        if (act && k < ln) { if (k < i0) Z = Z + t; else y = y - t; }
+        if (act && k < i0) Z = Z + t;               // (k < i0 implies k < ln)
+        if (k >= i0 && k < ln) y = y - t;           // (ln < nC for every lane that reaches here with k < nC ... and k < ln)
       }
     }
     return y;
@@ -169,6 +187,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     double lcol[MAXR];   // this lane's column of L, fetched up front so that the substitution chain does not wait on LDS
 #pragma unroll
     for (int k = 0; k < MAXR; k++) lcol[k] = C.L[k * CLD + me];
+    coopPin24(lcol);
     double Z = 0.0, y = rhs;
 #pragma unroll
     for (int k = MAXR - 1; k >= 0; k--) {
@@ -177,7 +196,8 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         if (kr == i0) y = rhs - Z;
         const double xk = w.bcast(y, k);
         const double t = lcol[k] * xk;
-        if (act && kr < jr) { if (kr < i0) Z = Z + t; else y = y - t; }
+        if (act && kr < i0) Z = Z + t;
+        if (act && kr >= i0 && kr < jr) y = y - t;
       }
     }
     return y;
@@ -746,14 +766,26 @@ DEV void coopCascadeStage1(const W& w, CascadeLds& C, const CoopRow& R, double X
   CoopLcpRow row;
   int mapTo;
   int n0;
+#if defined(NBL_CASCADE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  const int ln = w.lane();
+  long long s1T = clock64();
+#define S1_ADD(k) do { const long long n_ = clock64(); if (ln == 0) atomicAdd(&g_dzStat[k], (unsigned long long)(n_ - s1T)); s1T = n_; } while (0)
+#else
+#define S1_ADD(k) do { } while (0)
+#endif
   coopLoadProblem(w, C, R, 0.0, X0, row, mapTo, n0);
+  S1_ADD(12);
   const int nr = coopLcpReduce(w, C, n0, row, mapTo);
+  S1_ADD(13);
   const int rc = coopDantzig(w, C, nr, row);
+  S1_ADD(14);
   out.X = 0.0; out.flags = 0;
   if (rc == 1) {
     out.X = coopMapOut(w, C, R.m, mapTo, row.x, nr);
     out.flags = CS_SOLVED | (coopValid(w, C.v[0], R, out.X, false, 0.0) ? CS_VALID : 0);
   } else if (rc < 0) out.flags = CS_NAN;
+  S1_ADD(15);
+#undef S1_ADD
 }
 // stage 2: CFM + PGS from the pre-solve x (:539-597)
 template <class W, class LDS>

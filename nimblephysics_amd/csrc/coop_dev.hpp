@@ -233,6 +233,237 @@ DEV int coopPinv(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
   return r;
 }
 
+// 1 / sqrt(x) of a wave-uniform positive x.  Device: the hardware estimate (v_rsq_f64) and two Newton steps - 10 dependent
+// instructions instead of the ~35 of sqrt followed by a division; good to the last bit or two, which is all a factorisation needs.
+DEV double coopRsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
+// S.P <- pseudo-inverse of a SYMMETRIC POSITIVE SEMI-DEFINITE 24 x 24 matrix (masked rows / columns zero) whose column j (= row j) is
+// a[] of lane j (< 24): A restricted to the guess rows, or Q = A(clamping, clamping) + cfm I when no friction row sits on its bound.
+// Same contract as coopPinv (cTrue = number of unmasked columns, returns the rank), about a third of its instructions and of its
+// dependent chain:
+//   1. diagonally pivoted Cholesky  Q = G G^T,  G 24 x r (rows in lane order - nothing is permuted; rows in LDS); rank by the same
+//      threshold as the reference's complete orthogonal decomposition, eps * size, on the pivots (the pivots of both factorisations
+//      sit at the scale of the singular values of Q)
+//   2. K = G^T G  (r x r, positive definite)                                   one GEMM: the matrix cores on the device
+//   3. Cholesky K = L L^T, lane t = row t of L
+//   4. W = G K^-1: lane j solves L y = g_j, L^T w = y for its row  (L broadcast from LDS, the right-hand side in registers)
+//   5. Q^+ = W W^T = G (G^T G)^-2 G^T                                          one GEMM: the matrix cores on the device
+// Accuracy: both Cholesky factorisations are backward stable and K has the condition number of Q on its range, so Q^+ carries
+// cond(Q) eps like the QR route (measured on 1200 contact matrices of the metric, box-stack and soak distributions: rank equal to
+// the COD's in every case, Q^+ b to 1e-9 at cond 3e6, median 2e-14).  Non-symmetric Q (a friction row on its bound folds its column
+// into its normal's) stays with coopPinv.
+// Code shape: fully unrolled over the factorisation step k, so that step k does exactly k multiply-adds per lane (the left-looking dot
+// products and the substitutions are triangular: a rolled loop over fixed-length rows does 2-4 x the work) with every LDS offset a
+// compile-time constant; a full-rank Q (every Q with the fallback CFM on its diagonal) skips steps 2-3: there W = G^-T, one
+// substitution with the (row-permuted) triangular G itself.
+template <class W>
+DEV int coopPinvSym(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
+  const int ln = w.lane();
+  const bool act = ln < MAXR;
+  const int row = act ? ln : 0;
+  // Q into LDS: S.R[i][j] (column j by lane j; symmetric)
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) if (act) S.R[i * CLD + ln] = a[i];
+  w.sync();
+  double d = act ? S.R[row * CLD + row] : -1.0;     // remaining diagonal of this lane's row
+  bool done = !act;
+  double g[MAXR];                                   // this lane's row of G, later of W
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) g[i] = 0.0;
+  const double thr = 2.220446049250313e-16 * cTrue;
+  double best0 = 0.0;
+  int r = 0;
+  // ---- 1. pivoted Cholesky, left-looking: column k of G from column p of Q and the pivot row so far ----
+#pragma unroll
+  for (int k = 0; k < MAXR; k++) {
+    const double cand = done ? -1.0 : d;
+    const double best = w.maxAll(cand);
+    if (k == 0) best0 = best;
+    if (!(best > thr * best0) || !(best > 0.0)) break;
+    const int p = __builtin_ctzll(w.ballot(cand == best));
+    const double inv = coopRsqrt(best);              // overlaps with the dot product below
+    double s0 = S.R[row * CLD + p], s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < k; i++) {
+      const double pr = S.G[p * CLD + i];            // G[p][i], broadcast
+      if (i & 1) s1 = fma(-g[i], pr, s1); else s0 = fma(-g[i], pr, s0);
+    }
+    const double gk = done ? 0.0 : (s0 + s1) * inv;  // rows already pivoted are exactly zero from here on
+    g[k] = gk;
+    d = fma(-gk, gk, d);
+    if (ln == p) done = true;
+    if (act) S.G[row * CLD + k] = gk;
+    if (ln == 0) { S.perm[k] = p; S.invd[k] = inv; }
+    w.sync();
+    r = k + 1;
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) if (act) S.P[i * CLD + ln] = 0.0;
+    w.sync();
+    return 0;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const int li = ln & 15, lk = ln >> 4;
+#endif
+  if (r >= cTrue) {
+    // ---- full rank on the unmasked block: Q^-1 = G^-T G^-1, W = G^-T.  Row j of W = column j of G^-1 = the solution of G x = e_j;
+    //      G's row perm[k] ends at column k, so x_k comes from that row: x_k = ([j == perm[k]] - sum_{i<k} G[perm[k]][i] x_i) / G[perm[k]][k]
+    //      (1 / G[perm[k]][k] = the reciprocal square root of pivot k).  Masked lanes are no pivot: their row stays zero. ----
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) {
+      if (k < r) {
+        const int pk = S.perm[k];
+        double s0 = (ln == pk) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+          const double gp = S.G[pk * CLD + i];
+          if (i & 1) s1 = fma(-gp, g[i], s1); else s0 = fma(-gp, g[i], s0);
+        }
+        g[k] = (s0 + s1) * S.invd[k];                // (g[] is overwritten front to back: entries < k are x, entries >= k still G)
+      }
+    }
+  } else {
+    // ---- 2. K = G^T G -> S.P (r x r) ----
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_mfma_f64_16x16x4_f64: A operand lane l = A[l & 15][l >> 4], B operand lane l = B[l >> 4][l & 15], D register q of lane l =
+    // D[(l >> 4) + 4 q][l & 15].  K[m][n] = sum_j G[j][m] G[j][n]: both operands read G[4 ks + lk][16 t + li].
+#pragma unroll
+    for (int tr = 0; tr < 2; tr++) {
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++) {
+        if ((tr == 0 && tj == 0) || r > 16) {          // ranks up to 16 (two flat feet: 12) need one tile
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          const int mi = 16 * tr + li, ni = 16 * tj + li;
+          const int mc = mi < MAXR ? mi : 0, nc2 = ni < MAXR ? ni : 0;
+#pragma unroll
+          for (int ks = 0; ks < MAXR / 4; ks++) {
+            const int kk = 4 * ks + lk;
+            const double av = S.G[kk * CLD + mc], bv = S.G[kk * CLD + nc2];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mi < r ? av : 0.0, ni < r ? bv : 0.0, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int rr = 16 * tr + lk + 4 * q, cc = 16 * tj + li;
+            if (rr < MAXR && cc < MAXR) S.P[rr * CLD + cc] = acc[q];
+          }
+        }
+      }
+    }
+#else
+    if (act) {
+      for (int t = 0; t < MAXR; t++) {
+        double sum = 0.0;
+        for (int j = 0; j < MAXR; j++) sum += (t < r && ln < r) ? S.G[j * CLD + t] * S.G[j * CLD + ln] : 0.0;
+        S.P[t * CLD + ln] = sum;
+      }
+    }
+#endif
+    w.sync();
+    // ---- 3. K = L L^T, lane t (< r) = row t of L; rows also in S.R for the broadcast, reciprocal diagonal in S.invd ----
+    {
+      double l2[MAXR];
+#pragma unroll
+      for (int i = 0; i < MAXR; i++) l2[i] = 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXR; k++) {
+        if (k < r) {
+          double s0 = S.P[row * CLD + k], s1 = 0.0;
+#pragma unroll
+          for (int i = 0; i < k; i++) {
+            const double lk2 = S.R[k * CLD + i];       // L[k][i], broadcast
+            if (i & 1) s1 = fma(-l2[i], lk2, s1); else s0 = fma(-l2[i], lk2, s0);
+          }
+          const double sK = s0 + s1;
+          const double inv = coopRsqrt(w.bcast(sK, k));
+          const double v = (ln >= k && ln < r) ? sK * inv : 0.0;
+          l2[k] = v;
+          if (act) S.R[row * CLD + k] = v;
+          if (ln == 0) S.invd[k] = inv;
+          w.sync();
+        }
+      }
+    }
+    // ---- 4. this lane's row of W = G K^-1: forward with L, backward with L^T ----
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) {
+      if (k < r) {
+        double s0 = g[k], s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+          const double lk2 = S.R[k * CLD + i];
+          if (i & 1) s1 = fma(-lk2, g[i], s1); else s0 = fma(-lk2, g[i], s0);
+        }
+        g[k] = (s0 + s1) * S.invd[k];
+      }
+    }
+#pragma unroll
+    for (int k = MAXR - 1; k >= 0; k--) {
+      if (k < r) {
+        const double wk = g[k] * S.invd[k];
+        g[k] = wk;
+#pragma unroll
+        for (int i = 0; i < k; i++) g[i] = fma(-S.R[k * CLD + i], wk, g[i]);
+      }
+    }
+  }
+  w.sync();
+#pragma unroll
+  for (int t = 0; t < MAXR; t++) if (act) S.G[row * CLD + t] = g[t];      // W (columns >= r are zero)
+  w.sync();
+  // ---- 5. Q^+ = W W^T -> S.P ----
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    const int ksteps = (r + 3) >> 2;
+#pragma unroll
+    for (int tr = 0; tr < 2; tr++) {
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const int mi = 16 * tr + li, ni = 16 * tj + li;
+        const int mc = mi < MAXR ? mi : 0, nc2 = ni < MAXR ? ni : 0;
+#pragma unroll
+        for (int ks = 0; ks < MAXR / 4; ks++) {
+          if (ks < ksteps) {
+            const int kk = 4 * ks + lk;
+            const double av = S.G[mc * CLD + kk], bv = S.G[nc2 * CLD + kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mi < MAXR ? av : 0.0, ni < MAXR ? bv : 0.0, acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int rr = 16 * tr + lk + 4 * q, cc = 16 * tj + li;
+          if (rr < MAXR && cc < MAXR) S.P[rr * CLD + cc] = acc[q];
+        }
+      }
+    }
+  }
+#else
+  if (act) {
+    double out[MAXR];
+    for (int c = 0; c < MAXR; c++) {
+      double sum = 0.0;
+      for (int t = 0; t < MAXR; t++) sum += S.G[ln * CLD + t] * S.G[c * CLD + t];
+      out[c] = sum;
+    }
+    for (int c = 0; c < MAXR; c++) S.P[ln * CLD + c] = out[c];
+  }
+#endif
+  w.sync();
+  return r;
+}
+
 // y_lane = sum_k P[lane][k] x_k (TRANS: P[k][lane]) with x given one entry per lane (lanes >= 24 ignored)
 template <class W, bool TRANS>
 DEV double coopPinvApply(const W& w, CoopLds& S, double xLane, int slot) {
@@ -390,6 +621,15 @@ DEV void coopBuildQ(const W& w, CoopLds& S, const CoopRow& R, const CoopClasses&
   if (K.nu > 0) w.sync();   // reads of the staged A complete before the factorisation reuses the buffer
 }
 
+// Q^+ of the Q that coopBuildQ left in a[]: without upper-bound rows Q = A(clamping, clamping) + cfm I is symmetric positive
+// semi-definite (the Cholesky route); a friction row on its bound folds its column into its normal's and Q is a general matrix (the
+// Householder route).
+template <class W>
+DEV int coopPinvOfQ(const W& w, double (&a)[MAXR], CoopLds& S, const CoopClasses& K) {
+  if (K.nu == 0) return coopPinvSym(w, a, S, K.nc);
+  return coopPinv(w, a, S, K.nc);
+}
+
 struct CoopStage0 {
   double X, X0;       // solution / pre-solve x of this lane's row
   CoopClasses K;
@@ -418,7 +658,7 @@ DEV bool coopStandardizeLoop(const W& w, CoopLds& S, const CoopRow& R, double& X
     if (iter == 0 && K.nu == 0 && guessMask != 0 && K.clampMask == guessMask) fc = X;
     else {
       coopBuildQ(w, S, R, K, cfm, a);
-      coopPinv(w, a, S, K.nc);
+      coopPinvOfQ(w, a, S, K);
       fc = coopPinvApply<W, false>(w, S, K.cls == RC_CLAMPING ? R.Bv : 0.0, 0);
       pinvValid = true;
     }
@@ -459,7 +699,7 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
 #pragma unroll
       for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(Ac, i) : 0.0;
       NBL_PHASE(43);
-      coopPinv(w, a, S, __builtin_popcount(guessMask));
+      coopPinvSym(w, a, S, __builtin_popcount(guessMask));      // A restricted to the guess rows: symmetric positive semi-definite
       NBL_PHASE(44);
       X = coopPinvApply<W, false>(w, S, in ? R.Bv : 0.0, 0);
       NBL_PHASE(45);

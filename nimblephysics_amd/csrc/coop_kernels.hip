@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
     if (K.nc > 0) {                                       // Q^+ of the whole clamping set (block diagonal over the groups) for the record
       double a[MAXR];
       coopBuildQ(w, S, R, K, 0.0, a);
-      coopPinv(w, a, S, K.nc);
+      coopPinvOfQ(w, a, S, K);
       pinvValid = true;
     }
     const uint32_t nanBit = coopContactOutputs(w, S, n, m, X, K, 0.0, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
   if (!pinvValid && K.nc > 0) {
     double a[MAXR];
     coopBuildQ(w, S, R, K, cfmRow, a);
-    coopPinv(w, a, S, K.nc);
+    coopPinvOfQ(w, a, S, K);
     pinvValid = true;
   }
   const uint32_t nanBit = coopContactOutputs(w, S, n, m, X, K, cfmRow, pinvValid, saved, lay, dn, cacheOut, nv, B, b);

@@ -10,7 +10,13 @@ namespace nbl {
 
 struct DevWave {
   DEV int lane() const { return (int)(threadIdx.x & 63u); }
-  DEV void sync() const { __syncthreads(); }
+  // Every DevWave kernel runs ONE wavefront per workgroup, and a wave's LDS instructions execute in order: a write is visible to the
+  // wave's later reads without waiting.  The "barrier" therefore only has to stop the COMPILER from moving LDS accesses across it;
+  // __syncthreads() would also drain the LDS queue (s_waitcnt lgkmcnt(0)) and stall the loads already in flight behind it.
+  DEV void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   // max over the wavefront.  DPP row shifts (register crossbar, a few cycles each) instead of six ds_bpermute round trips:
   // after row_shr 1, 2, 4, 8 the last lane of every 16-lane row holds the row maximum; four readlanes finish.
   DEV double maxAll(double v) const {
@@ -39,12 +45,7 @@ struct DevWave {
 // The same primitives for kernels whose workgroups hold SEVERAL independent wavefronts (k_contact_cascade_stages: one stage per
 // wavefront): "sync" orders the wave's own LDS traffic (a wave's LDS instructions execute in order; the fence only stops the
 // compiler from moving accesses across it) and never waits for the other wavefronts of the group.
-struct DevWaveInGroup : DevWave {
-  DEV void sync() const {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-};
+struct DevWaveInGroup : DevWave {};
 
 // workgroup -> world: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a contiguous range of worlds
 // (neighbouring worlds share the cache lines of the lane-interleaved rows of the saved record, which then meet in one L2)

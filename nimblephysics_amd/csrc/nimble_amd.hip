@@ -862,7 +862,13 @@ int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double*
 // ---- self-test: the device Dantzig driver on caller-supplied problems (host pointers) ----------------------------------
 int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                  const int32_t* findex, double* x, int32_t* rc) {
+  return nbl_selftest_lcp_dantzig_timed(count, n, A, b, lo, hi, findex, x, rc, 1, nullptr);
+}
+
+int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
+                                       const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch) {
   if (!A || !b || !lo || !hi || !findex || !x || !rc) return fail(NBL_E_BADARG, "null argument");
+  if (reps < 1) return fail(NBL_E_BADARG, "reps must be positive");
   if (count <= 0 || n <= 0 || n > MAX_ROWS) return fail(NBL_E_BADARG, "count must be positive and 1 <= n <= 24");
   if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
   const size_t nv = (size_t)count * n, nm = nv * n;
@@ -877,9 +883,24 @@ int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, cons
   if (e == hipSuccess) e = hipMemcpy(dv + 2 * nv, hi, nv * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(di, findex, nv * sizeof(int32_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv,
-                       di + nv);
-    e = hipDeviceSynchronize();
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (ms_per_launch) { e = hipEventCreate(&t0); if (e == hipSuccess) e = hipEventCreate(&t1); }
+    if (e == hipSuccess && ms_per_launch) {     // one untimed launch first (code load)
+      hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv, di + nv);
+      e = hipEventRecord(t0, 0);
+    }
+    for (int r = 0; r < reps && e == hipSuccess; r++)
+      hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv,
+                         di + nv);
+    if (e == hipSuccess && ms_per_launch) e = hipEventRecord(t1, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && ms_per_launch) {
+      float ms = 0.f;
+      e = hipEventElapsedTime(&ms, t0, t1);
+      *ms_per_launch = (double)ms / reps;
+    }
+    if (t0) hipEventDestroy(t0);
+    if (t1) hipEventDestroy(t1);
   }
   if (e == hipSuccess) e = hipMemcpy(x, dv + 3 * nv, nv * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(rc, di + nv, count * sizeof(int32_t), hipMemcpyDeviceToHost);

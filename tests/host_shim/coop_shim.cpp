@@ -23,6 +23,21 @@ int shim_coop_pinv(const double* Q, int cTrue, double* Pout) {
   return rank;
 }
 
+// the symmetric positive semi-definite route (coopPinvSym): same arguments
+int shim_coop_pinv_sym(const double* Q, int cTrue, double* Pout) {
+  static CoopLds S;
+  int rank = -1;
+  emuRunWave([&](const EmuWave& w) {
+    double a[MAXR];
+    const int ln = w.lane();
+    for (int i = 0; i < MAXR; i++) a[i] = ln < MAXR ? Q[i * MAXR + ln] : 0.0;
+    const int r = coopPinvSym(w, a, S, cTrue);
+    if (ln == 0) rank = r;
+  });
+  for (int i = 0; i < MAXR; i++) for (int j = 0; j < MAXR; j++) Pout[i * MAXR + j] = S.P[i * CLD + j];
+  return rank;
+}
+
 static void fillRow(CoopRow& R, int ln, int m, const double* A, const double* b, const double* mu) {
   R.m = m; R.fric = (ln % 3) != 0; R.fp = ln < MAXR ? ln - (ln % 3) : 0;
   R.mu = ln < m ? mu[ln / 3] : 0.0; R.Bv = ln < m ? b[ln] : 0.0;

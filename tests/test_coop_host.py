@@ -57,6 +57,44 @@ def test_coop_pinv_equals_numpy_pinv_on_masked_rank_deficient_systems(shim):
     assert shim.shim_coop_pinv(_p(Z), 5, _p(P)) == 0 and not P.any()
 
 
+def test_coop_pinv_sym_equals_numpy_pinv_on_positive_semidefinite_systems(shim):
+    """coopPinvSym: the pseudo-inverse of symmetric positive semi-definite Q by two Cholesky factorisations, Q = G G^T (diagonally
+    pivoted, rank by the threshold of the reference's complete orthogonal decomposition) and Q^+ = G (G^T G)^-2 G^T - the route the
+    kernels take whenever no friction row sits on its bound.  Random masked rank-deficient and full-rank blocks, contact matrices
+    J D J^T of two flat feet (rank 12 of 24), the same with the fallback CFM on the diagonal (full rank, cond ~ 1e5): Q^+ and the
+    rank against numpy, and against the Householder route (coopPinv) on the same input."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for trial in range(80):
+        c = int(rng.integers(1, 25)); idx = np.sort(rng.choice(24, c, replace=False))
+        if trial % 4 == 3:                         # a standing robot: c rows on two 6-DOF bodies (+ the CFM every other time)
+            k = min(c, 12)
+            J = rng.normal(0, 1, (c, 12)); sub = J @ np.diag(rng.uniform(0.1, 2, 12)) @ J.T
+            if trial % 8 == 7:
+                sub = sub + 1e-4 * np.eye(c); k = c
+        else:
+            k = int(rng.integers(1, c + 1))
+            U = rng.normal(0, 1, (c, k)); sub = U @ U.T
+        Q = np.zeros((24, 24)); Q[np.ix_(idx, idx)] = sub
+        Q = 0.5 * (Q + Q.T)
+        P = np.zeros((24, 24)); P2 = np.zeros((24, 24))
+        rank = shim.shim_coop_pinv_sym(_p(np.ascontiguousarray(Q)), c, _p(P))
+        rank2 = shim.shim_coop_pinv(_p(np.ascontiguousarray(Q)), c, _p(P2))
+        assert rank == k and rank2 == k, (trial, rank, rank2, k)
+        sv = np.linalg.svd(sub, compute_uv=False)
+        cond = sv[0] / sv[k - 1]
+        ref = np.linalg.pinv(Q, rcond=0.5 * sv[k - 1] / sv[0])
+        scale = max(np.abs(ref).max(), 1e-30)
+        e = np.abs(P - ref).max() / scale
+        worst = max(worst, e / (cond * 2.2e-16))
+        assert e <= 200 * cond * 2.2e-16, (trial, e, cond)               # cond(Q) eps, like the QR route
+        assert np.abs(P - P2).max() / scale <= 400 * cond * 2.2e-16
+        assert np.abs(P - P.T).max() <= 1e-12 * scale
+    print("coopPinvSym: worst error in units of cond(Q) eps:", worst)
+    Z = np.zeros((24, 24)); P = np.ones((24, 24))
+    assert shim.shim_coop_pinv_sym(_p(Z), 5, _p(P)) == 0 and not P.any()
+
+
 def _contact_problem(rng, trial):
     nc = int(rng.integers(1, 9)); m = 3 * nc
     ndof = int(rng.choice([6, 12, 30]))

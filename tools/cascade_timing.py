@@ -29,12 +29,14 @@ calls, idx, piv, rem = dz[8], dz[9], dz[10], dz[11]
 print(f"Dantzig: {calls} solves, {idx / max(calls, 1):.1f} driving rows, {piv / max(calls, 1):.1f} pivot iterations, {rem / max(calls, 1):.1f} C->N removals per solve")
 for k, nm in enumerate(names_dz):
     print(f"  {nm:18s} {dz[k] / max(calls, 1):10.0f} cycles per solve")
+for k, nm in ((12, "stage 1: load problem"), (13, "stage 1: reduce"), (14, "stage 1: Dantzig (all of it)"), (15, "stage 1: map out + validity")):
+    print(f"  {nm:30s} {dz[k] / max(calls, 1):10.0f} cycles per solve")
 stat = status.cpu().numpy()
 ws = world._workspace(B).view(torch.float64).cpu().numpy()
 nb = 15
 lws = ws[nb * 288 * B:]
 LW_JB = 144
-base = LW_JB + 3 * 24 + 3          # LW_STAGE_CYCLES
+base = LW_JB + 3 * 24 + 3 * 8 + 1          # LW_STAGE_CYCLES (model_dev.hpp, coop_kernels.hip)
 rows = lws[: (lws.size // B) * B].reshape(-1, B)[base:base + 4]
 failed = np.where((stat & 0x2) == 0)[0]
 print("failed worlds", len(failed))
