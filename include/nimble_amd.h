@@ -311,6 +311,15 @@ int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, cons
 int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                        const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch);
 
+/* Runs the library's device pseudo-inverses on `count` caller-supplied 24 x 24 matrices (HOST pointers: Q [count][24*24] row-major,
+ * rows / columns outside the block of interest zero; cTrue [count] = size of that block, Eigen's `size` in the rank threshold), one
+ * wavefront per matrix: route 0 = column-pivoted Householder QR + complete orthogonal decomposition (any matrix; what
+ * CGGM.cpp:280 / LCPUtils.cpp:113 get from Eigen), route 1 = two Cholesky factorisations (symmetric positive semi-definite input:
+ * A restricted to the guess rows, Q without upper-bound rows).  Outputs P [count][24*24] and rank [count]; launched `reps` times
+ * between two HIP events, *ms_per_launch (may be NULL) = average launch duration.  For tests and tools/pinv_bench.py. */
+int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank, int32_t reps,
+                          double* ms_per_launch);
+
 /*
  * Layout helpers: the Python surface takes world-major tensors [B][d] like a stack of the
  * reference's 1-D state vectors; these transpose to/from the library's [d][B] layout on device.

@@ -268,6 +268,9 @@ DEV double coopRsqrt(double x) {
 // substitution with the (row-permuted) triangular G itself.
 template <class W>
 DEV int coopPinvSym(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
+#ifdef NBL_NO_PINV_SYM       // A/B build (tools): every pseudo-inverse by the Householder route
+  return coopPinv(w, a, S, cTrue);
+#endif
   const int ln = w.lane();
   const bool act = ln < MAXR;
   const int row = act ? ln : 0;
@@ -280,7 +283,13 @@ DEV int coopPinvSym(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
   double g[MAXR];                                   // this lane's row of G, later of W
 #pragma unroll
   for (int i = 0; i < MAXR; i++) g[i] = 0.0;
-  const double thr = 2.220446049250313e-16 * cTrue;
+  // Rank threshold.  The reference's complete orthogonal decomposition drops a column when |R_kk| <= eps * size * |R_00|; on an exactly
+  // singular Q (four coplanar corners per foot, two contacts at one point) the quantity tested is pure round-off, a few eps, in
+  // either factorisation - only a factor ~5-10 below that threshold, and the round-off of a down-dated Cholesky pivot is not the
+  // round-off of a Householder column (soak seed 30168: the COD says rank 5, a pivot of 1.4e-15 passes eps * 6).  64 x the threshold
+  // keeps every round-off pivot out; it differs from the reference's decision only for a Q whose trailing singular value sits between
+  // 5e-15 and 3e-13 of the largest - where the reference's own solution is round-off times 1e12.
+  const double thr = 64.0 * 2.220446049250313e-16 * cTrue;
   double best0 = 0.0;
   int r = 0;
   // ---- 1. pivoted Cholesky, left-looking: column k of G from column p of Q and the pivot row so far ----

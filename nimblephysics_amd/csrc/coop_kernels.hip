@@ -372,6 +372,28 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig(int count, int n, const
   if (ln == 0) rc[pb] = r;
 }
 
+// Self-test of the device pseudo-inverses (nbl_selftest_pinv): one wavefront per 24 x 24 matrix (row-major, masked rows / columns zero),
+// route 0 = coopPinv (Householder QR + complete orthogonal decomposition), 1 = coopPinvSym (two Cholesky factorisations, symmetric
+// positive semi-definite input), exactly the code the contact kernels run.
+__global__ __launch_bounds__(64) void k_selftest_pinv(int count, const double* __restrict__ Q, const int32_t* __restrict__ cTrue, int route,
+                                                     double* __restrict__ P, int32_t* __restrict__ rank) {
+  __shared__ CoopLds S;
+  const DevWave w;
+  const int ln = w.lane();
+  const int64_t pb = blockIdx.x;
+  if (pb >= count) return;
+  double a[MAXR];
+  const double* q = Q + pb * MAXR * MAXR;
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) a[i] = ln < MAXR ? q[i * MAXR + ln] : 0.0;
+  const int r = route == 1 ? coopPinvSym(w, a, S, cTrue[pb]) : coopPinv(w, a, S, cTrue[pb]);
+  if (ln < MAXR) {
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) P[pb * MAXR * MAXR + i * MAXR + ln] = S.P[i * CLD + ln];
+  }
+  if (ln == 0) rank[pb] = r;
+}
+
 // Dense part of the contact adjoint, one world per wavefront (the header of contact_backward.hip derives the
 // quantities), with lane = LCP row for the c-vectors and lane = DOF for the
 // n-vectors.  Row-indexed vectors are zero outside the clamping set, which replaces the index compaction:

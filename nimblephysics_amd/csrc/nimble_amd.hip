@@ -911,6 +911,45 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
   return NBL_OK;
 }
 
+// ---- self-test: the device pseudo-inverses on caller-supplied matrices (host pointers) ----------------------------------------
+int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank, int32_t reps,
+                          double* ms_per_launch) {
+  if (!Q || !cTrue || !P || !rank) return fail(NBL_E_BADARG, "null argument");
+  if (count <= 0 || reps < 1 || (route != 0 && route != 1)) return fail(NBL_E_BADARG, "bad count / reps / route");
+  if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
+  const size_t nm = (size_t)count * MAX_ROWS * MAX_ROWS;
+  double *dQ = nullptr, *dP = nullptr;
+  int32_t* di = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipError_t e = hipMalloc((void**)&dQ, nm * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dP, nm * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&di, 2 * (size_t)count * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(dQ, Q, nm * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(di, cTrue, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipEventCreate(&t0);
+  if (e == hipSuccess) e = hipEventCreate(&t1);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_selftest_pinv, dim3((unsigned)count), dim3(64), 0, 0, count, dQ, di, route, dP, di + count);   // untimed (code load)
+    e = hipEventRecord(t0, 0);
+    for (int r = 0; r < reps && e == hipSuccess; r++)
+      hipLaunchKernelGGL(k_selftest_pinv, dim3((unsigned)count), dim3(64), 0, 0, count, dQ, di, route, dP, di + count);
+    if (e == hipSuccess) e = hipEventRecord(t1, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t0, t1);
+    if (ms_per_launch) *ms_per_launch = (double)ms / reps;
+  }
+  if (e == hipSuccess) e = hipMemcpy(P, dP, nm * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(rank, di + count, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (t0) hipEventDestroy(t0);
+  if (t1) hipEventDestroy(t1);
+  if (dQ) hipFree(dQ);
+  if (dP) hipFree(dP);
+  if (di) hipFree(di);
+  if (e != hipSuccess) return fail(NBL_E_HIP, std::string("nbl_selftest_pinv: ") + hipGetErrorString(e));
+  return NBL_OK;
+}
+
 #ifdef NBL_CASCADE_TIMING
 int32_t nbl_debug_dantzig_stats(unsigned long long* out16, int32_t reset) {
   HIP_TRY(hipDeviceSynchronize());

@@ -91,6 +91,14 @@ def test_coop_pinv_sym_equals_numpy_pinv_on_positive_semidefinite_systems(shim):
         assert np.abs(P - P2).max() / scale <= 400 * cond * 2.2e-16
         assert np.abs(P - P.T).max() <= 1e-12 * scale
     print("coopPinvSym: worst error in units of cond(Q) eps:", worst)
+    # an exactly singular contact matrix whose last Cholesky pivot (round-off) lands above eps * size: rank 5 like the COD's
+    import json
+    f = json.load(open(os.path.join(HERE, "golden", "pinv_rank_borderline.json")))
+    A6 = np.array([[float.fromhex(x) for x in row] for row in f["A"]])
+    Q = np.zeros((24, 24)); Q[:6, :6] = A6
+    P = np.zeros((24, 24)); P2 = np.zeros((24, 24))
+    assert shim.shim_coop_pinv_sym(_p(np.ascontiguousarray(Q)), 6, _p(P)) == 5 and shim.shim_coop_pinv(_p(np.ascontiguousarray(Q)), 6, _p(P2)) == 5
+    assert np.abs(P - P2).max() <= 1e-10 * np.abs(P2).max()
     Z = np.zeros((24, 24)); P = np.ones((24, 24))
     assert shim.shim_coop_pinv_sym(_p(Z), 5, _p(P)) == 0 and not P.any()
 
