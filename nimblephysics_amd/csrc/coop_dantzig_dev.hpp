@@ -330,6 +330,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     nN++; nC--;
   };
   bool hitFirstFriction = false;
+#ifdef NBL_DZ_COUNTS
+  int dzIters = 0, dzRemovals = 0, dzTransfers = 0;
+#endif
   DZ_ADD(0);   // setup
   for (int i = 0; i < n; ++i) {
     DZ_CNT(9);
@@ -367,6 +370,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         const int dir = (wi <= 0) ? 1 : -1;
         const double dirf = dir;
         DZ_CNT(10);
+#ifdef NBL_DZ_COUNTS
+        dzIters++;
+#endif
         solve1(i, dir);
         DZ_ADD(2);   // solve1
         // dw(N) = A(N,C) dx(C) +/- A(i,N);  dw[i] = A(i,C) dx(C) + A(i,i) dirf   (lcp.cpp:926-928)
@@ -441,6 +447,10 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
           case 6: if (ln == si) { x = hi; st = 1; } removeFromC(si); break;
         }
         if (cmdB >= 5) DZ_CNT(11);
+#ifdef NBL_DZ_COUNTS
+        if (cmdB >= 5) dzRemovals++;
+        if (cmdB == 4) dzTransfers++;
+#endif
         DZ_ADD(5);   // apply + transfer
         if (cmdB <= 3) break;
       }
@@ -454,6 +464,9 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   row.x = on ? C.v[0][ln] : 0.0;
   w.sync();
   DZ_FLUSH();
+#ifdef NBL_DZ_COUNTS      // developer build (tools/dantzig_bench.py): the iteration counts instead of the solution
+  row.x = ln == 0 ? (double)dzIters : (ln == 1 ? (double)dzRemovals : (ln == 2 ? (double)dzTransfers : 0.0));
+#endif
   return 1;
 }
 

@@ -39,6 +39,14 @@ DEV int opaqueI(int x) {
   return x;
 }
 
+// Nothing is scheduled across this point (device; no code): bounds how far ahead the compiler hoists the LDS loads of the next dense
+// product, i.e. how many registers the products of a kernel hold at once.
+DEV void coopSchedFence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 constexpr int CLD = MAXR + 1;  // odd leading dimension: row reads and column reads of the LDS matrices are both conflict-free
 
 struct CoopLds {
@@ -143,7 +151,7 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
 // S.P <- pseudo-inverse of the 24 x 24 matrix whose column j is a[] of lane j (< 24) (masked rows/columns zero);
 // cTrue = number of unmasked columns (Eigen's `size` in the rank threshold).  Returns the rank.
 template <class W>
-DEV int coopPinv(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
+DEV int coopPinvImpl(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
   const int ln = w.lane();
   if (ln >= MAXR) {
     const int e = opaqueI(ln - MAXR);
@@ -267,17 +275,10 @@ DEV double coopRsqrt(double x) {
 // compile-time constant; a full-rank Q (every Q with the fallback CFM on its diagonal) skips steps 2-3: there W = G^-T, one
 // substitution with the (row-permuted) triangular G itself.
 template <class W>
-DEV int coopPinvSym(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
-#ifdef NBL_NO_PINV_SYM       // A/B build (tools): every pseudo-inverse by the Householder route
-  return coopPinv(w, a, S, cTrue);
-#endif
+DEV int coopPinvSymImpl(const W& w, CoopLds& S, int cTrue) {      // Q in S.R[i][j] (symmetric)
   const int ln = w.lane();
   const bool act = ln < MAXR;
   const int row = act ? ln : 0;
-  // Q into LDS: S.R[i][j] (column j by lane j; symmetric)
-#pragma unroll
-  for (int i = 0; i < MAXR; i++) if (act) S.R[i * CLD + ln] = a[i];
-  w.sync();
   double d = act ? S.R[row * CLD + row] : -1.0;     // remaining diagonal of this lane's row
   bool done = !act;
   double g[MAXR];                                   // this lane's row of G, later of W
@@ -473,6 +474,25 @@ DEV int coopPinvSym(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
   return r;
 }
 
+// S.P <- pseudo-inverse of the 24 x 24 matrix whose column j is a[] of lane j (< 24): Householder QR + complete orthogonal decomposition.
+// (Both routes were also tried as OUT-OF-LINE device functions with the matrix passed through LDS - one copy per kernel instead of two
+// to four inlined ones: the kernels keep their ~220 registers (the callee's count is the kernel's) and every call costs ~10 us of
+// k_contact_solve_coop in callee-saved spills: 6.11 -> 5.84 M/s.  Inlined.)
+template <class W>
+DEV int coopPinv(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) { return coopPinvImpl(w, a, S, cTrue); }
+// ... of a symmetric positive semi-definite matrix: two Cholesky factorisations
+template <class W>
+DEV int coopPinvSym(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
+#ifdef NBL_NO_PINV_SYM       // A/B build (tools): every pseudo-inverse by the Householder route
+  return coopPinvImpl(w, a, S, cTrue);
+#endif
+  const int ln = w.lane();
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.R[i * CLD + ln] = a[i];      // Q into LDS: S.R[i][j] (column j by lane j; symmetric)
+  w.sync();
+  return coopPinvSymImpl(w, S, cTrue);
+}
+
 // y_lane = sum_k P[lane][k] x_k (TRANS: P[k][lane]) with x given one entry per lane (lanes >= 24 ignored)
 template <class W, bool TRANS>
 DEV double coopPinvApply(const W& w, CoopLds& S, double xLane, int slot) {
@@ -481,12 +501,18 @@ DEV double coopPinvApply(const W& w, CoopLds& S, double xLane, int slot) {
   w.sync();
   const int i = ln < MAXR ? ln : 0;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;   // four partial sums instead of one 24-deep dependent chain
+  // a REAL loop of three blocks of eight terms: fully unrolled, the 48 LDS loads of a product (and, hoisted, of the NEXT products of the
+  // caller) are all issued up front - k_bwd_contact_a_coop, five such products in a row, sat at 256 VGPRs + 192 AGPRs
+#pragma unroll 1
+  for (int kb = 0; kb < MAXR; kb += 8) {
 #pragma unroll
-  for (int k = 0; k < MAXR; k += 4) {
-    y0 = fma(TRANS ? S.P[k * CLD + i] : S.P[i * CLD + k], S.vec[slot][k], y0);
-    y1 = fma(TRANS ? S.P[(k + 1) * CLD + i] : S.P[i * CLD + k + 1], S.vec[slot][k + 1], y1);
-    y2 = fma(TRANS ? S.P[(k + 2) * CLD + i] : S.P[i * CLD + k + 2], S.vec[slot][k + 2], y2);
-    y3 = fma(TRANS ? S.P[(k + 3) * CLD + i] : S.P[i * CLD + k + 3], S.vec[slot][k + 3], y3);
+    for (int kq = 0; kq < 8; kq += 4) {
+      const int k = kb + kq;
+      y0 = fma(TRANS ? S.P[k * CLD + i] : S.P[i * CLD + k], S.vec[slot][k], y0);
+      y1 = fma(TRANS ? S.P[(k + 1) * CLD + i] : S.P[i * CLD + k + 1], S.vec[slot][k + 1], y1);
+      y2 = fma(TRANS ? S.P[(k + 2) * CLD + i] : S.P[i * CLD + k + 2], S.vec[slot][k + 2], y2);
+      y3 = fma(TRANS ? S.P[(k + 3) * CLD + i] : S.P[i * CLD + k + 3], S.vec[slot][k + 3], y3);
+    }
   }
   const double y = (y0 + y1) + (y2 + y3);
   return y;
@@ -521,11 +547,14 @@ DEV double coopAx(const W& w, double* vec, const CoopRow& R, double xLane) {
   const int ln = w.lane();
   if (ln < MAXR) vec[ln] = R.on ? xLane : 0.0;
   w.sync();
-  double v = 0.0;
+  double v0 = 0.0, v1 = 0.0;
   const double* Ac = R.fresh();
+#pragma unroll 1
+  for (int jb = 0; jb < MAXR; jb += 8) {             // eight loads of the column in flight per block (a real loop: see coopPinvApply)
 #pragma unroll
-  for (int jx = 0; jx < MAXR; jx++) v = fma(R.a(Ac, jx), vec[jx], v);
-  return v;
+    for (int jq = 0; jq < 8; jq += 2) { const int jx = jb + jq; v0 = fma(R.a(Ac, jx), vec[jx], v0); v1 = fma(R.a(Ac, jx + 1), vec[jx + 1], v1); }
+  }
+  return v0 + v1;
 }
 
 // LCPUtils::isLCPSolutionValid (LCPUtils.cpp:12-80), uniform result

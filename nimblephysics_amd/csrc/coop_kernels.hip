@@ -37,10 +37,13 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
   }
   R.on = on;
   R.Acol = dn + lay.A + (on ? ln : 0);
-  double cn = 0.0;
+  double cn = 0.0, cn1 = 0.0;
+#pragma unroll 1
+  for (int ib = 0; ib < MAXR; ib += 8) {
 #pragma unroll
-  for (int i = 0; i < MAXR; i++) { const double x = R.a(i); cn = fma(x, x, cn); }
-  R.colNorm = cn;
+    for (int iq = 0; iq < 8; iq += 2) { const double x = R.a(ib + iq), y = R.a(ib + iq + 1); cn = fma(x, x, cn); cn1 = fma(y, y, cn1); }
+  }
+  R.colNorm = cn + cn1;
 }
 
 // Constrained groups of a world's contacts (ConstraintSolver::buildConstrainedGroups :724-780, ContactConstraint::uniteSkeletons
@@ -101,16 +104,27 @@ DEV uint32_t coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, 
   if (ln < MAXR) S.vec[2][ln] = X;
   w.sync();
   if (ln < n) {
-    double wd = 0.0;
+    double wd = 0.0, wd1 = 0.0;
+#pragma unroll 1
+    for (int rb = 0; rb < MAXR; rb += 8) {
 #pragma unroll
-    for (int r = 0; r < MAXR; r++) wd = fma(r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, S.vec[2][r], wd);   // columns >= m were never written
+      for (int rq = 0; rq < 8; rq += 2) {
+        const int r = rb + rq;
+        wd = fma(r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, S.vec[2][r], wd);   // columns >= m were never written
+        wd1 = fma(r + 1 < m ? dn[lay.massed + ln * MAX_ROWS + r + 1] : 0.0, S.vec[2][r + 1], wd1);
+      }
+    }
+    wd += wd1;
     svAt(saved, lay.w + ln, B, b) = wd;
     vNext = svAt(saved, lay.vpre + ln, B, b) + wd;
     nv[(int64_t)ln * B + b] = vNext;
   }
   if (pinvValid && ln < MAXR) {
+#pragma unroll 1
+    for (int ib = 0; ib < MAXR; ib += 8) {
 #pragma unroll
-    for (int i = 0; i < MAXR; i++) dn[lay.pinv + i * MAX_ROWS + ln] = S.P[i * CLD + ln];
+      for (int iq = 0; iq < 8; iq++) dn[lay.pinv + (ib + iq) * MAX_ROWS + ln] = S.P[(ib + iq) * CLD + ln];
+    }
   }
   return w.ballot(!__builtin_isfinite(vNext)) != 0ull ? 0x40u : 0u;   // NBL_ST_NAN: a non-finite next velocity (poisoned inputs end up here)
 }
@@ -271,22 +285,15 @@ __global__ __launch_bounds__(128) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade
   }
 }
 
-// Select + standardise (per unresolved constrained group) + outputs for one unresolved world (one wavefront).
-template <bool MULTI>
-__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_final(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
-                                                              double* __restrict__ saved, SavedLayout lay,
-                                                              double* __restrict__ cacheOut, double* __restrict__ next,
-                                                              uint32_t* __restrict__ status, double* __restrict__ lws,
-                                                              const int32_t* __restrict__ failList,
-                                                              const uint32_t* __restrict__ failCount) {
-  __shared__ CoopLds S;
-  if (blockIdx.x >= *failCount) return;
-#ifdef NBL_CASCADE_TIMING
-  const long long t0 = clock64();
-#endif
-  const DevWave w;
+// Select + standardise (per unresolved constrained group) + outputs for one unresolved world (one wavefront).  The candidates of the
+// three stages come from `stageX` (3 x MAX_ROWS doubles, stride `sx` between entries) and `stageFlags` (3 x MAX_CONTACTS flag words as
+// doubles, stride `sf`): the world's scratch rows in global memory (k_contact_cascade_final) or the workgroup's LDS (fused kernel).
+template <bool MULTI, class W>
+DEV void coopCascadeFinish(const W& w, CoopLds& S, const DevModel& mdl, const DevContactModel* __restrict__ cm, int64_t B, int64_t b,
+                           double* __restrict__ saved, const SavedLayout& lay, double* __restrict__ cacheOut, double* __restrict__ next,
+                           uint32_t* __restrict__ status, const double* __restrict__ lws, const double* stageX, int64_t sx,
+                           const double* stageFlags, int64_t sf) {
   const int ln = w.lane();
-  const int64_t b = failList[blockIdx.x];
   const int n = mdl.n;
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   double* nv = next + (int64_t)n * B;
@@ -316,12 +323,12 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
     R.on = rowOn && gid == g;
     CoopRow& Rg = R;
     CoopStageResult r1, r2, r3;
-    r1.X = Rg.on ? lws[(int64_t)(LW_STAGE_X + row) * B + b] : 0.0;
-    r2.X = Rg.on ? lws[(int64_t)(LW_STAGE_X + MAX_ROWS + row) * B + b] : 0.0;
-    r3.X = Rg.on ? lws[(int64_t)(LW_STAGE_X + 2 * MAX_ROWS + row) * B + b] : 0.0;
-    r1.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 0 * MAX_CONTACTS + g) * B + b];
-    r2.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 1 * MAX_CONTACTS + g) * B + b];
-    r3.flags = (int)lws[(int64_t)(LW_STAGE_FLAGS + 2 * MAX_CONTACTS + g) * B + b];
+    r1.X = Rg.on ? stageX[(int64_t)row * sx] : 0.0;
+    r2.X = Rg.on ? stageX[(int64_t)(MAX_ROWS + row) * sx] : 0.0;
+    r3.X = Rg.on ? stageX[(int64_t)(2 * MAX_ROWS + row) * sx] : 0.0;
+    r1.flags = (int)stageFlags[(int64_t)(0 * MAX_CONTACTS + g) * sf];
+    r2.flags = (int)stageFlags[(int64_t)(1 * MAX_CONTACTS + g) * sf];
+    r3.flags = (int)stageFlags[(int64_t)(2 * MAX_CONTACTS + g) * sf];
     CoopCascadeOut out;
     coopCascadeSelect(w, S, Rg, Rg.on ? X0 : 0.0, cm->fallbackCfm, r1, r2, r3, out);
     if (Rg.on) { X = out.X; cfmRow = out.cfm; cls = out.K.cls; E = out.K.E; }
@@ -344,9 +351,103 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
   }
   const uint32_t nanBit = coopContactOutputs(w, S, n, m, X, K, cfmRow, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
   if (ln == 0 && status) status[b] |= st | nanBit;
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_final(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                              double* __restrict__ saved, SavedLayout lay,
+                                                              double* __restrict__ cacheOut, double* __restrict__ next,
+                                                              uint32_t* __restrict__ status, double* __restrict__ lws,
+                                                              const int32_t* __restrict__ failList,
+                                                              const uint32_t* __restrict__ failCount) {
+  __shared__ CoopLds S;
+  if (blockIdx.x >= *failCount) return;
 #ifdef NBL_CASCADE_TIMING
-  if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
+  const long long t0 = clock64();
 #endif
+  const DevWave w;
+  const int64_t b = failList[blockIdx.x];
+  coopCascadeFinish<MULTI>(w, S, mdl, cm, B, b, saved, lay, cacheOut, next, status, lws, lws + (int64_t)LW_STAGE_X * B + b, B,
+                           lws + (int64_t)LW_STAGE_FLAGS * B + b, B);
+#ifdef NBL_CASCADE_TIMING
+  if (w.lane() == 0) lws[(int64_t)(LW_STAGE_CYCLES + 3) * B + b] = (double)(clock64() - t0);
+#endif
+}
+
+// Stages 1-3 AND the final part in ONE launch (the default): the two stage wavefronts of a world leave their candidates in the
+// workgroup's LDS, and whichever of the two arrives second goes on with select + standardise + outputs (coopCascadeFinish) on the LDS
+// the stages no longer need.  A world's final part therefore starts when ITS stages are done instead of when the slowest world of the
+// launch is - the launch boundary between k_contact_cascade_stages and k_contact_cascade_final made every world wait for the longest
+// Dantzig run of the slice (tail: 2-3 x the mean) - and one launch and one pass over the scratch rows go away.
+struct FusedCascadeLds {
+  union {
+    struct { CascadeLds C1; PgsLds C2; } stages;
+    CoopLds S;
+  } u;
+  double stageX[3 * MAX_ROWS];
+  double stageFlags[3 * MAX_CONTACTS];
+  int arrive;
+  int pad;
+};
+
+template <bool MULTI>
+__global__ __launch_bounds__(128) NBL_WAVES(2) void k_contact_cascade_fused(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B,
+                                                              double* __restrict__ saved, SavedLayout lay,
+                                                              double* __restrict__ cacheOut, double* __restrict__ next,
+                                                              uint32_t* __restrict__ status, double* __restrict__ lws,
+                                                              const int32_t* __restrict__ failList,
+                                                              const uint32_t* __restrict__ failCount) {
+  __shared__ FusedCascadeLds F;
+  if (blockIdx.x >= *failCount) return;
+  const DevWaveInGroup w;
+  const int ln = w.lane();
+  const int wave = (int)(threadIdx.x >> 6);
+  if (threadIdx.x == 0) F.arrive = 0;
+  if (threadIdx.x < 3 * MAX_ROWS) F.stageX[threadIdx.x] = 0.0;
+  __syncthreads();   // the only workgroup-wide barrier: from here on the two wavefronts never wait for each other
+  const int64_t b = failList[blockIdx.x];
+  {
+    const int m = 3 * (int)svAt(saved, lay.nc, B, b);
+    double* dn = denseOf(saved, lay, B, b);
+    CoopRow R;
+    coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+    const double X0 = ln < m ? lws[(int64_t)(LW_X0 + ln) * B + b] : 0.0;
+    const uint32_t failMask = MULTI ? (uint32_t)lws[(int64_t)LW_FAILMASK * B + b] : 1u;
+    int gid = 0;
+    if (MULTI) coopGroups(w, cm, saved, lay, B, b, m, gid);
+    const bool rowOn = R.on;
+#pragma unroll 1
+    for (int g = 0; g < (MULTI ? MAX_CONTACTS : 1); g++) {
+      if (!((failMask >> g) & 1u)) continue;
+      R.on = rowOn && gid == g;
+      CoopRow& Rg = R;
+      auto publish = [&](int stage, const CoopStageResult& r) {
+        if (Rg.on) F.stageX[stage * MAX_ROWS + ln] = r.X;
+        if (ln == 0) F.stageFlags[stage * MAX_CONTACTS + g] = (double)r.flags;
+      };
+      CoopStageResult r;
+      if (wave == 0) {
+        coopCascadeStage1(w, F.u.stages.C1, Rg, X0, r);
+        publish(0, r);
+      } else {
+        coopCascadeStage2(w, F.u.stages.C2, Rg, X0, cm->fallbackCfm, r);
+        publish(1, r);
+        const bool stage2Valid = (r.flags & (CS_SOLVED | CS_VALID)) == (CS_SOLVED | CS_VALID);
+        r.X = 0.0; r.flags = 0;
+        if (!stage2Valid) coopCascadeStage3(w, F.u.stages.C2, Rg, X0, cm->fallbackCfm, r);
+        publish(2, r);
+      }
+      w.sync();
+    }
+  }
+  // arrival: LDS operations of a wavefront execute in order, so the candidates above are in LDS before this wavefront's increment is;
+  // the wavefront that reads 1 is the second one and sees both sets
+  int prev = 0;
+  if (ln == 0) prev = atomicAdd(&F.arrive, 1);
+  prev = __builtin_amdgcn_readfirstlane(prev);
+  if (prev == 0) return;
+  w.sync();
+  coopCascadeFinish<MULTI>(w, F.u.S, mdl, cm, B, b, saved, lay, cacheOut, next, status, lws, F.stageX, 1, F.stageFlags, 1);
 }
 
 // Self-test of the device Dantzig driver (nbl_selftest_lcp_dantzig): one wavefront per problem of a batch of n-row boxed LCPs
@@ -485,12 +586,20 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
   // no M^-1 solve needed here (k_bwd_recompute_coop computes lambda1 for the tree part meanwhile)
   double t = 0.0;
   {
-    double ta = 0.0, tb = 0.0;   // all loads of the column in flight together (d < n <= MAX_DOF_CONTACT), two partial sums
+    // the column in chunks of eight loads in flight (all 40 at once cost 80 registers on top of the A / Q^+ columns: the kernel sat at
+    // 256 VGPRs + 192 AGPRs, ONE wavefront per SIMD, and waited for an empty SIMD whenever another slice's kernels held the chip)
+    double ta = 0.0, tb = 0.0;
+#pragma unroll 1
+    for (int d0 = 0; d0 < MAX_DOF_CONTACT; d0 += 8) {
+      if (d0 >= n) break;
+      double v[8];
 #pragma unroll
-    for (int d = 0; d < MAX_DOF_CONTACT; d += 2) {
-      const double v0 = d < n ? dn[lay.massed + d * MAX_ROWS + row] : 0.0, v1 = d + 1 < n ? dn[lay.massed + (d + 1) * MAX_ROWS + row] : 0.0;
-      ta = fma(v0, d < n ? bc[d] : 0.0, ta);
-      tb = fma(v1, d + 1 < n ? bc[d + 1] : 0.0, tb);
+      for (int q = 0; q < 8; q++) v[q] = d0 + q < n ? dn[lay.massed + (d0 + q) * MAX_ROWS + row] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        ta = fma(v[q], d0 + q < n ? bc[d0 + q] : 0.0, ta);
+        tb = fma(v[q + 1], d0 + q + 1 < n ? bc[d0 + q + 1] : 0.0, tb);
+      }
     }
     t = rowOn ? ta + tb : 0.0;
   }
@@ -518,8 +627,11 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
     if (ln < MAXR) S.vec[slot][ln] = rowOn ? xLane : 0.0;
     w.sync();
     double v0 = 0.0, v1 = 0.0;
+#pragma unroll 1
+    for (int jb = 0; jb < MAXR; jb += 8) {
 #pragma unroll
-    for (int jx = 0; jx < MAXR; jx += 2) { v0 = fma(S.G[jx * CLD + row], S.vec[slot][jx], v0); v1 = fma(S.G[(jx + 1) * CLD + row], S.vec[slot][jx + 1], v1); }
+      for (int jq = 0; jq < 8; jq += 2) { const int jx = jb + jq; v0 = fma(S.G[jx * CLD + row], S.vec[slot][jx], v0); v1 = fma(S.G[(jx + 1) * CLD + row], S.vec[slot][jx + 1], v1); }
+    }
     return v0 + v1;
   };
   // ---- was Q inverted precisely?  The reference switches between two formulas for the derivative of Q^+ b
@@ -572,27 +684,38 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
     S.vec[0][ln] = acc;                      // 64 partial sums in the 96 doubles of S.vec
     w.sync();
     double imp2 = 0.0;
+#pragma unroll 1
+    for (int kb = 0; kb < 64; kb += 8) {       // (eight loads in flight, not 64)
 #pragma unroll
-    for (int k = 0; k < 64; k++) imp2 += S.vec[0][k];
+      for (int k = 0; k < 8; k++) imp2 += S.vec[0][kb + k];
+    }
     precise = imp2 < 1e-18;
     w.sync();
   }
+  // (scheduling fences between the six 24 x 24 products: each reads 48 LDS values; left alone the scheduler issues the loads of all of them
+  // up front - 256 VGPRs + 192 AGPRs, one wavefront per SIMD)
   const double bcl = clamp ? R.Bv : 0.0;
   const double mu = coopPinvApply<DevWave, true>(w, S, fbar, 0);     // (Q^+)^T fbar
+  coopSchedFence();
   const double fls = coopPinvApply<DevWave, false>(w, S, bcl, 1);    // Q^+ b, the reference's least-squares f_c (not the applied x: they differ when the cascade's answer is not standardised)
+  coopSchedFence();
   double al[3], be[3];
   al[0] = -mu; be[0] = fls;
   {
     const double axv = ax(spread(fls), 2);
     al[1] = clamp ? bcl - (axv + cfm * fls) : 0.0;
   }
+  coopSchedFence();
   be[1] = coopPinvApply<DevWave, false>(w, S, mu, 3);
+  coopSchedFence();
   al[2] = coopPinvApply<DevWave, true>(w, S, fls, 0);
+  coopSchedFence();
   {
     const double t2 = ax(mu, 1);
     const double t2f = fold(t2);
     be[2] = clamp ? fbar - (t2 + t2f + cfm * mu) : 0.0;
   }
+  coopSchedFence();
   if (precise) { al[1] = 0.0; be[1] = 0.0; al[2] = 0.0; be[2] = 0.0; }   // -Q^+ dQ Q^+ b alone
   // bounce diagonals (CGGM.cpp:770, BackpropSnapshot.cpp:3099-3146): b = -beta A_c^T v_pre with beta = 1 + e on the normal rows that
   // bounced, so the adjoint of b reaches v_pre (and the contact geometry through A_c^T v_pre) scaled by beta; the pairs of dQ are not
@@ -609,12 +732,21 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
   w.sync();
   if (ln < n) {
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int r0 = 0; r0 < MAXR; r0 += 6) {          // six rows (12 loads) in flight
+      double ms[6], aa[6];
 #pragma unroll
-    for (int r = 0; r < MAXR; r++) {
-      const double ms = r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, aa = r < m ? dn[lay.aall + ln * MAX_ROWS + r] : 0.0;   // columns >= m were never written
+      for (int q = 0; q < 6; q++) {
+        const int r = r0 + q;
+        ms[q] = r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0; aa[q] = r < m ? dn[lay.aall + ln * MAX_ROWS + r] : 0.0;   // columns >= m were never written
+      }
 #pragma unroll
-      for (int k = 0; k < 6; k++) acc[k] = fma(bc[k * MAXR + r], ms, acc[k]);
-      acc[6] = fma(bc[6 * MAXR + r], aa, acc[6]);
+      for (int q = 0; q < 6; q++) {
+        const int r = r0 + q;
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[k] = fma(bc[k * MAXR + r], ms[q], acc[k]);
+        acc[6] = fma(bc[6 * MAXR + r], aa[q], acc[6]);
+      }
     }
     for (int k = 0; k < 3; k++) {
       lws[(int64_t)(LB_S + k * MAX_DOF_CONTACT + ln) * B + b] = acc[k];

@@ -36,11 +36,11 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int NBL_MAX_SLICES = 8;
-enum KernelId { K_FWD = 0, K_DETECT, K_BWD, K_RECOMPUTE, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_BWD_BOUNCE, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_BWD, K_RECOMPUTE, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_BWD_BOUNCE, K_CASCADE_FUSED, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect",
                                            "k_step_backward", "k_bwd_recompute",
                                            "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop", "k_step_forward_coop", "k_bwd_recompute_coop",
-                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final", "k_bwd_bounce"};
+                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final", "k_bwd_bounce", "k_contact_cascade_fused"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -73,6 +73,11 @@ struct nbl_model {
   bool auxOverlap = false;           // NBL_AUX_OVERLAP=1: k_bwd_recompute_coop on an auxiliary stream next to k_bwd_contact_a_coop.
                                      // Measured: no gain (1 slice 7.65 vs 7.68 M/s, 2 slices 8.52 vs 8.57) and a loss once the
                                      // streams exceed four (4 slices 7.4 vs 9.0 M/s): the chip is already shared by the slices.
+  bool fusedCascade = false;         // NBL_FUSED_CASCADE=1: stages + final part in one launch (k_contact_cascade_fused).  Measured on MI355X,
+                                     // metric distribution: one 1024-world slice alone 453 us per step against 503 (the final part of a world no
+                                     // longer waits for the slowest Dantzig run of the launch), four slices in flight 5.93 against 6.11 M/s: the
+                                     // fused kernel holds the final part's 256 registers through the stages (2 waves per SIMD instead of 3) and
+                                     // the other slices' tree kernels wait for the CUs (k_step_forward_coop 70 -> 111 us).  Off by default.
   bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
   int nPairs = 0;                    // candidate collider pairs of the model
   bool multiGroup = false;           // colliders on more than one skeleton: a world can hold several constrained groups
@@ -463,6 +468,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e6 = getenv("NBL_COOP_FINAL")) m->coopFinal = atoi(e6) != 0;
     if (const char* e10 = getenv("NBL_AUX_OVERLAP")) m->auxOverlap = atoi(e10) != 0;
     if (const char* e13 = getenv("NBL_DETECT_SPLIT")) m->detectSplit = atoi(e13) != 0;
+    if (const char* e14 = getenv("NBL_FUSED_CASCADE")) m->fusedCascade = atoi(e14) != 0;
     m->nPairs = hc.nPairs;
     // measured (MI355X, B = 4096, world-frame sweeps): 5.5 vs 3.8 M/s with colliders, 16.4 vs 11.0 M/s without
     m->coopTree = coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
@@ -618,10 +624,15 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(mg ? k_contact_solve_coop<true> : k_contact_solve_coop<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
                                              (double*)saved, m->lay, lcp_cache_in, lcp_cache_out, next_state, status, lws,
                                              failList, failCount));
-      TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(mg ? k_contact_cascade_stages<true> : k_contact_cascade_stages<false>, dim3((unsigned)cnt), dim3(128), 0, s, mdl, m->dContact, B,
-                                               (double*)saved, m->lay, lws, failList, failCount));
-      TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(mg ? k_contact_cascade_final<true> : k_contact_cascade_final<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
-                                                (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+      if (m->fusedCascade) {
+        TIMED(K_CASCADE_FUSED, hipLaunchKernelGGL(mg ? k_contact_cascade_fused<true> : k_contact_cascade_fused<false>, dim3((unsigned)cnt), dim3(128), 0, s, mdl, m->dContact, B,
+                                                  (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+      } else {
+        TIMED(K_CASCADE_COOP, hipLaunchKernelGGL(mg ? k_contact_cascade_stages<true> : k_contact_cascade_stages<false>, dim3((unsigned)cnt), dim3(128), 0, s, mdl, m->dContact, B,
+                                                 (double*)saved, m->lay, lws, failList, failCount));
+        TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(mg ? k_contact_cascade_final<true> : k_contact_cascade_final<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
+                                                  (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
+      }
     }
   return NBL_OK;
 }

@@ -57,3 +57,41 @@ def test_a_70_body_tree_runs_one_world_per_lane(shape, free_root):
     rng = np.random.default_rng(4242)
     md = random_tree(rng, 70, shape, free_root)
     _compare(md, 64, 11, tol=1e-6 if shape == "chain" else 1e-7)
+
+
+def test_fused_cascade_launch_is_bit_identical_to_the_two_launches(monkeypatch):
+    """NBL_FUSED_CASCADE=1: stages 1-3 and the final part of the LCP cascade in ONE launch (k_contact_cascade_fused: the wavefront of a
+    world that finishes its stage second goes on with select + standardise + outputs, candidates through LDS) against the default
+    two launches (k_contact_cascade_stages, k_contact_cascade_final): next states, status words, warm starts and gradients bit for bit,
+    on the metric distribution (half of the worlds in the cascade) and on two cubes side by side (several constrained groups)."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    from util import box_stack_inputs
+    cases = [contact_inputs("atlas20", 1024, 13, joint_noise=0.02, vel_noise=0.01, action_noise=0.0), box_stack_inputs(512, 32)]
+    md2 = na.box_stack(); n2 = md2.num_dofs; rng = np.random.default_rng(21)
+    s2 = np.zeros((512, 2 * n2))
+    gb = md2.boxes[0]; top = (md2.bodies[0].T_pj @ gb.T)[1, 3] + 0.5 * gb.size[1]; half = 0.5 * gb.size[0]
+    for k, x0 in enumerate((-0.4, 0.4)):
+        o = 6 * k; c0 = md2.bodies[1 + k].T_pj[:3, 3]
+        s2[:, o + 1] = rng.uniform(-1, 1, 512); s2[:, o + 3] = x0 * half + rng.uniform(-0.15, 0.15, 512) * half - c0[0]
+        s2[:, o + 4] = top + 0.1 - rng.uniform(1e-4, 1e-3, 512) - c0[1]; s2[:, o + 5] = rng.uniform(-0.5, 0.5, 512) * half - c0[2]
+        s2[:, n2 + o:n2 + o + 6] = rng.normal(0, 0.05, (512, 6))
+    cases.append((md2, s2, rng.normal(0, 0.1, (512, n2))))
+    results = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("NBL_FUSED_CASCADE", fused)
+        out = []
+        for md, s, a in cases:
+            g = np.random.default_rng(5).normal(0, 1, s.shape)
+            world = na.World(md, device="cuda:0")
+            st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+            y = timestep(world, st, at)
+            status = world.last_status.clone(); cache = world.lcp_cache.clone()
+            y.backward(torch.tensor(g, device="cuda:0"))
+            out.append((y.detach().clone(), status, cache, st.grad.clone(), at.grad.clone()))
+        results[fused] = out
+    for ra, rb in zip(results["0"], results["1"]):
+        assert ((ra[1] & 0x2) == 0).float().mean() > 0.2            # the cascade is exercised
+        for ta, tb in zip(ra, rb):
+            assert torch.equal(ta, tb)
