@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: timed region without the per-kernel HIP events")
     ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (torch.distributed.run, one process per GPU, RCCL) even for --gpus 1")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the secondary one-launch-per-kernel measurement")
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed region until this much time has been timed; the median repetition is reported")
     ap.add_argument("--max-reps", type=int, default=25)
     args = ap.parse_args()
@@ -219,7 +220,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0):
+    def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0, bounds=bounds, streams=streams):
         """W untimed + K timed fwd+bwd steps on a fresh synthetic batch of the workload at pose noise `noise`."""
         md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, noise)
         worlds = [na.World(md, device=dev) for _ in bounds]
@@ -291,6 +292,10 @@ def main():
     if has_contact and args.easy_noise > 0 and args.easy_noise != args.joint_noise:
         # the easy distribution: every world resolves at LCP stage 0 (round 1's headline), half the steps, no kernel events
         easy = measure(args.easy_noise, max(1, args.steps // 2), min(args.warmup, 4), False)
+    single = None
+    if has_contact and len(bounds) > 1 and not args.no_single_stream:
+        # the same batch as ONE launch per kernel per step (no stream slices): what the chain costs without the overlap of the slices
+        single = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1])
     elapsed, st, tm, timing_period, md, s_np, a_np, wl_desc, world = (R[x] for x in ("elapsed", "status", "timing", "timing_period", "md", "s", "a", "desc", "world"))
     n = world.n
 
@@ -398,6 +403,12 @@ def main():
                 "steps": esteps, "ms_per_step": easy["elapsed"] / esteps * 1e3,
                 "lanes_resolved_at_lcp_stage0": float((est & 0x2).astype(bool).mean()),
                 "note": "same workload on the easy pose distribution (every world short-circuits at LCP stage 0): round 1's headline regime"}}
+        if single is not None:
+            ssteps = max(1, args.steps // 2)
+            out.setdefault("secondary", {})["single_stream"] = {
+                "value": units_per_step * ssteps / single["elapsed"], "unit": "worlds*timesteps/s", "steps": ssteps,
+                "ms_per_step": single["elapsed"] / ssteps * 1e3, "stream_slices": 1,
+                "note": "the same batch and distribution with ONE launch per kernel per step (all worlds of the GPU in one chain, no stream slices)"}
         if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(md, s_np, a_np)

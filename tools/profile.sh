@@ -4,7 +4,7 @@
 #   usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---steps 8 --warmup 2 --no-cpu-baseline --easy-noise 0 --min-seconds 0}
+ARGS=${*:---steps 8 --warmup 2 --no-cpu-baseline --easy-noise 0 --min-seconds 0 --no-single-stream}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
