@@ -27,28 +27,32 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
   t2 = cross(n, t1);
 }
 
-__global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBody* __restrict__ bodies,
-                                                       const DevContactModel* __restrict__ cm, int64_t B,
-                                                       double* __restrict__ saved, SavedLayout lay,
-                                                       uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists,
-                                                       uint32_t* __restrict__ failCount, int ppw) {
+// The narrow phase of `wl` worlds x `ppw` lanes (threads tid < wl * ppw of the workgroup `bid`; any further threads of the workgroup
+// only take part in its barriers).  keptP: MAX_CONTACTS * 3 * 64 doubles, clipBuf: 48 * 64 doubles, stage: the staging area of the
+// ppw > 1 scheme - all LDS.  qFk != nullptr: the world transforms of the collider bodies are computed HERE from the positions (the
+// kernel runs next to the forward tree kernel, not after it) and the status word is left alone: the contact count goes to the record
+// with + 0.5 when contacts were dropped, k_contact_solve_coop raises NBL_ST_CONTACT / NBL_ST_CONTACT_OVERFLOW from it.
+DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodies, const DevContactModel* __restrict__ cm, int64_t B,
+                           double* __restrict__ saved, const SavedLayout& lay, uint32_t* __restrict__ status, double* __restrict__ ws,
+                           int doTwists, uint32_t* __restrict__ failCount, int ppw, const double* __restrict__ qFk, int bid, int wl,
+                           double* keptP, double* clipBuf, double* stage) {
+  const int tid = (int)threadIdx.x;
   // the counter of the unresolved-worlds list of this slice starts at zero for the solve kernel that follows on the stream
   // (a separate hipMemsetAsync node cost ~6 us of every forward step)
-  if (failCount && blockIdx.x == 0 && threadIdx.x == 0) *failCount = 0u;
+  if (failCount && bid == 0 && tid == 0) *failCount = 0u;
   NBL_PHASE(56);
   // ppw lanes per world (1, 2 or 4): the narrow phases of ppw collider pairs of a world run side by side, each lane parks its
   // candidate contacts in LDS, and the world's first lane then accepts them in pair order - exactly the order and the filters
   // of the one-lane loop, at about 1 / ppw of its dependent chain (two foot-ground pairs: 74k -> ~40k cycles).
-  extern __shared__ __attribute__((aligned(16))) double stage[];   // [thread][8 candidates][CR_SIZE] + counts (ppw > 1 only)
-  const int pl = (int)threadIdx.x % ppw, wl = (int)blockDim.x / ppw;
-  const int64_t b = mdl.b0 + (int64_t)blockIdx.x * wl + (int)threadIdx.x / ppw;
-  const bool valid = b < mdl.b1;
+  const bool extra = tid >= wl * ppw;                 // threads of a wider workgroup: barriers only
+  const int pl = tid % ppw;
+  const int64_t b = mdl.b0 + (int64_t)bid * wl + tid / ppw;
+  const bool valid = !extra && b < mdl.b1;
   if (!valid && ppw == 1) return;
   const int64_t bs = valid ? b : mdl.b1 - 1;       // lanes of a padding world repeat the last world's narrow phase, store nothing
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, bs, saved, &lay);
-  __shared__ double keptP[MAX_CONTACTS * 3 * 64];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
-  __shared__ double clipBuf[48 * 64];               // clip polygons of boxBox, [entry][lane]
-  LaneBuf clip; clip.base = clipBuf + threadIdx.x;
+  const int ltid = extra ? 0 : tid;
+  LaneBuf clip; clip.base = clipBuf + ltid;
   int nC = 0;
   bool overflow = false, edge = false;
   // accept one candidate (lane pl == 0 of the world, or the only lane): postProcess + depth filter + append to the record
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
     // LDS (reading them back from the record would be a global round trip per comparison)
     bool close = false;
     for (int e = 0; e < nC; e++) {
-      const V3 d = pt - mk3(keptP[(e * 3 + 0) * 64 + threadIdx.x], keptP[(e * 3 + 1) * 64 + threadIdx.x], keptP[(e * 3 + 2) * 64 + threadIdx.x]);
+      const V3 d = pt - mk3(keptP[(e * 3 + 0) * 64 + ltid], keptP[(e * 3 + 1) * 64 + ltid], keptP[(e * 3 + 2) * 64 + ltid]);
       if (norm3(d) < 3.0e-12) { close = true; break; }
     }
     if (close) return;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
     if (depth < 0.0 || depth > cm->clippingDepth) return;
     if (nC >= cm->maxContacts) { overflow = true; return; }
     const int r0 = lay.contacts + nC * CR_SIZE;
-    keptP[(nC * 3 + 0) * 64 + threadIdx.x] = pt.x; keptP[(nC * 3 + 1) * 64 + threadIdx.x] = pt.y; keptP[(nC * 3 + 2) * 64 + threadIdx.x] = pt.z;
+    keptP[(nC * 3 + 0) * 64 + ltid] = pt.x; keptP[(nC * 3 + 1) * 64 + ltid] = pt.y; keptP[(nC * 3 + 2) * 64 + ltid] = pt.z;
 #pragma unroll
     for (int e = 0; e < CR_SIZE; e++) {
       double v = ct[e * stride];
@@ -88,13 +92,26 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
     out[CR_EB_FIXED] = ct.edgeBFixed.x; out[CR_EB_FIXED + 1] = ct.edgeBFixed.y; out[CR_EB_FIXED + 2] = ct.edgeBFixed.z;
     out[CR_EB_DIR] = ct.edgeBDir.x; out[CR_EB_DIR + 1] = ct.edgeBDir.y; out[CR_EB_DIR + 2] = ct.edgeBDir.z;
   };
+  // BodyNode::mWorldTransform of a collider body: from the tree block the forward kernel left, or - qFk - the product of the joint
+  // transforms down its ancestor chain (ancestors are numbered before their descendants)
+  auto worldT = [&](int body) -> T12 {
+    if (!qFk) return ldTAt(c, body, WS_TW);
+    uint64_t chain = cm->ancestors[body];
+    T12 TW = jointRelTransform(bodies[__builtin_ctzll(chain)], qFk, B, bs);
+    chain &= chain - 1;
+    while (chain) {
+      TW = mulT(TW, jointRelTransform(bodies[__builtin_ctzll(chain)], qFk, B, bs));
+      chain &= chain - 1;
+    }
+    return TW;
+  };
   // narrow phase of collider pair pi, every contact handed to emit(ct)
   auto runPair = [&](int pi, auto emit) {
     const DevBox& ba = cm->boxes[cm->pairA[pi]];
     const DevBox& bb = cm->boxes[cm->pairB[pi]];
     T12 Ta = cT(ba.T), Tb = cT(bb.T);
-    if (ba.body >= 0) Ta = mulT(ldTAt(c, ba.body, WS_TW), Ta);
-    if (bb.body >= 0) Tb = mulT(ldTAt(c, bb.body, WS_TW), Tb);
+    if (ba.body >= 0) Ta = mulT(worldT(ba.body), Ta);
+    if (bb.body >= 0) Tb = mulT(worldT(bb.body), Tb);
     // dispatch on the two shape types (collide(), DARTCollide.cpp:5030-5260)
     const V3 ha = mk3(ba.half[0], ba.half[1], ba.half[2]), hb = mk3(bb.half[0], bb.half[1], bb.half[2]);
     const bool sa = ba.shape == SHAPE_SPHERE, sb = bb.shape == SHAPE_SPHERE;
@@ -110,12 +127,13 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
   } else {
     // the world's first lane accepts the contacts of ITS pair directly (it is the first pair of the group, so the order holds);
     // only the other lanes park theirs: (ppw - 1) staging slots per world
-    const int wI = (int)threadIdx.x / ppw;
+    const int wI = ltid / ppw;
     double* mine = stage + (size_t)(wI * (ppw - 1) + (pl > 0 ? pl - 1 : 0)) * (8 * CR_SIZE);
     int* counts = reinterpret_cast<int*>(stage + (size_t)wl * (ppw - 1) * (8 * CR_SIZE));
     for (int p0 = 0; p0 < nPairs; p0 += ppw) {       // ppw pairs of every world at a time
       int cnt = 0;
-      if (pl == 0) {
+      if (extra) {
+      } else if (pl == 0) {
         if (valid) runPair(p0, [&](const DevContact& ct) { double rec[CR_SIZE]; toRec(ct, rec); acceptRec(rec, 1, p0); });
       } else {
         if (p0 + pl < nPairs) runPair(p0 + pl, [&](const DevContact& ct) { if (cnt < 8) { toRec(ct, mine + cnt * CR_SIZE); cnt++; } });
@@ -137,12 +155,12 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
   // NOTE: the duplicate filter above only sees contacts that were kept; the reference compares against every
   // contact of the total result including ones later dropped by the depth filter.  Those can only coincide
   // with a kept point if they are the same point, which the depth filter treats identically.
-  svAt(saved, lay.nc, B, b) = (double)nC;
+  svAt(saved, lay.nc, B, b) = (double)nC + ((qFk && overflow) ? 0.5 : 0.0);
   uint32_t st = 0;
   if (nC > 0) st |= 0x1u;
   if (overflow) st |= 0x80u;
   (void)edge;
-  if (status) status[b] |= st;          // the forward tree kernel initialised the word (0, or NBL_ST_NAN for a non-finite unconstrained step)
+  if (status && !qFk) status[b] |= st;  // the forward tree kernel initialised the word (0, or NBL_ST_NAN for a non-finite unconstrained step)
   NBL_PHASE(60);
   if (!doTwists || !__any(nC > 0)) return;   // k_step_forward_coop already left the twists
   // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_VTW (the dead bias
@@ -154,6 +172,18 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
     if (bd.parent >= 0) V = V + AdInvT(ldT(c, i), ldV6(c, bd.parent, WS_VTW));
     stV6(c, i, WS_VTW, V);
   }
+}
+
+__global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                       const DevContactModel* __restrict__ cm, int64_t B,
+                                                       double* __restrict__ saved, SavedLayout lay,
+                                                       uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists,
+                                                       uint32_t* __restrict__ failCount, int ppw) {
+  extern __shared__ __attribute__((aligned(16))) double stage[];   // [thread][8 candidates][CR_SIZE] + counts (ppw > 1 only)
+  __shared__ double keptP[MAX_CONTACTS * 3 * 64];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
+  __shared__ double clipBuf[48 * 64];               // clip polygons of boxBox, [entry][lane]
+  contactDetectBody(mdl, bodies, cm, B, saved, lay, status, ws, doTwists, failCount, ppw, nullptr, (int)blockIdx.x, (int)blockDim.x / ppw,
+                    keptP, clipBuf, stage);
 }
 
 }  // namespace nbl

@@ -145,8 +145,12 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
   if (b >= mdl.b1) return;
   const int n = mdl.n;
-  const int nC = (int)svAt(saved, lay.nc, B, b);
+  const double ncD = svAt(saved, lay.nc, B, b);
+  const int nC = (int)ncD;
   const int m = 3 * nC;
+  // the narrow phase that runs NEXT TO the forward tree kernel (k_forward_detect_coop) leaves the status word to this kernel: contacts
+  // present, contacts dropped (count + 0.5).  Idempotent after the stand-alone narrow phase, which sets the bits itself.
+  if (ln == 0 && status) status[b] |= (nC > 0 ? 0x1u : 0u) | (ncD - (double)nC > 0.25 ? 0x80u : 0u);
   double* nv = next + (int64_t)n * B;
   double* dn = denseOf(saved, lay, B, b);
   if (m == 0) {

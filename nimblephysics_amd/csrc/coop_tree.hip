@@ -20,7 +20,7 @@ template <int P> __host__ __device__ constexpr int coopWorldDoubles(int nbp, int
 // returns false for a padding world
 template <int P>
 DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __restrict__ bodies, const DevDof* __restrict__ dofs,
-                       double* lds, int64_t B) {
+                       double* lds, int64_t B, uint32_t bid = blockIdx.x, uint32_t nblk = gridDim.x) {
   DevBody* lb = reinterpret_cast<DevBody*>(lds);
   DevDof* ld = reinterpret_cast<DevDof*>(lb + mdl.nb);
   double* st = reinterpret_cast<double*>(ld + mdl.n);
@@ -56,7 +56,7 @@ DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __res
   int sub = tl / mdl.nbp;
   const bool spare = sub >= wpw;            // lanes beyond the last packed world (64 not a multiple of nbp): idle
   if (spare) sub = wpw - 1;
-  const int64_t first = mdl.b0 + (coopWorld(blockIdx.x, gridDim.x) * wpb + wv) * wpw;
+  const int64_t first = mdl.b0 + (coopWorld(bid, nblk) * wpb + wv) * wpw;
   // worlds past the end of the slice repeat its last world (same inputs, same values stored to the same addresses) instead of
   // branching around every store
   const int64_t b = first + sub < mdl.b1 ? first + sub : mdl.b1 - 1;
@@ -317,15 +317,13 @@ DEV void stepAba(const CoopCtxT<PROF_FWD>& c, const double* __restrict__ q, cons
 }
 
 // World::step without contact + (contact models) the body twists at the pre-contact velocity
-__global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
-                                                          const DevDof* __restrict__ dofs, int64_t B,
-                                                          const double* __restrict__ state, const double* __restrict__ action,
-                                                          double* __restrict__ next, double* __restrict__ saved,
-                                                          uint32_t* __restrict__ status, SavedLayout lay, int withTwists) {
-  extern __shared__ __attribute__((aligned(16))) double ldsTree[];
+DEV void stepForwardCoopBody(const DevModel& mdl, const DevBody* __restrict__ bodies, const DevDof* __restrict__ dofs, int64_t B,
+                             const double* __restrict__ state, const double* __restrict__ action, double* __restrict__ next,
+                             double* __restrict__ saved, uint32_t* __restrict__ status, const SavedLayout& lay, int withTwists,
+                             double* ldsTree, uint32_t bid, uint32_t nblk) {
   CoopCtxT<PROF_FWD> c;
   NBL_PHASE(0);
-  if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B)) return;
+  if (!coopTreeSetup(c, mdl, bodies, dofs, ldsTree, B, bid, nblk)) return;
   const int64_t b = c.b;
   bodies = c.bodies; dofs = c.dofs;   // the LDS copies
   stepForwardCore(c, state, action, next, saved, lay);
@@ -365,6 +363,37 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_step
     if (c.lane == 0) status[b] = (votes & gmask) != 0ull ? 0x40u : 0u;
   }
   NBL_PHASE(10);
+}
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_step_forward_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                          const DevDof* __restrict__ dofs, int64_t B,
+                                                          const double* __restrict__ state, const double* __restrict__ action,
+                                                          double* __restrict__ next, double* __restrict__ saved,
+                                                          uint32_t* __restrict__ status, SavedLayout lay, int withTwists) {
+  extern __shared__ __attribute__((aligned(16))) double ldsTree[];
+  stepForwardCoopBody(mdl, bodies, dofs, B, state, action, next, saved, status, lay, withTwists, ldsTree, blockIdx.x, gridDim.x);
+}
+
+// The forward tree kernel AND the narrow phase in one launch (models with colliders, the default): the first `nDetect` workgroups run the
+// narrow phase of wl worlds each (contactDetectBody with its own forward kinematics of the collider bodies - contacts are detected at
+// q_t, they need nothing the tree sweeps compute), the others the tree sweeps.  The two are independent, the narrow phase is a
+// ~40 us chain of one lane per collider pair on 1/8 of the chip, and as a launch of its own it stood between the tree kernel and the
+// contact-row kernel of every step; streams cannot provide the overlap (a fifth stream in flight halves the throughput).
+__global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forward_detect_coop(DevModel mdl, const DevBody* __restrict__ bodies,
+                                                          const DevDof* __restrict__ dofs, const DevContactModel* __restrict__ cm, int64_t B,
+                                                          const double* __restrict__ state, const double* __restrict__ action,
+                                                          double* __restrict__ next, double* __restrict__ saved,
+                                                          uint32_t* __restrict__ status, SavedLayout lay, double* __restrict__ ws,
+                                                          uint32_t* __restrict__ failCount, int ppw, int wl, int nDetect) {
+  extern __shared__ __attribute__((aligned(16))) double ldsTree[];
+  if ((int)blockIdx.x < nDetect) {
+    double* keptP = ldsTree;                              // MAX_CONTACTS * 3 * 64
+    double* clipBuf = keptP + MAX_CONTACTS * 3 * 64;      // 48 * 64
+    double* stage = clipBuf + 48 * 64;
+    contactDetectBody(mdl, bodies, cm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage);
+    return;
+  }
+  stepForwardCoopBody(mdl, bodies, dofs, B, state, action, next, saved, status, lay, 1, ldsTree, blockIdx.x - (uint32_t)nDetect,
+                      gridDim.x - (uint32_t)nDetect);
 }
 
 // ---- backward sweeps in the WORLD frame (lane = body) ---------------------------------------------------------------------

@@ -242,6 +242,38 @@ DEV V6 jointTwist(const DevBody& bd, const double* __restrict__ v, int64_t B, in
   return v[bd.dofOff * B + b] * cV6(bd.S);
 }
 
+// T_parent->child of one body at the positions q ([n][B]): T_pj Q(q) T_cj^-1 with Q of the joint type (RevoluteJoint.cpp:203-211,
+// PrismaticJoint, ScrewJoint.cpp:217-232, FreeJoint.cpp:74-81, BallJoint.cpp:91-95; ball joints and free joints below the root are
+// chains of coincident single-axis bodies whose first one carries the exponential map).  The same expressions as the tree kernels'
+// first sweep; used by the narrow phase when it runs next to the forward tree kernel instead of after it.
+DEV T12 jointRelTransform(const DevBody& bd, const double* __restrict__ q, int64_t B, int64_t b) {
+  T12 Q;
+  if (bd.jtype == JT_REVOLUTE) {
+    const double qi = q[bd.dofOff * B + b];
+    Q.R = expAngular(mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi));
+    Q.p = mk3(0, 0, 0);
+  } else if (bd.jtype == JT_PRISMATIC) {
+    const double qi = q[bd.dofOff * B + b];
+    Q.R = eye3();
+    Q.p = mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi);
+  } else if (bd.jtype == JT_SCREW) {
+    const double qi = q[bd.dofOff * B + b], hq = bd.screwRate * qi;
+    Q.R = expAngular(mk3(bd.axis[0] * qi, bd.axis[1] * qi, bd.axis[2] * qi));
+    Q.p = mk3(bd.axis[0] * hq, bd.axis[1] * hq, bd.axis[2] * hq);
+  } else if (bd.jtype == JT_FREEC) {
+    const int o = bd.dofOff;
+    Q.R = bd.ballComp == 0 ? expMapRot(mk3(q[(o + 0) * B + b], q[(o + 1) * B + b], q[(o + 2) * B + b])) : eye3();
+    Q.p = bd.ballComp == 0 ? mk3(q[(o + 3) * B + b], q[(o + 4) * B + b], q[(o + 5) * B + b]) : mk3(0, 0, 0);
+  } else if (bd.jtype == JT_BALL) {
+    Q.R = bd.ballComp == 0 ? expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b])) : eye3();
+    Q.p = mk3(0, 0, 0);
+  } else {
+    Q.R = expMapRot(mk3(q[(bd.dofOff + 0) * B + b], q[(bd.dofOff + 1) * B + b], q[(bd.dofOff + 2) * B + b]));
+    Q.p = mk3(q[(bd.dofOff + 3) * B + b], q[(bd.dofOff + 4) * B + b], q[(bd.dofOff + 5) * B + b]);
+  }
+  return mulT(mulT(cT(bd.Tpj), Q), cT(bd.TcjInv));
+}
+
 // ---------------------------------------------------------------------------------------------
 // The three ABA sweeps.  q, v: [n][B];  tau fetched through tauAt(d).  Leaves T, V, AI, AIS, psi,
 // A in the workspace; joint accelerations are handed to `emit(d, qdd)`.

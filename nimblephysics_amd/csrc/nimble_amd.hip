@@ -36,11 +36,11 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int NBL_MAX_SLICES = 8;
-enum KernelId { K_FWD = 0, K_DETECT, K_BWD, K_RECOMPUTE, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_BWD_BOUNCE, K_CASCADE_FUSED, K_COUNT };
+enum KernelId { K_FWD = 0, K_DETECT, K_BWD, K_RECOMPUTE, K_BWD_FINAL, K_SOLVE_COOP, K_BWD_A_COOP, K_ROWS_COOP, K_BWD_B_COOP, K_FWD_COOP, K_RECOMPUTE_COOP, K_BWD_FINAL_COOP, K_TREE_TO_LANES, K_CASCADE_COOP, K_CASCADE_FINAL, K_BWD_BOUNCE, K_CASCADE_FUSED, K_FWD_DETECT, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_step_forward", "k_contact_detect",
                                            "k_step_backward", "k_bwd_recompute",
                                            "k_bwd_final", "k_contact_solve_coop", "k_bwd_contact_a_coop", "k_contact_rows_coop", "k_bwd_contact_b_coop", "k_step_forward_coop", "k_bwd_recompute_coop",
-                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final", "k_bwd_bounce", "k_contact_cascade_fused"};
+                                           "k_bwd_final_coop", "k_tree_to_lanes", "k_contact_cascade_stages", "k_contact_cascade_final", "k_bwd_bounce", "k_contact_cascade_fused", "k_forward_detect_coop"};
 struct TimedLaunch {
   hipEvent_t start, stop;
   int kernel;
@@ -78,6 +78,7 @@ struct nbl_model {
                                      // longer waits for the slowest Dantzig run of the launch), four slices in flight 5.93 against 6.11 M/s: the
                                      // fused kernel holds the final part's 256 registers through the stages (2 waves per SIMD instead of 3) and
                                      // the other slices' tree kernels wait for the CUs (k_step_forward_coop 70 -> 111 us).  Off by default.
+  bool fusedDetect = true;           // NBL_FUSED_DETECT=0: the narrow phase as a launch of its own after the forward tree kernel
   bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
   int nPairs = 0;                    // candidate collider pairs of the model
   bool multiGroup = false;           // colliders on more than one skeleton: a world can hold several constrained groups
@@ -469,6 +470,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e10 = getenv("NBL_AUX_OVERLAP")) m->auxOverlap = atoi(e10) != 0;
     if (const char* e13 = getenv("NBL_DETECT_SPLIT")) m->detectSplit = atoi(e13) != 0;
     if (const char* e14 = getenv("NBL_FUSED_CASCADE")) m->fusedCascade = atoi(e14) != 0;
+    if (const char* e15 = getenv("NBL_FUSED_DETECT")) m->fusedDetect = atoi(e15) != 0;
     m->nPairs = hc.nPairs;
     // measured (MI355X, B = 4096, world-frame sweeps): 5.5 vs 3.8 M/s with colliders, 16.4 vs 11.0 M/s without
     m->coopTree = coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
@@ -512,6 +514,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_step_forward_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_forward_detect_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_recompute_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_final_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
@@ -596,14 +599,25 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     const size_t treeLds = m->ldsFwd;
     const int64_t perBlockF = (int64_t)std::max(1, m->wpbFwd) * std::max(1, (int)m->mdl.pad);   // worlds per workgroup
     const dim3 treeGrid((unsigned)((cnt + perBlockF - 1) / perBlockF)), treeBlock(64 * std::max(1, m->wpbFwd));
-    if (m->coopTree && (saved || !m->hasContact))
+    // lanes per world of the narrow phase: the collider pairs of a world side by side (k_contact_detect / contactDetectBody)
+    const int ppwD = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
+    const int wlD = std::min(tl, 64 / ppwD);                       // worlds per narrow-phase workgroup
+    const size_t detectLds = ((size_t)MAX_CONTACTS * 3 * 64 + 48 * 64) * sizeof(double) +
+                             (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0);
+    const bool fusedDetect = m->hasContact && m->coopTree && saved && m->fusedDetect && std::max(treeLds, detectLds) <= 160u * 1024u;
+    if (fusedDetect) {
+      const int nDetect = (int)((cnt + wlD - 1) / wlD);
+      TIMED(K_FWD_DETECT, hipLaunchKernelGGL(k_forward_detect_coop, dim3(treeGrid.x + (unsigned)nDetect), treeBlock, std::max(treeLds, detectLds), s, mdl,
+                                             m->dBodies, m->dDofs, m->dContact, B, state, action, next_state, (double*)saved, status, m->lay,
+                                             (double*)workspace, failCountAll + si, ppwD, wlD, nDetect));
+    } else if (m->coopTree && (saved || !m->hasContact))
       TIMED(K_FWD_COOP, hipLaunchKernelGGL(k_step_forward_coop, treeGrid, treeBlock, treeLds, s, mdl, m->dBodies, m->dDofs, B,
                                            state, action, next_state, (double*)saved, status, m->lay, m->hasContact ? 1 : 0));
     else
       TIMED(K_FWD, hipLaunchKernelGGL(k_step_forward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, state, action, next_state,
                                       (double*)saved, status, (double*)workspace, m->lay));
     if (m->hasContact) {
-      {
+      if (!fusedDetect) {
         // lanes per world of the narrow phase: the collider pairs of a world side by side (k_contact_detect)
         const int ppw = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
         const int wl = std::min(tl, 64 / ppw);                       // worlds per workgroup
