@@ -389,7 +389,18 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
     double* keptP = ldsTree;                              // MAX_CONTACTS * 3 * 64
     double* clipBuf = keptP + MAX_CONTACTS * 3 * 64;      // 48 * 64
     double* stage = clipBuf + 48 * 64;
-    contactDetectBody(mdl, bodies, cm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage);
+    // the body constants of the forward kinematics from LDS (the two feet of a world sit on different lanes: indexed per lane, the
+    // constants would be ~190 dependent global loads per lane)
+    const size_t stageDoubles = ppw > 1 ? (size_t)wl * (ppw - 1) * (8 * CR_SIZE) + ((size_t)wl * (ppw - 1) + 1) / 2 : 0;
+    DevBody* lb = reinterpret_cast<DevBody*>(stage + ((stageDoubles + 1) & ~(size_t)1));
+    {
+      double* dst = reinterpret_cast<double*>(lb);
+      const double* src = reinterpret_cast<const double*>(bodies);
+      const int cnt = mdl.nb * (int)(sizeof(DevBody) / sizeof(double));
+      for (int i = (int)threadIdx.x; i < cnt; i += (int)blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    contactDetectBody(mdl, lb, cm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage);
     return;
   }
   stepForwardCoopBody(mdl, bodies, dofs, B, state, action, next, saved, status, lay, 1, ldsTree, blockIdx.x - (uint32_t)nDetect,

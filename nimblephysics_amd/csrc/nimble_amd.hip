@@ -603,7 +603,8 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     const int ppwD = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
     const int wlD = std::min(tl, 64 / ppwD);                       // worlds per narrow-phase workgroup
     const size_t detectLds = ((size_t)MAX_CONTACTS * 3 * 64 + 48 * 64) * sizeof(double) +
-                             (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0);
+                             (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0) +
+                             (size_t)m->nb * sizeof(DevBody) + 32;   // + the body constants of the narrow phase's own forward kinematics
     const bool fusedDetect = m->hasContact && m->coopTree && saved && m->fusedDetect && std::max(treeLds, detectLds) <= 160u * 1024u;
     if (fusedDetect) {
       const int nDetect = (int)((cnt + wlD - 1) / wlD);
