@@ -29,6 +29,7 @@ class WrtMassBodyNodeEntryType(enum.IntEnum):
 
 
 _DIMS = {WrtMassBodyNodeEntryType.INERTIA_MASS: 1, WrtMassBodyNodeEntryType.INERTIA_COM: 3,
+         WrtMassBodyNodeEntryType.INERTIA_COM_MU: 1,
          WrtMassBodyNodeEntryType.INERTIA_DIAGONAL: 3, WrtMassBodyNodeEntryType.INERTIA_OFF_DIAGONAL: 3,
          WrtMassBodyNodeEntryType.INERTIA_FULL: 10}
 
@@ -75,6 +76,9 @@ class WrtMassEntry:
             return np.array([b.mass], dtype=np.float64)
         if self.type == t.INERTIA_COM:
             return np.asarray(b.com, dtype=np.float64).copy()
+        if self.type == t.INERTIA_COM_MU:   # the first axis the scaling group moves (WithRespectToMass.cpp:157-166)
+            k = 0 if b.beta[0] != 0 else (1 if b.beta[1] != 0 else 2)
+            return np.array([b.com[k] / b.beta[k]], dtype=np.float64)
         if self.type == t.INERTIA_DIAGONAL:
             return np.asarray(b.inertia[:3], dtype=np.float64).copy()
         if self.type == t.INERTIA_OFF_DIAGONAL:
@@ -94,6 +98,8 @@ class WrtMassEntry:
             b.mass = new
         elif self.type == t.INERTIA_COM:
             b.com = tuple(float(x) for x in value)
+        elif self.type == t.INERTIA_COM_MU:   # COM = beta * mu (WithRespectToMass.cpp:76-92)
+            b.com = tuple(float(be) * float(value[0]) for be in b.beta)
         elif self.type == t.INERTIA_DIAGONAL:
             b.inertia = tuple(float(x) for x in value) + tuple(b.inertia[3:])
         elif self.type == t.INERTIA_OFF_DIAGONAL:
@@ -143,6 +149,8 @@ class WrtMassEntry:
             return [d_mass_only()]
         if self.type == t.INERTIA_COM:
             return [d_com(k) for k in range(3)]
+        if self.type == t.INERTIA_COM_MU:
+            return [sum(float(b.beta[k]) * d_com(k) for k in range(3))]
         if self.type == t.INERTIA_DIAGONAL:
             return [d_diag(k) for k in range(3)]
         if self.type == t.INERTIA_OFF_DIAGONAL:
@@ -151,7 +159,8 @@ class WrtMassEntry:
 
 
 class WithRespectToMass:
-    """The registered entries of one world, in registration order."""
+    """The registered entries of one world, in registration order.  INERTIA_COM_MU reads BodySpec.beta (BodyNode::getBeta, set
+    by the reference's scaling groups; ones by default)."""
 
     def __init__(self, description: ModelDescription):
         self.description = description
@@ -164,8 +173,6 @@ class WithRespectToMass:
                 raise KeyError(f"no body named {body!r}")
             body = names.index(body)
         type = WrtMassBodyNodeEntryType(type)
-        if type == WrtMassBodyNodeEntryType.INERTIA_COM_MU:
-            raise NotImplementedError("INERTIA_COM_MU needs BodyNode::getBeta (scaling groups), outside the hot path")
         if any(e.body == body for e in self.entries):
             raise ValueError("body already registered")   # the reference keeps one entry per node (WithRespectToMass.cpp registerNode)
         d = _DIMS[type]

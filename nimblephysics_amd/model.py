@@ -91,6 +91,7 @@ class BodySpec:
     force_hi: Sequence[float] = ()
     friction: float = 1.0  # BodyNodeAspect.hpp:47
     axes: Sequence[Sequence[float]] = ()   # compound joints with free axes (universal: 2, translational2d: 2, planar: 2 in-plane axes)
+    beta: Sequence[float] = (1.0, 1.0, 1.0)   # BodyNode::mBeta (BodyNode.cpp:1301 ctor default ones): the COM moves along beta under an INERTIA_COM_MU mass entry
     skeleton: int = -1   # index of the dart Skeleton the body belongs to; -1 (every body of the model) = one skeleton per tree
     pitch: float = 0.1   # screw joints: translation along the axis per turn (ScrewJoint::mPitch, default 0.1)
 
@@ -160,7 +161,7 @@ def expand_compound_joints(bodies, boxes):
                 mass=b.mass if last else 0.0, com=tuple(b.com) if last else (0.0, 0.0, 0.0),
                 inertia=tuple(b.inertia) if last else (0.0,) * 6,
                 **{key: dof(getattr(b, key), i) for key in ("damping", "spring", "rest", "pos_lo", "pos_hi", "vel_lo", "vel_hi", "force_lo", "force_hi")},
-                friction=b.friction, skeleton=b.skeleton)
+                friction=b.friction, beta=tuple(b.beta) if last else (1.0, 1.0, 1.0), skeleton=b.skeleton)
             parent = len(out)
             out.append(nb)
         where.append(len(out) - 1)
@@ -437,7 +438,7 @@ class ModelDescription:
     def to_json(self) -> dict:
         def body(b: BodySpec):
             d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()
-                 if k != "axes" and not (k == "skeleton" and v < 0) and not (k == "pitch" and b.joint_type != "screw")}   # compound joints are already expanded: every stored joint has its single `axis`
+                 if k != "axes" and not (k == "skeleton" and v < 0) and not (k == "beta" and tuple(v) == (1.0, 1.0, 1.0)) and not (k == "pitch" and b.joint_type != "screw")}   # compound joints are already expanded: every stored joint has its single `axis`
             return d
         return {
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,

@@ -73,6 +73,8 @@ def test_pendulum_and_cartpole_all_entry_types():
     md = copy.deepcopy(md); md.bodies[0].com = (0.1, -0.3, 0.05)
     for t in (T.INERTIA_MASS, T.INERTIA_COM, T.INERTIA_DIAGONAL, T.INERTIA_OFF_DIAGONAL, T.INERTIA_FULL):
         _check(md, [(0, t)], s, a, 22)
+    mu = copy.deepcopy(md); mu.bodies[0].beta = (0.5, -1.5, 0.25); mu.bodies[0].com = (0.1, -0.3, 0.05)   # COM = beta * 0.2
+    _check(mu, [(0, T.INERTIA_COM_MU)], s, a, 22)
     md, s, a = cfg_inputs("cartpole", 64, 23)
     _check(md, [(0, T.INERTIA_MASS), (1, T.INERTIA_FULL)], s, a, 24)
 

@@ -15,7 +15,7 @@ def _merged_G(md, body):
     return spatial_inertia(b.mass, b.com, b.inertia)
 
 
-@pytest.mark.parametrize("etype", [T.INERTIA_MASS, T.INERTIA_COM, T.INERTIA_DIAGONAL, T.INERTIA_OFF_DIAGONAL, T.INERTIA_FULL])
+@pytest.mark.parametrize("etype", [T.INERTIA_MASS, T.INERTIA_COM, T.INERTIA_COM_MU, T.INERTIA_DIAGONAL, T.INERTIA_OFF_DIAGONAL, T.INERTIA_FULL])
 def test_directions_match_finite_differences_through_welds(etype):
     md = copy.deepcopy(na.atlas("atlas20", ground=True))   # arms welded: composite bodies
     targets, _ = md.weld_targets()
@@ -23,6 +23,9 @@ def test_directions_match_finite_differences_through_welds(etype):
     moving = [i for i, b in enumerate(md.bodies) if b.joint_type == "revolute"]
     for body in (welded[0], welded[-1], moving[3]):
         md.bodies[body].com = (0.01, -0.02, 0.03)
+        if etype == T.INERTIA_COM_MU:   # the COM of a scaling-group body lies on its beta axis
+            md.bodies[body].beta = (0.5, -1.0, 1.5)
+            md.bodies[body].com = (0.01, -0.02, 0.03)
         md.bodies[body].inertia = (0.11, 0.12, 0.13, 0.004, -0.003, 0.002)
         w = WithRespectToMass(md)
         w.registerNode(body, etype)
@@ -54,8 +57,27 @@ def test_mass_vector_layout_and_bounds():
         w.set([1.0])
     with pytest.raises(ValueError):
         w.registerNode(1, T.INERTIA_COM)
-    with pytest.raises(NotImplementedError):
-        w.registerNode(0, T.INERTIA_COM_MU)
+
+
+def test_com_mu_entry_follows_beta():
+    """INERTIA_COM_MU: one scalar mu, COM = beta * mu; the getter divides by the first non-zero beta (WithRespectToMass.cpp:76-92, 157-166)."""
+    md = copy.deepcopy(na.cartpole())
+    w = WithRespectToMass(md)
+    assert tuple(md.bodies[1].beta) == (1.0, 1.0, 1.0)   # BodyNode's default
+    e = w.registerNode(1, T.INERTIA_COM_MU)
+    assert e.dim() == 1 and w.dim() == 1
+    w.set([0.25])
+    assert tuple(md.bodies[1].com) == (0.25, 0.25, 0.25) and np.allclose(w.get(), [0.25])
+    md.bodies[1].beta = (0.0, -2.0, 0.5)
+    w.set([0.1])
+    assert np.allclose(md.bodies[1].com, (0.0, -0.2, 0.05)) and np.allclose(w.get(), [0.1])
+    md.bodies[1].beta = (0.0, 0.0, 4.0)
+    w.set([0.1])
+    assert np.allclose(md.bodies[1].com, (0.0, 0.0, 0.4)) and np.allclose(w.get(), [0.1])
+    # the description round-trips the non-default beta and omits the default one
+    d = md.to_json()
+    assert d["bodies"][1]["beta"] == [0.0, 0.0, 4.0] and "beta" not in d["bodies"][0]
+    assert tuple(type(md).from_json(d).bodies[1].beta) == (0.0, 0.0, 4.0)
 
 
 def test_setting_the_mass_rescales_the_moment():
