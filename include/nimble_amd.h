@@ -65,7 +65,8 @@ extern "C" {
 #define NBL_ST_LCP_PIVOT 0x4u     /* pivoting (Dantzig-equivalent) stage used */
 #define NBL_ST_LCP_PGS 0x8u       /* CFM + PGS fallback used */
 #define NBL_ST_LCP_NOFRIC 0x10u   /* friction dropped fallback used */
-#define NBL_ST_LCP_FAILED 0x20u   /* every stage failed: impulses zeroed (BoxedLcpConstraintSolver.cpp:679-687) */
+#define NBL_ST_LCP_FAILED 0x20u   /* every stage failed its validity check: like the reference, the last stage's (frictionless PGS) iterate is applied as is
+                                     (BoxedLcpConstraintSolver.cpp:590-676); the impulses are zeroed only if that iterate is non-finite (:678-687, NBL_ST_NAN) */
 #define NBL_ST_NAN 0x40u          /* non-finite value seen: in the LCP stages, or in the world's next state (NaN / Inf inputs); other worlds are unaffected */
 #define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts than max_contacts; extra ones dropped */
 #define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
