@@ -119,8 +119,12 @@ typedef struct nbl_model_desc {
   double fallback_cfm;           /* 1e-4  World.cpp:85 */
 
   /* ---- collider shapes (appended; NULL = every collider is a box) ----
-   * [n_boxes] NBL_SHAPE_BOX | NBL_SHAPE_SPHERE.  A sphere's radius is box_size[3*i]; sphere-box, box-sphere and
-   * sphere-sphere pairs follow collideSphereBox / collideBoxSphere / collideSphereSphere (DARTCollide.cpp:1482-1880). */
+   * [n_boxes] NBL_SHAPE_BOX | NBL_SHAPE_SPHERE | NBL_SHAPE_CAPSULE.  A sphere's radius is box_size[3*i]; sphere-box, box-sphere and
+   * sphere-sphere pairs follow collideSphereBox / collideBoxSphere / collideSphereSphere (DARTCollide.cpp:1482-1880).
+   * A capsule (CapsuleShape: axis = z of the shape frame) has radius box_size[3*i] and cylinder height box_size[3*i+1];
+   * capsule-capsule, sphere-capsule and capsule-sphere pairs follow collideCapsuleCapsule / collideSphereCapsule /
+   * collideCapsuleSphere (DARTCollide.cpp:4183-4420).  A model in which a capsule can meet a BOX is refused: that pair runs
+   * libccd's MPR in the reference (DARTCollide.cpp:4422-4645), a third-party iterative algorithm outside this path. */
   const int32_t* box_shape;
 
   /* ---- restitution (appended; NULL = 0 everywhere, the reference's default BodyNodeAspect.hpp:48) ----
@@ -150,6 +154,7 @@ typedef struct nbl_model_desc {
 
 #define NBL_SHAPE_BOX 0
 #define NBL_SHAPE_SPHERE 1
+#define NBL_SHAPE_CAPSULE 2
 
 typedef struct nbl_model nbl_model; /* opaque */
 

@@ -3,10 +3,10 @@
 Drop-in for ONE hot path of nimblephysics: `timestep(world, state, action)`
 (python/nimblephysics/timestep.py:63-69).  See DESIGN.md / INTEGRATION.md.
 """
-from .model import (BodySpec, BoxSpec, ModelDescription, SphereSpec, atlas, box_stack, cartpole,  # noqa: F401
+from .model import (BodySpec, BoxSpec, CapsuleSpec, ModelDescription, SphereSpec, atlas, box_stack, cartpole,  # noqa: F401
                     make_transform, single_pendulum)
 
-__all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
+__all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "CapsuleSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
            "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "load_model", "loadWorld", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep", "neural", "forwardPass", "BackpropSnapshot",
            "LossGradient", "LossGradientHighLevelAPI"]
 

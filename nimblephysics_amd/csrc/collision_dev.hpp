@@ -12,6 +12,7 @@
 namespace nbl {
 
 constexpr int CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3, CT_SPHERE_BOX = 4, CT_BOX_SPHERE = 5, CT_SPHERE_SPHERE = 6;   // Contact.hpp:45-61
+constexpr int CT_PIPE_SPHERE = 13, CT_SPHERE_PIPE = 14, CT_PIPE_PIPE = 15;   // capsule contacts, Contact.hpp:72-74
 
 struct DevContact {
   V3 point, normal;
@@ -308,6 +309,126 @@ DEV int sphereSphere(double r0, const T12& T0, double r1, const T12& T1, double 
   if (nsq < 1e-6) { c.normal = mk3(0, 0, 0); c.depth = rsum; }
   else { const double len = sqrt(nsq); c.normal = (1.0 / len) * normal; c.depth = rsum - len; }
   if (c.depth > clippingDepth) return 0;
+  emit(c);
+  return 1;
+}
+
+// ---- capsules (CapsuleShape: axis = z of the shape frame, `height` = length of the cylinder part) --------------------------------
+// dSegmentsClosestApproach (DARTCollide.cpp:301-381): parameters of the closest points of the segments pa->pb and ua->ub
+DEV void segmentsClosestApproach(V3 pa, V3 ua, V3 pb, V3 ub, double* alpha, double* beta) {
+  const V3 u = pb - pa, v = ub - ua, w = pa - ua;
+  const double a = dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w);
+  const double D = a * c - b * b;
+  double sN, sD = D, tN, tD = D;
+  const double SMALL_NUM = 1e-15;
+  if (D < SMALL_NUM) { sN = 0.0; sD = 1.0; tN = e; tD = c; }
+  else {
+    sN = (b * e - c * d);
+    tN = (a * e - b * d);
+    if (sN < 0.0) { sN = 0.0; tN = e; tD = c; }
+    else if (sN > sD) { sN = sD; tN = e + b; tD = c; }
+  }
+  if (tN < 0.0) {
+    tN = 0.0;
+    if (-d < 0.0) sN = 0.0;
+    else if (-d > a) sN = sD;
+    else { sN = -d; sD = a; }
+  } else if (tN > tD) {
+    tN = tD;
+    if ((-d + b) < 0.0) sN = 0;
+    else if ((-d + b) > a) sN = sD;
+    else { sN = (-d + b); sD = a; }
+  }
+  *alpha = (fabs(sN) < SMALL_NUM ? 0.0 : sN / sD);
+  *beta = (fabs(tN) < SMALL_NUM ? 0.0 : tN / tD);
+}
+
+// dDistPointToSegment (DARTCollide.cpp:384-410)
+DEV double distPointToSegment(V3 p, V3 ua, V3 ub, double* alpha) {
+  const V3 v = ub - ua, w = p - ua;
+  const double c1 = dot(w, v);
+  if (c1 <= 0) { *alpha = 0; return norm3(p - ua); }
+  const double c2 = dot(v, v);
+  if (c2 <= c1) { *alpha = 1; return norm3(p - ub); }
+  *alpha = c1 / c2;
+  return norm3(p - (ua + *alpha * v));
+}
+
+// Annotations of the capsule contact types in the four edge slots (the backward pass reads the two capsule radii from the model):
+//   SPHERE_SPHERE (an end cap against an end cap / a sphere): like sphereSphere above
+//   SPHERE_PIPE / PIPE_SPHERE: edgeAFixed = sphere centre, edgeADir = pipe direction, edgeBFixed = the pipe's fixed point,
+//                              edgeBDir = (|closest point on the pipe - sphere centre|, sphere radius, pipe radius)
+//   PIPE_PIPE: edgeAFixed / edgeADir / edgeBFixed / edgeBDir = the two axis lines, as for EDGE_EDGE
+// collideCapsuleCapsule (DARTCollide.cpp:4183-4284)
+template <class Emit>
+DEV int capsuleCapsule(double height0, double radius0, const T12& T0, double height1, double radius1, const T12& T1,
+                       double clippingDepth, Emit emit) {
+  const V3 z0 = colOf(T0.R, 2), z1 = colOf(T1.R, 2);
+  const V3 pa = (-(height0 / 2)) * z0 + T0.p, pb = (height0 / 2) * z0 + T0.p;
+  const V3 ua = (-(height1 / 2)) * z1 + T1.p, ub = (height1 / 2) * z1 + T1.p;
+  double alpha, beta;
+  segmentsClosestApproach(pa, ua, pb, ub, &alpha, &beta);
+  alpha = fmin(fmax(alpha, 0.0), 1.0);
+  beta = fmin(fmax(beta, 0.0), 1.0);
+  const V3 closest0 = pa + alpha * (pb - pa), closest1 = ua + beta * (ub - ua);
+  const double dist = norm3(closest0 - closest1), rsum = radius0 + radius1;
+  if (!(dist <= rsum)) return 0;
+  radius0 /= rsum; radius1 /= rsum;
+  DevContact c;
+  c.edgeAClosest = closest0; c.edgeBClosest = closest1;
+  c.depth = rsum - dist;
+  if (c.depth > clippingDepth) return 0;
+  c.point = radius1 * closest0 + radius0 * closest1;
+  c.normal = unit3(closest0 - closest1);
+  const double SPHERE_THRESHOLD = 1e-8;
+  const bool isSphere0 = fabs(alpha) < SPHERE_THRESHOLD || fabs(1 - alpha) < SPHERE_THRESHOLD;
+  const bool isSphere1 = fabs(beta) < SPHERE_THRESHOLD || fabs(1 - beta) < SPHERE_THRESHOLD;
+  if (isSphere0 && isSphere1) {
+    c.type = CT_SPHERE_SPHERE;
+    c.edgeAFixed = closest0; c.edgeBFixed = closest1; c.edgeADir = mk3(radius0 * rsum, radius1 * rsum, 0); c.edgeBDir = mk3(0, 0, 0);
+  } else if (isSphere0) {
+    c.type = CT_SPHERE_PIPE;
+    c.edgeAFixed = closest0; c.edgeADir = unit3(ub - ua); c.edgeBFixed = ua; c.edgeBDir = mk3(dist, radius0 * rsum, radius1 * rsum);
+  } else if (isSphere1) {
+    c.type = CT_PIPE_SPHERE;
+    c.edgeAFixed = closest1; c.edgeADir = unit3(pb - pa); c.edgeBFixed = pa; c.edgeBDir = mk3(dist, radius1 * rsum, radius0 * rsum);
+  } else {
+    c.type = CT_PIPE_PIPE;
+    c.edgeAFixed = pa; c.edgeADir = unit3(pb - pa); c.edgeBFixed = ua; c.edgeBDir = unit3(ub - ua);
+  }
+  emit(c);
+  return 1;
+}
+
+// collideSphereCapsule (DARTCollide.cpp:4286-4352; the sphere is the first object) / collideCapsuleSphere (:4354-4420)
+template <class Emit>
+DEV int sphereCapsulePair(bool sphereFirst, double rSphere, const T12& Ts, double height, double rCapsule, const T12& Tc,
+                          double clippingDepth, Emit emit) {
+  double alpha;
+  const V3 center = Ts.p, zc = colOf(Tc.R, 2);
+  const V3 ua = (-(height / 2)) * zc + Tc.p, ub = (height / 2) * zc + Tc.p;
+  const double dist = distPointToSegment(center, ua, ub, &alpha);
+  double radius0 = sphereFirst ? rSphere : rCapsule, radius1 = sphereFirst ? rCapsule : rSphere;
+  if (!(dist < radius0 + radius1)) return 0;
+  const V3 closest = ua + alpha * (ub - ua);
+  const double rsum = radius0 + radius1;
+  radius0 /= rsum; radius1 /= rsum;
+  DevContact c;
+  c.edgeAClosest = c.edgeBClosest = mk3(0, 0, 0);
+  c.depth = rsum - dist;
+  if (c.depth > clippingDepth) return 0;
+  const V3 first = sphereFirst ? center : closest, second = sphereFirst ? closest : center;
+  c.point = radius1 * first + radius0 * second;
+  c.normal = unit3(first - second);
+  const double SPHERE_THRESHOLD = 1e-8;
+  if (fabs(alpha) < SPHERE_THRESHOLD || fabs(1 - alpha) < SPHERE_THRESHOLD) {
+    c.type = CT_SPHERE_SPHERE;
+    c.edgeAFixed = first; c.edgeBFixed = second; c.edgeADir = mk3(radius0 * rsum, radius1 * rsum, 0); c.edgeBDir = mk3(0, 0, 0);
+  } else {
+    c.type = sphereFirst ? CT_SPHERE_PIPE : CT_PIPE_SPHERE;
+    c.edgeAFixed = center; c.edgeADir = unit3(ub - ua); c.edgeBFixed = ua;
+    c.edgeBDir = mk3(dist, (sphereFirst ? radius0 : radius1) * rsum, (sphereFirst ? radius1 : radius0) * rsum);
+  }
   emit(c);
   return 1;
 }

@@ -54,14 +54,19 @@ __global__ __launch_bounds__(64) void k_bwd_recompute(DevModel mdl, const DevBod
 }
 
 // ---- contact-geometry pieces of k_bwd_contact_b_coop ----
-struct ContactRec { V3 p, nrm, eAP, eAD, eBP, eBD; int type, bA, bB; };
+struct ContactRec { V3 p, nrm, eAP, eAD, eBP, eBD; int type, bA, bB; double depth, radA, radB; };   // radA / radB: the colliders' radii (spheres, capsules)
+template <bool CAPS = false>
 DEV ContactRec loadContactRec(const LaneMem& SV, const SavedLayout& lay, const DevContactModel* __restrict__ cm, int ci) {
   const int r0 = lay.contacts + ci * CR_SIZE;
   ContactRec R;
   R.p = mk3(SV.at(r0 + CR_POINT), SV.at(r0 + CR_POINT + 1), SV.at(r0 + CR_POINT + 2));
   R.nrm = mk3(SV.at(r0 + CR_NORMAL), SV.at(r0 + CR_NORMAL + 1), SV.at(r0 + CR_NORMAL + 2));
   R.type = (int)SV.at(r0 + CR_TYPE);
-  R.bA = cm->boxes[(int)SV.at(r0 + CR_BOXA)].body; R.bB = cm->boxes[(int)SV.at(r0 + CR_BOXB)].body;
+  const DevBox& boxA = cm->boxes[(int)SV.at(r0 + CR_BOXA)];
+  const DevBox& boxB = cm->boxes[(int)SV.at(r0 + CR_BOXB)];
+  R.bA = boxA.body; R.bB = boxB.body;
+  R.depth = 0; R.radA = 0; R.radB = 0;
+  if (CAPS) { R.depth = SV.at(r0 + CR_DEPTH); R.radA = boxA.half[0]; R.radB = boxB.half[0]; }
   R.eAP = mk3(SV.at(r0 + CR_EA_FIXED), SV.at(r0 + CR_EA_FIXED + 1), SV.at(r0 + CR_EA_FIXED + 2));
   R.eAD = mk3(SV.at(r0 + CR_EA_DIR), SV.at(r0 + CR_EA_DIR + 1), SV.at(r0 + CR_EA_DIR + 2));
   R.eBP = mk3(SV.at(r0 + CR_EB_FIXED), SV.at(r0 + CR_EB_FIXED + 1), SV.at(r0 + CR_EB_FIXED + 2));
@@ -85,6 +90,8 @@ DEV TangentFrame tangentFrameOf(V3 nrm) {
 // body B under the joint rates z_row: what a position twist of a DOF on the vertex side / face side / edge A / edge B
 // contributes through dF/dq.
 struct RowTerms { V6 vertexTerm, faceTerm, edgeTermA, edgeTermB; };
+// CAPS: the model has capsule colliders (their contact types are compiled into that instantiation only: registers)
+template <bool CAPS = false>
 DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k, V3 d, V6 Zall) {
   const V3 p = R.p, nrm = R.nrm, t1 = TF.t1, crs = TF.crs;
   const double tn = TF.tn;
@@ -142,23 +149,56 @@ DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k,
     out.edgeTermA = mk6(cross(cA, xa), xa);
     out.edgeTermB = mk6(cross(cB, xb), xb);
   }
-  if (R.type == CT_EDGE_EDGE) {
+  // Closest points of two lines (math::getContactPointGradient, Geometry.cpp:1129-1236): the point wA * closestA + wB * closestB
+  // moves linearly with the position twist of the DOF carrying line A / line B; adjoints of that map applied to x, accumulated.
+  V3 gPa = mk3(0, 0, 0), gDa = gPa, gPb = gPa, gDb = gPa;
+  auto lineAdjoint = [&](V3 x, double wA, double wB) {
     const V3 eAP = R.eAP, eAD = R.eAD, eBP = R.eBP, eBD = R.eBD;
-    const double sgnN = dot(cross(eBD, eAD), nrm) < 0 ? -1.0 : 1.0;
-    V3 pv = eBP - eAP;
+    const V3 pv = eBP - eAP;
     const double uaub = dot(eAD, eBD), q1 = dot(eAD, pv), q2 = -dot(eBD, pv), dd = 1 - uaub * uaub;
-    V3 gPa, gDa, gPb, gDb;
-    if (dd <= 0) { gPa = 0.5 * cv; gDa = mk3(0, 0, 0); gPb = 0.5 * cv; gDb = mk3(0, 0, 0); }
-    else {
-      const double e = 1.0 / dd, N1 = q1 + uaub * q2, N2 = uaub * q1 + q2, alpha = N1 * e, beta = N2 * e;
-      const double ca = dot(cv, eAD), cb = dot(cv, eBD), k2 = 2 * uaub * e * e;
-      gPa = 0.5 * (cv + ca * (e * uaub * eBD - e * eAD) + cb * (e * eBD - e * uaub * eAD));
-      gDa = 0.5 * (alpha * cv + ca * ((k2 * N1 + e * q2) * eBD + e * pv) + cb * ((k2 * N2 + e * q1) * eBD + (e * uaub) * pv));
-      gPb = 0.5 * (cv + ca * (e * eAD - e * uaub * eBD) + cb * (e * uaub * eAD - e * eBD));
-      gDb = 0.5 * (beta * cv + ca * ((k2 * N1 + e * q2) * eAD - (e * uaub) * pv) + cb * ((k2 * N2 + e * q1) * eAD - e * pv));
-    }
-    out.edgeTermA = mk6(cross(eAP, gPa) + cross(eAD, gDa) + sgnN * cross(eAD, cross(hN, eBD)), gPa);
-    out.edgeTermB = mk6(cross(eBP, gPb) + cross(eBD, gDb) + sgnN * cross(eBD, cross(eAD, hN)), gPb);
+    if (dd <= 0) { gPa = gPa + wA * x; gPb = gPb + wB * x; return; }
+    const double e = 1.0 / dd, N1 = q1 + uaub * q2, N2 = uaub * q1 + q2, alpha = N1 * e, beta = N2 * e;
+    const double ca = wA * dot(x, eAD), cb = wB * dot(x, eBD), k2 = 2 * uaub * e * e;
+    gPa = gPa + (wA * x + ca * (e * uaub * eBD - e * eAD) + cb * (e * eBD - e * uaub * eAD));
+    gDa = gDa + ((wA * alpha) * x + ca * ((k2 * N1 + e * q2) * eBD + e * pv) + cb * ((k2 * N2 + e * q1) * eBD + (e * uaub) * pv));
+    gPb = gPb + (wB * x + ca * (e * eAD - e * uaub * eBD) + cb * (e * uaub * eAD - e * eBD));
+    gDb = gDb + ((wB * beta) * x + ca * ((k2 * N1 + e * q2) * eAD - (e * uaub) * pv) + cb * ((k2 * N2 + e * q1) * eAD - e * pv));
+  };
+  if (R.type == CT_EDGE_EDGE) {
+    const V3 eAD = R.eAD, eBD = R.eBD;
+    const double sgnN = dot(cross(eBD, eAD), nrm) < 0 ? -1.0 : 1.0;
+    lineAdjoint(cv, 0.5, 0.5);
+    out.edgeTermA = mk6(cross(R.eAP, gPa) + cross(eAD, gDa) + sgnN * cross(eAD, cross(hN, eBD)), gPa);
+    out.edgeTermB = mk6(cross(R.eBP, gPb) + cross(eBD, gDb) + sgnN * cross(eBD, cross(eAD, hN)), gPb);
+  }
+  // Capsule contacts (DCC.cpp:484-547 point, :819-938 normal).  PIPE_PIPE: the contact point divides the closest points of the two
+  // axis lines by the radii, the normal is their difference normalised: the same line map with the weights (1, -1).
+  if (CAPS && R.type == CT_PIPE_PIPE) {
+    const double rsum = R.radA + R.radB, rA = R.radA / rsum, rB = R.radB / rsum, dist = rsum - R.depth;
+    const V3 y = (1.0 / dist) * (hN - dot(nrm, hN) * nrm);
+    lineAdjoint(cv, rB / (rA + rB), rA / (rA + rB));
+    lineAdjoint(y, 1.0, -1.0);
+    out.edgeTermA = mk6(cross(R.eAP, gPa) + cross(R.eAD, gDa), gPa);
+    out.edgeTermB = mk6(cross(R.eBP, gPb) + cross(R.eBD, gDb), gPb);
+  }
+  // SPHERE_PIPE / PIPE_SPHERE (c sphere centre, e pipe direction, f the pipe's fixed point, rel = e . (c - f)):
+  //   sphere side: dp = [w + (1 - w) e e^T] g_c,  w = r_pipe / (r_sphere + r_pipe);   dn = sigma (1 - n n^T)(1 - e e^T) g_c / dist
+  //   pipe side:   dp = r_sphere / (r_sphere + r_pipe) raw,  raw = g_f + rel (w x e) + ((w x e).(c - f) - e.g_f) e
+  //                (math::closestPointOnLineGradient);                                 dn = -sigma (1 - n n^T) raw / dist
+  //   sigma = +1 when the sphere is the first object (the normal points from the second object to the first)
+  if (CAPS && (R.type == CT_SPHERE_PIPE || R.type == CT_PIPE_SPHERE)) {
+    const V3 c = R.eAP, e = R.eAD, f = R.eBP;
+    const double dist = R.eBD.x, rs = R.eBD.y, rp = R.eBD.z;
+    const bool sphereIsA = R.type == CT_SPHERE_PIPE;
+    const double sigma = sphereIsA ? 1.0 : -1.0, wgt = rp / (rs + rp);
+    const V3 y = (sigma / dist) * (hN - dot(nrm, hN) * nrm);
+    const V3 xs = wgt * cv + ((1 - wgt) * dot(e, cv)) * e + (y - dot(e, y) * e);
+    const V6 sphereSide = mk6(cross(c, xs), xs);
+    const V3 xp = (rs / (rs + rp)) * cv - y;
+    const double rel = dot(e, c - f), xe = dot(xp, e);
+    const V6 pipeSide = mk6(cross(f, xp) + rel * cross(e, xp) + xe * cross(e, c), xp - xe * e);
+    out.edgeTermA = sphereIsA ? sphereSide : pipeSide;
+    out.edgeTermB = sphereIsA ? pipeSide : sphereSide;
   }
   return out;
 }

@@ -115,7 +115,12 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
     // dispatch on the two shape types (collide(), DARTCollide.cpp:5030-5260)
     const V3 ha = mk3(ba.half[0], ba.half[1], ba.half[2]), hb = mk3(bb.half[0], bb.half[1], bb.half[2]);
     const bool sa = ba.shape == SHAPE_SPHERE, sb = bb.shape == SHAPE_SPHERE;
-    if (sa && sb) sphereSphere(ba.half[0], Ta, bb.half[0], Tb, cm->clippingDepth, emit);
+    const bool ca = ba.shape == SHAPE_CAPSULE, cb = bb.shape == SHAPE_CAPSULE;   // half = (radius, height / 2, -)
+    if (ca && cb) capsuleCapsule(2 * ba.half[1], ba.half[0], Ta, 2 * bb.half[1], bb.half[0], Tb, cm->clippingDepth, emit);
+    else if (sa && cb) sphereCapsulePair(true, ba.half[0], Ta, 2 * bb.half[1], bb.half[0], Tb, cm->clippingDepth, emit);
+    else if (ca && sb) sphereCapsulePair(false, bb.half[0], Tb, 2 * ba.half[1], ba.half[0], Ta, cm->clippingDepth, emit);
+    else if (ca || cb) {}   // capsule-box: refused at model creation
+    else if (sa && sb) sphereSphere(ba.half[0], Ta, bb.half[0], Tb, cm->clippingDepth, emit);
     else if (sa) sphereBoxPair(true, ba.half[0], Ta, hb, Tb, cm->clippingDepth, emit);
     else if (sb) sphereBoxPair(false, bb.half[0], Tb, ha, Ta, cm->clippingDepth, emit);
     else boxBox(Ta, ha, Tb, hb, cm->clippingDepth, clip, emit);

@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
 //   4  lane = body: xi_W = C + sum_e dad(FW[par][e], Phi_e) - sum_pairs (dad(FW[par][adj], TF[acc]) + dad(FW[par][acc], TF[adj])),
 //      projected on the joint (applyHt) -> the position cotangent LB_QX
 // lds doubles: FW[nb][9][6] D[nb][54] { tmp[54][24] | TF[nb][9][6] }
+template <bool CAPS>
 __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                            const DevContactModel* __restrict__ cm, int64_t B,
                                                            double* __restrict__ saved, SavedLayout lay,
@@ -1203,10 +1204,10 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
     const int row = ln, ci = row / 3, k = row % 3;
     for (int e = 0; e < 8; e++) { cf[e] = lws[(int64_t)(LB_COEF + row * 8 + e) * B + b]; any = any || cf[e] != 0.0; }
     if (any) {
-      CR = loadContactRec(SV, lay, cm, ci);
+      CR = loadContactRec<CAPS>(SV, lay, cm, ci);
       CR.p = CR.p - worldOrigin;
       if (CR.type >= CT_EDGE_EDGE) CR.eAP = CR.eAP - worldOrigin;                                        // edge A's point / the sphere centre (A's)
-      if (CR.type == CT_EDGE_EDGE || CR.type == CT_SPHERE_SPHERE) CR.eBP = CR.eBP - worldOrigin;          // edge B's point / sphere B's centre
+      if (CR.type == CT_EDGE_EDGE || CR.type == CT_SPHERE_SPHERE || CR.type >= CT_PIPE_SPHERE) CR.eBP = CR.eBP - worldOrigin;   // edge B's point / sphere B's centre / the pipe's fixed point
       const TangentFrame TF_ = tangentFrameOf(CR.nrm);
       const V3 d = k == 0 ? CR.nrm : (k == 1 ? TF_.t1 : TF_.t2);
       Fw = mk6(cross(CR.p, d), d);
@@ -1217,7 +1218,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
         return z;
       };
       TA = twistOf(CR.bA); TB = twistOf(CR.bB);
-      RT = contactRowTerms(CR, TF_, k, d, TA - TB);
+      RT = contactRowTerms<CAPS>(CR, TF_, k, d, TA - TB);
     }
   }
   NBL_PHASE(51);

@@ -79,7 +79,7 @@ struct DevDof {
 struct DevModel {
   int32_t nb, n, nAction, pad;   // pad: worlds packed into one wavefront of the lane = body tree kernels (>= 1)
   int32_t maxLevel, maxRank, nbp, nFree;  // tree depth, max sibling rank, bodies padded, free-joint bodies (coop tree kernels)
-  int32_t hasBounce, pad2;                // some collider pair can bounce (restitution product > 1e-3): k_bwd_bounce runs
+  int32_t hasBounce, hasCapsule;          // some collider pair can bounce (restitution product > 1e-3): k_bwd_bounce runs; some collider is a capsule
   double gravity[3];
   double dt;
   int64_t b0, b1;     // the worlds [b0, b1) this launch processes (the batch may be sliced over several HIP streams)
@@ -121,8 +121,8 @@ constexpr int MAX_ROWS = 3 * MAX_CONTACTS;
 constexpr int MAX_BOXES = 16;
 constexpr int MAX_PAIRS = 32;
 
-constexpr int SHAPE_BOX = 0, SHAPE_SPHERE = 1;   // NBL_SHAPE_*
-struct DevBox {       // a collider: box (half extents) or sphere (radius in half[0])
+constexpr int SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CAPSULE = 2;   // NBL_SHAPE_*
+struct DevBox {       // a collider: box (half extents), sphere (radius in half[0]) or capsule (radius in half[0], half the cylinder height in half[1])
   int32_t body, shape;
   double T[12];     // shape frame in the body frame
   double half[3];
@@ -144,7 +144,7 @@ constexpr int CR_POINT = 0, CR_NORMAL = 3, CR_DEPTH = 6, CR_TYPE = 7, CR_BOXA = 
 constexpr int CR_EA_FIXED = 10, CR_EA_DIR = 13, CR_EB_FIXED = 16, CR_EB_DIR = 19, CR_SIZE = 22;
 // sphere contacts reuse the four edge slots: SPHERE_BOX / BOX_SPHERE: EA_FIXED = sphere centre, EA_DIR / EB_FIXED / EB_DIR = the
 // three box face normals (zero when the face is not "locked"); SPHERE_SPHERE: EA_FIXED = centre A, EB_FIXED = centre B,
-// EA_DIR = (radius A, radius B, 0).
+// EA_DIR = (radius A, radius B, 0).  Capsule contacts: see collision_dev.hpp (capsuleCapsule).
 
 // Layout of the saved record.  Rows q .. pflag are lane-interleaved (row index; every row holds B doubles, `total` rows);
 // the dense per-world block follows: world b owns `dense` contiguous doubles at saved[total * B + b * dense] and

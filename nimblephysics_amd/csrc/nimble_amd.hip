@@ -386,8 +386,13 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       if (bx.body >= d->n_bodies) return fail(NBL_E_BADARG, "box collider attached to an unknown body");
       for (int k = 0; k < 12; k++) bx.T[k] = d->box_T[12 * i + k];
       bx.shape = d->box_shape ? d->box_shape[i] : NBL_SHAPE_BOX;
-      if (bx.shape != NBL_SHAPE_BOX && bx.shape != NBL_SHAPE_SPHERE) return fail(NBL_E_UNSUPPORTED, "collider shape outside the device path (box, sphere)");
+      if (bx.shape != NBL_SHAPE_BOX && bx.shape != NBL_SHAPE_SPHERE && bx.shape != NBL_SHAPE_CAPSULE)
+        return fail(NBL_E_UNSUPPORTED, "collider shape outside the device path (box, sphere, capsule)");
       for (int k = 0; k < 3; k++) bx.half[k] = bx.shape == NBL_SHAPE_SPHERE ? d->box_size[3 * i] : 0.5 * d->box_size[3 * i + k];   // sphere: radius
+      if (bx.shape == NBL_SHAPE_CAPSULE) {   // (radius, height, -) -> (radius, height / 2, 0)
+        bx.half[0] = d->box_size[3 * i]; bx.half[1] = 0.5 * d->box_size[3 * i + 1]; bx.half[2] = 0.0;
+        if (!(bx.half[0] > 0.0) || !(bx.half[1] >= 0.0)) return fail(NBL_E_BADARG, "capsule collider needs radius > 0 and height >= 0");
+      }
       bx.mu = d->box_mu[i];
       bx.restitution = d->box_restitution ? d->box_restitution[i] : 0.0;
       if (!(bx.restitution >= 0.0)) return fail(NBL_E_BADARG, "negative restitution coefficient");
@@ -398,6 +403,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
         int bi = d->box_body[i], bj = d->box_body[j];
         if (bi == bj) continue;                       // same body (or both fixed to the world)
         if (bi >= 0 && bj >= 0 && skelOf(bi) == skelOf(bj)) continue;  // same skeleton, self-collision disabled
+        if ((hc.boxes[i].shape == NBL_SHAPE_CAPSULE) != (hc.boxes[j].shape == NBL_SHAPE_CAPSULE)
+            && (hc.boxes[i].shape == NBL_SHAPE_BOX || hc.boxes[j].shape == NBL_SHAPE_BOX))
+          return fail(NBL_E_UNSUPPORTED, "a capsule collider can meet a box collider: that pair runs libccd's MPR in the reference (DARTCollide.cpp:4422-4645), outside this path");
         if (hc.nPairs >= MAX_PAIRS) return fail(NBL_E_UNSUPPORTED, "too many collider pairs for the device path");
         hc.pairA[hc.nPairs] = i;
         hc.pairB[hc.nPairs] = j;
@@ -482,10 +490,13 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   m->device = device;
   if (const char* e1 = getenv("NBL_TREE_LANES")) m->treeLanes = atoi(e1);
   m->nb = d->n_bodies; m->n = d->n_dofs; m->k = d->n_action; m->maxContacts = d->max_contacts;
-  m->mdl.hasBounce = 0; m->mdl.pad2 = 0;
+  m->mdl.hasBounce = 0; m->mdl.hasCapsule = 0;
   if (hasContact)
     for (int pi = 0; pi < hc.nPairs; pi++)
       if (hc.boxes[hc.pairA[pi]].restitution * hc.boxes[hc.pairB[pi]].restitution > 1e-3) m->mdl.hasBounce = 1;
+  if (hasContact)
+    for (int i = 0; i < hc.nBoxes; i++)
+      if (hc.boxes[i].shape == NBL_SHAPE_CAPSULE) m->mdl.hasCapsule = 1;
   if (m->mdl.hasBounce && !(m->coopTree && m->coopFinal)) {
     nbl_model_destroy(m);
     return fail(NBL_E_UNSUPPORTED, "restitution needs the wavefront-per-world kernels (NBL_COOP_TREE / NBL_COOP_FINAL are off or the model does not fit them)");
@@ -512,7 +523,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_step_forward_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_forward_detect_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_recompute_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -723,8 +735,12 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
       if (forkRecompute) HIP_TRY(hipStreamWaitEvent(s, m->auxJoin[si], 0));
       {
         const size_t bLds = ((size_t)m->nb * 120 + std::max((size_t)m->nb * 54, (size_t)54 * MAX_ROWS) + MAX_CONTACTS) * sizeof(double);   // FW D {tmp | TF} TW contact bodies
-        TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
-                                               sv, m->lay, (const double*)workspace, lws));
+        if (mdl.hasCapsule)
+          TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop<true>, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
+                                                 sv, m->lay, (const double*)workspace, lws));
+        else
+          TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_coop<false>, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
+                                                 sv, m->lay, (const double*)workspace, lws));
       }
       if (mdl.hasBounce)
         TIMED(K_BWD_BOUNCE, hipLaunchKernelGGL(k_bwd_bounce, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dBodies, B, (const double*)saved, m->lay,

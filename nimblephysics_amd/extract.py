@@ -146,7 +146,9 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
                 elif shp.getType() == "SphereShape":
                     r = float(shp.getRadius())
                     boxes.append(BoxSpec(gidx, T, (r, r, r), mu, "sphere", e))
-                # meshes, capsules, ...: outside the analytic box / sphere narrow phase (dropped, like in the loaders)
+                elif shp.getType() == "CapsuleShape":
+                    boxes.append(BoxSpec(gidx, T, (float(shp.getRadius()), float(shp.getHeight()), 0.0), mu, "capsule", e))
+                # meshes, cylinders, ...: outside the analytic narrow phases (dropped, like in the loaders)
     g = tuple(float(x) for x in np.asarray(world.getGravity()).reshape(3))
     md = ModelDescription(name, bodies, boxes, g, float(world.getTimeStep()), None, max_contacts=max_contacts if boxes else 0,
                           contact_clipping_depth=float(world.getContactClippingDepth()),

@@ -191,7 +191,7 @@ def _text(el, tag, default=None, cast=float):
 def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_colliders=False):
     """Parse a SKEL world (`<skel><world>`: physics + skeletons) into ONE ModelDescription (all skeletons of the world in one
     model, like `with_ground`).  `skeletons`: names of the skeletons to keep (default: all), in file order.  Collision shapes other than
-    boxes and spheres (isotropic ellipsoids) raise unless `drop_unsupported_colliders` (the body is then loaded without that collider).
+    boxes, spheres (isotropic ellipsoids) and capsules that only meet capsules / spheres raise unless `drop_unsupported_colliders` (the body is then loaded without that collider).
 
     Subset, following SkelParser.cpp: <physics> time_step / gravity (:520-560); per <body> name, <transformation> = the body's
     WORLD transform at the zero configuration (:1082-1092), <inertia> mass / offset / moment_of_inertia (:1095-1128; without a
@@ -234,8 +234,11 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                 box = geom.find("box") if geom is not None else None
                 ell = geom.find("ellipsoid") if geom is not None else None
                 sph = geom.find("sphere") if geom is not None else None
+                cap = geom.find("capsule") if geom is not None else None
                 if box is not None:
                     out.append(("box", tuple(float(x) for x in box.find("size").text.split()), _skel_T(cs)))
+                elif cap is not None:      # CapsuleShape(radius, height), axis = z of the shape frame (SkelParser.cpp:1302-1308)
+                    out.append(("capsule", (float(cap.find("radius").text), float(cap.find("height").text), 0.0), _skel_T(cs)))
                 elif sph is not None:
                     r = float(sph.find("radius").text)
                     out.append(("sphere", (r, r, r), _skel_T(cs)))
@@ -245,7 +248,7 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                         raise ValueError(f"{path}: anisotropic ellipsoid collider outside the analytic narrow phase")
                     out.append(("sphere", (d[0] / 2,) * 3, _skel_T(cs)))
                 elif geom is not None and len(geom) and not drop_unsupported_colliders:
-                    # capsule / cylinder / mesh / ...: the reference collides them through libccd or its mesh code; loading the body without
+                    # cylinder / mesh / ...: the reference collides them through libccd or its mesh code; loading the body without
                     # its collider would silently change the physics (it falls through the ground)
                     raise ValueError(f"{path}: {geom[0].tag} collider on body {b.get('name')} is outside the analytic narrow phases (box, sphere); "
                                      "drop_unsupported_colliders=True loads the model without it")
@@ -277,6 +280,8 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                             shp = [("sphere", (d[0] / 2,) * 3, np.eye(4))]
                         else:
                             raise ValueError(f"{path}: default inertia of body {b.get('name')} from an anisotropic ellipsoid is outside the subset")
+                    elif vg is not None and vg.find("capsule") is not None:
+                        shp = [("capsule", (float(vg.find("capsule/radius").text), float(vg.find("capsule/height").text), 0.0), np.eye(4))]
                     elif vg is not None and len(vg):
                         raise ValueError(f"{path}: default inertia of body {b.get('name')} from a {vg[0].tag} visualization shape is outside the subset")
                 if not shp:
@@ -286,6 +291,12 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                     if kind == "box":                            # BoxShape::computeInertia (BoxShape.cpp:74-83)
                         I6 = (mass / 12.0 * (size[1] ** 2 + size[2] ** 2), mass / 12.0 * (size[0] ** 2 + size[2] ** 2),
                               mass / 12.0 * (size[0] ** 2 + size[1] ** 2), 0.0, 0.0, 0.0)
+                    elif kind == "capsule":                      # CapsuleShape::computeInertia (CapsuleShape.cpp:107-131)
+                        r, h = size[0], size[1]
+                        v_cyl, v_sph = np.pi * r * r * h, 4.0 / 3.0 * np.pi * r ** 3
+                        m_cyl, m_sph = mass * v_cyl / (v_cyl + v_sph), mass * v_sph / (v_cyl + v_sph)
+                        ixx = m_cyl * (h * h / 12.0 + r * r / 4.0) + m_sph * (h * h + 3.0 / 8.0 * h * r + 0.4 * r * r)
+                        I6 = (ixx, ixx, m_cyl * (r * r / 2.0) + m_sph * (0.4 * r * r), 0.0, 0.0, 0.0)
                     else:                                        # sphere: 2/5 m r^2
                         I6 = (0.4 * mass * size[0] ** 2,) * 3 + (0.0, 0.0, 0.0)
             return mass, com, I6
@@ -438,7 +449,14 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
             raise ValueError(f"{path}: bodies without a parent joint: {sorted(missing)}")
     if name is None:
         name = os.path.splitext(os.path.basename(path))[0]
-    return ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=max_contacts if boxes else 0)
+    md = ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=max_contacts if boxes else 0)
+    if md.capsule_meets_box():
+        # capsule-capsule and capsule-sphere pairs are closed form (DARTCollide.cpp:4183-4420); capsule-box is libccd's MPR (:4422-4645)
+        if not drop_unsupported_colliders:
+            raise ValueError(f"{path}: a capsule collider can meet a box collider, a pair outside the analytic narrow phases; "
+                             "drop_unsupported_colliders=True loads the model without its capsule colliders")
+        md.boxes = [bx for bx in md.boxes if bx.shape != "capsule"]
+    return md
 
 
 def load_model(path, **kw):

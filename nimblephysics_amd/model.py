@@ -170,7 +170,8 @@ def expand_compound_joints(bodies, boxes):
 
 @dataclass
 class BoxSpec:
-    """A collider: a box (full side lengths `size`) or, with shape = "sphere", a sphere of radius size[0]."""
+    """A collider: a box (full side lengths `size`), with shape = "sphere" a sphere of radius size[0], or with shape = "capsule" a
+    capsule of radius size[0] and cylinder height size[1] along the z axis of its frame (dynamics::CapsuleShape)."""
     body: int  # -1 = fixed to the world
     T: np.ndarray
     size: Sequence[float]
@@ -183,7 +184,11 @@ def SphereSpec(body: int, T: np.ndarray, radius: float, mu: float = 1.0) -> "Box
     return BoxSpec(body, T, (float(radius),) * 3, mu, "sphere")
 
 
-SHAPE_CODES = {"box": 0, "sphere": 1}
+def CapsuleSpec(body: int, T: np.ndarray, radius: float, height: float, mu: float = 1.0) -> "BoxSpec":
+    return BoxSpec(body, T, (float(radius), float(height), 0.0), mu, "capsule")
+
+
+SHAPE_CODES = {"box": 0, "sphere": 1, "capsule": 2}
 
 
 def _inertia_matrix(i6) -> np.ndarray:
@@ -393,6 +398,11 @@ class ModelDescription:
                     a[key][off:off + nd] = vals
             off += nd
         nbx = len(self.boxes)
+        # capsule-box pairs run libccd's MPR in the reference (DARTCollide.cpp:4422-4645), an iterative third-party algorithm outside the
+        # closed-form narrow phases of this path: refuse a model in which such a pair is tested (same rule as CollisionFilter.cpp:105-154)
+        if self.capsule_meets_box():
+            raise ValueError("a capsule collider can meet a box collider: the reference runs libccd's MPR on that pair, outside the "
+                             "closed-form narrow phases (capsule-capsule, capsule-sphere) of this path")
         a["box_body"] = np.array([bx.body for bx in self.boxes], np.int32).reshape(nbx)
         a["box_T"] = np.array([_t12(bx.T) for bx in self.boxes], np.float64).reshape(nbx, 12)
         a["box_size"] = np.array([bx.size for bx in self.boxes], np.float64).reshape(nbx, 3)
@@ -403,6 +413,19 @@ class ModelDescription:
         a["body_skeleton"] = np.array(self.body_skeletons(), np.int32).reshape(nb)
         a["pitch"] = np.array([b.pitch for b in self.bodies], np.float64).reshape(nb)
         return a
+
+    def capsule_meets_box(self) -> bool:
+        """Some capsule collider is tested against some box collider (different bodies, not both fixed to the world, different skeletons:
+        the pairs CollisionFilter.cpp:105-154 lets through)."""
+        skel = self.body_skeletons()
+        for i, bi in enumerate(self.boxes):
+            for bj in self.boxes[i + 1:]:
+                if {bi.shape, bj.shape} != {"capsule", "box"} or bi.body == bj.body:
+                    continue
+                if bi.body >= 0 and bj.body >= 0 and skel[bi.body] == skel[bj.body]:
+                    continue
+                return True
+        return False
 
     def to_desc(self):
         """Returns (ModelDesc, keepalive). The keepalive must outlive any use of the struct."""

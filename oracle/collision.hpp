@@ -14,7 +14,8 @@
 namespace nbo {
 
 enum ContactType { CT_UNSUPPORTED = 0, CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3,   // Contact.hpp:45-61
-                   CT_SPHERE_BOX = 4, CT_BOX_SPHERE = 5, CT_SPHERE_SPHERE = 6 };
+                   CT_SPHERE_BOX = 4, CT_BOX_SPHERE = 5, CT_SPHERE_SPHERE = 6,
+                   CT_PIPE_SPHERE = 13, CT_SPHERE_PIPE = 14, CT_PIPE_PIPE = 15 };   // capsule contacts, Contact.hpp:72-74
 
 struct Contact {
   Vec3 point, normal;
@@ -27,6 +28,9 @@ struct Contact {
   bool faceLocked[3] = {false, false, false};
   Vec3 centerA = mk3(0, 0, 0), centerB = mk3(0, 0, 0);
   s_t radiusA = 0, radiusB = 0;
+  // capsule contacts (Contact.hpp:186-199): the cylinder ("pipe") side is a line through pipeFixedPoint along pipeDir
+  Vec3 pipeDir = mk3(0, 0, 0), pipeFixedPoint = mk3(0, 0, 0), pipeClosestPoint = mk3(0, 0, 0);
+  s_t sphereRadius = 0, pipeRadius = 0;
 };
 
 inline Vec3 col(const Mat3& R, int j) { return mk3(R(0, j), R(1, j), R(2, j)); }
@@ -356,6 +360,129 @@ inline int sphereSphere(s_t r0in, const Iso& T0, s_t r1in, const Iso& T1, s_t cl
   return 1;
 }
 
+// dSegmentsClosestApproach (DARTCollide.cpp:301-381): parameters of the closest points of the segments pa->pb and ua->ub
+inline void segmentsClosestApproach(const Vec3& pa, const Vec3& ua, const Vec3& pb, const Vec3& ub, s_t* alpha, s_t* beta) {
+  Vec3 u = pb - pa, v = ub - ua, w = pa - ua;
+  s_t a = dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w);
+  s_t D = a * c - b * b;
+  s_t sN, sD = D, tN, tD = D;
+  const s_t SMALL_NUM = 1e-15;
+  if (D < SMALL_NUM) { sN = 0.0; sD = 1.0; tN = e; tD = c; }
+  else {
+    sN = (b * e - c * d);
+    tN = (a * e - b * d);
+    if (sN < 0.0) { sN = 0.0; tN = e; tD = c; }
+    else if (sN > sD) { sN = sD; tN = e + b; tD = c; }
+  }
+  if (tN < 0.0) {
+    tN = 0.0;
+    if (-d < 0.0) sN = 0.0;
+    else if (-d > a) sN = sD;
+    else { sN = -d; sD = a; }
+  } else if (tN > tD) {
+    tN = tD;
+    if ((-d + b) < 0.0) sN = 0;
+    else if ((-d + b) > a) sN = sD;
+    else { sN = (-d + b); sD = a; }
+  }
+  *alpha = (std::fabs(sN) < SMALL_NUM ? 0.0 : sN / sD);
+  *beta = (std::fabs(tN) < SMALL_NUM ? 0.0 : tN / tD);
+}
+
+// dDistPointToSegment (DARTCollide.cpp:384-410)
+inline s_t distPointToSegment(const Vec3& p, const Vec3& ua, const Vec3& ub, s_t* alpha) {
+  Vec3 v = ub - ua, w = p - ua;
+  s_t c1 = dot(w, v);
+  if (c1 <= 0) { *alpha = 0; return norm(p - ua); }
+  s_t c2 = dot(v, v);
+  if (c2 <= c1) { *alpha = 1; return norm(p - ub); }
+  *alpha = c1 / c2;
+  Vec3 Pb = ua + *alpha * v;
+  return norm(p - Pb);
+}
+
+inline Contact blankContact() {
+  Contact ct;
+  ct.edgeAClosestPoint = ct.edgeAFixedPoint = ct.edgeADir = ct.edgeBClosestPoint = ct.edgeBFixedPoint = ct.edgeBDir = mk3(0, 0, 0);
+  return ct;
+}
+
+// collideCapsuleCapsule (DARTCollide.cpp:4183-4284).  A capsule's axis is the z axis of its shape frame, `height` is the length
+// of the cylinder part.  An end of a segment (alpha / beta within 1e-8 of 0 or 1) makes that side a sphere.
+inline int capsuleCapsule(s_t height0, s_t radius0, const Iso& T0, s_t height1, s_t radius1, const Iso& T1, s_t clippingDepth,
+                          std::vector<Contact>& out) {
+  Vec3 pa = apply(T0, mk3(0, 0, 1) * -(height0 / 2)), pb = apply(T0, mk3(0, 0, 1) * (height0 / 2));
+  Vec3 ua = apply(T1, mk3(0, 0, 1) * -(height1 / 2)), ub = apply(T1, mk3(0, 0, 1) * (height1 / 2));
+  s_t alpha, beta;
+  segmentsClosestApproach(pa, ua, pb, ub, &alpha, &beta);
+  if (alpha < 0) alpha = 0;
+  if (alpha > 1) alpha = 1;
+  if (beta < 0) beta = 0;
+  if (beta > 1) beta = 1;
+  Vec3 closest0 = pa + (pb - pa) * alpha, closest1 = ua + (ub - ua) * beta;
+  s_t dist = norm(closest0 - closest1), rsum = radius0 + radius1;
+  if (!(dist <= rsum)) return 0;
+  radius0 /= rsum; radius1 /= rsum;
+  Contact ct = blankContact();
+  ct.depth = rsum - dist;
+  if (ct.depth > clippingDepth) return 0;
+  ct.point = (closest0 * radius1) + (closest1 * radius0);
+  ct.normal = normalized(closest0 - closest1);
+  const s_t SPHERE_THRESHOLD = 1e-8;
+  ct.radiusA = radius0 * rsum; ct.radiusB = radius1 * rsum;
+  bool isSphere0 = std::fabs(alpha) < SPHERE_THRESHOLD || std::fabs(1 - alpha) < SPHERE_THRESHOLD;
+  bool isSphere1 = std::fabs(beta) < SPHERE_THRESHOLD || std::fabs(1 - beta) < SPHERE_THRESHOLD;
+  if (isSphere0 && isSphere1) { ct.type = CT_SPHERE_SPHERE; ct.centerA = closest0; ct.centerB = closest1; }
+  else if (isSphere0) {
+    ct.type = CT_SPHERE_PIPE;
+    ct.sphereRadius = radius0 * rsum; ct.sphereCenter = closest0;
+    ct.pipeRadius = radius1 * rsum; ct.pipeClosestPoint = closest1; ct.pipeFixedPoint = ua; ct.pipeDir = normalized(ub - ua);
+  } else if (isSphere1) {
+    ct.type = CT_PIPE_SPHERE;
+    ct.pipeRadius = radius0 * rsum; ct.pipeClosestPoint = closest0; ct.pipeFixedPoint = pa; ct.pipeDir = normalized(pb - pa);
+    ct.sphereRadius = radius1 * rsum; ct.sphereCenter = closest1;
+  } else {
+    ct.type = CT_PIPE_PIPE;
+    ct.radiusA = radius0; ct.radiusB = radius1;   // the NORMALISED radii, as in the reference (:4265-4266)
+    ct.edgeAFixedPoint = pa; ct.edgeAClosestPoint = closest0; ct.edgeADir = normalized(pb - pa);
+    ct.edgeBFixedPoint = ua; ct.edgeBClosestPoint = closest1; ct.edgeBDir = normalized(ub - ua);
+  }
+  out.push_back(ct);
+  return 1;
+}
+
+// collideSphereCapsule (DARTCollide.cpp:4286-4352, the sphere is object 1) / collideCapsuleSphere (:4354-4420, the capsule is)
+inline int sphereCapsulePair(bool sphereFirst, s_t rSphere, const Iso& Ts, s_t height, s_t rCapsule, const Iso& Tc, s_t clippingDepth,
+                             std::vector<Contact>& out) {
+  s_t alpha;
+  Vec3 center = Ts.p;
+  Vec3 ua = apply(Tc, mk3(0, 0, 1) * -(height / 2)), ub = apply(Tc, mk3(0, 0, 1) * (height / 2));
+  s_t dist = distPointToSegment(center, ua, ub, &alpha);
+  s_t radius0 = sphereFirst ? rSphere : rCapsule, radius1 = sphereFirst ? rCapsule : rSphere;
+  if (!(dist < radius0 + radius1)) return 0;
+  Vec3 closest = ua + (ub - ua) * alpha;
+  s_t rsum = radius0 + radius1;
+  radius0 /= rsum; radius1 /= rsum;
+  Contact ct = blankContact();
+  ct.depth = rsum - dist;
+  if (ct.depth > clippingDepth) return 0;
+  const Vec3& first = sphereFirst ? center : closest;
+  const Vec3& second = sphereFirst ? closest : center;
+  ct.point = (first * radius1) + (second * radius0);
+  ct.normal = normalized(first - second);
+  const s_t SPHERE_THRESHOLD = 1e-8;
+  ct.radiusA = radius0 * rsum; ct.radiusB = radius1 * rsum;
+  bool isSphere1 = std::fabs(alpha) < SPHERE_THRESHOLD || std::fabs(1 - alpha) < SPHERE_THRESHOLD;
+  if (isSphere1) { ct.type = CT_SPHERE_SPHERE; ct.centerA = first; ct.centerB = second; }
+  else {
+    ct.type = sphereFirst ? CT_SPHERE_PIPE : CT_PIPE_SPHERE;
+    ct.sphereRadius = (sphereFirst ? radius0 : radius1) * rsum; ct.pipeRadius = (sphereFirst ? radius1 : radius0) * rsum;
+    ct.sphereCenter = center; ct.pipeClosestPoint = closest; ct.pipeFixedPoint = ua; ct.pipeDir = normalized(ub - ua);
+  }
+  out.push_back(ct);
+  return 1;
+}
+
 inline int skeletonRoot(const Model& m, int body) {
   while (body >= 0 && m.bodies[body].parent >= 0) body = m.bodies[body].parent;
   return body;
@@ -375,7 +502,12 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
       std::vector<Contact> pair;
       // dispatch on the two shape types (collide(), DARTCollide.cpp:5030-5260)
       const bool si = bi.shape == NBL_SHAPE_SPHERE, sj = bj.shape == NBL_SHAPE_SPHERE;
-      if (si && sj) sphereSphere(bi.size[0], Ti, bj.size[0], Tj, m.clippingDepth, pair);
+      const bool ci = bi.shape == NBL_SHAPE_CAPSULE, cj = bj.shape == NBL_SHAPE_CAPSULE;   // size = (radius, height, -)
+      if (ci && cj) capsuleCapsule(bi.size[1], bi.size[0], Ti, bj.size[1], bj.size[0], Tj, m.clippingDepth, pair);
+      else if (si && cj) sphereCapsulePair(true, bi.size[0], Ti, bj.size[1], bj.size[0], Tj, m.clippingDepth, pair);
+      else if (ci && sj) sphereCapsulePair(false, bj.size[0], Tj, bi.size[1], bi.size[0], Ti, m.clippingDepth, pair);
+      else if (ci || cj) continue;   // capsule-box runs libccd's MPR in the reference (DARTCollide.cpp:4422-4645): such pairs are refused at model creation
+      else if (si && sj) sphereSphere(bi.size[0], Ti, bj.size[0], Tj, m.clippingDepth, pair);
       else if (si) sphereBoxPair(true, bi.size[0], Ti, 0.5 * bj.size, Tj, m.clippingDepth, pair);
       else if (sj) sphereBoxPair(false, bj.size[0], Tj, 0.5 * bi.size, Ti, m.clippingDepth, pair);
       else boxBox(Ti, 0.5 * bi.size, Tj, 0.5 * bj.size, m.clippingDepth, pair);

@@ -553,7 +553,8 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
 // Backward: contact terms of the BackpropSnapshot Jacobians
 // ---------------------------------------------------------------------------------------------
 enum DofContactType { DCT_NONE = 0, DCT_VERTEX, DCT_FACE, DCT_EDGE_A, DCT_EDGE_B, DCT_SELF_COLLISION, DCT_UNSUPPORTED,
-                      DCT_SPHERE_TO_BOX, DCT_BOX_TO_SPHERE, DCT_SPHERE_A, DCT_SPHERE_B };
+                      DCT_SPHERE_TO_BOX, DCT_BOX_TO_SPHERE, DCT_SPHERE_A, DCT_SPHERE_B,
+                      DCT_SPHERE_TO_PIPE, DCT_PIPE_TO_SPHERE, DCT_PIPE_A, DCT_PIPE_B };
 
 // DifferentiableContactConstraint::getDofContactType (DCC.cpp:116-228), box-box contact types only
 inline int dofContactType(const Model& m, const Contact& ct, int dofBody) {
@@ -567,6 +568,9 @@ inline int dofContactType(const Model& m, const Contact& ct, int dofBody) {
     if (ct.type == CT_SPHERE_BOX) return DCT_SPHERE_TO_BOX;
     if (ct.type == CT_BOX_SPHERE) return DCT_BOX_TO_SPHERE;
     if (ct.type == CT_SPHERE_SPHERE) return DCT_SPHERE_A;
+    if (ct.type == CT_SPHERE_PIPE) return DCT_SPHERE_TO_PIPE;
+    if (ct.type == CT_PIPE_SPHERE) return DCT_PIPE_TO_SPHERE;
+    if (ct.type == CT_PIPE_PIPE) return DCT_PIPE_A;
     return DCT_UNSUPPORTED;
   }
   if (ct.type == CT_FACE_VERTEX) return DCT_VERTEX;
@@ -575,10 +579,37 @@ inline int dofContactType(const Model& m, const Contact& ct, int dofBody) {
   if (ct.type == CT_SPHERE_BOX) return DCT_BOX_TO_SPHERE;
   if (ct.type == CT_BOX_SPHERE) return DCT_SPHERE_TO_BOX;
   if (ct.type == CT_SPHERE_SPHERE) return DCT_SPHERE_B;
+  if (ct.type == CT_SPHERE_PIPE) return DCT_PIPE_TO_SPHERE;
+  if (ct.type == CT_PIPE_SPHERE) return DCT_SPHERE_TO_PIPE;
+  if (ct.type == CT_PIPE_PIPE) return DCT_PIPE_B;
   return DCT_UNSUPPORTED;
 }
 
-// math::getContactPointGradient (Geometry.cpp:1129-1236) with radiusA = radiusB = 1
+// math::getContactPointGradient (Geometry.cpp:1129-1236); edge-edge contacts call it with radiusA = radiusB = 1
+inline Vec3 contactPointGradient(const Vec3& aP, const Vec3& aPg, const Vec3& aD, const Vec3& aDg, const Vec3& bP,
+                                 const Vec3& bPg, const Vec3& bD, const Vec3& bDg, s_t radiusA, s_t radiusB) {
+  Vec3 p = bP - aP, d_p = bPg - aPg;
+  s_t uaub = dot(aD, bD), d_uaub = dot(aDg, bD) + dot(aD, bDg);
+  s_t q1 = dot(aD, p), d_q1 = dot(aDg, p) + dot(aD, d_p);
+  s_t q2 = -dot(bD, p), d_q2 = -dot(bDg, p) - dot(bD, d_p);
+  s_t d = 1 - uaub * uaub, d_d = -2 * d_uaub * uaub;
+  auto over = [](const Vec3& x, s_t s) { return mk3(x[0] / s, x[1] / s, x[2] / s); };   // Eigen's vector / scalar divides every component
+  if (d <= 0) return over(aPg * radiusB + bPg * radiusA, radiusA + radiusB);
+  s_t e = 1.0 / d, d_e = -(1.0 / (d * d)) * d_d;
+  s_t alpha = (q1 + uaub * q2) * e, d_alpha = (q1 + uaub * q2) * d_e + (d_q1 + d_uaub * q2 + uaub * d_q2) * e;
+  s_t beta = (uaub * q1 + q2) * e, d_beta = (uaub * q1 + q2) * d_e + (d_uaub * q1 + uaub * d_q1 + d_q2) * e;
+  return over((aPg + alpha * aDg + d_alpha * aD) * radiusB + (bPg + beta * bDg + d_beta * bD) * radiusA, radiusA + radiusB);
+}
+// math::closestPointOnLineGradient (Geometry.cpp:4427-4445)
+inline Vec3 closestPointOnLineGradient(const Vec3& pointOnLine, const Vec3& pointOnLineGradient, const Vec3& lineDirection,
+                                       const Vec3& lineDirectionGradient, const Vec3& goalPoint, const Vec3& goalPointGradient) {
+  s_t offset = dot(lineDirection, pointOnLine);
+  s_t dOffset = dot(lineDirectionGradient, pointOnLine) + dot(lineDirection, pointOnLineGradient);
+  s_t goalOffset = dot(lineDirection, goalPoint);
+  s_t dGoalOffset = dot(lineDirectionGradient, goalPoint) + dot(lineDirection, goalPointGradient);
+  s_t relative = goalOffset - offset, dRelative = dGoalOffset - dOffset;
+  return pointOnLineGradient + relative * lineDirectionGradient + dRelative * lineDirection;
+}
 inline Vec3 contactPointGradient(const Vec3& aP, const Vec3& aPg, const Vec3& aD, const Vec3& aDg, const Vec3& bP,
                                  const Vec3& bPg, const Vec3& bD, const Vec3& bDg) {
   Vec3 p = bP - aP, d_p = bPg - aPg;
@@ -651,6 +682,23 @@ struct ContactGrad {
     if (type == DCT_SPHERE_B) return (ct.radiusA / (ct.radiusA + ct.radiusB)) * gradTheta(ct.centerB);
     if (type == DCT_SPHERE_TO_BOX) return unlock(gradTheta(ct.sphereCenter));                              // :352-373
     if (type == DCT_BOX_TO_SPHERE) return gradTheta(ct.point) + unlock(-1.0 * gradTheta(ct.sphereCenter)); // :374-403
+    if (type == DCT_SPHERE_TO_PIPE) {                                                                       // DCC.cpp:484-495
+      s_t weight = ct.pipeRadius / (ct.sphereRadius + ct.pipeRadius);
+      Vec3 raw = gradTheta(ct.sphereCenter);
+      Vec3 par = dot(ct.pipeDir, raw) * ct.pipeDir;
+      return par + weight * (raw - par);
+    }
+    if (type == DCT_PIPE_TO_SPHERE) {                                                                       // :496-509
+      Vec3 raw = closestPointOnLineGradient(ct.pipeFixedPoint, gradTheta(ct.pipeFixedPoint), ct.pipeDir, cross(w, ct.pipeDir),
+                                            ct.sphereCenter, mk3(0, 0, 0));
+      return (ct.sphereRadius / (ct.sphereRadius + ct.pipeRadius)) * raw;
+    }
+    if (type == DCT_PIPE_A)                                                                                 // :510-528
+      return contactPointGradient(ct.edgeAFixedPoint, gradTheta(ct.edgeAFixedPoint), ct.edgeADir, cross(w, ct.edgeADir),
+                                  ct.edgeBFixedPoint, mk3(0, 0, 0), ct.edgeBDir, mk3(0, 0, 0), ct.radiusA, ct.radiusB);
+    if (type == DCT_PIPE_B)                                                                                 // :529-547
+      return contactPointGradient(ct.edgeAFixedPoint, mk3(0, 0, 0), ct.edgeADir, mk3(0, 0, 0), ct.edgeBFixedPoint,
+                                  gradTheta(ct.edgeBFixedPoint), ct.edgeBDir, cross(w, ct.edgeBDir), ct.radiusA, ct.radiusB);
     if (type == DCT_EDGE_A)
       return contactPointGradient(ct.edgeAFixedPoint, gradTheta(ct.edgeAFixedPoint), ct.edgeADir, cross(w, ct.edgeADir),
                                   ct.edgeBFixedPoint, mk3(0, 0, 0), ct.edgeBDir, mk3(0, 0, 0));
@@ -681,6 +729,35 @@ struct ContactGrad {
       // BOX_SPHERE: normal = contact point - sphere centre; SPHERE_BOX: the opposite
       Vec3 total = ct.type == CT_BOX_SPHERE ? cpg - spg : spg - cpg;
       return total - dot(total, ct.normal) * ct.normal;
+    }
+    if (type == DCT_SPHERE_TO_PIPE || type == DCT_PIPE_TO_SPHERE) {                                        // DCC.cpp:819-861
+      Vec3 v = tail(posTwist[dof]);
+      auto gradTheta = [&](const Vec3& pt) { return (norm(w) > 1e-6) ? cross(w, pt) + v : v; };
+      s_t nrm = norm(ct.pipeClosestPoint - ct.sphereCenter);
+      Vec3 ng;
+      if (type == DCT_SPHERE_TO_PIPE) {
+        ng = gradTheta(ct.sphereCenter);
+        ng = ng - dot(ng, ct.pipeDir) * ct.pipeDir;
+      } else
+        ng = closestPointOnLineGradient(ct.pipeFixedPoint, gradTheta(ct.pipeFixedPoint), ct.pipeDir, cross(w, ct.pipeDir),
+                                        ct.sphereCenter, mk3(0, 0, 0));
+      ng = (1.0 / nrm) * ng;
+      ng = ng - dot(ct.normal, ng) * ct.normal;
+      // the normal points from object 2 to object 1: the moving side is object 1 exactly when the contact type names it first
+      const bool first = type == DCT_SPHERE_TO_PIPE ? ct.type == CT_SPHERE_PIPE : ct.type == CT_PIPE_SPHERE;
+      return first ? ng : -1.0 * ng;
+    }
+    if (type == DCT_PIPE_A || type == DCT_PIPE_B) {                                                        // DCC.cpp:862-938
+      Vec3 v = tail(posTwist[dof]);
+      auto gradTheta = [&](const Vec3& pt) { return (norm(w) > 1e-6) ? cross(w, pt) + v : v; };
+      const bool a = type == DCT_PIPE_A;
+      const Vec3 z = mk3(0, 0, 0);
+      const Vec3 aPg = a ? gradTheta(ct.edgeAFixedPoint) : z, aDg = a ? cross(w, ct.edgeADir) : z;
+      const Vec3 bPg = a ? z : gradTheta(ct.edgeBFixedPoint), bDg = a ? z : cross(w, ct.edgeBDir);
+      Vec3 cA = contactPointGradient(ct.edgeAFixedPoint, aPg, ct.edgeADir, aDg, ct.edgeBFixedPoint, bPg, ct.edgeBDir, bDg, 0.0, 1.0);
+      Vec3 cB = contactPointGradient(ct.edgeAFixedPoint, aPg, ct.edgeADir, aDg, ct.edgeBFixedPoint, bPg, ct.edgeBDir, bDg, 1.0, 0.0);
+      Vec3 ng = (1.0 / norm(ct.edgeAClosestPoint - ct.edgeBClosestPoint)) * (cA - cB);
+      return ng - dot(ct.normal, ng) * ct.normal;
     }
     s_t sign = dot(cross(ct.edgeBDir, ct.edgeADir), ct.normal) < 0 ? -1.0 : 1.0;
     if (type == DCT_EDGE_A) return sign * cross(ct.edgeBDir, cross(w, ct.edgeADir));

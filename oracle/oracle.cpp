@@ -473,6 +473,27 @@ int nbo_sphere_pair(int which, const double* T1, const double* size1, const doub
   }
   return n;
 }
+// which: 0 = capsule vs capsule, 1 = sphere (size1[0]) vs capsule, 2 = capsule vs sphere; a capsule's size = (radius, height).
+// out: 48 doubles (the layout of ref_collide_capsule, oracle/ref_boxbox_epilogue.hpp)
+int nbo_capsule_pair(int which, const double* T1, const double* size1, const double* T2, const double* size2, double clip, double* out) {
+  std::vector<Contact> cs;
+  int n;
+  if (which == 0) n = capsuleCapsule(size1[1], size1[0], loadIso(T1), size2[1], size2[0], loadIso(T2), clip, cs);
+  else if (which == 1) n = sphereCapsulePair(true, size1[0], loadIso(T1), size2[1], size2[0], loadIso(T2), clip, cs);
+  else n = sphereCapsulePair(false, size2[0], loadIso(T2), size1[1], size1[0], loadIso(T1), clip, cs);
+  if (n) {
+    const Contact& c = cs[0];
+    double* o = out;
+    for (int k = 0; k < 3; k++) {
+      o[k] = c.point[k]; o[3 + k] = c.normal[k]; o[8 + k] = c.centerA[k]; o[11 + k] = c.centerB[k];
+      o[16 + k] = c.sphereCenter[k]; o[19 + k] = c.pipeDir[k]; o[22 + k] = c.pipeFixedPoint[k]; o[25 + k] = c.pipeClosestPoint[k];
+      o[30 + k] = c.edgeAFixedPoint[k]; o[33 + k] = c.edgeADir[k]; o[36 + k] = c.edgeBFixedPoint[k]; o[39 + k] = c.edgeBDir[k];
+      o[42 + k] = c.edgeAClosestPoint[k]; o[45 + k] = c.edgeBClosestPoint[k];
+    }
+    o[6] = c.depth; o[7] = c.type; o[14] = c.radiusA; o[15] = c.radiusB; o[28] = c.sphereRadius; o[29] = c.pipeRadius;
+  }
+  return n;
+}
 static LcpProblem mkProblem(int n, const double* A, const double* x, const double* b, const double* lo, const double* hi,
                             const int32_t* findex) {
   LcpProblem p;
@@ -571,6 +592,10 @@ int nbo_prim(const char* name, const double* in0, const double* in1, double* out
   if (f == "tangentBasisGradient") { Vec3 t1, t2; tangentBasisGradient(v3(in0), v3(in1), t1, t2); for (int i = 0; i < 3; i++) { out[i] = t1[i]; out[3 + i] = t2[i]; } return 6; }
   if (f == "contactPointGradient")
     return o3(contactPointGradient(v3(in0), v3(in0 + 3), v3(in0 + 6), v3(in0 + 9), v3(in0 + 12), v3(in0 + 15), v3(in0 + 18), v3(in0 + 21)));
+  if (f == "contactPointGradientRadii")   // in1 = (radiusA, radiusB)
+    return o3(contactPointGradient(v3(in0), v3(in0 + 3), v3(in0 + 6), v3(in0 + 9), v3(in0 + 12), v3(in0 + 15), v3(in0 + 18), v3(in0 + 21), in1[0], in1[1]));
+  if (f == "closestPointOnLineGradient")
+    return o3(closestPointOnLineGradient(v3(in0), v3(in0 + 3), v3(in0 + 6), v3(in0 + 9), v3(in0 + 12), v3(in0 + 15)));
   if (f == "transformInertia") {
     Mat6 I; for (int i = 0; i < 36; i++) I.m[i] = in1[i];
     const Mat6 r = transformInertia(iso(in0), I);

@@ -38,6 +38,35 @@ extern "C" int ref_collide_sphere(int which, const double* size0, const double* 
   return packSphere(res, out, cap);
 }
 
+// which: 0 = collideCapsuleCapsule, 1 = collideSphereCapsule (sphere = object 1), 2 = collideCapsuleSphere; size = (radius, height)
+// out: 48 doubles per contact: point(3) normal(3) depth type | centerA(3) centerB(3) radiusA radiusB | sphereCenter(3) pipeDir(3)
+// pipeFixedPoint(3) pipeClosestPoint(3) sphereRadius pipeRadius | edgeAFixed(3) edgeADir(3) edgeBFixed(3) edgeBDir(3) edgeAClosest(3) edgeBClosest(3)
+extern "C" int ref_collide_capsule(int which, const double* size0, const double* T0, const double* size1, const double* T1, double clippingDepth,
+                                   double* out, int cap) {
+  using namespace dart::collision;
+  CollisionObject o1, o2;
+  CollisionOption opt;
+  opt.contactClippingDepth = clippingDepth;
+  CollisionResult res;
+  if (which == 0) collideCapsuleCapsule(&o1, &o2, size0[1], size0[0], isoOf(T0), size1[1], size1[0], isoOf(T1), opt, res);
+  else if (which == 1) collideSphereCapsule(&o1, &o2, size0[0], isoOf(T0), size1[1], size1[0], isoOf(T1), opt, res);
+  else collideCapsuleSphere(&o1, &o2, size0[1], size0[0], isoOf(T0), size1[0], isoOf(T1), opt, res);
+  int n = 0;
+  for (const Contact& c : res.contacts) {
+    if (n >= cap) break;
+    double* o = out + 48 * n;
+    for (int k = 0; k < 3; k++) {
+      o[k] = c.point[k]; o[3 + k] = c.normal[k]; o[8 + k] = c.centerA[k]; o[11 + k] = c.centerB[k];
+      o[16 + k] = c.sphereCenter[k]; o[19 + k] = c.pipeDir[k]; o[22 + k] = c.pipeFixedPoint[k]; o[25 + k] = c.pipeClosestPoint[k];
+      o[30 + k] = c.edgeAFixedPoint[k]; o[33 + k] = c.edgeADir[k]; o[36 + k] = c.edgeBFixedPoint[k]; o[39 + k] = c.edgeBDir[k];
+      o[42 + k] = c.edgeAClosestPoint[k]; o[45 + k] = c.edgeBClosestPoint[k];
+    }
+    o[6] = c.penetrationDepth; o[7] = (double)c.type; o[14] = c.radiusA; o[15] = c.radiusB; o[28] = c.sphereRadius; o[29] = c.pipeRadius;
+    n++;
+  }
+  return (int)res.contacts.size();
+}
+
 extern "C" int ref_collide_box_box(const double* size0, const double* T0, const double* size1, const double* T1, double clippingDepth,
                                    double* out, int cap) {
   using namespace dart::collision;

@@ -1,6 +1,6 @@
 // oracle/ref_boxbox_prelude.hpp - TEST INFRASTRUCTURE.  What the reference's own analytic narrow phases (dart/collision/dart/
 // DARTCollide.cpp: the ODE-derived dBoxBox and its helpers from `typedef s_t dVector3[4]` to the end of collideBoxBox, and collideBoxSphere /
-// collideSphereBox / collideSphereSphere) need in order to compile WITHOUT Eigen and without the rest of DART: stand-ins for the handful of Eigen::Vector3s / Isometry3s operations that range uses and
+// collideSphereBox / collideSphereSphere, and collideCapsuleCapsule / collideSphereCapsule / collideCapsuleSphere) need in order to compile WITHOUT Eigen and without the rest of DART: stand-ins for the handful of Eigen::Vector3s / Isometry3s operations that range uses and
 // for the collision types it fills in.  oracle/ref_build.py concatenates this file, that line range read from /root/reference at build time
 // (nothing of it is stored in this repo) and ref_boxbox_epilogue.hpp into oracle/_ref/, and compiles libdboxbox_ref.so from it.
 #pragma once
@@ -33,6 +33,7 @@ struct Vector3s {
   Vector3s& operator-=(const Vector3s& o) { v[0] -= o.v[0]; v[1] -= o.v[1]; v[2] -= o.v[2]; return *this; }
   Vector3s& operator*=(double s) { v[0] *= s; v[1] *= s; v[2] *= s; return *this; }
   double dot(const Vector3s& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
+  static Vector3s UnitZ() { return Vector3s(0, 0, 1); }
   double squaredNorm() const { return dot(*this); }
   double norm() const { return std::sqrt(squaredNorm()); }                      // Eigen: sqrt of the sum of squares, in this order
   void setZero() { v[0] = v[1] = v[2] = 0; }
@@ -83,7 +84,8 @@ inline double pi() { return 3.141592653589793238462643383279502884; }
 namespace collision {
 struct CollisionObject {};
 struct CollisionOption { double contactClippingDepth = 0.03; };
-enum ContactType { UNSUPPORTED = 0, VERTEX_FACE = 1, FACE_VERTEX = 2, EDGE_EDGE = 3, SPHERE_BOX = 4, BOX_SPHERE = 5, SPHERE_SPHERE = 6 };
+enum ContactType { UNSUPPORTED = 0, VERTEX_FACE = 1, FACE_VERTEX = 2, EDGE_EDGE = 3, SPHERE_BOX = 4, BOX_SPHERE = 5, SPHERE_SPHERE = 6,
+                   PIPE_SPHERE = 13, SPHERE_PIPE = 14, PIPE_PIPE = 15 };
 enum ClipSphereHalfspace { BOTH = 0, TOP = 1, BOTTOM = 2 };
 #define DART_COLLISION_EPS 1E-6
 struct Contact {
@@ -96,6 +98,8 @@ struct Contact {
   Eigen::Vector3s sphereCenter, face1Normal, face2Normal, face3Normal, centerA, centerB;
   bool face1Locked = false, face2Locked = false, face3Locked = false;
   double radiusA = 0, radiusB = 0;
+  Eigen::Vector3s pipeDir, pipeClosestPoint, pipeFixedPoint;   // capsule contacts (Contact.hpp:186-199)
+  double sphereRadius = 0, pipeRadius = 0;
 };
 struct CollisionResult {
   std::vector<Contact> contacts;

@@ -83,6 +83,12 @@ def build_boxbox():
         s2 = next(i for i in range(s1, len(lines)) if lines[i] == "}")
         f.write(f'#line {s0 + 1} "{src}"\n')
         f.write("\n".join(lines[s0:s2 + 1]) + "\n")
+        # ... and the closed-form capsule narrow phases: collideCapsuleCapsule .. end of collideCapsuleSphere
+        c0 = next(i for i, l in enumerate(lines) if l.startswith("int collideCapsuleCapsule("))
+        c1 = next(i for i, l in enumerate(lines) if l.startswith("int collideCapsuleSphere("))
+        c2 = next(i for i in range(c1, len(lines)) if lines[i] == "}")
+        f.write(f'#line {c0 + 1} "{src}"\n')
+        f.write("\n".join(lines[c0:c2 + 1]) + "\n")
         f.write('#line 1 "ref_boxbox_epilogue.hpp"\n')
         f.write(open(parts[1]).read())
     # -ffp-contract=off: the reference's build has no fused multiply-adds
@@ -102,6 +108,7 @@ GEOMETRY_FUNCTIONS = [   # signature prefix at column 0 of dart/math/Geometry.cp
     "Eigen::Matrix3s eulerXYZToMatrix(", "Eigen::Matrix3s eulerZYXToMatrix(", "Eigen::Isometry3s expMap(", "Eigen::Isometry3s expAngular(",
     "Eigen::Isometry3s expMapDart(", "Eigen::Vector6s dad(", "Inertia transformInertia(",
     "void dLineClosestApproach(", "Eigen::Vector3s getContactPoint(", "Eigen::Vector3s getContactPointGradient(",
+    "Eigen::Vector3s closestPointOnLineGradient(",
 ]
 
 

@@ -67,6 +67,10 @@ void ref_getContactPoint(const double* in, double rA, double rB, double* out) {
 void ref_getContactPointGradient(const double* in, double rA, double rB, double* out) {
   o3(getContactPointGradient(v3(in), v3(in + 3), v3(in + 6), v3(in + 9), v3(in + 12), v3(in + 15), v3(in + 18), v3(in + 21), rA, rB), out);
 }
+// math::closestPointOnLineGradient (capsule contacts): in = pointOnLine, its gradient, lineDirection, its gradient, goalPoint, its gradient
+void ref_closestPointOnLineGradient(const double* in, double* out) {
+  o3(closestPointOnLineGradient(v3(in), v3(in + 3), v3(in + 6), v3(in + 9), v3(in + 12), v3(in + 15)), out);
+}
 
 // dart::dynamics::SimpleFeatherstone::forwardDynamics on a caller-described tree of n one-DOF joints (no gravity, no damping: the
 // reference's flat-array ABA has neither): parent[n] (-1 = root), axis [n][6] (the joint's screw axis: position map expMap(axis q) AND

@@ -17,7 +17,8 @@ class _Iso:                      # Eigen::Isometry3s as bound by eigen_geometry_
 
 class _Shape:
     def __init__(self, bx): self._bx = bx
-    def getType(self): return "SphereShape" if self._bx.shape == "sphere" else "BoxShape"
+    def getType(self): return {"sphere": "SphereShape", "capsule": "CapsuleShape"}.get(self._bx.shape, "BoxShape")
+    def getHeight(self): return float(self._bx.size[1])
     def getSize(self): return np.array(self._bx.size, dtype=np.float64)
     def getRadius(self): return float(self._bx.size[0])
 
@@ -175,6 +176,20 @@ def test_extraction_keeps_spheres_friction_action_space_and_leaves_the_world_unt
     assert w._tuned == []                                   # the mass vector was registered on a clone only
     assert [bx.shape for bx in got.boxes] == [bx.shape for bx in md.boxes] and got.boxes[0].mu == 0.3
     assert list(got.action_map) == [5, 6, 12]
+    _same(got, md)
+
+
+def test_extraction_keeps_capsules():
+    """CapsuleShape (getRadius / getHeight, python/_nimblephysics/dynamics/Shape.cpp:769-782) -> capsule colliders."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import capsule_world
+    md = capsule_world(order="free_first", kinds=("capsule", "sphere"))
+    md.bodies.append(na.BodySpec("fixed", -1, "weld", "fix"))          # a live World has no body-less colliders: the fixed capsule on a welded body
+    md.boxes[-1].body = len(md.bodies) - 1
+    got = model_from_nimble_world(StandInWorld(md), name=md.name, max_contacts=md.max_contacts)
+    assert [bx.shape for bx in got.boxes] == ["capsule", "sphere", "capsule"]
+    assert [tuple(bx.size) for bx in got.boxes] == [tuple(bx.size) for bx in md.boxes]
     _same(got, md)
 
 

@@ -259,5 +259,25 @@ def test_contact_geometry_gradients_match_the_references(ref):
         want = np.zeros(3)
         ref.ref_getContactPointGradient(_p(x), 1.0, 1.0, _p(want))
         worst_p = max(worst_p, _ulps(_oracle_prim("contactPointGradient", x, None, 3), want))
+    # capsule contacts (PIPE_A / PIPE_B, DCC.cpp:510-547, 862-938) call it with the capsules' normalised radii and with (0, 1) / (1, 0);
+    # SPHERE_TO_PIPE / PIPE_TO_SPHERE go through math::closestPointOnLineGradient (Geometry.cpp:4427-4445)
+    ref.ref_closestPointOnLineGradient.argtypes = [PD, PD]; ref.ref_closestPointOnLineGradient.restype = None
+    worst_r = worst_l = 0.0
+    for trial in range(600):
+        x = rng.normal(0, 1, 24)
+        for k in (6, 18):
+            x[k:k + 3] /= np.linalg.norm(x[k:k + 3])
+        if trial % 50 == 0:
+            x[18:21] = x[6:9]
+        rA = rng.uniform(0.05, 0.95)
+        radii = np.array([(rA, 1 - rA), (0.0, 1.0), (1.0, 0.0)][trial % 3])
+        want = np.zeros(3)
+        ref.ref_getContactPointGradient(_p(x), radii[0], radii[1], _p(want))
+        worst_r = max(worst_r, _ulps(_oracle_prim("contactPointGradientRadii", x, radii, 3), want))
+        y = rng.normal(0, 1, 18); y[6:9] /= np.linalg.norm(y[6:9])
+        ref.ref_closestPointOnLineGradient(_p(y), _p(want))
+        worst_l = max(worst_l, _ulps(_oracle_prim("closestPointOnLineGradient", y, None, 3), want))
+    print("contact-point gradient with radii / closest-point-on-line gradient vs the reference's (ulps):", worst_r, worst_l)
+    assert worst_r == 0.0 and worst_l == 0.0
     print("tangent-basis gradient / contact-point gradient vs the reference's, worst difference (ulps):", worst_t, worst_p)
     assert worst_t == 0.0 and worst_p == 0.0       # (the pin found the oracle multiplying by 1 / |t| where the reference divides: 16 ulps, fixed)

@@ -97,6 +97,20 @@ def ball_world(order="box_first", n_balls=1, radius=0.1, arm=False):
     return na.ModelDescription("balls", bodies, boxes, max_contacts=8)
 
 
+# ---- capsule colliders (tests/test_oracle_capsules.py, tests/test_gpu_capsules.py) ----
+def capsule_world(order="fixed_first", kinds=("capsule",), radius=0.1, height=0.4):
+    """Free-joint capsules (axis = their z, radius 0.1, cylinder height 0.4) / spheres (radius 0.1) over a world-fixed capsule of radius
+    0.25 whose axis is the world's z axis through the origin (a capsule cannot meet a box: that pair is libccd's in the reference)."""
+    bodies, cols = [], []
+    ground = na.CapsuleSpec(-1, np.eye(4), 0.25, 3.0, 1.0)
+    for i, kind in enumerate(kinds):
+        I = 0.4 * radius * radius
+        bodies.append(na.BodySpec(f"{kind}{i}", -1, "free", f"{kind}{i}_joint", mass=1.0, inertia=(I, I, 0.5 * I, 0, 0, 0)))
+        cols.append(na.CapsuleSpec(i, np.eye(4), radius, height, 0.8) if kind == "capsule" else na.SphereSpec(i, np.eye(4), radius, 0.8))
+    boxes = [ground] + cols if order == "fixed_first" else cols + [ground]
+    return na.ModelDescription("capsules", bodies, boxes, max_contacts=8)
+
+
 def ball_state(md, centres, seed, pen=2e-3, radius=0.1):
     rng = np.random.default_rng(seed)
     n = md.num_dofs

@@ -8,6 +8,8 @@ reduced size as tests/test_gpu_stress.py.
   mu      friction from 1.01e-3 (just above the frictionless threshold) to 10
   subset  a random third of the DOFs actuated (World::setActionSpace; unmapped torques are zero)
   atlimit positions, velocities and torques exactly at their limits in half of the worlds (clipLossGradientsToBounds)
+  capsule every box collider becomes a capsule (radius = half its smallest side, cylinder height = its longest side, axis = that side's) and
+          the ground a world-fixed sphere of radius 100 m with its top at y = 0 (a capsule cannot meet a box: libccd in the reference)
 usage (GPU box): python tools/soak_stress.py <mode> [first seed] [count] [B]"""
 import os
 import sys
@@ -17,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit")
+MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule")
 
 
 def mutator(mode):
@@ -49,6 +51,27 @@ def mutator(mode):
         elif mode == "subset":
             keep = sorted(rng.choice(n, size=max(1, n // 3), replace=False).tolist())
             md.set_action_space(keep); a = a[:, :len(keep)]
+        elif mode == "capsule":
+            import nimblephysics_amd as na
+            g0 = md.boxes[0]
+            assert g0.body < 0 and g0.shape == "box"
+            ground = na.SphereSpec(-1, na.make_transform((0.0, -100.0, 0.0)), 100.0, g0.mu)
+            ground.restitution = g0.restitution
+            md.boxes[0] = ground
+            for bx in md.boxes[1:]:
+                if bx.shape != "box":
+                    continue
+                size = np.asarray(bx.size, dtype=np.float64)
+                ax = int(np.argmax(size))
+                Rz = np.eye(4)                                    # the capsule's z axis along the box's longest side
+                if ax == 0:
+                    Rz[:3, :3] = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], dtype=np.float64)
+                elif ax == 1:
+                    Rz[:3, :3] = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=np.float64)
+                bx.T = np.asarray(bx.T, dtype=np.float64) @ Rz
+                r = float(0.5 * np.min(size))
+                bx.size = (r, float(max(size[ax] - 2 * r, 0.0)), 0.0)
+                bx.shape = "capsule"
         elif mode == "atlimit":
             for i, b in enumerate(md.bodies):
                 if md.joint_ndof(i) == 1 and rng.random() < 0.5:
