@@ -70,6 +70,7 @@ extern "C" {
 #define NBL_ST_NAN 0x40u          /* non-finite value seen: in the LCP stages, or in the world's next state (NaN / Inf inputs); other worlds are unaffected */
 #define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts than max_contacts; extra ones dropped */
 #define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
+#define NBL_ST_JOINT_LIMIT 0x400u  /* >=1 joint-limit constraint row was active (dof_limit_enforced) */
 #define NBL_ST_GRAD_PARTIAL 0x200u /* reserved (never set: the EDGE_EDGE contact-geometry gradient terms, DCC.cpp:397-424,
                                       700-735, are evaluated by the device backward) */
 
@@ -150,6 +151,17 @@ typedef struct nbl_model_desc {
   /* ---- screw joints (appended; NULL = 0.1 for every screw joint, ScrewJointAspect's default) ----
    * [n_bodies] ScrewJoint::mPitch: translation along the axis per full turn; read for NBL_JOINT_SCREW bodies only. */
   const double* pitch;
+
+  /* ---- joint-limit constraint rows (appended; NULL = none, the reference's default: Joint::isPositionLimitEnforced is false,
+   * JointAspect.hpp:165) ----
+   * [n_dofs] non-zero: the DOF's joint enforces its position limits (Joint::setPositionLimitEnforced).  A DOF at or beyond pos_lo /
+   * pos_hi then adds one row to the LCP of its skeleton's constrained group, after the contact rows (JointLimitConstraint.cpp:182-290,
+   * ConstraintSolver.cpp:641-696): unit impulse on the DOF, b = -qdot (error allowance 0), bounds [0, inf) at the lower and
+   * (-inf, 0] at the upper limit.  Honoured for the single-DOF joints (revolute, prismatic, screw and the coordinates of expanded
+   * compound joints); a limit row takes one of the max_contacts contact slots.  The backward pass follows the reference's: its
+   * DifferentiableContactConstraint gives a non-contact constraint a zero constraint-force column (DCC.cpp:51-99), so the row drops out
+   * of every Jacobian. */
+  const int32_t* dof_limit_enforced;
 } nbl_model_desc;
 
 #define NBL_SHAPE_BOX 0

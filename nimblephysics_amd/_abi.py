@@ -74,4 +74,5 @@ class ModelDesc(C.Structure):
         ("penetration_correction", C.c_int32),
         ("body_skeleton", _pi),
         ("pitch", _pd),
+        ("dof_limit_enforced", _pi),
     ]

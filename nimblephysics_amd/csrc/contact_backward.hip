@@ -62,8 +62,9 @@ DEV ContactRec loadContactRec(const LaneMem& SV, const SavedLayout& lay, const D
   R.p = mk3(SV.at(r0 + CR_POINT), SV.at(r0 + CR_POINT + 1), SV.at(r0 + CR_POINT + 2));
   R.nrm = mk3(SV.at(r0 + CR_NORMAL), SV.at(r0 + CR_NORMAL + 1), SV.at(r0 + CR_NORMAL + 2));
   R.type = (int)SV.at(r0 + CR_TYPE);
-  const DevBox& boxA = cm->boxes[(int)SV.at(r0 + CR_BOXA)];
-  const DevBox& boxB = cm->boxes[(int)SV.at(r0 + CR_BOXB)];
+  const int codeA = (int)SV.at(r0 + CR_BOXA), codeB = (int)SV.at(r0 + CR_BOXB);   // (a joint-limit row never reaches the backward pass: its coefficients are zero)
+  const DevBox& boxA = cm->boxes[codeA < MAX_BOXES ? codeA : 0];
+  const DevBox& boxB = cm->boxes[codeB < MAX_BOXES ? codeB : 0];
   R.bA = boxA.body; R.bB = boxB.body;
   R.depth = 0; R.radA = 0; R.radB = 0;
   if (CAPS) { R.depth = SV.at(r0 + CR_DEPTH); R.radA = boxA.half[0]; R.radB = boxB.half[0]; }

@@ -160,9 +160,33 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   // NOTE: the duplicate filter above only sees contacts that were kept; the reference compares against every
   // contact of the total result including ones later dropped by the depth filter.  Those can only coincide
   // with a kept point if they are the same point, which the depth filter treats identically.
+  // ---- joint-limit constraint rows (JointLimitConstraint::update, JointLimitConstraint.cpp:182-237): every limit-enforcing DOF at or
+  //      below its lower / at or above its upper limit is appended as a pseudo-contact after the contacts (ConstraintSolver.cpp:641-696
+  //      pushes the joint-limit constraints after the contact constraints) ----
+  int nLim = 0;
+  for (int k = 0; k < cm->nLimitDofs; k++) {
+    const int d = cm->limitDof[k];
+    const double qd = qFk ? qFk[(int64_t)d * B + b] : svAt(saved, lay.q + d, B, b);
+    double sigma = 0.0;
+    if (qd - cm->limitLo[k] <= 0.0) sigma = 1.0;
+    else if (qd - cm->limitHi[k] >= 0.0) sigma = -1.0;
+    if (sigma == 0.0) continue;
+    if (nC >= cm->maxContacts) { overflow = true; continue; }
+    const int r0 = lay.contacts + nC * CR_SIZE;
+    const int body = cm->limitBody[k];
+    for (int e = 0; e < CR_SIZE; e++) svAt(saved, r0 + e, B, b) = 0.0;
+    svAt(saved, r0 + CR_NORMAL + 1, B, b) = 1.0;                  // (a unit vector: the tangent-basis code runs on every record)
+    svAt(saved, r0 + CR_TYPE, B, b) = (double)CT_LIMIT;
+    svAt(saved, r0 + CR_BOXA, B, b) = (double)(CR_BODY_CODE + 1 + body);
+    svAt(saved, r0 + CR_BOXB, B, b) = (double)(CR_BODY_CODE + 1 + bodies[body].parent);
+    svAt(saved, r0 + CR_EA_FIXED, B, b) = (double)d;
+    svAt(saved, r0 + CR_EA_FIXED + 1, B, b) = sigma;
+    nC++; nLim++;
+  }
   svAt(saved, lay.nc, B, b) = (double)nC + ((qFk && overflow) ? 0.5 : 0.0);
   uint32_t st = 0;
-  if (nC > 0) st |= 0x1u;
+  if (nC - nLim > 0) st |= 0x1u;
+  if (nLim > 0) st |= 0x400u;
   if (overflow) st |= 0x80u;
   (void)edge;
   if (status && !qFk) status[b] |= st;  // the forward tree kernel initialised the word (0, or NBL_ST_NAN for a non-finite unconstrained step)

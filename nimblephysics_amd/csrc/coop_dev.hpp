@@ -526,6 +526,10 @@ struct CoopRow {
   double mu, Bv, colNorm;
   const double* Acol;  // &A[0][lane] (stride MAXR): column (= row, A is symmetric) `lane` of A.  Re-read where needed
                        // instead of being held in 48 VGPRs across the factorisations (it stays in L2).
+  // joint-limit rows (model_dev.hpp, CT_LIMIT; only the general - MULTI - instantiation of the contact kernels sets these): this lane's row
+  // is one / it is carried negated (upper limit) / the limit rows of the world (uniform)
+  bool lim = false, neg = false;
+  uint32_t limMask = 0u;
   bool on;             // this lane's row exists in the problem being solved: lane < m and, where a world has several
                        // constrained groups, its row belongs to the group at hand (rows that are off are inert everywhere)
   DEV double a(int i) const { return (on && i < m) ? Acol[i * MAXR] : 0.0; }
@@ -653,6 +657,10 @@ DEV void coopBuildQ(const W& w, CoopLds& S, const CoopRow& R, const CoopClasses&
   for (int i = 0; i < MAXR; i++) {
     double q = R.a(Ac, i);
     if (K.nu > 0) q = fma(e2, S.R[i * CLD + c2], fma(e1, S.R[i * CLD + c1], q));
+    // The reference forms Q = A_c^T M^-1 (A_c + A_ub E) from constraint-force columns when a friction row sits on its bound, and a
+    // joint-limit constraint has none (a DifferentiableContactConstraint without a contact: zero world force, DCC.cpp:51-99): its row
+    // and column of Q are zero.  (Without upper-bound rows Q is the clamping block of A itself, CGGM.cpp:256-266, couplings included.)
+    if (K.nu > 0 && (R.lim || ((R.limMask >> i) & 1u))) q = 0.0;
     if (i == ln) q += cfm;
     a[i] = (colOn && ((K.clampMask >> i) & 1u)) ? q : 0.0;
   }
@@ -729,7 +737,9 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
   bool pinvValid = false;
   if (haveCache) X = R.on ? Xcache : 0.0;
   else {
-    const bool in = R.on && (R.fric ? R.mu != 0.0 : R.Bv > 0);   // (the empty tangent rows of frictionless contacts are not rows of the reference's problem)
+    // (the empty tangent rows of frictionless contacts are not rows of the reference's problem; a negated joint-limit row: the reference
+    // tests ITS b > 0)
+    const bool in = R.on && (R.fric ? R.mu != 0.0 : (R.neg ? R.Bv < 0 : R.Bv > 0));
     guessMask = (uint32_t)w.ballot(in);
     if (guessMask != 0) {
       double a[MAXR];

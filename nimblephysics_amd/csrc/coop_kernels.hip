@@ -21,6 +21,7 @@ constexpr int LW_FAILMASK = LW_STAGE_FLAGS + 3 * MAX_CONTACTS;   // bit g: const
 constexpr int LW_STAGE_CYCLES = LW_FAILMASK + 1;        // NBL_CASCADE_TIMING: cycles of the stage waves and of the final kernel
 static_assert(LW_STAGE_CYCLES + 4 <= LW_TOTAL, "stage results must fit the contact scratch rows");
 
+template <bool LIM = false>
 DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved, const double* __restrict__ dn,
                      const SavedLayout& lay, const DevContactModel* __restrict__ cm, int64_t B, int64_t b) {
   R.m = m;
@@ -30,12 +31,15 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
   const bool on = ln < m;
   if (on) {
     const int r0 = lay.contacts + (ln / 3) * CR_SIZE;
-    const double muA = cm->boxes[(int)saved[(int64_t)(r0 + CR_BOXA) * B + b]].mu, muB = cm->boxes[(int)saved[(int64_t)(r0 + CR_BOXB) * B + b]].mu;
+    const int cA = (int)saved[(int64_t)(r0 + CR_BOXA) * B + b], cB = (int)saved[(int64_t)(r0 + CR_BOXB) * B + b];
+    const double muA = LIM ? crMuOf(cm, cA) : cm->boxes[cA].mu, muB = LIM ? crMuOf(cm, cB) : cm->boxes[cB].mu;
+    if (LIM && cA >= CR_BODY_CODE) { R.lim = (ln % 3) == 0; R.neg = R.lim && saved[(int64_t)(r0 + CR_EA_FIXED + 1) * B + b] < 0.0; }
     R.mu = muA < muB ? muA : muB;
     if (!(R.mu > 1e-3)) R.mu = 0.0;   // frictionless contact: its tangent rows are empty (k_contact_rows_coop) and pinned to 0
     R.Bv = saved[(int64_t)(lay.b + ln) * B + b];
   }
   R.on = on;
+  if (LIM) R.limMask = (uint32_t)__ballot(R.lim ? 1 : 0);
   R.Acol = dn + lay.A + (on ? ln : 0);
   double cn = 0.0, cn1 = 0.0;
 #pragma unroll 1
@@ -59,7 +63,7 @@ DEV int coopGroups(const W& w, const DevContactModel* __restrict__ cm, const dou
   if (ln < nC) {
     const int r0 = lay.contacts + ln * CR_SIZE;
     const int bxA = (int)saved[(int64_t)(r0 + CR_BOXA) * B + b], bxB = (int)saved[(int64_t)(r0 + CR_BOXB) * B + b];
-    const int bA = cm->boxes[bxA].body, bB = cm->boxes[bxB].body;
+    const int bA = crBodyOf(cm, bxA), bB = crBodyOf(cm, bxB);   // (a joint-limit row: child and parent body of its joint, one skeleton)
     const int sA = bA >= 0 ? cm->skelOf[bA] : -1, sB = bB >= 0 ? cm->skelOf[bB] : -1;
     u = sA >= 0 ? sA : sB;
     v = (sA >= 0 && sB >= 0) ? sB : u;
@@ -87,14 +91,35 @@ DEV int coopGroups(const W& w, const DevContactModel* __restrict__ cm, const dou
 
 // x, classes, cfm, warm start, v' = v_pre + M^-1 J^T x and (when valid) the pseudo-inverse of the final Q -> saved record
 template <class W>
-DEV uint32_t coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValid,
+DEV uint32_t coopContactOutputs(const W& w, CoopLds& S, const CoopRow& R, int n, int m, double X, const CoopClasses& K, double cfm, bool pinvValidIn,
                             double* __restrict__ saved, const SavedLayout& lay, double* __restrict__ dn,
                             double* __restrict__ cacheOut, double* __restrict__ nv, int64_t B, int64_t b) {
   const int ln = w.lane();
+  // Joint-limit rows: the reference's backward pass gives them a zero constraint-force column (model_dev.hpp), which takes them out of
+  // every Jacobian: the record classifies them "not clamping", and a Q^+ that couples them to the contacts is not the backward pass's.
+  // The warm-start cache carries the reference's sign of a negated (upper-limit) row.
+  bool pinvValid = pinvValidIn;
+  if ((K.clampMask & R.limMask) != 0u) {   // (uniform; never taken by the instantiation without joint-limit rows)
+    CoopClasses Kb = K;
+    if (R.lim) Kb.cls = RC_NOT_CLAMPING;
+    Kb.clampMask &= ~R.limMask;
+    Kb.nc = __builtin_popcount(Kb.clampMask);
+    if (Kb.nc > 0) {
+      double a[MAXR];
+      coopBuildQ(w, S, R, Kb, cfm, a);
+      coopPinvOfQ(w, a, S, Kb);
+    } else if (ln < MAXR) {
+#pragma unroll 1
+      for (int i = 0; i < MAXR; i++) S.P[i * CLD + ln] = 0.0;
+    }
+    w.sync();
+    pinvValid = true;
+  }
   if (ln < MAX_ROWS) {
     svAt(saved, lay.x + ln, B, b) = X;
-    svAt(saved, lay.cls + ln, B, b) = K.cls == RC_UPPER_BOUND ? (K.E > 0 ? 2.0 : -2.0) : (double)K.cls;
-    if (cacheOut) cacheOut[(int64_t)ln * B + b] = X;
+    // (3: a joint-limit row that was clamping - "not clamping" to every reader, k_bwd_contact_a_coop looks at it for the precise-inverse switch)
+    svAt(saved, lay.cls + ln, B, b) = R.lim ? (K.cls == RC_CLAMPING ? 3.0 : 0.0) : (K.cls == RC_UPPER_BOUND ? (K.E > 0 ? 2.0 : -2.0) : (double)K.cls);
+    if (cacheOut) cacheOut[(int64_t)ln * B + b] = R.neg ? -X : X;
   }
   if (ln == MAX_ROWS && cacheOut) cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
   if (ln < MAX_ROWS) svAt(saved, lay.cfm + ln, B, b) = cfm;     // this row's constant (its group's, CFM_CONSTANTS)
@@ -115,7 +140,13 @@ DEV uint32_t coopContactOutputs(const W& w, CoopLds& S, int n, int m, double X, 
       }
     }
     wd += wd1;
-    svAt(saved, lay.w + ln, B, b) = wd;
+    // the record's velocity change is the backward pass's: without the joint-limit impulses, which the reference's Jacobians do not know
+    double wdLim = 0.0;
+    for (uint32_t lm = R.limMask; lm != 0u; lm &= lm - 1u) {
+      const int r = __builtin_ctz(lm);
+      wdLim = fma(dn[lay.massed + ln * MAX_ROWS + r], S.vec[2][r], wdLim);
+    }
+    svAt(saved, lay.w + ln, B, b) = wd - wdLim;
     vNext = svAt(saved, lay.vpre + ln, B, b) + wd;
     nv[(int64_t)ln * B + b] = vNext;
   }
@@ -150,7 +181,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   const int m = 3 * nC;
   // the narrow phase that runs NEXT TO the forward tree kernel (k_forward_detect_coop) leaves the status word to this kernel: contacts
   // present, contacts dropped (count + 0.5).  Idempotent after the stand-alone narrow phase, which sets the bits itself.
-  if (ln == 0 && status) status[b] |= (nC > 0 ? 0x1u : 0u) | (ncD - (double)nC > 0.25 ? 0x80u : 0u);
+  if (ln == 0 && status) status[b] |= ((!MULTI && nC > 0) ? 0x1u : 0u) | (ncD - (double)nC > 0.25 ? 0x80u : 0u);
   double* nv = next + (int64_t)n * B;
   double* dn = denseOf(saved, lay, B, b);
   if (m == 0) {
@@ -162,10 +193,14 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
     return;
   }
   CoopRow R;
-  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  coopLoadRow<MULTI>(R, ln, m, saved, dn, lay, cm, B, b);
   NBL_PHASE(41);
+  if (MULTI && ln == 0 && status) {   // (joint-limit rows are pseudo-contacts of the record: NBL_ST_CONTACT counts the real ones)
+    const int nLim = __builtin_popcount(R.limMask);
+    status[b] |= (nC - nLim > 0 ? 0x1u : 0u) | (nLim > 0 ? 0x400u : 0u);
+  }
   const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
-  const double Xcache = (haveCache && ln < m) ? cacheIn[(int64_t)ln * B + b] : 0.0;
+  const double Xcache = (haveCache && ln < m) ? (R.neg ? -1.0 : 1.0) * cacheIn[(int64_t)ln * B + b] : 0.0;
   NBL_PHASE(42);
   int gid = 0;
   const int nGroups = MULTI ? coopGroups(w, cm, saved, lay, B, b, m, gid) : 1;
@@ -173,7 +208,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
     CoopStage0 out;
     coopStage0(w, S, R, haveCache, Xcache, out);
     if (out.ok) {
-      const uint32_t nanBit = coopContactOutputs(w, S, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+      const uint32_t nanBit = coopContactOutputs(w, S, R, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
       if (ln == 0 && status) status[b] |= 0x2u | 0x100u | nanBit;
       NBL_PHASE(47);
     } else {
@@ -208,7 +243,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
       coopPinvOfQ(w, a, S, K);
       pinvValid = true;
     }
-    const uint32_t nanBit = coopContactOutputs(w, S, n, m, X, K, 0.0, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+    const uint32_t nanBit = coopContactOutputs(w, S, R, n, m, X, K, 0.0, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
     if (ln == 0 && status) status[b] |= 0x2u | 0x100u | nanBit;
   } else {
     // rows of resolved groups: their result (x, class) waits in the scratch rows for k_contact_cascade_final
@@ -247,7 +282,7 @@ __global__ __launch_bounds__(128) NBL_WAVES(NBL_W_STAGES) void k_contact_cascade
   const int m = 3 * (int)svAt(saved, lay.nc, B, b);
   double* dn = denseOf(saved, lay, B, b);
   CoopRow R;
-  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  coopLoadRow<MULTI>(R, ln, m, saved, dn, lay, cm, B, b);
   const double X0 = ln < m ? lws[(int64_t)(LW_X0 + ln) * B + b] : 0.0;
   // the constrained groups stage 0 left unresolved, one after the other (almost always: the world's only group)
   const uint32_t failMask = MULTI ? (uint32_t)lws[(int64_t)LW_FAILMASK * B + b] : 1u;
@@ -305,7 +340,7 @@ DEV void coopCascadeFinish(const W& w, CoopLds& S, const DevModel& mdl, const De
   const int row = ln < MAX_ROWS ? ln : 0;
   const double X0 = ln < m ? lws[(int64_t)(LW_X0 + ln) * B + b] : 0.0;
   CoopRow R;
-  coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+  coopLoadRow<MULTI>(R, ln, m, saved, dn, lay, cm, B, b);
   const uint32_t failMask = MULTI ? (uint32_t)lws[(int64_t)LW_FAILMASK * B + b] : 1u;
   int gid = 0;
   const int nGroups = MULTI ? coopGroups(w, cm, saved, lay, B, b, m, gid) : 1;
@@ -353,7 +388,7 @@ DEV void coopCascadeFinish(const W& w, CoopLds& S, const DevModel& mdl, const De
     coopPinvOfQ(w, a, S, K);
     pinvValid = true;
   }
-  const uint32_t nanBit = coopContactOutputs(w, S, n, m, X, K, cfmRow, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
+  const uint32_t nanBit = coopContactOutputs(w, S, R, n, m, X, K, cfmRow, pinvValid, saved, lay, dn, cacheOut, nv, B, b);
   if (ln == 0 && status) status[b] |= st | nanBit;
 }
 
@@ -414,7 +449,7 @@ __global__ __launch_bounds__(128) NBL_WAVES(2) void k_contact_cascade_fused(DevM
     const int m = 3 * (int)svAt(saved, lay.nc, B, b);
     double* dn = denseOf(saved, lay, B, b);
     CoopRow R;
-    coopLoadRow(R, ln, m, saved, dn, lay, cm, B, b);
+    coopLoadRow<MULTI>(R, ln, m, saved, dn, lay, cm, B, b);
     const double X0 = ln < m ? lws[(int64_t)(LW_X0 + ln) * B + b] : 0.0;
     const uint32_t failMask = MULTI ? (uint32_t)lws[(int64_t)LW_FAILMASK * B + b] : 1u;
     int gid = 0;
@@ -694,6 +729,9 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
       for (int k = 0; k < 8; k++) imp2 += S.vec[0][kb + k];
     }
     precise = imp2 < 1e-18;
+    // A clamping joint-limit row is a zero row and column of the reference's Q = A_c^T M^-1 A_c (no constraint-force column), with its
+    // group's CFM constant on the diagonal: without one Q is singular, ||I - Q Q^+||^2 >= 1 and the reference takes the full derivative
+    if (w.ballot(rowOn && cvRaw == 3.0 && cfmRaw == 0.0) != 0ull) precise = false;
     w.sync();
   }
   // (scheduling fences between the six 24 x 24 products: each reads 48 LDS values; left alone the scheduler issues the loads of all of them
@@ -946,6 +984,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   const V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
   const V3 nrm = mk3(svAt(saved, r0 + CR_NORMAL, B, b), svAt(saved, r0 + CR_NORMAL + 1, B, b), svAt(saved, r0 + CR_NORMAL + 2, B, b));
   const int bxA = (int)svAt(saved, r0 + CR_BOXA, B, b), bxB = (int)svAt(saved, r0 + CR_BOXB, B, b);
+  const bool isLim = (int)svAt(saved, r0 + CR_TYPE, B, b) == CT_LIMIT;   // a joint-limit row (model_dev.hpp): unit impulse on a DOF
+  const double limSigma = svAt(saved, r0 + CR_EA_FIXED + 1, B, b);
   const int nC = (int)ncD;
   const int m = 3 * nC;
   if (m == 0) return;
@@ -983,14 +1023,28 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   // rows are EMPTY: zero wrench -> zero row / column of A, b = 0, zero A_c column, bounds 0.  Every stage leaves such rows at
   // x = 0 and they add exact zeros to the sums of the other rows, so the result equals the reference's one-row problem.
   // (rows beyond the contacts in use read stale record slots: clamp the collider indices before using them as addresses)
-  const double muRow = fmin(cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].mu, cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].mu);
+  const double muRow = isLim ? 0.0 : fmin(cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].mu, cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].mu);
   const V3 dirOn = kk == 0 ? nrm : (kk == 1 ? t1 : t2);
   const V3 dir = (kk != 0 && !(muRow > 1e-3)) ? mk3(0.0, 0.0, 0.0) : dirOn;
-  const int bA = w.shflI(myBoxBody, bxA), bB = w.shflI(myBoxBody, bxB);
+  const int bAc = w.shflI(myBoxBody, bxA), bBc = w.shflI(myBoxBody, bxB);
+  const int bA = isLim ? bxA - CR_BODY_CODE - 1 : bAc, bB = isLim ? bxB - CR_BODY_CODE - 1 : bBc;
   // wrench of a unit impulse along dir at p (on A; minus it on B), about the origin of A's tree and about the origin of B's
   const V3 oA = mk3(w.shfl(myOrigin.x, bA < 0 ? 0 : bA), w.shfl(myOrigin.y, bA < 0 ? 0 : bA), w.shfl(myOrigin.z, bA < 0 ? 0 : bA));
   const V3 oB = mk3(w.shfl(myOrigin.x, bB < 0 ? 0 : bB), w.shfl(myOrigin.y, bB < 0 ? 0 : bB), w.shfl(myOrigin.z, bB < 0 ? 0 : bB));
-  const V6 F = mk6(cross(p - oA, dir), dir), FB = mk6(cross(p - oB, dir), dir);
+  V6 F = mk6(cross(p - oA, dir), dir), FB = mk6(cross(p - oB, dir), dir);
+  if (cm->nLimitDofs > 0) {
+    // joint-limit row: the generalized unit impulse sigma e_d is the wrench pair (+F on the joint's child body, -F on its parent) with
+    // S_d . F = sigma, F = sigma S_d / |S_d|^2 (S_d the joint's world-frame axis; child and parent share their tree's origin): the
+    // relative velocity F . (V_child - V_parent) is sigma qdot_d, the response F . (dV_child - dV_parent) is sigma d(qdot_d), and above
+    // the parent the two wrenches cancel.  (JointLimitConstraint::applyUnitImpulse / getVelocityChange, JointLimitConstraint.cpp:293-349)
+    w.sync();                                           // Sw of the prologue
+    if (isLim) {
+      const V6 Sd = ld6(Sw + 6 * (on ? bA : 0));
+      const double s2 = dot(Sd, Sd);
+      F = kk == 0 ? (limSigma / s2) * Sd : zero6();
+      FB = F;
+    }
+  }
   const int ancLoA = w.shflI((int)(uint32_t)myAnc, bA), ancHiA = w.shflI((int)(uint32_t)(myAnc >> 32), bA);
   const int ancLoB = w.shflI((int)(uint32_t)myAnc, bB), ancHiB = w.shflI((int)(uint32_t)(myAnc >> 32), bB);
   const uint64_t mA = bA >= 0 ? ((uint64_t)(uint32_t)ancHiA << 32) | (uint32_t)ancLoA : 0ull;
@@ -1013,13 +1067,13 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
       // restitution one capped at 100.  The coefficient of the contacts that bounced (ContactConstraint::getCoefficientOfRestitution,
       // 0 otherwise) goes to the record for the backward pass.
       double bouncing = 0.0;
-      if (cm->penetrationCorrection) {
+      if (cm->penetrationCorrection && !isLim) {
         double bv = svAt(saved, r0 + CR_DEPTH, B, b) - 0.0;
         if (bv < 0.0) bv = 0.0;
         else { bv *= 0.01 * (1.0 / mdl.dt); if (bv > 1e-3) bv = 1e-3; }
         bouncing = bv;
       }
-      const double eR = cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].restitution * cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].restitution;
+      const double eR = isLim ? 0.0 : cm->boxes[(unsigned)bxA < (unsigned)MAX_BOXES ? bxA : 0].restitution * cm->boxes[(unsigned)bxB < (unsigned)MAX_BOXES ? bxB : 0].restitution;
       double coeff = 0.0;
       if (eR > 1e-3) {
         const double rv = rel * eR;
@@ -1158,8 +1212,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
   }
   if (ln < nC) {
     const int q0 = lay.contacts + ln * CR_SIZE;
-    cbody[ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXA, B, b)].body;
-    cbody[MAX_CONTACTS + ln] = cm->boxes[(int)svAt(saved, q0 + CR_BOXB, B, b)].body;
+    cbody[ln] = crBodyOf(cm, (int)svAt(saved, q0 + CR_BOXA, B, b));
+    cbody[MAX_CONTACTS + ln] = crBodyOf(cm, (int)svAt(saved, q0 + CR_BOXB, B, b));
   }
   for (int idx = ln; idx < nb * 54; idx += 64) D[idx] = 0.0;
   w.sync();

@@ -120,6 +120,7 @@ constexpr int MAX_CONTACTS = 8;              // per world (8 frictional contacts
 constexpr int MAX_ROWS = 3 * MAX_CONTACTS;
 constexpr int MAX_BOXES = 16;
 constexpr int MAX_PAIRS = 32;
+constexpr int MAX_DOF_CONTACT = 40;
 
 constexpr int SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CAPSULE = 2;   // NBL_SHAPE_*
 struct DevBox {       // a collider: box (half extents), sphere (radius in half[0]) or capsule (radius in half[0], half the cylinder height in half[1])
@@ -137,7 +138,19 @@ struct DevContactModel {
   DevBox boxes[MAX_BOXES];
   uint64_t ancestors[64];   // bit i of ancestors[b]: body i is b or an ancestor of b
   int32_t skelOf[64];       // per body: its skeleton (constrained groups unite skeletons, ConstraintSolver.cpp:724-780); < 64
+  // joint-limit constraint rows (JointLimitConstraint.cpp; nbl_model_desc.dof_limit_enforced): the single-DOF joints that enforce a finite
+  // position limit.  An active one becomes a pseudo-contact of the record (CT_LIMIT) after the world's contacts
+  int32_t nLimitDofs, padL;
+  int32_t limitDof[MAX_DOF_CONTACT], limitBody[MAX_DOF_CONTACT];
+  double limitLo[MAX_DOF_CONTACT], limitHi[MAX_DOF_CONTACT];
 };
+// A joint-limit row in the contact record: type CT_LIMIT, the two "colliders" are the codes CR_BODY_CODE + 1 + body of the joint's child
+// body (A) and of its parent body (B; world = -1), CR_EA_FIXED = (DOF, sigma, 0).  sigma = +1 at the lower limit; at the upper limit the
+// row is carried NEGATED (sigma = -1: x' = -x >= 0, row and column of A and b negated - exact in IEEE arithmetic) so that every stage sees
+// a frictionless normal row with bounds [0, inf); the warm-start cache and LCPUtils::guessSolution's `b > 0` use the reference's sign.
+constexpr int CT_LIMIT = 30, CR_BODY_CODE = 64;
+__device__ __forceinline__ int crBodyOf(const DevContactModel* __restrict__ cm, int code) { return code >= CR_BODY_CODE ? code - CR_BODY_CODE - 1 : cm->boxes[code].body; }
+__device__ __forceinline__ double crMuOf(const DevContactModel* __restrict__ cm, int code) { return code >= CR_BODY_CODE ? 0.0 : cm->boxes[code].mu; }
 
 // Per-contact record kept in the saved-for-backward buffer (doubles per world)
 constexpr int CR_POINT = 0, CR_NORMAL = 3, CR_DEPTH = 6, CR_TYPE = 7, CR_BOXA = 8, CR_BOXB = 9;
@@ -162,7 +175,6 @@ constexpr int LW_JA = 0;                               // MAX_ROWS x 6 body-fram
 constexpr int LW_JB = LW_JA + MAX_ROWS * 6;            // same for body B
 constexpr int LW_TOTAL = LW_JB + MAX_ROWS * 6;         // (the per-world factorisations live in LDS, not here)
 // contact backward scratch
-constexpr int MAX_DOF_CONTACT = 40;
 constexpr int LCP_LANES = 16;                             // worlds per workgroup in the LDS-staged dense kernels
 constexpr int LCP_LDS_BYTES = 2 * MAX_ROWS * MAX_ROWS * 8 * LCP_LANES;
 constexpr int LB_LAM1 = LW_TOTAL;                          // lambda1 = M^-1 g

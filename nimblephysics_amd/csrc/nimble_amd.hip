@@ -366,14 +366,30 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   // ---- contact model: box colliders, candidate pairs (CollisionFilter.cpp:105-154), ancestor masks ----
   DevContactModel hc;
   std::memset(&hc, 0, sizeof(hc));
-  bool hasContact = d->n_boxes > 0 && d->max_contacts > 0;
-  bool multiGroupModel = false;
+  // joint-limit constraint rows (dof_limit_enforced): the single-DOF joints with a finite limit to enforce
+  std::vector<int> limitDofs;
+  if (d->dof_limit_enforced)
+    for (int i = 0; i < d->n_bodies; i++) {
+      const int jt = d->joint_type[i];
+      if (jt != NBL_JOINT_REVOLUTE && jt != NBL_JOINT_PRISMATIC && jt != NBL_JOINT_SCREW) continue;
+      const int j = d->dof_offset[i];
+      if (d->dof_limit_enforced[j] && (std::isfinite(hd[j].posLo) || std::isfinite(hd[j].posHi))) limitDofs.push_back(i);
+    }
+  if (!limitDofs.empty() && d->max_contacts <= 0)
+    return fail(NBL_E_BADARG, "dof_limit_enforced needs max_contacts > 0: a joint-limit row takes one contact slot of the LCP");
+  bool hasContact = (d->n_boxes > 0 || !limitDofs.empty()) && d->max_contacts > 0;
+  bool multiGroupModel = !limitDofs.empty();   // the general instantiation of the contact kernels carries the joint-limit rows
   if (hasContact) {
     if (d->n_boxes > MAX_BOXES) return fail(NBL_E_UNSUPPORTED, "too many box colliders for the device path");
     if (d->max_contacts > MAX_CONTACTS) return fail(NBL_E_UNSUPPORTED, "max_contacts above 8 is not supported by the device path yet");
     if (d->n_bodies > 64) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 64 bodies");
     if (d->n_dofs > MAX_DOF_CONTACT) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 40 DOFs");
     hc.nBoxes = d->n_boxes;
+    hc.nLimitDofs = (int)limitDofs.size();
+    for (int k = 0; k < hc.nLimitDofs; k++) {
+      const int body = limitDofs[k], j = d->dof_offset[body];
+      hc.limitDof[k] = j; hc.limitBody[k] = body; hc.limitLo[k] = hd[j].posLo; hc.limitHi[k] = hd[j].posHi;
+    }
     hc.maxContacts = d->max_contacts;
     hc.clippingDepth = d->contact_clipping_depth;
     hc.fallbackCfm = d->fallback_cfm;

@@ -93,7 +93,9 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
                             vel_lo=tuple(_limit(j.getVelocityLowerLimit(k), True) for k in range(nd)),
                             vel_hi=tuple(_limit(j.getVelocityUpperLimit(k), False) for k in range(nd)),
                             force_lo=tuple(_limit(j.getControlForceLowerLimit(k), True) for k in range(nd)),
-                            force_hi=tuple(_limit(j.getControlForceUpperLimit(k), False) for k in range(nd)))
+                            force_hi=tuple(_limit(j.getControlForceUpperLimit(k), False) for k in range(nd)),
+                            # Joint::isPositionLimitEnforced (python/_nimblephysics/dynamics/Joint.cpp:202): joint-limit LCP rows
+                            limit_enforced=bool(j.isPositionLimitEnforced()) if hasattr(j, "isPositionLimitEnforced") else False)
             if jt in _COMPOUND_TYPES:
                 # expanded into 1-DOF chains by ModelDescription (model.py); only the axes differ per class
                 kw = per_dof()

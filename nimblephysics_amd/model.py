@@ -92,6 +92,7 @@ class BodySpec:
     friction: float = 1.0  # BodyNodeAspect.hpp:47
     axes: Sequence[Sequence[float]] = ()   # compound joints with free axes (universal: 2, translational2d: 2, planar: 2 in-plane axes)
     beta: Sequence[float] = (1.0, 1.0, 1.0)   # BodyNode::mBeta (BodyNode.cpp:1301 ctor default ones): the COM moves along beta under an INERTIA_COM_MU mass entry
+    limit_enforced: bool = False   # Joint::isPositionLimitEnforced (JointAspect.hpp:165: off by default): the joint's position limits become LCP rows
     skeleton: int = -1   # index of the dart Skeleton the body belongs to; -1 (every body of the model) = one skeleton per tree
     pitch: float = 0.1   # screw joints: translation along the axis per turn (ScrewJoint::mPitch, default 0.1)
 
@@ -161,7 +162,7 @@ def expand_compound_joints(bodies, boxes):
                 mass=b.mass if last else 0.0, com=tuple(b.com) if last else (0.0, 0.0, 0.0),
                 inertia=tuple(b.inertia) if last else (0.0,) * 6,
                 **{key: dof(getattr(b, key), i) for key in ("damping", "spring", "rest", "pos_lo", "pos_hi", "vel_lo", "vel_hi", "force_lo", "force_hi")},
-                friction=b.friction, beta=tuple(b.beta) if last else (1.0, 1.0, 1.0), skeleton=b.skeleton)
+                friction=b.friction, beta=tuple(b.beta) if last else (1.0, 1.0, 1.0), limit_enforced=b.limit_enforced, skeleton=b.skeleton)
             parent = len(out)
             out.append(nb)
         where.append(len(out) - 1)
@@ -371,7 +372,7 @@ class ModelDescription:
             "parent": np.zeros(nb, np.int32), "joint_type": np.zeros(nb, np.int32), "dof_offset": np.zeros(nb, np.int32),
             "T_pj": np.zeros((nb, 12)), "T_cj": np.zeros((nb, 12)), "axis": np.zeros((nb, 3)), "mass": np.zeros(nb),
             "com": np.zeros((nb, 3)), "inertia": np.zeros((nb, 6)),
-            "damping": np.zeros(n), "spring": np.zeros(n), "rest": np.zeros(n),
+            "damping": np.zeros(n), "spring": np.zeros(n), "rest": np.zeros(n), "dof_limit_enforced": np.zeros(n, np.int32),
             "pos_lo": np.full(n, -inf), "pos_hi": np.full(n, inf), "vel_lo": np.full(n, -inf), "vel_hi": np.full(n, inf),
             "force_lo": np.full(n, -inf), "force_hi": np.full(n, inf),
         }
@@ -396,6 +397,7 @@ class ModelDescription:
                     if len(vals) != nd:
                         raise ValueError(f"body {b.name}: {key} has {len(vals)} entries, joint has {nd} dofs")
                     a[key][off:off + nd] = vals
+            a["dof_limit_enforced"][off:off + nd] = 1 if b.limit_enforced else 0
             off += nd
         nbx = len(self.boxes)
         # capsule-box pairs run libccd's MPR in the reference (DARTCollide.cpp:4422-4645), an iterative third-party algorithm outside the
@@ -442,7 +444,7 @@ class ModelDescription:
         def pi(x):
             return x.ctypes.data_as(C.POINTER(C.c_int32))
 
-        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape", "body_skeleton"):
+        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape", "body_skeleton", "dof_limit_enforced"):
             setattr(d, k, pi(a[k]))
         for k in ("T_pj", "T_cj", "axis", "mass", "com", "inertia", "damping", "spring", "rest", "pos_lo", "pos_hi",
                   "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu", "box_restitution", "pitch"):
@@ -451,7 +453,8 @@ class ModelDescription:
         d.dt = self.dt
         d.n_action = len(a["action_map"])
         d.n_boxes = len(self.boxes)
-        d.max_contacts = self.max_contacts
+        # (a joint-limit row takes one of the contact slots of the LCP: a model without colliders that enforces limits still needs them)
+        d.max_contacts = self.max_contacts or (8 if any(b.limit_enforced for b in self.bodies) else 0)
         d.contact_clipping_depth = self.contact_clipping_depth
         d.fallback_cfm = self.fallback_cfm
         d.penetration_correction = 1 if self.penetration_correction else 0
@@ -461,7 +464,7 @@ class ModelDescription:
     def to_json(self) -> dict:
         def body(b: BodySpec):
             d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()
-                 if k != "axes" and not (k == "skeleton" and v < 0) and not (k == "beta" and tuple(v) == (1.0, 1.0, 1.0)) and not (k == "pitch" and b.joint_type != "screw")}   # compound joints are already expanded: every stored joint has its single `axis`
+                 if k != "axes" and not (k == "skeleton" and v < 0) and not (k == "beta" and tuple(v) == (1.0, 1.0, 1.0)) and not (k == "limit_enforced" and not v) and not (k == "pitch" and b.joint_type != "screw")}   # compound joints are already expanded: every stored joint has its single `axis`
             return d
         return {
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,

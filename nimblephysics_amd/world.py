@@ -135,6 +135,24 @@ class World:
     def getPenetrationCorrectionEnabled(self) -> bool:
         return self.description.penetration_correction
 
+    def setPositionLimitEnforced(self, enforced: bool, joints=None):
+        """Joint::setPositionLimitEnforced (Joint.cpp:1366) on the named joints / bodies (default: every joint): their position limits
+        become rows of the contact LCP (JointLimitConstraint.cpp).  Off by default, like in the reference (JointAspect.hpp:165)."""
+        changed = False
+        for md in {id(self.description): self.description, id(self.model): self.model}.values():
+            for b in md.bodies:
+                if joints is None or b.joint_name in joints or b.name in joints:
+                    if b.limit_enforced != bool(enforced):
+                        b.limit_enforced = bool(enforced)
+                        changed = True
+        if changed:
+            self._create_handle()
+            if self._wrt_mass.entries:
+                self._push_inertia_params()
+
+    def getPositionLimitEnforced(self):
+        return {b.joint_name or b.name: bool(b.limit_enforced) for b in self.description.bodies}
+
     def removeDofFromActionSpace(self, index: int):
         self.setActionSpace([a for a in self.getActionSpace() if a != index])
 

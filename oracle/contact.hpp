@@ -20,7 +20,8 @@ enum RowClass { RC_NOT_CLAMPING = 0, RC_CLAMPING = 1, RC_UPPER_BOUND = 2, RC_ILL
 
 struct ContactResult {
   std::vector<Contact> contacts;   // active contact constraints, in LCP order
-  std::vector<int> rowContact, rowDir;  // LCP row -> (contact, 0 = normal / 1,2 = tangents)
+  std::vector<int> rowContact, rowDir;  // LCP row -> (contact, 0 = normal / 1,2 = tangents); rowContact = -1: a joint-limit row
+  std::vector<int> rowDof;              // joint-limit rows (JointLimitConstraint): the DOF, -1 on contact rows
   std::vector<int> contactOffset;  // first row of each contact
   std::vector<Vec6> JA, JB;        // per row: ContactConstraint::mSpatialNormalA/B columns (body frames)
   std::vector<Vec3> dirs;          // per row: world force direction
@@ -268,8 +269,17 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
                           const s_t* vPre, VecX& lcpCache, ContactResult& out, s_t* vOut, uint32_t* status) {
   out = ContactResult();
   *status = 0;
-  if (m.boxes.empty()) return;
   const int n = m.n;
+  // ---- joint-limit constraints (ConstraintSolver.cpp:641-696, JointLimitConstraint::update :182-237): a DOF of a joint that
+  //      enforces its limits, at or below its lower / at or above its upper limit, is one LCP row after the contact rows ----
+  std::vector<int> limDof, limSide;                              // side: -1 lower limit active, +1 upper
+  for (int d = 0; d < n; d++) {
+    if (!m.limitEnforced[d]) continue;
+    if (q[d] - m.posLo[d] <= 0.0) { limDof.push_back(d); limSide.push_back(-1); }
+    else if (q[d] - m.posHi[d] >= 0.0) { limDof.push_back(d); limSide.push_back(+1); }
+  }
+  const int L = (int)limDof.size();
+  if (m.boxes.empty() && L == 0) return;
   // ---- collision detection at q_t, filter by penetration depth (ConstraintSolver.cpp:563-613) ----
   std::vector<Contact> all;
   collideAll(m, kin, all);
@@ -280,11 +290,13 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     out.contacts.push_back(c);
   }
   const int C = (int)out.contacts.size();
-  if (C == 0) return;
-  *status |= NBL_ST_CONTACT;
+  if (C == 0 && L == 0) return;
+  if (C > 0) *status |= NBL_ST_CONTACT;
+  if (L > 0) *status |= NBL_ST_JOINT_LIMIT;
   // The reference has no contact cap; the device path keeps max_contacts and flags the world.  The oracle solves with all of
   // them (like the reference) and raises the same flag, so that a comparison knows which worlds the device truncated.
-  if (m.maxContacts > 0 && C > m.maxContacts) *status |= 0x80u;   // NBL_ST_CONTACT_OVERFLOW
+  // (a joint-limit row takes one contact slot of the device)
+  if (m.maxContacts > 0 && C + L > m.maxContacts) *status |= 0x80u;   // NBL_ST_CONTACT_OVERFLOW
 
   // body velocities at the post-ABA, pre-contact velocity (ContactConstraint::getRelVelocity)
   std::vector<Kin> kinPre;
@@ -321,23 +333,39 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
       out.JB.push_back(jb);
     }
   }
+  out.rowDof.assign(out.rowContact.size(), -1);
+  const int contactRows = (int)out.rowContact.size();
+  for (int l = 0; l < L; l++) {
+    out.rowContact.push_back(-1); out.rowDir.push_back(0); out.rowDof.push_back(limDof[l]);
+    out.dirs.push_back(mk3(0, 0, 0)); out.JA.push_back(zero6()); out.JB.push_back(zero6());
+  }
+  std::vector<int> dofBodyOf(n, -1);
+  for (int bi = 0; bi < m.nb; bi++) for (int k = 0; k < m.bodies[bi].ndof; k++) dofBodyOf[m.bodies[bi].dofOff + k] = bi;
   const int mrows = (int)out.rowContact.size();
   out.m = mrows;
   out.A = MatX(mrows, mrows);
   out.b.assign(mrows, 0.0); out.lo.assign(mrows, 0.0); out.hi.assign(mrows, 0.0);
-  out.restCoeff.clear();
+  out.restCoeff.assign(mrows, 0.0);
   out.findex.assign(mrows, -1);
   out.massed = MatX(n, mrows);
   out.Aall = MatX(n, mrows);
 
   // ---- getInformation: b, lo, hi, findex (restitution 0 and penetration correction off by default) ----
-  for (int r = 0; r < mrows; r++) {
+  for (int r = contactRows; r < mrows; r++) {
+    // JointLimitConstraint::getInformation (:240-290): b = -qdot + bouncing velocity; the error allowance is 0 (DART_ERROR_ALLOWANCE), so
+    // the bouncing velocity is -+0 * ERP / dt = 0; x starts from 0 (the constraint objects are rebuilt every step: life time 0)
+    const int l = r - contactRows;
+    out.b[r] = -vPre[limDof[l]];
+    if (limSide[l] < 0) { out.lo[r] = 0.0; out.hi[r] = INFINITY; }
+    else { out.lo[r] = -INFINITY; out.hi[r] = 0.0; }
+    out.findex[r] = -1;
+  }
+  for (int r = 0; r < contactRows; r++) {
     const Contact& ct = out.contacts[out.rowContact[r]];
     s_t rel = 0;
     if (ct.bodyA >= 0) rel -= dot(out.JA[r], kinPre[ct.bodyA].V);
     if (ct.bodyB >= 0) rel -= dot(out.JB[r], kinPre[ct.bodyB].V);
     out.b[r] = rel;
-    out.restCoeff.push_back(0.0);
     if (out.rowDir[r] == 0) {
       // "Bouncing" of getInformation (ContactConstraint.cpp:393-441, ctor :95-110).  A: penetration correction, only when the
       // world enables it (ConstraintSolver.cpp:69-71: off by default; DART_ERROR_ALLOWANCE 0, DART_ERP 0.01, DART_MAX_ERV 1e-3, :45-47)
@@ -367,37 +395,48 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     }
   }
 
-  // ---- impulse tests: rows of A and massed impulse tests (BoxedLcpConstraintSolver.cpp:250-320) ----
-  for (int c = 0; c < C; c++) {
-    for (int k = 0; k < dim[c]; k++) {
-      const int row = out.contactOffset[c] + k;
-      const Contact& ct = out.contacts[c];
+  // ---- impulse tests: rows of A and massed impulse tests (BoxedLcpConstraintSolver.cpp:250-320): a unit impulse on every dimension
+  //      of every constraint in turn; its own and the later constraints read their velocity change, earlier ones are mirrored ----
+  std::vector<int> consFirst, consDim;                            // the constraints in LCP order: contacts, then joint-limit rows
+  for (int c = 0; c < C; c++) { consFirst.push_back(out.contactOffset[c]); consDim.push_back(dim[c]); }
+  for (int l = 0; l < L; l++) { consFirst.push_back(contactRows + l); consDim.push_back(1); }
+  const int nCons = (int)consFirst.size();
+  for (int c = 0; c < nCons; c++) {
+    for (int k = 0; k < consDim[c]; k++) {
+      const int row = consFirst[c] + k;
       std::vector<Vec6> imps(m.nb, zero6()), dV;
-      if (ct.bodyA >= 0) imps[ct.bodyA] = imps[ct.bodyA] + out.JA[row];
-      if (ct.bodyB >= 0) imps[ct.bodyB] = imps[ct.bodyB] + out.JB[row];
+      VecX jimp(n, 0.0);
+      if (out.rowContact[row] >= 0) {
+        const Contact& ct = out.contacts[out.rowContact[row]];
+        if (ct.bodyA >= 0) imps[ct.bodyA] = imps[ct.bodyA] + out.JA[row];
+        if (ct.bodyB >= 0) imps[ct.bodyB] = imps[ct.bodyB] + out.JB[row];
+      } else jimp[out.rowDof[row]] = 1.0;                        // JointLimitConstraint::applyUnitImpulse (:293-318)
       VecX delV(n, 0.0);
-      impulseDynamics(m, kin, art, imps, delV.data(), &dV);
+      impulseDynamics(m, kin, art, imps, delV.data(), &dV, jimp.data());
       for (int i = 0; i < n; i++) out.massed(i, row) = delV[i];
-      // own block and later constraints computed, earlier ones mirrored
-      for (int c2 = c; c2 < C; c2++)
-        for (int k2 = 0; k2 < dim[c2]; k2++) {
-          const int col = out.contactOffset[c2] + k2;
-          const Contact& ct2 = out.contacts[c2];
+      for (int c2 = c; c2 < nCons; c2++)
+        for (int k2 = 0; k2 < consDim[c2]; k2++) {
+          const int col = consFirst[c2] + k2;
           s_t v = 0;
-          if (ct2.bodyA >= 0) v += dot(out.JA[col], dV[ct2.bodyA]);
-          if (ct2.bodyB >= 0) v += dot(out.JB[col], dV[ct2.bodyB]);
+          if (out.rowContact[col] >= 0) {                          // ContactConstraint::getVelocityChange
+            const Contact& ct2 = out.contacts[out.rowContact[col]];
+            if (ct2.bodyA >= 0) v += dot(out.JA[col], dV[ct2.bodyA]);
+            if (ct2.bodyB >= 0) v += dot(out.JB[col], dV[ct2.bodyB]);
+          } else v = delV[out.rowDof[col]];                        // JointLimitConstraint::getVelocityChange (:321-349, withCfm false)
           out.A(row, col) = v;
         }
       for (int c2 = 0; c2 < c; c2++)
-        for (int k2 = 0; k2 < dim[c2]; k2++) {
-          const int col = out.contactOffset[c2] + k2;
+        for (int k2 = 0; k2 < consDim[c2]; k2++) {
+          const int col = consFirst[c2] + k2;
           out.A(row, col) = out.A(col, row);
         }
     }
   }
 
   // ---- constraint forces in joint space: A_c columns (DCC.cpp:231-270, 2961-2988; Joint.cpp:1176-1181) ----
-  for (int r = 0; r < mrows; r++) {
+  // (a joint-limit constraint is not a contact constraint: DifferentiableContactConstraint gives it a zero world force, DCC.cpp:51-99,
+  //  so its column of A_c is zero - in the standardisation's Q when friction rows sit on their bounds, and in the backward pass)
+  for (int r = 0; r < contactRows; r++) {
     const Contact& ct = out.contacts[out.rowContact[r]];
     Vec6 F = mk6(cross(ct.point, out.dirs[r]), out.dirs[r]);
     for (int bi = 0; bi < m.nb; bi++) {
@@ -434,8 +473,12 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     out.rowGroup.assign(mrows, 0);
     out.numGroups = 0;
     for (int r = 0; r < mrows; r++) {
-      const Contact& ct = out.contacts[out.rowContact[r]];
-      const int root = find(m.skeleton[reactive(ct.bodyA) ? ct.bodyA : ct.bodyB]);
+      int skelBody;
+      if (out.rowContact[r] >= 0) {
+        const Contact& ct = out.contacts[out.rowContact[r]];
+        skelBody = reactive(ct.bodyA) ? ct.bodyA : ct.bodyB;
+      } else skelBody = dofBodyOf[out.rowDof[r]];                  // JointLimitConstraint::getRootSkeleton: the joint's skeleton
+      const int root = find(m.skeleton[skelBody]);
       if (groupOfRoot[root] < 0) groupOfRoot[root] = out.numGroups++;
       out.rowGroup[r] = groupOfRoot[root];
     }
@@ -515,6 +558,7 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   if (allStandardized) *status |= NBL_ST_STANDARDIZED;
   // the world-level classification vectors of the backward pass (BackpropSnapshot assembles the groups' matrices, :4215-4409;
   // clamping / upper-bound rows are numbered in row order here, which is a permutation of the reference's group-major order)
+  if (getenv("NBO_DBG_DROP_LIMIT")) for (int r = contactRows; r < mrows; r++) out.rowClass[r] = RC_NOT_CLAMPING;   // debugging aid
   out.clampingIndex.assign(mrows, -1); out.upperBoundIndex.assign(mrows, -1);
   out.numClamping = 0; out.numUpperBound = 0;
   for (int r = 0; r < mrows; r++) {
@@ -534,16 +578,19 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
 
   // ---- applyImpulse + computeImpulseForwardDynamics (ContactConstraint.cpp:630-684, Skeleton.cpp:13571-13595) ----
   std::vector<Vec6> imps(m.nb, zero6());
+  VecX jimp(n, 0.0);
   bool any = false;
   for (int r = 0; r < mrows; r++) {
-    const Contact& ct = out.contacts[out.rowContact[r]];
-    if (ct.bodyA >= 0) imps[ct.bodyA] = imps[ct.bodyA] + out.JA[r] * X[r];
-    if (ct.bodyB >= 0) imps[ct.bodyB] = imps[ct.bodyB] + out.JB[r] * X[r];
+    if (out.rowContact[r] >= 0) {
+      const Contact& ct = out.contacts[out.rowContact[r]];
+      if (ct.bodyA >= 0) imps[ct.bodyA] = imps[ct.bodyA] + out.JA[r] * X[r];
+      if (ct.bodyB >= 0) imps[ct.bodyB] = imps[ct.bodyB] + out.JB[r] * X[r];
+    } else jimp[out.rowDof[r]] += X[r];                            // JointLimitConstraint::applyImpulse (:364-381)
     any = true;
   }
   if (any) {
     VecX delV(n, 0.0);
-    impulseDynamics(m, kin, art, imps, delV.data());
+    impulseDynamics(m, kin, art, imps, delV.data(), nullptr, jimp.data());
     for (int i = 0; i < n; i++) vOut[i] = vPre[i] + delV[i];
   }
   out.status = *status;
@@ -887,7 +934,9 @@ inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const 
 
   // per-row constraint-force Jacobians (cached like mWorldConstraintJacCache)
   std::vector<MatX> rowJac(mrows);
-  for (int j = 0; j < mrows; j++) if (cr.rowClass[j] == RC_CLAMPING || cr.rowClass[j] == RC_UPPER_BOUND) rowJac[j] = cg.constraintForcesJacobian(j);
+  for (int j = 0; j < mrows; j++)
+    if (cr.rowClass[j] == RC_CLAMPING || cr.rowClass[j] == RC_UPPER_BOUND)
+      rowJac[j] = cr.rowContact[j] >= 0 ? cg.constraintForcesJacobian(j) : MatX(n, n);   // a joint-limit row: zero world force, zero Jacobian
   auto jacClamping = [&](const VecX& f0) { MatX r(n, n); for (int i = 0; i < nc; i++) r = addX(r, rowJac[clampRows[i]], f0[i]); return r; };
   auto jacClampingT = [&](const VecX& v0) { MatX r(nc, n); for (int i = 0; i < nc; i++) { VecX row = matTvec(rowJac[clampRows[i]], v0); for (int k = 0; k < n; k++) r(i, k) = row[k]; } return r; };
   auto jacUpper = [&](const VecX& Ef0) { MatX r(n, n); for (int i = 0; i < nu; i++) r = addX(r, rowJac[ubRows[i]], Ef0[i]); return r; };
@@ -943,7 +992,13 @@ inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const 
   s_t impNorm2 = 0;
   for (s_t x : imprecision.d) impNorm2 += x * x;
   MatX dQ_b = scaleX(codSolveMat(Q, dQ(Qinv_b)), -1.0);
-  if (!(impNorm2 < 1e-18)) {
+  bool imprecise = !(impNorm2 < 1e-18);
+  if (const char* dbg = getenv("NBO_DBG_PRECISE")) {   // debugging aid: 0 / 1 force the branch, 2 prints the norm
+    if (dbg[0] == '0') imprecise = true;
+    if (dbg[0] == '1') imprecise = false;
+    if (dbg[0] == '2') fprintf(stderr, "[oracle] |I - Q Q^+|^2 = %.3e\n", (double)impNorm2);
+  }
+  if (imprecise) {
     VecX ib = matvec(imprecision, bvec);
     dQ_b = addX(dQ_b, codSolveMat(Q, matmul(transposeX(Qinv), dQT(ib))));
     MatX IQQ = addX(identityX(nc), matmul(Qinv, Q), -1.0);

@@ -41,6 +41,7 @@ struct Model {
   int maxContacts;
   s_t clippingDepth, fallbackCfm;
   bool penetrationCorrection = false;   // World::setPenetrationCorrectionEnabled (off by default)
+  std::vector<int> limitEnforced;       // per DOF: Joint::isPositionLimitEnforced of its joint (JointAspect.hpp:165: off by default)
 };
 
 inline Iso loadIso(const double* t) {
@@ -114,6 +115,8 @@ inline Model buildModel(const nbl_model_desc* d) {
   const double inf = INFINITY;
   cp(d->damping, m.damping, 0); cp(d->spring, m.spring, 0); cp(d->rest, m.rest, 0);
   cp(d->pos_lo, m.posLo, -inf); cp(d->pos_hi, m.posHi, inf);
+  m.limitEnforced.assign(m.n, 0);
+  if (d->dof_limit_enforced) for (int i = 0; i < m.n; i++) m.limitEnforced[i] = d->dof_limit_enforced[i] != 0;
   cp(d->vel_lo, m.velLo, -inf); cp(d->vel_hi, m.velHi, inf);
   cp(d->force_lo, m.forceLo, -inf); cp(d->force_hi, m.forceHi, inf);
   m.gravity = mk3(d->gravity[0], d->gravity[1], d->gravity[2]);
@@ -295,7 +298,8 @@ inline void forwardDynamics(const Model& m, const std::vector<Kin>& kin, const s
 //  GenericJoint.hpp:2482-2498, 2607-2613, 2713-2725).  impulses[i] is the constraint impulse on body i
 // expressed in its own frame (BodyNode::mConstraintImpulse).  Returns delta joint velocities.
 inline void impulseDynamics(const Model& m, const std::vector<Kin>& kin, const std::vector<Art>& art,
-                            const std::vector<Vec6>& impulses, s_t* delV, std::vector<Vec6>* bodyDelV = nullptr) {
+                            const std::vector<Vec6>& impulses, s_t* delV, std::vector<Vec6>* bodyDelV = nullptr,
+                            const s_t* jointImpulses = nullptr) {   // jointImpulses: Joint::mConstraintImpulses (joint-limit rows)
   std::vector<Vec6> bias(m.nb), dV(m.nb);
   std::vector<s_t> total(m.n > 0 ? m.n : 1);
   for (int i = m.nb - 1; i >= 0; i--) {
@@ -314,7 +318,8 @@ inline void impulseDynamics(const Model& m, const std::vector<Kin>& kin, const s
       B = B + dAdInvT(kin[c].Trel, beta);
     }
     bias[i] = B;
-    for (int k = 0; k < b.ndof; k++) total[b.dofOff + k] = -dot(b.S[k], B);  // constraint impulses on joints are 0 here
+    // GenericJoint::updateTotalImpulse: mTotalImpulse = mConstraintImpulses - S^T biasImpulse
+    for (int k = 0; k < b.ndof; k++) total[b.dofOff + k] = (jointImpulses ? jointImpulses[b.dofOff + k] : 0.0) - dot(b.S[k], B);
   }
   for (int i = 0; i < m.nb; i++) {
     const Body& b = m.bodies[i];

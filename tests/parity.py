@@ -19,6 +19,8 @@ def assert_match_or_reference_unstable(tag, ow, s, a, g, dev, ref, tol, lcp=None
     result must be one of the oracle's outcomes: within `tol` of a perturbed run ("tol" branch), or - where those outcomes form a
     continuum - at least 1 / `closeness` times closer to one of them than they scatter ("closeness" branch).  Prints how many worlds
     took which branch and returns (unstable worlds, worlds that needed the closeness branch)."""
+    for k in KEYS:
+        assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), (tag, k, "non-finite values", int((~np.isfinite(dev[k])).sum()), int((~np.isfinite(ref[k])).sum()))
     errs, scales = world_errors(dev, ref)
     worst = np.maximum.reduce([errs[k] for k in KEYS])
     bad = np.where(worst > tol)[0]

@@ -42,6 +42,7 @@ class _Joint:
     def __init__(self, b): self._b = b
     def getType(self): return "EulerJoint" if self._b.joint_type.startswith("euler_") else self.TYPES[self._b.joint_type]
     def getName(self): return self._b.joint_name
+    def isPositionLimitEnforced(self): return bool(self._b.limit_enforced)
     def getNumDofs(self):
         from nimblephysics_amd.model import COMPOUND_JOINTS
         return COMPOUND_JOINTS.get(self._b.joint_type, {"free": 6, "weld": 0, "ball": 3}.get(self._b.joint_type, 1))
@@ -176,6 +177,18 @@ def test_extraction_keeps_spheres_friction_action_space_and_leaves_the_world_unt
     assert w._tuned == []                                   # the mass vector was registered on a clone only
     assert [bx.shape for bx in got.boxes] == [bx.shape for bx in md.boxes] and got.boxes[0].mu == 0.3
     assert list(got.action_map) == [5, 6, 12]
+    _same(got, md)
+
+
+def test_extraction_keeps_the_position_limit_enforcement_flag():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import limited_arm
+    md = limited_arm()
+    md.bodies[2].limit_enforced = False
+    got = model_from_nimble_world(StandInWorld(md), name=md.name, max_contacts=8)
+    assert [b.limit_enforced for b in got.bodies] == [True, True, False, True, True]
+    assert got.flat()["dof_limit_enforced"].tolist() == [1, 1, 0, 1, 1]
     _same(got, md)
 
 

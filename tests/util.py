@@ -97,6 +97,24 @@ def ball_world(order="box_first", n_balls=1, radius=0.1, arm=False):
     return na.ModelDescription("balls", bodies, boxes, max_contacts=8)
 
 
+# ---- joint-limit rows (tests/test_oracle_joint_limits.py, tests/test_gpu_joint_limits.py) ----
+def limited_arm(enforce=True, ground=False, n_links=4):
+    """A prismatic base (vertical slide) carrying a chain of revolute links with position limits [-0.5, 0.4]; every joint enforces its
+    limits when `enforce`.  With `ground`: a ground box under it and a box collider on the base, which touches the ground for slide positions
+    in (-0.03, 0] (contacts and limit rows in one LCP)."""
+    bodies = [na.BodySpec("base", -1, "prismatic", "slide", axis=(0, 1, 0), mass=1.0, inertia=(0.01, 0.01, 0.01, 0, 0, 0), pos_lo=(-0.2,), pos_hi=(0.6,),
+                          limit_enforced=enforce)]
+    for k in range(n_links):
+        bodies.append(na.BodySpec(f"link{k}", k, "revolute", f"hinge{k}", axis=(0, 0, 1) if k % 2 == 0 else (1, 0, 0),
+                                  T_pj=na.make_transform((0.2 if k else 0.0, 0, 0)), T_cj=na.make_transform((-0.1, 0, 0)), mass=0.5,
+                                  inertia=(0.002, 0.003, 0.004, 0, 0, 0), damping=(0.05,), pos_lo=(-0.5,), pos_hi=(0.4,), limit_enforced=enforce))
+    boxes = []
+    if ground:
+        boxes = [na.BoxSpec(-1, na.make_transform((0, -0.55, 0)), (6.0, 1.0, 6.0), 1.0),
+                 na.BoxSpec(0, np.eye(4), (0.2, 0.1, 0.2), 0.8)]
+    return na.ModelDescription("limited_arm", bodies, boxes, max_contacts=8)
+
+
 # ---- capsule colliders (tests/test_oracle_capsules.py, tests/test_gpu_capsules.py) ----
 def capsule_world(order="fixed_first", kinds=("capsule",), radius=0.1, height=0.4):
     """Free-joint capsules (axis = their z, radius 0.1, cylinder height 0.4) / spheres (radius 0.1) over a world-fixed capsule of radius
