@@ -75,7 +75,7 @@ def make_case(seed, B=256, big=False, multi=False, balls=False, far=False):
 
 def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False, far=False, mutate=None):
   """mutate(seed, md, s, a, g) -> (md, s, a, g): a stress variant applied to every case (tools/soak_stress.py)."""
-  tot = {"worlds": 0, "contact": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "MISMATCH": 0}
+  tot = {"worlds": 0, "contact": 0, "limit_rows": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "MISMATCH": 0}
   for seed in range(first, first + count):
       case = make_case(seed, B, big, multi, balls, far)
       if case is None:
@@ -94,7 +94,7 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=Fa
       err = np.maximum.reduce([np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev])
       overflow = ((status | ref["status"]) & 0x80) != 0
       err[overflow] = 0.0                                   # more than 8 contacts: flagged by both, results undefined
-      assert np.array_equal(status & 0x81, ref["status"] & 0x81), ("contact / overflow flags differ", seed)
+      assert np.array_equal(status & 0x481, ref["status"] & 0x481), ("contact / joint-limit / overflow flags differ", seed)
       bad = np.where(err > 1e-5)[0]
       unstable = mismatch = 0
       prng = np.random.default_rng(1)
@@ -108,8 +108,8 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=Fa
           else:
               mismatch += 1
               print(f"  MISMATCH seed {seed} world {wd}: err {err[wd]:.2e} spread {spread:.2e} nearest {dist.min():.2e} status dev {status[wd]:#x} ref {ref['status'][wd]:#x}")
-      c = (status & 1) != 0
-      tot["worlds"] += B; tot["contact"] += int(c.sum()); tot["cascade"] += int((c & ((status & 2) == 0)).sum())
+      c = (status & 0x401) != 0                            # a constraint row of either kind: a contact or an enforced joint limit
+      tot["worlds"] += B; tot["contact"] += int(((status & 1) != 0).sum()); tot["limit_rows"] += int(((status & 0x400) != 0).sum()); tot["cascade"] += int((c & ((status & 2) == 0)).sum())
       tot["gt1e-7"] += int((err > 1e-7).sum()); tot["gt1e-5"] += len(bad); tot["unstable"] += unstable; tot["MISMATCH"] += mismatch
       if verbose:
           print(f"seed {seed}: nb {len(md.bodies)} n {md.num_dofs} colliders {len(md.boxes) - 1} contact {c.mean():.2f} cascade {(c & ((status & 2) == 0)).mean():.2f} "

@@ -8,6 +8,8 @@ reduced size as tests/test_gpu_stress.py.
   mu      friction from 1.01e-3 (just above the frictionless threshold) to 10
   subset  a random third of the DOFs actuated (World::setActionSpace; unmapped torques are zero)
   atlimit positions, velocities and torques exactly at their limits in half of the worlds (clipLossGradientsToBounds)
+  limits  like atlimit, and those joints ENFORCE their position limits (Joint::setPositionLimitEnforced): joint-limit rows in the LCP next to
+          the contact rows (JointLimitConstraint.cpp), half of the limited DOFs exactly at a limit, a quarter beyond it
   capsule every box collider becomes a capsule (radius = half its smallest side, cylinder height = its longest side, axis = that side's) and
           the ground a world-fixed sphere of radius 100 m with its top at y = 0 (a capsule cannot meet a box: libccd in the reference)
 usage (GPU box): python tools/soak_stress.py <mode> [first seed] [count] [B]"""
@@ -19,7 +21,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule")
+MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits")
 
 
 def mutator(mode):
@@ -72,16 +74,19 @@ def mutator(mode):
                 r = float(0.5 * np.min(size))
                 bx.size = (r, float(max(size[ax] - 2 * r, 0.0)), 0.0)
                 bx.shape = "capsule"
-        elif mode == "atlimit":
+        elif mode in ("atlimit", "limits"):
             for i, b in enumerate(md.bodies):
-                if md.joint_ndof(i) == 1 and rng.random() < 0.5:
+                if md.joint_ndof(i) == 1 and rng.random() < (0.5 if mode == "atlimit" else 0.35):
                     b.pos_lo, b.pos_hi = (-0.3,), (0.4,); b.vel_lo, b.vel_hi = (-0.7,), (0.9,); b.force_lo, b.force_hi = (-0.2,), (0.25,)
+                    b.limit_enforced = mode == "limits"
             md = type(md)(md.name, md.bodies, md.boxes, gravity=md.gravity, dt=md.dt, max_contacts=md.max_contacts)
             fl = md.flat(); s = s.copy(); a = a.copy()
             for d in range(n):
                 if np.isfinite(fl["pos_lo"][d]):
                     half = rng.random(s.shape[0]) < 0.5
                     s[half, d] = rng.choice([fl["pos_lo"][d], fl["pos_hi"][d]], half.sum())
+                    if mode == "limits":                       # ... and some of them beyond the limit
+                        s[half, d] += rng.choice([0.0, 0.0, -0.02, 0.02], half.sum()) * (np.abs(s[half, d]) > 0)
                     s[half, n + d] = rng.choice([fl["vel_lo"][d], fl["vel_hi"][d]], half.sum())
                     a[half, d] = rng.choice([fl["force_lo"][d], fl["force_hi"][d]], half.sum())
         return md, s, a, g
