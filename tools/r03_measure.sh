@@ -1,0 +1,12 @@
+set -u
+mkdir -p gpurun_out
+bash tools/profile.sh r03 > gpurun_out/r03_profile.log 2>&1
+python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_driver.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --streams 1 --batch 1024 > gpurun_out/r03_bench_slice1.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --batch 32768 > gpurun_out/r03_bench_b32768.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --batch 8192 > gpurun_out/r03_bench_b8192.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas20_freefall > gpurun_out/r03_bench_freefall.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --batch 8192 > gpurun_out/r03_bench_atlas33.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --rollout 64 --batch 8192 > gpurun_out/r03_bench_atlas33_rollout.json 2>/dev/null
+for f in gpurun_out/r03_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
