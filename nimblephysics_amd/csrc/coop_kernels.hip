@@ -124,29 +124,31 @@ DEV uint32_t coopContactOutputs(const W& w, CoopLds& S, const CoopRow& R, int n,
   if (ln == MAX_ROWS && cacheOut) cacheOut[(int64_t)MAX_ROWS * B + b] = (double)m;
   if (ln < MAX_ROWS) svAt(saved, lay.cfm + ln, B, b) = cfm;     // this row's constant (its group's, CFM_CONSTANTS)
   if (ln == 0) svAt(saved, lay.pflag, B, b) = pinvValid ? 1.0 : 0.0;
-  // v' = v_pre + M^-1 J^T x  (lane = DOF)
+  // v' = v_pre + M^-1 J^T x  (lane = DOF), and the velocity change the BACKWARD pass works with: the reference's Jacobians take
+  // A_c f_c + A_ub E f_c (BackpropSnapshot.cpp:980-1066), the impulses of the clamping rows and, for a friction row on its bound, E times
+  // its normal's - the same as x on a standardised world; on a world that fell through every solver stage the raw PGS iterate also
+  // holds impulses below the classification thresholds, which those Jacobians do not know.  Joint-limit rows: never (no force column).
   double vNext = 0.0;
-  if (ln < MAXR) S.vec[2][ln] = X;
+  {
+    const double Xn = w.shfl(X, R.fp);
+    const double xb = R.lim ? 0.0 : (K.cls == RC_CLAMPING ? X : (K.cls == RC_UPPER_BOUND ? K.E * Xn : 0.0));
+    if (ln < MAXR) { S.vec[2][ln] = X; S.vec[1][ln] = xb; }
+  }
   w.sync();
   if (ln < n) {
-    double wd = 0.0, wd1 = 0.0;
+    double wd = 0.0, wd1 = 0.0, wb = 0.0, wb1 = 0.0;
 #pragma unroll 1
     for (int rb = 0; rb < MAXR; rb += 8) {
 #pragma unroll
       for (int rq = 0; rq < 8; rq += 2) {
         const int r = rb + rq;
-        wd = fma(r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, S.vec[2][r], wd);   // columns >= m were never written
-        wd1 = fma(r + 1 < m ? dn[lay.massed + ln * MAX_ROWS + r + 1] : 0.0, S.vec[2][r + 1], wd1);
+        const double m0 = r < m ? dn[lay.massed + ln * MAX_ROWS + r] : 0.0, m1 = r + 1 < m ? dn[lay.massed + ln * MAX_ROWS + r + 1] : 0.0;   // columns >= m were never written
+        wd = fma(m0, S.vec[2][r], wd); wd1 = fma(m1, S.vec[2][r + 1], wd1);
+        wb = fma(m0, S.vec[1][r], wb); wb1 = fma(m1, S.vec[1][r + 1], wb1);
       }
     }
     wd += wd1;
-    // the record's velocity change is the backward pass's: without the joint-limit impulses, which the reference's Jacobians do not know
-    double wdLim = 0.0;
-    for (uint32_t lm = R.limMask; lm != 0u; lm &= lm - 1u) {
-      const int r = __builtin_ctz(lm);
-      wdLim = fma(dn[lay.massed + ln * MAX_ROWS + r], S.vec[2][r], wdLim);
-    }
-    svAt(saved, lay.w + ln, B, b) = wd - wdLim;
+    svAt(saved, lay.w + ln, B, b) = wb + wb1;
     vNext = svAt(saved, lay.vpre + ln, B, b) + wd;
     nv[(int64_t)ln * B + b] = vNext;
   }

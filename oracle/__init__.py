@@ -168,6 +168,7 @@ class OracleWorld:
         li_p = ll_p = lo_p = lol_p = None
         if lcp_in is not None:
             lcp_in = _arr(lcp_in)
+            assert lcp_in.shape == (B, stride), (lcp_in.shape, (B, stride))   # rows of 3 * max_contacts doubles
             lcp_len_in = np.ascontiguousarray(lcp_len_in, dtype=np.int32)
             li_p, ll_p = _p(lcp_in), lcp_len_in.ctypes.data_as(C.POINTER(C.c_int32))
         lcp_out = lcp_len_out = None

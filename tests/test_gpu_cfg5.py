@@ -10,7 +10,8 @@ from util import contact_inputs
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
-NORTH_STAR_TOL = 1e-5
+NORTH_STAR_TOL = 1e-7   # north_star asks for 1e-5; since round 3 (the record's velocity change is the reference's A_c f_c + A_ub E f_c) every
+                        # cascade world is held to the 1e-7 of the stage-0 worlds, or proven reference-unstable
 STAGE_BITS = 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100
 
 
@@ -117,7 +118,7 @@ def test_cfg5_atlas33_warm_started_trajectory_vs_oracle_chain():
     e_s = np.abs(st.grad.cpu().numpy() - gcot).max(1) / np.abs(gcot).max()
     e_a = np.abs(at.grad.cpu().numpy() - gas).reshape(B, -1).max(1) / max(np.abs(gas).max(), 1e-30)
     off = (e_s > NORTH_STAR_TOL) | (e_a > NORTH_STAR_TOL)
-    print(f"[cfg5 trajectory] T = {T} gradient: worlds above 1e-5: {int(off.sum())} of {B} (max state {e_s.max():.2e}, action {e_a.max():.2e}); "
+    print(f"[cfg5 trajectory] T = {T} gradient: worlds above {NORTH_STAR_TOL:g}: {int(off.sum())} of {B} (max state {e_s.max():.2e}, action {e_a.max():.2e}); "
           f"worlds with a reference-unstable step: {int(ever_unstable.sum())}")
     assert not np.any(off & ~ever_unstable), np.where(off & ~ever_unstable)[0][:10]
     assert off.mean() <= 0.05

@@ -88,7 +88,8 @@ def test_full_lcp_cascade_on_noisy_poses(B, seed):
     assert 0.3 < gpu0.mean() < 0.7                      # the cascade is really exercised
     assert not np.any((st & 0x1) == 0)
     _report(f"atlas20 sigma=0.02 B={B}", errs)
-    unstable = _assert_all_worlds_match_or_reference_is_unstable(f"atlas20 sigma=0.02 B={B}", errs, world, NORTH_STAR_TOL)
+    # (1e-7 on EVERY world since round 3, cascade worlds included - north_star asks for 1e-5 - or the proof of instability)
+    unstable = _assert_all_worlds_match_or_reference_is_unstable(f"atlas20 sigma=0.02 B={B}", errs, world, TOL)
     assert unstable <= 0.01 * B
     assert (errs["next"][gpu0] > TOL).sum() == 0
     for k in ("grad_state", "grad_action"):

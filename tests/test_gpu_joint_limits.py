@@ -45,15 +45,7 @@ def _compare(tag, md, s, a, seed, min_limit=0.5, min_contact=None, lcp=None):
     dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
     keep = (status & 0x80) == 0                                                  # (overflowing worlds: flagged by both, truncated on the device)
     sub = lambda d_: {k: v_[keep] for k, v_ in d_.items() if k in dev}
-    # the suite's criterion (tests/test_gpu_contact.py): every world within north_star's 1e-5 or proven reference-unstable, and 1e-7 on the
-    # worlds stage 0 resolved (on worlds that fall through every solver stage the unstandardised PGS iterate leaves impulses between
-    # the 1e-6 clamping threshold and the 1e-5 tie-break band, which the reference's Jacobians ignore and the record's velocity change keeps)
-    from parity import world_errors, KEYS
-    assert_match_or_reference_unstable(tag, ow, s[keep], a[keep], g[keep], sub(dev), sub(ref), 1e-5, max_unstable=0.02 * len(s))
-    errs, _ = world_errors(sub(dev), sub(ref))
-    st0 = ((status & 0x2) != 0)[keep]
-    for k in KEYS:
-        assert errs[k][st0].max() < TOL, (tag, k, errs[k][st0].max())
+    assert_match_or_reference_unstable(tag, ow, s[keep], a[keep], g[keep], sub(dev), sub(ref), TOL, max_unstable=0.02 * len(s))
     print(f"[{tag}] limit rows in {(status & 0x400).astype(bool).mean():.2f} of the worlds, contacts in {(status & 1).mean():.2f}, stage 0 resolved "
           f"{((status & 0x2) != 0).mean():.2f}, overflow {(status & 0x80).astype(bool).mean():.3f}")
     return world, ow, status
@@ -113,7 +105,8 @@ def test_warm_started_second_step_uses_the_cache_in_the_references_sign():
     n2, _, status2 = world.step_soa(n1, at)
     s1 = world.from_soa(n1).cpu().numpy()
     # the device keeps three row slots per constraint (a limit row has two empty tangent slots), the reference one row per limit
-    ref = ow.step_batch(s1, a, None, threads=8, lcp_in=np.ascontiguousarray(cache[:, 0:24:3]), lcp_len_in=rows // 3)
+    compact = np.zeros((len(s), 24)); compact[:, :8] = cache[:, 0:24:3]      # (the oracle reads rows of 3 * max_contacts doubles)
+    ref = ow.step_batch(s1, a, None, threads=8, lcp_in=compact, lcp_len_in=rows // 3)
     err = np.abs(world.from_soa(n2).cpu().numpy() - ref["next"]).max(1)
     st2 = status2.cpu().numpy().astype(np.uint32)
     assert np.array_equal(st2 & 0x481, ref["status"] & 0x481)

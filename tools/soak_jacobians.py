@@ -31,6 +31,7 @@ def run(first=0, count=20, W=4, mode="balls", verbose=True):
         Js, Ja = snap.getStateJacobian(world).cpu().numpy(), snap.getActionJacobian(world).cpu().numpy()
         ow = OracleWorld(md)
         for b in range(W):
+            ow.reset_lcp_cache()        # every world of the device batch starts cold; the oracle world would carry world b-1's solution as a warm start
             ow.step(s[b], a[b])
             if (st[b] | ow.last_status) & 0x80:
                 continue
