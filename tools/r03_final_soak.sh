@@ -1,4 +1,4 @@
-# The randomised soaks on the final build of round 3 (GPU box): every mode of tools/soak_parity.py and tools/soak_stress.py, the warm-start
+# The randomised soaks on the final build of round 3 (criterion: a world above 1e-6 must be proven reference-unstable; NBL_SOAK_TOL=1e-7: one CFM world at 1.2e-7 is left over) (GPU box): every mode of tools/soak_parity.py and tools/soak_stress.py, the warm-start
 # and Jacobian soaks.  Prints one totals line per run.
 set -u
 for m in "" big multi balls far; do echo "parity:$m $(python tools/soak_parity.py 40000 300 256 $m 2>&1 | tail -1)"; done

@@ -1,6 +1,6 @@
 """Randomised parity soak (GPU box): random articulated trees with random colliders (boxes / spheres, random friction incl.
 frictionless, restitution, penetration correction on/off) dropped on the ground; every world's next state and gradients are
-compared with the CPU oracle.  A world above 1e-5 must be one where the oracle itself flips under 1-ulp input perturbations
+compared with the CPU oracle.  A world above 1e-6 (round 2: 1e-5; NBL_SOAK_TOL) must be one where the oracle itself flips under 1-ulp input perturbations
 (the criterion of tests/test_gpu_contact.py), otherwise it is reported as a MISMATCH.
   usage: python tools/soak_parity.py [first seed] [count] [B] [big|multi|balls]      (big: 8-21 bodies, 3-7 colliders; multi: 2-3 separate skeletons;
   balls: 40 % of the joints below the root are ball joints; far: the same, the scene ~10 m from the world origin)"""
@@ -73,8 +73,11 @@ def make_case(seed, B=256, big=False, multi=False, balls=False, far=False):
     return md, s, a, g
 
 
-def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False, far=False, mutate=None):
+def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=False, far=False, mutate=None, tol=None):
   """mutate(seed, md, s, a, g) -> (md, s, a, g): a stress variant applied to every case (tools/soak_stress.py)."""
+  # a world above `tol` must be PROVEN reference-unstable.  Round 2: 1e-5 (north_star).  1e-6 since the record carries the reference's
+  # velocity change; at 1e-7 one world in 826 000 of the final soak is left over: a CFM + PGS world (condition number ~1e6) at 1.2e-7
+  tol = float(os.environ.get("NBL_SOAK_TOL", "1e-6")) if tol is None else tol
   tot = {"worlds": 0, "contact": 0, "limit_rows": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "MISMATCH": 0}
   for seed in range(first, first + count):
       case = make_case(seed, B, big, multi, balls, far)
@@ -95,7 +98,7 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=Fa
       overflow = ((status | ref["status"]) & 0x80) != 0
       err[overflow] = 0.0                                   # more than 8 contacts: flagged by both, results undefined
       assert np.array_equal(status & 0x481, ref["status"] & 0x481), ("contact / joint-limit / overflow flags differ", seed)
-      bad = np.where(err > 1e-5)[0]
+      bad = np.where(err > tol)[0]
       unstable = mismatch = 0
       prng = np.random.default_rng(1)
       for wd in bad:
@@ -103,17 +106,17 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=Fa
           r = ow.step_batch(sp, np.repeat(a[wd][None], 64, 0), np.repeat(g[wd][None], 64, 0), threads=8)
           dist = np.maximum.reduce([np.abs(r[k] - dev[k][wd][None]).max(1) / scales[k] for k in dev])
           spread = max(np.abs(r[k] - ref[k][wd][None]).max() / scales[k] for k in dev)
-          if spread > 1e-5 and dist.min() <= max(1e-5, 0.1 * spread):
+          if spread > tol and dist.min() <= max(tol, 0.1 * spread):
               unstable += 1
           else:
               mismatch += 1
               print(f"  MISMATCH seed {seed} world {wd}: err {err[wd]:.2e} spread {spread:.2e} nearest {dist.min():.2e} status dev {status[wd]:#x} ref {ref['status'][wd]:#x}")
       c = (status & 0x401) != 0                            # a constraint row of either kind: a contact or an enforced joint limit
       tot["worlds"] += B; tot["contact"] += int(((status & 1) != 0).sum()); tot["limit_rows"] += int(((status & 0x400) != 0).sum()); tot["cascade"] += int((c & ((status & 2) == 0)).sum())
-      tot["gt1e-7"] += int((err > 1e-7).sum()); tot["gt1e-5"] += len(bad); tot["unstable"] += unstable; tot["MISMATCH"] += mismatch
+      tot["gt1e-7"] += int((err > 1e-7).sum()); tot["gt1e-5"] += int((err > 1e-5).sum()); tot["unstable"] += unstable; tot["MISMATCH"] += mismatch
       if verbose:
           print(f"seed {seed}: nb {len(md.bodies)} n {md.num_dofs} colliders {len(md.boxes) - 1} contact {c.mean():.2f} cascade {(c & ((status & 2) == 0)).mean():.2f} "
-              f"max err {err.max():.1e} >1e-7 {(err > 1e-7).sum()} >1e-5 {len(bad)} (unstable {unstable}, mismatch {mismatch})", flush=True)
+              f"max err {err.max():.1e} >1e-7 {(err > 1e-7).sum()} >1e-5 {(err > 1e-5).sum()} (unstable {unstable}, mismatch {mismatch})", flush=True)
   return tot
 
 
