@@ -120,7 +120,7 @@ constexpr int MAX_CONTACTS = 8;              // per world (8 frictional contacts
 constexpr int MAX_ROWS = 3 * MAX_CONTACTS;
 constexpr int MAX_BOXES = 16;
 constexpr int MAX_PAIRS = 32;
-constexpr int MAX_DOF_CONTACT = 40;
+constexpr int MAX_DOF_CONTACT = 64;   // lane = DOF in the wavefront kernels (round 2: 40)
 
 constexpr int SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CAPSULE = 2;   // NBL_SHAPE_*
 struct DevBox {       // a collider: box (half extents), sphere (radius in half[0]) or capsule (radius in half[0], half the cylinder height in half[1])

@@ -383,7 +383,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (d->n_boxes > MAX_BOXES) return fail(NBL_E_UNSUPPORTED, "too many box colliders for the device path");
     if (d->max_contacts > MAX_CONTACTS) return fail(NBL_E_UNSUPPORTED, "max_contacts above 8 is not supported by the device path yet");
     if (d->n_bodies > 64) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 64 bodies");
-    if (d->n_dofs > MAX_DOF_CONTACT) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 40 DOFs");
+    if (d->n_dofs > MAX_DOF_CONTACT) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 64 DOFs");
     hc.nBoxes = d->n_boxes;
     hc.nLimitDofs = (int)limitDofs.size();
     for (int k = 0; k < hc.nLimitDofs; k++) {

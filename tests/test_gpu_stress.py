@@ -103,6 +103,27 @@ def test_the_largest_models_of_the_contact_path_39_dofs_34_device_bodies(shape):
     assert (status & 1).mean() > 0.05 and err.max() < 1e-5
 
 
+def test_models_up_to_the_64_dof_64_body_limits_of_the_contact_path():
+    """lane = DOF / lane = body in the wavefront kernels: 64 of each (round 2 stopped at 40 DOFs).  A free root with 19 ball joints: 63 DOFs
+    on 1 + 3 * 19 = 58 device bodies, four colliders; a chain of 57 revolute joints on a free root: 63 DOFs, 58 bodies."""
+    import nimblephysics_amd as na
+    from test_gpu_random_trees import random_tree
+    for kind in ("balls", "revolutes"):
+        rng = np.random.default_rng(2)
+        md = random_tree(rng, 20 if kind == "balls" else 58, "random" if kind == "balls" else "chain", True, colliders=4, spheres=True, balls=1.0 if kind == "balls" else 0.0)
+        if kind == "balls":
+            for b in md.bodies[1:]:
+                b.joint_type = "ball"; b.damping = (); b.spring = (); b.rest = ()
+        md = na.ModelDescription("limit64", md.bodies, md.boxes, gravity=md.gravity, dt=md.dt, max_contacts=8)
+        n = md.num_dofs; B = 64
+        assert n == 63, n
+        q = rng.normal(0, 0.2, (B, n)); q[:, 3] = rng.normal(0, 0.3, B); q[:, 5] = rng.normal(0, 0.3, B); q[:, 4] = rng.uniform(0.02, 0.5, B)
+        s = np.concatenate([q, rng.normal(0, 0.3, (B, n))], 1); a = rng.normal(0, 0.3, (B, len(md.action_map))); g = rng.normal(0, 1, s.shape)
+        err, status = _fwd_bwd_vs_oracle(md, s, a, g)
+        print(kind, "n", n, "in contact", (status & 1).mean(), "overflow", ((status & 0x80) != 0).mean(), "max err", err.max())
+        assert (status & 1).mean() > 0.05 and err.max() < 1e-5
+
+
 def test_mass_gradients_of_random_models_vs_central_differences_of_the_oracle():
     """dL/dmass of random models (ball / free / revolute / prismatic joints, welds) in free fall, random bodies and entry types, against
     central differences of the oracle step with respect to the same parameters."""

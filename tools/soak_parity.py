@@ -21,7 +21,7 @@ from test_gpu_random_trees import random_tree  # noqa: E402
 
 
 def make_case(seed, B=256, big=False, multi=False, balls=False, far=False):
-    """The model, states, actions and cotangents of one soak seed (None when the model has more than 40 DOFs)."""
+    """The model, states, actions and cotangents of one soak seed (None when the model has more than 64 DOFs)."""
     rng = np.random.default_rng(50000 + seed)
     nb = int(rng.integers(8, 22)) if big else int(rng.integers(1, 10))
     if multi:
@@ -50,7 +50,7 @@ def make_case(seed, B=256, big=False, multi=False, balls=False, far=False):
         bx.restitution = float(rng.uniform(0.3, 1.0)) if rng.random() < 0.3 else 0.0
     md.penetration_correction = bool(rng.random() < 0.3)
     n = md.num_dofs
-    if n > 40:
+    if n > 64:
         return None
     q = rng.normal(0, 0.25, (B, n)); q[:, 3] = rng.normal(0, 0.3, B); q[:, 5] = rng.normal(0, 0.3, B)
     q[:, 4] = rng.uniform(0.02, 0.5, B)
