@@ -157,8 +157,8 @@ typedef struct nbl_model_desc {
    * [n_dofs] non-zero: the DOF's joint enforces its position limits (Joint::setPositionLimitEnforced).  A DOF at or beyond pos_lo /
    * pos_hi then adds one row to the LCP of its skeleton's constrained group, after the contact rows (JointLimitConstraint.cpp:182-290,
    * ConstraintSolver.cpp:641-696): unit impulse on the DOF, b = -qdot (error allowance 0), bounds [0, inf) at the lower and
-   * (-inf, 0] at the upper limit.  Honoured for the single-DOF joints (revolute, prismatic, screw and the coordinates of expanded
-   * compound joints); a limit row takes one of the max_contacts contact slots.  The backward pass follows the reference's: its
+   * (-inf, 0] at the upper limit.  Every joint type except the free-joint root (refused when such a coordinate has a finite limit);
+   * a limit row takes one of the max_contacts contact slots.  The backward pass follows the reference's: its
    * DifferentiableContactConstraint gives a non-contact constraint a zero constraint-force column (DCC.cpp:51-99), so the row drops out
    * of every Jacobian. */
   const int32_t* dof_limit_enforced;

@@ -366,12 +366,23 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   // ---- contact model: box colliders, candidate pairs (CollisionFilter.cpp:105-154), ancestor masks ----
   DevContactModel hc;
   std::memset(&hc, 0, sizeof(hc));
-  // joint-limit constraint rows (dof_limit_enforced): the single-DOF joints with a finite limit to enforce
+  // joint-limit constraint rows (dof_limit_enforced): the joints with a finite limit to enforce, one entry per DOF (= per device body)
   std::vector<int> limitDofs;
   if (d->dof_limit_enforced)
     for (int i = 0; i < d->n_bodies; i++) {
       const int jt = d->joint_type[i];
-      if (jt != NBL_JOINT_REVOLUTE && jt != NBL_JOINT_PRISMATIC && jt != NBL_JOINT_SCREW) continue;
+      if (jt == NBL_JOINT_WELD) continue;
+      if (jt == NBL_JOINT_FREE) {
+        // the free-joint root is solved in its body frame by the impulse tests (no world-frame axis per DOF): no rows for its coordinates
+        for (int k = 0; k < 6; k++) {
+          const int j = d->dof_offset[i] + k;
+          if (d->dof_limit_enforced[j] && (std::isfinite(hd[j].posLo) || std::isfinite(hd[j].posHi)))
+            return fail(NBL_E_UNSUPPORTED, "dof_limit_enforced with a finite limit on the coordinates of a free-joint root");
+        }
+        continue;
+      }
+      // (the three / six coincident single-axis bodies of a ball joint / a free joint below the root carry the joint's own generalized
+      //  velocities, so a unit impulse on one of their DOFs IS the joint's JointLimitConstraint::applyUnitImpulse)
       const int j = d->dof_offset[i];
       if (d->dof_limit_enforced[j] && (std::isfinite(hd[j].posLo) || std::isfinite(hd[j].posHi))) limitDofs.push_back(i);
     }

@@ -114,6 +114,28 @@ def test_warm_started_second_step_uses_the_cache_in_the_references_sign():
     assert err.max() < 1e-9, err.max()
 
 
+def test_limits_on_the_coordinates_of_ball_joints_and_of_free_joints_below_the_root():
+    """JointLimitConstraint works on the generalized coordinates of ANY joint: exponential coordinates of a BallJoint, the six coordinates
+    of a FreeJoint.  On the device those joints are chains of coincident single-axis bodies that carry the joint's own generalized
+    velocities, so the same pseudo-contact serves (between two bodies of the chain).  Refused: limits on a free-joint ROOT."""
+    import nimblephysics_amd as na
+    I = (0.003, 0.004, 0.005, 0, 0, 0)
+    lim = dict(pos_lo=(-0.4, -0.3, -0.5), pos_hi=(0.35, 0.45, 0.3), limit_enforced=True)
+    bodies = [na.BodySpec("base", -1, "revolute", "yaw", axis=(0, 1, 0), mass=1.0, inertia=I),
+              na.BodySpec("upper", 0, "ball", "shoulder", T_pj=na.make_transform((0.1, 0.2, 0)), T_cj=na.make_transform((0, 0.15, 0)), mass=0.6, inertia=I, **lim),
+              na.BodySpec("lower", 1, "revolute", "elbow", axis=(1, 0, 0), T_pj=na.make_transform((0, -0.15, 0)), T_cj=na.make_transform((0, 0.12, 0)),
+                          mass=0.4, inertia=I, pos_lo=(-0.2,), pos_hi=(0.6,), limit_enforced=True),
+              na.BodySpec("hand", 2, "free", "wrist", T_pj=na.make_transform((0, -0.12, 0)), mass=0.2, inertia=I,
+                          pos_lo=(-0.3, -0.3, -0.3, -0.05, -0.05, -0.05), pos_hi=(0.3, 0.3, 0.3, 0.05, 0.05, 0.05), limit_enforced=True)]
+    md = na.ModelDescription("limited_ball_arm", bodies, [], max_contacts=8)
+    s, a = _states(md, 512, 11, at_limit=0.25, spread=0.15)
+    _compare("ball / free joint limits", md, s, a, 12, min_limit=0.6)
+    root = na.ModelDescription("limited_root", [na.BodySpec("b", -1, "free", "root", mass=1.0, inertia=I, pos_lo=(-1,) * 6, pos_hi=(1,) * 6, limit_enforced=True)],
+                               [], max_contacts=8)
+    with pytest.raises(Exception, match="free-joint root"):
+        na.World(root, device="cuda:0")
+
+
 def test_limit_enforcement_needs_contact_slots_and_single_dof_joints():
     import ctypes as C
     import nimblephysics_amd as na

@@ -79,6 +79,9 @@ def mutator(mode):
                 if md.joint_ndof(i) == 1 and rng.random() < (0.5 if mode == "atlimit" else 0.35):
                     b.pos_lo, b.pos_hi = (-0.3,), (0.4,); b.vel_lo, b.vel_hi = (-0.7,), (0.9,); b.force_lo, b.force_hi = (-0.2,), (0.25,)
                     b.limit_enforced = mode == "limits"
+                elif mode == "limits" and md.joint_ndof(i) == 3 and b.joint_type == "ball" and rng.random() < 0.35:
+                    # limits on the exponential coordinates of a ball joint (JointLimitConstraint works on any joint's coordinates)
+                    b.pos_lo, b.pos_hi = (-0.3, -0.25, -0.35), (0.4, 0.3, 0.25); b.limit_enforced = True
             md = type(md)(md.name, md.bodies, md.boxes, gravity=md.gravity, dt=md.dt, max_contacts=md.max_contacts)
             fl = md.flat(); s = s.copy(); a = a.copy()
             for d in range(n):
