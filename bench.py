@@ -260,7 +260,7 @@ def main():
             run(warmup)
         sync()
         # per-kernel HIP events on a sample of the timed steps (every 8th): events around all ~12 launches of every step cost 8 %
-        timing_period = 8 if steps >= 32 else (4 if steps >= 8 else 1)
+        timing_period = 8 if steps >= 16 else (4 if steps >= 8 else 1)
         world.set_timing(kernel_timing, timing_period)
         # The timed region = EXACTLY `steps` steps between barrier + synchronize on both sides, max over ranks.  A short region (the
         # driver's --steps 20 is 12 ms) is a noisy sample: it is repeated until `min_seconds` have been timed (every rank takes the
