@@ -364,20 +364,22 @@ def test_independent_objects_are_solved_as_separate_constrained_groups():
     # corners (rank-deficient block) makes the reference's JOINT precise-inverse test (BackpropSnapshot.cpp:2964-2984) choose the full
     # pseudo-inverse derivative for both blocks; its extra terms are round-off amplified by |Q^+|^2 ~ 1e8 on the CFM block, so the
     # reference's gradient carries ~1e-4 of arithmetic noise there (it takes a few discrete values under 1-ulp perturbations, none
-    # of them privileged).  Those worlds are held to the next state strictly and to 2e-3 on the gradients; all others to the
-    # strict criterion.
+    # of them privileged).  Those worlds are held to the next state strictly and to 1e-5 on the gradients (2e-3 in round 2) unless the oracle's own
+    # gradient scatters by more than that under 1-ulp perturbations; all others to the strict criterion.
     noisy = (status & 0x18) != 0          # a group ended in stage 2 or 3: both carry the fallback CFM on their block
     assert (errs["next"][same] < TOL).all()
     loose = noisy & same
     gerr = np.maximum(errs["grad_state"], errs["grad_action"])
-    worse = np.where(loose & (gerr >= 2e-3))[0]
+    worse = np.where(loose & (gerr >= 1e-5))[0]      # (round 2 held these worlds to 2e-3; with the reference's velocity change in the record: 1 of 1554 above 1e-5)
+    print(f"[two cubes side by side] worlds with a CFM block: {int(loose.sum())}; their gradients above 1e-7 / 1e-5 / 2e-3: "
+          f"{int((loose & (gerr > 1e-7)).sum())} / {len(worse)} / {int((loose & (gerr > 2e-3)).sum())}")
     assert len(worse) <= 3                     # ... except where the oracle's own gradient scatters by more than that (non-standardised PGS results)
     prng = np.random.default_rng(3)
     for wd in worse:
         sp = s[wd][None] * (1.0 + prng.choice([-1.0, 0.0, 1.0], (64, s.shape[1])) * 2.220446049250313e-16)
         r = ow.step_batch(sp, np.repeat(a[wd][None], 64, 0), np.repeat(g[wd][None], 64, 0), threads=8)
         spread = max(np.abs(r[k] - ref[k][wd][None]).max() / scales[k] for k in ("grad_state", "grad_action"))
-        assert spread > 1e-3 and gerr[wd] < 5 * spread, (int(wd), float(gerr[wd]), float(spread))
+        assert spread > 1e-5 and gerr[wd] < 5 * spread, (int(wd), float(gerr[wd]), float(spread))
     strict = {k: np.where(loose, 0.0, e) for k, e in errs.items()}
     # (perturbations of up to 16 ulps here: the device's A differs from the oracle's in the last bits - world-frame against body-frame
     # impulse tests - and a Dantzig early exit that a 1-ulp change of the STATE does not reach can still be decided by those bits)
