@@ -162,6 +162,19 @@ typedef struct nbl_model_desc {
    * DifferentiableContactConstraint gives a non-contact constraint a zero constraint-force column (DCC.cpp:51-99), so the row drops out
    * of every Jacobian. */
   const int32_t* dof_limit_enforced;
+
+  /* ---- self-collision (appended; NULL = off, the reference's default: Skeleton::mEnabledSelfCollisionCheck is false) ----
+   * [n_bodies] bit 0: the body's skeleton checks self-collisions (Skeleton::enableSelfCollisionCheck), bit 1: also between adjacent
+   * bodies (enableAdjacentBodyCheck).  Two colliders of one skeleton are tested when bit 0 is set on both bodies and, unless bit 1
+   * is set, neither body is the other's parent (BodyNodeCollisionFilter::ignoresCollision, CollisionFilter.cpp:105-154).  A DOF
+   * above both bodies of such a contact moves it rigidly (DofContactType::SELF_COLLISION, DCC.cpp:116-130) and gets no
+   * constraint force from it (getControlForceMultiple 0). */
+  const int32_t* body_self_collision;
+  /* [n_boxes] (appended; NULL = the collider's body and that body's parent) the BodyNode a collider belongs to and that node's parent, in
+   * any numbering: "adjacent" above means box_node_parent[i] == box_node[j] or the reverse.  A caller that merges welded bodies before
+   * nbl_model_create passes the identities of the unmerged BodyNodes here (a body welded to its neighbour's child is not adjacent to it). */
+  const int32_t* box_node;
+  const int32_t* box_node_parent;
 } nbl_model_desc;
 
 #define NBL_SHAPE_BOX 0

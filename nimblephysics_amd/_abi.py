@@ -75,4 +75,7 @@ class ModelDesc(C.Structure):
         ("body_skeleton", _pi),
         ("pitch", _pd),
         ("dof_limit_enforced", _pi),
+        ("body_self_collision", _pi),
+        ("box_node", _pi),
+        ("box_node_parent", _pi),
     ]

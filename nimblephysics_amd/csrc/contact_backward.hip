@@ -90,7 +90,7 @@ DEV TangentFrame tangentFrameOf(V3 nrm) {
 // Adjoint terms of one contact row (k = 0 normal, 1 / 2 tangents) given Z_all = world twist of body A minus that of
 // body B under the joint rates z_row: what a position twist of a DOF on the vertex side / face side / edge A / edge B
 // contributes through dF/dq.
-struct RowTerms { V6 vertexTerm, faceTerm, edgeTermA, edgeTermB; };
+struct RowTerms { V6 vertexTerm, faceTerm, edgeTermA, edgeTermB; V3 commonAngular; };   // commonAngular: see CT_EDGE_EDGE below (self-collision)
 // CAPS: the model has capsule colliders (their contact types are compiled into that instantiation only: registers)
 template <bool CAPS = false>
 DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k, V3 d, V6 Zall) {
@@ -115,7 +115,7 @@ DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k,
   // edge-edge contacts (DCC.cpp:397-424, 700-735; math::getContactPointGradient Geometry.cpp:1129-1236):
   // the contact point is the midpoint of the closest points of the two edge lines, the normal follows
   // +-eB x eA.  Both are linear in the position twist [w; u] of the moving DOF; their adjoints:
-  out.edgeTermA = zero6(); out.edgeTermB = zero6();
+  out.edgeTermA = zero6(); out.edgeTermB = zero6(); out.commonAngular = mk3(0, 0, 0);
   V3 hN = mk3(0, 0, 0);   // cc . d(dir) = hN . dn for a normal that moves by dn (direction k follows through the tangent basis)
   if (R.type >= CT_EDGE_EDGE) {
     if (k == 0) hN = cc;
@@ -171,6 +171,27 @@ DEV RowTerms contactRowTerms(const ContactRec& R, const TangentFrame& TF, int k,
     lineAdjoint(cv, 0.5, 0.5);
     out.edgeTermA = mk6(cross(R.eAP, gPa) + cross(eAD, gDa) + sgnN * cross(eAD, cross(hN, eBD)), gPa);
     out.edgeTermB = mk6(cross(R.eBP, gPb) + cross(eBD, gDb) + sgnN * cross(eBD, cross(eAD, hN)), gPb);
+    // Self-collision: a DOF above BOTH bodies moves the contact rigidly in the reference (DofContactType::SELF_COLLISION: dn = w x n,
+    // DCC.cpp:594-610).  The two edge models add up to dn = sgn (eB x (w x eA) + (w x eB) x eA) = w x (sgn eB x eA) (Jacobi identity) - the
+    // edge normal model differentiates the UNNORMALISED cross product of the annotated edges, which is the contact normal only up to its
+    // length for a separating-axis edge contact and not at all for a clipped face contact annotated as an edge contact - so such a DOF is
+    // owed dn = w x (n - sgn eB x eA): hN . dn = w . ((n - sgn eB x eA) x hN), added at the lowest common ancestor of the two bodies
+    // (k_bwd_contact_b_coop).
+    out.commonAngular = cross(nrm - sgnN * cross(eBD, eAD), hN);
+    // ... and the point: the edge model moves the midpoint of the closest points of the two edge LINES (math::getContactPoint), the
+    // reference's SELF_COLLISION the contact point itself (gradientWrtTheta(point), DCC.cpp:336-340) - the same point for a pure
+    // edge-edge contact of the separating-axis test, not for the clipped face contacts that are annotated as edge contacts
+    // (DARTCollide.cpp:1280-1381): the DOF is owed dp = w x (p - p_model), cv . dp = w . ((p - p_model) x cv)
+    {
+      const V3 pv = R.eBP - R.eAP;
+      const double uaub = dot(eAD, eBD), q1 = dot(eAD, pv), q2 = -dot(eBD, pv), dd = 1 - uaub * uaub;
+      V3 pModel = 0.5 * (R.eAP + R.eBP);
+      if (dd > 0) {
+        const double e = 1.0 / dd, alpha = (q1 + uaub * q2) * e, beta = (uaub * q1 + q2) * e;
+        pModel = 0.5 * ((R.eAP + alpha * eAD) + (R.eBP + beta * eBD));
+      }
+      out.commonAngular = out.commonAngular + cross(p - pModel, cv);
+    }
   }
   // Capsule contacts (DCC.cpp:484-547 point, :819-938 normal).  PIPE_PIPE: the contact point divides the closest points of the two
   // axis lines by the radii, the normal is their difference normalised: the same line map with the weights (1, -1).

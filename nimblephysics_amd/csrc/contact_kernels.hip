@@ -28,7 +28,7 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
 }
 
 // The narrow phase of `wl` worlds x `ppw` lanes (threads tid < wl * ppw of the workgroup `bid`; any further threads of the workgroup
-// only take part in its barriers).  keptP: MAX_CONTACTS * 3 * 64 doubles, clipBuf: 48 * 64 doubles, stage: the staging area of the
+// only take part in its barriers).  keptP: SEEN_POINTS * 3 * 64 doubles, clipBuf: 48 * 64 doubles, stage: the staging area of the
 // ppw > 1 scheme - all LDS.  qFk != nullptr: the world transforms of the collider bodies are computed HERE from the positions (the
 // kernel runs next to the forward tree kernel, not after it) and the status word is left alone: the contact count goes to the record
 // with + 0.5 when contacts were dropped, k_contact_solve_coop raises NBL_ST_CONTACT / NBL_ST_CONTACT_OVERFLOW from it.
@@ -53,23 +53,35 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, bs, saved, &lay);
   const int ltid = extra ? 0 : tid;
   LaneBuf clip; clip.base = clipBuf + ltid;
-  int nC = 0;
+  int nC = 0, nDropped = 0;
   bool overflow = false, edge = false;
   // accept one candidate (lane pl == 0 of the world, or the only lane): postProcess + depth filter + append to the record
   auto acceptRec = [&](const double* ct, int stride, int pi) {   // ct: CR layout, element e at ct[e * stride]
     const V3 pt = mk3(ct[(CR_POINT + 0) * stride], ct[(CR_POINT + 1) * stride], ct[(CR_POINT + 2) * stride]);
     const V3 nr = mk3(ct[(CR_NORMAL + 0) * stride], ct[(CR_NORMAL + 1) * stride], ct[(CR_NORMAL + 2) * stride]);
     const double depth = ct[CR_DEPTH * stride];
-    // skip points within 3e-12 of an accepted contact (DARTCollisionDetector.cpp:360-400); the accepted points are kept in
-    // LDS (reading them back from the record would be a global round trip per comparison)
+    // skip points within 3e-12 of a contact already in the collision result (DARTCollisionDetector.cpp:360-400: postProcess compares with
+    // EVERY contact the detector has added so far - the constraint solver's depth / zero-normal filters come later, ConstraintSolver.cpp:
+    // 598-601 - so a point the depth filter drops still shadows a later contact at the same place: a sphere on the corner of a box whose
+    // corner is deep in the ground).  Seen points live in LDS: the kept contacts in slots 0 .. nC-1, dropped ones from the top down.
     bool close = false;
     for (int e = 0; e < nC; e++) {
       const V3 d = pt - mk3(keptP[(e * 3 + 0) * 64 + ltid], keptP[(e * 3 + 1) * 64 + ltid], keptP[(e * 3 + 2) * 64 + ltid]);
       if (norm3(d) < 3.0e-12) { close = true; break; }
     }
+    for (int e = SEEN_POINTS - nDropped; e < SEEN_POINTS && !close; e++) {
+      const V3 d = pt - mk3(keptP[(e * 3 + 0) * 64 + ltid], keptP[(e * 3 + 1) * 64 + ltid], keptP[(e * 3 + 2) * 64 + ltid]);
+      if (norm3(d) < 3.0e-12) close = true;
+    }
     if (close) return;
-    if (dot(nr, nr) < 1e-12) return;
-    if (depth < 0.0 || depth > cm->clippingDepth) return;
+    if (dot(nr, nr) < 1e-12 || depth < 0.0 || depth > cm->clippingDepth) {
+      if (nC + nDropped < SEEN_POINTS) {          // (a full list stops remembering dropped points: 16 seen points per world)
+        nDropped++;
+        const int e = SEEN_POINTS - nDropped;
+        keptP[(e * 3 + 0) * 64 + ltid] = pt.x; keptP[(e * 3 + 1) * 64 + ltid] = pt.y; keptP[(e * 3 + 2) * 64 + ltid] = pt.z;
+      }
+      return;
+    }
     if (nC >= cm->maxContacts) { overflow = true; return; }
     const int r0 = lay.contacts + nC * CR_SIZE;
     keptP[(nC * 3 + 0) * 64 + ltid] = pt.x; keptP[(nC * 3 + 1) * 64 + ltid] = pt.y; keptP[(nC * 3 + 2) * 64 + ltid] = pt.z;
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
                                                        uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists,
                                                        uint32_t* __restrict__ failCount, int ppw) {
   extern __shared__ __attribute__((aligned(16))) double stage[];   // [thread][8 candidates][CR_SIZE] + counts (ppw > 1 only)
-  __shared__ double keptP[MAX_CONTACTS * 3 * 64];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
+  __shared__ double keptP[SEEN_POINTS * 3 * 64];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
   __shared__ double clipBuf[48 * 64];               // clip polygons of boxBox, [entry][lane]
   contactDetectBody(mdl, bodies, cm, B, saved, lay, status, ws, doTwists, failCount, ppw, nullptr, (int)blockIdx.x, (int)blockDim.x / ppw,
                     keptP, clipBuf, stage);

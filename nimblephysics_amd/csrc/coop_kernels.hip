@@ -1306,6 +1306,27 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
     }
     w.sync();
   }
+  if (cm->selfCollision) {
+    // third pass (models with self-collision only): what a DOF above both bodies of an edge-edge contact is owed (contactRowTerms), added
+    // at the lowest common ancestor of the two bodies = the deepest body whose joint moves both (bodies are numbered parents first)
+    if (ln < MAX_ROWS) {
+      const bool both = any && CR.type == CT_EDGE_EDGE && CR.bA >= 0 && CR.bB >= 0;
+      const V3 ca = both ? RT.commonAngular : mk3(0, 0, 0);
+      tmp[0 * MAX_ROWS + ln] = ca.x; tmp[1 * MAX_ROWS + ln] = ca.y; tmp[2 * MAX_ROWS + ln] = ca.z;
+    }
+    w.sync();
+    if (ln < 3) {
+      for (int ci = 0; ci < nC; ci++) {
+        const int bA = cbody[ci], bB = cbody[MAX_CONTACTS + ci];
+        if (bA < 0 || bB < 0) continue;
+        const uint64_t common = cm->ancestors[bA] & cm->ancestors[bB];
+        if (common == 0ull) continue;
+        const int lca = 63 - __builtin_clzll(common);
+        D[lca * 54 + ln] += (tmp[ln * MAX_ROWS + 3 * ci] + tmp[ln * MAX_ROWS + 3 * ci + 1]) + tmp[ln * MAX_ROWS + 3 * ci + 2];
+      }
+    }
+    w.sync();
+  }
   NBL_PHASE(52);
   // ---- phase 1b (after the rows: TF takes over tmp's storage): local wrenches of the nine fields, world frame ----
   for (int item = ln; item < nb * 9; item += 64) {

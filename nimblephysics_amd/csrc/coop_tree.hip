@@ -386,8 +386,8 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
                                                           uint32_t* __restrict__ failCount, int ppw, int wl, int nDetect) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
   if ((int)blockIdx.x < nDetect) {
-    double* keptP = ldsTree;                              // MAX_CONTACTS * 3 * 64
-    double* clipBuf = keptP + MAX_CONTACTS * 3 * 64;      // 48 * 64
+    double* keptP = ldsTree;                              // SEEN_POINTS * 3 * 64
+    double* clipBuf = keptP + SEEN_POINTS * 3 * 64;       // 48 * 64
     double* stage = clipBuf + 48 * 64;
     // the body constants of the forward kinematics from LDS (the two feet of a world sit on different lanes: indexed per lane, the
     // constants would be ~190 dependent global loads per lane)

@@ -120,6 +120,7 @@ constexpr int MAX_CONTACTS = 8;              // per world (8 frictional contacts
 constexpr int MAX_ROWS = 3 * MAX_CONTACTS;
 constexpr int MAX_BOXES = 16;
 constexpr int MAX_PAIRS = 32;
+constexpr int SEEN_POINTS = 2 * 8;   // narrow phase: points the duplicate filter compares with (the kept contacts + unique points the depth filter dropped)
 constexpr int MAX_DOF_CONTACT = 64;   // lane = DOF in the wavefront kernels (round 2: 40)
 
 constexpr int SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CAPSULE = 2;   // NBL_SHAPE_*
@@ -140,7 +141,7 @@ struct DevContactModel {
   int32_t skelOf[64];       // per body: its skeleton (constrained groups unite skeletons, ConstraintSolver.cpp:724-780); < 64
   // joint-limit constraint rows (JointLimitConstraint.cpp; nbl_model_desc.dof_limit_enforced): the single-DOF joints that enforce a finite
   // position limit.  An active one becomes a pseudo-contact of the record (CT_LIMIT) after the world's contacts
-  int32_t nLimitDofs, padL;
+  int32_t nLimitDofs, selfCollision;   // selfCollision: some pair of colliders sits on one skeleton (body_self_collision)
   int32_t limitDof[MAX_DOF_CONTACT], limitBody[MAX_DOF_CONTACT];
   double limitLo[MAX_DOF_CONTACT], limitHi[MAX_DOF_CONTACT];
 };

@@ -192,7 +192,7 @@ namespace {
 // caller's description are mapped to the last body of each triple (the one that carries mass, colliders and children).
 struct ExpandedDesc {
   nbl_model_desc desc;
-  std::vector<int32_t> parent, jointType, dofOffset, boxBody, bodySkeleton, bodyMap, ballComp;
+  std::vector<int32_t> parent, jointType, dofOffset, boxBody, bodySkeleton, bodyMap, ballComp, bodySelf;
   std::vector<double> Tpj, Tcj, axis, mass, com, inertia, pitch;
 };
 constexpr int NBL_JOINT_FREE_CHAIN = 6;   // internal (= JT_FREEC): one of the six coincident axes of a free joint below the root
@@ -213,6 +213,7 @@ void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
     e.mass.push_back(mass); e.com.insert(e.com.end(), com ? com : z6, (com ? com : z6) + 3);
     e.inertia.insert(e.inertia.end(), inertia ? inertia : z6, (inertia ? inertia : z6) + 6);
     e.bodySkeleton.push_back(skel); e.ballComp.push_back(comp);
+    e.bodySelf.push_back(d->body_self_collision ? d->body_self_collision[srcBody] : 0);
     e.pitch.push_back(jt == NBL_JOINT_SCREW && d->pitch ? d->pitch[srcBody] : 0.1);
   };
   // skeleton ids: the caller's, or (default: one skeleton per tree) the root of the tree in the CALLER's numbering - any id shared by
@@ -256,6 +257,7 @@ void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
   e.desc.T_pj = e.Tpj.data(); e.desc.T_cj = e.Tcj.data(); e.desc.axis = e.axis.data();
   e.desc.mass = e.mass.data(); e.desc.com = e.com.data(); e.desc.inertia = e.inertia.data();
   e.desc.box_body = e.boxBody.data(); e.desc.body_skeleton = e.bodySkeleton.data(); e.desc.pitch = e.pitch.data();
+  e.desc.body_self_collision = e.bodySelf.data();
 }
 }  // namespace
 
@@ -428,8 +430,22 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     for (int i = 0; i + 1 < d->n_boxes; i++)
       for (int j = i + 1; j < d->n_boxes; j++) {
         int bi = d->box_body[i], bj = d->box_body[j];
-        if (bi == bj) continue;                       // same body (or both fixed to the world)
-        if (bi >= 0 && bj >= 0 && skelOf(bi) == skelOf(bj)) continue;  // same skeleton, self-collision disabled
+        // same body (or both fixed to the world) - unless the caller merged welded bodies and the two colliders belong to different
+        // BodyNodes of the reference (box_node): those are tested like any two bodies of a skeleton (their rows are empty: no relative motion)
+        if (bi == bj && !(bi >= 0 && d->box_node && d->box_node[i] != d->box_node[j])) continue;
+        if (bi >= 0 && bj >= 0 && skelOf(bi) == skelOf(bj)) {
+          // same skeleton (BodyNodeCollisionFilter::ignoresCollision, CollisionFilter.cpp:138-148): only with the self-collision check on, and
+          // without the adjacent-body check not between a body and its parent (the description's parent: a ball joint's / a free joint's
+          // chain of coincident bodies is one joint)
+          const int fi = d->body_self_collision ? d->body_self_collision[bi] : 0, fj = d->body_self_collision ? d->body_self_collision[bj] : 0;
+          if (!((fi & 1) && (fj & 1))) continue;
+          auto realParent = [&](int b) { if (ballModel) for (int k = expanded.ballComp[b]; k > 0; k--) b = d->parent[b]; return d->parent[b]; };
+          const bool adjacent = (d->box_node && d->box_node_parent)
+                                    ? (d->box_node_parent[i] == d->box_node[j] || d->box_node_parent[j] == d->box_node[i])
+                                    : (realParent(bi) == bj || realParent(bj) == bi);
+          if (!((fi & 2) && (fj & 2)) && adjacent) continue;
+          hc.selfCollision = 1;
+        }
         if ((hc.boxes[i].shape == NBL_SHAPE_CAPSULE) != (hc.boxes[j].shape == NBL_SHAPE_CAPSULE)
             && (hc.boxes[i].shape == NBL_SHAPE_BOX || hc.boxes[j].shape == NBL_SHAPE_BOX))
           return fail(NBL_E_UNSUPPORTED, "a capsule collider can meet a box collider: that pair runs libccd's MPR in the reference (DARTCollide.cpp:4422-4645), outside this path");
@@ -548,7 +564,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess) e = hipMemcpy(m->dDofs, hd.data(), sizeof(DevDof) * hd.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && hasContact) e = hipMalloc((void**)&m->dContact, sizeof(DevContactModel));
   if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
-  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -641,7 +657,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     // lanes per world of the narrow phase: the collider pairs of a world side by side (k_contact_detect / contactDetectBody)
     const int ppwD = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
     const int wlD = std::min(tl, 64 / ppwD);                       // worlds per narrow-phase workgroup
-    const size_t detectLds = ((size_t)MAX_CONTACTS * 3 * 64 + 48 * 64) * sizeof(double) +
+    const size_t detectLds = ((size_t)SEEN_POINTS * 3 * 64 + 48 * 64) * sizeof(double) +
                              (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0) +
                              (size_t)m->nb * sizeof(DevBody) + 32;   // + the body constants of the narrow phase's own forward kinematics
     const bool fusedDetect = m->hasContact && m->coopTree && saved && m->fusedDetect && std::max(treeLds, detectLds) <= 160u * 1024u;

@@ -69,6 +69,9 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
     bodies, boxes = [], []
     for si in range(world.getNumSkeletons()):
         sk = world.getSkeleton(si)
+        # Skeleton::isEnabledSelfCollisionCheck / isEnabledAdjacentBodyCheck (python/_nimblephysics/dynamics/Skeleton.cpp:505-533)
+        self_col = bool(sk.isEnabledSelfCollisionCheck()) if hasattr(sk, "isEnabledSelfCollisionCheck") else False
+        adj_col = bool(sk.isEnabledAdjacentBodyCheck()) if hasattr(sk, "isEnabledAdjacentBodyCheck") else False
         index = {}
         for bi in range(sk.getNumBodyNodes()):                 # skeleton order = parents before children = DOF order
             b = sk.getBodyNode(bi)
@@ -127,7 +130,7 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
             bodies.append(BodySpec(b.getName(), pidx, jtype, j.getName(), axis=axis,
                                    T_pj=_mat4(j.getTransformFromParentBodyNode()), T_cj=_mat4(j.getTransformFromChildBodyNode()),
                                    mass=float(b.getMass()), com=tuple(float(x) for x in np.asarray(b.getLocalCOM()).reshape(3)),
-                                   inertia=tuple(float(x) for x in m[4:10]), skeleton=si, **kw))
+                                   inertia=tuple(float(x) for x in m[4:10]), skeleton=si, self_collision=self_col, adjacent_body_check=adj_col, **kw))
             gidx = len(bodies) - 1
             index[b.getName()] = gidx
             for k in range(int(b.getNumShapeNodes())):

@@ -93,6 +93,8 @@ class BodySpec:
     axes: Sequence[Sequence[float]] = ()   # compound joints with free axes (universal: 2, translational2d: 2, planar: 2 in-plane axes)
     beta: Sequence[float] = (1.0, 1.0, 1.0)   # BodyNode::mBeta (BodyNode.cpp:1301 ctor default ones): the COM moves along beta under an INERTIA_COM_MU mass entry
     limit_enforced: bool = False   # Joint::isPositionLimitEnforced (JointAspect.hpp:165: off by default): the joint's position limits become LCP rows
+    self_collision: bool = False        # Skeleton::isEnabledSelfCollisionCheck of the body's skeleton (off by default): colliders of one skeleton meet
+    adjacent_body_check: bool = False   # Skeleton::isEnabledAdjacentBodyCheck: ... also those of a body and its parent
     skeleton: int = -1   # index of the dart Skeleton the body belongs to; -1 (every body of the model) = one skeleton per tree
     pitch: float = 0.1   # screw joints: translation along the axis per turn (ScrewJoint::mPitch, default 0.1)
 
@@ -162,7 +164,7 @@ def expand_compound_joints(bodies, boxes):
                 mass=b.mass if last else 0.0, com=tuple(b.com) if last else (0.0, 0.0, 0.0),
                 inertia=tuple(b.inertia) if last else (0.0,) * 6,
                 **{key: dof(getattr(b, key), i) for key in ("damping", "spring", "rest", "pos_lo", "pos_hi", "vel_lo", "vel_hi", "force_lo", "force_hi")},
-                friction=b.friction, beta=tuple(b.beta) if last else (1.0, 1.0, 1.0), limit_enforced=b.limit_enforced, skeleton=b.skeleton)
+                friction=b.friction, beta=tuple(b.beta) if last else (1.0, 1.0, 1.0), limit_enforced=b.limit_enforced, self_collision=b.self_collision, adjacent_body_check=b.adjacent_body_check, skeleton=b.skeleton)
             parent = len(out)
             out.append(nb)
         where.append(len(out) - 1)
@@ -179,6 +181,8 @@ class BoxSpec:
     mu: float = 1.0
     shape: str = "box"
     restitution: float = 0.0   # BodyNode restitution coefficient of the owning body (default 0: no bounce)
+    node: int = -1             # after merge_welds: the body of the ORIGINAL description that carried the collider (BodyNode identity for
+    node_parent: int = -2      # the adjacent-body rule of self-collision) and that body's parent there; -1 / -2: `body` and its parent
 
 
 def SphereSpec(body: int, T: np.ndarray, radius: float, mu: float = 1.0) -> "BoxSpec":
@@ -322,7 +326,9 @@ class ModelDescription:
             else:
                 t = target[bx.body]
                 Tb = T_in_target[bx.body] @ bx.T
-                boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu, bx.shape, bx.restitution))
+                node = bx.node if bx.node >= 0 else bx.body
+                boxes.append(BoxSpec(-1 if t < 0 else new_index[t], Tb, tuple(bx.size), bx.mu, bx.shape, bx.restitution, node,
+                                     bx.node_parent if bx.node >= 0 else bodies[bx.body].parent))
         m = ModelDescription(self.name, out, boxes, self.gravity, self.dt, self._action_map, self.max_contacts,
                              self.contact_clipping_depth, self.fallback_cfm, self.penetration_correction)
         return m
@@ -411,10 +417,33 @@ class ModelDescription:
         a["box_mu"] = np.array([bx.mu for bx in self.boxes], np.float64).reshape(nbx)
         a["box_shape"] = np.array([SHAPE_CODES[bx.shape] for bx in self.boxes], np.int32).reshape(nbx)
         a["box_restitution"] = np.array([bx.restitution for bx in self.boxes], np.float64).reshape(nbx)
+        a["box_node"] = np.array([bx.node if bx.node >= 0 else bx.body for bx in self.boxes], np.int32).reshape(nbx)
+        a["box_node_parent"] = np.array([bx.node_parent if bx.node >= 0 else (self.bodies[bx.body].parent if bx.body >= 0 else -1) for bx in self.boxes], np.int32).reshape(nbx)
         a["action_map"] = np.array(self.action_map, np.int32)
         a["body_skeleton"] = np.array(self.body_skeletons(), np.int32).reshape(nb)
         a["pitch"] = np.array([b.pitch for b in self.bodies], np.float64).reshape(nb)
+        a["body_self_collision"] = np.array([(1 if b.self_collision else 0) | (2 if b.adjacent_body_check else 0) for b in self.bodies], np.int32).reshape(nb)
         return a
+
+    def colliders_are_tested(self, bi: "BoxSpec", bj: "BoxSpec", skel=None) -> bool:
+        """BodyNodeCollisionFilter::ignoresCollision (CollisionFilter.cpp:105-154) for two colliders of this model: not on one body, not both
+        fixed to the world; on one skeleton only with self-collision enabled and, unless the adjacent-body check is on, not on a body
+        and its parent."""
+        ni, nj = (bi.node if bi.node >= 0 else bi.body), (bj.node if bj.node >= 0 else bj.body)
+        if bi.body == bj.body and (bi.body < 0 or ni == nj):
+            return False                      # (two BodyNodes welded into one body stay two nodes for this rule)
+        if bi.body < 0 or bj.body < 0:
+            return True
+        skel = self.body_skeletons() if skel is None else skel
+        if skel[bi.body] != skel[bj.body]:
+            return True
+        a, b = self.bodies[bi.body], self.bodies[bj.body]
+        if not (a.self_collision and b.self_collision):
+            return False
+        pi, pj = (bi.node_parent if bi.node >= 0 else a.parent), (bj.node_parent if bj.node >= 0 else b.parent)
+        if not (a.adjacent_body_check and b.adjacent_body_check) and (pi == nj or pj == ni):
+            return False
+        return True
 
     def capsule_meets_box(self) -> bool:
         """Some capsule collider is tested against some box collider (different bodies, not both fixed to the world, different skeletons:
@@ -422,11 +451,8 @@ class ModelDescription:
         skel = self.body_skeletons()
         for i, bi in enumerate(self.boxes):
             for bj in self.boxes[i + 1:]:
-                if {bi.shape, bj.shape} != {"capsule", "box"} or bi.body == bj.body:
-                    continue
-                if bi.body >= 0 and bj.body >= 0 and skel[bi.body] == skel[bj.body]:
-                    continue
-                return True
+                if {bi.shape, bj.shape} == {"capsule", "box"} and self.colliders_are_tested(bi, bj, skel):
+                    return True
         return False
 
     def to_desc(self):
@@ -444,7 +470,7 @@ class ModelDescription:
         def pi(x):
             return x.ctypes.data_as(C.POINTER(C.c_int32))
 
-        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape", "body_skeleton", "dof_limit_enforced"):
+        for k in ("parent", "joint_type", "dof_offset", "box_body", "action_map", "box_shape", "body_skeleton", "dof_limit_enforced", "body_self_collision", "box_node", "box_node_parent"):
             setattr(d, k, pi(a[k]))
         for k in ("T_pj", "T_cj", "axis", "mass", "com", "inertia", "damping", "spring", "rest", "pos_lo", "pos_hi",
                   "vel_lo", "vel_hi", "force_lo", "force_hi", "box_T", "box_size", "box_mu", "box_restitution", "pitch"):
@@ -464,7 +490,7 @@ class ModelDescription:
     def to_json(self) -> dict:
         def body(b: BodySpec):
             d = {k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple, list)) else v) for k, v in b.__dict__.items()
-                 if k != "axes" and not (k == "skeleton" and v < 0) and not (k == "beta" and tuple(v) == (1.0, 1.0, 1.0)) and not (k == "limit_enforced" and not v) and not (k == "pitch" and b.joint_type != "screw")}   # compound joints are already expanded: every stored joint has its single `axis`
+                 if k != "axes" and not (k == "skeleton" and v < 0) and not (k == "beta" and tuple(v) == (1.0, 1.0, 1.0)) and not (k in ("limit_enforced", "self_collision", "adjacent_body_check") and not v) and not (k == "pitch" and b.joint_type != "screw")}   # compound joints are already expanded: every stored joint has its single `axis`
             return d
         return {
             "name": self.name, "gravity": list(self.gravity), "dt": self.dt, "action_map": self._action_map,

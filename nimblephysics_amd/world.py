@@ -150,6 +150,22 @@ class World:
             if self._wrt_mass.entries:
                 self._push_inertia_params()
 
+    def setSelfCollisionCheck(self, enable: bool, adjacent_bodies: bool = False, skeletons=None):
+        """Skeleton::setSelfCollisionCheck / setAdjacentBodyCheck (Skeleton.cpp; off by default) on the given skeleton ids (default: all):
+        colliders of one skeleton meet, except - unless `adjacent_bodies` - those of a body and its parent."""
+        changed = False
+        for md in {id(self.description): self.description, id(self.model): self.model}.values():
+            ids = md.body_skeletons()
+            for b, sk in zip(md.bodies, ids):
+                if skeletons is None or sk in skeletons:
+                    if (b.self_collision, b.adjacent_body_check) != (bool(enable), bool(enable and adjacent_bodies)):
+                        b.self_collision, b.adjacent_body_check = bool(enable), bool(enable and adjacent_bodies)
+                        changed = True
+        if changed:
+            self._create_handle()
+            if self._wrt_mass.entries:
+                self._push_inertia_params()
+
     def getPositionLimitEnforced(self):
         return {b.joint_name or b.name: bool(b.limit_enforced) for b in self.description.bodies}
 

@@ -496,7 +496,13 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
       const BoxCollider &bi = m.boxes[i], &bj = m.boxes[j];
       if (bi.body == bj.body) continue;
       if (bi.body < 0 && bj.body < 0) continue;
-      if (bi.body >= 0 && bj.body >= 0 && m.skeleton[bi.body] == m.skeleton[bj.body]) continue;   // same skeleton: self-collision is off
+      if (bi.body >= 0 && bj.body >= 0 && m.skeleton[bi.body] == m.skeleton[bj.body]) {
+        // same skeleton (BodyNodeCollisionFilter::ignoresCollision, CollisionFilter.cpp:138-148): only with the self-collision check on, and
+        // without the adjacent-body check not between a body and its parent
+        const int fi = m.selfCollision[bi.body], fj = m.selfCollision[bj.body];
+        if (!((fi & 1) && (fj & 1))) continue;
+        if (!((fi & 2) && (fj & 2)) && (m.bodies[bi.body].parent == bj.body || m.bodies[bj.body].parent == bi.body)) continue;
+      }
       Iso Ti = bi.body >= 0 ? kin[bi.body].Tworld * bi.T : bi.T;
       Iso Tj = bj.body >= 0 ? kin[bj.body].Tworld * bj.T : bj.T;
       std::vector<Contact> pair;
@@ -511,6 +517,7 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
       else if (si) sphereBoxPair(true, bi.size[0], Ti, 0.5 * bj.size, Tj, m.clippingDepth, pair);
       else if (sj) sphereBoxPair(false, bj.size[0], Tj, 0.5 * bi.size, Ti, m.clippingDepth, pair);
       else boxBox(Ti, 0.5 * bi.size, Tj, 0.5 * bj.size, m.clippingDepth, pair);
+      if (getenv("NBO_DBG_COLLIDE")) fprintf(stderr, "[collide] pair (%d, %d) bodies (%d, %d): %d contacts\n", i, j, bi.body, bj.body, (int)pair.size());
       // postProcess: drop points closer than 3e-12 to an already accepted contact
       for (Contact& c : pair) {
         bool close = false;

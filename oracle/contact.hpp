@@ -290,6 +290,11 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     out.contacts.push_back(c);
   }
   const int C = (int)out.contacts.size();
+  if (getenv("NBO_DBG_COLLIDE")) {
+    fprintf(stderr, "[solveContacts] %d candidates, %d kept, %d limit rows:", (int)all.size(), C, L);
+    for (const Contact& c : all) fprintf(stderr, " (%d,%d depth %.4g |n|2 %.3g)", c.bodyA, c.bodyB, (double)c.depth, (double)dot(c.normal, c.normal));
+    fprintf(stderr, "\n");
+  }
   if (C == 0 && L == 0) return;
   if (C > 0) *status |= NBL_ST_CONTACT;
   if (L > 0) *status |= NBL_ST_JOINT_LIMIT;

@@ -41,6 +41,7 @@ struct Model {
   int maxContacts;
   s_t clippingDepth, fallbackCfm;
   bool penetrationCorrection = false;   // World::setPenetrationCorrectionEnabled (off by default)
+  std::vector<int> selfCollision;       // per body: bit 0 Skeleton::isEnabledSelfCollisionCheck, bit 1 isEnabledAdjacentBodyCheck
   std::vector<int> limitEnforced;       // per DOF: Joint::isPositionLimitEnforced of its joint (JointAspect.hpp:165: off by default)
 };
 
@@ -115,6 +116,8 @@ inline Model buildModel(const nbl_model_desc* d) {
   const double inf = INFINITY;
   cp(d->damping, m.damping, 0); cp(d->spring, m.spring, 0); cp(d->rest, m.rest, 0);
   cp(d->pos_lo, m.posLo, -inf); cp(d->pos_hi, m.posHi, inf);
+  m.selfCollision.assign(m.nb, 0);
+  if (d->body_self_collision) for (int i = 0; i < m.nb; i++) m.selfCollision[i] = d->body_self_collision[i];
   m.limitEnforced.assign(m.n, 0);
   if (d->dof_limit_enforced) for (int i = 0; i < m.n; i++) m.limitEnforced[i] = d->dof_limit_enforced[i] != 0;
   cp(d->vel_lo, m.velLo, -inf); cp(d->vel_hi, m.velHi, inf);

@@ -97,6 +97,8 @@ class _Skeleton:
     def __init__(self, md, idxs): self._md, self._idxs = md, idxs
     def getNumBodyNodes(self): return len(self._idxs)
     def getBodyNode(self, i): return _Body(self._md, self._idxs[i])
+    def isEnabledSelfCollisionCheck(self): return bool(self._md.bodies[self._idxs[0]].self_collision)
+    def isEnabledAdjacentBodyCheck(self): return bool(self._md.bodies[self._idxs[0]].adjacent_body_check)
 
 
 class StandInWorld:
@@ -190,6 +192,19 @@ def test_extraction_keeps_the_position_limit_enforcement_flag():
     assert [b.limit_enforced for b in got.bodies] == [True, True, False, True, True]
     assert got.flat()["dof_limit_enforced"].tolist() == [1, 1, 0, 1, 1]
     _same(got, md)
+
+
+def test_extraction_keeps_the_self_collision_flags_of_the_skeletons():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import folding_arm
+    for adjacent in (False, True):
+        md = folding_arm(True, "sphere", adjacent=adjacent)
+        got = model_from_nimble_world(StandInWorld(md), name=md.name, max_contacts=8)
+        assert all(b.self_collision and b.adjacent_body_check == adjacent for b in got.bodies)
+        assert got.flat()["body_self_collision"].tolist() == [3 if adjacent else 1] * 3
+        _same(got, md)
+    assert model_from_nimble_world(StandInWorld(folding_arm(False)), name="x", max_contacts=8).flat()["body_self_collision"].tolist() == [0, 0, 0]
 
 
 def test_extraction_keeps_capsules():

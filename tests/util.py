@@ -97,6 +97,21 @@ def ball_world(order="box_first", n_balls=1, radius=0.1, arm=False):
     return na.ModelDescription("balls", bodies, boxes, max_contacts=8)
 
 
+# ---- self-collision (tests/test_oracle_self_collision.py, tests/test_gpu_self_collision.py) ----
+def folding_arm(self_collision=True, tip="sphere", adjacent=False):
+    """A planar three-link arm (revolute joints about z, links of 0.3 m along their x axes, a box on each of the first two links) whose last
+    link folds back onto the FIRST one (q1 ~ 2.1, q2 ~ 1.9): a contact between two non-adjacent bodies of one skeleton, with joint 0 above
+    both of them.  tip: the collider of the last link, "sphere" or "box"."""
+    I = (0.002, 0.002, 0.002, 0, 0, 0)
+    kw = dict(self_collision=self_collision, adjacent_body_check=adjacent)
+    bodies = [na.BodySpec("l0", -1, "revolute", "j0", axis=(0, 0, 1), T_cj=na.make_transform((-0.15, 0, 0)), mass=1.0, inertia=I, **kw),
+              na.BodySpec("l1", 0, "revolute", "j1", axis=(0, 0, 1), T_pj=na.make_transform((0.15, 0, 0)), T_cj=na.make_transform((-0.15, 0, 0)), mass=0.8, inertia=I, **kw),
+              na.BodySpec("l2", 1, "revolute", "j2", axis=(0, 0, 1), T_pj=na.make_transform((0.15, 0, 0)), T_cj=na.make_transform((-0.15, 0, 0)), mass=0.6, inertia=I, **kw)]
+    cols = [na.BoxSpec(0, np.eye(4), (0.3, 0.06, 0.06), 0.8), na.BoxSpec(1, np.eye(4), (0.3, 0.06, 0.06), 0.8),
+            na.SphereSpec(2, na.make_transform((0.12, 0, 0)), 0.04, 0.8) if tip == "sphere" else na.BoxSpec(2, na.make_transform((0.1, 0, 0), rpy=(0.5, 0.3, 0.2)), (0.1, 0.06, 0.06), 0.8)]   # (tilted: no parallel edges)
+    return na.ModelDescription("folding_arm", bodies, cols, gravity=(0, -9.81, 0), max_contacts=8)
+
+
 # ---- joint-limit rows (tests/test_oracle_joint_limits.py, tests/test_gpu_joint_limits.py) ----
 def limited_arm(enforce=True, ground=False, n_links=4):
     """A prismatic base (vertical slide) carrying a chain of revolute links with position limits [-0.5, 0.4]; every joint enforces its

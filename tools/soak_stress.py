@@ -10,6 +10,10 @@ reduced size as tests/test_gpu_stress.py.
   atlimit positions, velocities and torques exactly at their limits in half of the worlds (clipLossGradientsToBounds)
   limits  like atlimit, and those joints ENFORCE their position limits (Joint::setPositionLimitEnforced): joint-limit rows in the LCP next to
           the contact rows (JointLimitConstraint.cpp), half of the limited DOFs exactly at a limit, a quarter beyond it
+  selfcol every skeleton checks self-collisions (Skeleton::enableSelfCollisionCheck), joint angles x 3 so that limbs fold onto each other:
+          contacts between two bodies of one tree, DOFs above both of them.  (Without the adjacent-body check: two bodies joined by ONE
+          single-DOF joint have a rank-1 Delassus block, and the reference's stage 0 then succeeds or fails with the last bit of A -
+          1e-15 of noise on the oracle's own A flips it, tools/dbg notes in DESIGN.md section 5 - which no perturbation of the STATE probes.)
   capsule every box collider becomes a capsule (radius = half its smallest side, cylinder height = its longest side, axis = that side's) and
           the ground a world-fixed sphere of radius 100 m with its top at y = 0 (a capsule cannot meet a box: libccd in the reference)
 usage (GPU box): python tools/soak_stress.py <mode> [first seed] [count] [B]"""
@@ -21,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits")
+MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits", "selfcol")
 
 
 def mutator(mode):
@@ -53,6 +57,18 @@ def mutator(mode):
         elif mode == "subset":
             keep = sorted(rng.choice(n, size=max(1, n // 3), replace=False).tolist())
             md.set_action_space(keep); a = a[:, :len(keep)]
+        elif mode == "selfcol":
+            for b in md.bodies:
+                b.self_collision = True
+            # (only the single-DOF joints: exponential coordinates near pi are where the ORACLE's finite-differenced integration Jacobian
+            #  loses its digits)
+            s = s.copy()
+            off = 0
+            for i in range(len(md.bodies)):
+                nd = md.joint_ndof(i)
+                if nd == 1:
+                    s[:, off] *= 3.0
+                off += nd
         elif mode == "capsule":
             import nimblephysics_amd as na
             g0 = md.boxes[0]
