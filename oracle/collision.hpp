@@ -517,7 +517,6 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
       else if (si) sphereBoxPair(true, bi.size[0], Ti, 0.5 * bj.size, Tj, m.clippingDepth, pair);
       else if (sj) sphereBoxPair(false, bj.size[0], Tj, 0.5 * bi.size, Ti, m.clippingDepth, pair);
       else boxBox(Ti, 0.5 * bi.size, Tj, 0.5 * bj.size, m.clippingDepth, pair);
-      if (getenv("NBO_DBG_COLLIDE")) fprintf(stderr, "[collide] pair (%d, %d) bodies (%d, %d): %d contacts\n", i, j, bi.body, bj.body, (int)pair.size());
       // postProcess: drop points closer than 3e-12 to an already accepted contact
       for (Contact& c : pair) {
         bool close = false;

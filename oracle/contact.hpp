@@ -290,11 +290,6 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     out.contacts.push_back(c);
   }
   const int C = (int)out.contacts.size();
-  if (getenv("NBO_DBG_COLLIDE")) {
-    fprintf(stderr, "[solveContacts] %d candidates, %d kept, %d limit rows:", (int)all.size(), C, L);
-    for (const Contact& c : all) fprintf(stderr, " (%d,%d depth %.4g |n|2 %.3g)", c.bodyA, c.bodyB, (double)c.depth, (double)dot(c.normal, c.normal));
-    fprintf(stderr, "\n");
-  }
   if (C == 0 && L == 0) return;
   if (C > 0) *status |= NBL_ST_CONTACT;
   if (L > 0) *status |= NBL_ST_JOINT_LIMIT;
@@ -563,7 +558,6 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   if (allStandardized) *status |= NBL_ST_STANDARDIZED;
   // the world-level classification vectors of the backward pass (BackpropSnapshot assembles the groups' matrices, :4215-4409;
   // clamping / upper-bound rows are numbered in row order here, which is a permutation of the reference's group-major order)
-  if (getenv("NBO_DBG_DROP_LIMIT")) for (int r = contactRows; r < mrows; r++) out.rowClass[r] = RC_NOT_CLAMPING;   // debugging aid
   out.clampingIndex.assign(mrows, -1); out.upperBoundIndex.assign(mrows, -1);
   out.numClamping = 0; out.numUpperBound = 0;
   for (int r = 0; r < mrows; r++) {
@@ -998,11 +992,6 @@ inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const 
   for (s_t x : imprecision.d) impNorm2 += x * x;
   MatX dQ_b = scaleX(codSolveMat(Q, dQ(Qinv_b)), -1.0);
   bool imprecise = !(impNorm2 < 1e-18);
-  if (const char* dbg = getenv("NBO_DBG_PRECISE")) {   // debugging aid: 0 / 1 force the branch, 2 prints the norm
-    if (dbg[0] == '0') imprecise = true;
-    if (dbg[0] == '1') imprecise = false;
-    if (dbg[0] == '2') fprintf(stderr, "[oracle] |I - Q Q^+|^2 = %.3e\n", (double)impNorm2);
-  }
   if (imprecise) {
     VecX ib = matvec(imprecision, bvec);
     dQ_b = addX(dQ_b, codSolveMat(Q, matmul(transposeX(Qinv), dQT(ib))));
