@@ -4,4 +4,4 @@ set -u
 for m in "" big multi balls far; do echo "parity:$m $(python tools/soak_parity.py 40000 300 256 $m 2>&1 | tail -1)"; done
 echo "warm $(python tools/soak_warm.py 41000 300 256 balls 2>&1 | tail -1)"
 echo "jacobians $(python tools/soak_jacobians.py 42000 100 4 2>&1 | tail -1)"
-for mode in dt tinydt fast torque mass nograv geom mu subset atlimit capsule limits; do echo "stress:$mode $(python tools/soak_stress.py $mode 43000 120 256 2>&1 | tail -1)"; done
+for mode in dt tinydt fast torque mass nograv geom mu subset atlimit capsule limits selfcol; do echo "stress:$mode $(python tools/soak_stress.py $mode 43000 120 256 2>&1 | tail -1)"; done
