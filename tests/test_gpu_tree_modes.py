@@ -95,3 +95,35 @@ def test_fused_cascade_launch_is_bit_identical_to_the_two_launches(monkeypatch):
         assert ((ra[1] & 0x2) == 0).float().mean() > 0.2            # the cascade is exercised
         for ta, tb in zip(ra, rb):
             assert torch.equal(ta, tb)
+
+
+FEATURE_MODES = [{"NBL_COOP_TREE": "0"}, {"NBL_COOP_FINAL": "0"}, {"NBL_SAVE_TREE": "0"}, {"NBL_FUSED_DETECT": "0"}, {"NBL_DETECT_SPLIT": "0"}]
+
+
+@pytest.mark.parametrize("mode", FEATURE_MODES, ids=["-".join(f"{k[4:]}={v}" for k, v in m.items()) for m in FEATURE_MODES])
+def test_round3_features_in_the_fallback_modes(mode, monkeypatch):
+    """Joint-limit rows next to contacts, capsule contacts and self-collision (the narrow phase appends the limit rows from the saved q
+    when it does not run inside the forward launch; the colliders' world transforms come from the tree block instead of the kernel's own
+    forward kinematics): every world against the oracle like in the default mode."""
+    for k, v in mode.items():
+        monkeypatch.setenv(k, v)
+    import test_gpu_capsules as tc
+    import test_gpu_joint_limits as tl
+    import test_gpu_self_collision as ts
+    from util import capsule_world, folding_arm, limited_arm
+    md = limited_arm(ground=True)
+    s, a = tl._states(md, 256, 5, at_limit=0.35)
+    s[:, 0] = np.random.default_rng(6).uniform(-0.025, 0.008, len(s))
+    tl._compare(f"limited arm on the ground {mode}", md, s, a, 7, min_limit=0.5, min_contact=0.3)
+    md = capsule_world(order="fixed_first", kinds=("capsule", "capsule", "sphere"))
+
+    def pose(rng):
+        y0 = 0.35 - rng.uniform(1e-3, 3e-3)
+        return [((0.0, np.pi / 2 + rng.normal(0, 0.02), 0.0), (0.0, y0, 0.0)),
+                ((np.pi / 2 + rng.normal(0, 0.05), 0.0, 0.0), (0.15 + rng.normal(0, 0.01), y0 + 0.1 + 0.1 + 0.2 - rng.uniform(1e-3, 3e-3), rng.normal(0, 0.01))),
+                (rng.normal(0, 0.3, 3), (-0.15 + rng.normal(0, 0.01), y0 + 0.1 + 0.1 - rng.uniform(1e-3, 3e-3), rng.normal(0, 0.01)))]
+    s, a = tc._states(md, pose, 128, 7)
+    tc._compare(f"capsule pile {mode}", md, s, a, 8, [13, 15])
+    md = folding_arm(True, "box")
+    s, a = ts._states(256, 1, 1.872, 2.14)
+    ts._compare(f"folding arm {mode}", md, s, a, 2, 0.7)
