@@ -68,7 +68,8 @@ extern "C" {
 #define NBL_ST_LCP_FAILED 0x20u   /* every stage failed its validity check: like the reference, the last stage's (frictionless PGS) iterate is applied as is
                                      (BoxedLcpConstraintSolver.cpp:590-676); the impulses are zeroed only if that iterate is non-finite (:678-687, NBL_ST_NAN) */
 #define NBL_ST_NAN 0x40u          /* non-finite value seen: in the LCP stages, or in the world's next state (NaN / Inf inputs); other worlds are unaffected */
-#define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts than max_contacts; extra ones dropped */
+#define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts (+ active joint-limit rows) than max_contacts: extra ones dropped; or a contact kept after 16
+                                        distinct points from the narrow phases (kept or dropped by the depth filter): the duplicate filter's memory */
 #define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
 #define NBL_ST_JOINT_LIMIT 0x400u  /* >=1 joint-limit constraint row was active (dof_limit_enforced) */
 #define NBL_ST_GRAD_PARTIAL 0x200u /* reserved (never set: the EDGE_EDGE contact-geometry gradient terms, DCC.cpp:397-424,
@@ -186,7 +187,12 @@ typedef struct nbl_model nbl_model; /* opaque */
 /* Human-readable text for the last error on this thread. */
 const char* nbl_last_error(void);
 
-/* Library/ABI version (major<<16 | minor). */
+/* Library/ABI version (major<<16 | minor).  The minor number counts the revisions that APPENDED fields to the model description struct: a NULL
+ * pointer / zero in an appended field always means "the behaviour before that field existed"; a caller that zero-initialises
+ * the struct and is compiled against this header keeps working, a caller compiled against minor k needs a library of minor >= k:
+ *   minor 1: the struct up to and including pitch;
+ *   minor 2: + dof_limit_enforced, body_self_collision, box_node, box_node_parent; NBL_SHAPE_CAPSULE; NBL_ST_JOINT_LIMIT. */
+#define NBL_ABI_MINOR 2
 int32_t nbl_version(void);
 
 /* Number of visible HIP devices (0 if none). */

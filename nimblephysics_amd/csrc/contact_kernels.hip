@@ -74,8 +74,11 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
       if (norm3(d) < 3.0e-12) close = true;
     }
     if (close) return;
+    // A full list cannot remember another point.  A contact that passes the depth filter after that may be the duplicate of a point that
+    // was not remembered: the world is flagged like one with too many contacts (NBL_ST_CONTACT_OVERFLOW).
+    const bool full = nC + nDropped >= SEEN_POINTS;
     if (dot(nr, nr) < 1e-12 || depth < 0.0 || depth > cm->clippingDepth) {
-      if (nC + nDropped < SEEN_POINTS) {          // (a full list stops remembering dropped points: 16 seen points per world)
+      if (!full) {
         nDropped++;
         const int e = SEEN_POINTS - nDropped;
         keptP[(e * 3 + 0) * 64 + ltid] = pt.x; keptP[(e * 3 + 1) * 64 + ltid] = pt.y; keptP[(e * 3 + 2) * 64 + ltid] = pt.z;
@@ -83,6 +86,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
       return;
     }
     if (nC >= cm->maxContacts) { overflow = true; return; }
+    if (full) { overflow = true; if (nDropped > 0) nDropped--; }   // (the kept point takes the slot of the last remembered dropped one)
     const int r0 = lay.contacts + nC * CR_SIZE;
     keptP[(nC * 3 + 0) * 64 + ltid] = pt.x; keptP[(nC * 3 + 1) * 64 + ltid] = pt.y; keptP[(nC * 3 + 2) * 64 + ltid] = pt.z;
 #pragma unroll

@@ -264,7 +264,7 @@ void expandBallJoints(const nbl_model_desc* d, ExpandedDesc& e) {
 extern "C" {
 
 const char* nbl_last_error(void) { return g_err.c_str(); }
-int32_t nbl_version(void) { return (0 << 16) | 1; }
+int32_t nbl_version(void) { return (0 << 16) | NBL_ABI_MINOR; }
 
 int32_t nbl_device_count(void) {
   int n = 0;

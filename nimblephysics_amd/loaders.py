@@ -188,6 +188,43 @@ def _text(el, tag, default=None, cast=float):
     return default if t is None or t.text is None else cast(t.text.strip())
 
 
+def _shape_inertia(geom, mass):
+    """Diagonal of Shape::computeInertia(mass) for a SKEL <geometry> element, shape kinds in readShape's order of tests
+    (SkelParser.cpp:1277-1316); None for a kind outside the list (plane, multi_sphere, mesh...)."""
+    def nums(e, tag):
+        return [float(x) for x in e.find(tag).text.split()]
+    e = geom.find("sphere")
+    if e is not None:                                # SphereShape.cpp:91-100
+        r, = nums(e, "radius")
+        return (2.0 / 5.0 * mass * r ** 2,) * 3
+    e = geom.find("box")
+    if e is not None:                                # BoxShape.cpp:74-83
+        x, y, z = nums(e, "size")
+        return (mass / 12.0 * (y ** 2 + z ** 2), mass / 12.0 * (x ** 2 + z ** 2), mass / 12.0 * (x ** 2 + y ** 2))
+    e = geom.find("ellipsoid")
+    if e is not None:                                # EllipsoidShape.cpp:125-140 (size = diameters)
+        a, bb, c = (x ** 2 for x in nums(e, "size"))
+        return (mass / 20.0 * (bb + c), mass / 20.0 * (a + c), mass / 20.0 * (a + bb))
+    e = geom.find("cylinder")
+    if e is not None:                                # CylinderShape.cpp:104-113
+        (r,), (h,) = nums(e, "radius"), nums(e, "height")
+        ixx = mass * (3.0 * r ** 2 + h ** 2) / 12.0
+        return (ixx, ixx, 0.5 * mass * r * r)
+    e = geom.find("capsule")
+    if e is not None:                                # CapsuleShape.cpp:107-131
+        (r,), (h,) = nums(e, "radius"), nums(e, "height")
+        v_cyl, v_sph = np.pi * r * r * h, 4.0 / 3.0 * np.pi * r ** 3
+        m_cyl, m_sph = mass * v_cyl / (v_cyl + v_sph), mass * v_sph / (v_cyl + v_sph)
+        ixx = m_cyl * (h * h / 12.0 + r * r / 4.0) + m_sph * (h * h + 3.0 / 8.0 * h * r + 0.4 * r * r)
+        return (ixx, ixx, m_cyl * (r * r / 2.0) + m_sph * (0.4 * r * r))
+    e = geom.find("cone")
+    if e is not None:                                # ConeShape.cpp:106-117
+        (r,), (h,) = nums(e, "radius"), nums(e, "height")
+        ixx = (3.0 / 20.0) * mass * (r * r + (2.0 / 3.0) * h * h)
+        return (ixx, ixx, (3.0 / 10.0) * mass * r * r)
+    return None
+
+
 def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_colliders=False):
     """Parse a SKEL world (`<skel><world>`: physics + skeletons) into ONE ModelDescription (all skeletons of the world in one
     model, like `with_ground`).  `skeletons`: names of the skeletons to keep (default: all), in file order.  Collision shapes other than
@@ -267,38 +304,18 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
             else:
                 I6 = (1.0, 1.0, 1.0, 0.0, 0.0, 0.0)
                 # the inertia of the body's FIRST ShapeNode for this mass (:618-645); visualization shapes are read before collision
-                # shapes (:612-616), so that is the first <visualization_shape> when there is one
-                shp = []
-                vis = b.find("visualization_shape")
-                if vis is not None:
-                    vg = vis.find("geometry")
-                    if vg is not None and vg.find("box") is not None:
-                        shp = [("box", tuple(float(x) for x in vg.find("box/size").text.split()), np.eye(4))]
-                    elif vg is not None and vg.find("ellipsoid") is not None:
-                        d = [float(x) for x in vg.find("ellipsoid/size").text.split()]
-                        if abs(d[0] - d[1]) <= 1e-12 and abs(d[0] - d[2]) <= 1e-12:
-                            shp = [("sphere", (d[0] / 2,) * 3, np.eye(4))]
-                        else:
-                            raise ValueError(f"{path}: default inertia of body {b.get('name')} from an anisotropic ellipsoid is outside the subset")
-                    elif vg is not None and vg.find("capsule") is not None:
-                        shp = [("capsule", (float(vg.find("capsule/radius").text), float(vg.find("capsule/height").text), 0.0), np.eye(4))]
-                    elif vg is not None and len(vg):
-                        raise ValueError(f"{path}: default inertia of body {b.get('name')} from a {vg[0].tag} visualization shape is outside the subset")
-                if not shp:
-                    shp = shapes_of(b)
-                if shp:
-                    kind, size, _ = shp[0]
-                    if kind == "box":                            # BoxShape::computeInertia (BoxShape.cpp:74-83)
-                        I6 = (mass / 12.0 * (size[1] ** 2 + size[2] ** 2), mass / 12.0 * (size[0] ** 2 + size[2] ** 2),
-                              mass / 12.0 * (size[0] ** 2 + size[1] ** 2), 0.0, 0.0, 0.0)
-                    elif kind == "capsule":                      # CapsuleShape::computeInertia (CapsuleShape.cpp:107-131)
-                        r, h = size[0], size[1]
-                        v_cyl, v_sph = np.pi * r * r * h, 4.0 / 3.0 * np.pi * r ** 3
-                        m_cyl, m_sph = mass * v_cyl / (v_cyl + v_sph), mass * v_sph / (v_cyl + v_sph)
-                        ixx = m_cyl * (h * h / 12.0 + r * r / 4.0) + m_sph * (h * h + 3.0 / 8.0 * h * r + 0.4 * r * r)
-                        I6 = (ixx, ixx, m_cyl * (r * r / 2.0) + m_sph * (0.4 * r * r), 0.0, 0.0, 0.0)
-                    else:                                        # sphere: 2/5 m r^2
-                        I6 = (0.4 * mass * size[0] ** 2,) * 3 + (0.0, 0.0, 0.0)
+                # shapes (:612-616), so that is the first <visualization_shape> when there is one - whether or not the shape is one
+                # the device can collide
+                first = b.find("visualization_shape")
+                if first is None:
+                    first = b.find("collision_shape")
+                geom = first.find("geometry") if first is not None else None
+                if geom is not None:
+                    d = _shape_inertia(geom, mass)
+                    if d is None and len(geom):
+                        raise ValueError(f"{path}: default inertia of body {b.get('name')} from a {geom[0].tag} shape is outside the subset")
+                    if d is not None:
+                        I6 = d + (0.0, 0.0, 0.0)
             return mass, com, I6
 
         # Assembly order = body and DOF order of the reference (readSkeleton :999-1040 with getNextJointAndNodePair :753-805): take the

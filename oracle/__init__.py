@@ -59,6 +59,10 @@ def _declare(lib):
     lib.nbo_action_jacobian.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int, pd]
     lib.nbo_set_lcp_cache.argtypes = [C.c_void_p, pd, C.c_int]
     lib.nbo_get_lcp_cache.argtypes = [C.c_void_p, pd, C.c_int]
+    lib.nbo_set_lcp_noise.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int]
+    lib.nbo_set_lcp_noise.restype = None
+    lib.nbo_set_lcp_forced.argtypes = [C.c_void_p, pd, C.c_int, C.c_int]
+    lib.nbo_set_lcp_forced.restype = None
     lib.nbo_get_lcp_cache.restype = C.c_int
     lib.nbo_mass_matrix.argtypes = [C.c_void_p, pd, pd]
     lib.nbo_coriolis_gravity.argtypes = [C.c_void_p, pd, pd, pd]
@@ -213,6 +217,22 @@ class OracleWorld:
     def integrate_positions(self, q, v):
         q, v = _arr(q), _arr(v); out = np.zeros(self.n)
         self._lib.nbo_integrate_positions(self._h, _p(q), _p(v), _p(out)); return out
+
+    def set_lcp_noise(self, ulps, seed=0, absolute=False):
+        """Test instrument, not the reference's behaviour: every entry of the LCP matrix A times 1 + j ulps 2^-52, j in {-1, 0, 1} per
+        entry and per solve - the A another order of the same sums could have given; absolute: j ulps 2^-52 max |A| ADDED to every
+        non-zero entry instead (the rounding error of entries that are sums with cancellation).  0 switches it off."""
+        self._lib.nbo_set_lcp_noise(self._h, int(ulps), int(seed), 1 if absolute else 0)
+
+    def set_lcp_forced(self, x=None, cfm_stage=False):
+        """Test instrument, not the reference's behaviour: x (one entry per LCP row) stands in for the OUTPUT of the solver stages 1 - 3
+        ("had Dantzig ended on this solution") where stage 0 fails; the step reports 0x40000000 when isLCPSolutionValid rejects it.
+        Registration, row classes, standardisation and the backward pass stay the reference's.  cfm_stage: x is the output of stage 2 (the
+        fallback CFM on the diagonal + PGS) instead of stage 1.  None switches it off."""
+        if x is None:
+            self._lib.nbo_set_lcp_forced(self._h, None, 0, 0)
+        else:
+            x = _arr(x); self._lib.nbo_set_lcp_forced(self._h, _p(x), len(x), 1 if cfm_stage else 0)
 
     def last_contacts(self):
         buf = np.zeros((64, 12))

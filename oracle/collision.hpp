@@ -488,7 +488,10 @@ inline int skeletonRoot(const Model& m, int body) {
   return body;
 }
 
-inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<Contact>& contacts) {
+// seenListOverflow (optional): set when a point that would pass the constraint solver's filters is dropped as the duplicate of a point
+// the DEVICE's duplicate filter could no longer remember (it keeps 16 distinct points per world, model_dev.hpp SEEN_POINTS) - there
+// the device keeps a contact the reference does not have and flags the world (NBL_ST_CONTACT_OVERFLOW).
+inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<Contact>& contacts, bool* seenListOverflow = nullptr) {
   contacts.clear();
   const int nbx = (int)m.boxes.size();
   for (int i = 0; i + 1 < nbx; i++)
@@ -520,8 +523,12 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
       // postProcess: drop points closer than 3e-12 to an already accepted contact
       for (Contact& c : pair) {
         bool close = false;
-        for (const Contact& t : contacts)
-          if (norm(c.point - t.point) < 3.0e-12) { close = true; break; }
+        for (size_t ti = 0; ti < contacts.size(); ti++)
+          if (norm(c.point - contacts[ti].point) < 3.0e-12) {
+            close = true;
+            if (ti >= 16 && seenListOverflow && dot(c.normal, c.normal) >= 1e-12 && c.depth >= 0.0 && c.depth <= m.clippingDepth) *seenListOverflow = true;
+            break;
+          }
         if (close) continue;
         c.boxA = i; c.boxB = j; c.bodyA = bi.body; c.bodyB = bj.body;
         contacts.push_back(c);

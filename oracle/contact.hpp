@@ -282,14 +282,20 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   if (m.boxes.empty() && L == 0) return;
   // ---- collision detection at q_t, filter by penetration depth (ConstraintSolver.cpp:563-613) ----
   std::vector<Contact> all;
-  collideAll(m, kin, all);
-  for (const Contact& c : all) {
+  bool seenListFull = false;
+  collideAll(m, kin, all, &seenListFull);
+  for (size_t ci = 0; ci < all.size(); ci++) {
+    const Contact& c = all[ci];
     if (dot(c.normal, c.normal) < 1e-12) continue;           // Contact::isZeroNormal
     if (c.depth < 0.0 || c.depth > m.clippingDepth) continue;
     if (c.bodyA < 0 && c.bodyB < 0) continue;                 // neither body reactive -> constraint inactive
+    // (the device's duplicate filter remembers 16 distinct points per world - model_dev.hpp SEEN_POINTS -, kept or dropped by the depth
+    //  filter: a contact kept after that flags the world, see below)
+    if (ci >= 16) seenListFull = true;
     out.contacts.push_back(c);
   }
   const int C = (int)out.contacts.size();
+  if (m.maxContacts > 0 && seenListFull) *status |= 0x80u;      // NBL_ST_CONTACT_OVERFLOW, see above
   if (C == 0 && L == 0) return;
   if (C > 0) *status |= NBL_ST_CONTACT;
   if (L > 0) *status |= NBL_ST_JOINT_LIMIT;
@@ -297,6 +303,7 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   // them (like the reference) and raises the same flag, so that a comparison knows which worlds the device truncated.
   // (a joint-limit row takes one contact slot of the device)
   if (m.maxContacts > 0 && C + L > m.maxContacts) *status |= 0x80u;   // NBL_ST_CONTACT_OVERFLOW
+
 
   // body velocities at the post-ABA, pre-contact velocity (ContactConstraint::getRelVelocity)
   std::vector<Kin> kinPre;
@@ -432,6 +439,25 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
         }
     }
   }
+  if (m.lcpNoiseUlps > 0) {                                       // test instrument, see Model::lcpNoiseUlps
+    const uint64_t sample = m.lcpNoiseSample++;
+    s_t amax = 0;
+    for (int i = 0; i < mrows; i++) for (int j = 0; j < mrows; j++) amax = std::max(amax, std::fabs(out.A(i, j)));
+    for (int i = 0; i < mrows; i++)
+      for (int j = i; j < mrows; j++) {
+        uint64_t h = m.lcpNoiseSeed * 0x9E3779B97F4A7C15ull + sample * 0xBF58476D1CE4E5B9ull + (uint64_t)(i * 64 + j) * 0x94D049BB133111EBull;
+        h ^= h >> 31; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29;
+        const s_t e = (s_t)((int)(h % 3) - 1) * (s_t)m.lcpNoiseUlps * 2.220446049250313e-16;
+        if (m.lcpNoiseAbsolute) {
+          if (out.A(i, j) == 0 && out.A(j, i) == 0) continue;   // structural zeros (rows of other constrained groups, decoupled rows) stay
+          out.A(i, j) += e * amax;
+          if (j != i) out.A(j, i) += e * amax;
+        } else {
+          out.A(i, j) *= 1.0 + e;
+          if (j != i) out.A(j, i) *= 1.0 + e;
+        }
+      }
+  }
 
   // ---- constraint forces in joint space: A_c columns (DCC.cpp:231-270, 2961-2988; Joint.cpp:1176-1181) ----
   // (a joint-limit constraint is not a contact constraint: DifferentiableContactConstraint gives it a zero world force, DCC.cpp:51-99,
@@ -529,7 +555,13 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     if (success) Xg = g.X;
     else allStage0 = false;
     // stages 1-3 (:461-687)
-    if (!success) {
+    if (!success && (int)m.lcpForced.size() == mrows) {              // test instrument, see Model::lcpForced
+      for (int i = 0; i < mg; i++) Xg[i] = m.lcpForced[idx[i]];
+      MatX Av = sub.A;
+      if (m.lcpForcedCfm) { cfm = m.fallbackCfm; for (int i = 0; i < mg; i++) { Av(i, i) += cfm; aGrad(i, i) += cfm; } }
+      if (isLCPSolutionValid(Av, Xg, sub.b, sub.hi, sub.lo, sub.findex, false)) *status |= m.lcpForcedCfm ? NBL_ST_LCP_PGS : NBL_ST_LCP_PIVOT;
+      else *status |= 0x40000000u;
+    } else if (!success) {
       uint32_t st13 = 0;
       lcpCascade(sub.A, sub.b, sub.lo, sub.hi, sub.findex, XBackup, m.fallbackCfm, Xg, cfm, hadToIgnoreFriction, st13);
       *status |= st13;

@@ -226,6 +226,18 @@ void nbo_set_lcp_cache(void* h, const double* x, int len) {
   if (len <= 0) o->lcpCache.clear();
   else o->lcpCache.assign(x, x + len);
 }
+// test instrument (Model::lcpNoiseUlps): ulps = 0 switches it off
+void nbo_set_lcp_noise(void* h, int ulps, uint64_t seed, int absolute) {
+  Oracle* o = (Oracle*)h;
+  o->model.lcpNoiseUlps = ulps; o->model.lcpNoiseSeed = seed; o->model.lcpNoiseSample = 0; o->model.lcpNoiseAbsolute = absolute != 0;
+}
+// test instrument (Model::lcpForced): len <= 0 switches it off
+void nbo_set_lcp_forced(void* h, const double* x, int len, int cfmStage) {
+  Oracle* o = (Oracle*)h;
+  o->model.lcpForcedCfm = cfmStage != 0;
+  if (len <= 0) o->model.lcpForced.clear();
+  else o->model.lcpForced.assign(x, x + len);
+}
 int nbo_get_lcp_cache(void* h, double* x, int cap) {
   Oracle* o = (Oracle*)h;
   int len = (int)o->lcpCache.size();
@@ -309,6 +321,7 @@ int nbo_step_batch(void* h, int64_t B, const double* state, const double* action
       o.model = m;
       // contiguous chunk of worlds per thread (one cloned world per thread stepping its share)
       const int64_t per = (B + threads - 1) / threads, b0 = t * per, b1 = std::min<int64_t>(B, b0 + per);
+      o.model.lcpNoiseSample = (uint64_t)b0;
       for (int64_t b = b0; b < b1; b++) {
         if (lcpIn && lcpLenIn && lcpLenIn[b] > 0) o.lcpCache.assign(lcpIn + b * lcpStride, lcpIn + b * lcpStride + lcpLenIn[b]);
         else o.lcpCache.clear();

@@ -114,6 +114,51 @@ int shim_coop_stage0_masked(int m, const double* A, const double* b, const doubl
   return ret;
 }
 
+// the same two with joint-limit rows (CoopRow::lim / neg / limMask as coopLoadRow<true> sets them): limMask = the limit rows, negMask = the
+// ones carried negated (upper limits); A, b in the device's form (those rows and columns already negated)
+int shim_coop_stage0_lim(int m, const double* A, const double* b, const double* mu, unsigned mask, unsigned limMask, unsigned negMask,
+                         double* X, double* X0, int* cls, double* E) {
+  static CoopLds S;
+  int ret = 0;
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopRow R;
+    fillRow(R, ln, m, A, b, mu);
+    R.on = R.on && ((mask >> ln) & 1u);
+    R.lim = ln < 32 && ((limMask >> ln) & 1u); R.neg = ln < 32 && ((negMask >> ln) & 1u); R.limMask = limMask;
+    CoopStage0 out;
+    coopStage0(w, S, R, false, 0.0, out);
+    if (ln < MAXR) { X[ln] = out.X; X0[ln] = out.X0; cls[ln] = out.K.cls; E[ln] = out.K.E; }
+    if (ln == 0) ret = (out.ok ? 1 : 0) | (out.pinvValid ? 2 : 0);
+  });
+  return ret;
+}
+int shim_coop_cascade_lim(int m, const double* A, const double* b, const double* mu, const double* x0, unsigned mask, unsigned limMask,
+                          unsigned negMask, double fallbackCfm, double* X, double* cfmOut, int* stages) {
+  static CascadeLds C1;
+  static PgsLds C2, C3;
+  uint32_t stOut = 0;
+  emuRunWave([&](const EmuWave& w) {
+    const int ln = w.lane();
+    CoopRow R;
+    fillRow(R, ln, m, A, b, mu);
+    R.on = R.on && ((mask >> ln) & 1u);
+    R.lim = ln < 32 && ((limMask >> ln) & 1u); R.neg = ln < 32 && ((negMask >> ln) & 1u); R.limMask = limMask;
+    const double X0 = R.on ? x0[ln] : 0.0;
+    CoopStageResult r1, r2, r3;
+    coopCascadeStage1(w, C1, R, X0, r1);
+    coopCascadeStage2(w, C2, R, X0, fallbackCfm, r2);
+    coopCascadeStage3(w, C3, R, X0, fallbackCfm, r3);
+    double x, cfm;
+    bool noFric;
+    uint32_t st;
+    coopCascadeChoose(w, m, X0, fallbackCfm, r1, r2, r3, x, cfm, noFric, st);
+    if (ln < MAXR) X[ln] = x;
+    if (ln == 0) { stOut = st; *cfmOut = cfm; stages[0] = r1.flags; stages[1] = r2.flags; stages[2] = r3.flags; }
+  });
+  return (int)stOut;
+}
+
 // the one-world-per-lane statement (laneStage0 of lcp_dev.hpp) on the same problem
 int shim_lane_stage0(int m, const double* A, const double* b, const double* mu, int haveCache, const double* xcache,
                      double* X, double* X0, int* cls, double* E) {

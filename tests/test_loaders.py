@@ -343,3 +343,22 @@ def test_skel_capsule_colliders(tmp_path):
     md.boxes.append(na.CapsuleSpec(1, np.eye(4), 0.05, 0.4))
     with pytest.raises(ValueError, match="capsule"):
         md.flat()
+
+
+@pytest.mark.parametrize("geometry, expect", [
+    ("<sphere><radius>0.3</radius></sphere>", (2 / 5 * 2 * 0.09,) * 3),                                                  # SphereShape.cpp:91-100
+    ("<ellipsoid><size>0.2 0.4 0.6</size></ellipsoid>", (2 / 20 * (0.16 + 0.36), 2 / 20 * (0.04 + 0.36), 2 / 20 * (0.04 + 0.16))),   # EllipsoidShape.cpp:125-140
+    ("<cylinder><radius>0.1</radius><height>0.5</height></cylinder>", (2 * (0.03 + 0.25) / 12,) * 2 + (0.5 * 2 * 0.01,)),   # CylinderShape.cpp:104-113
+    ("<cone><radius>0.1</radius><height>0.5</height></cone>", (3 / 20 * 2 * (0.01 + 2 / 3 * 0.25),) * 2 + (3 / 10 * 2 * 0.01,)),  # ConeShape.cpp:106-117
+])
+def test_skel_default_inertia_of_every_shape_kind_the_reference_reads(tmp_path, geometry, expect):
+    """A body with a mass and no <moment_of_inertia> gets computeInertia(mass) of its first ShapeNode (SkelParser.cpp:620-645) - of every
+    shape kind readShape knows (:1277-1316), also the ones that are visual only here."""
+    f = tmp_path / "s.skel"
+    f.write_text(f"""<?xml version="1.0" ?><skel version="1.0"><world name="w"><physics><time_step>0.001</time_step><gravity>0 -9.81 0</gravity></physics>
+      <skeleton name="s"><body name="b"><inertia><mass>2</mass><offset>0 0 0</offset></inertia>
+        <visualization_shape><transformation>0 0 0 0 0 0</transformation><geometry>{geometry}</geometry></visualization_shape></body>
+      <joint type="revolute" name="j"><parent>world</parent><child>b</child><axis><xyz>0 0 1</xyz></axis></joint></skeleton></world></skel>""")
+    md = na.load_skel(str(f))
+    assert np.allclose(md.bodies[0].inertia, expect + (0.0, 0.0, 0.0), rtol=1e-14, atol=0)
+    assert md.bodies[0].mass == 2.0

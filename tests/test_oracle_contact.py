@@ -447,3 +447,37 @@ def test_sphere_narrow_phases_equal_the_references_own_functions_on_random_pairs
     # box-sphere and sphere-box with 1, 2, 3 locked faces, the centre-inside cases (plain vertex-face types), sphere-sphere
     for key in [(0, 5, 1), (0, 5, 2), (0, 5, 3), (1, 4, 1), (1, 4, 2), (1, 4, 3), (0, 2, 0), (1, 1, 0), (2, 6, 0)]:
         assert seen.get(key, 0) > 5, (key, seen)
+
+
+def test_the_soak_instruments_leave_the_oracle_alone_when_off_and_replay_its_own_solution():
+    """OracleWorld.set_lcp_noise / set_lcp_forced are instruments of the randomised soaks (tools/soak_parity.py), not reference behaviour:
+    switched off they change nothing; one-ulp noise on A leaves a well-posed world's answer within 1e-9; the oracle's OWN cascade
+    solution forced back in as the solver's output reproduces next state and gradients bit for bit; a solution that violates the LCP is
+    refused (0x40000000)."""
+    md, s, a = contact_inputs("atlas20", 64, 7, joint_noise=0.05)
+    g = np.random.default_rng(0).normal(0, 1, s.shape)
+    w = OracleWorld(md)
+    ref = w.step_batch(s, a, g, threads=2)
+    cascade = [i for i in range(len(s)) if (ref["status"][i] & 0xC) and not (ref["status"][i] & 0x10)]
+    assert cascade, "no world of the sample resolves at the pivoting or the CFM + PGS stage"
+    w.set_lcp_noise(1, 5)
+    noisy = w.step_batch(s, a, g, threads=2)
+    w.set_lcp_noise(0)
+    again = w.step_batch(s, a, g, threads=2)
+    for k in ("next", "grad_state", "grad_action"):
+        assert np.array_equal(again[k], ref[k])
+    stage0 = (ref["status"] & 0x2) != 0
+    assert stage0.any() and np.abs(noisy["next"][stage0] - ref["next"][stage0]).max() < 1e-9
+    i = cascade[0]
+    w.reset_lcp_cache(); nx = w.step(s[i], a[i]); x = w.last_lcp()["x"].copy(); gs, ga = w.backprop(g[i])
+    pgs = bool(ref["status"][i] & 0x8)
+    w.reset_lcp_cache(); w.set_lcp_forced(x, cfm_stage=pgs)
+    nx2 = w.step(s[i], a[i]); st2 = w.last_status; gs2, ga2 = w.backprop(g[i])
+    assert not (st2 & 0x40000000) and (st2 & (0x8 if pgs else 0x4))
+    assert np.array_equal(nx, nx2) and np.array_equal(gs, gs2) and np.array_equal(ga, ga2)
+    w.reset_lcp_cache(); w.set_lcp_forced(-np.abs(x) - 1.0)
+    w.step(s[i], a[i])
+    assert w.last_status & 0x40000000
+    w.set_lcp_forced(None)
+    w.reset_lcp_cache()
+    assert np.array_equal(w.step(s[i], a[i]), nx)

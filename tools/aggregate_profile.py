@@ -20,7 +20,7 @@ def find(sub, pat):
     fs = glob.glob(os.path.join(P, f"{tag}_{sub}", "**", pat), recursive=True)
     if not fs:
         raise SystemExit(f"no {pat} under {tag}_{sub}")
-    return fs[0]
+    return max(fs, key=os.path.getmtime)   # several runs of one tag leave one file each: the latest
 
 
 stats = find("stats", "*kernel_stats.csv")

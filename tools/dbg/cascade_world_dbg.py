@@ -1,5 +1,5 @@
 """Debug: the PRODUCT's device cascade (host emulation, tests/host_shim) on the LCP of one soak world as the oracle built it, group by group.
-usage: python tools/dbg/cascade_world_dbg.py <seed> <world> [big|multi|balls]"""
+usage: python tools/dbg/cascade_world_dbg.py <seed> <world> [big|multi|balls] [stress mode of tools/soak_stress.py]"""
 import ctypes as C
 import os, sys, types
 import numpy as np
@@ -14,6 +14,9 @@ _p = lambda a: a.ctypes.data_as(pd)
 _pi = lambda a: a.ctypes.data_as(pi)
 seed, wd = int(sys.argv[1]), int(sys.argv[2]); mode = sys.argv[3] if len(sys.argv) > 3 else ""
 md, s, a, g = mod.make_case(seed, 256, big=mode == "big", multi=mode == "multi", balls=mode == "balls")
+if len(sys.argv) > 4:
+    import soak_stress
+    md, s, a, g = soak_stress.mutator(sys.argv[4])(seed, md, s, a, g)
 ow = OracleWorld(md)
 ow.step(s[wd], a[wd])
 L = ow.last_lcp()

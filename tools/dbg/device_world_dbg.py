@@ -10,6 +10,9 @@ from oracle import OracleWorld
 import soak_parity
 seed, wd = int(sys.argv[1]), int(sys.argv[2]); mode = sys.argv[3] if len(sys.argv) > 3 else ""
 md, s, a, g = soak_parity.make_case(seed, 256, big=mode == "big", multi=mode == "multi", balls=mode == "balls")
+if len(sys.argv) > 4:
+    import soak_stress
+    md, s, a, g = soak_stress.mutator(sys.argv[4])(seed, md, s, a, g)
 B = 64
 S = np.repeat(s[wd][None], B, 0); A_ = np.repeat(a[wd][None], B, 0)
 world = na.World(md, device="cuda:0"); ow = OracleWorld(md)
@@ -35,10 +38,17 @@ print("device cfm", rows[cfm_row:cfm_row + 3 * nc, 0])
 dense = 2 * MAXR * MAXR + 2 * n * MAXR
 dn = sv[total * B: total * B + dense * B].reshape(B, dense)[0]
 Ad = dn[:MAXR * MAXR].reshape(MAXR, MAXR)[:3 * nc, :3 * nc]
-Ao = L["A"] - (md.fallback_cfm * np.eye(m) if ow.last_status & 0x18 else 0)
-print("max |A dev - A oracle|", np.abs(Ad - Ao).max() if Ad.shape == Ao.shape else (Ad.shape, Ao.shape), "scale", np.abs(Ao).max())
+Ao_c = L["A"] - (md.fallback_cfm * np.eye(m) if ow.last_status & 0x18 else 0)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from lcp_layout import to_device_layout
+D = to_device_layout(L, Ao_c, len(ow.last_contacts()))
+Ao = D["A"][:3 * nc, :3 * nc]
+print("oracle in device layout: rows", D["rows"], "limMask", hex(D["limMask"]), "negMask", hex(D["negMask"]))
+print("max |A dev - A oracle|", np.abs(Ad - Ao).max() if D["rows"] == 3 * nc else ("rows differ", 3 * nc, D["rows"]), "scale", np.abs(Ao).max())
+print("max |b dev - b oracle|", np.abs(rows[b_row:b_row + 3 * nc, 0] - D["b"][:3 * nc]).max())
 np.set_printoptions(linewidth=200, precision=6)
-print("A device\n", Ad); print("A oracle\n", Ao)
+if os.environ.get("PRINT_A"):
+    print("A device\n", Ad); print("A oracle\n", Ao)
 for c in range(nc):
     r0 = contacts + c * CR
     print("contact", c, rows[r0:r0 + CR, 0])
@@ -51,15 +61,23 @@ _pi = lambda a: a.ctypes.data_as(pi)
 shim = C.CDLL(os.path.join(ROOT, "tests", "host_shim", "libcoop_shim.so"))
 for name, Ause in (("device A", Ad), ("oracle A", Ao)):
     A24 = np.zeros((24, 24)); A24[:3 * nc, :3 * nc] = Ause; b24 = np.zeros(24); b24[:3 * nc] = rows[b_row:b_row + 3 * nc, 0]
-    mu = np.ones(8)
-    for c in range(nc):
-        mu[c] = L["hi"][3 * c + 1] if L["findex"][3 * c + 1] >= 0 else 0.0
-    mask = (1 << (3 * nc)) - 1
-    X = np.zeros(24); X0 = np.zeros(24); cls = np.zeros(24, np.int32); E = np.zeros(24)
-    ret = shim.shim_coop_stage0_masked(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), C.c_uint(mask), _p(X), _p(X0), _pi(cls), _p(E))
-    Xc = np.zeros(24); Xs = np.zeros(24); cls2 = np.zeros(24, np.int32); cfm = C.c_double(0)
-    stt = shim.shim_coop_cascade_masked(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), _p(X0), C.c_uint(mask), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _p(Xs), _pi(cls2))
-    print(name, ": sv", np.linalg.svd(Ause, compute_uv=False), "asym", np.abs(Ause - Ause.T).max())
-    print(name, ": X0", X0[:3 * nc])
-    print(name, ": emulation stage0 ok", ret & 1, "cascade status", hex(stt), "x", Xc[:3 * nc])
+    mu = D["mu"]
+    grp = list(range(nc))
+    for i in range(nc):
+        for j in range(nc):
+            if np.abs(A24[3 * i:3 * i + 3, 3 * j:3 * j + 3]).max() > 0:
+                gi, gj = grp[i], grp[j]
+                grp = [gi if x == gj else x for x in grp]
+    for gid in sorted(set(grp)):
+      mask = sum(7 << (3 * c) for c in range(nc) if grp[c] == gid)
+      print("group", gid, "mask", hex(mask))
+      X = np.zeros(24); X0 = np.zeros(24); cls = np.zeros(24, np.int32); E = np.zeros(24)
+      ret = shim.shim_coop_stage0_lim(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), C.c_uint(mask), C.c_uint(D["limMask"]), C.c_uint(D["negMask"]), _p(X), _p(X0), _pi(cls), _p(E))
+      Xc = np.zeros(24); Xs = np.zeros(24); cls2 = np.zeros(24, np.int32); cfm = C.c_double(0)
+      stg = np.zeros(3, np.int32)
+      stt = shim.shim_coop_cascade_lim(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), _p(X0), C.c_uint(mask), C.c_uint(D["limMask"]), C.c_uint(D["negMask"]), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _pi(stg))
+      print("stage flags", stg)
+      print(name, ": sv", np.linalg.svd(Ause, compute_uv=False), "asym", np.abs(Ause - Ause.T).max())
+      print(name, ": X0", X0[:3 * nc])
+      print(name, ": emulation stage0 ok", ret & 1, "cascade status", hex(stt), "x", Xc[:3 * nc])
 print("mu", mu[:nc], [ (bx.mu, bx.body) for bx in md.boxes])

@@ -14,17 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "build", "variants")
 VARIANTS = {
     "base": [],
-    "cfinal2": ["-DNBL_W_CFINAL=2"],
-    "bwda2": ["-DNBL_W_BWDA=2"],
-    "solve3": ["-DNBL_W_SOLVE=3"],
-    "fwd3": ["-DNBL_W_FWD=3"],
     "bwdb3": ["-DNBL_W_BWDB=3"],
     "recomp3": ["-DNBL_W_RECOMP=3"],
     "bfinal3": ["-DNBL_W_BFINAL=3"],
-    "stages4": ["-DNBL_W_STAGES=4"],
+    "stages3": ["-DNBL_W_STAGES=3"],
+    "fwd3": ["-DNBL_W_FWD=3"],
+    "bwda4": ["-DNBL_W_BWDA=4"],
     "rows4": ["-DNBL_W_ROWS=4"],
-    "all": ["-DNBL_W_CFINAL=2", "-DNBL_W_BWDA=2", "-DNBL_W_SOLVE=3", "-DNBL_W_FWD=3", "-DNBL_W_BWDB=3", "-DNBL_W_RECOMP=3",
-            "-DNBL_W_BFINAL=3", "-DNBL_W_STAGES=4", "-DNBL_W_ROWS=4"],
 }
 
 

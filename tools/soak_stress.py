@@ -16,7 +16,10 @@ reduced size as tests/test_gpu_stress.py.
           1e-15 of noise on the oracle's own A flips it, tools/dbg notes in DESIGN.md section 5 - which no perturbation of the STATE probes.)
   capsule every box collider becomes a capsule (radius = half its smallest side, cylinder height = its longest side, axis = that side's) and
           the ground a world-fixed sphere of radius 100 m with its top at y = 0 (a capsule cannot meet a box: libccd in the reference)
-usage (GPU box): python tools/soak_stress.py <mode> [first seed] [count] [B]"""
+  mix     a random subset (each with probability 1/2, drawn from the seed) of capsule, geom, mass, mu, selfcol, limits, subset, dt in ONE
+          model: the interactions of the features (limit rows next to capsule and self-collision contacts in the eight slots, ...)
+  a+b+c   the named mutations one after the other
+usage (GPU box): python tools/soak_stress.py <mode> [first seed] [count] [B] [balls|big|multi]"""
 import os
 import sys
 
@@ -28,7 +31,21 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.p
 MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits", "selfcol")
 
 
+MIX_ORDER = ("capsule", "geom", "mass", "mu", "selfcol", "limits", "subset", "dt")   # (limits rebuilds the description: before subset)
+
+
 def mutator(mode):
+    if mode == "mix" or "+" in mode:
+        def chain(seed, md, s, a, g):
+            if mode == "mix":
+                pick = np.random.default_rng(seed + 77).random(len(MIX_ORDER)) < 0.5
+                parts = [m for m, p in zip(MIX_ORDER, pick) if p]
+            else:
+                parts = mode.split("+")
+            for k, m in enumerate(parts):
+                md, s, a, g = mutator(m)(seed + 1000003 * k, md, s, a, g)
+            return md, s, a, g
+        return chain
     assert mode in MODES, mode
 
     def mutate(seed, md, s, a, g):
@@ -112,11 +129,13 @@ def mutator(mode):
     return mutate
 
 
-def run(mode, first=0, count=20, B=256, verbose=False):
+def run(mode, first=0, count=20, B=256, verbose=False, variant="balls"):
+    """variant: the model family of tools/soak_parity.py the mutation is applied to (balls, big, multi)."""
     import soak_parity
-    return soak_parity.run(first, count, B, verbose=verbose, balls=True, mutate=mutator(mode))
+    return soak_parity.run(first, count, B, verbose=verbose, balls=variant == "balls", big=variant == "big", multi=variant == "multi",
+                           mutate=mutator(mode))
 
 
 if __name__ == "__main__":
     print(sys.argv[1], run(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[3]) if len(sys.argv) > 3 else 150,
-                           int(sys.argv[4]) if len(sys.argv) > 4 else 256))
+                           int(sys.argv[4]) if len(sys.argv) > 4 else 256, variant=sys.argv[5] if len(sys.argv) > 5 else "balls"))
