@@ -40,6 +40,10 @@ def load_urdf(path, name=None, weld_joints=(), drop_unsupported_colliders=False)
         name = root.get("name", "model")
     links = {l.get("name"): l for l in root.findall("link")}
     joints = {j.get("name"): j for j in root.findall("joint")}
+    for jn_, j_ in joints.items():
+        if j_.find("mimic") is not None:
+            # DartLoader::addMimicJointsRecursive (DartLoader.cpp:318-380): the joint becomes a MIMIC actuator driven by another joint
+            raise ValueError(f"{path}: joint {jn_} is a mimic joint: kinematically driven joints are outside the hot-path scope")
     child_of = {}
     children = {ln: [] for ln in links}
     for jn in sorted(joints):  # std::map order
@@ -259,6 +263,10 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
             continue
         skel_T = _skel_T(sk)                                     # optional skeleton frame (:948-955)
         bel = {b.get("name"): b for b in sk.findall("body")}
+        for bn, b_ in bel.items():
+            if b_.find("soft_shape") is not None:
+                # readSoftBodyNode (SkelParser.cpp:285-, called from :972): a SoftBodyNode with point masses and its own dynamics, nothing of it is rigid-body ABA
+                raise ValueError(f"{path}: body {bn} is a soft body (<soft_shape>): outside the hot-path scope")
         Tw = {n: skel_T @ _skel_T(b) for n, b in bel.items()}
         joints = sk.findall("joint")
         child_joint = {j.find("child").text.strip(): j for j in joints}

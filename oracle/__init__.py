@@ -224,6 +224,12 @@ class OracleWorld:
         non-zero entry instead (the rounding error of entries that are sums with cancellation).  0 switches it off."""
         self._lib.nbo_set_lcp_noise(self._h, int(ulps), int(seed), 1 if absolute else 0)
 
+    def set_lcp_alternate_a(self, on=True):
+        """Test instrument: the LCP matrix recomputed as J M^-1 J^T from the dense inverse mass matrix - the same matrix through another
+        valid order of floating-point operations than the reference's impulse tests.  A world whose answer changes under it has no
+        answer that is independent of the evaluation order."""
+        self._lib.nbo_set_lcp_noise(self._h, 0, 0, 2 if on else 0)
+
     def set_lcp_forced(self, x=None, cfm_stage=False):
         """Test instrument, not the reference's behaviour: x (one entry per LCP row) stands in for the OUTPUT of the solver stages 1 - 3
         ("had Dantzig ended on this solution") where stage 0 fails; the step reports 0x40000000 when isLCPSolutionValid rejects it.

@@ -457,6 +457,15 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
           if (j != i) out.A(j, i) *= 1.0 + e;
         }
       }
+    s_t bmax = 0;                                                 // ... and the same on the right-hand side b = -J v (+ bounce)
+    for (int i = 0; i < mrows; i++) bmax = std::max(bmax, std::fabs(out.b[i]));
+    for (int i = 0; i < mrows; i++) {
+      uint64_t h = m.lcpNoiseSeed * 0x9E3779B97F4A7C15ull + sample * 0xBF58476D1CE4E5B9ull + (uint64_t)(4096 + i) * 0x94D049BB133111EBull;
+      h ^= h >> 31; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29;
+      const s_t e = (s_t)((int)(h % 3) - 1) * (s_t)m.lcpNoiseUlps * 2.220446049250313e-16;
+      if (m.lcpNoiseAbsolute) { if (out.b[i] != 0) out.b[i] += e * bmax; }
+      else out.b[i] *= 1.0 + e;
+    }
   }
 
   // ---- constraint forces in joint space: A_c columns (DCC.cpp:231-270, 2961-2988; Joint.cpp:1176-1181) ----
@@ -513,6 +522,19 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   // ---- per group: warm start / guess, stage 0, stages 1-3, registration (BoxedLcpConstraintSolver.cpp:190-789 runs once per
   //      constrained group, ConstraintSolver.cpp:800-811) ----
   MatX Minv = invMassMatrix(m, kin, art);
+  if (m.lcpAlternateA) {                                          // test instrument, see Model::lcpAlternateA
+    MatX Jt(n, mrows);                                            // column r: the generalized force of a unit impulse on row r
+    for (int r = 0; r < mrows; r++)
+      for (int d_ = 0; d_ < n; d_++) Jt(d_, r) = out.rowContact[r] >= 0 ? out.Aall(d_, r) : (d_ == out.rowDof[r] ? 1.0 : 0.0);
+    MatX MJ = matmul(Minv, Jt);
+    for (int i = 0; i < mrows; i++)
+      for (int j = 0; j < mrows; j++) {
+        if (out.A(i, j) == 0 && out.A(j, i) == 0) continue;       // structural zeros stay
+        s_t s_ = 0;
+        for (int d_ = 0; d_ < n; d_++) s_ += Jt(d_, i) * MJ(d_, j);
+        out.A(i, j) = s_;
+      }
+  }
   const bool haveCache = (int)lcpCache.size() == mrows;
   VecX X(mrows, 0.0);
   out.cfmRow.assign(mrows, 0.0);

@@ -43,7 +43,7 @@ struct Model {
   bool penetrationCorrection = false;   // World::setPenetrationCorrectionEnabled (off by default)
   std::vector<int> selfCollision;       // per body: bit 0 Skeleton::isEnabledSelfCollisionCheck, bit 1 isEnabledAdjacentBodyCheck
   std::vector<int> limitEnforced;       // per DOF: Joint::isPositionLimitEnforced of its joint (JointAspect.hpp:165: off by default)
-  // Test instrument (tools/soak_parity.py), NOT the reference's behaviour: with lcpNoiseUlps = k > 0 every entry of the LCP matrix A is
+  // Test instrument (tools/soak_parity.py), NOT the reference's behaviour: with lcpNoiseUlps = k > 0 every entry of the LCP matrix A (and of b) is
   // multiplied by 1 + j k 2^-52, j in {-1, 0, 1} drawn per entry pair (i, j) / (j, i) from (seed, sample): the A another valid order
   // of the same floating-point sums could have produced.  Worlds whose answer changes under it have no stable reference answer.
   // lcpNoiseAbsolute: the noise is j k 2^-52 max |A| ADDED to every entry instead - the rounding error of entries that are sums with
@@ -53,6 +53,9 @@ struct Model {
   // Second test instrument: lcpForced (one entry per LCP row) replaces the OUTPUT of the solver stages 1-3 of a group whose stage 0 fails -
   // "had Dantzig ended on this solution" -, if isLCPSolutionValid accepts it on the group's A (else the step reports 0x40000000);
   // everything after the solver (registration, row classes, standardisation, impulses, backward pass) is the reference's.
+  // lcpAlternateA: A is recomputed as J M^-1 J^T from the dense inverse mass matrix and the joint-space constraint forces - the same
+  // matrix through another valid order of floating-point operations than the reference's impulse tests (no random draw involved).
+  bool lcpAlternateA = false;
   std::vector<s_t> lcpForced;
   bool lcpForcedCfm = false;            // ... as the output of stage 2 (the fallback CFM on the diagonal, PGS) instead of stage 1
   uint64_t lcpNoiseSeed = 0;

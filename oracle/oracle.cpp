@@ -227,8 +227,11 @@ void nbo_set_lcp_cache(void* h, const double* x, int len) {
   else o->lcpCache.assign(x, x + len);
 }
 // test instrument (Model::lcpNoiseUlps): ulps = 0 switches it off
+// absolute: 0 relative noise, 1 absolute noise, 2 no noise but A recomputed as J M^-1 J^T (Model::lcpAlternateA)
 void nbo_set_lcp_noise(void* h, int ulps, uint64_t seed, int absolute) {
   Oracle* o = (Oracle*)h;
+  o->model.lcpAlternateA = absolute == 2;
+  if (absolute == 2) ulps = 0;
   o->model.lcpNoiseUlps = ulps; o->model.lcpNoiseSeed = seed; o->model.lcpNoiseSample = 0; o->model.lcpNoiseAbsolute = absolute != 0;
 }
 // test instrument (Model::lcpForced): len <= 0 switches it off

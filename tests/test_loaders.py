@@ -82,6 +82,11 @@ def test_unsupported_urdf_features_raise(tmp_path):
     with pytest.raises(ValueError):                      # a collider outside the analytic narrow phases is not dropped silently ...
         na.load_urdf(str(f))
     assert len(na.load_urdf(str(f), drop_unsupported_colliders=True).bodies) == 6          # ... unless asked to
+    import re
+    first_joint = re.search(r'<joint name="([^"]+)" type="(revolute|continuous|prismatic)">', URDF)
+    f.write_text(URDF.replace(first_joint.group(0), first_joint.group(0) + f'<mimic joint="{first_joint.group(1)}" multiplier="2"/>', 1))
+    with pytest.raises(ValueError, match="mimic"):       # a MIMIC actuator in the reference (DartLoader.cpp:318-380)
+        na.load_urdf(str(f))
 
 
 def test_urdf_floating_and_planar_joints_like_dart_loader(tmp_path):
@@ -362,3 +367,15 @@ def test_skel_default_inertia_of_every_shape_kind_the_reference_reads(tmp_path, 
     md = na.load_skel(str(f))
     assert np.allclose(md.bodies[0].inertia, expect + (0.0, 0.0, 0.0), rtol=1e-14, atol=0)
     assert md.bodies[0].mass == 2.0
+
+
+def test_skel_soft_bodies_are_refused(tmp_path):
+    """A <soft_shape> makes the body a SoftBodyNode in the reference (SkelParser.cpp readSoftBodyNode): loading it as a rigid body would
+    silently change the physics."""
+    f = tmp_path / "soft.skel"
+    f.write_text("""<?xml version="1.0" ?><skel version="1.0"><world name="w"><physics><time_step>0.001</time_step><gravity>0 -9.81 0</gravity></physics>
+      <skeleton name="s"><body name="b"><inertia><mass>1</mass><offset>0 0 0</offset></inertia>
+        <soft_shape><total_mass>1</total_mass><geometry><box><size>0.1 0.1 0.1</size><frags>3 3 3</frags></box></geometry><kv>500</kv><ke>0</ke><damp>5</damp></soft_shape></body>
+      <joint type="free" name="j"><parent>world</parent><child>b</child></joint></skeleton></world></skel>""")
+    with pytest.raises(ValueError, match="soft body"):
+        na.load_skel(str(f))

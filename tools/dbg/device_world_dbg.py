@@ -48,7 +48,9 @@ print("max |A dev - A oracle|", np.abs(Ad - Ao).max() if D["rows"] == 3 * nc els
 print("max |b dev - b oracle|", np.abs(rows[b_row:b_row + 3 * nc, 0] - D["b"][:3 * nc]).max())
 np.set_printoptions(linewidth=200, precision=6)
 if os.environ.get("PRINT_A"):
-    print("A device\n", Ad); print("A oracle\n", Ao)
+    np.set_printoptions(linewidth=200, precision=17)
+    print("A device\n", repr(Ad)); print("A oracle\n", repr(Ao)); print("b device", repr(rows[b_row:b_row + 3 * nc, 0])); print("b oracle", repr(D["b"][:3 * nc]))
+    np.set_printoptions(linewidth=200, precision=6)
 for c in range(nc):
     r0 = contacts + c * CR
     print("contact", c, rows[r0:r0 + CR, 0])

@@ -98,8 +98,8 @@ if os.environ.get("NOISE"):
     rng = np.random.default_rng(0)
     fi = L["findex"].astype(np.int32)
     x0 = np.zeros(m); OL.nbo_lcp_guess(m, _p(A), _p(L["b"].copy()), _pi(fi), _p(x0))
-    for what in ("b", "A", "A+b", "Q"):
-        for ulps in (1, 4):
+    for what in ("b", "A", "A+b", "Q", "N"):
+        for ulps in ((1, 4) if what != "Q" else (1, 4, 16, 64)):
             cnt = collections.Counter()
             for t in range(200):
                 A2 = A.copy(); b2 = L["b"].copy()
@@ -109,6 +109,8 @@ if os.environ.get("NOISE"):
                 if what == "Q":                                   # absolute: ulps * eps * max |A| on every entry, symmetric
                     N = np.triu(rng.integers(-1, 2, (m, m))); N = N + np.triu(N, 1).T
                     A2 = A + N * ulps * 2.220446049250313e-16 * np.abs(A).max()
+                if what == "N":                                   # like A, but (i, j) and (j, i) drawn independently
+                    A2 = A * (1 + rng.integers(-1, 2, (m, m)) * ulps * 2.220446049250313e-16)
                 if "b" in what:
                     b2 = b2 * (1 + rng.integers(-1, 2, m) * ulps * 2.220446049250313e-16)
                 x0 = np.zeros(m); OL.nbo_lcp_guess(m, _p(np.ascontiguousarray(A2)), _p(b2), _pi(fi), _p(x0))
