@@ -63,6 +63,8 @@ def _declare(lib):
     lib.nbo_set_lcp_noise.restype = None
     lib.nbo_set_lcp_forced.argtypes = [C.c_void_p, pd, C.c_int, C.c_int]
     lib.nbo_set_lcp_forced.restype = None
+    lib.nbo_set_lcp_cache_slots.argtypes = [C.c_void_p, C.c_int]
+    lib.nbo_set_lcp_cache_slots.restype = None
     lib.nbo_get_lcp_cache.restype = C.c_int
     lib.nbo_mass_matrix.argtypes = [C.c_void_p, pd, pd]
     lib.nbo_coriolis_gravity.argtypes = [C.c_void_p, pd, pd, pd]
@@ -221,14 +223,20 @@ class OracleWorld:
     def set_lcp_noise(self, ulps, seed=0, absolute=False):
         """Test instrument, not the reference's behaviour: every entry of the LCP matrix A times 1 + j ulps 2^-52, j in {-1, 0, 1} per
         entry and per solve - the A another order of the same sums could have given; absolute: j ulps 2^-52 max |A| ADDED to every
-        non-zero entry instead (the rounding error of entries that are sums with cancellation).  0 switches it off."""
-        self._lib.nbo_set_lcp_noise(self._h, int(ulps), int(seed), 1 if absolute else 0)
+        non-zero entry instead; absolute="bound": j ulps 2^-52 x (the sum of the magnitudes of the terms of A = J M^-1 J^T / b = -J v
+        the entry is the sum of): the first-order rounding-error bound of that entry.  0 switches it off."""
+        self._lib.nbo_set_lcp_noise(self._h, int(ulps), int(seed), {False: 0, True: 1, "bound": 3}[absolute])
 
     def set_lcp_alternate_a(self, on=True):
         """Test instrument: the LCP matrix recomputed as J M^-1 J^T from the dense inverse mass matrix - the same matrix through another
         valid order of floating-point operations than the reference's impulse tests.  A world whose answer changes under it has no
         answer that is independent of the evaluation order."""
         self._lib.nbo_set_lcp_noise(self._h, 0, 0, 2 if on else 0)
+
+    def set_lcp_cache_slots(self, on=True):
+        """The LCP cache (set_lcp_cache / get_lcp_cache / step_batch's lcp_in, lcp out) in the DEVICE's format: three entries per
+        constraint - a frictionless contact and a joint-limit row use the first - instead of the reference's 3 / 1 / 1 rows."""
+        self._lib.nbo_set_lcp_cache_slots(self._h, 1 if on else 0)
 
     def set_lcp_forced(self, x=None, cfm_stage=False):
         """Test instrument, not the reference's behaviour: x (one entry per LCP row) stands in for the OUTPUT of the solver stages 1 - 3

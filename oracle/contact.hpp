@@ -352,6 +352,7 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   out.m = mrows;
   out.A = MatX(mrows, mrows);
   out.b.assign(mrows, 0.0); out.lo.assign(mrows, 0.0); out.hi.assign(mrows, 0.0);
+  VecX bTerms(mrows, 0.0);
   out.restCoeff.assign(mrows, 0.0);
   out.findex.assign(mrows, -1);
   out.massed = MatX(n, mrows);
@@ -363,6 +364,7 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     // the bouncing velocity is -+0 * ERP / dt = 0; x starts from 0 (the constraint objects are rebuilt every step: life time 0)
     const int l = r - contactRows;
     out.b[r] = -vPre[limDof[l]];
+    bTerms[r] = std::fabs(vPre[limDof[l]]);
     if (limSide[l] < 0) { out.lo[r] = 0.0; out.hi[r] = INFINITY; }
     else { out.lo[r] = -INFINITY; out.hi[r] = 0.0; }
     out.findex[r] = -1;
@@ -373,6 +375,10 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
     if (ct.bodyA >= 0) rel -= dot(out.JA[r], kinPre[ct.bodyA].V);
     if (ct.bodyB >= 0) rel -= dot(out.JB[r], kinPre[ct.bodyB].V);
     out.b[r] = rel;
+    for (int k = 0; k < 6; k++) {                                 // sum of the magnitudes of the terms (Model::lcpNoiseBound)
+      if (ct.bodyA >= 0) bTerms[r] += std::fabs(out.JA[r][k] * kinPre[ct.bodyA].V[k]);
+      if (ct.bodyB >= 0) bTerms[r] += std::fabs(out.JB[r][k] * kinPre[ct.bodyB].V[k]);
+    }
     if (out.rowDir[r] == 0) {
       // "Bouncing" of getInformation (ContactConstraint.cpp:393-441, ctor :95-110).  A: penetration correction, only when the
       // world enables it (ConstraintSolver.cpp:69-71: off by default; DART_ERROR_ALLOWANCE 0, DART_ERP 0.01, DART_MAX_ERV 1e-3, :45-47)
@@ -535,6 +541,33 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
         out.A(i, j) = s_;
       }
   }
+  if (m.lcpCacheSlots && (int)lcpCache.size() == 3 * nCons) {      // Model::lcpCacheSlots: three entries per constraint -> the reference's rows
+    VecX compact(mrows, 0.0);
+    for (int c = 0; c < nCons; c++) for (int k = 0; k < consDim[c]; k++) compact[consFirst[c] + k] = lcpCache[3 * c + k];
+    lcpCache = compact;
+  } else if (m.lcpCacheSlots) lcpCache.clear();
+  if (m.lcpNoiseBound > 0) {                                       // test instrument, see Model::lcpNoiseBound
+    MatX Jt(n, mrows);
+    for (int r = 0; r < mrows; r++)
+      for (int d_ = 0; d_ < n; d_++) Jt(d_, r) = out.rowContact[r] >= 0 ? out.Aall(d_, r) : (d_ == out.rowDof[r] ? 1.0 : 0.0);
+    MatX MJ = matmul(Minv, Jt);
+    const uint64_t sample = m.lcpNoiseSample++;
+    auto draw = [&](uint64_t idx) {
+      uint64_t h = m.lcpNoiseSeed * 0x9E3779B97F4A7C15ull + sample * 0xBF58476D1CE4E5B9ull + idx * 0x94D049BB133111EBull;
+      h ^= h >> 31; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29;
+      return (s_t)((int)(h % 3) - 1) * (s_t)m.lcpNoiseBound * 2.220446049250313e-16;
+    };
+    for (int i = 0; i < mrows; i++)
+      for (int j = i; j < mrows; j++) {
+        if (out.A(i, j) == 0 && out.A(j, i) == 0) continue;       // structural zeros stay
+        s_t terms = 0;
+        for (int d_ = 0; d_ < n; d_++) terms += std::fabs(Jt(d_, i) * MJ(d_, j));
+        const s_t e = draw((uint64_t)(i * 64 + j)) * terms;
+        out.A(i, j) += e;
+        if (j != i) out.A(j, i) += e;
+      }
+    for (int i = 0; i < mrows; i++) if (out.b[i] != 0) out.b[i] += draw((uint64_t)(4096 + i)) * bTerms[i];
+  }
   const bool haveCache = (int)lcpCache.size() == mrows;
   VecX X(mrows, 0.0);
   out.cfmRow.assign(mrows, 0.0);
@@ -628,6 +661,10 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   out.x = X;
   out.standardized = allStandardized;
   lcpCache = X;  // mX persists inside the solver (BoxedLcpConstraintSolver.cpp:176-187)
+  if (m.lcpCacheSlots) {
+    lcpCache.assign(3 * nCons, 0.0);
+    for (int c = 0; c < nCons; c++) for (int k = 0; k < consDim[c]; k++) lcpCache[3 * c + k] = X[consFirst[c] + k];
+  }
 
   // ---- applyImpulse + computeImpulseForwardDynamics (ContactConstraint.cpp:630-684, Skeleton.cpp:13571-13595) ----
   std::vector<Vec6> imps(m.nb, zero6());

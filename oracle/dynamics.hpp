@@ -56,6 +56,13 @@ struct Model {
   // lcpAlternateA: A is recomputed as J M^-1 J^T from the dense inverse mass matrix and the joint-space constraint forces - the same
   // matrix through another valid order of floating-point operations than the reference's impulse tests (no random draw involved).
   bool lcpAlternateA = false;
+  // lcpNoiseBound = k > 0: every entry of A = J M^-1 J^T and of b = -J v moves by j k 2^-52 x (the sum of the MAGNITUDES of the terms it
+  // is the sum of), j in {-1, 0, 1} per entry and solve: the first-order rounding-error bound of those sums, which is what another
+  // order of evaluation can move an entry by where the terms cancel (fast bodies with a small relative velocity, light bodies on heavy ones).
+  int lcpNoiseBound = 0;
+  // Interchange format of the LCP cache with the device (not the reference's): three entries per constraint - a frictionless contact
+  // and a joint-limit row use the first, the other two are zero - instead of the reference's 3 / 1 / 1 rows.
+  bool lcpCacheSlots = false;
   std::vector<s_t> lcpForced;
   bool lcpForcedCfm = false;            // ... as the output of stage 2 (the fallback CFM on the diagonal, PGS) instead of stage 1
   uint64_t lcpNoiseSeed = 0;

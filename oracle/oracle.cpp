@@ -227,13 +227,17 @@ void nbo_set_lcp_cache(void* h, const double* x, int len) {
   else o->lcpCache.assign(x, x + len);
 }
 // test instrument (Model::lcpNoiseUlps): ulps = 0 switches it off
-// absolute: 0 relative noise, 1 absolute noise, 2 no noise but A recomputed as J M^-1 J^T (Model::lcpAlternateA)
+// absolute: 0 relative noise, 1 absolute noise, 2 no noise but A recomputed as J M^-1 J^T (Model::lcpAlternateA), 3 noise in units of
+// the rounding-error bound of every entry (Model::lcpNoiseBound)
 void nbo_set_lcp_noise(void* h, int ulps, uint64_t seed, int absolute) {
   Oracle* o = (Oracle*)h;
   o->model.lcpAlternateA = absolute == 2;
-  if (absolute == 2) ulps = 0;
+  o->model.lcpNoiseBound = absolute == 3 ? ulps : 0;
+  if (absolute >= 2) ulps = 0;
   o->model.lcpNoiseUlps = ulps; o->model.lcpNoiseSeed = seed; o->model.lcpNoiseSample = 0; o->model.lcpNoiseAbsolute = absolute != 0;
 }
+// LCP cache in the device's interchange format (Model::lcpCacheSlots)
+void nbo_set_lcp_cache_slots(void* h, int on) { ((Oracle*)h)->model.lcpCacheSlots = on != 0; }
 // test instrument (Model::lcpForced): len <= 0 switches it off
 void nbo_set_lcp_forced(void* h, const double* x, int len, int cfmStage) {
   Oracle* o = (Oracle*)h;

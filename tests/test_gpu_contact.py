@@ -25,6 +25,8 @@ def _run(name, B, seed, **kw):
     out.backward(torch.tensor(g, device="cuda:0"))
     ref = ow.step_batch(s, a, g, threads=8)
     dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
+    for k in dev:                                              # (a NaN would compare as "not above the tolerance")
+        assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), (name, k, "non-finite values")
     scales = {k: np.abs(ref[k]).max() for k in dev}
     errs = {k: np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev}
     world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}}
@@ -349,6 +351,8 @@ def test_independent_objects_are_solved_as_separate_constrained_groups():
     out.backward(torch.tensor(g, device="cuda:0"))
     ref = ow.step_batch(s, a, g, threads=8)
     dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
+    for k in dev:                                              # (a NaN would compare as "not above the tolerance")
+        assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), (name, k, "non-finite values")
     scales = {k: np.abs(ref[k]).max() for k in dev}
     errs = {k: np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev}
     world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}}

@@ -233,3 +233,54 @@ def test_checkpointed_rollout_is_bit_identical_and_keeps_only_K_records(contact,
     per = w1._L.nbl_saved_bytes(w1._h, B)
     assert isinstance(rec1, RolloutRecord) and rec1.saved.numel() == K * per and rec0.numel() == T * per
     assert rec1.resident_bytes() < (K + 1) * per
+
+
+@pytest.mark.parametrize("variant,first", [("balls", 310000), ("big", 310100), ("multi", 310200)])
+def test_rollout_of_random_mixed_feature_models_equals_the_chain_of_timesteps(variant, first):
+    """The T-step driver on the mixed-feature models of the soak (tools/soak_stress.py mix: capsules, enforced joint limits,
+    self-collision, frictionless and barely-frictional contacts, action subsets, several skeletons ...): warm-started, with and without
+    checkpointing, the states are bit-identical to the chain of single steps and the gradients equal to round-off - joint-limit rows
+    and frictionless contacts ride in the carried LCP solution like contacts do."""
+    import os
+    import sys
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import rollout
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak_parity
+    import soak_stress
+    B, T, done, limit_rows, nan_worlds = 64, 5, 0, 0, 0
+    for seed in range(first, first + 12):
+        case = soak_parity.make_case(seed, B, variant == "big", variant == "multi", variant == "balls", False)
+        if case is None:
+            continue
+        md, s0, a0, _ = soak_stress.mutator("mix")(seed, *case)
+        try:
+            world = na.World(md, device="cuda:0"); world2 = na.World(md, device="cuda:0")
+        except na.NimbleAmdError:
+            continue
+        rng = np.random.default_rng(seed)
+        acts = np.repeat(a0[:, None, :], T, 1) + rng.normal(0, 0.05, (B, T, a0.shape[1]))
+        w = rng.normal(0, 1, (B, T + 1, s0.shape[1]))
+        st, at, xs = _chain(world, s0, acts, True)
+        (xs * torch.tensor(w, device="cuda:0")).sum().backward()
+        for k in (0, 2):
+            st2 = torch.tensor(s0, device="cuda:0", requires_grad=True); at2 = torch.tensor(acts, device="cuda:0", requires_grad=True)
+            ys = rollout(world2, st2, at2, warm_start=True, checkpoint_every=k) if k else rollout(world2, st2, at2, warm_start=True)
+            (ys * torch.tensor(w, device="cuda:0")).sum().backward()
+            # (a world whose state leaves the finite range - a limb driven through its enforced limit at 5 ms steps - is NaN from there on in
+            #  both, flagged NBL_ST_NAN, and poisons nothing else: DESIGN.md section 1)
+            ok = torch.isfinite(xs.detach()).flatten(1).all(1)
+            assert torch.equal(ok, torch.isfinite(ys.detach()).flatten(1).all(1)), (seed, k)
+            assert ok.float().mean().item() > 0.9, (seed, ok.float().mean().item())
+            assert torch.equal(ys.detach()[ok], xs.detach()[ok]), (seed, k)
+            for a, b in ((st2.grad, st.grad), (at2.grad, at.grad)):
+                assert torch.isfinite(a[ok]).all() and torch.isfinite(b[ok]).all(), (seed, k)
+                assert (a[ok] - b[ok]).abs().max().item() <= 1e-11 * max(b[ok].abs().max().item(), 1.0), (seed, k)
+            nan_worlds += int((~ok).sum())
+        limit_rows += int((world2.rollout_status.cpu().numpy() & 0x400 != 0).sum())
+        done += 1
+    print(variant, "models", done, "worlds with joint-limit rows", limit_rows, "non-finite worlds", nan_worlds)
+    assert done >= 8
+    if variant != "multi":
+        assert limit_rows > 0

@@ -36,6 +36,7 @@ def run(first=0, count=20, W=4, mode="balls", verbose=True):
             if (st[b] | ow.last_status) & 0x80:
                 continue
             Rs, Ra = ow.getStateJacobian(), ow.getActionJacobian()
+            assert np.isfinite(Js[b]).all() and np.isfinite(Ja[b]).all() and np.isfinite(Rs).all() and np.isfinite(Ra).all(), ("non-finite Jacobian", seed, b)
             e = max(np.abs(Js[b] - Rs).max() / max(np.abs(Rs).max(), 1e-30), np.abs(Ja[b] - Ra).max() / max(np.abs(Ra).max(), 1e-30))
             tot["worlds"] += 1; tot["contact"] += int(st[b] & 1); tot["gt1e-7"] += int(e > 1e-7); tot["gt1e-5"] += int(e > 1e-5)
             tot["worst"] = max(tot["worst"], float(e))

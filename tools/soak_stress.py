@@ -16,7 +16,8 @@ reduced size as tests/test_gpu_stress.py.
           1e-15 of noise on the oracle's own A flips it, tools/dbg notes in DESIGN.md section 5 - which no perturbation of the STATE probes.)
   capsule every box collider becomes a capsule (radius = half its smallest side, cylinder height = its longest side, axis = that side's) and
           the ground a world-fixed sphere of radius 100 m with its top at y = 0 (a capsule cannot meet a box: libccd in the reference)
-  mix     a random subset (each with probability 1/2, drawn from the seed) of capsule, geom, mass, mu, selfcol, limits, subset, dt in ONE
+  mix     a random subset (each with probability 1/2, drawn from the seed) of capsule, geom, mass, mu, selfcol, limits, subset, dt, fast,
+          torque, nograv in ONE
           model: the interactions of the features (limit rows next to capsule and self-collision contacts in the eight slots, ...)
   a+b+c   the named mutations one after the other
 usage (GPU box): python tools/soak_stress.py <mode> [first seed] [count] [B] [balls|big|multi]"""
@@ -31,14 +32,14 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.p
 MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits", "selfcol")
 
 
-MIX_ORDER = ("capsule", "geom", "mass", "mu", "selfcol", "limits", "subset", "dt")   # (limits rebuilds the description: before subset)
+MIX_ORDER = ("capsule", "geom", "mass", "mu", "selfcol", "limits", "subset", "dt", "fast", "torque", "nograv")   # (limits rebuilds the description: before subset)
 
 
 def mutator(mode):
     if mode == "mix" or "+" in mode:
         def chain(seed, md, s, a, g):
             if mode == "mix":
-                pick = np.random.default_rng(seed + 77).random(len(MIX_ORDER)) < 0.5
+                pick = np.random.default_rng(seed + 77).random(len(MIX_ORDER)) < 0.5          # (the first eight draws are the ones of the eight-mode mix)
                 parts = [m for m, p in zip(MIX_ORDER, pick) if p]
             else:
                 parts = mode.split("+")
@@ -123,8 +124,10 @@ def mutator(mode):
                     s[half, d] = rng.choice([fl["pos_lo"][d], fl["pos_hi"][d]], half.sum())
                     if mode == "limits":                       # ... and some of them beyond the limit
                         s[half, d] += rng.choice([0.0, 0.0, -0.02, 0.02], half.sum()) * (np.abs(s[half, d]) > 0)
-                    s[half, n + d] = rng.choice([fl["vel_lo"][d], fl["vel_hi"][d]], half.sum())
-                    a[half, d] = rng.choice([fl["force_lo"][d], fl["force_hi"][d]], half.sum())
+                    if np.isfinite(fl["vel_lo"][d]) and np.isfinite(fl["vel_hi"][d]):      # (a ball joint's coordinates carry position limits only)
+                        s[half, n + d] = rng.choice([fl["vel_lo"][d], fl["vel_hi"][d]], half.sum())
+                    if np.isfinite(fl["force_lo"][d]) and np.isfinite(fl["force_hi"][d]):
+                        a[half, d] = rng.choice([fl["force_lo"][d], fl["force_hi"][d]], half.sum())
         return md, s, a, g
     return mutate
 
