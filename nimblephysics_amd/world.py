@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import _abi
@@ -347,11 +348,28 @@ class World:
         js = torch.empty((n2, n2, B), dtype=torch.float64, device=self.device)
         ja = torch.empty((n2, self.k, B), dtype=torch.float64, device=self.device)
         g = torch.zeros((n2, B), dtype=torch.float64, device=self.device)
+        # The backward pass ends with clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479): with a coordinate exactly ON a limit the
+        # entry of the gradient that points out of the box is zeroed - a property of backprop(), not of the Jacobians, which the
+        # reference assembles without it (getStateJacobian, World.cpp:2210-2226).  The clipping looks at the sign, so of the two
+        # products with +e_i and -e_i exactly one keeps such an entry: models with finite limits pay the second pass.
+        fl = self._limits_finite()
         for i in range(n2):
             g[i] = 1.0
-            js[i], ja[i] = self.backward_soa(saved, g)
+            rs, ra = self.backward_soa(saved, g)
+            if fl:
+                g[i] = -1.0
+                ms, ma = self.backward_soa(saved, g)
+                rs = torch.where(rs != 0, rs, -ms); ra = torch.where(ra != 0, ra, -ma)
+            js[i], ja[i] = rs, ra
             g[i] = 0.0
         return js, ja
+
+    def _limits_finite(self) -> bool:
+        if getattr(self, "_limits_finite_cache", None) is None:
+            f = self.description.flat()
+            self._limits_finite_cache = bool(any(np.isfinite(np.asarray(f[k], dtype=np.float64)).any()
+                                                 for k in ("pos_lo", "pos_hi", "vel_lo", "vel_hi", "force_lo", "force_hi")))
+        return self._limits_finite_cache
 
     def getStateJacobian(self) -> torch.Tensor:
         """World::getStateJacobian (World.cpp:2210-2226) of the last step: [B, 2n, 2n], out[b, i, j] = d next[i] / d state[j]."""

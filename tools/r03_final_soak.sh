@@ -8,3 +8,4 @@ echo "jacobians $(python tools/soak_jacobians.py $((42000+S)) 100 4 2>&1 | tail 
 for mode in dt tinydt fast torque mass nograv geom mu subset atlimit capsule limits selfcol; do echo "stress:$mode $(python tools/soak_stress.py $mode $((43000+S)) 120 256 2>&1 | tail -1)"; done
 for v in balls big multi; do echo "stress:mix:$v $(python tools/soak_stress.py mix $((44000+S)) 200 256 $v 2>&1 | tail -1)"; done
 echo "warm:mix $(python tools/soak_warm.py $((45000+S)) 300 256 balls mix 2>&1 | tail -1)"
+for v in balls big; do echo "jacobians:mix:$v $(python tools/soak_jacobians.py $((46000+S)) 150 4 $v mix 2>&1 | tail -1)"; done

@@ -16,15 +16,21 @@ import soak_parity  # noqa: E402
 from oracle import OracleWorld  # noqa: E402
 
 
-def run(first=0, count=20, W=4, mode="balls", verbose=True):
+def run(first=0, count=20, W=4, mode="balls", verbose=True, stress=None):
     tot = {"models": 0, "worlds": 0, "contact": 0, "gt1e-7": 0, "gt1e-5": 0, "worst": 0.0}
     for seed in range(first, first + count):
         case = soak_parity.make_case(seed, 64, big=mode == "big", multi=mode == "multi", balls=mode == "balls")
         if case is None:
             continue
-        md, s, a, _ = case
+        md, s, a, g_ = case
+        if stress is not None:
+            import soak_stress
+            md, s, a, g_ = soak_stress.mutator(stress)(seed, md, s, a, g_)
         s, a = s[:W], a[:W]
-        world = na.World(md, device="cuda:0")
+        try:
+            world = na.World(md, device="cuda:0")
+        except na.NimbleAmdError:
+            continue
         world.setState(torch.tensor(s)); world.setAction(torch.tensor(a))
         snap = na.neural.forwardPass(world, idempotent=True)
         st = snap.getStatus().cpu().numpy().astype(np.uint32)
@@ -48,4 +54,4 @@ def run(first=0, count=20, W=4, mode="balls", verbose=True):
 
 if __name__ == "__main__":
     print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 20, int(sys.argv[3]) if len(sys.argv) > 3 else 4,
-              sys.argv[4] if len(sys.argv) > 4 else "balls"))
+              sys.argv[4] if len(sys.argv) > 4 else "balls", stress=sys.argv[5] if len(sys.argv) > 5 else None))
