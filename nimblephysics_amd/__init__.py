@@ -8,10 +8,13 @@ from .model import (BodySpec, BoxSpec, CapsuleSpec, ModelDescription, SphereSpec
 
 __all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "CapsuleSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
            "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "load_model", "loadWorld", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep", "neural", "forwardPass", "BackpropSnapshot",
-           "LossGradient", "LossGradientHighLevelAPI"]
+           "LossGradient", "LossGradientHighLevelAPI", "NimbleAmdError"]
 
 
 def __getattr__(name):
+    if name == "NimbleAmdError":                             # what every refused model / failed call raises
+        from ._lib import NimbleAmdError
+        return NimbleAmdError
     if name == "GraphedStep":
         from .graph import GraphedStep
         return GraphedStep
