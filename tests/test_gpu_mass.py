@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_fd(md, entries, s, a, g, eps_rel=1e-6):
+def _oracle_fd(md, entries, s, a, g, eps_rel=1e-6, fd_relative=False):
     """d(g . step(s, a; theta))/dtheta per world by central differences of the oracle, [B, dims]."""
     from oracle import OracleWorld
     from nimblephysics_amd.mass import WithRespectToMass
@@ -20,7 +20,8 @@ def _oracle_fd(md, entries, s, a, g, eps_rel=1e-6):
     x0 = w.get()
     out = np.zeros((s.shape[0], w.dim()))
     for p in range(w.dim()):
-        eps = eps_rel * max(1.0, abs(x0[p]))
+        # (fd_relative: the step relative to the parameter itself - masses x 1e-2 leave inertia entries of 1e-6, below an absolute step)
+        eps = eps_rel * (max(1.0, abs(x0[p])) if not fd_relative or x0[p] == 0 else 100.0 * abs(x0[p]))
         vals = []
         for sgn in (+1, -1):
             x = x0.copy(); x[p] += sgn * eps
@@ -46,10 +47,10 @@ def _device(md, entries, s, a, g, masses=None):
     return gm.T.cpu().numpy(), world.from_soa(nxt).cpu().numpy(), world
 
 
-def _check(md, entries, s, a, seed, tol=2e-6, second_eps=None, max_outliers=0.0):
+def _check(md, entries, s, a, seed, tol=2e-6, second_eps=None, max_outliers=0.0, fd_relative=False):
     g = np.random.default_rng(seed).normal(0, 1, s.shape)
     dev, _, _ = _device(md, entries, s, a, g)
-    ref = _oracle_fd(md, entries, s, a, g)
+    ref = _oracle_fd(md, entries, s, a, g, fd_relative=fd_relative)
     if second_eps is not None:
         # with contacts a perturbed oracle step can land on another LCP branch (status bit 0x100, non-unique solutions):
         # that difference quotient is ~1e5 at one step size and fine at the other.  Keep, per entry, the quotient closer

@@ -170,6 +170,22 @@ def test_mass_gradients_of_random_models_vs_central_differences_of_the_oracle():
         _check(md, entries, s, a, seed + 1, tol=2e-5)
         done += 1
     assert done >= 4
+    # ... and of the soak's mixed-feature models without their colliders and enforced limits (masses x 1e-2 .. 1e2, 5 ms steps, action
+    # subsets, no gravity: the parameter extremes; fast / torque left out - central differences of a step with |v| ~ 20 carry no digits)
+    import soak_stress
+    done = 0
+    for seed in range(600, 612):
+        case = soak_parity.make_case(seed, 16, balls=True)
+        if case is None:
+            continue
+        md, s, a, g = soak_stress.mutator("mass+subset+dt" if seed % 2 else "mass+nograv")(seed, *case)
+        md.boxes = []; md.max_contacts = 0
+        rng = np.random.default_rng(seed)
+        movable = [i for i, b in enumerate(md.bodies) if b.joint_type != "weld"]
+        entries = list({e[0]: e for e in [(int(rng.choice(movable)), T(int(rng.choice([0, 1, 3, 4, 5])))) for _ in range(3)]}.values())
+        _check(md, entries, s, a, seed + 1, tol=5e-5, fd_relative=True)
+        done += 1
+    assert done >= 8
 
 
 def test_creating_and_destroying_worlds_leaks_no_device_memory_and_changes_no_result():
