@@ -30,7 +30,7 @@ def _fwd_bwd_vs_oracle(md, s, a, g):
     return err, status
 
 
-@pytest.mark.parametrize("mode", ["dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits", "selfcol", "mix"])
+@pytest.mark.parametrize("mode", ["dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits", "selfcol", "adjacent", "mix"])
 def test_stress_variants_of_the_random_soak_all_worlds_vs_oracle(mode):
     """(Round 2 at full size, 150 models x 256 worlds per mode: 368 640 worlds, 0 mismatches.)"""
     import soak_stress

@@ -14,6 +14,7 @@ reduced size as tests/test_gpu_stress.py.
           contacts between two bodies of one tree, DOFs above both of them.  (Without the adjacent-body check: two bodies joined by ONE
           single-DOF joint have a rank-1 Delassus block, and the reference's stage 0 then succeeds or fails with the last bit of A -
           1e-15 of noise on the oracle's own A flips it, tools/dbg notes in DESIGN.md section 5 - which no perturbation of the STATE probes.)
+  adjacent like selfcol, and half of the skeletons also check a body against its parent (enableAdjacentBodyCheck)
   capsule every box collider becomes a capsule (radius = half its smallest side, cylinder height = its longest side, axis = that side's) and
           the ground a world-fixed sphere of radius 100 m with its top at y = 0 (a capsule cannot meet a box: libccd in the reference)
   mix     a random subset (each with probability 1/2, drawn from the seed) of capsule, geom, mass, mu, selfcol, limits, subset, dt, fast,
@@ -29,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits", "selfcol")
+MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subset", "atlimit", "capsule", "limits", "selfcol", "adjacent")
 
 
 MIX_ORDER = ("capsule", "geom", "mass", "mu", "selfcol", "limits", "subset", "dt", "fast", "torque", "nograv")   # (limits rebuilds the description: before subset)
@@ -75,9 +76,15 @@ def mutator(mode):
         elif mode == "subset":
             keep = sorted(rng.choice(n, size=max(1, n // 3), replace=False).tolist())
             md.set_action_space(keep); a = a[:, :len(keep)]
-        elif mode == "selfcol":
-            for b in md.bodies:
+        elif mode in ("selfcol", "adjacent"):
+            # adjacent: ... and, skeleton by skeleton with probability 1/2, also between a body and its parent (Skeleton::enableAdjacentBodyCheck):
+            # rank-1 Delassus blocks, judged by the rounding-level probes and the replay of tools/soak_parity.py
+            sk = md.body_skeletons() if hasattr(md, "body_skeletons") else [0] * len(md.bodies)
+            adj = {k: bool(rng.random() < 0.5) for k in sorted(set(sk))}
+            for i, b in enumerate(md.bodies):
                 b.self_collision = True
+                if mode == "adjacent" and adj[sk[i]]:
+                    b.adjacent_body_check = True
             # (only the single-DOF joints: exponential coordinates near pi are where the ORACLE's finite-differenced integration Jacobian
             #  loses its digits)
             s = s.copy()
