@@ -90,3 +90,35 @@ def test_limit_rows_share_the_lcp_with_contacts():
         else:                                      # the contacts push the joint against its limit: the row stops it there
             assert nxt[n + 2] < 1e-5
     assert hit > 20
+
+
+def test_the_lcp_cache_in_the_devices_slot_format_is_the_same_warm_start():
+    """OracleWorld.set_lcp_cache_slots: the cache with three entries per constraint (a joint-limit row and a frictionless contact on the
+    first of them) - the format the device keeps it in - is the same warm start as the reference's 3 / 1 / 1 rows: a second step from
+    either gives bit-identical results, and the two caches hold the same numbers."""
+    md = limited_arm(ground=True)
+    for bx in md.boxes[1:2]:
+        bx.mu = 0.0                                                             # one frictionless collider: a one-row contact
+    w = OracleWorld(md); ws = OracleWorld(md); ws.set_lcp_cache_slots(True); n = w.n
+    rng = np.random.default_rng(8)
+    warm = 0
+    for trial in range(30):
+        q = np.clip(rng.normal(0, 0.2, n), -0.15, 0.3); v = rng.normal(0, 0.3, n); a = rng.normal(0, 0.2, w.k)
+        q[0] = rng.uniform(-0.025, 0.005); q[2] = 0.4; v[2] = 0.8
+        s = np.concatenate([q, v])
+        w.reset_lcp_cache(); ws.reset_lcp_cache()
+        s1 = w.step(s, a); s1s = ws.step(s, a)
+        assert np.array_equal(s1, s1s)
+        L = w.last_lcp(); c, cs = w.get_lcp_cache(), ws.get_lcp_cache()
+        assert len(c) == len(L["x"])
+        if len(cs) == 0:
+            continue
+        assert len(cs) % 3 == 0 and len(cs) >= len(c)
+        assert np.array_equal(np.sort(np.abs(cs[cs != 0])), np.sort(np.abs(c[c != 0])))
+        s2 = w.step(s1, a); st2 = w.last_status
+        s2s = ws.step(s1s, a)
+        assert np.array_equal(s2, s2s) and ws.last_status == st2
+        warm += int(bool(st2 & 0x2))
+        g = rng.normal(0, 1, 2 * n)
+        assert all(np.array_equal(x, y) for x, y in zip(w.backprop(g), ws.backprop(g)))
+    assert warm > 5
