@@ -351,7 +351,8 @@ class World:
         # The backward pass ends with clipLossGradientsToBounds (BackpropSnapshot.cpp:425-479): with a coordinate exactly ON a limit the
         # entry of the gradient that points out of the box is zeroed - a property of backprop(), not of the Jacobians, which the
         # reference assembles without it (getStateJacobian, World.cpp:2210-2226).  The clipping looks at the sign, so of the two
-        # products with +e_i and -e_i exactly one keeps such an entry: models with finite limits pay the second pass.
+        # products with +e_i and -e_i exactly one keeps such an entry: models with finite limits pay the second pass.  (A coordinate
+        # whose lower and upper limit coincide and that sits on them is clipped in both: its column stays zero.)
         fl = self._limits_finite()
         for i in range(n2):
             g[i] = 1.0
