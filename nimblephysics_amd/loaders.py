@@ -40,7 +40,11 @@ def load_urdf(path, name=None, weld_joints=(), drop_unsupported_colliders=False)
         name = root.get("name", "model")
     links = {l.get("name"): l for l in root.findall("link")}
     joints = {j.get("name"): j for j in root.findall("joint")}
+    link_names = {ln_.get("name") for ln_ in root.findall("link")}
     for jn_, j_ in joints.items():
+        for end in ("parent", "child"):                                      # (urdfdom refuses such a file: DartLoader returns no skeleton)
+            if j_.find(end) is None or j_.find(end).get("link") not in link_names:
+                raise ValueError(f"{path}: joint {jn_} refers to a {end} link that the file does not define")
         if j_.find("mimic") is not None:
             # DartLoader::addMimicJointsRecursive (DartLoader.cpp:318-380): the joint becomes a MIMIC actuator driven by another joint
             raise ValueError(f"{path}: joint {jn_} is a mimic joint: kinematically driven joints are outside the hot-path scope")

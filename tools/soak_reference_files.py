@@ -1,4 +1,4 @@
-"""Every SKEL world of the reference's data directory that the loader accepts, stepped forward + backward on the device and in the
+"""Every SKEL world and URDF robot of the reference's data directory that the loaders accept, stepped forward + backward on the device and in the
 oracle on random states (GPU box, needs /root/reference - a development tool, not part of the suite): loader -> description -> device
 against loader -> description -> oracle, so what it pins is the DEVICE on the reference's own model files (joint types, frames, inertias,
 collider placement), not the loader.   usage: python tools/soak_reference_files.py [dir] [B]"""
@@ -20,10 +20,11 @@ from oracle import OracleWorld  # noqa: E402
 
 def run(directory, B=64, tol=1e-6):
     tot = {"files": 0, "loaded": 0, "refused_by_loader": 0, "refused_by_device": 0, "worlds": 0, "contact": 0, "gt_tol": 0, "unstable": 0, "MISMATCH": 0}
-    for path in sorted(glob.glob(os.path.join(directory, "**", "*.skel"), recursive=True)):
+    for path in sorted(glob.glob(os.path.join(directory, "**", "*.skel"), recursive=True) + glob.glob(os.path.join(directory, "**", "*.urdf"), recursive=True)):
         tot["files"] += 1
         try:
-            md = na.load_skel(path)
+            # (URDF: colliders outside the analytic narrow phases - meshes - are dropped: what is compared is the dynamics of the file's tree)
+            md = na.load_skel(path) if path.endswith(".skel") else na.load_urdf(path, drop_unsupported_colliders=True)
         except Exception:
             tot["refused_by_loader"] += 1
             continue
