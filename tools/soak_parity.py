@@ -93,8 +93,8 @@ def prove_reference_unstable(ow, seed, tol, s_w, a_w, g_w, dev_w, ref_w, scales,
     """The proof that the reference has no stable answer for one world the device misses by more than tol.  dev_w / ref_w: next state and
     gradients of the device / of the oracle; dev_cache_w: the device's LCP solution (three entries per constraint) + its row count;
     lcp = (row, length): the warm start both sides were given (tools/soak_warm.py; in the device's format: the oracle must be in
-    set_lcp_cache_slots mode).  Returns (how, spread, nearest): how = None (not proven), "state", "unstable_A_ulp", "unstable_A_abs" or
-    "unstable_other_solution"."""
+    set_lcp_cache_slots mode).  Returns (how, spread, nearest): how = None (not proven), "state", "unstable_A_ulp", "unstable_A_abs",
+    "unstable_other_solution" or "rank_ambiguous_guess"."""
     keys = list(dev_w)
 
     def run(sb, nd):
@@ -141,7 +141,25 @@ def prove_reference_unstable(ow, seed, tol, s_w, a_w, g_w, dev_w, ref_w, scales,
     # solver - registration, row classes, standardisation, impulses, the backward pass - run on that solution
     # (OracleWorld.set_lcp_forced) must reproduce the device's next state and gradients within tol.  (Solutions of the
     # friction-less stage are not replayed.)
-    if flipped and (status_w & 0x10) == 0:
+    # (or: the reference's first guess, A^+ b by a complete orthogonal decomposition (LCPUtils.cpp:86-140), sits on a rank decision
+    #  no two implementations have to share - masses four decades apart leave A = J M^-1 J^T with singular values of 1e-8 .. 1e-14
+    #  of its largest, far above Eigen's threshold of 2e-15 and yet nothing but round-off of M^-1: the guess is then A^-1 b at a
+    #  condition number of 1e12, PGS runs its 30 sweeps from there, and whether it converges differs between Eigen's QR, the oracle's and
+    #  the device's pivoted Cholesky.  DESIGN.md section 5, "rank decisions on numerically ambiguous Q".)
+    ambiguous = False
+    if not flipped and (status_w & 0x10) == 0:
+        if lcp is None:
+            ow.reset_lcp_cache()
+        else:
+            ow.set_lcp_cache(lcp[0][:int(lcp[1])])
+        ow.step(s_w, a_w)
+        A_ = ow.last_lcp()["A"]
+        if A_.size and (ow.last_status & 0x18):              # (the record holds A with the fallback CFM on its diagonal once a CFM stage ran)
+            A_ = A_ - ow.model.fallback_cfm * np.eye(len(A_))
+        if A_.size:
+            sv = np.linalg.svd(A_, compute_uv=False)
+            ambiguous = bool(((sv > 1e-14 * sv[0]) & (sv < 1e-8 * sv[0])).any())
+    if (flipped or ambiguous) and (status_w & 0x10) == 0:
         def start():
             if lcp is None:
                 ow.reset_lcp_cache()
@@ -163,7 +181,7 @@ def prove_reference_unstable(ow, seed, tol, s_w, a_w, g_w, dev_w, ref_w, scales,
             d2 = max(np.abs(nx - dev_w["next"]).max() / scales["next"], np.abs(gs - dev_w["grad_state"]).max() / scales["grad_state"],
                      np.abs(ga - dev_w["grad_action"]).max() / scales["grad_action"])
             if not (st_f & 0x40000000) and d2 <= tol:
-                return "unstable_other_solution", spread, nearest
+                return ("unstable_other_solution" if flipped else "rank_ambiguous_guess"), spread, nearest
         ow.set_lcp_forced(None); ow.reset_lcp_cache()
     return None, spread, nearest
 
@@ -173,7 +191,7 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=Fa
   # a world above `tol` must be PROVEN reference-unstable.  Round 2: 1e-5 (north_star).  1e-6 since the record carries the reference's
   # velocity change; at 1e-7 one world in 826 000 of the final soak is left over: a CFM + PGS world (condition number ~1e6) at 1.2e-7
   tol = float(os.environ.get("NBL_SOAK_TOL", "1e-6")) if tol is None else tol
-  tot = {"worlds": 0, "contact": 0, "limit_rows": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "unstable_A_ulp": 0, "unstable_A_abs": 0, "unstable_other_solution": 0, "nonfinite": 0, "MISMATCH": 0}
+  tot = {"worlds": 0, "contact": 0, "limit_rows": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "unstable_A_ulp": 0, "unstable_A_abs": 0, "unstable_other_solution": 0, "rank_ambiguous_guess": 0, "nonfinite": 0, "MISMATCH": 0}
   for seed in range(first, first + count):
       case = make_case(seed, B, big, multi, balls, far)
       if case is None:
