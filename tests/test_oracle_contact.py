@@ -481,3 +481,16 @@ def test_the_soak_instruments_leave_the_oracle_alone_when_off_and_replay_its_own
     w.set_lcp_forced(None)
     w.reset_lcp_cache()
     assert np.array_equal(w.step(s[i], a[i]), nx)
+
+
+def test_the_oracle_flags_a_contact_kept_after_sixteen_distinct_narrow_phase_points():
+    """The device's duplicate filter remembers 16 distinct points per world (kept or dropped by the depth filter); a contact kept after
+    that may be an unnoticed duplicate, the device flags the world (NBL_ST_CONTACT_OVERFLOW) and the oracle raises the same flag by
+    the same rule, so that a comparison can leave the world out (tests/test_gpu_contact.py has the device side)."""
+    from util import duplicate_filter_scene
+    for deep, flagged in ((4, True), (3, False)):
+        md, s, a = duplicate_filter_scene(deep)
+        w = OracleWorld(md)
+        w.step(s[0], a[0])
+        assert len(w.last_contacts()) == 4 and (w.last_status & 0x1)
+        assert bool(w.last_status & 0x80) == flagged, (deep, hex(w.last_status))

@@ -177,3 +177,20 @@ def have_ref():
     import os
     import oracle
     return os.path.exists(os.path.join(os.path.dirname(oracle.__file__), "_ref", "libodelcp_ref.so"))
+
+
+def duplicate_filter_scene(deep=4):
+    """One free body carrying `deep` + 1 small boxes in a row above a ground plate: the first `deep` sit 0.05 deep in the ground (their
+    four bottom corners are narrow-phase points that the depth filter drops - 0.03 is the clipping depth), the last one 0.01 deep (four
+    contacts).  With deep = 4 the kept contacts arrive as distinct points 17..20 of the world: past the 16 the device's duplicate
+    filter remembers (NBL_ST_CONTACT_OVERFLOW); with deep = 3 as points 13..16: no flag.  -> (model, state [1, 12], action [1, 6])."""
+    import nimblephysics_amd as na
+    I = (0.02, 0.02, 0.02, 0.0, 0.0, 0.0)
+    bodies = [na.BodySpec("carrier", -1, "free", "root", mass=1.0, inertia=I)]
+    boxes = [na.BoxSpec(-1, na.make_transform((0.0, -0.5, 0.0)), (10.0, 1.0, 10.0), 1.0)]
+    for k in range(deep + 1):
+        down = 0.05 if k < deep else 0.01
+        boxes.append(na.BoxSpec(0, na.make_transform((0.3 * k, 0.05 - down, 0.0)), (0.1, 0.1, 0.1), 1.0))
+    md = na.ModelDescription("duplicate_filter", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=8)
+    s = np.zeros((1, 12)); s[0, 1] = 0.01                        # a little yaw: no two corners share a coordinate
+    return md, s, np.zeros((1, 6))
