@@ -68,8 +68,9 @@ extern "C" {
 #define NBL_ST_LCP_FAILED 0x20u   /* every stage failed its validity check: like the reference, the last stage's (frictionless PGS) iterate is applied as is
                                      (BoxedLcpConstraintSolver.cpp:590-676); the impulses are zeroed only if that iterate is non-finite (:678-687, NBL_ST_NAN) */
 #define NBL_ST_NAN 0x40u          /* non-finite value seen: in the LCP stages, or in the world's next state (NaN / Inf inputs); other worlds are unaffected */
-#define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts (+ active joint-limit rows) than max_contacts: extra ones dropped; or a contact kept after 16
-                                        distinct points from the narrow phases (kept or dropped by the depth filter): the duplicate filter's memory */
+#define NBL_ST_CONTACT_OVERFLOW 0x80u /* more contacts (+ active joint-limit rows) than max_contacts: extra ones dropped; or a contact kept after
+                                        2 x nbl_model_max_contacts() distinct points from the narrow phases (kept or dropped by the depth filter):
+                                        the duplicate filter's memory */
 #define NBL_ST_STANDARDIZED 0x100u /* least-squares standardized x replaced solver x (CGGM.cpp:321-332) */
 #define NBL_ST_JOINT_LIMIT 0x400u  /* >=1 joint-limit constraint row was active (dof_limit_enforced) */
 #define NBL_ST_GRAD_PARTIAL 0x200u /* reserved (never set: the EDGE_EDGE contact-geometry gradient terms, DCC.cpp:397-424,
@@ -114,7 +115,10 @@ typedef struct nbl_model_desc {
   const double* box_T;      /* [n_boxes][12] shape transform in the body frame */
   const double* box_size;   /* [n_boxes][3] full side lengths */
   const double* box_mu;     /* [n_boxes] friction coefficient of the owning body (default 1, BodyNodeAspect.hpp:47) */
-  int32_t max_contacts;     /* per world; rows m = 3 * max_contacts */
+  int32_t max_contacts;     /* per world, <= 16; rows m = 3 * max_contacts.  The reference keeps every contact of every pair
+                               (ConstraintSolver.cpp:563-606); a world with more is truncated and flagged NBL_ST_CONTACT_OVERFLOW.  The library
+                               holds two instantiations of its contact stage: models with max_contacts <= 8, <= 16 colliders and <= 32
+                               collider pairs run the 24-row one, everything up to 16 contacts / 32 colliders / 64 pairs the 48-row one */
 
   /* ---- options mirrored from the reference defaults ---- */
   double contact_clipping_depth; /* 0.03  World.cpp:86 */
@@ -191,8 +195,9 @@ const char* nbl_last_error(void);
  * pointer / zero in an appended field always means "the behaviour before that field existed"; a caller that zero-initialises
  * the struct and is compiled against this header keeps working, a caller compiled against minor k needs a library of minor >= k:
  *   minor 1: the struct up to and including pitch;
- *   minor 2: + dof_limit_enforced, body_self_collision, box_node, box_node_parent; NBL_SHAPE_CAPSULE; NBL_ST_JOINT_LIMIT. */
-#define NBL_ABI_MINOR 2
+ *   minor 2: + dof_limit_enforced, body_self_collision, box_node, box_node_parent; NBL_SHAPE_CAPSULE; NBL_ST_JOINT_LIMIT;
+ *   minor 3: max_contacts up to 16 (32 colliders, 64 pairs); + nbl_model_max_contacts, nbl_selftest_pinv_rows; the Dantzig self-test takes n <= 48. */
+#define NBL_ABI_MINOR 3
 int32_t nbl_version(void);
 
 /* Number of visible HIP devices (0 if none). */
@@ -207,7 +212,8 @@ void nbl_model_destroy(nbl_model* m);
 
 int32_t nbl_model_num_dofs(const nbl_model* m);
 int32_t nbl_model_num_action(const nbl_model* m);
-int32_t nbl_model_lcp_rows(const nbl_model* m); /* rows of the LCP warm-start buffer: 24 impulses + 1 row holding the row count they belong to; 0 without colliders */
+int32_t nbl_model_lcp_rows(const nbl_model* m); /* rows of the LCP warm-start buffer: 3 * nbl_model_max_contacts() impulses + 1 row holding the row count they belong to; 0 without colliders */
+int32_t nbl_model_max_contacts(const nbl_model* m); /* contact slots per world of the instantiation the model runs on: 8 or 16 (>= desc.max_contacts); 0 without colliders */
 
 /* Bytes of scratch the library needs for a batch of B worlds (forward or backward). */
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B);
@@ -339,7 +345,8 @@ int32_t nbl_rollout_backward_checkpointed(nbl_model* m, int64_t B, int32_t T, in
  * nub = 0, earlyTermination = true; the stage-1 code of the LCP cascade) on `count` caller-supplied n-row problems, one wavefront
  * per problem.  HOST pointers: A [count][n*n] row-major (only the lower triangles are read), b / lo / hi / findex [count][n] with
  * the bounds as DantzigBoxedLcpSolver::solve hands them over (friction rows: lo = -mu, hi = mu, findex = their normal row);
- * outputs x [count][n] and rc [count] (1 solved, 0 early termination, -1 NaN step).  Synchronous; for tests: on identical
+ * outputs x [count][n] and rc [count] (1 solved, 0 early termination, -1 NaN step).  n <= 48 (n <= 24 runs the 24-row instantiation's
+ * code, larger n the 48-row one's).  Synchronous; for tests: on identical
  * inputs x and rc are bit-identical to the reference solver's. */
 int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                  const int32_t* findex, double* x, int32_t* rc);
@@ -356,6 +363,9 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
  * between two HIP events, *ms_per_launch (may be NULL) = average launch duration.  For tests and tools/pinv_bench.py. */
 int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank, int32_t reps,
                           double* ms_per_launch);
+/* The same on rows x rows matrices, rows = 24 or 48: the pseudo-inverses of the 24-row and of the 48-row instantiation of the contact stage. */
+int32_t nbl_selftest_pinv_rows(int32_t count, int32_t rows, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank,
+                               int32_t reps, double* ms_per_launch);
 
 /*
  * Layout helpers: the Python surface takes world-major tensors [B][d] like a stack of the

@@ -38,7 +38,7 @@ def lib():
     L.nbl_model_create.restype = C.c_int32
     L.nbl_model_destroy.argtypes = [vp]
     L.nbl_model_destroy.restype = None
-    for f in ("nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows"):
+    for f in ("nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows", "nbl_model_max_contacts"):
         getattr(L, f).argtypes = [vp]
         getattr(L, f).restype = C.c_int32
     L.nbl_workspace_bytes.argtypes = [vp, C.c_int64]
@@ -100,6 +100,8 @@ def lib():
     L.nbl_selftest_lcp_dantzig_timed.restype = C.c_int32
     L.nbl_selftest_pinv.argtypes = [C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_int32, vp]
     L.nbl_selftest_pinv.restype = C.c_int32
+    L.nbl_selftest_pinv_rows.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_int32, vp]
+    L.nbl_selftest_pinv_rows.restype = C.c_int32
     _lib = L
     return L
 
@@ -111,6 +113,7 @@ EXPORTED_SYMBOLS = [
     "nbl_set_body_inertia", "nbl_set_body_inertias", "nbl_set_inertia_params", "nbl_set_inertia_params_on", "nbl_num_inertia_params", "nbl_backward_inertia", "nbl_rollout_backward_inertia",
     "nbl_rollout_checkpoint_bytes", "nbl_rollout_forward_checkpointed", "nbl_rollout_backward_checkpointed",
     "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing", "nbl_selftest_lcp_dantzig", "nbl_selftest_lcp_dantzig_timed", "nbl_selftest_pinv",
+    "nbl_model_max_contacts", "nbl_selftest_pinv_rows",
 ]
 
 

@@ -19,10 +19,10 @@ template <int I> struct IntTag { static constexpr int value = I; };
 // eight values: a statement waits for its own operands only, so the 24 loads of a row stay in flight together.
 DEV void coopPin24(double (&a)[MAXR]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(MAXR == 24, "three groups of eight");
-  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-  asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
-  asm volatile("" : "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]));
+  static_assert(MAXR % 8 == 0, "groups of eight");
+#pragma unroll
+  for (int g = 0; g < MAXR; g += 8)
+    asm volatile("" : "+v"(a[g]), "+v"(a[g + 1]), "+v"(a[g + 2]), "+v"(a[g + 3]), "+v"(a[g + 4]), "+v"(a[g + 5]), "+v"(a[g + 6]), "+v"(a[g + 7]));
 #endif
 }
 
@@ -555,55 +555,73 @@ DEV int coopLcpRemoveFriction(const W& w, LDS& C, int n, CoopLcpRow& row, int& m
 //     normal row; other rows (cL, cH) = (lo, hi) and xf = 1; rows left out (a_ii < eps, lanes >= n) cL = cH = 0, which pins them to
 //     0 exactly like the reference's "x[i] = 0; continue";
 //   * xf follows the normal row through the broadcast change, and only after NORMAL rows (a wave-uniform bit test);
-//   * the sweep is instantiated for 8, 16 or 24 rows (the frictionless stage has 8).
+//   * the sweep is instantiated for MAXR / 3, 2 MAXR / 3 or MAXR rows (24-row build: 8, 16, 24; the frictionless stage has 8).
 // One row step = two hand-scheduled blocks around the broadcast.  In C++ the step compiled to 42-86 instructions (lane masks
 // hoisted and spilled to VGPR lanes, boolean bookkeeping in 64-bit scalar masks, selects instead of the uniform skip); written
 // out it is 18 (first sweep) / 21 instructions.  Both blocks run in wave-uniform control flow and restore EXEC themselves.
 //   pgsOwnRow<I>:    on lane I only:  xi = min(max(x + r, cL xf), cH xf);  d = xi - x;  bad |= test(d, xi);  x = xi
 //   pgsFollowRow<I>: on the lanes whose findex is I:  xf += ds   (ds = d of lane I, wave-uniform)
 #if defined(__HIP_DEVICE_COMPILE__)
+#define NBL_PGS_OWN_FIRST                         \
+        "s_mov_b64 %[sv], exec\n\t"                 \
+        "s_mov_b64 exec, %[lane]\n\t"               \
+        "v_add_f64 %[t0], %[x], %[r]\n\t"           \
+        "v_mul_f64 %[d], %[cL], %[xf]\n\t"          \
+        "v_max_f64 %[t0], %[t0], %[d]\n\t"          \
+        "v_mul_f64 %[d], %[cH], %[xf]\n\t"          \
+        "v_min_f64 %[t0], %[t0], %[d]\n\t"          \
+        "v_add_f64 %[d], %[t0], -%[x]\n\t"          \
+        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[thr]\n\t"  \
+        "s_or_b64 %[bad], %[bad], vcc\n\t"          \
+        "v_mov_b64 %[x], %[t0]\n\t"                 \
+        "s_mov_b64 exec, %[sv]"
+#define NBL_PGS_OWN_LATER                         \
+        "s_mov_b64 %[sv], exec\n\t"                 \
+        "s_mov_b64 exec, %[lane]\n\t"               \
+        "v_add_f64 %[t0], %[x], %[r]\n\t"           \
+        "v_mul_f64 %[d], %[cL], %[xf]\n\t"          \
+        "v_max_f64 %[t0], %[t0], %[d]\n\t"          \
+        "v_mul_f64 %[d], %[cH], %[xf]\n\t"          \
+        "v_min_f64 %[t0], %[t0], %[d]\n\t"          \
+        "v_add_f64 %[d], %[t0], -%[x]\n\t"          \
+        "v_mul_f64 %[t2], |%[t0]|, %[rel]\n\t"      \
+        "v_cmp_gt_f64_e64 %[sc], |%[t0]|, %[eps]\n\t" \
+        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[t2]\n\t"   \
+        "s_and_b64 vcc, vcc, %[sc]\n\t"             \
+        "s_or_b64 %[bad], %[bad], vcc\n\t"          \
+        "v_mov_b64 %[x], %[t0]\n\t"                 \
+        "s_mov_b64 exec, %[sv]"
+// (the lane mask of row I: an inline constant for rows < 32; rows 32 .. 47 of the 16-contact build take it from an SGPR pair)
 template <int I, bool FIRST>
 DEV double pgsOwnRow(double& x, double r, double xf, double cL, double cH, double thrFirst, double relTol, double epsDiv,
                      unsigned long long& bad) {
   double d, t0, t2;
   unsigned long long sv, sc;
-  if (FIRST) {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[lane]\n\t"
-        "v_add_f64 %[t0], %[x], %[r]\n\t"
-        "v_mul_f64 %[d], %[cL], %[xf]\n\t"
-        "v_max_f64 %[t0], %[t0], %[d]\n\t"
-        "v_mul_f64 %[d], %[cH], %[xf]\n\t"
-        "v_min_f64 %[t0], %[t0], %[d]\n\t"
-        "v_add_f64 %[d], %[t0], -%[x]\n\t"
-        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[thr]\n\t"
-        "s_or_b64 %[bad], %[bad], vcc\n\t"
-        "v_mov_b64 %[x], %[t0]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [sv] "=&s"(sv)
-        : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [thr] "v"(thrFirst), [lane] "n"(1u << I)
-        : "vcc", "scc");
+  if constexpr (I < 32) {
+    if (FIRST) {
+      asm volatile(NBL_PGS_OWN_FIRST
+          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [sv] "=&s"(sv)
+          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [thr] "v"(thrFirst), [lane] "n"(1u << (I & 31))
+          : "vcc", "scc");
+    } else {
+      asm volatile(NBL_PGS_OWN_LATER
+          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [t2] "=&v"(t2), [sv] "=&s"(sv), [sc] "=&s"(sc)
+          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [rel] "v"(relTol), [eps] "v"(epsDiv), [lane] "n"(1u << (I & 31))
+          : "vcc", "scc");
+    }
   } else {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[lane]\n\t"
-        "v_add_f64 %[t0], %[x], %[r]\n\t"
-        "v_mul_f64 %[d], %[cL], %[xf]\n\t"
-        "v_max_f64 %[t0], %[t0], %[d]\n\t"
-        "v_mul_f64 %[d], %[cH], %[xf]\n\t"
-        "v_min_f64 %[t0], %[t0], %[d]\n\t"
-        "v_add_f64 %[d], %[t0], -%[x]\n\t"
-        "v_mul_f64 %[t2], |%[t0]|, %[rel]\n\t"
-        "v_cmp_gt_f64_e64 %[sc], |%[t0]|, %[eps]\n\t"
-        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[t2]\n\t"
-        "s_and_b64 vcc, vcc, %[sc]\n\t"
-        "s_or_b64 %[bad], %[bad], vcc\n\t"
-        "v_mov_b64 %[x], %[t0]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [t2] "=&v"(t2), [sv] "=&s"(sv), [sc] "=&s"(sc)
-        : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [rel] "v"(relTol), [eps] "v"(epsDiv), [lane] "n"(1u << I)
-        : "vcc", "scc");
+    const unsigned long long laneMask = 1ull << I;
+    if (FIRST) {
+      asm volatile(NBL_PGS_OWN_FIRST
+          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [sv] "=&s"(sv)
+          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [thr] "v"(thrFirst), [lane] "s"(laneMask)
+          : "vcc", "scc");
+    } else {
+      asm volatile(NBL_PGS_OWN_LATER
+          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [t2] "=&v"(t2), [sv] "=&s"(sv), [sc] "=&s"(sc)
+          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [rel] "v"(relTol), [eps] "v"(epsDiv), [lane] "s"(laneMask)
+          : "vcc", "scc");
+    }
   }
   return d;   // defined on lane I only
 }
@@ -633,6 +651,15 @@ DEV double pgsOwnRow(double& x, double r, double xf, double cL, double cH, doubl
 template <int I>
 DEV void pgsFollowRow(double& xf, int fi, double ds) { if (fi == I) xf += ds; }
 #endif
+
+// rowStep(IntTag<I0>{}, tag); ... rowStep(IntTag<I1 - 1>{}, tag);   (a compile-time unrolled row loop: the row index is an instruction operand)
+template <int I0, int I1, class F, class T>
+DEV void pgsRowRange(F& rowStep, T tag) {
+  if constexpr (I0 < I1) {
+    rowStep(IntTag<I0>{}, tag);
+    pgsRowRange<I0 + 1, I1>(rowStep, tag);
+  }
+}
 
 template <class W, class LDS>
 DEV bool coopPgs(const W& w, LDS& C, int n, CoopLcpRow& row) {
@@ -681,16 +708,7 @@ DEV bool coopPgs(const W& w, LDS& C, int n, CoopLcpRow& row) {
   };
   auto sweep = [&](auto nTag, auto firstTag) {
     constexpr int NR = decltype(nTag)::value;
-    rowStep(IntTag<0>{}, firstTag); rowStep(IntTag<1>{}, firstTag); rowStep(IntTag<2>{}, firstTag); rowStep(IntTag<3>{}, firstTag);
-    rowStep(IntTag<4>{}, firstTag); rowStep(IntTag<5>{}, firstTag); rowStep(IntTag<6>{}, firstTag); rowStep(IntTag<7>{}, firstTag);
-    if (NR > 8) {
-      rowStep(IntTag<8>{}, firstTag); rowStep(IntTag<9>{}, firstTag); rowStep(IntTag<10>{}, firstTag); rowStep(IntTag<11>{}, firstTag);
-      rowStep(IntTag<12>{}, firstTag); rowStep(IntTag<13>{}, firstTag); rowStep(IntTag<14>{}, firstTag); rowStep(IntTag<15>{}, firstTag);
-    }
-    if (NR > 16) {
-      rowStep(IntTag<16>{}, firstTag); rowStep(IntTag<17>{}, firstTag); rowStep(IntTag<18>{}, firstTag); rowStep(IntTag<19>{}, firstTag);
-      rowStep(IntTag<20>{}, firstTag); rowStep(IntTag<21>{}, firstTag); rowStep(IntTag<22>{}, firstTag); rowStep(IntTag<23>{}, firstTag);
-    }
+    pgsRowRange<0, NR>(rowStep, firstTag);       // rowStep(IntTag<0>{}, firstTag); ... rowStep(IntTag<NR - 1>{}, firstTag);
   };
 #if defined(__HIP_DEVICE_COMPILE__)
   auto noneBad = [&]() -> bool { return bad == 0ull; };                 // "no row moved by more than the tolerance"
@@ -709,7 +727,8 @@ DEV bool coopPgs(const W& w, LDS& C, int n, CoopLcpRow& row) {
     }
     return done;
   };
-  const bool done = n <= 8 ? solve(IntTag<8>{}) : (n <= 16 ? solve(IntTag<16>{}) : solve(IntTag<24>{}));
+  // (the sweep is instantiated for a third, two thirds and all of the rows)
+  const bool done = n <= MAXR / 3 ? solve(IntTag<MAXR / 3>{}) : (n <= 2 * MAXR / 3 ? solve(IntTag<2 * MAXR / 3>{}) : solve(IntTag<MAXR>{}));
   row.x = x;
   return done;
 }
@@ -750,9 +769,9 @@ DEV void coopLoadProblem(const W& w, LDS& C, const CoopRow& R, double cfmDiag, d
   // The empty tangent rows of frictionless contacts (mu <= 1e-3, k_contact_rows_coop) do not exist in the reference's problem
   // (ContactConstraint dimension 1): take them out, from the last one down, so that the solvers see the reference's rows in the
   // reference's order - the initial permutation of dSolveLCP and with it the whole pivot sequence depend on it.
-  const uint32_t dead = (uint32_t)w.ballot(ln < m && (!R.on || (R.fric && R.mu == 0.0)));   // ... and the rows of the world's other constrained groups
+  const RowMask dead = (RowMask)w.ballot(ln < m && (!R.on || (R.fric && R.mu == 0.0)));   // ... and the rows of the world's other constrained groups
   nOut = m;
-  if (dead != 0u) {
+  if (dead != 0) {
     for (int i = m - 1; i >= 0; i--) {
       if (!((dead >> i) & 1u)) continue;
       if (row.findex > i) row.findex -= 1;

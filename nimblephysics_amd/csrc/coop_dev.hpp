@@ -1,12 +1,14 @@
 // coop_dev.hpp — wavefront-cooperative dense linear algebra for the contact LCP: ONE WORLD PER WAVEFRONT.
 //
-// The one-world-per-lane kernels (lcp_dev.hpp) are a single long dependent instruction stream per wave (~6e5
-// instructions for a 24-row stage-0 solve) and a B = 4096 launch has only 64..256 of them for 1024 SIMDs.  Here a
-// wavefront owns one world; lane j (< 24) owns column j / row j of the 24 x 24 system, lanes 24..47 carry the
-// identity through the factorisation (they end up holding H^T explicitly, for free), and the serial chain per wave
-// drops to ~1e4 instructions while 4096 waves fill the chip.
+// A one-world-per-lane solver is a single long dependent instruction stream per wave (~6e5 instructions for a 24-row
+// stage-0 solve) and a B = 4096 launch has only 64..256 of them for 1024 SIMDs.  Here a wavefront owns one world; lane j
+// (< MAXR) owns column j / row j of the MAXR x MAXR system (MAXR = 24, or 48 in the 16-contact build), and the serial
+// chain per wave drops to ~1e4 instructions while 4096 waves fill the chip.  With 24 rows, lanes 24..47 carry the identity
+// through the Householder factorisation (they end up holding H^T explicitly, for free); with 48 rows the reflectors are
+// recorded in LDS and played back on the identity in a second pass over the same lanes (coopQrReplay).
 //
-// Same mathematics as lcp_dev.hpp (which remains the host-testable statement of it and the slow-path code):
+// Same mathematics as the plain sequential statement in tests/host_shim/lane_lcp_statement.hpp (test harness only: the
+// host-testable statement the CPU tests compare this code with):
 //   * column-pivoted Householder QR, rank by Eigen's threshold eps * size * |R_00| (CGGM.cpp:280, LCPUtils.cpp:113)
 //   * complete orthogonal decomposition for rank-deficient systems: a second (unpivoted) Householder QR of R^T,
 //     R = [T^T 0] Z^T, minimum-norm solution Z1 T^-T c1 (what Eigen's completeOrthogonalDecomposition().solve() returns)
@@ -47,13 +49,29 @@ DEV void coopSchedFence() {
 #endif
 }
 
+// The two pseudo-inverse routes are inlined into their callers in the 24-row build (measured: out of line costs 10 us per call there, see
+// coopPinv below).  The 48-row build - whose job is to exist, not to set the headline - keeps them out of line: one copy per kernel
+// instead of up to four fully unrolled 48-step factorisations (compile time and code size).
+#if NBL_MAXC > 8 && defined(__HIP_DEVICE_COMPILE__)
+#define DEV_PINV __device__ __noinline__
+#else
+#define DEV_PINV DEV
+#endif
+
 constexpr int CLD = MAXR + 1;  // odd leading dimension: row reads and column reads of the LDS matrices are both conflict-free
+constexpr int MFMA_TILES = (MAXR + 15) / 16;   // 16 x 16 output tiles per dimension of a MAXR x MAXR product on v_mfma_f64_16x16x4_f64
+
+// The block carried through a Householder factorisation (the identity, ending as H^T / Z^T) rides on lanes MAXR .. 2 MAXR - 1 of the same
+// pass when they exist (24 rows); otherwise (48 rows) every reflector stays in LDS (CoopLds::refl) and coopQrReplay applies them to the
+// carried columns afterwards, on lanes 0 .. MAXR - 1.
+constexpr bool QR_CARRY_LANES = 2 * MAXR <= 64;
 
 struct CoopLds {
   double R[MAXR * CLD];        // rows of R (lane order; perm maps pivot position -> lane), later rows of T
   double G[MAXR * CLD];        // rows of G = H^T
   double P[MAXR * CLD];        // rows of Z^T during the second factorisation, then the pseudo-inverse (row-major)
-  double vbuf[2][MAXR + 2];    // reflector broadcast, double-buffered: [1..23] v (v_0 = 1 implied), [24] tau
+  double vbuf[2][MAXR + 2];    // reflector broadcast, double-buffered: [1..MAXR-1] v (v_0 = 1 implied), [MAXR] tau, [MAXR+1] 1 / v_k
+  double refl[QR_CARRY_LANES ? 2 : MAXR * (MAXR + 2)];   // !QR_CARRY_LANES: the reflector of every step, same layout as vbuf
   double invd[MAXR];           // reciprocals of the diagonal of R / T
   double vec[4][MAXR];         // vector broadcast scratch
   int perm[MAXR];
@@ -106,7 +124,7 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
     // not zeroed either: a finished column is never a candidate again and its rows of the triangular factor are written as
     // zeros below (one select instead of 23 moves).
     const bool wasDone = done;
-    double* vb = S.vbuf[k & 1];
+    double* vb = QR_CARRY_LANES ? S.vbuf[k & 1] : S.refl + k * (MAXR + 2);
     if (ln == p) {
       vb[MAXR] = tauMine;
       vb[MAXR + 1] = inv;
@@ -132,7 +150,7 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
 #pragma unroll
     for (int i = 1; i < MAXR; i++) a[i] = fma(-dv, vb[i], a[i]);   // v re-read from LDS: cheaper than 48 live VGPRs
     if (ln < MAXR) rowsOut[k * CLD + ln] = wasDone ? 0.0 : a[0];
-    else if (ln < 2 * MAXR) carryOut[k * CLD + ln - MAXR] = a[0];
+    else if (QR_CARRY_LANES && ln < 2 * MAXR) carryOut[k * CLD + ln - MAXR] = a[0];
 #pragma unroll
     for (int i = 0; i < MAXR - 1; i++) a[i] = a[i + 1];
     a[MAXR - 1] = 0.0;
@@ -148,18 +166,55 @@ DEV int coopQr(const W& w, double (&a)[MAXR], CoopLds& S, double* rowsOut, doubl
   return rank;
 }
 
-// S.P <- pseudo-inverse of the 24 x 24 matrix whose column j is a[] of lane j (< 24) (masked rows/columns zero);
+// !QR_CARRY_LANES: the `steps` reflectors the last coopQr left in S.refl, applied to the carried block whose column j is a[] of lane j
+// (< MAXR) - the arithmetic of the carried lanes of coopQr, one pass later.  Row k of the result goes to carryOut[k * CLD + lane].
+template <class W>
+DEV void coopQrReplay(const W& w, double (&a)[MAXR], CoopLds& S, double* carryOut, int steps) {
+  const int ln = w.lane();
+#pragma unroll 1
+  for (int k = 0; k < steps; k++) {
+    const double* vb = S.refl + k * (MAXR + 2);
+    const double tau = vb[MAXR], vinv = vb[MAXR + 1];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+    for (int i = 1; i + 3 < MAXR; i += 4) {
+      d0 = fma(vb[i], a[i], d0); d1 = fma(vb[i + 1], a[i + 1], d1); d2 = fma(vb[i + 2], a[i + 2], d2); d3 = fma(vb[i + 3], a[i + 3], d3);
+    }
+#pragma unroll
+    for (int i = 1 + 4 * ((MAXR - 1) / 4); i < MAXR; i++) d0 = fma(vb[i], a[i], d0);
+    double d = fma(vinv, (d0 + d1) + (d2 + d3), a[0]);
+    d = d * tau;
+    a[0] -= d;
+    const double dv = d * vinv;
+#pragma unroll
+    for (int i = 1; i < MAXR; i++) a[i] = fma(-dv, vb[i], a[i]);
+    if (ln < MAXR) carryOut[k * CLD + ln] = a[0];
+#pragma unroll
+    for (int i = 0; i < MAXR - 1; i++) a[i] = a[i + 1];
+    a[MAXR - 1] = 0.0;
+  }
+  w.sync();
+}
+
+// a[] <- column e of the identity (e out of range: zero)
+DEV void coopIdentityColumn(double (&a)[MAXR], int eIn) {
+  const int e = opaqueI(eIn);
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) a[i] = (e == i) ? 1.0 : 0.0;
+}
+
+// S.P <- pseudo-inverse of the MAXR x MAXR matrix whose column j is a[] of lane j (< MAXR) (masked rows/columns zero);
 // cTrue = number of unmasked columns (Eigen's `size` in the rank threshold).  Returns the rank.
 template <class W>
-DEV int coopPinvImpl(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
+DEV_PINV int coopPinvImpl(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
   const int ln = w.lane();
-  if (ln >= MAXR) {
-    const int e = opaqueI(ln - MAXR);
-#pragma unroll
-    for (int i = 0; i < MAXR; i++) a[i] = (e == i) ? 1.0 : 0.0;
-  }
+  if (QR_CARRY_LANES && ln >= MAXR) coopIdentityColumn(a, ln - MAXR);
   const double thr = 2.220446049250313e-16 * cTrue;
   const int r = coopQr<W, true>(w, a, S, S.R, S.G, MAXR, thr * thr);
+  if (!QR_CARRY_LANES && r > 0) {
+    coopIdentityColumn(a, ln < MAXR ? ln : -1);
+    coopQrReplay(w, a, S, S.G, r);
+  }
   if (r == 0) {
 #pragma unroll
     for (int i = 0; i < MAXR; i++) if (ln < MAXR) S.P[i * CLD + ln] = 0.0;
@@ -198,13 +253,13 @@ DEV int coopPinvImpl(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) {
   if (ln < MAXR) {
 #pragma unroll
     for (int pp = 0; pp < MAXR; pp++) a[pp] = (ln < r) ? S.R[ln * CLD + S.perm[pp]] : 0.0;
-  } else {
-    const int e = opaqueI(ln - MAXR);
-#pragma unroll
-    for (int i = 0; i < MAXR; i++) a[i] = (e == i) ? 1.0 : 0.0;
-  }
+  } else if (QR_CARRY_LANES) coopIdentityColumn(a, ln - MAXR);
   w.sync();   // every row of R is in registers before T overwrites the buffer
   coopQr<W, false>(w, a, S, S.R, S.P, r, 0.0);
+  if (!QR_CARRY_LANES) {
+    coopIdentityColumn(a, ln < MAXR ? ln : -1);
+    coopQrReplay(w, a, S, S.P, r);
+  }
   if (ln < r) S.invd[ln] = 1.0 / S.R[ln * CLD + ln];
   w.sync();
   // column j of Q^+ = P Z1 T^-T G1[:, j] in two passes, so that the 24 substitution registers and the 24 accumulators are never
@@ -275,7 +330,7 @@ DEV double coopRsqrt(double x) {
 // compile-time constant; a full-rank Q (every Q with the fallback CFM on its diagonal) skips steps 2-3: there W = G^-T, one
 // substitution with the (row-permuted) triangular G itself.
 template <class W>
-DEV int coopPinvSymImpl(const W& w, CoopLds& S, int cTrue) {      // Q in S.R[i][j] (symmetric)
+DEV_PINV int coopPinvSymImpl(const W& w, CoopLds& S, int cTrue) {      // Q in S.R[i][j] (symmetric)
   const int ln = w.lane();
   const bool act = ln < MAXR;
   const int row = act ? ln : 0;
@@ -350,10 +405,10 @@ DEV int coopPinvSymImpl(const W& w, CoopLds& S, int cTrue) {      // Q in S.R[i]
     // v_mfma_f64_16x16x4_f64: A operand lane l = A[l & 15][l >> 4], B operand lane l = B[l >> 4][l & 15], D register q of lane l =
     // D[(l >> 4) + 4 q][l & 15].  K[m][n] = sum_j G[j][m] G[j][n]: both operands read G[4 ks + lk][16 t + li].
 #pragma unroll
-    for (int tr = 0; tr < 2; tr++) {
+    for (int tr = 0; tr < MFMA_TILES; tr++) {
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++) {
-        if ((tr == 0 && tj == 0) || r > 16) {          // ranks up to 16 (two flat feet: 12) need one tile
+      for (int tj = 0; tj < MFMA_TILES; tj++) {
+        if (r > 16 * (tr > tj ? tr : tj)) {            // ranks up to 16 (two flat feet: 12) need one tile
           v4d acc = {0.0, 0.0, 0.0, 0.0};
           const int mi = 16 * tr + li, ni = 16 * tj + li;
           const int mc = mi < MAXR ? mi : 0, nc2 = ni < MAXR ? ni : 0;
@@ -437,9 +492,9 @@ DEV int coopPinvSymImpl(const W& w, CoopLds& S, int cTrue) {      // Q in S.R[i]
   {
     const int ksteps = (r + 3) >> 2;
 #pragma unroll
-    for (int tr = 0; tr < 2; tr++) {
+    for (int tr = 0; tr < MFMA_TILES; tr++) {
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++) {
+      for (int tj = 0; tj < MFMA_TILES; tj++) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const int mi = 16 * tr + li, ni = 16 * tj + li;
         const int mc = mi < MAXR ? mi : 0, nc2 = ni < MAXR ? ni : 0;
@@ -529,7 +584,7 @@ struct CoopRow {
   // joint-limit rows (model_dev.hpp, CT_LIMIT; only the general - MULTI - instantiation of the contact kernels sets these): this lane's row
   // is one / it is carried negated (upper limit) / the limit rows of the world (uniform)
   bool lim = false, neg = false;
-  uint32_t limMask = 0u;
+  RowMask limMask = 0;
   bool on;             // this lane's row exists in the problem being solved: lane < m and, where a world has several
                        // constrained groups, its row belongs to the group at hand (rows that are off are inert everywhere)
   DEV double a(int i) const { return (on && i < m) ? Acol[i * MAXR] : 0.0; }
@@ -594,7 +649,7 @@ DEV bool coopValid(const W& w, CoopLds& S, const CoopRow& R, double X, bool igno
 struct CoopClasses {
   int cls;            // this lane's row
   double E;
-  uint32_t clampMask, ubMask;   // uniform
+  RowMask clampMask, ubMask;   // uniform
   int nc, nu;
 };
 
@@ -627,10 +682,10 @@ DEV void coopClassify(const W& w, const CoopRow& R, double X, bool ignoreFrictio
     E = (fabs(X - ub) < fabs(X - lb)) ? hi : lo;
   }
   K.cls = cls; K.E = E;
-  K.clampMask = (uint32_t)clampBits;
-  K.ubMask = (uint32_t)w.ballot(cls == RC_UPPER_BOUND);
-  K.nc = __builtin_popcount(K.clampMask);
-  K.nu = __builtin_popcount(K.ubMask);
+  K.clampMask = (RowMask)clampBits;
+  K.ubMask = (RowMask)w.ballot(cls == RC_UPPER_BOUND);
+  K.nc = rmPop(K.clampMask);
+  K.nu = rmPop(K.ubMask);
 }
 
 // lane s (< 24): a[i] = Q[i][s] = A[i][s] + [s normal] sum_{u = s+1, s+2 upper-bound} E[u] A[i][u] + cfm [i == s]
@@ -688,7 +743,7 @@ struct CoopStage0 {
 // already in S.P (stage 0's guess), 0 / false otherwise.  Returns whether the results are standardised.
 template <class W>
 DEV bool coopStandardizeLoop(const W& w, CoopLds& S, const CoopRow& R, double& X, double cfm, bool ignoreFriction,
-                             uint32_t guessMask, bool& pinvValid, CoopClasses& K) {
+                             RowMask guessMask, bool& pinvValid, CoopClasses& K) {
   double a[MAXR];
   bool ok = false;
 #pragma unroll 1
@@ -733,21 +788,21 @@ template <class W>
 DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, double Xcache, CoopStage0& out) {
   const int ln = w.lane();
   double X = 0.0;
-  uint32_t guessMask = 0;
+  RowMask guessMask = 0;
   bool pinvValid = false;
   if (haveCache) X = R.on ? Xcache : 0.0;
   else {
     // (the empty tangent rows of frictionless contacts are not rows of the reference's problem; a negated joint-limit row: the reference
     // tests ITS b > 0)
     const bool in = R.on && (R.fric ? R.mu != 0.0 : (R.neg ? R.Bv < 0 : R.Bv > 0));
-    guessMask = (uint32_t)w.ballot(in);
+    guessMask = (RowMask)w.ballot(in);
     if (guessMask != 0) {
       double a[MAXR];
       const double* Ac = R.fresh();
 #pragma unroll
       for (int i = 0; i < MAXR; i++) a[i] = (in && ((guessMask >> i) & 1u)) ? R.a(Ac, i) : 0.0;
       NBL_PHASE(43);
-      coopPinvSym(w, a, S, __builtin_popcount(guessMask));      // A restricted to the guess rows: symmetric positive semi-definite
+      coopPinvSym(w, a, S, rmPop(guessMask));      // A restricted to the guess rows: symmetric positive semi-definite
       NBL_PHASE(44);
       X = coopPinvApply<W, false>(w, S, in ? R.Bv : 0.0, 0);
       NBL_PHASE(45);

@@ -39,7 +39,7 @@ DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved
     R.Bv = saved[(int64_t)(lay.b + ln) * B + b];
   }
   R.on = on;
-  if (LIM) R.limMask = (uint32_t)__ballot(R.lim ? 1 : 0);
+  if (LIM) R.limMask = (RowMask)__ballot(R.lim ? 1 : 0);
   R.Acol = dn + lay.A + (on ? ln : 0);
   double cn = 0.0, cn1 = 0.0;
 #pragma unroll 1
@@ -99,11 +99,11 @@ DEV uint32_t coopContactOutputs(const W& w, CoopLds& S, const CoopRow& R, int n,
   // every Jacobian: the record classifies them "not clamping", and a Q^+ that couples them to the contacts is not the backward pass's.
   // The warm-start cache carries the reference's sign of a negated (upper-limit) row.
   bool pinvValid = pinvValidIn;
-  if ((K.clampMask & R.limMask) != 0u) {   // (uniform; never taken by the instantiation without joint-limit rows)
+  if ((K.clampMask & R.limMask) != 0) {   // (uniform; never taken by the instantiation without joint-limit rows)
     CoopClasses Kb = K;
     if (R.lim) Kb.cls = RC_NOT_CLAMPING;
     Kb.clampMask &= ~R.limMask;
-    Kb.nc = __builtin_popcount(Kb.clampMask);
+    Kb.nc = rmPop(Kb.clampMask);
     if (Kb.nc > 0) {
       double a[MAXR];
       coopBuildQ(w, S, R, Kb, cfm, a);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   coopLoadRow<MULTI>(R, ln, m, saved, dn, lay, cm, B, b);
   NBL_PHASE(41);
   if (MULTI && ln == 0 && status) {   // (joint-limit rows are pseudo-contacts of the record: NBL_ST_CONTACT counts the real ones)
-    const int nLim = __builtin_popcount(R.limMask);
+    const int nLim = rmPop(R.limMask);
     status[b] |= (nC - nLim > 0 ? 0x1u : 0u) | (nLim > 0 ? 0x400u : 0u);
   }
   const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   if (failMask == 0u) {
     CoopClasses K;
     K.cls = cls; K.E = E;
-    K.clampMask = (uint32_t)w.ballot(cls == RC_CLAMPING); K.ubMask = (uint32_t)w.ballot(cls == RC_UPPER_BOUND);
-    K.nc = __builtin_popcount(K.clampMask); K.nu = __builtin_popcount(K.ubMask);
+    K.clampMask = (RowMask)w.ballot(cls == RC_CLAMPING); K.ubMask = (RowMask)w.ballot(cls == RC_UPPER_BOUND);
+    K.nc = rmPop(K.clampMask); K.nu = rmPop(K.ubMask);
     bool pinvValid = false;
     if (K.nc > 0) {                                       // Q^+ of the whole clamping set (block diagonal over the groups) for the record
       double a[MAXR];
@@ -379,8 +379,8 @@ DEV void coopCascadeFinish(const W& w, CoopLds& S, const DevModel& mdl, const De
   R.on = rowOn;
   CoopClasses K;
   K.cls = cls; K.E = E;
-  K.clampMask = (uint32_t)w.ballot(cls == RC_CLAMPING); K.ubMask = (uint32_t)w.ballot(cls == RC_UPPER_BOUND);
-  K.nc = __builtin_popcount(K.clampMask); K.nu = __builtin_popcount(K.ubMask);
+  K.clampMask = (RowMask)w.ballot(cls == RC_CLAMPING); K.ubMask = (RowMask)w.ballot(cls == RC_UPPER_BOUND);
+  K.nc = rmPop(K.clampMask); K.nu = rmPop(K.ubMask);
   // The record always carries Q^+ of the final classification when there is a clamping row (of the whole world: block diagonal
   // over its groups, each block with its group's CFM), so that the backward pass never has to factorise.  Stages that end without
   // one (PGS results accepted as they are) and worlds with several groups pay for it here.
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_CFINAL) void k_contact_cascade_
 #endif
 }
 
-// Stages 1-3 AND the final part in ONE launch (the default): the two stage wavefronts of a world leave their candidates in the
+// Stages 1-3 AND the final part in ONE launch (opt-in, NBL_FUSED_CASCADE=1: measured slower with four slices in flight, nimble_amd.hip): the two stage wavefronts of a world leave their candidates in the
 // workgroup's LDS, and whichever of the two arrives second goes on with select + standardise + outputs (coopCascadeFinish) on the LDS
 // the stages no longer need.  A world's final part therefore starts when ITS stages are done instead of when the slowest world of the
 // launch is - the launch boundary between k_contact_cascade_stages and k_contact_cascade_final made every world wait for the longest
@@ -481,10 +481,13 @@ __global__ __launch_bounds__(128) NBL_WAVES(2) void k_contact_cascade_fused(DevM
       w.sync();
     }
   }
-  // arrival: LDS operations of a wavefront execute in order, so the candidates above are in LDS before this wavefront's increment is;
-  // the wavefront that reads 1 is the second one and sees both sets
+  // arrival: the candidates above must be in LDS before this wavefront's increment is, and the wavefront that reads 1 (the second one)
+  // must see both sets: a release / acquire increment with workgroup fences on both sides (the compiler may otherwise move the plain
+  // stores past a relaxed atomic)
   int prev = 0;
-  if (ln == 0) prev = atomicAdd(&F.arrive, 1);
+  __threadfence_block();
+  if (ln == 0) prev = __hip_atomic_fetch_add(&F.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __threadfence_block();
   prev = __builtin_amdgcn_readfirstlane(prev);
   if (prev == 0) return;
   w.sync();
@@ -602,10 +605,10 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
   const double cfm = rowOn ? cfmRaw : 0.0;
   K.cls = cv == 1.0 ? RC_CLAMPING : ((cv == 2.0 || cv == -2.0) ? RC_UPPER_BOUND : RC_NOT_CLAMPING);
   K.E = K.cls == RC_UPPER_BOUND ? (cv > 0 ? R.mu : -R.mu) : 0.0;
-  K.clampMask = (uint32_t)w.ballot(K.cls == RC_CLAMPING);
-  K.ubMask = (uint32_t)w.ballot(K.cls == RC_UPPER_BOUND);
-  K.nc = __builtin_popcount(K.clampMask);
-  K.nu = __builtin_popcount(K.ubMask);
+  K.clampMask = (RowMask)w.ballot(K.cls == RC_CLAMPING);
+  K.ubMask = (RowMask)w.ballot(K.cls == RC_UPPER_BOUND);
+  K.nc = rmPop(K.clampMask);
+  K.nu = rmPop(K.ubMask);
   const bool clamp = K.cls == RC_CLAMPING, isUb = K.cls == RC_UPPER_BOUND;
   const double xRaw = rowOn ? xRaw0 : 0.0;   // the impulses that were applied
   auto fold = [&](double t) -> double {   // normal rows collect E_u t_u of their contact's upper-bound rows
@@ -695,14 +698,15 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDA) void k_bwd_contact_a_coop
     w.sync();
     // Q Q^+ = A spread(Q^+) + cfm Q^+ is the one true GEMM of the contact adjoint (24 x 24 x 24): on the matrix cores.
     // v_mfma_f64_16x16x4_f64: A operand lane l = A[l & 15][l >> 4], B operand lane l = B[l >> 4][l & 15], D register g of lane l =
-    // D[(l >> 4) + 4 g][l & 15].  Output padded to 32 x 32 (2 x 2 tiles), K = 24 in 6 steps: 24 MFMAs instead of 576 FMAs per lane.
+    // D[(l >> 4) + 4 g][l & 15].  Output padded to 32 x 32 (2 x 2 tiles), K = 24 in 6 steps: 24 MFMAs instead of 576 FMAs per lane
+    // (48 rows: 3 x 3 tiles, 12 steps).
     typedef double v4d __attribute__((ext_vector_type(4)));
     const int li = ln & 15, lk = ln >> 4;
     double acc = 0.0;
 #pragma unroll
-    for (int tr = 0; tr < 2; tr++) {
+    for (int tr = 0; tr < MFMA_TILES; tr++) {
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++) {
+      for (int tj = 0; tj < MFMA_TILES; tj++) {
         v4d d = {0.0, 0.0, 0.0, 0.0};
         const int r = 16 * tr + li, j = 16 * tj + li;
 #pragma unroll
@@ -833,8 +837,8 @@ __global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* 
   const double cv = svAt(saved, lay.cls + row, B, b);
   const double eRow = svAt(saved, lay.rest + row / 3, B, b);
   const bool bouncing = ln < m && (ln % 3) == 0 && cv == 1.0 && eRow > 0.0;
-  const uint32_t bmask = (uint32_t)w.ballot(bouncing);
-  if (bmask == 0u) {                                    // nothing bounced in this world: X = I
+  const RowMask bmask = (RowMask)w.ballot(bouncing);
+  if (bmask == 0) {                                    // nothing bounced in this world: X = I
     if (ln < n) lws[(int64_t)(LB_VX + ln) * B + b] = 0.0;
     return;
   }
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* 
 #pragma unroll
     for (int kk = 0; kk < MAXR; kk++) if (kk == k) gcol[kk] = bouncing ? dotik * dotik : 0.0;     // G[k][i] (symmetric)
   }
-  coopPinv(w, gcol, S, __builtin_popcount(bmask));
+  coopPinv(w, gcol, S, rmPop(bmask));
   const double cRow = coopPinvApply<DevWave, false>(w, S, bouncing ? eRow + nrm2 : 0.0, 0);
   // ---- (X - I) y = -A_b (c o t)   (lane = DOF) ----
   w.sync();

@@ -6,7 +6,20 @@
 
 namespace nbl {
 
-constexpr int MAXR = 24;  // LCP rows per world handled by the device path (8 frictional contacts)
+#ifndef NBL_MAXC
+#define NBL_MAXC 8
+#endif
+constexpr int MAXR = 3 * NBL_MAXC;  // LCP rows per world handled by the device path (8 frictional contacts: 24; the 16-contact build: 48)
+
+// one bit per LCP row of a world (ballots restricted to the row lanes)
+#if NBL_MAXC > 8
+typedef uint64_t RowMask;
+#else
+typedef uint32_t RowMask;
+#endif
+DEV int rmPop(RowMask m) { return __builtin_popcountll((unsigned long long)m); }
+DEV int rmCtz(RowMask m) { return __builtin_ctzll((unsigned long long)m); }
+constexpr RowMask RM1 = 1;
 
 struct LaneMem {
   double* base;

@@ -116,11 +116,17 @@ constexpr int WS_XI = 282;      // 6   world-frame adjoint of the joint's positi
 constexpr int WS_PER_BODY = 288;
 
 // ---- contact stage -------------------------------------------------------------------------
-constexpr int MAX_CONTACTS = 8;              // per world (8 frictional contacts = 24 LCP rows)
+// The library is built TWICE from these sources (__graft_entry__.build / nimble_amd_dispatch.cpp): NBL_MAXC = 8 (24 LCP rows: the fast
+// instantiation every BASELINE config runs) and NBL_MAXC = 16 (48 LCP rows, 32 colliders, 64 collider pairs: namespace nbl_c16); a model
+// is given to one or the other when it is created, by max_contacts / its collider and pair counts.
+#ifndef NBL_MAXC
+#define NBL_MAXC 8
+#endif
+constexpr int MAX_CONTACTS = NBL_MAXC;       // per world (8 frictional contacts = 24 LCP rows; 16 = 48 rows)
 constexpr int MAX_ROWS = 3 * MAX_CONTACTS;
-constexpr int MAX_BOXES = 16;
-constexpr int MAX_PAIRS = 32;
-constexpr int SEEN_POINTS = 2 * 8;   // narrow phase: points the duplicate filter compares with (the kept contacts + unique points the depth filter dropped)
+constexpr int MAX_BOXES = NBL_MAXC > 8 ? 32 : 16;
+constexpr int MAX_PAIRS = NBL_MAXC > 8 ? 64 : 32;
+constexpr int SEEN_POINTS = 2 * MAX_CONTACTS;   // narrow phase: points the duplicate filter compares with (the kept contacts + unique points the depth filter dropped)
 constexpr int MAX_DOF_CONTACT = 64;   // lane = DOF in the wavefront kernels (round 2: 40)
 
 constexpr int SHAPE_BOX = 0, SHAPE_SPHERE = 1, SHAPE_CAPSULE = 2;   // NBL_SHAPE_*

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "abi_variants.h"   // (before the ABI header: the two instantiations of the library rename its entry points, see there)
 #include "../../include/nimble_amd.h"
 #include "kernels.hip"
 #include "contact_kernels.hip"
@@ -393,8 +394,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   bool hasContact = (d->n_boxes > 0 || !limitDofs.empty()) && d->max_contacts > 0;
   bool multiGroupModel = !limitDofs.empty();   // the general instantiation of the contact kernels carries the joint-limit rows
   if (hasContact) {
-    if (d->n_boxes > MAX_BOXES) return fail(NBL_E_UNSUPPORTED, "too many box colliders for the device path");
-    if (d->max_contacts > MAX_CONTACTS) return fail(NBL_E_UNSUPPORTED, "max_contacts above 8 is not supported by the device path yet");
+    // (NBL_E_CAPACITY: the 24-row build hands such a model on to the 48-row build, nimble_amd_dispatch.cpp; from that one it is final)
+    if (d->n_boxes > MAX_BOXES) return fail(NBL_E_CAPACITY, "more than " + std::to_string(MAX_BOXES) + " colliders: outside the device path");
+    if (d->max_contacts > MAX_CONTACTS) return fail(NBL_E_CAPACITY, "max_contacts above " + std::to_string(MAX_CONTACTS) + " is outside the device path");
     if (d->n_bodies > 64) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 64 bodies");
     if (d->n_dofs > MAX_DOF_CONTACT) return fail(NBL_E_UNSUPPORTED, "contact path supports at most 64 DOFs");
     hc.nBoxes = d->n_boxes;
@@ -449,7 +451,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
         if ((hc.boxes[i].shape == NBL_SHAPE_CAPSULE) != (hc.boxes[j].shape == NBL_SHAPE_CAPSULE)
             && (hc.boxes[i].shape == NBL_SHAPE_BOX || hc.boxes[j].shape == NBL_SHAPE_BOX))
           return fail(NBL_E_UNSUPPORTED, "a capsule collider can meet a box collider: that pair runs libccd's MPR in the reference (DARTCollide.cpp:4422-4645), outside this path");
-        if (hc.nPairs >= MAX_PAIRS) return fail(NBL_E_UNSUPPORTED, "too many collider pairs for the device path");
+        if (hc.nPairs >= MAX_PAIRS) return fail(NBL_E_CAPACITY, "more than " + std::to_string(MAX_PAIRS) + " collider pairs: outside the device path");
         hc.pairA[hc.nPairs] = i;
         hc.pairB[hc.nPairs] = j;
         hc.nPairs++;
@@ -464,6 +466,17 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
       for (int a = bdy; a >= 0; a = d->parent[a]) mask |= (1ull << a);
       hc.ancestors[bdy] = mask;
     }
+  }
+
+  if (hasContact) {
+    // the per-world LDS images of k_contact_rows_coop ([body][6][row] velocity changes, launchForward) and k_bwd_contact_b_coop
+    int nFreeRoots = 0;
+    for (int i = 0; i < d->n_bodies; i++) if (d->joint_type[i] == NBL_JOINT_FREE) nFreeRoots++;
+    const size_t rowsLds = ((size_t)d->n_bodies * 6 * MAX_ROWS + 12 * MAX_ROWS + 19 * (size_t)d->n_bodies + 54 * (size_t)nFreeRoots + MAX_CONTACTS) * sizeof(double);
+    const size_t bLds = ((size_t)d->n_bodies * 120 + std::max((size_t)d->n_bodies * 54, (size_t)54 * MAX_ROWS) + MAX_CONTACTS) * sizeof(double);
+    if (std::max(rowsLds, bLds) > 160u * 1024u)
+      return fail(NBL_E_UNSUPPORTED, "bodies x LCP rows exceed the 160 kB of LDS of a compute unit (" + std::to_string(d->n_bodies) + " device bodies, " +
+                                         std::to_string(MAX_ROWS) + " rows): " + (MAX_CONTACTS > 8 ? "use max_contacts <= 8 or fewer bodies" : "fewer bodies"));
   }
 
   nbl_model* m = new nbl_model();
@@ -564,7 +577,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess) e = hipMemcpy(m->dDofs, hd.data(), sizeof(DevDof) * hd.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess && hasContact) e = hipMalloc((void**)&m->dContact, sizeof(DevContactModel));
   if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
-  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
+  // (k_contact_detect: 160 kB less its static arrays - the remembered points and the clip polygons)
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             std::min(104 * 1024, 160 * 1024 - (SEEN_POINTS * 3 * 64 + 48 * 64) * (int)sizeof(double)));
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -602,6 +617,7 @@ void nbl_model_destroy(nbl_model* m) {
 int32_t nbl_model_num_dofs(const nbl_model* m) { return m ? m->n : 0; }
 int32_t nbl_model_num_action(const nbl_model* m) { return m ? m->k : 0; }
 int32_t nbl_model_lcp_rows(const nbl_model* m) { return (m && m->hasContact) ? MAX_ROWS + 1 : 0; }
+int32_t nbl_model_max_contacts(const nbl_model* m) { return (m && m->hasContact) ? MAX_CONTACTS : 0; }
 
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
@@ -818,6 +834,7 @@ int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const doub
 }
 
 // ---- inertia ("mass") parameters: World::setMasses / lossWrtMass (World.cpp:1821-1824, BackpropSnapshot.cpp:167-179) ----
+extern "C++" {   // (internal helpers: C++ linkage keeps them local to this instantiation of the library)
 namespace {
 // keeps the calling thread's current device across an entry point that has to work on the model's device
 struct DeviceGuard {
@@ -836,6 +853,7 @@ int32_t ensureStaging(nbl_model* m, size_t bytes) {
   return NBL_OK;
 }
 }  // namespace
+}  // extern "C++"
 
 // Replaces the inertial constants of `count` bodies with ONE stream-ordered copy on `stream`: launches issued on that stream
 // afterwards see the new values, launches issued before it the old ones; no device synchronisation.
@@ -954,7 +972,7 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
                                        const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch) {
   if (!A || !b || !lo || !hi || !findex || !x || !rc) return fail(NBL_E_BADARG, "null argument");
   if (reps < 1) return fail(NBL_E_BADARG, "reps must be positive");
-  if (count <= 0 || n <= 0 || n > MAX_ROWS) return fail(NBL_E_BADARG, "count must be positive and 1 <= n <= 24");
+  if (count <= 0 || n <= 0 || n > MAX_ROWS) return fail(NBL_E_BADARG, "count must be positive and 1 <= n <= " + std::to_string(MAX_ROWS));
   if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
   const size_t nv = (size_t)count * n, nm = nv * n;
   double *dA = nullptr, *dv = nullptr;
@@ -997,6 +1015,11 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
 }
 
 // ---- self-test: the device pseudo-inverses on caller-supplied matrices (host pointers) ----------------------------------------
+int32_t nbl_selftest_pinv_rows(int32_t count, int32_t rows, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank,
+                               int32_t reps, double* ms_per_launch) {
+  if (rows != MAX_ROWS) return fail(NBL_E_BADARG, "rows must be " + std::to_string(MAX_ROWS) + " in this instantiation of the library");
+  return nbl_selftest_pinv(count, Q, cTrue, route, P, rank, reps, ms_per_launch);
+}
 int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank, int32_t reps,
                           double* ms_per_launch) {
   if (!Q || !cTrue || !P || !rank) return fail(NBL_E_BADARG, "null argument");
@@ -1053,9 +1076,11 @@ int32_t nbl_debug_phase_stamps(unsigned long long* out64) {
 #endif
 
 // ---- T-step rollout -------------------------------------------------------------------
+extern "C++" {   // (internal helpers: C++ linkage keeps them local to this instantiation of the library)
 namespace {
 size_t alignUp(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
+}  // extern "C++"
 
 size_t nbl_rollout_workspace_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
@@ -1064,6 +1089,7 @@ size_t nbl_rollout_workspace_bytes(const nbl_model* m, int64_t B) {
          alignUp((size_t)2 * m->n * B * sizeof(double));
 }
 
+extern "C++" {   // (internal helpers: C++ linkage keeps them local to this instantiation of the library)
 namespace {
 __global__ __launch_bounds__(256) void k_add_rows(double* __restrict__ dst, const double* __restrict__ src, int64_t B, int64_t b0,
                                                   int64_t b1, int rows) {   // dst[r][b] += src[r][b] for b in [b0, b1)
@@ -1127,6 +1153,7 @@ RolloutBufs rolloutBufs(const nbl_model* m, int64_t B, int32_t T, int32_t segmen
   return r;
 }
 }  // namespace
+}  // extern "C++"
 
 size_t nbl_rollout_checkpoint_bytes(const nbl_model* m, int64_t B, int32_t T, int32_t segment) {
   if (!m || B <= 0 || T <= 0 || segment <= 0) return 0;

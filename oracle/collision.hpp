@@ -488,24 +488,43 @@ inline int skeletonRoot(const Model& m, int body) {
   return body;
 }
 
+// two colliders are tested against each other (BodyNodeCollisionFilter::ignoresCollision, CollisionFilter.cpp:105-154)
+inline bool pairIsTested(const Model& m, int i, int j) {
+  const BoxCollider &bi = m.boxes[i], &bj = m.boxes[j];
+  if (bi.body == bj.body) return false;
+  if (bi.body < 0 && bj.body < 0) return false;
+  if (bi.body >= 0 && bj.body >= 0 && m.skeleton[bi.body] == m.skeleton[bj.body]) {
+    // same skeleton (CollisionFilter.cpp:138-148): only with the self-collision check on, and without the adjacent-body check not between
+    // a body and its parent
+    const int fi = m.selfCollision[bi.body], fj = m.selfCollision[bj.body];
+    if (!((fi & 1) && (fj & 1))) return false;
+    if (!((fi & 2) && (fj & 2)) && (m.bodies[bi.body].parent == bj.body || m.bodies[bj.body].parent == bi.body)) return false;
+  }
+  return true;
+}
+
+// Distinct narrow-phase points per world the DEVICE's duplicate filter remembers (model_dev.hpp SEEN_POINTS = 2 x the contact slots of the
+// instantiation of the library the model runs on: 8, or 16 for a model with max_contacts > 8, more than 16 colliders or more than 32
+// collider pairs - nimble_amd_dispatch.cpp)
+inline int deviceSeenPoints(const Model& m) {
+  const int nbx = (int)m.boxes.size();
+  int pairs = 0;
+  for (int i = 0; i + 1 < nbx; i++)
+    for (int j = i + 1; j < nbx; j++) pairs += pairIsTested(m, i, j) ? 1 : 0;
+  return (m.maxContacts > 8 || nbx > 16 || pairs > 32) ? 32 : 16;
+}
+
 // seenListOverflow (optional): set when a point that would pass the constraint solver's filters is dropped as the duplicate of a point
-// the DEVICE's duplicate filter could no longer remember (it keeps 16 distinct points per world, model_dev.hpp SEEN_POINTS) - there
-// the device keeps a contact the reference does not have and flags the world (NBL_ST_CONTACT_OVERFLOW).
+// the DEVICE's duplicate filter could no longer remember (deviceSeenPoints) - there the device keeps a contact the reference does not
+// have and flags the world (NBL_ST_CONTACT_OVERFLOW).
 inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<Contact>& contacts, bool* seenListOverflow = nullptr) {
   contacts.clear();
   const int nbx = (int)m.boxes.size();
+  const size_t seenCap = seenListOverflow ? (size_t)deviceSeenPoints(m) : 0;
   for (int i = 0; i + 1 < nbx; i++)
     for (int j = i + 1; j < nbx; j++) {
       const BoxCollider &bi = m.boxes[i], &bj = m.boxes[j];
-      if (bi.body == bj.body) continue;
-      if (bi.body < 0 && bj.body < 0) continue;
-      if (bi.body >= 0 && bj.body >= 0 && m.skeleton[bi.body] == m.skeleton[bj.body]) {
-        // same skeleton (BodyNodeCollisionFilter::ignoresCollision, CollisionFilter.cpp:138-148): only with the self-collision check on, and
-        // without the adjacent-body check not between a body and its parent
-        const int fi = m.selfCollision[bi.body], fj = m.selfCollision[bj.body];
-        if (!((fi & 1) && (fj & 1))) continue;
-        if (!((fi & 2) && (fj & 2)) && (m.bodies[bi.body].parent == bj.body || m.bodies[bj.body].parent == bi.body)) continue;
-      }
+      if (!pairIsTested(m, i, j)) continue;
       Iso Ti = bi.body >= 0 ? kin[bi.body].Tworld * bi.T : bi.T;
       Iso Tj = bj.body >= 0 ? kin[bj.body].Tworld * bj.T : bj.T;
       std::vector<Contact> pair;
@@ -526,7 +545,7 @@ inline void collideAll(const Model& m, const std::vector<Kin>& kin, std::vector<
         for (size_t ti = 0; ti < contacts.size(); ti++)
           if (norm(c.point - contacts[ti].point) < 3.0e-12) {
             close = true;
-            if (ti >= 16 && seenListOverflow && dot(c.normal, c.normal) >= 1e-12 && c.depth >= 0.0 && c.depth <= m.clippingDepth) *seenListOverflow = true;
+            if (seenListOverflow && ti >= seenCap && dot(c.normal, c.normal) >= 1e-12 && c.depth >= 0.0 && c.depth <= m.clippingDepth) *seenListOverflow = true;
             break;
           }
         if (close) continue;

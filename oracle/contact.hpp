@@ -284,14 +284,15 @@ inline void solveContacts(const Model& m, const std::vector<Kin>& kin, const std
   std::vector<Contact> all;
   bool seenListFull = false;
   collideAll(m, kin, all, &seenListFull);
+  const size_t seenCap = (size_t)deviceSeenPoints(m);
   for (size_t ci = 0; ci < all.size(); ci++) {
     const Contact& c = all[ci];
     if (dot(c.normal, c.normal) < 1e-12) continue;           // Contact::isZeroNormal
     if (c.depth < 0.0 || c.depth > m.clippingDepth) continue;
     if (c.bodyA < 0 && c.bodyB < 0) continue;                 // neither body reactive -> constraint inactive
-    // (the device's duplicate filter remembers 16 distinct points per world - model_dev.hpp SEEN_POINTS -, kept or dropped by the depth
-    //  filter: a contact kept after that flags the world, see below)
-    if (ci >= 16) seenListFull = true;
+    // (the device's duplicate filter remembers 16 or 32 distinct points per world - collision.hpp deviceSeenPoints -, kept or dropped by
+    //  the depth filter: a contact kept after that flags the world, see below)
+    if (ci >= seenCap) seenListFull = true;
     out.contacts.push_back(c);
   }
   const int C = (int)out.contacts.size();

@@ -8,6 +8,8 @@
 using namespace nbl;
 
 extern "C" {
+// (every "24" below reads MAXR: the shim is built twice, for the 24-row and - -DNBL_MAXC=16 - the 48-row instantiation of the device code)
+int shim_rows() { return MAXR; }
 // Q: 24 x 24 row-major (masked rows/columns zero), P out 24 x 24 row-major; returns rank
 int shim_coop_pinv(const double* Q, int cTrue, double* Pout) {
   static CoopLds S;
@@ -68,7 +70,7 @@ int shim_coop_stage0(int m, const double* A, const double* b, const double* mu, 
 
 // stages 1-3 + the order of preference + standardisation on the rows of `mask` only; outputs like shim_coop_cascade plus the
 // standardised x and the row classes
-int shim_coop_cascade_masked(int m, const double* A, const double* b, const double* mu, const double* x0, unsigned mask, double fallbackCfm,
+int shim_coop_cascade_masked(int m, const double* A, const double* b, const double* mu, const double* x0, unsigned long long mask, double fallbackCfm,
                              double* X, double* cfmOut, double* Xstd, int* cls) {
   static CascadeLds C1;
   static PgsLds C2, C3;
@@ -78,7 +80,7 @@ int shim_coop_cascade_masked(int m, const double* A, const double* b, const doub
     const int ln = w.lane();
     CoopRow R;
     fillRow(R, ln, m, A, b, mu);
-    R.on = R.on && ((mask >> ln) & 1u);
+    R.on = R.on && ((mask >> ln) & 1ull);
     const double X0 = R.on ? x0[ln] : 0.0;
     CoopStageResult r1, r2, r3;
     coopCascadeStage1(w, C1, R, X0, r1);
@@ -98,14 +100,14 @@ int shim_coop_cascade_masked(int m, const double* A, const double* b, const doub
 }
 
 // stage 0 on the rows of `mask` only (the rows of a world's other constrained groups switched off, as the kernels run it)
-int shim_coop_stage0_masked(int m, const double* A, const double* b, const double* mu, unsigned mask, double* X, double* X0, int* cls, double* E) {
+int shim_coop_stage0_masked(int m, const double* A, const double* b, const double* mu, unsigned long long mask, double* X, double* X0, int* cls, double* E) {
   static CoopLds S;
   int ret = 0;
   emuRunWave([&](const EmuWave& w) {
     const int ln = w.lane();
     CoopRow R;
     fillRow(R, ln, m, A, b, mu);
-    R.on = R.on && ((mask >> ln) & 1u);
+    R.on = R.on && ((mask >> ln) & 1ull);
     CoopStage0 out;
     coopStage0(w, S, R, false, 0.0, out);
     if (ln < MAXR) { X[ln] = out.X; X0[ln] = out.X0; cls[ln] = out.K.cls; E[ln] = out.K.E; }
@@ -116,7 +118,7 @@ int shim_coop_stage0_masked(int m, const double* A, const double* b, const doubl
 
 // the same two with joint-limit rows (CoopRow::lim / neg / limMask as coopLoadRow<true> sets them): limMask = the limit rows, negMask = the
 // ones carried negated (upper limits); A, b in the device's form (those rows and columns already negated)
-int shim_coop_stage0_lim(int m, const double* A, const double* b, const double* mu, unsigned mask, unsigned limMask, unsigned negMask,
+int shim_coop_stage0_lim(int m, const double* A, const double* b, const double* mu, unsigned long long mask, unsigned long long limMask, unsigned long long negMask,
                          double* X, double* X0, int* cls, double* E) {
   static CoopLds S;
   int ret = 0;
@@ -124,8 +126,8 @@ int shim_coop_stage0_lim(int m, const double* A, const double* b, const double* 
     const int ln = w.lane();
     CoopRow R;
     fillRow(R, ln, m, A, b, mu);
-    R.on = R.on && ((mask >> ln) & 1u);
-    R.lim = ln < 32 && ((limMask >> ln) & 1u); R.neg = ln < 32 && ((negMask >> ln) & 1u); R.limMask = limMask;
+    R.on = R.on && ((mask >> ln) & 1ull);
+    R.lim = ((limMask >> ln) & 1ull); R.neg = ((negMask >> ln) & 1ull); R.limMask = (RowMask)limMask;
     CoopStage0 out;
     coopStage0(w, S, R, false, 0.0, out);
     if (ln < MAXR) { X[ln] = out.X; X0[ln] = out.X0; cls[ln] = out.K.cls; E[ln] = out.K.E; }
@@ -133,8 +135,8 @@ int shim_coop_stage0_lim(int m, const double* A, const double* b, const double* 
   });
   return ret;
 }
-int shim_coop_cascade_lim(int m, const double* A, const double* b, const double* mu, const double* x0, unsigned mask, unsigned limMask,
-                          unsigned negMask, double fallbackCfm, double* X, double* cfmOut, int* stages) {
+int shim_coop_cascade_lim(int m, const double* A, const double* b, const double* mu, const double* x0, unsigned long long mask, unsigned long long limMask,
+                          unsigned long long negMask, double fallbackCfm, double* X, double* cfmOut, int* stages) {
   static CascadeLds C1;
   static PgsLds C2, C3;
   uint32_t stOut = 0;
@@ -142,8 +144,8 @@ int shim_coop_cascade_lim(int m, const double* A, const double* b, const double*
     const int ln = w.lane();
     CoopRow R;
     fillRow(R, ln, m, A, b, mu);
-    R.on = R.on && ((mask >> ln) & 1u);
-    R.lim = ln < 32 && ((limMask >> ln) & 1u); R.neg = ln < 32 && ((negMask >> ln) & 1u); R.limMask = limMask;
+    R.on = R.on && ((mask >> ln) & 1ull);
+    R.lim = ((limMask >> ln) & 1ull); R.neg = ((negMask >> ln) & 1ull); R.limMask = (RowMask)limMask;
     const double X0 = R.on ? x0[ln] : 0.0;
     CoopStageResult r1, r2, r3;
     coopCascadeStage1(w, C1, R, X0, r1);

@@ -236,7 +236,7 @@ DEV void buildQ(const LcpView& L, const Classes& K, double cfm, const LaneMem& o
 // rows drop out of the clamping set, CGGM.cpp:321-332).  On return K holds the last classification and X the
 // last accepted solution; returns whether the results are standardised (valid least-squares solution).
 DEV bool standardizeLoop(const LcpView& V, const LaneMem& L, CodFactor& F, double* X, const double* Bv, const double* colNorm,
-                         double cfm, bool ignoreFriction, uint32_t guessMask, Classes& K) {
+                         double cfm, bool ignoreFriction, RowMask guessMask, Classes& K) {
   const int m = V.m;
   bool ok = false;
   for (int iter = 0; iter < MAXR + 1; iter++) {
@@ -249,8 +249,8 @@ DEV bool standardizeLoop(const LcpView& V, const LaneMem& L, CodFactor& F, doubl
       break;
     }
     double bc[MAXR], fc[MAXR], newX[MAXR], origFc[MAXR];
-    uint32_t clampMask = 0;
-    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) { origFc[K.cidx[r]] = X[r]; clampMask |= 1u << r; }
+    RowMask clampMask = 0;
+    for (int r = 0; r < m; r++) if (K.cls[r] == RC_CLAMPING) { origFc[K.cidx[r]] = X[r]; clampMask |= RM1 << r; }
     if (iter == 0 && K.nu == 0 && guessMask != 0 && clampMask == guessMask) {
       // the clamping set is exactly the guess's set: Q and b_c are the system just solved, f_c = that solution
       for (int i = 0; i < K.nc; i++) fc[i] = origFc[i];
@@ -289,10 +289,10 @@ DEV bool laneStage0(const LcpView& V, const LaneMem& L, bool haveCache, double* 
   const int m = V.m;
   CodFactor F;
   F.ld = MAXR; F.offQR = 0; F.offChol = MAXR * MAXR;
-  uint32_t guessMask = 0;   // rows of the guess's clamping set; its factorisation can be reused by the first standardisation
+  RowMask guessMask = 0;   // rows of the guess's clamping set; its factorisation can be reused by the first standardisation
   if (!haveCache) {
     int idx[MAXR], nc = 0;
-    for (int r = 0; r < m; r++) if ((r % 3) != 0 || Bv[r] > 0) { idx[nc++] = r; guessMask |= 1u << r; }
+    for (int r = 0; r < m; r++) if ((r % 3) != 0 || Bv[r] > 0) { idx[nc++] = r; guessMask |= RM1 << r; }
     for (int r = 0; r < m; r++) X[r] = 0;
     if (nc > 0) {
       double rhs[MAXR], sol[MAXR];

@@ -18,16 +18,30 @@ ROOT = os.path.dirname(HERE)
 pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
 
 
-@pytest.fixture(scope="module")
-def shim():
+def _build_shim(maxc):
     src = os.path.join(HERE, "host_shim", "coop_shim.cpp")
-    out = os.path.join(HERE, "host_shim", "libcoop_shim.so")
+    out = os.path.join(HERE, "host_shim", "libcoop_shim.so" if maxc == 8 else f"libcoop_shim{maxc}.so")
     deps = [src, os.path.join(HERE, "host_shim", "wave_emu.hpp")] + \
         [os.path.join(ROOT, "nimblephysics_amd", "csrc", f) for f in ("coop_dev.hpp", "coop_dantzig_dev.hpp", "lcp_dev.hpp", "spatial_dev.hpp")] + [os.path.join(HERE, "host_shim", "lane_lcp_statement.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(HERE, "host_shim"),
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", f"-DNBL_MAXC={maxc}", "-I", os.path.join(HERE, "host_shim"),
                                "-I", os.path.join(ROOT, "nimblephysics_amd", "csrc"), "-o", out, src])
-    return C.CDLL(out)
+    lib = C.CDLL(out)
+    lib.R = lib.shim_rows()          # LCP rows of this instantiation of the device code (24 / 48)
+    lib.NC = lib.R // 3
+    assert lib.R == 3 * maxc
+    return lib
+
+
+@pytest.fixture(scope="module", params=[8, 16], ids=["rows24", "rows48"])
+def shim(request):
+    """The device code of BOTH instantiations of the library (csrc/abi_variants.h): 8 contacts / 24 LCP rows and 16 contacts / 48 rows."""
+    return _build_shim(request.param)
+
+
+@pytest.fixture(scope="module")
+def shim24():
+    return _build_shim(8)
 
 
 def _p(a):
@@ -41,19 +55,20 @@ def _pi(a):
 def test_coop_pinv_equals_numpy_pinv_on_masked_rank_deficient_systems(shim):
     """Full-rank and rank-deficient, symmetric and non-symmetric, with rows/columns masked out (zero) the way the
     kernels select the clamping block: Q^+ to 1e-9, rank exact."""
+    R, NC = shim.R, shim.NC
     rng = np.random.default_rng(0)
-    for trial in range(50):
-        c = int(rng.integers(1, 25)); k = int(rng.integers(1, c + 1))
-        idx = np.sort(rng.choice(24, c, replace=False))
+    for trial in range(50 if R == 24 else 24):
+        c = int(rng.integers(1, R + 1)); k = int(rng.integers(1, c + 1))
+        idx = np.sort(rng.choice(R, c, replace=False))
         U = rng.normal(0, 1, (c, k)); V = rng.normal(0, 1, (c, k))
         sub = U @ U.T if trial % 2 == 0 else U @ V.T
-        Q = np.zeros((24, 24)); Q[np.ix_(idx, idx)] = sub
-        P = np.zeros((24, 24))
+        Q = np.zeros((R, R)); Q[np.ix_(idx, idx)] = sub
+        P = np.zeros((R, R))
         rank = shim.shim_coop_pinv(_p(np.ascontiguousarray(Q)), c, _p(P))
         ref = np.linalg.pinv(Q, rcond=1e-11)
         assert rank == k
         assert np.abs(P - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30)
-    Z = np.zeros((24, 24)); P = np.ones((24, 24))
+    Z = np.zeros((R, R)); P = np.ones((R, R))
     assert shim.shim_coop_pinv(_p(Z), 5, _p(P)) == 0 and not P.any()
 
 
@@ -63,10 +78,11 @@ def test_coop_pinv_sym_equals_numpy_pinv_on_positive_semidefinite_systems(shim):
     kernels take whenever no friction row sits on its bound.  Random masked rank-deficient and full-rank blocks, contact matrices
     J D J^T of two flat feet (rank 12 of 24), the same with the fallback CFM on the diagonal (full rank, cond ~ 1e5): Q^+ and the
     rank against numpy, and against the Householder route (coopPinv) on the same input."""
+    R, NC = shim.R, shim.NC
     rng = np.random.default_rng(7)
     worst = 0.0
-    for trial in range(80):
-        c = int(rng.integers(1, 25)); idx = np.sort(rng.choice(24, c, replace=False))
+    for trial in range(80 if R == 24 else 32):
+        c = int(rng.integers(1, R + 1)); idx = np.sort(rng.choice(R, c, replace=False))
         if trial % 4 == 3:                         # a standing robot: c rows on two 6-DOF bodies (+ the CFM every other time)
             k = min(c, 12)
             J = rng.normal(0, 1, (c, 12)); sub = J @ np.diag(rng.uniform(0.1, 2, 12)) @ J.T
@@ -75,9 +91,9 @@ def test_coop_pinv_sym_equals_numpy_pinv_on_positive_semidefinite_systems(shim):
         else:
             k = int(rng.integers(1, c + 1))
             U = rng.normal(0, 1, (c, k)); sub = U @ U.T
-        Q = np.zeros((24, 24)); Q[np.ix_(idx, idx)] = sub
+        Q = np.zeros((R, R)); Q[np.ix_(idx, idx)] = sub
         Q = 0.5 * (Q + Q.T)
-        P = np.zeros((24, 24)); P2 = np.zeros((24, 24))
+        P = np.zeros((R, R)); P2 = np.zeros((R, R))
         rank = shim.shim_coop_pinv_sym(_p(np.ascontiguousarray(Q)), c, _p(P))
         rank2 = shim.shim_coop_pinv(_p(np.ascontiguousarray(Q)), c, _p(P2))
         assert rank == k and rank2 == k, (trial, rank, rank2, k)
@@ -95,35 +111,36 @@ def test_coop_pinv_sym_equals_numpy_pinv_on_positive_semidefinite_systems(shim):
     import json
     f = json.load(open(os.path.join(HERE, "golden", "pinv_rank_borderline.json")))
     A6 = np.array([[float.fromhex(x) for x in row] for row in f["A"]])
-    Q = np.zeros((24, 24)); Q[:6, :6] = A6
-    P = np.zeros((24, 24)); P2 = np.zeros((24, 24))
+    Q = np.zeros((R, R)); Q[:6, :6] = A6
+    P = np.zeros((R, R)); P2 = np.zeros((R, R))
     assert shim.shim_coop_pinv_sym(_p(np.ascontiguousarray(Q)), 6, _p(P)) == 5 and shim.shim_coop_pinv(_p(np.ascontiguousarray(Q)), 6, _p(P2)) == 5
     assert np.abs(P - P2).max() <= 1e-10 * np.abs(P2).max()
-    Z = np.zeros((24, 24)); P = np.ones((24, 24))
+    Z = np.zeros((R, R)); P = np.ones((R, R))
     assert shim.shim_coop_pinv_sym(_p(Z), 5, _p(P)) == 0 and not P.any()
 
 
-def _contact_problem(rng, trial):
-    nc = int(rng.integers(1, 9)); m = 3 * nc
+def _contact_problem(rng, trial, R=24):
+    NC = R // 3
+    nc = int(rng.integers(1, NC + 1)); m = 3 * nc
     ndof = int(rng.choice([6, 12, 30]))
     J = rng.normal(0, 1, (m, ndof))
-    A = np.zeros((24, 24)); A[:m, :m] = J @ np.diag(rng.uniform(0.1, 2, ndof)) @ J.T
-    mu = np.zeros(8); mu[:nc] = rng.choice([0.5, 1.0], nc)
-    xs = np.zeros(24)
+    A = np.zeros((R, R)); A[:m, :m] = J @ np.diag(rng.uniform(0.1, 2, ndof)) @ J.T
+    mu = np.zeros(NC); mu[:nc] = rng.choice([0.5, 1.0], nc)
+    xs = np.zeros(R)
     for c in range(nc):
         if rng.random() < 0.7:
             xs[3 * c] = rng.uniform(0.1, 2)
             xs[3 * c + 1:3 * c + 3] = rng.uniform(-0.5, 0.5, 2) * mu[c] * xs[3 * c]
             if rng.random() < 0.4:       # sliding: one friction row on its bound
                 xs[3 * c + 1 + int(rng.integers(0, 2))] = rng.choice([-1, 1]) * mu[c] * xs[3 * c]
-    b = np.zeros(24); b[:m] = (A @ xs)[:m]
+    b = np.zeros(R); b[:m] = (A @ xs)[:m]
     kind = trial % 3
     if kind == 1:
         b[:m] += rng.normal(0, 0.05, m)
     if kind == 2:
         b[:m] = rng.normal(0, 1, m)
     have = int(trial % 5 >= 3)
-    xc = np.zeros(24); xc[:m] = xs[:m] + rng.normal(0, 1e-3, m) * (trial % 2)
+    xc = np.zeros(R); xc[:m] = xs[:m] + rng.normal(0, 1e-3, m) * (trial % 2)
     return m, A, b, mu, have, xc
 
 
@@ -131,12 +148,13 @@ def test_coop_stage0_equals_the_one_world_per_lane_statement(shim):
     """guessSolution / warm start -> classification -> least-squares standardisation -> isLCPSolutionValid, on resting,
     sliding (upper-bound rows), perturbed and random contact problems of 1..8 contacts with rank-deficient A: same
     accept/reject decision, same x, same classes, and the pseudo-inverse left in LDS is that of the final Q."""
+    R, NC = shim.R, shim.NC
     rng = np.random.default_rng(1)
     n_ok = n_ub = n_fail = 0
-    for trial in range(240):
-        m, A, b, mu, have, xc = _contact_problem(rng, trial)
-        X1 = np.zeros(24); X01 = np.zeros(24); c1 = np.zeros(24, np.int32); E1 = np.zeros(24); P = np.zeros((24, 24))
-        X2 = np.zeros(24); X02 = np.zeros(24); c2 = np.zeros(24, np.int32); E2 = np.zeros(24)
+    for trial in range(240 if R == 24 else 90):
+        m, A, b, mu, have, xc = _contact_problem(rng, trial, R)
+        X1 = np.zeros(R); X01 = np.zeros(R); c1 = np.zeros(R, np.int32); E1 = np.zeros(R); P = np.zeros((R, R))
+        X2 = np.zeros(R); X02 = np.zeros(R); c2 = np.zeros(R, np.int32); E2 = np.zeros(R)
         r1 = shim.shim_coop_stage0(m, _p(A), _p(b), _p(mu), have, _p(xc), _p(X1), _p(X01), _pi(c1), _p(E1), _p(P))
         r2 = shim.shim_lane_stage0(m, _p(A), _p(b), _p(mu), have, _p(xc), _p(X2), _p(X02), _pi(c2), _p(E2))
         assert (r1 & 1) == r2
@@ -150,12 +168,12 @@ def test_coop_stage0_equals_the_one_world_per_lane_statement(shim):
         n_ub += int((c1 == 2).any())
         if (r1 & 2):
             cl = c1 == 1
-            Q = np.zeros((24, 24)); Q[np.ix_(cl, cl)] = A[np.ix_(cl, cl)]
+            Q = np.zeros((R, R)); Q[np.ix_(cl, cl)] = A[np.ix_(cl, cl)]
             for u in np.where(c1 == 2)[0]:          # upper-bound rows ride on their normal column
                 Q[cl, u - u % 3] += E1[u] * A[cl, u]
             ref = np.linalg.pinv(Q, rcond=1e-11)
             assert np.abs(P - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-30)
-    assert n_ok > 50 and n_ub > 10 and n_fail > 50
+    assert n_ok > (50 if R == 24 else 12) and n_ub > (10 if R == 24 else 3) and n_fail > (50 if R == 24 else 12)
 
 
 # ---- stages 1-3 of the solver cascade, cooperative (coop_dantzig_dev.hpp) ----
@@ -172,10 +190,11 @@ def test_coop_dantzig_is_bit_identical_to_the_reference_dsolvelcp(shim):
     fused multiply-adds): against the reference's own solver (oracle/_ref) the success flag and EVERY BIT of x must be equal,
     on full-rank problems and on rank-deficient ones (6- and 3-DOF bodies with up to 8 frictional contacts) where A(C,C)
     goes singular and the s <= 0 early exit is decided by round-off."""
+    R, NC = shim.R, shim.NC
     rng = np.random.default_rng(0)
     solved = failed = 0
-    for trial in range(40):
-        nc = int(rng.integers(1, 9)); n = 3 * nc
+    for trial in range(40 if R == 24 else 14):
+        nc = int(rng.integers(1, NC + 1)); n = 3 * nc
         ndof = n + int(rng.integers(0, 6)) if trial % 3 == 0 else int(rng.choice([3, 6, 12]))   # 2 of 3: rank-deficient A
         A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
         xr = np.zeros(n); xd = np.zeros(n)
@@ -190,14 +209,15 @@ def test_coop_dantzig_is_bit_identical_to_the_reference_dsolvelcp(shim):
             assert np.array_equal(xr, xd), (trial, n, ndof, np.abs(xr - xd).max())
         else:
             failed += 1
-    assert solved > 20 and failed > 0
+    assert solved > (20 if R == 24 else 4) and failed > 0
 
 
 def test_coop_pgs_and_reduce_equal_the_oracle_restatement(shim):
+    R, NC = shim.R, shim.NC
     rng = np.random.default_rng(2)
-    for trial in range(21):
-        nc = int(rng.integers(1, 9)); n = 3 * nc
-        A, b, lo, hi, fi = contact_lcp(rng, nc, int(rng.integers(3, 24)), cfm=1e-4)
+    for trial in range(21 if R == 24 else 6):
+        nc = int(rng.integers(1, NC + 1)); n = 3 * nc
+        A, b, lo, hi, fi = contact_lcp(rng, nc, int(rng.integers(3, R)), cfm=1e-4)
         if trial % 3 == 0 and nc >= 2:      # duplicate a contact so that reduce() has something to merge
             A[3:6, :] = A[0:3, :]; A[:, 3:6] = A[:, 0:3]; b[3:6] = b[0:3]; hi[3:6] = hi[0:3]; lo[3:6] = lo[0:3]
         x0 = rng.normal(0, 0.1, n)
@@ -222,9 +242,10 @@ def test_stage0_on_one_constrained_group_equals_stage0_of_that_group_alone(shim)
     """A world with two constrained groups is a block-diagonal LCP; the kernels run stage 0 group by group with the other group's
     rows switched off (CoopRow::on).  The result on a group's rows must be what stage 0 gives on that group's own problem, whatever
     position its rows have in the world (first or second group, 3 + 4 or 4 + 3 contacts)."""
+    R, NC = shim.R, shim.NC
     rng = np.random.default_rng(11)
-    for trial in range(40):
-        nA, nB = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    for trial in range(40 if R == 24 else 10):
+        nA, nB = int(rng.integers(1, NC // 2 + 1)), int(rng.integers(1, NC // 2 + 1))
         parts = []
         for nc in (nA, nB):
             m = 3 * nc
@@ -238,17 +259,17 @@ def test_stage0_on_one_constrained_group_equals_stage0_of_that_group_alone(shim)
             b = A @ xs + (rng.normal(0, 0.05, m) if trial % 2 else 0.0)
             parts.append((m, A, b))
         mT = parts[0][0] + parts[1][0]
-        A = np.zeros((24, 24)); b = np.zeros(24); mu = np.ones(8)
+        A = np.zeros((R, R)); b = np.zeros(R); mu = np.ones(NC)
         A[:parts[0][0], :parts[0][0]] = parts[0][1]; A[parts[0][0]:mT, parts[0][0]:mT] = parts[1][1]
         b[:parts[0][0]] = parts[0][2]; b[parts[0][0]:mT] = parts[1][2]
         off = 0
         for (m, Ag, bg) in parts:
             mask = ((1 << m) - 1) << off
-            X = np.zeros(24); X0 = np.zeros(24); cls = np.zeros(24, np.int32); E = np.zeros(24)
-            ret = shim.shim_coop_stage0_masked(mT, _p(np.ascontiguousarray(A)), _p(b), _p(mu), C.c_uint(mask), _p(X), _p(X0), _pi(cls), _p(E))
-            A1 = np.zeros((24, 24)); A1[:m, :m] = Ag; b1 = np.zeros(24); b1[:m] = bg
-            X1 = np.zeros(24); X01 = np.zeros(24); cls1 = np.zeros(24, np.int32); E1 = np.zeros(24); P1 = np.zeros((24, 24))
-            ret1 = shim.shim_coop_stage0(m, _p(np.ascontiguousarray(A1)), _p(b1), _p(mu), 0, _p(np.zeros(24)), _p(X1), _p(X01), _pi(cls1), _p(E1), _p(P1))
+            X = np.zeros(R); X0 = np.zeros(R); cls = np.zeros(R, np.int32); E = np.zeros(R)
+            ret = shim.shim_coop_stage0_masked(mT, _p(np.ascontiguousarray(A)), _p(b), _p(mu), C.c_uint64(mask), _p(X), _p(X0), _pi(cls), _p(E))
+            A1 = np.zeros((R, R)); A1[:m, :m] = Ag; b1 = np.zeros(R); b1[:m] = bg
+            X1 = np.zeros(R); X01 = np.zeros(R); cls1 = np.zeros(R, np.int32); E1 = np.zeros(R); P1 = np.zeros((R, R))
+            ret1 = shim.shim_coop_stage0(m, _p(np.ascontiguousarray(A1)), _p(b1), _p(mu), 0, _p(np.zeros(R)), _p(X1), _p(X01), _pi(cls1), _p(E1), _p(P1))
             assert (ret & 1) == (ret1 & 1), (trial, off, ret, ret1)
             assert np.array_equal(cls[off:off + m], cls1[:m]), (trial, off)
             assert np.abs(X[off:off + m] - X1[:m]).max() <= 1e-10 * max(np.abs(X1).max(), 1e-30), (trial, off)
@@ -260,11 +281,12 @@ def test_stage0_on_one_constrained_group_equals_stage0_of_that_group_alone(shim)
 def test_cascade_on_one_constrained_group_equals_the_cascade_of_that_group_alone(shim):
     """The same for stages 1-3, the order of preference and the standardisation that follows (CFM on the diagonal included):
     problems that stage 0 cannot resolve (random b, rank-deficient A), as the second and as the first group of a two-group world."""
+    R, NC = shim.R, shim.NC
     rng = np.random.default_rng(12)
     seen = set()
     for trial in range(7):
         parts = []
-        for nc in (int(rng.integers(1, 5)), int(rng.integers(1, 5))):
+        for nc in (int(rng.integers(1, NC // 2 + 1)), int(rng.integers(1, NC // 2 + 1))):
             m = 3 * nc
             ndof = int(rng.choice([3, 6, 12]))
             J = rng.normal(0, 1, (m, ndof))
@@ -272,28 +294,29 @@ def test_cascade_on_one_constrained_group_equals_the_cascade_of_that_group_alone
             b = rng.normal(0, 1, m) if trial % 3 else A @ np.abs(rng.normal(0, 1, m))
             parts.append((m, A, b, rng.normal(0, 0.1, m)))
         mT = parts[0][0] + parts[1][0]
-        A = np.zeros((24, 24)); b = np.zeros(24); x0 = np.zeros(24); mu = np.ones(8)
+        A = np.zeros((R, R)); b = np.zeros(R); x0 = np.zeros(R); mu = np.ones(NC)
         o = 0
         for (m, Ag, bg, xg) in parts:
             A[o:o + m, o:o + m] = Ag; b[o:o + m] = bg; x0[o:o + m] = xg; o += m
         off = 0
         for (m, Ag, bg, xg) in parts:
             mask = ((1 << m) - 1) << off
-            X = np.zeros(24); Xs = np.zeros(24); cls = np.zeros(24, np.int32); cfm = C.c_double(0)
-            st = shim.shim_coop_cascade_masked(mT, _p(np.ascontiguousarray(A)), _p(b), _p(mu), _p(x0), C.c_uint(mask), C.c_double(1e-4), _p(X), C.byref(cfm), _p(Xs), _pi(cls))
-            A1 = np.zeros((24, 24)); A1[:m, :m] = Ag; b1 = np.zeros(24); b1[:m] = bg; x1 = np.zeros(24); x1[:m] = xg
-            X1 = np.zeros(24); Xs1 = np.zeros(24); cls1 = np.zeros(24, np.int32); cfm1 = C.c_double(0)
-            st1 = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A1)), _p(b1), _p(mu), _p(x1), C.c_uint((1 << m) - 1), C.c_double(1e-4), _p(X1), C.byref(cfm1), _p(Xs1), _pi(cls1))
+            X = np.zeros(R); Xs = np.zeros(R); cls = np.zeros(R, np.int32); cfm = C.c_double(0)
+            st = shim.shim_coop_cascade_masked(mT, _p(np.ascontiguousarray(A)), _p(b), _p(mu), _p(x0), C.c_uint64(mask), C.c_double(1e-4), _p(X), C.byref(cfm), _p(Xs), _pi(cls))
+            A1 = np.zeros((R, R)); A1[:m, :m] = Ag; b1 = np.zeros(R); b1[:m] = bg; x1 = np.zeros(R); x1[:m] = xg
+            X1 = np.zeros(R); Xs1 = np.zeros(R); cls1 = np.zeros(R, np.int32); cfm1 = C.c_double(0)
+            st1 = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A1)), _p(b1), _p(mu), _p(x1), C.c_uint64((1 << m) - 1), C.c_double(1e-4), _p(X1), C.byref(cfm1), _p(Xs1), _pi(cls1))
             assert st == st1 and cfm.value == cfm1.value, (trial, off, hex(st), hex(st1))
             assert np.array_equal(X[off:off + m], X1[:m]), (trial, off)                  # the solvers see the same problem: bit for bit
             assert np.array_equal(cls[off:off + m], cls1[:m]) and np.abs(Xs[off:off + m] - Xs1[:m]).max() <= 1e-10 * max(np.abs(Xs1).max(), 1e-30)
             assert not X[:off].any() and not X[off + m:].any()
             seen.add(st & 0x13c)
             off += m
-    assert len(seen) >= 3, seen      # the trials reach several exits of the cascade
+    assert len(seen) >= (3 if R == 24 else 2), seen      # the trials reach several exits of the cascade
 
 
-def test_reverse_mode_of_the_so3_integration_is_exact_up_to_the_log_map_singularity(shim):
+def test_reverse_mode_of_the_so3_integration_is_exact_up_to_the_log_map_singularity(shim24):
+    shim = shim24
     """spatial_dev.hpp so3IntegrationVjp (the VJP of q' = logMap(exp(q) exp(w dt)) the device uses where the reference finite-differences,
     BallJoint.cpp:351-408 / FreeJoint.cpp:950-1007) against a five-point stencil of the same function in 80-bit arithmetic, from a generic
     rotation down to 2e-3 rad short of pi, where logMap in doubles loses digits like 1e-16 / gap^2 (and a quotient in doubles with eps 1e-6,

@@ -10,10 +10,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _cases(rng, count):
-    Q = np.zeros((count, 24, 24)); size = np.zeros(count, np.int32); rank = np.zeros(count, np.int32)
+def _cases(rng, count, R=24):
+    Q = np.zeros((count, R, R)); size = np.zeros(count, np.int32); rank = np.zeros(count, np.int32)
     for t in range(count):
-        c = int(rng.integers(1, 25)); idx = np.sort(rng.choice(24, c, replace=False))
+        c = int(rng.integers(1, R + 1)); idx = np.sort(rng.choice(R, c, replace=False))
         kind = t % 6
         if kind == 0:                                   # a standing robot: c rows on two 6-DOF bodies
             k = min(c, 12); J = rng.normal(0, 1, (c, 12)); sub = J @ np.diag(rng.uniform(0.1, 2, 12)) @ J.T
@@ -27,16 +27,17 @@ def _cases(rng, count):
     return Q, size, rank
 
 
-def test_device_pseudo_inverses_equal_numpy_pinv():
+@pytest.mark.parametrize("R", [24, 48])      # the 24-row and the 48-row instantiation of the library (csrc/abi_variants.h)
+def test_device_pseudo_inverses_equal_numpy_pinv(R):
     from nimblephysics_amd._lib import check, lib
-    rng = np.random.default_rng(11)
-    count = 768
-    Q, size, rank = _cases(rng, count)
+    rng = np.random.default_rng(11 + R)
+    count = 768 if R == 24 else 384
+    Q, size, rank = _cases(rng, count, R)
     vp = lambda a: C.c_void_p(a.ctypes.data)
     out = {}
     for route in (0, 1):
         P = np.zeros_like(Q); r = np.zeros(count, np.int32)
-        check(lib().nbl_selftest_pinv(count, vp(Q), vp(size), route, vp(P), vp(r), 1, None), "nbl_selftest_pinv")
+        check(lib().nbl_selftest_pinv_rows(count, R, vp(Q), vp(size), route, vp(P), vp(r), 1, None), "nbl_selftest_pinv_rows")
         out[route] = (P, r)
     worst = {0: 0.0, 1: 0.0}
     for t in range(count):
@@ -53,7 +54,8 @@ def test_device_pseudo_inverses_equal_numpy_pinv():
     print("worst error in units of cond(Q) eps: Householder route", worst[0], " Cholesky route", worst[1])
 
 
-def test_round_off_pivots_of_exactly_singular_contact_matrices_are_rejected_like_the_references_cod():
+@pytest.mark.parametrize("R", [24, 48])
+def test_round_off_pivots_of_exactly_singular_contact_matrices_are_rejected_like_the_references_cod(R):
     """An exactly singular Q (two contacts of one body that span five directions): the last pivot of the diagonally pivoted Cholesky
     is pure round-off but comes out ABOVE the eps * size threshold of the reference's decomposition (1.4e-15 of the first pivot against
     1.3e-15), the COD's last |R_kk| below it (3e-16): tests/golden/pinv_rank_borderline.json, a matrix the randomised soak found
@@ -67,20 +69,20 @@ def test_round_off_pivots_of_exactly_singular_contact_matrices_are_rejected_like
     rng = np.random.default_rng(12)
     mats, ranks = [A], [5]
     for t in range(256):
-        nc = int(rng.integers(2, 9)); ndof = int(rng.choice([6, 7, 12]))
+        nc = int(rng.integers(2, R // 3 + 1)); ndof = int(rng.choice([6, 7, 12]))
         J = rng.normal(0, 1, (3 * nc, ndof))
         if t % 2 == 0:
             J[3:6] = J[0:3] + (0.0 if t % 4 == 0 else 1.0) * rng.normal(0, 1, (1, ndof))     # a repeated contact / a contact one direction away
         M = J @ np.diag(rng.uniform(0.1, 2, ndof)) @ J.T
         mats.append(0.5 * (M + M.T)); ranks.append(int(np.linalg.matrix_rank(J)))
     count = len(mats)
-    Q = np.zeros((count, 24, 24)); size = np.zeros(count, np.int32)
+    Q = np.zeros((count, R, R)); size = np.zeros(count, np.int32)
     for t, M in enumerate(mats):
         Q[t, :len(M), :len(M)] = M; size[t] = len(M)
     vp = lambda a: C.c_void_p(a.ctypes.data)
     for route in (0, 1):
         P = np.zeros_like(Q); r = np.zeros(count, np.int32)
-        check(lib().nbl_selftest_pinv(count, vp(Q), vp(size), route, vp(P), vp(r), 1, None), "nbl_selftest_pinv")
+        check(lib().nbl_selftest_pinv_rows(count, R, vp(Q), vp(size), route, vp(P), vp(r), 1, None), "nbl_selftest_pinv_rows")
         assert np.array_equal(r, np.array(ranks)), (route, np.where(r != np.array(ranks))[0][:10])
         for t in (0, 1, 2, 3):
             sv = np.linalg.svd(Q[t], compute_uv=False)

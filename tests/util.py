@@ -194,3 +194,51 @@ def duplicate_filter_scene(deep=4):
     md = na.ModelDescription("duplicate_filter", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=8)
     s = np.zeros((1, 12)); s[0, 1] = 0.01                        # a little yaw: no two corners share a coordinate
     return md, s, np.zeros((1, 6))
+
+
+# ---- more than 8 contacts per world: the 48-row instantiation of the library (tests/test_gpu_contacts16.py) ----
+def cube_world(n_cubes=3, max_contacts=16, side=0.2, mass=0.1, mu=1.0):
+    """A welded ground plate (top face y = 0) and `n_cubes` FreeJoint cubes (zero configuration: centre at the origin)."""
+    I = mass * side * side / 6.0
+    bodies = [na.BodySpec(f"cube{i}", -1, "free", f"cube{i}_joint", mass=mass, inertia=(I, I, I, 0, 0, 0)) for i in range(n_cubes)]
+    boxes = [na.BoxSpec(-1, na.make_transform((0, -0.5, 0)), (6.0, 1.0, 6.0), mu)]
+    boxes += [na.BoxSpec(i, np.eye(4), (side, side, side), mu) for i in range(n_cubes)]
+    return na.ModelDescription("cubes", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=max_contacts)
+
+
+def cube_tower_inputs(B, seed, n_cubes=3, side=0.2, **kw):
+    """A tower of cubes on the ground plate: 4 contacts per interface (FACE_VERTEX / VERTEX_FACE / EDGE_EDGE between cubes of one yaw and a
+    small lateral offset), 12 contacts with three cubes, 16 with four."""
+    rng = np.random.default_rng(seed)
+    md = cube_world(n_cubes, side=side, **kw)
+    n = 6 * n_cubes
+    q = np.zeros((B, n)); v = np.zeros((B, n))
+    yaw = rng.uniform(-1.0, 1.0, B)
+    x, z = rng.uniform(-0.3, 0.3, B), rng.uniform(-0.3, 0.3, B)
+    c, s_ = np.cos(yaw), np.sin(yaw)
+    y = np.zeros(B)
+    for k in range(n_cubes):
+        y = y + (0.5 * side if k == 0 else side) - rng.uniform(1e-4, 1e-3, B)
+        off = (rng.uniform(0.005, 0.03, (B, 2)) * rng.choice([-1, 1], (B, 2))) if k else np.zeros((B, 2))
+        x = x + c * off[:, 0] + s_ * off[:, 1]; z = z - s_ * off[:, 0] + c * off[:, 1]
+        q[:, 6 * k + 1] = yaw; q[:, 6 * k + 3] = x; q[:, 6 * k + 4] = y; q[:, 6 * k + 5] = z
+        v[:, [6 * k + 3, 6 * k + 5]] = rng.normal(0, 0.05, (B, 2))
+    return md, np.concatenate([q, v], 1), np.zeros((B, n))
+
+
+def table_inputs(B, seed, feet=4, max_contacts=16):
+    """One free body standing on `feet` small boxes (4 contacts each: 16 with four feet), randomly pushed: 48 LCP rows of rank 6."""
+    rng = np.random.default_rng(seed)
+    I = (0.05, 0.08, 0.05, 0.0, 0.0, 0.0)
+    bodies = [na.BodySpec("table", -1, "free", "root", mass=2.0, inertia=I)]
+    boxes = [na.BoxSpec(-1, na.make_transform((0.0, -0.5, 0.0)), (10.0, 1.0, 10.0), 1.0)]
+    corners = [(-0.3, -0.2), (0.3, -0.2), (-0.3, 0.2), (0.3, 0.2), (0.0, 0.0)][:feet]
+    for (cx, cz) in corners:
+        boxes.append(na.BoxSpec(0, na.make_transform((cx, 0.05, cz)), (0.1, 0.1, 0.1), 1.0))
+    md = na.ModelDescription("table", bodies, boxes, gravity=(0.0, -9.81, 0.0), dt=1e-3, max_contacts=max_contacts)
+    s = np.zeros((B, 12))
+    s[:, 1] = rng.uniform(-1.0, 1.0, B)                                   # yaw
+    s[:, 3] = rng.uniform(-1, 1, B); s[:, 5] = rng.uniform(-1, 1, B)
+    s[:, 4] = -rng.uniform(1e-4, 2e-3, B)                                 # feet 0.1 .. 2 mm in the ground
+    s[:, 6:] = rng.normal(0, 0.05, (B, 6)) * np.where(rng.random((B, 1)) < 0.7, 1.0, 0.02)   # most pushed / spun, some nearly at rest
+    return md, s, rng.normal(0, 0.2, (B, 6))
