@@ -25,6 +25,8 @@ The nimblephysics package cannot be built in this repo's environment; tests/test
 stand-in that exposes exactly the methods above."""
 from __future__ import annotations
 
+from typing import Optional
+
 import numpy as np
 
 from .model import BodySpec, BoxSpec, ModelDescription
@@ -45,7 +47,7 @@ def _limit(v, lo: bool):
     return v if np.isfinite(v) else (-np.inf if lo else np.inf)
 
 
-def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 8, inertia_entry_type=None) -> ModelDescription:
+def model_from_nimble_world(world, name: str = "extracted", max_contacts: Optional[int] = None, inertia_entry_type=None) -> ModelDescription:
     """`world`: a live nimblephysics.simulation.World (or anything exposing the methods listed in the module docstring).
     inertia_entry_type: nimblephysics.neural.WrtMassBodyNodeEntryType.INERTIA_FULL (looked up when nimblephysics is importable)."""
     if inertia_entry_type is None:
@@ -155,10 +157,12 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: int = 
                     boxes.append(BoxSpec(gidx, T, (float(shp.getRadius()), float(shp.getHeight()), 0.0), mu, "capsule", e))
                 # meshes, cylinders, ...: outside the analytic narrow phases (dropped, like in the loaders)
     g = tuple(float(x) for x in np.asarray(world.getGravity()).reshape(3))
-    md = ModelDescription(name, bodies, boxes, g, float(world.getTimeStep()), None, max_contacts=max_contacts if boxes else 0,
+    md = ModelDescription(name, bodies, boxes, g, float(world.getTimeStep()), None, max_contacts=(max_contacts or 0) if boxes else 0,
                           contact_clipping_depth=float(world.getContactClippingDepth()),
                           fallback_cfm=float(world.getFallbackConstraintForceMixingConstant()),
                           penetration_correction=bool(world.getPenetrationCorrectionEnabled()))
+    if boxes and max_contacts is None:          # (not said: 8 or 16 by what the world's collider pairs can hold)
+        md.max_contacts = md.suggest_max_contacts()
     aspace = [int(a) for a in world.getActionSpace()]
     if aspace != list(range(md.num_dofs)):
         md.set_action_space(aspace)

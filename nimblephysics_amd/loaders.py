@@ -233,7 +233,7 @@ def _shape_inertia(geom, mass):
     return None
 
 
-def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_colliders=False):
+def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupported_colliders=False, immobile="weld"):
     """Parse a SKEL world (`<skel><world>`: physics + skeletons) into ONE ModelDescription (all skeletons of the world in one
     model, like `with_ground`).  `skeletons`: names of the skeletons to keep (default: all), in file order.  Collision shapes other than
     boxes, spheres (isotropic ellipsoids) and capsules that only meet capsules / spheres raise unless `drop_unsupported_colliders` (the body is then loaded without that collider).
@@ -248,7 +248,12 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
     <axis><dynamics>), spring_stiffness / spring_rest_position, <limit> lower / upper (:1870-1960).  Bodies are emitted
     parents-before-children in the file's joint order, which is the skeleton's DOF order.  Ball joints and the
     <dof> elements of every joint type are read too; a file without <world> is a skeleton file.  Soft bodies, meshes, screw joints and
-    <init_pos> / <init_vel> (a state, not a model constant) are outside the subset: unsupported joints raise."""
+    <init_pos> / <init_vel> (a state, not a model constant) are outside the subset: unsupported joints raise.
+    `immobile`: a skeleton with <mobile>false</mobile> (Skeleton::setMobile, SkelParser.cpp:958-964: World::step skips its dynamics,
+    World.cpp:221-254, and its bodies are not reactive in contacts, BodyNode.cpp:2394-2400 - the ground of cartpole.skel / fullbody1.skel) is
+    loaded WELDED to the world at its zero configuration ("weld": what the reference's world does with it as long as nobody gives it a
+    velocity; its joint coordinates are then not part of the state vector, the one difference to the reference's World) or refused ("error").
+    `max_contacts`: contact slots per world (<= 16); None = ModelDescription.suggest_max_contacts() (8 or 16 by what the collider pairs can hold)."""
     root = ET.parse(path).getroot()
     world = root.find("world")
     if world is None:
@@ -266,6 +271,10 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
         if skeletons is not None and sk.get("name") not in skeletons:
             continue
         skel_T = _skel_T(sk)                                     # optional skeleton frame (:948-955)
+        mob = sk.find("mobile")
+        is_mobile = mob is None or mob.text.strip().lower() not in ("false", "0")
+        if not is_mobile and immobile != "weld":
+            raise ValueError(f"{path}: skeleton {sk.get('name')} is immobile (<mobile>false</mobile>); immobile=\"weld\" loads it welded to the world")
         bel = {b.get("name"): b for b in sk.findall("body")}
         for bn, b_ in bel.items():
             if b_.find("soft_shape") is not None:
@@ -465,6 +474,8 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
                             kw[key] = tuple(vals)
                         else:
                             kw.pop(key, None)
+                if not is_mobile:                 # an immobile skeleton: every joint frozen at its zero configuration
+                    jtype, kw, axis = "weld", {}, (0.0, 0.0, 1.0)
                 mass, com, I6 = inertial(bel[cn])
                 base = len(bodies)
                 bodies.append(BodySpec(cn, -1 if pn == "world" else index[pn], jtype, j.get("name"), axis=axis, T_pj=T_pj, T_cj=c2j,
@@ -478,7 +489,9 @@ def load_skel(path, name=None, skeletons=None, max_contacts=8, drop_unsupported_
             raise ValueError(f"{path}: bodies without a parent joint: {sorted(missing)}")
     if name is None:
         name = os.path.splitext(os.path.basename(path))[0]
-    md = ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=max_contacts if boxes else 0)
+    md = ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=(max_contacts or 0) if boxes else 0)
+    if boxes and max_contacts is None:          # (not said: 8 or 16 by what the collider pairs of the world can hold, ModelDescription.suggest_max_contacts)
+        md.max_contacts = md.suggest_max_contacts()
     if md.capsule_meets_box():
         # capsule-capsule and capsule-sphere pairs are closed form (DARTCollide.cpp:4183-4420); capsule-box is libccd's MPR (:4422-4645)
         if not drop_unsupported_colliders:

@@ -445,6 +445,23 @@ class ModelDescription:
             return False
         return True
 
+    def suggest_max_contacts(self) -> int:
+        """Contact slots per world for a description that does not say (the loaders' default): 8 - the 24-row build of the library, the fast
+        one - when the collider pairs that can meet cannot hold more than 8 contacts in their usual configurations (a face of a box on
+        another box: 4 points; every sphere / capsule pair: 1 or 2), else 16, the most the device path carries (the reference itself keeps
+        every contact, ConstraintSolver.cpp:563-606; a world that exceeds the slots is truncated and flagged NBL_ST_CONTACT_OVERFLOW).
+        Models with more than 16 colliders or 32 collider pairs run the 48-row build whatever this says."""
+        if not self.boxes:
+            return 0
+        m = self.merge_welds() if self.has_welds() else self
+        skel = m.body_skeletons()
+        est = 0
+        for i, bi in enumerate(m.boxes):
+            for bj in m.boxes[i + 1:]:
+                if m.colliders_are_tested(bi, bj, skel):
+                    est += 4 if (bi.shape == "box" and bj.shape == "box") else (2 if (bi.shape == "capsule" and bj.shape == "capsule") else 1)
+        return 8 if est <= 8 else 16
+
     def capsule_meets_box(self) -> bool:
         """Some capsule collider is tested against some box collider (different bodies, not both fixed to the world, different skeletons:
         the pairs CollisionFilter.cpp:105-154 lets through)."""

@@ -324,6 +324,7 @@ def test_independent_objects_are_solved_as_separate_constrained_groups():
     from nimblephysics_amd.timestep import timestep
     from oracle import OracleWorld
     md = na.box_stack()
+    md.max_contacts = 16             # a cube on the rim of the ground box has more than four contacts: the 48-row build keeps them all
     n = md.num_dofs
     B = 2048
     rng = np.random.default_rng(21)
@@ -352,17 +353,15 @@ def test_independent_objects_are_solved_as_separate_constrained_groups():
     ref = ow.step_batch(s, a, g, threads=8)
     dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
     for k in dev:                                              # (a NaN would compare as "not above the tolerance")
-        assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), (name, k, "non-finite values")
+        assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), ("two cubes", k, "non-finite values")
     scales = {k: np.abs(ref[k]).max() for k in dev}
     errs = {k: np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev}
     world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}}
     assert (status & 0x1).mean() > 0.99
     assert np.array_equal(status & 0x81, ref["status"] & 0x81)               # contact, contact overflow
-    ovf = (status & 0x80) != 0                                                # a ninth contact (cube on the rim): truncated by the device, flagged by both
-    assert ovf.mean() < 0.25
-    errs = {k: np.where(ovf, 0.0, e) for k, e in errs.items()}
+    assert not (status & 0x80).any()                                          # (round 3: a quarter of these worlds had a ninth contact, were truncated and masked here)
     same = (status & 0x13e) == (ref["status"] & 0x13e)                        # every group ended in the same stage, standardised or not
-    assert same[~ovf].mean() > 0.95
+    assert same.mean() > 0.95
     _report("two cubes side by side", errs)
     # A world with one cube on the CFM fallback (full-rank, ill-conditioned block: status bit 0x8) next to one on four coplanar
     # corners (rank-deficient block) makes the reference's JOINT precise-inverse test (BackpropSnapshot.cpp:2964-2984) choose the full

@@ -1,0 +1,117 @@
+"""Three of the reference's OWN worlds that the 24-row build of the library had to refuse (more than 16 colliders, more than 32
+collider pairs, more than 8 contacts), transcribed by tools/urdf_to_model.py from data/skel/biped.skel, data/skel/fullbody1.skel and
+data/skel/test/box_stacking.skel (nimblephysics_amd/data/*.json): forward + backward on the device against the oracle."""
+import numpy as np
+import pytest
+
+from parity import assert_match_or_reference_unstable, world_errors
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+def _fwd_bwd(md, s, a, seed):
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    world = na.World(md, device="cuda:0")
+    g = np.random.default_rng(seed).normal(0, 1, s.shape)
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    out = timestep(world, st, at)
+    status = world.last_status.cpu().numpy().astype(np.uint32)
+    out.backward(torch.tensor(g, device="cuda:0"))
+    dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
+    return world, dev, status, g
+
+
+def _clip_to_limits(md, q):
+    fl = md.merge_welds().flat() if md.has_welds() else md.flat()
+    lo, hi = np.asarray(fl["pos_lo"]), np.asarray(fl["pos_hi"])
+    return np.clip(q, np.where(np.isfinite(lo), lo + 1e-3, -np.inf), np.where(np.isfinite(hi), hi - 1e-3, np.inf))
+
+
+def test_fullbody1_standing_on_sixteen_contacts():
+    """data/skel/fullbody1.skel: a 37-DOF humanoid (free root, Euler / universal / revolute joints, 33 bodies, 21 box colliders) over its
+    ground box.  Lowered by 5 - 7 cm it stands on heels and toes: 2 x 2 x 4 = 16 contacts, 48 LCP rows."""
+    import nimblephysics_amd as na
+    from oracle import OracleWorld
+    md = na.ModelDescription.load("fullbody1")
+    assert md.max_contacts == 16 and len(md.boxes) == 21
+    n, B = md.num_dofs, 256
+    rng = np.random.default_rng(71)
+    q = np.zeros((B, n)); q[:, 6:] = rng.normal(0, 0.01, (B, n - 6))
+    q = _clip_to_limits(md, q)
+    q[:, 4] = -rng.uniform(0.05, 0.07, B)
+    v = rng.normal(0, 0.01, (B, n)); a = rng.normal(0, 0.1, (B, len(md.action_map)))
+    s = np.concatenate([q, v], 1)
+    world, dev, st, g = _fwd_bwd(md, s, a, 72)
+    assert world._L.nbl_model_max_contacts(world._h) == 16
+    ow = OracleWorld(md)
+    ref = ow.step_batch(s, a, g, threads=8)
+    assert (st & 0x1).all() and np.array_equal(st & 0x81, ref["status"] & 0x81) and not (st & 0x80).any()
+    ow.step(s[0], a[0])
+    assert len(ow.last_contacts()) == 16
+    print("[fullbody1] device stages:", {hex(int(k)): int(c) for k, c in zip(*np.unique(st & 0x13e, return_counts=True))})
+    bad, by_closeness = assert_match_or_reference_unstable("fullbody1 on 16 contacts", ow, s, a, g, dev, ref, TOL, ulps=16)
+    assert bad <= 0.05 * B
+
+
+def test_biped_with_twenty_colliders_in_free_fall():
+    """data/skel/biped.skel: 37 DOFs, 20 box colliders on one skeleton without self-collision: no pair is ever tested, but the collider table
+    alone exceeded the 24-row build."""
+    import nimblephysics_amd as na
+    from oracle import OracleWorld
+    md = na.ModelDescription.load("biped")
+    assert len(md.boxes) == 20
+    n, B = md.num_dofs, 256
+    rng = np.random.default_rng(73)
+    q = _clip_to_limits(md, rng.normal(0, 0.2, (B, n)))
+    s = np.concatenate([q, rng.normal(0, 0.5, (B, n))], 1); a = rng.normal(0, 0.5, (B, len(md.action_map)))
+    world, dev, st, g = _fwd_bwd(md, s, a, 74)
+    ow = OracleWorld(md)
+    ref = ow.step_batch(s, a, g, threads=8)
+    assert not (st & 0x1).any() and not (ref["status"] & 0x1).any()
+    e, _ = world_errors(dev, ref)
+    for k in e:
+        assert e[k].max() < TOL, (k, float(e[k].max()))
+
+
+def test_box_stacking_world_with_four_of_its_ten_cubes_stacked():
+    """data/skel/test/box_stacking.skel as it is: a ground box and ten FreeJoint cubes (60 DOFs, 55 collider pairs).  Four cubes stacked on
+    the ground (16 contacts, one constrained group of four skeletons), the other six falling next to them."""
+    import nimblephysics_amd as na
+    from oracle import OracleWorld
+    md = na.ModelDescription.load("box_stacking_full")
+    mw = md.merge_welds()
+    n, B = md.num_dofs, 256
+    assert n == 60
+    rng = np.random.default_rng(75)
+    gb = mw.boxes[0]
+    top = gb.T[1, 3] + 0.5 * gb.size[1]
+    centres = [b.T_pj[:3, 3] for b in mw.bodies]
+    q = np.zeros((B, n)); v = np.zeros((B, n))
+    yaw = rng.uniform(-1.0, 1.0, B)
+    x, z = rng.uniform(-0.3, 0.3, B), rng.uniform(-0.3, 0.3, B)
+    c, s_ = np.cos(yaw), np.sin(yaw)
+    y = np.full(B, top)
+    for k in range(10):
+        o = 6 * k
+        if k < 4:
+            y = y + (0.1 if k == 0 else 0.2) - rng.uniform(1e-4, 1e-3, B)
+            off = (rng.uniform(0.005, 0.03, (B, 2)) * rng.choice([-1, 1], (B, 2))) if k else np.zeros((B, 2))
+            x = x + c * off[:, 0] + s_ * off[:, 1]; z = z - s_ * off[:, 0] + c * off[:, 1]
+            q[:, o + 1] = yaw; q[:, o + 3] = x - centres[k][0]; q[:, o + 4] = y - centres[k][1]; q[:, o + 5] = z - centres[k][2]
+            v[:, [o + 3, o + 5]] = rng.normal(0, 0.05, (B, 2))
+        else:
+            q[:, o:o + 3] = rng.normal(0, 0.3, (B, 3))
+            q[:, o + 3] = 0.8 * (k - 6.5) - centres[k][0]; q[:, o + 4] = 1.0 - centres[k][1]; q[:, o + 5] = 0.9 - centres[k][2]
+            v[:, o:o + 6] = rng.normal(0, 0.3, (B, 6))
+    s = np.concatenate([q, v], 1); a = np.zeros((B, len(md.action_map)))
+    world, dev, st, g = _fwd_bwd(md, s, a, 76)
+    ow = OracleWorld(md)
+    ref = ow.step_batch(s, a, g, threads=8)
+    assert (st & 0x1).all() and np.array_equal(st & 0x81, ref["status"] & 0x81) and not (st & 0x80).any()
+    ow.step(s[0], a[0])
+    assert len(ow.last_contacts()) == 16
+    bad, _ = assert_match_or_reference_unstable("box_stacking.skel, 4 of 10 cubes stacked", ow, s, a, g, dev, ref, TOL, ulps=16)
+    assert bad <= 0.03 * B

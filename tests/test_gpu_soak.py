@@ -22,14 +22,14 @@ def test_random_models_all_worlds_vs_oracle():
 
 
 def test_random_larger_models_with_many_colliders_all_worlds_vs_oracle():
-    """8-21 bodies, 3-7 colliders: up to 8 contacts at once and the contact-overflow flag (the oracle solves with every contact
-    like the reference and raises the same flag; truncated worlds are excluded from the comparison, their flags must agree).
-    Soak of the round: 300 models x 256 worlds = 76 800 worlds, 29 610 in contact, 21 434 through the cascade: 3 above 1e-5, all
+    """8-21 bodies, 3-7 colliders, 16 contact slots per world (the 48-row build of the library; with 8 slots 0.2 % of these worlds held a
+    ninth contact, were truncated, flagged and left out of the comparison in round 3): no world overflows, none is left out.
+    Soak of round 3 (8 slots): 300 models x 256 worlds = 76 800 worlds, 29 610 in contact, 21 434 through the cascade: 3 above 1e-5, all
     reference-unstable, 0 mismatches."""
     import soak_parity
     tot = soak_parity.run(7000, 40, 256, verbose=False, big=True)
     print(tot)
-    assert tot["MISMATCH"] == 0, tot
+    assert tot["MISMATCH"] == 0 and tot["overflow"] == 0, tot
     assert tot["contact"] > 0.2 * tot["worlds"], tot
 
 

@@ -31,7 +31,7 @@ def run(directory, B=64, tol=1e-6):
         if md.num_dofs == 0:
             continue
         if md.boxes and not md.max_contacts:
-            md.max_contacts = 8
+            md.max_contacts = md.suggest_max_contacts()
         try:
             world = na.World(md, device="cuda:0")
         except na.NimbleAmdError as e:
@@ -49,7 +49,7 @@ def run(directory, B=64, tol=1e-6):
         st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
         out = timestep(world, st, at)
         status = world.last_status.cpu().numpy().astype(np.uint32)
-        dev_cache = world.lcp_cache.cpu().numpy() if world.lcp_cache is not None else np.zeros((25, B))
+        dev_cache = world.lcp_cache.cpu().numpy() if world.lcp_cache is not None else np.zeros((3 * max(md.max_contacts, 8) + 1, B))
         out.backward(torch.tensor(g, device="cuda:0"))
         ref = ow.step_batch(s, a, g, threads=8)
         dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}

@@ -139,11 +139,11 @@ def mutator(mode):
     return mutate
 
 
-def run(mode, first=0, count=20, B=256, verbose=False, variant="balls"):
+def run(mode, first=0, count=20, B=256, verbose=False, variant="balls", slots=None):
     """variant: the model family of tools/soak_parity.py the mutation is applied to (balls, big, multi)."""
     import soak_parity
     return soak_parity.run(first, count, B, verbose=verbose, balls=variant == "balls", big=variant == "big", multi=variant == "multi",
-                           mutate=mutator(mode))
+                           mutate=mutator(mode), slots=slots)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,7 @@ def main():
         "box_stack": skel_models()[1],
     }
     skel.update(ball_joint_models())
+    skel.update(many_collider_worlds())
     for name, mdl in skel.items():
         with open(os.path.join(out_dir, name + ".json"), "w") as f:
             json.dump(mdl.to_json(), f, indent=1)
@@ -70,6 +71,19 @@ def skel_models():
     for b, jn in zip(stack.bodies, ("ground_joint", "box1_joint", "box2_joint")):
         b.joint_name = jn
     return pend, stack
+
+
+def many_collider_worlds():
+    """Three of the reference's own worlds that need the 48-row build of the library (more than 16 colliders / 32 collider pairs / 8
+    contacts): data/skel/biped.skel (20 colliders), data/skel/fullbody1.skel (21 colliders: a humanoid over a ground box) and the whole
+    data/skel/test/box_stacking.skel (ground + 10 cubes: 55 collider pairs), as load_skel reads them."""
+    out = {}
+    for nm, rel in (("biped", "data/skel/biped.skel"), ("fullbody1", "data/skel/fullbody1.skel"), ("box_stacking_full", "data/skel/test/box_stacking.skel")):
+        md = load_skel(os.path.join(REF, rel), nm)
+        if md.boxes:
+            md.max_contacts = 16
+        out[nm] = md
+    return out
 
 
 def ball_joint_models():
