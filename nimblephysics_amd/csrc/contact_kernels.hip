@@ -173,9 +173,6 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
     if (pl != 0 || !valid) return;
   }
   NBL_PHASE(59);
-  // NOTE: the duplicate filter above only sees contacts that were kept; the reference compares against every
-  // contact of the total result including ones later dropped by the depth filter.  Those can only coincide
-  // with a kept point if they are the same point, which the depth filter treats identically.
   // ---- joint-limit constraint rows (JointLimitConstraint::update, JointLimitConstraint.cpp:182-237): every limit-enforcing DOF at or
   //      below its lower / at or above its upper limit is appended as a pseudo-contact after the contacts (ConstraintSolver.cpp:641-696
   //      pushes the joint-limit constraints after the contact constraints) ----

@@ -168,7 +168,17 @@ def expand_compound_joints(bodies, boxes):
             parent = len(out)
             out.append(nb)
         where.append(len(out) - 1)
-    nboxes = [BoxSpec(bx.body if bx.body < 0 else where[bx.body], bx.T, tuple(bx.size), bx.mu, bx.shape, bx.restitution) for bx in boxes]
+    # colliders follow their bodies; their BodyNode identity for the adjacent-body rule of self-collision (BodyNodeCollisionFilter::
+    # areAdjacentBodies compares getParentBodyNode, CollisionFilter.cpp:150-154) is the REAL body and its REAL parent - not the massless
+    # virtual link '#v*' the chain put between them
+    def node_of(bx):
+        if bx.body < 0:
+            return -1, -2
+        if bx.node >= 0:                      # identities from an earlier stage (merge_welds): keep them
+            return bx.node, bx.node_parent
+        p = bodies[bx.body].parent
+        return where[bx.body], (where[p] if p >= 0 else -1)
+    nboxes = [BoxSpec(bx.body if bx.body < 0 else where[bx.body], bx.T, tuple(bx.size), bx.mu, bx.shape, bx.restitution, *node_of(bx)) for bx in boxes]
     return out, nboxes, where
 
 @dataclass
@@ -515,7 +525,8 @@ class ModelDescription:
             "fallback_cfm": self.fallback_cfm, **({"penetration_correction": True} if self.penetration_correction else {}), "bodies": [body(b) for b in self.bodies],
             "boxes": [{"body": bx.body, "T": np.asarray(bx.T).tolist(), "size": list(bx.size), "mu": bx.mu,
                        **({} if bx.shape == "box" else {"shape": bx.shape}),
-                       **({} if bx.restitution == 0.0 else {"restitution": bx.restitution})} for bx in self.boxes],
+                       **({} if bx.restitution == 0.0 else {"restitution": bx.restitution}),
+                       **({} if bx.node < 0 else {"node": bx.node, "node_parent": bx.node_parent})} for bx in self.boxes],
         }
 
     @staticmethod
@@ -526,7 +537,7 @@ class ModelDescription:
             b["T_pj"] = np.array(b["T_pj"], dtype=np.float64)
             b["T_cj"] = np.array(b["T_cj"], dtype=np.float64)
             bodies.append(BodySpec(**b))
-        boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0), bx.get("shape", "box"), bx.get("restitution", 0.0)) for bx in d.get("boxes", [])]
+        boxes = [BoxSpec(bx["body"], np.array(bx["T"], dtype=np.float64), tuple(bx["size"]), bx.get("mu", 1.0), bx.get("shape", "box"), bx.get("restitution", 0.0), bx.get("node", -1), bx.get("node_parent", -2)) for bx in d.get("boxes", [])]
         return ModelDescription(d["name"], bodies, boxes, d.get("gravity", (0, -9.81, 0)), d.get("dt", 1e-3),
                                 d.get("action_map"), d.get("max_contacts", 0), d.get("contact_clipping_depth", 0.03),
                                 d.get("fallback_cfm", 1e-4), d.get("penetration_correction", False))

@@ -58,25 +58,31 @@ class World:
         if self.device.index is None:                      # a bare "cuda": the current device, like torch does
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._L = lib()
-        self._create_handle()
-        self.n = self._L.nbl_model_num_dofs(self._h)
-        self.k = self._L.nbl_model_num_action(self._h)
-        self.m = self._L.nbl_model_lcp_rows(self._h)
+        self._h = None
         self._ws = None
         self._ws_B = 0
         self._state = None   # [2n][B]
         self._action = None  # [k][B]
         self.lcp_cache = None  # [m][B] hidden warm start (BoxedLcpConstraintSolver::mX)
         self.last_status = None
+        self._create_handle()
 
     def _create_handle(self):
-        """(Re-)upload the model constants; an existing handle (device buffers, side streams, events) is released first."""
-        self._destroy_handle()
-        desc, self._keep = self.model.to_desc()
+        """(Re-)upload the model constants.  The new handle is created FIRST: when the library refuses the description (a finite limit on a
+        free-joint root, a capsule-box pair that self-collision exposes, ...) this raises and the World keeps its old handle; on success the
+        old handle (device buffers, side streams, events) is released and everything sized by the handle is refreshed - the LCP row count
+        changes when a collider-less model starts to enforce joint limits, and a warm start of the old row layout means nothing."""
+        desc, keep = self.model.to_desc()
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self._L.nbl_model_create(C.byref(desc), self.device.index, C.byref(h)), "nbl_model_create")
-        self._h = h
+        self._destroy_handle()
+        self._h, self._keep = h, keep
+        self.n = self._L.nbl_model_num_dofs(self._h)
+        self.k = self._L.nbl_model_num_action(self._h)
+        self.m = self._L.nbl_model_lcp_rows(self._h)
+        self.lcp_cache = None
+        self._ws, self._ws_B, self._scratch_saved = None, 0, None
         self._uploaded_inertia = [(float(b.mass), tuple(float(x) for x in b.com), tuple(float(x) for x in b.inertia)) for b in self.model.bodies]
 
     def _destroy_handle(self):
@@ -118,7 +124,6 @@ class World:
         self.model.set_action_space(mapping)
         self.description.set_action_space(mapping)
         self._create_handle()                              # re-upload the constants (the old handle is destroyed, not leaked)
-        self.k = self._L.nbl_model_num_action(self._h)
         self._action = None
         if self._wrt_mass.entries:                         # the registered mass parameters survive the re-upload
             self._push_inertia_params()
@@ -136,26 +141,43 @@ class World:
     def getPenetrationCorrectionEnabled(self) -> bool:
         return self.description.penetration_correction
 
+    def _descriptions(self):
+        return list({id(self.description): self.description, id(self.model): self.model}.values())
+
+    def _reupload_or_roll_back(self, snapshot):
+        """After the body flags of the descriptions changed: upload; if the library refuses the new model, put the flags back (the World
+        stays usable on its old handle) and re-raise."""
+        try:
+            self._create_handle()
+        except Exception:
+            for md, flags in zip(self._descriptions(), snapshot):
+                for b, (le, sc, ab) in zip(md.bodies, flags):
+                    b.limit_enforced, b.self_collision, b.adjacent_body_check = le, sc, ab
+            raise
+        if self._wrt_mass.entries:
+            self._push_inertia_params()
+
+    def _flag_snapshot(self):
+        return [[(b.limit_enforced, b.self_collision, b.adjacent_body_check) for b in md.bodies] for md in self._descriptions()]
+
     def setPositionLimitEnforced(self, enforced: bool, joints=None):
         """Joint::setPositionLimitEnforced (Joint.cpp:1366) on the named joints / bodies (default: every joint): their position limits
         become rows of the contact LCP (JointLimitConstraint.cpp).  Off by default, like in the reference (JointAspect.hpp:165)."""
-        changed = False
-        for md in {id(self.description): self.description, id(self.model): self.model}.values():
+        snapshot, changed = self._flag_snapshot(), False
+        for md in self._descriptions():
             for b in md.bodies:
                 if joints is None or b.joint_name in joints or b.name in joints:
                     if b.limit_enforced != bool(enforced):
                         b.limit_enforced = bool(enforced)
                         changed = True
         if changed:
-            self._create_handle()
-            if self._wrt_mass.entries:
-                self._push_inertia_params()
+            self._reupload_or_roll_back(snapshot)
 
     def setSelfCollisionCheck(self, enable: bool, adjacent_bodies: bool = False, skeletons=None):
         """Skeleton::setSelfCollisionCheck / setAdjacentBodyCheck (Skeleton.cpp; off by default) on the given skeleton ids (default: all):
         colliders of one skeleton meet, except - unless `adjacent_bodies` - those of a body and its parent."""
-        changed = False
-        for md in {id(self.description): self.description, id(self.model): self.model}.values():
+        snapshot, changed = self._flag_snapshot(), False
+        for md in self._descriptions():
             ids = md.body_skeletons()
             for b, sk in zip(md.bodies, ids):
                 if skeletons is None or sk in skeletons:
@@ -163,9 +185,7 @@ class World:
                         b.self_collision, b.adjacent_body_check = bool(enable), bool(enable and adjacent_bodies)
                         changed = True
         if changed:
-            self._create_handle()
-            if self._wrt_mass.entries:
-                self._push_inertia_params()
+            self._reupload_or_roll_back(snapshot)
 
     def getPositionLimitEnforced(self):
         return {b.joint_name or b.name: bool(b.limit_enforced) for b in self.description.bodies}

@@ -498,7 +498,10 @@ inline bool pairIsTested(const Model& m, int i, int j) {
     // a body and its parent
     const int fi = m.selfCollision[bi.body], fj = m.selfCollision[bj.body];
     if (!((fi & 1) && (fj & 1))) return false;
-    if (!((fi & 2) && (fj & 2)) && (m.bodies[bi.body].parent == bj.body || m.bodies[bj.body].parent == bi.body)) return false;
+    // areAdjacentBodies compares the BodyNodes' parents (CollisionFilter.cpp:150-154): the nodes of the caller's description when given
+    const bool adjacent = (bi.node != -2 && bj.node != -2) ? (bi.nodeParent == bj.node || bj.nodeParent == bi.node)
+                                                           : (m.bodies[bi.body].parent == bj.body || m.bodies[bj.body].parent == bi.body);
+    if (!((fi & 2) && (fj & 2)) && adjacent) return false;
   }
   return true;
 }

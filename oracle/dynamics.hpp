@@ -27,6 +27,9 @@ struct BoxCollider {
   s_t mu;
   int shape;  // NBL_SHAPE_BOX | NBL_SHAPE_SPHERE (radius = size.x)
   s_t restitution = 0;   // BodyNode::getRestitutionCoeff of the owning body
+  // the BodyNode the collider belongs to and that node's parent, in the caller's numbering (nbl_model_desc.box_node / box_node_parent: a
+  // compound joint expanded into a chain of 1-DOF joints puts massless virtual links between a body and its real parent); -2: not given
+  int node = -2, nodeParent = -2;
 };
 
 struct Model {
@@ -157,6 +160,7 @@ inline Model buildModel(const nbl_model_desc* d) {
     bc.mu = d->box_mu[i];
     bc.shape = d->box_shape ? d->box_shape[i] : NBL_SHAPE_BOX;
     bc.restitution = d->box_restitution ? d->box_restitution[i] : 0.0;
+    if (d->box_node && d->box_node_parent) { bc.node = d->box_node[i]; bc.nodeParent = d->box_node_parent[i]; }
     m.boxes.push_back(bc);
   }
   m.maxContacts = d->max_contacts;

@@ -3,6 +3,8 @@ against the CPU oracle, through the C ABI.  Tolerance 1e-7 relative (north_star:
 import numpy as np
 import pytest
 
+from parity import assert_match_or_reference_unstable, world_errors
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
 
@@ -27,34 +29,24 @@ def _run(name, B, seed, **kw):
     dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
     for k in dev:                                              # (a NaN would compare as "not above the tolerance")
         assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), (name, k, "non-finite values")
-    scales = {k: np.abs(ref[k]).max() for k in dev}
-    errs = {k: np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev}
-    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}}
+    errs, scales = world_errors(dev, ref)              # per world and per block (tests/parity.py)
+    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}, "md": md}
     return errs, status, ref["status"], world
 
 
-def _assert_all_worlds_match_or_reference_is_unstable(tag, errs, world, tol, n_perturb=64, closeness=0.1, ulps=1):
+def _assert_all_worlds_match_or_reference_is_unstable(tag, errs, world, tol, n_perturb=64, closeness=0.1, ulps=1, max_by_closeness=None, only=None):
     """Every world within `tol` of the oracle - or, for the few that are not, PROOF that the reference algorithm itself has no
     stable answer there: re-run the oracle on that world with +-1-ulp perturbations of the input state; its own results (next state or
     gradients) must scatter by more than `tol` (on singular A(C,C) the Dantzig early exit s <= 0, and with it friction-or-no-friction, is
     decided by round-off) AND the device result must coincide, to `tol`, with one of the reference's own outcomes (next state
-    and both gradients of the SAME perturbed run).  Returns the number of such reference-unstable worlds."""
+    and both gradients of the SAME perturbed run) - tests/parity.py, which also bounds how many worlds may pass by being 1 / closeness
+    times closer to an outcome than the outcomes scatter, and holds the gradients of worlds next to the log-map singularity of a free
+    joint (box-stack yaw ~ U(-pi, pi)) to the accuracy of the reference's own finite differences there.  only: mask of the worlds to
+    judge.  Returns the number of reference-unstable worlds."""
     P = world._parity
-    bad = np.where(np.maximum.reduce([errs[k] for k in ("next", "grad_state", "grad_action")]) > tol)[0]
-    rng = np.random.default_rng(12345)
-    for wd in bad:
-        s0 = P["s"][wd]
-        sp = s0[None, :] * (1.0 + rng.integers(-ulps, ulps + 1, (n_perturb, s0.size)) * 2.220446049250313e-16)
-        r = P["ow"].step_batch(sp, np.repeat(P["a"][wd][None], n_perturb, 0), np.repeat(P["g"][wd][None], n_perturb, 0), threads=8)
-        dist = np.maximum.reduce([np.abs(r[k] - P["dev"][k][wd][None]).max(1) / P["scales"][k] for k in ("next", "grad_state", "grad_action")])
-        spread = max(np.abs(r[k] - P["ref"][k][wd][None]).max() / P["scales"][k] for k in ("next", "grad_state", "grad_action"))   # vs the unperturbed run
-        assert spread > tol, (tag, int(wd), "the reference is stable here but the device differs", float(dist.min()))
-        # ... one of its outcomes: within tol of a perturbed run, or - where the reference's outcomes form a continuum (its
-        # gradient amplifies round-off by 1e11+) - at least 10 x closer to one of them than they scatter around the unperturbed run
-        assert dist.min() <= max(tol, closeness * spread), (tag, int(wd), "device result is none of the reference's own outcomes", float(dist.min()), float(spread))
-    print(f"[{tag}] reference-unstable worlds (oracle flips under {ulps}-ulp input perturbations; device equals one of its outcomes): "
-          f"{len(bad)} of {len(errs['next'])}")
-    return len(bad)
+    bad, _ = assert_match_or_reference_unstable(tag, P["ow"], P["s"], P["a"], P["g"], P["dev"], P["ref"], tol, n_perturb=n_perturb,
+                                                closeness=closeness, ulps=ulps, max_by_closeness=max_by_closeness, fd_model=P.get("md"), only=only)
+    return bad
 
 
 @pytest.mark.parametrize("name,B,seed", [("atlas20", 4096, 11), ("atlas33", 1024, 12)])
@@ -184,14 +176,21 @@ def test_contact_backward_vs_finite_differences_of_gpu_step():
 
 def test_edge_edge_contact_gradients_box_over_the_rim():
     """EDGE_EDGE contacts (DCC.cpp:397-424, 700-735): a cube hanging over the rim of the world-fixed ground box."""
-    errs, st, ost, _ = _run("box_stack", 512, 31, overhang=True)
+    errs, st, ost, world = _run("box_stack", 512, 31, overhang=True)
     stage_bits = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100
     assert np.array_equal(st & stage_bits, ost & stage_bits)
     assert ((st & 0x2) != 0).mean() > 0.9
     assert errs["next"].max() < TOL
     # yaw ~ U(-pi, pi): near |yaw| = pi the oracle's central-difference free-joint Jacobians (FreeJoint.cpp:950-1007,
-    # restated literally) lose accuracy (d logMap blows up); the kernels use the exact reverse-mode expression.
-    assert errs["grad_state"].max() < 1e-5 and errs["grad_action"].max() < 1e-6
+    # restated literally) lose accuracy (d logMap blows up like 1 / (pi - |yaw|)^2); the kernels use the exact reverse-mode expression.
+    # Away from the singularity every world is held to 1e-7 (per world and block), towards it to the accuracy the reference's quotient has.
+    yaw = np.abs(world._parity["s"][:, 1])
+    gap = np.pi - yaw
+    for lo, hi, tol in ((0.5, 4.0, TOL), (0.1, 0.5, 1e-6), (0.0, 0.1, 1e-4)):
+        sel = (gap >= lo) & (gap < hi)
+        print(f"[edge-edge over the rim] pi - |yaw| in [{lo}, {hi}): {int(sel.sum())} worlds, grad_state max {errs['grad_state'][sel].max() if sel.any() else 0:.2e}")
+        assert not sel.any() or errs["grad_state"][sel].max() < tol, (lo, hi, float(errs["grad_state"][sel].max()))
+    assert errs["grad_action"].max() < 1e-6
     assert np.median(errs["grad_state"]) < 1e-8
 
 
@@ -265,9 +264,8 @@ def test_frictionless_contacts_fwd_bwd_vs_oracle(mus, max_unstable):
     ref = ow.step_batch(s, a, g, threads=8)
     assert np.all(status & 0x1)
     dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
-    scales = {k: np.abs(ref[k]).max() for k in dev}
-    errs = {k: np.abs(dev[k] - ref[k]).max(1) / max(scales[k], 1e-30) for k in dev}
-    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}}
+    errs, scales = world_errors(dev, ref)
+    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}, "md": md}
     _report(f"frictionless mus={mus}", errs)
     # nothing brakes the lateral velocities when every contact is frictionless
     if max(mus) <= 1e-3 or mus[1] <= 1e-3:
@@ -279,9 +277,9 @@ def test_frictionless_contacts_fwd_bwd_vs_oracle(mus, max_unstable):
     degenerate = max_unstable >= 1.0
     unstable = _assert_all_worlds_match_or_reference_is_unstable(f"frictionless {mus}", errs, world, NORTH_STAR_TOL,
                                                                  n_perturb=256 if degenerate else 64, closeness=0.25 if degenerate else 0.1,
-                                                                 ulps=4 if degenerate else 1)
+                                                                 ulps=4 if degenerate else 1, max_by_closeness=B if degenerate else None)
     assert unstable <= max_unstable * B
-    assert np.median(errs["next"]) < 1e-12
+    assert np.median(errs["next"]) < 1e-10            # (per world and block: the lateral velocities of the cubes are a block of ~0.05)
 
 
 def test_frictionless_single_contacts_are_well_posed_and_match():
@@ -354,9 +352,8 @@ def test_independent_objects_are_solved_as_separate_constrained_groups():
     dev = {"next": out.detach().cpu().numpy(), "grad_state": st.grad.cpu().numpy(), "grad_action": at.grad.cpu().numpy()}
     for k in dev:                                              # (a NaN would compare as "not above the tolerance")
         assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), ("two cubes", k, "non-finite values")
-    scales = {k: np.abs(ref[k]).max() for k in dev}
-    errs = {k: np.abs(dev[k] - ref[k]).max(1) / scales[k] for k in dev}
-    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}}
+    errs, scales = world_errors(dev, ref)
+    world._parity = {"ow": ow, "s": s, "a": a, "g": g, "dev": dev, "scales": scales, "ref": {k: ref[k] for k in dev}, "md": md}
     assert (status & 0x1).mean() > 0.99
     assert np.array_equal(status & 0x81, ref["status"] & 0x81)               # contact, contact overflow
     assert not (status & 0x80).any()                                          # (round 3: a quarter of these worlds had a ninth contact, were truncated and masked here)
@@ -381,12 +378,12 @@ def test_independent_objects_are_solved_as_separate_constrained_groups():
     for wd in worse:
         sp = s[wd][None] * (1.0 + prng.choice([-1.0, 0.0, 1.0], (64, s.shape[1])) * 2.220446049250313e-16)
         r = ow.step_batch(sp, np.repeat(a[wd][None], 64, 0), np.repeat(g[wd][None], 64, 0), threads=8)
-        spread = max(np.abs(r[k] - ref[k][wd][None]).max() / scales[k] for k in ("grad_state", "grad_action"))
+        spread = max(float((np.abs(r[k] - ref[k][wd][None]) / scales[k][wd][None]).max()) for k in ("grad_state", "grad_action"))
         assert spread > 1e-5 and gerr[wd] < 5 * spread, (int(wd), float(gerr[wd]), float(spread))
     strict = {k: np.where(loose, 0.0, e) for k, e in errs.items()}
     # (perturbations of up to 16 ulps here: the device's A differs from the oracle's in the last bits - world-frame against body-frame
     # impulse tests - and a Dantzig early exit that a 1-ulp change of the STATE does not reach can still be decided by those bits)
-    n_unstable = _assert_all_worlds_match_or_reference_is_unstable("two cubes side by side", strict, world, NORTH_STAR_TOL, n_perturb=128, ulps=16)
+    n_unstable = _assert_all_worlds_match_or_reference_is_unstable("two cubes side by side", strict, world, NORTH_STAR_TOL, n_perturb=128, ulps=16, only=~loose)
     assert n_unstable < 0.02 * B
     cascade = (status & 0x2) == 0
     assert 0.05 < cascade.mean() < 0.95

@@ -93,7 +93,7 @@ def test_a_table_on_four_feet_has_sixteen_contacts_of_rank_six():
     e, _ = world_errors(dev, ref)
     for k in e:
         assert e[k][stage0].max() < TOL, (k, float(e[k][stage0].max()))
-    bad, by_closeness = assert_match_or_reference_unstable("table on 16 contacts", ow, s, a, g, dev, ref, TOL, ulps=16, closeness=1.0)
+    bad, by_closeness = assert_match_or_reference_unstable("table on 16 contacts", ow, s, a, g, dev, ref, TOL, ulps=16, closeness=1.0, max_by_closeness=int(0.02 * B))
     assert bad <= 0.10 * B and by_closeness <= 0.02 * B
 
 

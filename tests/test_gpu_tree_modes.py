@@ -127,3 +127,27 @@ def test_round3_features_in_the_fallback_modes(mode, monkeypatch):
     md = folding_arm(True, "box")
     s, a = ts._states(256, 1, 1.872, 2.14)
     ts._compare(f"folding arm {mode}", md, s, a, 2, 0.7)
+
+
+def test_the_fused_cascade_launch_equals_the_two_launch_cascade_bit_for_bit(monkeypatch):
+    """NBL_FUSED_CASCADE=1 (stages 1-3 and the final part of the LCP cascade in ONE launch, the two stage wavefronts of a world handing
+    their candidates over through LDS with a release / acquire arrival counter; opt-in: measured slower with four slices in flight) runs
+    the same device functions as the default k_contact_cascade_stages + k_contact_cascade_final: on the metric distribution, where a
+    third of the worlds go through it, every bit of the next state, the status words and both gradients must be equal."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    md, s, a = contact_inputs("atlas20", 1024, 13, joint_noise=0.02, vel_noise=0.01, action_noise=0.0)
+    g = np.random.default_rng(14).normal(0, 1, s.shape)
+    res = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("NBL_FUSED_CASCADE", fused)
+        world = na.World(md, device="cuda:0")
+        st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+        out = timestep(world, st, at)
+        status = world.last_status.cpu().numpy().astype(np.uint32)
+        out.backward(torch.tensor(g, device="cuda:0"))
+        res.append((out.detach().cpu().numpy(), status, st.grad.cpu().numpy(), at.grad.cpu().numpy()))
+    assert 0.2 < ((res[0][1] & 0x2) == 0).mean() < 0.8                          # the cascade is exercised
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)

@@ -50,3 +50,30 @@ def test_self_contact_gradient_with_a_dof_above_both_bodies(tip, q2):
     md0 = folding_arm(True, tip); md0.gravity = (0.0, 0.0, 0.0)
     w0 = OracleWorld(md0); w0.step(s, a); gs0, _ = w0.backprop(g)
     assert abs(gs0[0]) < 1e-9                                                           # without gravity: exactly nothing
+
+
+def test_a_child_on_a_compound_joint_is_adjacent_to_its_real_parent_not_to_a_virtual_link():
+    """BodyNodeCollisionFilter::areAdjacentBodies compares BodyNode::getParentBodyNode (CollisionFilter.cpp:150-154).  A universal / Euler /
+    planar joint is expanded here into a chain of 1-DOF joints through massless virtual links ('#v*'): with self-collision on and the
+    adjacent-body check off the pair (child on a universal joint, its real parent) must stay untested, exactly like the same child on a
+    revolute joint - in the description's filter, in the arrays handed to the device (box_node / box_node_parent) and in the oracle's
+    narrow phase (the virtual link was taken for the parent and the pair was tested)."""
+    import nimblephysics_amd as na
+    from oracle import OracleWorld
+    I = (0.002, 0.002, 0.002, 0, 0, 0)
+    for child_joint, kw in (("revolute", dict(axis=(0, 0, 1))), ("universal", dict(axes=[(0, 0, 1), (1, 0, 0)])), ("euler_xyz", {})):
+        for adjacent_check in (False, True):
+            opts = dict(self_collision=True, adjacent_body_check=adjacent_check)
+            bodies = [na.BodySpec("l0", -1, "revolute", "j0", axis=(0, 0, 1), mass=1.0, inertia=I, **opts),
+                      na.BodySpec("l1", 0, child_joint, "j1", T_pj=na.make_transform((0.1, 0, 0)), mass=0.8, inertia=I, **opts, **kw)]
+            cols = [na.BoxSpec(0, np.eye(4), (0.3, 0.1, 0.1), 0.8), na.BoxSpec(1, na.make_transform((0, 0.09, 0)), (0.3, 0.1, 0.1), 0.8)]   # 1 cm deep in one another
+            md = na.ModelDescription("pair", bodies, cols, gravity=(0, -9.81, 0), max_contacts=8)
+            tested = md.colliders_are_tested(md.boxes[0], md.boxes[1])
+            assert tested == adjacent_check, (child_joint, adjacent_check)
+            fl = md.flat()
+            adj = fl["box_node_parent"][1] == fl["box_node"][0] or fl["box_node_parent"][0] == fl["box_node"][1]
+            assert adj, (child_joint, fl["box_node"], fl["box_node_parent"])
+            ow = OracleWorld(md)
+            n = md.num_dofs
+            ow.step(np.zeros(2 * n), np.zeros(n))
+            assert bool(ow.last_status & 0x1) == adjacent_check, (child_joint, adjacent_check, hex(ow.last_status))

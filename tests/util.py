@@ -113,7 +113,7 @@ def folding_arm(self_collision=True, tip="sphere", adjacent=False):
 
 
 # ---- joint-limit rows (tests/test_oracle_joint_limits.py, tests/test_gpu_joint_limits.py) ----
-def limited_arm(enforce=True, ground=False, n_links=4):
+def limited_arm(enforce=True, ground=False, n_links=4, max_contacts=None):
     """A prismatic base (vertical slide) carrying a chain of revolute links with position limits [-0.5, 0.4]; every joint enforces its
     limits when `enforce`.  With `ground`: a ground box under it and a box collider on the base, which touches the ground for slide positions
     in (-0.03, 0] (contacts and limit rows in one LCP)."""
@@ -127,7 +127,8 @@ def limited_arm(enforce=True, ground=False, n_links=4):
     if ground:
         boxes = [na.BoxSpec(-1, na.make_transform((0, -0.55, 0)), (6.0, 1.0, 6.0), 1.0),
                  na.BoxSpec(0, np.eye(4), (0.2, 0.1, 0.2), 0.8)]
-    return na.ModelDescription("limited_arm", bodies, boxes, max_contacts=8)
+    # (with the ground: four corner contacts + up to five limit rows - more than 8 constraint slots: the 48-row build)
+    return na.ModelDescription("limited_arm", bodies, boxes, max_contacts=max_contacts or (16 if ground else 8))
 
 
 # ---- capsule colliders (tests/test_oracle_capsules.py, tests/test_gpu_capsules.py) ----
