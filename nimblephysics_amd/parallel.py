@@ -28,9 +28,14 @@ def allgather_sum(partial: torch.Tensor, group=None) -> torch.Tensor:
         return partial.clone()
     ws = dist.get_world_size(group)
     flat = partial.contiguous().view(-1)
-    buf = torch.empty(ws * flat.numel(), dtype=partial.dtype, device=partial.device)
-    dist.all_gather_into_tensor(buf, flat, group=group)   # concatenated form: valid for RCCL and gloo
-    return buf.view(ws, *partial.shape).sum(dim=0)
+    # (a gloo group - the CPU tests, two ranks sharing one GPU in tests/test_gpu_sharded_step.py: RCCL refuses two ranks on one device -
+    #  moves host memory: the O(parameters) partial takes the trip through the host there)
+    via_host = flat.is_cuda and dist.get_backend(group) == "gloo"
+    send = flat.cpu() if via_host else flat
+    buf = torch.empty(ws * send.numel(), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(buf, send, group=group)   # concatenated form: valid for RCCL and gloo
+    total = buf.view(ws, *partial.shape).sum(dim=0)         # every rank sums the partials in rank order: bit-identical results
+    return total.to(partial.device) if via_host else total
 
 
 def shared_parameter_grad(per_world_grad_soa: torch.Tensor, group=None) -> torch.Tensor:
