@@ -44,11 +44,11 @@ for gid in sorted(set(grp)):
         if grp[c] == gid:
             mask |= 7 << (3 * c)
     X = np.zeros(24); X0 = np.zeros(24); cls = np.zeros(24, np.int32); E = np.zeros(24)
-    ret = shim.shim_coop_stage0_masked(m, _p(np.ascontiguousarray(A)), _p(b), _p(mu), C.c_uint(mask), _p(X), _p(X0), _pi(cls), _p(E))
+    ret = shim.shim_coop_stage0_masked(m, _p(np.ascontiguousarray(A)), _p(b), _p(mu), C.c_uint64(mask), _p(X), _p(X0), _pi(cls), _p(E))
     print(f"group {gid} mask {mask:#x}: stage0 ok {ret & 1}")
     if not (ret & 1):
         Xc = np.zeros(24); Xs = np.zeros(24); cls2 = np.zeros(24, np.int32); cfm = C.c_double(0)
-        st = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A)), _p(b), _p(mu), _p(X0), C.c_uint(mask), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm),
+        st = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A)), _p(b), _p(mu), _p(X0), C.c_uint64(mask), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm),
                                            _p(Xs), _pi(cls2))
         print(f"   device cascade status {st:#x} cfm {cfm.value}  x {Xc[:m]}")
 print("oracle x", L["x"])
@@ -96,8 +96,8 @@ for scale in (1e-16, 1e-15, 1e-14, 1e-13):
         E_ = rng.normal(0, scale, (m, m)); E_ = (E_ + E_.T) / 2
         A24 = np.zeros((24, 24)); A24[:m, :m] = L["A"] * (1.0 + E_ / np.maximum(np.abs(L["A"]), 1e-300) * 0) + E_
         X = np.zeros(24); X0_ = np.zeros(24); cls = np.zeros(24, np.int32); E2 = np.zeros(24)
-        ret = shim.shim_coop_stage0_masked(m, _p(np.ascontiguousarray(A24)), _p(b), _p(mu8), C.c_uint((1 << m) - 1), _p(X), _p(X0_), _pi(cls), _p(E2))
+        ret = shim.shim_coop_stage0_masked(m, _p(np.ascontiguousarray(A24)), _p(b), _p(mu8), C.c_uint64((1 << m) - 1), _p(X), _p(X0_), _pi(cls), _p(E2))
         Xc = np.zeros(24); Xs = np.zeros(24); cls2 = np.zeros(24, np.int32); cfm = C.c_double(0)
-        stt = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A24)), _p(b), _p(mu8), _p(X0_), C.c_uint((1 << m) - 1), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _p(Xs), _pi(cls2))
+        stt = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A24)), _p(b), _p(mu8), _p(X0_), C.c_uint64((1 << m) - 1), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _p(Xs), _pi(cls2))
         cnt[(ret & 1, hex(stt))] += 1
     print(f"|dA| ~ {scale:g}: {dict(cnt)}")

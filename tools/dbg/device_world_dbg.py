@@ -74,10 +74,10 @@ for name, Ause in (("device A", Ad), ("oracle A", Ao)):
       mask = sum(7 << (3 * c) for c in range(nc) if grp[c] == gid)
       print("group", gid, "mask", hex(mask))
       X = np.zeros(24); X0 = np.zeros(24); cls = np.zeros(24, np.int32); E = np.zeros(24)
-      ret = shim.shim_coop_stage0_lim(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), C.c_uint(mask), C.c_uint(D["limMask"]), C.c_uint(D["negMask"]), _p(X), _p(X0), _pi(cls), _p(E))
+      ret = shim.shim_coop_stage0_lim(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), C.c_uint64(mask), C.c_uint64(D["limMask"]), C.c_uint64(D["negMask"]), _p(X), _p(X0), _pi(cls), _p(E))
       Xc = np.zeros(24); Xs = np.zeros(24); cls2 = np.zeros(24, np.int32); cfm = C.c_double(0)
       stg = np.zeros(3, np.int32)
-      stt = shim.shim_coop_cascade_lim(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), _p(X0), C.c_uint(mask), C.c_uint(D["limMask"]), C.c_uint(D["negMask"]), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _pi(stg))
+      stt = shim.shim_coop_cascade_lim(3 * nc, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), _p(X0), C.c_uint64(mask), C.c_uint64(D["limMask"]), C.c_uint64(D["negMask"]), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _pi(stg))
       print("stage flags", stg)
       print(name, ": sv", np.linalg.svd(Ause, compute_uv=False), "asym", np.abs(Ause - Ause.T).max())
       print(name, ": X0", X0[:3 * nc])

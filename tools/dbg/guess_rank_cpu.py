@@ -44,9 +44,9 @@ for seed in range(first, first + count):
         mu = np.ones(8); mu[:nc] = [L["hi"][3 * c + 1] for c in range(nc)]
         X = np.zeros(24); X0 = np.zeros(24); cls = np.zeros(24, np.int32); E = np.zeros(24)
         mask = (1 << m) - 1
-        shim.shim_coop_stage0_masked(m, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), C.c_uint(mask), _p(X), _p(X0), _pi(cls), _p(E))
+        shim.shim_coop_stage0_masked(m, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), C.c_uint64(mask), _p(X), _p(X0), _pi(cls), _p(E))
         Xc = np.zeros(24); Xs = np.zeros(24); cls2 = np.zeros(24, np.int32); cfm = C.c_double(0)
-        sd = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), _p(X0), C.c_uint(mask), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _p(Xs), _pi(cls2))
+        sd = shim.shim_coop_cascade_masked(m, _p(np.ascontiguousarray(A24)), _p(b24), _p(mu), _p(X0), C.c_uint64(mask), C.c_double(md.fallback_cfm), _p(Xc), C.byref(cfm), _p(Xs), _pi(cls2))
         xg = np.zeros(m); OL.nbo_lcp_guess(m, _p(np.ascontiguousarray(A)), _p(L["b"].copy()), _pi(fi.astype(np.int32)), _p(xg))
         gd = np.abs(X0[:m] - xg).max() > 1e-6 * max(np.abs(xg).max(), 1e-30)
         sv = np.linalg.svd(A, compute_uv=False); nz = sv[sv > 1e-13 * sv[0]]; cond = nz[0] / nz[-1]
