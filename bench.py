@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--no-single-stream", action="store_true", help="skip the secondary one-launch-per-kernel measurement")
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed region until this much time has been timed; the median repetition is reported")
     ap.add_argument("--max-reps", type=int, default=25)
+    ap.add_argument("--max-contacts", type=int, default=0, help="diagnostic: contact slots per world of the model (0 = the workload's own, 8); 16 runs the "
+                    "same worlds on the 48-row instantiation of the contact stage")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,6 +225,9 @@ def main():
     def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0, bounds=bounds, streams=streams):
         """W untimed + K timed fwd+bwd steps on a fresh synthetic batch of the workload at pose noise `noise`."""
         md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, noise)
+        if args.max_contacts > 0 and md.max_contacts:
+            md.max_contacts = args.max_contacts
+            wl_desc += f" [max_contacts = {args.max_contacts}: the {3 * max(8, args.max_contacts) if args.max_contacts <= 8 else 48}-row build]"
         worlds = [na.World(md, device=dev) for _ in bounds]
         world = worlds[0]
         k = world.k

@@ -284,7 +284,7 @@ def test_cascade_on_one_constrained_group_equals_the_cascade_of_that_group_alone
     R, NC = shim.R, shim.NC
     rng = np.random.default_rng(12)
     seen = set()
-    for trial in range(7):
+    for trial in range(7 if R == 24 else 2):
         parts = []
         for nc in (int(rng.integers(1, NC // 2 + 1)), int(rng.integers(1, NC // 2 + 1))):
             m = 3 * nc
