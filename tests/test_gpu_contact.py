@@ -277,7 +277,7 @@ def test_frictionless_contacts_fwd_bwd_vs_oracle(mus, max_unstable):
     degenerate = max_unstable >= 1.0
     unstable = _assert_all_worlds_match_or_reference_is_unstable(f"frictionless {mus}", errs, world, NORTH_STAR_TOL,
                                                                  n_perturb=256 if degenerate else 64, closeness=0.25 if degenerate else 0.1,
-                                                                 ulps=4 if degenerate else 1, max_by_closeness=B if degenerate else None)
+                                                                 ulps=4 if degenerate else 1, max_by_closeness=8 if degenerate else None)   # (measured: 2 of 512 need the closeness branch)
     assert unstable <= max_unstable * B
     assert np.median(errs["next"]) < 1e-10            # (per world and block: the lateral velocities of the cubes are a block of ~0.05)
 

@@ -9,14 +9,17 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
+# Worlds that pass the proof-of-instability only by being 10 x closer to one of the oracle's perturbed outcomes than those scatter (not
+# within tol of one): counted by tools/soak_parity.py and bounded here ("by_closeness is printed but never bounded")
+BY_CLOSENESS_MAX = 2
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
 def test_random_models_all_worlds_vs_oracle():
     import soak_parity
-    tot = soak_parity.run(1000, 80, 256, verbose=False)
+    tot = soak_parity.run(1000, 100, 256, verbose=False)
     print(tot)
-    assert tot["MISMATCH"] == 0, tot
+    assert tot["MISMATCH"] == 0 and tot["by_closeness"] <= BY_CLOSENESS_MAX, tot
     assert tot["contact"] > 0.1 * tot["worlds"] and tot["cascade"] > 0.05 * tot["worlds"], tot       # the soak does reach the cascade
     assert tot["gt1e-7"] <= 0.001 * tot["worlds"], tot
 
@@ -29,7 +32,7 @@ def test_random_larger_models_with_many_colliders_all_worlds_vs_oracle():
     import soak_parity
     tot = soak_parity.run(7000, 40, 256, verbose=False, big=True)
     print(tot)
-    assert tot["MISMATCH"] == 0 and tot["overflow"] == 0, tot
+    assert tot["MISMATCH"] == 0 and tot["overflow"] == 0 and tot["by_closeness"] <= BY_CLOSENESS_MAX, tot
     assert tot["contact"] > 0.2 * tot["worlds"], tot
 
 
@@ -40,7 +43,7 @@ def test_random_worlds_with_several_skeletons_all_worlds_vs_oracle():
     import soak_parity
     tot = soak_parity.run(9500, 40, 256, verbose=False, multi=True)
     print(tot)
-    assert tot["MISMATCH"] == 0, tot
+    assert tot["MISMATCH"] == 0 and tot["by_closeness"] <= BY_CLOSENESS_MAX, tot
     assert tot["contact"] > 0.2 * tot["worlds"] and tot["cascade"] > 0.1 * tot["worlds"], tot
 
 
@@ -50,7 +53,7 @@ def test_random_models_with_ball_joints_all_worlds_vs_oracle():
     import soak_parity
     tot = soak_parity.run(9000, 40, 256, verbose=False, balls=True)
     print(tot)
-    assert tot["MISMATCH"] == 0, tot
+    assert tot["MISMATCH"] == 0 and tot["by_closeness"] <= BY_CLOSENESS_MAX, tot
     assert tot["contact"] > 0.1 * tot["worlds"], tot
     assert tot["gt1e-7"] <= 0.002 * tot["worlds"], tot
 
@@ -62,7 +65,7 @@ def test_random_models_ten_metres_from_the_world_origin_all_worlds_vs_oracle():
     import soak_parity
     tot = soak_parity.run(11000, 30, 256, verbose=False, balls=True, far=True)
     print(tot)
-    assert tot["MISMATCH"] == 0, tot
+    assert tot["MISMATCH"] == 0 and tot["by_closeness"] <= BY_CLOSENESS_MAX, tot
     assert tot["contact"] > 0.1 * tot["worlds"], tot
     assert tot["gt1e-7"] <= 0.002 * tot["worlds"], tot
 

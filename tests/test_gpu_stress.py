@@ -58,7 +58,7 @@ def test_a_world_that_exhausts_the_duplicate_filters_memory_is_flagged():
     tot = soak_stress.run(mode, 160020, 1, 256, variant="big", slots=8)        # (asserts the overflow flags world by world)
     assert tot["MISMATCH"] == 0, tot
     md, s, a, g = soak_parity.make_case(160020, 256, True, False, False, False, slots=8)
-    md, s, a, g = soak_stress.mutator(mode)(160020, md, s, a, g)
+    md, s, a, g = soak_stress.mutator(mode, slots=8)(160020, md, s, a, g)
     world = na.World(md, device="cuda:0")
     timestep(world, torch.tensor(s, device="cuda:0"), torch.tensor(a, device="cuda:0"))
     status = world.last_status.cpu().numpy().astype(np.uint32)

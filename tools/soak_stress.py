@@ -36,7 +36,7 @@ MODES = ("dt", "tinydt", "fast", "torque", "mass", "nograv", "geom", "mu", "subs
 MIX_ORDER = ("capsule", "geom", "mass", "mu", "selfcol", "limits", "subset", "dt", "fast", "torque", "nograv")   # (limits rebuilds the description: before subset)
 
 
-def mutator(mode):
+def mutator(mode, slots=None):
     if mode == "mix" or "+" in mode:
         def chain(seed, md, s, a, g):
             if mode == "mix":
@@ -45,7 +45,7 @@ def mutator(mode):
             else:
                 parts = mode.split("+")
             for k, m in enumerate(parts):
-                md, s, a, g = mutator(m)(seed + 1000003 * k, md, s, a, g)
+                md, s, a, g = mutator(m, slots)(seed + 1000003 * k, md, s, a, g)
             return md, s, a, g
         return chain
     assert mode in MODES, mode
@@ -123,7 +123,8 @@ def mutator(mode):
                 elif mode == "limits" and md.joint_ndof(i) == 3 and b.joint_type == "ball" and rng.random() < 0.35:
                     # limits on the exponential coordinates of a ball joint (JointLimitConstraint works on any joint's coordinates)
                     b.pos_lo, b.pos_hi = (-0.3, -0.25, -0.35), (0.4, 0.3, 0.25); b.limit_enforced = True
-            md = type(md)(md.name, md.bodies, md.boxes, gravity=md.gravity, dt=md.dt, max_contacts=md.max_contacts)
+            # (enforced limits share the constraint slots with the contacts: 16 slots - the 48-row build - so that no world is truncated)
+            md = type(md)(md.name, md.bodies, md.boxes, gravity=md.gravity, dt=md.dt, max_contacts=(slots or 16) if mode == "limits" else md.max_contacts)
             fl = md.flat(); s = s.copy(); a = a.copy()
             for d in range(n):
                 if np.isfinite(fl["pos_lo"][d]):
@@ -143,7 +144,7 @@ def run(mode, first=0, count=20, B=256, verbose=False, variant="balls", slots=No
     """variant: the model family of tools/soak_parity.py the mutation is applied to (balls, big, multi)."""
     import soak_parity
     return soak_parity.run(first, count, B, verbose=verbose, balls=variant == "balls", big=variant == "big", multi=variant == "multi",
-                           mutate=mutator(mode), slots=slots)
+                           mutate=mutator(mode, slots), slots=slots)
 
 
 if __name__ == "__main__":
