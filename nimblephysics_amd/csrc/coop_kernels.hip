@@ -937,30 +937,44 @@ __global__ __launch_bounds__(64) void k_bwd_bounce(DevModel mdl, const DevBody* 
 // to the world frame once; then the contact wrench F is the same 6-vector at every body, impulses add up the chain and
 // velocity changes pass down it without transforms, and an entry of A is F_col . (dV_A - dV_B).  Only the free-joint root
 // is solved in its body frame like in abaSweeps.
-//   lds doubles: Fw[24][6]  Sw[nb][6]  AISw[nb][6]  Vw[nb][6]  acc[nb][6][24]
+//   lds doubles: Fw[rows][6] x 2  Sw[nb][6]  AISw[nb][6]  Vw[nb][6]  acc[nb][6][rows]  psi[nb]  free[nFree][54]  contact bodies
+// WPW = 2 (24-row build, models of at most 32 device bodies): TWO worlds per wavefront - lanes 0..31 work for the first, lanes 32..63 for
+// the second (lane within the half = body in the lane = body phases, LCP row in the others).  With 24 rows per world a wavefront of one world
+// runs on 23 of its 64 lanes (profiles/r03 fp64_flops.json: 22.8 active lanes); the serial loops below go over the BODIES of the model,
+// which the two worlds share, so the second world rides along in the idle lanes: half the wavefronts for the same chain length.  The
+// model's topology (parent, joint type, collider -> body, ancestor masks) is read from the lanes of the first half by both.
+template <int WPW>
 __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(DevModel mdl, const DevBody* __restrict__ bodies,
                                                           const DevContactModel* __restrict__ cm, int64_t B,
                                                           double* __restrict__ saved, SavedLayout lay,
                                                           const double* __restrict__ ws) {
+  static_assert(WPW == 1 || (WPW == 2 && MAX_ROWS <= 32), "two worlds per wavefront: 32 lanes each");
   extern __shared__ __attribute__((aligned(16))) double ldsRows[];
   const int nb = mdl.nb;
-  double* Fs = ldsRows;                            // the row's wrench about the frame origin of body A's tree ...
-  double* FsB = Fs + 6 * MAX_ROWS;                 // ... and of body B's tree
-  double* Sw = FsB + 6 * MAX_ROWS;
-  double* AISw = Sw + 6 * nb;
-  double* Vw = AISw + 6 * nb;
-  double* acc = Vw + 6 * nb;
+  constexpr int RW = WPW * MAX_ROWS;                // LCP rows of the wavefront's worlds side by side
+  const DevWave w;
+  const int ln = w.lane();
+  const int h = WPW == 2 ? (ln >> 5) : 0;           // which of the wavefront's worlds this lane works for
+  const int l = WPW == 2 ? (ln & 31) : ln;          // lane within that world
+  const int hl = WPW == 2 ? (h << 5) : 0;           // first lane of the half
+  double* Fs = ldsRows;                             // the row's wrench about the frame origin of body A's tree ...
+  double* FsB = Fs + 6 * RW;                        // ... and of body B's tree
+  double* Sw = FsB + 6 * RW + 6 * nb * h;           // (per world from here on)
+  double* AISw = FsB + 6 * RW + 6 * nb * WPW + 6 * nb * h;
+  double* Vw = FsB + 6 * RW + 12 * nb * WPW + 6 * nb * h;
+  double* acc = FsB + 6 * RW + 18 * nb * WPW;       // [body][6][RW]
   // what the serial body loops below read per body, staged once (a global load inside those loops is waited for per body):
   // psi of the 1-DOF joints; per free joint its LDL^T (21), articulated inertia (21) and world transform (12); the two
   // bodies of every contact
-  double* psiL = acc + 6 * nb * MAX_ROWS;
-  double* freeL = psiL + nb;                       // [nFree][54]
-  int* cbody = reinterpret_cast<int*>(freeL + 54 * mdl.nFree);   // [2][MAX_CONTACTS]
-  const DevWave w;
-  const int ln = w.lane();
+  double* psiL = acc + 6 * nb * RW + nb * h;
+  double* freeAll = acc + 6 * nb * RW + nb * WPW;   // [WPW][nFree][54]
+  double* freeL = freeAll + 54 * mdl.nFree * h;
+  int* cbody = reinterpret_cast<int*>(freeAll + 54 * mdl.nFree * WPW) + 2 * MAX_CONTACTS * h;   // [WPW][2][MAX_CONTACTS]
   NBL_PHASE(32);
-  const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
-  if (b >= mdl.b1) return;
+  const int64_t bw0 = mdl.b0 + (int64_t)WPW * coopWorld(blockIdx.x, gridDim.x);
+  if (bw0 >= mdl.b1) return;
+  const bool valid = bw0 + h < mdl.b1;              // (an odd number of worlds: the last wavefront's second half idles)
+  const int64_t b = valid ? bw0 + h : bw0;
   Ctx c = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, b, saved, &lay);
   double* dn = denseOf(saved, lay, B, b);
   auto ld6 = [](const double* base) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = base[e]; return fromArr(a); };
@@ -968,23 +982,24 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   // ---- every global load of the prologue in ONE batch: none depends on another (lanes beyond nb / beyond the rows in use
   //      read body 0 / stale contact slots - valid memory, unused values), so their latency is paid once ----
   const double ncD = svAt(saved, lay.nc, B, b);
-  const int bl = ln < nb ? ln : 0;
+  const int bl = l < nb ? l : 0;
   const DevBody& bdL = bodies[bl];
-  // topology of body `ln` in the lane's registers: the serial body loops below fetch it with v_readlane (no memory access)
-  const int myParent = ln < nb ? bdL.parent : -1, myJtype = ln < nb ? bdL.jtype : 0;
-  const int myDofOff = ln < nb ? bdL.dofOff : 0, myFreeIdx = ln < nb ? bdL.freeIdx : -1;
+  // topology of body `l` in the lane's registers: the serial body loops below fetch it with v_readlane (no memory access)
+  const int myParent = l < nb ? bdL.parent : -1, myJtype = l < nb ? bdL.jtype : 0;
+  const int myDofOff = l < nb ? bdL.dofOff : 0, myFreeIdx = l < nb ? bdL.freeIdx : -1;
   // The "world frame" of the spatial quantities has its origin at the root of each body's tree instead of the world's (one pure translation
   // per tree: within a tree one wrench still serves every body; a row between two trees has one wrench per side).  Moments about a far
   // origin would blur A's singular structure with the square of the distance and flip the rank decisions of the solver.
-  const int myRoot = ln < nb ? bdL.root : 0;
+  const int myRoot = l < nb ? bdL.root : 0;
   const V3 myOrigin = ldTAt(c, myRoot, WS_TW).p;
   T12 TWl = ldTAt(c, bl, WS_TW);
   TWl.p = TWl.p - myOrigin;
   const V6 vtwL = ldV6(c, bl, WS_VTW), aisL = ldV6(c, bl, WS_AIS), SL = cV6(bdL.S);
   const double psiMine = wsAt(c, bl, WS_PSI);
-  const int myBoxBody = cm->boxes[ln < MAX_BOXES ? ln : 0].body;      // collider -> body and body -> ancestor mask tables,
+  const int myBoxBody = cm->boxes[l < MAX_BOXES ? l : 0].body;       // collider -> body and body -> ancestor mask tables,
   const uint64_t myAnc = cm->ancestors[bl];                           // looked up with ds_bpermute below
-  const int row = ln < MAX_ROWS ? ln : 0;
+  const int row = l < MAX_ROWS ? l : 0;
+  const int rw = h * MAX_ROWS + row;                                  // this lane's row among the wavefront's rows
   const int ci = row / 3, kk = row % 3;
   const int r0 = lay.contacts + ci * CR_SIZE;
   const V3 p = mk3(svAt(saved, r0 + CR_POINT, B, b), svAt(saved, r0 + CR_POINT + 1, B, b), svAt(saved, r0 + CR_POINT + 2, B, b));
@@ -992,33 +1007,40 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   const int bxA = (int)svAt(saved, r0 + CR_BOXA, B, b), bxB = (int)svAt(saved, r0 + CR_BOXB, B, b);
   const bool isLim = (int)svAt(saved, r0 + CR_TYPE, B, b) == CT_LIMIT;   // a joint-limit row (model_dev.hpp): unit impulse on a DOF
   const double limSigma = svAt(saved, r0 + CR_EA_FIXED + 1, B, b);
-  const int nC = (int)ncD;
+  const int nC = valid ? (int)ncD : 0;
   const int m = 3 * nC;
-  if (m == 0) return;
+  if (WPW == 1 ? m == 0 : w.ballot(m > 0) == 0ull) return;
   {
     uint64_t fm = w.ballot(myFreeIdx >= 0);          // the (few) free-joint bodies
+    if (WPW == 2) fm &= 0xffffffffull;               // (the second half holds the same topology)
     while (fm) {
       const int fb = __builtin_ctzll(fm);
       fm &= fm - 1;
-      if (ln < 54) {
-        const int slot = ln < 21 ? WS_PSI + ln : (ln < 42 ? WS_AI + (ln - 21) : WS_TW + (ln - 42));
-        // a free joint is the root of its tree: in the frame of its own origin its world transform has no translation
-        freeL[54 * w.bcastI(myFreeIdx, fb) + ln] = ln >= 51 ? 0.0 : wsAt(c, fb, slot);
+      const int fIdx = w.bcastI(myFreeIdx, fb);
+#pragma unroll
+      for (int hh = 0; hh < WPW; hh++) {             // lanes 0..53 copy the block of world hh
+        if (ln < 54) {
+          const int64_t bh = (bw0 + hh < mdl.b1) ? bw0 + hh : bw0;
+          const Ctx ch = makeCtx(mdl, bodies, nullptr, const_cast<double*>(ws), B, bh, saved, &lay);
+          const int slot = ln < 21 ? WS_PSI + ln : (ln < 42 ? WS_AI + (ln - 21) : WS_TW + (ln - 42));
+          // a free joint is the root of its tree: in the frame of its own origin its world transform has no translation
+          freeAll[54 * (mdl.nFree * hh + fIdx) + ln] = ln >= 51 ? 0.0 : wsAt(ch, fb, slot);
+        }
       }
     }
   }
   // ---- lane = body: world-frame joint axis, AI*S and twist at v_pre ----
-  if (ln < nb) {
-    st6(Vw + 6 * ln, AdT(TWl, vtwL));
+  if (l < nb) {
+    st6(Vw + 6 * l, AdT(TWl, vtwL));
     if (myJtype != JT_FREE) {
-      st6(Sw + 6 * ln, AdT(TWl, SL));
-      st6(AISw + 6 * ln, dAdInvT(TWl, aisL));
-      psiL[ln] = psiMine;
+      st6(Sw + 6 * l, AdT(TWl, SL));
+      st6(AISw + 6 * l, dAdInvT(TWl, aisL));
+      psiL[l] = psiMine;
     }
   }
   NBL_PHASE(33);
-  const bool on = ln < m;
-  auto accAt = [&](int body, int e) -> double& { return acc[(body * 6 + e) * MAX_ROWS + row]; };
+  const bool on = l < m;
+  auto accAt = [&](int body, int e) -> double& { return acc[(body * 6 + e) * RW + rw]; };
   auto ldAcc = [&](int body) -> V6 { double a[6]; for (int e = 0; e < 6; e++) a[e] = accAt(body, e); return fromArr(a); };
   auto stAcc = [&](int body, V6 x) { double a[6]; toArr(x, a); for (int e = 0; e < 6; e++) accAt(body, e) = a[e]; };
   // ---- this row's wrench and the two bodies it acts on ----
@@ -1035,8 +1057,10 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   const int bAc = w.shflI(myBoxBody, bxA), bBc = w.shflI(myBoxBody, bxB);
   const int bA = isLim ? bxA - CR_BODY_CODE - 1 : bAc, bB = isLim ? bxB - CR_BODY_CODE - 1 : bBc;
   // wrench of a unit impulse along dir at p (on A; minus it on B), about the origin of A's tree and about the origin of B's
-  const V3 oA = mk3(w.shfl(myOrigin.x, bA < 0 ? 0 : bA), w.shfl(myOrigin.y, bA < 0 ? 0 : bA), w.shfl(myOrigin.z, bA < 0 ? 0 : bA));
-  const V3 oB = mk3(w.shfl(myOrigin.x, bB < 0 ? 0 : bB), w.shfl(myOrigin.y, bB < 0 ? 0 : bB), w.shfl(myOrigin.z, bB < 0 ? 0 : bB));
+  // (the origins are per WORLD: read from the body lanes of this lane's own half)
+  const int lA = hl + (bA < 0 ? 0 : bA), lB = hl + (bB < 0 ? 0 : bB);
+  const V3 oA = mk3(w.shfl(myOrigin.x, lA), w.shfl(myOrigin.y, lA), w.shfl(myOrigin.z, lA));
+  const V3 oB = mk3(w.shfl(myOrigin.x, lB), w.shfl(myOrigin.y, lB), w.shfl(myOrigin.z, lB));
   V6 F = mk6(cross(p - oA, dir), dir), FB = mk6(cross(p - oB, dir), dir);
   if (cm->nLimitDofs > 0) {
     // joint-limit row: the generalized unit impulse sigma e_d is the wrench pair (+F on the joint's child body, -F on its parent) with
@@ -1056,7 +1080,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
   const uint64_t mA = bA >= 0 ? ((uint64_t)(uint32_t)ancHiA << 32) | (uint32_t)ancLoA : 0ull;
   const uint64_t mB = bB >= 0 ? ((uint64_t)(uint32_t)ancHiB << 32) | (uint32_t)ancLoB : 0ull;
   if (on) {
-    st6(Fs + 6 * row, F); st6(FsB + 6 * row, FB);
+    st6(Fs + 6 * rw, F); st6(FsB + 6 * rw, FB);
     if (kk == 0) { cbody[ci] = bA; cbody[MAX_CONTACTS + ci] = bB; }
   }
   w.sync();
@@ -1092,26 +1116,33 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
       svAt(saved, lay.rest + ci, B, b) = coeff;
     }
     svAt(saved, lay.b + row, B, b) = rel;
+  }
+  // (the serial loops over the model's bodies run for every lane of the wavefront: topology by v_readlane from the first half's lanes;
+  //  rows that are off only keep their lanes in step)
+  {
     // constraint forces in joint space (DCC::getConstraintForces): A_c[i] = sigma_i s_i . F
     for (int i = 0; i < nb; i++) {
       const int jt = w.bcastI(myJtype, i), dofOff = w.bcastI(myDofOff, i);
-      const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
-      const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
-      const V6 Fi = pb ? FB : F;                       // the wrench about the origin of body i's tree (pa && pb: mult = 0)
-      if (jt != JT_FREE) dn[lay.aall + dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), Fi);
-      else {
-        double v6[6];
-        toArr(dAdT(cT(bodies[i].Tcj), dAdT(cT(freeL + 54 * w.bcastI(myFreeIdx, i) + 42), Fi)), v6);
-        for (int e = 0; e < 6; e++) dn[lay.aall + (dofOff + e) * MAX_ROWS + row] = mult * v6[e];
+      const int fIdx = w.bcastI(myFreeIdx, i);
+      if (on) {
+        const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
+        const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
+        const V6 Fi = pb ? FB : F;                       // the wrench about the origin of body i's tree (pa && pb: mult = 0)
+        if (jt != JT_FREE) dn[lay.aall + dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), Fi);
+        else {
+          double v6[6];
+          toArr(dAdT(cT(bodies[i].Tcj), dAdT(cT(freeL + 54 * fIdx + 42), Fi)), v6);
+          for (int e = 0; e < 6; e++) dn[lay.aall + (dofOff + e) * MAX_ROWS + row] = mult * v6[e];
+        }
+        for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
       }
-      for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
     }
     NBL_PHASE(35);
     // ---- unit-impulse test of this row.  leaf -> root: bias impulses along the two ancestor chains (world wrenches) ----
-    const uint64_t chain = mA | mB;
+    const uint64_t chain = on ? (mA | mB) : 0ull;
     for (int i = nb - 1; i >= 0; i--) {
-      if (!((chain >> i) & 1ull)) continue;
       const int jt = w.bcastI(myJtype, i), par = w.bcastI(myParent, i);
+      if (!((chain >> i) & 1ull)) continue;
       V6 Bi = ldAcc(i);
       if (i == bA) Bi = Bi - F;
       if (i == bB) Bi = Bi + FB;
@@ -1125,6 +1156,8 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
     // root -> leaf: velocity changes of every body (world twists), joint-space response
     for (int i = 0; i < nb; i++) {
       const int jt = w.bcastI(myJtype, i), par = w.bcastI(myParent, i), dofOff = w.bcastI(myDofOff, i);
+      const int fIdx = w.bcastI(myFreeIdx, i);
+      if (!on) continue;
       const V6 X = par >= 0 ? ldAcc(par) : zero6();
       const V6 Bi = ((chain >> i) & 1ull) ? ldAcc(i) : zero6();
       if (jt != JT_FREE) {
@@ -1134,7 +1167,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
         dn[lay.massed + dofOff * MAX_ROWS + row] = dq;
       } else {
         // the free-joint root in its body frame
-        const double* fl = freeL + 54 * w.bcastI(myFreeIdx, i);
+        const double* fl = freeL + 54 * fIdx;
         const T12 Tcj = cT(bodies[i].Tcj), TW = cT(fl + 42);
         LDL6 f;
         for (int e = 0; e < 15; e++) f.l[e] = fl[e];
@@ -1153,14 +1186,16 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_ROWS) void k_contact_rows_coop(
     }
     NBL_PHASE(37);
     // row of A: relative-velocity response at every row of the contacts c2 >= ci, mirrored into the earlier rows
-    for (int c2 = ci; c2 < nC; c2++) {
-      const int b2A = cbody[c2], b2B = cbody[MAX_CONTACTS + c2];
-      const V6 dVA = b2A >= 0 ? ldAcc(b2A) : zero6(), dVB = b2B >= 0 ? ldAcc(b2B) : zero6();
-      for (int k2 = 0; k2 < 3; k2++) {
-        const int col = 3 * c2 + k2;
-        const double val = dot(ld6(Fs + 6 * col), dVA) - dot(ld6(FsB + 6 * col), dVB);
-        dn[lay.A + row * MAX_ROWS + col] = val;
-        if (c2 > ci) dn[lay.A + col * MAX_ROWS + row] = val;
+    if (on) {
+      for (int c2 = ci; c2 < nC; c2++) {
+        const int b2A = cbody[c2], b2B = cbody[MAX_CONTACTS + c2];
+        const V6 dVA = b2A >= 0 ? ldAcc(b2A) : zero6(), dVB = b2B >= 0 ? ldAcc(b2B) : zero6();
+        for (int k2 = 0; k2 < 3; k2++) {
+          const int col = 3 * c2 + k2;
+          const double val = dot(ld6(Fs + 6 * (h * MAX_ROWS + col)), dVA) - dot(ld6(FsB + 6 * (h * MAX_ROWS + col)), dVB);
+          dn[lay.A + row * MAX_ROWS + col] = val;
+          if (c2 > ci) dn[lay.A + col * MAX_ROWS + row] = val;
+        }
       }
     }
     NBL_PHASE(38);

@@ -81,6 +81,7 @@ struct nbl_model {
                                      // the other slices' tree kernels wait for the CUs (k_step_forward_coop 70 -> 111 us).  Off by default.
   bool fusedDetect = true;           // NBL_FUSED_DETECT=0: the narrow phase as a launch of its own after the forward tree kernel
   bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
+  int rowsPack = 1;                  // worlds per wavefront of k_contact_rows_coop (2: the 24-row build, <= 32 device bodies; NBL_ROWS_PACK=1 forces 1)
   int nPairs = 0;                    // candidate collider pairs of the model
   bool multiGroup = false;           // colliders on more than one skeleton: a world can hold several constrained groups
   bool coopFinal = true;             // the backward sweeps too, in the world frame (NBL_COOP_FINAL=0: one world per lane, fed by k_tree_to_lanes)
@@ -536,6 +537,11 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e14 = getenv("NBL_FUSED_CASCADE")) m->fusedCascade = atoi(e14) != 0;
     if (const char* e15 = getenv("NBL_FUSED_DETECT")) m->fusedDetect = atoi(e15) != 0;
     m->nPairs = hc.nPairs;
+    {
+      const size_t oneWorld = ((size_t)d->n_bodies * 6 * MAX_ROWS + 12 * MAX_ROWS + 19 * (size_t)d->n_bodies + 54 * (size_t)nFree + MAX_CONTACTS) * sizeof(double);
+      m->rowsPack = (MAX_ROWS <= 32 && d->n_bodies <= 32 && 2 * oneWorld <= 160u * 1024u) ? 2 : 1;
+      if (const char* e16 = getenv("NBL_ROWS_PACK")) m->rowsPack = std::max(1, std::min(m->rowsPack, atoi(e16)));
+    }
     // measured (MI355X, B = 4096, world-frame sweeps): 5.5 vs 3.8 M/s with colliders, 16.4 vs 11.0 M/s without
     m->coopTree = coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
     if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
@@ -580,7 +586,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   // (k_contact_detect: 160 kB less its static arrays - the remembered points and the clip polygons)
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                              std::min(104 * 1024, 160 * 1024 - (SEEN_POINTS * 3 * 64 + 48 * 64) * (int)sizeof(double)));
-  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if constexpr (MAX_ROWS <= 32)
+    if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_step_forward_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -699,10 +707,19 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
                                            failCountAll + si, ppw));
       }
       {
-        const size_t rowsLds = ((size_t)m->nb * 6 * MAX_ROWS + 12 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
+        // worlds per wavefront of the row kernel: two (lanes 0..31 | 32..63) in the 24-row build when the model's bodies fit a half
+        const int wpw = m->rowsPack;
+        const size_t rowsLds = (size_t)wpw * ((size_t)m->nb * 6 * MAX_ROWS + 12 * MAX_ROWS + 19 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + MAX_CONTACTS) *
                                sizeof(double);   // acc, Fw, Sw/AISw/Vw/psi, free-joint blocks, contact bodies
-        TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop, dim3((unsigned)cnt), dim3(64), rowsLds, s, mdl, m->dBodies, m->dContact, B,
-                                              (double*)saved, m->lay, (const double*)workspace));
+        const dim3 rowsGrid((unsigned)((cnt + wpw - 1) / wpw));
+        if constexpr (MAX_ROWS <= 32) {
+          if (wpw == 2)
+            TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop<2>, rowsGrid, dim3(64), rowsLds, s, mdl, m->dBodies, m->dContact, B,
+                                                  (double*)saved, m->lay, (const double*)workspace));
+        }
+        if (wpw == 1)
+          TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_coop<1>, rowsGrid, dim3(64), rowsLds, s, mdl, m->dBodies, m->dContact, B,
+                                                (double*)saved, m->lay, (const double*)workspace));
       }
       int32_t* failList = failListAll + b0;          // the slice's own compacted list and counter
       uint32_t* failCount = failCountAll + si;   // zeroed by k_contact_detect
