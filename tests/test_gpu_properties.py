@@ -42,6 +42,11 @@ def test_determinism_permutation_equivariance_and_batch_independence(ground):
     rs = _fwd_bwd(md, s[sub], a[sub], g[sub])
     for x, y in zip(r1, rs):
         assert np.array_equal(x[sub], y)                                 # same world, any batch size, same bits
+    for odd in (1, 3, 63):                                               # odd batches: the last wavefront of the row kernel (two worlds per
+        sub = np.sort(np.random.default_rng(5 + odd).choice(B, odd, replace=False))   # wavefront) works with an idle second half
+        rs = _fwd_bwd(md, s[sub], a[sub], g[sub])
+        for x, y in zip(r1, rs):
+            assert np.array_equal(x[sub], y)
 
 
 def test_backward_is_linear_in_the_cotangent():
