@@ -35,8 +35,30 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
 DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodies, const DevContactModel* __restrict__ cm, int64_t B,
                            double* __restrict__ saved, const SavedLayout& lay, uint32_t* __restrict__ status, double* __restrict__ ws,
                            int doTwists, uint32_t* __restrict__ failCount, int ppw, const double* __restrict__ qFk, int bid, int wl,
-                           double* keptP, double* clipBuf, double* stage) {
+                           double* keptP, double* clipBuf, double* stage, double* fkT = nullptr) {
   const int tid = (int)threadIdx.x;
+  // ---- qFk with fkT (the narrow phase next to the forward tree kernel): the joint transforms T_parent->child of every body on an ancestor
+  //      chain of a collider, for the wl worlds of the workgroup, by ALL its threads - (world, body) items side by side instead of one lane
+  //      per collider pair walking its 7-joint chain alone (an exponential map with its sine and cosine per joint: 55 k of the 140 k cycles
+  //      of these workgroups).  The chains are then products of LDS-resident transforms, in the same order: identical arithmetic. ----
+  uint64_t fkNeed = 0ull;
+  if (qFk && fkT) {
+    for (int i = 0; i < cm->nBoxes; i++) { const int bdy = cm->boxes[i].body; if (bdy >= 0) fkNeed |= cm->ancestors[bdy]; }
+    const int nNeed = __builtin_popcountll(fkNeed);
+    for (int item = tid; item < wl * nNeed; item += (int)blockDim.x) {
+      const int wI = item / nNeed, k = item - wI * nNeed;
+      uint64_t mk = fkNeed;
+      for (int j = 0; j < k; j++) mk &= mk - 1;
+      const int body = __builtin_ctzll(mk);
+      const int64_t bw = mdl.b0 + (int64_t)bid * wl + wI;
+      const T12 T = jointRelTransform(bodies[body], qFk, B, bw < mdl.b1 ? bw : mdl.b1 - 1);
+      double* dst = fkT + (size_t)item * 12;
+#pragma unroll
+      for (int e = 0; e < 9; e++) dst[e] = T.R.m[e];
+      dst[9] = T.p.x; dst[10] = T.p.y; dst[11] = T.p.z;
+    }
+    __syncthreads();
+  }
   // the counter of the unresolved-worlds list of this slice starts at zero for the solve kernel that follows on the stream
   // (a separate hipMemsetAsync node cost ~6 us of every forward step)
   if (failCount && bid == 0 && tid == 0) *failCount = 0u;
@@ -112,6 +134,26 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   // transforms down its ancestor chain (ancestors are numbered before their descendants)
   auto worldT = [&](int body) -> T12 {
     if (!qFk) return ldTAt(c, body, WS_TW);
+    if (fkT) {
+      const int nNeed = __builtin_popcountll(fkNeed);
+      const double* mine = fkT + (size_t)(ltid / ppw) * nNeed * 12;
+      auto rel = [&](int i) -> T12 {
+        const double* t = mine + 12 * __builtin_popcountll(fkNeed & ((1ull << i) - 1ull));
+        T12 T;
+#pragma unroll
+        for (int e = 0; e < 9; e++) T.R.m[e] = t[e];
+        T.p = mk3(t[9], t[10], t[11]);
+        return T;
+      };
+      uint64_t chain = cm->ancestors[body];
+      T12 TW = rel(__builtin_ctzll(chain));
+      chain &= chain - 1;
+      while (chain) {
+        TW = mulT(TW, rel(__builtin_ctzll(chain)));
+        chain &= chain - 1;
+      }
+      return TW;
+    }
     uint64_t chain = cm->ancestors[body];
     T12 TW = jointRelTransform(bodies[__builtin_ctzll(chain)], qFk, B, bs);
     chain &= chain - 1;

@@ -400,7 +400,8 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
       for (int i = (int)threadIdx.x; i < cnt; i += (int)blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    contactDetectBody(mdl, lb, cm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage);
+    double* fkT = reinterpret_cast<double*>(lb + mdl.nb);      // [wl][bodies on the collider chains][12] joint transforms (contactDetectBody)
+    contactDetectBody(mdl, lb, cm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage, fkT);
     return;
   }
   stepForwardCoopBody(mdl, bodies, dofs, B, state, action, next, saved, status, lay, 1, ldsTree, blockIdx.x - (uint32_t)nDetect,

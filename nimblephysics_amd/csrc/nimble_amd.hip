@@ -81,6 +81,7 @@ struct nbl_model {
                                      // the other slices' tree kernels wait for the CUs (k_step_forward_coop 70 -> 111 us).  Off by default.
   bool fusedDetect = true;           // NBL_FUSED_DETECT=0: the narrow phase as a launch of its own after the forward tree kernel
   bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
+  int fkBodies = 0;                  // bodies on the ancestor chains of the colliders (forward kinematics of the fused narrow phase)
   int rowsPack = 1;                  // worlds per wavefront of k_contact_rows_coop (2: the 24-row build, <= 32 device bodies; NBL_ROWS_PACK=1 forces 1)
   int nPairs = 0;                    // candidate collider pairs of the model
   bool multiGroup = false;           // colliders on more than one skeleton: a world can hold several constrained groups
@@ -537,6 +538,11 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e14 = getenv("NBL_FUSED_CASCADE")) m->fusedCascade = atoi(e14) != 0;
     if (const char* e15 = getenv("NBL_FUSED_DETECT")) m->fusedDetect = atoi(e15) != 0;
     m->nPairs = hc.nPairs;
+    if (hasContact) {
+      uint64_t need = 0ull;
+      for (int i = 0; i < hc.nBoxes; i++) if (hc.boxes[i].body >= 0) need |= hc.ancestors[hc.boxes[i].body];
+      m->fkBodies = __builtin_popcountll(need);
+    }
     {
       const size_t oneWorld = ((size_t)d->n_bodies * 6 * MAX_ROWS + 12 * MAX_ROWS + 19 * (size_t)d->n_bodies + 54 * (size_t)nFree + MAX_CONTACTS) * sizeof(double);
       m->rowsPack = (MAX_ROWS <= 32 && d->n_bodies <= 32 && 2 * oneWorld <= 160u * 1024u) ? 2 : 1;
@@ -683,7 +689,8 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     const int wlD = std::min(tl, 64 / ppwD);                       // worlds per narrow-phase workgroup
     const size_t detectLds = ((size_t)SEEN_POINTS * 3 * 64 + 48 * 64) * sizeof(double) +
                              (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0) +
-                             (size_t)m->nb * sizeof(DevBody) + 32;   // + the body constants of the narrow phase's own forward kinematics
+                             (size_t)m->nb * sizeof(DevBody) + 32 +   // + the body constants of the narrow phase's own forward kinematics
+                             (size_t)wlD * m->fkBodies * 12 * sizeof(double);   // + the joint transforms of the bodies on the collider chains
     const bool fusedDetect = m->hasContact && m->coopTree && saved && m->fusedDetect && std::max(treeLds, detectLds) <= 160u * 1024u;
     if (fusedDetect) {
       const int nDetect = (int)((cnt + wlD - 1) / wlD);
