@@ -75,6 +75,7 @@ DEV int intersectRectQuad(double h0, double h1, const double* p, LaneBuf bufA, L
 // handed over one at a time so that they stay in registers (an out[8] array of 26-double records lived in scratch memory).
 template <class Emit>
 DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, LaneBuf clip, Emit emit) {
+  NBL_PHASE_FIRST(61);
   const double fudge = 1.05;
   const M3& R1 = T1.R;
   const M3& R2 = T2.R;
@@ -117,6 +118,7 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
       }
     }
   }
+  NBL_PHASE_FIRST(62);
   if (!code) return 0;
   if (s > 0.0) return 0;
   V3 normal;
@@ -190,7 +192,9 @@ DEV int boxBox(const T12& T1, V3 A, const T12& T2, V3 Bh, double clippingDepth, 
   }
   const double rect0 = Sa[code1], rect1 = Sa[code2];
   const LaneBuf ret = clip.at(32);   // clip: 48 doubles per lane (two polygon buffers + the result)
+  NBL_PHASE_FIRST(39);
   int n = intersectRectQuad(rect0, rect1, quad, clip, clip.at(16), ret);
+  NBL_PHASE_FIRST(63);
   if (n < 1) return 0;
   double det1 = 1.0 / (m11 * m22 - m12 * m21);
   m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;

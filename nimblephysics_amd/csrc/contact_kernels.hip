@@ -37,6 +37,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
                            int doTwists, uint32_t* __restrict__ failCount, int ppw, const double* __restrict__ qFk, int bid, int wl,
                            double* keptP, double* clipBuf, double* stage, double* fkT = nullptr) {
   const int tid = (int)threadIdx.x;
+  NBL_PHASE_FIRST(19);
   // ---- qFk with fkT (the narrow phase next to the forward tree kernel): the joint transforms T_parent->child of every body on an ancestor
   //      chain of a collider, for the wl worlds of the workgroup, by ALL its threads - (world, body) items side by side instead of one lane
   //      per collider pair walking its 7-joint chain alone (an exponential map with its sine and cosine per joint: 55 k of the 140 k cycles
@@ -62,7 +63,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   // the counter of the unresolved-worlds list of this slice starts at zero for the solve kernel that follows on the stream
   // (a separate hipMemsetAsync node cost ~6 us of every forward step)
   if (failCount && bid == 0 && tid == 0) *failCount = 0u;
-  NBL_PHASE(56);
+  NBL_PHASE_FIRST(56);
   // ppw lanes per world (1, 2 or 4): the narrow phases of ppw collider pairs of a world run side by side, each lane parks its
   // candidate contacts in LDS, and the world's first lane then accepts them in pair order - exactly the order and the filters
   // of the one-lane loop, at about 1 / ppw of its dependent chain (two foot-ground pairs: 74k -> ~40k cycles).
@@ -73,6 +74,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   if (!valid && ppw == 1) return;
   const int64_t bs = valid ? b : mdl.b1 - 1;       // lanes of a padding world repeat the last world's narrow phase, store nothing
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, bs, saved, &lay);
+  NBL_PHASE_FIRST(29);
   const int ltid = extra ? 0 : tid;
   LaneBuf clip; clip.base = clipBuf + ltid;
   int nC = 0, nDropped = 0;
@@ -146,8 +148,10 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
         return T;
       };
       uint64_t chain = cm->ancestors[body];
+      NBL_PHASE_FIRST(30);
       T12 TW = rel(__builtin_ctzll(chain));
       chain &= chain - 1;
+      NBL_PHASE_FIRST(31);
       while (chain) {
         TW = mulT(TW, rel(__builtin_ctzll(chain)));
         chain &= chain - 1;
@@ -170,6 +174,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
     T12 Ta = cT(ba.T), Tb = cT(bb.T);
     if (ba.body >= 0) Ta = mulT(worldT(ba.body), Ta);
     if (bb.body >= 0) Tb = mulT(worldT(bb.body), Tb);
+    NBL_PHASE_FIRST(28);
     // dispatch on the two shape types (collide(), DARTCollide.cpp:5030-5260)
     const V3 ha = mk3(ba.half[0], ba.half[1], ba.half[2]), hb = mk3(bb.half[0], bb.half[1], bb.half[2]);
     const bool sa = ba.shape == SHAPE_SPHERE, sb = bb.shape == SHAPE_SPHERE;
@@ -194,15 +199,18 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
     double* mine = stage + (size_t)(wI * (ppw - 1) + (pl > 0 ? pl - 1 : 0)) * (8 * CR_SIZE);
     int* counts = reinterpret_cast<int*>(stage + (size_t)wl * (ppw - 1) * (8 * CR_SIZE));
     for (int p0 = 0; p0 < nPairs; p0 += ppw) {       // ppw pairs of every world at a time
+      // ONE call for both kinds of lane - two calls with different continuations are two copies of the narrow phase, and the wavefront
+      // runs the copies of a divergent branch one after the other (measured: 71 k cycles for the two pairs of a world, 35 k each)
       int cnt = 0;
-      if (extra) {
-      } else if (pl == 0) {
-        if (valid) runPair(p0, [&](const DevContact& ct) { double rec[CR_SIZE]; toRec(ct, rec); acceptRec(rec, 1, p0); });
-      } else {
-        if (p0 + pl < nPairs) runPair(p0 + pl, [&](const DevContact& ct) { if (cnt < 8) { toRec(ct, mine + cnt * CR_SIZE); cnt++; } });
-        counts[wI * (ppw - 1) + pl - 1] = cnt;
-      }
+      if (!extra && (pl == 0 ? valid : p0 + pl < nPairs))
+        runPair(p0 + pl, [&](const DevContact& ct) {
+          if (pl == 0) { double rec[CR_SIZE]; toRec(ct, rec); acceptRec(rec, 1, p0); }
+          else if (cnt < 8) { toRec(ct, mine + cnt * CR_SIZE); cnt++; }
+        });
+      if (!extra && pl != 0) counts[wI * (ppw - 1) + pl - 1] = cnt;
+      NBL_PHASE_FIRST(57);
       __syncthreads();
+      NBL_PHASE_FIRST(58);
       if (pl == 0 && valid) {
         for (int q = 1; q < ppw && p0 + q < nPairs; q++) {
           const double* src = stage + (size_t)(wI * (ppw - 1) + q - 1) * (8 * CR_SIZE);
@@ -214,7 +222,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
     }
     if (pl != 0 || !valid) return;
   }
-  NBL_PHASE(59);
+  NBL_PHASE_FIRST(59);
   // ---- joint-limit constraint rows (JointLimitConstraint::update, JointLimitConstraint.cpp:182-237): every limit-enforcing DOF at or
   //      below its lower / at or above its upper limit is appended as a pseudo-contact after the contacts (ConstraintSolver.cpp:641-696
   //      pushes the joint-limit constraints after the contact constraints) ----
@@ -245,7 +253,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   if (overflow) st |= 0x80u;
   (void)edge;
   if (status && !qFk) status[b] |= st;  // the forward tree kernel initialised the word (0, or NBL_ST_NAN for a non-finite unconstrained step)
-  NBL_PHASE(60);
+  NBL_PHASE_FIRST(60);
   if (!doTwists || !__any(nC > 0)) return;   // k_step_forward_coop already left the twists
   // body twists at the pre-contact velocity (BodyNode::getSpatialVelocity after integrateVelocities) -> WS_VTW (the dead bias
   // accumulator slot; WS_A keeps the accelerations for the backward pass), for the relative velocities b = -J^T V of the contact-row kernel

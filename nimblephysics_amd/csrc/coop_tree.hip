@@ -386,6 +386,7 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
                                                           uint32_t* __restrict__ failCount, int ppw, int wl, int nDetect) {
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
   if ((int)blockIdx.x < nDetect) {
+    NBL_PHASE_FIRST(18);
     double* keptP = ldsTree;                              // SEEN_POINTS * 3 * 64
     double* clipBuf = keptP + SEEN_POINTS * 3 * 64;       // 48 * 64
     double* stage = clipBuf + 48 * 64;
@@ -399,9 +400,18 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
       const int cnt = mdl.nb * (int)(sizeof(DevBody) / sizeof(double));
       for (int i = (int)threadIdx.x; i < cnt; i += (int)blockDim.x) dst[i] = src[i];
     }
+    // ... and the collider model (pairs -> colliders -> bodies -> ancestor chains are dependent loads, per lane: through global memory they
+    // were 30 k of the 70 k cycles of a lane's narrow phase)
+    DevContactModel* lcm = reinterpret_cast<DevContactModel*>(lb + mdl.nb);
+    {
+      static_assert(sizeof(DevContactModel) % sizeof(double) == 0 && sizeof(DevBody) % sizeof(double) == 0, "copied as doubles");
+      double* dst = reinterpret_cast<double*>(lcm);
+      const double* src = reinterpret_cast<const double*>(cm);
+      for (int i = (int)threadIdx.x; i < (int)(sizeof(DevContactModel) / sizeof(double)); i += (int)blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
-    double* fkT = reinterpret_cast<double*>(lb + mdl.nb);      // [wl][bodies on the collider chains][12] joint transforms (contactDetectBody)
-    contactDetectBody(mdl, lb, cm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage, fkT);
+    double* fkT = reinterpret_cast<double*>(lcm + 1);      // [wl][bodies on the collider chains][12] joint transforms (contactDetectBody)
+    contactDetectBody(mdl, lb, lcm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage, fkT);
     return;
   }
   stepForwardCoopBody(mdl, bodies, dofs, B, state, action, next, saved, status, lay, 1, ldsTree, blockIdx.x - (uint32_t)nDetect,

@@ -47,8 +47,10 @@ namespace nbl {
 #ifdef NBL_PHASE_TIMING
 __device__ unsigned long long g_phaseStamp[64];
 #define NBL_PHASE(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_phaseStamp[k] = clock64(); } while (0)
+#define NBL_PHASE_FIRST(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phaseStamp[k] = clock64(); } while (0)   // (the narrow-phase workgroups come first)
 #else
 #define NBL_PHASE(k) do { } while (0)
+#define NBL_PHASE_FIRST(k) do { } while (0)
 #endif
 
 constexpr int JT_REVOLUTE = 0, JT_PRISMATIC = 1, JT_FREE = 2, JT_BALL = 4, JT_SCREW = 5, JT_FREEC = 6;   // = NBL_JOINT_*; JT_BALL: one of the three coincident axes of a ball joint; JT_FREEC (internal): one of the SIX coincident axes (3 rotations, 3 translations) of a free joint below the root

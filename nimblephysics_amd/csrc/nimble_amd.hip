@@ -517,7 +517,9 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     m->mdl.pad = wpw;
     auto pickWpb = [&](size_t perWorld, int& wpb, size_t& bytes) {   // wavefronts per workgroup
       int best = 0, bestWaves = 0;
-      for (int w = 1; w <= TREE_WPB_MAX; w++) {
+      int wCap = TREE_WPB_MAX;
+      if (const char* e17 = getenv("NBL_TREE_WPB")) wCap = std::max(1, std::min(TREE_WPB_MAX, atoi(e17)));
+      for (int w = 1; w <= wCap; w++) {
         const size_t need = modelLds + (size_t)w * wpw * perWorld;
         if (need > 160u * 1024u) break;
         int waves = (int)((160u * 1024u) / need) * w;
@@ -690,6 +692,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     const size_t detectLds = ((size_t)SEEN_POINTS * 3 * 64 + 48 * 64) * sizeof(double) +
                              (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0) +
                              (size_t)m->nb * sizeof(DevBody) + 32 +   // + the body constants of the narrow phase's own forward kinematics
+                             sizeof(DevContactModel) +                // + the collider model
                              (size_t)wlD * m->fkBodies * 12 * sizeof(double);   // + the joint transforms of the bodies on the collider chains
     const bool fusedDetect = m->hasContact && m->coopTree && saved && m->fusedDetect && std::max(treeLds, detectLds) <= 160u * 1024u;
     if (fusedDetect) {

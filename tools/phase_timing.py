@@ -52,9 +52,11 @@ for it in range(3):
     print(f"   bwd_b total {t[55] - t[48]}")
     for k in sorted(bb):
         print(f"   {bb[k]:38s} {t[k] - t[k - 1]:8d}")
-    dn_ = {57: "detect: world transforms of pair 0", 58: "detect: narrow phase + accept, pair 0", 59: "detect: remaining pairs", 60: "detect: count, status"}
-    print(f"   detect total {t[60] - t[56]}")
+    dn_ = {56: "detect: joint transforms of the collider chains (all threads)", 57: "detect: narrow phase of the lane's pair (thread 0)",
+           58: "detect: barrier (the slowest lane of the workgroup)", 59: "detect: accept parked contacts", 60: "detect: limits, count, status"}
+    print(f"   detect workgroup 0: kernel entry -> end {t[60] - t[18]} (the last tree workgroup: {t[10] - t[0]}); staging of the body and collider constants {t[19] - t[18]}")
+    print(f"   box-box of thread 0: start -> context {int(t[29]) - int(t[56])}, -> chain mask loaded {int(t[30]) - int(t[29])}, first link {int(t[31]) - int(t[30])}, rest of the chain + collider offset {int(t[28]) - int(t[31])}, -> entry {int(t[61]) - int(t[28])}, 15 axes {int(t[62]) - int(t[61])}, face set-up {int(t[39]) - int(t[62])}, clip {int(t[63]) - int(t[39])}, points + accept {int(t[57]) - int(t[63])}")
     for k in sorted(dn_):
-        print(f"   {dn_[k]:38s} {t[k] - t[k - 1]:8d}")
+        print(f"   {dn_[k]:38s} {t[k] - (t[19] if k == 56 else t[k - 1]):8d}")
     for k in sorted(bnames):
         print(f"   {bnames[k]:34s} {t[k] - t[k - 1]:8d}")
