@@ -203,6 +203,20 @@ DEV void coopIdentityColumn(double (&a)[MAXR], int eIn) {
   for (int i = 0; i < MAXR; i++) a[i] = (e == i) ? 1.0 : 0.0;
 }
 
+DEV double coopRsqrt(double x);
+#if defined(NBL_CASCADE_TIMING) && defined(__HIPCC__)
+__device__ unsigned long long g_pinvStat[8];   // developer counters of the Householder route (tools/cascade_timing.py): calls, cycles of the parts
+#endif
+#if defined(NBL_CASCADE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define PINV_T0() long long pvT = clock64()
+#define PINV_ADD(k) do { const long long pvN = clock64(); if (ln == 0) atomicAdd(&g_pinvStat[k], (unsigned long long)(pvN - pvT)); pvT = pvN; } while (0)
+#define PINV_CNT(k) do { if (ln == 0) atomicAdd(&g_pinvStat[k], 1ull); } while (0)
+#else
+#define PINV_T0() do { } while (0)
+#define PINV_ADD(k) do { } while (0)
+#define PINV_CNT(k) do { } while (0)
+#endif
+
 // S.P <- pseudo-inverse of the MAXR x MAXR matrix whose column j is a[] of lane j (< MAXR) (masked rows/columns zero);
 // cTrue = number of unmasked columns (Eigen's `size` in the rank threshold).  Returns the rank.
 template <class W>
@@ -210,7 +224,10 @@ DEV_PINV int coopPinvImpl(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) 
   const int ln = w.lane();
   if (QR_CARRY_LANES && ln >= MAXR) coopIdentityColumn(a, ln - MAXR);
   const double thr = 2.220446049250313e-16 * cTrue;
+  PINV_T0();
+  PINV_CNT(0);
   const int r = coopQr<W, true>(w, a, S, S.R, S.G, MAXR, thr * thr);
+  PINV_ADD(1);
   if (!QR_CARRY_LANES && r > 0) {
     coopIdentityColumn(a, ln < MAXR ? ln : -1);
     coopQrReplay(w, a, S, S.G, r);
@@ -246,6 +263,156 @@ DEV_PINV int coopPinvImpl(const W& w, double (&a)[MAXR], CoopLds& S, int cTrue) 
 #pragma unroll 1
     for (int pp = r; pp < MAXR; pp++) if (ln < MAXR) S.P[S.perm[pp] * CLD + ln] = 0.0;
     w.sync();
+    return r;
+  }
+  if constexpr (QR_CARRY_LANES != 0) {
+    // rank deficient (two flat feet: rank 12 of up to 23 clamping rows): R = [R1 R2] = R1 [I W] in pivot order, W = R1^-1 R2, and the
+    // minimum-norm solution of R u = g is u = [I; W^T] (I + W W^T)^-1 R1^-1 g  (R R^T = R1 (I + W W^T) R1^T).  The complete orthogonal
+    // decomposition's second Householder pass over R^T - r more reflector steps, each a norm, a square root, a division and two sweeps
+    // over 24 entries - becomes two triangular substitutions and the Cholesky factorisation of the r x r matrix I + W W^T, which column
+    // pivoting keeps well conditioned (|W| <~ 1) whatever the condition of Q: the accuracy is that of the triangular solves with R1,
+    // cond(Q) eps like the second pass (tests/test_coop_host.py).  Lane j < 24: column j of G1 (the first r rows of Q_h^T); lane 24 + t:
+    // the remaining column perm[r + t] of R (masked columns are zero columns: their W is zero, their row of Q^+ comes out zero).
+    const bool gl = ln < MAXR;
+    const int tW = ln - MAXR;
+    const bool wl = ln >= MAXR && tW < MAXR - r;
+    if (ln < r) S.invd[ln] = 1.0 / S.R[ln * CLD + S.perm[ln]];
+    const double* src = gl ? S.G : S.R;
+    const int col = gl ? ln : (wl ? S.perm[r + tW] : 0);
+#pragma unroll
+    for (int m = 0; m < MAXR; m++) {
+      const double v = src[(m < r ? m : 0) * CLD + col];
+      g[m] = (m < r && (gl || wl)) ? v : 0.0;
+    }
+    w.sync();
+    // x = R1^-1 (column): back substitution, R1[i][k] = S.R[i][perm[k]]   (reading the pivot columns and reciprocal pivots up front so
+    // that the loads of R1 run ahead of the substitution costs 72 registers: measured slower, the kernels sit at 256)
+#pragma unroll
+    for (int k = MAXR - 1; k >= 0; k--) {
+      if (k < r) {
+        const int pk = S.perm[k];
+        const double xk = g[k] * S.invd[k];
+        g[k] = xk;
+#pragma unroll
+        for (int i = 0; i < k; i++) g[i] = fma(-S.R[i * CLD + pk], xk, g[i]);
+      }
+    }
+    PINV_ADD(2);
+    w.sync();    // every lane has its column of G1 / R in registers and is done with R1: the buffers are free
+    if (ln >= MAXR && ln < 2 * MAXR) {
+#pragma unroll
+      for (int i = 0; i < MAXR; i++) S.G[i * CLD + tW] = g[i];       // W[i][t] (zero beyond the rank and beyond the remaining columns)
+    }
+    w.sync();
+    // I + W W^T -> S.P (r x r; the identity is added when the Cholesky factorisation reads it)
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      typedef double v4d __attribute__((ext_vector_type(4)));
+      const int li = ln & 15, lk = ln >> 4;
+      const int ksteps = (MAXR - r + 3) >> 2;
+#pragma unroll
+      for (int tr = 0; tr < MFMA_TILES; tr++) {
+#pragma unroll
+        for (int tj = 0; tj < MFMA_TILES; tj++) {
+          if (r > 16 * (tr > tj ? tr : tj)) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const int mi = 16 * tr + li, ni = 16 * tj + li;
+            const int mc = mi < MAXR ? mi : 0, nc2 = ni < MAXR ? ni : 0;
+#pragma unroll
+            for (int ks = 0; ks < MAXR / 4; ks++) {
+              if (ks < ksteps) {
+                const int kk = 4 * ks + lk;
+                const double av = S.G[mc * CLD + kk], bv = S.G[nc2 * CLD + kk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mi < r ? av : 0.0, ni < r ? bv : 0.0, acc, 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int rr = 16 * tr + lk + 4 * q, cc = 16 * tj + li;
+              if (rr < MAXR && cc < MAXR) S.P[rr * CLD + cc] = acc[q];
+            }
+          }
+        }
+      }
+    }
+#else
+    if (gl) {
+      for (int t2 = 0; t2 < MAXR; t2++) {
+        double sum = 0.0;
+        for (int jj = 0; jj < MAXR - r; jj++) sum += (t2 < r && ln < r) ? S.G[t2 * CLD + jj] * S.G[ln * CLD + jj] : 0.0;
+        S.P[t2 * CLD + ln] = sum;
+      }
+    }
+#endif
+    w.sync();
+    PINV_ADD(3);
+    // I + W W^T = L L^T, lane t (< r) = row t of L; rows also in S.R for the broadcast, reciprocal diagonal in S.invd
+    {
+      const int row = gl ? ln : 0;
+      double l2[MAXR];
+#pragma unroll
+      for (int i = 0; i < MAXR; i++) l2[i] = 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXR; k++) {
+        if (k < r) {
+          double s0 = S.P[row * CLD + k] + (row == k ? 1.0 : 0.0), s1 = 0.0;
+#pragma unroll
+          for (int i = 0; i < k; i++) {
+            const double lk2 = S.R[k * CLD + i];       // L[k][i], broadcast
+            if (i & 1) s1 = fma(-l2[i], lk2, s1); else s0 = fma(-l2[i], lk2, s0);
+          }
+          const double sK = s0 + s1;
+          const double inv = coopRsqrt(w.bcast(sK, k));
+          const double v = (ln >= k && ln < r) ? sK * inv : 0.0;
+          l2[k] = v;
+          if (gl) S.R[row * CLD + k] = v;
+          if (ln == 0) S.invd[k] = inv;
+          w.sync();
+        }
+      }
+    }
+    PINV_ADD(4);
+    // z = (L L^T)^-1 x for the columns of G1: forward with L, backward with L^T
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) {
+      if (k < r) {
+        double s0 = g[k], s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+          const double lk2 = S.R[k * CLD + i];
+          if (i & 1) s1 = fma(-lk2, g[i], s1); else s0 = fma(-lk2, g[i], s0);
+        }
+        g[k] = (s0 + s1) * S.invd[k];
+      }
+    }
+#pragma unroll
+    for (int k = MAXR - 1; k >= 0; k--) {
+      if (k < r) {
+        const double wk = g[k] * S.invd[k];
+        g[k] = wk;
+#pragma unroll
+        for (int i = 0; i < k; i++) g[i] = fma(-S.R[k * CLD + i], wk, g[i]);
+      }
+    }
+    PINV_ADD(5);
+    // column ln of Q^+ = P [z; W^T z]   (W^T z as a (24 - r) x r x 24 product on the matrix cores: 11 k -> 4 k cycles here, and 25 k more
+    // elsewhere in the kernels that inline this - they sit at 256 registers and the accumulator tiles spill)
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) if (k < r && gl) S.P[S.perm[k] * CLD + ln] = g[k];
+#pragma unroll 1
+    for (int tt = 0; tt < MAXR - r; tt++) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i4 = 0; i4 < MAXR; i4 += 4) {
+        if (i4 < r) {
+          s0 = fma(S.G[i4 * CLD + tt], g[i4], s0); s1 = fma(S.G[(i4 + 1) * CLD + tt], g[i4 + 1], s1);
+          s0 = fma(S.G[(i4 + 2) * CLD + tt], g[i4 + 2], s0); s1 = fma(S.G[(i4 + 3) * CLD + tt], g[i4 + 3], s1);
+        }
+      }
+      if (gl) S.P[S.perm[r + tt] * CLD + ln] = s0 + s1;
+    }
+    w.sync();
+    PINV_ADD(6);
     return r;
   }
   // rank deficient: R = [R1 R2] (r x c, pivot order).  Second factorisation R^T = Z [T; 0]: lane i (< r) takes row i
@@ -651,6 +818,9 @@ struct CoopClasses {
   double E;
   RowMask clampMask, ubMask;   // uniform
   int nc, nu;
+#ifdef NBL_CASCADE_TIMING
+  int dbgRank = -1;   // developer stamp: rank of the last Q factorised in the standardisation loop
+#endif
 };
 
 // CGGM::constructMatrices classification (CGGM.cpp:535-713), lane = row
@@ -736,6 +906,9 @@ struct CoopStage0 {
   CoopClasses K;
   bool ok;            // standardised valid solution found (uniform)
   bool pinvValid;     // S.P is the pseudo-inverse of the Q of the final classification (uniform)
+#ifdef NBL_CASCADE_TIMING
+  long long tGuess; int nu, fast;   // developer stamps (tools/cascade_timing.py)
+#endif
 };
 
 // CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (standardizeLoop of lcp_dev.hpp, lane = row).
@@ -759,7 +932,11 @@ DEV bool coopStandardizeLoop(const W& w, CoopLds& S, const CoopRow& R, double& X
     if (iter == 0 && K.nu == 0 && guessMask != 0 && K.clampMask == guessMask) fc = X;
     else {
       coopBuildQ(w, S, R, K, cfm, a);
+#ifdef NBL_CASCADE_TIMING
+      K.dbgRank = coopPinvOfQ(w, a, S, K);
+#else
       coopPinvOfQ(w, a, S, K);
+#endif
       fc = coopPinvApply<W, false>(w, S, K.cls == RC_CLAMPING ? R.Bv : 0.0, 0);
       pinvValid = true;
     }
@@ -811,8 +988,14 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
     }
   }
   out.X0 = X;
+#if defined(NBL_CASCADE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  out.tGuess = clock64();
+#endif
   CoopClasses K;
   const bool ok = coopStandardizeLoop(w, S, R, X, 0.0, false, guessMask, pinvValid, K);
+#if defined(NBL_CASCADE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  out.nu = K.nu + 100 * K.nc + 10000 * (K.dbgRank > 0 ? K.dbgRank : 0); out.fast = (K.nu == 0 && guessMask != 0 && K.clampMask == guessMask) ? 1 : (K.dbgRank >= 0 && K.dbgRank < K.nc ? 2 : 0);
+#endif
   NBL_PHASE(46);
   out.X = X; out.K = K; out.ok = ok; out.pinvValid = ok && pinvValid;
 }

@@ -19,7 +19,7 @@ constexpr int LW_STAGE_X = LW_JB;                       // 3 x MAX_ROWS candidat
 constexpr int LW_STAGE_FLAGS = LW_JB + 3 * MAX_ROWS;    // 3 x MAX_CONTACTS flag words [stage][group] (as doubles)
 constexpr int LW_FAILMASK = LW_STAGE_FLAGS + 3 * MAX_CONTACTS;   // bit g: constrained group g was not resolved by stage 0
 constexpr int LW_STAGE_CYCLES = LW_FAILMASK + 1;        // NBL_CASCADE_TIMING: cycles of the stage waves and of the final kernel
-static_assert(LW_STAGE_CYCLES + 4 <= LW_TOTAL, "stage results must fit the contact scratch rows");
+static_assert(LW_STAGE_CYCLES + 9 <= LW_TOTAL, "stage results must fit the contact scratch rows");
 
 template <bool LIM = false>
 DEV void coopLoadRow(CoopRow& R, int ln, int m, const double* __restrict__ saved, const double* __restrict__ dn,
@@ -177,6 +177,12 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   NBL_PHASE(40);
   const int64_t b = mdl.b0 + coopWorld(blockIdx.x, gridDim.x);
   if (b >= mdl.b1) return;
+#ifdef NBL_CASCADE_TIMING
+  const long long tSolve0 = clock64();
+#define NBL_SOLVE_CYCLES() do { if (ln == 0) lws[(int64_t)(LW_STAGE_CYCLES + 4) * B + b] = (double)(clock64() - tSolve0); } while (0)
+#else
+#define NBL_SOLVE_CYCLES() do { } while (0)
+#endif
   const int n = mdl.n;
   const double ncD = svAt(saved, lay.nc, B, b);
   const int nC = (int)ncD;
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
     if (ln < MAX_ROWS) svAt(saved, lay.cfm + ln, B, b) = 0.0;
     if (ln == 0) svAt(saved, lay.pflag, B, b) = 0.0;
     if (ln < n) svAt(saved, lay.w + ln, B, b) = 0.0;
+    NBL_SOLVE_CYCLES();
     return;
   }
   CoopRow R;
@@ -209,6 +216,14 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
   if (!MULTI || nGroups == 1) {
     CoopStage0 out;
     coopStage0(w, S, R, haveCache, Xcache, out);
+#ifdef NBL_CASCADE_TIMING
+    if (ln == 0) {
+      lws[(int64_t)(LW_STAGE_CYCLES + 5) * B + b] = (double)(out.tGuess - tSolve0);
+      lws[(int64_t)(LW_STAGE_CYCLES + 6) * B + b] = (double)(clock64() - out.tGuess);
+      lws[(int64_t)(LW_STAGE_CYCLES + 7) * B + b] = (double)out.nu;
+      lws[(int64_t)(LW_STAGE_CYCLES + 8) * B + b] = (double)out.fast;
+    }
+#endif
     if (out.ok) {
       const uint32_t nanBit = coopContactOutputs(w, S, R, n, m, out.X, out.K, 0.0, out.pinvValid, saved, lay, dn, cacheOut, nv, B, b);
       if (ln == 0 && status) status[b] |= 0x2u | 0x100u | nanBit;
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE) void k_contact_solve_coo
       if (ln < MAX_ROWS) lws[(int64_t)(LW_X0 + ln) * B + b] = out.X0;
       if (ln == 0) { lws[(int64_t)LW_FAILMASK * B + b] = 1.0; const uint32_t slot = atomicAdd(failCount, 1u); failList[slot] = (int32_t)b; }
     }
+    NBL_SOLVE_CYCLES();
     return;
   }
   // Several constrained groups: stage 0 group by group (rows of the other groups switched off).  Groups that resolve keep their

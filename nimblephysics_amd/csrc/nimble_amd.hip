@@ -1088,8 +1088,9 @@ int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, 
 #ifdef NBL_CASCADE_TIMING
 int32_t nbl_debug_dantzig_stats(unsigned long long* out16, int32_t reset) {
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dzStat), sizeof(unsigned long long) * 16));
-  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dzStat), z, sizeof(z))); }
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dzStat), sizeof(unsigned long long) * 16));   // (out16: 24 entries, the last 8 = g_pinvStat)
+  HIP_TRY(hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(g_pinvStat), sizeof(unsigned long long) * 8));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dzStat), z, sizeof(z))); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pinvStat), z, sizeof(unsigned long long) * 8)); }
   return NBL_OK;
 }
 #endif

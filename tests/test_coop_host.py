@@ -72,6 +72,55 @@ def test_coop_pinv_equals_numpy_pinv_on_masked_rank_deficient_systems(shim):
     assert shim.shim_coop_pinv(_p(Z), 5, _p(P)) == 0 and not P.any()
 
 
+def test_coop_pinv_on_contact_matrices_with_friction_rows_on_their_bound(shim):
+    """The matrices the Householder route is there for: Q = A(c, c) + A(c, u) E of a robot standing on two flat feet, some friction rows on
+    their bound folded into their normal's column - non-symmetric, up to 23 rows of rank 12, the body inertias spread over 1e2.  The
+    rank-deficient completion (24-row build: R = R1 [I W], Cholesky of I + W W^T; 48-row build: the second Householder pass) against
+    numpy's pseudo-inverse: rank exact, Q^+ to cond(Q) eps."""
+    R, NC = shim.R, shim.NC
+    rng = np.random.default_rng(11)
+    worst, tested = 0.0, 0
+    for trial in range(60 if R == 24 else 16):
+        nb = int(rng.integers(1, 3))                                   # one or two 6-DOF bodies
+        J = np.zeros((R, 6 * nb))
+        for cidx in range(NC):                                          # contact -> body, point on its sole
+            bdy = int(rng.integers(0, nb)); pt = np.array([rng.uniform(-0.1, 0.1), 0.0, rng.uniform(-0.05, 0.05)])
+            for ax in range(3):
+                d = np.eye(3)[[1, 0, 2][ax]]
+                J[3 * cidx + ax, 6 * bdy:6 * bdy + 3] = np.cross(pt, d); J[3 * cidx + ax, 6 * bdy + 3:6 * bdy + 6] = d
+        Lam = np.zeros((6 * nb, 6 * nb))
+        for bdy in range(nb):
+            M = rng.normal(0, 1, (6, 6)); Lam[6 * bdy:6 * bdy + 6, 6 * bdy:6 * bdy + 6] = M @ np.diag(10 ** rng.uniform(-1, 1, 6)) @ M.T
+        A = J @ Lam @ J.T
+        cls = rng.choice([0, 1, 2], size=R, p=[0.15, 0.6, 0.25])      # not clamping / clamping / upper bound (friction rows only)
+        cls[0::3] = np.where(cls[0::3] == 2, 1, cls[0::3])
+        Q = np.zeros((R, R))
+        cl = np.where(cls == 1)[0]
+        if len(cl) == 0:
+            continue
+        Q[np.ix_(cl, cl)] = A[np.ix_(cl, cl)]
+        for u in np.where(cls == 2)[0]:
+            nrm = u - u % 3
+            if cls[nrm] == 1:
+                Q[cl, nrm] += rng.choice([-1.0, 1.0]) * rng.uniform(0.3, 1.0) * A[cl, u]
+        sub = Q[np.ix_(cl, cl)]
+        sv = np.linalg.svd(sub, compute_uv=False)
+        k = int((sv > 1e-12 * sv[0]).sum())
+        cond = sv[0] / sv[k - 1]
+        if cond > 1e8:                                                  # (no clear gap between the singular values that count and round-off)
+            continue
+        tested += 1
+        P = np.zeros((R, R))
+        rank = shim.shim_coop_pinv(_p(np.ascontiguousarray(Q)), len(cl), _p(P))
+        assert rank == k, (trial, rank, k, len(cl))
+        ref = np.linalg.pinv(Q, rcond=0.5 * sv[k - 1] / sv[0])
+        e = np.abs(P - ref).max() / np.abs(ref).max()
+        worst = max(worst, e / (cond * 2.2e-16))
+        assert e <= 500 * cond * 2.2e-16, (trial, e, cond, k, len(cl))
+    assert tested >= (40 if R == 24 else 10), tested
+    print("coopPinv on contact matrices: worst error in units of cond(Q) eps:", worst, "over", tested, "matrices")
+
+
 def test_coop_pinv_sym_equals_numpy_pinv_on_positive_semidefinite_systems(shim):
     """coopPinvSym: the pseudo-inverse of symmetric positive semi-definite Q by two Cholesky factorisations, Q = G G^T (diagonally
     pivoted, rank by the threshold of the reference's complete orthogonal decomposition) and Q^+ = G (G^T G)^-2 G^T - the route the

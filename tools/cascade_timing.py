@@ -2,7 +2,7 @@
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DNBL_CASCADE_TIMING nimblephysics_amd/csrc/nimble_amd.hip \\
         -o tools/dbg/libnimble_amd_timing.so
 usage (GPU box): python tools/cascade_timing.py <joint noise>"""
-import os, sys, shutil
+import os, sys, shutil, collections
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -18,7 +18,7 @@ B = 4096
 st = world.to_soa(torch.tensor(s, device="cuda:0")); at = world.to_soa(torch.tensor(a, device="cuda:0"))
 import ctypes
 L = _lib.lib()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 L.nbl_debug_dantzig_stats(buf, 1)
 nxt, saved, status = world.step_soa(st, at)
 torch.cuda.synchronize()
@@ -31,19 +31,42 @@ for k, nm in enumerate(names_dz):
     print(f"  {nm:18s} {dz[k] / max(calls, 1):10.0f} cycles per solve")
 for k, nm in ((12, "stage 1: load problem"), (13, "stage 1: reduce"), (14, "stage 1: Dantzig (all of it)"), (15, "stage 1: map out + validity")):
     print(f"  {nm:30s} {dz[k] / max(calls, 1):10.0f} cycles per solve")
+pv = dz[16:24]
+if pv[0]:
+    print(f"Householder route: {pv[0]} factorisations; cycles each: pivoted QR {pv[1] / pv[0]:.0f}, R1^-1 [R2 | G1] {pv[2] / pv[0]:.0f}, W W^T {pv[3] / pv[0]:.0f}, "
+          f"Cholesky of I + W W^T {pv[4] / pv[0]:.0f}, two substitutions {pv[5] / pv[0]:.0f}, [z; W^T z] {pv[6] / pv[0]:.0f}")
 stat = status.cpu().numpy()
 ws = world._workspace(B).view(torch.float64).cpu().numpy()
 nb = 15
 lws = ws[nb * 288 * B:]
 LW_JB = 144
 base = LW_JB + 3 * 24 + 3 * 8 + 1          # LW_STAGE_CYCLES (model_dev.hpp, coop_kernels.hip)
-rows = lws[: (lws.size // B) * B].reshape(-1, B)[base:base + 4]
+rows = lws[: (lws.size // B) * B].reshape(-1, B)[base:base + 9]
 failed = np.where((stat & 0x2) == 0)[0]
 print("failed worlds", len(failed))
 names = ["stage 1 wave (reduce + Dantzig + validity)", "stage 2 wave (CFM: reduce + PGS + validity)", "stage 3 wave (no friction: PGS)", "final kernel (select + standardise + outputs)"]
 for k, nme in enumerate(names):
     d = rows[k, failed]
     print(f"{nme:48s} mean {d.mean():9.0f}  p50 {np.percentile(d, 50):9.0f}  p90 {np.percentile(d, 90):9.0f}  p99 {np.percentile(d, 99):9.0f}  max {d.max():9.0f} cycles")
+d = rows[4]
+ok = np.where((stat & 0x2) != 0)[0]
+for nme, sel in (("stage-0 kernel, all worlds", slice(None)), ("stage-0 kernel, worlds it resolves", ok), ("stage-0 kernel, worlds it hands on", failed)):
+    x = d[sel]
+    print(f"{nme:48s} mean {x.mean():9.0f}  p50 {np.percentile(x, 50):9.0f}  p90 {np.percentile(x, 90):9.0f}  p99 {np.percentile(x, 99):9.0f}  max {x.max():9.0f} cycles")
+con = np.where((stat & 0x1) != 0)[0]
+g, lp, packed, fast = rows[5][con], rows[6][con], rows[7][con].astype(int), rows[8][con]
+nu, ncl, rk = packed % 100, (packed // 100) % 100, packed // 10000
+hh = nu > 0
+print("Householder-route worlds: clamping rows (nc) histogram", dict(collections.Counter(ncl[hh].tolist())), "rank histogram", dict(collections.Counter(rk[hh].tolist())))
+okc = ((stat & 0x2) != 0)[con]
+print(f"worlds with contacts {len(con)}: guess (load + factorisation + apply) mean {g.mean():.0f} p90 {np.percentile(g, 90):.0f} max {g.max():.0f}")
+for nme, sel in (("final classification = the guess rows (no second factorisation)", fast == 1), ("other classification, no friction row on its bound (Cholesky route)", (fast != 1) & (nu == 0)),
+                 ("friction rows on their bound (Householder route), Q of full rank", (nu > 0) & (fast == 0)),
+                 ("friction rows on their bound (Householder route), Q rank deficient", (nu > 0) & (fast == 2))):
+    for tag, sel2 in (("resolved", sel & okc), ("handed on", sel & ~okc)):
+        if sel2.sum():
+            x = lp[sel2]
+            print(f"  {nme:70s} {tag:9s} {sel2.sum():5d} worlds: loop mean {x.mean():8.0f} p50 {np.percentile(x, 50):8.0f} p90 {np.percentile(x, 90):8.0f} max {x.max():8.0f}")
 crit = np.maximum.reduce([rows[0, failed], rows[1, failed], rows[2, failed]])
 print(f"{'longest stage wave of a world':48s} mean {crit.mean():9.0f}  p90 {np.percentile(crit, 90):9.0f}  max {crit.max():9.0f}")
 import collections
