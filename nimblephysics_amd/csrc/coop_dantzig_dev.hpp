@@ -897,7 +897,10 @@ DEV void coopCascadeSelect(const W& w, CoopLds& S, const CoopRow& R, double X0, 
   bool pinvValid = false;
   const bool std = coopStandardizeLoop(w, S, R, X, cfm, ignoreFriction, 0u, pinvValid, out.K);
   if (std) st |= 0x100u;
-  out.X = X; out.cfm = cfm; out.st = st; out.pinvValid = std && pinvValid;
+  // (pinvValid also when the loop ended on an invalid standardised solution: S.P is then still Q^+ of the classification handed back,
+  //  factorised in that very iteration - the record wants exactly that matrix, and factorising it again cost the slowest worlds of
+  //  k_contact_cascade_final 65-100 k of their 200 k cycles)
+  out.X = X; out.cfm = cfm; out.st = st; out.pinvValid = pinvValid;
 }
 
 }  // namespace nbl

@@ -71,3 +71,10 @@ crit = np.maximum.reduce([rows[0, failed], rows[1, failed], rows[2, failed]])
 print(f"{'longest stage wave of a world':48s} mean {crit.mean():9.0f}  p90 {np.percentile(crit, 90):9.0f}  max {crit.max():9.0f}")
 import collections
 print(collections.Counter(hex(x) for x in stat[failed]))
+fin = rows[3, failed]
+order = np.argsort(-fin)[:12]
+print("slowest worlds of the final kernel (cycles, status, share of the failed worlds above 70 k / 100 k cycles):", [(int(fin[i]), hex(stat[failed[i]])) for i in order],
+      float((fin > 70e3).mean()), float((fin > 100e3).mean()))
+for bits in sorted(set(stat[failed].tolist())):
+    x = fin[stat[failed] == bits]
+    print(f"   status {bits:#x}: {len(x):5d} worlds, final kernel mean {x.mean():8.0f} p90 {np.percentile(x, 90):8.0f} max {x.max():8.0f}")
