@@ -26,12 +26,13 @@ DEV double norm3(V3 a) { return sqrt(dot(a, a)); }
 DEV V3 unit3(V3 a) { double n = norm3(a); return mk3(a.x / n, a.y / n, a.z / n); }   // like Eigen's normalized(): divisions, no reciprocal
 DEV void set3(V3& a, int i, double v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
 
-// A small per-lane array in LDS, element i of the lane at base[i * 64] (conflict-free): the clip polygons are indexed
+// A small per-lane array in LDS, element i of the lane at base[i * ls] (ls = 64 or the narrow-phase lanes of the workgroup; conflict-free): the clip polygons are indexed
 // dynamically, which in private memory means scratch (= global memory) round trips.
 struct LaneBuf {
   double* base;
-  DEV double& operator[](int i) const { return base[i * 64]; }
-  DEV LaneBuf at(int i) const { LaneBuf r; r.base = base + i * 64; return r; }
+  int ls = 64;        // lanes that share the buffer (the stride between two elements of one lane)
+  DEV double& operator[](int i) const { return base[i * ls]; }
+  DEV LaneBuf at(int i) const { LaneBuf r; r.base = base + i * ls; r.ls = ls; return r; }
 };
 
 // clip the quad p against |x| <= h0, |y| <= h1; returns the number of points written to ret (<= 8).

@@ -28,14 +28,14 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
 }
 
 // The narrow phase of `wl` worlds x `ppw` lanes (threads tid < wl * ppw of the workgroup `bid`; any further threads of the workgroup
-// only take part in its barriers).  keptP: SEEN_POINTS * 3 * 64 doubles, clipBuf: 48 * 64 doubles, stage: the staging area of the
+// only take part in its barriers).  keptP: SEEN_POINTS * 3 * ls doubles, clipBuf: 48 * ls doubles (ls >= wl * ppw: the lane stride), stage: the staging area of the
 // ppw > 1 scheme - all LDS.  qFk != nullptr: the world transforms of the collider bodies are computed HERE from the positions (the
 // kernel runs next to the forward tree kernel, not after it) and the status word is left alone: the contact count goes to the record
 // with + 0.5 when contacts were dropped, k_contact_solve_coop raises NBL_ST_CONTACT / NBL_ST_CONTACT_OVERFLOW from it.
 DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodies, const DevContactModel* __restrict__ cm, int64_t B,
                            double* __restrict__ saved, const SavedLayout& lay, uint32_t* __restrict__ status, double* __restrict__ ws,
                            int doTwists, uint32_t* __restrict__ failCount, int ppw, const double* __restrict__ qFk, int bid, int wl,
-                           double* keptP, double* clipBuf, double* stage, double* fkT = nullptr) {
+                           double* keptP, double* clipBuf, double* stage, double* fkT = nullptr, int ls = 64) {
   const int tid = (int)threadIdx.x;
   NBL_PHASE_FIRST(19);
   // ---- qFk with fkT (the narrow phase next to the forward tree kernel): the joint transforms T_parent->child of every body on an ancestor
@@ -76,7 +76,7 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   Ctx c = makeCtx(mdl, bodies, nullptr, ws, B, bs, saved, &lay);
   NBL_PHASE_FIRST(29);
   const int ltid = extra ? 0 : tid;
-  LaneBuf clip; clip.base = clipBuf + ltid;
+  LaneBuf clip; clip.base = clipBuf + ltid; clip.ls = ls;
   int nC = 0, nDropped = 0;
   bool overflow = false, edge = false;
   // accept one candidate (lane pl == 0 of the world, or the only lane): postProcess + depth filter + append to the record
@@ -90,11 +90,11 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
     // corner is deep in the ground).  Seen points live in LDS: the kept contacts in slots 0 .. nC-1, dropped ones from the top down.
     bool close = false;
     for (int e = 0; e < nC; e++) {
-      const V3 d = pt - mk3(keptP[(e * 3 + 0) * 64 + ltid], keptP[(e * 3 + 1) * 64 + ltid], keptP[(e * 3 + 2) * 64 + ltid]);
+      const V3 d = pt - mk3(keptP[(e * 3 + 0) * ls + ltid], keptP[(e * 3 + 1) * ls + ltid], keptP[(e * 3 + 2) * ls + ltid]);
       if (norm3(d) < 3.0e-12) { close = true; break; }
     }
     for (int e = SEEN_POINTS - nDropped; e < SEEN_POINTS && !close; e++) {
-      const V3 d = pt - mk3(keptP[(e * 3 + 0) * 64 + ltid], keptP[(e * 3 + 1) * 64 + ltid], keptP[(e * 3 + 2) * 64 + ltid]);
+      const V3 d = pt - mk3(keptP[(e * 3 + 0) * ls + ltid], keptP[(e * 3 + 1) * ls + ltid], keptP[(e * 3 + 2) * ls + ltid]);
       if (norm3(d) < 3.0e-12) close = true;
     }
     if (close) return;
@@ -105,14 +105,14 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
       if (!full) {
         nDropped++;
         const int e = SEEN_POINTS - nDropped;
-        keptP[(e * 3 + 0) * 64 + ltid] = pt.x; keptP[(e * 3 + 1) * 64 + ltid] = pt.y; keptP[(e * 3 + 2) * 64 + ltid] = pt.z;
+        keptP[(e * 3 + 0) * ls + ltid] = pt.x; keptP[(e * 3 + 1) * ls + ltid] = pt.y; keptP[(e * 3 + 2) * ls + ltid] = pt.z;
       }
       return;
     }
     if (nC >= cm->maxContacts) { overflow = true; return; }
     if (full) { overflow = true; if (nDropped > 0) nDropped--; }   // (the kept point takes the slot of the last remembered dropped one)
     const int r0 = lay.contacts + nC * CR_SIZE;
-    keptP[(nC * 3 + 0) * 64 + ltid] = pt.x; keptP[(nC * 3 + 1) * 64 + ltid] = pt.y; keptP[(nC * 3 + 2) * 64 + ltid] = pt.z;
+    keptP[(nC * 3 + 0) * ls + ltid] = pt.x; keptP[(nC * 3 + 1) * ls + ltid] = pt.y; keptP[(nC * 3 + 2) * ls + ltid] = pt.z;
 #pragma unroll
     for (int e = 0; e < CR_SIZE; e++) {
       double v = ct[e * stride];

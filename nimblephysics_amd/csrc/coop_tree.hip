@@ -387,9 +387,10 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
   extern __shared__ __attribute__((aligned(16))) double ldsTree[];
   if ((int)blockIdx.x < nDetect) {
     NBL_PHASE_FIRST(18);
-    double* keptP = ldsTree;                              // SEEN_POINTS * 3 * 64
-    double* clipBuf = keptP + SEEN_POINTS * 3 * 64;       // 48 * 64
-    double* stage = clipBuf + 48 * 64;
+    const int ls = wl * ppw;                              // narrow-phase lanes of the workgroup
+    double* keptP = ldsTree;                              // SEEN_POINTS * 3 * ls
+    double* clipBuf = keptP + SEEN_POINTS * 3 * ls;       // 48 * ls
+    double* stage = clipBuf + 48 * ls;
     // the body constants of the forward kinematics from LDS (the two feet of a world sit on different lanes: indexed per lane, the
     // constants would be ~190 dependent global loads per lane)
     const size_t stageDoubles = ppw > 1 ? (size_t)wl * (ppw - 1) * (8 * CR_SIZE) + ((size_t)wl * (ppw - 1) + 1) / 2 : 0;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
     }
     __syncthreads();
     double* fkT = reinterpret_cast<double*>(lcm + 1);      // [wl][bodies on the collider chains][12] joint transforms (contactDetectBody)
-    contactDetectBody(mdl, lb, lcm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage, fkT);
+    contactDetectBody(mdl, lb, lcm, B, saved, lay, status, ws, 0, failCount, ppw, state, (int)blockIdx.x, wl, keptP, clipBuf, stage, fkT, ls);
     return;
   }
   stepForwardCoopBody(mdl, bodies, dofs, B, state, action, next, saved, status, lay, 1, ldsTree, blockIdx.x - (uint32_t)nDetect,

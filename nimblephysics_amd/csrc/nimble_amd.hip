@@ -81,6 +81,7 @@ struct nbl_model {
                                      // the other slices' tree kernels wait for the CUs (k_step_forward_coop 70 -> 111 us).  Off by default.
   bool fusedDetect = true;           // NBL_FUSED_DETECT=0: the narrow phase as a launch of its own after the forward tree kernel
   bool detectSplit = true;           // NBL_DETECT_SPLIT=0: one lane per world in k_contact_detect (collider pairs one after the other)
+  int detectWl = 0;                  // NBL_DETECT_WL: cap of the worlds per narrow-phase workgroup of k_forward_detect_coop (0: a full wavefront)
   int fkBodies = 0;                  // bodies on the ancestor chains of the colliders (forward kinematics of the fused narrow phase)
   int rowsPack = 1;                  // worlds per wavefront of k_contact_rows_coop (2: the 24-row build, <= 32 device bodies; NBL_ROWS_PACK=1 forces 1)
   int nPairs = 0;                    // candidate collider pairs of the model
@@ -539,6 +540,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     if (const char* e13 = getenv("NBL_DETECT_SPLIT")) m->detectSplit = atoi(e13) != 0;
     if (const char* e14 = getenv("NBL_FUSED_CASCADE")) m->fusedCascade = atoi(e14) != 0;
     if (const char* e15 = getenv("NBL_FUSED_DETECT")) m->fusedDetect = atoi(e15) != 0;
+    if (const char* e19 = getenv("NBL_DETECT_WL")) m->detectWl = atoi(e19);
     m->nPairs = hc.nPairs;
     if (hasContact) {
       uint64_t need = 0ull;
@@ -688,8 +690,9 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     const dim3 treeGrid((unsigned)((cnt + perBlockF - 1) / perBlockF)), treeBlock(64 * std::max(1, m->wpbFwd));
     // lanes per world of the narrow phase: the collider pairs of a world side by side (k_contact_detect / contactDetectBody)
     const int ppwD = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
-    const int wlD = std::min(tl, 64 / ppwD);                       // worlds per narrow-phase workgroup
-    const size_t detectLds = ((size_t)SEEN_POINTS * 3 * 64 + 48 * 64) * sizeof(double) +
+    int wlD = std::min(tl, 64 / ppwD);                             // worlds per narrow-phase workgroup
+    if (m->detectWl > 0) wlD = std::max(1, std::min(wlD, m->detectWl));
+    const size_t detectLds = ((size_t)SEEN_POINTS * 3 + 48) * (size_t)(wlD * ppwD) * sizeof(double) +
                              (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0) +
                              (size_t)m->nb * sizeof(DevBody) + 32 +   // + the body constants of the narrow phase's own forward kinematics
                              sizeof(DevContactModel) +                // + the collider model

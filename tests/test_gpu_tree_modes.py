@@ -97,6 +97,40 @@ def test_fused_cascade_launch_is_bit_identical_to_the_two_launches(monkeypatch):
             assert torch.equal(ta, tb)
 
 
+LAUNCH_SHAPES = [{"NBL_FUSED_DETECT": "0"}, {"NBL_TREE_WPB": "1", "NBL_DETECT_WL": "8"}, {"NBL_TREE_WPB": "2", "NBL_DETECT_WL": "16"}, {"NBL_DETECT_SPLIT": "0"},
+                 {"NBL_ROWS_PACK": "1"}, {"NBL_TREE_PACK": "1"}]
+
+
+@pytest.mark.parametrize("mode", LAUNCH_SHAPES, ids=["-".join(f"{k[4:]}={v}" for k, v in m.items()) for m in LAUNCH_SHAPES])
+def test_the_launch_shapes_do_not_change_a_bit(mode, monkeypatch):
+    """How the worlds are dealt to workgroups and lanes is a launch decision, not arithmetic: the narrow phase as a launch of its own (world
+    transforms from the tree block) or next to the tree kernel (its own forward kinematics from LDS-resident joint transforms, all threads
+    of the workgroup), 8 / 16 / 32 worlds per narrow-phase workgroup (lane stride of its LDS buffers), one / two / three tree wavefronts per
+    workgroup, one lane or several per world in the narrow phase, one or two worlds per wavefront in the contact-row kernel, one or four
+    worlds per wavefront in the tree kernels: next states, status words, warm starts and both gradients bit for bit against the default,
+    on the metric distribution (half of the worlds in the cascade)."""
+    import torch
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    md, s, a = contact_inputs("atlas20", 1024, 13, joint_noise=0.02, vel_noise=0.01, action_noise=0.0)
+    g = np.random.default_rng(5).normal(0, 1, s.shape)
+    results = []
+    for env in ({}, mode):
+        for k in ("NBL_FUSED_DETECT", "NBL_TREE_WPB", "NBL_DETECT_WL", "NBL_DETECT_SPLIT", "NBL_ROWS_PACK", "NBL_TREE_PACK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        world = na.World(md, device="cuda:0")
+        st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+        y = timestep(world, st, at)
+        status = world.last_status.clone(); cache = world.lcp_cache.clone()
+        y.backward(torch.tensor(g, device="cuda:0"))
+        results.append((y.detach().clone(), status, cache, st.grad.clone(), at.grad.clone()))
+    assert ((results[0][1] & 0x2) == 0).float().mean() > 0.2            # the cascade is exercised
+    for name, ta, tb in zip(("next", "status", "warm start", "grad_state", "grad_action"), results[0], results[1]):
+        assert torch.equal(ta, tb), (mode, name)
+
+
 FEATURE_MODES = [{"NBL_COOP_TREE": "0"}, {"NBL_COOP_FINAL": "0"}, {"NBL_SAVE_TREE": "0"}, {"NBL_FUSED_DETECT": "0"}, {"NBL_DETECT_SPLIT": "0"}]
 
 
