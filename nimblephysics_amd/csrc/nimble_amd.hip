@@ -692,11 +692,16 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     const int ppwD = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
     int wlD = std::min(tl, 64 / ppwD);                             // worlds per narrow-phase workgroup
     if (m->detectWl > 0) wlD = std::max(1, std::min(wlD, m->detectWl));
-    const size_t detectLds = ((size_t)SEEN_POINTS * 3 + 48) * (size_t)(wlD * ppwD) * sizeof(double) +
-                             (ppwD > 1 ? (size_t)wlD * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wlD * (ppwD - 1) * sizeof(int) : 0) +
-                             (size_t)m->nb * sizeof(DevBody) + 32 +   // + the body constants of the narrow phase's own forward kinematics
-                             sizeof(DevContactModel) +                // + the collider model
-                             (size_t)wlD * m->fkBodies * 12 * sizeof(double);   // + the joint transforms of the bodies on the collider chains
+    auto detectLdsFor = [&](int wl) -> size_t {
+      return ((size_t)SEEN_POINTS * 3 + 48) * (size_t)(wl * ppwD) * sizeof(double) +
+             (ppwD > 1 ? (size_t)wl * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wl * (ppwD - 1) * sizeof(int) : 0) +
+             (size_t)m->nb * sizeof(DevBody) + 32 +   // + the body constants of the narrow phase's own forward kinematics
+             sizeof(DevContactModel) +                // + the collider model
+             (size_t)wl * m->fkBodies * 12 * sizeof(double);   // + the joint transforms of the bodies on the collider chains
+    };
+    // (many colliders on long chains - a humanoid on the 48-row build: fewer worlds per workgroup rather than the narrow phase as a launch of its own)
+    while (wlD > 1 && detectLdsFor(wlD) > 160u * 1024u) wlD /= 2;
+    const size_t detectLds = detectLdsFor(wlD);
     const bool fusedDetect = m->hasContact && m->coopTree && saved && m->fusedDetect && std::max(treeLds, detectLds) <= 160u * 1024u;
     if (fusedDetect) {
       const int nDetect = (int)((cnt + wlD - 1) / wlD);

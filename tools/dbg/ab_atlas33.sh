@@ -1,0 +1,5 @@
+# Atlas-33 (cfg5's model): one 2048-world slice alone, then the four-slice run
+for a in "--streams 1 --batch 2048" "--batch 8192"; do python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact $a 2>/dev/null | python -c "
+import sys,json
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=j['roofline']['kernels_avg_ms']
+print('$a','M/s',round(j['value']/1e6,3),'ms',round(j['ms_per_step'],4),' '.join('%s=%.0f'%(n.replace('k_','').replace('_coop','').replace('contact_','c_'),v*1e3) for n,v in k.items()))"; done
