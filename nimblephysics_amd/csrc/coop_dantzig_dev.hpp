@@ -63,6 +63,121 @@ struct CoopLcpRow {
   int findex;
 };
 
+// ---- the two triangular solves of the Dantzig driver, one substitution step as hand-placed EXEC masks (device, factors of up to 32 rows) ----
+// A step of dSolveL1 / dSolveL1T for ALL rows of the factor at once (lane = row): x_k, final on lane k, is broadcast; t = L[row][k] x_k; the
+// rows of k's own 4-block that come after it subtract t from their running y, every later row adds t to its block sum Z, and a row
+// switches from Z to y = rhs - Z when the step reaches the first column of its block (fastlsolve.cpp / fastltsolve.cpp: that order of
+// the additions is what makes the result bit-identical to the reference's).  ONE accumulator per lane holds Z before the switch and y
+// after it; which lanes do what at step k is a compile-time lane mask once the block grid is fixed - for dSolveL1 the grid starts at
+// row 0, for dSolveL1T (reversed index) at row nC mod 4 - so a step is broadcast + multiply + two predicated adds under literal EXEC
+// masks: 9-12 instructions instead of the 21-31 the compiler makes of the compare / select form below (which the host emulation and the
+// 48-row build keep).  ym: the lanes that subtract, zm: the lanes that add (before the cut to the rows of the factor: & ncm).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <unsigned SW>
+DEV void dzSwitchStep(double& acc, double rhs) {          // acc = rhs - acc on the lanes SW
+  unsigned long long sv;
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               "s_mov_b64 exec, %[sw]\n\t"
+               "v_add_f64 %[acc], %[rhs], -%[acc]\n\t"
+               "s_mov_b64 exec, %[sv]"
+               : [acc] "+v"(acc), [sv] "=&s"(sv)
+               : [rhs] "v"(rhs), [sw] "n"(SW));
+}
+template <unsigned YM, unsigned ZM>
+DEV void dzSubstStep(double& acc, double l, double xk, unsigned long long ncm) {
+  unsigned long long sv;
+  double t;
+  if constexpr (YM != 0u) {
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_mul_f64 %[t], %[l], %[xk]\n\t"
+                 "s_mov_b64 exec, %[ym]\n\t"
+                 "v_add_f64 %[acc], %[acc], -%[t]\n\t"
+                 "s_and_b64 exec, %[ncm], %[zm]\n\t"
+                 "v_add_f64 %[acc], %[acc], %[t]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [acc] "+v"(acc), [t] "=&v"(t), [sv] "=&s"(sv)
+                 : [l] "v"(l), [xk] "s"(xk), [ncm] "s"(ncm), [ym] "n"(YM), [zm] "n"(ZM)
+                 : "scc");
+  } else {
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_mul_f64 %[t], %[l], %[xk]\n\t"
+                 "s_and_b64 exec, %[ncm], %[zm]\n\t"
+                 "v_add_f64 %[acc], %[acc], %[t]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [acc] "+v"(acc), [t] "=&v"(t), [sv] "=&s"(sv)
+                 : [l] "v"(l), [xk] "s"(xk), [ncm] "s"(ncm), [zm] "n"(ZM)
+                 : "scc");
+  }
+}
+constexpr unsigned dzLanes(int from, int to) { return from >= to ? 0u : (unsigned)(((1ull << to) - 1ull) & ~((1ull << from) - 1ull)); }   // lanes [from, to)
+// dSolveL1: the complete 4-blocks (rows below nb4 = nC & ~3), then at most three single rows.  The guards nest - one test per block, and
+// the first block that is not complete ends the walk with the single rows.
+template <int K, class W>
+DEV void dzL1BlockStep(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], unsigned long long ncm) {
+  if constexpr (K % 4 == 0) dzSwitchStep<dzLanes(K, K + 4)>(acc, rhs);
+  const double xk = w.bcast(acc, K);
+  dzSubstStep<dzLanes(K + 1, (K | 3) + 1), dzLanes((K | 3) + 1, 32)>(acc, lrow[K], xk, ncm);
+}
+template <int K, class W>
+DEV void dzL1TailStep(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], unsigned long long ncm) {
+  dzSwitchStep<dzLanes(K, K + 1)>(acc, rhs);
+  const double xk = w.bcast(acc, K);
+  dzSubstStep<0u, dzLanes(K + 1, 32)>(acc, lrow[K], xk, ncm);
+}
+template <int J, class W>
+DEV void dzL1Blocks(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], int nC, int nb4, unsigned long long ncm) {
+  if constexpr (4 * J < MAXR) {
+    if (4 * J < nb4) {
+      dzL1BlockStep<4 * J>(w, acc, rhs, lrow, ncm);
+      dzL1BlockStep<4 * J + 1>(w, acc, rhs, lrow, ncm);
+      dzL1BlockStep<4 * J + 2>(w, acc, rhs, lrow, ncm);
+      dzL1BlockStep<4 * J + 3>(w, acc, rhs, lrow, ncm);
+      dzL1Blocks<J + 1>(w, acc, rhs, lrow, nC, nb4, ncm);
+    } else if (4 * J < nC) {
+      dzL1TailStep<4 * J>(w, acc, rhs, lrow, ncm);
+      if (4 * J + 1 < nC) {
+        dzL1TailStep<4 * J + 1>(w, acc, rhs, lrow, ncm);
+        if (4 * J + 2 < nC) dzL1TailStep<4 * J + 2>(w, acc, rhs, lrow, ncm);
+      }
+    }
+  }
+}
+// dSolveL1T (K runs down), the block grid of the REVERSED index starting at lane RHO = nC mod 4: lanes [RHO + 4j, RHO + 4j + 4) are one
+// block whose first reversed row is its LAST lane; the lanes below RHO are the single rows and come last.
+template <int RHO, int K, class W>
+DEV void dzL1TBlockStep(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], unsigned long long ncm) {
+  constexpr int B0 = RHO + 4 * ((K - RHO) / 4);                    // first lane of K's block
+  if constexpr (K == B0 + 3) dzSwitchStep<dzLanes(B0, B0 + 4)>(acc, rhs);
+  const double xk = w.bcast(acc, K);
+  dzSubstStep<dzLanes(B0, K), dzLanes(0, B0)>(acc, lcol[K], xk, ncm);
+}
+template <int K, class W>
+DEV void dzL1TTailStep(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], unsigned long long ncm) {
+  dzSwitchStep<dzLanes(K, K + 1)>(acc, rhs);
+  const double xk = w.bcast(acc, K);
+  dzSubstStep<0u, dzLanes(0, K)>(acc, lcol[K], xk, ncm);
+}
+// blocks from the top one down: block J covers lanes RHO + 4J .. RHO + 4J + 3 and exists when its last lane is below nC
+template <int RHO, int J, class W>
+DEV void dzL1TBlocks(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], int nC, unsigned long long ncm) {
+  if constexpr (J >= 0) {
+    if constexpr (RHO + 4 * J + 3 < MAXR) {
+      if (RHO + 4 * J + 3 < nC) {
+        dzL1TBlockStep<RHO, RHO + 4 * J + 3>(w, acc, rhs, lcol, ncm);
+        dzL1TBlockStep<RHO, RHO + 4 * J + 2>(w, acc, rhs, lcol, ncm);
+        dzL1TBlockStep<RHO, RHO + 4 * J + 1>(w, acc, rhs, lcol, ncm);
+        dzL1TBlockStep<RHO, RHO + 4 * J>(w, acc, rhs, lcol, ncm);
+      }
+    }
+    dzL1TBlocks<RHO, J - 1>(w, acc, rhs, lcol, nC, ncm);
+  } else {
+    if constexpr (RHO >= 3) dzL1TTailStep<2>(w, acc, rhs, lcol, ncm);
+    if constexpr (RHO >= 2) dzL1TTailStep<1>(w, acc, rhs, lcol, ncm);
+    if constexpr (RHO >= 1) dzL1TTailStep<0>(w, acc, rhs, lcol, ncm);
+  }
+}
+#endif
+
 // The Dantzig driver: dSolveLCP (dart/external/odelcpsolver/lcp.cpp:780-1113) with nub = 0, earlyTermination = true, restated
 // OPERATION BY OPERATION: the factor of A(C,C) is the reference's L / d (unit lower factor by rows, RECIPROCAL pivots) kept in
 // the reference's own row order through the index vector C[] (lcp.cpp:100-108); a row entering C appends ell / Dell to it
@@ -165,6 +280,14 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
 #pragma unroll
     for (int k = 0; k < MAXR; k++) lrow[k] = C.L[me * CLD + k];
     coopPin24(lrow);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MAXR <= 32) {
+      double acc = 0.0;
+      const unsigned long long ncm = (1ull << nC) - 1ull;
+      dzL1Blocks<0>(w, acc, rhs, lrow, nC, nb4, ncm);
+      return ln < nC ? acc : rhs;
+    }
+#endif
     double Z = 0.0, y = rhs;
 #pragma unroll
     for (int k = 0; k < MAXR; k++) {
@@ -188,6 +311,19 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
 #pragma unroll
     for (int k = 0; k < MAXR; k++) lcol[k] = C.L[k * CLD + me];
     coopPin24(lcol);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MAXR <= 32) {
+      double acc = 0.0;
+      const unsigned long long ncm = (1ull << nC) - 1ull;
+      const int rho = nC & 3;
+      constexpr int JTOP = MAXR / 4 - 1;
+      if (rho == 0) dzL1TBlocks<0, JTOP>(w, acc, rhs, lcol, nC, ncm);
+      else if (rho == 1) dzL1TBlocks<1, JTOP>(w, acc, rhs, lcol, nC, ncm);
+      else if (rho == 2) dzL1TBlocks<2, JTOP>(w, acc, rhs, lcol, nC, ncm);
+      else dzL1TBlocks<3, JTOP>(w, acc, rhs, lcol, nC, ncm);
+      return ln < nC ? acc : rhs;
+    }
+#endif
     double Z = 0.0, y = rhs;
 #pragma unroll
     for (int k = MAXR - 1; k >= 0; k--) {

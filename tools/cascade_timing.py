@@ -69,6 +69,12 @@ for nme, sel in (("final classification = the guess rows (no second factorisatio
             print(f"  {nme:70s} {tag:9s} {sel2.sum():5d} worlds: loop mean {x.mean():8.0f} p50 {np.percentile(x, 50):8.0f} p90 {np.percentile(x, 90):8.0f} max {x.max():8.0f}")
 crit = np.maximum.reduce([rows[0, failed], rows[1, failed], rows[2, failed]])
 print(f"{'longest stage wave of a world':48s} mean {crit.mean():9.0f}  p90 {np.percentile(crit, 90):9.0f}  max {crit.max():9.0f}")
+w1 = rows[1, failed] + rows[2, failed]            # the PGS wavefront runs stage 2, then (when stage 2 is not valid) stage 3
+both = np.maximum(rows[0, failed], w1)
+print(f"{'PGS wavefront (stage 2 + stage 3)':48s} mean {w1.mean():9.0f}  p90 {np.percentile(w1, 90):9.0f}  p99 {np.percentile(w1, 99):9.0f}  max {w1.max():9.0f}")
+print(f"{'the slower of the two wavefronts of a world':48s} mean {both.mean():9.0f}  p90 {np.percentile(both, 90):9.0f}  p99 {np.percentile(both, 99):9.0f}  max {both.max():9.0f};  "
+      f"worlds whose PGS wavefront is the slower one: {float((w1 > rows[0, failed]).mean()):.2f}; the ten slowest worlds (Dantzig, PGS): "
+      f"{[(int(rows[0, failed][i]), int(w1[i])) for i in np.argsort(-both)[:10]]}")
 import collections
 print(collections.Counter(hex(x) for x in stat[failed]))
 fin = rows[3, failed]
