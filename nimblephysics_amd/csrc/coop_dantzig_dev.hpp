@@ -260,9 +260,16 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
     w.sync();
     if (ln < MAXR) { C.v[2][ln] = ln < mid ? prod : 0.0; C.v[3][ln] = (ln >= mid && ln < to) ? prod : 0.0; }
     w.sync();
+    // (terms at and beyond `to` are +0.0 in both vectors, and a running sum that starts at +0.0 is never -0.0: leaving their additions out
+    //  changes no bit - and the two chains of dependent additions are what this costs; one guard per four terms)
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXR; k++) { s1 = s1 + C.v[2][k]; s2 = s2 + C.v[3][k]; }
+    for (int k4 = 0; k4 < MAXR; k4 += 4) {
+      if (k4 < to) {
+#pragma unroll
+        for (int k = k4; k < k4 + 4; k++) { s1 = s1 + C.v[2][k]; s2 = s2 + C.v[3][k]; }
+      }
+    }
   };
   auto seqSum = [&](double prod, int from, int to) -> double {   // from == 0 at every call site
     double s1, s2;
