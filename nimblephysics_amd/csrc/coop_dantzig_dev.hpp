@@ -627,6 +627,49 @@ DEV void coopRemoveRow(const W& w, LDS& C, int n, int col, CoopLcpRow& row) {
   if (ln >= col && ln + 1 < n) { row.x = x1; row.b = b1; row.lo = l1; row.hi = h1; row.findex = f1; }
 }
 
+// Keep the rows / columns `keep` (bits < n) of the n-row problem, in their order: what removing the others one by one from the last one
+// down (coopRemoveRow: two LDS passes over the matrix and five shuffles PER ROW - 16 times over for the friction rows of eight contacts)
+// leaves, as one gather.  Pure data movement.  findex of a kept row follows its normal row (which is kept with it); mapTo (original row ->
+// column of the problem) follows the columns, -1 for a row that is gone.  Returns the new size.
+template <class W, class LDS>
+DEV int coopKeepRows(const W& w, LDS& C, int n, uint64_t keep, CoopLcpRow& row, int& mapTo) {
+  const int ln = w.lane();
+  const int nNew = __builtin_popcountll(keep);
+  auto newIdx = [&](int p) -> int { return __builtin_popcountll(keep & ((1ull << p) - 1ull)); };
+  const bool kept = ln < n && ((keep >> ln) & 1ull);
+  w.sync();
+  if (kept) C.v[0][newIdx(ln)] = (double)ln;                    // new row -> old row
+  w.sync();
+  const int src = ln < nNew ? (int)C.v[0][ln] : 0;
+  double col[MAXR];
+  {
+    uint64_t mm = keep;
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) {
+      if (j < nNew) {
+        const int sj = __builtin_ctzll(mm);                     // (uniform)
+        mm &= mm - 1ull;
+        col[j] = C.A[src * CLD + sj];
+      }
+    }
+  }
+  w.sync();
+  if (kept) { const int t = newIdx(ln); C.v[0][t] = row.x; C.v[1][t] = row.b; C.v[2][t] = row.lo; C.v[3][t] = row.hi; }
+  const int fOld = w.shflI(row.findex, src);                    // (findex of the row this lane becomes)
+  if (ln < nNew) {
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) if (j < nNew) C.A[ln * CLD + j] = col[j];
+  }
+  w.sync();
+  if (ln < nNew) {
+    row.x = C.v[0][ln]; row.b = C.v[1][ln]; row.lo = C.v[2][ln]; row.hi = C.v[3][ln];
+    row.findex = fOld >= 0 ? newIdx(fOld) : -1;
+  }
+  if (mapTo >= 0) mapTo = ((keep >> mapTo) & 1ull) ? newIdx(mapTo) : -1;
+  w.sync();
+  return nNew;
+}
+
 // merge near-identical columns (squared distance < 1e-4, |b_a - b_b| < 1e-4, same findex / hi / lo).  mapTo: this lane's
 // ORIGINAL row -> reduced column.  Returns the reduced size.
 template <class W, class LDS>
@@ -670,16 +713,8 @@ DEV int coopLcpReduce(const W& w, LDS& C, int n, CoopLcpRow& row, int& mapTo) {
 // drop every friction row (from the last one down)
 template <class W, class LDS>
 DEV int coopLcpRemoveFriction(const W& w, LDS& C, int n, CoopLcpRow& row, int& mapTo) {
-  for (int i = n - 1; i >= 0; i--) {
-    const int fi = w.bcastI(row.findex, i);
-    if (fi == -1) continue;
-    if (row.findex > i) row.findex -= 1;
-    coopRemoveRow(w, C, n, i, row);
-    n -= 1;
-    if (mapTo == i) mapTo = -1;
-    else if (mapTo > i) mapTo -= 1;
-  }
-  return n;
+  const int ln = w.lane();
+  return coopKeepRows(w, C, n, w.ballot(ln < n && row.findex == -1), row, mapTo);
 }
 
 // ---- PgsBoxedLcpSolver::solve (PgsBoxedLcpSolver.cpp:79-268), Option(30, 1e-6, 1e-3, 1e-9, false) ----
@@ -914,16 +949,7 @@ DEV void coopLoadProblem(const W& w, LDS& C, const CoopRow& R, double cfmDiag, d
   // reference's order - the initial permutation of dSolveLCP and with it the whole pivot sequence depend on it.
   const RowMask dead = (RowMask)w.ballot(ln < m && (!R.on || (R.fric && R.mu == 0.0)));   // ... and the rows of the world's other constrained groups
   nOut = m;
-  if (dead != 0) {
-    for (int i = m - 1; i >= 0; i--) {
-      if (!((dead >> i) & 1u)) continue;
-      if (row.findex > i) row.findex -= 1;
-      coopRemoveRow(w, C, nOut, i, row);
-      nOut -= 1;
-      if (mapTo == i) mapTo = -1;
-      else if (mapTo > i) mapTo -= 1;
-    }
-  }
+  if (dead != 0) nOut = coopKeepRows(w, C, m, (uint64_t)w.ballot(ln < m) & ~(uint64_t)dead, row, mapTo);
 }
 // X[o] = x_reduced[mapTo[o]]
 template <class W, class LDS>
