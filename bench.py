@@ -222,13 +222,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0, bounds=bounds, streams=streams):
+    def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0, bounds=bounds, streams=streams, slices=None):
         """W untimed + K timed fwd+bwd steps on a fresh synthetic batch of the workload at pose noise `noise`."""
         md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, noise)
         if args.max_contacts > 0 and md.max_contacts:
             md.max_contacts = args.max_contacts
             wl_desc += f" [max_contacts = {args.max_contacts}: the {3 * max(8, args.max_contacts) if args.max_contacts <= 8 else 48}-row build]"
         worlds = [na.World(md, device=dev) for _ in bounds]
+        if slices is not None:
+            for w_ in worlds:
+                w_.set_slices(slices)
         world = worlds[0]
         k = world.k
         state0 = [w.to_soa(torch.tensor(s_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
@@ -297,10 +300,12 @@ def main():
     if has_contact and args.easy_noise > 0 and args.easy_noise != args.joint_noise:
         # the easy distribution: every world resolves at LCP stage 0 (round 1's headline), half the steps, no kernel events
         easy = measure(args.easy_noise, max(1, args.steps // 2), min(args.warmup, 4), False)
-    single = None
+    single = single_call = None
     if has_contact and len(bounds) > 1 and not args.no_single_stream:
         # the same batch as ONE launch per kernel per step (no stream slices): what the chain costs without the overlap of the slices
-        single = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1])
+        single = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1], slices=1)
+        # ... and as ONE call per step with the library's own slicing (what a caller gets who hands over the whole batch at once)
+        single_call = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1])
     elapsed, st, tm, timing_period, md, s_np, a_np, wl_desc, world = (R[x] for x in ("elapsed", "status", "timing", "timing_period", "md", "s", "a", "desc", "world"))
     n = world.n
 
@@ -414,6 +419,12 @@ def main():
                 "value": units_per_step * ssteps / single["elapsed"], "unit": "worlds*timesteps/s", "steps": ssteps,
                 "ms_per_step": single["elapsed"] / ssteps * 1e3, "stream_slices": 1,
                 "note": "the same batch and distribution with ONE launch per kernel per step (all worlds of the GPU in one chain, no stream slices)"}
+        if single_call is not None:
+            ssteps = max(1, args.steps // 2)
+            out.setdefault("secondary", {})["single_call"] = {
+                "value": units_per_step * ssteps / single_call["elapsed"], "unit": "worlds*timesteps/s", "steps": ssteps,
+                "ms_per_step": single_call["elapsed"] / ssteps * 1e3, "stream_slices": single_call["slices"],
+                "note": "the same batch and distribution handed to ONE World in one call per pass (the library slices the call itself; every call joins before it returns)"}
         if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(md, s_np, a_np)

@@ -381,8 +381,10 @@ int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, 
  * dense contact kernels are one world per wavefront. */
 int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes);
 /* Batch slicing: the worlds of a call are processed as `slices` contiguous ranges whose kernels overlap on internal HIP
- * streams forked from / joined into the caller's stream (0 = default = 1; max 8; environment NBL_SLICES).  Results do not
- * depend on it; on MI355X it does not pay inside one call (the per-call join), see DESIGN.md.  nbl_slices_for: the number a call with B worlds will use. */
+ * streams forked from / joined into the caller's stream (0 = default: 2 from 4096 worlds on for a model with colliders, else 1;
+ * max 8; environment NBL_SLICES).  Results do not depend on it; every call joins before it returns, so a caller who owns the whole
+ * forward + backward loop gets more from one model handle per slice on its own stream.  nbl_slices_for: the number a
+ * call with B worlds will use. */
 int32_t nbl_set_slices(nbl_model* m, int32_t slices);
 int32_t nbl_slices_for(const nbl_model* m, int64_t B);
 /* enabled = 0: off (and reset); 1: HIP events around every kernel launch; N > 1: around the launches of every N-th forward /

@@ -128,10 +128,12 @@ static void packSpatialInertia(double m, const double* c, const double* I, doubl
 // ---- batch slicing over HIP streams ----------------------------------------------------------------------------------
 // A call can process its worlds as several contiguous slices whose kernels overlap on internal HIP streams (slice 0 on the
 // caller's stream, the others fork from / join into it with events, so the call keeps stream semantics and stays capturable
-// in a hipGraph).  Measured on MI355X at B = 4096: NO gain inside one call (1 slice 5.93, 2 slices 5.88, 4 slices 5.35 M/s) -
-// the join at the end of every forward / backward call is what prevents the useful overlap, which is between the FORWARD of
-// one slice and the BACKWARD of another: callers that own the whole fwd+bwd loop get +16 % by running one World per slice on
-// its own stream (bench.py --streams, tools/batch_slicing_experiment.py).  Default: 1 slice; NBL_SLICES / nbl_set_slices.
+// in a hipGraph).  The join at the end of every forward / backward call prevents the most useful overlap, which is between the
+// FORWARD of one slice and the BACKWARD of another: callers that own the whole fwd+bwd loop get the most by running one World per
+// slice on its own stream (bench.py --streams: 6.86 M/s at B = 4096).  Inside one call, measured on MI355X at the end of round 4
+// (metric distribution, one World): B = 4096: 1 slice 5.26, 2 slices 5.76, 3 slices 5.48, 4 slices 5.20 M/s; B = 8192: 6.36 / 6.85 -
+// two slices let the tail of one slice's launch (its slowest world) overlap with the other's.  Default (auto): 2 slices from 4096
+// worlds for models with colliders, else 1; NBL_SLICES / nbl_set_slices.
 // slices of a rollout: every slice runs ALL its steps on its stream and the slices join only at the end, so the steps of
 // different slices overlap (the per-call join is what makes in-call slicing useless for a single step)
 static int rolloutSlicesFor(const nbl_model* m, int64_t B) {
@@ -141,7 +143,7 @@ static int rolloutSlicesFor(const nbl_model* m, int64_t B) {
   return sl;
 }
 static int slicesFor(const nbl_model* m, int64_t B) {
-  int sl = m->slices > 0 ? m->slices : 1;
+  int sl = m->slices > 0 ? m->slices : ((m->hasContact && B >= 4096) ? 2 : 1);
   if (sl > NBL_MAX_SLICES) sl = NBL_MAX_SLICES;
   while (sl > 1 && B / sl < 256) sl--;
   return sl;
