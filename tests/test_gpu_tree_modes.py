@@ -131,6 +131,37 @@ def test_the_launch_shapes_do_not_change_a_bit(mode, monkeypatch):
         assert torch.equal(ta, tb), (mode, name)
 
 
+def test_a_call_cut_into_stream_slices_gives_the_same_bits_and_can_be_captured():
+    """From 4096 worlds on, a call of a model with colliders is cut into two slices on two HIP streams by default (fork / join events
+    around the caller's stream): next states, status words, warm starts and gradients bit for bit as with one slice and with four, and
+    the sliced step captured in a HIP graph replays to the same bits."""
+    import torch
+    import nimblephysics_amd as na
+    B = 4096
+    md, s, a = contact_inputs("atlas20", B, 17, joint_noise=0.02, vel_noise=0.01, action_noise=0.0)
+    g = np.random.default_rng(6).normal(0, 1, s.shape)
+    out = {}
+    for slices in (0, 1, 4):
+        world = na.World(md, device="cuda:0")
+        world.set_slices(slices)
+        assert world.slices_for(B) == {0: 2, 1: 1, 4: 4}[slices] and world.slices_for(1024) == (1 if slices < 4 else 4)
+        st = world.to_soa(torch.tensor(s, device="cuda:0")); at = world.to_soa(torch.tensor(a, device="cuda:0")); gt = world.to_soa(torch.tensor(g, device="cuda:0"))
+        nxt, sv, status = world.step_soa(st, at)
+        gs, ga = world.backward_soa(sv, gt)
+        out[slices] = (nxt.clone(), status.clone(), world.lcp_cache.clone(), gs.clone(), ga.clone())
+    for slices in (1, 4):
+        for name, ta, tb in zip(("next", "status", "warm start", "grad_state", "grad_action"), out[0], out[slices]):
+            assert torch.equal(ta, tb), (slices, name)
+    assert ((out[0][1] & 0x2) == 0).float().mean() > 0.2
+    world = na.World(md, device="cuda:0")
+    graphed = na.GraphedStep(world, B).capture()
+    graphed.state.copy_(world.to_soa(torch.tensor(s, device="cuda:0"))); graphed.action.copy_(world.to_soa(torch.tensor(a, device="cuda:0")))
+    graphed.grad_next.copy_(world.to_soa(torch.tensor(g, device="cuda:0")))
+    nxt, dstate, daction = graphed.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(nxt, out[0][0]) and torch.equal(dstate, out[0][3]) and torch.equal(daction, out[0][4])
+
+
 FEATURE_MODES = [{"NBL_COOP_TREE": "0"}, {"NBL_COOP_FINAL": "0"}, {"NBL_SAVE_TREE": "0"}, {"NBL_FUSED_DETECT": "0"}, {"NBL_DETECT_SPLIT": "0"}]
 
 
