@@ -84,6 +84,9 @@ DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
   constexpr int KEPT = P == PROF_FWD ? 71 : 31, U = 8;
   const int body = c.lane;
   if (body < c.nbp) {
+    // the articulated inertia (21 of the forward profile's 71 kept rows) has ONE reader per tree: the 6 x 6 solve of a free-joint root
+    // (kernels.hip, k_contact_rows_coop's free-joint block) - the other bodies' rows stay in LDS (30 % of the block's write traffic)
+    const bool keepsAI = !(STORE && P == PROF_FWD) || (body < c.nb && c.bodies[body].jtype == JT_FREE);
     for (int r0 = 0; r0 < KEPT; r0 += U) {
       double tmp[U];
 #pragma unroll
@@ -95,7 +98,7 @@ DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
       for (int u = 0; u < U; u++) {
         const int r = r0 + u;
         if (r < KEPT) {
-          if (STORE) blk[coopRowSlot<P>(r) * c.nbp + body] = tmp[u];
+          if (STORE) { if (keepsAI || r < WS_AI || r >= WS_AI + 21) blk[coopRowSlot<P>(r) * c.nbp + body] = tmp[u]; }
           else c.lds[r * c.nbp + body] = tmp[u];
         }
       }
