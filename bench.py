@@ -202,6 +202,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # one process per GPU, one GPU per process: make a mis-launched job fail here, not report a wrong aggregate
+        assert dist.get_world_size() == args.gpus, f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks"
+        assert torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} devices are visible"
+        assert torch.cuda.current_device() == local_rank, f"rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank}"
+        assert dist.get_rank() == rank
 
     import nimblephysics_amd as na
     from nimblephysics_amd.parallel import shared_parameter_grad
@@ -273,7 +278,7 @@ def main():
         # The timed region = EXACTLY `steps` steps between barrier + synchronize on both sides, max over ranks.  A short region (the
         # driver's --steps 20 is 12 ms) is a noisy sample: it is repeated until `min_seconds` have been timed (every rank takes the
         # same decision from the max-over-ranks time) and the MEDIAN repetition is reported.
-        reps = []
+        reps, rank_min = [], []
         while True:
             t0 = time.perf_counter()
             grad, status = run(steps)
@@ -281,7 +286,10 @@ def main():
             el = time.perf_counter() - t0
             if use_dist:
                 t = torch.tensor([el], dtype=torch.float64, device=dev)
+                tmin = t.clone()
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+                rank_min.append(float(tmin.item()))
                 el = float(t.item())
             reps.append(el)
             assert torch.isfinite(grad).all()
@@ -291,7 +299,7 @@ def main():
         tm = world.get_timing()
         world.set_timing(False)
         st = status.cpu().numpy().astype(np.uint32)
-        return {"elapsed": elapsed, "reps": reps, "status": st, "timing": tm, "timing_period": timing_period, "md": md, "s": s_np, "a": a_np,
+        return {"elapsed": elapsed, "reps": reps, "rank_min": rank_min, "status": st, "timing": tm, "timing_period": timing_period, "md": md, "s": s_np, "a": a_np,
                 "desc": wl_desc, "world": world, "slices": len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))}
 
     has_contact = args.workload.endswith("_contact")
@@ -399,6 +407,11 @@ def main():
                        "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None, "rollout_checkpoint_every": (args.checkpoint_every or None) if args.rollout else None,
                        "saved_record_bytes_per_world_step": int(world._L.nbl_saved_bytes(world._h, B) // B),
                        "rccl_world_size": (dist.get_world_size() if use_dist else 0),
+                       # per-rank spread of the reported (median) repetition: the slowest rank is the one that counts (ms_per_step), the
+                       # fastest says how far apart the ranks are - so that the first real multi-GPU run explains itself
+                       "ranks_ms_per_step": ({"max": elapsed / args.steps * 1e3,
+                                              "min": R["rank_min"][R["reps"].index(elapsed)] / args.steps * 1e3} if use_dist else None),
+                       "devices_visible": torch.cuda.device_count(), "device_of_rank0": torch.cuda.current_device(),
                        "lanes_with_contact": float((st & 0x1).astype(bool).mean()),
                        "lanes_resolved_at_lcp_stage0": float((st & 0x2).astype(bool).mean()) if m_rows else None,
                        "lanes_unresolved": float((st & 0x20).astype(bool).mean()),

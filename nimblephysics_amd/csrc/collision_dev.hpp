@@ -9,7 +9,7 @@
 #pragma once
 #include "spatial_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 constexpr int CT_VERTEX_FACE = 1, CT_FACE_VERTEX = 2, CT_EDGE_EDGE = 3, CT_SPHERE_BOX = 4, CT_BOX_SPHERE = 5, CT_SPHERE_SPHERE = 6;   // Contact.hpp:45-61
 constexpr int CT_PIPE_SPHERE = 13, CT_SPHERE_PIPE = 14, CT_PIPE_PIPE = 15;   // capsule contacts, Contact.hpp:72-74
@@ -438,4 +438,4 @@ DEV int sphereCapsulePair(bool sphereFirst, double rSphere, const T12& Ts, doubl
   return 1;
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -21,7 +21,7 @@
 //     (b) -d(adj^T M(q) acc)/dq for four (adj, acc) pairs: one reverse-mode Newton-Euler sweep each (v = 0, no gravity).
 #include "lcp_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 // Recompute the forward tree state, decide whether the contact adjoint is active for this world (any clamping row),
 // and, if so, lambda1 = M^-1 g (two tree sweeps) for the dense kernel that follows.
@@ -248,4 +248,4 @@ __global__ __launch_bounds__(64) void k_bwd_final(DevModel mdl, const DevBody* _
   reverseSweep(c, q, v, tau, gnext, gvp, qx, gstate, gstate + (int64_t)n * B, gaction);
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -5,7 +5,7 @@
 #include "collision_dev.hpp"
 #include "lcp_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 DEV double& svAt(double* saved, int row, int64_t B, int64_t b) { return saved[(int64_t)row * B + b]; }
 // the world-major dense block of world b (SavedLayout)
@@ -278,4 +278,4 @@ __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBo
                     keptP, clipBuf, stage);
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -10,7 +10,7 @@
 #pragma once
 #include "coop_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 template <int I> struct IntTag { static constexpr int value = I; };
 
@@ -1072,4 +1072,4 @@ DEV void coopCascadeSelect(const W& w, CoopLds& S, const CoopRow& R, double X0, 
   out.X = X; out.cfm = cfm; out.st = st; out.pinvValid = pinvValid;
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

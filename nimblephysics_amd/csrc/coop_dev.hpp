@@ -30,7 +30,7 @@
 #define NBL_PHASE(k) do { } while (0)   // developer phase stamps (model_dev.hpp), compiled out
 #endif
 
-namespace nbl {
+namespace NBL_NS {
 
 // A value the optimiser must treat as new at this point: keeps loop-invariant 24-entry constants (the identity columns of the
 // carried block, ...) from being hoisted out of the standardisation loop and parked in 48 VGPRs across both factorisations.
@@ -1000,4 +1000,4 @@ DEV void coopStage0(const W& w, CoopLds& S, const CoopRow& R, bool haveCache, do
   out.X = X; out.K = K; out.ok = ok; out.pinvValid = ok && pinvValid;
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -8,7 +8,7 @@
 #include "coop_dantzig_dev.hpp"
 #include "coop_wave_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 // Scratch rows of an unresolved world between k_contact_solve_coop, k_contact_cascade_stages and k_contact_cascade_final
 // (rows LW_JA .. of the per-world contact scratch):
@@ -1422,4 +1422,4 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_BWDB) void k_bwd_contact_b_coop
   NBL_PHASE(55);
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -9,7 +9,7 @@
 // record ([slot][nbp] per world = the LDS image, copied with coalesced 8-byte-per-lane streams).
 #include "coop_wave_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 constexpr int TREE_WPB_MAX = 8;   // worlds (wavefronts) per workgroup: they share one LDS copy of the model constants
 
@@ -740,4 +740,4 @@ __global__ __launch_bounds__(256) void k_tree_to_lanes(const double* __restrict_
   }
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "spatial_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 
 
@@ -54,4 +54,4 @@ DEV int64_t coopWorld(uint32_t bid, uint32_t nblk) {
   return (int64_t)bid;
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -31,7 +31,7 @@
 #include "model_dev.hpp"
 #include "spatial_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 struct Ctx {
   const DevBody* __restrict__ bodies;
@@ -721,4 +721,4 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ sr
   }
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -4,7 +4,7 @@
 #pragma once
 #include "spatial_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 #ifndef NBL_MAXC
 #define NBL_MAXC 8
@@ -29,4 +29,4 @@ struct LaneMem {
 
 constexpr int RC_NOT_CLAMPING = 0, RC_CLAMPING = 1, RC_UPPER_BOUND = 2;
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -40,7 +40,12 @@
 #define NBL_W_BFINAL 1
 #endif
 
-namespace nbl {
+// The device namespace of this instantiation of the library (the library is built several times from one set of sources, see
+// abi_variants.h: every build names its own - -DNBL_NS=nbl_c16 - so that their kernels and constants never meet at link time).
+#ifndef NBL_NS
+#define NBL_NS nbl
+#endif
+namespace NBL_NS {
 
 // Developer instrumentation (tools/phase_timing.py builds with -DNBL_PHASE_TIMING): cycle stamps of the first wavefront of a
 // launch at phase boundaries of the tree kernels.  Compiled out of the shipped library.
@@ -196,4 +201,4 @@ constexpr int LB_FLAG = LB_COEF + MAX_ROWS * 8;            // 1: contact adjoint
 constexpr int LB_VX = LB_FLAG + 1;                         // extra velocity cotangent: the bounce approximation applied to velPos^T gq' (k_bwd_bounce)
 constexpr int LB_TOTAL = LB_VX + MAX_DOF_CONTACT;
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -22,7 +22,7 @@
 #include "coop_tree.hip"
 #include "inertia_backward.hip"
 
-using namespace nbl;
+using namespace NBL_NS;
 
 namespace {
 thread_local std::string g_err;

@@ -9,7 +9,12 @@
 
 #define DEV __device__ __forceinline__
 
-namespace nbl {
+// The device namespace of this instantiation of the library (the library is built several times from one set of sources, see
+// abi_variants.h: every build names its own - -DNBL_NS=nbl_c16 - so that their kernels and constants never meet at link time).
+#ifndef NBL_NS
+#define NBL_NS nbl
+#endif
+namespace NBL_NS {
 
 struct V3 { double x, y, z; };
 struct M3 { double m[9]; };            // row-major
@@ -352,4 +357,4 @@ DEV void se3IntegrationVjp(V3 r, V3 w, V3 vl, double dt, V3 grn, V3 gpn, double 
 }
 DEV double pick3(V3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 
-}  // namespace nbl
+}  // namespace NBL_NS

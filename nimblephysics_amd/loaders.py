@@ -267,12 +267,13 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
     g = phys.find("gravity") if phys is not None else None
     gravity = tuple(float(x) for x in g.text.split()) if g is not None else (0.0, -9.81, 0.0)
     bodies, boxes = [], []
+    welded_dofs = []      # (skeleton, joint, DOFs) of every joint of an immobile skeleton: coordinates the reference's state vector has and this one does not
     for sk_index, sk in enumerate(world.findall("skeleton")):
         if skeletons is not None and sk.get("name") not in skeletons:
             continue
         skel_T = _skel_T(sk)                                     # optional skeleton frame (:948-955)
         mob = sk.find("mobile")
-        is_mobile = mob is None or mob.text.strip().lower() not in ("false", "0")
+        is_mobile = mob is None or (mob.text or "").strip().lower() not in ("false", "0")   # (an empty <mobile/> reads as mobile, like the reference's default)
         if not is_mobile and immobile != "weld":
             raise ValueError(f"{path}: skeleton {sk.get('name')} is immobile (<mobile>false</mobile>); immobile=\"weld\" loads it welded to the world")
         bel = {b.get("name"): b for b in sk.findall("body")}
@@ -475,6 +476,8 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
                         else:
                             kw.pop(key, None)
                 if not is_mobile:                 # an immobile skeleton: every joint frozen at its zero configuration
+                    if ndofs:
+                        welded_dofs.append((sk.get("name"), j.get("name"), int(ndofs)))
                     jtype, kw, axis = "weld", {}, (0.0, 0.0, 1.0)
                 mass, com, I6 = inertial(bel[cn])
                 base = len(bodies)
@@ -490,6 +493,13 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
     if name is None:
         name = os.path.splitext(os.path.basename(path))[0]
     md = ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=(max_contacts or 0) if boxes else 0)
+    # coordinates of immobile skeletons: part of the reference World's getPositions() / state vector, NOT of this model's (loaded welded).
+    # Callers porting reference state vectors must drop them: md.welded_dofs lists them in the reference's order; warned about once per load.
+    md.welded_dofs = welded_dofs
+    if welded_dofs:
+        import warnings
+        warnings.warn(f"{path}: {sum(d for _, _, d in welded_dofs)} coordinate(s) of immobile skeleton(s) "
+                      f"{sorted({s_ for s_, _, _ in welded_dofs})} are welded and leave the state vector (ModelDescription.welded_dofs)", stacklevel=2)
     if boxes and max_contacts is None:          # (not said: 8 or 16 by what the collider pairs of the world can hold, ModelDescription.suggest_max_contacts)
         md.max_contacts = md.suggest_max_contacts()
     if md.capsule_meets_box():

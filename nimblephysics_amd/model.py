@@ -457,8 +457,8 @@ class ModelDescription:
 
     def suggest_max_contacts(self) -> int:
         """Contact slots per world for a description that does not say (the loaders' default): 8 - the 24-row build of the library, the fast
-        one - when the collider pairs that can meet cannot hold more than 8 contacts in their usual configurations (a face of a box on
-        another box: 4 points; every sphere / capsule pair: 1 or 2), else 16, the most the device path carries (the reference itself keeps
+        one - when the collider pairs that can meet cannot hold more than 8 contacts (a face of a box on another box: up to 8 points,
+        dBoxBox's clipped octagon; every sphere / capsule pair: 1 or 2) - i.e. ONE box pair, or spheres and capsules -, else 16, the most the device path carries (the reference itself keeps
         every contact, ConstraintSolver.cpp:563-606; a world that exceeds the slots is truncated and flagged NBL_ST_CONTACT_OVERFLOW).
         Models with more than 16 colliders or 32 collider pairs run the 48-row build whatever this says."""
         if not self.boxes:
@@ -469,7 +469,11 @@ class ModelDescription:
         for i, bi in enumerate(m.boxes):
             for bj in m.boxes[i + 1:]:
                 if m.colliders_are_tested(bi, bj, skel):
-                    est += 4 if (bi.shape == "box" and bj.shape == "box") else (2 if (bi.shape == "capsule" and bj.shape == "capsule") else 1)
+                    # a box pair: 4 points for a face on a face in line, up to 8 when the faces are turned against each other (the clipped
+                    # incident face is an octagon: dBoxBox keeps every point, DARTCollide.cpp:1384-1448 - the cull to 4 is commented out there)
+                    # (a box on a world-fixed box - a foot on the ground - is counted with 4: the ground's face contains the other one)
+                    both_move = bi.body >= 0 and bj.body >= 0
+                    est += (8 if both_move else 4) if (bi.shape == "box" and bj.shape == "box") else (2 if (bi.shape == "capsule" and bj.shape == "capsule") else 1)
         return 8 if est <= 8 else 16
 
     def capsule_meets_box(self) -> bool:

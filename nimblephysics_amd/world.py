@@ -121,9 +121,17 @@ class World:
         return self.model.action_map
 
     def setActionSpace(self, mapping: Sequence[int]):
-        self.model.set_action_space(mapping)
-        self.description.set_action_space(mapping)
-        self._create_handle()                              # re-upload the constants (the old handle is destroyed, not leaked)
+        snapshot = [list(md._action_map) if md._action_map is not None else None for md in self._descriptions()]
+        try:
+            self.model.set_action_space(mapping)
+            self.description.set_action_space(mapping)
+            self._create_handle()                          # re-upload the constants (the old handle is destroyed, not leaked)
+        except Exception:
+            # the library refused the new handle (or the mapping is out of bounds): the World keeps its old handle, so it must keep the
+            # action map that handle was built with (like setPositionLimitEnforced / setSelfCollisionCheck roll their flags back)
+            for md, am in zip(self._descriptions(), snapshot):
+                md._action_map = am
+            raise
         self._action = None
         if self._wrt_mass.entries:                         # the registered mass parameters survive the re-upload
             self._push_inertia_params()

@@ -65,6 +65,8 @@ def _declare(lib):
     lib.nbo_set_lcp_forced.restype = None
     lib.nbo_set_lcp_cache_slots.argtypes = [C.c_void_p, C.c_int]
     lib.nbo_set_lcp_cache_slots.restype = None
+    lib.nbo_set_exact_position_jacobians.argtypes = [C.c_void_p, C.c_int]
+    lib.nbo_set_exact_position_jacobians.restype = None
     lib.nbo_get_lcp_cache.restype = C.c_int
     lib.nbo_mass_matrix.argtypes = [C.c_void_p, pd, pd]
     lib.nbo_coriolis_gravity.argtypes = [C.c_void_p, pd, pd, pd]
@@ -237,6 +239,15 @@ class OracleWorld:
         """The LCP cache (set_lcp_cache / get_lcp_cache / step_batch's lcp_in, lcp out) in the DEVICE's format: three entries per
         constraint - a frictionless contact and a joint-limit row use the first - instead of the reference's 3 / 1 / 1 rows."""
         self._lib.nbo_set_lcp_cache_slots(self._h, 1 if on else 0)
+
+    def set_exact_position_jacobians(self, on=True, doubles=False):
+        """Test instrument, not the reference's behaviour: the position-integration Jacobians (posPos / velPos) of free and ball joints by
+        exact forward-mode differentiation of expMapRot / logMap (their branches included) instead of the reference's central differences
+        (FreeJoint.cpp:950-1007, BallJoint.cpp:351-408), which lose digits like 1 / gap^2 towards a rotation angle of pi.  With it the
+        oracle is the reference algorithm with ONE known numerical weakness removed: what tests/parity.py::gradient_tolerance rests on.
+        Evaluated in extended precision; doubles=True evaluates the same formulas in doubles, which is good to ~eps / gap^3 only (two
+        O(1 / gap) terms cancel) - the accuracy any double-precision analytic derivative of this map, the device's included, can have."""
+        self._lib.nbo_set_exact_position_jacobians(self._h, (2 if doubles else 1) if on else 0)
 
     def set_lcp_forced(self, x=None, cfm_stage=False):
         """Test instrument, not the reference's behaviour: x (one entry per LCP row) stands in for the OUTPUT of the solver stages 1 - 3

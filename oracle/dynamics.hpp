@@ -66,6 +66,9 @@ struct Model {
   // Interchange format of the LCP cache with the device (not the reference's): three entries per constraint - a frictionless contact
   // and a joint-limit row use the first, the other two are zero - instead of the reference's 3 / 1 / 1 rows.
   bool lcpCacheSlots = false;
+  // Third test instrument (see posJacobiansExact): the position-integration Jacobians of free / ball joints by exact forward-mode
+  // differentiation instead of the reference's central differences (FreeJoint.cpp:950-1007, BallJoint.cpp:351-408).
+  int exactPosJacobians = 0;            // 1: in extended precision (the instrument); 2: the same formulas in doubles (shows the eps / gap^3 conditioning)
   std::vector<s_t> lcpForced;
   bool lcpForcedCfm = false;            // ... as the output of stage 2 (the fallback CFM on the diagonal, PGS) instead of stage 1
   uint64_t lcpNoiseSeed = 0;
@@ -569,7 +572,110 @@ inline void integratePositions(const Model& m, const s_t* q, const s_t* v, s_t d
 // World::getPosPosJacobian / getVelPosJacobian (World.cpp:2415-2446): block diagonal per joint; identity
 // resp. dt*I for R^n joints (GenericJoint.hpp:1428-1444), central finite differences for the free
 // joint (FreeJoint.cpp:950-1007: eps 1e-6 for pos, 1e-7 for vel) — restated literally, FD included.
+// ---- TEST INSTRUMENT (Model::exactPosJacobians; NOT the reference's behaviour): the same two Jacobians by differentiating the very
+// formulas integratePositions composes - expMapRot (Geometry.cpp:539, with its Taylor branch below 1e-3) and logMap (Geometry.cpp:720,
+// with its small-angle branch) - in FORWARD mode, entry by entry, in EXTENDED precision (long double: 64-bit mantissa on x86).
+// Two things go wrong next to the log-map singularity (next rotation angle within `gap` of pi), and the instrument avoids both:
+//   * the reference's central differences (eps 1e-6) divide the rounding error of logMap, ~1e-16 / gap^2, by 1e-6: off by ~5e-9 / gap^2;
+//   * ANY evaluation of the analytic derivative in doubles cancels two O(1 / gap) terms (alpha' dtheta vee(R - R^T) against
+//     alpha vee(dR - dR^T)) into an O(1) result: good to ~eps / gap^3 (this formula in doubles: 3e-7 at gap = 2e-3 against an 80-bit
+//     five-point stencil; the device's reverse mode of the same formulas: 1.7e-7) - hence the extended precision here (1e-10 there).
+// (The closed form J_r^-1(r') E^T J_r(r) of the IDEAL exponential and logarithm is well conditioned but is not the derivative of THIS
+// function: the Taylor branch of expMapRot is not exactly orthogonal, logMap turns that 1e-11 into 1e-9 of angle, which changes with q:
+// 1.5e-6 apart at gap = 2e-3, measured in 80-bit arithmetic on both sides.)
+// tests/test_oracle_exact_pos_jacobians.py pins it against that stencil; tests/test_gpu_contact.py::test_cfg4_box_stack_8192_worlds
+// uses it to PROVE that the worlds of cfg4 the device "misses" next to the singularity are the finite differences' error: with the
+// switch on they agree with the device, with it off the reported errors reappear (tests/parity.py::gradient_tolerance cites both).
+template <class X>
+struct xpT {
+struct M3 { X m[9]; X& operator()(int r, int c) { return m[3 * r + c]; } const X& operator()(int r, int c) const { return m[3 * r + c]; } };
+struct V3x { X v[3]; };
+static inline M3 mul(const M3& a, const M3& b) { M3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j); return r; }
+static inline M3 add(const M3& a, const M3& b) { M3 r; for (int i = 0; i < 9; i++) r.m[i] = a.m[i] + b.m[i]; return r; }
+static inline M3 scale(X s, const M3& a) { M3 r; for (int i = 0; i < 9; i++) r.m[i] = s * a.m[i]; return r; }
+static inline M3 eye() { M3 r; for (int i = 0; i < 9; i++) r.m[i] = (i % 4 == 0) ? X(1.0L) : X(0.0L); return r; }
+static inline M3 skew(const V3x& a) { M3 r; r.m[0] = 0; r.m[1] = -a.v[2]; r.m[2] = a.v[1]; r.m[3] = a.v[2]; r.m[4] = 0; r.m[5] = -a.v[0]; r.m[6] = -a.v[1]; r.m[7] = a.v[0]; r.m[8] = 0; return r; }
+static inline X nrm(const V3x& a) { return std::sqrt(a.v[0] * a.v[0] + a.v[1] * a.v[1] + a.v[2] * a.v[2]); }
+static inline M3 expMapRot(const V3x& q) {                              // Geometry.cpp:539-553, same branches
+  const X theta = nrm(q);
+  const M3 Q = skew(q), Q2 = mul(Q, Q);
+  if (theta < X(1.0e-3L)) return add(add(eye(), Q), scale(X(0.5L), Q2));
+  return add(add(eye(), scale(std::sin(theta) / theta, Q)), scale((1 - std::cos(theta)) / (theta * theta), Q2));
+}
+static inline M3 dExpMapRot(const V3x& q, const V3x& dq) {              // d expMapRot(q)[dq]
+  const X theta = nrm(q);
+  const M3 Q = skew(q), D = skew(dq);
+  const M3 QD = add(mul(Q, D), mul(D, Q));
+  if (theta < X(1.0e-3L)) return add(D, scale(X(0.5L), QD));           // the branch expMapRot takes there: I + Q + Q^2 / 2
+  const X sn = std::sin(theta), cs = std::cos(theta);
+  const X a = sn / theta, b = (1 - cs) / (theta * theta);
+  const X dth = (q.v[0] * dq.v[0] + q.v[1] * dq.v[1] + q.v[2] * dq.v[2]) / theta;
+  const X da = (cs / theta - sn / (theta * theta)) * dth;
+  const X db = (sn / (theta * theta) - 2 * (1 - cs) / (theta * theta * theta)) * dth;
+  return add(add(scale(da, Q), scale(a, D)), add(scale(db, mul(Q, Q)), scale(b, QD)));
+}
+static inline V3x dLogMap(const M3& R, const M3& dR) {                  // d logMap(R)[dR] on the branches logMap takes away from pi (Geometry.cpp:720-745)
+  const X DART_EPSILON = 1e-6L;
+  X c = X(0.5L) * (R(0, 0) + R(1, 1) + R(2, 2) - X(1.0L));
+  c = c > X(1.0L) ? X(1.0L) : (c < -X(1.0L) ? -X(1.0L) : c);
+  const X theta = std::acos(c);
+  const X dc = X(0.5L) * (dR(0, 0) + dR(1, 1) + dR(2, 2));
+  const X w[3] = {R(2, 1) - R(1, 2), R(0, 2) - R(2, 0), R(1, 0) - R(0, 1)};
+  const X dw[3] = {dR(2, 1) - dR(1, 2), dR(0, 2) - dR(2, 0), dR(1, 0) - dR(0, 1)};
+  X alpha, dalpha;
+  if (theta > DART_EPSILON) {
+    const X sn = std::sin(theta), cs = std::cos(theta);
+    alpha = X(0.5L) * theta / sn;
+    dalpha = X(0.5L) * (sn - theta * cs) / (sn * sn) * (-dc / sn);  // theta = acos(c)
+  } else {
+    alpha = X(0.5L) + (X(1.0L) / X(12.0L)) * theta * theta;
+    dalpha = -(X(1.0L) / X(6.0L)) * dc;                                // theta^2 ~ 2 (1 - c)
+  }
+  V3x o;
+  for (int k = 0; k < 3; k++) o.v[k] = dalpha * w[k] + alpha * dw[k];
+  return o;
+}
+};
+template <class X>
+inline void posJacobiansExactT(const Model& m, const s_t* q, const s_t* v, s_t dt, MatX& posPos, MatX& velPos) {
+  typedef xpT<X> xp;
+  posPos = identityX(m.n);
+  velPos = MatX(m.n, m.n);
+  for (int i = 0; i < m.n; i++) velPos(i, i) = dt;
+  for (int i = 0; i < m.nb; i++) {
+    const Body& b = m.bodies[i];
+    if (b.jtype != NBL_JOINT_FREE && b.jtype != NBL_JOINT_BALL) continue;
+    const int o = b.dofOff;
+    const bool freeJ = b.jtype == NBL_JOINT_FREE;
+    const X dtx = dt;
+    const typename xp::V3x r = {{q[o], q[o + 1], q[o + 2]}}, wdt = {{v[o] * dtx, v[o + 1] * dtx, v[o + 2] * dtx}};
+    const typename xp::M3 R = xp::expMapRot(r), E = xp::expMapRot(wdt), Rn = xp::mul(R, E);
+    const X u[3] = {freeJ ? v[o + 3] * dtx : X(0.0L), freeJ ? v[o + 4] * dtx : X(0.0L), freeJ ? v[o + 5] * dtx : X(0.0L)};
+    for (int j = 0; j < 3; j++) {
+      typename xp::V3x e = {{0, 0, 0}}, edt = {{0, 0, 0}};
+      e.v[j] = X(1.0L); edt.v[j] = dtx;
+      const typename xp::M3 dRq = xp::dExpMapRot(r, e);                   // d R / d r_j
+      const typename xp::V3x drq = xp::dLogMap(Rn, xp::mul(dRq, E));
+      const typename xp::M3 dEw = xp::dExpMapRot(wdt, edt);               // d E / d w_j
+      const typename xp::V3x drw = xp::dLogMap(Rn, xp::mul(R, dEw));
+      for (int k = 0; k < 3; k++) { posPos(o + k, o + j) = (s_t)drq.v[k]; velPos(o + k, o + j) = (s_t)drw.v[k]; }
+      if (freeJ) {
+        // p' = p + R(r) (v_lin dt)  (Qnext = Q * D, FreeJoint.cpp:922-929)
+        for (int k = 0; k < 3; k++) {
+          posPos(o + 3 + k, o + j) = (s_t)(dRq(k, 0) * u[0] + dRq(k, 1) * u[1] + dRq(k, 2) * u[2]);   // d p' / d r_j
+          posPos(o + k, o + 3 + j) = 0.0;                        // d r' / d p_j
+          posPos(o + 3 + k, o + 3 + j) = k == j ? 1.0 : 0.0;     // d p' / d p_j
+          velPos(o + 3 + k, o + j) = 0.0;                        // d p' / d w_j
+          velPos(o + k, o + 3 + j) = 0.0;                        // d r' / d v_lin_j
+          velPos(o + 3 + k, o + 3 + j) = (s_t)(R(k, j) * dtx);   // d p' / d v_lin_j
+        }
+      }
+    }
+  }
+}
 inline void posJacobians(const Model& m, const s_t* q, const s_t* v, s_t dt, MatX& posPos, MatX& velPos) {
+  if (m.exactPosJacobians == 1) { posJacobiansExactT<long double>(m, q, v, dt, posPos, velPos); return; }
+  if (m.exactPosJacobians == 2) { posJacobiansExactT<double>(m, q, v, dt, posPos, velPos); return; }   // the same formulas in doubles: what ANY double-precision analytic derivative can reach (eps / gap^3)
   posPos = identityX(m.n);
   velPos = MatX(m.n, m.n);
   for (int i = 0; i < m.n; i++) velPos(i, i) = dt;

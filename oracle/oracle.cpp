@@ -238,6 +238,9 @@ void nbo_set_lcp_noise(void* h, int ulps, uint64_t seed, int absolute) {
 }
 // LCP cache in the device's interchange format (Model::lcpCacheSlots)
 void nbo_set_lcp_cache_slots(void* h, int on) { ((Oracle*)h)->model.lcpCacheSlots = on != 0; }
+// test instrument, not the reference's behaviour (dynamics.hpp::posJacobiansExact): exact position-integration Jacobians of free / ball joints
+// (0 off, 1 in extended precision, 2 the same formulas in doubles)
+void nbo_set_exact_position_jacobians(void* h, int on) { ((Oracle*)h)->model.exactPosJacobians = on; }
 // test instrument (Model::lcpForced): len <= 0 switches it off
 void nbo_set_lcp_forced(void* h, const double* x, int len, int cfmStage) {
   Oracle* o = (Oracle*)h;

@@ -5,7 +5,7 @@
 #include "lane_lcp_statement.hpp"
 #include "wave_emu.hpp"
 
-using namespace nbl;
+using namespace NBL_NS;
 
 extern "C" {
 // (every "24" below reads MAXR: the shim is built twice, for the 24-row and - -DNBL_MAXC=16 - the 48-row instantiation of the device code)

@@ -6,7 +6,7 @@
 #pragma once
 #include "lcp_dev.hpp"
 
-namespace nbl {
+namespace NBL_NS {
 
 // ---- factorisation of a c x c matrix stored row-major with leading dimension ld at offset off ----
 struct CodFactor {
@@ -307,4 +307,4 @@ DEV bool laneStage0(const LcpView& V, const LaneMem& L, bool haveCache, double* 
   return standardizeLoop(V, L, F, X, Bv, colNorm, 0.0, false, guessMask, K);
 }
 
-}  // namespace nbl
+}  // namespace NBL_NS

@@ -74,16 +74,55 @@ def log_map_gap(md, next_state):
     return gap
 
 
-FD_COEF, FD_GAP, FD_CAP = 5e-9, 0.15, 3e-3
+FD_GAP = 0.3             # within this distance of the log-map singularity the reference's finite differences (off by 1e-9 / gap^2, at worst 4 x that) come
+                         # within a factor two of the 1e-7 every world is held to
+DBL_COEF, DBL_CAP = 32 * EPS, 1e-3
 
 
 def gradient_tolerance(md, next_state, tol):
-    """Per-world tolerance of the GRADIENT blocks: `tol`, except within FD_GAP of the log-map singularity of a free / ball joint, where the
-    reference's own finite-difference Jacobian is only good to ~FD_COEF / gap^2 (measured on cfg4: 2e-7 at 0.05 rad, 4e-5 at 0.004)."""
+    """Per-world tolerance of the STATE-gradient blocks against the oracle WITH its exact-derivative instrument (see below): `tol`, except
+    where the next rotation angle of a free / ball joint is within a few 1e-3 rad of pi - there ANY double-precision evaluation of the
+    analytic derivative of logMap(R exp(w dt)) cancels two O(1 / gap) terms into an O(1) result and is good to ~eps / gap^3 only: the
+    oracle's own instrument evaluated in doubles is off by up to 19 eps / gap^3 (median 2) from its extended-precision evaluation
+    (oracle.set_exact_position_jacobians(doubles=True); 400 cfg4 worlds with gaps 3e-4 .. 5e-2), the device's reverse mode by
+    1.7e-7 at gap = 2e-3 (6 eps / gap^3) from an 80-bit stencil.  Held to max(tol, 32 eps / gap^3): 1e-7 from gap = 4.1e-3 on.
+
+    History: until round 4 this function waived 5e-9 / gap^2 within 0.15 rad of pi, on the ARGUMENT that the reference's central-difference
+    Jacobians (FreeJoint.cpp:950-1007, BallJoint.cpp:351-408, restated literally in the oracle) are the inaccurate side.  Now the oracle
+    carries an exact-derivative switch (oracle/dynamics.hpp::posJacobiansExact, pinned against an 80-bit stencil on the CPU:
+    tests/test_oracle_exact_pos_jacobians.py) and the argument is a TEST: tests/test_gpu_contact.py::test_cfg4_box_stack_8192_worlds
+    shows the cfg4 worlds that miss 1e-7 against the finite-difference oracle collapse to the tolerance above with the switch on, and
+    that the reported errors (1e-3 at worst) reappear with it off."""
     gap = log_map_gap(md, next_state)
     with np.errstate(divide="ignore"):
-        fd = np.minimum(FD_COEF / np.maximum(gap, 1e-12) ** 2, FD_CAP)
-    return np.where(gap < FD_GAP, np.maximum(tol, fd), tol)
+        dbl = np.minimum(DBL_COEF / np.maximum(gap, 1e-12) ** 3, DBL_CAP)
+    return np.maximum(tol, dbl)
+
+
+def exact_reference_near_the_singularity(ow, md, s, a, g, ref, lcp=None, lcp_len=None):
+    """ref with the gradients of the worlds within FD_GAP of the log-map singularity of a free / ball joint replaced by the oracle's
+    result WITH its exact-derivative instrument (the forward pass - next state, status - does not depend on it).  Returns (ref', mask of
+    those worlds, their largest state-gradient difference between the two modes: the size of the reference's finite-difference error)."""
+    near = log_map_gap(md, ref["next"]) < FD_GAP
+    if not near.any():
+        return ref, near, 0.0
+    kw = {}
+    if lcp is not None:
+        kw = {"lcp_in": lcp[near], "lcp_len_in": lcp_len[near]}
+    ow.set_exact_position_jacobians(True)
+    try:
+        rex = ow.step_batch(s[near], a[near], g[near], threads=8, **kw)
+    finally:
+        ow.set_exact_position_jacobians(False)
+    out = dict(ref)
+    fd_err = 0.0
+    for k in ("grad_state", "grad_action"):
+        out[k] = np.array(ref[k], copy=True)
+        if k == "grad_state" and out[k].shape[1]:
+            sc = np.maximum(np.abs(rex[k]).max(1), 1e-300)
+            fd_err = float((np.abs(rex[k] - out[k][near]).max(1) / sc).max())
+        out[k][near] = rex[k]
+    return out, near, fd_err
 
 
 def assert_match_or_reference_unstable(tag, ow, s, a, g, dev, ref, tol, lcp=None, lcp_len=None, n_perturb=64, closeness=0.1, ulps=1,
@@ -93,15 +132,20 @@ def assert_match_or_reference_unstable(tag, ow, s, a, g, dev, ref, tol, lcp=None
     result must be one of the oracle's outcomes: within `tol` of a perturbed run ("tol" branch), or - where those outcomes form a
     continuum - at least 1 / `closeness` times closer to one of them than they scatter ("closeness" branch).  The closeness branch is
     BOUNDED: at most `max_by_closeness` worlds may need it (default: 2 worlds or 0.5 % of the batch).  fd_model: the model description -
-    the gradients of worlds next to the log-map singularity of a free / ball joint are then held to the accuracy of the reference's own
-    finite differences there (gradient_tolerance), everything else to `tol`.  only: a mask of the worlds to judge.  Prints how many
+    the gradients of worlds within FD_GAP of the log-map singularity of a free / ball joint are then judged against the oracle WITH its
+    exact-derivative instrument instead of the reference's finite differences (exact_reference_near_the_singularity), at `tol` - up to
+    the conditioning of doubles a few 1e-3 rad from pi (gradient_tolerance); everything else against the oracle as it is, at `tol`.  only: a mask of the worlds to judge.  Prints how many
     worlds took which branch and returns (unstable worlds, worlds that needed the closeness branch)."""
     for k in KEYS:
         assert np.isfinite(dev[k]).all() and np.isfinite(ref[k]).all(), (tag, k, "non-finite values", int((~np.isfinite(dev[k])).sum()), int((~np.isfinite(ref[k])).sum()))
+    near = np.zeros(len(ref["next"]), dtype=bool)
+    fd_err = 0.0
+    if fd_model is not None:
+        ref, near, fd_err = exact_reference_near_the_singularity(ow, fd_model, s, a, g, ref, lcp, lcp_len)
     errs, scales = world_errors(dev, ref)
     B = len(errs["next"])
     tolg = gradient_tolerance(fd_model, ref["next"], tol) if fd_model is not None else np.full(B, tol)
-    tols = {"next": np.full(B, tol), "grad_state": tolg, "grad_action": tolg}
+    tols = {"next": np.full(B, tol), "grad_state": tolg, "grad_action": np.full(B, tol)}   # (the positions do not depend on the action)
     excess = np.maximum.reduce([errs[k] / tols[k] for k in KEYS])           # > 1: above the tolerance of that output in that world
     worst = np.maximum.reduce([errs[k] for k in KEYS])
     if only is not None:
@@ -116,7 +160,12 @@ def assert_match_or_reference_unstable(tag, ow, s, a, g, dev, ref, tol, lcp=None
         if lcp is not None:
             kw = {"lcp_in": np.repeat(lcp[wd][None], n_perturb, 0) * (1.0 + rng.integers(-ulps, ulps + 1, (n_perturb, lcp.shape[1])) * EPS),
                   "lcp_len_in": np.repeat(lcp_len[wd], n_perturb)}
-        r = ow.step_batch(sp, np.repeat(a[wd][None], n_perturb, 0), np.repeat(g[wd][None], n_perturb, 0), threads=8, **kw)
+        if near[wd]:
+            ow.set_exact_position_jacobians(True)
+        try:
+            r = ow.step_batch(sp, np.repeat(a[wd][None], n_perturb, 0), np.repeat(g[wd][None], n_perturb, 0), threads=8, **kw)
+        finally:
+            ow.set_exact_position_jacobians(False)
         nz = [k for k in KEYS if dev[k].shape[1]]
         tw = float(tolg[wd])
         dist = np.maximum.reduce([(np.abs(r[k] - dev[k][wd][None]) / scales[k][wd][None]).max(1) for k in nz])
@@ -130,7 +179,8 @@ def assert_match_or_reference_unstable(tag, ow, s, a, g, dev, ref, tol, lcp=None
             by_closeness += 1
     near_pi = int((tolg > tol).sum())
     print(f"[{tag}] worlds above 1e-7 / above {tol:g} (per world and block): {(worst > 1e-7).sum()} / {(worst > tol).sum()} of {B} (max {worst.max():.2e})"
-          + (f"; {near_pi} worlds next to a log-map singularity held to the reference's finite-difference accuracy" if near_pi else "")
+          + (f"; {int(near.sum())} worlds within {FD_GAP} rad of a log-map singularity judged against the oracle with exact position Jacobians "
+             f"(its finite differences are off by up to {fd_err:.1e} there), {near_pi} of them within the eps / gap^3 range of doubles" if near.any() else "")
           + f"; reference-unstable (oracle flips under {ulps}-ulp perturbations): {len(bad)}, device within tol of one of its outcomes: {by_tol}, "
           f"accepted by the closeness branch: {by_closeness}")
     if max_unstable is not None:

@@ -181,15 +181,20 @@ def test_edge_edge_contact_gradients_box_over_the_rim():
     assert np.array_equal(st & stage_bits, ost & stage_bits)
     assert ((st & 0x2) != 0).mean() > 0.9
     assert errs["next"].max() < TOL
-    # yaw ~ U(-pi, pi): near |yaw| = pi the oracle's central-difference free-joint Jacobians (FreeJoint.cpp:950-1007,
-    # restated literally) lose accuracy (d logMap blows up like 1 / (pi - |yaw|)^2); the kernels use the exact reverse-mode expression.
-    # Away from the singularity every world is held to 1e-7 (per world and block), towards it to the accuracy the reference's quotient has.
-    yaw = np.abs(world._parity["s"][:, 1])
-    gap = np.pi - yaw
-    for lo, hi, tol in ((0.5, 4.0, TOL), (0.1, 0.5, 1e-6), (0.0, 0.1, 1e-4)):
-        sel = (gap >= lo) & (gap < hi)
-        print(f"[edge-edge over the rim] pi - |yaw| in [{lo}, {hi}): {int(sel.sum())} worlds, grad_state max {errs['grad_state'][sel].max() if sel.any() else 0:.2e}")
-        assert not sel.any() or errs["grad_state"][sel].max() < tol, (lo, hi, float(errs["grad_state"][sel].max()))
+    # yaw ~ U(-pi, pi): near |yaw| = pi the oracle's central-difference free-joint Jacobians (FreeJoint.cpp:950-1007, restated literally)
+    # lose accuracy (5e-9 / gap^2); the kernels use the exact reverse-mode expression.  Worlds within 0.3 rad of the singularity are
+    # therefore judged against the oracle with its exact-derivative instrument (tests/parity.py; test_cfg4_box_stack_8192_worlds shows why
+    # that is the right comparison) - and then EVERY world is held to 1e-7 (round 4: 1e-6 from 0.5 rad, 1e-4 from 0.1 rad on).
+    from parity import exact_reference_near_the_singularity, gradient_tolerance
+    P = world._parity
+    ref_ex, near, fd_err = exact_reference_near_the_singularity(P["ow"], P["md"], P["s"], P["a"], P["g"], P["ref"])
+    errs_ex, _ = world_errors(P["dev"], ref_ex)
+    tolg = gradient_tolerance(P["md"], P["ref"]["next"], TOL)
+    print(f"[edge-edge over the rim] {int(near.sum())} worlds next to the log-map singularity: grad_state against the finite-difference oracle max "
+          f"{errs['grad_state'][near].max() if near.any() else 0:.2e}, against the exact one max {errs_ex['grad_state'][near].max() if near.any() else 0:.2e} "
+          f"(the two oracle modes differ by {fd_err:.1e}); all other worlds max {errs['grad_state'][~near].max():.2e}")
+    assert (errs_ex["grad_state"] <= tolg).all(), (float((errs_ex["grad_state"] / tolg).max()), int(np.argmax(errs_ex["grad_state"] / tolg)))
+    errs = errs_ex
     assert errs["grad_action"].max() < 1e-6
     assert np.median(errs["grad_state"]) < 1e-8
 
@@ -205,7 +210,31 @@ def test_cfg4_box_stack_8192_worlds():
     _report("cfg4 box stack B=8192", errs)
     stage_bits = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100
     print("[cfg4] worlds resolved by a different stage than in the oracle:", int(((st & stage_bits) != (ost & stage_bits)).sum()))
-    unstable = _assert_all_worlds_match_or_reference_is_unstable("cfg4 box stack B=8192", errs, world, NORTH_STAR_TOL)
+    # ---- the log-map singularity (yaw ~ U(-pi, pi): several hundred cubes within 0.3 rad of a rotation by pi), as a TEST instead of an
+    # argument.  The reference finite-differences the position integration of its free joints (FreeJoint.cpp:950-1007),
+    # the oracle restates that, the device differentiates exactly.  (1) against the oracle AS IT IS the device "misses" 1e-7 in hundreds of
+    # worlds and north_star's 1e-5 in tens - every one of them next to the singularity; (2) against the oracle WITH its exact-derivative
+    # instrument (oracle/dynamics.hpp::posJacobiansExact, pinned on the CPU against an 80-bit stencil) the same worlds agree with the device
+    # to the tolerance of every other world, up to the eps / gap^3 conditioning of doubles a few 1e-3 rad from pi. ----
+    from parity import FD_GAP, exact_reference_near_the_singularity, gradient_tolerance, log_map_gap
+    P = world._parity
+    worst_fd = np.maximum.reduce([errs[k] for k in errs])
+    gap = log_map_gap(P["md"], P["ref"]["next"])
+    ref_ex, near, fd_err = exact_reference_near_the_singularity(P["ow"], P["md"], P["s"], P["a"], P["g"], P["ref"])
+    errs_ex, _ = world_errors(P["dev"], ref_ex)
+    worst_ex = np.maximum.reduce([errs_ex[k] for k in errs_ex])
+    tolg = gradient_tolerance(P["md"], P["ref"]["next"], TOL)
+    off_fd = worst_fd > TOL
+    print(f"[cfg4] {int(near.sum())} worlds within {FD_GAP} rad of the log-map singularity.  Against the finite-difference oracle (the reference): "
+          f"{int((off_fd & near).sum())} of them above 1e-7, {int(((worst_fd > NORTH_STAR_TOL) & near).sum())} above 1e-5, max {worst_fd[near].max():.1e} "
+          f"(the oracle's two modes differ by up to {fd_err:.1e} there); against the oracle with exact position Jacobians: "
+          f"{int(((worst_ex > TOL) & near).sum())} above 1e-7 (all {int(((worst_ex > TOL) & near & (tolg > TOL)).sum())} within 4.1e-3 rad of pi, "
+          f"smallest gap {gap.min():.1e}), max {worst_ex[near].max():.1e}")
+    assert near.sum() > 300 and (off_fd & near).sum() >= 100 and worst_fd[near].max() > NORTH_STAR_TOL      # (1) the reported errors are there ...
+    assert (off_fd & ~near).sum() <= 0.005 * 8192                                                            # ... and nowhere else
+    stable_near = near & (worst_ex <= np.maximum(tolg, TOL))
+    assert (near & ~stable_near).sum() <= 3, np.where(near & ~stable_near)[0][:10]                           # (2) ... and gone (<= 3: the criterion below judges those)
+    unstable = _assert_all_worlds_match_or_reference_is_unstable("cfg4 box stack B=8192", errs, world, TOL)
     assert unstable <= 0.005 * 8192
 
 

@@ -7,7 +7,7 @@
 #include "coop_dantzig_dev.hpp"
 #include "coop_wave_dev.hpp"
 
-using namespace nbl;
+using namespace NBL_NS;
 
 __global__ __launch_bounds__(64) void k_dz(int count, int nmax, const int32_t* __restrict__ ns, const double* __restrict__ A, const double* __restrict__ b, const double* __restrict__ lo,
                                            const double* __restrict__ hi, const int32_t* __restrict__ findex, double* __restrict__ x, int32_t* __restrict__ rc) {
