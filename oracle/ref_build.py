@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build oracle/_ref/libodelcp_ref.so and oracle/_ref/libdboxbox_ref.so.
+"""Build oracle/_ref/libodelcp_ref.so, libdboxbox_ref.so, libgeometry_ref.so and liblcputils_ref.so (build_lcputils: the reference's LCPUtils).
 libdboxbox_ref.so: the reference's own box-box narrow phase - the ODE-derived dBoxBox with its helpers and the collideBoxBox wrapper,
 dart/collision/dart/DARTCollide.cpp from `typedef s_t dVector3[4];` to the end of collideBoxBox - compiled from the reference's file where it
 lies: that line range is read at build time into oracle/_ref/ (git-ignored) between ref_boxbox_prelude.hpp (stand-ins for the few Eigen /
@@ -191,6 +191,44 @@ def build_geometry():
     return 0
 
 
+def build_lcputils():
+    """liblcputils_ref.so: the reference's own LCPUtils::isLCPSolutionValid, reduce, removeFriction with their helpers mergeLCPColumns and
+    dropLCPColumn (dart/constraint/LCPUtils.cpp:12-80, 144-247, 346-549: dynamic Eigen containers, no decomposition) compiled from the
+    reference's file where it lies, between ref_lcputils_prelude.hpp (a small dynamic matrix / vector class under Eigen's names + the class
+    shell) and ref_lcputils_epilogue.hpp (C entry points).  The generated translation unit is deleted after the build."""
+    src = os.path.join(REF, "dart", "constraint", "LCPUtils.cpp")
+    if not os.path.exists(src):
+        return 0
+    out_dir = os.path.join(HERE, "_ref")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "liblcputils_ref.so")
+    parts = [os.path.join(HERE, "ref_lcputils_prelude.hpp"), os.path.join(HERE, "ref_lcputils_epilogue.hpp")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in parts + [src, __file__]):
+        return 0
+    lines = open(src).read().split("\n")
+    tu = os.path.join(out_dir, "lcputils_tu.cpp")
+    with open(tu, "w") as f:
+        f.write(open(parts[0]).read())
+        thr = next(i for i, l in enumerate(lines) if l.startswith("#define MERGE_THRESHOLD"))      # the merge threshold, as the file has it
+        f.write(f'#line {thr + 1} "{src}"\n' + lines[thr] + "\n")
+        f.write("namespace dart {\nnamespace constraint {\n")
+        for prefix in ("bool LCPUtils::isLCPSolutionValid(", "Eigen::MatrixXs LCPUtils::reduce(", "Eigen::MatrixXs LCPUtils::removeFriction(",
+                       "void LCPUtils::mergeLCPColumns(", "void LCPUtils::dropLCPColumn("):
+            a, b = _function(lines, prefix)
+            f.write(f'#line {a + 1} "{src}"\n' + "\n".join(lines[a:b + 1]) + "\n")
+        f.write("}  // namespace constraint\n}  // namespace dart\n")
+        f.write('#line 1 "ref_lcputils_epilogue.hpp"\n')
+        f.write(open(parts[1]).read())
+    # -ffp-contract=off: the reference's build has no fused multiply-adds; NDEBUG like a release build (the functions assert their own preconditions)
+    cmd = ["g++", "-O2", "-DNDEBUG", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-o", out, tu]
+    print("[ref_build]", " ".join(cmd))
+    try:
+        subprocess.check_call(cmd)
+    finally:
+        os.remove(tu)      # the generated translation unit holds reference source: only the shared object stays
+    return 0
+
+
 if __name__ == "__main__":
     rc = main()
-    sys.exit(rc or build_boxbox() or build_geometry())
+    sys.exit(rc or build_boxbox() or build_geometry() or build_lcputils())
