@@ -1,0 +1,425 @@
+// gen_dantzig_dev.hpp — the Dantzig boxed-LCP driver for problems of ANY size, and stages 1-3 of the solver cascade around it.
+//
+// genDantzig restates dSolveLCP (dart/external/odelcpsolver/lcp.cpp:780-1113, the dLCP object :330-780, with dLDLTAddTL / dLDLTRemove /
+// dRemoveRowCol of matrix.cpp:286-460, dSolveL1 / dSolveL1T of fastlsolve.cpp / fastltsolve.cpp and dDot of fastdot.cpp) operation by
+// operation, as ONE sequential instruction stream (lane 0 of the world's wavefront): the same driving order, the same index sets and
+// swaps, the factor L / d of A(C,C) in the reference's own row order with rows appended (ell / Dell) and removed (down-dating), the
+// blocked order of the additions in the two triangular solves, no fused multiply-adds - so that x and the success flag are BIT-IDENTICAL
+// to the reference's solver on identical inputs, rank-deficient problems included (tests/test_gen_host.py against the reference's
+// compiled dSolveLCP up to 192 rows; tests/test_gpu_general.py on the device).  The wavefront-cooperative statement of the same driver
+// (coop_dantzig_dev.hpp) is what the 24- and 48-row builds run; it owes its speed to lane = row and cannot go past 64 rows.
+// Contact problems have no unbounded rows (nub = 0: the driver's initial factorisation does not occur).
+#pragma once
+#include "gen_lcp_dev.hpp"
+
+namespace NBL_NS {
+
+struct GenDantzigMem {      // all in the world's HBM scratch
+  double* A;                // n x n (leading dimension GLD): the problem's matrix; symmetrised and permuted in place
+  double* L;                // factor rows
+  double *d, *x, *w, *b, *lo, *hi, *dx, *dw, *ell, *Dell, *tmp, *tvec, *W1, *W2;
+  int *p, *C, *findex, *state;
+};
+
+// returns 1 solved, 0 early termination (s <= 0), -1 NaN step
+DEV int genDantzigSeq(const GenDantzigMem& M, int n, double* xOut) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  double* A = M.A; double* L = M.L;
+  auto AA = [&](int i, int j) -> double& { return A[(size_t)i * GLD + j]; };
+  auto LL = [&](int i, int j) -> double& { return L[(size_t)i * GLD + j]; };
+  // dDot (fastdot.cpp): the running sum from 0 in index order
+  auto dotRows = [&](const double* a, const double* b, int cnt) -> double { double s = 0.0; for (int k = 0; k < cnt; k++) s = s + a[k] * b[k]; return s; };
+  int nC = 0, nN = 0;
+  for (int k = 0; k < n; k++) { M.p[k] = k; M.x[k] = 0.0; M.w[k] = 0.0; M.state[k] = 0; M.dx[k] = 0.0; M.dw[k] = 0.0; }
+  // the reference only references the LOWER triangle of A (lcp.cpp:138-140, which matters after column merging): symmetrise from it once,
+  // then keep the permuted matrix symmetric
+  for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) AA(i, j) = AA(j, i);
+  auto swapProblem = [&](int i1, int i2) {
+    if (i1 == i2) return;
+    for (int k = 0; k < n; k++) { const double t = AA(i1, k); AA(i1, k) = AA(i2, k); AA(i2, k) = t; }
+    for (int k = 0; k < n; k++) { const double t = AA(k, i1); AA(k, i1) = AA(k, i2); AA(k, i2) = t; }
+    double t;
+    t = M.x[i1]; M.x[i1] = M.x[i2]; M.x[i2] = t;
+    t = M.b[i1]; M.b[i1] = M.b[i2]; M.b[i2] = t;
+    t = M.w[i1]; M.w[i1] = M.w[i2]; M.w[i2] = t;
+    t = M.lo[i1]; M.lo[i1] = M.lo[i2]; M.lo[i2] = t;
+    t = M.hi[i1]; M.hi[i1] = M.hi[i2]; M.hi[i2] = t;
+    int ti;
+    ti = M.p[i1]; M.p[i1] = M.p[i2]; M.p[i2] = ti;
+    ti = M.state[i1]; M.state[i1] = M.state[i2]; M.state[i2] = ti;
+    ti = M.findex[i1]; M.findex[i1] = M.findex[i2]; M.findex[i2] = ti;
+  };
+  // every findex row goes to the end (lcp.cpp:487-498)
+  {
+    int atEnd = 0;
+    for (int k = n - 1; k >= 0; k--)
+      if (M.findex[k] >= 0) { swapProblem(k, n - 1 - atEnd); atEnd++; }
+  }
+  // dSolveL1 (fastlsolve.cpp): L y = B in place, blocks of four rows: Z = the sum over the columns before the block (index order),
+  // then the block's own columns subtracted one by one
+  auto solveL1 = [&](double* B, int cnt) {
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+      double Z0 = 0.0, Z1 = 0.0, Z2 = 0.0, Z3 = 0.0;
+      for (int j = 0; j < i; j++) {
+        const double q = B[j];
+        Z0 = Z0 + LL(i, j) * q; Z1 = Z1 + LL(i + 1, j) * q; Z2 = Z2 + LL(i + 2, j) * q; Z3 = Z3 + LL(i + 3, j) * q;
+      }
+      const double y0 = B[i] - Z0;
+      B[i] = y0;
+      const double y1 = B[i + 1] - Z1 - LL(i + 1, i) * y0;
+      B[i + 1] = y1;
+      const double y2 = B[i + 2] - Z2 - LL(i + 2, i) * y0 - LL(i + 2, i + 1) * y1;
+      B[i + 2] = y2;
+      const double y3 = B[i + 3] - Z3 - LL(i + 3, i) * y0 - LL(i + 3, i + 1) * y1 - LL(i + 3, i + 2) * y2;
+      B[i + 3] = y3;
+    }
+    for (; i < cnt; i++) {
+      double Z = 0.0;
+      for (int j = 0; j < i; j++) Z = Z + LL(i, j) * B[j];
+      B[i] = B[i] - Z;
+    }
+  };
+  // dSolveL1T (fastltsolve.cpp): L^T y = B in place - the same blocking on the reversed index (rr = cnt - 1 - row)
+  auto solveL1T = [&](double* B, int cnt) {
+    auto Lt = [&](int rr, int jj) -> double { return LL(cnt - 1 - jj, cnt - 1 - rr); };   // L^T between reversed indices, jj < rr
+    auto Bv = [&](int rr) -> double& { return B[cnt - 1 - rr]; };
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+      double Z0 = 0.0, Z1 = 0.0, Z2 = 0.0, Z3 = 0.0;
+      for (int j = 0; j < i; j++) {
+        const double q = Bv(j);
+        Z0 = Z0 + Lt(i, j) * q; Z1 = Z1 + Lt(i + 1, j) * q; Z2 = Z2 + Lt(i + 2, j) * q; Z3 = Z3 + Lt(i + 3, j) * q;
+      }
+      const double y0 = Bv(i) - Z0;
+      Bv(i) = y0;
+      const double y1 = Bv(i + 1) - Z1 - Lt(i + 1, i) * y0;
+      Bv(i + 1) = y1;
+      const double y2 = Bv(i + 2) - Z2 - Lt(i + 2, i) * y0 - Lt(i + 2, i + 1) * y1;
+      Bv(i + 2) = y2;
+      const double y3 = Bv(i + 3) - Z3 - Lt(i + 3, i) * y0 - Lt(i + 3, i + 1) * y1 - Lt(i + 3, i + 2) * y2;
+      Bv(i + 3) = y3;
+    }
+    for (; i < cnt; i++) {
+      double Z = 0.0;
+      for (int j = 0; j < i; j++) Z = Z + Lt(i, j) * Bv(j);
+      Bv(i) = Bv(i) - Z;
+    }
+  };
+  // Dell = L^-1 A(i, C[.]), ell = Dell * d      (first half of dLCP::solve1, lcp.cpp:700-730)
+  auto solveEll = [&](int i) {
+    for (int j = 0; j < nC; j++) M.Dell[j] = AA(i, M.C[j]);
+    solveL1(M.Dell, nC);
+    for (int j = 0; j < nC; j++) M.ell[j] = M.Dell[j] * M.d[j];
+  };
+  auto solve1 = [&](int i, int dir) {
+    if (nC == 0) return;
+    solveEll(i);
+    for (int j = 0; j < nC; j++) M.tmp[j] = M.ell[j];
+    solveL1T(M.tmp, nC);
+    if (dir > 0) for (int j = 0; j < nC; j++) M.dx[M.C[j]] = -M.tmp[j];
+    else for (int j = 0; j < nC; j++) M.dx[M.C[j]] = M.tmp[j];
+  };
+  // the row at position i (with ell / Dell of the last solveEll(i)) becomes factor row nC   (transfer_i_to_C, lcp.cpp:520-553)
+  auto appendFactorRow = [&](int i) {
+    if (nC > 0) {
+      for (int j = 0; j < nC; j++) LL(nC, j) = M.ell[j];
+      M.d[nC] = 1.0 / (AA(i, i) - dotRows(M.ell, M.Dell, nC));
+    } else M.d[0] = 1.0 / AA(i, i);
+  };
+  // dLDLTAddTL (matrix.cpp:286-359) on the trailing block of the factor that starts at row / column r0 (n2 rows) with the vector a
+  auto ldltAddTL = [&](int r0, int n2, const double* a) {
+    if (n2 < 2) return;
+    const double SQ = 0.70710678118654752440;   // M_SQRT1_2
+    double* W1 = M.W1; double* W2 = M.W2;
+    W1[0] = 0.0; W2[0] = 0.0;
+    for (int j = 1; j < n2; j++) W1[j] = W2[j] = a[j] * SQ;
+    const double W11 = (0.5 * a[0] + 1.0) * SQ, W21 = (0.5 * a[0] - 1.0) * SQ;
+    double alpha1 = 1.0, alpha2 = 1.0;
+    {
+      double dee = M.d[r0];
+      double alphanew = alpha1 + (W11 * W11) * dee;
+      dee /= alphanew;
+      const double gamma1 = W11 * dee;
+      dee *= alpha1;
+      alpha1 = alphanew;
+      alphanew = alpha2 - (W21 * W21) * dee;
+      dee /= alphanew;
+      alpha2 = alphanew;
+      const double k1 = 1.0 - W21 * gamma1;
+      const double k2 = W21 * gamma1 * W11 - W21;
+      for (int pp = 1; pp < n2; pp++) {
+        const double Wp = W1[pp];
+        const double el = LL(r0 + pp, r0);
+        W1[pp] = Wp - W11 * el;
+        W2[pp] = k1 * Wp + k2 * el;
+      }
+    }
+    for (int j = 1; j < n2; j++) {
+      const double k1 = W1[j], k2 = W2[j];
+      double dee = M.d[r0 + j];
+      double alphanew = alpha1 + (k1 * k1) * dee;
+      dee /= alphanew;
+      const double gamma1 = k1 * dee;
+      dee *= alpha1;
+      alpha1 = alphanew;
+      alphanew = alpha2 - (k2 * k2) * dee;
+      dee /= alphanew;
+      const double gamma2 = k2 * dee;
+      dee *= alpha2;
+      M.d[r0 + j] = dee;
+      alpha2 = alphanew;
+      for (int pp = j + 1; pp < n2; pp++) {
+        double el = LL(r0 + pp, r0 + j);
+        double Wp = W1[pp] - k1 * el;
+        el += gamma1 * Wp;
+        W1[pp] = Wp;
+        Wp = W2[pp] - k2 * el;
+        el -= gamma2 * Wp;
+        W2[pp] = Wp;
+        LL(r0 + pp, r0 + j) = el;
+      }
+    }
+  };
+  // dLDLTRemove (matrix.cpp:374-426): factor row / column r leaves the n2-row factor; then dRemoveRowCol snips it out of L and d
+  auto ldltRemove = [&](int n2, int r) {
+    if (r == n2 - 1) return;    // deleting the last row / column is easy
+    double* a = M.tvec + n2;    // (the reference's tmp layout: t[0..r), a = t + r; any two disjoint buffers do)
+    if (r == 0) {
+      const int p0 = M.C[0];
+      for (int i = 0; i < n2; i++) a[i] = -AA(M.C[i], p0);      // GETA(p[i], p[0]) (the permuted matrix is kept symmetric)
+      a[0] += 1.0;
+      ldltAddTL(0, n2, a);
+    } else {
+      double* t = M.tvec;
+      for (int i = 0; i < r; i++) t[i] = LL(r, i) / M.d[i];
+      const int pr = M.C[r];
+      for (int i = 0; i < n2 - r; i++) a[i] = dotRows(&LL(r + i, 0), t, r) - AA(M.C[r + i], pr);
+      a[0] += 1.0;
+      ldltAddTL(r, n2 - r, a);
+    }
+    // dRemoveRowCol(L, n2, r) + memmove of d
+    for (int i = 0; i < n2 - 1; i++) {
+      const int si = i >= r ? i + 1 : i;
+      for (int j = 0; j < n2 - 1; j++) {
+        const int sj = j >= r ? j + 1 : j;
+        if (j <= i) LL(i, j) = LL(si, sj);   // (lower triangle; sources are never above-left of their targets' unread neighbours: si >= i, sj >= j)
+      }
+    }
+    for (int i = r; i + 1 < n2; i++) M.d[i] = M.d[i + 1];
+  };
+  // transfer_i_from_C_to_N (lcp.cpp:603-650): position i leaves C
+  auto removeFromC = [&](int i) {
+    int last_idx = -1;
+    int j = 0;
+    for (; j < nC; ++j) {
+      if (M.C[j] == nC - 1) last_idx = j;
+      if (M.C[j] == i) {
+        ldltRemove(nC, j);
+        int k;
+        if (last_idx == -1) {
+          for (k = j + 1; k < nC; ++k) if (M.C[k] == nC - 1) break;
+        } else k = last_idx;
+        M.C[k] = M.C[j];
+        for (int q = j; q + 1 < nC; q++) M.C[q] = M.C[q + 1];
+        break;
+      }
+    }
+    swapProblem(i, nC - 1);
+    nN++; nC--;
+  };
+  bool hitFirstFriction = false;
+  for (int i = 0; i < n; ++i) {
+    if (!hitFirstFriction && M.findex[i] >= 0) {
+      // un[p[j]] = x[j]; bounds of the friction rows frozen from the solved normals (lcp.cpp:856-873)
+      for (int j = 0; j < n; ++j) M.dw[M.p[j]] = M.x[j];
+      for (int k = i; k < n; ++k) {
+        const double wfk = M.dw[M.findex[k]];
+        if (wfk == 0) { M.hi[k] = 0; M.lo[k] = 0; }
+        else { M.hi[k] = fabs(M.hi[k] * wfk); M.lo[k] = -M.hi[k]; }
+      }
+      hitFirstFriction = true;
+    }
+    // w[i] = A(i,C) x(C) + A(i,N) x(N) - b[i]: two running sums (lcp.cpp:877)
+    M.w[i] = dotRows(&AA(i, 0), M.x, nC) + dotRows(&AA(i, nC), M.x + nC, nN) - M.b[i];
+    if (M.lo[i] == 0 && M.w[i] >= 0) { nN++; M.state[i] = 0; }
+    else if (M.hi[i] == 0 && M.w[i] <= 0) { nN++; M.state[i] = 1; }
+    else if (M.w[i] == 0) {
+      if (nC > 0) solveEll(i);                 // solve1(delta_x, i, 0, only_transfer)
+      appendFactorRow(i); swapProblem(nC, i); M.C[nC] = nC; nC++;
+    } else {
+      for (;;) {
+        const int dir = (M.w[i] <= 0) ? 1 : -1;
+        const double dirf = dir;
+        solve1(i, dir);
+        // dw(N) = A(N,C) dx(C) +/- A(i,N);  dw[i] = A(i,C) dx(C) + A(i,i) dirf   (lcp.cpp:926-928)
+        for (int k = 0; k < nN; k++) M.dw[nC + k] = dotRows(&AA(nC + k, 0), M.dx, nC);
+        if (dir > 0) for (int k = 0; k < nN; k++) M.dw[nC + k] += AA(i, nC + k);
+        else for (int k = 0; k < nN; k++) M.dw[nC + k] -= AA(i, nC + k);
+        M.dw[i] = dotRows(&AA(i, 0), M.dx, nC) + AA(i, i) * dirf;
+        // step length: the first minimum in the reference's scan order (lcp.cpp:938-998)
+        int cmd = 1, si = 0;
+        double s = -M.w[i] / M.dw[i];
+        if (dir > 0) {
+          if (M.hi[i] < INFINITY) { const double s2 = (M.hi[i] - M.x[i]) * dirf; if (s2 < s) { s = s2; cmd = 3; } }
+        } else {
+          if (M.lo[i] > -INFINITY) { const double s2 = (M.lo[i] - M.x[i]) * dirf; if (s2 < s) { s = s2; cmd = 2; } }
+        }
+        for (int k = 0; k < nN; ++k) {
+          const int r = nC + k;
+          if (!M.state[r] ? M.dw[r] < 0 : M.dw[r] > 0) {
+            if (M.lo[r] == 0 && M.hi[r] == 0) continue;
+            const double s2 = -M.w[r] / M.dw[r];
+            if (s2 < s) { s = s2; cmd = 4; si = r; }
+          }
+        }
+        for (int k = 0; k < nC; ++k) {
+          if (M.dx[k] < 0 && M.lo[k] > -INFINITY) { const double s2 = (M.lo[k] - M.x[k]) / M.dx[k]; if (s2 < s) { s = s2; cmd = 5; si = k; } }
+          if (M.dx[k] > 0 && M.hi[k] < INFINITY) { const double s2 = (M.hi[k] - M.x[k]) / M.dx[k]; if (s2 < s) { s = s2; cmd = 6; si = k; } }
+        }
+        if (s != s) return -1;      // (the wavefront-cooperative driver reports a NaN step the same way: coopDantzig)
+        if (s <= 0.0) return 0;     // earlyTermination (the caller always has the PGS fallback, BoxedLcpConstraintSolver.cpp:463)
+        // apply the step (lcp.cpp:1031-1036)
+        for (int k = 0; k < nC; k++) M.x[k] += s * M.dx[k];
+        M.x[i] += s * dirf;
+        for (int k = 0; k < nN; k++) M.w[nC + k] += s * M.dw[nC + k];
+        M.w[i] += s * M.dw[i];
+        switch (cmd) {
+          case 1: M.w[i] = 0; appendFactorRow(i); swapProblem(nC, i); M.C[nC] = nC; nC++; break;   // ell / Dell of solve1(i)
+          case 2: M.x[i] = M.lo[i]; M.state[i] = 0; nN++; break;
+          case 3: M.x[i] = M.hi[i]; M.state[i] = 1; nN++; break;
+          case 4:                                                                                  // transfer_i_from_N_to_C
+            M.w[si] = 0;
+            if (nC > 0) solveEll(si);
+            appendFactorRow(si); swapProblem(nC, si); M.C[nC] = nC; nN--; nC++; break;
+          case 5: M.x[si] = M.lo[si]; M.state[si] = 0; removeFromC(si); break;
+          case 6: M.x[si] = M.hi[si]; M.state[si] = 1; removeFromC(si); break;
+        }
+        if (cmd <= 3) break;
+      }
+    }
+  }
+  for (int j = 0; j < n; ++j) xOut[M.p[j]] = M.x[j];    // unpermute
+  return 1;
+}
+
+// ---- stages 1-3 of BoxedLcpConstraintSolver::solveLcp (:461-677) ------------------------------------------------------------------------
+constexpr int GS_SOLVED = 1;   // the solver reported success (Dantzig: no early termination; PGS: converged)
+constexpr int GS_VALID = 2;    // ... and isLCPSolutionValid accepted it
+constexpr int GS_NAN = 4;      // Dantzig: NaN step length
+
+// carve the problem arrays and the Dantzig arrays out of the world's scratch (mat[4]: the problem's matrix, mat[1]: the factor)
+DEV void genCarve(const GenScratch& S, GenProblem& P, GenDantzigMem& D) {
+  double* v = S.vec;
+  P.A = S.mat[4]; P.x = v; P.b = v + GR; P.lo = v + 2 * GR; P.hi = v + 3 * GR;
+  P.findex = reinterpret_cast<int*>(v + 4 * GR); P.mapTo = P.findex + GR;
+  D.A = S.mat[4]; D.L = S.mat[1];
+  D.d = v + 5 * GR; D.x = v + 6 * GR; D.w = v + 7 * GR; D.dx = v + 8 * GR; D.dw = v + 9 * GR; D.ell = v + 10 * GR; D.Dell = v + 11 * GR;
+  D.tmp = v + 12 * GR; D.tvec = S.mat[2]; D.W1 = S.mat[2] + 2 * GR; D.W2 = S.mat[2] + 3 * GR;
+  D.b = P.b; D.lo = P.lo; D.hi = P.hi; D.findex = P.findex;
+  D.p = reinterpret_cast<int*>(v + 13 * GR); D.C = D.p + GR; D.state = reinterpret_cast<int*>(v + 14 * GR);
+}
+
+// X[o] = x_reduced[mapTo[o]] -> out (rows that are off: 0)
+template <class W>
+DEV void genMapOut(const W& w, const GenRows& R, const GenProblem& P, const double* xred, double* out) {
+  for (int r = w.lane(); r < R.m; r += w.lanes()) out[r] = P.mapTo[r] >= 0 ? xred[P.mapTo[r]] : 0.0;
+  w.sync();
+}
+
+// stage 1: reduce + Dantzig with early termination (:461-522).  out: the candidate (m rows), returns GS_* flags
+template <class W>
+DEV int genStage1(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double* out) {
+  GenProblem P; GenDantzigMem D;
+  genCarve(S, P, D);
+  genLoadProblem(w, A, lda, R, 0.0, R.X0, P);
+  genLcpReduce(w, P, R.m);
+  if (w.lane() == 0) R.iscal[1] = genDantzigSeq(D, P.n, P.x);
+  w.sync();
+  const int rc = R.iscal[1];
+  int flags = 0;
+  for (int r = w.lane(); r < R.m; r += w.lanes()) out[r] = 0.0;
+  w.sync();
+  if (rc == 1) {
+    genMapOut(w, R, P, P.x, out);
+    flags = GS_SOLVED | (genValid(w, A, lda, R, out, false, 0.0, R.t2) ? GS_VALID : 0);
+  } else if (rc < 0) flags = GS_NAN;
+  return flags;
+}
+// stage 2: CFM + reduce + PGS from the pre-solve x (:539-597)
+template <class W>
+DEV int genStage2(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double cfm, double* out) {
+  GenProblem P; GenDantzigMem D;
+  genCarve(S, P, D);
+  genLoadProblem(w, A, lda, R, cfm, R.X0, P);
+  genLcpReduce(w, P, R.m);
+  int flags = 0;
+  for (int r = w.lane(); r < R.m; r += w.lanes()) out[r] = 0.0;
+  w.sync();
+  if (genPgs(w, R, P)) {
+    genMapOut(w, R, P, P.x, out);
+    flags = GS_SOLVED | (genValid(w, A, lda, R, out, false, cfm, R.t2) ? GS_VALID : 0);
+  }
+  return flags;
+}
+// stage 3: drop friction, PGS from zero (:606-677); its result is used whatever the solver says
+template <class W>
+DEV int genStage3(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double cfm, double* out) {
+  GenProblem P; GenDantzigMem D;
+  genCarve(S, P, D);
+  genLoadProblem(w, A, lda, R, cfm, R.X0, P);
+  genLcpRemoveFriction(w, P, R.m);
+  for (int c = w.lane(); c < P.n; c += w.lanes()) P.x[c] = 0.0;
+  w.sync();
+  const bool ok3 = genPgs(w, R, P);
+  genMapOut(w, R, P, P.x, out);
+  return ok3 ? GS_SOLVED : 0;
+}
+
+// The cascade for the rows that are on: the stages in the reference's order of preference (a later stage only runs when the earlier ones
+// did not deliver), then registration, classification and standardisation of the chosen solution (:718-736).  R.X0: the pre-solve x;
+// out: R.X (impulses), R.cls / R.E, cfmOut, st (NBL_ST_* bits), pinvValid (S.mat[3] is Q^+ of the classification).
+template <class W>
+DEV void genCascade(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double fallbackCfm, double& cfmOut, uint32_t& stOut,
+                    bool& pinvValid, GenClasses& K) {
+  const int m = R.m;
+  double* cand = S.vec + 15 * GR;
+  auto hasNan = [&](const double* x) -> bool { bool b = false; for (int r = w.lane(); r < m; r += w.lanes()) if (x[r] != x[r]) b = true; return w.anyAll(b); };
+  auto take = [&](const double* x) { for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = R.on[r] ? x[r] : 0.0; w.sync(); };
+  bool success = false, ignoreFriction = false;
+  uint32_t st = 0;
+  double cfm = 0.0;
+  take(R.X0);
+  const int f1 = genStage1(w, A, lda, R, S, cand);
+  if (f1 & GS_SOLVED) {
+    take(cand);
+    success = (f1 & GS_VALID) != 0;
+    if (success) st |= 0x4u;
+  }
+  if ((f1 & GS_NAN) || hasNan(R.X)) { success = false; for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = 0.0; w.sync(); st |= 0x40u; }
+  if (!success) {
+    cfm = fallbackCfm;
+    const int f2 = genStage2(w, A, lda, R, S, fallbackCfm, cand);
+    if (f2 & GS_SOLVED) {
+      take(cand);
+      success = (f2 & GS_VALID) != 0;
+      if (success) st |= 0x8u;
+    }
+  }
+  if (!success) {
+    ignoreFriction = true;
+    const int f3 = genStage3(w, A, lda, R, S, fallbackCfm, cand);
+    take(cand);
+    st |= 0x10u;
+    if (!(f3 & GS_SOLVED)) st |= 0x20u;
+  }
+  if (hasNan(R.X)) { for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = 0.0; w.sync(); st |= 0x40u; }
+  pinvValid = false;
+  const bool std = genStandardizeLoop(w, A, lda, R, S, cfm, ignoreFriction, nullptr, pinvValid, K);
+  if (std) st |= 0x100u;
+  cfmOut = cfm; stOut = st;
+}
+
+}  // namespace NBL_NS

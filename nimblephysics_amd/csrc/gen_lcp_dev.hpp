@@ -1,0 +1,597 @@
+// gen_lcp_dev.hpp — the contact LCP of a world with ANY number of rows (up to MAX_ROWS of the general instantiation: 192 = 64 contacts):
+// the solver cascade of BoxedLcpConstraintSolver::solveLcp (dart/constraint/BoxedLcpConstraintSolver.cpp:352-789) with the CGGM
+// classification / standardisation (dart/neural/ConstrainedGroupGradientMatrices.cpp:218-339, 482-872), one world per WAVEFRONT, every
+// matrix in the world's slice of HBM (L2-resident) and every per-row quantity in an array of `GenRows` (LDS).
+//
+// Why a second statement of the algorithm next to coop_dev.hpp / coop_dantzig_dev.hpp: those are written around lane = LCP row with a
+// compile-time row count <= 64 (register-resident columns, unrolled factorisations, LDS tiles) - that is what makes the 24-row metric
+// path fast and what caps it.  The reference has no cap (ConstraintSolver.cpp:563-606 keeps every contact of every pair; its own
+// data/skel/test/box_stacking.skel is a ten-cube tower: 40 contacts, 120 rows, in one constrained group).  This file trades the speed
+// for generality: loops over rows instead of lanes, lanes share a loop by striding through it (`for (i = lane; i < n; i += lanes)`), the
+// sequential parts (the Dantzig pivoting driver, whose value is being BIT-IDENTICAL to the reference's dSolveLCP; the row order of
+// Gauss-Seidel) run on lane 0.  A model gets it only when it asks for more than 16 contact slots (nimble_amd_dispatch.cpp).
+//
+// Everything is a template over a wave policy W (lane(), lanes(), sync(), maxAll, minAllI, sumAll, anyAll): GenWaveDev on the GPU
+// (gen_contact.hip), a ONE-lane policy on the host (tests/host_shim/gen_shim.cpp) under which this file is plain sequential code that the
+// CPU tests run against the oracle and against the reference's own dSolveLCP at every size up to 192 rows.
+#pragma once
+#include "lcp_dev.hpp"
+
+namespace NBL_NS {
+
+constexpr int GR = MAXR;            // rows of the arrays below (the general instantiation: 192)
+constexpr int GLD = MAXR;           // leading dimension of every scratch matrix
+
+// per-row data of one world's LCP (LDS on the device)
+struct GenRows {
+  int m;                            // rows in use (3 per contact slot)
+  double Bv[GR], mu[GR], colNorm[GR];
+  double X[GR], X0[GR], E[GR];
+  double t0[GR], t1[GR], t2[GR], t3[GR];   // scratch vectors
+  int cls[GR], fp[GR], perm[GR], gid[GR];
+  unsigned char fric[GR], lim[GR], neg[GR], rowOn[GR], on[GR], done[GR], in[GR], pad_[GR];
+  double invd[GR];
+  double scal[8];                   // broadcast scalars
+  int iscal[8];
+  int anyLim;
+};
+
+// scratch matrices of one world (HBM): GEN_NMAT blocks of GR x GLD doubles
+constexpr int GEN_NMAT = 5;
+constexpr size_t GEN_SCRATCH_DOUBLES = (size_t)GEN_NMAT * GR * GLD + 16 * GR;
+
+// ---- dense helpers: lanes stride through the rows / columns, A symmetric with leading dimension lda ----------------------------------
+// y_r = sum_j A[j][r] x_j over the rows that are on (y = 0 on the others); x is masked by `on` as well
+template <class W>
+DEV void genAx(const W& w, const double* A, int lda, const GenRows& R, const double* x, double* y) {
+  const int m = R.m;
+  for (int r = w.lane(); r < m; r += w.lanes()) {
+    double s = 0.0;
+    if (R.on[r]) for (int j = 0; j < m; j++) if (R.on[j]) s = fma(A[(size_t)j * lda + r], x[j], s);
+    y[r] = s;
+  }
+  w.sync();
+}
+
+// LCPUtils::isLCPSolutionValid (LCPUtils.cpp:12-80) on the rows that are on; v: scratch of m doubles.  Uniform result.
+template <class W>
+DEV bool genValid(const W& w, const double* A, int lda, const GenRows& R, const double* X, bool ignoreFriction, double cfm, double* v) {
+  const double tol = 1e-5;
+  genAx(w, A, lda, R, X, v);
+  bool bad = false;
+  for (int r = w.lane(); r < R.m; r += w.lanes()) {
+    if (!R.on[r]) continue;
+    const double x = X[r];
+    const double vr = -R.Bv[r] + cfm * x + v[r];
+    double upper = R.fric[r] ? R.mu[r] : INFINITY, lower = R.fric[r] ? -R.mu[r] : 0.0;
+    if (R.fric[r]) {
+      if (ignoreFriction) { if (x != 0.0) bad = true; continue; }
+      const double xn = R.on[R.fp[r]] ? X[R.fp[r]] : 0.0;
+      upper *= xn; lower *= xn;
+    }
+    if (fabs(lower) < tol && fabs(upper) < tol && fabs(x) < tol) {}
+    else if (fabs(x - lower) < tol) { if (vr < -tol) bad = true; }
+    else if (fabs(x - upper) < tol) { if (vr > tol) bad = true; }
+    else if (x > lower && x < upper) { if (fabs(vr) > tol) bad = true; }
+    else bad = true;
+  }
+  const bool any = w.anyAll(bad);
+  w.sync();
+  return !any;
+}
+
+struct GenClasses { int nc, nu; };
+
+// CGGM::constructMatrices classification (CGGM.cpp:535-713) of the rows that are on -> R.cls, R.E
+template <class W>
+DEV GenClasses genClassify(const W& w, GenRows& R, const double* X, bool ignoreFriction) {
+  const double TH = 1e-6, tie = 1e-5;
+  const int m = R.m;
+  // pass 1: clamping or not (a friction row looks at the impulse of its normal row, not at its class)
+  for (int r = w.lane(); r < m; r += w.lanes()) {
+    int cls = RC_NOT_CLAMPING;
+    bool inElse = false;
+    const double x = R.on[r] ? X[r] : 0.0;
+    const double xn = R.on[R.fp[r]] ? X[R.fp[r]] : 0.0;
+    const double hi = R.fric[r] ? R.mu[r] : INFINITY, lo = R.fric[r] ? -R.mu[r] : 0.0;
+    double upper = hi, lower = lo;
+    if (R.fric[r]) { upper *= xn; lower *= xn; }
+    if (R.on[r] && !(R.colNorm[r] < 1e-9)) {
+      if (fabs(x) < TH) {
+        if (R.fric[r] && !(fabs(xn) < TH) && !ignoreFriction) cls = RC_CLAMPING;
+      } else if ((x > lower + tie && x < upper - tie) || (lower - x > 1e-2 || x - upper > 1e-2)) cls = RC_CLAMPING;
+      else inElse = true;
+    }
+    R.cls[r] = cls;
+    R.in[r] = inElse ? 1 : 0;
+    R.E[r] = 0.0;
+  }
+  w.sync();
+  // pass 2: a friction row on its bound rides on its (clamping) normal row
+  for (int r = w.lane(); r < m; r += w.lanes()) {
+    if (!R.in[r] || !R.fric[r]) continue;
+    const int fp = R.fp[r];
+    const double xn = R.on[fp] ? X[fp] : 0.0;
+    if (fabs(xn) > 1e-9 && R.colNorm[fp] > 1e-9 && R.cls[fp] == RC_CLAMPING) {
+      R.cls[r] = RC_UPPER_BOUND;
+      const double ub = xn * R.mu[r], lb = -xn * R.mu[r];
+      R.E[r] = (fabs(X[r] - ub) < fabs(X[r] - lb)) ? R.mu[r] : -R.mu[r];
+    }
+  }
+  w.sync();
+  int nc = 0, nu = 0;
+  for (int r = w.lane(); r < m; r += w.lanes()) { nc += R.cls[r] == RC_CLAMPING; nu += R.cls[r] == RC_UPPER_BOUND; }
+  GenClasses K;
+  K.nc = (int)w.sumAll((double)nc); K.nu = (int)w.sumAll((double)nu);
+  return K;
+}
+
+// Q[i][s] = A[i][s] + [s normal] sum_{u = s+1, s+2 upper-bound} E[u] A[i][u] + cfm [i == s] for clamping i and s, zero elsewhere
+// (coopBuildQ of coop_dev.hpp with loops instead of lanes) -> M (row-major, leading dimension GLD)
+template <class W>
+DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const GenClasses& K, double cfm, double* M) {
+  const int m = R.m;
+  for (int s = w.lane(); s < m; s += w.lanes()) {
+    const bool colOn = R.cls[s] == RC_CLAMPING;
+    double e1 = 0.0, e2 = 0.0;
+    if (K.nu > 0 && !R.fric[s] && s + 2 < m) {
+      if (R.cls[s + 1] == RC_UPPER_BOUND) e1 = R.E[s + 1];
+      if (R.cls[s + 2] == RC_UPPER_BOUND) e2 = R.E[s + 2];
+    }
+    for (int i = 0; i < m; i++) {
+      double q = 0.0;
+      if (colOn && R.cls[i] == RC_CLAMPING) {
+        // (A is symmetric: A[i][s] = A[s][i]; rows that are off are inert)
+        auto a = [&](int c) -> double { return (R.on[c] && R.on[i]) ? A[(size_t)i * lda + c] : 0.0; };
+        q = a(s);
+        if (K.nu > 0 && !R.fric[s] && s + 2 < m) q = fma(e2, a(s + 2), fma(e1, a(s + 1), q));
+        // a joint-limit constraint has no constraint-force column in the reference's Q = A_c^T M^-1 (A_c + A_ub E) (DCC.cpp:51-99)
+        if (K.nu > 0 && (R.lim[s] || R.lim[i])) q = 0.0;
+        if (i == s) q += cfm;
+      }
+      M[(size_t)i * GLD + s] = q;
+    }
+  }
+  w.sync();
+}
+
+// P <- pseudo-inverse of the m x m matrix M (row-major, masked rows / columns zero; destroyed); G, T: scratch matrices.  cTrue = number
+// of unmasked columns (Eigen's `size` in the rank threshold eps * size * |R_00| of completeOrthogonalDecomposition, CGGM.cpp:280,
+// LCPUtils.cpp:113).  Column-pivoted Householder QR M Pi = H [R1 R2; 0], G = H^T carried along; full rank: Q^+ = Pi R1^-1 G1; rank
+// deficient: R = R1 [I W], W = R1^-1 R2, and the minimum-norm solution of R u = g is u = [I; W^T] (I + W W^T)^-1 R1^-1 g - the same
+// algebra as coopPinvImpl (coop_dev.hpp), which explains why that is as accurate as the second Householder pass.  Returns the rank.
+template <class W>
+DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue) {
+  const int ln = w.lane(), nl = w.lanes();
+  for (int j = ln; j < m; j += nl) { R.done[j] = 0; for (int i = 0; i < m; i++) G[(size_t)i * GLD + j] = (i == j) ? 1.0 : 0.0; }
+  w.sync();
+  const double thr = 2.220446049250313e-16 * cTrue;
+  double best0 = 0.0;
+  int rank = 0;
+  double* V = R.t3;
+  for (int k = 0; k < m; k++) {
+    // remaining squared column norms, pivot = the largest (lowest index among equals)
+    double myBest = -1.0;
+    int myCol = 0x7fffffff;
+    for (int j = ln; j < m; j += nl) {
+      if (R.done[j]) continue;
+      double s0 = 0.0, s1 = 0.0;
+      int i = k;
+      for (; i + 1 < m; i += 2) { const double a = M[(size_t)i * GLD + j], b = M[(size_t)(i + 1) * GLD + j]; s0 = fma(a, a, s0); s1 = fma(b, b, s1); }
+      if (i < m) { const double a = M[(size_t)i * GLD + j]; s0 = fma(a, a, s0); }
+      const double nrm = s0 + s1;
+      if (nrm > myBest) { myBest = nrm; myCol = j; }
+    }
+    const double best = w.maxAll(myBest);
+    if (k == 0) best0 = best;
+    if (!(best > thr * thr * best0) || !(best > 0.0)) break;
+    const int p = w.minAllI(myBest == best ? myCol : 0x7fffffff);
+    // the reflector of column p: V[i] = x_i (unscaled), v = x - alpha e_k scaled so that v_k = 1
+    for (int i = k + ln; i < m; i += nl) V[i] = M[(size_t)i * GLD + p];
+    w.sync();
+    const double akk = V[k];
+    double below = 0.0;
+    for (int i = k + 1; i < m; i++) below = fma(V[i], V[i], below);
+    const double normx = sqrt(fma(akk, akk, below));
+    const double alpha = akk > 0 ? -normx : normx;
+    const double vk = akk - alpha;
+    const double vnorm2 = fma(vk, vk, below);
+    const double vinv = 1.0 / vk;
+    const double tau = 2.0 * vk * vk / vnorm2;
+    // H = I - tau v v^T applied to the columns still in play and to the carried block
+    for (int jj = ln; jj < 2 * m; jj += nl) {
+      const bool carried = jj >= m;
+      const int j = carried ? jj - m : jj;
+      double* Mc = carried ? G : M;
+      if (!carried && (R.done[j] || j == p)) continue;
+      double d = 0.0;
+      for (int i = k + 1; i < m; i++) d = fma(V[i], Mc[(size_t)i * GLD + j], d);
+      d = fma(vinv, d, Mc[(size_t)k * GLD + j]) * tau;
+      Mc[(size_t)k * GLD + j] -= d;
+      const double dv = d * vinv;
+      for (int i = k + 1; i < m; i++) Mc[(size_t)i * GLD + j] = fma(-dv, V[i], Mc[(size_t)i * GLD + j]);
+    }
+    w.sync();
+    if (ln == 0) { M[(size_t)k * GLD + p] = alpha; R.done[p] = 1; R.perm[k] = p; }
+    for (int i = k + 1 + ln; i < m; i += nl) M[(size_t)i * GLD + p] = 0.0;
+    w.sync();
+    rank = k + 1;
+  }
+  const int r = rank;
+  if (ln == 0) {   // columns never chosen (dependent or masked) take the remaining pivot positions in index order
+    int pos = r;
+    for (int j = 0; j < m; j++) if (!R.done[j]) R.perm[pos++] = j;
+  }
+  w.sync();
+  if (r == 0) {
+    for (int j = ln; j < m; j += nl) for (int i = 0; i < m; i++) P[(size_t)i * GLD + j] = 0.0;
+    w.sync();
+    return 0;
+  }
+  for (int k = ln; k < r; k += nl) R.invd[k] = 1.0 / M[(size_t)k * GLD + R.perm[k]];
+  w.sync();
+  // x = R1^-1 (column) in place, R1[i][k] = M[i][perm[k]]: the columns of G1 (right-hand sides) and, rank deficient, those of R2
+  const int nExtra = r >= cTrue ? 0 : m - r;
+  for (int jj = ln; jj < m + nExtra; jj += nl) {
+    double* Mc = jj < m ? G : M;
+    const int j = jj < m ? jj : R.perm[r + (jj - m)];
+    for (int kk = r - 1; kk >= 0; kk--) {
+      const int pk = R.perm[kk];
+      const double y = Mc[(size_t)kk * GLD + j] * R.invd[kk];
+      Mc[(size_t)kk * GLD + j] = y;
+      for (int i = 0; i < kk; i++) Mc[(size_t)i * GLD + j] = fma(-M[(size_t)i * GLD + pk], y, Mc[(size_t)i * GLD + j]);
+    }
+  }
+  w.sync();
+  if (r >= cTrue) {
+    for (int j = ln; j < m; j += nl) {
+      for (int kk = 0; kk < r; kk++) P[(size_t)R.perm[kk] * GLD + j] = G[(size_t)kk * GLD + j];
+      for (int pp = r; pp < m; pp++) P[(size_t)R.perm[pp] * GLD + j] = 0.0;
+    }
+    w.sync();
+    return r;
+  }
+  // S = I + W W^T (r x r) -> T, W[i][t] = M[i][perm[r + t]]
+  const int nw = m - r;
+  for (int e = ln; e < r * r; e += nl) {
+    const int a = e / r, b = e - a * r;
+    double s = (a == b) ? 1.0 : 0.0;
+    for (int t = 0; t < nw; t++) { const int c = R.perm[r + t]; s = fma(M[(size_t)a * GLD + c], M[(size_t)b * GLD + c], s); }
+    T[(size_t)a * GLD + b] = s;
+  }
+  w.sync();
+  // Cholesky S = L L^T in place (lower triangle of T), lanes = rows below the pivot
+  for (int k = 0; k < r; k++) {
+    if (ln == 0) {
+      double s = T[(size_t)k * GLD + k];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * GLD + i], T[(size_t)k * GLD + i], s);
+      const double lkk = sqrt(s);
+      T[(size_t)k * GLD + k] = lkk;
+      R.scal[0] = 1.0 / lkk;
+    }
+    w.sync();
+    const double inv = R.scal[0];
+    for (int a = k + 1 + ln; a < r; a += nl) {
+      double s = T[(size_t)a * GLD + k];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)a * GLD + i], T[(size_t)k * GLD + i], s);
+      T[(size_t)a * GLD + k] = s * inv;
+    }
+    w.sync();
+  }
+  // z = S^-1 x for the columns of G1 (in place), then Q^+ = Pi [z; W^T z]
+  for (int j = ln; j < m; j += nl) {
+    for (int k = 0; k < r; k++) {
+      double s = G[(size_t)k * GLD + j];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * GLD + i], G[(size_t)i * GLD + j], s);
+      G[(size_t)k * GLD + j] = s / T[(size_t)k * GLD + k];
+    }
+    for (int k = r - 1; k >= 0; k--) {
+      double s = G[(size_t)k * GLD + j];
+      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * GLD + k], G[(size_t)i * GLD + j], s);
+      G[(size_t)k * GLD + j] = s / T[(size_t)k * GLD + k];
+    }
+    for (int k = 0; k < r; k++) P[(size_t)R.perm[k] * GLD + j] = G[(size_t)k * GLD + j];
+    for (int t = 0; t < nw; t++) {
+      const int c = R.perm[r + t];
+      double s = 0.0;
+      for (int i = 0; i < r; i++) s = fma(M[(size_t)i * GLD + c], G[(size_t)i * GLD + j], s);
+      P[(size_t)c * GLD + j] = s;
+    }
+  }
+  w.sync();
+  return r;
+}
+
+// y_i = sum_k P[i][k] x_k (TRANS: P[k][i]) for i < m
+template <class W, bool TRANS>
+DEV void genPinvApply(const W& w, const double* P, int m, const double* x, double* y) {
+  for (int i = w.lane(); i < m; i += w.lanes()) {
+    double s = 0.0;
+    for (int k = 0; k < m; k++) s = fma(TRANS ? P[(size_t)k * GLD + i] : P[(size_t)i * GLD + k], x[k], s);
+    y[i] = s;
+  }
+  w.sync();
+}
+
+// the world's scratch matrices
+struct GenScratch {
+  double* mat[GEN_NMAT];    // M, G, T, P, and one more for the cascade's problem / factor
+  double* vec;              // 16 x GR doubles
+};
+
+// CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (coopStandardizeLoop of coop_dev.hpp).  X in: the solver's x
+// (R.X), out: the last accepted solution.  guessValid: S.mat[3] holds the pseudo-inverse of A restricted to the rows R.in0 (stage 0's
+// guess).  Returns whether the results are standardised; pinvValid: S.mat[3] is Q^+ of the classification in R.cls.
+template <class W>
+DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double cfm, bool ignoreFriction,
+                            const unsigned char* guessRows, bool& pinvValid, GenClasses& K) {
+  const int m = R.m;
+  double* X = R.X;
+  double* fc = R.t0;
+  double* newX = R.t1;
+  bool ok = false;
+  for (int iter = 0; iter < m + 1; iter++) {
+    K = genClassify(w, R, X, ignoreFriction);
+    if (K.nc == 0) {
+      pinvValid = false;
+      for (int r = w.lane(); r < m; r += w.lanes()) newX[r] = 0.0;
+      w.sync();
+      ok = genValid(w, A, lda, R, newX, ignoreFriction, cfm, R.t2);
+      if (ok) { for (int r = w.lane(); r < m; r += w.lanes()) X[r] = 0.0; w.sync(); }
+      break;
+    }
+    bool sameAsGuess = false;
+    if (iter == 0 && K.nu == 0 && guessRows) {
+      bool diff = false;
+      for (int r = w.lane(); r < m; r += w.lanes()) if ((R.cls[r] == RC_CLAMPING) != (guessRows[r] != 0)) diff = true;
+      sameAsGuess = !w.anyAll(diff);
+    }
+    if (sameAsGuess) {
+      for (int r = w.lane(); r < m; r += w.lanes()) fc[r] = X[r];
+      w.sync();
+    } else {
+      genBuildQ(w, A, lda, R, K, cfm, S.mat[0]);
+      genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc);
+      for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = R.cls[r] == RC_CLAMPING ? R.Bv[r] : 0.0;
+      w.sync();
+      genPinvApply<W, false>(w, S.mat[3], m, R.t2, fc);
+      pinvValid = true;
+    }
+    bool newlyNot = false;
+    for (int r = w.lane(); r < m; r += w.lanes()) {
+      double nx = 0.0;
+      if (R.cls[r] == RC_CLAMPING) {
+        nx = fc[r];
+        if (fabs(nx) < 1e-6 && fabs(X[r]) > 1e-6 && !R.fric[r]) newlyNot = true;
+      } else if (R.cls[r] == RC_UPPER_BOUND) {
+        const double om = X[R.fp[r]] / X[r];
+        const double clean = (fabs(om - R.mu[r]) < fabs(om + R.mu[r])) ? R.mu[r] : -R.mu[r];
+        nx = fc[R.fp[r]] * clean;
+      }
+      newX[r] = nx;
+    }
+    w.sync();
+    const bool again = w.anyAll(newlyNot);
+    if (!genValid(w, A, lda, R, newX, ignoreFriction, cfm, R.t2)) { ok = false; break; }
+    for (int r = w.lane(); r < m; r += w.lanes()) X[r] = newX[r];
+    w.sync();
+    ok = true;
+    if (!again) break;
+  }
+  return ok;
+}
+
+// LCPUtils::guessSolution (when there is no matching warm start) + the standardisation loop: stage 0 of the solver cascade
+// (BoxedLcpConstraintSolver.cpp:380-460).  R.X in: the warm start (haveCache), out: the solution; R.X0: the pre-solve x.
+template <class W>
+DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, bool haveCache, bool& pinvValid, GenClasses& K) {
+  const int m = R.m;
+  pinvValid = false;
+  bool haveGuess = false;
+  unsigned char* in0 = R.pad_;
+  if (haveCache) {
+    for (int r = w.lane(); r < m; r += w.lanes()) { if (!R.on[r]) R.X[r] = 0.0; in0[r] = 0; }
+    w.sync();
+  } else {
+    // (the empty tangent rows of frictionless contacts are not rows of the reference's problem; a negated joint-limit row: the reference tests ITS b > 0)
+    int cnt = 0;
+    for (int r = w.lane(); r < m; r += w.lanes()) {
+      const bool in = R.on[r] && (R.fric[r] ? R.mu[r] != 0.0 : (R.neg[r] ? R.Bv[r] < 0 : R.Bv[r] > 0));
+      in0[r] = in ? 1 : 0;
+      cnt += in;
+      R.X[r] = 0.0;
+    }
+    w.sync();
+    const int nIn = (int)w.sumAll((double)cnt);
+    if (nIn > 0) {
+      double* M = S.mat[0];
+      for (int s = w.lane(); s < m; s += w.lanes())
+        for (int i = 0; i < m; i++) M[(size_t)i * GLD + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
+      w.sync();
+      genPinv(w, R, M, S.mat[1], S.mat[2], S.mat[3], m, nIn);
+      for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = in0[r] ? R.Bv[r] : 0.0;
+      w.sync();
+      genPinvApply<W, false>(w, S.mat[3], m, R.t2, R.t0);
+      for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = in0[r] ? R.t0[r] : 0.0;
+      w.sync();
+      haveGuess = true;
+      pinvValid = true;   // of A restricted to the guess rows; stays valid only if the first classification agrees
+    }
+  }
+  for (int r = w.lane(); r < m; r += w.lanes()) R.X0[r] = R.X[r];
+  w.sync();
+  const bool ok = genStandardizeLoop(w, A, lda, R, S, 0.0, false, haveGuess ? in0 : nullptr, pinvValid, K);
+  pinvValid = ok && pinvValid;
+  return ok;
+}
+
+// ---- stages 1-3: the reduced problems ---------------------------------------------------------------------------------------------------
+struct GenProblem {          // compacted boxed LCP (arrays in the world's scratch vectors), matrix n x n with leading dimension GLD
+  int n;
+  double *A, *x, *b, *lo, *hi;
+  int *findex, *mapTo;      // mapTo[original row] = column of the problem (-1: dropped)
+};
+
+// A (+ cfm on the diagonal) restricted to the rows the reference's problem has: rows that are on, without the empty tangent rows of
+// frictionless contacts (ContactConstraint dimension 1).  Lane 0 compacts the indices, the lanes copy.
+template <class W>
+DEV void genLoadProblem(const W& w, const double* A, int lda, GenRows& R, double cfmDiag, const double* x0, GenProblem& P) {
+  const int m = R.m;
+  if (w.lane() == 0) {
+    int n = 0;
+    for (int r = 0; r < m; r++) {
+      const bool keep = R.on[r] && !(R.fric[r] && R.mu[r] == 0.0);
+      P.mapTo[r] = keep ? n : -1;
+      if (keep) R.perm[n++] = r;
+    }
+    for (int r = 0; r < m; r++) {
+      const int c = P.mapTo[r];
+      if (c < 0) continue;
+      P.x[c] = x0[r]; P.b[c] = R.Bv[r];
+      P.lo[c] = R.fric[r] ? -R.mu[r] : 0.0; P.hi[c] = R.fric[r] ? R.mu[r] : INFINITY;
+      P.findex[c] = R.fric[r] ? P.mapTo[R.fp[r]] : -1;
+    }
+    R.iscal[0] = n;
+  }
+  w.sync();
+  const int n = R.iscal[0];
+  P.n = n;
+  for (int j = w.lane(); j < n; j += w.lanes()) {
+    const int sj = R.perm[j];
+    for (int i = 0; i < n; i++) P.A[(size_t)i * GLD + j] = A[(size_t)R.perm[i] * lda + sj] + (i == j ? cfmDiag : 0.0);
+  }
+  w.sync();
+}
+
+// delete row + column `col` (lane 0)
+DEV void genRemoveRowCol(GenProblem& P, int col) {
+  const int n = P.n;
+  for (int i = 0; i < n; i++) {
+    if (i == col) continue;
+    const int ni = i > col ? i - 1 : i;
+    for (int j = 0; j < n; j++) {
+      if (j == col) continue;
+      const int nj = j > col ? j - 1 : j;
+      P.A[(size_t)ni * GLD + nj] = P.A[(size_t)i * GLD + j];     // rows / columns move up-left: reads stay ahead of writes
+    }
+  }
+  for (int i = col; i + 1 < n; i++) { P.x[i] = P.x[i + 1]; P.b[i] = P.b[i + 1]; P.lo[i] = P.lo[i + 1]; P.hi[i] = P.hi[i + 1]; P.findex[i] = P.findex[i + 1]; }
+  P.n = n - 1;
+}
+
+// LCPUtils::reduce (LCPUtils.cpp:144-201, mergeLCPColumns :346-449): merge near-identical columns (squared distance < 1e-4, |b_a - b_b| <
+// 1e-4, same findex / hi / lo).  mOrig: rows of the world (for mapTo).
+template <class W>
+DEV void genLcpReduce(const W& w, GenProblem& P, int mOrig) {
+  const double TH = 1e-4;
+  if (w.lane() == 0) {
+    for (;;) {
+      const int n = P.n;
+      int ma = -1, mb = -1;
+      for (int a = 0; a < n - 1 && ma < 0; a++)
+        for (int b = a + 1; b < n; b++) {
+          if (!(fabs(P.b[a] - P.b[b]) < TH && P.findex[a] == P.findex[b] && P.hi[a] == P.hi[b] && P.lo[a] == P.lo[b])) continue;
+          double d2 = 0.0;
+          for (int r = 0; r < n; r++) { const double d = P.A[(size_t)r * GLD + a] - P.A[(size_t)r * GLD + b]; d2 += d * d; }
+          if (d2 < TH) { ma = a; mb = b; break; }
+        }
+      if (ma < 0) break;
+      for (int r = 0; r < n; r++) P.A[(size_t)r * GLD + ma] *= 2.0;
+      for (int i = 0; i < n; i++) {
+        if (P.findex[i] == mb) P.findex[i] = ma;
+        else if (P.findex[i] > mb) P.findex[i] -= 1;
+      }
+      genRemoveRowCol(P, mb);
+      for (int o = 0; o < mOrig; o++) {
+        if (P.mapTo[o] == mb) P.mapTo[o] = ma;
+        else if (P.mapTo[o] > mb) P.mapTo[o] -= 1;
+      }
+    }
+  }
+  w.sync();
+}
+
+// LCPUtils::removeFriction (LCPUtils.cpp:208-247): drop every row with findex != -1 (from the last one down)
+template <class W>
+DEV void genLcpRemoveFriction(const W& w, GenProblem& P, int mOrig) {
+  if (w.lane() == 0) {
+    for (int i = P.n - 1; i >= 0; i--) {
+      if (P.findex[i] == -1) continue;
+      for (int k = 0; k < P.n; k++) if (P.findex[k] > i) P.findex[k] -= 1;
+      genRemoveRowCol(P, i);
+      for (int o = 0; o < mOrig; o++) {
+        if (P.mapTo[o] == i) P.mapTo[o] = -1;
+        else if (P.mapTo[o] > i) P.mapTo[o] -= 1;
+      }
+    }
+  }
+  w.sync();
+}
+
+// PgsBoxedLcpSolver::solve (PgsBoxedLcpSolver.cpp:79-268), Option(30, 1e-6, 1e-3, 1e-9, false).  Gauss-Seidel is sequential over the
+// rows; the lanes share the dot product of a row (with one lane: the reference's own order of the sum).  A is modified (rows normalised)
+// like in the reference.  Uniform result.
+template <class W>
+DEV bool genPgs(const W& w, GenRows& R, GenProblem& P) {
+  const int n = P.n;
+  const int maxIteration = 30;
+  const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
+  const int ln = w.lane(), nl = w.lanes();
+  auto rowDot = [&](int i) -> double {          // sum_{j != i} A[i][j] x[j]
+    double s = 0.0;
+    for (int j = ln; j < n; j += nl) if (j != i) s += P.A[(size_t)i * GLD + j] * P.x[j];
+    return w.sumAll(s);
+  };
+  auto clampRow = [&](int i, double nx) -> double {
+    if (P.findex[i] >= 0) {
+      const double hiT = P.hi[i] * P.x[P.findex[i]], loT = -hiT;
+      return nx > hiT ? hiT : (nx < loT ? loT : nx);
+    }
+    return nx > P.hi[i] ? P.hi[i] : (nx < P.lo[i] ? P.lo[i] : nx);
+  };
+  int* order = R.perm;
+  int no = 0;
+  bool possible = true;
+  for (int i = 0; i < n; ++i) {
+    const double aii = P.A[(size_t)i * GLD + i];
+    if (aii < epsDiv) { w.sync(); if (ln == 0) P.x[i] = 0.0; w.sync(); continue; }
+    if (ln == 0) order[no] = i;
+    no++;
+    const double oldX = P.x[i];
+    const double nx = (P.b[i] - rowDot(i)) / aii;
+    const double xi = clampRow(i, nx);
+    w.sync();
+    if (ln == 0) P.x[i] = xi;
+    w.sync();
+    if (possible && fabs(xi - oldX) > dxTh) possible = false;
+  }
+  if (possible) return true;
+  w.sync();
+  for (int t = 0; t < no; t++) {
+    const int idx = order[t];
+    const double dummy = 1.0 / P.A[(size_t)idx * GLD + idx];
+    w.sync();
+    if (ln == 0) P.b[idx] *= dummy;
+    for (int j = ln; j < n; j += nl) P.A[(size_t)idx * GLD + j] *= dummy;
+    w.sync();
+  }
+  for (int iter = 1; iter < maxIteration; ++iter) {
+    possible = true;
+    for (int t = 0; t < no; t++) {
+      const int idx = order[t];
+      const double oldX = P.x[idx];
+      const double nx = P.b[idx] - rowDot(idx);
+      const double xi = clampRow(idx, nx);
+      w.sync();
+      if (ln == 0) P.x[idx] = xi;
+      w.sync();
+      if (possible && fabs(xi) > epsDiv) {
+        if (fabs((xi - oldX) / xi) > relTol) possible = false;
+      }
+    }
+    if (possible) break;
+  }
+  return possible;
+}
+
+}  // namespace NBL_NS

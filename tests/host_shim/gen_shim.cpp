@@ -1,0 +1,117 @@
+// Host build of the product's GENERAL-m contact LCP code (gen_lcp_dev.hpp, gen_dantzig_dev.hpp: any number of rows up to 192) under a
+// ONE-lane wave policy, where it is plain sequential code.  Test harness only (tests/test_gen_host.py).
+#include "gen_lcp_dev.hpp"
+#include "gen_dantzig_dev.hpp"
+
+#include <cstring>
+#include <vector>
+
+using namespace NBL_NS;
+
+struct HostWave1 {
+  int lane() const { return 0; }
+  int lanes() const { return 1; }
+  void sync() const {}
+  double maxAll(double v) const { return v; }
+  int minAllI(int v) const { return v; }
+  double sumAll(double v) const { return v; }
+  bool anyAll(bool b) const { return b; }
+};
+
+namespace {
+struct World {
+  GenRows R;
+  std::vector<double> buf;
+  GenScratch S;
+  World() : buf(GEN_SCRATCH_DOUBLES, 0.0) {
+    for (int k = 0; k < GEN_NMAT; k++) S.mat[k] = buf.data() + (size_t)k * GR * GLD;
+    S.vec = buf.data() + (size_t)GEN_NMAT * GR * GLD;
+    std::memset(&R, 0, sizeof(R));
+  }
+};
+// rows as the kernels set them up: three per contact, [normal, t1, t2]; mu per contact (mu <= 1e-3: frictionless, its tangent rows empty);
+// lim / neg per row (joint-limit pseudo-contacts), mask = the rows of the constrained group at hand
+void fillRows(GenRows& R, int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg) {
+  R.m = m;
+  R.anyLim = 0;
+  for (int r = 0; r < m; r++) {
+    R.fric[r] = (r % 3) != 0; R.fp[r] = r - (r % 3);
+    double mr = mu[r / 3];
+    if (lim && lim[r - (r % 3)]) mr = 0.0;
+    if (!(mr > 1e-3)) mr = 0.0;
+    R.mu[r] = mr; R.Bv[r] = b[r];
+    R.lim[r] = lim ? (lim[r] && (r % 3) == 0) : 0; R.neg[r] = neg ? neg[r] : 0;
+    if (R.lim[r]) R.anyLim = 1;
+    R.rowOn[r] = 1; R.on[r] = mask ? mask[r] : 1;
+    double cn = 0;
+    for (int i = 0; i < m; i++) cn += (R.on[r] ? A[(size_t)i * GLD + r] : 0.0) * (R.on[r] ? A[(size_t)i * GLD + r] : 0.0);
+    R.colNorm[r] = cn;
+  }
+}
+}  // namespace
+
+extern "C" {
+int gshim_rows() { return GR; }
+
+// Q: m x m row-major (masked rows / columns zero), P out m x m row-major; returns the rank
+int gshim_pinv(int m, const double* Q, int cTrue, double* Pout) {
+  World Wd;
+  const HostWave1 w;
+  Wd.R.m = m;
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Wd.S.mat[0][(size_t)i * GLD + j] = Q[(size_t)i * m + j];
+  const int r = genPinv(w, Wd.R, Wd.S.mat[0], Wd.S.mat[1], Wd.S.mat[2], Wd.S.mat[3], m, cTrue);
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Pout[(size_t)i * m + j] = Wd.S.mat[3][(size_t)i * GLD + j];
+  return r;
+}
+
+// the Dantzig driver on an n-row boxed LCP with explicit bounds (row-major A); returns 1 / 0 / -1 like genDantzigSeq
+int gshim_dantzig(int n, const double* A, const double* b, const double* lo, const double* hi, const int* findex, double* x) {
+  World Wd;
+  GenProblem P; GenDantzigMem D;
+  genCarve(Wd.S, P, D);
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) P.A[(size_t)i * GLD + j] = A[(size_t)i * n + j];
+    P.b[i] = b[i]; P.lo[i] = lo[i]; P.hi[i] = hi[i]; P.findex[i] = findex[i]; P.x[i] = 0.0;
+  }
+  std::vector<double> xo(n, 0.0);
+  const int rc = genDantzigSeq(D, n, xo.data());
+  for (int i = 0; i < n; i++) x[i] = rc == 1 ? xo[i] : 0.0;
+  return rc;
+}
+
+// stage 0 on the rows of `mask` (NULL: all): A m x m row-major, b[m], mu[m / 3]; outputs per row.  Returns ok | pinvValid << 1.
+int gshim_stage0(int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg,
+                 int haveCache, const double* xcache, double* X, double* X0, int* cls, double* E, double* Pout) {
+  World Wd;
+  const HostWave1 w;
+  std::vector<double> Ap((size_t)GR * GLD, 0.0);
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Ap[(size_t)i * GLD + j] = A[(size_t)i * m + j];
+  fillRows(Wd.R, m, Ap.data(), b, mu, mask, lim, neg);
+  for (int r = 0; r < m; r++) Wd.R.X[r] = (haveCache && Wd.R.on[r]) ? xcache[r] : 0.0;
+  bool pinvValid = false;
+  GenClasses K;
+  const bool ok = genStage0(w, Ap.data(), GLD, Wd.R, Wd.S, haveCache != 0, pinvValid, K);
+  for (int r = 0; r < m; r++) { X[r] = Wd.R.X[r]; X0[r] = Wd.R.X0[r]; cls[r] = Wd.R.cls[r]; E[r] = Wd.R.E[r]; }
+  if (Pout) for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Pout[(size_t)i * m + j] = Wd.S.mat[3][(size_t)i * GLD + j];
+  return (ok ? 1 : 0) | (pinvValid ? 2 : 0);
+}
+
+// stages 1-3 in the reference's order + standardisation on the rows of `mask`, from the pre-solve x `x0`; returns the status bits
+int gshim_cascade(int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg,
+                  const double* x0, double fallbackCfm, double* X, double* cfmOut, int* cls) {
+  World Wd;
+  const HostWave1 w;
+  std::vector<double> Ap((size_t)GR * GLD, 0.0);
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Ap[(size_t)i * GLD + j] = A[(size_t)i * m + j];
+  fillRows(Wd.R, m, Ap.data(), b, mu, mask, lim, neg);
+  for (int r = 0; r < m; r++) Wd.R.X0[r] = Wd.R.on[r] ? x0[r] : 0.0;
+  double cfm = 0.0;
+  uint32_t st = 0;
+  bool pinvValid = false;
+  GenClasses K;
+  genCascade(w, Ap.data(), GLD, Wd.R, Wd.S, fallbackCfm, cfm, st, pinvValid, K);
+  for (int r = 0; r < m; r++) { X[r] = Wd.R.X[r]; cls[r] = Wd.R.cls[r]; }
+  *cfmOut = cfm;
+  return (int)st;
+}
+}
