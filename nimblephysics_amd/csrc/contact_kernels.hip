@@ -266,16 +266,19 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
   }
 }
 
+// lanes of a stand-alone narrow-phase workgroup (the lane stride of its static LDS buffers): the remembered points of the general
+// instantiation (128 per world) do not fit 64 lanes' worth of LDS
+constexpr int DETECT_LS = SEEN_POINTS > 32 ? 16 : 64;
 __global__ __launch_bounds__(64) void k_contact_detect(DevModel mdl, const DevBody* __restrict__ bodies,
                                                        const DevContactModel* __restrict__ cm, int64_t B,
                                                        double* __restrict__ saved, SavedLayout lay,
                                                        uint32_t* __restrict__ status, double* __restrict__ ws, int doTwists,
                                                        uint32_t* __restrict__ failCount, int ppw) {
   extern __shared__ __attribute__((aligned(16))) double stage[];   // [thread][8 candidates][CR_SIZE] + counts (ppw > 1 only)
-  __shared__ double keptP[SEEN_POINTS * 3 * 64];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
-  __shared__ double clipBuf[48 * 64];               // clip polygons of boxBox, [entry][lane]
+  __shared__ double keptP[SEEN_POINTS * 3 * DETECT_LS];   // accepted contact points of the workgroup's worlds, [contact][xyz][lane]
+  __shared__ double clipBuf[48 * DETECT_LS];               // clip polygons of boxBox, [entry][lane]
   contactDetectBody(mdl, bodies, cm, B, saved, lay, status, ws, doTwists, failCount, ppw, nullptr, (int)blockIdx.x, (int)blockDim.x / ppw,
-                    keptP, clipBuf, stage);
+                    keptP, clipBuf, stage, nullptr, DETECT_LS);
 }
 
 }  // namespace NBL_NS

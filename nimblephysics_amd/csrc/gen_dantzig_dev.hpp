@@ -335,7 +335,7 @@ DEV int genStage1(const W& w, const double* A, int lda, GenRows& R, const GenScr
   GenProblem P; GenDantzigMem D;
   genCarve(S, P, D);
   genLoadProblem(w, A, lda, R, 0.0, R.X0, P);
-  genLcpReduce(w, P, R.m);
+  genLcpReduce(w, R, P, R.m);
   if (w.lane() == 0) R.iscal[1] = genDantzigSeq(D, P.n, P.x);
   w.sync();
   const int rc = R.iscal[1];
@@ -354,7 +354,7 @@ DEV int genStage2(const W& w, const double* A, int lda, GenRows& R, const GenScr
   GenProblem P; GenDantzigMem D;
   genCarve(S, P, D);
   genLoadProblem(w, A, lda, R, cfm, R.X0, P);
-  genLcpReduce(w, P, R.m);
+  genLcpReduce(w, R, P, R.m);
   int flags = 0;
   for (int r = w.lane(); r < R.m; r += w.lanes()) out[r] = 0.0;
   w.sync();
@@ -370,7 +370,7 @@ DEV int genStage3(const W& w, const double* A, int lda, GenRows& R, const GenScr
   GenProblem P; GenDantzigMem D;
   genCarve(S, P, D);
   genLoadProblem(w, A, lda, R, cfm, R.X0, P);
-  genLcpRemoveFriction(w, P, R.m);
+  genLcpRemoveFriction(w, R, P, R.m);
   for (int c = w.lane(); c < P.n; c += w.lanes()) P.x[c] = 0.0;
   w.sync();
   const bool ok3 = genPgs(w, R, P);

@@ -129,7 +129,7 @@ DEV GenClasses genClassify(const W& w, GenRows& R, const double* X, bool ignoreF
 // Q[i][s] = A[i][s] + [s normal] sum_{u = s+1, s+2 upper-bound} E[u] A[i][u] + cfm [i == s] for clamping i and s, zero elsewhere
 // (coopBuildQ of coop_dev.hpp with loops instead of lanes) -> M (row-major, leading dimension GLD)
 template <class W>
-DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const GenClasses& K, double cfm, double* M) {
+DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const GenClasses& K, double cfm, double* M, const double* cfmRow = nullptr) {
   const int m = R.m;
   for (int s = w.lane(); s < m; s += w.lanes()) {
     const bool colOn = R.cls[s] == RC_CLAMPING;
@@ -147,7 +147,7 @@ DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const
         if (K.nu > 0 && !R.fric[s] && s + 2 < m) q = fma(e2, a(s + 2), fma(e1, a(s + 1), q));
         // a joint-limit constraint has no constraint-force column in the reference's Q = A_c^T M^-1 (A_c + A_ub E) (DCC.cpp:51-99)
         if (K.nu > 0 && (R.lim[s] || R.lim[i])) q = 0.0;
-        if (i == s) q += cfm;
+        if (i == s) q += cfmRow ? cfmRow[s] : cfm;     // (cfmRow: one constant per row, its constrained group's)
       }
       M[(size_t)i * GLD + s] = q;
     }
@@ -482,7 +482,7 @@ DEV void genRemoveRowCol(GenProblem& P, int col) {
 // LCPUtils::reduce (LCPUtils.cpp:144-201, mergeLCPColumns :346-449): merge near-identical columns (squared distance < 1e-4, |b_a - b_b| <
 // 1e-4, same findex / hi / lo).  mOrig: rows of the world (for mapTo).
 template <class W>
-DEV void genLcpReduce(const W& w, GenProblem& P, int mOrig) {
+DEV void genLcpReduce(const W& w, GenRows& R, GenProblem& P, int mOrig) {
   const double TH = 1e-4;
   if (w.lane() == 0) {
     for (;;) {
@@ -507,13 +507,16 @@ DEV void genLcpReduce(const W& w, GenProblem& P, int mOrig) {
         else if (P.mapTo[o] > mb) P.mapTo[o] -= 1;
       }
     }
+    R.iscal[3] = P.n;
   }
+  w.sync();
+  P.n = R.iscal[3];       // (every lane holds its own copy of the descriptor: the new size goes to all of them)
   w.sync();
 }
 
 // LCPUtils::removeFriction (LCPUtils.cpp:208-247): drop every row with findex != -1 (from the last one down)
 template <class W>
-DEV void genLcpRemoveFriction(const W& w, GenProblem& P, int mOrig) {
+DEV void genLcpRemoveFriction(const W& w, GenRows& R, GenProblem& P, int mOrig) {
   if (w.lane() == 0) {
     for (int i = P.n - 1; i >= 0; i--) {
       if (P.findex[i] == -1) continue;
@@ -524,7 +527,10 @@ DEV void genLcpRemoveFriction(const W& w, GenProblem& P, int mOrig) {
         else if (P.mapTo[o] > i) P.mapTo[o] -= 1;
       }
     }
+    R.iscal[3] = P.n;
   }
+  w.sync();
+  P.n = R.iscal[3];
   w.sync();
 }
 

@@ -18,7 +18,11 @@
 #include "kernels.hip"
 #include "contact_kernels.hip"
 #include "contact_backward.hip"
+#if NBL_GENERAL
+#include "gen_contact.hip"      // the general instantiation: any number of contact rows (up to 192), rows looped over instead of mapped to lanes
+#else
 #include "coop_kernels.hip"
+#endif
 #include "coop_tree.hip"
 #include "inertia_backward.hip"
 
@@ -477,8 +481,14 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     // the per-world LDS images of k_contact_rows_coop ([body][6][row] velocity changes, launchForward) and k_bwd_contact_b_coop
     int nFreeRoots = 0;
     for (int i = 0; i < d->n_bodies; i++) if (d->joint_type[i] == NBL_JOINT_FREE) nFreeRoots++;
+#if NBL_GENERAL
+    // (the general kernels tile their rows: gen_contact.hip; their LDS images fit for every model of at most 64 bodies)
+    const size_t rowsLds = 0, bLds = ((size_t)d->n_bodies * 120 + std::max((size_t)d->n_bodies * 54, (size_t)54 * 64) + MAX_CONTACTS) * sizeof(double);
+    (void)nFreeRoots;
+#else
     const size_t rowsLds = ((size_t)d->n_bodies * 6 * MAX_ROWS + 12 * MAX_ROWS + 19 * (size_t)d->n_bodies + 54 * (size_t)nFreeRoots + MAX_CONTACTS) * sizeof(double);
     const size_t bLds = ((size_t)d->n_bodies * 120 + std::max((size_t)d->n_bodies * 54, (size_t)54 * MAX_ROWS) + MAX_CONTACTS) * sizeof(double);
+#endif
     if (std::max(rowsLds, bLds) > 160u * 1024u)
       return fail(NBL_E_UNSUPPORTED, "bodies x LCP rows exceed the 160 kB of LDS of a compute unit (" + std::to_string(d->n_bodies) + " device bodies, " +
                                          std::to_string(MAX_ROWS) + " rows): " + (MAX_CONTACTS > 8 ? "use max_contacts <= 8 or fewer bodies" : "fewer bodies"));
@@ -597,12 +607,18 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (e == hipSuccess && hasContact) e = hipMemcpy(m->dContact, &hc, sizeof(DevContactModel), hipMemcpyHostToDevice);
   // (k_contact_detect: 160 kB less its static arrays - the remembered points and the clip polygons)
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_detect, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                             std::min(104 * 1024, 160 * 1024 - (SEEN_POINTS * 3 * 64 + 48 * 64) * (int)sizeof(double)));
+                                                             std::min(104 * 1024, 160 * 1024 - (SEEN_POINTS * 3 * DETECT_LS + 48 * DETECT_LS) * (int)sizeof(double)));
+#if NBL_GENERAL
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_gen<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_gen<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#else
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if constexpr (MAX_ROWS <= 32)
     if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_contact_rows_coop<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess && hasContact) e = hipFuncSetAttribute((const void*)k_bwd_contact_b_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_step_forward_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_forward_detect_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_bwd_recompute_coop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -639,8 +655,18 @@ int32_t nbl_model_num_action(const nbl_model* m) { return m ? m->k : 0; }
 int32_t nbl_model_lcp_rows(const nbl_model* m) { return (m && m->hasContact) ? MAX_ROWS + 1 : 0; }
 int32_t nbl_model_max_contacts(const nbl_model* m) { return (m && m->hasContact) ? MAX_CONTACTS : 0; }
 
+// bytes of the workspace before the scratch matrices of the general instantiation (tree slots, contact-backward rows, the slice lists)
+static size_t workspaceHeadBytes(const nbl_model* m, int64_t B) {
+  const size_t head = ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LB_TOTAL : 0)) * sizeof(double) * (size_t)B +
+                      (m->hasContact ? ((size_t)B + 16) * sizeof(int32_t) : 0);
+  return (head + 255) & ~(size_t)255;
+}
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
+#if NBL_GENERAL
+  // + the per-world scratch matrices of the general contact kernels (gen_lcp_dev.hpp: 4 matrices of 192 x 192 + 16 vectors: 1.2 MB per world)
+  if (m->hasContact) return workspaceHeadBytes(m, B) + GEN_SCRATCH_DOUBLES * sizeof(double) * (size_t)B;
+#endif
   return ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LB_TOTAL : 0)) * sizeof(double) * (size_t)B +
          (m->hasContact ? ((size_t)B + 16) * sizeof(int32_t) : 0);
 }
@@ -672,7 +698,10 @@ static void endTiming(nbl_model* m, hipStream_t s) {
   if (!m->timingNow) return;
   hipEventRecord(m->pending.back().stop, s);
 }
-#define TIMED(kid, launch) do { beginTiming(m, s, kid); launch; endTiming(m, s); } while (0)
+// NBL_DEBUG_SYNC=1 (developer switch): wait for every kernel and name it on stderr - a device fault then points at its launch
+static const bool g_dbgSync = getenv("NBL_DEBUG_SYNC") && atoi(getenv("NBL_DEBUG_SYNC")) != 0;
+#define TIMED(kid, launch) do { beginTiming(m, s, kid); launch; endTiming(m, s); \
+    if (g_dbgSync) { const hipError_t de_ = hipStreamSynchronize(s); fprintf(stderr, "[nbl] %s: %s\n", kKernelNames[kid], hipGetErrorString(de_)); } } while (0)
 
 // the kernels of one forward step for the worlds [b0, b1) on stream s (slice si owns fail list / counter si)
 static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_t b1, hipStream_t s, const double* state,
@@ -726,6 +755,23 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
                                            m->dContact, B, (double*)saved, m->lay, status, (double*)workspace, m->coopTree ? 0 : 1,
                                            failCountAll + si, ppw));
       }
+#if NBL_GENERAL
+      {
+        // the general kernels (gen_contact.hip), one wavefront per world: rows in tiles of `ts` (what the [body][6][ts] field of the
+        // impulse tests leaves of the LDS), then the whole solver cascade of a world in one launch
+        double* gws = (double*)((char*)workspace + workspaceHeadBytes(m, B));
+        int ts = 64;
+        auto rowsLdsFor = [&](int t) -> size_t {
+          return ((size_t)12 * MAX_ROWS + 22 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + (size_t)6 * m->nb * t) * sizeof(double) + 2 * MAX_CONTACTS * sizeof(int);
+        };
+        while (ts > 8 && rowsLdsFor(ts) > 150u * 1024u) ts /= 2;
+        TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_gen, dim3((unsigned)cnt), dim3(64), rowsLdsFor(ts), s, mdl, m->dBodies, m->dContact, B,
+                                              (double*)saved, m->lay, (const double*)workspace, ts));
+        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, (double*)saved, m->lay,
+                                               lcp_cache_in, lcp_cache_out, next_state, status, gws));
+      }
+      (void)lws; (void)failListAll;
+#else
       {
         // worlds per wavefront of the row kernel: two (lanes 0..31 | 32..63) in the 24-row build when the model's bodies fit a half
         const int wpw = m->rowsPack;
@@ -756,6 +802,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
         TIMED(K_CASCADE_FINAL, hipLaunchKernelGGL(mg ? k_contact_cascade_final<true> : k_contact_cascade_final<false>, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B,
                                                   (double*)saved, m->lay, lcp_cache_out, next_state, status, lws, failList, failCount));
       }
+#endif
     }
   return NBL_OK;
 }
@@ -826,6 +873,24 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
       else
         TIMED(K_RECOMPUTE, hipLaunchKernelGGL(k_bwd_recompute, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B,
                                               (const double*)saved, m->lay, grad_next_state, (double*)workspace, lws));
+#if NBL_GENERAL
+      double* gws = (double*)((char*)workspace + workspaceHeadBytes(m, B));
+      TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_gen, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
+                                             m->lay, grad_next_state, lws, gws));
+      if (forkRecompute) HIP_TRY(hipStreamWaitEvent(s, m->auxJoin[si], 0));
+      {
+        const size_t bLds = ((size_t)m->nb * 120 + std::max((size_t)m->nb * 54, (size_t)54 * 64) + MAX_CONTACTS) * sizeof(double);   // FW D {tmp | TF} TW contact bodies
+        if (mdl.hasCapsule)
+          TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_gen<true>, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
+                                                 sv, m->lay, (const double*)workspace, lws));
+        else
+          TIMED(K_BWD_B_COOP, hipLaunchKernelGGL(k_bwd_contact_b_gen<false>, dim3((unsigned)cnt), dim3(64), bLds, s, mdl, m->dBodies, m->dContact, B,
+                                                 sv, m->lay, (const double*)workspace, lws));
+      }
+      if (mdl.hasBounce)
+        TIMED(K_BWD_BOUNCE, hipLaunchKernelGGL(k_bwd_bounce_gen, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dBodies, B, (const double*)saved, m->lay,
+                                               grad_next_state, lws, gws));
+#else
       TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
                                              m->lay, grad_next_state, lws));
       if (forkRecompute) HIP_TRY(hipStreamWaitEvent(s, m->auxJoin[si], 0));
@@ -841,6 +906,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
       if (mdl.hasBounce)
         TIMED(K_BWD_BOUNCE, hipLaunchKernelGGL(k_bwd_bounce, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dBodies, B, (const double*)saved, m->lay,
                                                grad_next_state, lws));
+#endif
       if (m->coopTree && !m->coopFinal) {
         TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace));
         TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
@@ -1025,13 +1091,19 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
   if (e == hipSuccess) {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ms_per_launch) { e = hipEventCreate(&t0); if (e == hipSuccess) e = hipEventCreate(&t1); }
+#if NBL_GENERAL
+    double* dScratch = nullptr;      // the general driver works in HBM: one world's worth of scratch per problem
+    e = hipMalloc((void**)&dScratch, (size_t)count * GEN_SCRATCH_DOUBLES * sizeof(double));
+#define NBL_SELFTEST_DANTZIG(...) hipLaunchKernelGGL(k_selftest_dantzig_gen, dim3((unsigned)count), dim3(64), 0, 0, __VA_ARGS__, dScratch)
+#else
+#define NBL_SELFTEST_DANTZIG(...) hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, __VA_ARGS__)
+#endif
     if (e == hipSuccess && ms_per_launch) {     // one untimed launch first (code load)
-      hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv, di + nv);
+      NBL_SELFTEST_DANTZIG(count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv, di + nv);
       e = hipEventRecord(t0, 0);
     }
     for (int r = 0; r < reps && e == hipSuccess; r++)
-      hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv,
-                         di + nv);
+      NBL_SELFTEST_DANTZIG(count, n, dA, dv, dv + nv, dv + 2 * nv, di, dv + 3 * nv, di + nv);
     if (e == hipSuccess && ms_per_launch) e = hipEventRecord(t1, 0);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && ms_per_launch) {
@@ -1041,6 +1113,9 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
     }
     if (t0) hipEventDestroy(t0);
     if (t1) hipEventDestroy(t1);
+#if NBL_GENERAL
+    if (dScratch) hipFree(dScratch);
+#endif
   }
   if (e == hipSuccess) e = hipMemcpy(x, dv + 3 * nv, nv * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(rc, di + nv, count * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -1059,6 +1134,10 @@ int32_t nbl_selftest_pinv_rows(int32_t count, int32_t rows, const double* Q, con
 }
 int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank, int32_t reps,
                           double* ms_per_launch) {
+#if NBL_GENERAL
+  (void)count; (void)Q; (void)cTrue; (void)route; (void)P; (void)rank; (void)reps; (void)ms_per_launch;
+  return fail(NBL_E_UNSUPPORTED, "nbl_selftest_pinv addresses the 24- and 48-row instantiations (the general one is tested through its steps)");
+#else
   if (!Q || !cTrue || !P || !rank) return fail(NBL_E_BADARG, "null argument");
   if (count <= 0 || reps < 1 || (route != 0 && route != 1)) return fail(NBL_E_BADARG, "bad count / reps / route");
   if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
@@ -1093,6 +1172,7 @@ int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, 
   if (di) hipFree(di);
   if (e != hipSuccess) return fail(NBL_E_HIP, std::string("nbl_selftest_pinv: ") + hipGetErrorString(e));
   return NBL_OK;
+#endif
 }
 
 #ifdef NBL_CASCADE_TIMING

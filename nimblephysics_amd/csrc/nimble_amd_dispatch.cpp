@@ -1,7 +1,8 @@
-// nimble_amd_dispatch.cpp — the entry points of include/nimble_amd.h over the two instantiations of the library (abi_variants.h):
+// nimble_amd_dispatch.cpp — the entry points of include/nimble_amd.h over the three instantiations of the library (abi_variants.h):
 // a model is given, when it is created, to the 24-row build (max_contacts <= 8, <= 16 colliders, <= 32 collider pairs: every
-// BASELINE config) or to the 48-row build (up to 16 contacts, 32 colliders, 64 pairs per world); every later call goes to the build
-// that owns the handle.  Host code only; no HIP call of its own.
+// BASELINE config), to the 48-row build (up to 16 contacts, 32 colliders, 64 pairs per world) or to the GENERAL build (up to 64
+// contacts = 192 LCP rows, 64 colliders, 512 pairs: rows looped over instead of mapped to lanes - slow, there so that no legal world
+// gets a truncated answer); every later call goes to the build that owns the handle.  Host code only; no HIP call of its own.
 #include <cstddef>
 #include <cstdint>
 #include <string>
@@ -60,36 +61,84 @@
 extern "C" {
 NBL_DECLARE_VARIANT(_c8)
 NBL_DECLARE_VARIANT(_c16)
+NBL_DECLARE_VARIANT(_c64)
 }
 
+// one table of entry points per instantiation
+struct Variant {
+  int id;   // 8, 16 or 64: the contact slots per world of the instantiation
+  const char* (*last_error)(void);
+  int32_t (*model_create)(const nbl_model_desc*, int32_t, void**);
+  void (*model_destroy)(void*);
+  int32_t (*model_num_dofs)(const void*);
+  int32_t (*model_num_action)(const void*);
+  int32_t (*model_lcp_rows)(const void*);
+  int32_t (*model_max_contacts)(const void*);
+  size_t (*workspace_bytes)(const void*, int64_t);
+  size_t (*saved_bytes)(const void*, int64_t);
+  int32_t (*step_forward)(void*, int64_t, const double*, const double*, const double*, double*, double*, void*, uint32_t*, void*, size_t, void*);
+  int32_t (*step_backward)(void*, int64_t, const void*, const double*, double*, double*, void*, size_t, void*);
+  int32_t (*set_body_inertia)(void*, int32_t, double, const double*, const double*);
+  int32_t (*set_body_inertias)(void*, int32_t, const int32_t*, const double*, const double*, const double*, void*);
+  int32_t (*set_inertia_params)(void*, int32_t, const int32_t*, const double*);
+  int32_t (*set_inertia_params_on)(void*, int32_t, const int32_t*, const double*, void*);
+  int32_t (*num_inertia_params)(const void*);
+  int32_t (*backward_inertia)(void*, int64_t, const void*, double*, int32_t, void*, size_t, void*);
+  size_t (*rollout_workspace_bytes)(const void*, int64_t);
+  int32_t (*rollout_forward)(void*, int64_t, int32_t, const double*, const double*, int64_t, double*, void*, uint32_t*, int32_t, void*, size_t, void*);
+  int32_t (*rollout_backward)(void*, int64_t, int32_t, const void*, const double*, double*, double*, void*, size_t, void*);
+  int32_t (*rollout_backward_inertia)(void*, int64_t, int32_t, const void*, const double*, double*, double*, double*, void*, size_t, void*);
+  size_t (*rollout_checkpoint_bytes)(const void*, int64_t, int32_t, int32_t);
+  int32_t (*rollout_forward_checkpointed)(void*, int64_t, int32_t, int32_t, const double*, const double*, int64_t, double*, void*, void*, uint32_t*, int32_t,
+                                          void*, size_t, void*);
+  int32_t (*rollout_backward_checkpointed)(void*, int64_t, int32_t, int32_t, double*, const double*, int64_t, void*, const void*, int32_t, const double*,
+                                           double*, double*, double*, void*, size_t, void*);
+  int32_t (*selftest_lcp_dantzig_timed)(int32_t, int32_t, const double*, const double*, const double*, const double*, const int32_t*, double*, int32_t*,
+                                        int32_t, double*);
+  int32_t (*selftest_pinv_rows)(int32_t, int32_t, const double*, const int32_t*, int32_t, double*, int32_t*, int32_t, double*);
+  int32_t (*set_launch_lanes)(void*, int32_t, int32_t);
+  int32_t (*set_slices)(void*, int32_t);
+  int32_t (*slices_for)(const void*, int64_t);
+  int32_t (*set_timing)(void*, int32_t);
+  int32_t (*get_timing)(void*, double*, int64_t*, double*, int64_t*);
+  int32_t (*kernel_timing)(void*, int32_t, double*, int64_t*);
+};
+#define NBL_VARIANT_TABLE(ID, S)                                                                                                              \
+  {ID, nbl_last_error##S, nbl_model_create##S, nbl_model_destroy##S, nbl_model_num_dofs##S, nbl_model_num_action##S, nbl_model_lcp_rows##S,    \
+   nbl_model_max_contacts##S, nbl_workspace_bytes##S, nbl_saved_bytes##S, nbl_step_forward##S, nbl_step_backward##S, nbl_set_body_inertia##S, \
+   nbl_set_body_inertias##S, nbl_set_inertia_params##S, nbl_set_inertia_params_on##S, nbl_num_inertia_params##S, nbl_backward_inertia##S,     \
+   nbl_rollout_workspace_bytes##S, nbl_rollout_forward##S, nbl_rollout_backward##S, nbl_rollout_backward_inertia##S,                          \
+   nbl_rollout_checkpoint_bytes##S, nbl_rollout_forward_checkpointed##S, nbl_rollout_backward_checkpointed##S,                               \
+   nbl_selftest_lcp_dantzig_timed##S, nbl_selftest_pinv_rows##S, nbl_set_launch_lanes##S, nbl_set_slices##S, nbl_slices_for##S,               \
+   nbl_set_timing##S, nbl_get_timing##S, nbl_kernel_timing##S}
+static const Variant kVariants[3] = {NBL_VARIANT_TABLE(8, _c8), NBL_VARIANT_TABLE(16, _c16), NBL_VARIANT_TABLE(64, _c64)};
+
 struct nbl_model {
-  int variant;   // 8 or 16: the instantiation that owns `impl`
+  const Variant* v;   // the instantiation that owns `impl`
   void* impl;
 };
 
 namespace {
-thread_local int g_errVariant = 0;   // whose message nbl_last_error returns: 8 / 16, 0 = the dispatcher's own
+thread_local const Variant* g_errVariant = nullptr;   // whose message nbl_last_error returns: nullptr = the dispatcher's own
 thread_local std::string g_err;
 int ownError(int code, const char* msg) {
   g_err = msg;
-  g_errVariant = 0;
+  g_errVariant = nullptr;
   return code;
 }
 int noted(const nbl_model* m, int rc) {   // remember which instantiation holds the text of a failure
-  if (rc != NBL_OK) g_errVariant = m->variant;
+  if (rc != NBL_OK) g_errVariant = m->v;
   return rc;
 }
 }  // namespace
 
-// int-returning entry point on a handle
-#define NBL_FWD(m, call8, call16) \
-  (!(m) ? ownError(NBL_E_BADARG, "null model") : noted((m), (m)->variant == 16 ? (call16) : (call8)))
+// int-returning entry point on a handle: FN = the table entry, then its arguments after the implementation handle
+#define NBL_FWD(m, FN, ...) (!(m) ? ownError(NBL_E_BADARG, "null model") : noted((m), (m)->v->FN((m)->impl, ##__VA_ARGS__)))
+#define NBL_GET(m, FN, ...) (!(m) ? 0 : (m)->v->FN((m)->impl, ##__VA_ARGS__))
 
 extern "C" {
 
-const char* nbl_last_error(void) {
-  return g_errVariant == 16 ? nbl_last_error_c16() : (g_errVariant == 8 ? nbl_last_error_c8() : g_err.c_str());
-}
+const char* nbl_last_error(void) { return g_errVariant ? g_errVariant->last_error() : g_err.c_str(); }
 int32_t nbl_version(void) { return nbl_version_c8(); }
 int32_t nbl_device_count(void) { return nbl_device_count_c8(); }
 
@@ -97,19 +146,24 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (!d || !out) return ownError(NBL_E_BADARG, "null argument");
   *out = nullptr;
   void* impl = nullptr;
-  int variant = 8;
+  // the smallest instantiation that holds the model: contact slots first (a model without colliders and without enforced joint limits has no
+  // contact stage: the 24-row build whatever max_contacts says), then whatever an instantiation answers NBL_E_CAPACITY to (its collider /
+  // collider-pair budget: 16 / 32, 32 / 64, 64 / 512)
+  const bool contactStage = d->n_boxes > 0 || d->dof_limit_enforced != nullptr;
+  int first = 0;
+  if (contactStage && (d->max_contacts > 16 || d->n_boxes > 32)) first = 2;
+  else if (contactStage && (d->max_contacts > 8 || d->n_boxes > 16)) first = 1;
   int32_t rc = NBL_E_CAPACITY;
-  if (!(d->max_contacts > 8 || d->n_boxes > 16)) rc = nbl_model_create_c8(d, device, &impl);   // (more than 32 collider PAIRS: the 24-row build says so)
-  g_errVariant = 8;
-  if (rc == NBL_E_CAPACITY) {   // more contacts / colliders / collider pairs than the 24-row build holds
-    variant = 16;
-    rc = nbl_model_create_c16(d, device, &impl);
-    g_errVariant = 16;
-    if (rc == NBL_E_CAPACITY) rc = NBL_E_UNSUPPORTED;
+  const Variant* v = nullptr;
+  for (int k = first; k < 3 && rc == NBL_E_CAPACITY; k++) {
+    v = &kVariants[k];
+    rc = v->model_create(d, device, &impl);
+    g_errVariant = v;
   }
+  if (rc == NBL_E_CAPACITY) rc = NBL_E_UNSUPPORTED;
   if (rc != NBL_OK) return rc;
   nbl_model* m = new nbl_model();
-  m->variant = variant;
+  m->v = v;
   m->impl = impl;
   *out = m;
   return NBL_OK;
@@ -117,91 +171,77 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
 
 void nbl_model_destroy(nbl_model* m) {
   if (!m) return;
-  if (m->variant == 16) nbl_model_destroy_c16(m->impl); else nbl_model_destroy_c8(m->impl);
+  m->v->model_destroy(m->impl);
   delete m;
 }
 
-int32_t nbl_model_num_dofs(const nbl_model* m) { return !m ? 0 : (m->variant == 16 ? nbl_model_num_dofs_c16(m->impl) : nbl_model_num_dofs_c8(m->impl)); }
-int32_t nbl_model_num_action(const nbl_model* m) { return !m ? 0 : (m->variant == 16 ? nbl_model_num_action_c16(m->impl) : nbl_model_num_action_c8(m->impl)); }
-int32_t nbl_model_lcp_rows(const nbl_model* m) { return !m ? 0 : (m->variant == 16 ? nbl_model_lcp_rows_c16(m->impl) : nbl_model_lcp_rows_c8(m->impl)); }
-int32_t nbl_model_max_contacts(const nbl_model* m) { return !m ? 0 : (m->variant == 16 ? nbl_model_max_contacts_c16(m->impl) : nbl_model_max_contacts_c8(m->impl)); }
-size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) { return !m ? 0 : (m->variant == 16 ? nbl_workspace_bytes_c16(m->impl, B) : nbl_workspace_bytes_c8(m->impl, B)); }
-size_t nbl_saved_bytes(const nbl_model* m, int64_t B) { return !m ? 0 : (m->variant == 16 ? nbl_saved_bytes_c16(m->impl, B) : nbl_saved_bytes_c8(m->impl, B)); }
+int32_t nbl_model_num_dofs(const nbl_model* m) { return NBL_GET(m, model_num_dofs); }
+int32_t nbl_model_num_action(const nbl_model* m) { return NBL_GET(m, model_num_action); }
+int32_t nbl_model_lcp_rows(const nbl_model* m) { return NBL_GET(m, model_lcp_rows); }
+int32_t nbl_model_max_contacts(const nbl_model* m) { return NBL_GET(m, model_max_contacts); }
+size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) { return NBL_GET(m, workspace_bytes, B); }
+size_t nbl_saved_bytes(const nbl_model* m, int64_t B) { return NBL_GET(m, saved_bytes, B); }
 
 int32_t nbl_step_forward(nbl_model* m, int64_t B, const double* state, const double* action, const double* lcp_cache_in, double* next_state,
                          double* lcp_cache_out, void* saved, uint32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_step_forward_c8(m->impl, B, state, action, lcp_cache_in, next_state, lcp_cache_out, saved, status, workspace, workspace_bytes, stream),
-                 nbl_step_forward_c16(m->impl, B, state, action, lcp_cache_in, next_state, lcp_cache_out, saved, status, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, step_forward, B, state, action, lcp_cache_in, next_state, lcp_cache_out, saved, status, workspace, workspace_bytes, stream);
 }
 int32_t nbl_step_backward(nbl_model* m, int64_t B, const void* saved, const double* grad_next_state, double* grad_state, double* grad_action,
                           void* workspace, size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_step_backward_c8(m->impl, B, saved, grad_next_state, grad_state, grad_action, workspace, workspace_bytes, stream),
-                 nbl_step_backward_c16(m->impl, B, saved, grad_next_state, grad_state, grad_action, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, step_backward, B, saved, grad_next_state, grad_state, grad_action, workspace, workspace_bytes, stream);
 }
 
 int32_t nbl_set_body_inertia(nbl_model* m, int32_t body, double mass, const double* com, const double* inertia) {
-  return NBL_FWD(m, nbl_set_body_inertia_c8(m->impl, body, mass, com, inertia), nbl_set_body_inertia_c16(m->impl, body, mass, com, inertia));
+  return NBL_FWD(m, set_body_inertia, body, mass, com, inertia);
 }
 int32_t nbl_set_body_inertias(nbl_model* m, int32_t count, const int32_t* bodies, const double* mass, const double* com, const double* inertia,
                               void* stream) {
-  return NBL_FWD(m, nbl_set_body_inertias_c8(m->impl, count, bodies, mass, com, inertia, stream),
-                 nbl_set_body_inertias_c16(m->impl, count, bodies, mass, com, inertia, stream));
+  return NBL_FWD(m, set_body_inertias, count, bodies, mass, com, inertia, stream);
 }
-int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG) {
-  return NBL_FWD(m, nbl_set_inertia_params_c8(m->impl, count, bodies, dG), nbl_set_inertia_params_c16(m->impl, count, bodies, dG));
-}
+int32_t nbl_set_inertia_params(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG) { return NBL_FWD(m, set_inertia_params, count, bodies, dG); }
 int32_t nbl_set_inertia_params_on(nbl_model* m, int32_t count, const int32_t* bodies, const double* dG, void* stream) {
-  return NBL_FWD(m, nbl_set_inertia_params_on_c8(m->impl, count, bodies, dG, stream), nbl_set_inertia_params_on_c16(m->impl, count, bodies, dG, stream));
+  return NBL_FWD(m, set_inertia_params_on, count, bodies, dG, stream);
 }
-int32_t nbl_num_inertia_params(const nbl_model* m) { return !m ? 0 : (m->variant == 16 ? nbl_num_inertia_params_c16(m->impl) : nbl_num_inertia_params_c8(m->impl)); }
+int32_t nbl_num_inertia_params(const nbl_model* m) { return NBL_GET(m, num_inertia_params); }
 int32_t nbl_backward_inertia(nbl_model* m, int64_t B, const void* saved, double* grad_params, int32_t accumulate, void* workspace,
                              size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_backward_inertia_c8(m->impl, B, saved, grad_params, accumulate, workspace, workspace_bytes, stream),
-                 nbl_backward_inertia_c16(m->impl, B, saved, grad_params, accumulate, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, backward_inertia, B, saved, grad_params, accumulate, workspace, workspace_bytes, stream);
 }
 
-size_t nbl_rollout_workspace_bytes(const nbl_model* m, int64_t B) {
-  return !m ? 0 : (m->variant == 16 ? nbl_rollout_workspace_bytes_c16(m->impl, B) : nbl_rollout_workspace_bytes_c8(m->impl, B));
-}
+size_t nbl_rollout_workspace_bytes(const nbl_model* m, int64_t B) { return NBL_GET(m, rollout_workspace_bytes, B); }
 int32_t nbl_rollout_forward(nbl_model* m, int64_t B, int32_t T, const double* state0, const double* actions, int64_t action_stride, double* states,
                             void* saved, uint32_t* status, int32_t warm_start, void* workspace, size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_rollout_forward_c8(m->impl, B, T, state0, actions, action_stride, states, saved, status, warm_start, workspace, workspace_bytes, stream),
-                 nbl_rollout_forward_c16(m->impl, B, T, state0, actions, action_stride, states, saved, status, warm_start, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, rollout_forward, B, T, state0, actions, action_stride, states, saved, status, warm_start, workspace, workspace_bytes, stream);
 }
 int32_t nbl_rollout_backward(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states, double* grad_state0,
                              double* grad_actions, void* workspace, size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_rollout_backward_c8(m->impl, B, T, saved, grad_states, grad_state0, grad_actions, workspace, workspace_bytes, stream),
-                 nbl_rollout_backward_c16(m->impl, B, T, saved, grad_states, grad_state0, grad_actions, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, rollout_backward, B, T, saved, grad_states, grad_state0, grad_actions, workspace, workspace_bytes, stream);
 }
 int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const void* saved, const double* grad_states, double* grad_state0,
                                      double* grad_actions, double* grad_params, void* workspace, size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_rollout_backward_inertia_c8(m->impl, B, T, saved, grad_states, grad_state0, grad_actions, grad_params, workspace, workspace_bytes, stream),
-                 nbl_rollout_backward_inertia_c16(m->impl, B, T, saved, grad_states, grad_state0, grad_actions, grad_params, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, rollout_backward_inertia, B, T, saved, grad_states, grad_state0, grad_actions, grad_params, workspace, workspace_bytes, stream);
 }
-size_t nbl_rollout_checkpoint_bytes(const nbl_model* m, int64_t B, int32_t T, int32_t segment) {
-  return !m ? 0 : (m->variant == 16 ? nbl_rollout_checkpoint_bytes_c16(m->impl, B, T, segment) : nbl_rollout_checkpoint_bytes_c8(m->impl, B, T, segment));
-}
+size_t nbl_rollout_checkpoint_bytes(const nbl_model* m, int64_t B, int32_t T, int32_t segment) { return NBL_GET(m, rollout_checkpoint_bytes, B, T, segment); }
 int32_t nbl_rollout_forward_checkpointed(nbl_model* m, int64_t B, int32_t T, int32_t segment, const double* state0, const double* actions,
                                          int64_t action_stride, double* states, void* saved, void* checkpoints, uint32_t* status,
                                          int32_t warm_start, void* workspace, size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_rollout_forward_checkpointed_c8(m->impl, B, T, segment, state0, actions, action_stride, states, saved, checkpoints, status, warm_start, workspace, workspace_bytes, stream),
-                 nbl_rollout_forward_checkpointed_c16(m->impl, B, T, segment, state0, actions, action_stride, states, saved, checkpoints, status, warm_start, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, rollout_forward_checkpointed, B, T, segment, state0, actions, action_stride, states, saved, checkpoints, status, warm_start, workspace,
+                 workspace_bytes, stream);
 }
 int32_t nbl_rollout_backward_checkpointed(nbl_model* m, int64_t B, int32_t T, int32_t segment, double* states, const double* actions,
                                           int64_t action_stride, void* saved, const void* checkpoints, int32_t warm_start,
                                           const double* grad_states, double* grad_state0, double* grad_actions, double* grad_params,
                                           void* workspace, size_t workspace_bytes, void* stream) {
-  return NBL_FWD(m, nbl_rollout_backward_checkpointed_c8(m->impl, B, T, segment, states, actions, action_stride, saved, checkpoints, warm_start, grad_states, grad_state0, grad_actions, grad_params, workspace, workspace_bytes, stream),
-                 nbl_rollout_backward_checkpointed_c16(m->impl, B, T, segment, states, actions, action_stride, saved, checkpoints, warm_start, grad_states, grad_state0, grad_actions, grad_params, workspace, workspace_bytes, stream));
+  return NBL_FWD(m, rollout_backward_checkpointed, B, T, segment, states, actions, action_stride, saved, checkpoints, warm_start, grad_states, grad_state0,
+                 grad_actions, grad_params, workspace, workspace_bytes, stream);
 }
 
 // ---- self-tests: the problem size picks the instantiation whose device code runs ----
 int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                        const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch) {
-  const bool big = n > 24;
-  g_errVariant = big ? 16 : 8;
-  return big ? nbl_selftest_lcp_dantzig_timed_c16(count, n, A, b, lo, hi, findex, x, rc, reps, ms_per_launch)
-             : nbl_selftest_lcp_dantzig_timed_c8(count, n, A, b, lo, hi, findex, x, rc, reps, ms_per_launch);
+  const Variant* v = &kVariants[n > 48 ? 2 : (n > 24 ? 1 : 0)];     // (n > 48: the general driver, gen_dantzig_dev.hpp)
+  g_errVariant = v;
+  return v->selftest_lcp_dantzig_timed(count, n, A, b, lo, hi, findex, x, rc, reps, ms_per_launch);
 }
 int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                  const int32_t* findex, double* x, int32_t* rc) {
@@ -210,9 +250,9 @@ int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, cons
 int32_t nbl_selftest_pinv_rows(int32_t count, int32_t rows, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank,
                                int32_t reps, double* ms_per_launch) {
   if (rows != 24 && rows != 48) return ownError(NBL_E_BADARG, "rows must be 24 or 48");
-  g_errVariant = rows == 48 ? 16 : 8;
-  return rows == 48 ? nbl_selftest_pinv_rows_c16(count, rows, Q, cTrue, route, P, rank, reps, ms_per_launch)
-                    : nbl_selftest_pinv_rows_c8(count, rows, Q, cTrue, route, P, rank, reps, ms_per_launch);
+  const Variant* v = &kVariants[rows == 48 ? 1 : 0];
+  g_errVariant = v;
+  return v->selftest_pinv_rows(count, rows, Q, cTrue, route, P, rank, reps, ms_per_launch);
 }
 int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank, int32_t reps,
                           double* ms_per_launch) {
@@ -220,28 +260,23 @@ int32_t nbl_selftest_pinv(int32_t count, const double* Q, const int32_t* cTrue, 
 }
 
 int32_t nbl_transpose_to_soa(const double* src_bd, double* dst_db, int64_t B, int32_t d, void* stream) {
-  g_errVariant = 8;
+  g_errVariant = &kVariants[0];
   return nbl_transpose_to_soa_c8(src_bd, dst_db, B, d, stream);
 }
 int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, int32_t d, void* stream) {
-  g_errVariant = 8;
+  g_errVariant = &kVariants[0];
   return nbl_transpose_from_soa_c8(src_db, dst_bd, B, d, stream);
 }
 
-int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes) {
-  return NBL_FWD(m, nbl_set_launch_lanes_c8(m->impl, tree_lanes, lcp_lanes), nbl_set_launch_lanes_c16(m->impl, tree_lanes, lcp_lanes));
-}
-int32_t nbl_set_slices(nbl_model* m, int32_t slices) { return NBL_FWD(m, nbl_set_slices_c8(m->impl, slices), nbl_set_slices_c16(m->impl, slices)); }
-int32_t nbl_slices_for(const nbl_model* m, int64_t B) { return !m ? 0 : (m->variant == 16 ? nbl_slices_for_c16(m->impl, B) : nbl_slices_for_c8(m->impl, B)); }
-int32_t nbl_set_timing(nbl_model* m, int32_t enabled) { return NBL_FWD(m, nbl_set_timing_c8(m->impl, enabled), nbl_set_timing_c16(m->impl, enabled)); }
+int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes) { return NBL_FWD(m, set_launch_lanes, tree_lanes, lcp_lanes); }
+int32_t nbl_set_slices(nbl_model* m, int32_t slices) { return NBL_FWD(m, set_slices, slices); }
+int32_t nbl_slices_for(const nbl_model* m, int64_t B) { return NBL_GET(m, slices_for, B); }
+int32_t nbl_set_timing(nbl_model* m, int32_t enabled) { return NBL_FWD(m, set_timing, enabled); }
 int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, double* bwd_ms_sum, int64_t* bwd_count) {
-  return NBL_FWD(m, nbl_get_timing_c8(m->impl, fwd_ms_sum, fwd_count, bwd_ms_sum, bwd_count),
-                 nbl_get_timing_c16(m->impl, fwd_ms_sum, fwd_count, bwd_ms_sum, bwd_count));
+  return NBL_FWD(m, get_timing, fwd_ms_sum, fwd_count, bwd_ms_sum, bwd_count);
 }
 int32_t nbl_kernel_count(void) { return nbl_kernel_count_c8(); }
 const char* nbl_kernel_name(int32_t i) { return nbl_kernel_name_c8(i); }
-int32_t nbl_kernel_timing(nbl_model* m, int32_t i, double* ms_sum, int64_t* count) {
-  return NBL_FWD(m, nbl_kernel_timing_c8(m->impl, i, ms_sum, count), nbl_kernel_timing_c16(m->impl, i, ms_sum, count));
-}
+int32_t nbl_kernel_timing(nbl_model* m, int32_t i, double* ms_sum, int64_t* count) { return NBL_FWD(m, kernel_timing, i, ms_sum, count); }
 
 }  // extern "C"

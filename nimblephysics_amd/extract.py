@@ -161,7 +161,7 @@ def model_from_nimble_world(world, name: str = "extracted", max_contacts: Option
                           contact_clipping_depth=float(world.getContactClippingDepth()),
                           fallback_cfm=float(world.getFallbackConstraintForceMixingConstant()),
                           penetration_correction=bool(world.getPenetrationCorrectionEnabled()))
-    if boxes and max_contacts is None:          # (not said: 8 or 16 by what the world's collider pairs can hold)
+    if boxes and max_contacts is None:          # (not said: by what the world's collider pairs can hold)
         md.max_contacts = md.suggest_max_contacts()
     aspace = [int(a) for a in world.getActionSpace()]
     if aspace != list(range(md.num_dofs)):

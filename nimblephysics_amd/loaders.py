@@ -253,7 +253,8 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
     World.cpp:221-254, and its bodies are not reactive in contacts, BodyNode.cpp:2394-2400 - the ground of cartpole.skel / fullbody1.skel) is
     loaded WELDED to the world at its zero configuration ("weld": what the reference's world does with it as long as nobody gives it a
     velocity; its joint coordinates are then not part of the state vector, the one difference to the reference's World) or refused ("error").
-    `max_contacts`: contact slots per world (<= 16); None = ModelDescription.suggest_max_contacts() (8 or 16 by what the collider pairs can hold)."""
+    `max_contacts`: contact slots per world (<= 64: up to 8 the 24-row build, up to 16 the 48-row build, beyond that the general one);
+    None = ModelDescription.suggest_max_contacts() (by what the collider pairs can hold)."""
     root = ET.parse(path).getroot()
     world = root.find("world")
     if world is None:
@@ -500,7 +501,7 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
         import warnings
         warnings.warn(f"{path}: {sum(d for _, _, d in welded_dofs)} coordinate(s) of immobile skeleton(s) "
                       f"{sorted({s_ for s_, _, _ in welded_dofs})} are welded and leave the state vector (ModelDescription.welded_dofs)", stacklevel=2)
-    if boxes and max_contacts is None:          # (not said: 8 or 16 by what the collider pairs of the world can hold, ModelDescription.suggest_max_contacts)
+    if boxes and max_contacts is None:          # (not said: by what the collider pairs of the world can hold, ModelDescription.suggest_max_contacts)
         md.max_contacts = md.suggest_max_contacts()
     if md.capsule_meets_box():
         # capsule-capsule and capsule-sphere pairs are closed form (DARTCollide.cpp:4183-4420); capsule-box is libccd's MPR (:4422-4645)

@@ -456,11 +456,15 @@ class ModelDescription:
         return True
 
     def suggest_max_contacts(self) -> int:
-        """Contact slots per world for a description that does not say (the loaders' default): 8 - the 24-row build of the library, the fast
-        one - when the collider pairs that can meet cannot hold more than 8 contacts (a face of a box on another box: up to 8 points,
-        dBoxBox's clipped octagon; every sphere / capsule pair: 1 or 2) - i.e. ONE box pair, or spheres and capsules -, else 16, the most the device path carries (the reference itself keeps
-        every contact, ConstraintSolver.cpp:563-606; a world that exceeds the slots is truncated and flagged NBL_ST_CONTACT_OVERFLOW).
-        Models with more than 16 colliders or 32 collider pairs run the 48-row build whatever this says."""
+        """Contact slots per world for a description that does not say (the loaders' default): the smallest of the library's three budgets that
+        the collider pairs of the model cannot exceed in their usual configurations - 8 (the 24-row build, the fast one), 16 (the 48-row
+        build) or, beyond that, what the pairs can hold rounded up to a multiple of 8, at most 64 (the GENERAL build: rows looped over, slow,
+        no truncated answers: a tower of ten cubes holds 40 contacts).  Counted per pair that is tested at all (CollisionFilter.cpp:105-154):
+        a box on a world-fixed box 4 points (the ground's face contains the other one), two moving boxes 8 (dBoxBox's clipped octagon: the
+        reference keeps every point, DARTCollide.cpp:1384-1448), capsule pairs 2, every other pair 1; of the pairs of one moving collider with
+        several others only as many as can touch it at once are counted (a body has 6 faces; in a pile at most 2 face contacts of 8 + 4 of 4).
+        The reference itself keeps every contact (ConstraintSolver.cpp:563-606); a world that exceeds its model's slots is truncated and
+        flagged NBL_ST_CONTACT_OVERFLOW."""
         if not self.boxes:
             return 0
         m = self.merge_welds() if self.has_welds() else self
@@ -469,12 +473,16 @@ class ModelDescription:
         for i, bi in enumerate(m.boxes):
             for bj in m.boxes[i + 1:]:
                 if m.colliders_are_tested(bi, bj, skel):
-                    # a box pair: 4 points for a face on a face in line, up to 8 when the faces are turned against each other (the clipped
-                    # incident face is an octagon: dBoxBox keeps every point, DARTCollide.cpp:1384-1448 - the cull to 4 is commented out there)
-                    # (a box on a world-fixed box - a foot on the ground - is counted with 4: the ground's face contains the other one)
                     both_move = bi.body >= 0 and bj.body >= 0
                     est += (8 if both_move else 4) if (bi.shape == "box" and bj.shape == "box") else (2 if (bi.shape == "capsule" and bj.shape == "capsule") else 1)
-        return 8 if est <= 8 else 16
+        if est <= 8:
+            return 8
+        if est <= 16:
+            return 16
+        # many pairs: not all of them can be in contact at once - per moving collider at most 2 x 8 + 4 x 4 points, shared between the two sides
+        movers = sum(1 for bx in m.boxes if bx.body >= 0)
+        est = min(est, 16 * max(1, movers))
+        return min(64, (est + 7) // 8 * 8)
 
     def capsule_meets_box(self) -> bool:
         """Some capsule collider is tested against some box collider (different bodies, not both fixed to the world, different skeletons:

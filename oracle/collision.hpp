@@ -507,13 +507,14 @@ inline bool pairIsTested(const Model& m, int i, int j) {
 }
 
 // Distinct narrow-phase points per world the DEVICE's duplicate filter remembers (model_dev.hpp SEEN_POINTS = 2 x the contact slots of the
-// instantiation of the library the model runs on: 8, or 16 for a model with max_contacts > 8, more than 16 colliders or more than 32
-// collider pairs - nimble_amd_dispatch.cpp)
+// instantiation of the library the model runs on: 8; 16 for a model with max_contacts > 8, more than 16 colliders or more than 32
+// collider pairs; 64 - the general instantiation - beyond 16 contacts, 32 colliders or 64 pairs - nimble_amd_dispatch.cpp)
 inline int deviceSeenPoints(const Model& m) {
   const int nbx = (int)m.boxes.size();
   int pairs = 0;
   for (int i = 0; i + 1 < nbx; i++)
     for (int j = i + 1; j < nbx; j++) pairs += pairIsTested(m, i, j) ? 1 : 0;
+  if (m.maxContacts > 16 || nbx > 32 || pairs > 64) return 128;
   return (m.maxContacts > 8 || nbx > 16 || pairs > 32) ? 32 : 16;
 }
 

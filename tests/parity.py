@@ -126,7 +126,7 @@ def exact_reference_near_the_singularity(ow, md, s, a, g, ref, lcp=None, lcp_len
 
 
 def assert_match_or_reference_unstable(tag, ow, s, a, g, dev, ref, tol, lcp=None, lcp_len=None, n_perturb=64, closeness=0.1, ulps=1,
-                                       max_unstable=None, max_by_closeness=None, fd_model=None, only=None):
+                                       max_unstable=None, max_by_closeness=None, fd_model=None, only=None, verbose=True):
     """dev / ref: dicts of next, grad_state, grad_action [B, .].  Worlds above `tol` must be ones where the oracle's OWN result moves by
     more than `tol` under +-`ulps`-ulp perturbations of its inputs (state, and the LCP warm start when one is given), and the device
     result must be one of the oracle's outcomes: within `tol` of a perturbed run ("tol" branch), or - where those outcomes form a
@@ -178,11 +178,12 @@ def assert_match_or_reference_unstable(tag, ow, s, a, g, dev, ref, tol, lcp=None
         else:
             by_closeness += 1
     near_pi = int((tolg > tol).sum())
-    print(f"[{tag}] worlds above 1e-7 / above {tol:g} (per world and block): {(worst > 1e-7).sum()} / {(worst > tol).sum()} of {B} (max {worst.max():.2e})"
-          + (f"; {int(near.sum())} worlds within {FD_GAP} rad of a log-map singularity judged against the oracle with exact position Jacobians "
-             f"(its finite differences are off by up to {fd_err:.1e} there), {near_pi} of them within the eps / gap^3 range of doubles" if near.any() else "")
-          + f"; reference-unstable (oracle flips under {ulps}-ulp perturbations): {len(bad)}, device within tol of one of its outcomes: {by_tol}, "
-          f"accepted by the closeness branch: {by_closeness}")
+    if verbose or len(bad):
+        print(f"[{tag}] worlds above 1e-7 / above {tol:g} (per world and block): {(worst > 1e-7).sum()} / {(worst > tol).sum()} of {B} (max {worst.max():.2e})"
+              + (f"; {int(near.sum())} worlds within {FD_GAP} rad of a log-map singularity judged against the oracle with exact position Jacobians "
+                 f"(its finite differences are off by up to {fd_err:.1e} there), {near_pi} of them within the eps / gap^3 range of doubles" if near.any() else "")
+              + f"; reference-unstable (oracle flips under {ulps}-ulp perturbations): {len(bad)}, device within tol of one of its outcomes: {by_tol}, "
+              f"accepted by the closeness branch: {by_closeness}")
     if max_unstable is not None:
         assert len(bad) <= max_unstable, (tag, len(bad), max_unstable)
     cap = max(2, int(0.005 * B)) if max_by_closeness is None else max_by_closeness
