@@ -359,6 +359,15 @@ int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, cons
  * one launch over the `count` problems (NULL: not timed).  The micro-benchmark of the stage-1 solver (tools/dantzig_bench.py). */
 int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                        const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch);
+/* The solver cascade of the GENERAL instantiation (csrc/gen_lcp_dev.hpp, gen_dantzig_dev.hpp: what a model with max_contacts > 16 runs) on
+ * caller-supplied contact LCPs (HOST pointers): `count` problems of m = 3 * contacts rows each (m <= 192): A [count][m][m], b [count][m],
+ * mu [count][m / 3], x_cache [count][m] (the warm start; have_cache = 0: LCPUtils::guessSolution instead), on [count][m] bytes (NULL: every
+ * row; else the rows of the constrained group at hand).  Per problem: stage 0 and, if that fails, stages 1-3 in the reference's order, then
+ * the classification / standardisation: x [count][m], row classes cls [count][m] (0 / 1 / 2), status bits st [count] (NBL_ST_* of the LCP:
+ * 0x2 stage 0, 0x4 Dantzig, 0x8 CFM + PGS, 0x10 friction dropped, 0x20 PGS not converged, 0x40 NaN, 0x100 standardised), cfm [count].
+ * Exactly the device code of k_contact_solve_gen; tests/test_gpu_general.py compares it with the same code compiled for the host. */
+int32_t nbl_selftest_lcp_cascade(int32_t count, int32_t m, const double* A, const double* b, const double* mu, int32_t have_cache,
+                                 const double* x_cache, const uint8_t* on, double fallback_cfm, double* x, int32_t* cls, uint32_t* st, double* cfm);
 
 /* Runs the library's device pseudo-inverses on `count` caller-supplied 24 x 24 matrices (HOST pointers: Q [count][24*24] row-major,
  * rows / columns outside the block of interest zero; cTrue [count] = size of that block, Eigen's `size` in the rank threshold), one

@@ -98,6 +98,8 @@ def lib():
     L.nbl_selftest_lcp_dantzig.restype = C.c_int32
     L.nbl_selftest_lcp_dantzig_timed.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
     L.nbl_selftest_lcp_dantzig_timed.restype = C.c_int32
+    L.nbl_selftest_lcp_cascade.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, C.c_double, vp, vp, vp, vp]
+    L.nbl_selftest_lcp_cascade.restype = C.c_int32
     L.nbl_selftest_pinv.argtypes = [C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_int32, vp]
     L.nbl_selftest_pinv.restype = C.c_int32
     L.nbl_selftest_pinv_rows.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_int32, vp]
@@ -112,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing", "nbl_set_launch_lanes", "nbl_set_slices", "nbl_slices_for", "nbl_rollout_workspace_bytes", "nbl_rollout_forward", "nbl_rollout_backward",
     "nbl_set_body_inertia", "nbl_set_body_inertias", "nbl_set_inertia_params", "nbl_set_inertia_params_on", "nbl_num_inertia_params", "nbl_backward_inertia", "nbl_rollout_backward_inertia",
     "nbl_rollout_checkpoint_bytes", "nbl_rollout_forward_checkpointed", "nbl_rollout_backward_checkpointed",
-    "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing", "nbl_selftest_lcp_dantzig", "nbl_selftest_lcp_dantzig_timed", "nbl_selftest_pinv",
+    "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing", "nbl_selftest_lcp_dantzig", "nbl_selftest_lcp_dantzig_timed", "nbl_selftest_lcp_cascade", "nbl_selftest_pinv",
     "nbl_model_max_contacts", "nbl_selftest_pinv_rows",
 ]
 

@@ -1,6 +1,8 @@
-/* abi_variants.h — the library is built from ONE set of sources in two instantiations of the contact stage:
+/* abi_variants.h — the library is built from ONE set of sources in three instantiations of the contact stage:
  *   NBL_MAXC = 8   24 LCP rows, 16 colliders, 32 collider pairs   (suffix _c8,  device namespace nbl)
  *   NBL_MAXC = 16  48 LCP rows, 32 colliders, 64 collider pairs   (suffix _c16, device namespace nbl_c16)
+ *   NBL_MAXC = 64  192 LCP rows, 64 colliders, 512 collider pairs (suffix _c64, device namespace nbl_c64): the GENERAL instantiation, whose
+ *                  dense contact kernels loop over the rows (gen_contact.hip) instead of mapping them to lanes (coop_kernels.hip)
  * Each instantiation is one translation unit (nimble_amd.hip compiled with -DNBL_MAXC=.. -DNBL_VARIANT_SUFFIX=..); this header,
  * included before include/nimble_amd.h, renames the ABI's entry points and its opaque handle type with the suffix so that both fit in
  * one shared library.  nimble_amd_dispatch.cpp exports the names of include/nimble_amd.h and hands every model to the instantiation
@@ -43,6 +45,7 @@
 #define nbl_saved_bytes NBL_V(nbl_saved_bytes)
 #define nbl_selftest_lcp_dantzig NBL_V(nbl_selftest_lcp_dantzig)
 #define nbl_selftest_lcp_dantzig_timed NBL_V(nbl_selftest_lcp_dantzig_timed)
+#define nbl_selftest_lcp_cascade NBL_V(nbl_selftest_lcp_cascade)
 #define nbl_selftest_pinv NBL_V(nbl_selftest_pinv)
 #define nbl_selftest_pinv_rows NBL_V(nbl_selftest_pinv_rows)
 #define nbl_set_body_inertia NBL_V(nbl_set_body_inertia)

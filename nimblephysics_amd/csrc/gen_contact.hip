@@ -864,4 +864,43 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig_gen(int count, int n, c
   }
 }
 
+// Self-test of the general solver cascade (nbl_selftest_lcp_cascade): one wavefront per problem, the rows set up like k_contact_solve_gen
+// sets them up (three per contact, mu per contact, optionally a mask of the rows of one constrained group), then genStage0 / genCascade.
+__global__ __launch_bounds__(64) void k_selftest_cascade_gen(int count, int m, const double* __restrict__ A, const double* __restrict__ b,
+                                                            const double* __restrict__ mu, int haveCache, const double* __restrict__ xcache,
+                                                            const uint8_t* __restrict__ on, double fallbackCfm, double* __restrict__ x,
+                                                            int32_t* __restrict__ cls, uint32_t* __restrict__ st, double* __restrict__ cfmOut,
+                                                            double* __restrict__ gws) {
+  __shared__ GenRows R;
+  const GenWaveDev w;
+  const int ln = w.lane();
+  const int64_t pb = blockIdx.x;
+  if (pb >= count) return;
+  const GenScratch S = genScratchOf(gws, pb, gws + (size_t)pb * GEN_SCRATCH_DOUBLES + (size_t)3 * GR * GLD);
+  double* Ap = gws + (size_t)pb * GEN_SCRATCH_DOUBLES + (size_t)4 * GR * GLD + 16 * GR;      // the problem's matrix with leading dimension GLD (6th block)
+  for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) Ap[(size_t)i * GLD + j] = A[((size_t)pb * m + i) * m + j];
+  if (ln == 0) R.m = m;
+  w.sync();
+  for (int r = ln; r < m; r += 64) {
+    double mr = mu[(size_t)pb * (m / 3) + r / 3];
+    if (!(mr > 1e-3)) mr = 0.0;
+    R.mu[r] = mr; R.Bv[r] = b[(size_t)pb * m + r];
+    R.fric[r] = (r % 3) != 0; R.fp[r] = r - (r % 3);
+    R.lim[r] = 0; R.neg[r] = 0; R.rowOn[r] = 1;
+    R.on[r] = on ? on[(size_t)pb * m + r] : 1;
+    double cn = 0.0;
+    if (R.on[r]) for (int i = 0; i < m; i++) { const double a = Ap[(size_t)i * GLD + r]; cn = fma(a, a, cn); }
+    R.colNorm[r] = cn;
+    R.X[r] = (haveCache && R.on[r]) ? xcache[(size_t)pb * m + r] : 0.0;
+  }
+  w.sync();
+  bool pinvValid = false;
+  GenClasses K;
+  double cfmG = 0.0;
+  uint32_t stG = 0x2u | 0x100u;
+  if (!genStage0(w, Ap, GLD, R, S, haveCache != 0, pinvValid, K)) genCascade(w, Ap, GLD, R, S, fallbackCfm, cfmG, stG, pinvValid, K);
+  for (int r = ln; r < m; r += 64) { x[(size_t)pb * m + r] = R.X[r]; cls[(size_t)pb * m + r] = R.on[r] ? R.cls[r] : 0; }
+  if (ln == 0) { st[pb] = stG; cfmOut[pb] = cfmG; }
+}
+
 }  // namespace NBL_NS

@@ -38,7 +38,7 @@ struct GenRows {
 
 // scratch matrices of one world (HBM): GEN_NMAT blocks of GR x GLD doubles
 constexpr int GEN_NMAT = 5;
-constexpr size_t GEN_SCRATCH_DOUBLES = (size_t)GEN_NMAT * GR * GLD + 16 * GR;
+constexpr size_t GEN_SCRATCH_DOUBLES = (size_t)GEN_NMAT * GR * GLD + 16 * GR;      // (four matrices + 16 vectors in the step; the fifth matrix: the self-test's problem)
 
 // ---- dense helpers: lanes stride through the rows / columns, A symmetric with leading dimension lda ----------------------------------
 // y_r = sum_j A[j][r] x_j over the rows that are on (y = 0 on the others); x is masked by `on` as well

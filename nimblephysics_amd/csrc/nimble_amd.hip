@@ -1126,6 +1126,49 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
   return NBL_OK;
 }
 
+// ---- self-test: the solver cascade of the general instantiation on caller-supplied contact LCPs (host pointers) ---------------------
+int32_t nbl_selftest_lcp_cascade(int32_t count, int32_t mRows, const double* A, const double* b, const double* mu, int32_t have_cache,
+                                 const double* x_cache, const uint8_t* on, double fallback_cfm, double* x, int32_t* cls, uint32_t* st, double* cfm) {
+#if NBL_GENERAL
+  if (!A || !b || !mu || !x || !cls || !st || !cfm || (have_cache && !x_cache)) return fail(NBL_E_BADARG, "null argument");
+  if (count <= 0 || mRows <= 0 || mRows > MAX_ROWS || mRows % 3) return fail(NBL_E_BADARG, "count must be positive and m a multiple of 3 up to " + std::to_string(MAX_ROWS));
+  if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
+  const size_t nv = (size_t)count * mRows, nm = nv * mRows, nc = (size_t)count * (mRows / 3);
+  double *dA = nullptr, *dv = nullptr, *dS = nullptr;
+  int32_t* di = nullptr;
+  uint8_t* dOn = nullptr;
+  hipError_t e = hipMalloc((void**)&dA, nm * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dv, (3 * nv + nc + count) * sizeof(double));       // b, xcache, x, mu, cfm
+  if (e == hipSuccess) e = hipMalloc((void**)&di, (nv + count) * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dS, (size_t)count * GEN_SCRATCH_DOUBLES * sizeof(double));
+  if (e == hipSuccess && on) e = hipMalloc((void**)&dOn, nv);
+  if (e == hipSuccess) e = hipMemcpy(dA, A, nm * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv, b, nv * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess && have_cache) e = hipMemcpy(dv + nv, x_cache, nv * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv + 3 * nv, mu, nc * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess && on) e = hipMemcpy(dOn, on, nv, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_selftest_cascade_gen, dim3((unsigned)count), dim3(64), 0, 0, count, mRows, dA, dv, dv + 3 * nv, have_cache, dv + nv, dOn, fallback_cfm,
+                       dv + 2 * nv, di, (uint32_t*)(di + nv), dv + 3 * nv + nc, dS);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(x, dv + 2 * nv, nv * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cls, di, nv * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(st, di + nv, count * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cfm, dv + 3 * nv + nc, count * sizeof(double), hipMemcpyDeviceToHost);
+  if (dA) hipFree(dA);
+  if (dv) hipFree(dv);
+  if (di) hipFree(di);
+  if (dS) hipFree(dS);
+  if (dOn) hipFree(dOn);
+  if (e != hipSuccess) return fail(NBL_E_HIP, std::string("nbl_selftest_lcp_cascade: ") + hipGetErrorString(e));
+  return NBL_OK;
+#else
+  (void)count; (void)mRows; (void)A; (void)b; (void)mu; (void)have_cache; (void)x_cache; (void)on; (void)fallback_cfm; (void)x; (void)cls; (void)st; (void)cfm;
+  return fail(NBL_E_UNSUPPORTED, "nbl_selftest_lcp_cascade addresses the general instantiation");
+#endif
+}
+
 // ---- self-test: the device pseudo-inverses on caller-supplied matrices (host pointers) ----------------------------------------
 int32_t nbl_selftest_pinv_rows(int32_t count, int32_t rows, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank,
                                int32_t reps, double* ms_per_launch) {

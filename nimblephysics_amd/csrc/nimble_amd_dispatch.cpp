@@ -47,6 +47,8 @@
   int32_t nbl_selftest_lcp_dantzig_timed##S(int32_t, int32_t, const double*, const double*, const double*, const double*, const int32_t*,  \
                                             double*, int32_t*, int32_t, double*);                                                          \
   int32_t nbl_selftest_pinv_rows##S(int32_t, int32_t, const double*, const int32_t*, int32_t, double*, int32_t*, int32_t, double*);        \
+  int32_t nbl_selftest_lcp_cascade##S(int32_t, int32_t, const double*, const double*, const double*, int32_t, const double*, const uint8_t*, double,   \
+                                      double*, int32_t*, uint32_t*, double*);                                                              \
   int32_t nbl_transpose_to_soa##S(const double*, double*, int64_t, int32_t, void*);                                                        \
   int32_t nbl_transpose_from_soa##S(const double*, double*, int64_t, int32_t, void*);                                                      \
   int32_t nbl_set_launch_lanes##S(void*, int32_t, int32_t);                                                                                \
@@ -246,6 +248,11 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
 int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                  const int32_t* findex, double* x, int32_t* rc) {
   return nbl_selftest_lcp_dantzig_timed(count, n, A, b, lo, hi, findex, x, rc, 1, nullptr);
+}
+int32_t nbl_selftest_lcp_cascade(int32_t count, int32_t m, const double* A, const double* b, const double* mu, int32_t have_cache,
+                                 const double* x_cache, const uint8_t* on, double fallback_cfm, double* x, int32_t* cls, uint32_t* st, double* cfm) {
+  g_errVariant = &kVariants[2];       // (the general instantiation's code, whatever the size)
+  return nbl_selftest_lcp_cascade_c64(count, m, A, b, mu, have_cache, x_cache, on, fallback_cfm, x, cls, st, cfm);
 }
 int32_t nbl_selftest_pinv_rows(int32_t count, int32_t rows, const double* Q, const int32_t* cTrue, int32_t route, double* P, int32_t* rank,
                                int32_t reps, double* ms_per_launch) {

@@ -115,3 +115,22 @@ int gshim_cascade(int m, const double* A, const double* b, const double* mu, con
   return (int)st;
 }
 }
+
+extern "C" {
+// one stage of the cascade alone (1, 2 or 3) on the rows of `mask`, from the pre-solve x: the RAW candidate and the GS_* flags
+int gshim_stage(int stage, int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const double* x0, double fallbackCfm, double* X) {
+  World Wd;
+  const HostWave1 w;
+  std::vector<double> Ap((size_t)GR * GLD, 0.0);
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Ap[(size_t)i * GLD + j] = A[(size_t)i * m + j];
+  fillRows(Wd.R, m, Ap.data(), b, mu, mask, nullptr, nullptr);
+  for (int r = 0; r < m; r++) Wd.R.X0[r] = Wd.R.on[r] ? x0[r] : 0.0;
+  std::vector<double> out(GR, 0.0);
+  int flags = 0;
+  if (stage == 1) flags = genStage1(w, Ap.data(), GLD, Wd.R, Wd.S, out.data());
+  else if (stage == 2) flags = genStage2(w, Ap.data(), GLD, Wd.R, Wd.S, fallbackCfm, out.data());
+  else flags = genStage3(w, Ap.data(), GLD, Wd.R, Wd.S, fallbackCfm, out.data());
+  for (int r = 0; r < m; r++) X[r] = out[r];
+  return flags;
+}
+}
