@@ -314,6 +314,25 @@ def main():
         single = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1], slices=1)
         # ... and as ONE call per step with the library's own slicing (what a caller gets who hands over the whole batch at once)
         single_call = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1])
+    host_tensors = None
+    if has_contact and not args.no_single_stream and world_size == 1 and args.rollout == 0:
+        # the reference's OWN calling convention (python/nimblephysics/timestep.py:31-40): float64 CPU tensors [B, 2n] / [B, k] in, CPU tensors
+        # out, through the drop-in surface timestep() + .backward() of ONE World - pinned staging, asynchronous copies on the step's stream,
+        # the two layout transposes, everything.  PCIe-inclusive: a secondary figure, never `value`.
+        from nimblephysics_amd.timestep import timestep
+        hw = na.World(R["md"], device=dev)
+        hs = torch.tensor(R["s"], requires_grad=True); ha = torch.tensor(R["a"], requires_grad=True)
+        hsteps = max(4, args.steps // 2)
+        for it in range(3 + hsteps):
+            if it == 3:
+                torch.cuda.synchronize(dev); t0h = time.perf_counter()
+            hs.grad = None; ha.grad = None
+            hw.reset_lcp_cache()
+            hout = timestep(hw, hs, ha)
+            (hout * hout).sum().backward()
+        torch.cuda.synchronize(dev)
+        host_tensors = {"elapsed": time.perf_counter() - t0h, "steps": hsteps}
+        del hw
     elapsed, st, tm, timing_period, md, s_np, a_np, wl_desc, world = (R[x] for x in ("elapsed", "status", "timing", "timing_period", "md", "s", "a", "desc", "world"))
     n = world.n
 
@@ -438,6 +457,12 @@ def main():
                 "value": units_per_step * ssteps / single_call["elapsed"], "unit": "worlds*timesteps/s", "steps": ssteps,
                 "ms_per_step": single_call["elapsed"] / ssteps * 1e3, "stream_slices": single_call["slices"],
                 "note": "the same batch and distribution handed to ONE World in one call per pass (the library slices the call itself; every call joins before it returns)"}
+        if host_tensors is not None:
+            out.setdefault("secondary", {})["host_tensors"] = {
+                "value": B * host_tensors["steps"] / host_tensors["elapsed"], "unit": "worlds*timesteps/s", "steps": host_tensors["steps"],
+                "ms_per_step": host_tensors["elapsed"] / host_tensors["steps"] * 1e3,
+                "note": "PCIe-inclusive: timestep(world, state, action) + backward() of ONE World with float64 CPU tensors [B, 2n] / [B, k] in and CPU tensors "
+                        "out (the reference's own convention); pinned staging + asynchronous copies on the step's stream.  Never `value`."}
         if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(md, s_np, a_np)

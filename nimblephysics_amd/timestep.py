@@ -44,6 +44,8 @@ class TimestepLayer(torch.autograd.Function):
         out = world.from_soa(nxt)                             # torch.tensor(world.getState())
         if one_d:
             out = out[0]
+        if in_device.type == "cpu" and out.device.type == "cuda":
+            return world._to_host(out)                        # (pinned, asynchronous, one synchronisation: World._to_host)
         return out.to(in_device)
 
     @staticmethod
@@ -52,7 +54,7 @@ class TimestepLayer(torch.autograd.Function):
         g = grad_state.detach()
         if ctx.one_d:
             g = g.unsqueeze(0)
-        g = g.to(device=world.device, dtype=torch.float64).contiguous()
+        g = world._prep(g, 2 * world.n, "backprop").contiguous()
         gs, ga = world.backward_soa(ctx.saved_record, world.to_soa(g))     # snapshot.backpropState(world, grad)
         d_state, d_action = world.from_soa(gs), world.from_soa(ga)
         d_mass = None
@@ -61,6 +63,9 @@ class TimestepLayer(torch.autograd.Function):
             d_mass = world.backward_inertia_soa(ctx.saved_record, g.shape[0]).sum(dim=1).to(ctx.mass_device)
         if ctx.one_d:
             d_state, d_action = d_state[0], d_action[0]
+        if ctx.in_device.type == "cpu" and ctx.action_device.type == "cpu" and d_state.device.type == "cuda":
+            d_state, d_action = world._to_host(d_state, d_action)
+            return None, d_state, d_action, d_mass
         return None, d_state.to(ctx.in_device), d_action.to(ctx.action_device), d_mass
 
 

@@ -236,7 +236,25 @@ class World:
             x = x.unsqueeze(0)
         if x.dim() != 2 or x.shape[1] != width:
             raise ValueError(f"World.{what}() called with a tensor of incorrect size {tuple(x.shape)}; expected [B, {width}]")
-        return x.detach().to(device=self.device, dtype=torch.float64)
+        x = x.detach()
+        if x.device.type == "cpu" and self.device.type == "cuda":
+            # the reference's own convention - CPU float64 tensors in and out (python/nimblephysics/timestep.py:31-40) - without the
+            # pageable-memory copies (each one a staging pass inside the driver + a device synchronisation: 10 ms per step at B = 4096, DESIGN
+            # section 6): one pass into pinned memory (the caching host allocator hands the block back), then an asynchronous copy on the step's stream
+            pin = torch.empty(x.shape, dtype=torch.float64, pin_memory=True)
+            pin.copy_(x)
+            return pin.to(self.device, non_blocking=True)
+        return x.to(device=self.device, dtype=torch.float64)
+
+    def _to_host(self, *tensors):
+        """Device tensors -> pinned CPU tensors with asynchronous copies on the current stream and ONE synchronisation for all of them."""
+        outs = []
+        for t in tensors:
+            o = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            o.copy_(t, non_blocking=True)
+            outs.append(o)
+        torch.cuda.current_stream(self.device).synchronize()
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     # ---- state / action API ---------------------------------------------------------------------
     def setState(self, state: torch.Tensor):
