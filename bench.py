@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed region until this much time has been timed; the median repetition is reported")
     ap.add_argument("--max-reps", type=int, default=25)
     ap.add_argument("--max-contacts", type=int, default=0, help="diagnostic: contact slots per world of the model (0 = the workload's own, 8); 16 runs the "
-                    "same worlds on the 48-row instantiation of the contact stage")
+                    "same worlds on the 48-row instantiation of the contact stage, 17..64 on the general one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -232,7 +232,8 @@ def main():
         md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, noise)
         if args.max_contacts > 0 and md.max_contacts:
             md.max_contacts = args.max_contacts
-            wl_desc += f" [max_contacts = {args.max_contacts}: the {3 * max(8, args.max_contacts) if args.max_contacts <= 8 else 48}-row build]"
+            build = "24-row" if args.max_contacts <= 8 else "48-row" if args.max_contacts <= 16 else "general (up to 192 rows, matrices in HBM scratch)"
+            wl_desc += f" [max_contacts = {args.max_contacts}: the {build} build]"
         worlds = [na.World(md, device=dev) for _ in bounds]
         if slices is not None:
             for w_ in worlds:
@@ -322,7 +323,13 @@ def main():
         from nimblephysics_amd.timestep import timestep
         hw = na.World(R["md"], device=dev)
         hs = torch.tensor(R["s"], requires_grad=True); ha = torch.tensor(R["a"], requires_grad=True)
-        hsteps = max(4, args.steps // 2)
+        hsteps = max(8, args.steps)
+        # torch's CPU ops of this leg (copies of 1.3 MB, the loss) run on ONE intra-op thread: torch's default (one OpenMP thread per logical
+        # CPU, 256 here, spinning after every op) overruns the container's CFS quota (16 CPUs on the GPU boxes of this pool) and the whole
+        # process is throttled for the rest of the 100 ms period once every few steps (tools/dbg/host_alloc_stall_probe.py: cpu.stat
+        # nr_throttled goes up, 0.39 M/s instead of 3.3); a caller in such a container sets OMP_NUM_THREADS to its quota for the same reason
+        cpu_threads = torch.get_num_threads()
+        torch.set_num_threads(1)
         for it in range(3 + hsteps):
             if it == 3:
                 torch.cuda.synchronize(dev); t0h = time.perf_counter()
@@ -332,6 +339,7 @@ def main():
             (hout * hout).sum().backward()
         torch.cuda.synchronize(dev)
         host_tensors = {"elapsed": time.perf_counter() - t0h, "steps": hsteps}
+        torch.set_num_threads(cpu_threads)
         del hw
     elapsed, st, tm, timing_period, md, s_np, a_np, wl_desc, world = (R[x] for x in ("elapsed", "status", "timing", "timing_period", "md", "s", "a", "desc", "world"))
     n = world.n
@@ -462,7 +470,9 @@ def main():
                 "value": B * host_tensors["steps"] / host_tensors["elapsed"], "unit": "worlds*timesteps/s", "steps": host_tensors["steps"],
                 "ms_per_step": host_tensors["elapsed"] / host_tensors["steps"] * 1e3,
                 "note": "PCIe-inclusive: timestep(world, state, action) + backward() of ONE World with float64 CPU tensors [B, 2n] / [B, k] in and CPU tensors "
-                        "out (the reference's own convention); pinned staging + asynchronous copies on the step's stream.  Never `value`."}
+                        "out (the reference's own convention); the World's pinned staging buffers + asynchronous copies on the step's stream; torch CPU "
+                        "intra-op threads = 1 for this leg (the default overruns the container's CFS quota, see bench.py).  Never `value`.",
+                "torch_cpu_threads": 1}
         if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(md, s_np, a_np)

@@ -1,6 +1,6 @@
 # The measurements of a round on its final build (GPU box): the seven rocprofv3 passes of tools/profile.sh + the bench variants.
 #   usage: bash tools/measure.sh <tag>      -> gpurun_out/<tag>_*
-TAG=${1:-r04}
+TAG=${1:-r05}
 set -u
 mkdir -p gpurun_out
 bash tools/profile.sh ${TAG} > gpurun_out/${TAG}_profile.log 2>&1
@@ -13,4 +13,5 @@ python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload a
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --batch 8192 > gpurun_out/${TAG}_bench_atlas33.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --rollout 64 --batch 8192 > gpurun_out/${TAG}_bench_atlas33_rollout.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --max-contacts 16 > gpurun_out/${TAG}_bench_48rows.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --max-contacts 24 --steps 8 --warmup 2 > gpurun_out/${TAG}_bench_general.json 2>/dev/null
 for f in gpurun_out/${TAG}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
