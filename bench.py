@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="slices of the per-GPU batch, each a World on its own HIP stream (0 = auto: 4 from 4096 worlds, 2 from 2048)")
     ap.add_argument("--checkpoint-every", type=int, default=0, help="with --rollout: keep the backward records of K steps instead of T (the backward pass recomputes the other segments)")
     ap.add_argument("--rollout", type=int, default=0, help="diagnostic: one step = one pass of a T-step rollout fwd+bwd (nbl_rollout_*), value counts T*B worlds*steps per pass")
+    ap.add_argument("--graph", action="store_true", help="with --rollout: capture the rollout's forward + backward pass in ONE HIP graph and time its replays")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: timed region without the per-kernel HIP events")
     ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (torch.distributed.run, one process per GPU, RCCL) even for --gpus 1")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the secondary one-launch-per-kernel measurement")
@@ -244,9 +245,22 @@ def main():
         action = [w.to_soa(torch.tensor(a_np[lo:hi], device=dev)) for w, (lo, hi) in zip(worlds, bounds)]
         torch.cuda.synchronize(dev)
 
+        graphed = None
+        if args.rollout > 0 and args.graph:
+            from nimblephysics_amd.graph import GraphedRollout
+            graphed = GraphedRollout(world, B, args.rollout, shared_action=True, warm_start=True,
+                                     loss_grad=lambda states: torch.cat([torch.zeros_like(states[:-1]), 2.0 * states[-1:]], 0))
+            graphed.state0.copy_(state0[0]); graphed.actions.copy_(action[0])
+            graphed.capture()
+
         def run(T):
             ga_total = [torch.zeros((k, hi - lo), dtype=torch.float64, device=dev) for (lo, hi) in bounds]
             status = [None] * len(bounds)
+            if args.rollout > 0 and args.graph:      # the same pass replayed from ONE captured HIP graph (nimblephysics_amd.graph.GraphedRollout)
+                for _ in range(T):
+                    graphed.replay()
+                    ga_total[0] += graphed.grad_actions.sum(0)
+                return shared_parameter_grad(ga_total[0]), graphed.status[0]
             if args.rollout > 0:      # cfg5-style: T-step trajectory, loss = |q_T|^2 + |v_T|^2, one shared control vector
                 for _ in range(T):
                     states, sv, st_all = world.rollout_soa(state0[0], action[0], T=args.rollout, want_saved=True, warm_start=True, checkpoint_every=args.checkpoint_every)

@@ -7,7 +7,7 @@ from .model import (BodySpec, BoxSpec, CapsuleSpec, ModelDescription, SphereSpec
                     make_transform, single_pendulum)
 
 __all__ = ["ModelDescription", "BodySpec", "BoxSpec", "SphereSpec", "CapsuleSpec", "World", "timestep", "TimestepLayer", "rollout", "RolloutLayer", "single_pendulum", "cartpole",
-           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "load_model", "loadWorld", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep", "neural", "forwardPass", "BackpropSnapshot",
+           "atlas", "box_stack", "make_transform", "load_urdf", "load_skel", "with_ground", "load_model", "loadWorld", "model_from_nimble_world", "WrtMassBodyNodeEntryType", "GraphedStep", "GraphedRollout", "neural", "forwardPass", "BackpropSnapshot",
            "LossGradient", "LossGradientHighLevelAPI", "NimbleAmdError"]
 
 
@@ -15,9 +15,9 @@ def __getattr__(name):
     if name == "NimbleAmdError":                             # what every refused model / failed call raises
         from ._lib import NimbleAmdError
         return NimbleAmdError
-    if name == "GraphedStep":
-        from .graph import GraphedStep
-        return GraphedStep
+    if name in ("GraphedStep", "GraphedRollout"):
+        from . import graph as _g
+        return getattr(_g, name)
     if name == "WrtMassBodyNodeEntryType":
         from .mass import WrtMassBodyNodeEntryType
         return WrtMassBodyNodeEntryType
