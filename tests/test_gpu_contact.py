@@ -265,8 +265,8 @@ def test_results_do_not_depend_on_uninitialised_memory():
             ref[ci] = res
 
 
-@pytest.mark.parametrize("mus,max_unstable", [((0.0, 1.0, 1.0), 0.01), ((1.0, 0.0005, 1.0), 1.0), ((0.0, 0.0, 0.0), 1.0)])
-def test_frictionless_contacts_fwd_bwd_vs_oracle(mus, max_unstable):
+@pytest.mark.parametrize("mus,min_unstable,max_unstable", [((0.0, 1.0, 1.0), 0.0, 0.01), ((1.0, 0.0005, 1.0), 0.55, 0.72), ((0.0, 0.0, 0.0), 0.55, 0.72)])
+def test_frictionless_contacts_fwd_bwd_vs_oracle(mus, min_unstable, max_unstable):
     """Contacts with mu = min(mu_A, mu_B) <= 1e-3 have ONE row in the reference (ContactConstraint.cpp:107-118, 229); the
     oracle restates that, the device keeps three row slots with the tangent rows empty.  Box stack with a frictionless
     ground (ground-cube contacts frictionless, cube-cube frictional: well posed, every world within 1e-5), a frictionless
@@ -303,11 +303,14 @@ def test_frictionless_contacts_fwd_bwd_vs_oracle(mus, max_unstable):
     # In the two degenerate variants the reference's gradient is round-off times 1e11 (a continuum of outcomes, not a few branches): the
     # device's value has to lie INSIDE the cloud of the reference's own outcomes - closer to one of 256 perturbed runs than a quarter of
     # their scatter; its own round-off differs from the oracle's (spatial quantities about the tree roots, not per body frame)
-    degenerate = max_unstable >= 1.0
+    degenerate = max_unstable >= 0.5
     unstable = _assert_all_worlds_match_or_reference_is_unstable(f"frictionless {mus}", errs, world, NORTH_STAR_TOL,
                                                                  n_perturb=256 if degenerate else 64, closeness=0.25 if degenerate else 0.1,
                                                                  ulps=4 if degenerate else 1, max_by_closeness=8 if degenerate else None)   # (measured: 2 of 512 need the closeness branch)
-    assert unstable <= max_unstable * B
+    print(f"[frictionless mus={mus}] reference-unstable worlds: {unstable} of {B} = {unstable / B:.3f}")
+    # the expected reference-unstable fraction, two-sided (measured: 1, 324 and 324 of 512): a change of either the device or the oracle
+    # that moves worlds into or out of the proven-unstable class fails here
+    assert min_unstable * B <= unstable <= max_unstable * B, (unstable, B)
     assert np.median(errs["next"]) < 1e-10            # (per world and block: the lateral velocities of the cubes are a block of ~0.05)
 
 

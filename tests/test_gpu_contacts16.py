@@ -2,6 +2,8 @@
 pair, DARTCollide.cpp:1384-1448): models with max_contacts up to 16, up to 32 colliders and 64 collider pairs run the 48-row instantiation
 of the library's contact stage (csrc/abi_variants.h).  Every world against the oracle, which solves with all the contacts there are;
 no world may carry NBL_ST_CONTACT_OVERFLOW and none is masked."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,11 @@ from parity import assert_match_or_reference_unstable, world_errors
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
+# The perturbation the reference-instability proofs may use, and how much closer to one of the oracle's perturbed outcomes than they scatter
+# a device result has to be where those form a continuum.  Rounds 3-4 ran these files at 16 ulps / closeness 1.0; at 4 ulps / 0.25
+#  nothing breaks: every file passes with the same world counts (profiles/r05_hatches_ulps4.log).
+ULPS = int(os.environ.get("NBL_TEST_ULPS", "4"))
+CLOSENESS = float(os.environ.get("NBL_TEST_CLOSENESS", "0.25"))
 
 
 def _fwd_bwd(md, s, a, seed):
@@ -69,7 +76,7 @@ def test_cube_towers_of_12_and_16_contacts(n_cubes, B, seed):
     assert np.array_equal(st & 0x1, ref["status"] & 0x1) and (st & 0x1).all()
     same = (st & 0x13e) == (ref["status"] & 0x13e)
     print(f"[{n_cubes} cubes] stage histogram (device):", {hex(int(k)): int(v) for k, v in zip(*np.unique(st & 0x13e, return_counts=True))}, "same stage as the oracle:", float(same.mean()))
-    bad, _ = assert_match_or_reference_unstable(f"{n_cubes}-cube tower", ow, s, a, g, dev, ref, TOL, ulps=16, n_perturb=64)
+    bad, _ = assert_match_or_reference_unstable(f"{n_cubes}-cube tower", ow, s, a, g, dev, ref, TOL, ulps=ULPS, n_perturb=64)
     assert bad <= 0.03 * B
 
 
@@ -93,8 +100,11 @@ def test_a_table_on_four_feet_has_sixteen_contacts_of_rank_six():
     e, _ = world_errors(dev, ref)
     for k in e:
         assert e[k][stage0].max() < TOL, (k, float(e[k][stage0].max()))
-    bad, by_closeness = assert_match_or_reference_unstable("table on 16 contacts", ow, s, a, g, dev, ref, TOL, ulps=16, closeness=1.0, max_by_closeness=int(0.02 * B))
-    assert bad <= 0.10 * B and by_closeness <= 0.02 * B
+    bad, by_closeness = assert_match_or_reference_unstable("table on 16 contacts", ow, s, a, g, dev, ref, TOL, ulps=ULPS, closeness=CLOSENESS, max_by_closeness=int(0.02 * B))
+    # 33 of 512 worlds (6.4 %) on this seed, each one PROVEN above (the oracle's own answer moves by more than 1e-7 under 4-ulp perturbations
+    # of that world's state, and the device result is within 1e-7 of one of those outcomes: 31, or 4 x closer to one than they scatter: 2).
+    # Two-sided, so that a change of the cascade in either direction shows up
+    assert 0.03 * B <= bad <= 0.08 * B and by_closeness <= 0.02 * B, (bad, by_closeness)
 
 
 def test_more_than_sixteen_colliders_run_the_48_row_build_too():
@@ -118,5 +128,5 @@ def test_more_than_sixteen_colliders_run_the_48_row_build_too():
     ow = OracleWorld(md)
     ref = ow.step_batch(s, a, g, threads=8)
     assert (st & 0x1).all() and np.array_equal(st & 0x81, ref["status"] & 0x81)
-    bad, _ = assert_match_or_reference_unstable("20 colliders", ow, s, a, g, dev, ref, TOL, ulps=16)
+    bad, _ = assert_match_or_reference_unstable("20 colliders", ow, s, a, g, dev, ref, TOL, ulps=ULPS)
     assert bad <= 0.03 * B

@@ -5,6 +5,7 @@ data/skel/test/box_stacking.skel in the configuration it ships in (ten cubes sta
 several cubes from the first step, 40 in ONE group once the tower stands on the ground) - and, so that the new kernels are judged where the answer is known best, the
 metric distribution and the earlier many-contact scenes run through the general kernels as well."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -13,6 +14,8 @@ from parity import assert_match_or_reference_unstable, world_errors
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
+ULPS = int(os.environ.get("NBL_TEST_ULPS", "4"))            # (as in tests/test_gpu_contacts16.py)
+CLOSENESS = float(os.environ.get("NBL_TEST_CLOSENESS", "0.25"))
 # ten cubes: 120 LCP rows of rank 60, Q^+ of a 108 x 108 clamping block whose condition number on its range is ~1e6 - the least-squares
 # impulses (and everything downstream) carry cond(Q) eps ~ 1e-9 .. 1e-7 on BOTH sides; held to 1e-6 (north_star: 1e-5)
 TOL_BIG = 1e-6
@@ -122,7 +125,7 @@ def test_cube_towers_of_twenty_and_forty_contacts(n_cubes, B):
     e, _ = world_errors(dev, ref)
     print(f"[{n_cubes}-cube tower] stages:", {hex(int(k)): int(c) for k, c in zip(*np.unique(st & 0x13e, return_counts=True))},
           "max errors:", {k: float(v.max()) for k, v in e.items()})
-    bad, _ = assert_match_or_reference_unstable(f"{n_cubes}-cube tower, {4 * n_cubes} contacts", ow, s, a, g, dev, ref, TOL if n_cubes <= 5 else TOL_BIG, ulps=16,
+    bad, _ = assert_match_or_reference_unstable(f"{n_cubes}-cube tower, {4 * n_cubes} contacts", ow, s, a, g, dev, ref, TOL if n_cubes <= 5 else TOL_BIG, ulps=ULPS,
                                                 max_unstable=max(3, int(0.1 * B)))
 
 
@@ -169,7 +172,10 @@ def test_two_towers_and_a_table_are_three_constrained_groups():
     assert (st & 1).all() and not ((st | ref["status"]) & 0x80).any()
     e, _ = world_errors(dev, ref)
     print("[three constrained groups, 44 contacts] max errors:", {k: float(v_.max()) for k, v_ in e.items()})
-    assert_match_or_reference_unstable("three groups", ow, s, a, g, dev, ref, TOL, ulps=16, max_unstable=int(0.15 * B), closeness=1.0, max_by_closeness=4)
+    # closeness 1.0 here, not the file's 0.25: the table group is the most degenerate LCP of the suite (tests/test_gpu_contacts16.py) and with
+    # 64 perturbed runs of the oracle per world one world (36 of this seed) lands 0.37 from the nearest of outcomes that scatter by 0.72 -
+    # ratio 0.51: what breaks at 4 ulps / 0.25, everything else in the three files passes there
+    assert_match_or_reference_unstable("three groups", ow, s, a, g, dev, ref, TOL, ulps=ULPS, max_unstable=int(0.15 * B), closeness=1.0, max_by_closeness=4)
 
 
 def test_box_stacking_skel_as_it_ships_until_the_tower_rests_on_the_ground():
@@ -246,7 +252,7 @@ def test_box_stacking_skel_as_it_ships_until_the_tower_rests_on_the_ground():
             if len(unstable_steps) < 2:      # the proof, on the first two (64 perturbed oracle runs each).  The full instruments of the soak take a minute per
                                              # step and proved the next ones in a development run (profiles/r05_box_stacking_rollout_proofs.log: unstable_A_abs)
                 assert_match_or_reference_unstable(f"box_stacking.skel step {t}", ow, xin, a, g, dev, ref, TOL_BIG, lcp=kw.get("lcp_in"), lcp_len=kw.get("lcp_len_in"),
-                                                   ulps=16, max_unstable=B, closeness=1.0, max_by_closeness=B)
+                                                   ulps=ULPS, max_unstable=B, closeness=CLOSENESS, max_by_closeness=B)
             unstable_steps.append(t)
         # the device's narrow phase found exactly the reference's contacts (the LCP warm start leaving the step carries their number)
         ow.reset_lcp_cache(); ow.step(xin[0], a[0])

@@ -1,6 +1,8 @@
 """Three of the reference's OWN worlds that the 24-row build of the library had to refuse (more than 16 colliders, more than 32
 collider pairs, more than 8 contacts), transcribed by tools/urdf_to_model.py from data/skel/biped.skel, data/skel/fullbody1.skel and
 data/skel/test/box_stacking.skel (nimblephysics_amd/data/*.json): forward + backward on the device against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,11 @@ from parity import assert_match_or_reference_unstable, world_errors
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
+# The perturbation the reference-instability proofs may use, and how much closer to one of the oracle's perturbed outcomes than they scatter
+# a device result has to be where those form a continuum.  Rounds 3-4 ran these files at 16 ulps / closeness 1.0; at 4 ulps / 0.25
+#  nothing breaks: every file passes with the same world counts (profiles/r05_hatches_ulps4.log).
+ULPS = int(os.environ.get("NBL_TEST_ULPS", "4"))
+CLOSENESS = float(os.environ.get("NBL_TEST_CLOSENESS", "0.25"))
 
 
 def _fwd_bwd(md, s, a, seed):
@@ -52,7 +59,7 @@ def test_fullbody1_standing_on_sixteen_contacts():
     ow.step(s[0], a[0])
     assert len(ow.last_contacts()) == 16
     print("[fullbody1] device stages:", {hex(int(k)): int(c) for k, c in zip(*np.unique(st & 0x13e, return_counts=True))})
-    bad, by_closeness = assert_match_or_reference_unstable("fullbody1 on 16 contacts", ow, s, a, g, dev, ref, TOL, ulps=16)
+    bad, by_closeness = assert_match_or_reference_unstable("fullbody1 on 16 contacts", ow, s, a, g, dev, ref, TOL, ulps=ULPS)
     assert bad <= 0.05 * B
 
 
@@ -113,5 +120,5 @@ def test_box_stacking_world_with_four_of_its_ten_cubes_stacked():
     assert (st & 0x1).all() and np.array_equal(st & 0x81, ref["status"] & 0x81) and not (st & 0x80).any()
     ow.step(s[0], a[0])
     assert len(ow.last_contacts()) == 16
-    bad, _ = assert_match_or_reference_unstable("box_stacking.skel, 4 of 10 cubes stacked", ow, s, a, g, dev, ref, TOL, ulps=16)
+    bad, _ = assert_match_or_reference_unstable("box_stacking.skel, 4 of 10 cubes stacked", ow, s, a, g, dev, ref, TOL, ulps=ULPS)
     assert bad <= 0.03 * B
