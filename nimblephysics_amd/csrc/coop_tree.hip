@@ -75,7 +75,7 @@ DEV bool coopTreeSetup(CoopCtxT<P>& c, const DevModel& mdl, const DevBody* __res
 DEV double* treeBlock(double* saved, const SavedLayout& lay, int64_t B, int64_t b) {
   return saved + ((int64_t)lay.total + lay.dense) * B + b * (int64_t)lay.treeRows;
 }
-// kept slots: LDS image (compact rows + free-joint blocks) <-> tree block ([slot][nbp], every kept slot of every body).
+// kept slots: LDS image (compact rows + free-joint blocks) <-> the compact tree block of the record (treeCompactRow, model_dev.hpp).
 // Lanes are laid over (row, body) so that a wavefront moves 64 / nbp rows per trip without integer divisions in the loop.
 template <int P, bool STORE>
 DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
@@ -87,19 +87,24 @@ DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
     // the articulated inertia (21 of the forward profile's 71 kept rows) has ONE reader per tree: the 6 x 6 solve of a free-joint root
     // (kernels.hip, k_contact_rows_coop's free-joint block) - the other bodies' rows stay in LDS (30 % of the block's write traffic)
     const bool keepsAI = !(STORE && P == PROF_FWD) || (body < c.nb && c.bodies[body].jtype == JT_FREE);
+    const int fiMine = body < c.nb ? c.bodies[body].freeIdx : -1;
+#pragma unroll        // (fully unrolled: the row -> slot -> block-row maps fold to constants)
     for (int r0 = 0; r0 < KEPT; r0 += U) {
       double tmp[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = r0 + u;
-        if (r < KEPT) tmp[u] = STORE ? c.lds[r * c.nbp + body] : blk[coopRowSlot<P>(r) * c.nbp + body];
+        if (r < KEPT) tmp[u] = STORE ? c.lds[r * c.nbp + body] : blk[treeCompactRow(coopRowSlot<P>(r)) * c.nbp + body];   // (the rows the backward profile keeps are rows of the block)
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = r0 + u;
         if (r < KEPT) {
-          if (STORE) { if (keepsAI || r < WS_AI || r >= WS_AI + 21) blk[coopRowSlot<P>(r) * c.nbp + body] = tmp[u]; }
-          else c.lds[r * c.nbp + body] = tmp[u];
+          if (STORE) {
+            const int cr = treeCompactRow(coopRowSlot<P>(r));
+            if (cr >= 0) blk[cr * c.nbp + body] = tmp[u];
+            else if (keepsAI && P == PROF_FWD) blk[TREE_ROWS * c.nbp + fiMine * TREE_FREE + (-1 - cr)] = tmp[u];   // AI of a free-joint body
+          } else c.lds[r * c.nbp + body] = tmp[u];
         }
       }
     }
@@ -108,9 +113,9 @@ DEV void coopCopyTree(const CoopCtxT<P>& c, double* blk) {
     const int fi = c.bodies[fb].freeIdx;
     if (fi < 0 || body >= c.nbp) continue;
     for (int e = body; e < coopFreeExtra<P>(); e += c.nbp) {
-      const int slot = coopFreeSlot<P>(e);
-      if (STORE) blk[slot * c.nbp + fb] = c.ldsFree[fi * coopFreeExtra<P>() + e];
-      else c.ldsFree[fi * coopFreeExtra<P>() + e] = blk[slot * c.nbp + fb];
+      double* at = blk + TREE_ROWS * c.nbp + fi * TREE_FREE + (-1 - treeCompactRow(coopFreeSlot<P>(e)));   // (every slot of the free-joint LDS block lives in the free-joint part)
+      if (STORE) *at = c.ldsFree[fi * coopFreeExtra<P>() + e];
+      else c.ldsFree[fi * coopFreeExtra<P>() + e] = *at;
     }
   }
 }
@@ -716,11 +721,11 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_BFINAL) void k_b
   }
 }
 
-// World-major tree blocks [b][slot][nbp]  ->  the lane-interleaved kept slots of the workspace ws[(body * 288 + slot) * B + b],
+// Compact world-major tree blocks (model_dev.hpp)  ->  the lane-interleaved kept slots of the workspace ws[(body * 288 + slot) * B + b],
 // for the one-world-per-lane k_bwd_final / k_step_backward (the heavy reverse sweep is VALU-issue bound with lane = body:
 // 3 of 64 lanes busy; one world per lane stays the better shape for it).  LDS-tiled transpose, both sides coalesced.
 __global__ __launch_bounds__(256) void k_tree_to_lanes(const double* __restrict__ saved, SavedLayout lay, int nb, int64_t B,
-                                                       int64_t b0, int64_t b1, double* __restrict__ ws) {
+                                                       int64_t b0, int64_t b1, double* __restrict__ ws, const DevBody* __restrict__ bodies) {
   __shared__ double tile[32][33];
   const double* blk = saved + ((int64_t)lay.total + lay.dense) * B;
   const int64_t cols = lay.treeRows;                     // entries per world
@@ -734,7 +739,13 @@ __global__ __launch_bounds__(256) void k_tree_to_lanes(const double* __restrict_
   for (int k = ty; k < 32; k += 8) {
     const int64_t cc = c0 + k, r = r0 + tx;
     if (r < b1 && cc < cols) {
-      const int slot = (int)(cc / lay.treeNbp), body = (int)(cc % lay.treeNbp);
+      int slot, body;
+      if (cc < (int64_t)TREE_ROWS * lay.treeNbp) { slot = treeRowSlot((int)(cc / lay.treeNbp)); body = (int)(cc % lay.treeNbp); }
+      else {                                                  // the free-joint part: entry of the fi-th free-joint body
+        const int e = (int)(cc - (int64_t)TREE_ROWS * lay.treeNbp), fi = e / TREE_FREE;
+        slot = treeFreeSlot(e % TREE_FREE); body = nb;
+        for (int i = 0; i < nb; i++) if (bodies[i].freeIdx == fi) body = i;
+      }
       if (body < nb) ws[((int64_t)body * WS_PER_BODY + slot) * B + r] = tile[tx][k];
     }
   }

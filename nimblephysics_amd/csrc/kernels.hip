@@ -38,7 +38,8 @@ struct Ctx {
   const DevDof* __restrict__ dofs;
   double* __restrict__ ws;
   double* __restrict__ tree;   // slots < WS_KEEP: element (body, slot) at tree[body * tBody + slot * tSlot] (the saved record's
-  int64_t tBody, tSlot;        // tree block, lane-interleaved or world-major, or the workspace itself)
+  int64_t tBody, tSlot;        // lane-interleaved tree block, or the workspace itself), or - tCompact - in the compact world-major
+  int tCompact;                // tree block of the record (treeCompactRow, model_dev.hpp; tSlot = nbp)
   int64_t B, b;
   int nb, n;
   double dt;
@@ -46,7 +47,15 @@ struct Ctx {
 };
 
 DEV double& wsAt(const Ctx& c, int body, int slot) {
-  return slot < WS_KEEP ? c.tree[body * c.tBody + slot * c.tSlot] : c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b];
+  if (slot >= WS_KEEP) return c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b];
+  if (c.tCompact) {
+    const int r = treeCompactRow(slot);
+    if (r >= 0) return c.tree[r * c.tSlot + body];
+    // AI / PSI[1..20] / U[1..5]: the record holds them for free-joint bodies only; for any other body they are scratch (workspace)
+    const int fi = c.bodies[body].freeIdx;
+    return fi >= 0 ? c.tree[TREE_ROWS * c.tSlot + fi * TREE_FREE + (-1 - r)] : c.ws[((int64_t)body * WS_PER_BODY + slot) * c.B + c.b];
+  }
+  return c.tree[body * c.tBody + slot * c.tSlot];
 }
 
 // One world per WAVEFRONT, lane = body: the whole per-body state of the sweeps lives in LDS, lds[slot * nbp + body]
@@ -407,9 +416,9 @@ DEV Ctx makeCtx(const DevModel& mdl, const DevBody* bodies, const DevDof* dofs, 
   c.bodies = bodies; c.dofs = dofs; c.ws = ws; c.B = B; c.b = b;
   if (saved && lay && lay->treeRows > 0) {
     double* blk = saved + ((int64_t)lay->total + lay->dense) * B;
-    if (lay->treeNbp > 0) { c.tree = blk + b * (int64_t)lay->treeRows; c.tBody = 1; c.tSlot = lay->treeNbp; }
-    else { c.tree = blk + b; c.tBody = (int64_t)WS_KEEP * B; c.tSlot = B; }
-  } else { c.tree = ws + b; c.tBody = (int64_t)WS_PER_BODY * B; c.tSlot = B; }
+    if (lay->treeNbp > 0) { c.tree = blk + b * (int64_t)lay->treeRows; c.tBody = 1; c.tSlot = lay->treeNbp; c.tCompact = 1; }
+    else { c.tree = blk + b; c.tBody = (int64_t)WS_KEEP * B; c.tSlot = B; c.tCompact = 0; }
+  } else { c.tree = ws + b; c.tBody = (int64_t)WS_PER_BODY * B; c.tSlot = B; c.tCompact = 0; }
   c.nb = mdl.nb; c.n = mdl.n; c.dt = mdl.dt;
   c.g = mk3(mdl.gravity[0], mdl.gravity[1], mdl.gravity[2]);
   return c;

@@ -107,6 +107,23 @@ constexpr int WS_TW = 84;      // 12  world transform of the body
 // (SavedLayout::treeRows) the forward kernels write them there and the backward pass reads them back instead of
 // re-running the three ABA sweeps; the slots from WS_KEEP on are scratch in the workspace.
 constexpr int WS_KEEP = 96;
+// The WORLD-MAJOR tree block of the saved record (SavedLayout::treeNbp > 0, the lane = body tree kernels) is compact: rows
+// [TREE_ROWS][nbp] for the kept slots every body owns (T V AIS PSI[0] BACC/VTW U[0] A TW), then [TREE_FREE] doubles per free-joint body
+// for the slots only a free joint owns (AI - its one reader is the 6 x 6 solve of a free-joint root -, PSI[1..20], U[1..5]):
+// 50 nbp + 46 nFree doubles per world and step instead of 96 nbp (Atlas-20: 6.8 kB instead of 12.3 kB).
+constexpr int TREE_ROWS = 50, TREE_FREE = 46;
+__host__ __device__ inline int treeCompactRow(int s) {   // kept slot -> row (>= 0), or -(1 + entry of the free-joint part)
+  if (s < 18) return s;                         // T V                 rows 0..17      (WS_T, WS_V)
+  if (s < 39) return -(1 + (s - 18));           // AI                  free 0..20      (WS_AI)
+  if (s <= 45) return 18 + (s - 39);            // AIS PSI[0]          rows 18..24     (WS_AIS, WS_PSI)
+  if (s < 66) return -(1 + 21 + (s - 46));      // PSI[1..20]          free 21..40
+  if (s <= 72) return 25 + (s - 66);            // BACC / VTW, U[0]    rows 25..31     (WS_BACC, WS_U)
+  if (s < 78) return -(1 + 41 + (s - 73));      // U[1..5]             free 41..45
+  return 32 + (s - 78);                         // A TW                rows 32..49     (WS_A, WS_TW)
+}
+__host__ __device__ inline int treeRowSlot(int r) { return r < 18 ? r : (r < 25 ? 39 + (r - 18) : (r < 32 ? 66 + (r - 25) : 78 + (r - 32))); }
+__host__ __device__ inline int treeFreeSlot(int k) { return k < 21 ? 18 + k : (k < 41 ? 46 + (k - 21) : 73 + (k - 41)); }
+static_assert(WS_V == 12 && WS_AI == 18 && WS_AIS == 39 && WS_PSI == 45 && WS_BACC == 66 && WS_U == 72 && WS_A == 78 && WS_TW == 84, "treeCompactRow follows the slot map above");
 constexpr int WS_BIMP = 96;    // 6   impulse-bias accumulator (M^-1 solves)
 constexpr int WS_UIMP = 102;   // 6
 constexpr int WS_W = 108;      // 6   twist generated by lambda = M^-1 g   (adjoint of transmitted force)
@@ -186,7 +203,7 @@ struct SavedLayout {
   int32_t n, q, v, tau, vpre, w, nc, contacts, x, b, cls, cfm, pflag, rest, total;   // rest: MAX_CONTACTS rows, restitution coefficient of the contacts that bounced
   int32_t A, massed, aall, pinv, dense;
   int32_t treeRows;   // doubles per world of the tree block after the dense block (0: tree state not saved, backward recomputes)
-  int32_t treeNbp;    // 0: lane-interleaved rows [body * WS_KEEP + slot][B];  > 0: world-major blocks [b][slot][treeNbp] (coop tree kernels)
+  int32_t treeNbp;    // 0: lane-interleaved rows [body * WS_KEEP + slot][B];  > 0: compact world-major blocks [b]{[TREE_ROWS][treeNbp], [nFree][TREE_FREE]} (coop tree kernels)
 };
 // Extra lane-interleaved scratch rows after the per-body workspace (contact stage)
 constexpr int LW_JA = 0;                               // MAX_ROWS x 6 body-frame wrench on body A per row

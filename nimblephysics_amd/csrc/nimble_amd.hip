@@ -568,7 +568,7 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     m->coopTree = coopTree && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64;
     if (const char* e7 = getenv("NBL_COOP_TREE_FORCE")) m->coopTree = atoi(e7) != 0 && saveTree && d->n_bodies <= 64 && d->n_dofs <= 64 && coopTreeLds <= 160u * 1024u;
     L.treeNbp = m->coopTree ? nbp : 0;
-    L.treeRows = !saveTree ? 0 : (m->coopTree ? WS_KEEP * nbp : d->n_bodies * WS_KEEP);
+    L.treeRows = !saveTree ? 0 : (m->coopTree ? TREE_ROWS * nbp + TREE_FREE * nFree : d->n_bodies * WS_KEEP);
     m->mdl.nbp = nbp;
   }
   m->device = device;
@@ -841,7 +841,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
     const dim3 treeGrid((unsigned)((cnt + perBlockB - 1) / perBlockB)), treeBlock(64 * std::max(1, m->wpbBwd));
     const dim3 t2lGrid((unsigned)((m->lay.treeRows + 31) / 32), (unsigned)((cnt + 31) / 32));
     if (!m->hasContact && m->coopTree && !m->coopFinal) {
-      TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace));
+      TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace, m->dBodies));
       TIMED(K_BWD, hipLaunchKernelGGL(k_step_backward, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
                                       grad_next_state, grad_state, grad_action, (double*)workspace, 1));
     } else if (!m->hasContact && m->coopTree) {
@@ -908,7 +908,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
                                                grad_next_state, lws));
 #endif
       if (m->coopTree && !m->coopFinal) {
-        TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace));
+        TIMED(K_TREE_TO_LANES, hipLaunchKernelGGL(k_tree_to_lanes, t2lGrid, dim3(256), 0, s, (const double*)saved, m->lay, m->nb, B, b0, b1, (double*)workspace, m->dBodies));
         TIMED(K_BWD_FINAL, hipLaunchKernelGGL(k_bwd_final, grid, block, 0, s, mdl, m->dBodies, m->dDofs, B, (const double*)saved, layLanes,
                                               grad_next_state, grad_state, grad_action, (double*)workspace, (const double*)lws, 1));
       } else if (m->coopTree)
