@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
   if (!pinvValid) {
     if (K.nc > 0) {
       genBuildQ(w, A, MAX_ROWS, R, K, 0.0, S.mat[0], Fn.cfm);
-      genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc);
+      genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc, K.nu == 0);
     } else {
       for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) S.mat[3][(size_t)i * GLD + j] = 0.0;
       w.sync();

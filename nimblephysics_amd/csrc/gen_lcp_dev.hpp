@@ -161,11 +161,17 @@ DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const
 // deficient: R = R1 [I W], W = R1^-1 R2, and the minimum-norm solution of R u = g is u = [I; W^T] (I + W W^T)^-1 R1^-1 g - the same
 // algebra as coopPinvImpl (coop_dev.hpp), which explains why that is as accurate as the second Householder pass.  Returns the rank.
 template <class W>
-DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue) {
+DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue, bool symPsd = false) {
   const int ln = w.lane(), nl = w.lanes();
   for (int j = ln; j < m; j += nl) { R.done[j] = 0; for (int i = 0; i < m; i++) G[(size_t)i * GLD + j] = (i == j) ? 1.0 : 0.0; }
   w.sync();
-  const double thr = 2.220446049250313e-16 * cTrue;
+  // Rank threshold: the reference's eps * size * |R_00| (CGGM.cpp:280, LCPUtils.cpp:113).  For a SYMMETRIC positive semi-definite matrix
+  // (A on the guess rows; Q with no friction row on its bound) 64 x that, the policy of the 24- / 48-row builds' Cholesky route
+  // (coopPinvSymImpl, coop_dev.hpp): on an exactly singular Q the trailing pivot is pure round-off, a few eps - close enough to
+  // eps * size that this factorisation's round-off passes it where the reference's does not (soak seeds 240049 / 243083 on the
+  // general build: a 3 x 3 Q of rank 2 inverted at rank 3, gradients of 1e13); 64 x keeps every round-off pivot out and differs from
+  // the reference only where its own answer is round-off times 1e12
+  const double thr = (symPsd ? 64.0 : 1.0) * 2.220446049250313e-16 * cTrue;
   double best0 = 0.0;
   int rank = 0;
   double* V = R.t3;
@@ -351,7 +357,7 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
       w.sync();
     } else {
       genBuildQ(w, A, lda, R, K, cfm, S.mat[0]);
-      genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc);
+      genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc, K.nu == 0);
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = R.cls[r] == RC_CLAMPING ? R.Bv[r] : 0.0;
       w.sync();
       genPinvApply<W, false>(w, S.mat[3], m, R.t2, fc);
@@ -408,7 +414,7 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
       for (int s = w.lane(); s < m; s += w.lanes())
         for (int i = 0; i < m; i++) M[(size_t)i * GLD + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
       w.sync();
-      genPinv(w, R, M, S.mat[1], S.mat[2], S.mat[3], m, nIn);
+      genPinv(w, R, M, S.mat[1], S.mat[2], S.mat[3], m, nIn, true);          // A restricted to the guess rows: symmetric positive semi-definite
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = in0[r] ? R.Bv[r] : 0.0;
       w.sync();
       genPinvApply<W, false>(w, S.mat[3], m, R.t2, R.t0);

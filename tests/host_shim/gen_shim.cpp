@@ -64,6 +64,17 @@ int gshim_pinv(int m, const double* Q, int cTrue, double* Pout) {
   return r;
 }
 
+// the same with the symmetric-positive-semi-definite rank policy (64 x the reference's threshold, see genPinv)
+int gshim_pinv_sym(int m, const double* Q, int cTrue, double* Pout) {
+  World Wd;
+  const HostWave1 w;
+  Wd.R.m = m;
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Wd.S.mat[0][(size_t)i * GLD + j] = Q[(size_t)i * m + j];
+  const int r = genPinv(w, Wd.R, Wd.S.mat[0], Wd.S.mat[1], Wd.S.mat[2], Wd.S.mat[3], m, cTrue, true);
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Pout[(size_t)i * m + j] = Wd.S.mat[3][(size_t)i * GLD + j];
+  return r;
+}
+
 // the Dantzig driver on an n-row boxed LCP with explicit bounds (row-major A); returns 1 / 0 / -1 like genDantzigSeq
 int gshim_dantzig(int n, const double* A, const double* b, const double* lo, const double* hi, const int* findex, double* x) {
   World Wd;

@@ -201,6 +201,8 @@ def run(first=0, count=20, B=256, verbose=True, big=False, multi=False, balls=Fa
   # a world above `tol` must be PROVEN reference-unstable.  Round 2: 1e-5 (north_star).  1e-6 since the record carries the reference's
   # velocity change; at 1e-7 one world in 826 000 of the final soak is left over: a CFM + PGS world (condition number ~1e6) at 1.2e-7
   tol = float(os.environ.get("NBL_SOAK_TOL", "1e-6")) if tol is None else tol
+  if slots is None and os.environ.get("NBL_SOAK_SLOTS"):     # e.g. 64: every model of the soak on the GENERAL instantiation of the contact stage
+      slots = int(os.environ["NBL_SOAK_SLOTS"])
   prove_reference_unstable.by_closeness = 0
   tot = {"worlds": 0, "contact": 0, "limit_rows": 0, "cascade": 0, "gt1e-7": 0, "gt1e-5": 0, "unstable": 0, "unstable_A_ulp": 0, "unstable_A_abs": 0, "unstable_other_solution": 0, "rank_ambiguous_guess": 0, "nonfinite": 0, "MISMATCH": 0}
   for seed in range(first, first + count):
