@@ -955,6 +955,7 @@ DEV bool coopStandardizeLoop(const W& w, CoopLds& S, const CoopRow& R, double& X
     X = newX;
     ok = true;
     if (w.ballot(newlyNot) == 0ull) break;
+    pinvValid = false;   // X moved on: K and S.P belong to the previous iterate until the next pass refactorises (matters when the loop runs out)
   }
   return ok;
 }

@@ -383,6 +383,7 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
     w.sync();
     ok = true;
     if (!again) break;
+    pinvValid = false;   // X moved on: K and S.mat[3] belong to the previous iterate until the next pass refactorises (matters when the loop runs out)
   }
   return ok;
 }

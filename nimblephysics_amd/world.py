@@ -239,10 +239,9 @@ class World:
             raise ValueError(f"World.{what}() called with a tensor of incorrect size {tuple(x.shape)}; expected [B, {width}]")
         x = x.detach()
         if x.device.type == "cpu" and self.device.type == "cuda":
-            # the reference's own convention - CPU float64 tensors in and out (python/nimblephysics/timestep.py:31-40) - without the
-            # pageable-memory host-to-device copies (4.5 ms for 1.3 MB on this box): one pass into a pinned staging buffer the
-            # World keeps per role and shape (hipHostMalloc costs 50-90 ms, so nothing is allocated per call), then an asynchronous copy on
-            # the step's stream
+            # the reference's own convention - CPU float64 tensors in and out (python/nimblephysics/timestep.py:31-40): one pass into a pinned
+            # staging buffer the World keeps per role and shape (a fresh pinned allocation costs 50-90 ms, so nothing is allocated per call),
+            # then an asynchronous copy on the step's stream ("Host tensors")
             pin, ev = self._staging(what, x.shape)
             ev.synchronize()                           # the previous copy out of this buffer has been consumed
             pin.copy_(x)

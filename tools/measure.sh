@@ -12,6 +12,9 @@ python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --batch 8192
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas20_freefall > gpurun_out/${TAG}_bench_freefall.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --batch 8192 > gpurun_out/${TAG}_bench_atlas33.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --rollout 64 --batch 8192 > gpurun_out/${TAG}_bench_atlas33_rollout.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --rollout 64 --batch 8192 --graph > gpurun_out/${TAG}_bench_atlas33_rollout_graph.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --rollout 64 > gpurun_out/${TAG}_bench_atlas20_rollout.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --rollout 64 --graph > gpurun_out/${TAG}_bench_atlas20_rollout_graph.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --max-contacts 16 > gpurun_out/${TAG}_bench_48rows.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --max-contacts 24 --steps 8 --warmup 2 > gpurun_out/${TAG}_bench_general.json 2>/dev/null
 for f in gpurun_out/${TAG}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
