@@ -115,13 +115,15 @@ typedef struct nbl_model_desc {
   const double* box_T;      /* [n_boxes][12] shape transform in the body frame */
   const double* box_size;   /* [n_boxes][3] full side lengths */
   const double* box_mu;     /* [n_boxes] friction coefficient of the owning body (default 1, BodyNodeAspect.hpp:47) */
-  int32_t max_contacts;     /* per world, <= 64; rows m = 3 * max_contacts.  The reference keeps every contact of every pair
+  int32_t max_contacts;     /* per world, <= 128; rows m = 3 * max_contacts.  The reference keeps every contact of every pair
                                (ConstraintSolver.cpp:563-606); a world with more than its model's slots is truncated and flagged
                                NBL_ST_CONTACT_OVERFLOW.  The library holds three instantiations of its contact stage: models with max_contacts
                                <= 8, <= 16 colliders and <= 32 collider pairs run the 24-row one (the fast one), up to 16 contacts / 32
                                colliders / 64 pairs the 48-row one, everything up to 64 contacts (192 rows) / 64 colliders / 512 pairs the
                                GENERAL one, whose dense kernels loop over the rows: slow, and roomy enough that a model can always be given
-                               the slots its colliders can fill (a tower of ten cubes: 40 contacts in one constrained group) */
+                               the slots its colliders can fill (a tower of ten cubes: 40 contacts in one constrained group).  A model that
+                               asks for 65 .. 128 slots gets the same general code with 384 rows (four times the scratch and record per world:
+                               ten cubes each turned against the next touch in clipped octagons, 80 contacts) */
 
   /* ---- options mirrored from the reference defaults ---- */
   double contact_clipping_depth; /* 0.03  World.cpp:86 */
@@ -201,7 +203,8 @@ const char* nbl_last_error(void);
  *   minor 2: + dof_limit_enforced, body_self_collision, box_node, box_node_parent; NBL_SHAPE_CAPSULE; NBL_ST_JOINT_LIMIT;
  *   minor 3: max_contacts up to 16 (32 colliders, 64 pairs); + nbl_model_max_contacts, nbl_selftest_pinv_rows; the Dantzig self-test takes n <= 48.
  *   minor 4: max_contacts up to 64 (64 colliders, 512 pairs: the general instantiation); the Dantzig self-test takes n <= 192;
- *            nbl_workspace_bytes of such a model includes 1.2 MB of scratch matrices per world. */
+ *            nbl_workspace_bytes of such a model includes 1.5 MB of scratch matrices per world; max_contacts 65 .. 128: a second general
+ *            instantiation of 384 rows (5.9 MB of scratch per world), the Dantzig self-test then takes n <= 384. */
 #define NBL_ABI_MINOR 4
 int32_t nbl_version(void);
 
@@ -218,7 +221,7 @@ void nbl_model_destroy(nbl_model* m);
 int32_t nbl_model_num_dofs(const nbl_model* m);
 int32_t nbl_model_num_action(const nbl_model* m);
 int32_t nbl_model_lcp_rows(const nbl_model* m); /* rows of the LCP warm-start buffer: 3 * nbl_model_max_contacts() impulses + 1 row holding the row count they belong to; 0 without colliders */
-int32_t nbl_model_max_contacts(const nbl_model* m); /* contact slots per world of the instantiation the model runs on: 8, 16 or 64 (>= desc.max_contacts); 0 without colliders */
+int32_t nbl_model_max_contacts(const nbl_model* m); /* contact slots per world of the instantiation the model runs on: 8, 16, 64 or 128 (>= desc.max_contacts); 0 without colliders */
 
 /* Bytes of scratch the library needs for a batch of B worlds (forward or backward). */
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B);

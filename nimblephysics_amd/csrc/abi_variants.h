@@ -1,8 +1,10 @@
-/* abi_variants.h — the library is built from ONE set of sources in three instantiations of the contact stage:
+/* abi_variants.h — the library is built from ONE set of sources in four instantiations of the contact stage:
  *   NBL_MAXC = 8   24 LCP rows, 16 colliders, 32 collider pairs   (suffix _c8,  device namespace nbl)
  *   NBL_MAXC = 16  48 LCP rows, 32 colliders, 64 collider pairs   (suffix _c16, device namespace nbl_c16)
  *   NBL_MAXC = 64  192 LCP rows, 64 colliders, 512 collider pairs (suffix _c64, device namespace nbl_c64): the GENERAL instantiation, whose
  *                  dense contact kernels loop over the rows (gen_contact.hip) instead of mapping them to lanes (coop_kernels.hip)
+ *   NBL_MAXC = 128 the same general code with 384 rows (suffix _c128, device namespace nbl_c128): only for models that ask for more than 64
+ *                  contact slots (its per-world scratch and record are four times the 192-row build's)
  * Each instantiation is one translation unit (nimble_amd.hip compiled with -DNBL_MAXC=.. -DNBL_VARIANT_SUFFIX=..); this header,
  * included before include/nimble_amd.h, renames the ABI's entry points and its opaque handle type with the suffix so that both fit in
  * one shared library.  nimble_amd_dispatch.cpp exports the names of include/nimble_amd.h and hands every model to the instantiation

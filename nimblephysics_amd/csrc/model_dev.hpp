@@ -149,7 +149,7 @@ constexpr int WS_PER_BODY = 288;
 // A THIRD instantiation, NBL_MAXC = 64 (192 LCP rows, 64 colliders, 512 collider pairs: namespace nbl_c64), is the GENERAL one: its dense
 // contact kernels (gen_contact.hip) loop over the rows instead of mapping them to lanes - slow, and without a compile-time row budget
 // that a legal world could exceed in practice (the reference itself has none, ConstraintSolver.cpp:563-606).
-constexpr int MAX_CONTACTS = NBL_MAXC;       // per world (8 frictional contacts = 24 LCP rows; 16 = 48 rows; 64 = 192 rows)
+constexpr int MAX_CONTACTS = NBL_MAXC;       // per world (8 frictional contacts = 24 LCP rows; 16 = 48 rows; 64 = 192 rows; 128 = 384 rows: the general code again)
 constexpr int MAX_ROWS = 3 * MAX_CONTACTS;
 constexpr int MAX_BOXES = NBL_MAXC > 16 ? 64 : (NBL_MAXC > 8 ? 32 : 16);      // (<= 64: collider codes below CR_BODY_CODE)
 constexpr int MAX_PAIRS = NBL_MAXC > 16 ? 512 : (NBL_MAXC > 8 ? 64 : 32);

@@ -64,6 +64,7 @@ extern "C" {
 NBL_DECLARE_VARIANT(_c8)
 NBL_DECLARE_VARIANT(_c16)
 NBL_DECLARE_VARIANT(_c64)
+NBL_DECLARE_VARIANT(_c128)
 }
 
 // one table of entry points per instantiation
@@ -113,7 +114,9 @@ struct Variant {
    nbl_rollout_checkpoint_bytes##S, nbl_rollout_forward_checkpointed##S, nbl_rollout_backward_checkpointed##S,                               \
    nbl_selftest_lcp_dantzig_timed##S, nbl_selftest_pinv_rows##S, nbl_set_launch_lanes##S, nbl_set_slices##S, nbl_slices_for##S,               \
    nbl_set_timing##S, nbl_get_timing##S, nbl_kernel_timing##S}
-static const Variant kVariants[3] = {NBL_VARIANT_TABLE(8, _c8), NBL_VARIANT_TABLE(16, _c16), NBL_VARIANT_TABLE(64, _c64)};
+constexpr int kNumVariants = 4;
+static const Variant kVariants[kNumVariants] = {NBL_VARIANT_TABLE(8, _c8), NBL_VARIANT_TABLE(16, _c16), NBL_VARIANT_TABLE(64, _c64),
+                                                     NBL_VARIANT_TABLE(128, _c128)};
 
 struct nbl_model {
   const Variant* v;   // the instantiation that owns `impl`
@@ -150,14 +153,16 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   void* impl = nullptr;
   // the smallest instantiation that holds the model: contact slots first (a model without colliders and without enforced joint limits has no
   // contact stage: the 24-row build whatever max_contacts says), then whatever an instantiation answers NBL_E_CAPACITY to (its collider /
-  // collider-pair budget: 16 / 32, 32 / 64, 64 / 512)
+  // collider-pair budget: 16 / 32, 32 / 64, 64 / 512, 64 / 512).  The two general instantiations differ in their row budget only (192 / 384 rows:
+  // the size of the per-world scratch and record): 64 slots unless the model asks for more
   const bool contactStage = d->n_boxes > 0 || d->dof_limit_enforced != nullptr;
   int first = 0;
-  if (contactStage && (d->max_contacts > 16 || d->n_boxes > 32)) first = 2;
+  if (contactStage && d->max_contacts > 64) first = 3;
+  else if (contactStage && (d->max_contacts > 16 || d->n_boxes > 32)) first = 2;
   else if (contactStage && (d->max_contacts > 8 || d->n_boxes > 16)) first = 1;
   int32_t rc = NBL_E_CAPACITY;
   const Variant* v = nullptr;
-  for (int k = first; k < 3 && rc == NBL_E_CAPACITY; k++) {
+  for (int k = first; k < kNumVariants && rc == NBL_E_CAPACITY; k++) {
     v = &kVariants[k];
     rc = v->model_create(d, device, &impl);
     g_errVariant = v;
@@ -241,7 +246,7 @@ int32_t nbl_rollout_backward_checkpointed(nbl_model* m, int64_t B, int32_t T, in
 // ---- self-tests: the problem size picks the instantiation whose device code runs ----
 int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                        const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch) {
-  const Variant* v = &kVariants[n > 48 ? 2 : (n > 24 ? 1 : 0)];     // (n > 48: the general driver, gen_dantzig_dev.hpp)
+  const Variant* v = &kVariants[n > 192 ? 3 : (n > 48 ? 2 : (n > 24 ? 1 : 0))];     // (n > 48: the general driver, gen_dantzig_dev.hpp; n > 192: its 384-row build)
   g_errVariant = v;
   return v->selftest_lcp_dantzig_timed(count, n, A, b, lo, hi, findex, x, rc, reps, ms_per_launch);
 }

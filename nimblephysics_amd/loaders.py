@@ -253,7 +253,7 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
     World.cpp:221-254, and its bodies are not reactive in contacts, BodyNode.cpp:2394-2400 - the ground of cartpole.skel / fullbody1.skel) is
     loaded WELDED to the world at its zero configuration ("weld": what the reference's world does with it as long as nobody gives it a
     velocity; its joint coordinates are then not part of the state vector, the one difference to the reference's World) or refused ("error").
-    `max_contacts`: contact slots per world (<= 64: up to 8 the 24-row build, up to 16 the 48-row build, beyond that the general one);
+    `max_contacts`: contact slots per world (<= 128: up to 8 the 24-row build, up to 16 the 48-row build, beyond that the general one with 64 or 128 slots);
     None = ModelDescription.suggest_max_contacts() (by what the collider pairs can hold)."""
     root = ET.parse(path).getroot()
     world = root.find("world")

@@ -482,7 +482,7 @@ class ModelDescription:
         # many pairs: not all of them can be in contact at once - per moving collider at most 2 x 8 + 4 x 4 points, shared between the two sides
         movers = sum(1 for bx in m.boxes if bx.body >= 0)
         est = min(est, 16 * max(1, movers))
-        return min(64, (est + 7) // 8 * 8)
+        return min(64, (est + 7) // 8 * 8)      # (a caller who expects more - boxes turned against each other touch in octagons - asks for up to 128 itself)
 
     def capsule_meets_box(self) -> bool:
         """Some capsule collider is tested against some box collider (different bodies, not both fixed to the world, different skeletons:

@@ -260,12 +260,12 @@ class OracleWorld:
             x = _arr(x); self._lib.nbo_set_lcp_forced(self._h, _p(x), len(x), 1 if cfm_stage else 0)
 
     def last_contacts(self):
-        buf = np.zeros((64, 12))
-        c = self._lib.nbo_last_contacts(self._h, _p(buf), 64)
+        buf = np.zeros((256, 12))
+        c = self._lib.nbo_last_contacts(self._h, _p(buf), 256)
         return buf[:c].copy()
 
     def last_lcp(self):
-        cap = 3 * 64
+        cap = 3 * 128
         A = np.zeros(cap * cap); b = np.zeros(cap); x = np.zeros(cap); lo = np.zeros(cap); hi = np.zeros(cap)
         fi = np.zeros(cap, np.int32); rc = np.zeros(cap, np.int32)
         m = self._lib.nbo_last_lcp(self._h, _p(A), _p(b), _p(x), _p(lo), _p(hi), fi.ctypes.data_as(C.POINTER(C.c_int32)),

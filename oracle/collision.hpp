@@ -514,6 +514,7 @@ inline int deviceSeenPoints(const Model& m) {
   int pairs = 0;
   for (int i = 0; i + 1 < nbx; i++)
     for (int j = i + 1; j < nbx; j++) pairs += pairIsTested(m, i, j) ? 1 : 0;
+  if (m.maxContacts > 64) return 256;                                     // (the 384-row general build)
   if (m.maxContacts > 16 || nbx > 32 || pairs > 64) return 128;
   return (m.maxContacts > 8 || nbx > 16 || pairs > 32) ? 32 : 16;
 }

@@ -39,7 +39,7 @@ def _fwd_bwd(md, s, a, seed, lcp=None):
 
 def test_the_general_dantzig_driver_is_bit_identical_to_the_reference_on_the_device():
     """nbl_selftest_lcp_dantzig with n > 48 runs gen_dantzig_dev.hpp::genDantzigSeq on the GPU (lane 0 of a wavefront per problem, the
-    problem in HBM): success flag and every bit of x equal to the reference's own dSolveLCP (oracle/_ref), 51 .. 192 rows, rank-deficient
+    problem in HBM): success flag and every bit of x equal to the reference's own dSolveLCP (oracle/_ref), 51 .. 384 rows, rank-deficient
     contact problems included."""
     import oracle
     from nimblephysics_amd import _lib
@@ -51,7 +51,7 @@ def test_the_general_dantzig_driver_is_bit_identical_to_the_reference_on_the_dev
     pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     rng = np.random.default_rng(0)
     solved = failed = 0
-    for n_contacts, count in ((17, 24), (27, 16), (40, 12), (64, 8)):
+    for n_contacts, count in ((17, 24), (27, 16), (40, 12), (64, 8), (80, 4), (128, 3)):      # (above 192 rows: the 384-row build of the same code)
         n = 3 * n_contacts
         probs = []
         for k in range(count):
@@ -80,7 +80,7 @@ def test_the_general_dantzig_driver_is_bit_identical_to_the_reference_on_the_dev
                 assert np.array_equal(xr, x[k]), (n, k, np.abs(xr - x[k]).max())
             else:
                 failed += 1
-    print(f"[general Dantzig on the device] {solved} problems of 51 .. 192 rows solved bit for bit, {failed} early exits, all flags equal")
+    print(f"[general Dantzig on the device] {solved} problems of 51 .. 384 rows solved bit for bit, {failed} early exits, all flags equal")
     assert solved >= 20
 
 
@@ -127,6 +127,43 @@ def test_cube_towers_of_twenty_and_forty_contacts(n_cubes, B):
           "max errors:", {k: float(v.max()) for k, v in e.items()})
     bad, _ = assert_match_or_reference_unstable(f"{n_cubes}-cube tower, {4 * n_cubes} contacts", ow, s, a, g, dev, ref, TOL if n_cubes <= 5 else TOL_BIG, ulps=ULPS,
                                                 max_unstable=max(3, int(0.1 * B)))
+
+
+def test_a_tower_of_cubes_turned_against_each_other_needs_more_than_sixty_four_contacts():
+    """Ten cubes, each turned about the vertical by 25 - 65 degrees against the one below: two box faces that overlap at such an angle are
+    clipped to an octagon and the reference keeps all eight points (DARTCollide.cpp:1384-1448), so the tower holds 4 + 9 x 8 = 76 contacts in one
+    constrained group - 228 LCP rows.  A model that asks for more than 64 slots runs the general code's 384-row instantiation; no contact is
+    dropped, the contact count equals the oracle's, next state and gradients pass the parity criterion."""
+    from oracle import OracleWorld
+    from util import cube_world
+    import nimblephysics_amd as na
+    n_cubes, side, B = 10, 0.2, 6
+    rng = np.random.default_rng(77)
+    md = cube_world(n_cubes, side=side, max_contacts=96)
+    n = 6 * n_cubes
+    q = np.zeros((B, n)); v = np.zeros((B, n))
+    yaw0 = rng.uniform(-0.3, 0.3, B)
+    y = np.zeros(B)
+    for k in range(n_cubes):
+        y = y + (0.5 * side if k == 0 else side) - rng.uniform(2e-4, 8e-4, B)
+        # odd cubes turned by 25 - 65 degrees against their even neighbours (the rotation vectors stay far from the log-map singularity)
+        yaw = yaw0 + rng.normal(0, 0.02, B) + (rng.uniform(25.0, 65.0, B) * np.pi / 180.0 if k % 2 else 0.0)
+        q[:, 6 * k + 1] = yaw; q[:, 6 * k + 4] = y
+        q[:, 6 * k + 3] = rng.normal(0, 2e-3, B); q[:, 6 * k + 5] = rng.normal(0, 2e-3, B)
+        v[:, [6 * k + 3, 6 * k + 5]] = rng.normal(0, 0.02, (B, 2))
+    s = np.concatenate([q, v], 1); a = np.zeros((B, n))
+    world, dev, st, g = _fwd_bwd(md, s, a, 78)
+    assert world._L.nbl_model_max_contacts(world._h) == 128
+    ow = OracleWorld(md)
+    ref = ow.step_batch(s, a, g, threads=8)
+    nc_dev = (world.lcp_cache[-1].cpu().numpy() / 3).astype(int)
+    nc_ref = []
+    for w_ in range(B):
+        ow.reset_lcp_cache(); ow.step(s[w_], a[w_]); nc_ref.append(len(ow.last_contacts()))
+    print("[turned tower] contacts per world: device", nc_dev.tolist(), "oracle", nc_ref, "status", [hex(int(x)) for x in st])
+    assert not (st & 0x80).any() and not (ref["status"] & 0x80).any(), "a contact was dropped"
+    assert np.array_equal(nc_dev, np.array(nc_ref)) and nc_dev.max() > 64 and nc_dev.min() >= 60
+    assert_match_or_reference_unstable("turned tower, 76 contacts", ow, s, a, g, dev, ref, TOL_BIG, ulps=ULPS, max_unstable=B, closeness=1.0, max_by_closeness=B)
 
 
 def three_groups_scene(B, towers=2, table=True, seed=21):

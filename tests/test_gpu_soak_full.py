@@ -64,3 +64,12 @@ def test_parity_soak_on_the_general_build(family):
     tot = soak_parity.run(48000, 100, 128, verbose=False, slots=64, **FAMILIES[family])
     print(f"general parity:{family}", tot)
     assert tot["MISMATCH"] == 0 and tot["overflow"] == 0 and tot["nonfinite"] == 0 and tot["worlds"] >= 12000, tot
+
+
+def test_parity_soak_on_the_384_row_general_build():
+    """The same general code compiled for 128 contact slots (models that ask for more than 64): two families, every world against the oracle."""
+    import soak_parity
+    for fam in ("multi", "big"):
+        tot = soak_parity.run(49000, 30, 64, verbose=False, slots=128, **FAMILIES[fam])
+        print(f"384-row general parity:{fam}", tot)
+        assert tot["MISMATCH"] == 0 and tot["overflow"] == 0 and tot["nonfinite"] == 0 and tot["worlds"] >= 1800, tot
