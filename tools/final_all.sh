@@ -1,8 +1,11 @@
-TAG=${1:-r04}
-# Everything that is measured on the final build of a round, in one call on the GPU box: the GPU suite, the profile + bench variants
-# (tools/measure.sh), both passes of the randomised soaks (tools/final_soak.sh) and the large mixed-feature soak.
+TAG=${1:-r05}
+# Everything that is measured on the final build of a round, in one call on the GPU box: the GPU suite, the general-build tests verbosely, the
+# profile + bench variants (tools/measure.sh) and both passes of the randomised soaks (tools/final_soak.sh: as built, and with every model forced
+# onto the general instantiation of the contact stage).
 set -u
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_gpu_suite.log 2>&1; tail -1 gpurun_out/${TAG}_gpu_suite.log
-bash tools/measure.sh ${TAG} > gpurun_out/${TAG}_measure.log 2>&1; tail -9 gpurun_out/${TAG}_measure.log | cut -c1-200
-bash tools/final_soaks_only.sh ${TAG}
+timeout 900 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_suite.log 2>&1; tail -1 gpurun_out/${TAG}_gpu_suite.log
+timeout 600 python -m pytest tests/test_gpu_general.py -q -s 2>&1 | grep -v amdgpu.ids | cut -c1-600 > gpurun_out/${TAG}_gpu_general_tests.log; tail -1 gpurun_out/${TAG}_gpu_general_tests.log
+bash tools/measure.sh ${TAG} > gpurun_out/${TAG}_measure.log 2>&1; tail -32 gpurun_out/${TAG}_measure.log | cut -c1-200
+timeout 600 bash tools/final_soak.sh 300000 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_final_soak.log; grep -c "MISMATCH.: 0" gpurun_out/${TAG}_final_soak.log
+NBL_SOAK_SLOTS=64 timeout 600 bash tools/final_soak.sh 200000 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_general_final_soak.log; grep -c "MISMATCH.: 0" gpurun_out/${TAG}_general_final_soak.log
