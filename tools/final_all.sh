@@ -4,8 +4,9 @@ TAG=${1:-r05}
 # onto the general instantiation of the contact stage).
 set -u
 mkdir -p gpurun_out
+(rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -i -E "sclk|power|temp" | head -8) > gpurun_out/${TAG}_box_state.log
+bash tools/measure.sh ${TAG} > gpurun_out/${TAG}_measure.log 2>&1; tail -32 gpurun_out/${TAG}_measure.log | cut -c1-200
 timeout 900 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_suite.log 2>&1; tail -1 gpurun_out/${TAG}_gpu_suite.log
 timeout 600 python -m pytest tests/test_gpu_general.py -q -s 2>&1 | grep -v amdgpu.ids | cut -c1-600 > gpurun_out/${TAG}_gpu_general_tests.log; tail -1 gpurun_out/${TAG}_gpu_general_tests.log
-bash tools/measure.sh ${TAG} > gpurun_out/${TAG}_measure.log 2>&1; tail -32 gpurun_out/${TAG}_measure.log | cut -c1-200
 timeout 600 bash tools/final_soak.sh 300000 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_final_soak.log; grep -c "MISMATCH.: 0" gpurun_out/${TAG}_final_soak.log
 NBL_SOAK_SLOTS=64 timeout 600 bash tools/final_soak.sh 200000 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_general_final_soak.log; grep -c "MISMATCH.: 0" gpurun_out/${TAG}_general_final_soak.log

@@ -13,6 +13,7 @@ python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload a
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --batch 8192 > gpurun_out/${TAG}_bench_atlas33.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --rollout 64 --batch 8192 > gpurun_out/${TAG}_bench_atlas33_rollout.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --rollout 64 --batch 8192 --graph > gpurun_out/${TAG}_bench_atlas33_rollout_graph.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --workload atlas33_contact --rollout 64 --batch 8192 --checkpoint-every 16 > gpurun_out/${TAG}_bench_atlas33_rollout_checkpoint16.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --rollout 64 > gpurun_out/${TAG}_bench_atlas20_rollout.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --rollout 64 --graph > gpurun_out/${TAG}_bench_atlas20_rollout_graph.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --max-contacts 16 > gpurun_out/${TAG}_bench_48rows.json 2>/dev/null
