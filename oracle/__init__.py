@@ -60,6 +60,7 @@ def _declare(lib):
     lib.nbo_set_lcp_cache.argtypes = [C.c_void_p, pd, C.c_int]
     lib.nbo_get_lcp_cache.argtypes = [C.c_void_p, pd, C.c_int]
     lib.nbo_set_lcp_noise.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int]
+    lib.nbo_set_pinv_noise.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
     lib.nbo_set_lcp_noise.restype = None
     lib.nbo_set_lcp_forced.argtypes = [C.c_void_p, pd, C.c_int, C.c_int]
     lib.nbo_set_lcp_forced.restype = None
@@ -228,6 +229,13 @@ class OracleWorld:
         non-zero entry instead; absolute="bound": j ulps 2^-52 x (the sum of the magnitudes of the terms of A = J M^-1 J^T / b = -J v
         the entry is the sum of): the first-order rounding-error bound of that entry.  0 switches it off."""
         self._lib.nbo_set_lcp_noise(self._h, int(ulps), int(seed), {False: 0, True: 1, "bound": 3}[absolute])
+
+    def set_pinv_noise(self, ulps, seed=0):
+        """Test instrument, not the reference's behaviour: every entry of the pseudo-inverse Q^+ of the BACKWARD pass times 1 + j ulps 2^-52, j in
+        {-1, 0, 1} per entry and world - the Q^+ another algorithm of the same accuracy returns.  On a full-rank, ill-conditioned Q the reference's
+        imprecise-inverse branch (BackpropSnapshot.cpp:2964-2984) adds Q^+T Q^+ x (the round-off of its own pseudo-inverse): a gradient that moves
+        under this instrument is that round-off times cond(Q)^2.  0 switches it off."""
+        self._lib.nbo_set_pinv_noise(self._h, int(ulps), int(seed))
 
     def set_lcp_alternate_a(self, on=True):
         """Test instrument: the LCP matrix recomputed as J M^-1 J^T from the dense inverse mass matrix - the same matrix through another

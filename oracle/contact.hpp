@@ -1060,6 +1060,15 @@ inline void contactJacobians(const Model& m, const std::vector<Kin>& kin, const 
   MatX dFc_vel = codSolveMat(Q, dB_vel), dFc_force = codSolveMat(Q, dB_force);
   // dQ_b for POSITION (getJacobianOfLCPConstraintMatrixClampingSubset)
   MatX Qinv = pinvCod(Q);
+  if (m.pinvNoiseUlps > 0) {                                      // test instrument, see Model::pinvNoiseUlps
+    const uint64_t sample = m.pinvNoiseSample++;
+    for (int i = 0; i < nc; i++)
+      for (int j = 0; j < nc; j++) {
+        uint64_t h = m.lcpNoiseSeed * 0x9E3779B97F4A7C15ull + sample * 0xBF58476D1CE4E5B9ull + (uint64_t)(8192 + i * 512 + j) * 0x94D049BB133111EBull;
+        h ^= h >> 31; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+        Qinv(i, j) *= 1.0 + (s_t)((int)(h % 3) - 1) * (s_t)m.pinvNoiseUlps * 2.220446049250313e-16;
+      }
+  }
   auto dQ = [&](const VecX& rhs) {
     VecX Ar = matvec(AcubE, rhs);
     MatX t1 = jacClampingT(matvec(Minv, Ar));

@@ -69,6 +69,12 @@ struct Model {
   // Third test instrument (see posJacobiansExact): the position-integration Jacobians of free / ball joints by exact forward-mode
   // differentiation instead of the reference's central differences (FreeJoint.cpp:950-1007, BallJoint.cpp:351-408).
   int exactPosJacobians = 0;            // 1: in extended precision (the instrument); 2: the same formulas in doubles (shows the eps / gap^3 conditioning)
+  // Fourth test instrument: pinvNoiseUlps = k > 0 multiplies every entry of the pseudo-inverse Q^+ the BACKWARD pass forms (BackpropSnapshot.cpp:2964-2984)
+  // by 1 + j k 2^-52, j in {-1, 0, 1} per entry and world: the Q^+ another pseudo-inverse algorithm of the same accuracy returns.  On a full-rank but
+  // ill-conditioned Q the reference's imprecise-inverse branch (||I - Q Q^+||^2 >= 1e-18) adds terms that are Q^+T Q^+ x (I - Q Q^+) b - the round-off of
+  // its own pseudo-inverse times cond(Q)^2: a world whose gradient moves under this instrument has no answer that is independent of it.
+  int pinvNoiseUlps = 0;
+  mutable uint64_t pinvNoiseSample = 0;
   std::vector<s_t> lcpForced;
   bool lcpForcedCfm = false;            // ... as the output of stage 2 (the fallback CFM on the diagonal, PGS) instead of stage 1
   uint64_t lcpNoiseSeed = 0;

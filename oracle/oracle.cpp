@@ -237,6 +237,11 @@ void nbo_set_lcp_noise(void* h, int ulps, uint64_t seed, int absolute) {
   o->model.lcpNoiseUlps = ulps; o->model.lcpNoiseSeed = seed; o->model.lcpNoiseSample = 0; o->model.lcpNoiseAbsolute = absolute != 0;
 }
 // LCP cache in the device's interchange format (Model::lcpCacheSlots)
+// test instrument (Model::pinvNoiseUlps): ulps = 0 switches it off
+void nbo_set_pinv_noise(void* h, int ulps, uint64_t seed) {
+  Oracle* o = (Oracle*)h;
+  o->model.pinvNoiseUlps = ulps; o->model.pinvNoiseSample = 0; if (ulps > 0) o->model.lcpNoiseSeed = seed;
+}
 void nbo_set_lcp_cache_slots(void* h, int on) { ((Oracle*)h)->model.lcpCacheSlots = on != 0; }
 // test instrument, not the reference's behaviour (dynamics.hpp::posJacobiansExact): exact position-integration Jacobians of free / ball joints
 // (0 off, 1 in extended precision, 2 the same formulas in doubles)
@@ -331,7 +336,7 @@ int nbo_step_batch(void* h, int64_t B, const double* state, const double* action
       o.model = m;
       // contiguous chunk of worlds per thread (one cloned world per thread stepping its share)
       const int64_t per = (B + threads - 1) / threads, b0 = t * per, b1 = std::min<int64_t>(B, b0 + per);
-      o.model.lcpNoiseSample = (uint64_t)b0;
+      o.model.lcpNoiseSample = (uint64_t)b0; o.model.pinvNoiseSample = (uint64_t)b0;
       for (int64_t b = b0; b < b1; b++) {
         if (lcpIn && lcpLenIn && lcpLenIn[b] > 0) o.lcpCache.assign(lcpIn + b * lcpStride, lcpIn + b * lcpStride + lcpLenIn[b]);
         else o.lcpCache.clear();

@@ -450,7 +450,7 @@ def test_sphere_narrow_phases_equal_the_references_own_functions_on_random_pairs
 
 
 def test_the_soak_instruments_leave_the_oracle_alone_when_off_and_replay_its_own_solution():
-    """OracleWorld.set_lcp_noise / set_lcp_forced are instruments of the randomised soaks (tools/soak_parity.py), not reference behaviour:
+    """OracleWorld.set_lcp_noise / set_lcp_forced / set_pinv_noise are instruments of the randomised soaks (tools/soak_parity.py), not reference behaviour:
     switched off they change nothing; one-ulp noise on A leaves a well-posed world's answer within 1e-9; the oracle's OWN cascade
     solution forced back in as the solver's output reproduces next state and gradients bit for bit; a solution that violates the LCP is
     refused (0x40000000)."""
@@ -481,6 +481,17 @@ def test_the_soak_instruments_leave_the_oracle_alone_when_off_and_replay_its_own
     w.set_lcp_forced(None)
     w.reset_lcp_cache()
     assert np.array_equal(w.step(s[i], a[i]), nx)
+    # the fourth instrument (round 5): one ulp on every entry of the BACKWARD pass's pseudo-inverse.  A well-conditioned world does not notice
+    # (the gradients of the stage-0 worlds move by < 1e-9, the next state not at all); switched off it changes nothing
+    w.set_pinv_noise(1, 3)
+    noisy = w.step_batch(s, a, g, threads=2)
+    w.set_pinv_noise(0)
+    assert np.array_equal(noisy["next"], ref["next"])
+    scale = np.abs(ref["grad_state"]).max()
+    assert np.abs(noisy["grad_state"][stage0] - ref["grad_state"][stage0]).max() < 1e-9 * scale
+    again = w.step_batch(s, a, g, threads=2)
+    for k in ("next", "grad_state", "grad_action"):
+        assert np.array_equal(again[k], ref[k])
 
 
 def test_the_oracle_flags_a_contact_kept_after_sixteen_distinct_narrow_phase_points():
