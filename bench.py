@@ -197,16 +197,20 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn"]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.call(cmd, env=env))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one device per rank: LOCAL_RANK indexes the visible devices - unless the launcher masks them per rank (ROCR / HIP_VISIBLE_DEVICES: every
+    # process then sees exactly one device, its own, as device 0)
+    masked = world_size > 1 and torch.cuda.device_count() == 1
+    dev_index = 0 if masked else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run (any N, also 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
         # one process per GPU, one GPU per process: make a mis-launched job fail here, not report a wrong aggregate
         assert dist.get_world_size() == args.gpus, f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks"
-        assert torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} devices are visible"
-        assert torch.cuda.current_device() == local_rank, f"rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank}"
+        assert masked or torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} devices are visible"
+        assert torch.cuda.current_device() == dev_index, f"rank {rank}: current device {torch.cuda.current_device()} != {dev_index} (LOCAL_RANK {local_rank})"
         assert dist.get_rank() == rank
 
     import nimblephysics_amd as na
