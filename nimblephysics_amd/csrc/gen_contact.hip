@@ -25,17 +25,18 @@ struct GenWaveDev {
   DEV bool anyAll(bool b) const { return __ballot(b ? 1 : 0) != 0ull; }
 };
 
-// the world's scratch: GEN_SCRATCH_DOUBLES per world after the contact-backward rows of the workspace; mat[3] (the pseudo-inverse) is the
+// the world's scratch: genScratchDoubles(ld) per world after the contact-backward rows of the workspace; mat[3] (the pseudo-inverse) is the
 // record's own Q^+ block (same leading dimension), so the last factorisation of the cascade lands where the backward pass reads it
-DEV GenScratch genScratchOf(double* gws, int64_t world, double* recordPinv) {
+DEV GenScratch genScratchOf(double* gws, int64_t world, double* recordPinv, int ld) {
   GenScratch S;
-  double* base = gws + (size_t)world * GEN_SCRATCH_DOUBLES;
-  S.mat[0] = base; S.mat[1] = base + (size_t)GR * GLD; S.mat[2] = base + (size_t)2 * GR * GLD; S.mat[3] = recordPinv;
-  S.mat[4] = base + (size_t)3 * GR * GLD;
-  S.vec = base + (size_t)4 * GR * GLD;
+  const size_t mat = (size_t)ld * ld;
+  double* base = gws + (size_t)world * genScratchDoubles(ld);
+  S.ld = ld;
+  S.mat[0] = base; S.mat[1] = base + mat; S.mat[2] = base + 2 * mat; S.mat[3] = recordPinv;
+  S.mat[4] = base + 3 * mat;
+  S.vec = base + 4 * mat;
   return S;
 }
-static_assert(GEN_SCRATCH_DOUBLES >= (size_t)4 * GR * GLD + 16 * GR, "scratch carve-up");
 
 // ======================================================================================================================================
 // rows: see k_contact_rows_coop (coop_kernels.hip) for the mathematics - world-aligned frame with its origin at the root of each tree, one
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const Dev
   const int nb = mdl.nb;
   const GenWaveDev w;
   const int ln = w.lane();
+  const int ldr = lay.ldr;              // leading dimension of the record's dense blocks and of the world's scratch matrices
   double* Fs = ldsG;
   double* FsB = Fs + 6 * MAX_ROWS;
   double* Sw = FsB + 6 * MAX_ROWS;
@@ -175,11 +177,11 @@ __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const Dev
         const bool pa = (mA >> i) & 1ull, pb = (mB >> i) & 1ull;
         const double mult = (pa && pb) ? 0.0 : (pa ? 1.0 : (pb ? -1.0 : 0.0));
         const V6 Fi = pb ? FB : F;
-        if (bd.jtype != JT_FREE) dn[lay.aall + bd.dofOff * MAX_ROWS + row] = mult * dot(ld6(Sw + 6 * i), Fi);
+        if (bd.jtype != JT_FREE) dn[lay.aall + bd.dofOff * ldr + row] = mult * dot(ld6(Sw + 6 * i), Fi);
         else {
           double v6[6];
           toArr(dAdT(cT(bd.Tcj), dAdT(cT(freeL + 54 * bd.freeIdx + 42), Fi)), v6);
-          for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * MAX_ROWS + row] = mult * v6[e];
+          for (int e = 0; e < 6; e++) dn[lay.aall + (bd.dofOff + e) * ldr + row] = mult * v6[e];
         }
         for (int e = 0; e < 6; e++) accAt(i, e) = 0.0;
       }
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const Dev
           const V6 S = ld6(Sw + 6 * i);
           const double dq = psiL[i] * (-dot(S, Bi) - dot(ld6(AISw + 6 * i), X));
           stAcc(i, X + dq * S);
-          dn[lay.massed + bd.dofOff * MAX_ROWS + row] = dq;
+          dn[lay.massed + bd.dofOff * ldr + row] = dq;
         } else {
           const double* fl = freeL + 54 * bd.freeIdx;
           const T12 Tcj = cT(bd.Tcj), TW = cT(fl + 42);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const Dev
           for (int e = 0; e < 6; e++) r[e] = -u[e] - pj[e];
           ldl6Solve(f, r);
           stAcc(i, AdT(TW, Xb + AdT(Tcj, fromArr(r))));
-          for (int e = 0; e < 6; e++) dn[lay.massed + (bd.dofOff + e) * MAX_ROWS + row] = r[e];
+          for (int e = 0; e < 6; e++) dn[lay.massed + (bd.dofOff + e) * ldr + row] = r[e];
         }
       }
       // row of A: relative-velocity response at every row of the contacts c2 >= ci, mirrored into the earlier rows
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const Dev
         for (int k2 = 0; k2 < 3; k2++) {
           const int col = 3 * c2 + k2;
           const double val = dot(ld6(Fs + 6 * col), dVA) - dot(ld6(FsB + 6 * col), dVB);
-          dn[lay.A + row * MAX_ROWS + col] = val;
-          if (c2 > ci) dn[lay.A + col * MAX_ROWS + row] = val;
+          dn[lay.A + row * ldr + col] = val;
+          if (c2 > ci) dn[lay.A + col * ldr + row] = val;
         }
       }
     }
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
   __shared__ GenFinal Fn;
   const GenWaveDev w;
   const int ln = w.lane();
+  const int ldr = lay.ldr;              // leading dimension of the record's dense blocks and of the world's scratch matrices
   const int64_t b = mdl.b0 + (int64_t)blockIdx.x;
   if (b >= mdl.b1) return;
   const int n = mdl.n;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     for (int d = ln; d < n; d += 64) svAt(saved, lay.w + d, B, b) = 0.0;
     return;
   }
-  const GenScratch S = genScratchOf(gws, b, dn + lay.pinv);
+  const GenScratch S = genScratchOf(gws, b, dn + lay.pinv, ldr);
   // ---- the rows ----
   const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
   int nLimMine = 0;
@@ -294,12 +297,12 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     R.fric[r] = (r % 3) != 0; R.fp[r] = r - (r % 3);
     R.rowOn[r] = 1; R.on[r] = 1;
     double cn = 0.0;
-    for (int i = 0; i < m; i++) { const double a = A[(size_t)i * MAX_ROWS + r]; cn = fma(a, a, cn); }
+    for (int i = 0; i < m; i++) { const double a = A[(size_t)i * ldr + r]; cn = fma(a, a, cn); }
     R.colNorm[r] = cn;
     Fn.xcache[r] = haveCache ? (R.neg[r] ? -1.0 : 1.0) * cacheIn[(int64_t)r * B + b] : 0.0;
     Fn.X[r] = 0.0; Fn.E[r] = 0.0; Fn.cfm[r] = 0.0; Fn.cls[r] = RC_NOT_CLAMPING;
   }
-  if (ln == 0) R.m = m;
+  if (ln == 0) { R.m = m; R.ld = ldr; }
   const int nLim = (int)w.sumAll((double)nLimMine);
   if (ln == 0) { R.anyLim = nLim > 0; if (status) status[b] |= (nC - nLim > 0 ? 0x1u : 0u) | (nLim > 0 ? 0x400u : 0u); }
   // ---- constrained groups (ConstraintSolver::buildConstrainedGroups :724-780, ContactConstraint::uniteSkeletons :879-907): skeletons
@@ -341,11 +344,11 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     bool pinvValid = false;
     GenClasses K;
     double cfmG = 0.0;
-    const bool ok = genStage0(w, A, MAX_ROWS, R, S, haveCache, pinvValid, K);
+    const bool ok = genStage0(w, A, ldr, R, S, haveCache, pinvValid, K);
     if (!ok) {
       anyFail = true;
       uint32_t st = 0;
-      genCascade(w, A, MAX_ROWS, R, S, cm->fallbackCfm, cfmG, st, pinvValid, K);
+      genCascade(w, A, ldr, R, S, cm->fallbackCfm, cfmG, st, pinvValid, K);
       stAll = (stAll & ~0x100u) | (st & ~0x100u) | (stAll & st & 0x100u);
     }
     for (int r = ln; r < m; r += 64)
@@ -374,10 +377,10 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
   bool pinvValid = pinvValidWorld && !anyLimClamp;
   if (!pinvValid) {
     if (K.nc > 0) {
-      genBuildQ(w, A, MAX_ROWS, R, K, 0.0, S.mat[0], Fn.cfm);
+      genBuildQ(w, A, ldr, R, K, 0.0, S.mat[0], Fn.cfm);
       genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc, K.nu == 0);
     } else {
-      for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) S.mat[3][(size_t)i * GLD + j] = 0.0;
+      for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) S.mat[3][(size_t)i * ldr + j] = 0.0;
       w.sync();
     }
     pinvValid = K.nc > 0 || anyLimClamp;
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
   for (int d = ln; d < n; d += 64) {
     double wd = 0.0, wb = 0.0;
     for (int r = 0; r < m; r++) {
-      const double ms = dn[lay.massed + d * MAX_ROWS + r];
+      const double ms = dn[lay.massed + d * ldr + r];
       wd = fma(ms, Fn.X[r], wd); wb = fma(ms, R.t1[r], wb);
     }
     svAt(saved, lay.w + d, B, b) = wb;
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_gen(DevModel mdl, const De
   __shared__ GenBwdA L;
   const GenWaveDev w;
   const int ln = w.lane();
+  const int ldr = lay.ldr;              // leading dimension of the record's dense blocks and of the world's scratch matrices
   const int64_t b = mdl.b0 + (int64_t)blockIdx.x;
   if (b >= mdl.b1) return;
   const int n = mdl.n;
@@ -482,15 +486,15 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_gen(DevModel mdl, const De
     w.sync();
   };
   auto ax = [&](const double* x, double* out) {       // A x, A symmetric
-    for (int r = ln; r < m; r += 64) { double s = 0.0; for (int j = 0; j < m; j++) s = fma(A[(size_t)j * MAX_ROWS + r], x[j], s); out[r] = s; }
+    for (int r = ln; r < m; r += 64) { double s = 0.0; for (int j = 0; j < m; j++) s = fma(A[(size_t)j * ldr + r], x[j], s); out[r] = s; }
     w.sync();
   };
   auto pinvApply = [&](const double* x, double* out, bool trans) {
-    for (int i = ln; i < m; i += 64) { double s = 0.0; for (int k = 0; k < m; k++) s = fma(trans ? P[(size_t)k * MAX_ROWS + i] : P[(size_t)i * MAX_ROWS + k], x[k], s); out[i] = s; }
+    for (int i = ln; i < m; i += 64) { double s = 0.0; for (int k = 0; k < m; k++) s = fma(trans ? P[(size_t)k * ldr + i] : P[(size_t)i * ldr + k], x[k], s); out[i] = s; }
     w.sync();
   };
   // fbar = Abar^T lambda1 = (M^-1 A_c)^T g: the saved impulse tests applied to g
-  for (int r = ln; r < m; r += 64) { double s = 0.0; for (int d = 0; d < n; d++) s = fma(dn[lay.massed + d * MAX_ROWS + r], L.g[d], s); L.t[r] = s; }
+  for (int r = ln; r < m; r += 64) { double s = 0.0; for (int d = 0; d < n; d++) s = fma(dn[lay.massed + d * ldr + r], L.g[d], s); L.t[r] = s; }
   w.sync();
   fold(L.t, L.tmp);
   for (int r = ln; r < m; r += 64) L.fbar[r] = L.clamp[r] ? L.t[r] + L.tmp[r] : 0.0;
@@ -509,10 +513,10 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_gen(DevModel mdl, const De
       double y = 0.0;
       for (int k = 0; k < m; k++) {
         // spread(Q^+)[k][j] = sc_k P[src_k][j]
-        const double xe = L.clamp[k] ? P[(size_t)k * MAX_ROWS + j] : (L.ub[k] ? L.E[k] * P[(size_t)L.fp[k] * MAX_ROWS + j] : 0.0);
-        y = fma(A[(size_t)k * MAX_ROWS + r], xe, y);
+        const double xe = L.clamp[k] ? P[(size_t)k * ldr + j] : (L.ub[k] ? L.E[k] * P[(size_t)L.fp[k] * ldr + j] : 0.0);
+        y = fma(A[(size_t)k * ldr + r], xe, y);
       }
-      y += L.cfm[r] * P[(size_t)r * MAX_ROWS + j];
+      y += L.cfm[r] * P[(size_t)r * ldr + j];
       const double dlt = ((r == j) ? 1.0 : 0.0) - y;
       acc = fma(dlt, dlt, acc);
     }
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_gen(DevModel mdl, const De
   for (int d = ln; d < n; d += 64) {
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < m; r++) {
-      const double ms = dn[lay.massed + d * MAX_ROWS + r], aa = dn[lay.aall + d * MAX_ROWS + r];
+      const double ms = dn[lay.massed + d * ldr + r], aa = dn[lay.aall + d * ldr + r];
       for (int k = 0; k < 3; k++) { acc[k] = fma(L.clamp[r] ? L.al[k][r] : 0.0, ms, acc[k]); acc[3 + k] = fma(L.beE[k][r], ms, acc[3 + k]); }
       acc[6] = fma(L.clamp[r] ? L.muB[r] : 0.0, aa, acc[6]);
     }
@@ -763,6 +767,7 @@ __global__ __launch_bounds__(64) void k_bwd_bounce_gen(DevModel mdl, const DevBo
   __shared__ int brow[MAX_CONTACTS];
   const GenWaveDev w;
   const int ln = w.lane();
+  const int ldr = lay.ldr;              // leading dimension of the record's dense blocks and of the world's scratch matrices
   const int64_t b = mdl.b0 + (int64_t)blockIdx.x;
   if (b >= mdl.b1) return;
   const int n = mdl.n;
@@ -772,6 +777,7 @@ __global__ __launch_bounds__(64) void k_bwd_bounce_gen(DevModel mdl, const DevBo
     for (int r = 0; r < m; r += 3)
       if (svAt(saved, lay.cls + r, B, b) == 1.0 && svAt(saved, lay.rest + r / 3, B, b) > 0.0) brow[nbn++] = r;
     R.iscal[0] = nbn;
+    R.ld = ldr;                                         // (genPinv below works in the world's scratch matrices)
   }
   w.sync();
   const int nbn = R.iscal[0];
@@ -812,27 +818,27 @@ __global__ __launch_bounds__(64) void k_bwd_bounce_gen(DevModel mdl, const DevBo
   }
   w.sync();
   // ---- G (nbn x nbn, compact) -> scratch, t = a_i . y, rhs = e_i + |a_i|^2 ----
-  const GenScratch S = genScratchOf(gws, b, gws + (size_t)b * GEN_SCRATCH_DOUBLES + (size_t)3 * GR * GLD);   // (P in the last scratch matrix: the record's Q^+ stays)
+  const GenScratch S = genScratchOf(gws, b, gws + (size_t)b * genScratchDoubles(ldr) + (size_t)3 * ldr * ldr, ldr);   // (P in the last scratch matrix: the record's Q^+ stays)
   for (int e = ln; e < nbn * nbn; e += 64) {
     const int i = e / nbn, k = e - i * nbn;
     double dotik = 0.0;
-    for (int d = 0; d < n; d++) dotik = fma(dn[lay.aall + d * MAX_ROWS + brow[i]], dn[lay.aall + d * MAX_ROWS + brow[k]], dotik);
-    S.mat[0][(size_t)i * GLD + k] = dotik * dotik;
+    for (int d = 0; d < n; d++) dotik = fma(dn[lay.aall + d * ldr + brow[i]], dn[lay.aall + d * ldr + brow[k]], dotik);
+    S.mat[0][(size_t)i * ldr + k] = dotik * dotik;
   }
   for (int i = ln; i < nbn; i += 64) {
     double a2 = 0.0, sq = 0.0, sv = 0.0;
-    for (int d = 0; d < n; d++) { const double a = dn[lay.aall + d * MAX_ROWS + brow[i]]; sq = fma(a, yq[d], sq); sv = fma(a, yv[d], sv); a2 = fma(a, a, a2); }
+    for (int d = 0; d < n; d++) { const double a = dn[lay.aall + d * ldr + brow[i]]; sq = fma(a, yq[d], sq); sv = fma(a, yv[d], sv); a2 = fma(a, a, a2); }
     tq[i] = sq; tv[i] = sv; rhs[i] = svAt(saved, lay.rest + brow[i] / 3, B, b) + a2;
   }
   w.sync();
   genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], nbn, nbn);
-  for (int i = ln; i < nbn; i += 64) { double s = 0.0; for (int k = 0; k < nbn; k++) s = fma(S.mat[3][(size_t)i * GLD + k], rhs[k], s); cRow[i] = s; }
+  for (int i = ln; i < nbn; i += 64) { double s = 0.0; for (int k = 0; k < nbn; k++) s = fma(S.mat[3][(size_t)i * ldr + k], rhs[k], s); cRow[i] = s; }
   w.sync();
   // ---- (X - I) y = -A_b (c o t)   (lane = DOF) ----
   for (int d = ln; d < n; d += 64) {
     double dq = 0.0, dv = 0.0;
     for (int i = 0; i < nbn; i++) {
-      const double a = dn[lay.aall + d * MAX_ROWS + brow[i]];
+      const double a = dn[lay.aall + d * ldr + brow[i]];
       dq = fma(-a, cRow[i] * tq[i], dq); dv = fma(-a, cRow[i] * tv[i], dv);
     }
     lws[(int64_t)(LB_QX + d) * B + b] += dq;
@@ -849,11 +855,11 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig_gen(int count, int n, c
   const int ln = w.lane();
   const int64_t pb = blockIdx.x;
   if (pb >= count) return;
-  const GenScratch S = genScratchOf(gws, pb, gws + (size_t)pb * GEN_SCRATCH_DOUBLES + (size_t)3 * GR * GLD);
+  const GenScratch S = genScratchOf(gws, pb, gws + (size_t)pb * genScratchDoubles(GR) + (size_t)3 * GR * GR, GR);   // (self-test: leading dimension = the cap)
   GenProblem P; GenDantzigMem D;
   genCarve(S, P, D);
   for (int j = ln; j < n; j += 64) {
-    for (int i = 0; i < n; i++) P.A[(size_t)i * GLD + j] = A[(pb * n + i) * n + j];
+    for (int i = 0; i < n; i++) P.A[(size_t)i * GR + j] = A[(pb * n + i) * n + j];
     P.b[j] = b[pb * n + j]; P.lo[j] = lo[pb * n + j]; P.hi[j] = hi[pb * n + j]; P.findex[j] = findex[pb * n + j]; P.x[j] = 0.0;
   }
   w.sync();
@@ -876,10 +882,13 @@ __global__ __launch_bounds__(64) void k_selftest_cascade_gen(int count, int m, c
   const int ln = w.lane();
   const int64_t pb = blockIdx.x;
   if (pb >= count) return;
-  const GenScratch S = genScratchOf(gws, pb, gws + (size_t)pb * GEN_SCRATCH_DOUBLES + (size_t)3 * GR * GLD);
-  double* Ap = gws + (size_t)pb * GEN_SCRATCH_DOUBLES + (size_t)4 * GR * GLD + 16 * GR;      // the problem's matrix with leading dimension GLD (6th block)
-  for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) Ap[(size_t)i * GLD + j] = A[((size_t)pb * m + i) * m + j];
-  if (ln == 0) R.m = m;
+  // per problem: the scratch of a world with the cap as leading dimension (five matrices + 16 vectors): M, G, T, then the block that serves
+  // as Q^+ AND - never at the same time - as the cascade's problem matrix, the vectors, and in the fifth block the problem handed in
+  double* base = gws + (size_t)pb * genScratchDoubles(GR);
+  const GenScratch S = genScratchOf(gws, pb, base + (size_t)3 * GR * GR, GR);
+  double* Ap = base + (size_t)4 * GR * GR + 16 * GR;
+  for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) Ap[(size_t)i * GR + j] = A[((size_t)pb * m + i) * m + j];
+  if (ln == 0) { R.m = m; R.ld = GR; }
   w.sync();
   for (int r = ln; r < m; r += 64) {
     double mr = mu[(size_t)pb * (m / 3) + r / 3];
@@ -889,7 +898,7 @@ __global__ __launch_bounds__(64) void k_selftest_cascade_gen(int count, int m, c
     R.lim[r] = 0; R.neg[r] = 0; R.rowOn[r] = 1;
     R.on[r] = on ? on[(size_t)pb * m + r] : 1;
     double cn = 0.0;
-    if (R.on[r]) for (int i = 0; i < m; i++) { const double a = Ap[(size_t)i * GLD + r]; cn = fma(a, a, cn); }
+    if (R.on[r]) for (int i = 0; i < m; i++) { const double a = Ap[(size_t)i * GR + r]; cn = fma(a, a, cn); }
     R.colNorm[r] = cn;
     R.X[r] = (haveCache && R.on[r]) ? xcache[(size_t)pb * m + r] : 0.0;
   }
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(64) void k_selftest_cascade_gen(int count, int m, c
   GenClasses K;
   double cfmG = 0.0;
   uint32_t stG = 0x2u | 0x100u;
-  if (!genStage0(w, Ap, GLD, R, S, haveCache != 0, pinvValid, K)) genCascade(w, Ap, GLD, R, S, fallbackCfm, cfmG, stG, pinvValid, K);
+  if (!genStage0(w, Ap, GR, R, S, haveCache != 0, pinvValid, K)) genCascade(w, Ap, GR, R, S, fallbackCfm, cfmG, stG, pinvValid, K);
   for (int r = ln; r < m; r += 64) { x[(size_t)pb * m + r] = R.X[r]; cls[(size_t)pb * m + r] = R.on[r] ? R.cls[r] : 0; }
   if (ln == 0) { st[pb] = stG; cfmOut[pb] = cfmG; }
 }

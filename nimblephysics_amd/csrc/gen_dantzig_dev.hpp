@@ -15,7 +15,8 @@
 namespace NBL_NS {
 
 struct GenDantzigMem {      // all in the world's HBM scratch
-  double* A;                // n x n (leading dimension GLD): the problem's matrix; symmetrised and permuted in place
+  int ld;                   // leading dimension of A and L
+  double* A;                // n x n (leading dimension ld): the problem's matrix; symmetrised and permuted in place
   double* L;                // factor rows
   double *d, *x, *w, *b, *lo, *hi, *dx, *dw, *ell, *Dell, *tmp, *tvec, *W1, *W2;
   int *p, *C, *findex, *state;
@@ -27,8 +28,8 @@ DEV int genDantzigSeq(const GenDantzigMem& M, int n, double* xOut) {
 #pragma clang fp contract(off)
 #endif
   double* A = M.A; double* L = M.L;
-  auto AA = [&](int i, int j) -> double& { return A[(size_t)i * GLD + j]; };
-  auto LL = [&](int i, int j) -> double& { return L[(size_t)i * GLD + j]; };
+  auto AA = [&](int i, int j) -> double& { return A[(size_t)i * M.ld + j]; };
+  auto LL = [&](int i, int j) -> double& { return L[(size_t)i * M.ld + j]; };
   // dDot (fastdot.cpp): the running sum from 0 in index order
   auto dotRows = [&](const double* a, const double* b, int cnt) -> double { double s = 0.0; for (int k = 0; k < cnt; k++) s = s + a[k] * b[k]; return s; };
   int nC = 0, nN = 0;
@@ -313,13 +314,15 @@ constexpr int GS_NAN = 4;      // Dantzig: NaN step length
 // carve the problem arrays and the Dantzig arrays out of the world's scratch (mat[4]: the problem's matrix, mat[1]: the factor)
 DEV void genCarve(const GenScratch& S, GenProblem& P, GenDantzigMem& D) {
   double* v = S.vec;
-  P.A = S.mat[4]; P.x = v; P.b = v + GR; P.lo = v + 2 * GR; P.hi = v + 3 * GR;
-  P.findex = reinterpret_cast<int*>(v + 4 * GR); P.mapTo = P.findex + GR;
+  const int g = S.ld;       // (every vector of the carve-up has ld entries: ld >= the model's rows, a multiple of 8)
+  P.ld = g; D.ld = g;
+  P.A = S.mat[4]; P.x = v; P.b = v + g; P.lo = v + 2 * g; P.hi = v + 3 * g;
+  P.findex = reinterpret_cast<int*>(v + 4 * g); P.mapTo = P.findex + g;
   D.A = S.mat[4]; D.L = S.mat[1];
-  D.d = v + 5 * GR; D.x = v + 6 * GR; D.w = v + 7 * GR; D.dx = v + 8 * GR; D.dw = v + 9 * GR; D.ell = v + 10 * GR; D.Dell = v + 11 * GR;
-  D.tmp = v + 12 * GR; D.tvec = S.mat[2]; D.W1 = S.mat[2] + 2 * GR; D.W2 = S.mat[2] + 3 * GR;
+  D.d = v + 5 * g; D.x = v + 6 * g; D.w = v + 7 * g; D.dx = v + 8 * g; D.dw = v + 9 * g; D.ell = v + 10 * g; D.Dell = v + 11 * g;
+  D.tmp = v + 12 * g; D.tvec = S.mat[2]; D.W1 = S.mat[2] + 2 * g; D.W2 = S.mat[2] + 3 * g;
   D.b = P.b; D.lo = P.lo; D.hi = P.hi; D.findex = P.findex;
-  D.p = reinterpret_cast<int*>(v + 13 * GR); D.C = D.p + GR; D.state = reinterpret_cast<int*>(v + 14 * GR);
+  D.p = reinterpret_cast<int*>(v + 13 * g); D.C = D.p + g; D.state = reinterpret_cast<int*>(v + 14 * g);
 }
 
 // X[o] = x_reduced[mapTo[o]] -> out (rows that are off: 0)
@@ -385,7 +388,7 @@ template <class W>
 DEV void genCascade(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double fallbackCfm, double& cfmOut, uint32_t& stOut,
                     bool& pinvValid, GenClasses& K) {
   const int m = R.m;
-  double* cand = S.vec + 15 * GR;
+  double* cand = S.vec + 15 * S.ld;
   auto hasNan = [&](const double* x) -> bool { bool b = false; for (int r = w.lane(); r < m; r += w.lanes()) if (x[r] != x[r]) b = true; return w.anyAll(b); };
   auto take = [&](const double* x) { for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = R.on[r] ? x[r] : 0.0; w.sync(); };
   bool success = false, ignoreFriction = false;

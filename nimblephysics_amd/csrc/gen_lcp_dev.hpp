@@ -19,12 +19,16 @@
 
 namespace NBL_NS {
 
-constexpr int GR = MAXR;            // rows of the arrays below (the general instantiation: 192)
-constexpr int GLD = MAXR;           // leading dimension of every scratch matrix
+constexpr int GR = MAXR;            // rows of the arrays below: the instantiation's cap (192 / 384)
+// The leading dimension of every scratch matrix AND of the record's dense blocks is a property of the MODEL, not of the build: its rows
+// (3 x max_contacts) rounded up to a multiple of 8 - GenRows::ld, SavedLayout::ldr.  A tower of five cubes (28 slots, 88 rows) then holds
+// 62 kB per matrix instead of the cap's 295 kB.
+__host__ __device__ inline int genLeadingDim(int maxContacts) { const int r = (3 * maxContacts + 7) & ~7; return r < 8 ? 8 : (r > MAXR ? MAXR : r); }
 
 // per-row data of one world's LCP (LDS on the device)
 struct GenRows {
   int m;                            // rows in use (3 per contact slot)
+  int ld;                           // leading dimension of the world's scratch matrices and of the record's dense blocks (genLeadingDim)
   double Bv[GR], mu[GR], colNorm[GR];
   double X[GR], X0[GR], E[GR];
   double t0[GR], t1[GR], t2[GR], t3[GR];   // scratch vectors
@@ -36,9 +40,10 @@ struct GenRows {
   int anyLim;
 };
 
-// scratch matrices of one world (HBM): GEN_NMAT blocks of GR x GLD doubles
+// scratch of one world (HBM): GEN_NMAT matrices of ld x ld doubles + 16 vectors of ld (four matrices + the vectors in the step; the fifth
+// matrix: the self-test's problem)
 constexpr int GEN_NMAT = 5;
-constexpr size_t GEN_SCRATCH_DOUBLES = (size_t)GEN_NMAT * GR * GLD + 16 * GR;      // (four matrices + 16 vectors in the step; the fifth matrix: the self-test's problem)
+__host__ __device__ inline size_t genScratchDoubles(int ld) { return (size_t)GEN_NMAT * ld * ld + (size_t)16 * ld; }
 
 // ---- dense helpers: lanes stride through the rows / columns, A symmetric with leading dimension lda ----------------------------------
 // y_r = sum_j A[j][r] x_j over the rows that are on (y = 0 on the others); x is masked by `on` as well
@@ -127,9 +132,10 @@ DEV GenClasses genClassify(const W& w, GenRows& R, const double* X, bool ignoreF
 }
 
 // Q[i][s] = A[i][s] + [s normal] sum_{u = s+1, s+2 upper-bound} E[u] A[i][u] + cfm [i == s] for clamping i and s, zero elsewhere
-// (coopBuildQ of coop_dev.hpp with loops instead of lanes) -> M (row-major, leading dimension GLD)
+// (coopBuildQ of coop_dev.hpp with loops instead of lanes) -> M (row-major, leading dimension R.ld)
 template <class W>
 DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const GenClasses& K, double cfm, double* M, const double* cfmRow = nullptr) {
+  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const int m = R.m;
   for (int s = w.lane(); s < m; s += w.lanes()) {
     const bool colOn = R.cls[s] == RC_CLAMPING;
@@ -149,7 +155,7 @@ DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const
         if (K.nu > 0 && (R.lim[s] || R.lim[i])) q = 0.0;
         if (i == s) q += cfmRow ? cfmRow[s] : cfm;     // (cfmRow: one constant per row, its constrained group's)
       }
-      M[(size_t)i * GLD + s] = q;
+      M[(size_t)i * ld + s] = q;
     }
   }
   w.sync();
@@ -162,8 +168,9 @@ DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const
 // algebra as coopPinvImpl (coop_dev.hpp), which explains why that is as accurate as the second Householder pass.  Returns the rank.
 template <class W>
 DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue, bool symPsd = false) {
+  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const int ln = w.lane(), nl = w.lanes();
-  for (int j = ln; j < m; j += nl) { R.done[j] = 0; for (int i = 0; i < m; i++) G[(size_t)i * GLD + j] = (i == j) ? 1.0 : 0.0; }
+  for (int j = ln; j < m; j += nl) { R.done[j] = 0; for (int i = 0; i < m; i++) G[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0; }
   w.sync();
   // Rank threshold: the reference's eps * size * |R_00| (CGGM.cpp:280, LCPUtils.cpp:113).  For a SYMMETRIC positive semi-definite matrix
   // (A on the guess rows; Q with no friction row on its bound) 64 x that, the policy of the 24- / 48-row builds' Cholesky route
@@ -183,8 +190,8 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
       if (R.done[j]) continue;
       double s0 = 0.0, s1 = 0.0;
       int i = k;
-      for (; i + 1 < m; i += 2) { const double a = M[(size_t)i * GLD + j], b = M[(size_t)(i + 1) * GLD + j]; s0 = fma(a, a, s0); s1 = fma(b, b, s1); }
-      if (i < m) { const double a = M[(size_t)i * GLD + j]; s0 = fma(a, a, s0); }
+      for (; i + 1 < m; i += 2) { const double a = M[(size_t)i * ld + j], b = M[(size_t)(i + 1) * ld + j]; s0 = fma(a, a, s0); s1 = fma(b, b, s1); }
+      if (i < m) { const double a = M[(size_t)i * ld + j]; s0 = fma(a, a, s0); }
       const double nrm = s0 + s1;
       if (nrm > myBest) { myBest = nrm; myCol = j; }
     }
@@ -193,7 +200,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     if (!(best > thr * thr * best0) || !(best > 0.0)) break;
     const int p = w.minAllI(myBest == best ? myCol : 0x7fffffff);
     // the reflector of column p: V[i] = x_i (unscaled), v = x - alpha e_k scaled so that v_k = 1
-    for (int i = k + ln; i < m; i += nl) V[i] = M[(size_t)i * GLD + p];
+    for (int i = k + ln; i < m; i += nl) V[i] = M[(size_t)i * ld + p];
     w.sync();
     const double akk = V[k];
     double below = 0.0;
@@ -211,15 +218,15 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
       double* Mc = carried ? G : M;
       if (!carried && (R.done[j] || j == p)) continue;
       double d = 0.0;
-      for (int i = k + 1; i < m; i++) d = fma(V[i], Mc[(size_t)i * GLD + j], d);
-      d = fma(vinv, d, Mc[(size_t)k * GLD + j]) * tau;
-      Mc[(size_t)k * GLD + j] -= d;
+      for (int i = k + 1; i < m; i++) d = fma(V[i], Mc[(size_t)i * ld + j], d);
+      d = fma(vinv, d, Mc[(size_t)k * ld + j]) * tau;
+      Mc[(size_t)k * ld + j] -= d;
       const double dv = d * vinv;
-      for (int i = k + 1; i < m; i++) Mc[(size_t)i * GLD + j] = fma(-dv, V[i], Mc[(size_t)i * GLD + j]);
+      for (int i = k + 1; i < m; i++) Mc[(size_t)i * ld + j] = fma(-dv, V[i], Mc[(size_t)i * ld + j]);
     }
     w.sync();
-    if (ln == 0) { M[(size_t)k * GLD + p] = alpha; R.done[p] = 1; R.perm[k] = p; }
-    for (int i = k + 1 + ln; i < m; i += nl) M[(size_t)i * GLD + p] = 0.0;
+    if (ln == 0) { M[(size_t)k * ld + p] = alpha; R.done[p] = 1; R.perm[k] = p; }
+    for (int i = k + 1 + ln; i < m; i += nl) M[(size_t)i * ld + p] = 0.0;
     w.sync();
     rank = k + 1;
   }
@@ -230,11 +237,11 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   }
   w.sync();
   if (r == 0) {
-    for (int j = ln; j < m; j += nl) for (int i = 0; i < m; i++) P[(size_t)i * GLD + j] = 0.0;
+    for (int j = ln; j < m; j += nl) for (int i = 0; i < m; i++) P[(size_t)i * ld + j] = 0.0;
     w.sync();
     return 0;
   }
-  for (int k = ln; k < r; k += nl) R.invd[k] = 1.0 / M[(size_t)k * GLD + R.perm[k]];
+  for (int k = ln; k < r; k += nl) R.invd[k] = 1.0 / M[(size_t)k * ld + R.perm[k]];
   w.sync();
   // x = R1^-1 (column) in place, R1[i][k] = M[i][perm[k]]: the columns of G1 (right-hand sides) and, rank deficient, those of R2
   const int nExtra = r >= cTrue ? 0 : m - r;
@@ -243,16 +250,16 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     const int j = jj < m ? jj : R.perm[r + (jj - m)];
     for (int kk = r - 1; kk >= 0; kk--) {
       const int pk = R.perm[kk];
-      const double y = Mc[(size_t)kk * GLD + j] * R.invd[kk];
-      Mc[(size_t)kk * GLD + j] = y;
-      for (int i = 0; i < kk; i++) Mc[(size_t)i * GLD + j] = fma(-M[(size_t)i * GLD + pk], y, Mc[(size_t)i * GLD + j]);
+      const double y = Mc[(size_t)kk * ld + j] * R.invd[kk];
+      Mc[(size_t)kk * ld + j] = y;
+      for (int i = 0; i < kk; i++) Mc[(size_t)i * ld + j] = fma(-M[(size_t)i * ld + pk], y, Mc[(size_t)i * ld + j]);
     }
   }
   w.sync();
   if (r >= cTrue) {
     for (int j = ln; j < m; j += nl) {
-      for (int kk = 0; kk < r; kk++) P[(size_t)R.perm[kk] * GLD + j] = G[(size_t)kk * GLD + j];
-      for (int pp = r; pp < m; pp++) P[(size_t)R.perm[pp] * GLD + j] = 0.0;
+      for (int kk = 0; kk < r; kk++) P[(size_t)R.perm[kk] * ld + j] = G[(size_t)kk * ld + j];
+      for (int pp = r; pp < m; pp++) P[(size_t)R.perm[pp] * ld + j] = 0.0;
     }
     w.sync();
     return r;
@@ -262,46 +269,46 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   for (int e = ln; e < r * r; e += nl) {
     const int a = e / r, b = e - a * r;
     double s = (a == b) ? 1.0 : 0.0;
-    for (int t = 0; t < nw; t++) { const int c = R.perm[r + t]; s = fma(M[(size_t)a * GLD + c], M[(size_t)b * GLD + c], s); }
-    T[(size_t)a * GLD + b] = s;
+    for (int t = 0; t < nw; t++) { const int c = R.perm[r + t]; s = fma(M[(size_t)a * ld + c], M[(size_t)b * ld + c], s); }
+    T[(size_t)a * ld + b] = s;
   }
   w.sync();
   // Cholesky S = L L^T in place (lower triangle of T), lanes = rows below the pivot
   for (int k = 0; k < r; k++) {
     if (ln == 0) {
-      double s = T[(size_t)k * GLD + k];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * GLD + i], T[(size_t)k * GLD + i], s);
+      double s = T[(size_t)k * ld + k];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * ld + i], T[(size_t)k * ld + i], s);
       const double lkk = sqrt(s);
-      T[(size_t)k * GLD + k] = lkk;
+      T[(size_t)k * ld + k] = lkk;
       R.scal[0] = 1.0 / lkk;
     }
     w.sync();
     const double inv = R.scal[0];
     for (int a = k + 1 + ln; a < r; a += nl) {
-      double s = T[(size_t)a * GLD + k];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)a * GLD + i], T[(size_t)k * GLD + i], s);
-      T[(size_t)a * GLD + k] = s * inv;
+      double s = T[(size_t)a * ld + k];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)a * ld + i], T[(size_t)k * ld + i], s);
+      T[(size_t)a * ld + k] = s * inv;
     }
     w.sync();
   }
   // z = S^-1 x for the columns of G1 (in place), then Q^+ = Pi [z; W^T z]
   for (int j = ln; j < m; j += nl) {
     for (int k = 0; k < r; k++) {
-      double s = G[(size_t)k * GLD + j];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * GLD + i], G[(size_t)i * GLD + j], s);
-      G[(size_t)k * GLD + j] = s / T[(size_t)k * GLD + k];
+      double s = G[(size_t)k * ld + j];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * ld + i], G[(size_t)i * ld + j], s);
+      G[(size_t)k * ld + j] = s / T[(size_t)k * ld + k];
     }
     for (int k = r - 1; k >= 0; k--) {
-      double s = G[(size_t)k * GLD + j];
-      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * GLD + k], G[(size_t)i * GLD + j], s);
-      G[(size_t)k * GLD + j] = s / T[(size_t)k * GLD + k];
+      double s = G[(size_t)k * ld + j];
+      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * ld + k], G[(size_t)i * ld + j], s);
+      G[(size_t)k * ld + j] = s / T[(size_t)k * ld + k];
     }
-    for (int k = 0; k < r; k++) P[(size_t)R.perm[k] * GLD + j] = G[(size_t)k * GLD + j];
+    for (int k = 0; k < r; k++) P[(size_t)R.perm[k] * ld + j] = G[(size_t)k * ld + j];
     for (int t = 0; t < nw; t++) {
       const int c = R.perm[r + t];
       double s = 0.0;
-      for (int i = 0; i < r; i++) s = fma(M[(size_t)i * GLD + c], G[(size_t)i * GLD + j], s);
-      P[(size_t)c * GLD + j] = s;
+      for (int i = 0; i < r; i++) s = fma(M[(size_t)i * ld + c], G[(size_t)i * ld + j], s);
+      P[(size_t)c * ld + j] = s;
     }
   }
   w.sync();
@@ -310,10 +317,10 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
 
 // y_i = sum_k P[i][k] x_k (TRANS: P[k][i]) for i < m
 template <class W, bool TRANS>
-DEV void genPinvApply(const W& w, const double* P, int m, const double* x, double* y) {
+DEV void genPinvApply(const W& w, const double* P, int ld, int m, const double* x, double* y) {
   for (int i = w.lane(); i < m; i += w.lanes()) {
     double s = 0.0;
-    for (int k = 0; k < m; k++) s = fma(TRANS ? P[(size_t)k * GLD + i] : P[(size_t)i * GLD + k], x[k], s);
+    for (int k = 0; k < m; k++) s = fma(TRANS ? P[(size_t)k * ld + i] : P[(size_t)i * ld + k], x[k], s);
     y[i] = s;
   }
   w.sync();
@@ -321,8 +328,9 @@ DEV void genPinvApply(const W& w, const double* P, int m, const double* x, doubl
 
 // the world's scratch matrices
 struct GenScratch {
-  double* mat[GEN_NMAT];    // M, G, T, P, and one more for the cascade's problem / factor
-  double* vec;              // 16 x GR doubles
+  double* mat[GEN_NMAT];    // M, G, T, P, and one more for the cascade's problem / factor (ld x ld each)
+  double* vec;              // 16 x ld doubles
+  int ld;
 };
 
 // CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (coopStandardizeLoop of coop_dev.hpp).  X in: the solver's x
@@ -360,7 +368,7 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
       genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc, K.nu == 0);
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = R.cls[r] == RC_CLAMPING ? R.Bv[r] : 0.0;
       w.sync();
-      genPinvApply<W, false>(w, S.mat[3], m, R.t2, fc);
+      genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, fc);
       pinvValid = true;
     }
     bool newlyNot = false;
@@ -392,6 +400,7 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
 // (BoxedLcpConstraintSolver.cpp:380-460).  R.X in: the warm start (haveCache), out: the solution; R.X0: the pre-solve x.
 template <class W>
 DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, bool haveCache, bool& pinvValid, GenClasses& K) {
+  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const int m = R.m;
   pinvValid = false;
   bool haveGuess = false;
@@ -413,12 +422,12 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
     if (nIn > 0) {
       double* M = S.mat[0];
       for (int s = w.lane(); s < m; s += w.lanes())
-        for (int i = 0; i < m; i++) M[(size_t)i * GLD + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
+        for (int i = 0; i < m; i++) M[(size_t)i * ld + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
       w.sync();
       genPinv(w, R, M, S.mat[1], S.mat[2], S.mat[3], m, nIn, true);          // A restricted to the guess rows: symmetric positive semi-definite
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = in0[r] ? R.Bv[r] : 0.0;
       w.sync();
-      genPinvApply<W, false>(w, S.mat[3], m, R.t2, R.t0);
+      genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, R.t0);
       for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = in0[r] ? R.t0[r] : 0.0;
       w.sync();
       haveGuess = true;
@@ -433,8 +442,8 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
 }
 
 // ---- stages 1-3: the reduced problems ---------------------------------------------------------------------------------------------------
-struct GenProblem {          // compacted boxed LCP (arrays in the world's scratch vectors), matrix n x n with leading dimension GLD
-  int n;
+struct GenProblem {          // compacted boxed LCP (arrays in the world's scratch vectors), matrix n x n with leading dimension ld
+  int n, ld;
   double *A, *x, *b, *lo, *hi;
   int *findex, *mapTo;      // mapTo[original row] = column of the problem (-1: dropped)
 };
@@ -443,6 +452,7 @@ struct GenProblem {          // compacted boxed LCP (arrays in the world's scrat
 // frictionless contacts (ContactConstraint dimension 1).  Lane 0 compacts the indices, the lanes copy.
 template <class W>
 DEV void genLoadProblem(const W& w, const double* A, int lda, GenRows& R, double cfmDiag, const double* x0, GenProblem& P) {
+  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const int m = R.m;
   if (w.lane() == 0) {
     int n = 0;
@@ -462,16 +472,17 @@ DEV void genLoadProblem(const W& w, const double* A, int lda, GenRows& R, double
   }
   w.sync();
   const int n = R.iscal[0];
-  P.n = n;
+  P.n = n; P.ld = ld;
   for (int j = w.lane(); j < n; j += w.lanes()) {
     const int sj = R.perm[j];
-    for (int i = 0; i < n; i++) P.A[(size_t)i * GLD + j] = A[(size_t)R.perm[i] * lda + sj] + (i == j ? cfmDiag : 0.0);
+    for (int i = 0; i < n; i++) P.A[(size_t)i * ld + j] = A[(size_t)R.perm[i] * lda + sj] + (i == j ? cfmDiag : 0.0);
   }
   w.sync();
 }
 
 // delete row + column `col` (lane 0)
 DEV void genRemoveRowCol(GenProblem& P, int col) {
+  const int ld = P.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const int n = P.n;
   for (int i = 0; i < n; i++) {
     if (i == col) continue;
@@ -479,7 +490,7 @@ DEV void genRemoveRowCol(GenProblem& P, int col) {
     for (int j = 0; j < n; j++) {
       if (j == col) continue;
       const int nj = j > col ? j - 1 : j;
-      P.A[(size_t)ni * GLD + nj] = P.A[(size_t)i * GLD + j];     // rows / columns move up-left: reads stay ahead of writes
+      P.A[(size_t)ni * ld + nj] = P.A[(size_t)i * ld + j];     // rows / columns move up-left: reads stay ahead of writes
     }
   }
   for (int i = col; i + 1 < n; i++) { P.x[i] = P.x[i + 1]; P.b[i] = P.b[i + 1]; P.lo[i] = P.lo[i + 1]; P.hi[i] = P.hi[i + 1]; P.findex[i] = P.findex[i + 1]; }
@@ -490,6 +501,7 @@ DEV void genRemoveRowCol(GenProblem& P, int col) {
 // 1e-4, same findex / hi / lo).  mOrig: rows of the world (for mapTo).
 template <class W>
 DEV void genLcpReduce(const W& w, GenRows& R, GenProblem& P, int mOrig) {
+  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const double TH = 1e-4;
   if (w.lane() == 0) {
     for (;;) {
@@ -499,11 +511,11 @@ DEV void genLcpReduce(const W& w, GenRows& R, GenProblem& P, int mOrig) {
         for (int b = a + 1; b < n; b++) {
           if (!(fabs(P.b[a] - P.b[b]) < TH && P.findex[a] == P.findex[b] && P.hi[a] == P.hi[b] && P.lo[a] == P.lo[b])) continue;
           double d2 = 0.0;
-          for (int r = 0; r < n; r++) { const double d = P.A[(size_t)r * GLD + a] - P.A[(size_t)r * GLD + b]; d2 += d * d; }
+          for (int r = 0; r < n; r++) { const double d = P.A[(size_t)r * ld + a] - P.A[(size_t)r * ld + b]; d2 += d * d; }
           if (d2 < TH) { ma = a; mb = b; break; }
         }
       if (ma < 0) break;
-      for (int r = 0; r < n; r++) P.A[(size_t)r * GLD + ma] *= 2.0;
+      for (int r = 0; r < n; r++) P.A[(size_t)r * ld + ma] *= 2.0;
       for (int i = 0; i < n; i++) {
         if (P.findex[i] == mb) P.findex[i] = ma;
         else if (P.findex[i] > mb) P.findex[i] -= 1;
@@ -546,13 +558,14 @@ DEV void genLcpRemoveFriction(const W& w, GenRows& R, GenProblem& P, int mOrig) 
 // like in the reference.  Uniform result.
 template <class W>
 DEV bool genPgs(const W& w, GenRows& R, GenProblem& P) {
+  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const int n = P.n;
   const int maxIteration = 30;
   const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
   const int ln = w.lane(), nl = w.lanes();
   auto rowDot = [&](int i) -> double {          // sum_{j != i} A[i][j] x[j]
     double s = 0.0;
-    for (int j = ln; j < n; j += nl) if (j != i) s += P.A[(size_t)i * GLD + j] * P.x[j];
+    for (int j = ln; j < n; j += nl) if (j != i) s += P.A[(size_t)i * ld + j] * P.x[j];
     return w.sumAll(s);
   };
   auto clampRow = [&](int i, double nx) -> double {
@@ -566,7 +579,7 @@ DEV bool genPgs(const W& w, GenRows& R, GenProblem& P) {
   int no = 0;
   bool possible = true;
   for (int i = 0; i < n; ++i) {
-    const double aii = P.A[(size_t)i * GLD + i];
+    const double aii = P.A[(size_t)i * ld + i];
     if (aii < epsDiv) { w.sync(); if (ln == 0) P.x[i] = 0.0; w.sync(); continue; }
     if (ln == 0) order[no] = i;
     no++;
@@ -582,10 +595,10 @@ DEV bool genPgs(const W& w, GenRows& R, GenProblem& P) {
   w.sync();
   for (int t = 0; t < no; t++) {
     const int idx = order[t];
-    const double dummy = 1.0 / P.A[(size_t)idx * GLD + idx];
+    const double dummy = 1.0 / P.A[(size_t)idx * ld + idx];
     w.sync();
     if (ln == 0) P.b[idx] *= dummy;
-    for (int j = ln; j < n; j += nl) P.A[(size_t)idx * GLD + j] *= dummy;
+    for (int j = ln; j < n; j += nl) P.A[(size_t)idx * ld + j] *= dummy;
     w.sync();
   }
   for (int iter = 1; iter < maxIteration; ++iter) {

@@ -202,6 +202,8 @@ constexpr int CR_EA_FIXED = 10, CR_EA_DIR = 13, CR_EB_FIXED = 16, CR_EB_DIR = 19
 struct SavedLayout {
   int32_t n, q, v, tau, vpre, w, nc, contacts, x, b, cls, cfm, pflag, rest, total;   // rest: MAX_CONTACTS rows, restitution coefficient of the contacts that bounced
   int32_t A, massed, aall, pinv, dense;
+  int32_t ldr;        // leading dimension of A / massed / aall / pinv: MAX_ROWS in the 24- / 48-row builds; in the general builds the model's own rows
+                      // (3 x max_contacts rounded up to 8: genLeadingDim), so that record and scratch are sized by the model, not by the cap
   int32_t treeRows;   // doubles per world of the tree block after the dense block (0: tree state not saved, backward recomputes)
   int32_t treeNbp;    // 0: lane-interleaved rows [body * WS_KEEP + slot][B];  > 0: compact world-major blocks [b]{[TREE_ROWS][treeNbp], [nFree][TREE_FREE]} (coop tree kernels)
 };

@@ -502,12 +502,18 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     const int n = d->n_dofs;
     L.n = n; L.q = 0; L.v = n; L.tau = 2 * n;
     if (!hasContact) { L.vpre = L.w = L.nc = L.contacts = L.x = L.b = L.cls = L.cfm = L.pflag = L.rest = -1; L.total = 3 * n;
-                       L.A = L.massed = L.aall = L.pinv = -1; L.dense = 0; }
+                       L.A = L.massed = L.aall = L.pinv = -1; L.dense = 0; L.ldr = MAX_ROWS; }
     else {
       L.vpre = 3 * n; L.w = 4 * n; L.nc = 5 * n; L.contacts = L.nc + 1; L.x = L.contacts + MAX_CONTACTS * CR_SIZE;
       L.b = L.x + MAX_ROWS; L.cls = L.b + MAX_ROWS; L.cfm = L.cls + MAX_ROWS; L.pflag = L.cfm + MAX_ROWS; L.rest = L.pflag + 1; L.total = L.rest + MAX_CONTACTS;   // cfm: one constant per row (its group's)
-      L.A = 0; L.massed = L.A + MAX_ROWS * MAX_ROWS; L.aall = L.massed + n * MAX_ROWS; L.pinv = L.aall + n * MAX_ROWS;
-      L.dense = L.pinv + MAX_ROWS * MAX_ROWS;
+#if NBL_GENERAL
+      const int ldr = genLeadingDim(d->max_contacts);      // the general builds size record and scratch by the MODEL's rows, not by their cap
+#else
+      const int ldr = MAX_ROWS;
+#endif
+      L.ldr = ldr;
+      L.A = 0; L.massed = L.A + ldr * ldr; L.aall = L.massed + n * ldr; L.pinv = L.aall + n * ldr;
+      L.dense = L.pinv + ldr * ldr;
     }
     bool saveTree = true;   // trade 8 * WS_KEEP * n_bodies bytes per world and step for the ABA re-run of the backward pass
     if (const char* e0 = getenv("NBL_SAVE_TREE")) saveTree = atoi(e0) != 0;
@@ -664,8 +670,9 @@ static size_t workspaceHeadBytes(const nbl_model* m, int64_t B) {
 size_t nbl_workspace_bytes(const nbl_model* m, int64_t B) {
   if (!m || B <= 0) return 0;
 #if NBL_GENERAL
-  // + the per-world scratch matrices of the general contact kernels (gen_lcp_dev.hpp: 4 matrices of 192 x 192 + 16 vectors: 1.2 MB per world)
-  if (m->hasContact) return workspaceHeadBytes(m, B) + GEN_SCRATCH_DOUBLES * sizeof(double) * (size_t)B;
+  // + the per-world scratch matrices of the general contact kernels (gen_lcp_dev.hpp: 5 matrices of ld x ld + 16 vectors, ld = the model's rows:
+  // 1.5 MB per world at 64 slots, 62 kB x 5 at 28)
+  if (m->hasContact) return workspaceHeadBytes(m, B) + genScratchDoubles(m->lay.ldr) * sizeof(double) * (size_t)B;
 #endif
   return ((size_t)m->nb * WS_PER_BODY + (m->hasContact ? LB_TOTAL : 0)) * sizeof(double) * (size_t)B +
          (m->hasContact ? ((size_t)B + 16) * sizeof(int32_t) : 0);
@@ -1093,7 +1100,7 @@ int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A
     if (ms_per_launch) { e = hipEventCreate(&t0); if (e == hipSuccess) e = hipEventCreate(&t1); }
 #if NBL_GENERAL
     double* dScratch = nullptr;      // the general driver works in HBM: one world's worth of scratch per problem
-    e = hipMalloc((void**)&dScratch, (size_t)count * GEN_SCRATCH_DOUBLES * sizeof(double));
+    e = hipMalloc((void**)&dScratch, (size_t)count * genScratchDoubles(GR) * sizeof(double));
 #define NBL_SELFTEST_DANTZIG(...) hipLaunchKernelGGL(k_selftest_dantzig_gen, dim3((unsigned)count), dim3(64), 0, 0, __VA_ARGS__, dScratch)
 #else
 #define NBL_SELFTEST_DANTZIG(...) hipLaunchKernelGGL(k_selftest_dantzig, dim3((unsigned)count), dim3(64), 0, 0, __VA_ARGS__)
@@ -1140,7 +1147,7 @@ int32_t nbl_selftest_lcp_cascade(int32_t count, int32_t mRows, const double* A, 
   hipError_t e = hipMalloc((void**)&dA, nm * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&dv, (3 * nv + nc + count) * sizeof(double));       // b, xcache, x, mu, cfm
   if (e == hipSuccess) e = hipMalloc((void**)&di, (nv + count) * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dS, (size_t)count * GEN_SCRATCH_DOUBLES * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dS, (size_t)count * genScratchDoubles(GR) * sizeof(double));
   if (e == hipSuccess && on) e = hipMalloc((void**)&dOn, nv);
   if (e == hipSuccess) e = hipMemcpy(dA, A, nm * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(dv, b, nv * sizeof(double), hipMemcpyHostToDevice);

@@ -19,19 +19,25 @@ struct HostWave1 {
 };
 
 namespace {
+// The leading dimension of a problem of m rows: the rows rounded up to a multiple of 8, like the library sizes the scratch and the record of a
+// model (genLeadingDim) - every call exercises the run-time strides at its own size instead of at the cap.
+static int shimLd(int m) { const int r = (m + 7) & ~7; return r < 8 ? 8 : (r > GR ? GR : r); }
 struct World {
   GenRows R;
   std::vector<double> buf;
   GenScratch S;
-  World() : buf(GEN_SCRATCH_DOUBLES, 0.0) {
-    for (int k = 0; k < GEN_NMAT; k++) S.mat[k] = buf.data() + (size_t)k * GR * GLD;
-    S.vec = buf.data() + (size_t)GEN_NMAT * GR * GLD;
+  int ld;
+  explicit World(int m) : buf(genScratchDoubles(shimLd(m)), 0.0), ld(shimLd(m)) {
+    for (int k = 0; k < GEN_NMAT; k++) S.mat[k] = buf.data() + (size_t)k * ld * ld;
+    S.vec = buf.data() + (size_t)GEN_NMAT * ld * ld;
+    S.ld = ld;
     std::memset(&R, 0, sizeof(R));
+    R.ld = ld;
   }
 };
 // rows as the kernels set them up: three per contact, [normal, t1, t2]; mu per contact (mu <= 1e-3: frictionless, its tangent rows empty);
 // lim / neg per row (joint-limit pseudo-contacts), mask = the rows of the constrained group at hand
-void fillRows(GenRows& R, int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg) {
+void fillRows(GenRows& R, int m, const double* A, int GLD, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg) {
   R.m = m;
   R.anyLim = 0;
   for (int r = 0; r < m; r++) {
@@ -55,7 +61,8 @@ int gshim_rows() { return GR; }
 
 // Q: m x m row-major (masked rows / columns zero), P out m x m row-major; returns the rank
 int gshim_pinv(int m, const double* Q, int cTrue, double* Pout) {
-  World Wd;
+  World Wd(m);
+  const int GLD = Wd.ld;
   const HostWave1 w;
   Wd.R.m = m;
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Wd.S.mat[0][(size_t)i * GLD + j] = Q[(size_t)i * m + j];
@@ -66,7 +73,8 @@ int gshim_pinv(int m, const double* Q, int cTrue, double* Pout) {
 
 // the same with the symmetric-positive-semi-definite rank policy (64 x the reference's threshold, see genPinv)
 int gshim_pinv_sym(int m, const double* Q, int cTrue, double* Pout) {
-  World Wd;
+  World Wd(m);
+  const int GLD = Wd.ld;
   const HostWave1 w;
   Wd.R.m = m;
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Wd.S.mat[0][(size_t)i * GLD + j] = Q[(size_t)i * m + j];
@@ -77,7 +85,8 @@ int gshim_pinv_sym(int m, const double* Q, int cTrue, double* Pout) {
 
 // the Dantzig driver on an n-row boxed LCP with explicit bounds (row-major A); returns 1 / 0 / -1 like genDantzigSeq
 int gshim_dantzig(int n, const double* A, const double* b, const double* lo, const double* hi, const int* findex, double* x) {
-  World Wd;
+  World Wd(n);
+  const int GLD = Wd.ld;
   GenProblem P; GenDantzigMem D;
   genCarve(Wd.S, P, D);
   for (int i = 0; i < n; i++) {
@@ -93,11 +102,12 @@ int gshim_dantzig(int n, const double* A, const double* b, const double* lo, con
 // stage 0 on the rows of `mask` (NULL: all): A m x m row-major, b[m], mu[m / 3]; outputs per row.  Returns ok | pinvValid << 1.
 int gshim_stage0(int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg,
                  int haveCache, const double* xcache, double* X, double* X0, int* cls, double* E, double* Pout) {
-  World Wd;
+  World Wd(m);
+  const int GLD = Wd.ld;
   const HostWave1 w;
-  std::vector<double> Ap((size_t)GR * GLD, 0.0);
+  std::vector<double> Ap((size_t)GLD * GLD, 0.0);
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Ap[(size_t)i * GLD + j] = A[(size_t)i * m + j];
-  fillRows(Wd.R, m, Ap.data(), b, mu, mask, lim, neg);
+  fillRows(Wd.R, m, Ap.data(), GLD, b, mu, mask, lim, neg);
   for (int r = 0; r < m; r++) Wd.R.X[r] = (haveCache && Wd.R.on[r]) ? xcache[r] : 0.0;
   bool pinvValid = false;
   GenClasses K;
@@ -110,11 +120,12 @@ int gshim_stage0(int m, const double* A, const double* b, const double* mu, cons
 // stages 1-3 in the reference's order + standardisation on the rows of `mask`, from the pre-solve x `x0`; returns the status bits
 int gshim_cascade(int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg,
                   const double* x0, double fallbackCfm, double* X, double* cfmOut, int* cls) {
-  World Wd;
+  World Wd(m);
+  const int GLD = Wd.ld;
   const HostWave1 w;
-  std::vector<double> Ap((size_t)GR * GLD, 0.0);
+  std::vector<double> Ap((size_t)GLD * GLD, 0.0);
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Ap[(size_t)i * GLD + j] = A[(size_t)i * m + j];
-  fillRows(Wd.R, m, Ap.data(), b, mu, mask, lim, neg);
+  fillRows(Wd.R, m, Ap.data(), GLD, b, mu, mask, lim, neg);
   for (int r = 0; r < m; r++) Wd.R.X0[r] = Wd.R.on[r] ? x0[r] : 0.0;
   double cfm = 0.0;
   uint32_t st = 0;
@@ -130,11 +141,12 @@ int gshim_cascade(int m, const double* A, const double* b, const double* mu, con
 extern "C" {
 // one stage of the cascade alone (1, 2 or 3) on the rows of `mask`, from the pre-solve x: the RAW candidate and the GS_* flags
 int gshim_stage(int stage, int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const double* x0, double fallbackCfm, double* X) {
-  World Wd;
+  World Wd(m);
+  const int GLD = Wd.ld;
   const HostWave1 w;
-  std::vector<double> Ap((size_t)GR * GLD, 0.0);
+  std::vector<double> Ap((size_t)GLD * GLD, 0.0);
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Ap[(size_t)i * GLD + j] = A[(size_t)i * m + j];
-  fillRows(Wd.R, m, Ap.data(), b, mu, mask, nullptr, nullptr);
+  fillRows(Wd.R, m, Ap.data(), GLD, b, mu, mask, nullptr, nullptr);
   for (int r = 0; r < m; r++) Wd.R.X0[r] = Wd.R.on[r] ? x0[r] : 0.0;
   std::vector<double> out(GR, 0.0);
   int flags = 0;
