@@ -40,18 +40,28 @@ def _pu(a):
     return a.ctypes.data_as(pu8) if a is not None else None
 
 
-@pytest.fixture(scope="module")
-def gen():
+def _build_gen_shim(maxc):
     src = os.path.join(HERE, "host_shim", "gen_shim.cpp")
-    out = os.path.join(HERE, "host_shim", "libgen_shim.so")
+    out = os.path.join(HERE, "host_shim", "libgen_shim.so" if maxc == 64 else f"libgen_shim{maxc}.so")
     deps = [src] + [os.path.join(ROOT, "nimblephysics_amd", "csrc", f) for f in ("gen_lcp_dev.hpp", "gen_dantzig_dev.hpp", "lcp_dev.hpp", "spatial_dev.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-DNBL_MAXC=64", "-I", os.path.join(HERE, "host_shim"),
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", f"-DNBL_MAXC={maxc}", "-I", os.path.join(HERE, "host_shim"),
                                "-I", os.path.join(ROOT, "nimblephysics_amd", "csrc"), "-o", out, src])
     lib = C.CDLL(out)
-    assert lib.gshim_rows() == 192
+    assert lib.gshim_rows() == 3 * maxc
     lib.gshim_cascade.argtypes = [C.c_int, pd, pd, pd, pu8, pu8, pu8, pd, C.c_double, pd, pd, pi]
     return lib
+
+
+@pytest.fixture(scope="module")
+def gen():
+    return _build_gen_shim(64)
+
+
+@pytest.fixture(scope="module")
+def gen128():
+    """the same device text compiled with the 384-row cap (the instantiation a model gets when it asks for 65 .. 128 contact slots)"""
+    return _build_gen_shim(128)
 
 
 def test_pinv_equals_numpy_pinv_up_to_192_rows(gen):
@@ -158,6 +168,41 @@ def test_dantzig_is_bit_identical_to_the_reference_dsolvelcp_up_to_192_rows(gen)
             failed += 1
     print(f"Dantzig up to 192 rows: {solved} solved bit for bit, {failed} early exits, all flags equal")
     assert solved > 20 and failed > 0
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+def test_the_384_row_build_of_the_same_text_dantzig_bit_identical_and_pinv_up_to_384_rows(gen128):
+    """-DNBL_MAXC=128: nothing but the cap of the per-row arrays changes (the leading dimension of the matrices is a run-time property of the
+    problem).  Dantzig bit-identical to the reference's dSolveLCP at 65 .. 128 contacts, the pseudo-inverse against numpy up to 384 rows."""
+    rng = np.random.default_rng(3)
+    solved = 0
+    for trial, nc in enumerate([65, 72, 80, 96, 110, 128, 128]):
+        n = 3 * nc
+        ndof = n + 3 if trial % 3 == 0 else int(rng.choice([30, 60, 120]))
+        A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
+        if trial % 2 == 1:
+            b = np.abs(b)
+        xr = np.zeros(n); xd = np.zeros(n)
+        okr = OL.nbo_lcp_dantzig(n, _p(A), _p(xr), _p(b.copy()), _p(lo.copy()), _p(hi.copy()), _pi(fi.copy()), 1)
+        okd = gen128.gshim_dantzig(n, _p(A), _p(b.copy()), _p(lo.copy()), _p(hi.copy()), _pi(fi.copy()), _p(xd))
+        if okd == -1:
+            assert okr == 0 or not np.all(np.isfinite(xr)), (trial, okr)
+            continue
+        assert okr == okd, (trial, n, okr, okd)
+        if okr == 1:
+            solved += 1
+            assert np.array_equal(xr, xd), (trial, n, np.abs(xr - xd).max())
+    assert solved >= 2
+    for trial, m in enumerate([200, 264, 384, 384]):
+        c = int(rng.integers(m // 2, m + 1)); k = c if trial % 2 == 0 else int(rng.integers(c // 2, c))
+        idx = np.sort(rng.choice(m, c, replace=False))
+        U = rng.normal(0, 1, (c, k)); V = rng.normal(0, 1, (c, k))
+        Q = np.zeros((m, m)); Q[np.ix_(idx, idx)] = U @ U.T if trial < 2 else U @ V.T
+        P = np.zeros((m, m))
+        rank = gen128.gshim_pinv(m, _p(np.ascontiguousarray(Q)), c, _p(P))
+        ref = np.linalg.pinv(Q, rcond=1e-11)
+        assert rank == k, (m, c, k, rank)
+        assert np.abs(P - ref).max() <= 1e-9 * m * max(np.abs(ref).max(), 1e-30), (m, c, k)
 
 
 def _contact_problem(rng, trial, R):
