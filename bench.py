@@ -38,8 +38,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # default of FOUR hardware queues per process an idle stream still owns a queue and two of the four slice streams then share one: measured
 # 4.27 against 6.66 M worlds*steps/s per GPU ("Throughput").  Eight queues give every stream its own again.  Read by the HIP
 # runtime when it initialises, i.e. before the first torch.cuda call below; a caller's own setting wins.
-if "WORLD_SIZE" in os.environ:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "WORLD_SIZE" in os.environ and not os.environ.get("GPU_MAX_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
