@@ -442,7 +442,7 @@ def main():
             roof = {"bound": "fp64", "kernel": "whole step (all kernels of one forward + one backward)", "achieved": fp64["achieved_TFs"],
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64["frac"], "traffic": traffic, "fp64": fp64, "hbm": hbm, **common,
                     "note": "fp64-ALU / latency bound (SURVEY.md 8d); peak = fp64 vector peak 78.6 TF (v_fma_f64 measured at 62.5 TF, "
-                            "v_mfma_f64 at 49.0 TF on this chip: profiles/r02c_fp64_rate.jsonl); flop counted by SQ_INSTS_VALU_*_F64"}
+                            "v_mfma_f64 at 49.0 TF on this chip: docs/profiles_history/r02c_fp64_rate.jsonl); flop counted by SQ_INSTS_VALU_*_F64"}
         else:
             roof = {"bound": "hbm", **hbm, "fp64": None, **common,
                     "note": "no fp64 flop count for the kernels built right now (profiles/fp64_flops.json is absent or was counted on other "

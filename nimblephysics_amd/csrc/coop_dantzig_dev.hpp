@@ -30,12 +30,18 @@ DEV void coopPin24(double (&a)[MAXR]) {
 // summed over all worlds.  Compiled out of the shipped library.
 #if defined(NBL_CASCADE_TIMING) && defined(__HIPCC__)
 __device__ unsigned long long g_dzStat[16];
+__device__ unsigned long long g_dzStatSlow[16];   // the same sums over the SLOW solves only (more than NBL_DZ_SLOW cycles: the tail that a launch waits for)
+#ifndef NBL_DZ_SLOW
+#define NBL_DZ_SLOW 300000
+#endif
 #endif
 #if defined(NBL_CASCADE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define DZ_T0() long long dzT = clock64(); long long dzAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define DZ_ADD(k) do { const long long dzN = clock64(); dzAcc[k] += dzN - dzT; dzT = dzN; } while (0)
 #define DZ_CNT(k) do { dzAcc[k] += 1; } while (0)
-#define DZ_FLUSH() do { if (ln == 0) for (int dzK = 0; dzK < 12; dzK++) atomicAdd(&g_dzStat[dzK], (unsigned long long)dzAcc[dzK]); } while (0)
+#define DZ_FLUSH() do { if (ln == 0) { long long dzTot = 0; for (int dzK = 0; dzK < 8; dzK++) dzTot += dzAcc[dzK];                      \
+                                        for (int dzK = 0; dzK < 12; dzK++) atomicAdd(&g_dzStat[dzK], (unsigned long long)dzAcc[dzK]);           \
+                                        if (dzTot > NBL_DZ_SLOW) for (int dzK = 0; dzK < 12; dzK++) atomicAdd(&g_dzStatSlow[dzK], (unsigned long long)dzAcc[dzK]); } } while (0)
 #else
 #define DZ_T0() do { } while (0)
 #define DZ_ADD(k) do { } while (0)
@@ -70,74 +76,82 @@ struct CoopLcpRow {
 // the additions is what makes the result bit-identical to the reference's).  ONE accumulator per lane holds Z before the switch and y
 // after it; which lanes do what at step k is a compile-time lane mask once the block grid is fixed - for dSolveL1 the grid starts at
 // row 0, for dSolveL1T (reversed index) at row nC mod 4 - so a step is broadcast + multiply + two predicated adds under literal EXEC
-// masks: 9-12 instructions instead of the 21-31 the compiler makes of the compare / select form below (which the host emulation and the
-// 48-row build keep).  ym: the lanes that subtract, zm: the lanes that add (before the cut to the rows of the factor: & ncm).
+// masks.  The host emulation and the 48-row build keep the compare / select form below.
+//
+// Round 6 (tools/dbg/lat_probe.hip on MI355X): a wavefront that is alone on its SIMD issues ONE instruction every ~5.5 cycles, whatever
+// the instruction (s_mov, s_nop, v_readlane, v_add_f64 alike; a dependent v_add_f64 10) - what a step costs is its instruction COUNT: 9
+// (pad, two v_readlane, v_mul, mask, v_add, mask, v_add, EXEC back to `all`, the mask the solve was entered with; round 5 also saved
+// EXEC per step and cut the second mask to the rows of the factor - the accumulator of a lane beyond them is never read).  Measured at
+// NO gain over this, each bit-identical on the device: the entries of a lane's own block negated so that ONE addition serves both kinds
+// of row and EXEC is written once per step (the 24 sign flips per solve cost what the second addition and its mask cost); EXEC left
+// narrowed between the statements of a block (the multiplication of the next step needs the lanes of both additions: a third mask).
+// Every statement ends with EXEC = all, so the compiler's own instructions between two statements always see the full mask.
 #if defined(__HIP_DEVICE_COMPILE__)
+constexpr unsigned dzLanes(int from, int to) { return from >= to ? 0u : (unsigned)(((1ull << to) - 1ull) & ~((1ull << from) - 1ull)); }   // lanes [from, to)
 template <unsigned SW>
-DEV void dzSwitchStep(double& acc, double rhs) {          // acc = rhs - acc on the lanes SW
-  unsigned long long sv;
-  asm volatile("s_mov_b64 %[sv], exec\n\t"
-               "s_mov_b64 exec, %[sw]\n\t"
+DEV void dzSwitchStep(double& acc, double rhs, unsigned long long all) {          // acc = rhs - acc on the lanes SW
+  asm volatile("s_mov_b64 exec, %[sw]\n\t"
                "v_add_f64 %[acc], %[rhs], -%[acc]\n\t"
-               "s_mov_b64 exec, %[sv]"
-               : [acc] "+v"(acc), [sv] "=&s"(sv)
-               : [rhs] "v"(rhs), [sw] "n"(SW));
+               "s_mov_b64 exec, %[all]"
+               : [acc] "+v"(acc)
+               : [rhs] "v"(rhs), [sw] "n"(SW), [all] "s"(all));
 }
 template <unsigned YM, unsigned ZM>
-DEV void dzSubstStep(double& acc, double l, double xk, unsigned long long ncm) {
-  unsigned long long sv;
+DEV void dzSubstStep(double& acc, double l, double xk, unsigned long long all) {
   double t;
-  if constexpr (YM != 0u) {
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "v_mul_f64 %[t], %[l], %[xk]\n\t"
+  if constexpr (YM != 0u && ZM != 0u) {
+    asm volatile("v_mul_f64 %[t], %[l], %[xk]\n\t"
                  "s_mov_b64 exec, %[ym]\n\t"
                  "v_add_f64 %[acc], %[acc], -%[t]\n\t"
-                 "s_and_b64 exec, %[ncm], %[zm]\n\t"
+                 "s_mov_b64 exec, %[zm]\n\t"
                  "v_add_f64 %[acc], %[acc], %[t]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [acc] "+v"(acc), [t] "=&v"(t), [sv] "=&s"(sv)
-                 : [l] "v"(l), [xk] "s"(xk), [ncm] "s"(ncm), [ym] "n"(YM), [zm] "n"(ZM)
-                 : "scc");
-  } else {
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "v_mul_f64 %[t], %[l], %[xk]\n\t"
-                 "s_and_b64 exec, %[ncm], %[zm]\n\t"
+                 "s_mov_b64 exec, %[all]"
+                 : [acc] "+v"(acc), [t] "=&v"(t)
+                 : [l] "v"(l), [xk] "s"(xk), [ym] "n"(YM), [zm] "n"(ZM), [all] "s"(all));
+  } else if constexpr (YM != 0u) {
+    asm volatile("v_mul_f64 %[t], %[l], %[xk]\n\t"
+                 "s_mov_b64 exec, %[ym]\n\t"
+                 "v_add_f64 %[acc], %[acc], -%[t]\n\t"
+                 "s_mov_b64 exec, %[all]"
+                 : [acc] "+v"(acc), [t] "=&v"(t)
+                 : [l] "v"(l), [xk] "s"(xk), [ym] "n"(YM), [all] "s"(all));
+  } else if constexpr (ZM != 0u) {
+    asm volatile("v_mul_f64 %[t], %[l], %[xk]\n\t"
+                 "s_mov_b64 exec, %[zm]\n\t"
                  "v_add_f64 %[acc], %[acc], %[t]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [acc] "+v"(acc), [t] "=&v"(t), [sv] "=&s"(sv)
-                 : [l] "v"(l), [xk] "s"(xk), [ncm] "s"(ncm), [zm] "n"(ZM)
-                 : "scc");
+                 "s_mov_b64 exec, %[all]"
+                 : [acc] "+v"(acc), [t] "=&v"(t)
+                 : [l] "v"(l), [xk] "s"(xk), [zm] "n"(ZM), [all] "s"(all));
   }
 }
-constexpr unsigned dzLanes(int from, int to) { return from >= to ? 0u : (unsigned)(((1ull << to) - 1ull) & ~((1ull << from) - 1ull)); }   // lanes [from, to)
 // dSolveL1: the complete 4-blocks (rows below nb4 = nC & ~3), then at most three single rows.  The guards nest - one test per block, and
 // the first block that is not complete ends the walk with the single rows.
 template <int K, class W>
-DEV void dzL1BlockStep(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], unsigned long long ncm) {
-  if constexpr (K % 4 == 0) dzSwitchStep<dzLanes(K, K + 4)>(acc, rhs);
+DEV void dzL1BlockStep(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], unsigned long long all) {
+  if constexpr (K % 4 == 0) dzSwitchStep<dzLanes(K, K + 4)>(acc, rhs, all);
   const double xk = w.bcast(acc, K);
-  dzSubstStep<dzLanes(K + 1, (K | 3) + 1), dzLanes((K | 3) + 1, 32)>(acc, lrow[K], xk, ncm);
+  dzSubstStep<dzLanes(K + 1, (K | 3) + 1), dzLanes((K | 3) + 1, 32)>(acc, lrow[K], xk, all);
 }
 template <int K, class W>
-DEV void dzL1TailStep(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], unsigned long long ncm) {
-  dzSwitchStep<dzLanes(K, K + 1)>(acc, rhs);
+DEV void dzL1TailStep(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], unsigned long long all) {
+  dzSwitchStep<dzLanes(K, K + 1)>(acc, rhs, all);
   const double xk = w.bcast(acc, K);
-  dzSubstStep<0u, dzLanes(K + 1, 32)>(acc, lrow[K], xk, ncm);
+  dzSubstStep<0u, dzLanes(K + 1, 32)>(acc, lrow[K], xk, all);
 }
 template <int J, class W>
-DEV void dzL1Blocks(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], int nC, int nb4, unsigned long long ncm) {
+DEV void dzL1Blocks(const W& w, double& acc, double rhs, const double (&lrow)[MAXR], int nC, int nb4, unsigned long long all) {
   if constexpr (4 * J < MAXR) {
     if (4 * J < nb4) {
-      dzL1BlockStep<4 * J>(w, acc, rhs, lrow, ncm);
-      dzL1BlockStep<4 * J + 1>(w, acc, rhs, lrow, ncm);
-      dzL1BlockStep<4 * J + 2>(w, acc, rhs, lrow, ncm);
-      dzL1BlockStep<4 * J + 3>(w, acc, rhs, lrow, ncm);
-      dzL1Blocks<J + 1>(w, acc, rhs, lrow, nC, nb4, ncm);
+      dzL1BlockStep<4 * J>(w, acc, rhs, lrow, all);
+      dzL1BlockStep<4 * J + 1>(w, acc, rhs, lrow, all);
+      dzL1BlockStep<4 * J + 2>(w, acc, rhs, lrow, all);
+      dzL1BlockStep<4 * J + 3>(w, acc, rhs, lrow, all);
+      dzL1Blocks<J + 1>(w, acc, rhs, lrow, nC, nb4, all);
     } else if (4 * J < nC) {
-      dzL1TailStep<4 * J>(w, acc, rhs, lrow, ncm);
+      dzL1TailStep<4 * J>(w, acc, rhs, lrow, all);
       if (4 * J + 1 < nC) {
-        dzL1TailStep<4 * J + 1>(w, acc, rhs, lrow, ncm);
-        if (4 * J + 2 < nC) dzL1TailStep<4 * J + 2>(w, acc, rhs, lrow, ncm);
+        dzL1TailStep<4 * J + 1>(w, acc, rhs, lrow, all);
+        if (4 * J + 2 < nC) dzL1TailStep<4 * J + 2>(w, acc, rhs, lrow, all);
       }
     }
   }
@@ -145,35 +159,35 @@ DEV void dzL1Blocks(const W& w, double& acc, double rhs, const double (&lrow)[MA
 // dSolveL1T (K runs down), the block grid of the REVERSED index starting at lane RHO = nC mod 4: lanes [RHO + 4j, RHO + 4j + 4) are one
 // block whose first reversed row is its LAST lane; the lanes below RHO are the single rows and come last.
 template <int RHO, int K, class W>
-DEV void dzL1TBlockStep(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], unsigned long long ncm) {
+DEV void dzL1TBlockStep(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], unsigned long long all) {
   constexpr int B0 = RHO + 4 * ((K - RHO) / 4);                    // first lane of K's block
-  if constexpr (K == B0 + 3) dzSwitchStep<dzLanes(B0, B0 + 4)>(acc, rhs);
+  if constexpr (K == B0 + 3) dzSwitchStep<dzLanes(B0, B0 + 4)>(acc, rhs, all);
   const double xk = w.bcast(acc, K);
-  dzSubstStep<dzLanes(B0, K), dzLanes(0, B0)>(acc, lcol[K], xk, ncm);
+  dzSubstStep<dzLanes(B0, K), dzLanes(0, B0)>(acc, lcol[K], xk, all);
 }
 template <int K, class W>
-DEV void dzL1TTailStep(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], unsigned long long ncm) {
-  dzSwitchStep<dzLanes(K, K + 1)>(acc, rhs);
+DEV void dzL1TTailStep(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], unsigned long long all) {
+  dzSwitchStep<dzLanes(K, K + 1)>(acc, rhs, all);
   const double xk = w.bcast(acc, K);
-  dzSubstStep<0u, dzLanes(0, K)>(acc, lcol[K], xk, ncm);
+  dzSubstStep<0u, dzLanes(0, K)>(acc, lcol[K], xk, all);
 }
 // blocks from the top one down: block J covers lanes RHO + 4J .. RHO + 4J + 3 and exists when its last lane is below nC
 template <int RHO, int J, class W>
-DEV void dzL1TBlocks(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], int nC, unsigned long long ncm) {
+DEV void dzL1TBlocks(const W& w, double& acc, double rhs, const double (&lcol)[MAXR], int nC, unsigned long long all) {
   if constexpr (J >= 0) {
     if constexpr (RHO + 4 * J + 3 < MAXR) {
       if (RHO + 4 * J + 3 < nC) {
-        dzL1TBlockStep<RHO, RHO + 4 * J + 3>(w, acc, rhs, lcol, ncm);
-        dzL1TBlockStep<RHO, RHO + 4 * J + 2>(w, acc, rhs, lcol, ncm);
-        dzL1TBlockStep<RHO, RHO + 4 * J + 1>(w, acc, rhs, lcol, ncm);
-        dzL1TBlockStep<RHO, RHO + 4 * J>(w, acc, rhs, lcol, ncm);
+        dzL1TBlockStep<RHO, RHO + 4 * J + 3>(w, acc, rhs, lcol, all);
+        dzL1TBlockStep<RHO, RHO + 4 * J + 2>(w, acc, rhs, lcol, all);
+        dzL1TBlockStep<RHO, RHO + 4 * J + 1>(w, acc, rhs, lcol, all);
+        dzL1TBlockStep<RHO, RHO + 4 * J>(w, acc, rhs, lcol, all);
       }
     }
-    dzL1TBlocks<RHO, J - 1>(w, acc, rhs, lcol, nC, ncm);
+    dzL1TBlocks<RHO, J - 1>(w, acc, rhs, lcol, nC, all);
   } else {
-    if constexpr (RHO >= 3) dzL1TTailStep<2>(w, acc, rhs, lcol, ncm);
-    if constexpr (RHO >= 2) dzL1TTailStep<1>(w, acc, rhs, lcol, ncm);
-    if constexpr (RHO >= 1) dzL1TTailStep<0>(w, acc, rhs, lcol, ncm);
+    if constexpr (RHO >= 3) dzL1TTailStep<2>(w, acc, rhs, lcol, all);
+    if constexpr (RHO >= 2) dzL1TTailStep<1>(w, acc, rhs, lcol, all);
+    if constexpr (RHO >= 1) dzL1TTailStep<0>(w, acc, rhs, lcol, all);
   }
 }
 #endif
@@ -226,14 +240,17 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
   // (lcp.cpp:487-498).  The swaps are played on the index vectors only (p[j] = the row that ends at position j); the matrix is
   // symmetrised from its lower triangle (lcp.cpp:138-140) and permuted in ONE pass, the row data follows with one shuffle each.
   {
+    // which position holds a friction row when the scan reaches it is known up front: a swap touches position k only at step k
+    const uint64_t fricBits = w.ballot(on && fidx >= 0);
     int atEnd = 0;
     for (int k = n - 1; k >= 0; k--) {
-      const int fk = w.bcastI(fidx, k);
-      if (fk >= 0) {
+      if ((fricBits >> k) & 1ull) {
         const int i2 = n - 1 - atEnd;
-        if (k != i2) {
-          const int src = ln == k ? i2 : (ln == i2 ? k : ln);
-          p = w.shflI(p, src); fidx = w.shflI(fidx, src);
+        if (k != i2) {       // lanes k and i2 trade p and findex: both lanes are wave-uniform, so four v_readlane and selects, no LDS round trip
+          const int pk = w.bcastI(p, k), pi = w.bcastI(p, i2), fk = w.bcastI(fidx, k), f2 = w.bcastI(fidx, i2);
+          const bool isK = ln == k, isI2 = ln == i2;
+          p = isK ? pi : (isI2 ? pk : p);
+          fidx = isK ? f2 : (isI2 ? fk : fidx);
         }
         atEnd++;
       }
@@ -247,21 +264,38 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
       col[r] = (on && r < n) ? av : 0.0;
     }
     w.sync();
+    // (one EXEC region for the 24 stores - a guard per row compiled to a branch per store; rows and columns beyond n get zeros, nobody reads them)
+    if (ln < MAXR) {
 #pragma unroll
-    for (int r = 0; r < MAXR; r++) if (on && r < n) C.A[r * CLD + ln] = col[r];
+      for (int r = 0; r < MAXR; r++) C.A[r * CLD + ln] = col[r];
+    }
     b = w.shfl(b, p); lo = w.shfl(lo, p); hi = w.shfl(hi, p);
     w.sync();
   }
-  // dDot over lanes [from, to): the running sum from 0 in lane order (fastdot.cpp); every lane gets the result.  The products
-  // go through LDS, already masked to their range by the lane that owns them (a term outside its range enters as +0.0, which
-  // leaves the sum unchanged bit for bit): broadcast reads issued together and two chains of adds with no branch or select.
+  // dDot over lanes [from, to): the running sum from +0.0 in lane order (fastdot.cpp); every lane gets the result.  The term of lane k
+  // comes through v_readlane (k is wave-uniform: an SGPR lane select) straight into the scalar operand of the addition - no LDS round
+  // trip (round 5: the products went through two LDS vectors, masked to their ranges, and every lane read all of them back: two waits of
+  // an LDS latency per sum and 2 x 24 additions; 1330 cycles per w[i]).  Lanes outside [from, to) are never read, which is what adding
+  // their +0.0 was: a running sum that starts at +0.0 is never -0.0, so leaving a +0.0 term out changes no bit.  Rolled loops, four terms
+  // per trip: the eight readlanes of a trip do not depend on the sum and are issued ahead of the chain of dependent additions.
+  auto seqRange = [&](double prod, int from, int to) -> double {
+    double s = 0.0;
+    int k = from;
+#pragma unroll 1
+    for (; k + 4 <= to; k += 4) {
+      const double t0 = w.bcast(prod, k), t1 = w.bcast(prod, k + 1), t2 = w.bcast(prod, k + 2), t3 = w.bcast(prod, k + 3);
+      s = s + t0; s = s + t1; s = s + t2; s = s + t3;
+    }
+#pragma unroll 1
+    for (; k < to; k++) s = s + w.bcast(prod, k);
+    return s;
+  };
   // seqSum2: s1 = sum over [0, mid), s2 = sum over [mid, to).
+#ifdef NBL_SEQSUM_LDS      // A/B switch (developer): round 5's form - the products through two LDS vectors, two interleaved chains of additions
   auto seqSum2 = [&](double prod, int mid, int to, double& s1, double& s2) {
     w.sync();
     if (ln < MAXR) { C.v[2][ln] = ln < mid ? prod : 0.0; C.v[3][ln] = (ln >= mid && ln < to) ? prod : 0.0; }
     w.sync();
-    // (terms at and beyond `to` are +0.0 in both vectors, and a running sum that starts at +0.0 is never -0.0: leaving their additions out
-    //  changes no bit - and the two chains of dependent additions are what this costs; one guard per four terms)
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
     for (int k4 = 0; k4 < MAXR; k4 += 4) {
@@ -271,11 +305,17 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
       }
     }
   };
-  auto seqSum = [&](double prod, int from, int to) -> double {   // from == 0 at every call site
-    double s1, s2;
-    seqSum2(prod, to, to, s1, s2);
-    return s1;
+#else
+  auto seqSum2 = [&](double prod, int mid, int to, double& s1, double& s2) {
+    s1 = seqRange(prod, 0, mid);
+    s2 = seqRange(prod, mid, to);
   };
+#endif
+#ifdef NBL_SEQSUM_LDS
+  auto seqSum = [&](double prod, int from, int to) -> double { double s1, s2; seqSum2(prod, to, to, s1, s2); return s1; };
+#else
+  auto seqSum = [&](double prod, int from, int to) -> double { return seqRange(prod, from, to); };
+#endif
   // dSolveL1 (fastlsolve.cpp): L y = rhs over the factor rows, lane = row.  Step k: y_k (final on lane k) is broadcast, every lane forms
   // its product with column k of its row UNCONDITIONALLY and only the one-instruction updates are predicated - written any other way
   // the compiler sinks the LDS loads of the factor into the divergent branches (an LDS round trip per step: 250 cycles instead of 40).
@@ -290,8 +330,8 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (MAXR <= 32) {
       double acc = 0.0;
-      const unsigned long long ncm = (1ull << nC) - 1ull;
-      dzL1Blocks<0>(w, acc, rhs, lrow, nC, nb4, ncm);
+      const unsigned long long all = __builtin_amdgcn_read_exec();
+      dzL1Blocks<0>(w, acc, rhs, lrow, nC, nb4, all);
       return ln < nC ? acc : rhs;
     }
 #endif
@@ -321,13 +361,13 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (MAXR <= 32) {
       double acc = 0.0;
-      const unsigned long long ncm = (1ull << nC) - 1ull;
+      const unsigned long long all = __builtin_amdgcn_read_exec();
       const int rho = nC & 3;
       constexpr int JTOP = MAXR / 4 - 1;
-      if (rho == 0) dzL1TBlocks<0, JTOP>(w, acc, rhs, lcol, nC, ncm);
-      else if (rho == 1) dzL1TBlocks<1, JTOP>(w, acc, rhs, lcol, nC, ncm);
-      else if (rho == 2) dzL1TBlocks<2, JTOP>(w, acc, rhs, lcol, nC, ncm);
-      else dzL1TBlocks<3, JTOP>(w, acc, rhs, lcol, nC, ncm);
+      if (rho == 0) dzL1TBlocks<0, JTOP>(w, acc, rhs, lcol, nC, all);
+      else if (rho == 1) dzL1TBlocks<1, JTOP>(w, acc, rhs, lcol, nC, all);
+      else if (rho == 2) dzL1TBlocks<2, JTOP>(w, acc, rhs, lcol, nC, all);
+      else dzL1TBlocks<3, JTOP>(w, acc, rhs, lcol, nC, all);
       return ln < nC ? acc : rhs;
     }
 #endif
@@ -519,22 +559,35 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         solve1(i, dir);
         DZ_ADD(2);   // solve1
         // dw(N) = A(N,C) dx(C) +/- A(i,N);  dw[i] = A(i,C) dx(C) + A(i,i) dirf   (lcp.cpp:926-928)
+        // The running sum of a row takes its terms in blocks of four behind ONE guard (a guard per term was a compare, a branch and a
+        // wait per term: 10 instructions for one multiplication and one addition).  dx is taken as +0.0 beyond C, so the terms of the
+        // last block that lie beyond C are +-0.0, and a running sum that starts at +0.0 is never -0.0: adding them changes no bit.
         {
           double arow[MAXR];
 #pragma unroll
           for (int j = 0; j < MAXR; j++) arow[j] = C.A[me * CLD + j];
+          const double ai = C.A[me * CLD + i];
+          coopPin24(arow);
+          const double dxz = ln < nC ? dx : 0.0;
           double s = 0.0;
 #pragma unroll
-          for (int j = 0; j < MAXR; j++) { if (j < nC) { const double pr = arow[j] * w.bcast(dx, j); s = s + pr; } }   // guard, not break: arow[] stays in registers
+          for (int j4 = 0; j4 < MAXR; j4 += 4) {
+            if (j4 < nC) {
+              const double x0 = w.bcast(dxz, j4), x1 = w.bcast(dxz, j4 + 1), x2 = w.bcast(dxz, j4 + 2), x3 = w.bcast(dxz, j4 + 3);
+              const double p0 = arow[j4] * x0, p1 = arow[j4 + 1] * x1, p2 = arow[j4 + 2] * x2, p3 = arow[j4 + 3] * x3;
+              s = s + p0; s = s + p1; s = s + p2; s = s + p3;
+            }
+          }
           const bool inN = ln >= nC && ln < nC + nN;
-          const double ai = C.A[me * CLD + i];
           if (inN) dw = dir > 0 ? s + ai : s - ai;
           if (ln == i) dw = s + ai * dirf;
         }
         // step length: first minimum in the reference's scan order (i's own events, N rows, C rows)
         DZ_ADD(3);   // dw
         // every lane's candidate is one quotient (lcp.cpp:938-998): -w / dw for the driving row and the N rows, (lo - x) / dx or
-        // (hi - x) / dx for the C rows - formed with ONE division for the whole wave (the same operands, so the same bits)
+        // (hi - x) / dx for the C rows - formed with ONE division for the whole wave (the same operands, so the same bits).  (Which
+        // event a lane stands for stays a nest of ifs: written as a chain of selects it measured 170 cycles per iteration SLOWER - the
+        // EXEC regions skip what the selects compute for every lane.)
         const bool inN = ln >= nC && ln < nC + nN, inC = ln < nC, isI = ln == i;
         const bool dn = dx < 0;
         const double num = (isI || inN) ? -ww : ((dn ? lo : hi) - x);
@@ -556,7 +609,7 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         // i's value: arg-min over (s, scan position)
         const double sOwn = w.bcast(s, i);
         if (sOwn != sOwn) { row.x = 0.0; DZ_FLUSH(); return -1; }
-        const double sMin = -w.maxAll(cmd != 0 ? -s : -INFINITY);
+        const double sMin = w.template minRows<MAXR>(cmd != 0 ? s : INFINITY);
         const uint64_t tie = w.ballot(cmd != 0 && s == sMin);
         if (tie == 0ull) { row.x = 0.0; DZ_FLUSH(); return -1; }
         // first of the ties in scan order: lane i, then the N lanes by position, then the C lanes by position
@@ -594,7 +647,8 @@ DEV int coopDantzig(const W& w, CascadeLds& C, int n, CoopLcpRow& row) {
         if (cmdB >= 5) dzRemovals++;
         if (cmdB == 4) dzTransfers++;
 #endif
-        DZ_ADD(5);   // apply + transfer
+        if (cmdB >= 5) DZ_ADD(7);   // apply + a row leaving C (dLDLTRemove)
+        else DZ_ADD(5);             // apply + a row entering C / N
         if (cmdB <= 3) break;
       }
     }
@@ -734,100 +788,107 @@ DEV int coopLcpRemoveFriction(const W& w, LDS& C, int n, CoopLcpRow& row, int& m
 //     0 exactly like the reference's "x[i] = 0; continue";
 //   * xf follows the normal row through the broadcast change, and only after NORMAL rows (a wave-uniform bit test);
 //   * the sweep is instantiated for MAXR / 3, 2 MAXR / 3 or MAXR rows (24-row build: 8, 16, 24; the frictionless stage has 8).
-// One row step = two hand-scheduled blocks around the broadcast.  In C++ the step compiled to 42-86 instructions (lane masks
-// hoisted and spilled to VGPR lanes, boolean bookkeeping in 64-bit scalar masks, selects instead of the uniform skip); written
-// out it is 18 (first sweep) / 21 instructions.  Both blocks run in wave-uniform control flow and restore EXEC themselves.
-//   pgsOwnRow<I>:    on lane I only:  xi = min(max(x + r, cL xf), cH xf);  d = xi - x;  bad |= test(d, xi);  x = xi
-//   pgsFollowRow<I>: on the lanes whose findex is I:  xf += ds   (ds = d of lane I, wave-uniform)
+// One row step = two hand-scheduled blocks around the broadcast (the two v_readlane of the change stay with the compiler: an asm
+// operand cannot name the halves of a register pair).  Round 5's step was 27 instructions; this one is 17 (13 in a problem without
+// friction rows):
+//   * EXEC is not saved and restored around every block: the sweeps run in wave-uniform control flow, `all` (the EXEC mask on entry,
+//     one SGPR pair for the whole solve) is put back where a block ends - v_readlane ignores EXEC;
+//   * the convergence test of a row (5 instructions) is not part of its step: lane i keeps the change d_i of ITS row - its step runs under
+//     EXEC = lane i, so the write lands in that lane only - and x_i is not touched again before the sweep ends, so ONE vector test after
+//     the sweep judges all rows with the operands the reference's per-row test sees (pgsSweepBad);
+//   * NOFRIC (stage 3: no friction row): every row has xf = 1, so lo = cL * 1 and hi = cH * 1 are cL and cH themselves (exact) and no
+//     row follows another: no products, no follow step.
+//   pgsOwnRow<I>:    on lane I only:  xi = min(max(x + r, cL xf), cH xf);  d = xi - x;  x = xi
+//   pgsFollowRow<I>: on the lanes whose findex is I:  xf += ds  (ds = d of lane I, wave-uniform);  then on all lanes  r -= a'_I ds
 #if defined(__HIP_DEVICE_COMPILE__)
-#define NBL_PGS_OWN_FIRST                         \
-        "s_mov_b64 %[sv], exec\n\t"                 \
-        "s_mov_b64 exec, %[lane]\n\t"               \
-        "v_add_f64 %[t0], %[x], %[r]\n\t"           \
-        "v_mul_f64 %[d], %[cL], %[xf]\n\t"          \
-        "v_max_f64 %[t0], %[t0], %[d]\n\t"          \
-        "v_mul_f64 %[d], %[cH], %[xf]\n\t"          \
-        "v_min_f64 %[t0], %[t0], %[d]\n\t"          \
-        "v_add_f64 %[d], %[t0], -%[x]\n\t"          \
-        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[thr]\n\t"  \
-        "s_or_b64 %[bad], %[bad], vcc\n\t"          \
-        "v_mov_b64 %[x], %[t0]\n\t"                 \
-        "s_mov_b64 exec, %[sv]"
-#define NBL_PGS_OWN_LATER                         \
-        "s_mov_b64 %[sv], exec\n\t"                 \
-        "s_mov_b64 exec, %[lane]\n\t"               \
-        "v_add_f64 %[t0], %[x], %[r]\n\t"           \
-        "v_mul_f64 %[d], %[cL], %[xf]\n\t"          \
-        "v_max_f64 %[t0], %[t0], %[d]\n\t"          \
-        "v_mul_f64 %[d], %[cH], %[xf]\n\t"          \
-        "v_min_f64 %[t0], %[t0], %[d]\n\t"          \
-        "v_add_f64 %[d], %[t0], -%[x]\n\t"          \
-        "v_mul_f64 %[t2], |%[t0]|, %[rel]\n\t"      \
-        "v_cmp_gt_f64_e64 %[sc], |%[t0]|, %[eps]\n\t" \
-        "v_cmp_gt_f64_e64 vcc, |%[d]|, %[t2]\n\t"   \
-        "s_and_b64 vcc, vcc, %[sc]\n\t"             \
-        "s_or_b64 %[bad], %[bad], vcc\n\t"          \
-        "v_mov_b64 %[x], %[t0]\n\t"                 \
-        "s_mov_b64 exec, %[sv]"
+#define NBL_PGS_OWN_NOFRIC                        \
+        "s_mov_b64 exec, %[lane]\n\t"             \
+        "v_add_f64 %[t0], %[x], %[r]\n\t"         \
+        "v_max_f64 %[t0], %[t0], %[cL]\n\t"       \
+        "v_min_f64 %[t0], %[t0], %[cH]\n\t"       \
+        "v_add_f64 %[d], %[t0], -%[x]\n\t"        \
+        "v_mov_b64 %[x], %[t0]\n\t"               \
+        "s_mov_b64 exec, %[all]"
+#define NBL_PGS_OWN_FRIC                          \
+        "s_mov_b64 exec, %[lane]\n\t"             \
+        "v_add_f64 %[t0], %[x], %[r]\n\t"         \
+        "v_mul_f64 %[t1], %[cL], %[xf]\n\t"       \
+        "v_max_f64 %[t0], %[t0], %[t1]\n\t"       \
+        "v_mul_f64 %[t1], %[cH], %[xf]\n\t"       \
+        "v_min_f64 %[t0], %[t0], %[t1]\n\t"       \
+        "v_add_f64 %[d], %[t0], -%[x]\n\t"        \
+        "v_mov_b64 %[x], %[t0]\n\t"               \
+        "s_mov_b64 exec, %[all]"
 // (the lane mask of row I: an inline constant for rows < 32; rows 32 .. 47 of the 16-contact build take it from an SGPR pair)
-template <int I, bool FIRST>
-DEV double pgsOwnRow(double& x, double r, double xf, double cL, double cH, double thrFirst, double relTol, double epsDiv,
-                     unsigned long long& bad) {
-  double d, t0, t2;
-  unsigned long long sv, sc;
+template <int I, bool NOFRIC>
+DEV void pgsOwnRow(double& x, double r, double xf, double cL, double cH, double& d, unsigned long long all) {
+  double t0, t1;
   if constexpr (I < 32) {
-    if (FIRST) {
-      asm volatile(NBL_PGS_OWN_FIRST
-          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [sv] "=&s"(sv)
-          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [thr] "v"(thrFirst), [lane] "n"(1u << (I & 31))
-          : "vcc", "scc");
-    } else {
-      asm volatile(NBL_PGS_OWN_LATER
-          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [t2] "=&v"(t2), [sv] "=&s"(sv), [sc] "=&s"(sc)
-          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [rel] "v"(relTol), [eps] "v"(epsDiv), [lane] "n"(1u << (I & 31))
-          : "vcc", "scc");
-    }
+    if constexpr (NOFRIC)
+      asm volatile(NBL_PGS_OWN_NOFRIC : [x] "+v"(x), [d] "+v"(d), [t0] "=&v"(t0)
+                   : [r] "v"(r), [cL] "v"(cL), [cH] "v"(cH), [lane] "n"(1u << (I & 31)), [all] "s"(all));
+    else
+      asm volatile(NBL_PGS_OWN_FRIC : [x] "+v"(x), [d] "+v"(d), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                   : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [lane] "n"(1u << (I & 31)), [all] "s"(all));
   } else {
     const unsigned long long laneMask = 1ull << I;
-    if (FIRST) {
-      asm volatile(NBL_PGS_OWN_FIRST
-          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [sv] "=&s"(sv)
-          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [thr] "v"(thrFirst), [lane] "s"(laneMask)
-          : "vcc", "scc");
-    } else {
-      asm volatile(NBL_PGS_OWN_LATER
-          : [x] "+v"(x), [bad] "+s"(bad), [d] "=&v"(d), [t0] "=&v"(t0), [t2] "=&v"(t2), [sv] "=&s"(sv), [sc] "=&s"(sc)
-          : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [rel] "v"(relTol), [eps] "v"(epsDiv), [lane] "s"(laneMask)
-          : "vcc", "scc");
-    }
+    if constexpr (NOFRIC)
+      asm volatile(NBL_PGS_OWN_NOFRIC : [x] "+v"(x), [d] "+v"(d), [t0] "=&v"(t0)
+                   : [r] "v"(r), [cL] "v"(cL), [cH] "v"(cH), [lane] "s"(laneMask), [all] "s"(all));
+    else
+      asm volatile(NBL_PGS_OWN_FRIC : [x] "+v"(x), [d] "+v"(d), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                   : [r] "v"(r), [xf] "v"(xf), [cL] "v"(cL), [cH] "v"(cH), [lane] "s"(laneMask), [all] "s"(all));
   }
-  return d;   // defined on lane I only
 }
+// (ds comes from two v_readlane just ahead of the statement: a VALU read of an SGPR a VALU wrote needs two wait states - v_cmpx, which
+//  does not read it, is one of them)
 template <int I>
-DEV void pgsFollowRow(double& xf, int fi, double ds) {
-  unsigned long long sv;
-  asm volatile(
-      "s_mov_b64 %[sv], exec\n\t"
-      "v_cmpx_eq_u32_e32 vcc, %[row], %[fi]\n\t"
-      "v_add_f64 %[xf], %[xf], %[ds]\n\t"
-      "s_mov_b64 exec, %[sv]"
-      : [xf] "+v"(xf), [sv] "=&s"(sv)
-      : [fi] "v"(fi), [ds] "s"(ds), [row] "n"(I)
-      : "vcc");
+DEV void pgsFollowRow(double& xf, double& r, int fi, double ds, double narowI, unsigned long long all) {
+  asm volatile("v_cmpx_eq_u32_e32 vcc, %[row], %[fi]\n\t"
+               "s_nop 0\n\t"
+               "v_add_f64 %[xf], %[xf], %[ds]\n\t"
+               "s_mov_b64 exec, %[all]\n\t"
+               "v_fmac_f64_e32 %[r], %[ds], %[na]"
+               : [xf] "+v"(xf), [r] "+v"(r)
+               : [fi] "v"(fi), [ds] "s"(ds), [na] "v"(narowI), [row] "n"(I), [all] "s"(all)
+               : "vcc");
+}
+// the reference's per-row convergence test on all rows at once: FIRST sweep |d| > thr, later |x| > eps and |d| > rel |x|
+template <bool FIRST>
+DEV bool pgsSweepBad(double x, double d, double thrFirst, double relTol, double epsDiv) {
+  unsigned long long bad;
+  if constexpr (FIRST) {
+    asm volatile("v_cmp_gt_f64_e64 %[bad], |%[d]|, %[thr]" : [bad] "=s"(bad) : [d] "v"(d), [thr] "v"(thrFirst));
+  } else {
+    double t2;
+    unsigned long long sc;
+    asm volatile("v_mul_f64 %[t2], |%[x]|, %[rel]\n\t"
+                 "v_cmp_gt_f64_e64 %[sc], |%[x]|, %[eps]\n\t"
+                 "v_cmp_gt_f64_e64 %[bad], |%[d]|, %[t2]\n\t"
+                 "s_and_b64 %[bad], %[bad], %[sc]"
+                 : [bad] "=&s"(bad), [sc] "=&s"(sc), [t2] "=&v"(t2)
+                 : [x] "v"(x), [d] "v"(d), [rel] "v"(relTol), [eps] "v"(epsDiv)
+                 : "scc");
+  }
+  return bad != 0ull;
 }
 #else
-template <int I, bool FIRST>
-DEV double pgsOwnRow(double& x, double r, double xf, double cL, double cH, double thrFirst, double relTol, double epsDiv,
-                     unsigned long long& bad) {
-  // host statement of the same step (wave emulation: `bad` is this lane's own flag, the caller ballots it)
-  const double xi = fmin(fmax(x + r, cL * xf), cH * xf);
-  const double d = xi - x;
-  if (FIRST ? fabs(d) > thrFirst : (fabs(xi) > epsDiv && fabs(d) > relTol * fabs(xi))) bad |= 1ull;
+// host statements of the same steps (wave emulation: a thread per lane, the caller guards pgsOwnRow by the lane and ballots pgsSweepBad)
+template <int I, bool NOFRIC>
+DEV void pgsOwnRow(double& x, double r, double xf, double cL, double cH, double& d, unsigned long long) {
+  const double xi = NOFRIC ? fmin(fmax(x + r, cL), cH) : fmin(fmax(x + r, cL * xf), cH * xf);
+  d = xi - x;
   x = xi;
-  return d;
 }
 template <int I>
-DEV void pgsFollowRow(double& xf, int fi, double ds) { if (fi == I) xf += ds; }
+DEV void pgsFollowRow(double& xf, double& r, int fi, double ds, double narowI, unsigned long long) {
+  if (fi == I) xf += ds;
+  r = fma(narowI, ds, r);
+}
+template <bool FIRST>
+DEV bool pgsSweepBad(double x, double d, double thrFirst, double relTol, double epsDiv) {
+  return FIRST ? fabs(d) > thrFirst : (fabs(x) > epsDiv && fabs(d) > relTol * fabs(x));
+}
 #endif
 
 // rowStep(IntTag<I0>{}, tag); ... rowStep(IntTag<I1 - 1>{}, tag);   (a compile-time unrolled row loop: the row index is an instruction operand)
@@ -839,74 +900,85 @@ DEV void pgsRowRange(F& rowStep, T tag) {
   }
 }
 
-template <class W, class LDS>
+// NOFRIC: the caller knows that no row has a friction index (stage 3)
+template <bool NOFRIC = false, class W, class LDS>
 DEV bool coopPgs(const W& w, LDS& C, int n, CoopLcpRow& row) {
   const int maxIteration = 30;
   const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
   const int ln = w.lane();
   const bool on = ln < n;
   const int me = on ? ln : 0;
-  double arow[MAXR];
+  double narow[MAXR];       // MINUS this lane's row of A scaled by 1 / a_ii (the sign is exact, and the residual update wants it)
 #pragma unroll
-  for (int j = 0; j < MAXR; j++) { const double av = C.A[me * CLD + j]; arow[j] = (on && j < n) ? av : 0.0; }
+  for (int j = 0; j < MAXR; j++) { const double av = C.A[me * CLD + j]; narow[j] = (on && j < n) ? av : 0.0; }
   const double aii = on ? C.A[me * CLD + me] : 1.0;
   const bool inOrder = on && !(aii < epsDiv);          // rows with a_ii ~ 0 are set to 0 once and then left alone
   const double sc = inOrder ? 1.0 / aii : 1.0;
+  const double nsc = -sc;
 #pragma unroll
-  for (int j = 0; j < MAXR; j++) arow[j] *= sc;
+  for (int j = 0; j < MAXR; j++) narow[j] *= nsc;
   double x = on ? row.x : 0.0;
   double r0 = row.b * sc, r1 = 0.0;
 #pragma unroll
   for (int j = 0; j < MAXR; j += 2) {
-    r0 = fma(-arow[j], j < n ? w.bcast(x, j) : 0.0, r0);
-    r1 = fma(-arow[j + 1], j + 1 < n ? w.bcast(x, j + 1) : 0.0, r1);
+    r0 = fma(narow[j], j < n ? w.bcast(x, j) : 0.0, r0);
+    r1 = fma(narow[j + 1], j + 1 < n ? w.bcast(x, j + 1) : 0.0, r1);
   }
   double r = r0 + r1;
   const int fi = on ? row.findex : -1;
   const bool fric = fi >= 0;
   const double cH = !inOrder ? 0.0 : row.hi, cL = !inOrder ? 0.0 : (fric ? -row.hi : row.lo);
-  const double xNormal = w.shfl(x, fric ? fi : 0);
-  double xf = fric ? xNormal : 1.0;
+  double xf = 1.0;
+  if constexpr (!NOFRIC) {
+    const double xNormal = w.shfl(x, fric ? fi : 0);
+    xf = fric ? xNormal : 1.0;
+  }
   const double thrFirst = inOrder ? dxTh : INFINITY;
-  // bad: on the device a 64-bit lane mask in SGPRs (bit i set by row i's own step), on the host emulation this lane's flag
-  unsigned long long bad = 0ull;
-  const double relTolV = relTol, epsDivV = epsDiv;
-  auto rowStep = [&](auto iTag, auto firstTag) {
-    constexpr int i = decltype(iTag)::value;
-    constexpr bool first = decltype(firstTag)::value != 0;
+  double d = 0.0;           // lane i: the change of row i in the sweep that is running (rows the sweep does not step keep 0 and x = 0)
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double d = pgsOwnRow<i, first>(x, r, xf, cL, cH, thrFirst, relTolV, epsDivV, bad);
+  const unsigned long long all = __builtin_amdgcn_read_exec();
 #else
-    double d = 0.0;
-    if (ln == i) d = pgsOwnRow<i, first>(x, r, xf, cL, cH, thrFirst, relTolV, epsDivV, bad);
+  const unsigned long long all = 0ull;
+#endif
+  auto rowStep = [&](auto iTag, auto) {
+    constexpr int i = decltype(iTag)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    pgsOwnRow<i, NOFRIC>(x, r, xf, cL, cH, d, all);
+#else
+    if (ln == i) pgsOwnRow<i, NOFRIC>(x, r, xf, cL, cH, d, all);
 #endif
     const double ds = w.bcast(d, i);
-    r = fma(-arow[i], ds, r);
-    pgsFollowRow<i>(xf, fi, ds);
+    if constexpr (NOFRIC) r = fma(narow[i], ds, r);
+    else pgsFollowRow<i>(xf, r, fi, ds, narow[i], all);
   };
-  auto sweep = [&](auto nTag, auto firstTag) {
+  auto sweep = [&](auto nTag) {
     constexpr int NR = decltype(nTag)::value;
-    pgsRowRange<0, NR>(rowStep, firstTag);       // rowStep(IntTag<0>{}, firstTag); ... rowStep(IntTag<NR - 1>{}, firstTag);
+    pgsRowRange<0, NR>(rowStep, IntTag<0>{});       // rowStep(IntTag<0>{}, .); ... rowStep(IntTag<NR - 1>{}, .);
   };
+  // "no row moved by more than the tolerance": the device's test is already a lane mask, the host emulation ballots its lanes' flags
+  auto noneBad = [&](auto firstTag) -> bool {
+    constexpr bool first = decltype(firstTag)::value != 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-  auto noneBad = [&]() -> bool { return bad == 0ull; };                 // "no row moved by more than the tolerance"
+    return !pgsSweepBad<first>(x, d, thrFirst, relTol, epsDiv);
 #else
-  auto noneBad = [&]() -> bool { return w.ballot(bad != 0ull) == 0ull; };
+    return w.ballot(pgsSweepBad<first>(x, d, thrFirst, relTol, epsDiv)) == 0ull;
 #endif
+  };
   auto solve = [&](auto nTag) -> bool {
-    sweep(nTag, IntTag<1>{});
-    if (noneBad()) return true;
+    sweep(nTag);
+    if (noneBad(IntTag<1>{})) return true;
     bool done = false;
 #pragma unroll 1
     for (int iter = 1; iter < maxIteration; ++iter) {
-      bad = 0ull;
-      sweep(nTag, IntTag<0>{});
-      if (noneBad()) { done = true; break; }
+      sweep(nTag);
+      if (noneBad(IntTag<0>{})) { done = true; break; }
     }
     return done;
   };
-  // (the sweep is instantiated for a third, two thirds and all of the rows)
-  const bool done = n <= MAXR / 3 ? solve(IntTag<MAXR / 3>{}) : (n <= 2 * MAXR / 3 ? solve(IntTag<2 * MAXR / 3>{}) : solve(IntTag<MAXR>{}));
+  // (the sweep is instantiated for a third, two thirds and all of the rows; without friction rows there is at most a third)
+  bool done;
+  if constexpr (NOFRIC) done = solve(IntTag<MAXR / 3>{});
+  else done = n <= MAXR / 3 ? solve(IntTag<MAXR / 3>{}) : (n <= 2 * MAXR / 3 ? solve(IntTag<2 * MAXR / 3>{}) : solve(IntTag<MAXR>{}));
   row.x = x;
   return done;
 }
@@ -1011,7 +1083,7 @@ DEV void coopCascadeStage3(const W& w, LDS& C, const CoopRow& R, double X0, doub
   coopLoadProblem(w, C, R, cfm, X0, row, mapTo, n0);
   const int nr = coopLcpRemoveFriction(w, C, n0, row, mapTo);
   row.x = 0.0;
-  const bool ok3 = coopPgs(w, C, nr, row);
+  const bool ok3 = coopPgs<true>(w, C, nr, row);    // (nr <= MAX_CONTACTS rows, none with a friction index)
   out.X = coopMapOut(w, C, R.m, mapTo, row.x, nr);
   out.flags = ok3 ? CS_SOLVED : 0;
 }

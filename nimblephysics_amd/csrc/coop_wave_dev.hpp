@@ -31,6 +31,31 @@ struct DevWave {
 #undef NBL_DPP_MAX_STEP
     return fmax(fmax(bcast(v, 15), bcast(v, 31)), fmax(bcast(v, 47), bcast(v, 63)));
   }
+  // min over the lanes that can hold a row (lanes >= ROWS must hold +inf or a NaN; NaNs lose, like in maxAll's fmax).  Builds of at most 32
+  // rows: two DPP rows instead of four, and v_min_f64 itself - fmin() makes the compiler quiet both operands first (a v_max_f64 v, v, v
+  // each: the reduction was 40 instructions, it is 19).
+  template <int ROWS>
+  DEV double minRows(double v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (ROWS <= 32) {
+#define NBL_DPP_MIN_STEP(CTRL)                                                                             \
+      {                                                                                                    \
+        const int lo = __double2loint(v), hi = __double2hiint(v);                                          \
+        const int tlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);                        \
+        const int thi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);                        \
+        const double t = __hiloint2double(thi, tlo);                                                       \
+        asm("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(t));                                            \
+      }
+      NBL_DPP_MIN_STEP(0x111) NBL_DPP_MIN_STEP(0x112) NBL_DPP_MIN_STEP(0x114) NBL_DPP_MIN_STEP(0x118)
+#undef NBL_DPP_MIN_STEP
+      const double a = bcast(v, 15), b = bcast(v, 31);
+      double r;
+      asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      return r;
+    }
+#endif
+    return -maxAll(-v);
+  }
   DEV uint64_t ballot(bool p) const { return (uint64_t)__ballot(p ? 1 : 0); }
   DEV double shfl(double v, int src) const { return __shfl(v, src & 63); }
   DEV int shflI(int v, int src) const { return __shfl(v, src & 63); }

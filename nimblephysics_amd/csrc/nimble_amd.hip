@@ -756,7 +756,9 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
       if (!fusedDetect) {
         // lanes per world of the narrow phase: the collider pairs of a world side by side (k_contact_detect)
         const int ppw = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
-        const int wl = std::min(tl, 64 / ppw);                       // worlds per workgroup
+        // worlds per workgroup: its threads (wl * ppw) index the kernel's static LDS slices, whose lane stride is DETECT_LS (16 in the
+        // general builds: their 128 remembered points per world do not fit 64 lanes' worth of LDS)
+        const int wl = std::max(1, std::min(tl, DETECT_LS / ppw));
         const size_t stageBytes = ppw > 1 ? (size_t)wl * (ppw - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wl * (ppw - 1) * sizeof(int) : 0;
         TIMED(K_DETECT, hipLaunchKernelGGL(k_contact_detect, dim3((unsigned)((cnt + wl - 1) / wl)), dim3(wl * ppw), stageBytes, s, mdl, m->dBodies,
                                            m->dContact, B, (double*)saved, m->lay, status, (double*)workspace, m->coopTree ? 0 : 1,
@@ -1230,7 +1232,13 @@ int32_t nbl_debug_dantzig_stats(unsigned long long* out16, int32_t reset) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dzStat), sizeof(unsigned long long) * 16));   // (out16: 24 entries, the last 8 = g_pinvStat)
   HIP_TRY(hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(g_pinvStat), sizeof(unsigned long long) * 8));
-  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dzStat), z, sizeof(z))); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pinvStat), z, sizeof(unsigned long long) * 8)); }
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dzStat), z, sizeof(z))); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pinvStat), z, sizeof(unsigned long long) * 8));
+               HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dzStatSlow), z, sizeof(z))); }
+  return NBL_OK;
+}
+int32_t nbl_debug_dantzig_stats_slow(unsigned long long* out16) {   // the same sums over the solves of more than NBL_DZ_SLOW cycles
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dzStatSlow), sizeof(unsigned long long) * 16));
   return NBL_OK;
 }
 #endif

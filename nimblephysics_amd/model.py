@@ -482,7 +482,17 @@ class ModelDescription:
         # many pairs: not all of them can be in contact at once - per moving collider at most 2 x 8 + 4 x 4 points, shared between the two sides
         movers = sum(1 for bx in m.boxes if bx.body >= 0)
         est = min(est, 16 * max(1, movers))
-        return min(64, (est + 7) // 8 * 8)      # (a caller who expects more - boxes turned against each other touch in octagons - asks for up to 128 itself)
+        slots = min(64, (est + 7) // 8 * 8)     # (a caller who expects more - boxes turned against each other touch in octagons - asks for up to 128 itself)
+        # this default lands on the GENERAL instantiation of the contact stage - correct for every world of up to `slots` contacts,
+        # several times slower than the 24- / 48-row builds and with a per-world scratch that grows with the square of the rows: say so once
+        import warnings
+        ld = (3 * slots + 7) // 8 * 8
+        warnings.warn(f"{self.name}: the collider pairs of this model can hold about {est} contacts at once: defaulting to max_contacts = {slots}, which runs "
+                      f"on the general build of the contact stage (rows looped over: several times slower than the 8- / 16-slot builds; "
+                      f"{(5 * ld * ld + 16 * ld) * 8 / 1e6:.2f} MB of workspace per world, {(5 * ld * ld + 16 * ld) * 8 * 4096 / 1e9:.1f} GB at 4096 worlds).  "
+                      f"Pass max_contacts=16 (or 8) to the loader / set ModelDescription.max_contacts to stay on the fast builds: worlds with more "
+                      f"contacts are then truncated and flagged NBL_ST_CONTACT_OVERFLOW.", stacklevel=3)
+        return slots
 
     def capsule_meets_box(self) -> bool:
         """Some capsule collider is tested against some box collider (different bodies, not both fixed to the world, different skeletons:

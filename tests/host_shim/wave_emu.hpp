@@ -29,6 +29,7 @@ struct EmuWave {
     barrier();
     return m;
   }
+  template <int ROWS> double minRows(double v) const { return -maxAll(-v); }
   uint64_t ballot(bool p) const {
     sh->bslot[ln] = p ? 1 : 0; barrier();
     uint64_t m = 0;

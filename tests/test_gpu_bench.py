@@ -40,3 +40,18 @@ def test_bench_cfg5_workload_is_selectable():
     d = _run(["--workload", "atlas33_contact", "--rollout", "8", "--steps", "1", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--easy-noise", "0"])
     assert d["config"]["n_dofs"] == 33 and d["config"]["rollout_T"] == 8 and d["value"] > 0
     assert "N(0,0.02^2)" in d["config"]["workload"]
+
+
+def test_scale_curve_tool_at_one_gpu():
+    """tools/scale_curve.py on the box's one GPU: the plain launch and the launcher path (torch.distributed.run + RCCL, one rank) of the
+    same command, the table, and its assertion that the launcher path costs at most a few percent (10 % here: two short
+    runs on a shared box - the tool's own default is 3 % with the driver's 20 steps)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_curve.py"), "--gpus", "1", "2", "--steps", "20", "--warmup", "5",
+                        "--tolerance", "0.10"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert [r["n_gpus"] for r in rec["launcher"]] in ([1], [1, 2]) and rec["launcher"][0]["rccl_world_size"] == 1
+    assert rec["launcher"][0]["efficiency_vs_first"] == 1.0 and abs(rec["launcher_vs_plain_n1"]) <= 0.10
+    assert rec["skipped"] in ([2], [])            # a 1-GPU box says so instead of failing
+    assert "efficiency" in p.stdout and "RCCL ranks" in p.stdout

@@ -17,8 +17,11 @@ TOL = 1e-7
 ULPS = int(os.environ.get("NBL_TEST_ULPS", "4"))            # (as in tests/test_gpu_contacts16.py)
 CLOSENESS = float(os.environ.get("NBL_TEST_CLOSENESS", "0.25"))
 # ten cubes: 120 LCP rows of rank 60, Q^+ of a 108 x 108 clamping block whose condition number on its range is ~1e6 - the least-squares
-# impulses (and everything downstream) carry cond(Q) eps ~ 1e-9 .. 1e-7 on BOTH sides; held to 1e-6 (north_star: 1e-5)
-TOL_BIG = 1e-6
+# impulses (and everything downstream) carry cond(Q) eps ~ 1e-9 .. 1e-7 on BOTH sides: observed 1.3e-7 (ten cubes face to face) and 3.0e-7
+# (ten cubes turned against each other, 228 rows); held to what is observed with a margin of 1.5 (north_star: 1e-5), so that a regression fails
+TOL_TOWER10 = 2e-7
+TOL_TURNED = 4.5e-7
+TOL_BIG = 1e-6           # (the box_stacking.skel rollout's stable steps)
 
 
 def _fwd_bwd(md, s, a, seed, lcp=None):
@@ -125,8 +128,37 @@ def test_cube_towers_of_twenty_and_forty_contacts(n_cubes, B):
     e, _ = world_errors(dev, ref)
     print(f"[{n_cubes}-cube tower] stages:", {hex(int(k)): int(c) for k, c in zip(*np.unique(st & 0x13e, return_counts=True))},
           "max errors:", {k: float(v.max()) for k, v in e.items()})
-    bad, _ = assert_match_or_reference_unstable(f"{n_cubes}-cube tower, {4 * n_cubes} contacts", ow, s, a, g, dev, ref, TOL if n_cubes <= 5 else TOL_BIG, ulps=ULPS,
-                                                max_unstable=max(3, int(0.1 * B)))
+    bad, _ = assert_match_or_reference_unstable(f"{n_cubes}-cube tower, {4 * n_cubes} contacts", ow, s, a, g, dev, ref, TOL if n_cubes <= 5 else TOL_TOWER10, ulps=ULPS,
+                                                max_unstable=max(3, int(0.1 * B)), max_by_closeness=0)
+
+
+@pytest.mark.parametrize("scene", ["metric", "tower5"])
+def test_the_stand_alone_narrow_phase_of_the_general_build(scene, monkeypatch):
+    """NBL_FUSED_DETECT=0 on a general-build model: k_contact_detect as a launch of its own.  Its static LDS slices (remembered points, clip
+    polygons) have a lane stride of 16 in the general builds (DETECT_LS, contact_kernels.hip), so the launch must not put more than 16 threads
+    in a workgroup (it used up to 64 and the lanes overwrote each other's remembered points).  Two collider pairs per world (the
+    metric worlds: 2 lanes per world) and a five-cube tower (15 pairs: 4 lanes per world): the same worlds as the fused default, bit for bit,
+    and against the oracle."""
+    from oracle import OracleWorld
+    from util import contact_inputs, cube_tower_inputs
+    if scene == "metric":
+        B = 192
+        md, s, a = contact_inputs("atlas20", B, 13, joint_noise=0.02, vel_noise=0.01, action_noise=0.0)
+        md.max_contacts = 24
+    else:
+        B = 48
+        md, s, a = cube_tower_inputs(B, 12, 5, max_contacts=28)
+    _, dev_fused, st_fused, g = _fwd_bwd(md, s, a, 3)
+    monkeypatch.setenv("NBL_FUSED_DETECT", "0")
+    world, dev, st, _ = _fwd_bwd(md, s, a, 3)
+    assert world._L.nbl_model_max_contacts(world._h) == 64
+    assert np.array_equal(st, st_fused)
+    for k in dev:
+        assert np.array_equal(dev[k], dev_fused[k]), (scene, k, "the stand-alone narrow phase differs from the fused one")
+    ow = OracleWorld(md)
+    ref = ow.step_batch(s, a, g, threads=8)
+    assert (st & 1).all() and not ((st | ref["status"]) & 0x80).any()
+    assert_match_or_reference_unstable(f"stand-alone narrow phase, general build, {scene}", ow, s, a, g, dev, ref, TOL, ulps=ULPS, max_unstable=max(3, int(0.1 * B)))
 
 
 def test_a_tower_of_cubes_turned_against_each_other_needs_more_than_sixty_four_contacts():
@@ -163,7 +195,8 @@ def test_a_tower_of_cubes_turned_against_each_other_needs_more_than_sixty_four_c
     print("[turned tower] contacts per world: device", nc_dev.tolist(), "oracle", nc_ref, "status", [hex(int(x)) for x in st])
     assert not (st & 0x80).any() and not (ref["status"] & 0x80).any(), "a contact was dropped"
     assert np.array_equal(nc_dev, np.array(nc_ref)) and nc_dev.max() > 64 and nc_dev.min() >= 60
-    assert_match_or_reference_unstable("turned tower, 76 contacts", ow, s, a, g, dev, ref, TOL_BIG, ulps=ULPS, max_unstable=B, closeness=1.0, max_by_closeness=B)
+    # no escape hatch: every world within the tolerance (observed: 0 reference-unstable worlds, worst 3.0e-7)
+    assert_match_or_reference_unstable("turned tower, 76 contacts", ow, s, a, g, dev, ref, TOL_TURNED, ulps=ULPS, max_unstable=0, max_by_closeness=0)
 
 
 def three_groups_scene(B, towers=2, table=True, seed=21):
@@ -209,10 +242,14 @@ def test_two_towers_and_a_table_are_three_constrained_groups():
     assert (st & 1).all() and not ((st | ref["status"]) & 0x80).any()
     e, _ = world_errors(dev, ref)
     print("[three constrained groups, 44 contacts] max errors:", {k: float(v_.max()) for k, v_ in e.items()})
-    # closeness 1.0 here, not the file's 0.25: the table group is the most degenerate LCP of the suite (tests/test_gpu_contacts16.py) and with
-    # 64 perturbed runs of the oracle per world one world (36 of this seed) lands 0.37 from the nearest of outcomes that scatter by 0.72 -
-    # ratio 0.51: what breaks at 4 ulps / 0.25, everything else in the three files passes there
-    assert_match_or_reference_unstable("three groups", ow, s, a, g, dev, ref, TOL, ulps=ULPS, max_unstable=int(0.15 * B), closeness=1.0, max_by_closeness=4)
+    # Every world but one at the file's 4 ulps / closeness 0.25 with NO world allowed through the closeness branch.  World 36 of this seed is
+    # judged on its own: the table group is the most degenerate LCP of the suite (tests/test_gpu_contacts16.py) and with 64 perturbed runs of
+    # the oracle that world lands 0.37 from the nearest of outcomes that scatter by 0.72 (ratio 0.51) - proven reference-unstable (its own
+    # outcomes scatter by far more than the tolerance) and accepted at closeness 1.0, that world only.
+    w36 = np.arange(B) == 36
+    assert_match_or_reference_unstable("three groups (all worlds but 36)", ow, s, a, g, dev, ref, TOL, ulps=ULPS, max_unstable=4, closeness=CLOSENESS,
+                                       max_by_closeness=0, only=~w36)
+    assert_match_or_reference_unstable("three groups (world 36)", ow, s, a, g, dev, ref, TOL, ulps=ULPS, max_unstable=1, closeness=1.0, max_by_closeness=1, only=w36)
 
 
 def test_box_stacking_skel_as_it_ships_until_the_tower_rests_on_the_ground():

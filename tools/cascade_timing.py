@@ -1,20 +1,22 @@
 """Debug: per-stage cycle stamps of the cooperative cascade.  Needs the library built with the stamps compiled in:
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DNBL_CASCADE_TIMING nimblephysics_amd/csrc/nimble_amd.hip \\
         -o tools/dbg/libnimble_amd_timing.so
-usage (GPU box): python tools/cascade_timing.py <joint noise>"""
+usage (GPU box): python tools/cascade_timing.py <joint noise> [worlds]"""
 import os, sys, shutil, collections
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import nimblephysics_amd._lib as _lib
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "dbg", "libnimble_amd_timing.so")
+_lib.LIB_PATH = os.environ.get("NBL_TIMING_LIB", os.path.join(ROOT, "tools", "dbg", "libnimble_amd_timing.so"))
 import nimblephysics_amd as na
 from util import contact_inputs
 jn = float(sys.argv[1]) if len(sys.argv) > 1 else 0.005
-md, s, a = contact_inputs("atlas20", 4096, 1000, joint_noise=jn, vel_noise=jn / 2, action_noise=0.1)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096      # 1024 = one stream slice of the bench: ~1 stage wavefront per SIMD, like in the timed run
+md, s, a = contact_inputs("atlas20", B, 1000, joint_noise=jn, vel_noise=jn / 2, action_noise=0.1)
 world = na.World(md, device="cuda:0")
-B = 4096
+if len(sys.argv) > 2:
+    world.set_slices(1)
 st = world.to_soa(torch.tensor(s, device="cuda:0")); at = world.to_soa(torch.tensor(a, device="cuda:0"))
 import ctypes
 L = _lib.lib()
@@ -24,11 +26,20 @@ nxt, saved, status = world.step_soa(st, at)
 torch.cuda.synchronize()
 L.nbl_debug_dantzig_stats(buf, 0)
 dz = list(buf)
-names_dz = ["setup", "w[i]", "solve1", "dw", "step selection", "apply + transfer", "(loop tail)"]
+names_dz = ["setup", "w[i]", "solve1", "dw", "step selection", "apply + row enters C / N", "(loop tail)", "apply + row leaves C"]
 calls, idx, piv, rem = dz[8], dz[9], dz[10], dz[11]
 print(f"Dantzig: {calls} solves, {idx / max(calls, 1):.1f} driving rows, {piv / max(calls, 1):.1f} pivot iterations, {rem / max(calls, 1):.1f} C->N removals per solve")
 for k, nm in enumerate(names_dz):
-    print(f"  {nm:18s} {dz[k] / max(calls, 1):10.0f} cycles per solve")
+    print(f"  {nm:26s} {dz[k] / max(calls, 1):10.0f} cycles per solve")
+if hasattr(L, "nbl_debug_dantzig_stats_slow"):
+    sb = (ctypes.c_ulonglong * 16)()
+    L.nbl_debug_dantzig_stats_slow(sb)
+    sl = list(sb)
+    if sl[8]:
+        c2 = sl[8]
+        print(f"the SLOW solves (the tail a launch waits for): {c2} solves, {sl[9] / c2:.1f} driving rows, {sl[10] / c2:.1f} pivot iterations, {sl[11] / c2:.1f} C->N removals per solve")
+        for k, nm in enumerate(names_dz):
+            print(f"  {nm:26s} {sl[k] / c2:10.0f} cycles per solve")
 for k, nm in ((12, "stage 1: load problem"), (13, "stage 1: reduce"), (14, "stage 1: Dantzig (all of it)"), (15, "stage 1: map out + validity")):
     print(f"  {nm:30s} {dz[k] / max(calls, 1):10.0f} cycles per solve")
 pv = dz[16:24]
