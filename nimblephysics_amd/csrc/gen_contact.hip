@@ -23,6 +23,13 @@ struct GenWaveDev {
   DEV int minAllI(int v) const { for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
   DEV double sumAll(double v) const { for (int o = 32; o > 0; o >>= 1) v = v + __shfl_xor(v, o); return v; }   // (a + b on both partners: every lane ends with the same bits)
   DEV bool anyAll(bool b) const { return __ballot(b ? 1 : 0) != 0ull; }
+  // the value of lane `src` (wave-uniform): v_readlane
+  DEV double bcast(double v, int src) const {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+  }
+  // orders the wave's own LDS traffic (a wave's LDS instructions execute in order; this only stops the compiler from moving them)
+  DEV void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 };
 
 // the world's scratch: genScratchDoubles(ld) per world after the contact-backward rows of the workspace; mat[3] (the pseudo-inverse) is the
@@ -247,20 +254,29 @@ __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const Dev
 // ======================================================================================================================================
 // the solver cascade of one world
 // ======================================================================================================================================
-struct GenFinal {           // the result row by row while the groups are solved one after the other
-  double X[GR], E[GR], cfm[GR];
-  int cls[GR];
-  double xcache[GR];
+struct GenFinal {           // the result row by row while the groups are solved one after the other (carved out of the pool behind the rows)
+  double *X, *E, *cfm, *xcache;
+  int* cls;
 };
+__host__ __device__ inline size_t genFinalDoubles(int cap) { return (size_t)4 * cap + ((size_t)cap + 1) / 2; }
+// dynamic LDS of k_contact_solve_gen for a model of `rows` rows: the rows' pool + the final-result arrays
+__host__ __device__ inline size_t genSolveLdsBytes(int rows) { const int cap = genRowsCap(rows); return (genRowsDoubles(cap) + genFinalDoubles(cap)) * sizeof(double); }
 
 __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B, double* __restrict__ saved,
                                                           SavedLayout lay, const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
                                                           double* __restrict__ next, uint32_t* __restrict__ status, double* __restrict__ gws) {
-  __shared__ GenRows R;
-  __shared__ GenFinal Fn;
+  extern __shared__ __attribute__((aligned(16))) double ldsRows[];
   const GenWaveDev w;
   const int ln = w.lane();
   const int ldr = lay.ldr;              // leading dimension of the record's dense blocks and of the world's scratch matrices
+  GenRows R;
+  GenFinal Fn;
+  {
+    const int cap = genRowsCap(ldr);
+    genRowsCarve(R, ldsRows, cap);
+    double* f = ldsRows + genRowsDoubles(cap);
+    Fn.X = f; Fn.E = f + cap; Fn.cfm = f + 2 * cap; Fn.xcache = f + 3 * cap; Fn.cls = reinterpret_cast<int*>(f + 4 * cap);
+  }
   const int64_t b = mdl.b0 + (int64_t)blockIdx.x;
   if (b >= mdl.b1) return;
   const int n = mdl.n;
@@ -279,6 +295,8 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     return;
   }
   const GenScratch S = genScratchOf(gws, b, dn + lay.pinv, ldr);
+  GEN_T0();
+  GEN_CNT(10);
   // ---- the rows ----
   const bool haveCache = cacheIn && ((int)cacheIn[(int64_t)MAX_ROWS * B + b] == m);
   int nLimMine = 0;
@@ -302,9 +320,10 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     Fn.xcache[r] = haveCache ? (R.neg[r] ? -1.0 : 1.0) * cacheIn[(int64_t)r * B + b] : 0.0;
     Fn.X[r] = 0.0; Fn.E[r] = 0.0; Fn.cfm[r] = 0.0; Fn.cls[r] = RC_NOT_CLAMPING;
   }
-  if (ln == 0) { R.m = m; R.ld = ldr; }
+  R.m = m; R.ld = ldr;
   const int nLim = (int)w.sumAll((double)nLimMine);
-  if (ln == 0) { R.anyLim = nLim > 0; if (status) status[b] |= (nC - nLim > 0 ? 0x1u : 0u) | (nLim > 0 ? 0x400u : 0u); }
+  R.anyLim = nLim > 0;
+  if (ln == 0 && status) status[b] |= (nC - nLim > 0 ? 0x1u : 0u) | (nLim > 0 ? 0x400u : 0u);
   // ---- constrained groups (ConstraintSolver::buildConstrainedGroups :724-780, ContactConstraint::uniteSkeletons :879-907): skeletons
   //      connected by a contact between two reactive bodies are one group; groups are numbered by their first contact (coopGroups) ----
   if (ln == 0) {
@@ -344,11 +363,14 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     bool pinvValid = false;
     GenClasses K;
     double cfmG = 0.0;
+    GEN_T(0);
     const bool ok = genStage0(w, A, ldr, R, S, haveCache, pinvValid, K);
+    GEN_T(1);
     if (!ok) {
       anyFail = true;
       uint32_t st = 0;
       genCascade(w, A, ldr, R, S, cm->fallbackCfm, cfmG, st, pinvValid, K);
+      GEN_T(12);
       stAll = (stAll & ~0x100u) | (st & ~0x100u) | (stAll & st & 0x100u);
     }
     for (int r = ln; r < m; r += 64)
@@ -375,6 +397,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
   GenClasses K;
   K.nc = (int)w.sumAll((double)ncMine); K.nu = (int)w.sumAll((double)nuMine);
   bool pinvValid = pinvValidWorld && !anyLimClamp;
+  GEN_T(0);
   if (!pinvValid) {
     if (K.nc > 0) {
       genBuildQ(w, A, ldr, R, K, 0.0, S.mat[0], Fn.cfm);
@@ -385,6 +408,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     }
     pinvValid = K.nc > 0 || anyLimClamp;
   }
+  GEN_T(2);
   // ---- outputs (coopContactOutputs) ----
   for (int r = ln; r < MAX_ROWS; r += 64) {
     const bool in = r < m;
@@ -416,6 +440,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
   }
   const bool nan = w.anyAll(bad);
   if (ln == 0 && status) status[b] |= (anyFail ? stAll : (0x2u | 0x100u)) | (nan ? 0x40u : 0u);
+  GEN_T(3);
 }
 
 // ======================================================================================================================================
@@ -762,7 +787,9 @@ __global__ __launch_bounds__(64) void k_bwd_contact_b_gen(DevModel mdl, const De
 __global__ __launch_bounds__(64) void k_bwd_bounce_gen(DevModel mdl, const DevBody* __restrict__ bodies, int64_t B, const double* __restrict__ savedC,
                                                        SavedLayout lay, const double* __restrict__ gnext, double* __restrict__ lws, double* __restrict__ gws) {
   double* saved = const_cast<double*>(savedC);
-  __shared__ GenRows R;
+  extern __shared__ __attribute__((aligned(16))) double ldsRows[];
+  GenRows R;
+  genRowsCarve(R, ldsRows, genRowsCap(MAX_CONTACTS));
   __shared__ double yq[MAX_DOF_CONTACT], yv[MAX_DOF_CONTACT], tq[MAX_CONTACTS], tv[MAX_CONTACTS], rhs[MAX_CONTACTS], cRow[MAX_CONTACTS];
   __shared__ int brow[MAX_CONTACTS];
   const GenWaveDev w;
@@ -777,8 +804,8 @@ __global__ __launch_bounds__(64) void k_bwd_bounce_gen(DevModel mdl, const DevBo
     for (int r = 0; r < m; r += 3)
       if (svAt(saved, lay.cls + r, B, b) == 1.0 && svAt(saved, lay.rest + r / 3, B, b) > 0.0) brow[nbn++] = r;
     R.iscal[0] = nbn;
-    R.ld = ldr;                                         // (genPinv below works in the world's scratch matrices)
   }
+  R.ld = ldr;                                           // (genPinv below works in the world's scratch matrices)
   w.sync();
   const int nbn = R.iscal[0];
   if (nbn == 0) {                                       // nothing bounced in this world: X = I
@@ -847,7 +874,7 @@ __global__ __launch_bounds__(64) void k_bwd_bounce_gen(DevModel mdl, const DevBo
 }
 
 // Self-test of the general Dantzig driver (nbl_selftest_lcp_dantzig with n > 48): one wavefront per problem of a batch of n-row boxed LCPs
-// with explicit bounds, exactly the code k_contact_solve_gen runs in its stage 1 (lane 0).  Problems are dense [count][n * n] / [count][n].
+// with explicit bounds, exactly the code k_contact_solve_gen runs in its stage 1.  Problems are dense [count][n * n] / [count][n].
 __global__ __launch_bounds__(64) void k_selftest_dantzig_gen(int count, int n, const double* __restrict__ A, const double* __restrict__ b,
                                                             const double* __restrict__ lo, const double* __restrict__ hi, const int32_t* __restrict__ findex,
                                                             double* __restrict__ x, int32_t* __restrict__ rc, double* __restrict__ gws) {
@@ -863,11 +890,10 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig_gen(int count, int n, c
     P.b[j] = b[pb * n + j]; P.lo[j] = lo[pb * n + j]; P.hi[j] = hi[pb * n + j]; P.findex[j] = findex[pb * n + j]; P.x[j] = 0.0;
   }
   w.sync();
-  if (ln == 0) {
-    const int r = genDantzigSeq(D, n, P.x);
-    rc[pb] = r;
-    for (int i = 0; i < n; i++) x[pb * n + i] = r == 1 ? P.x[i] : 0.0;
-  }
+  __shared__ double sb[4 * GR];      // the driver's four shared vectors (the step kernel lends it GenRows::t0 .. t3)
+  const int r = genDantzigPar(w, D, n, P.x, sb, sb + GR, sb + 2 * GR, sb + 3 * GR, S.mat[0]);
+  if (ln == 0) rc[pb] = r;
+  for (int i = ln; i < n; i += 64) x[pb * n + i] = r == 1 ? P.x[i] : 0.0;
 }
 
 // Self-test of the general solver cascade (nbl_selftest_lcp_cascade): one wavefront per problem, the rows set up like k_contact_solve_gen
@@ -877,7 +903,9 @@ __global__ __launch_bounds__(64) void k_selftest_cascade_gen(int count, int m, c
                                                             const uint8_t* __restrict__ on, double fallbackCfm, double* __restrict__ x,
                                                             int32_t* __restrict__ cls, uint32_t* __restrict__ st, double* __restrict__ cfmOut,
                                                             double* __restrict__ gws) {
-  __shared__ GenRows R;
+  extern __shared__ __attribute__((aligned(16))) double ldsRows[];
+  GenRows R;
+  genRowsCarve(R, ldsRows, GR);
   const GenWaveDev w;
   const int ln = w.lane();
   const int64_t pb = blockIdx.x;
@@ -888,7 +916,7 @@ __global__ __launch_bounds__(64) void k_selftest_cascade_gen(int count, int m, c
   const GenScratch S = genScratchOf(gws, pb, base + (size_t)3 * GR * GR, GR);
   double* Ap = base + (size_t)4 * GR * GR + 16 * GR;
   for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) Ap[(size_t)i * GR + j] = A[((size_t)pb * m + i) * m + j];
-  if (ln == 0) { R.m = m; R.ld = GR; }
+  R.m = m; R.ld = GR;
   w.sync();
   for (int r = ln; r < m; r += 64) {
     double mr = mu[(size_t)pb * (m / 3) + r / 3];

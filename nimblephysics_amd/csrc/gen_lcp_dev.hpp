@@ -19,26 +19,59 @@
 
 namespace NBL_NS {
 
+// developer instrumentation of the general solve kernel (-DNBL_GEN_TIMING, tools/gen_timing.py): cycles per phase summed over the worlds
+#if defined(NBL_GEN_TIMING) && defined(__HIPCC__)
+__device__ unsigned long long g_genStat[16];
+#endif
+#if defined(NBL_GEN_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define GEN_T0() long long genT = clock64()
+#define GEN_T(k) do { const long long n_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_genStat[k], (unsigned long long)(n_ - genT)); genT = n_; } while (0)
+#define GEN_CNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_genStat[k], 1ull); } while (0)
+#else
+#define GEN_T0() do { } while (0)
+#define GEN_T(k) do { } while (0)
+#define GEN_CNT(k) do { } while (0)
+#endif
+
 constexpr int GR = MAXR;            // rows of the arrays below: the instantiation's cap (192 / 384)
 // The leading dimension of every scratch matrix AND of the record's dense blocks is a property of the MODEL, not of the build: its rows
 // (3 x max_contacts) rounded up to a multiple of 8 - GenRows::ld, SavedLayout::ldr.  A tower of five cubes (28 slots, 88 rows) then holds
 // 62 kB per matrix instead of the cap's 295 kB.
 __host__ __device__ inline int genLeadingDim(int maxContacts) { const int r = (3 * maxContacts + 7) & ~7; return r < 8 ? 8 : (r > MAXR ? MAXR : r); }
 
-// per-row data of one world's LCP (LDS on the device)
+// per-row data of one world's LCP (LDS on the device).  The arrays are carved out of ONE pool whose size follows the rows the MODEL can hold
+// (round 6: they were members of GR = 192 / 384 entries each - 24.6 kB of LDS per world for a model of 72 rows, five worlds per CU;
+// genRowsCarve(pool, cap) with cap = the model's rows: 8.3 kB, and the registers become the limit).  Every lane holds its own copy of the
+// descriptor (pointers, m, ld, anyLim: wave-uniform values); scal / iscal are the shared scalars lane 0 writes for the others.
 struct GenRows {
   int m;                            // rows in use (3 per contact slot)
   int ld;                           // leading dimension of the world's scratch matrices and of the record's dense blocks (genLeadingDim)
-  double Bv[GR], mu[GR], colNorm[GR];
-  double X[GR], X0[GR], E[GR];
-  double t0[GR], t1[GR], t2[GR], t3[GR];   // scratch vectors
-  int cls[GR], fp[GR], perm[GR], gid[GR];
-  unsigned char fric[GR], lim[GR], neg[GR], rowOn[GR], on[GR], done[GR], in[GR], pad_[GR];
-  double invd[GR];
-  double scal[8];                   // broadcast scalars
-  int iscal[8];
+  int cap;                          // entries of every array below
   int anyLim;
+  double *Bv, *mu, *colNorm;
+  double *X, *X0, *E;
+  double *t0, *t1, *t2, *t3;        // scratch vectors
+  double* invd;
+  double* scal;                     // 8 broadcast scalars
+  int *cls, *fp, *perm, *gid;
+  int* iscal;                       // 8
+  unsigned char *fric, *lim, *neg, *rowOn, *on, *done, *in, *pad_;      // (pad_: stage 0's guess rows)
 };
+constexpr int GEN_ROWS_MINCAP = NBL_MAXC > 64 ? NBL_MAXC : 64;      // (perm doubles as 64 skeleton labels, t0 as 2 x MAX_CONTACTS ints)
+__host__ __device__ inline int genRowsCap(int rows) { const int c = (rows + 7) & ~7; return c < GEN_ROWS_MINCAP ? GEN_ROWS_MINCAP : c; }
+// doubles (8-byte units) of the pool of a GenRows of `cap` entries: 11 double arrays + 8 scalars, 4 int arrays + 8 ints, 8 byte arrays
+__host__ __device__ inline size_t genRowsDoubles(int cap) { return (size_t)11 * cap + 8 + ((size_t)4 * cap + 8 + 1) / 2 + (size_t)cap; }
+__host__ __device__ inline void genRowsCarve(GenRows& R, double* pool, int cap) {
+  R.cap = cap; R.m = 0; R.ld = 0; R.anyLim = 0;
+  double* d = pool;
+  R.Bv = d; d += cap; R.mu = d; d += cap; R.colNorm = d; d += cap; R.X = d; d += cap; R.X0 = d; d += cap; R.E = d; d += cap;
+  R.t0 = d; d += cap; R.t1 = d; d += cap; R.t2 = d; d += cap; R.t3 = d; d += cap; R.invd = d; d += cap; R.scal = d; d += 8;
+  int* i = reinterpret_cast<int*>(d);
+  R.cls = i; i += cap; R.fp = i; i += cap; R.perm = i; i += cap; R.gid = i; i += cap; R.iscal = i; i += 8;
+  if ((4 * cap + 8) & 1) i += 1;
+  unsigned char* u = reinterpret_cast<unsigned char*>(i);
+  R.fric = u; u += cap; R.lim = u; u += cap; R.neg = u; u += cap; R.rowOn = u; u += cap; R.on = u; u += cap; R.done = u; u += cap; R.in = u; u += cap; R.pad_ = u;
+}
 
 // scratch of one world (HBM): GEN_NMAT matrices of ld x ld doubles + 16 vectors of ld (four matrices + the vectors in the step; the fifth
 // matrix: the self-test's problem)
@@ -331,7 +364,16 @@ struct GenScratch {
   double* mat[GEN_NMAT];    // M, G, T, P, and one more for the cascade's problem / factor (ld x ld each)
   double* vec;              // 16 x ld doubles
   int ld;
+  // A small pool the lanes share FAST (LDS on the device; NULL: none): GEN_FAST_MATS matrices of fastN x fastN and 20 vectors of fastN
+  // doubles.  A problem of at most fastN rows - eight or ten contacts of a model that asked for many more slots - runs its Dantzig driver
+  // and its Gauss-Seidel sweeps there instead of in HBM scratch, whose latency (the scratch of a launch does not fit the L2) every one of
+  // their dependent steps waited for.  Placement only: the arithmetic does not change.
+  double* fast = nullptr;
+  int fastN = 0;
 };
+constexpr int GEN_FAST_N = 32;
+constexpr int GEN_FAST_MATS = 3;
+constexpr int GEN_FAST_DOUBLES = GEN_FAST_MATS * GEN_FAST_N * GEN_FAST_N + 20 * GEN_FAST_N;
 
 // CGGM::constructMatrices + opportunisticallyStandardizeResults as a loop (coopStandardizeLoop of coop_dev.hpp).  X in: the solver's x
 // (R.X), out: the last accepted solution.  guessValid: S.mat[3] holds the pseudo-inverse of A restricted to the rows R.in0 (stage 0's
@@ -498,23 +540,35 @@ DEV void genRemoveRowCol(GenProblem& P, int col) {
 }
 
 // LCPUtils::reduce (LCPUtils.cpp:144-201, mergeLCPColumns :346-449): merge near-identical columns (squared distance < 1e-4, |b_a - b_b| <
-// 1e-4, same findex / hi / lo).  mOrig: rows of the world (for mapTo).
+// 1e-4, same findex / hi / lo).  mOrig: rows of the world (for mapTo).  The SEARCH for the first pair (a, b) in the reference's order - a
+// ascending, then b - is shared by the lanes (round 6; on lane 0 alone it was 276 pairs x four dependent loads from HBM scratch for the
+// metric worlds, where nothing merges): for every a the lanes test the columns b > a side by side - the cheap conditions first, the n-term
+// column distance only where they hold - and the lowest b that passes wins.  The merge itself (rare) stays with lane 0.
 template <class W>
 DEV void genLcpReduce(const W& w, GenRows& R, GenProblem& P, int mOrig) {
   const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
   const double TH = 1e-4;
-  if (w.lane() == 0) {
-    for (;;) {
-      const int n = P.n;
-      int ma = -1, mb = -1;
-      for (int a = 0; a < n - 1 && ma < 0; a++)
-        for (int b = a + 1; b < n; b++) {
-          if (!(fabs(P.b[a] - P.b[b]) < TH && P.findex[a] == P.findex[b] && P.hi[a] == P.hi[b] && P.lo[a] == P.lo[b])) continue;
-          double d2 = 0.0;
-          for (int r = 0; r < n; r++) { const double d = P.A[(size_t)r * ld + a] - P.A[(size_t)r * ld + b]; d2 += d * d; }
-          if (d2 < TH) { ma = a; mb = b; break; }
-        }
-      if (ma < 0) break;
+  const int ln = w.lane(), nl = w.lanes();
+  for (;;) {
+    const int n = P.n;
+    int ma = -1, mb = -1;
+    for (int a = 0; a < n - 1; a++) {
+      const double ba = P.b[a], ha = P.hi[a], la = P.lo[a];
+      const int fa = P.findex[a];
+      int mine = 0x7fffffff;
+      for (int b = a + 1 + ln; b < n; b += nl) {
+        if (!(fabs(ba - P.b[b]) < TH && fa == P.findex[b] && ha == P.hi[b] && la == P.lo[b])) continue;
+        double d2 = 0.0;
+        for (int r = 0; r < n; r++) { const double d = P.A[(size_t)r * ld + a] - P.A[(size_t)r * ld + b]; d2 += d * d; }
+        if (d2 < TH) { mine = b; break; }       // (a lane visits its columns in ascending order: its first hit is its lowest)
+      }
+      if (!w.anyAll(mine != 0x7fffffff)) continue;
+      ma = a; mb = w.minAllI(mine);
+      break;
+    }
+    if (ma < 0) break;
+    w.sync();
+    if (ln == 0) {
       for (int r = 0; r < n; r++) P.A[(size_t)r * ld + ma] *= 2.0;
       for (int i = 0; i < n; i++) {
         if (P.findex[i] == mb) P.findex[i] = ma;
@@ -526,97 +580,205 @@ DEV void genLcpReduce(const W& w, GenRows& R, GenProblem& P, int mOrig) {
         else if (P.mapTo[o] > mb) P.mapTo[o] -= 1;
       }
     }
-    R.iscal[3] = P.n;
+    P.n = n - 1;            // (every lane holds its own copy of the descriptor)
+    w.sync();
+  }
+}
+
+// LCPUtils::removeFriction (LCPUtils.cpp:208-247): drop every row with findex != -1.  What removing them one by one from the last one
+// down leaves - the kept rows / columns in their order, findex of a kept row unchanged (-1), mapTo of a dropped row -1 - as ONE gather
+// through the scratch matrix T (round 6; one by one on lane 0 it was sixteen passes over the matrix in HBM scratch for eight contacts:
+// 1.2 M cycles, more than the Gauss-Seidel sweeps it prepares).  Pure data movement.
+template <class W>
+DEV void genLcpRemoveFriction(const W& w, GenRows& R, GenProblem& P, int mOrig, double* T) {
+  const int ld = R.ld;
+  const int ln = w.lane(), nl = w.lanes();
+  const int n = P.n;
+  int* src = R.perm;                // new row -> old row
+  int* newOf = R.cls;               // old row -> new row or -1 (the classes are not in use between the stages)
+  if (ln == 0) {
+    int k = 0;
+    for (int i = 0; i < n; i++) { const bool keep = P.findex[i] == -1; newOf[i] = keep ? k : -1; if (keep) src[k++] = i; }
+    R.iscal[3] = k;
   }
   w.sync();
-  P.n = R.iscal[3];       // (every lane holds its own copy of the descriptor: the new size goes to all of them)
+  const int nNew = R.iscal[3];
+  for (int o = ln; o < mOrig; o += nl) { const int c = P.mapTo[o]; if (c >= 0) P.mapTo[o] = newOf[c]; }
+  for (int idx = ln; idx < nNew * nNew; idx += nl) { const int i = idx / nNew, j = idx - i * nNew; T[(size_t)i * ld + j] = P.A[(size_t)src[i] * ld + src[j]]; }
+  // (the row data through the four scratch vectors of the rows: gathered, barrier, written back)
+  for (int k = ln; k < nNew; k += nl) { const int sk = src[k]; R.t0[k] = P.x[sk]; R.t1[k] = P.b[sk]; R.t2[k] = P.lo[sk]; R.t3[k] = P.hi[sk]; }
+  w.sync();
+  for (int idx = ln; idx < nNew * nNew; idx += nl) { const int i = idx / nNew, j = idx - i * nNew; P.A[(size_t)i * ld + j] = T[(size_t)i * ld + j]; }
+  for (int k = ln; k < nNew; k += nl) { P.x[k] = R.t0[k]; P.b[k] = R.t1[k]; P.lo[k] = R.t2[k]; P.hi[k] = R.t3[k]; P.findex[k] = -1; }
+  P.n = nNew;
   w.sync();
 }
 
-// LCPUtils::removeFriction (LCPUtils.cpp:208-247): drop every row with findex != -1 (from the last one down)
-template <class W>
-DEV void genLcpRemoveFriction(const W& w, GenRows& R, GenProblem& P, int mOrig) {
-  if (w.lane() == 0) {
-    for (int i = P.n - 1; i >= 0; i--) {
-      if (P.findex[i] == -1) continue;
-      for (int k = 0; k < P.n; k++) if (P.findex[k] > i) P.findex[k] -= 1;
-      genRemoveRowCol(P, i);
-      for (int o = 0; o < mOrig; o++) {
-        if (P.mapTo[o] == i) P.mapTo[o] = -1;
-        else if (P.mapTo[o] > i) P.mapTo[o] -= 1;
-      }
-    }
-    R.iscal[3] = P.n;
+// one Gauss-Seidel row: x <- clamp(x + r) between the bounds (a friction row: +- mu times the impulse of its normal row, read from xs);
+// returns the change.  FIRST: the first sweep's test |d| > 1e-6, later |d| > 1e-3 |x| where |x| > 1e-9 (the reference divides; the product
+// form is what the lane = row builds test).  zeroRow: "x[i] = 0; continue" - the row leaves the problem, the others see x_i go to 0.
+DEV double genPgsClamp(const double* xs, double xo, double r, double hi, double lo, int fi, bool first, bool zeroRow, double& nxOut, bool& moved) {
+  const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
+  double nx = 0.0;
+  if (!zeroRow) {
+    nx = xo + r;
+    if (fi >= 0) { hi = hi * xs[fi]; lo = -hi; }
+    nx = nx > hi ? hi : (nx < lo ? lo : nx);
   }
-  w.sync();
-  P.n = R.iscal[3];
-  w.sync();
+  const double d = nx - xo;
+  if (!zeroRow && (first ? fabs(d) > dxTh : (fabs(nx) > epsDiv && fabs(d) > relTol * fabs(nx)))) moved = true;
+  nxOut = nx;
+  return d;
+}
+// The sweeps with every lane holding its NTT rows (row j = lane + lanes * t) in registers: residual, x, bounds, findex; the entries
+// a'_.i of a step (row i of AT) are fetched one step ahead.  The only shared traffic of a step is x_i (written by its owner, read by the
+// friction rows that follow it) and the broadcast of the change.  R.t0 = x, R.t1 = r, R.t2 / R.t3 = bounds, R.cls = findex, R.perm = the
+// rows in the problem (`no` of them), R.in = rows left out: set up by genPgs.  x comes back in R.t0.
+template <int NTT, class W>
+DEV bool genPgsHeld(const W& w, GenRows& R, int n, int no, const double* AT, int atLd) {
+  const int maxIteration = 30;
+  const int ln = w.lane(), nl = w.lanes();
+  double* xs = R.t0;
+  const int* order = R.perm;
+  double cn[NTT], rr[NTT], xx[NTT], hh[NTT], ll[NTT];
+  int ff[NTT];
+#pragma unroll
+  for (int t = 0; t < NTT; t++) {
+    const int j = ln + nl * t; const bool in = j < n;
+    rr[t] = in ? R.t1[j] : 0.0; xx[t] = in ? xs[j] : 0.0; ll[t] = in ? R.t2[j] : 0.0; hh[t] = in ? R.t3[j] : 0.0; ff[t] = in ? R.cls[j] : -1; cn[t] = 0.0;
+  }
+  auto fetch = [&](int i) {
+    if (i < 0) return;
+    const double* col = AT + (size_t)i * atLd;
+#pragma unroll
+    for (int t = 0; t < NTT; t++) { const int j = ln + nl * t; cn[t] = j < n ? col[j] : 0.0; }
+  };
+  auto rowStep = [&](int i, int iNext, bool first, bool zeroRow, bool& moved) {
+    const int owner = NTT == 1 ? i : i % nl, slot = NTT == 1 ? 0 : i / nl;
+    double cc[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; t++) cc[t] = cn[t];
+    fetch(iNext);
+    double d = 0.0;
+    if (ln == owner) {
+      double xo = 0.0, r = 0.0, hi = 0.0, lo = 0.0; int fi = -1;
+#pragma unroll
+      for (int t = 0; t < NTT; t++) if (t == slot) { xo = xx[t]; r = rr[t]; hi = hh[t]; lo = ll[t]; fi = ff[t]; }
+      double nx;
+      d = genPgsClamp(xs, xo, r, hi, lo, fi, first, zeroRow, nx, moved);
+#pragma unroll
+      for (int t = 0; t < NTT; t++) if (t == slot) xx[t] = nx;
+      xs[i] = nx;
+    }
+    d = w.bcast(d, owner);
+#pragma unroll
+    for (int t = 0; t < NTT; t++) rr[t] = fma(-cc[t], d, rr[t]);
+    w.fence();
+  };
+  bool moved = false;
+  fetch(n > 0 ? 0 : -1);
+  for (int i = 0; i < n; ++i) rowStep(i, i + 1 < n ? i + 1 : -1, true, R.in[i] != 0, moved);
+  bool possible = !w.anyAll(moved);
+  if (!possible) {
+    for (int iter = 1; iter < maxIteration; ++iter) {
+      moved = false;
+      fetch(no > 0 ? order[0] : -1);
+      int iCur = no > 0 ? order[0] : -1;
+      for (int t = 0; t < no; t++) {
+        const int iNext = t + 1 < no ? order[t + 1] : -1;
+        rowStep(iCur, iNext, false, false, moved);
+        iCur = iNext;
+      }
+      possible = !w.anyAll(moved);
+      if (possible) break;
+    }
+  }
+  return possible;
 }
 
 // PgsBoxedLcpSolver::solve (PgsBoxedLcpSolver.cpp:79-268), Option(30, 1e-6, 1e-3, 1e-9, false).  Gauss-Seidel is sequential over the
-// rows; the lanes share the dot product of a row (with one lane: the reference's own order of the sum).  A is modified (rows normalised)
-// like in the reference.  Uniform result.
+// rows: up to 30 sweeps x n row steps are one dependent chain and its length is the cost.  RESIDUAL form, like the lane = row builds
+// (coopPgs, coop_dantzig_dev.hpp): every row j keeps the scaled residual r_j = b'_j - sum_i a'_ji x_i of ITS row (a'_j = row j of A over
+// a_jj, as the reference scales the rows after its first sweep; b'_j = b_j / a_jj).  The step of row i is  x_i <- clamp(x_i + r_i)  by
+// the lane that owns row i, ONE broadcast of the change d, and r_j -= a'_ji d for every row j (lane-strided; the entries a'_.i of a
+// step are one contiguous row of AT, the scaled matrix transposed, built once per solve in the scratch matrix the caller lends).  x and
+// r live in the rows' scratch vectors (LDS on the device).  Round 5 formed the reference's 23-term dot product per row step with the
+// lanes sharing the sum - two barriers and a tree reduction per step, x and A in HBM scratch: 1500 cycles per step, 2.6 M cycles per
+// world that reaches the fallback stages.  The two orders agree to round-off; the clamps, the convergence tests (the reference's
+// division form) and the iteration cap are the reference's.  Rows with a_ii < eps are set to 0 once and left alone.  Uniform result.
 template <class W>
-DEV bool genPgs(const W& w, GenRows& R, GenProblem& P) {
-  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
+DEV bool genPgs(const W& w, GenRows& R, GenProblem& P, double* AT, int atLd) {
+  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up); atLd: that of AT
   const int n = P.n;
   const int maxIteration = 30;
   const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
   const int ln = w.lane(), nl = w.lanes();
-  auto rowDot = [&](int i) -> double {          // sum_{j != i} A[i][j] x[j]
-    double s = 0.0;
-    for (int j = ln; j < n; j += nl) if (j != i) s += P.A[(size_t)i * ld + j] * P.x[j];
-    return w.sumAll(s);
-  };
-  auto clampRow = [&](int i, double nx) -> double {
-    if (P.findex[i] >= 0) {
-      const double hiT = P.hi[i] * P.x[P.findex[i]], loT = -hiT;
-      return nx > hiT ? hiT : (nx < loT ? loT : nx);
-    }
-    return nx > P.hi[i] ? P.hi[i] : (nx < P.lo[i] ? P.lo[i] : nx);
-  };
+  double* xs = R.t0;                // x
+  double* rs = R.t1;                // scaled residuals
+  double* los = R.t2;               // lower bound (or, friction rows: unused) / upper bound (friction rows: mu)
+  double* his = R.t3;
+  double* inv = R.E;                // 1 / a_jj (1 for the rows left out)
+  int* fidx = R.cls;                // findex (the classes are not in use between the stages)
   int* order = R.perm;
-  int no = 0;
-  bool possible = true;
-  for (int i = 0; i < n; ++i) {
-    const double aii = P.A[(size_t)i * ld + i];
-    if (aii < epsDiv) { w.sync(); if (ln == 0) P.x[i] = 0.0; w.sync(); continue; }
-    if (ln == 0) order[no] = i;
-    no++;
-    const double oldX = P.x[i];
-    const double nx = (P.b[i] - rowDot(i)) / aii;
-    const double xi = clampRow(i, nx);
-    w.sync();
-    if (ln == 0) P.x[i] = xi;
-    w.sync();
-    if (possible && fabs(xi - oldX) > dxTh) possible = false;
+  for (int j = ln; j < n; j += nl) {
+    const double ajj = P.A[(size_t)j * ld + j];
+    inv[j] = ajj < epsDiv ? 1.0 : 1.0 / ajj;
+    R.in[j] = ajj < epsDiv ? 1 : 0;                     // (left out of the problem)
+    xs[j] = P.x[j]; los[j] = P.lo[j]; his[j] = P.hi[j]; fidx[j] = P.findex[j];
   }
-  if (possible) return true;
+  if (ln == 0) {
+    int no = 0;
+    for (int i = 0; i < n; i++) if (!(P.A[(size_t)i * ld + i] < epsDiv)) order[no++] = i;
+    R.iscal[4] = no;
+  }
   w.sync();
-  for (int t = 0; t < no; t++) {
-    const int idx = order[t];
-    const double dummy = 1.0 / P.A[(size_t)idx * ld + idx];
-    w.sync();
-    if (ln == 0) P.b[idx] *= dummy;
-    for (int j = ln; j < n; j += nl) P.A[(size_t)idx * ld + j] *= dummy;
-    w.sync();
+  const int no = R.iscal[4];
+  for (int idx = ln; idx < n * n; idx += nl) { const int i = idx / n, j = idx - i * n; AT[(size_t)i * atLd + j] = P.A[(size_t)j * ld + i] * inv[j]; }
+  w.sync();
+  for (int j = ln; j < n; j += nl) {
+    double r0 = P.b[j] * inv[j], r1 = 0.0;
+    int i = 0;
+    for (; i + 1 < n; i += 2) { r0 = fma(-AT[(size_t)i * atLd + j], xs[i], r0); r1 = fma(-AT[(size_t)(i + 1) * atLd + j], xs[i + 1], r1); }
+    if (i < n) r0 = fma(-AT[(size_t)i * atLd + j], xs[i], r0);
+    rs[j] = r0 + r1;
   }
-  for (int iter = 1; iter < maxIteration; ++iter) {
-    possible = true;
-    for (int t = 0; t < no; t++) {
-      const int idx = order[t];
-      const double oldX = P.x[idx];
-      const double nx = P.b[idx] - rowDot(idx);
-      const double xi = clampRow(idx, nx);
-      w.sync();
-      if (ln == 0) P.x[idx] = xi;
-      w.sync();
-      if (possible && fabs(xi) > epsDiv) {
-        if (fabs((xi - oldX) / xi) > relTol) possible = false;
+  w.sync();
+  // When the wavefront covers the rows with at most NT rows per lane (always on the device), a lane HOLDS its rows in registers: genPgsHeld
+  // (one row per lane when the problem has at most as many rows as the wave has lanes - the usual case).  Otherwise (the one-lane host
+  // policy) everything is read in place.  Same arithmetic.
+  constexpr int NT = (GR + 63) / 64;
+  bool possible;
+  if (n <= nl) possible = genPgsHeld<1>(w, R, n, no, AT, atLd);
+  else if (nl * NT >= n) possible = genPgsHeld<NT>(w, R, n, no, AT, atLd);
+  else {
+    auto rowStep = [&](int i, bool first, bool zeroRow, bool& moved) {
+      const int owner = i % nl;
+      double d = 0.0;
+      if (ln == owner) {
+        double nx;
+        d = genPgsClamp(xs, xs[i], rs[i], his[i], los[i], fidx[i], first, zeroRow, nx, moved);
+        xs[i] = nx;
+      }
+      d = w.bcast(d, owner);
+      const double* col = AT + (size_t)i * atLd;
+      for (int j = ln; j < n; j += nl) rs[j] = fma(-col[j], d, rs[j]);
+      w.fence();
+    };
+    bool moved = false;
+    for (int i = 0; i < n; ++i) rowStep(i, true, R.in[i] != 0, moved);
+    possible = !w.anyAll(moved);
+    if (!possible) {
+      for (int iter = 1; iter < maxIteration; ++iter) {
+        moved = false;
+        for (int t = 0; t < no; t++) rowStep(order[t], false, false, moved);
+        possible = !w.anyAll(moved);
+        if (possible) break;
       }
     }
-    if (possible) break;
   }
+  w.sync();
+  for (int j = ln; j < n; j += nl) P.x[j] = xs[j];
+  w.sync();
   return possible;
 }
 

@@ -776,7 +776,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
         while (ts > 8 && rowsLdsFor(ts) > 150u * 1024u) ts /= 2;
         TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_gen, dim3((unsigned)cnt), dim3(64), rowsLdsFor(ts), s, mdl, m->dBodies, m->dContact, B,
                                               (double*)saved, m->lay, (const double*)workspace, ts));
-        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, (double*)saved, m->lay,
+        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), genSolveLdsBytes(m->lay.ldr), s, mdl, m->dContact, B, (double*)saved, m->lay,
                                                lcp_cache_in, lcp_cache_out, next_state, status, gws));
       }
       (void)lws; (void)failListAll;
@@ -897,7 +897,7 @@ static int32_t launchBackward(nbl_model* m, int64_t B, int si, int64_t b0, int64
                                                  sv, m->lay, (const double*)workspace, lws));
       }
       if (mdl.hasBounce)
-        TIMED(K_BWD_BOUNCE, hipLaunchKernelGGL(k_bwd_bounce_gen, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dBodies, B, (const double*)saved, m->lay,
+        TIMED(K_BWD_BOUNCE, hipLaunchKernelGGL(k_bwd_bounce_gen, dim3((unsigned)cnt), dim3(64), genRowsDoubles(genRowsCap(MAX_CONTACTS)) * sizeof(double), s, mdl, m->dBodies, B, (const double*)saved, m->lay,
                                                grad_next_state, lws, gws));
 #else
       TIMED(K_BWD_A_COOP, hipLaunchKernelGGL(k_bwd_contact_a_coop, dim3((unsigned)cnt), dim3(64), 0, s, mdl, m->dContact, B, sv,
@@ -1157,7 +1157,7 @@ int32_t nbl_selftest_lcp_cascade(int32_t count, int32_t mRows, const double* A, 
   if (e == hipSuccess) e = hipMemcpy(dv + 3 * nv, mu, nc * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess && on) e = hipMemcpy(dOn, on, nv, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_selftest_cascade_gen, dim3((unsigned)count), dim3(64), 0, 0, count, mRows, dA, dv, dv + 3 * nv, have_cache, dv + nv, dOn, fallback_cfm,
+    hipLaunchKernelGGL(k_selftest_cascade_gen, dim3((unsigned)count), dim3(64), genRowsDoubles(GR) * sizeof(double), 0, count, mRows, dA, dv, dv + 3 * nv, have_cache, dv + nv, dOn, fallback_cfm,
                        dv + 2 * nv, di, (uint32_t*)(di + nv), dv + 3 * nv + nc, dS);
     e = hipDeviceSynchronize();
   }
@@ -1239,6 +1239,15 @@ int32_t nbl_debug_dantzig_stats(unsigned long long* out16, int32_t reset) {
 int32_t nbl_debug_dantzig_stats_slow(unsigned long long* out16) {   // the same sums over the solves of more than NBL_DZ_SLOW cycles
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dzStatSlow), sizeof(unsigned long long) * 16));
+  return NBL_OK;
+}
+#endif
+
+#if defined(NBL_GEN_TIMING) && NBL_GENERAL
+int32_t nbl_debug_gen_stats(unsigned long long* out16, int32_t reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_genStat), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_genStat), z, sizeof(z))); }
   return NBL_OK;
 }
 #endif

@@ -5,6 +5,8 @@
 
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <pthread.h>
 
 using namespace NBL_NS;
 
@@ -16,6 +18,8 @@ struct HostWave1 {
   int minAllI(int v) const { return v; }
   double sumAll(double v) const { return v; }
   bool anyAll(bool b) const { return b; }
+  double bcast(double v, int) const { return v; }
+  void fence() const {}
 };
 
 namespace {
@@ -24,14 +28,14 @@ namespace {
 static int shimLd(int m) { const int r = (m + 7) & ~7; return r < 8 ? 8 : (r > GR ? GR : r); }
 struct World {
   GenRows R;
-  std::vector<double> buf;
+  std::vector<double> buf, rowsPool;
   GenScratch S;
   int ld;
-  explicit World(int m) : buf(genScratchDoubles(shimLd(m)), 0.0), ld(shimLd(m)) {
+  explicit World(int m) : buf(genScratchDoubles(shimLd(m)), 0.0), rowsPool(genRowsDoubles(genRowsCap(shimLd(m))), 0.0), ld(shimLd(m)) {
     for (int k = 0; k < GEN_NMAT; k++) S.mat[k] = buf.data() + (size_t)k * ld * ld;
     S.vec = buf.data() + (size_t)GEN_NMAT * ld * ld;
     S.ld = ld;
-    std::memset(&R, 0, sizeof(R));
+    genRowsCarve(R, rowsPool.data(), genRowsCap(ld));      // (the rows' arrays sized by the problem, like the library sizes them by the model)
     R.ld = ld;
   }
 };
@@ -99,6 +103,87 @@ int gshim_dantzig(int n, const double* A, const double* b, const double* lo, con
   return rc;
 }
 
+// A policy of SEVERAL lanes for the wave-shared driver (genDantzigPar): a thread per lane, sync() a barrier, the reductions through shared
+// slots - so that the CPU suite runs the text the device runs with its loops really strided over lanes and its barriers really needed.
+struct HostWaveShared {
+  pthread_barrier_t bar;
+  double dslot[64];
+  int islot[64];
+  int nl;
+};
+struct HostWaveN {
+  HostWaveShared* sh;
+  int ln;
+  int lane() const { return ln; }
+  int lanes() const { return sh->nl; }
+  void sync() const { pthread_barrier_wait(&sh->bar); }
+  double maxAll(double v) const {
+    sh->dslot[ln] = v; sync();
+    double m = sh->dslot[0];
+    for (int i = 1; i < sh->nl; i++) m = fmax(m, sh->dslot[i]);
+    sync();
+    return m;
+  }
+  int minAllI(int v) const {
+    sh->islot[ln] = v; sync();
+    int m = sh->islot[0];
+    for (int i = 1; i < sh->nl; i++) m = sh->islot[i] < m ? sh->islot[i] : m;
+    sync();
+    return m;
+  }
+  double sumAll(double v) const {
+    sh->dslot[ln] = v; sync();
+    double s = 0.0;
+    for (int i = 0; i < sh->nl; i++) s += sh->dslot[i];
+    sync();
+    return s;
+  }
+  bool anyAll(bool b) const { return minAllI(b ? 0 : 1) == 0; }
+  double bcast(double v, int src) const {
+    sh->dslot[ln] = v; sync();
+    const double r = sh->dslot[src];
+    sync();
+    return r;
+  }
+  void fence() const { sync(); }
+};
+
+// the wave-shared Dantzig driver (genDantzigPar) on `lanes` lanes (1: the one-lane policy, no threads); same interface as gshim_dantzig
+int gshim_dantzig_par(int n, const double* A, const double* b, const double* lo, const double* hi, const int* findex, double* x, int lanes) {
+  World Wd(n);
+  const int GLD = Wd.ld;
+  GenProblem P; GenDantzigMem D;
+  genCarve(Wd.S, P, D);
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) P.A[(size_t)i * GLD + j] = A[(size_t)i * n + j];
+    P.b[i] = b[i]; P.lo[i] = lo[i]; P.hi[i] = hi[i]; P.findex[i] = findex[i]; P.x[i] = 0.0;
+  }
+  std::vector<double> xo(n, 0.0), sb((size_t)4 * GR, 0.0);
+  int rc = 0;
+  if (lanes <= 1) {
+    const HostWave1 w;
+    rc = genDantzigPar(w, D, n, xo.data(), sb.data(), sb.data() + GR, sb.data() + 2 * GR, sb.data() + 3 * GR, Wd.S.mat[0]);
+  } else {
+    if (lanes > 64) lanes = 64;
+    HostWaveShared sh;
+    sh.nl = lanes;
+    pthread_barrier_init(&sh.bar, nullptr, (unsigned)lanes);
+    std::vector<int> rcs(lanes, 0);
+    std::vector<std::thread> th;
+    for (int l = 0; l < lanes; l++)
+      th.emplace_back([&, l]() {
+        const HostWaveN w{&sh, l};
+        rcs[l] = genDantzigPar(w, D, n, xo.data(), sb.data(), sb.data() + GR, sb.data() + 2 * GR, sb.data() + 3 * GR, Wd.S.mat[0]);
+      });
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&sh.bar);
+    rc = rcs[0];
+    for (int l = 1; l < lanes; l++) if (rcs[l] != rc) rc = -99;      // (the lanes must agree)
+  }
+  for (int i = 0; i < n; i++) x[i] = rc == 1 ? xo[i] : 0.0;
+  return rc;
+}
+
 // stage 0 on the rows of `mask` (NULL: all): A m x m row-major, b[m], mu[m / 3]; outputs per row.  Returns ok | pinvValid << 1.
 int gshim_stage0(int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const unsigned char* lim, const unsigned char* neg,
                  int haveCache, const double* xcache, double* X, double* X0, int* cls, double* E, double* Pout) {
@@ -155,5 +240,36 @@ int gshim_stage(int stage, int m, const double* A, const double* b, const double
   else flags = genStage3(w, Ap.data(), GLD, Wd.R, Wd.S, fallbackCfm, out.data());
   for (int r = 0; r < m; r++) X[r] = out[r];
   return flags;
+}
+
+// the same stage with the work shared by `lanes` lanes (threads + barriers: HostWaveN) - the text the device runs with its 64 lanes
+int gshim_stage_lanes(int stage, int m, const double* A, const double* b, const double* mu, const unsigned char* mask, const double* x0, double fallbackCfm,
+                      double* X, int lanes) {
+  World Wd(m);
+  const int GLD = Wd.ld;
+  std::vector<double> Ap((size_t)GLD * GLD, 0.0);
+  for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Ap[(size_t)i * GLD + j] = A[(size_t)i * m + j];
+  fillRows(Wd.R, m, Ap.data(), GLD, b, mu, mask, nullptr, nullptr);
+  for (int r = 0; r < m; r++) Wd.R.X0[r] = Wd.R.on[r] ? x0[r] : 0.0;
+  std::vector<double> out(GR, 0.0);
+  if (lanes > 64) lanes = 64;
+  if (lanes < 2) lanes = 2;
+  HostWaveShared sh;
+  sh.nl = lanes;
+  pthread_barrier_init(&sh.bar, nullptr, (unsigned)lanes);
+  std::vector<int> fl(lanes, 0);
+  std::vector<std::thread> th;
+  for (int l = 0; l < lanes; l++)
+    th.emplace_back([&, l]() {
+      const HostWaveN w{&sh, l};
+      if (stage == 1) fl[l] = genStage1(w, Ap.data(), GLD, Wd.R, Wd.S, out.data());
+      else if (stage == 2) fl[l] = genStage2(w, Ap.data(), GLD, Wd.R, Wd.S, fallbackCfm, out.data());
+      else fl[l] = genStage3(w, Ap.data(), GLD, Wd.R, Wd.S, fallbackCfm, out.data());
+    });
+  for (auto& t : th) t.join();
+  pthread_barrier_destroy(&sh.bar);
+  for (int l = 1; l < lanes; l++) if (fl[l] != fl[0]) return -99;      // (the lanes must agree)
+  for (int r = 0; r < m; r++) X[r] = out[r];
+  return fl[0];
 }
 }

@@ -45,7 +45,7 @@ def _build_gen_shim(maxc):
     out = os.path.join(HERE, "host_shim", "libgen_shim.so" if maxc == 64 else f"libgen_shim{maxc}.so")
     deps = [src] + [os.path.join(ROOT, "nimblephysics_amd", "csrc", f) for f in ("gen_lcp_dev.hpp", "gen_dantzig_dev.hpp", "lcp_dev.hpp", "spatial_dev.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", f"-DNBL_MAXC={maxc}", "-I", os.path.join(HERE, "host_shim"),
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", f"-DNBL_MAXC={maxc}", "-I", os.path.join(HERE, "host_shim"),
                                "-I", os.path.join(ROOT, "nimblephysics_amd", "csrc"), "-o", out, src])
     lib = C.CDLL(out)
     assert lib.gshim_rows() == 3 * maxc
@@ -168,6 +168,41 @@ def test_dantzig_is_bit_identical_to_the_reference_dsolvelcp_up_to_192_rows(gen)
             failed += 1
     print(f"Dantzig up to 192 rows: {solved} solved bit for bit, {failed} early exits, all flags equal")
     assert solved > 20 and failed > 0
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("lanes", [1, 5, 64])
+def test_the_wave_shared_dantzig_driver_is_bit_identical_to_the_reference_with_one_lane_and_with_many(gen, lanes):
+    """genDantzigPar (round 6: what the device runs - the loops with independent iterations strided over the lanes, dDot's products in
+    parallel and its running sum in index order, the triangular solves column block by column block) against the reference's compiled
+    dSolveLCP: x and the success flag BIT FOR BIT, with ONE lane (plain sequential code), with 5 lanes (a count that divides nothing:
+    every strided loop has a ragged end) and with 64 (the wavefront) - threads and barriers, so a missing barrier or a racing in-place
+    shift shows as a mismatch."""
+    rng = np.random.default_rng(10 + lanes)
+    solved = failed = 0
+    sizes = [1, 2, 3, 5, 8, 8, 11, 16, 16, 20, 27, 32, 40, 48, 64, 64] if lanes == 1 else [1, 2, 3, 5, 8, 8, 11, 16, 20, 27, 40, 64]
+    for trial in range(60 if lanes == 1 else 36):
+        nc = sizes[trial % len(sizes)]; n = 3 * nc
+        ndof = n + int(rng.integers(0, 6)) if trial % 3 == 0 else int(rng.choice([3, 6, 12, 30, 60]))   # 2 of 3: rank-deficient A
+        A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
+        if trial % 4 == 1:
+            b = np.abs(b)                                      # more rows end in the clamping set: long factor, many removals
+        xr = np.zeros(n); xd = np.zeros(n); xs = np.zeros(n)
+        okr = OL.nbo_lcp_dantzig(n, _p(A), _p(xr), _p(b.copy()), _p(lo.copy()), _p(hi.copy()), _pi(fi.copy()), 1)
+        okd = gen.gshim_dantzig_par(n, _p(A), _p(b.copy()), _p(lo.copy()), _p(hi.copy()), _pi(fi.copy()), _p(xd), lanes)
+        oks = gen.gshim_dantzig(n, _p(A), _p(b.copy()), _p(lo.copy()), _p(hi.copy()), _pi(fi.copy()), _p(xs))
+        assert okd == oks and np.array_equal(xd, xs), (trial, n, lanes, okd, oks, "the wave-shared driver differs from the sequential one")
+        if okd == -1:
+            assert okr == 0 or not np.all(np.isfinite(xr)), (trial, okr)
+            continue
+        assert okr == okd, (trial, n, ndof, okr, okd)
+        if okr == 1:
+            solved += 1
+            assert np.array_equal(xr, xd), (trial, n, ndof, np.abs(xr - xd).max())
+        else:
+            failed += 1
+    print(f"wave-shared Dantzig, {lanes} lane(s), up to 192 rows: {solved} solved bit for bit, {failed} early exits, all flags equal")
+    assert solved > 10 and failed > 0
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
@@ -312,3 +347,35 @@ def test_cascade_on_one_constrained_group_equals_the_cascade_of_that_group_alone
             assert np.abs(X[off:off + mg] - X1).max() <= 1e-10 * max(1.0, np.abs(X1).max())
             assert not X[:off].any() and not X[off + mg:].any()
             off += mg
+
+
+@pytest.mark.parametrize("lanes", [7, 64])
+def test_the_stages_with_the_work_shared_by_many_lanes_equal_the_one_lane_run_bit_for_bit(gen, lanes):
+    """Stage 1 (load, the shared column-pair search of reduce, the wave-shared Dantzig driver), stage 2 (CFM, reduce, Gauss-Seidel in
+    residual form: with 64 lanes every lane HOLDS its rows in registers and fetches a step's column one step ahead, with 7 lanes and with
+    one everything is read in place) and stage 3 (the friction rows dropped in one gather) of gen_lcp_dev.hpp / gen_dantzig_dev.hpp on
+    threads + barriers against the same text under the one-lane policy: flags and candidate x BIT FOR BIT - every number is formed by one
+    lane with the same operands in the same order whatever the lane count.  Random contact problems of 2 .. 40 contacts, rank-deficient
+    ones, merged columns (two contacts at one point) included."""
+    rng = np.random.default_rng(100 + lanes)
+    gen.gshim_stage.argtypes = [C.c_int, C.c_int, pd, pd, pd, pu8, pd, C.c_double, pd]
+    gen.gshim_stage_lanes.argtypes = [C.c_int, C.c_int, pd, pd, pd, pu8, pd, C.c_double, pd, C.c_int]
+    seen = {1: set(), 2: set(), 3: set()}
+    for trial in range(18):
+        nc = [2, 5, 8, 8, 12, 20, 27, 40, 16][trial % 9]
+        ndof = int(rng.choice([6, 12, 30])) if trial % 2 else 3 * nc + 3
+        A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
+        m = 3 * nc
+        if trial % 5 == 4 and nc >= 2:                     # two contacts at the same point: identical rows / columns, reduce merges them
+            A[3:6, :] = A[0:3, :]; A[:, 3:6] = A[:, 0:3]; b[3:6] = b[0:3]; hi[3:6] = hi[0:3]
+        mu = np.ascontiguousarray(hi[1::3])
+        x0 = rng.normal(0, 0.05, m) * (trial % 3 == 0)
+        for stage in (1, 2, 3):
+            X1 = np.zeros(m); XL = np.zeros(m)
+            f1 = gen.gshim_stage(stage, m, _p(np.ascontiguousarray(A)), _p(b.copy()), _p(mu), None, _p(x0.copy()), 1e-3, _p(X1))
+            fl = gen.gshim_stage_lanes(stage, m, _p(np.ascontiguousarray(A)), _p(b.copy()), _p(mu), None, _p(x0.copy()), 1e-3, _p(XL), lanes)
+            assert fl == f1, (trial, stage, lanes, fl, f1)
+            assert np.array_equal(X1, XL), (trial, stage, lanes, np.abs(X1 - XL).max())
+            seen[stage].add(int(f1))
+    print(f"stages on {lanes} lanes == one lane, flags seen:", seen)
+    assert len(seen[1]) >= 2 and len(seen[2]) >= 1
