@@ -28,6 +28,7 @@ struct GenWaveDev {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
   }
+  DEV int bcastI(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }
   // orders the wave's own LDS traffic (a wave's LDS instructions execute in order; this only stops the compiler from moving them)
   DEV void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 };
@@ -260,7 +261,9 @@ struct GenFinal {           // the result row by row while the groups are solved
 };
 __host__ __device__ inline size_t genFinalDoubles(int cap) { return (size_t)4 * cap + ((size_t)cap + 1) / 2; }
 // dynamic LDS of k_contact_solve_gen for a model of `rows` rows: the rows' pool + the final-result arrays
-__host__ __device__ inline size_t genSolveLdsBytes(int rows) { const int cap = genRowsCap(rows); return (genRowsDoubles(cap) + genFinalDoubles(cap)) * sizeof(double); }
+// ... + ONE fast matrix of GEN_FAST_N x GEN_FAST_N (8 kB: the scaled matrix of the Gauss-Seidel sweeps of a problem of up to 32 rows; with
+// 190 registers per lane eight worlds share a CU, so up to 20 kB of LDS per world are free)
+__host__ __device__ inline size_t genSolveLdsBytes(int rows) { const int cap = genRowsCap(rows); return (genRowsDoubles(cap) + genFinalDoubles(cap) + GEN_FAST_N * GEN_FAST_N) * sizeof(double); }
 
 __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B, double* __restrict__ saved,
                                                           SavedLayout lay, const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     double* f = ldsRows + genRowsDoubles(cap);
     Fn.X = f; Fn.E = f + cap; Fn.cfm = f + 2 * cap; Fn.xcache = f + 3 * cap; Fn.cls = reinterpret_cast<int*>(f + 4 * cap);
   }
+  double* fastMat = ldsRows + genRowsDoubles(genRowsCap(ldr)) + genFinalDoubles(genRowsCap(ldr));
   const int64_t b = mdl.b0 + (int64_t)blockIdx.x;
   if (b >= mdl.b1) return;
   const int n = mdl.n;
@@ -294,7 +298,8 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     for (int d = ln; d < n; d += 64) svAt(saved, lay.w + d, B, b) = 0.0;
     return;
   }
-  const GenScratch S = genScratchOf(gws, b, dn + lay.pinv, ldr);
+  GenScratch S = genScratchOf(gws, b, dn + lay.pinv, ldr);
+  S.fast = fastMat; S.fastN = GEN_FAST_N; S.fastMats = 1;
   GEN_T0();
   GEN_CNT(10);
   // ---- the rows ----

@@ -706,7 +706,7 @@ DEV int genStage1(const W& w, const double* A, int lda, GenRows& R, const GenScr
   genLcpReduce(w, R, P, R.m);
   GEN_T(4);
   int rc;
-  if (S.fast && P.n <= S.fastN) {
+  if (S.fast && S.fastMats >= GEN_FAST_MATS && P.n <= S.fastN) {
     // a small problem: matrix, factor, the removal's scratch matrix and every vector of the driver in the fast pool
     const int N = S.fastN, n = P.n;
     GenDantzigMem F;
@@ -744,8 +744,8 @@ DEV int genStage2(const W& w, const double* A, int lda, GenRows& R, const GenScr
   int flags = 0;
   for (int r = w.lane(); r < R.m; r += w.lanes()) out[r] = 0.0;
   w.sync();
-  const bool fastP2 = S.fast && P.n <= S.fastN;
-  if (genPgs(w, R, P, fastP2 ? S.fast : S.mat[1], fastP2 ? S.fastN : R.ld)) {
+  const bool fastP2 = S.fast && S.fastMats >= 1 && P.n <= S.fastN;
+  if (genPgs(w, R, P, fastP2 ? S.fast : S.mat[1], fastP2 ? S.fastN : R.ld, fastP2)) {
     genMapOut(w, R, P, P.x, out);
     flags = GS_SOLVED | (genValid(w, A, lda, R, out, false, cfm, R.t2) ? GS_VALID : 0);
   }
@@ -760,8 +760,8 @@ DEV int genStage3(const W& w, const double* A, int lda, GenRows& R, const GenScr
   genLcpRemoveFriction(w, R, P, R.m, S.mat[1]);
   for (int c = w.lane(); c < P.n; c += w.lanes()) P.x[c] = 0.0;
   w.sync();
-  const bool fastP3 = S.fast && P.n <= S.fastN;
-  const bool ok3 = genPgs(w, R, P, fastP3 ? S.fast : S.mat[1], fastP3 ? S.fastN : R.ld);
+  const bool fastP3 = S.fast && S.fastMats >= 1 && P.n <= S.fastN;
+  const bool ok3 = genPgs(w, R, P, fastP3 ? S.fast : S.mat[1], fastP3 ? S.fastN : R.ld, fastP3);
   genMapOut(w, R, P, P.x, out);
   return ok3 ? GS_SOLVED : 0;
 }

@@ -370,6 +370,7 @@ struct GenScratch {
   // their dependent steps waited for.  Placement only: the arithmetic does not change.
   double* fast = nullptr;
   int fastN = 0;
+  int fastMats = 0;         // matrices of fastN x fastN in the pool (the Dantzig driver wants GEN_FAST_MATS + its vectors, Gauss-Seidel one)
 };
 constexpr int GEN_FAST_N = 32;
 constexpr int GEN_FAST_MATS = 3;
@@ -696,6 +697,90 @@ DEV bool genPgsHeld(const W& w, GenRows& R, int n, int no, const double* AT, int
   return possible;
 }
 
+// ... and for a problem of at most as many rows as the wave has lanes (one row per lane: the usual case) NOTHING of a step goes through
+// shared memory but the column of AT: the lane of a friction row takes the impulse of its normal row from a second broadcast (xf), lane t holds the t-th row of the sweep order and hands the next row on through the broadcast primitive.
+// AT_LDS: AT is in LDS (else HBM scratch) - the device reads it through a pointer of that address space: a generic (flat) load counts
+// on both memory counters and every wait for one waits for all of them, the prefetch included.
+template <bool AT_LDS, class W>
+DEV bool genPgsHeld1(const W& w, GenRows& R, int n, int no, const double* AT, int atLd) {
+  const int maxIteration = 30;
+  const double dxTh = 1e-6, relTol = 1e-3, epsDiv = 1e-9;
+  const int ln = w.lane();
+  const bool in = ln < n;
+  double r = in ? R.t1[ln] : 0.0, x = in ? R.t0[ln] : 0.0;
+  const double lo = in ? R.t2[ln] : 0.0, hi = in ? R.t3[ln] : 0.0;
+  const int fi = in ? R.cls[ln] : -1;
+  double xf = fi >= 0 ? R.t0[fi] : 1.0;                       // the impulse of the normal row a friction row hangs on
+  const int myOrder = ln < no ? R.perm[ln] : 0;               // lane t: the t-th row of the later sweeps
+  const bool zeroMe = in && R.in[ln] != 0;
+  const bool identity = no == n;                              // nothing left out: the later sweeps visit 0 .. n-1 like the first one
+  // What a step costs on a wavefront that is alone on its SIMD is its instruction count (tools/dbg/lat_probe.hip: ~5.5 cycles each,
+  // whatever they are), so the loop is written for few of them: the entry a'_.i of a step is an UNCONDITIONAL load (lanes beyond the
+  // problem read their clamped neighbour's, rows beyond the sweep row 0's: never used), fetched four steps ahead (a generic-address
+  // load: AT may be LDS or HBM scratch).
+  const double* colBase = AT + (in ? ln : 0);
+  const unsigned ldu = (unsigned)atLd;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const double __attribute__((address_space(3)))* LdsPtr;
+  typedef const double __attribute__((address_space(1)))* GlobalPtr;
+  auto colOf = [&](int i) -> double {
+    const unsigned off = (unsigned)(i < 0 ? 0 : i) * ldu;
+    if constexpr (AT_LDS) return ((LdsPtr)colBase)[off];
+    else return ((GlobalPtr)colBase)[off];
+  };
+#else
+  auto colOf = [&](int i) -> double { return colBase[(unsigned)(i < 0 ? 0 : i) * ldu]; };
+#endif
+  bool moved = false;
+  auto rowStep = [&](int i, double cc, bool first) {
+    double d = 0.0;
+    if (ln == i) {
+      double nx = 0.0;
+      if (!zeroMe) {
+        nx = x + r;
+        double h = hi, l = lo;
+        if (fi >= 0) { h = hi * xf; l = -h; }
+        nx = nx > h ? h : (nx < l ? l : nx);
+      }
+      d = nx - x;
+      if (!zeroMe && (first ? fabs(d) > dxTh : (fabs(nx) > epsDiv && fabs(d) > relTol * fabs(nx)))) moved = true;
+      x = nx;
+    }
+    d = w.bcast(d, i);
+    r = fma(-cc, d, r);
+    const double xi = w.bcast(x, i);          // (the new x_i itself: x_old + (x_new - x_old) is not always x_new)
+    xf = fi == i ? xi : xf;
+  };
+  // a sweep over `cnt` rows, four rows per trip; ORDERED: the t-th row is lane t's myOrder, else t itself
+  auto sweep = [&](int cnt, bool first, bool ordered) {
+    auto rowAt = [&](int t) -> int { return t < cnt ? (ordered ? w.bcastI(myOrder, t) : t) : -1; };
+    int i0 = rowAt(0), i1 = rowAt(1), i2 = rowAt(2), i3 = rowAt(3);
+    double c0 = colOf(i0), c1 = colOf(i1), c2 = colOf(i2), c3 = colOf(i3);
+    for (int t0 = 0; t0 < cnt; t0 += 4) {
+      const int j0 = rowAt(t0 + 4), j1 = rowAt(t0 + 5), j2 = rowAt(t0 + 6), j3 = rowAt(t0 + 7);
+      const double n0 = colOf(j0), n1 = colOf(j1), n2 = colOf(j2), n3 = colOf(j3);
+      rowStep(i0, c0, first);
+      if (i1 >= 0) rowStep(i1, c1, first);
+      if (i2 >= 0) rowStep(i2, c2, first);
+      if (i3 >= 0) rowStep(i3, c3, first);
+      i0 = j0; i1 = j1; i2 = j2; i3 = j3; c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+  };
+  sweep(n, true, false);
+  bool possible = !w.anyAll(moved);
+  if (!possible) {
+    for (int iter = 1; iter < maxIteration; ++iter) {
+      moved = false;
+      sweep(no, false, !identity);
+      possible = !w.anyAll(moved);
+      if (possible) break;
+    }
+  }
+  if (in) R.t0[ln] = x;
+  w.fence();
+  return possible;
+}
+
 // PgsBoxedLcpSolver::solve (PgsBoxedLcpSolver.cpp:79-268), Option(30, 1e-6, 1e-3, 1e-9, false).  Gauss-Seidel is sequential over the
 // rows: up to 30 sweeps x n row steps are one dependent chain and its length is the cost.  RESIDUAL form, like the lane = row builds
 // (coopPgs, coop_dantzig_dev.hpp): every row j keeps the scaled residual r_j = b'_j - sum_i a'_ji x_i of ITS row (a'_j = row j of A over
@@ -707,7 +792,8 @@ DEV bool genPgsHeld(const W& w, GenRows& R, int n, int no, const double* AT, int
 // world that reaches the fallback stages.  The two orders agree to round-off; the clamps, the convergence tests (the reference's
 // division form) and the iteration cap are the reference's.  Rows with a_ii < eps are set to 0 once and left alone.  Uniform result.
 template <class W>
-DEV bool genPgs(const W& w, GenRows& R, GenProblem& P, double* AT, int atLd) {
+DEV bool genPgs(const W& w, GenRows& R, GenProblem& P, double* AT, int atLd, bool atLds = false) {
+  GEN_T0();
   const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up); atLd: that of AT
   const int n = P.n;
   const int maxIteration = 30;
@@ -743,12 +829,13 @@ DEV bool genPgs(const W& w, GenRows& R, GenProblem& P, double* AT, int atLd) {
     rs[j] = r0 + r1;
   }
   w.sync();
+  GEN_T(13);
   // When the wavefront covers the rows with at most NT rows per lane (always on the device), a lane HOLDS its rows in registers: genPgsHeld
   // (one row per lane when the problem has at most as many rows as the wave has lanes - the usual case).  Otherwise (the one-lane host
   // policy) everything is read in place.  Same arithmetic.
   constexpr int NT = (GR + 63) / 64;
   bool possible;
-  if (n <= nl) possible = genPgsHeld<1>(w, R, n, no, AT, atLd);
+  if (n <= nl) possible = atLds ? genPgsHeld1<true>(w, R, n, no, AT, atLd) : genPgsHeld1<false>(w, R, n, no, AT, atLd);
   else if (nl * NT >= n) possible = genPgsHeld<NT>(w, R, n, no, AT, atLd);
   else {
     auto rowStep = [&](int i, bool first, bool zeroRow, bool& moved) {
@@ -777,6 +864,7 @@ DEV bool genPgs(const W& w, GenRows& R, GenProblem& P, double* AT, int atLd) {
     }
   }
   w.sync();
+  GEN_T(14);
   for (int j = ln; j < n; j += nl) P.x[j] = xs[j];
   w.sync();
   return possible;

@@ -19,6 +19,7 @@ struct HostWave1 {
   double sumAll(double v) const { return v; }
   bool anyAll(bool b) const { return b; }
   double bcast(double v, int) const { return v; }
+  int bcastI(int v, int) const { return v; }
   void fence() const {}
 };
 
@@ -142,6 +143,12 @@ struct HostWaveN {
   double bcast(double v, int src) const {
     sh->dslot[ln] = v; sync();
     const double r = sh->dslot[src];
+    sync();
+    return r;
+  }
+  int bcastI(int v, int src) const {
+    sh->islot[ln] = v; sync();
+    const int r = sh->islot[src];
     sync();
     return r;
   }

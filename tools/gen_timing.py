@@ -29,5 +29,6 @@ print(f"{B} worlds, forward step {t0.elapsed_time(t1):.3f} ms; {g[10]} worlds in
 for k, nm, den in ((0, "rows, groups, final classification", nw), (1, "stage 0 (guess, classification, standardisation)", nw), (12, "cascade (all of it)", ncas),
                    (4, "  stage 1: load + reduce", ncas), (5, "  stage 1: Dantzig", ncas), (6, "  stage 1: map out + validity", ncas),
                    (7, "  stage 2: CFM + reduce + PGS + validity", ncas), (8, "  stage 3: frictionless PGS (+ NaN checks)", ncas),
-                   (9, "  standardisation loop of the chosen solution", ncas), (2, "the record's Q^+ when the last one is not it", nw), (3, "outputs", nw)):
+                   (9, "  standardisation loop of the chosen solution", ncas),
+                   (13, "  (Gauss-Seidel, both stages: set-up - scaling, transposed matrix, residuals)", ncas), (14, "  (Gauss-Seidel, both stages: the sweeps)", ncas), (2, "the record's Q^+ when the last one is not it", nw), (3, "outputs", nw)):
     print(f"  {nm:56s} {g[k] / den:12.0f} cycles per {'world' if den == nw else 'cascade'}")
