@@ -259,13 +259,16 @@ struct GenFinal {           // the result row by row while the groups are solved
   double *X, *E, *cfm, *xcache;
   int* cls;
 };
+#ifndef GEN_SOLVE_FAST_MATS
+#define GEN_SOLVE_FAST_MATS 0     // fast (LDS) matrices of the step kernel: measured - 8 kB of LDS more per world cost more occupancy than the LDS-resident Gauss-Seidel matrix gains
+#endif
 __host__ __device__ inline size_t genFinalDoubles(int cap) { return (size_t)4 * cap + ((size_t)cap + 1) / 2; }
 // dynamic LDS of k_contact_solve_gen for a model of `rows` rows: the rows' pool + the final-result arrays
 // ... + ONE fast matrix of GEN_FAST_N x GEN_FAST_N (8 kB: the scaled matrix of the Gauss-Seidel sweeps of a problem of up to 32 rows; with
 // 190 registers per lane eight worlds share a CU, so up to 20 kB of LDS per world are free)
-__host__ __device__ inline size_t genSolveLdsBytes(int rows) { const int cap = genRowsCap(rows); return (genRowsDoubles(cap) + genFinalDoubles(cap) + GEN_FAST_N * GEN_FAST_N) * sizeof(double); }
+__host__ __device__ inline size_t genSolveLdsBytes(int rows) { const int cap = genRowsCap(rows); return (genRowsDoubles(cap) + genFinalDoubles(cap) + GEN_SOLVE_FAST_MATS * GEN_FAST_N * GEN_FAST_N) * sizeof(double); }
 
-__global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B, double* __restrict__ saved,
+__global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE_GEN) void k_contact_solve_gen(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B, double* __restrict__ saved,
                                                           SavedLayout lay, const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
                                                           double* __restrict__ next, uint32_t* __restrict__ status, double* __restrict__ gws) {
   extern __shared__ __attribute__((aligned(16))) double ldsRows[];
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
     return;
   }
   GenScratch S = genScratchOf(gws, b, dn + lay.pinv, ldr);
-  S.fast = fastMat; S.fastN = GEN_FAST_N; S.fastMats = 1;
+  if (GEN_SOLVE_FAST_MATS > 0) { S.fast = fastMat; S.fastN = GEN_FAST_N; S.fastMats = GEN_SOLVE_FAST_MATS; }
   GEN_T0();
   GEN_CNT(10);
   // ---- the rows ----
@@ -331,7 +334,10 @@ __global__ __launch_bounds__(64) void k_contact_solve_gen(DevModel mdl, const De
   if (ln == 0 && status) status[b] |= (nC - nLim > 0 ? 0x1u : 0u) | (nLim > 0 ? 0x400u : 0u);
   // ---- constrained groups (ConstraintSolver::buildConstrainedGroups :724-780, ContactConstraint::uniteSkeletons :879-907): skeletons
   //      connected by a contact between two reactive bodies are one group; groups are numbered by their first contact (coopGroups) ----
-  if (ln == 0) {
+  if (cm->oneSkeleton) {               // (one skeleton: one constrained group - nothing to label; the labelling below is lane 0 alone)
+    for (int r = ln; r < m; r += 64) R.gid[r] = 0;
+    if (ln == 0) R.iscal[2] = 1;
+  } else if (ln == 0) {
     int* lab = R.perm;                 // label of skeleton s (< 64)
     int* cu = reinterpret_cast<int*>(R.t0);
     int* cv = cu + MAX_CONTACTS;

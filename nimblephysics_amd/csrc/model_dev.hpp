@@ -12,6 +12,9 @@
 // Minimum waves per SIMD the register allocator must leave room for, per kernel (512 registers per lane per SIMD, VGPRs + AGPRs:
 // 2 -> 256, 3 -> 168, 4 -> 128).  The defaults are the measured optimum (profiles/r02c_occupancy_sweep.json); -DNBL_W_<KERNEL>=k overrides.
 #define NBL_WAVES(k) __attribute__((amdgpu_waves_per_eu(k)))
+#ifndef NBL_W_SOLVE_GEN
+#define NBL_W_SOLVE_GEN 2      // (round 6: capped to 128 registers - four wavefronts per SIMD - it spills 324 B and measures 6 % slower)
+#endif
 #ifndef NBL_W_SOLVE
 #define NBL_W_SOLVE 2
 #endif
@@ -176,6 +179,7 @@ struct DevContactModel {
   // joint-limit constraint rows (JointLimitConstraint.cpp; nbl_model_desc.dof_limit_enforced): the single-DOF joints that enforce a finite
   // position limit.  An active one becomes a pseudo-contact of the record (CT_LIMIT) after the world's contacts
   int32_t nLimitDofs, selfCollision;   // selfCollision: some pair of colliders sits on one skeleton (body_self_collision)
+  int32_t oneSkeleton, pad0_;          // oneSkeleton: every body of the model is on one skeleton - a world has at most ONE constrained group
   int32_t limitDof[MAX_DOF_CONTACT], limitBody[MAX_DOF_CONTACT];
   double limitLo[MAX_DOF_CONTACT], limitHi[MAX_DOF_CONTACT];
 };

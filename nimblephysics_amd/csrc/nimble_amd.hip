@@ -468,6 +468,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
     for (int i = 0; i < d->n_boxes; i++)
       for (int j = i + 1; j < d->n_boxes; j++)
         if (d->box_body[i] >= 0 && d->box_body[j] >= 0 && skelOf(d->box_body[i]) != skelOf(d->box_body[j])) multiGroupModel = true;
+    hc.oneSkeleton = 1; hc.pad0_ = 0;
+    for (int bdy = 1; bdy < d->n_bodies; bdy++) if (skelOf(bdy) != skelOf(0)) hc.oneSkeleton = 0;
     for (int bdy = 0; bdy < d->n_bodies; bdy++) {
       hc.skelOf[bdy] = skelOf(bdy);
       if (hc.skelOf[bdy] < 0 || hc.skelOf[bdy] >= 64) return fail(NBL_E_BADARG, "body_skeleton must lie in [0, 64)");
@@ -776,7 +778,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
         while (ts > 8 && rowsLdsFor(ts) > 150u * 1024u) ts /= 2;
         TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_gen, dim3((unsigned)cnt), dim3(64), rowsLdsFor(ts), s, mdl, m->dBodies, m->dContact, B,
                                               (double*)saved, m->lay, (const double*)workspace, ts));
-        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), genSolveLdsBytes(m->lay.ldr), s, mdl, m->dContact, B, (double*)saved, m->lay,
+        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), genSolveLdsBytes(m->lay.ldr) + (getenv("NBL_GEN_EXTRA_LDS") ? atoi(getenv("NBL_GEN_EXTRA_LDS")) : 0), s, mdl, m->dContact, B, (double*)saved, m->lay,
                                                lcp_cache_in, lcp_cache_out, next_state, status, gws));
       }
       (void)lws; (void)failListAll;

@@ -269,6 +269,7 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
     gravity = tuple(float(x) for x in g.text.split()) if g is not None else (0.0, -9.81, 0.0)
     bodies, boxes = [], []
     welded_dofs = []      # (skeleton, joint, DOFs) of every joint of an immobile skeleton: coordinates the reference's state vector has and this one does not
+    ref_dof_mobile = []   # the reference World's coordinates in ITS order (skeleton by skeleton, joint by joint): True = one of this model's
     for sk_index, sk in enumerate(world.findall("skeleton")):
         if skeletons is not None and sk.get("name") not in skeletons:
             continue
@@ -476,6 +477,7 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
                             kw[key] = tuple(vals)
                         else:
                             kw.pop(key, None)
+                ref_dof_mobile.extend([bool(is_mobile)] * int(ndofs))
                 if not is_mobile:                 # an immobile skeleton: every joint frozen at its zero configuration
                     if ndofs:
                         welded_dofs.append((sk.get("name"), j.get("name"), int(ndofs)))
@@ -496,11 +498,16 @@ def load_skel(path, name=None, skeletons=None, max_contacts=None, drop_unsupport
     md = ModelDescription(name, bodies, boxes, gravity, dt, None, max_contacts=(max_contacts or 0) if boxes else 0)
     # coordinates of immobile skeletons: part of the reference World's getPositions() / state vector, NOT of this model's (loaded welded).
     # Callers porting reference state vectors must drop them: md.welded_dofs lists them in the reference's order; warned about once per load.
+    # Round 6: they STAY in the drop-in surface's state vector (World.getStateSize / setState / getState, timestep(): the reference's layout,
+    # nimblephysics_amd/ref_layout.py) as frozen coordinates - identity rows of the step's Jacobians - which must sit at zero, where the
+    # skeleton was welded; only the raw SoA entry points (step_soa, ...) see the device's shorter vector.
     md.welded_dofs = welded_dofs
+    md.ref_dof_mobile = ref_dof_mobile if welded_dofs else None
     if welded_dofs:
         import warnings
         warnings.warn(f"{path}: {sum(d for _, _, d in welded_dofs)} coordinate(s) of immobile skeleton(s) "
-                      f"{sorted({s_ for s_, _, _ in welded_dofs})} are welded and leave the state vector (ModelDescription.welded_dofs)", stacklevel=2)
+                      f"{sorted({s_ for s_, _, _ in welded_dofs})} are frozen at zero: part of the state vector of World / timestep() like in the "
+                      "reference (ModelDescription.welded_dofs, ref_dof_mobile), not of the device's SoA entry points", stacklevel=2)
     if boxes and max_contacts is None:          # (not said: by what the collider pairs of the world can hold, ModelDescription.suggest_max_contacts)
         md.max_contacts = md.suggest_max_contacts()
     if md.capsule_meets_box():

@@ -48,8 +48,20 @@ class BackpropSnapshot:
         self._check(world)
         if exploreAlternateStrategies:
             raise NimbleAmdError("exploreAlternateStrategies is outside the hot-path scope")
+        lay = world.ref_layout
+        g_full = nextTimestepStateLossGrad
+        if lay is not None:      # the reference's layout: the rows of the immobile coordinates are the identity's (ref_layout.py)
+            nextTimestepStateLossGrad = lay.restrict_state(g_full.detach(), "backpropState", check_frozen=False)
         g = world._prep(nextTimestepStateLossGrad, 2 * world.n, "backpropState")
         gs, ga = world.backward_soa(self._saved, world.to_soa(g))
+        if lay is not None:
+            gm = world.backward_inertia_soa(self._saved, g.shape[0]).sum(dim=1) if world.getMassDims() > 0 else torch.zeros(0, dtype=torch.float64, device=world.device)
+            gfull = g_full.detach().to(device=world.device, dtype=torch.float64)
+            gfull = gfull if gfull.dim() == 2 else gfull.unsqueeze(0)
+            ds = lay.expand_grad_state(world.from_soa(gs), gfull)
+            cols = torch.tensor(lay.action_columns(world._ref_action_map), dtype=torch.long, device=world.device)
+            da = torch.zeros((g.shape[0], len(world._ref_action_map)), dtype=torch.float64, device=world.device).index_copy(1, cols, world.from_soa(ga))
+            return LossGradientHighLevelAPI(self._out(ds), self._out(da), gm)
         gm = None
         if world.getMassDims() > 0:
             gm = world.backward_inertia_soa(self._saved, g.shape[0]).sum(dim=1)     # one mass vector shared by the worlds
@@ -61,7 +73,7 @@ class BackpropSnapshot:
                  exploreAlternateStrategies: bool = False) -> LossGradient:
         """BackpropSnapshot::backprop (:181-423) in its component form: nextTimestepLoss carries lossWrtPosition / lossWrtVelocity of
         the NEXT state; the result (also stored into thisTimestepLoss when given) carries lossWrtPosition / Velocity / Torque / Mass."""
-        n = world.n
+        n = world.getNumDofs()
         gq = world._prep(nextTimestepLoss.lossWrtPosition, n, "backprop")
         gv = world._prep(nextTimestepLoss.lossWrtVelocity, n, "backprop")
         hl = self.backpropState(world, torch.cat([gq, gv], dim=1), perfLog, exploreAlternateStrategies)
@@ -83,15 +95,19 @@ class BackpropSnapshot:
 
     def getStateJacobian(self, world: World) -> torch.Tensor:
         """[B, 2n, 2n]: d next_state / d state = [[posPos, velPos], [posVel, velVel]] (BackpropSnapshot.cpp:2889-2917)."""
-        return self._out(self._jacobians(world)[0].permute(2, 0, 1).contiguous())
+        J = self._jacobians(world)[0].permute(2, 0, 1).contiguous()
+        return self._out(world.ref_layout.state_jacobian(J) if world.ref_layout is not None else J)
 
     def getActionJacobian(self, world: World) -> torch.Tensor:
         """[B, 2n, k]: d next_state / d action = [[0], [forceVel]] on the action space (BackpropSnapshot.cpp:2919-2940)."""
-        return self._out(self._jacobians(world)[1].permute(2, 0, 1).contiguous())
+        J = self._jacobians(world)[1].permute(2, 0, 1).contiguous()
+        return self._out(world._ref_action_jacobian(J) if world.ref_layout is not None else J)
 
     def _block(self, world, rows, cols):
-        n = world.n
+        n = world.getNumDofs()
         J = self._jacobians(world)[0].permute(2, 0, 1)
+        if world.ref_layout is not None:
+            J = world.ref_layout.state_jacobian(J.contiguous())
         r0, c0 = (0 if rows == "pos" else n), (0 if cols == "pos" else n)
         return self._out(J[:, r0:r0 + n, c0:c0 + n].contiguous())
 

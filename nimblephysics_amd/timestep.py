@@ -70,8 +70,18 @@ class TimestepLayer(torch.autograd.Function):
 
 
 def timestep(world: World, state: torch.Tensor, action: torch.Tensor, mass: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Forward pass on `world`, storing what the backward pass needs (reference: timestep.py:63-69)."""
-    return TimestepLayer.apply(world, state, action, mass)
+    """Forward pass on `world`, storing what the backward pass needs (reference: timestep.py:63-69).  A world whose reference layout has
+    coordinates of immobile skeletons (world.ref_layout, ref_layout.py) takes and returns the REFERENCE's [q; v]: those coordinates
+    pass through unchanged (identity rows of the vector-Jacobian product), forces on them do nothing (zero gradient)."""
+    lay = world.ref_layout
+    if lay is None:
+        return TimestepLayer.apply(world, state, action, mass)
+    k_ref = len(world._ref_action_map)
+    if action.shape[-1] != k_ref:
+        raise ValueError(f"World.setAction() called with a tensor of incorrect size {tuple(action.shape)}; expected [B, {k_ref}]")
+    cols = torch.tensor(lay.action_columns(world._ref_action_map), dtype=torch.long, device=action.device)
+    out_dev = TimestepLayer.apply(world, lay.restrict_state(state, "World.setState()"), action.index_select(-1, cols), mass)
+    return lay.expand_state(out_dev, state)
 
 
 class RolloutLayer(torch.autograd.Function):
@@ -123,4 +133,11 @@ def rollout(world: World, state0: torch.Tensor, actions: torch.Tensor, warm_star
     world's registered mass vector.  checkpoint_every = K > 0 keeps the backward records of K steps instead of T (a record is
     ~32 kB per world-step on Atlas-20 with contacts): the backward pass re-runs the other segments from their stored start states;
     the forward kernels are bit-reproducible, so the gradients are bit for bit those of checkpoint_every = 0."""
-    return RolloutLayer.apply(world, state0, actions, warm_start, mass, checkpoint_every)
+    lay = world.ref_layout
+    if lay is None:
+        return RolloutLayer.apply(world, state0, actions, warm_start, mass, checkpoint_every)
+    # the reference's layout (ref_layout.py): the coordinates of immobile skeletons stay at state0's along the trajectory
+    cols = torch.tensor(lay.action_columns(world._ref_action_map), dtype=torch.long, device=actions.device)
+    dev = RolloutLayer.apply(world, lay.restrict_state(state0, "World.setState()"), actions.index_select(-1, cols), warm_start, mass, checkpoint_every)
+    like = state0.unsqueeze(-2).expand(*dev.shape[:-1], state0.shape[-1])
+    return lay.expand_state(dev, like)

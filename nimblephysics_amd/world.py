@@ -18,6 +18,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
+from .ref_layout import RefLayout
+
 from . import _abi
 from ._lib import NimbleAmdError, check, lib
 from .mass import WithRespectToMass, WrtMassBodyNodeEntryType
@@ -66,7 +68,14 @@ class World:
         self._action = None  # [k][B]
         self.lcp_cache = None  # [m][B] hidden warm start (BoxedLcpConstraintSolver::mX)
         self.last_status = None
+        # the reference's coordinate layout when it has coordinates the device model does not (immobile skeletons: ref_layout.py)
+        mob = getattr(self.description, "ref_dof_mobile", None)
+        self.ref_layout = RefLayout(mob) if mob is not None and not all(mob) else None
+        self._ref_action_map = list(range(self.ref_layout.n_ref)) if self.ref_layout is not None else None
+        self._ref_state_like = None
         self._create_handle()
+        if self.ref_layout is not None and self.ref_layout.n_dev != self.n:
+            raise NimbleAmdError(f"the reference layout names {self.ref_layout.n_dev} mobile coordinates, the model has {self.n}")
 
     def _create_handle(self):
         """(Re-)upload the model constants.  The new handle is created FIRST: when the library refuses the description (a finite limit on a
@@ -110,18 +119,32 @@ class World:
 
     # ---- sizes / action space (World.cpp:2016-2135) -------------------------------------------
     def getNumDofs(self) -> int:
-        return self.n
+        """World::getNumDofs: every skeleton's coordinates, the immobile ones included (their layout: ref_layout.py)."""
+        return self.ref_layout.n_ref if self.ref_layout is not None else self.n
 
     def getStateSize(self) -> int:
-        return 2 * self.n
+        return 2 * self.getNumDofs()
 
     def getActionSize(self) -> int:
-        return self.k
+        return len(self._ref_action_map) if self.ref_layout is not None else self.k
 
     def getActionSpace(self) -> List[int]:
-        return self.model.action_map
+        return list(self._ref_action_map) if self.ref_layout is not None else self.model.action_map
 
     def setActionSpace(self, mapping: Sequence[int]):
+        if self.ref_layout is not None:       # the caller speaks the reference's coordinates: forces on immobile skeletons do nothing
+            dev_map = self.ref_layout.device_action_map(mapping)
+            old = self._ref_action_map
+            self._ref_action_map = [int(d) for d in mapping]
+            try:
+                self._set_device_action_space(dev_map)
+            except Exception:
+                self._ref_action_map = old
+                raise
+            return
+        self._set_device_action_space(mapping)
+
+    def _set_device_action_space(self, mapping: Sequence[int]):
         snapshot = [list(md._action_map) if md._action_map is not None else None for md in self._descriptions()]
         try:
             self.model.set_action_space(mapping)
@@ -275,16 +298,37 @@ class World:
     # ---- state / action API ---------------------------------------------------------------------
     def setState(self, state: torch.Tensor):
         self._one_d = state.dim() == 1                  # one world given as the reference's 1-D vector (neural.forwardPass answers alike)
+        if self.ref_layout is not None:
+            full = state.detach()
+            self._ref_state_like = (full if full.dim() == 2 else full.unsqueeze(0)).to(device=self.device, dtype=torch.float64).clone()
+            state = self.ref_layout.restrict_state(full, "World.setState()")
         self._state = self.to_soa(self._prep(state, 2 * self.n, "setState"))
 
     def getState(self) -> torch.Tensor:
-        return self.from_soa(self._state)
+        out = self.from_soa(self._state)
+        if self.ref_layout is not None:
+            like = self._ref_state_like
+            if like is None or like.shape[0] != out.shape[0]:
+                like = torch.zeros((out.shape[0], 2 * self.ref_layout.n_ref), dtype=torch.float64, device=self.device)
+            out = self.ref_layout.expand_state(out, like)       # the coordinates of immobile skeletons stay where setState put them
+        return out
 
     def setAction(self, action: torch.Tensor):
+        if self.ref_layout is not None:
+            k_ref = len(self._ref_action_map)
+            if action.shape[-1] != k_ref:
+                raise ValueError(f"World.setAction() called with a tensor of incorrect size {tuple(action.shape)}; expected [B, {k_ref}]")
+            cols = torch.tensor(self.ref_layout.action_columns(self._ref_action_map), dtype=torch.long, device=action.device)
+            action = action.detach().index_select(-1, cols)
         self._action = self.to_soa(self._prep(action, self.k, "setAction"))
 
     def getAction(self) -> torch.Tensor:
-        return self.from_soa(self._action)
+        out = self.from_soa(self._action)
+        if self.ref_layout is not None:
+            full = torch.zeros((out.shape[0], len(self._ref_action_map)), dtype=torch.float64, device=out.device)
+            cols = torch.tensor(self.ref_layout.action_columns(self._ref_action_map), dtype=torch.long, device=out.device)
+            out = full.index_copy(1, cols, out)
+        return out
 
     def reset_lcp_cache(self):
         self.lcp_cache = None
@@ -440,7 +484,8 @@ class World:
             raise NimbleAmdError("getStateJacobian(): no step with a saved record has been taken")
         B = self.last_status.shape[0]
         self._last_jac = self.step_jacobians_soa(self._last_saved, B)
-        return self._last_jac[0].permute(2, 0, 1).contiguous()
+        J = self._last_jac[0].permute(2, 0, 1).contiguous()
+        return self.ref_layout.state_jacobian(J) if self.ref_layout is not None else J
 
     def getActionJacobian(self) -> torch.Tensor:
         """World::getActionJacobian (World.cpp:2229-2243) of the last step: [B, 2n, k]."""
@@ -448,7 +493,17 @@ class World:
             raise NimbleAmdError("getActionJacobian(): no step with a saved record has been taken")
         B = self.last_status.shape[0]
         jac = self.step_jacobians_soa(self._last_saved, B)
-        return jac[1].permute(2, 0, 1).contiguous()
+        J = jac[1].permute(2, 0, 1).contiguous()
+        return self._ref_action_jacobian(J) if self.ref_layout is not None else J
+
+    def _ref_action_jacobian(self, J: torch.Tensor) -> torch.Tensor:
+        """[B, 2 n_dev, k_dev] -> [B, 2 n_ref, k_ref]: zero rows for the immobile coordinates, zero columns for forces on them"""
+        lay = self.ref_layout
+        rows = lay._idx(J.device, "state")
+        cols = torch.tensor(lay.action_columns(self._ref_action_map), dtype=torch.long, device=J.device)
+        out = torch.zeros((J.shape[0], 2 * lay.n_ref, len(self._ref_action_map)), dtype=J.dtype, device=J.device)
+        out[:, rows[:, None], cols[None, :]] = J
+        return out
 
     # ---- T-step rollout on the device (SURVEY.md 8(f) row 1) ---------------------------------------
     def _rollout_workspace(self, B: int) -> torch.Tensor:

@@ -1,0 +1,65 @@
+"""GPU half of tests/test_ref_layout.py: a SKEL world whose ground skeleton is IMMOBILE with a free joint - like
+data/skel/fullbody1.skel and cartpole.skel of the reference - through the drop-in surface with the REFERENCE's state length:
+getStateSize() = 2 x (6 + 6), the immobile coordinates pass through a step unchanged with identity rows in the vector-Jacobian product,
+and the mobile coordinates are bit for bit what the device's own (shorter) layout gives."""
+import numpy as np
+import pytest
+import torch
+
+from test_ref_layout import load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_a_world_with_an_immobile_skeleton_speaks_the_references_state_layout(tmp_path):
+    import nimblephysics_amd as na
+    from nimblephysics_amd.timestep import timestep
+    md = load(tmp_path)
+    world = na.World(md, device="cuda:0")
+    lay = world.ref_layout
+    assert world.getNumDofs() == 12 and world.getStateSize() == 24 and world.getActionSize() == 12      # the reference's sizes
+    assert world.n == 6 and world.k == 6                                                               # the device's
+    B = 64
+    rng = np.random.default_rng(5)
+    s = np.zeros((B, 24))
+    s[:, 6 + 1] = rng.uniform(-1, 1, B); s[:, 6 + 3] = rng.normal(0, 0.02, B); s[:, 6 + 4] = -rng.uniform(1e-4, 1e-3, B)     # the cube, touching
+    s[:, 12:18] = rng.normal(0, 0.3, (B, 6))              # velocities of the IMMOBILE skeleton: carried, never used
+    s[:, 18:24] = rng.normal(0, 0.05, (B, 6))
+    a = rng.normal(0, 0.1, (B, 12))
+    g = rng.normal(0, 1, (B, 24))
+    st = torch.tensor(s, device="cuda:0", requires_grad=True); at = torch.tensor(a, device="cuda:0", requires_grad=True)
+    out = timestep(world, st, at)
+    assert out.shape == (B, 24)
+    assert (world.last_status.cpu().numpy() & 1).all(), "the cube rests on the immobile ground: contacts"
+    out.backward(torch.tensor(g, device="cuda:0"))
+    fro = [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17]
+    mob = [6, 7, 8, 9, 10, 11, 18, 19, 20, 21, 22, 23]
+    o = out.detach().cpu().numpy(); gs = st.grad.cpu().numpy(); ga = at.grad.cpu().numpy()
+    assert np.array_equal(o[:, fro], s[:, fro])                                 # frozen coordinates: unchanged ...
+    assert np.array_equal(gs[:, fro], g[:, fro])                                # ... identity rows ...
+    assert not ga[:, :6].any()                                                  # ... and forces on the immobile skeleton do nothing
+    # the mobile part equals the device-layout run bit for bit
+    w2 = na.World(md, device="cuda:0"); w2.ref_layout = None
+    st2 = torch.tensor(s[:, mob], device="cuda:0", requires_grad=True); at2 = torch.tensor(a[:, 6:], device="cuda:0", requires_grad=True)
+    out2 = timestep(w2, st2, at2)
+    out2.backward(torch.tensor(g[:, mob], device="cuda:0"))
+    assert np.array_equal(o[:, mob], out2.detach().cpu().numpy())
+    assert np.array_equal(gs[:, mob], st2.grad.cpu().numpy()) and np.array_equal(ga[:, 6:], at2.grad.cpu().numpy())
+    # World API in the reference's layout
+    world.setState(torch.tensor(s, device="cuda:0")); world.setAction(torch.tensor(a, device="cuda:0"))
+    assert np.array_equal(world.getState().cpu().numpy(), s) and np.array_equal(world.getAction().cpu().numpy()[:, 6:], a[:, 6:])
+    world.step()
+    assert np.array_equal(world.getState().cpu().numpy()[:, fro], s[:, fro])
+    world.setState(torch.tensor(s, device="cuda:0"))
+    snap = na.neural.forwardPass(world)                       # (keeps the record the Jacobian getters differentiate)
+    hl = snap.backpropState(world, torch.tensor(g, device="cuda:0"))
+    assert np.array_equal(hl.lossWrtState.cpu().numpy(), gs) and np.array_equal(hl.lossWrtAction.cpu().numpy(), ga)
+    assert snap.getPosPosJacobian(world).shape == (B, 12, 12)
+    J = world.getStateJacobian().cpu().numpy()
+    assert J.shape == (B, 24, 24) and np.array_equal(J[:, fro][:, :, fro], np.broadcast_to(np.eye(12), (B, 12, 12)))
+    assert not J[:, fro][:, :, mob].any() and not J[:, mob][:, :, fro].any()
+    with pytest.raises(ValueError, match="not zero"):
+        bad = s.copy(); bad[0, 4] = 0.1
+        world.setState(torch.tensor(bad, device="cuda:0"))
+    with pytest.raises(ValueError, match="expected 24"):
+        timestep(world, torch.zeros((B, 12), device="cuda:0", dtype=torch.float64), at)
