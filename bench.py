@@ -239,7 +239,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0, bounds=bounds, streams=streams, slices=None):
+    def measure(noise, steps, warmup, kernel_timing, min_seconds=0.0, bounds=bounds, streams=streams, slices=None, one_handle=False):
         """W untimed + K timed fwd+bwd steps on a fresh synthetic batch of the workload at pose noise `noise`."""
         md, s_np, a_np, wl_desc = make_workload(args.workload, B, 1000 + rank, noise)
         if args.max_contacts > 0 and md.max_contacts:
@@ -264,7 +264,38 @@ def main():
             graphed.state0.copy_(state0[0]); graphed.actions.copy_(action[0])
             graphed.capture()
 
+        deferred = None
+        if one_handle:
+            # ONE World handle in deferred-join mode (include/nimble_amd.h, ABI minor 5): the library runs every slice of a call on an
+            # internal stream and does not join per call; the loss of a slice is enqueued on the slice's stream.  Caller-owned buffers,
+            # reused every step: everything that touches the worlds of slice i runs on stream i, in order.
+            world.set_deferred_join(True)
+            sl = world.slices(B)
+            n2_ = 2 * world.n
+            deferred = dict(sl=sl, nxt=torch.empty((n2_, B), dtype=torch.float64, device=dev),
+                            saved=torch.empty(world.saved_bytes(B), dtype=torch.uint8, device=dev),
+                            status=torch.empty(B, dtype=torch.int32, device=dev),
+                            cache=torch.empty((world.m, B), dtype=torch.float64, device=dev) if world.m > 0 else None,
+                            g=torch.empty((n2_, B), dtype=torch.float64, device=dev), gs=torch.empty((n2_, B), dtype=torch.float64, device=dev),
+                            ga=torch.empty((k, B), dtype=torch.float64, device=dev))
+            torch.cuda.synchronize(dev)
+
         def run(T):
+            if deferred is not None:
+                d = deferred
+                ga_sum = torch.zeros((k, B), dtype=torch.float64, device=dev)
+                world.fork()                                   # (the slices' streams start behind what this stream holds: the zeroed sum)
+                for _ in range(T):
+                    world.step_into(state0[0], action[0], d["nxt"], d["saved"], d["status"], None, d["cache"])      # cold start: no warm start in
+                    for stream, lo, hi in d["sl"]:
+                        with torch.cuda.stream(stream):
+                            torch.mul(d["nxt"][:, lo:hi], 2.0, out=d["g"][:, lo:hi])                               # d/ds' of |s'|^2
+                    world.backward_into(d["saved"], d["g"], d["gs"], d["ga"])
+                    for stream, lo, hi in d["sl"]:
+                        with torch.cuda.stream(stream):
+                            ga_sum[:, lo:hi] += d["ga"][:, lo:hi]                                                   # the control vector is shared by all steps
+                world.join()
+                return shared_parameter_grad(ga_sum), d["status"]                                                 # ONE all-gather per timed region
             ga_total = [torch.zeros((k, hi - lo), dtype=torch.float64, device=dev) for (lo, hi) in bounds]
             status = [None] * len(bounds)
             if args.rollout > 0 and args.graph:      # the same pass replayed from ONE captured HIP graph (nimblephysics_amd.graph.GraphedRollout)
@@ -329,17 +360,26 @@ def main():
                 "desc": wl_desc, "world": world, "slices": len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))}
 
     has_contact = args.workload.endswith("_contact")
-    R = measure(args.joint_noise, args.steps, args.warmup, not args.no_kernel_timing, args.min_seconds)
+    # The timed region is ONE model handle in deferred-join mode (round 6): `--streams k` (k > 0) goes back to round 5's
+    # harness pattern - k Worlds, each on its own stream - which stays as a secondary figure (`four_handles`).
+    one = args.streams == 0 and args.rollout == 0
+    if one:
+        R = measure(args.joint_noise, args.steps, args.warmup, not args.no_kernel_timing, args.min_seconds, [(0, B)], streams[:1], one_handle=True)
+    else:
+        R = measure(args.joint_noise, args.steps, args.warmup, not args.no_kernel_timing, args.min_seconds)
     easy = None
     if has_contact and args.easy_noise > 0 and args.easy_noise != args.joint_noise:
         # the easy distribution: every world resolves at LCP stage 0 (round 1's headline), half the steps, no kernel events
         easy = measure(args.easy_noise, max(1, args.steps // 2), min(args.warmup, 4), False)
-    single = single_call = None
+    single = single_call = one_handle_deferred = None
     if has_contact and len(bounds) > 1 and not args.no_single_stream:
         # the same batch as ONE launch per kernel per step (no stream slices): what the chain costs without the overlap of the slices
         single = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1], slices=1)
         # ... and as ONE call per step with the library's own slicing (what a caller gets who hands over the whole batch at once)
         single_call = measure(args.joint_noise, max(1, args.steps // 2), min(args.warmup, 4), False, 0.0, [(0, B)], streams[:1])
+        # ... and round 5's harness pattern: one World per slice, each on its own HIP stream (what ONE handle in deferred-join mode replaces)
+        if one:
+            one_handle_deferred = measure(args.joint_noise, args.steps, min(args.warmup, 4), False, 0.0)
     host_tensors = None
     if has_contact and not args.no_single_stream and world_size == 1 and args.rollout == 0:
         # the reference's OWN calling convention (python/nimblephysics/timestep.py:31-40): float64 CPU tensors [B, 2n] / [B, k] in, CPU tensors
@@ -454,6 +494,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "reps": len(R["reps"]), "reps_ms_per_step": [round(r / args.steps * 1e3, 4) for r in R["reps"]], "timed_seconds": sum(R["reps"]),
             "config": {"workload": f"{wl_desc}; batch={B} worlds/GPU; fwd+bwd through the C ABI, cold LCP start each step" +
+                                   ("; ONE model handle in deferred-join mode (its slices run on the handle's own streams, the per-slice loss on them)" if one else f"; {len(bounds)} World handle(s), one stream each") +
                                    (f"; one step = one {args.rollout}-step rollout fwd+bwd (warm-started after its first step)" if args.rollout else ""),
                        "n_dofs": n, "contacts": m_rows // 3, "lcp_rows": m_rows, "worlds_per_gpu": B, "dt": md.dt,
                        "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None, "rollout_checkpoint_every": (args.checkpoint_every or None) if args.rollout else None,
@@ -490,7 +531,14 @@ def main():
             out.setdefault("secondary", {})["single_call"] = {
                 "value": units_per_step * ssteps / single_call["elapsed"], "unit": "worlds*timesteps/s", "steps": ssteps,
                 "ms_per_step": single_call["elapsed"] / ssteps * 1e3, "stream_slices": single_call["slices"],
-                "note": "the same batch and distribution handed to ONE World in one call per pass (the library slices the call itself; every call joins before it returns)"}
+                "note": "the same batch and distribution handed to ONE World in one JOINED call per pass - what timestep() gives behind autograd: the "
+                        "library slices the call itself and every call joins before it returns"}
+        if one_handle_deferred is not None:
+            out.setdefault("secondary", {})["four_handles"] = {
+                "value": units_per_step * args.steps / one_handle_deferred["elapsed"], "unit": "worlds*timesteps/s", "steps": args.steps,
+                "ms_per_step": one_handle_deferred["elapsed"] / args.steps * 1e3, "handles": len(bounds),
+                "note": "round 5's harness pattern: the batch cut into one World handle per slice by the caller, every handle on its own HIP stream "
+                        "(what `value` - ONE handle in deferred-join mode, nbl_set_deferred_join - replaces)"}
         if host_tensors is not None:
             out.setdefault("secondary", {})["host_tensors"] = {
                 "value": B * host_tensors["steps"] / host_tensors["elapsed"], "unit": "worlds*timesteps/s", "steps": host_tensors["steps"],

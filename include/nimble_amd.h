@@ -204,8 +204,9 @@ const char* nbl_last_error(void);
  *   minor 3: max_contacts up to 16 (32 colliders, 64 pairs); + nbl_model_max_contacts, nbl_selftest_pinv_rows; the Dantzig self-test takes n <= 48.
  *   minor 4: max_contacts up to 64 (64 colliders, 512 pairs: the general instantiation); the Dantzig self-test takes n <= 192;
  *            nbl_workspace_bytes of such a model includes 1.5 MB of scratch matrices per world; max_contacts 65 .. 128: a second general
- *            instantiation of 384 rows (5.9 MB of scratch per world), the Dantzig self-test then takes n <= 384. */
-#define NBL_ABI_MINOR 4
+ *            instantiation of 384 rows (5.9 MB of scratch per world), the Dantzig self-test then takes n <= 384.
+ *   minor 5: + nbl_set_deferred_join, nbl_slice_stream, nbl_fork_slices, nbl_join_slices (one handle, slices that are not joined per call). */
+#define NBL_ABI_MINOR 5
 int32_t nbl_version(void);
 
 /* Number of visible HIP devices (0 if none). */
@@ -404,6 +405,22 @@ int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes
  * call with B worlds will use. */
 int32_t nbl_set_slices(nbl_model* m, int32_t slices);
 int32_t nbl_slices_for(const nbl_model* m, int64_t B);
+/* Deferred join (ABI minor 5): with it enabled nbl_step_forward / nbl_step_backward return with their slices in flight: slice 0 on the
+ * `stream` of the call (always hand in the same one), the others on internal streams of the handle, none waiting for another and
+ * nothing recorded or awaited on `stream` per call (four busy streams is what the hardware runs side by side: the caller's is one
+ * of them).  The forward pass of one slice overlaps the
+ * backward pass of another across consecutive calls on ONE handle (what a caller otherwise gets from one handle per slice on its
+ * own stream; the reference has no counterpart: its World::step is synchronous on one CPU thread).  Ordering against the caller's
+ * streams is explicit: nbl_fork_slices(m, stream) makes every slice stream wait for what `stream` holds (after uploading inputs
+ * there), nbl_join_slices(m, stream) makes `stream` wait for everything the slices hold (before consuming results there).  A result
+ * can also be consumed on its slice's own stream: nbl_slice_stream gives the stream (a hipStream_t; NULL for slice 0: the calls' own) and the world range
+ * [first_world, end_world) of slice `slice` of a call with B worlds - enqueue the per-slice loss there.  The buffers of a call must
+ * stay valid until its slices have run.  nbl_slices_for(m, B) is the slice count (4 from 4096 worlds on).  Results are bit for bit
+ * those of the joined calls. */
+int32_t nbl_set_deferred_join(nbl_model* m, int32_t enabled);
+int32_t nbl_slice_stream(nbl_model* m, int64_t B, int32_t slice, void** stream, int64_t* first_world, int64_t* end_world);
+int32_t nbl_fork_slices(nbl_model* m, void* stream);
+int32_t nbl_join_slices(nbl_model* m, void* stream);
 /* enabled = 0: off (and reset); 1: HIP events around every kernel launch; N > 1: around the launches of every N-th forward /
  * backward call only (sampling keeps the perturbation of a timed region below 1 %). */
 int32_t nbl_set_timing(nbl_model* m, int32_t enabled);

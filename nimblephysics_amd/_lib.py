@@ -83,6 +83,14 @@ def lib():
     L.nbl_set_slices.restype = C.c_int32
     L.nbl_slices_for.argtypes = [vp, C.c_int64]
     L.nbl_slices_for.restype = C.c_int32
+    L.nbl_set_deferred_join.argtypes = [vp, C.c_int32]
+    L.nbl_set_deferred_join.restype = C.c_int32
+    L.nbl_slice_stream.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.nbl_slice_stream.restype = C.c_int32
+    L.nbl_join_slices.argtypes = [vp, vp]
+    L.nbl_join_slices.restype = C.c_int32
+    L.nbl_fork_slices.argtypes = [vp, vp]
+    L.nbl_fork_slices.restype = C.c_int32
     L.nbl_set_launch_lanes.argtypes = [vp, C.c_int32, C.c_int32]
     L.nbl_set_launch_lanes.restype = C.c_int32
     L.nbl_set_timing.argtypes = [vp, C.c_int32]
@@ -111,7 +119,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "nbl_last_error", "nbl_version", "nbl_device_count", "nbl_model_create", "nbl_model_destroy",
     "nbl_model_num_dofs", "nbl_model_num_action", "nbl_model_lcp_rows", "nbl_workspace_bytes", "nbl_saved_bytes",
-    "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing", "nbl_set_launch_lanes", "nbl_set_slices", "nbl_slices_for", "nbl_rollout_workspace_bytes", "nbl_rollout_forward", "nbl_rollout_backward",
+    "nbl_step_forward", "nbl_step_backward", "nbl_transpose_to_soa", "nbl_transpose_from_soa", "nbl_set_timing", "nbl_set_launch_lanes", "nbl_set_slices", "nbl_slices_for", "nbl_set_deferred_join", "nbl_slice_stream", "nbl_join_slices", "nbl_fork_slices", "nbl_rollout_workspace_bytes", "nbl_rollout_forward", "nbl_rollout_backward",
     "nbl_set_body_inertia", "nbl_set_body_inertias", "nbl_set_inertia_params", "nbl_set_inertia_params_on", "nbl_num_inertia_params", "nbl_backward_inertia", "nbl_rollout_backward_inertia",
     "nbl_rollout_checkpoint_bytes", "nbl_rollout_forward_checkpointed", "nbl_rollout_backward_checkpointed",
     "nbl_get_timing", "nbl_kernel_count", "nbl_kernel_name", "nbl_kernel_timing", "nbl_selftest_lcp_dantzig", "nbl_selftest_lcp_dantzig_timed", "nbl_selftest_lcp_cascade", "nbl_selftest_pinv",

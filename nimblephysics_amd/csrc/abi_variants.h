@@ -58,6 +58,10 @@
 #define nbl_set_slices NBL_V(nbl_set_slices)
 #define nbl_set_timing NBL_V(nbl_set_timing)
 #define nbl_slices_for NBL_V(nbl_slices_for)
+#define nbl_set_deferred_join NBL_V(nbl_set_deferred_join)
+#define nbl_slice_stream NBL_V(nbl_slice_stream)
+#define nbl_join_slices NBL_V(nbl_join_slices)
+#define nbl_fork_slices NBL_V(nbl_fork_slices)
 #define nbl_step_backward NBL_V(nbl_step_backward)
 #define nbl_step_forward NBL_V(nbl_step_forward)
 #define nbl_transpose_from_soa NBL_V(nbl_transpose_from_soa)

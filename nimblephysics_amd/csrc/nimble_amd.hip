@@ -66,6 +66,7 @@ struct nbl_model {
   int timingPeriod = 1;     // every timingPeriod-th forward / backward call carries HIP events
   int64_t fwdCalls = 0, bwdCalls = 0;
   int slices = 0;                    // batch slices over HIP streams (0 = auto), nbl_set_slices / NBL_SLICES
+  bool deferJoin = false;            // nbl_set_deferred_join: every slice on an internal stream, calls return without joining (nbl_join_slices joins)
   std::vector<hipStream_t> side;     // internal streams of slices 1..
   std::vector<hipEvent_t> sideDone;
   hipEvent_t fork = nullptr;
@@ -147,6 +148,7 @@ static int rolloutSlicesFor(const nbl_model* m, int64_t B) {
   return sl;
 }
 static int slicesFor(const nbl_model* m, int64_t B) {
+  if (m->deferJoin) return rolloutSlicesFor(m, B);      // nothing joins inside the call: as many slices as a rollout takes (4 from 4096 worlds)
   int sl = m->slices > 0 ? m->slices : ((m->hasContact && B >= 4096) ? 2 : 1);
   if (sl > NBL_MAX_SLICES) sl = NBL_MAX_SLICES;
   while (sl > 1 && B / sl < 256) sl--;
@@ -172,23 +174,33 @@ static int32_t ensureAux(nbl_model* m, int need) {
   }
   return NBL_OK;
 }
-// run fn(slice index, first world, one-past-last world, stream) for every slice, fork/join around the caller's stream
+// worlds per slice and the slices of a call
+static int64_t slicePer(int64_t B, int sl) { return (((B + sl - 1) / sl) + 15) & ~(int64_t)15; }
+// run fn(slice index, first world, one-past-last world, stream) for every slice, fork/join around the caller's stream.
+// DEFERRED JOIN (nbl_set_deferred_join): slice 0 runs on the caller's stream, the others on internal streams of the handle
+// (ordered after the caller's stream only where the caller says so: nbl_fork_slices), and the call returns WITHOUT making the caller's
+// stream wait for them: the slices of
+// consecutive calls - the forward pass of one, the backward pass of another - overlap like the four-handle pattern's, with ONE handle.
+// Whoever consumes a result does so on the slice's stream (nbl_slice_stream) or after nbl_join_slices.
 template <class Fn>
 static int32_t forSlices(nbl_model* m, int64_t B, int sl, hipStream_t s, Fn fn) {
+  const bool defer = m->deferJoin;
   if (sl > 1) {
     const int32_t rc = ensureSideStreams(m, sl - 1);
     if (rc != NBL_OK) return rc;
-    HIP_TRY(hipEventRecord(m->fork, s));
+    // (deferred: the call does not touch the caller's stream at all - an event recorded there per call queues behind whatever shares its
+    //  hardware queue, a slice's kernels included, and the slices of the NEXT call then wait for it: measured, the steps ran in lock-step)
+    if (!defer) HIP_TRY(hipEventRecord(m->fork, s));
   }
-  const int64_t per = (((B + sl - 1) / sl) + 15) & ~(int64_t)15;
+  const int64_t per = slicePer(B, sl);
   for (int i = 0; i < sl; i++) {
     const int64_t b0 = (int64_t)i * per, b1 = std::min(B, b0 + per);
     if (b0 >= b1) break;
-    hipStream_t st = i == 0 ? s : m->side[i - 1];
-    if (i > 0) HIP_TRY(hipStreamWaitEvent(st, m->fork, 0));
+    hipStream_t st = i == 0 ? s : m->side[i - 1];          // (slice 0 on the caller's stream in both modes: it is one of the workers)
+    if (i > 0 && !defer) HIP_TRY(hipStreamWaitEvent(st, m->fork, 0));
     const int32_t rc = fn(i, b0, b1, st);
     if (rc != NBL_OK) return rc;
-    if (i > 0) { HIP_TRY(hipEventRecord(m->sideDone[i - 1], st)); HIP_TRY(hipStreamWaitEvent(s, m->sideDone[i - 1], 0)); }
+    if (i > 0 && !defer) { HIP_TRY(hipEventRecord(m->sideDone[i - 1], st)); HIP_TRY(hipStreamWaitEvent(s, m->sideDone[i - 1], 0)); }
   }
   return NBL_OK;
 }
@@ -1459,6 +1471,40 @@ int32_t nbl_set_slices(nbl_model* m, int32_t slices) {
   return NBL_OK;
 }
 int32_t nbl_slices_for(const nbl_model* m, int64_t B) { return (m && B > 0) ? slicesFor(m, B) : 0; }
+int32_t nbl_set_deferred_join(nbl_model* m, int32_t enabled) {
+  if (!m) return fail(NBL_E_BADARG, "null model");
+  m->deferJoin = enabled != 0;
+  if (m->deferJoin) { const int32_t rc = ensureSideStreams(m, NBL_MAX_SLICES - 1); if (rc != NBL_OK) return rc; }   // (nbl_fork_slices before the first call reaches every stream)
+  return NBL_OK;
+}
+int32_t nbl_slice_stream(nbl_model* m, int64_t B, int32_t slice, void** stream, int64_t* first_world, int64_t* end_world) {
+  if (!m || B <= 0) return fail(NBL_E_BADARG, "null model or B <= 0");
+  if (!m->deferJoin) return fail(NBL_E_BADARG, "nbl_slice_stream: the handle is not in deferred-join mode (nbl_set_deferred_join)");
+  const int sl = slicesFor(m, B);
+  if (slice < 0 || slice >= sl) return fail(NBL_E_BADARG, "slice out of range");
+  const int32_t rc = ensureSideStreams(m, sl - 1);
+  if (rc != NBL_OK) return rc;
+  const int64_t per = slicePer(B, sl);
+  if (stream) *stream = slice == 0 ? nullptr : (void*)m->side[slice - 1];      // (NULL: slice 0 runs on the stream the calls are given)
+  if (first_world) *first_world = std::min(B, (int64_t)slice * per);
+  if (end_world) *end_world = std::min(B, (int64_t)(slice + 1) * per);
+  return NBL_OK;
+}
+int32_t nbl_fork_slices(nbl_model* m, void* stream) {
+  if (!m) return fail(NBL_E_BADARG, "null model");
+  if (!m->fork) HIP_TRY(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(m->fork, (hipStream_t)stream));
+  for (size_t i = 0; i < m->side.size(); i++) HIP_TRY(hipStreamWaitEvent(m->side[i], m->fork, 0));
+  return NBL_OK;
+}
+int32_t nbl_join_slices(nbl_model* m, void* stream) {
+  if (!m) return fail(NBL_E_BADARG, "null model");
+  for (size_t i = 0; i < m->side.size(); i++) {
+    HIP_TRY(hipEventRecord(m->sideDone[i], m->side[i]));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, m->sideDone[i], 0));
+  }
+  return NBL_OK;
+}
 
 int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes) {
   if (!m) return fail(NBL_E_BADARG, "null model");

@@ -54,6 +54,10 @@
   int32_t nbl_set_launch_lanes##S(void*, int32_t, int32_t);                                                                                \
   int32_t nbl_set_slices##S(void*, int32_t);                                                                                               \
   int32_t nbl_slices_for##S(const void*, int64_t);                                                                                         \
+  int32_t nbl_set_deferred_join##S(void*, int32_t);                                                                                        \
+  int32_t nbl_slice_stream##S(void*, int64_t, int32_t, void**, int64_t*, int64_t*);                                                        \
+  int32_t nbl_join_slices##S(void*, void*);                                                                                                \
+  int32_t nbl_fork_slices##S(void*, void*);                                                                                                \
   int32_t nbl_set_timing##S(void*, int32_t);                                                                                               \
   int32_t nbl_get_timing##S(void*, double*, int64_t*, double*, int64_t*);                                                                  \
   int32_t nbl_kernel_count##S(void);                                                                                                       \
@@ -102,6 +106,10 @@ struct Variant {
   int32_t (*set_launch_lanes)(void*, int32_t, int32_t);
   int32_t (*set_slices)(void*, int32_t);
   int32_t (*slices_for)(const void*, int64_t);
+  int32_t (*set_deferred_join)(void*, int32_t);
+  int32_t (*slice_stream)(void*, int64_t, int32_t, void**, int64_t*, int64_t*);
+  int32_t (*join_slices)(void*, void*);
+  int32_t (*fork_slices)(void*, void*);
   int32_t (*set_timing)(void*, int32_t);
   int32_t (*get_timing)(void*, double*, int64_t*, double*, int64_t*);
   int32_t (*kernel_timing)(void*, int32_t, double*, int64_t*);
@@ -113,6 +121,7 @@ struct Variant {
    nbl_rollout_workspace_bytes##S, nbl_rollout_forward##S, nbl_rollout_backward##S, nbl_rollout_backward_inertia##S,                          \
    nbl_rollout_checkpoint_bytes##S, nbl_rollout_forward_checkpointed##S, nbl_rollout_backward_checkpointed##S,                               \
    nbl_selftest_lcp_dantzig_timed##S, nbl_selftest_pinv_rows##S, nbl_set_launch_lanes##S, nbl_set_slices##S, nbl_slices_for##S,               \
+   nbl_set_deferred_join##S, nbl_slice_stream##S, nbl_join_slices##S, nbl_fork_slices##S,                                                                         \
    nbl_set_timing##S, nbl_get_timing##S, nbl_kernel_timing##S}
 constexpr int kNumVariants = 4;
 static const Variant kVariants[kNumVariants] = {NBL_VARIANT_TABLE(8, _c8), NBL_VARIANT_TABLE(16, _c16), NBL_VARIANT_TABLE(64, _c64),
@@ -283,6 +292,12 @@ int32_t nbl_transpose_from_soa(const double* src_db, double* dst_bd, int64_t B, 
 int32_t nbl_set_launch_lanes(nbl_model* m, int32_t tree_lanes, int32_t lcp_lanes) { return NBL_FWD(m, set_launch_lanes, tree_lanes, lcp_lanes); }
 int32_t nbl_set_slices(nbl_model* m, int32_t slices) { return NBL_FWD(m, set_slices, slices); }
 int32_t nbl_slices_for(const nbl_model* m, int64_t B) { return NBL_GET(m, slices_for, B); }
+int32_t nbl_set_deferred_join(nbl_model* m, int32_t enabled) { return NBL_FWD(m, set_deferred_join, enabled); }
+int32_t nbl_slice_stream(nbl_model* m, int64_t B, int32_t slice, void** stream, int64_t* first_world, int64_t* end_world) {
+  return NBL_FWD(m, slice_stream, B, slice, stream, first_world, end_world);
+}
+int32_t nbl_join_slices(nbl_model* m, void* stream) { return NBL_FWD(m, join_slices, stream); }
+int32_t nbl_fork_slices(nbl_model* m, void* stream) { return NBL_FWD(m, fork_slices, stream); }
 int32_t nbl_set_timing(nbl_model* m, int32_t enabled) { return NBL_FWD(m, set_timing, enabled); }
 int32_t nbl_get_timing(nbl_model* m, double* fwd_ms_sum, int64_t* fwd_count, double* bwd_ms_sum, int64_t* bwd_count) {
   return NBL_FWD(m, get_timing, fwd_ms_sum, fwd_count, bwd_ms_sum, bwd_count);

@@ -582,6 +582,49 @@ class World:
         nxt, _, _ = self.step_soa(self._state, self._action, want_saved=False)
         self._state = nxt
 
+    # ---- deferred join: one handle, slices that are not joined per call (nbl_set_deferred_join, include/nimble_amd.h) ----
+    def set_deferred_join(self, enabled: bool = True):
+        """With it on, step_into / backward_into (and step_soa / backward_soa) return while their slices still run on the handle's internal
+        streams; consume a result on its slice's stream (`slices(B)`) or after `join()`.  Buffers handed to a call must outlive it: use
+        the *_into entry points with buffers you keep (torch's caching allocator knows nothing of the internal streams)."""
+        check(self._L.nbl_set_deferred_join(self._h, 1 if enabled else 0), "nbl_set_deferred_join")
+        self._deferred = bool(enabled)
+
+    def slices(self, B: int):
+        """[(torch stream, first world, one-past-last world)] of a deferred-join call with B worlds"""
+        out = []
+        for i in range(self._L.nbl_slices_for(self._h, B)):
+            st, b0, b1 = C.c_void_p(), C.c_int64(), C.c_int64()
+            check(self._L.nbl_slice_stream(self._h, B, i, C.byref(st), C.byref(b0), C.byref(b1)), "nbl_slice_stream")
+            stream = torch.cuda.current_stream(self.device) if not st.value else torch.cuda.ExternalStream(st.value, device=self.device)
+            out.append((stream, int(b0.value), int(b1.value)))     # (slice 0 runs on the stream of the calls: the current one)
+        return out
+
+    def fork(self):
+        """the handle's slice streams wait for everything the current stream holds (inputs produced there)"""
+        check(self._L.nbl_fork_slices(self._h, self._stream()), "nbl_fork_slices")
+
+    def join(self):
+        """the current stream waits for everything the handle's slices hold"""
+        check(self._L.nbl_join_slices(self._h, self._stream()), "nbl_join_slices")
+
+    def step_into(self, state, action, nxt, saved, status, cache_in=None, cache_out=None):
+        """nbl_step_forward into caller-owned buffers (state [2n][B], action [k][B], nxt [2n][B], saved nbl_saved_bytes, status int32 [B],
+        the warm start in / out [m][B] or None)"""
+        B = state.shape[1]
+        ws = self._workspace(B)
+        check(self._L.nbl_step_forward(self._h, B, _ptr(state), _ptr(action), _ptr(cache_in), _ptr(nxt), _ptr(cache_out),
+                                       _ptr(saved), _ptr(status), _ptr(ws), ws.numel(), self._stream()), "nbl_step_forward")
+
+    def backward_into(self, saved, grad_next, grad_state, grad_action):
+        B = grad_next.shape[1]
+        ws = self._workspace(B)
+        check(self._L.nbl_step_backward(self._h, B, _ptr(saved), _ptr(grad_next), _ptr(grad_state), _ptr(grad_action), _ptr(ws), ws.numel(),
+                                        self._stream()), "nbl_step_backward")
+
+    def saved_bytes(self, B: int) -> int:
+        return int(self._L.nbl_saved_bytes(self._h, B))
+
     def set_slices(self, slices: int = 0):
         """Batch slices over HIP streams (0 = auto); results are independent of it."""
         check(self._L.nbl_set_slices(self._h, slices), "nbl_set_slices")

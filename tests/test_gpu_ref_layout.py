@@ -51,6 +51,7 @@ def test_a_world_with_an_immobile_skeleton_speaks_the_references_state_layout(tm
     world.step()
     assert np.array_equal(world.getState().cpu().numpy()[:, fro], s[:, fro])
     world.setState(torch.tensor(s, device="cuda:0"))
+    world.reset_lcp_cache()                                   # (cold LCP start, like the timestep() call above)
     snap = na.neural.forwardPass(world)                       # (keeps the record the Jacobian getters differentiate)
     hl = snap.backpropState(world, torch.tensor(g, device="cuda:0"))
     assert np.array_equal(hl.lossWrtState.cpu().numpy(), gs) and np.array_equal(hl.lossWrtAction.cpu().numpy(), ga)

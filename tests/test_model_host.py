@@ -71,7 +71,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(L, sym), f"{sym} declared in the header but not exported"
     assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
     L.nbl_version.restype = ctypes.c_int32
-    assert L.nbl_version() == int(re.search(r"#define NBL_ABI_MINOR (\d+)", hdr).group(1)) == 4   # NBL_ABI_MINOR of include/nimble_amd.h
+    assert L.nbl_version() == int(re.search(r"#define NBL_ABI_MINOR (\d+)", hdr).group(1)) == 5   # NBL_ABI_MINOR of include/nimble_amd.h
 
 
 def test_header_is_plain_c_and_the_python_mirror_matches_its_layout(tmp_path):
