@@ -327,8 +327,8 @@ int32_t nbl_rollout_backward_inertia(nbl_model* m, int64_t B, int32_t T, const v
                                      size_t workspace_bytes, void* stream);
 
 /*
- * Checkpointed rollout: the saved records of `segment` steps are resident instead of T (a record is ~32 kB per world-step on the
- * metric model, the states 16 n bytes).  The forward pass writes record t into slot t % segment of `saved`
+ * Checkpointed rollout: the saved records of `segment` steps are resident instead of T (a record is 26.7 kB per world-step on the
+ * metric model - nbl_saved_bytes / B -, the states 16 n bytes).  The forward pass writes record t into slot t % segment of `saved`
  * (segment * nbl_saved_bytes(m, B) bytes) and keeps the LCP warm start entering every segment in `checkpoints`
  * (nbl_rollout_checkpoint_bytes(m, B, T, segment) bytes; may be NULL when warm_start == 0 or the model has no colliders).  The
  * backward pass walks the segments from the last to the first: it runs the steps of a segment again from states[k * segment] -

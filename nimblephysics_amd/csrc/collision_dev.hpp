@@ -6,6 +6,10 @@
 // FACE_VERTEX / EDGE_EDGE with edge annotations :1280-1381, pure edge-edge case :1014-1054), written
 // for one world per lane: every lane runs its own branch pattern, the clip polygons live in small
 // private arrays, results are appended to the lane's contact list in HBM.
+// Attribution: the algorithm restated here derives from the Open Dynamics Engine (ODE), Copyright (C) 2001-2003 Russell L. Smith, which the
+// reference vendors under ODE's BSD-style licence (dart/external/odelcpsolver/, dart/collision/dart/DARTCollide.cpp); this file is an
+// independent restatement for another execution model - ODE's arithmetic order and, where the bit-for-bit tests need them recognisable,
+// its identifiers are kept on purpose.
 #pragma once
 #include "spatial_dev.hpp"
 

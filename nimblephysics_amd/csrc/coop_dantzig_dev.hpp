@@ -7,6 +7,10 @@
 // LDS, factorisation / triangular solves / products are lane-parallel, step-length events are found by a wave arg-min
 // with the reference's scan order as the tie-break.  Same mathematics and event order as dantzig_dev.hpp (which restates
 // dart/external/odelcpsolver/lcp.cpp:780-1113 and is pinned against the reference's own dSolveLCP on the host).
+// Attribution: the algorithm restated here derives from the Open Dynamics Engine (ODE), Copyright (C) 2001-2003 Russell L. Smith, which the
+// reference vendors under ODE's BSD-style licence (dart/external/odelcpsolver/, dart/collision/dart/DARTCollide.cpp); this file is an
+// independent restatement for another execution model - ODE's arithmetic order and, where the bit-for-bit tests need them recognisable,
+// its identifiers are kept on purpose.
 #pragma once
 #include "coop_dev.hpp"
 

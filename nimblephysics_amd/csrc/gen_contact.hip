@@ -266,7 +266,15 @@ __host__ __device__ inline size_t genFinalDoubles(int cap) { return (size_t)4 * 
 // dynamic LDS of k_contact_solve_gen for a model of `rows` rows: the rows' pool + the final-result arrays
 // ... + ONE fast matrix of GEN_FAST_N x GEN_FAST_N (8 kB: the scaled matrix of the Gauss-Seidel sweeps of a problem of up to 32 rows; with
 // 190 registers per lane eight worlds share a CU, so up to 20 kB of LDS per world are free)
-__host__ __device__ inline size_t genSolveLdsBytes(int rows) { const int cap = genRowsCap(rows); return (genRowsDoubles(cap) + genFinalDoubles(cap) + GEN_SOLVE_FAST_MATS * GEN_FAST_N * GEN_FAST_N) * sizeof(double); }
+// ... + the 16 scratch VECTORS of the cascade (the Dantzig driver's x, w, dx, dw, ell, ..., the compacted problem's x, b, lo, hi, the
+// candidate) when the model has at most GEN_VEC_LDS_ROWS rows: in HBM scratch every barrier after a store to one of them waited for the
+// store to land (hundreds of barriers per world); the matrices stay in HBM scratch.
+constexpr int GEN_VEC_LDS_ROWS = 96;
+__host__ __device__ inline size_t genSolveVecDoubles(int rows) { return rows <= GEN_VEC_LDS_ROWS ? (size_t)16 * rows : 0; }
+__host__ __device__ inline size_t genSolveLdsBytes(int rows) {
+  const int cap = genRowsCap(rows);
+  return (genRowsDoubles(cap) + genFinalDoubles(cap) + GEN_SOLVE_FAST_MATS * GEN_FAST_N * GEN_FAST_N + genSolveVecDoubles(rows)) * sizeof(double);
+}
 
 __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE_GEN) void k_contact_solve_gen(DevModel mdl, const DevContactModel* __restrict__ cm, int64_t B, double* __restrict__ saved,
                                                           SavedLayout lay, const double* __restrict__ cacheIn, double* __restrict__ cacheOut,
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE_GEN) void k_contact_solve
   }
   GenScratch S = genScratchOf(gws, b, dn + lay.pinv, ldr);
   if (GEN_SOLVE_FAST_MATS > 0) { S.fast = fastMat; S.fastN = GEN_FAST_N; S.fastMats = GEN_SOLVE_FAST_MATS; }
+  if (genSolveVecDoubles(ldr) > 0) { S.vec = fastMat + GEN_SOLVE_FAST_MATS * GEN_FAST_N * GEN_FAST_N; S.vecFast = true; }      // the cascade's vectors in LDS
   GEN_T0();
   GEN_CNT(10);
   // ---- the rows ----
@@ -411,8 +420,9 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE_GEN) void k_contact_solve
   GEN_T(0);
   if (!pinvValid) {
     if (K.nc > 0) {
-      genBuildQ(w, A, ldr, R, K, 0.0, S.mat[0], Fn.cfm);
-      genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc, K.nu == 0);
+      const GenPinvPair pp = genPinvPair(S, m);
+      genBuildQ(w, A, ldr, R, K, 0.0, pp.M, Fn.cfm, pp.ld);
+      genPinv(w, R, pp.M, pp.G, S.mat[2], S.mat[3], m, K.nc, K.nu == 0, pp.ld);
     } else {
       for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) S.mat[3][(size_t)i * ldr + j] = 0.0;
       w.sync();

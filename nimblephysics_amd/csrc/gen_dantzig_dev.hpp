@@ -9,6 +9,10 @@
 // compiled dSolveLCP up to 192 rows; tests/test_gpu_general.py on the device).  The wavefront-cooperative statement of the same driver
 // (coop_dantzig_dev.hpp) is what the 24- and 48-row builds run; it owes its speed to lane = row and cannot go past 64 rows.
 // Contact problems have no unbounded rows (nub = 0: the driver's initial factorisation does not occur).
+// Attribution: the algorithm restated here derives from the Open Dynamics Engine (ODE), Copyright (C) 2001-2003 Russell L. Smith, which the
+// reference vendors under ODE's BSD-style licence (dart/external/odelcpsolver/, dart/collision/dart/DARTCollide.cpp); this file is an
+// independent restatement for another execution model - ODE's arithmetic order and, where the bit-for-bit tests need them recognisable,
+// its identifiers are kept on purpose.
 #pragma once
 #include "gen_lcp_dev.hpp"
 

@@ -167,8 +167,8 @@ DEV GenClasses genClassify(const W& w, GenRows& R, const double* X, bool ignoreF
 // Q[i][s] = A[i][s] + [s normal] sum_{u = s+1, s+2 upper-bound} E[u] A[i][u] + cfm [i == s] for clamping i and s, zero elsewhere
 // (coopBuildQ of coop_dev.hpp with loops instead of lanes) -> M (row-major, leading dimension R.ld)
 template <class W>
-DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const GenClasses& K, double cfm, double* M, const double* cfmRow = nullptr) {
-  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
+DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const GenClasses& K, double cfm, double* M, const double* cfmRow = nullptr, int ldM = 0) {
+  const int ld = ldM > 0 ? ldM : R.ld;      // leading dimension of M (default: that of the scratch matrices - the model's rows, rounded up)
   const int m = R.m;
   for (int s = w.lane(); s < m; s += w.lanes()) {
     const bool colOn = R.cls[s] == RC_CLAMPING;
@@ -200,10 +200,11 @@ DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const
 // deficient: R = R1 [I W], W = R1^-1 R2, and the minimum-norm solution of R u = g is u = [I; W^T] (I + W W^T)^-1 R1^-1 g - the same
 // algebra as coopPinvImpl (coop_dev.hpp), which explains why that is as accurate as the second Householder pass.  Returns the rank.
 template <class W>
-DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue, bool symPsd = false) {
-  const int ld = R.ld;              // leading dimension of the scratch matrices (the model's rows, rounded up)
+DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue, bool symPsd = false, int ldMG = 0) {
+  const int ld = R.ld;              // leading dimension of T and P (the scratch matrices: the model's rows, rounded up)
+  const int lm = ldMG > 0 ? ldMG : ld;   // ... and of M and G: the caller may hand in a packed pair in fast memory (genPinvFast)
   const int ln = w.lane(), nl = w.lanes();
-  for (int j = ln; j < m; j += nl) { R.done[j] = 0; for (int i = 0; i < m; i++) G[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0; }
+  for (int j = ln; j < m; j += nl) { R.done[j] = 0; for (int i = 0; i < m; i++) G[(size_t)i * lm + j] = (i == j) ? 1.0 : 0.0; }
   w.sync();
   // Rank threshold: the reference's eps * size * |R_00| (CGGM.cpp:280, LCPUtils.cpp:113).  For a SYMMETRIC positive semi-definite matrix
   // (A on the guess rows; Q with no friction row on its bound) 64 x that, the policy of the 24- / 48-row builds' Cholesky route
@@ -223,8 +224,8 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
       if (R.done[j]) continue;
       double s0 = 0.0, s1 = 0.0;
       int i = k;
-      for (; i + 1 < m; i += 2) { const double a = M[(size_t)i * ld + j], b = M[(size_t)(i + 1) * ld + j]; s0 = fma(a, a, s0); s1 = fma(b, b, s1); }
-      if (i < m) { const double a = M[(size_t)i * ld + j]; s0 = fma(a, a, s0); }
+      for (; i + 1 < m; i += 2) { const double a = M[(size_t)i * lm + j], b = M[(size_t)(i + 1) * lm + j]; s0 = fma(a, a, s0); s1 = fma(b, b, s1); }
+      if (i < m) { const double a = M[(size_t)i * lm + j]; s0 = fma(a, a, s0); }
       const double nrm = s0 + s1;
       if (nrm > myBest) { myBest = nrm; myCol = j; }
     }
@@ -233,7 +234,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     if (!(best > thr * thr * best0) || !(best > 0.0)) break;
     const int p = w.minAllI(myBest == best ? myCol : 0x7fffffff);
     // the reflector of column p: V[i] = x_i (unscaled), v = x - alpha e_k scaled so that v_k = 1
-    for (int i = k + ln; i < m; i += nl) V[i] = M[(size_t)i * ld + p];
+    for (int i = k + ln; i < m; i += nl) V[i] = M[(size_t)i * lm + p];
     w.sync();
     const double akk = V[k];
     double below = 0.0;
@@ -251,15 +252,15 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
       double* Mc = carried ? G : M;
       if (!carried && (R.done[j] || j == p)) continue;
       double d = 0.0;
-      for (int i = k + 1; i < m; i++) d = fma(V[i], Mc[(size_t)i * ld + j], d);
-      d = fma(vinv, d, Mc[(size_t)k * ld + j]) * tau;
-      Mc[(size_t)k * ld + j] -= d;
+      for (int i = k + 1; i < m; i++) d = fma(V[i], Mc[(size_t)i * lm + j], d);
+      d = fma(vinv, d, Mc[(size_t)k * lm + j]) * tau;
+      Mc[(size_t)k * lm + j] -= d;
       const double dv = d * vinv;
-      for (int i = k + 1; i < m; i++) Mc[(size_t)i * ld + j] = fma(-dv, V[i], Mc[(size_t)i * ld + j]);
+      for (int i = k + 1; i < m; i++) Mc[(size_t)i * lm + j] = fma(-dv, V[i], Mc[(size_t)i * lm + j]);
     }
     w.sync();
-    if (ln == 0) { M[(size_t)k * ld + p] = alpha; R.done[p] = 1; R.perm[k] = p; }
-    for (int i = k + 1 + ln; i < m; i += nl) M[(size_t)i * ld + p] = 0.0;
+    if (ln == 0) { M[(size_t)k * lm + p] = alpha; R.done[p] = 1; R.perm[k] = p; }
+    for (int i = k + 1 + ln; i < m; i += nl) M[(size_t)i * lm + p] = 0.0;
     w.sync();
     rank = k + 1;
   }
@@ -274,7 +275,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     w.sync();
     return 0;
   }
-  for (int k = ln; k < r; k += nl) R.invd[k] = 1.0 / M[(size_t)k * ld + R.perm[k]];
+  for (int k = ln; k < r; k += nl) R.invd[k] = 1.0 / M[(size_t)k * lm + R.perm[k]];
   w.sync();
   // x = R1^-1 (column) in place, R1[i][k] = M[i][perm[k]]: the columns of G1 (right-hand sides) and, rank deficient, those of R2
   const int nExtra = r >= cTrue ? 0 : m - r;
@@ -283,15 +284,15 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     const int j = jj < m ? jj : R.perm[r + (jj - m)];
     for (int kk = r - 1; kk >= 0; kk--) {
       const int pk = R.perm[kk];
-      const double y = Mc[(size_t)kk * ld + j] * R.invd[kk];
-      Mc[(size_t)kk * ld + j] = y;
-      for (int i = 0; i < kk; i++) Mc[(size_t)i * ld + j] = fma(-M[(size_t)i * ld + pk], y, Mc[(size_t)i * ld + j]);
+      const double y = Mc[(size_t)kk * lm + j] * R.invd[kk];
+      Mc[(size_t)kk * lm + j] = y;
+      for (int i = 0; i < kk; i++) Mc[(size_t)i * lm + j] = fma(-M[(size_t)i * lm + pk], y, Mc[(size_t)i * lm + j]);
     }
   }
   w.sync();
   if (r >= cTrue) {
     for (int j = ln; j < m; j += nl) {
-      for (int kk = 0; kk < r; kk++) P[(size_t)R.perm[kk] * ld + j] = G[(size_t)kk * ld + j];
+      for (int kk = 0; kk < r; kk++) P[(size_t)R.perm[kk] * ld + j] = G[(size_t)kk * lm + j];
       for (int pp = r; pp < m; pp++) P[(size_t)R.perm[pp] * ld + j] = 0.0;
     }
     w.sync();
@@ -302,7 +303,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   for (int e = ln; e < r * r; e += nl) {
     const int a = e / r, b = e - a * r;
     double s = (a == b) ? 1.0 : 0.0;
-    for (int t = 0; t < nw; t++) { const int c = R.perm[r + t]; s = fma(M[(size_t)a * ld + c], M[(size_t)b * ld + c], s); }
+    for (int t = 0; t < nw; t++) { const int c = R.perm[r + t]; s = fma(M[(size_t)a * lm + c], M[(size_t)b * lm + c], s); }
     T[(size_t)a * ld + b] = s;
   }
   w.sync();
@@ -327,20 +328,20 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   // z = S^-1 x for the columns of G1 (in place), then Q^+ = Pi [z; W^T z]
   for (int j = ln; j < m; j += nl) {
     for (int k = 0; k < r; k++) {
-      double s = G[(size_t)k * ld + j];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * ld + i], G[(size_t)i * ld + j], s);
-      G[(size_t)k * ld + j] = s / T[(size_t)k * ld + k];
+      double s = G[(size_t)k * lm + j];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * ld + i], G[(size_t)i * lm + j], s);
+      G[(size_t)k * lm + j] = s / T[(size_t)k * ld + k];
     }
     for (int k = r - 1; k >= 0; k--) {
-      double s = G[(size_t)k * ld + j];
-      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * ld + k], G[(size_t)i * ld + j], s);
-      G[(size_t)k * ld + j] = s / T[(size_t)k * ld + k];
+      double s = G[(size_t)k * lm + j];
+      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * ld + k], G[(size_t)i * lm + j], s);
+      G[(size_t)k * lm + j] = s / T[(size_t)k * ld + k];
     }
-    for (int k = 0; k < r; k++) P[(size_t)R.perm[k] * ld + j] = G[(size_t)k * ld + j];
+    for (int k = 0; k < r; k++) P[(size_t)R.perm[k] * ld + j] = G[(size_t)k * lm + j];
     for (int t = 0; t < nw; t++) {
       const int c = R.perm[r + t];
       double s = 0.0;
-      for (int i = 0; i < r; i++) s = fma(M[(size_t)i * ld + c], G[(size_t)i * ld + j], s);
+      for (int i = 0; i < r; i++) s = fma(M[(size_t)i * lm + c], G[(size_t)i * lm + j], s);
       P[(size_t)c * ld + j] = s;
     }
   }
@@ -370,8 +371,19 @@ struct GenScratch {
   // their dependent steps waited for.  Placement only: the arithmetic does not change.
   double* fast = nullptr;
   int fastN = 0;
+  bool vecFast = false;     // `vec` lives in fast memory (LDS)
   int fastMats = 0;         // matrices of fastN x fastN in the pool (the Dantzig driver wants GEN_FAST_MATS + its vectors, Gauss-Seidel one)
 };
+// The working pair of genPinv (M, the matrix being factorised, and G, the carried block: what every Householder step reads and writes) for
+// a problem of m rows: packed (leading dimension m) in the cascade's 16 scratch vectors when those live in fast memory (vecFast: LDS on the
+// device, genSolveVecDoubles) and 2 m^2 doubles fit there - eight contacts of a 24-slot model: exactly.  Otherwise the scratch matrices.
+struct GenPinvPair { double* M; double* G; int ld; };
+DEV GenPinvPair genPinvPair(const GenScratch& S, int m) {
+  GenPinvPair p;
+  if (S.vecFast && (size_t)2 * m * m <= (size_t)16 * S.ld) { p.M = S.vec; p.G = S.vec + (size_t)m * m; p.ld = m; }
+  else { p.M = S.mat[0]; p.G = S.mat[1]; p.ld = S.ld; }
+  return p;
+}
 constexpr int GEN_FAST_N = 32;
 constexpr int GEN_FAST_MATS = 3;
 constexpr int GEN_FAST_DOUBLES = GEN_FAST_MATS * GEN_FAST_N * GEN_FAST_N + 20 * GEN_FAST_N;
@@ -407,8 +419,9 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
       for (int r = w.lane(); r < m; r += w.lanes()) fc[r] = X[r];
       w.sync();
     } else {
-      genBuildQ(w, A, lda, R, K, cfm, S.mat[0]);
-      genPinv(w, R, S.mat[0], S.mat[1], S.mat[2], S.mat[3], m, K.nc, K.nu == 0);
+      const GenPinvPair pp = genPinvPair(S, m);
+      genBuildQ(w, A, lda, R, K, cfm, pp.M, nullptr, pp.ld);
+      genPinv(w, R, pp.M, pp.G, S.mat[2], S.mat[3], m, K.nc, K.nu == 0, pp.ld);
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = R.cls[r] == RC_CLAMPING ? R.Bv[r] : 0.0;
       w.sync();
       genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, fc);
@@ -463,11 +476,12 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
     w.sync();
     const int nIn = (int)w.sumAll((double)cnt);
     if (nIn > 0) {
-      double* M = S.mat[0];
+      const GenPinvPair pp = genPinvPair(S, m);
+      double* M = pp.M;
       for (int s = w.lane(); s < m; s += w.lanes())
-        for (int i = 0; i < m; i++) M[(size_t)i * ld + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
+        for (int i = 0; i < m; i++) M[(size_t)i * pp.ld + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
       w.sync();
-      genPinv(w, R, M, S.mat[1], S.mat[2], S.mat[3], m, nIn, true);          // A restricted to the guess rows: symmetric positive semi-definite
+      genPinv(w, R, M, pp.G, S.mat[2], S.mat[3], m, nIn, true, pp.ld);          // A restricted to the guess rows: symmetric positive semi-definite
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = in0[r] ? R.Bv[r] : 0.0;
       w.sync();
       genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, R.t0);

@@ -131,7 +131,7 @@ def rollout(world: World, state0: torch.Tensor, actions: torch.Tensor, warm_star
     """states[:, 0] = state0, states[:, t+1] = timestep(world, states[:, t], actions[:, t][, mass]).
     state0 [B, 2n], actions [B, T, k] -> states [B, T+1, 2n]; differentiable wrt state0, actions and (when given) the
     world's registered mass vector.  checkpoint_every = K > 0 keeps the backward records of K steps instead of T (a record is
-    ~32 kB per world-step on Atlas-20 with contacts): the backward pass re-runs the other segments from their stored start states;
+    26.7 kB per world-step on Atlas-20 with contacts: world.saved_bytes(B) / B): the backward pass re-runs the other segments from their stored start states;
     the forward kernels are bit-reproducible, so the gradients are bit for bit those of checkpoint_every = 0."""
     lay = world.ref_layout
     if lay is None:

@@ -6,6 +6,10 @@
 // dart/collision/dart/DARTCollisionDetector.cpp:150-175, 360-400.
 // Same separating-axis order, same fudge factor and tie-breaks, same clipping order, so contact
 // order, count, types and edge annotations match the reference.
+// Attribution: the algorithm restated here derives from the Open Dynamics Engine (ODE), Copyright (C) 2001-2003 Russell L. Smith, which the
+// reference vendors under ODE's BSD-style licence (dart/external/odelcpsolver/, dart/collision/dart/DARTCollide.cpp); this file is an
+// independent restatement for another execution model - ODE's arithmetic order and, where the bit-for-bit tests need them recognisable,
+// its identifiers are kept on purpose.
 #pragma once
 #include <vector>
 

@@ -6,6 +6,10 @@
 // the reference tree), and a hook to the REAL vendored Dantzig solver: when oracle/_ref/libodelcp_ref.so
 // exists (built from /root/reference/dart/external/odelcpsolver/*.cpp where they lie, see
 // oracle/ref_build.py) stage 1 of the cascade calls the reference's own dSolveLCP.
+// Attribution: the algorithm restated here derives from the Open Dynamics Engine (ODE), Copyright (C) 2001-2003 Russell L. Smith, which the
+// reference vendors under ODE's BSD-style licence (dart/external/odelcpsolver/, dart/collision/dart/DARTCollide.cpp); this file is an
+// independent restatement for another execution model - ODE's arithmetic order and, where the bit-for-bit tests need them recognisable,
+// its identifiers are kept on purpose.
 #pragma once
 #include <dlfcn.h>
 
