@@ -270,7 +270,11 @@ __host__ __device__ inline size_t genFinalDoubles(int cap) { return (size_t)4 * 
 // candidate) when the model has at most GEN_VEC_LDS_ROWS rows: in HBM scratch every barrier after a store to one of them waited for the
 // store to land (hundreds of barriers per world); the matrices stay in HBM scratch.
 constexpr int GEN_VEC_LDS_ROWS = 96;
-__host__ __device__ inline size_t genSolveVecDoubles(int rows) { return rows <= GEN_VEC_LDS_ROWS ? (size_t)16 * rows : 0; }
+// ... and never fewer than GEN_VEC_LDS_MIN doubles: the pool also lends itself, packed by the WORLD's rows, to the working pair of the
+// pseudo-inverse (2 m^2) and to the matrix of the Gauss-Seidel sweeps (n^2) - 1152 doubles hold the pair of a world of eight contacts
+// whatever the model's slot count is (a 16-slot model would otherwise send its eight-contact worlds to HBM scratch: 1.46 against 1.74 M/s)
+constexpr int GEN_VEC_LDS_MIN = 1152;
+__host__ __device__ inline size_t genSolveVecDoubles(int rows) { return rows <= GEN_VEC_LDS_ROWS ? ((size_t)16 * rows > GEN_VEC_LDS_MIN ? (size_t)16 * rows : (size_t)GEN_VEC_LDS_MIN) : 0; }
 __host__ __device__ inline size_t genSolveLdsBytes(int rows) {
   const int cap = genRowsCap(rows);
   return (genRowsDoubles(cap) + genFinalDoubles(cap) + GEN_SOLVE_FAST_MATS * GEN_FAST_N * GEN_FAST_N + genSolveVecDoubles(rows)) * sizeof(double);
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE_GEN) void k_contact_solve
   }
   GenScratch S = genScratchOf(gws, b, dn + lay.pinv, ldr);
   if (GEN_SOLVE_FAST_MATS > 0) { S.fast = fastMat; S.fastN = GEN_FAST_N; S.fastMats = GEN_SOLVE_FAST_MATS; }
-  if (genSolveVecDoubles(ldr) > 0) { S.vec = fastMat + GEN_SOLVE_FAST_MATS * GEN_FAST_N * GEN_FAST_N; S.vecFast = true; }      // the cascade's vectors in LDS
+  if (genSolveVecDoubles(ldr) > 0) { S.vec = fastMat + GEN_SOLVE_FAST_MATS * GEN_FAST_N * GEN_FAST_N; S.vecFast = true; S.vecDoubles = (int)genSolveVecDoubles(ldr); }      // the cascade's vectors in LDS
   GEN_T0();
   GEN_CNT(10);
   // ---- the rows ----

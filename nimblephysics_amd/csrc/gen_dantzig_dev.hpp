@@ -687,10 +687,21 @@ DEV void genCarve(const GenScratch& S, GenProblem& P, GenDantzigMem& D) {
   P.A = S.mat[4]; P.x = v; P.b = v + g; P.lo = v + 2 * g; P.hi = v + 3 * g;
   P.findex = reinterpret_cast<int*>(v + 4 * g); P.mapTo = P.findex + g;
   D.A = S.mat[4]; D.L = S.mat[1];
-  D.d = v + 5 * g; D.x = v + 6 * g; D.w = v + 7 * g; D.dx = v + 8 * g; D.dw = v + 9 * g; D.ell = v + 10 * g; D.Dell = v + 11 * g;
-  D.tmp = v + 12 * g; D.tvec = S.mat[2]; D.W1 = S.mat[2] + 2 * g; D.W2 = S.mat[2] + 3 * g;
+  // (v + 5 g: the candidate of a stage, genCascade; the Dantzig driver's vectors come last: Gauss-Seidel takes their place, genPgsAT)
+  D.d = v + 6 * g; D.x = v + 7 * g; D.w = v + 8 * g; D.dx = v + 9 * g; D.dw = v + 10 * g; D.ell = v + 11 * g; D.Dell = v + 12 * g;
+  D.tmp = v + 13 * g; D.tvec = S.mat[2]; D.W1 = S.mat[2] + 2 * g; D.W2 = S.mat[2] + 3 * g;
   D.b = P.b; D.lo = P.lo; D.hi = P.hi; D.findex = P.findex;
-  D.p = reinterpret_cast<int*>(v + 13 * g); D.C = D.p + g; D.state = reinterpret_cast<int*>(v + 14 * g);
+  D.p = reinterpret_cast<int*>(v + 14 * g); D.C = D.p + g; D.state = reinterpret_cast<int*>(v + 15 * g);
+}
+// The scaled, transposed matrix of the Gauss-Seidel sweeps: packed in the part of the fast vector region the Dantzig driver's vectors
+// occupy (v + 6 ld to the end: they are dead while Gauss-Seidel runs) when the problem is small enough, else the scratch matrix.
+struct GenPgsAT { double* AT; int ld; bool lds; };
+DEV GenPgsAT genPgsAT(const GenScratch& S, int n) {
+  GenPgsAT a;
+  if (S.vecFast && (size_t)n * n + (size_t)6 * S.ld <= (size_t)S.vecDoubles) { a.AT = S.vec + 6 * S.ld; a.ld = n; a.lds = true; }
+  else if (S.fast && S.fastMats >= 1 && n <= S.fastN) { a.AT = S.fast; a.ld = S.fastN; a.lds = true; }
+  else { a.AT = S.mat[1]; a.ld = S.ld; a.lds = false; }
+  return a;
 }
 
 // X[o] = x_reduced[mapTo[o]] -> out (rows that are off: 0)
@@ -748,8 +759,8 @@ DEV int genStage2(const W& w, const double* A, int lda, GenRows& R, const GenScr
   int flags = 0;
   for (int r = w.lane(); r < R.m; r += w.lanes()) out[r] = 0.0;
   w.sync();
-  const bool fastP2 = S.fast && S.fastMats >= 1 && P.n <= S.fastN;
-  if (genPgs(w, R, P, fastP2 ? S.fast : S.mat[1], fastP2 ? S.fastN : R.ld, fastP2)) {
+  const GenPgsAT at = genPgsAT(S, P.n);
+  if (genPgs(w, R, P, at.AT, at.ld, at.lds)) {
     genMapOut(w, R, P, P.x, out);
     flags = GS_SOLVED | (genValid(w, A, lda, R, out, false, cfm, R.t2) ? GS_VALID : 0);
   }
@@ -764,8 +775,8 @@ DEV int genStage3(const W& w, const double* A, int lda, GenRows& R, const GenScr
   genLcpRemoveFriction(w, R, P, R.m, S.mat[1]);
   for (int c = w.lane(); c < P.n; c += w.lanes()) P.x[c] = 0.0;
   w.sync();
-  const bool fastP3 = S.fast && S.fastMats >= 1 && P.n <= S.fastN;
-  const bool ok3 = genPgs(w, R, P, fastP3 ? S.fast : S.mat[1], fastP3 ? S.fastN : R.ld, fastP3);
+  const GenPgsAT at = genPgsAT(S, P.n);
+  const bool ok3 = genPgs(w, R, P, at.AT, at.ld, at.lds);
   genMapOut(w, R, P, P.x, out);
   return ok3 ? GS_SOLVED : 0;
 }
@@ -777,7 +788,7 @@ template <class W>
 DEV void genCascade(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double fallbackCfm, double& cfmOut, uint32_t& stOut,
                     bool& pinvValid, GenClasses& K) {
   const int m = R.m;
-  double* cand = S.vec + 15 * S.ld;
+  double* cand = S.vec + 5 * S.ld;
   auto hasNan = [&](const double* x) -> bool { bool b = false; for (int r = w.lane(); r < m; r += w.lanes()) if (x[r] != x[r]) b = true; return w.anyAll(b); };
   auto take = [&](const double* x) { for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = R.on[r] ? x[r] : 0.0; w.sync(); };
   bool success = false, ignoreFriction = false;

@@ -372,15 +372,16 @@ struct GenScratch {
   double* fast = nullptr;
   int fastN = 0;
   bool vecFast = false;     // `vec` lives in fast memory (LDS)
+  int vecDoubles = 0;       // ... and has this many doubles (>= 16 ld)
   int fastMats = 0;         // matrices of fastN x fastN in the pool (the Dantzig driver wants GEN_FAST_MATS + its vectors, Gauss-Seidel one)
 };
 // The working pair of genPinv (M, the matrix being factorised, and G, the carried block: what every Householder step reads and writes) for
 // a problem of m rows: packed (leading dimension m) in the cascade's 16 scratch vectors when those live in fast memory (vecFast: LDS on the
-// device, genSolveVecDoubles) and 2 m^2 doubles fit there - eight contacts of a 24-slot model: exactly.  Otherwise the scratch matrices.
+// device, genSolveVecDoubles) and 2 m^2 doubles fit there (eight contacts: always).  Otherwise the scratch matrices.
 struct GenPinvPair { double* M; double* G; int ld; };
 DEV GenPinvPair genPinvPair(const GenScratch& S, int m) {
   GenPinvPair p;
-  if (S.vecFast && (size_t)2 * m * m <= (size_t)16 * S.ld) { p.M = S.vec; p.G = S.vec + (size_t)m * m; p.ld = m; }
+  if (S.vecFast && (size_t)2 * m * m <= (size_t)S.vecDoubles) { p.M = S.vec; p.G = S.vec + (size_t)m * m; p.ld = m; }
   else { p.M = S.mat[0]; p.G = S.mat[1]; p.ld = S.ld; }
   return p;
 }
@@ -745,25 +746,32 @@ DEV bool genPgsHeld1(const W& w, GenRows& R, int n, int no, const double* AT, in
 #else
   auto colOf = [&](int i) -> double { return colBase[(unsigned)(i < 0 ? 0 : i) * ldu]; };
 #endif
-  bool moved = false;
+  // A step WITHOUT a branch: every lane forms the clamped candidate of ITS row (the same instructions whether one lane runs them or all
+  // do), the owner's is taken with a select, the change and the new x_i come back through two broadcasts.  The bounds of a friction row
+  // (h = mu x_normal, l = -h) are registers, refreshed by the lanes that hang on row i.  The convergence test of a row needs only what
+  // its lane holds after its step (its last change and its x): it runs ONCE per sweep, for all rows at once (sweepMoved).
+  double h = hi, l = lo;
+  if (fi >= 0) { h = hi * xf; l = -h; }
+  double myD = 0.0;
   auto rowStep = [&](int i, double cc, bool first) {
-    double d = 0.0;
-    if (ln == i) {
-      double nx = 0.0;
-      if (!zeroMe) {
-        nx = x + r;
-        double h = hi, l = lo;
-        if (fi >= 0) { h = hi * xf; l = -h; }
-        nx = nx > h ? h : (nx < l ? l : nx);
-      }
-      d = nx - x;
-      if (!zeroMe && (first ? fabs(d) > dxTh : (fabs(nx) > epsDiv && fabs(d) > relTol * fabs(nx)))) moved = true;
-      x = nx;
-    }
-    d = w.bcast(d, i);
+    double nx = x + r;
+    nx = nx > h ? h : (nx < l ? l : nx);
+    if (first) nx = zeroMe ? 0.0 : nx;        // (rows left out of the problem: set to zero in the first sweep, never visited again)
+    const double dAll = nx - x;
+    const bool mine = ln == i;
+    x = mine ? nx : x;
+    myD = mine ? dAll : myD;
+    const double d = w.bcast(dAll, i);
     r = fma(-cc, d, r);
-    const double xi = w.bcast(x, i);          // (the new x_i itself: x_old + (x_new - x_old) is not always x_new)
-    xf = fi == i ? xi : xf;
+    const double xi = w.bcast(nx, i);          // (the new x_i itself: x_old + (x_new - x_old) is not always x_new)
+    const double hn = hi * xi;
+    const bool hangs = fi == i;
+    h = hangs ? hn : h;
+    l = hangs ? -hn : l;
+  };
+  auto sweepMoved = [&](bool first) -> bool {
+    const bool big = first ? fabs(myD) > dxTh : (fabs(x) > epsDiv && fabs(myD) > relTol * fabs(x));
+    return w.anyAll(in && !zeroMe && big);
   };
   // a sweep over `cnt` rows, four rows per trip; ORDERED: the t-th row is lane t's myOrder, else t itself
   auto sweep = [&](int cnt, bool first, bool ordered) {
@@ -781,12 +789,11 @@ DEV bool genPgsHeld1(const W& w, GenRows& R, int n, int no, const double* AT, in
     }
   };
   sweep(n, true, false);
-  bool possible = !w.anyAll(moved);
+  bool possible = !sweepMoved(true);
   if (!possible) {
     for (int iter = 1; iter < maxIteration; ++iter) {
-      moved = false;
       sweep(no, false, !identity);
-      possible = !w.anyAll(moved);
+      possible = !sweepMoved(false);
       if (possible) break;
     }
   }
@@ -849,6 +856,11 @@ DEV bool genPgs(const W& w, GenRows& R, GenProblem& P, double* AT, int atLd, boo
   // policy) everything is read in place.  Same arithmetic.
   constexpr int NT = (GR + 63) / 64;
   bool possible;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the address space the pointer IS in decides which typed load reads it, not the caller's word: a global load of an LDS address is a
+  // memory aperture violation (seen on worlds of 20 contacts when the flag travelled through the inlined callers: tools/dbg/r06_tower.py)
+  atLds = __builtin_amdgcn_is_shared(AT);
+#endif
   if (n <= nl) possible = atLds ? genPgsHeld1<true>(w, R, n, no, AT, atLd) : genPgsHeld1<false>(w, R, n, no, AT, atLd);
   else if (nl * NT >= n) possible = genPgsHeld<NT>(w, R, n, no, AT, atLd);
   else {

@@ -5,6 +5,7 @@
 // gets a truncated answer); every later call goes to the build that owns the handle.  Host code only; no HIP call of its own.
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/nimble_amd.h"
@@ -169,6 +170,8 @@ int32_t nbl_model_create(const nbl_model_desc* d, int32_t device, nbl_model** ou
   if (contactStage && d->max_contacts > 64) first = 3;
   else if (contactStage && (d->max_contacts > 16 || d->n_boxes > 32)) first = 2;
   else if (contactStage && (d->max_contacts > 8 || d->n_boxes > 16)) first = 1;
+  // developer knob: NBL_MIN_VARIANT=0..3 starts the search at a later instantiation (never an earlier one: that would truncate)
+  if (const char* e = getenv("NBL_MIN_VARIANT")) { const int f = atoi(e); if (f > first && f < kNumVariants) first = f; }
   int32_t rc = NBL_E_CAPACITY;
   const Variant* v = nullptr;
   for (int k = first; k < kNumVariants && rc == NBL_E_CAPACITY; k++) {

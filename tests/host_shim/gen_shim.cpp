@@ -26,16 +26,25 @@ struct HostWave1 {
 namespace {
 // The leading dimension of a problem of m rows: the rows rounded up to a multiple of 8, like the library sizes the scratch and the record of a
 // model (genLeadingDim) - every call exercises the run-time strides at its own size instead of at the cap.
-static int shimLd(int m) { const int r = (m + 7) & ~7; return r < 8 ? 8 : (r > GR ? GR : r); }
+// gshim_device_pool(rows): the worlds that follow are laid out like k_contact_solve_gen lays out a world of a MODEL of `rows` rows (0: off) -
+// that leading dimension and the cascade's vectors in their own "fast" pool of max(16 rows, 1152) doubles (LDS on the device), which
+// switches on the packed placements (genPinvPair, genPgsAT).  Placement only: every result must stay bit for bit what it was.
+static int g_modelRows = 0;
+static int shimLd(int m) { int r = (m + 7) & ~7; if (g_modelRows > r) r = (g_modelRows + 7) & ~7; return r < 8 ? 8 : (r > GR ? GR : r); }
 struct World {
   GenRows R;
-  std::vector<double> buf, rowsPool;
+  std::vector<double> buf, rowsPool, vecPool;
   GenScratch S;
   int ld;
   explicit World(int m) : buf(genScratchDoubles(shimLd(m)), 0.0), rowsPool(genRowsDoubles(genRowsCap(shimLd(m))), 0.0), ld(shimLd(m)) {
     for (int k = 0; k < GEN_NMAT; k++) S.mat[k] = buf.data() + (size_t)k * ld * ld;
     S.vec = buf.data() + (size_t)GEN_NMAT * ld * ld;
     S.ld = ld;
+    if (g_modelRows > 0) {
+      const size_t nv = (size_t)16 * ld > 1152 ? (size_t)16 * ld : 1152;
+      vecPool.assign(nv, 0.0);
+      S.vec = vecPool.data(); S.vecFast = true; S.vecDoubles = (int)nv;
+    }
     genRowsCarve(R, rowsPool.data(), genRowsCap(ld));      // (the rows' arrays sized by the problem, like the library sizes them by the model)
     R.ld = ld;
   }
@@ -63,6 +72,7 @@ void fillRows(GenRows& R, int m, const double* A, int GLD, const double* b, cons
 
 extern "C" {
 int gshim_rows() { return GR; }
+void gshim_device_pool(int rows) { g_modelRows = rows; }
 
 // Q: m x m row-major (masked rows / columns zero), P out m x m row-major; returns the rank
 int gshim_pinv(int m, const double* Q, int cTrue, double* Pout) {

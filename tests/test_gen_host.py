@@ -379,3 +379,39 @@ def test_the_stages_with_the_work_shared_by_many_lanes_equal_the_one_lane_run_bi
             seen[stage].add(int(f1))
     print(f"stages on {lanes} lanes == one lane, flags seen:", seen)
     assert len(seen[1]) >= 2 and len(seen[2]) >= 1
+
+
+@pytest.mark.parametrize("model_rows", [24, 48, 88])
+def test_the_device_placement_of_the_scratch_changes_no_bit(gen, model_rows):
+    """k_contact_solve_gen keeps the cascade's sixteen vectors in LDS (a pool of max(16 rows, 1152) doubles for a model of `rows` rows) and
+    lends that pool, packed by the WORLD's rows, to the working pair of the pseudo-inverse (genPinvPair) and to the matrix of the
+    Gauss-Seidel sweeps (genPgsAT, in the place of the Dantzig driver's vectors).  Placement only: the whole cascade (stage 0, the stages,
+    standardisation) and every stage on 64 lanes with the device's layout (gshim_device_pool) equal the plain layout bit for bit - worlds
+    of 2 .. 29 contacts in models of 8 .. 29 slots, the pool too small for the pair / the matrix included."""
+    rng = np.random.default_rng(500 + model_rows)
+    gen.gshim_device_pool.argtypes = [C.c_int]; gen.gshim_device_pool.restype = None
+    gen.gshim_stage_lanes.argtypes = [C.c_int, C.c_int, pd, pd, pd, pu8, pd, C.c_double, pd, C.c_int]
+    try:
+        for trial in range(6):
+            nc = int(rng.integers(2, model_rows // 3 + 1))
+            ndof = int(rng.choice([6, 12, 30])) if trial % 2 else 3 * nc + 3
+            A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
+            m = 3 * nc
+            mu = np.ascontiguousarray(hi[1::3])
+            x0 = rng.normal(0, 0.05, m) * (trial % 3 == 0)
+            res = []
+            for pool in (0, model_rows):
+                gen.gshim_device_pool(pool)
+                X, st, cfm, cls = _gen_cascade(gen, m, A, x0, b, hi)
+                stages = []
+                for stage in (1, 2, 3):
+                    XL = np.zeros(m)
+                    fl = gen.gshim_stage_lanes(stage, m, _p(np.ascontiguousarray(A)), _p(b.copy()), _p(mu), None, _p(x0.copy()), 1e-3, _p(XL), 64)
+                    stages.append((fl, XL))
+                res.append((X, st, cfm, cls, stages))
+            (X0, st0, cfm0, cls0, sg0), (X1, st1, cfm1, cls1, sg1) = res
+            assert st0 == st1 and cfm0 == cfm1 and np.array_equal(cls0, cls1) and np.array_equal(X0, X1), (trial, nc, hex(st0), hex(st1))
+            for (f0, x0_), (f1, x1_) in zip(sg0, sg1):
+                assert f0 == f1 and np.array_equal(x0_, x1_), (trial, nc)
+    finally:
+        gen.gshim_device_pool(0)

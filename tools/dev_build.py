@@ -1,5 +1,5 @@
-"""Developer build: recompile only the named instantiations of the library (default: c8) - and, with --timing, the single-instantiation
-library with the cascade's cycle stamps (tools/cascade_timing.py) - in parallel, then relink.  The other instantiations keep their old
+"""Developer build: recompile only the named instantiations of the library (default: c8) - and, with --timing / --gen-timing, the single-instantiation
+libraries with the cycle stamps (tools/cascade_timing.py / tools/gen_timing.py) - in parallel, then relink.  The other instantiations keep their old
 objects (same ABI).  The full build is __graft_entry__.build()."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +17,10 @@ if "--timing" in sys.argv:
     os.makedirs(os.path.join(ROOT, "tools", "dbg"), exist_ok=True)
     procs.append(subprocess.Popen([ge.HIPCC] + ge.HIPFLAGS + ["-shared", "-DNBL_CASCADE_TIMING", os.path.join(ge.CSRC, "nimble_amd.hip"),
                                    "-o", os.path.join(ROOT, "tools", "dbg", "libnimble_amd_timing.so")]))
+if "--gen-timing" in sys.argv:       # the general build's solve kernel with its cycle stamps (tools/gen_timing.py)
+    os.makedirs(os.path.join(ROOT, "tools", "dbg"), exist_ok=True)
+    procs.append(subprocess.Popen([ge.HIPCC] + ge.HIPFLAGS + ["-shared", "-DNBL_MAXC=64", "-DNBL_GEN_TIMING", os.path.join(ge.CSRC, "nimble_amd.hip"),
+                                   "-o", os.path.join(ROOT, "tools", "dbg", "libnimble_amd_gentiming.so")]))
 rc = [p.wait() for p in procs]
 assert not any(rc), rc
 objs = [os.path.join(objdir, f"nimble_amd_{n}.o") for n, _ in ge.VARIANTS] + [os.path.join(objdir, "nimble_amd_dispatch.o")]
