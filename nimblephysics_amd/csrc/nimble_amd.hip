@@ -790,7 +790,7 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
         while (ts > 8 && rowsLdsFor(ts) > 150u * 1024u) ts /= 2;
         TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_gen, dim3((unsigned)cnt), dim3(64), rowsLdsFor(ts), s, mdl, m->dBodies, m->dContact, B,
                                               (double*)saved, m->lay, (const double*)workspace, ts));
-        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), genSolveLdsBytes(m->lay.ldr) + (getenv("NBL_GEN_EXTRA_LDS") ? atoi(getenv("NBL_GEN_EXTRA_LDS")) : 0), s, mdl, m->dContact, B, (double*)saved, m->lay,
+        TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), genSolveLdsBytes(m->lay.ldr), s, mdl, m->dContact, B, (double*)saved, m->lay,
                                                lcp_cache_in, lcp_cache_out, next_state, status, gws));
       }
       (void)lws; (void)failListAll;

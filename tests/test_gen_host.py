@@ -181,7 +181,7 @@ def test_the_wave_shared_dantzig_driver_is_bit_identical_to_the_reference_with_o
     rng = np.random.default_rng(10 + lanes)
     solved = failed = 0
     sizes = [1, 2, 3, 5, 8, 8, 11, 16, 16, 20, 27, 32, 40, 48, 64, 64] if lanes == 1 else [1, 2, 3, 5, 8, 8, 11, 16, 20, 27, 40, 64]
-    for trial in range(60 if lanes == 1 else 36):
+    for trial in range(60 if lanes == 1 else (36 if lanes < 64 else 18)):      # (64 threads on a few cores: barriers are slow)
         nc = sizes[trial % len(sizes)]; n = 3 * nc
         ndof = n + int(rng.integers(0, 6)) if trial % 3 == 0 else int(rng.choice([3, 6, 12, 30, 60]))   # 2 of 3: rank-deficient A
         A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
@@ -361,7 +361,7 @@ def test_the_stages_with_the_work_shared_by_many_lanes_equal_the_one_lane_run_bi
     gen.gshim_stage.argtypes = [C.c_int, C.c_int, pd, pd, pd, pu8, pd, C.c_double, pd]
     gen.gshim_stage_lanes.argtypes = [C.c_int, C.c_int, pd, pd, pd, pu8, pd, C.c_double, pd, C.c_int]
     seen = {1: set(), 2: set(), 3: set()}
-    for trial in range(18):
+    for trial in range(18 if lanes < 64 else 9):
         nc = [2, 5, 8, 8, 12, 20, 27, 40, 16][trial % 9]
         ndof = int(rng.choice([6, 12, 30])) if trial % 2 else 3 * nc + 3
         A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
@@ -392,7 +392,7 @@ def test_the_device_placement_of_the_scratch_changes_no_bit(gen, model_rows):
     gen.gshim_device_pool.argtypes = [C.c_int]; gen.gshim_device_pool.restype = None
     gen.gshim_stage_lanes.argtypes = [C.c_int, C.c_int, pd, pd, pd, pu8, pd, C.c_double, pd, C.c_int]
     try:
-        for trial in range(6):
+        for trial in range(4):
             nc = int(rng.integers(2, model_rows // 3 + 1))
             ndof = int(rng.choice([6, 12, 30])) if trial % 2 else 3 * nc + 3
             A, b, lo, hi, fi = contact_lcp(rng, nc, ndof)
