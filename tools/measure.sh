@@ -1,6 +1,6 @@
 # The measurements of a round on its final build (GPU box): the seven rocprofv3 passes of tools/profile.sh + the bench variants.
 #   usage: bash tools/measure.sh <tag>      -> gpurun_out/<tag>_*
-TAG=${1:-r05}
+TAG=${1:-r06}
 set -u
 mkdir -p gpurun_out
 bash tools/profile.sh ${TAG} > gpurun_out/${TAG}_profile.log 2>&1
