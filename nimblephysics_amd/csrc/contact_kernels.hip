@@ -28,7 +28,7 @@ DEV void tangentBasis(V3 n, V3& t1, V3& t2) {
 }
 
 // The narrow phase of `wl` worlds x `ppw` lanes (threads tid < wl * ppw of the workgroup `bid`; any further threads of the workgroup
-// only take part in its barriers).  keptP: SEEN_POINTS * 3 * ls doubles, clipBuf: 48 * ls doubles (ls >= wl * ppw: the lane stride), stage: the staging area of the
+// only take part in its barriers).  keptP: seenPts * 3 * ls doubles, clipBuf: 48 * ls doubles (ls >= wl * ppw: the lane stride), stage: the staging area of the
 // ppw > 1 scheme - all LDS.  qFk != nullptr: the world transforms of the collider bodies are computed HERE from the positions (the
 // kernel runs next to the forward tree kernel, not after it) and the status word is left alone: the contact count goes to the record
 // with + 0.5 when contacts were dropped, k_contact_solve_coop raises NBL_ST_CONTACT / NBL_ST_CONTACT_OVERFLOW from it.
@@ -38,6 +38,13 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
                            double* keptP, double* clipBuf, double* stage, double* fkT = nullptr, int ls = 64) {
   const int tid = (int)threadIdx.x;
   NBL_PHASE_FIRST(19);
+  // points the duplicate filter remembers per world: twice the contact slots - of the BUILD in the 24- / 48-row builds, of the MODEL in the
+  // general builds (whose 128 / 256 per world made the narrow phase's LDS 110 kB per 16 worlds whatever the model asked for)
+#if NBL_GENERAL
+  const int seenPts = 2 * cm->maxContacts < SEEN_POINTS ? 2 * cm->maxContacts : SEEN_POINTS;
+#else
+  constexpr int seenPts = SEEN_POINTS;
+#endif
   // ---- qFk with fkT (the narrow phase next to the forward tree kernel): the joint transforms T_parent->child of every body on an ancestor
   //      chain of a collider, for the wl worlds of the workgroup, by ALL its threads - (world, body) items side by side instead of one lane
   //      per collider pair walking its 7-joint chain alone (an exponential map with its sine and cosine per joint: 55 k of the 140 k cycles
@@ -93,18 +100,18 @@ DEV void contactDetectBody(const DevModel& mdl, const DevBody* __restrict__ bodi
       const V3 d = pt - mk3(keptP[(e * 3 + 0) * ls + ltid], keptP[(e * 3 + 1) * ls + ltid], keptP[(e * 3 + 2) * ls + ltid]);
       if (norm3(d) < 3.0e-12) { close = true; break; }
     }
-    for (int e = SEEN_POINTS - nDropped; e < SEEN_POINTS && !close; e++) {
+    for (int e = seenPts - nDropped; e < seenPts && !close; e++) {
       const V3 d = pt - mk3(keptP[(e * 3 + 0) * ls + ltid], keptP[(e * 3 + 1) * ls + ltid], keptP[(e * 3 + 2) * ls + ltid]);
       if (norm3(d) < 3.0e-12) close = true;
     }
     if (close) return;
     // A full list cannot remember another point.  A contact that passes the depth filter after that may be the duplicate of a point that
     // was not remembered: the world is flagged like one with too many contacts (NBL_ST_CONTACT_OVERFLOW).
-    const bool full = nC + nDropped >= SEEN_POINTS;
+    const bool full = nC + nDropped >= seenPts;
     if (dot(nr, nr) < 1e-12 || depth < 0.0 || depth > cm->clippingDepth) {
       if (!full) {
         nDropped++;
-        const int e = SEEN_POINTS - nDropped;
+        const int e = seenPts - nDropped;
         keptP[(e * 3 + 0) * ls + ltid] = pt.x; keptP[(e * 3 + 1) * ls + ltid] = pt.y; keptP[(e * 3 + 2) * ls + ltid] = pt.z;
       }
       return;

@@ -396,8 +396,13 @@ __global__ __launch_bounds__(64 * TREE_WPB_MAX) NBL_WAVES(NBL_W_FWD) void k_forw
   if ((int)blockIdx.x < nDetect) {
     NBL_PHASE_FIRST(18);
     const int ls = wl * ppw;                              // narrow-phase lanes of the workgroup
-    double* keptP = ldsTree;                              // SEEN_POINTS * 3 * ls
-    double* clipBuf = keptP + SEEN_POINTS * 3 * ls;       // 48 * ls
+#if NBL_GENERAL
+    const int seenPts = 2 * cm->maxContacts < SEEN_POINTS ? 2 * cm->maxContacts : SEEN_POINTS;   // (contactDetectBody: by the MODEL's slots)
+#else
+    constexpr int seenPts = SEEN_POINTS;
+#endif
+    double* keptP = ldsTree;                              // seenPts * 3 * ls
+    double* clipBuf = keptP + seenPts * 3 * ls;           // 48 * ls
     double* stage = clipBuf + 48 * ls;
     // the body constants of the forward kinematics from LDS (the two feet of a world sit on different lanes: indexed per lane, the
     // constants would be ~190 dependent global loads per lane)

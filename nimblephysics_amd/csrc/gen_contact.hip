@@ -50,7 +50,7 @@ DEV GenScratch genScratchOf(double* gws, int64_t world, double* recordPinv, int 
 // rows: see k_contact_rows_coop (coop_kernels.hip) for the mathematics - world-aligned frame with its origin at the root of each tree, one
 // wrench per row and side, impulses up the two ancestor chains, velocity changes down the tree, A[r][c] = F_c . (dV_A - dV_B).  Here the rows
 // are processed in tiles of `ts` (a lane = a row of the tile; the velocity-change field [body][6][ts] is what limits a tile: LDS).
-//   lds doubles: F[rows][6] x 2, Sw / AISw / Vw [nb][6], psi[nb], origin[nb][3], free[nFree][54], acc[nb][6][ts], contact bodies
+//   lds doubles: F[the model's rows][6] x 2, Sw / AISw / Vw [nb][6], psi[nb], origin[nb][3], free[nFree][54], acc[nb][6][ts], contact bodies
 // ======================================================================================================================================
 __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const DevBody* __restrict__ bodies, const DevContactModel* __restrict__ cm, int64_t B,
                                                          double* __restrict__ saved, SavedLayout lay, const double* __restrict__ ws, int ts) {
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(64) void k_contact_rows_gen(DevModel mdl, const Dev
   const int ln = w.lane();
   const int ldr = lay.ldr;              // leading dimension of the record's dense blocks and of the world's scratch matrices
   double* Fs = ldsG;
-  double* FsB = Fs + 6 * MAX_ROWS;
-  double* Sw = FsB + 6 * MAX_ROWS;
+  double* FsB = Fs + 6 * ldr;           // (the wrench tables sized by the MODEL's rows, like the record: genLeadingDim)
+  double* Sw = FsB + 6 * ldr;
   double* AISw = Sw + 6 * nb;
   double* Vw = AISw + 6 * nb;
   double* psiL = Vw + 6 * nb;

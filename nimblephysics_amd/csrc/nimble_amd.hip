@@ -744,8 +744,9 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
     const int ppwD = !m->detectSplit ? 1 : (m->nPairs >= 4 ? 4 : (m->nPairs >= 2 ? 2 : 1));
     int wlD = std::min(tl, 64 / ppwD);                             // worlds per narrow-phase workgroup
     if (m->detectWl > 0) wlD = std::max(1, std::min(wlD, m->detectWl));
+    const int seenPts = NBL_GENERAL ? std::min(2 * m->maxContacts, (int)SEEN_POINTS) : (int)SEEN_POINTS;   // (contactDetectBody)
     auto detectLdsFor = [&](int wl) -> size_t {
-      return ((size_t)SEEN_POINTS * 3 + 48) * (size_t)(wl * ppwD) * sizeof(double) +
+      return ((size_t)seenPts * 3 + 48) * (size_t)(wl * ppwD) * sizeof(double) +
              (ppwD > 1 ? (size_t)wl * (ppwD - 1) * (8 * CR_SIZE) * sizeof(double) + (size_t)wl * (ppwD - 1) * sizeof(int) : 0) +
              (size_t)m->nb * sizeof(DevBody) + 32 +   // + the body constants of the narrow phase's own forward kinematics
              sizeof(DevContactModel) +                // + the collider model
@@ -783,11 +784,16 @@ static int32_t launchForward(nbl_model* m, int64_t B, int si, int64_t b0, int64_
         // the general kernels (gen_contact.hip), one wavefront per world: rows in tiles of `ts` (what the [body][6][ts] field of the
         // impulse tests leaves of the LDS), then the whole solver cascade of a world in one launch
         double* gws = (double*)((char*)workspace + workspaceHeadBytes(m, B));
+        // ... a tile no wider than the model's rows need, and small enough for three worlds per CU (48 kB) while it still holds 32 rows: a
+        // 24-slot model runs its eight-contact worlds in one pass of 32 rows at 35 kB instead of one of 64 rows at 71 kB (two worlds per CU)
         int ts = 64;
+        const int ldrRows = m->lay.ldr;
         auto rowsLdsFor = [&](int t) -> size_t {
-          return ((size_t)12 * MAX_ROWS + 22 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + (size_t)6 * m->nb * t) * sizeof(double) + 2 * MAX_CONTACTS * sizeof(int);
+          return ((size_t)12 * ldrRows + 22 * (size_t)m->nb + 54 * (size_t)m->mdl.nFree + (size_t)6 * m->nb * t) * sizeof(double) + 2 * MAX_CONTACTS * sizeof(int);
         };
         while (ts > 8 && rowsLdsFor(ts) > 150u * 1024u) ts /= 2;
+        while (ts > 32 && (ts / 2 >= ldrRows || rowsLdsFor(ts) > 48u * 1024u)) ts /= 2;
+        if (const char* e = getenv("NBL_ROWS_TS")) { const int t = atoi(e); if (t >= 8 && t <= 64 && rowsLdsFor(t) <= 150u * 1024u) ts = t; }
         TIMED(K_ROWS_COOP, hipLaunchKernelGGL(k_contact_rows_gen, dim3((unsigned)cnt), dim3(64), rowsLdsFor(ts), s, mdl, m->dBodies, m->dContact, B,
                                               (double*)saved, m->lay, (const double*)workspace, ts));
         TIMED(K_SOLVE_COOP, hipLaunchKernelGGL(k_contact_solve_gen, dim3((unsigned)cnt), dim3(64), genSolveLdsBytes(m->lay.ldr), s, mdl, m->dContact, B, (double*)saved, m->lay,

@@ -344,6 +344,24 @@ def test_box_stacking_skel_as_it_ships_until_the_tower_rests_on_the_ground():
           f"bottom cube at y = {fin[0, 4]:.4f} (rest: -0.395), |v| at the end {np.abs(fin[:, n:]).max():.2e}")
     assert contacts[0][1] >= 24 and contacts[-1][1] == 40       # (step 0: the interfaces whose 0.2 m spacing rounds to a gap of 1 ulp are out)
     assert abs(fin[0, 4] + 0.395) < 1e-2 and np.abs(fin[:, n:]).max() < 0.2      # (it lands at 2.8 m/s: 5 mm into the ground box, no penetration correction by default)
+    # the same rollout on the device alone (no oracle in the loop), forward + backward per step, for 1 world and for 256 copies of it:
+    # the time VERDICT r5 #2 asked to see next to the rates of the general build
+    import time
+    for Bt in (1, 256):
+        wt = na.World(md, device="cuda:0")
+        xb = torch.zeros((Bt, 2 * n), device="cuda:0", dtype=torch.float64)
+        ab = torch.zeros((Bt, n), device="cuda:0", dtype=torch.float64)
+        gb = torch.ones((Bt, 2 * n), device="cuda:0", dtype=torch.float64)
+        wt.reset_lcp_cache()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for t in range(T):
+            xt = xb.detach().clone().requires_grad_(True); att = ab.clone().requires_grad_(True)
+            y = timestep(wt, xt, att)
+            y.backward(gb)
+            xb = y.detach()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        assert np.array_equal(xb[0].cpu().numpy(), fin[0]), "the timed rollout is the tested one"
+        print(f"[box_stacking.skel as shipped] {T} steps forward + backward of {Bt} world(s) on the device: {dt:.2f} s = {dt / T * 1e3:.2f} ms per step, {Bt * T / dt:.0f} worlds*steps/s")
 
 
 def test_the_general_cascade_on_the_device_equals_the_same_code_on_the_host():

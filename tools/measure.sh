@@ -18,4 +18,5 @@ python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --rollout 64
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --rollout 64 --graph > gpurun_out/${TAG}_bench_atlas20_rollout_graph.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --max-contacts 16 > gpurun_out/${TAG}_bench_48rows.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 --max-contacts 24 --steps 8 --warmup 2 > gpurun_out/${TAG}_bench_general.json 2>/dev/null
+NBL_FUSED_DETECT=0 python bench.py --no-cpu-baseline --no-single-stream --easy-noise 0 > gpurun_out/${TAG}_bench_unfused_detect.json 2>/dev/null
 for f in gpurun_out/${TAG}_bench_*.json; do echo $f; tail -1 $f | cut -c1-260; done
