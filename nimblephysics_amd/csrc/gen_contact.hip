@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) NBL_WAVES(NBL_W_SOLVE_GEN) void k_contact_solve
     if (K.nc > 0) {
       const GenPinvPair pp = genPinvPair(S, m);
       genBuildQ(w, A, ldr, R, K, 0.0, pp.M, Fn.cfm, pp.ld);
-      genPinv(w, R, pp.M, pp.G, S.mat[2], S.mat[3], m, K.nc, K.nu == 0, pp.ld);
+      genPinv(w, R, pp.M, pp.G, S.mat[2], S.mat[3], m, K.nc, K.nu == 0, pp.ld, R.t0, 3 * R.cap);
     } else {
       for (int j = ln; j < m; j += 64) for (int i = 0; i < m; i++) S.mat[3][(size_t)i * ldr + j] = 0.0;
       w.sync();

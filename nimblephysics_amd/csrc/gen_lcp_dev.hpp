@@ -199,8 +199,12 @@ DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const
 // LCPUtils.cpp:113).  Column-pivoted Householder QR M Pi = H [R1 R2; 0], G = H^T carried along; full rank: Q^+ = Pi R1^-1 G1; rank
 // deficient: R = R1 [I W], W = R1^-1 R2, and the minimum-norm solution of R u = g is u = [I; W^T] (I + W W^T)^-1 R1^-1 g - the same
 // algebra as coopPinvImpl (coop_dev.hpp), which explains why that is as accurate as the second Householder pass.  Returns the rank.
+// Tfast / TfastDoubles: memory the lanes share FAST (LDS on the device) that is free for the duration of the call; the r x r matrix
+// I + W W^T and its Cholesky factor live there (packed, leading dimension r) when r^2 fits.  Its factorisation is a chain of 2 r barriers
+// each behind a store: through HBM scratch every one of them waited for the store to land (two flat feet: r = 12, ~100 k cycles per call).
 template <class W>
-DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue, bool symPsd = false, int ldMG = 0) {
+DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double* P, int m, int cTrue, bool symPsd = false, int ldMG = 0,
+                double* Tfast = nullptr, int TfastDoubles = 0) {
   const int ld = R.ld;              // leading dimension of T and P (the scratch matrices: the model's rows, rounded up)
   const int lm = ldMG > 0 ? ldMG : ld;   // ... and of M and G: the caller may hand in a packed pair in fast memory (genPinvFast)
   const int ln = w.lane(), nl = w.lanes();
@@ -300,28 +304,30 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   }
   // S = I + W W^T (r x r) -> T, W[i][t] = M[i][perm[r + t]]
   const int nw = m - r;
+  int lt = ld;
+  if (Tfast && r * r <= TfastDoubles) { T = Tfast; lt = r; }
   for (int e = ln; e < r * r; e += nl) {
     const int a = e / r, b = e - a * r;
     double s = (a == b) ? 1.0 : 0.0;
     for (int t = 0; t < nw; t++) { const int c = R.perm[r + t]; s = fma(M[(size_t)a * lm + c], M[(size_t)b * lm + c], s); }
-    T[(size_t)a * ld + b] = s;
+    T[(size_t)a * lt + b] = s;
   }
   w.sync();
   // Cholesky S = L L^T in place (lower triangle of T), lanes = rows below the pivot
   for (int k = 0; k < r; k++) {
     if (ln == 0) {
-      double s = T[(size_t)k * ld + k];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * ld + i], T[(size_t)k * ld + i], s);
+      double s = T[(size_t)k * lt + k];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * lt + i], T[(size_t)k * lt + i], s);
       const double lkk = sqrt(s);
-      T[(size_t)k * ld + k] = lkk;
+      T[(size_t)k * lt + k] = lkk;
       R.scal[0] = 1.0 / lkk;
     }
     w.sync();
     const double inv = R.scal[0];
     for (int a = k + 1 + ln; a < r; a += nl) {
-      double s = T[(size_t)a * ld + k];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)a * ld + i], T[(size_t)k * ld + i], s);
-      T[(size_t)a * ld + k] = s * inv;
+      double s = T[(size_t)a * lt + k];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)a * lt + i], T[(size_t)k * lt + i], s);
+      T[(size_t)a * lt + k] = s * inv;
     }
     w.sync();
   }
@@ -329,13 +335,13 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   for (int j = ln; j < m; j += nl) {
     for (int k = 0; k < r; k++) {
       double s = G[(size_t)k * lm + j];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * ld + i], G[(size_t)i * lm + j], s);
-      G[(size_t)k * lm + j] = s / T[(size_t)k * ld + k];
+      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * lt + i], G[(size_t)i * lm + j], s);
+      G[(size_t)k * lm + j] = s / T[(size_t)k * lt + k];
     }
     for (int k = r - 1; k >= 0; k--) {
       double s = G[(size_t)k * lm + j];
-      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * ld + k], G[(size_t)i * lm + j], s);
-      G[(size_t)k * lm + j] = s / T[(size_t)k * ld + k];
+      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * lt + k], G[(size_t)i * lm + j], s);
+      G[(size_t)k * lm + j] = s / T[(size_t)k * lt + k];
     }
     for (int k = 0; k < r; k++) P[(size_t)R.perm[k] * ld + j] = G[(size_t)k * lm + j];
     for (int t = 0; t < nw; t++) {
@@ -422,7 +428,7 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
     } else {
       const GenPinvPair pp = genPinvPair(S, m);
       genBuildQ(w, A, lda, R, K, cfm, pp.M, nullptr, pp.ld);
-      genPinv(w, R, pp.M, pp.G, S.mat[2], S.mat[3], m, K.nc, K.nu == 0, pp.ld);
+      genPinv(w, R, pp.M, pp.G, S.mat[2], S.mat[3], m, K.nc, K.nu == 0, pp.ld, R.t0, 3 * R.cap);      // (t0 .. t2: free here, contiguous)
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = R.cls[r] == RC_CLAMPING ? R.Bv[r] : 0.0;
       w.sync();
       genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, fc);
@@ -482,7 +488,7 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
       for (int s = w.lane(); s < m; s += w.lanes())
         for (int i = 0; i < m; i++) M[(size_t)i * pp.ld + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
       w.sync();
-      genPinv(w, R, M, pp.G, S.mat[2], S.mat[3], m, nIn, true, pp.ld);          // A restricted to the guess rows: symmetric positive semi-definite
+      genPinv(w, R, M, pp.G, S.mat[2], S.mat[3], m, nIn, true, pp.ld, R.t0, 3 * R.cap);          // A restricted to the guess rows: symmetric positive semi-definite
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = in0[r] ? R.Bv[r] : 0.0;
       w.sync();
       genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, R.t0);
