@@ -21,16 +21,20 @@ namespace NBL_NS {
 
 // developer instrumentation of the general solve kernel (-DNBL_GEN_TIMING, tools/gen_timing.py): cycles per phase summed over the worlds
 #if defined(NBL_GEN_TIMING) && defined(__HIPCC__)
-__device__ unsigned long long g_genStat[16];
+__device__ unsigned long long g_genStat[32];
 #endif
 #if defined(NBL_GEN_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define GEN_T0() long long genT = clock64()
 #define GEN_T(k) do { const long long n_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_genStat[k], (unsigned long long)(n_ - genT)); genT = n_; } while (0)
 #define GEN_CNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_genStat[k], 1ull); } while (0)
+#define GEN_L0() long long genL = clock64()
+#define GEN_L(k) do { const long long n_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_genStat[k], (unsigned long long)(n_ - genL)); genL = n_; } while (0)
 #else
 #define GEN_T0() do { } while (0)
 #define GEN_T(k) do { } while (0)
 #define GEN_CNT(k) do { } while (0)
+#define GEN_L0() do { } while (0)
+#define GEN_L(k) do { } while (0)
 #endif
 
 constexpr int GR = MAXR;            // rows of the arrays below: the instantiation's cap (192 / 384)
@@ -208,6 +212,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   const int ld = R.ld;              // leading dimension of T and P (the scratch matrices: the model's rows, rounded up)
   const int lm = ldMG > 0 ? ldMG : ld;   // ... and of M and G: the caller may hand in a packed pair in fast memory (genPinvFast)
   const int ln = w.lane(), nl = w.lanes();
+  GEN_L0(); GEN_CNT(29);
   for (int j = ln; j < m; j += nl) { R.done[j] = 0; for (int i = 0; i < m; i++) G[(size_t)i * lm + j] = (i == j) ? 1.0 : 0.0; }
   w.sync();
   // Rank threshold: the reference's eps * size * |R_00| (CGGM.cpp:280, LCPUtils.cpp:113).  For a SYMMETRIC positive semi-definite matrix
@@ -269,6 +274,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     rank = k + 1;
   }
   const int r = rank;
+  GEN_L(26);
   if (ln == 0) {   // columns never chosen (dependent or masked) take the remaining pivot positions in index order
     int pos = r;
     for (int j = 0; j < m; j++) if (!R.done[j]) R.perm[pos++] = j;
@@ -294,14 +300,17 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     }
   }
   w.sync();
+  GEN_L(27);
   if (r >= cTrue) {
     for (int j = ln; j < m; j += nl) {
       for (int kk = 0; kk < r; kk++) P[(size_t)R.perm[kk] * ld + j] = G[(size_t)kk * lm + j];
       for (int pp = r; pp < m; pp++) P[(size_t)R.perm[pp] * ld + j] = 0.0;
     }
     w.sync();
+    GEN_L(28);
     return r;
   }
+  GEN_CNT(30);
   // S = I + W W^T (r x r) -> T, W[i][t] = M[i][perm[r + t]]
   const int nw = m - r;
   int lt = ld;
@@ -352,6 +361,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     }
   }
   w.sync();
+  GEN_L(28);
   return r;
 }
 
@@ -406,8 +416,11 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
   double* fc = R.t0;
   double* newX = R.t1;
   bool ok = false;
+  GEN_L0();
   for (int iter = 0; iter < m + 1; iter++) {
+    GEN_CNT(24);
     K = genClassify(w, R, X, ignoreFriction);
+    GEN_L(19);
     if (K.nc == 0) {
       pinvValid = false;
       for (int r = w.lane(); r < m; r += w.lanes()) newX[r] = 0.0;
@@ -428,9 +441,11 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
     } else {
       const GenPinvPair pp = genPinvPair(S, m);
       genBuildQ(w, A, lda, R, K, cfm, pp.M, nullptr, pp.ld);
+      GEN_L(20); GEN_CNT(25);
       genPinv(w, R, pp.M, pp.G, S.mat[2], S.mat[3], m, K.nc, K.nu == 0, pp.ld, R.t0, 3 * R.cap);      // (t0 .. t2: free here, contiguous)
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = R.cls[r] == RC_CLAMPING ? R.Bv[r] : 0.0;
       w.sync();
+      GEN_L(21);
       genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, fc);
       pinvValid = true;
     }
@@ -449,7 +464,10 @@ DEV bool genStandardizeLoop(const W& w, const double* A, int lda, GenRows& R, co
     }
     w.sync();
     const bool again = w.anyAll(newlyNot);
-    if (!genValid(w, A, lda, R, newX, ignoreFriction, cfm, R.t2)) { ok = false; break; }
+    GEN_L(22);
+    const bool valid_ = genValid(w, A, lda, R, newX, ignoreFriction, cfm, R.t2);
+    GEN_L(23);
+    if (!valid_) { ok = false; break; }
     for (int r = w.lane(); r < m; r += w.lanes()) X[r] = newX[r];
     w.sync();
     ok = true;
@@ -468,6 +486,7 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
   pinvValid = false;
   bool haveGuess = false;
   unsigned char* in0 = R.pad_;
+  GEN_L0();
   if (haveCache) {
     for (int r = w.lane(); r < m; r += w.lanes()) { if (!R.on[r]) R.X[r] = 0.0; in0[r] = 0; }
     w.sync();
@@ -488,7 +507,9 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
       for (int s = w.lane(); s < m; s += w.lanes())
         for (int i = 0; i < m; i++) M[(size_t)i * pp.ld + s] = (in0[s] && in0[i]) ? A[(size_t)i * lda + s] : 0.0;
       w.sync();
-      genPinv(w, R, M, pp.G, S.mat[2], S.mat[3], m, nIn, true, pp.ld, R.t0, 3 * R.cap);          // A restricted to the guess rows: symmetric positive semi-definite
+      GEN_L(16);
+      genPinv(w, R, M, pp.G, S.mat[2], S.mat[3], m, nIn, true, pp.ld, R.t0, 3 * R.cap);
+      GEN_L(17);          // A restricted to the guess rows: symmetric positive semi-definite
       for (int r = w.lane(); r < m; r += w.lanes()) R.t2[r] = in0[r] ? R.Bv[r] : 0.0;
       w.sync();
       genPinvApply<W, false>(w, S.mat[3], R.ld, m, R.t2, R.t0);
@@ -500,6 +521,7 @@ DEV bool genStage0(const W& w, const double* A, int lda, GenRows& R, const GenSc
   }
   for (int r = w.lane(); r < m; r += w.lanes()) R.X0[r] = R.X[r];
   w.sync();
+  GEN_L(18);
   const bool ok = genStandardizeLoop(w, A, lda, R, S, 0.0, false, haveGuess ? in0 : nullptr, pinvValid, K);
   pinvValid = ok && pinvValid;
   return ok;

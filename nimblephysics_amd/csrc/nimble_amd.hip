@@ -1264,10 +1264,10 @@ int32_t nbl_debug_dantzig_stats_slow(unsigned long long* out16) {   // the same 
 #endif
 
 #if defined(NBL_GEN_TIMING) && NBL_GENERAL
-int32_t nbl_debug_gen_stats(unsigned long long* out16, int32_t reset) {
+int32_t nbl_debug_gen_stats(unsigned long long* out32, int32_t reset) {
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_genStat), sizeof(unsigned long long) * 16));
-  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_genStat), z, sizeof(z))); }
+  HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_genStat), sizeof(unsigned long long) * 32));
+  if (reset) { unsigned long long z[32] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_genStat), z, sizeof(z))); }
   return NBL_OK;
 }
 #endif

@@ -17,9 +17,10 @@ world = na.World(md, device="cuda:0")
 world.set_slices(1)
 st = world.to_soa(torch.tensor(s, device="cuda:0")); at = world.to_soa(torch.tensor(a, device="cuda:0"))
 L = _lib.lib()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 world.step_soa(st, at); torch.cuda.synchronize()          # warm-up
 L.nbl_debug_gen_stats(buf, 1)
+world.reset_lcp_cache()                                   # a COLD LCP start, like every step of bench.py's timed region
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record(); nxt, saved, status = world.step_soa(st, at); t1.record(); torch.cuda.synchronize()
 L.nbl_debug_gen_stats(buf, 0)
@@ -32,3 +33,12 @@ for k, nm, den in ((0, "rows, groups, final classification", nw), (1, "stage 0 (
                    (9, "  standardisation loop of the chosen solution", ncas),
                    (13, "  (Gauss-Seidel, both stages: set-up - scaling, transposed matrix, residuals)", ncas), (14, "  (Gauss-Seidel, both stages: the sweeps)", ncas), (2, "the record's Q^+ when the last one is not it", nw), (3, "outputs", nw)):
     print(f"  {nm:56s} {g[k] / den:12.0f} cycles per {'world' if den == nw else 'cascade'}")
+
+# finer stamps (round 6): stage 0's guess, the standardisation loop (stage 0's and the cascades' together), the pseudo-inverse
+print(f"  stage 0: guess rows + matrix {g[16] / nw:10.0f}  its pseudo-inverse {g[17] / nw:10.0f}  apply + X0 {g[18] / nw:10.0f}   cycles per world")
+it, pv = max(g[24], 1), max(g[25], 1)
+print(f"  standardisation loops: {g[24]} iterations ({g[24] / nw:.2f} per world), {g[25]} with a factorisation; per iteration: classify {g[19] / it:8.0f}  "
+      f"build Q {g[20] / pv:8.0f} (per factorisation)  pseudo-inverse {g[21] / pv:8.0f} (per factorisation)  apply + new x {g[22] / it:8.0f}  validity {g[23] / it:8.0f}")
+pc = max(g[29], 1)
+print(f"  pseudo-inverse: {g[29]} calls ({g[29] / nw:.2f} per world), {g[30]} rank-deficient; per call: pivoted Householder QR {g[26] / pc:8.0f}  R1^-1 solves {g[27] / pc:8.0f}  "
+      f"completion / output {g[28] / pc:8.0f}")
