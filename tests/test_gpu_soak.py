@@ -90,3 +90,55 @@ def test_warm_started_second_step_of_random_models_vs_oracle():
     print(tot)
     assert tot["MISMATCH"] == 0, tot
     assert tot["contact2"] > 0.1 * tot["worlds"] and tot["stage0"] > 0.3 * tot["contact2"], tot      # the warm start does resolve worlds at stage 0
+
+
+def test_the_references_finite_difference_noise_away_from_pi_is_proven_by_exact_derivatives():
+    """Round 6's only soak hit (warm:mix, seed 545103, world 6 - a free-floating tree with NO contact): next state and the action gradient
+    equal to round-off, ONE entry of the state gradient (the root's angular velocity about z) 3.4e-4 away from the oracle.  The reference
+    differentiates the position integration of a free joint by central differences with eps = 1e-6 (FreeJoint.cpp:950-1007; the oracle
+    restates it) of a logMap that takes the angle of the step's rotation increment (|w| dt ~ 1e-3 rad) from an arc cosine: 1e-10 of noise
+    in the forward pass - identical bits on both sides - amplified by 1 / eps.  Asserted here: the device's gradient (a) differs from the
+    finite-difference oracle by more than 1e-5 in that world, (b) equals the oracle WITH its exact-derivative instrument to 1e-7, (c)
+    equals central differences of the device's own forward step at h = 1e-4 to 1e-5; and the soak files such a world under
+    `reference_fd_exact_agrees`, not MISMATCH (tools/soak_parity.py::exact_derivatives_agree)."""
+    import numpy as np
+    import torch
+    import nimblephysics_amd as na
+    import soak_parity
+    import soak_stress
+    from nimblephysics_amd.timestep import timestep
+    from oracle import OracleWorld
+    seed, wd, B = 545103, 6, 256
+    md, s, a, g = soak_parity.make_case(seed, B, balls=True)
+    md, s, a, g = soak_stress.mutator("mix")(seed, md, s, a, g)
+    world = na.World(md, device="cuda:0")
+    ow = OracleWorld(md)
+    at = torch.tensor(a, device="cuda:0")
+    with torch.no_grad():
+        s1 = timestep(world, torch.tensor(s, device="cuda:0"), at)
+    assert not (world.last_status.cpu().numpy()[wd] & 1), "no contact in this world"
+    world.reset_lcp_cache()
+    st = s1.clone().requires_grad_(True); at2 = at.clone().requires_grad_(True)
+    out = timestep(world, st, at2)
+    out.backward(torch.tensor(g, device="cuda:0"))
+    s1n = s1.cpu().numpy()
+    dev = {"next": out.detach().cpu().numpy()[wd], "grad_state": st.grad.cpu().numpy()[wd], "grad_action": at2.grad.cpu().numpy()[wd]}
+    fd = ow.step_batch(s1n[wd:wd + 1], a[wd:wd + 1], g[wd:wd + 1])
+    ow.set_exact_position_jacobians(True)
+    ex = ow.step_batch(s1n[wd:wd + 1], a[wd:wd + 1], g[wd:wd + 1])
+    ow.set_exact_position_jacobians(False)
+    sc = {k: max(np.abs(fd[k]).max(), 1e-30) for k in dev}
+    e_fd = {k: float(np.abs(dev[k] - fd[k][0]).max() / sc[k]) for k in dev}
+    e_ex = {k: float(np.abs(dev[k] - ex[k][0]).max() / sc[k]) for k in dev}
+    print("[finite-difference noise away from pi] device vs the reference's differences:", e_fd, " vs exact derivatives:", e_ex)
+    assert e_fd["next"] < 1e-12 and e_fd["grad_action"] < 1e-12 and e_fd["grad_state"] > 1e-5
+    assert max(e_ex.values()) < 1e-7
+    e = int(np.abs(dev["grad_state"] - fd["grad_state"][0]).argmax())
+    h = 1e-4
+    sp = s1n.copy(); sm = s1n.copy(); sp[wd, e] += h; sm[wd, e] -= h
+    with torch.no_grad():
+        world.reset_lcp_cache(); fp = timestep(world, torch.tensor(sp, device="cuda:0"), at).cpu().numpy()[wd]
+        world.reset_lcp_cache(); fm = timestep(world, torch.tensor(sm, device="cuda:0"), at).cpu().numpy()[wd]
+    num = float(np.dot(g[wd], (fp - fm) / (2 * h)))
+    assert abs(num - dev["grad_state"][e]) < 1e-5 * sc["grad_state"], (num, dev["grad_state"][e], fd["grad_state"][0][e])
+    assert soak_parity.exact_derivatives_agree(ow, 1e-6, s1n[wd], a[wd], g[wd], dev, sc)

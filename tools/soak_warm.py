@@ -76,6 +76,9 @@ def run(first=0, count=20, B=256, mode="balls", verbose=True, stress=None):
             elif (soak_parity.near_log_map_singularity(md, r2["next"][wd]) and err[wd] < 3e-3
                   and max(np.abs(dev[k][wd] - r2[k][wd]).max() / scales[k] for k in ("next", "grad_action")) <= 1e-5):
                 tot["reference_fd_near_pi"] = tot.get("reference_fd_near_pi", 0) + 1   # (the reference's finite-differenced SO(3) integration)
+            elif soak_parity.exact_derivatives_agree(ow, 1e-5, s1n[wd], a[wd], g[wd], {k: dev[k][wd] for k in dev}, scales,
+                                                     lcp=(r1["lcp"][wd], int(r1["lcp_len"][wd]))):
+                tot["reference_fd_exact_agrees"] = tot.get("reference_fd_exact_agrees", 0) + 1   # (... proven by the exact-derivative instrument)
             else:
                 mismatch += 1
                 print(f"  MISMATCH seed {seed} world {wd}: err {err[wd]:.2e} spread {spread:.2e} nearest {nearest:.2e} status dev {st2[wd]:#x} ref {r2['status'][wd]:#x}")
