@@ -356,8 +356,14 @@ def main():
         tm = world.get_timing()
         world.set_timing(False)
         st = status.cpu().numpy().astype(np.uint32)
+        # (the handles - and the HIP streams they own - die with this frame: a later measurement starts with fresh streams.  The runtime maps
+        #  streams to its four hardware queues in creation order; with the streams of an earlier handle still alive the two slices of a
+        #  joined call shared a queue: `single_call` 3.85 instead of 5.9 M/s)
+        n_slices = len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))
+        dims = {"n": world.n, "m": world.m, "saved_bytes_per_world": int(world._L.nbl_saved_bytes(world._h, B) // B)}
+        del deferred, graphed, worlds, world
         return {"elapsed": elapsed, "reps": reps, "rank_min": rank_min, "status": st, "timing": tm, "timing_period": timing_period, "md": md, "s": s_np, "a": a_np,
-                "desc": wl_desc, "world": world, "slices": len(bounds) * max(1, world.slices_for(bounds[0][1] - bounds[0][0]))}
+                "desc": wl_desc, "dims": dims, "slices": n_slices}
 
     has_contact = args.workload.endswith("_contact")
     # The timed region is ONE model handle in deferred-join mode (round 6): `--streams k` (k > 0) goes back to round 5's
@@ -406,14 +412,14 @@ def main():
         host_tensors = {"elapsed": time.perf_counter() - t0h, "steps": hsteps}
         torch.set_num_threads(cpu_threads)
         del hw
-    elapsed, st, tm, timing_period, md, s_np, a_np, wl_desc, world = (R[x] for x in ("elapsed", "status", "timing", "timing_period", "md", "s", "a", "desc", "world"))
-    n = world.n
+    elapsed, st, tm, timing_period, md, s_np, a_np, wl_desc, dims = (R[x] for x in ("elapsed", "status", "timing", "timing_period", "md", "s", "a", "desc", "dims"))
+    n = dims["n"]
 
     if rank == 0:
         units_per_step = B * world_size * max(1, args.rollout)
         total_units = units_per_step * args.steps
         value = total_units / elapsed
-        m_rows = 24 if world.m > 0 else 0
+        m_rows = 24 if dims["m"] > 0 else 0
         kern = {kname: v["ms_sum"] / v["count"] for kname, v in tm["kernels"].items()}
         if not kern:   # no per-kernel events (--no-kernel-timing, or the rollout entry points, which own their streams): whole-step figures
             kern = {"whole_step": elapsed / args.steps * 1e3 / max(1, args.rollout)}
@@ -498,7 +504,7 @@ def main():
                                    (f"; one step = one {args.rollout}-step rollout fwd+bwd (warm-started after its first step)" if args.rollout else ""),
                        "n_dofs": n, "contacts": m_rows // 3, "lcp_rows": m_rows, "worlds_per_gpu": B, "dt": md.dt,
                        "joint_noise": args.joint_noise if has_contact else None, "rollout_T": args.rollout or None, "rollout_checkpoint_every": (args.checkpoint_every or None) if args.rollout else None,
-                       "saved_record_bytes_per_world_step": int(world._L.nbl_saved_bytes(world._h, B) // B),
+                       "saved_record_bytes_per_world_step": dims["saved_bytes_per_world"],
                        "rccl_world_size": (dist.get_world_size() if use_dist else 0),
                        # per-rank spread of the reported (median) repetition: the slowest rank is the one that counts (ms_per_step), the
                        # fastest says how far apart the ranks are - so that the first real multi-GPU run explains itself
