@@ -1100,12 +1100,30 @@ int32_t nbl_selftest_lcp_dantzig(int32_t count, int32_t n, const double* A, cons
   return nbl_selftest_lcp_dantzig_timed(count, n, A, b, lo, hi, findex, x, rc, 1, nullptr);
 }
 
+#if NBL_GENERAL
+// The self-tests of the general instantiations work in HBM scratch like the step: genScratchDoubles(GR) doubles per problem (1.5 MB at 192
+// rows, 5.9 MB at 384) whatever n is.  A batch that does not fit the device's free memory is refused with the number that would fit, instead
+// of a bare HIP out-of-memory error.
+static int32_t selftestScratchCheck(const char* what, int32_t count) {
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return NBL_OK;
+  const size_t per = genScratchDoubles(GR) * sizeof(double);
+  if ((size_t)count * per > freeB / 2)
+    return fail(NBL_E_BADARG, std::string(what) + ": this instantiation (" + std::to_string(GR) + " rows) needs " + std::to_string(per >> 10) + " kB of device scratch per problem; at most " +
+                                  std::to_string(freeB / 2 / per) + " problems per call fit half of the free device memory, " + std::to_string(count) + " were given");
+  return NBL_OK;
+}
+#endif
+
 int32_t nbl_selftest_lcp_dantzig_timed(int32_t count, int32_t n, const double* A, const double* b, const double* lo, const double* hi,
                                        const int32_t* findex, double* x, int32_t* rc, int32_t reps, double* ms_per_launch) {
   if (!A || !b || !lo || !hi || !findex || !x || !rc) return fail(NBL_E_BADARG, "null argument");
   if (reps < 1) return fail(NBL_E_BADARG, "reps must be positive");
   if (count <= 0 || n <= 0 || n > MAX_ROWS) return fail(NBL_E_BADARG, "count must be positive and 1 <= n <= " + std::to_string(MAX_ROWS));
   if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
+#if NBL_GENERAL
+  if (const int32_t rcS = selftestScratchCheck("nbl_selftest_lcp_dantzig", count)) return rcS;
+#endif
   const size_t nv = (size_t)count * n, nm = nv * n;
   double *dA = nullptr, *dv = nullptr;
   int32_t* di = nullptr;
@@ -1162,6 +1180,7 @@ int32_t nbl_selftest_lcp_cascade(int32_t count, int32_t mRows, const double* A, 
   if (!A || !b || !mu || !x || !cls || !st || !cfm || (have_cache && !x_cache)) return fail(NBL_E_BADARG, "null argument");
   if (count <= 0 || mRows <= 0 || mRows > MAX_ROWS || mRows % 3) return fail(NBL_E_BADARG, "count must be positive and m a multiple of 3 up to " + std::to_string(MAX_ROWS));
   if (nbl_device_count() <= 0) return fail(NBL_E_NOGPU, "no HIP device visible");
+  if (const int32_t rcS = selftestScratchCheck("nbl_selftest_lcp_cascade", count)) return rcS;
   const size_t nv = (size_t)count * mRows, nm = nv * mRows, nc = (size_t)count * (mRows / 3);
   double *dA = nullptr, *dv = nullptr, *dS = nullptr;
   int32_t* di = nullptr;

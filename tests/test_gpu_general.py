@@ -41,9 +41,10 @@ def _fwd_bwd(md, s, a, seed, lcp=None):
 
 
 def test_the_general_dantzig_driver_is_bit_identical_to_the_reference_on_the_device():
-    """nbl_selftest_lcp_dantzig with n > 48 runs gen_dantzig_dev.hpp::genDantzigSeq on the GPU (lane 0 of a wavefront per problem, the
-    problem in HBM): success flag and every bit of x equal to the reference's own dSolveLCP (oracle/_ref), 51 .. 384 rows, rank-deficient
-    contact problems included."""
+    """nbl_selftest_lcp_dantzig with n > 48 runs gen_dantzig_dev.hpp::genDantzigPar on the GPU (round 6: the wave-shared driver - what the
+    step runs -, one wavefront per problem, the problem in HBM): success flag and every bit of x equal to the reference's own dSolveLCP
+    (oracle/_ref), 51 .. 384 rows, rank-deficient contact problems included.  A batch whose scratch would not fit the device is refused
+    with a clear argument error."""
     import oracle
     from nimblephysics_amd import _lib
     from util import contact_lcp, have_ref
@@ -85,6 +86,10 @@ def test_the_general_dantzig_driver_is_bit_identical_to_the_reference_on_the_dev
                 failed += 1
     print(f"[general Dantzig on the device] {solved} problems of 51 .. 384 rows solved bit for bit, {failed} early exits, all flags equal")
     assert solved >= 20
+    # 2 million problems of 51 rows would need 3 TB of scratch (1.5 MB each): an argument error that says how many fit, before anything is read
+    r = L.nbl_selftest_lcp_dantzig(2_000_000, 51, A.ctypes.data_as(pd), b.ctypes.data_as(pd), lo.ctypes.data_as(pd), hi.ctypes.data_as(pd),
+                                   fi.ctypes.data_as(pi), x.ctypes.data_as(pd), rc.ctypes.data_as(pi))
+    assert r != 0 and b"problems per call" in L.nbl_last_error(), (r, L.nbl_last_error())
 
 
 def test_the_metric_distribution_on_the_general_build():
