@@ -14,3 +14,5 @@ timeout 900 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_suite.log 2
 timeout 600 python -m pytest tests/test_gpu_general.py -q -s 2>&1 | grep -v amdgpu.ids | cut -c1-600 > gpurun_out/${TAG}_gpu_general_tests.log; tail -1 gpurun_out/${TAG}_gpu_general_tests.log
 timeout 600 bash tools/final_soak.sh 500000 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_final_soak.log; grep -c "MISMATCH.: 0" gpurun_out/${TAG}_final_soak.log
 NBL_SOAK_SLOTS=64 timeout 600 bash tools/final_soak.sh 600000 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_general_final_soak.log; grep -c "MISMATCH.: 0" gpurun_out/${TAG}_general_final_soak.log
+# the bench lines once more, now that profiles/pmc_traffic.json and fp64_flops.json of THIS build exist (tools/aggregate_profile.py needs the
+# merged-back counters: run `python tools/aggregate_profile.py <tag> atlas20_contact@0.02` and then tools/dbg/r06_final2.sh for lines with `traffic` and `fp64`)
