@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64) void k_selftest_dantzig_gen(int count, int n, c
   if (pb >= count) return;
   const GenScratch S = genScratchOf(gws, pb, gws + (size_t)pb * genScratchDoubles(GR) + (size_t)3 * GR * GR, GR);   // (self-test: leading dimension = the cap)
   GenProblem P; GenDantzigMem D;
-  genCarve(S, P, D);
+  genCarve(S, P, D, n);
   for (int j = ln; j < n; j += 64) {
     for (int i = 0; i < n; i++) P.A[(size_t)i * GR + j] = A[(pb * n + i) * n + j];
     P.b[j] = b[pb * n + j]; P.lo[j] = lo[pb * n + j]; P.hi[j] = hi[pb * n + j]; P.findex[j] = findex[pb * n + j]; P.x[j] = 0.0;

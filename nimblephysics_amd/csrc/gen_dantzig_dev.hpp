@@ -19,7 +19,8 @@
 namespace NBL_NS {
 
 struct GenDantzigMem {      // all in the world's HBM scratch
-  int ld;                   // leading dimension of A and L
+  int ld;                   // leading dimension of A (and of the scratch matrix of the removals)
+  int ldL;                  // ... of L: the factor may live packed in fast memory (genCarve)
   double* A;                // n x n (leading dimension ld): the problem's matrix; symmetrised and permuted in place
   double* L;                // factor rows
   double *d, *x, *w, *b, *lo, *hi, *dx, *dw, *ell, *Dell, *tmp, *tvec, *W1, *W2;
@@ -33,7 +34,7 @@ DEV int genDantzigSeq(const GenDantzigMem& M, int n, double* xOut) {
 #endif
   double* A = M.A; double* L = M.L;
   auto AA = [&](int i, int j) -> double& { return A[(size_t)i * M.ld + j]; };
-  auto LL = [&](int i, int j) -> double& { return L[(size_t)i * M.ld + j]; };
+  auto LL = [&](int i, int j) -> double& { return L[(size_t)i * M.ldL + j]; };
   // dDot (fastdot.cpp): the running sum from 0 in index order
   auto dotRows = [&](const double* a, const double* b, int cnt) -> double { double s = 0.0; for (int k = 0; k < cnt; k++) s = s + a[k] * b[k]; return s; };
   int nC = 0, nN = 0;
@@ -336,9 +337,9 @@ DEV int genDantzigPar(const W& wv, const GenDantzigMem& M, int n, double* xOut, 
 #endif
   const int ln = wv.lane(), NL = wv.lanes();
   double* A = M.A; double* L = M.L;
-  const size_t ld = (size_t)M.ld;
+  const size_t ld = (size_t)M.ld, ldL = (size_t)M.ldL;
   auto AA = [&](int i, int j) -> double& { return A[(size_t)i * ld + j]; };
-  auto LL = [&](int i, int j) -> double& { return L[(size_t)i * ld + j]; };
+  auto LL = [&](int i, int j) -> double& { return L[(size_t)i * ldL + j]; };
   // the running sum of v[0 .. cnt) from +0.0 in index order (fastdot.cpp) - formed by every lane: the same bits everywhere
   auto runSum = [&](const double* v, int cnt) -> double { double s = 0.0; for (int k = 0; k < cnt; k++) s = s + v[k]; return s; };
   // dDot(a, b, cnt), uniform result.  (prod is free again when the call returns.)
@@ -679,26 +680,35 @@ constexpr int GS_SOLVED = 1;   // the solver reported success (Dantzig: no early
 constexpr int GS_VALID = 2;    // ... and isLCPSolutionValid accepted it
 constexpr int GS_NAN = 4;      // Dantzig: NaN step length
 
-// carve the problem arrays and the Dantzig arrays out of the world's scratch (mat[4]: the problem's matrix, mat[1]: the factor)
-DEV void genCarve(const GenScratch& S, GenProblem& P, GenDantzigMem& D) {
+// The stride of the cascade's scratch vectors: the model's rows in HBM scratch; in the fast pool (LDS) the WORLD's rows rounded up to 8 -
+// sixteen vectors of an eight-contact world then take 384 of the pool's 1152 doubles whatever the model's slot count is, and the rest
+// holds the Dantzig factor (genCarve) or the matrix of the Gauss-Seidel sweeps (genPgsAT).
+DEV int genVecStride(const GenScratch& S, int m) { return S.vecFast ? ((m + 7) & ~7) : S.ld; }
+// carve the problem arrays and the Dantzig arrays out of the world's scratch (mat[4]: the problem's matrix, mat[1]: the factor - or, for a
+// world small enough, the factor PACKED (leading dimension m) behind the vectors in the fast pool: the two triangular solves and the
+// factor updates of every pivot read and write it through barriers, and in HBM scratch each of those waited for memory - 21 k cycles per
+// pivot against the 24-row build's 8 k).  m: the world's rows.
+DEV void genCarve(const GenScratch& S, GenProblem& P, GenDantzigMem& D, int m) {
   double* v = S.vec;
-  const int g = S.ld;       // (every vector of the carve-up has ld entries: ld >= the model's rows, a multiple of 8)
-  P.ld = g; D.ld = g;
+  const int g = genVecStride(S, m);
+  P.ld = S.ld; D.ld = S.ld;
   P.A = S.mat[4]; P.x = v; P.b = v + g; P.lo = v + 2 * g; P.hi = v + 3 * g;
   P.findex = reinterpret_cast<int*>(v + 4 * g); P.mapTo = P.findex + g;
-  D.A = S.mat[4]; D.L = S.mat[1];
+  D.A = S.mat[4]; D.L = S.mat[1]; D.ldL = S.ld;
+  if (S.vecFast && (size_t)16 * g + (size_t)m * m <= (size_t)S.vecDoubles) { D.L = v + 16 * g; D.ldL = m; }
   // (v + 5 g: the candidate of a stage, genCascade; the Dantzig driver's vectors come last: Gauss-Seidel takes their place, genPgsAT)
   D.d = v + 6 * g; D.x = v + 7 * g; D.w = v + 8 * g; D.dx = v + 9 * g; D.dw = v + 10 * g; D.ell = v + 11 * g; D.Dell = v + 12 * g;
-  D.tmp = v + 13 * g; D.tvec = S.mat[2]; D.W1 = S.mat[2] + 2 * g; D.W2 = S.mat[2] + 3 * g;
+  D.tmp = v + 13 * g; D.tvec = S.mat[2]; D.W1 = S.mat[2] + 2 * S.ld; D.W2 = S.mat[2] + 3 * S.ld;
   D.b = P.b; D.lo = P.lo; D.hi = P.hi; D.findex = P.findex;
   D.p = reinterpret_cast<int*>(v + 14 * g); D.C = D.p + g; D.state = reinterpret_cast<int*>(v + 15 * g);
 }
 // The scaled, transposed matrix of the Gauss-Seidel sweeps: packed in the part of the fast vector region the Dantzig driver's vectors
-// occupy (v + 6 ld to the end: they are dead while Gauss-Seidel runs) when the problem is small enough, else the scratch matrix.
+// occupy (v + 6 g to the end: they are dead while Gauss-Seidel runs) when the problem is small enough, else the scratch matrix.
 struct GenPgsAT { double* AT; int ld; bool lds; };
-DEV GenPgsAT genPgsAT(const GenScratch& S, int n) {
+DEV GenPgsAT genPgsAT(const GenScratch& S, int n, int m) {
   GenPgsAT a;
-  if (S.vecFast && (size_t)n * n + (size_t)6 * S.ld <= (size_t)S.vecDoubles) { a.AT = S.vec + 6 * S.ld; a.ld = n; a.lds = true; }
+  const int g = genVecStride(S, m);
+  if (S.vecFast && (size_t)n * n + (size_t)6 * g <= (size_t)S.vecDoubles) { a.AT = S.vec + 6 * g; a.ld = n; a.lds = true; }
   else if (S.fast && S.fastMats >= 1 && n <= S.fastN) { a.AT = S.fast; a.ld = S.fastN; a.lds = true; }
   else { a.AT = S.mat[1]; a.ld = S.ld; a.lds = false; }
   return a;
@@ -716,7 +726,7 @@ template <class W>
 DEV int genStage1(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double* out) {
   GenProblem P; GenDantzigMem D;
   GEN_T0();
-  genCarve(S, P, D);
+  genCarve(S, P, D, R.m);
   genLoadProblem(w, A, lda, R, 0.0, R.X0, P);
   genLcpReduce(w, R, P, R.m);
   GEN_T(4);
@@ -726,7 +736,7 @@ DEV int genStage1(const W& w, const double* A, int lda, GenRows& R, const GenScr
     const int N = S.fastN, n = P.n;
     GenDantzigMem F;
     double* v = S.fast + (size_t)GEN_FAST_MATS * N * N;
-    F.ld = N; F.A = S.fast; F.L = S.fast + (size_t)N * N;
+    F.ld = N; F.ldL = N; F.A = S.fast; F.L = S.fast + (size_t)N * N;
     F.d = v; F.x = v + N; F.w = v + 2 * N; F.dx = v + 3 * N; F.dw = v + 4 * N; F.ell = v + 5 * N; F.Dell = v + 6 * N; F.tmp = v + 7 * N;
     F.b = v + 8 * N; F.lo = v + 9 * N; F.hi = v + 10 * N; F.tvec = v + 11 * N;                    // (tvec: 2 N)
     F.W1 = nullptr; F.W2 = nullptr;
@@ -753,13 +763,13 @@ DEV int genStage1(const W& w, const double* A, int lda, GenRows& R, const GenScr
 template <class W>
 DEV int genStage2(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double cfm, double* out) {
   GenProblem P; GenDantzigMem D;
-  genCarve(S, P, D);
+  genCarve(S, P, D, R.m);
   genLoadProblem(w, A, lda, R, cfm, R.X0, P);
   genLcpReduce(w, R, P, R.m);
   int flags = 0;
   for (int r = w.lane(); r < R.m; r += w.lanes()) out[r] = 0.0;
   w.sync();
-  const GenPgsAT at = genPgsAT(S, P.n);
+  const GenPgsAT at = genPgsAT(S, P.n, R.m);
   if (genPgs(w, R, P, at.AT, at.ld, at.lds)) {
     genMapOut(w, R, P, P.x, out);
     flags = GS_SOLVED | (genValid(w, A, lda, R, out, false, cfm, R.t2) ? GS_VALID : 0);
@@ -770,12 +780,12 @@ DEV int genStage2(const W& w, const double* A, int lda, GenRows& R, const GenScr
 template <class W>
 DEV int genStage3(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double cfm, double* out) {
   GenProblem P; GenDantzigMem D;
-  genCarve(S, P, D);
+  genCarve(S, P, D, R.m);
   genLoadProblem(w, A, lda, R, cfm, R.X0, P);
   genLcpRemoveFriction(w, R, P, R.m, S.mat[1]);
   for (int c = w.lane(); c < P.n; c += w.lanes()) P.x[c] = 0.0;
   w.sync();
-  const GenPgsAT at = genPgsAT(S, P.n);
+  const GenPgsAT at = genPgsAT(S, P.n, R.m);
   const bool ok3 = genPgs(w, R, P, at.AT, at.ld, at.lds);
   genMapOut(w, R, P, P.x, out);
   return ok3 ? GS_SOLVED : 0;
@@ -788,7 +798,7 @@ template <class W>
 DEV void genCascade(const W& w, const double* A, int lda, GenRows& R, const GenScratch& S, double fallbackCfm, double& cfmOut, uint32_t& stOut,
                     bool& pinvValid, GenClasses& K) {
   const int m = R.m;
-  double* cand = S.vec + 5 * S.ld;
+  double* cand = S.vec + 5 * genVecStride(S, m);
   auto hasNan = [&](const double* x) -> bool { bool b = false; for (int r = w.lane(); r < m; r += w.lanes()) if (x[r] != x[r]) b = true; return w.anyAll(b); };
   auto take = [&](const double* x) { for (int r = w.lane(); r < m; r += w.lanes()) R.X[r] = R.on[r] ? x[r] : 0.0; w.sync(); };
   bool success = false, ignoreFriction = false;

@@ -103,7 +103,7 @@ int gshim_dantzig(int n, const double* A, const double* b, const double* lo, con
   World Wd(n);
   const int GLD = Wd.ld;
   GenProblem P; GenDantzigMem D;
-  genCarve(Wd.S, P, D);
+  genCarve(Wd.S, P, D, n);
   for (int i = 0; i < n; i++) {
     for (int j = 0; j < n; j++) P.A[(size_t)i * GLD + j] = A[(size_t)i * n + j];
     P.b[i] = b[i]; P.lo[i] = lo[i]; P.hi[i] = hi[i]; P.findex[i] = findex[i]; P.x[i] = 0.0;
@@ -170,7 +170,7 @@ int gshim_dantzig_par(int n, const double* A, const double* b, const double* lo,
   World Wd(n);
   const int GLD = Wd.ld;
   GenProblem P; GenDantzigMem D;
-  genCarve(Wd.S, P, D);
+  genCarve(Wd.S, P, D, n);
   for (int i = 0; i < n; i++) {
     for (int j = 0; j < n; j++) P.A[(size_t)i * GLD + j] = A[(size_t)i * n + j];
     P.b[i] = b[i]; P.lo[i] = lo[i]; P.hi[i] = hi[i]; P.findex[i] = findex[i]; P.x[i] = 0.0;
