@@ -120,7 +120,8 @@ typedef struct nbl_model_desc {
                                NBL_ST_CONTACT_OVERFLOW.  The library holds three instantiations of its contact stage: models with max_contacts
                                <= 8, <= 16 colliders and <= 32 collider pairs run the 24-row one (the fast one), up to 16 contacts / 32
                                colliders / 64 pairs the 48-row one, everything up to 64 contacts (192 rows) / 64 colliders / 512 pairs the
-                               GENERAL one, whose dense kernels loop over the rows: slow, and roomy enough that a model can always be given
+                               GENERAL one, whose dense kernels loop over the rows (since round 6 at 2 M world-steps/s on eight-contact worlds, 29 % of the 24-row
+                               build's rate; on worlds that fill 12 - 16 slots the 48-row one is 2 - 3.7 x faster), roomy enough that a model can always be given
                                the slots its colliders can fill (a tower of ten cubes: 40 contacts in one constrained group).  A model that
                                asks for 65 .. 128 slots gets the same general code with 384 rows (four times the scratch and record per world:
                                ten cubes each turned against the next touch in clipped octagons, 80 contacts) */

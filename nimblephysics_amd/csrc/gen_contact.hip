@@ -5,7 +5,8 @@
 //                           group, the record's Q^+, v' = v_pre + M^-1 J^T x                            (gen_lcp_dev.hpp / gen_dantzig_dev.hpp)
 //   k_bwd_contact_a_gen     the dense (c x c) part of the contact adjoint;  k_bwd_contact_b_gen  its tree part;  k_bwd_bounce_gen
 // Same record, same scratch rows and the same mathematics as coop_kernels.hip, whose kernels are written around lane = LCP row with at most
-// 64 rows and register-resident columns: here a lane strides through the rows, matrices live in the world's slice of HBM and vectors in LDS.
+// 64 rows and register-resident columns: here a lane strides through the rows, matrices live in the world's slice of HBM, vectors - and,
+// for a world of few rows, the matrices a factorisation works on - in LDS (round 6: 0.58 -> 2 M world-steps/s on eight-contact worlds).
 // Nothing of the metric path runs through this file (nimble_amd_dispatch.cpp hands a model to this instantiation only when it asks for more
 // than 16 contact slots / 32 colliders / 64 collider pairs); it exists so that no legal world gets a truncated answer.
 #include "gen_lcp_dev.hpp"
@@ -273,7 +274,7 @@ constexpr int GEN_VEC_LDS_ROWS = 96;
 // ... and never fewer than GEN_VEC_LDS_MIN doubles: the pool also lends itself, packed by the WORLD's rows, to the working pair of the
 // pseudo-inverse (2 m^2) and to the matrix of the Gauss-Seidel sweeps (n^2) - 1152 doubles hold the pair of a world of eight contacts
 // whatever the model's slot count is (a 16-slot model would otherwise send its eight-contact worlds to HBM scratch: 1.46 against 1.74 M/s)
-constexpr int GEN_VEC_LDS_MIN = 1152;
+constexpr int GEN_VEC_LDS_MIN = 1152;      // (1536 - room for the Dantzig matrix as well - was measured: the solve kernel unchanged, its neighbours 2.5 % slower)
 __host__ __device__ inline size_t genSolveVecDoubles(int rows) { return rows <= GEN_VEC_LDS_ROWS ? ((size_t)16 * rows > GEN_VEC_LDS_MIN ? (size_t)16 * rows : (size_t)GEN_VEC_LDS_MIN) : 0; }
 __host__ __device__ inline size_t genSolveLdsBytes(int rows) {
   const int cap = genRowsCap(rows);

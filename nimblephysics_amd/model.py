@@ -458,8 +458,8 @@ class ModelDescription:
     def suggest_max_contacts(self) -> int:
         """Contact slots per world for a description that does not say (the loaders' default): the smallest of the library's three budgets that
         the collider pairs of the model cannot exceed in their usual configurations - 8 (the 24-row build, the fast one), 16 (the 48-row
-        build) or, beyond that, what the pairs can hold rounded up to a multiple of 8, at most 64 (the GENERAL build: rows looped over, slow,
-        no truncated answers: a tower of ten cubes holds 40 contacts).  Counted per pair that is tested at all (CollisionFilter.cpp:105-154):
+        build) or, beyond that, what the pairs can hold rounded up to a multiple of 8, at most 64 (the GENERAL build: rows looped over, 29 % of the
+        24-row build's rate on eight-contact worlds, no truncated answers: a tower of ten cubes holds 40 contacts).  Counted per pair that is tested at all (CollisionFilter.cpp:105-154):
         a box on a world-fixed box 4 points (the ground's face contains the other one), two moving boxes 8 (dBoxBox's clipped octagon: the
         reference keeps every point, DARTCollide.cpp:1384-1448), capsule pairs 2, every other pair 1; of the pairs of one moving collider with
         several others only as many as can touch it at once are counted (a body has 6 faces; in a pile at most 2 face contacts of 8 + 4 of 4).
