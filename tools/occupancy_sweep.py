@@ -14,12 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "build", "variants")
 VARIANTS = {
     "base": [],
-    "bwdb3": ["-DNBL_W_BWDB=3"],
-    "recomp3": ["-DNBL_W_RECOMP=3"],
-    "bfinal3": ["-DNBL_W_BFINAL=3"],
+    "stages2": ["-DNBL_W_STAGES=2"],
     "stages3": ["-DNBL_W_STAGES=3"],
-    "fwd3": ["-DNBL_W_FWD=3"],
-    "bwda4": ["-DNBL_W_BWDA=4"],
+    "stages4": ["-DNBL_W_STAGES=4"],
+    "solve1": ["-DNBL_W_SOLVE=1"],
+    "cfinal1": ["-DNBL_W_CFINAL=1"],
+    "bwdb3": ["-DNBL_W_BWDB=3"],
     "rows4": ["-DNBL_W_ROWS=4"],
 }
 
