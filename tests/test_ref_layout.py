@@ -73,3 +73,37 @@ def test_layout_arithmetic():
     assert torch.equal(J[[0, 3, 5, 8]][:, [0, 3, 5, 8]], torch.eye(4, dtype=torch.float64))
     assert float(J[1, 2]) == 7.0 and float(J[0, 1]) == 0.0 and float(J[1, 0]) == 0.0
     assert lay.device_action_map([0, 1, 2, 4]) == [0, 1, 2] and lay.action_columns([0, 1, 2, 4]) == [1, 2, 3]
+
+
+REF_SKEL = "/root/reference/data/skel"
+JOINT_DOFS = {"free": 6, "ball": 3, "euler": 3, "revolute": 1, "prismatic": 1, "screw": 1, "universal": 2, "translational": 3, "translational2d": 2, "planar": 3, "weld": 0}
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF_SKEL), reason="the reference's data files are not here")
+@pytest.mark.parametrize("name", ["cubes.skel", "fullbody1.skel", "cartpole.skel", "ground.skel", "two_cubes.skel", "test/box_stacking.skel", "test/file_info_world_test.skel"])
+def test_the_state_length_of_the_references_own_skel_files(name):
+    """getStateSize() of the drop-in surface = 2 x the coordinates of EVERY skeleton of the file, immobile ones included - what
+    World::getNumDofs() counts in the reference (World.cpp:2016-2047): the joints of the file, counted here straight from the XML, against
+    the loader's record of the reference's coordinate order (ref_dof_mobile: one entry per reference coordinate; True = a device coordinate)."""
+    import os
+    import warnings
+    import xml.etree.ElementTree as ET
+    from nimblephysics_amd.loaders import load_skel
+    from nimblephysics_amd.ref_layout import RefLayout
+    path = os.path.join(REF_SKEL, name)
+    want = 0
+    immobile = 0
+    for sk in ET.parse(path).getroot().iter("skeleton"):
+        mob = (sk.findtext("mobile") or "true").strip().lower() not in ("false", "0")
+        for j in sk.findall("joint"):
+            nd = JOINT_DOFS[j.get("type").lower()]
+            want += nd
+            immobile += 0 if mob else nd
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        md = load_skel(path)
+    mobile = md.ref_dof_mobile if md.ref_dof_mobile is not None else [True] * md.num_dofs
+    lay = RefLayout(mobile)
+    assert lay.n_ref == want, (name, lay.n_ref, want)                     # the reference's getNumDofs()
+    assert lay.n_dev == md.num_dofs == want - immobile, (name, lay.n_dev, md.num_dofs, want, immobile)
+    print(f"{name}: {want} reference coordinates, {immobile} of immobile skeletons (frozen), {md.num_dofs} on the device")
