@@ -341,7 +341,14 @@ DEV int genDantzigPar(const W& wv, const GenDantzigMem& M, int n, double* xOut, 
   auto AA = [&](int i, int j) -> double& { return A[(size_t)i * ld + j]; };
   auto LL = [&](int i, int j) -> double& { return L[(size_t)i * ldL + j]; };
   // the running sum of v[0 .. cnt) from +0.0 in index order (fastdot.cpp) - formed by every lane: the same bits everywhere
-  auto runSum = [&](const double* v, int cnt) -> double { double s = 0.0; for (int k = 0; k < cnt; k++) s = s + v[k]; return s; };
+  // (four terms fetched before the four dependent additions - gen_lcp_dev.hpp::genFmaSeq says why: a plain loop waits for every load)
+  auto runSum = [&](const double* v, int cnt) -> double {
+    double s = 0.0;
+    int k = 0;
+    for (; k + 3 < cnt; k += 4) { const double v0 = v[k], v1 = v[k + 1], v2 = v[k + 2], v3 = v[k + 3]; s = s + v0; s = s + v1; s = s + v2; s = s + v3; }
+    for (; k < cnt; k++) s = s + v[k];
+    return s;
+  };
   // dDot(a, b, cnt), uniform result.  (prod is free again when the call returns.)
   auto dotAll = [&](const double* a, const double* b, int cnt) -> double {
     for (int k = ln; k < cnt; k += NL) prod[k] = a[k] * b[k];
@@ -519,7 +526,15 @@ DEV int genDantzigPar(const W& wv, const GenDantzigMem& M, int n, double* xOut, 
       const int pr = M.C[r];
       for (int i = ln; i < n2 - r; i += NL) {
         double sdot = 0.0;
-        for (int k = 0; k < r; k++) sdot = sdot + LL(r + i, k) * t[k];           // dDot(L[r + i], t, r)
+        {                                                                         // dDot(L[r + i], t, r)
+          int k = 0;
+          for (; k + 3 < r; k += 4) {
+            const double l0 = LL(r + i, k), l1 = LL(r + i, k + 1), l2 = LL(r + i, k + 2), l3 = LL(r + i, k + 3);
+            const double t0 = t[k], t1 = t[k + 1], t2 = t[k + 2], t3 = t[k + 3];
+            sdot = sdot + l0 * t0; sdot = sdot + l1 * t1; sdot = sdot + l2 * t2; sdot = sdot + l3 * t3;
+          }
+          for (; k < r; k++) sdot = sdot + LL(r + i, k) * t[k];
+        }
         double v = sdot - AA(M.C[r + i], pr);
         if (i == 0) v += 1.0;
         a[i] = v;

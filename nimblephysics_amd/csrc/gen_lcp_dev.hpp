@@ -82,6 +82,35 @@ __host__ __device__ inline void genRowsCarve(GenRows& R, double* pool, int cap) 
 constexpr int GEN_NMAT = 5;
 __host__ __device__ inline size_t genScratchDoubles(int ld) { return (size_t)GEN_NMAT * ld * ld + (size_t)16 * ld; }
 
+// ---- sequential sums with their operands fetched FOUR steps at a time -------------------------------------------------------------------
+// acc = fma(a(i), b(i), acc) for i = from .. to - 1 IN THAT ORDER (the bits of the plain loop).  Written as a plain loop the compiler
+// neither unrolls it (run-time bounds) nor moves the loads of step i + 1 above the multiply-add of step i: every step then waits for
+// its own loads - an LDS or L2 round trip per term (the ISA of round 6's first build: s_waitcnt vmcnt(0) lgkmcnt(0) in every iteration,
+// 11 instructions per term).  Here the loads of four steps are independent statements before the four dependent multiply-adds.
+template <class FA, class FB>
+DEV double genFmaSeq(int from, int to, double acc, FA a, FB b) {
+  int i = from;
+  for (; i + 3 < to; i += 4) {
+    const double a0 = a(i), a1 = a(i + 1), a2 = a(i + 2), a3 = a(i + 3);
+    const double b0 = b(i), b1 = b(i + 1), b2 = b(i + 2), b3 = b(i + 3);
+    acc = fma(a0, b0, acc); acc = fma(a1, b1, acc); acc = fma(a2, b2, acc); acc = fma(a3, b3, acc);
+  }
+  for (; i < to; i++) acc = fma(a(i), b(i), acc);
+  return acc;
+}
+// y(i) = fma(c, x(i), y(i)) for i = from .. to - 1 (independent steps), four at a time: loads, multiply-adds, stores
+template <class FX, class FY>
+DEV void genAxpy4(int from, int to, double c, FX x, FY y) {
+  int i = from;
+  for (; i + 3 < to; i += 4) {
+    const double x0 = x(i), x1 = x(i + 1), x2 = x(i + 2), x3 = x(i + 3);
+    double& r0 = y(i); double& r1 = y(i + 1); double& r2 = y(i + 2); double& r3 = y(i + 3);
+    const double y0 = r0, y1 = r1, y2 = r2, y3 = r3;
+    r0 = fma(c, x0, y0); r1 = fma(c, x1, y1); r2 = fma(c, x2, y2); r3 = fma(c, x3, y3);
+  }
+  for (; i < to; i++) { double& r = y(i); r = fma(c, x(i), r); }
+}
+
 // ---- dense helpers: lanes stride through the rows / columns, A symmetric with leading dimension lda ----------------------------------
 // y_r = sum_j A[j][r] x_j over the rows that are on (y = 0 on the others); x is masked by `on` as well
 template <class W>
@@ -89,7 +118,19 @@ DEV void genAx(const W& w, const double* A, int lda, const GenRows& R, const dou
   const int m = R.m;
   for (int r = w.lane(); r < m; r += w.lanes()) {
     double s = 0.0;
-    if (R.on[r]) for (int j = 0; j < m; j++) if (R.on[j]) s = fma(A[(size_t)j * lda + r], x[j], s);
+    if (R.on[r]) {
+      int j = 0;
+      for (; j + 3 < m; j += 4) {      // (operands of four terms first, then the four steps in order: genFmaSeq with the row mask)
+        const double a0 = A[(size_t)j * lda + r], a1 = A[(size_t)(j + 1) * lda + r], a2 = A[(size_t)(j + 2) * lda + r], a3 = A[(size_t)(j + 3) * lda + r];
+        const double x0 = x[j], x1 = x[j + 1], x2 = x[j + 2], x3 = x[j + 3];
+        const bool o0 = R.on[j] != 0, o1 = R.on[j + 1] != 0, o2 = R.on[j + 2] != 0, o3 = R.on[j + 3] != 0;
+        if (o0) s = fma(a0, x0, s);
+        if (o1) s = fma(a1, x1, s);
+        if (o2) s = fma(a2, x2, s);
+        if (o3) s = fma(a3, x3, s);
+      }
+      for (; j < m; j++) if (R.on[j]) s = fma(A[(size_t)j * lda + r], x[j], s);
+    }
     y[r] = s;
   }
   w.sync();
@@ -233,6 +274,10 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
       if (R.done[j]) continue;
       double s0 = 0.0, s1 = 0.0;
       int i = k;
+      for (; i + 3 < m; i += 4) {
+        const double a = M[(size_t)i * lm + j], b = M[(size_t)(i + 1) * lm + j], c = M[(size_t)(i + 2) * lm + j], d = M[(size_t)(i + 3) * lm + j];
+        s0 = fma(a, a, s0); s1 = fma(b, b, s1); s0 = fma(c, c, s0); s1 = fma(d, d, s1);
+      }
       for (; i + 1 < m; i += 2) { const double a = M[(size_t)i * lm + j], b = M[(size_t)(i + 1) * lm + j]; s0 = fma(a, a, s0); s1 = fma(b, b, s1); }
       if (i < m) { const double a = M[(size_t)i * lm + j]; s0 = fma(a, a, s0); }
       const double nrm = s0 + s1;
@@ -246,8 +291,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     for (int i = k + ln; i < m; i += nl) V[i] = M[(size_t)i * lm + p];
     w.sync();
     const double akk = V[k];
-    double below = 0.0;
-    for (int i = k + 1; i < m; i++) below = fma(V[i], V[i], below);
+    const double below = genFmaSeq(k + 1, m, 0.0, [&](int i) { return V[i]; }, [&](int i) { return V[i]; });
     const double normx = sqrt(fma(akk, akk, below));
     const double alpha = akk > 0 ? -normx : normx;
     const double vk = akk - alpha;
@@ -260,12 +304,11 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
       const int j = carried ? jj - m : jj;
       double* Mc = carried ? G : M;
       if (!carried && (R.done[j] || j == p)) continue;
-      double d = 0.0;
-      for (int i = k + 1; i < m; i++) d = fma(V[i], Mc[(size_t)i * lm + j], d);
+      double d = genFmaSeq(k + 1, m, 0.0, [&](int i) { return V[i]; }, [&](int i) { return Mc[(size_t)i * lm + j]; });
       d = fma(vinv, d, Mc[(size_t)k * lm + j]) * tau;
       Mc[(size_t)k * lm + j] -= d;
       const double dv = d * vinv;
-      for (int i = k + 1; i < m; i++) Mc[(size_t)i * lm + j] = fma(-dv, V[i], Mc[(size_t)i * lm + j]);
+      genAxpy4(k + 1, m, -dv, [&](int i) { return V[i]; }, [&](int i) -> double& { return Mc[(size_t)i * lm + j]; });
     }
     w.sync();
     if (ln == 0) { M[(size_t)k * lm + p] = alpha; R.done[p] = 1; R.perm[k] = p; }
@@ -296,7 +339,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
       const int pk = R.perm[kk];
       const double y = Mc[(size_t)kk * lm + j] * R.invd[kk];
       Mc[(size_t)kk * lm + j] = y;
-      for (int i = 0; i < kk; i++) Mc[(size_t)i * lm + j] = fma(-M[(size_t)i * lm + pk], y, Mc[(size_t)i * lm + j]);
+      genAxpy4(0, kk, y, [&](int i) { return -M[(size_t)i * lm + pk]; }, [&](int i) -> double& { return Mc[(size_t)i * lm + j]; });
     }
   }
   w.sync();
@@ -318,7 +361,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   for (int e = ln; e < r * r; e += nl) {
     const int a = e / r, b = e - a * r;
     double s = (a == b) ? 1.0 : 0.0;
-    for (int t = 0; t < nw; t++) { const int c = R.perm[r + t]; s = fma(M[(size_t)a * lm + c], M[(size_t)b * lm + c], s); }
+    s = genFmaSeq(0, nw, s, [&](int t) { return M[(size_t)a * lm + R.perm[r + t]]; }, [&](int t) { return M[(size_t)b * lm + R.perm[r + t]]; });
     T[(size_t)a * lt + b] = s;
   }
   w.sync();
@@ -326,7 +369,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   for (int k = 0; k < r; k++) {
     if (ln == 0) {
       double s = T[(size_t)k * lt + k];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * lt + i], T[(size_t)k * lt + i], s);
+      s = genFmaSeq(0, k, s, [&](int i) { return -T[(size_t)k * lt + i]; }, [&](int i) { return T[(size_t)k * lt + i]; });
       const double lkk = sqrt(s);
       T[(size_t)k * lt + k] = lkk;
       R.scal[0] = 1.0 / lkk;
@@ -335,7 +378,7 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
     const double inv = R.scal[0];
     for (int a = k + 1 + ln; a < r; a += nl) {
       double s = T[(size_t)a * lt + k];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)a * lt + i], T[(size_t)k * lt + i], s);
+      s = genFmaSeq(0, k, s, [&](int i) { return -T[(size_t)a * lt + i]; }, [&](int i) { return T[(size_t)k * lt + i]; });
       T[(size_t)a * lt + k] = s * inv;
     }
     w.sync();
@@ -344,19 +387,19 @@ DEV int genPinv(const W& w, GenRows& R, double* M, double* G, double* T, double*
   for (int j = ln; j < m; j += nl) {
     for (int k = 0; k < r; k++) {
       double s = G[(size_t)k * lm + j];
-      for (int i = 0; i < k; i++) s = fma(-T[(size_t)k * lt + i], G[(size_t)i * lm + j], s);
+      s = genFmaSeq(0, k, s, [&](int i) { return -T[(size_t)k * lt + i]; }, [&](int i) { return G[(size_t)i * lm + j]; });
       G[(size_t)k * lm + j] = s / T[(size_t)k * lt + k];
     }
     for (int k = r - 1; k >= 0; k--) {
       double s = G[(size_t)k * lm + j];
-      for (int i = k + 1; i < r; i++) s = fma(-T[(size_t)i * lt + k], G[(size_t)i * lm + j], s);
+      s = genFmaSeq(k + 1, r, s, [&](int i) { return -T[(size_t)i * lt + k]; }, [&](int i) { return G[(size_t)i * lm + j]; });
       G[(size_t)k * lm + j] = s / T[(size_t)k * lt + k];
     }
     for (int k = 0; k < r; k++) P[(size_t)R.perm[k] * ld + j] = G[(size_t)k * lm + j];
     for (int t = 0; t < nw; t++) {
       const int c = R.perm[r + t];
       double s = 0.0;
-      for (int i = 0; i < r; i++) s = fma(M[(size_t)i * lm + c], G[(size_t)i * lm + j], s);
+      s = genFmaSeq(0, r, s, [&](int i) { return M[(size_t)i * lm + c]; }, [&](int i) { return G[(size_t)i * lm + j]; });
       P[(size_t)c * ld + j] = s;
     }
   }
@@ -370,7 +413,7 @@ template <class W, bool TRANS>
 DEV void genPinvApply(const W& w, const double* P, int ld, int m, const double* x, double* y) {
   for (int i = w.lane(); i < m; i += w.lanes()) {
     double s = 0.0;
-    for (int k = 0; k < m; k++) s = fma(TRANS ? P[(size_t)k * ld + i] : P[(size_t)i * ld + k], x[k], s);
+    s = genFmaSeq(0, m, s, [&](int k) { return TRANS ? P[(size_t)k * ld + i] : P[(size_t)i * ld + k]; }, [&](int k) { return x[k]; });
     y[i] = s;
   }
   w.sync();
