@@ -537,15 +537,15 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_gen(DevModel mdl, const De
     w.sync();
   };
   auto ax = [&](const double* x, double* out) {       // A x, A symmetric
-    for (int r = ln; r < m; r += 64) { double s = 0.0; for (int j = 0; j < m; j++) s = fma(A[(size_t)j * ldr + r], x[j], s); out[r] = s; }
+    for (int r = ln; r < m; r += 64) out[r] = genFmaSeq(0, m, 0.0, [&](int j) { return A[(size_t)j * ldr + r]; }, [&](int j) { return x[j]; });      // (operands four steps ahead: gen_lcp_dev.hpp)
     w.sync();
   };
   auto pinvApply = [&](const double* x, double* out, bool trans) {
-    for (int i = ln; i < m; i += 64) { double s = 0.0; for (int k = 0; k < m; k++) s = fma(trans ? P[(size_t)k * ldr + i] : P[(size_t)i * ldr + k], x[k], s); out[i] = s; }
+    for (int i = ln; i < m; i += 64) out[i] = genFmaSeq(0, m, 0.0, [&](int k) { return trans ? P[(size_t)k * ldr + i] : P[(size_t)i * ldr + k]; }, [&](int k) { return x[k]; });
     w.sync();
   };
   // fbar = Abar^T lambda1 = (M^-1 A_c)^T g: the saved impulse tests applied to g
-  for (int r = ln; r < m; r += 64) { double s = 0.0; for (int d = 0; d < n; d++) s = fma(dn[lay.massed + d * ldr + r], L.g[d], s); L.t[r] = s; }
+  for (int r = ln; r < m; r += 64) L.t[r] = genFmaSeq(0, n, 0.0, [&](int d) { return dn[lay.massed + d * ldr + r]; }, [&](int d) { return L.g[d]; });
   w.sync();
   fold(L.t, L.tmp);
   for (int r = ln; r < m; r += 64) L.fbar[r] = L.clamp[r] ? L.t[r] + L.tmp[r] : 0.0;
@@ -561,12 +561,9 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_gen(DevModel mdl, const De
     for (int e = ln; e < m * m; e += 64) {
       const int r = e / m, j = e - r * m;
       if (!L.clamp[r] || !L.clamp[j]) continue;
-      double y = 0.0;
-      for (int k = 0; k < m; k++) {
-        // spread(Q^+)[k][j] = sc_k P[src_k][j]
-        const double xe = L.clamp[k] ? P[(size_t)k * ldr + j] : (L.ub[k] ? L.E[k] * P[(size_t)L.fp[k] * ldr + j] : 0.0);
-        y = fma(A[(size_t)k * ldr + r], xe, y);
-      }
+      // spread(Q^+)[k][j] = sc_k P[src_k][j]; the four terms of a trip fetch their operands side by side (genFmaSeq)
+      double y = genFmaSeq(0, m, 0.0, [&](int k) { return A[(size_t)k * ldr + r]; },
+                           [&](int k) { return L.clamp[k] ? P[(size_t)k * ldr + j] : (L.ub[k] ? L.E[k] * P[(size_t)L.fp[k] * ldr + j] : 0.0); });
       y += L.cfm[r] * P[(size_t)r * ldr + j];
       const double dlt = ((r == j) ? 1.0 : 0.0) - y;
       acc = fma(dlt, dlt, acc);
@@ -599,11 +596,17 @@ __global__ __launch_bounds__(64) void k_bwd_contact_a_gen(DevModel mdl, const De
   // coefficient vectors for the DOF lanes
   for (int d = ln; d < n; d += 64) {
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int r = 0; r < m; r++) {
-      const double ms = dn[lay.massed + d * ldr + r], aa = dn[lay.aall + d * ldr + r];
+    auto term = [&](int r, double ms, double aa) {
       for (int k = 0; k < 3; k++) { acc[k] = fma(L.clamp[r] ? L.al[k][r] : 0.0, ms, acc[k]); acc[3 + k] = fma(L.beE[k][r], ms, acc[3 + k]); }
       acc[6] = fma(L.clamp[r] ? L.muB[r] : 0.0, aa, acc[6]);
+    };
+    int r = 0;
+    for (; r + 3 < m; r += 4) {      // (the record's entries of four rows first - every one an L2 round trip -, then the rows in order)
+      const double m0 = dn[lay.massed + d * ldr + r], m1 = dn[lay.massed + d * ldr + r + 1], m2 = dn[lay.massed + d * ldr + r + 2], m3 = dn[lay.massed + d * ldr + r + 3];
+      const double a0 = dn[lay.aall + d * ldr + r], a1 = dn[lay.aall + d * ldr + r + 1], a2 = dn[lay.aall + d * ldr + r + 2], a3 = dn[lay.aall + d * ldr + r + 3];
+      term(r, m0, a0); term(r + 1, m1, a1); term(r + 2, m2, a2); term(r + 3, m3, a3);
     }
+    for (; r < m; r++) term(r, dn[lay.massed + d * ldr + r], dn[lay.aall + d * ldr + r]);
     for (int k = 0; k < 3; k++) {
       lws[(int64_t)(LB_S + k * MAX_DOF_CONTACT + d) * B + b] = acc[k];
       lws[(int64_t)(LB_P + k * MAX_DOF_CONTACT + d) * B + b] = acc[3 + k];

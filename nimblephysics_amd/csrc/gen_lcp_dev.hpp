@@ -222,18 +222,35 @@ DEV void genBuildQ(const W& w, const double* A, int lda, const GenRows& R, const
       if (R.cls[s + 1] == RC_UPPER_BOUND) e1 = R.E[s + 1];
       if (R.cls[s + 2] == RC_UPPER_BOUND) e2 = R.E[s + 2];
     }
-    for (int i = 0; i < m; i++) {
+    // (A is symmetric: A[i][s] = A[s][i]; rows that are off are inert.)  The entries of A a row needs are fetched for FOUR rows before the
+    // first of them is used (every one an L2 round trip; behind the branches of the plain loop they came one by one: genFmaSeq)
+    const bool three = K.nu > 0 && !R.fric[s] && s + 2 < m;
+    const int s1 = s + 1 < m ? s + 1 : s, s2 = s + 2 < m ? s + 2 : s;
+    const bool onS = R.on[s] != 0, onS1 = R.on[s1] != 0, onS2 = R.on[s2] != 0, limS = R.lim[s] != 0;
+    auto qOf = [&](int i, double as, double as1, double as2) -> double {
       double q = 0.0;
       if (colOn && R.cls[i] == RC_CLAMPING) {
-        // (A is symmetric: A[i][s] = A[s][i]; rows that are off are inert)
-        auto a = [&](int c) -> double { return (R.on[c] && R.on[i]) ? A[(size_t)i * lda + c] : 0.0; };
-        q = a(s);
-        if (K.nu > 0 && !R.fric[s] && s + 2 < m) q = fma(e2, a(s + 2), fma(e1, a(s + 1), q));
+        const bool oi = R.on[i] != 0;
+        q = (onS && oi) ? as : 0.0;
+        if (three) q = fma(e2, (onS2 && oi) ? as2 : 0.0, fma(e1, (onS1 && oi) ? as1 : 0.0, q));
         // a joint-limit constraint has no constraint-force column in the reference's Q = A_c^T M^-1 (A_c + A_ub E) (DCC.cpp:51-99)
-        if (K.nu > 0 && (R.lim[s] || R.lim[i])) q = 0.0;
+        if (K.nu > 0 && (limS || R.lim[i])) q = 0.0;
         if (i == s) q += cfmRow ? cfmRow[s] : cfm;     // (cfmRow: one constant per row, its constrained group's)
       }
-      M[(size_t)i * ld + s] = q;
+      return q;
+    };
+    int i = 0;
+    for (; i + 3 < m; i += 4) {
+      const double* r0 = A + (size_t)i * lda; const double* r1 = r0 + lda; const double* r2 = r1 + lda; const double* r3 = r2 + lda;
+      const double a0 = r0[s], a1 = r1[s], a2 = r2[s], a3 = r3[s];
+      double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+      if (K.nu > 0) { b0 = r0[s1]; b1 = r1[s1]; b2 = r2[s1]; b3 = r3[s1]; c0 = r0[s2]; c1 = r1[s2]; c2 = r2[s2]; c3 = r3[s2]; }
+      const double q0 = qOf(i, a0, b0, c0), q1 = qOf(i + 1, a1, b1, c1), q2 = qOf(i + 2, a2, b2, c2), q3 = qOf(i + 3, a3, b3, c3);
+      M[(size_t)i * ld + s] = q0; M[(size_t)(i + 1) * ld + s] = q1; M[(size_t)(i + 2) * ld + s] = q2; M[(size_t)(i + 3) * ld + s] = q3;
+    }
+    for (; i < m; i++) {
+      const double* r0 = A + (size_t)i * lda;
+      M[(size_t)i * ld + s] = qOf(i, r0[s], K.nu > 0 ? r0[s1] : 0.0, K.nu > 0 ? r0[s2] : 0.0);
     }
   }
   w.sync();
@@ -604,7 +621,14 @@ DEV void genLoadProblem(const W& w, const double* A, int lda, GenRows& R, double
   P.n = n; P.ld = ld;
   for (int j = w.lane(); j < n; j += w.lanes()) {
     const int sj = R.perm[j];
-    for (int i = 0; i < n; i++) P.A[(size_t)i * ld + j] = A[(size_t)R.perm[i] * lda + sj] + (i == j ? cfmDiag : 0.0);
+    int i = 0;
+    for (; i + 3 < n; i += 4) {      // (four entries of the record's A before the four stores: genFmaSeq)
+      const int p0 = R.perm[i], p1 = R.perm[i + 1], p2 = R.perm[i + 2], p3 = R.perm[i + 3];
+      const double a0 = A[(size_t)p0 * lda + sj], a1 = A[(size_t)p1 * lda + sj], a2 = A[(size_t)p2 * lda + sj], a3 = A[(size_t)p3 * lda + sj];
+      P.A[(size_t)i * ld + j] = a0 + (i == j ? cfmDiag : 0.0); P.A[(size_t)(i + 1) * ld + j] = a1 + (i + 1 == j ? cfmDiag : 0.0);
+      P.A[(size_t)(i + 2) * ld + j] = a2 + (i + 2 == j ? cfmDiag : 0.0); P.A[(size_t)(i + 3) * ld + j] = a3 + (i + 3 == j ? cfmDiag : 0.0);
+    }
+    for (; i < n; i++) P.A[(size_t)i * ld + j] = A[(size_t)R.perm[i] * lda + sj] + (i == j ? cfmDiag : 0.0);
   }
   w.sync();
 }
