@@ -847,24 +847,30 @@ DEV bool genPgsHeld1(const W& w, GenRows& R, int n, int no, const double* AT, in
   // its lane holds after its step (its last change and its x): it runs ONCE per sweep, for all rows at once (sweepMoved).
   double h = hi, l = lo;
   if (fi >= 0) { h = hi * xf; l = -h; }
-  double myD = 0.0;
+  // ... and the change of a row is x after the sweep minus x before it (a row is visited once per sweep: the same subtraction); which
+  // rows have friction rows hanging on them is a wave-uniform bit mask, so that the steps of all the others skip the refresh of the bounds.
+  unsigned long long followed = 0ull;
+  for (int i = 0; i < n; i++) if (w.anyAll(fi == i)) followed |= 1ull << i;
+  double xStart = x;
   auto rowStep = [&](int i, double cc, bool first) {
     double nx = x + r;
     nx = nx > h ? h : (nx < l ? l : nx);
     if (first) nx = zeroMe ? 0.0 : nx;        // (rows left out of the problem: set to zero in the first sweep, never visited again)
     const double dAll = nx - x;
-    const bool mine = ln == i;
-    x = mine ? nx : x;
-    myD = mine ? dAll : myD;
+    x = ln == i ? nx : x;
     const double d = w.bcast(dAll, i);
     r = fma(-cc, d, r);
-    const double xi = w.bcast(nx, i);          // (the new x_i itself: x_old + (x_new - x_old) is not always x_new)
-    const double hn = hi * xi;
-    const bool hangs = fi == i;
-    h = hangs ? hn : h;
-    l = hangs ? -hn : l;
+    if ((followed >> i) & 1ull) {
+      const double xi = w.bcast(nx, i);        // (the new x_i itself: x_old + (x_new - x_old) is not always x_new)
+      const double hn = hi * xi;
+      const bool hangs = fi == i;
+      h = hangs ? hn : h;
+      l = hangs ? -hn : l;
+    }
   };
   auto sweepMoved = [&](bool first) -> bool {
+    const double myD = x - xStart;
+    xStart = x;
     const bool big = first ? fabs(myD) > dxTh : (fabs(x) > epsDiv && fabs(myD) > relTol * fabs(x));
     return w.anyAll(in && !zeroMe && big);
   };
